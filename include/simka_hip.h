@@ -1,0 +1,192 @@
+/*
+ * simka_hip.h -- C ABI of libsimka_hip.so, the MI355X (gfx950) implementation of Simka's
+ * multiset k-mer counting + pairwise ecological-distance hot path.
+ *
+ * Plain C, plain pointers and sizes; no C++/torch types cross this boundary.  Every entry
+ * point names the reference interface it replaces ("ref:", paths relative to the GATB/simka
+ * tree).  All functions return SIMKA_OK (0) or a SIMKA_ERR_* code and never throw; the
+ * message of the last failure is available from simka_last_error() -- this mirrors the
+ * reference's "catch gatb Exception -> print EXCEPTION: msg -> EXIT_FAILURE" convention
+ * (ref: src/SimkaPotara.cpp:149-160, src/SimkaCount.cpp:382-390, src/SimkaMerge.cpp:1582-1590).
+ *
+ * Threading: a simka_ctx is single-owner (one host thread, one GPU), like one simkaCount /
+ * simkaMerge process in the reference.  All device work of a ctx is issued on ONE HIP
+ * stream (the caller's, or a private one); calls are asynchronous unless stated.
+ */
+#ifndef SIMKA_HIP_H
+#define SIMKA_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SIMKA_ABI_VERSION 1
+
+enum {
+    SIMKA_OK = 0,
+    SIMKA_ERR_INVALID = 1,     /* bad argument (the reference: "ERROR: ..." + exit(1)) */
+    SIMKA_ERR_HIP = 2,         /* HIP runtime failure */
+    SIMKA_ERR_NOMEM = 3,       /* device or host allocation failed / arena exhausted */
+    SIMKA_ERR_OVERFLOW = 4,    /* a partition exceeded its LDS table: re-create with more partitions */
+    SIMKA_ERR_STATE = 5,       /* call order violated (e.g. merge before every sample was counted) */
+    SIMKA_ERR_IO = 6,          /* file could not be read / written */
+    SIMKA_ERR_UNSUPPORTED = 7  /* feature not available on the device path yet */
+};
+
+/* -simple-dist / -complex-dist   ref: src/core/Simka.cpp:25-117, src/core/SimkaAlgorithm.cpp:178-179 */
+enum { SIMKA_DIST_SIMPLE = 1u, SIMKA_DIST_COMPLEX = 2u };
+
+typedef struct simka_ctx simka_ctx;
+
+/* Job description: what `simka` passes down to simkaCount / simkaMerge on their command lines
+ * (ref: src/SimkaPotara.hpp:847-864, 1013-1024) plus the GPU-side sizing knobs. */
+typedef struct simka_config {
+    uint32_t struct_size;        /* = sizeof(simka_config) */
+    uint32_t nb_samples;         /* N, SimkaStatistics::_nbBanks (1..65535) */
+    uint32_t kmer_size;          /* -kmer-size, 1..31 (one 64-bit word; k>=32 is a later row) */
+    uint32_t abundance_min;      /* -abundance-min (ref: src/minikc/MiniKC.hpp:56) */
+    uint32_t abundance_max;      /* -abundance-max, clamped to 999999999 (ref: src/core/SimkaAlgorithm.cpp:188) */
+    uint32_t dist_flags;         /* SIMKA_DIST_* */
+    int32_t  device;             /* HIP device ordinal */
+    uint32_t shard_index;        /* this GPU's shard of the partition space ... */
+    uint32_t shard_count;        /* ... of shard_count (1 = everything); partitions p with p % count == index */
+    uint32_t log2_partitions;    /* 0 = derive from max_kmers_per_sample */
+    uint32_t log2_subranges;     /* 0 = derive from nb_samples */
+    uint32_t reserved0;
+    uint64_t max_kmers_per_sample; /* upper bound of k-mer occurrences of the largest sample (sizing) */
+    uint64_t solid_capacity;     /* capacity (records) of the solid-spectrum arena, 0 = from free memory */
+    uint64_t csr_capacity;       /* capacity (records) of the merged-group buffer, 0 = auto */
+    void    *stream;             /* hipStream_t to run on; NULL = private stream */
+} simka_config;
+
+/* One sample's reads, 2-bit packed: base b lives in bits [2*(b%32), 2*(b%32)+2) of word b/32;
+ * code A=0 C=1 T=2 G=3 (= (ascii>>1)&3, the tree's own convention, ref: src/core/SimkaCommons.hpp:400-411).
+ * Reads are concatenated without padding.  Non-ACGT letters never reach the device: the host
+ * packer splits a read at them (a k-mer window containing one is skipped, gatb Kmer model).
+ * `packed` must be readable for 16 bytes past the last word. */
+typedef struct simka_reads {
+    const uint64_t *packed;
+    uint64_t nb_bases;           /* total bases over all fragments */
+    uint64_t nb_reads;           /* fragments in `packed` */
+    const uint64_t *offsets;     /* [nb_reads+1] first base of each fragment; ignored if fixed_len>0 */
+    uint32_t fixed_len;          /* >0: every fragment has exactly this many bases */
+    uint32_t on_device;          /* 1: pointers are device memory, 0: host memory (copied) */
+    uint64_t nb_input_reads;     /* reads before splitting (the .ok file's nbReads line) */
+} simka_reads;
+
+/* The 4 lines of count_synchro/<ID>.ok (ref: src/SimkaCount.cpp:303-317,355-368) + pre-filter counts. */
+typedef struct simka_sample_totals {
+    uint64_t nb_reads;           /* line 1 */
+    uint64_t nb_distinct;        /* line 2: distinct k-mers kept by the abundance filter (D_i) */
+    uint64_t nb_kmers;           /* line 3: sum of their counts (N_i) */
+    uint64_t sum_sq;             /* line 4: sum of count^2 (Q_i, chord norm) */
+    uint64_t kmer_occurrences;   /* k-mer occurrences before the filter */
+    uint64_t distinct_all;       /* distinct canonical k-mers before the filter */
+} simka_sample_totals;
+
+/* Flat view of the accumulators == SimkaStatistics (ref: src/core/SimkaDistance.hpp:68-139).
+ * Pair arrays have nb_pairs = N(N-1)/2 cells, cell(i<j) = i*N - i*(i+1)/2 + (j-i-1).
+ * All are exact integers; `kl` (f64) exists only with SIMKA_DIST_COMPLEX. */
+typedef struct simka_stats_view {
+    uint32_t nb_samples, dist_flags;
+    uint64_t nb_pairs;
+    const uint64_t *nb_distinct;     /* [N] _nbSolidDistinctKmersPerBank */
+    const uint64_t *nb_kmers;        /* [N] _nbSolidKmersPerBank */
+    const uint64_t *sum_sq;          /* [N] squares of _chord_sqrt_N2 */
+    const uint64_t *shared_ij;       /* [pairs] _matrixNbSharedKmers[i][j] */
+    const uint64_t *shared_ji;       /* [pairs] _matrixNbSharedKmers[j][i] */
+    const uint64_t *distinct_shared; /* [pairs] _matrixNbDistinctSharedKmers */
+    const uint64_t *bray_curtis;     /* [pairs] _brayCurtisNumerator (== _kulczynski_minNiNj[i][j]) */
+    const uint64_t *chord;           /* [pairs] _chord_NiNj, simple */
+    const uint64_t *hellinger;       /* [pairs] _hellinger_SqrtNiNj, simple */
+    const uint64_t *whittaker;       /* [pairs] _whittaker_minNiNj, complex */
+    const uint64_t *canberra;        /* [pairs] _canberra, complex */
+    const double   *kl;              /* [pairs] _kullbackLeibler, complex */
+    uint64_t nb_distinct_kmers;      /* _nbDistinctKmers (union) */
+    uint64_t nb_shared_kmers;        /* _nbSharedKmers */
+} simka_stats_view;
+
+/* ---- lifecycle -------------------------------------------------------------------------- */
+int  simka_abi_version(void);
+int  simka_create(const simka_config *cfg, simka_ctx **out);
+void simka_destroy(simka_ctx *ctx);
+/* message of the last error on this ctx (ctx==NULL: last simka_create failure) */
+const char *simka_last_error(const simka_ctx *ctx);
+/* block until everything issued on the ctx's stream has finished */
+int  simka_sync(simka_ctx *ctx);
+
+/* ---- count side ---------------------------------------------------------------------------
+ * Replaces one `simkaCount` job: gatb SortingCountAlgorithm (k-mer extraction, canonical 2-bit
+ * coding, partitioning, counting; ref: src/SimkaCount.cpp:291-297) with the
+ * SimkaCompressedProcessor::process plugin fused in (abundance filter + per-partition totals,
+ * ref: src/minikc/MiniKC.hpp:54-79).  The solid spectrum stays resident in HBM, partitioned,
+ * where the reference writes solid/part_<p>/__p__<i>.gz.  Each sample index exactly once. */
+int simka_count_sample(simka_ctx *ctx, uint32_t sample_index, const simka_reads *reads);
+/* totals of a counted sample (synchronises). Replaces reading count_synchro/<ID>.ok. */
+int simka_get_sample_totals(simka_ctx *ctx, uint32_t sample_index, simka_sample_totals *out);
+
+/* ---- merge side ---------------------------------------------------------------------------
+ * Replaces every `simkaMerge` job: the N-way k-mer merge (ref: src/SimkaMerge.cpp:1164-1264),
+ * its gate (ref: :1307-1326) and SimkaCountProcessorSimple::process -> updateDistance*
+ * (ref: src/core/SimkaAlgorithm.hpp:200,341-516), over this shard's partitions, accumulating
+ * into the ctx-owned device SimkaStatistics.  Requires all nb_samples counted. */
+int simka_merge(simka_ctx *ctx);
+
+/* ---- statistics ---------------------------------------------------------------------------
+ * The accumulators live in ONE flat device buffer of nb_u64 64-bit words so that the
+ * cross-shard reduction (SimkaStatistics::operator+=, ref: src/core/SimkaDistance.cpp:156-213)
+ * is a single all-reduce(sum, uint64) issued by the caller (RCCL / torch.distributed). */
+int simka_stats_device_buffer(simka_ctx *ctx, void **device_ptr, uint64_t *nb_u64);
+/* download (synchronises) into a host buffer of nb_u64 words and describe it */
+int simka_stats_download(simka_ctx *ctx, uint64_t *host_buf, uint64_t nb_u64, simka_stats_view *view);
+/* describe an arbitrary host copy of the flat buffer (e.g. after the caller's all-reduce) */
+int simka_stats_describe(uint32_t nb_samples, uint32_t dist_flags, const uint64_t *host_buf, uint64_t nb_u64,
+                         simka_stats_view *view);
+uint64_t simka_stats_nb_u64(uint32_t nb_samples, uint32_t dist_flags);
+
+/* ---- finalisation (host) ------------------------------------------------------------------
+ * SimkaDistance: the 21 distance matrices as float32 cells (ref: src/core/SimkaDistance.cpp:920-1226,
+ * src/core/SimkaDistance.hpp:155-475) and the CSV writer (ref: src/core/SimkaDistance.cpp:603-699). */
+int         simka_nb_matrices(void);
+const char *simka_matrix_name(int which);                    /* "mat_abundance_braycurtis", ... reference order */
+int         simka_matrix_enabled(int which, uint32_t dist_flags);
+int simka_compute_matrix(const simka_stats_view *view, int which, float *out_nxn);
+/* writes <dir>/<name>.csv.gz (gz=1) or <dir>/<name>.csv exactly as dumpMatrix does */
+int simka_write_matrix_csv(const char *dir, const char *name, const char *const *sample_ids, uint32_t nb_samples,
+                           const float *matrix_nxn, int gz);
+
+/* ---- host-side ingest helper --------------------------------------------------------------
+ * 2-bit packer for ASCII reads (gatb Bank + Kmer model coding).  Appends to a growing packed
+ * buffer owned by the caller: *nb_bases is the running base count, `offsets` receives one entry
+ * per produced fragment (reads are split at non-ACGT letters).  Returns the number of fragments
+ * appended, or <0 on error.  Caller guarantees capacity for `len` more bases and len+1 offsets. */
+int64_t simka_pack_read(const char *seq, uint64_t len, uint64_t *packed, uint64_t *nb_bases, uint64_t *offsets_out);
+
+/* ---- profiling ----------------------------------------------------------------------------
+ * HIP-event timing of every kernel launched by the ctx, on the ctx's stream. */
+int simka_profile_enable(simka_ctx *ctx, int on);
+int simka_profile_reset(simka_ctx *ctx);
+int simka_profile_nb_kernels(simka_ctx *ctx);
+/* synchronises; name is a static string */
+int simka_profile_get(simka_ctx *ctx, int which, const char **name, uint64_t *nb_launches, double *total_ms);
+/* sizes chosen by the ctx (partition bits etc.), for DESIGN/bench reporting */
+int simka_get_geometry(simka_ctx *ctx, uint32_t *log2_level1, uint32_t *log2_level2, uint32_t *log2_subranges,
+                       uint64_t *arena_capacity, uint64_t *csr_capacity);
+
+/* ---- synthetic reads (bench / test utility, not part of the reference path) ---------------
+ * Seeded generator of SURVEY.md section 8(d): a pool of random genomes and reads sampled from
+ * it with substitution errors, written 2-bit packed straight into device memory.  Integer-only,
+ * so simka_amd/synth.py reproduces it bit-for-bit on the CPU for the parity tests. */
+int simka_synth_genomes(void *stream, uint64_t *d_pool, uint32_t nb_genomes, uint64_t genome_words, uint64_t seed);
+int simka_synth_reads(void *stream, uint64_t *d_packed, uint64_t nb_reads, uint32_t read_len,
+                      const uint64_t *d_pool, uint64_t genome_words, uint64_t genome_len,
+                      const uint32_t *d_genome_ids, const uint32_t *d_cdf, uint32_t nb_sel,
+                      uint64_t seed, uint32_t err_threshold16);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SIMKA_HIP_H */

@@ -1,0 +1,830 @@
+/*
+ * oracle/simka_oracle.c  --  TEST INFRASTRUCTURE, NOT PRODUCT CODE.
+ *
+ * Plain-C CPU restatement of Simka's hot path
+ *     simkaCount -> simkaMerge -> SimkaStatistics / SimkaDistance
+ * used ONLY as the checker for the HIP path (tests/, __graft_entry__.smoke(),
+ * bench.py's cpu_baseline leg).  Nothing under simka_amd/ may include, link or
+ * call this file.
+ *
+ * Pinning: the reference binary cannot be built here (thirdparty/gatb-core is an
+ * empty, un-vendored submodule, /root/reference/.gitmodules:1-3), so this
+ * restatement is pinned against the reference's own golden matrices
+ * (tests/truth/results_k{21,31}_t{0,2}/ *.csv, compared byte-for-byte exactly as
+ * /root/reference/tests/simple_test.py:29-68 does) -- see tests/test_oracle_golden.py.
+ *
+ * All "ref:" citations are relative to /root/reference/.
+ *
+ * Stages (SURVEY.md section 8a row names in brackets):
+ *   [a1] or_parse_input        ref: src/core/SimkaAlgorithm.cpp:245-351
+ *   [a2] or_read_file          ref: src/core/SimkaCommons.hpp:159-314 (default policy: all reads, no filter)
+ *   [a3] or_count_sample       ref: src/SimkaCount.cpp:291-297 (gatb SortingCountAlgorithm: canonical k-mers,
+ *                                   emitted in increasing order with their count; gatb-core 1.x, absent)
+ *   [a4] or_filter_totals      ref: src/minikc/MiniKC.hpp:54-79
+ *   [a5] totals                ref: src/SimkaCount.cpp:303-317
+ *   [a6] or_merge_partition    ref: src/SimkaMerge.cpp:1164-1264 (N-way min-heap merge)
+ *   [a7] or_insert             ref: src/SimkaMerge.cpp:1307-1326
+ *   [a8] or_update_*           ref: src/core/SimkaAlgorithm.hpp:341-516
+ *   [a9] or_stats_add          ref: src/core/SimkaDistance.cpp:156-213
+ *   [a10] or_dist_*            ref: src/core/SimkaDistance.cpp:920-1226, src/core/SimkaDistance.hpp:155-475
+ *   [a11] or_dump_matrix       ref: src/core/SimkaDistance.cpp:653-699
+ */
+#define _GNU_SOURCE
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <math.h>
+#include <limits.h>
+#include <zlib.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+#define OR_API __attribute__((visibility("default")))
+
+/* ------------------------------------------------------------------------- */
+/* small utilities                                                            */
+/* ------------------------------------------------------------------------- */
+typedef struct { uint64_t *v; size_t n, cap; } u64vec;
+
+static void u64vec_push(u64vec *a, uint64_t x) {
+    if (a->n == a->cap) {
+        a->cap = a->cap ? a->cap * 2 : 1024;
+        a->v = (uint64_t *)realloc(a->v, a->cap * sizeof(uint64_t));
+        if (!a->v) { fprintf(stderr, "oracle: out of memory\n"); abort(); }
+    }
+    a->v[a->n++] = x;
+}
+
+/* LSD radix sort of 64-bit keys, `bits` significant bits. */
+static void radix_sort_u64(uint64_t *a, size_t n, int bits) {
+    if (n < 2) return;
+    uint64_t *tmp = (uint64_t *)malloc(n * sizeof(uint64_t));
+    uint64_t *src = a, *dst = tmp;
+    for (int shift = 0; shift < bits; shift += 8) {
+        size_t hist[257];
+        memset(hist, 0, sizeof(hist));
+        for (size_t i = 0; i < n; i++) hist[((src[i] >> shift) & 0xff) + 1]++;
+        for (int d = 0; d < 256; d++) hist[d + 1] += hist[d];
+        for (size_t i = 0; i < n; i++) dst[hist[(src[i] >> shift) & 0xff]++] = src[i];
+        uint64_t *t = src; src = dst; dst = t;
+    }
+    if (src != a) memcpy(a, src, n * sizeof(uint64_t));
+    free(tmp);
+}
+
+/* ------------------------------------------------------------------------- */
+/* [a3] canonical 2-bit k-mers                                                */
+/* ------------------------------------------------------------------------- */
+/* Nucleotide code: A=0 C=1 T=2 G=3, i.e. (ascii>>1)&3 -- the tree's own table
+ * (ref: src/core/SimkaCommons.hpp:400-411).  Complement is code^2.  Any fixed
+ * total order gives the same distances. */
+static inline int or_code(unsigned char c) {
+    switch (c) {
+        case 'A': case 'a': return 0;
+        case 'C': case 'c': return 1;
+        case 'T': case 't': return 2;
+        case 'G': case 'g': return 3;
+        default: return -1; /* N / IUPAC: every window containing it is skipped */
+    }
+}
+
+/* Append the canonical k-mers of one read to `out`; returns #k-mers appended. */
+static size_t or_kmers_of_read(const char *seq, size_t len, int k, u64vec *out) {
+    const uint64_t mask = (k == 32) ? ~0ull : ((1ull << (2 * k)) - 1);
+    uint64_t fwd = 0, rev = 0;
+    size_t valid = 0, emitted = 0;
+    for (size_t i = 0; i < len; i++) {
+        int c = or_code((unsigned char)seq[i]);
+        if (c < 0) { valid = 0; fwd = rev = 0; continue; }
+        fwd = ((fwd << 2) | (uint64_t)c) & mask;
+        rev = (rev >> 2) | ((uint64_t)(c ^ 2) << (2 * (k - 1)));
+        if (++valid >= (size_t)k) {
+            u64vec_push(out, fwd < rev ? fwd : rev);
+            emitted++;
+        }
+    }
+    return emitted;
+}
+
+/* ------------------------------------------------------------------------- */
+/* samples                                                                    */
+/* ------------------------------------------------------------------------- */
+typedef struct {
+    char *id;
+    char **files; int nfiles; int nb_paired;   /* [a1] */
+    /* in-memory reads (alternative to files): concatenated ASCII + offsets */
+    const char *bases; const uint64_t *offsets; uint64_t nreads_mem;
+    /* [a3] results */
+    uint64_t nb_reads;      /* reads seen */
+    uint64_t k_occ;         /* k-mer occurrences */
+    uint64_t d_all;         /* distinct canonical k-mers before the abundance filter */
+    /* [a4] solid spectrum, sorted by k-mer */
+    uint64_t *kmer; uint32_t *count; size_t nsolid;
+    /* [a5] totals after filter */
+    uint64_t D, N, Q;
+} or_sample;
+
+typedef struct {
+    int n, simple, complex_;
+    size_t symsize;
+    /* ref: src/core/SimkaDistance.hpp:79-129 */
+    uint64_t *D, *Nk;                 /* _nbSolidDistinctKmersPerBank, _nbSolidKmersPerBank */
+    long double *sqrtN2;              /* _chord_sqrt_N2 */
+    uint64_t *a, *bc;                 /* _matrixNbDistinctSharedKmers, _brayCurtisNumerator (sym) */
+    uint64_t *S;                      /* _matrixNbSharedKmers [n][n] */
+    long double *chord;               /* _chord_NiNj [n][n] */
+    uint64_t *hell, *kul;             /* _hellinger_SqrtNiNj, _kulczynski_minNiNj [n][n] */
+    uint64_t *whit, *canb;            /* _whittaker_minNiNj, _canberra [n][n] */
+    long double *kl;                  /* _kullbackLeibler [n][n] */
+    uint64_t nb_distinct, nb_shared;  /* _nbDistinctKmers, _nbSharedKmers */
+} or_stats;
+
+typedef struct {
+    or_sample *s; int n;
+    int k; uint32_t amin, amax;
+    or_stats *stats;
+    char err[512];
+} oracle;
+
+/* ------------------------------------------------------------------------- */
+/* [a1] input grammar    ref: src/core/SimkaAlgorithm.cpp:245-351             */
+/* ------------------------------------------------------------------------- */
+static char *or_strndup(const char *s, size_t n) {
+    char *r = (char *)malloc(n + 1); memcpy(r, s, n); r[n] = 0; return r;
+}
+
+static int or_parse_input(oracle *o, const char *path) {
+    FILE *f = fopen(path, "r");
+    if (!f) { snprintf(o->err, sizeof o->err, "ERROR: Input filename does not exist"); return -1; }
+    char *rp = realpath(path, NULL);
+    char *slash = strrchr(rp, '/');
+    size_t dirlen = slash ? (size_t)(slash - rp) : 0;
+    char *line = NULL; size_t cap = 0; ssize_t len;
+    while ((len = getline(&line, &cap, f)) >= 0) {
+        /* remove ALL spaces (:269); also drop the newline getline keeps (std::getline strips it) */
+        size_t w = 0;
+        for (ssize_t i = 0; i < len; i++) if (line[i] != ' ' && line[i] != '\n' && line[i] != '\r') line[w++] = line[i];
+        line[w] = 0;
+        if (w == 0) continue;                                   /* :270 */
+        char *colon = strchr(line, ':');                        /* :278-283 */
+        if (!colon) { snprintf(o->err, sizeof o->err, "Syntax error in input file"); fclose(f); free(line); free(rp); return -1; }
+        o->s = (or_sample *)realloc(o->s, (o->n + 1) * sizeof(or_sample));
+        or_sample *s = &o->s[o->n++];
+        memset(s, 0, sizeof *s);
+        s->id = or_strndup(line, (size_t)(colon - line));
+        char *rest = colon + 1;
+        char *c2 = strchr(rest, ':'); if (c2) *c2 = 0;          /* only lineIdDatasets[1] is used (:283) */
+        /* split on ';' -> paired parts (:286-294), each on ',' -> files (:301-320) */
+        char *save1 = NULL;
+        for (char *part = strtok_r(rest, ";", &save1); part; part = strtok_r(NULL, ";", &save1)) {
+            s->nb_paired++;
+            char *save2 = NULL;
+            for (char *fn = strtok_r(part, ",", &save2); fn; fn = strtok_r(NULL, ",", &save2)) {
+                char *full;
+                if (fn[0] == '/') full = strdup(fn);            /* :312-314 */
+                else {                                          /* :315-319 relative to the input file's dir */
+                    full = (char *)malloc(dirlen + strlen(fn) + 2);
+                    memcpy(full, rp, dirlen); full[dirlen] = '/'; strcpy(full + dirlen + 1, fn);
+                }
+                s->files = (char **)realloc(s->files, (s->nfiles + 1) * sizeof(char *));
+                s->files[s->nfiles++] = full;
+            }
+        }
+    }
+    free(line); free(rp); fclose(f);
+    return 0;
+}
+
+/* ------------------------------------------------------------------------- */
+/* [a2] read iteration (default policy: every read of every listed file, in   */
+/* order; -max-reads / read filters are "next" rows)            */
+/* FASTA (multi-line) and FASTQ (4-line), plain or gz (zlib reads both).      */
+/* ------------------------------------------------------------------------- */
+typedef struct { char *b; size_t n, cap; } strbuf;
+static void sb_app(strbuf *s, const char *p, size_t n) {
+    if (s->n + n + 1 > s->cap) { s->cap = (s->n + n + 1) * 2; s->b = (char *)realloc(s->b, s->cap); }
+    memcpy(s->b + s->n, p, n); s->n += n; s->b[s->n] = 0;
+}
+
+static int or_read_file(const char *path, int k, u64vec *out, uint64_t *nreads, uint64_t *kocc) {
+    gzFile g = gzopen(path, "rb");
+    if (!g) return -1;
+    gzbuffer(g, 1 << 20);
+    static __thread char buf[1 << 16];
+    strbuf seq = {0};
+    int state = 0;   /* 0 none, 1 fasta seq, 2 fastq seq line next, 3 fastq '+' seen (skip quals) */
+    size_t qual_left = 0;
+    while (gzgets(g, buf, sizeof buf)) {
+        size_t l = strlen(buf);
+        int full_line = (l > 0 && buf[l - 1] == '\n');
+        while (l > 0 && (buf[l - 1] == '\n' || buf[l - 1] == '\r')) buf[--l] = 0;
+        if (state == 3) {           /* quality lines: consume as many chars as the sequence had */
+            if (l >= qual_left) { qual_left = 0; state = 0; } else qual_left -= l;
+            continue;
+        }
+        if (state != 2 && buf[0] == '>') {
+            if (seq.n) { *kocc += or_kmers_of_read(seq.b, seq.n, k, out); (*nreads)++; seq.n = 0; }
+            else if (state == 1) (*nreads)++;
+            state = 1;
+            while (!full_line && gzgets(g, buf, sizeof buf)) { size_t m = strlen(buf); full_line = (m > 0 && buf[m - 1] == '\n'); }
+            continue;
+        }
+        if (state == 0 && buf[0] == '@') {
+            state = 2; seq.n = 0;
+            while (!full_line && gzgets(g, buf, sizeof buf)) { size_t m = strlen(buf); full_line = (m > 0 && buf[m - 1] == '\n'); }
+            continue;
+        }
+        if (state == 2) {
+            if (buf[0] == '+' ) {
+                *kocc += or_kmers_of_read(seq.b ? seq.b : "", seq.n, k, out); (*nreads)++;
+                qual_left = seq.n; seq.n = 0; state = qual_left ? 3 : 0;
+                continue;
+            }
+            sb_app(&seq, buf, l);
+            continue;
+        }
+        if (state == 1) sb_app(&seq, buf, l);
+    }
+    if (state == 1) { if (seq.n) *kocc += or_kmers_of_read(seq.b, seq.n, k, out); (*nreads)++; }
+    free(seq.b);
+    gzclose(g);
+    return 0;
+}
+
+/* ------------------------------------------------------------------------- */
+/* [a3]+[a4]+[a5] per-sample counting, abundance filter, totals               */
+/* ------------------------------------------------------------------------- */
+static int or_count_sample(oracle *o, or_sample *s) {
+    u64vec km = {0};
+    s->nb_reads = 0; s->k_occ = 0;
+    if (s->bases) {
+        for (uint64_t r = 0; r < s->nreads_mem; r++) {
+            s->k_occ += or_kmers_of_read(s->bases + s->offsets[r], (size_t)(s->offsets[r + 1] - s->offsets[r]), o->k, &km);
+            s->nb_reads++;
+        }
+    } else {
+        for (int f = 0; f < s->nfiles; f++)
+            if (or_read_file(s->files[f], o->k, &km, &s->nb_reads, &s->k_occ) != 0) {
+                snprintf(o->err, sizeof o->err, "ERROR: Can't open dataset: %s", s->id);
+                free(km.v); return -1;
+            }
+    }
+    /* gatb DSK emits each distinct canonical k-mer once, in increasing order, with its
+     * count (the merge's min-heap assumes sorted streams, ref: src/SimkaMerge.cpp:1198-1263) */
+    radix_sort_u64(km.v, km.n, 2 * o->k);
+    size_t nd = 0, ns = 0;
+    s->kmer = (uint64_t *)malloc((km.n ? km.n : 1) * sizeof(uint64_t));
+    s->count = (uint32_t *)malloc((km.n ? km.n : 1) * sizeof(uint32_t));
+    s->D = s->N = s->Q = 0;
+    for (size_t i = 0; i < km.n;) {
+        size_t j = i + 1;
+        while (j < km.n && km.v[j] == km.v[i]) j++;
+        uint64_t c = j - i;
+        nd++;
+        /* SimkaCompressedProcessor::process, ref: src/minikc/MiniKC.hpp:54-62 */
+        if (!(c < o->amin || c > o->amax)) {
+            s->kmer[ns] = km.v[i]; s->count[ns] = (uint32_t)c; ns++;
+            s->D += 1;                  /* _nbDistinctKmerPerParts[partId] += 1 */
+            s->N += c;                  /* _nbKmerPerParts[partId] += count[0]  */
+            s->Q += (uint64_t)pow((double)c, 2);  /* _chordPerParts[partId] += pow(count[0], 2) */
+        }
+        i = j;
+    }
+    s->d_all = nd; s->nsolid = ns;
+    s->kmer = (uint64_t *)realloc(s->kmer, (ns ? ns : 1) * sizeof(uint64_t));
+    s->count = (uint32_t *)realloc(s->count, (ns ? ns : 1) * sizeof(uint32_t));
+    free(km.v);
+    return 0;
+}
+
+/* ------------------------------------------------------------------------- */
+/* SimkaStatistics   ref: src/core/SimkaDistance.cpp:27-153                   */
+/* ------------------------------------------------------------------------- */
+static or_stats *or_stats_new(const oracle *o, int simple, int complex_) {
+    int n = o->n;
+    or_stats *st = (or_stats *)calloc(1, sizeof *st);
+    st->n = n; st->simple = simple; st->complex_ = complex_;
+    st->symsize = ((size_t)n * (n + 1)) / 2;                      /* :31 */
+    st->D = (uint64_t *)calloc(n, 8); st->Nk = (uint64_t *)calloc(n, 8);
+    st->sqrtN2 = (long double *)calloc(n, sizeof(long double));
+    st->a = (uint64_t *)calloc(st->symsize, 8); st->bc = (uint64_t *)calloc(st->symsize, 8);
+    st->S = (uint64_t *)calloc((size_t)n * n, 8);
+    st->chord = (long double *)calloc((size_t)n * n, sizeof(long double));
+    st->hell = (uint64_t *)calloc((size_t)n * n, 8); st->kul = (uint64_t *)calloc((size_t)n * n, 8);
+    st->whit = (uint64_t *)calloc((size_t)n * n, 8); st->canb = (uint64_t *)calloc((size_t)n * n, 8);
+    st->kl = (long double *)calloc((size_t)n * n, sizeof(long double));
+    for (int i = 0; i < n; i++) {                                 /* totals come from the .ok files, :116-151 */
+        st->D[i] = o->s[i].D; st->Nk[i] = o->s[i].N;
+        st->sqrtN2[i] = sqrt((double)o->s[i].Q);                  /* :139  sqrt(strtoull(..)) -> double overload */
+    }
+    return st;
+}
+static void or_stats_free(or_stats *st) {
+    if (!st) return;
+    free(st->D); free(st->Nk); free(st->sqrtN2); free(st->a); free(st->bc); free(st->S); free(st->chord);
+    free(st->hell); free(st->kul); free(st->whit); free(st->canb); free(st->kl); free(st);
+}
+/* [a9] operator+=   ref: src/core/SimkaDistance.cpp:156-213 (per-sample vectors are NOT summed) */
+static void or_stats_add(or_stats *d, const or_stats *s) {
+    size_t nn = (size_t)d->n * d->n;
+    d->nb_distinct += s->nb_distinct; d->nb_shared += s->nb_shared;
+    for (size_t i = 0; i < d->symsize; i++) { d->bc[i] += s->bc[i]; d->a[i] += s->a[i]; }
+    for (size_t i = 0; i < nn; i++) d->S[i] += s->S[i];
+    if (d->simple) for (size_t i = 0; i < nn; i++) { d->chord[i] += s->chord[i]; d->hell[i] += s->hell[i]; d->kul[i] += s->kul[i]; }
+    if (d->complex_) for (size_t i = 0; i < nn; i++) { d->canb[i] += s->canb[i]; d->whit[i] += s->whit[i]; d->kl[i] += s->kl[i]; }
+}
+
+/* ------------------------------------------------------------------------- */
+/* [a8] accumulators   ref: src/core/SimkaAlgorithm.hpp:341-516               */
+/* counts[] is the dense CountVector of one k-mer; shared[] = {i : counts[i]}  */
+/* ------------------------------------------------------------------------- */
+static inline size_t or_sym(size_t n, size_t i, size_t j) { return j + ((n - 1) * i) - (i * (i - 1) / 2); } /* :364 */
+
+static void or_update_default(or_stats *st, const int32_t *counts, const uint16_t *shared, size_t ns) {
+    size_t n = st->n;
+    for (size_t ii = 0; ii < ns; ii++)
+        for (size_t jj = ii + 1; jj < ns; jj++) {
+            size_t i = shared[ii], j = shared[jj];
+            size_t sym = or_sym(n, i, j);
+            uint64_t ai = (uint64_t)counts[i], aj = (uint64_t)counts[j];
+            st->S[i * n + j] += counts[i];                       /* :369 */
+            st->S[j * n + i] += counts[j];                       /* :370 */
+            st->a[sym] += 1;                                     /* :371 */
+            st->bc[sym] += ai < aj ? ai : aj;                    /* :374 */
+        }
+}
+static void or_update_simple(or_stats *st, const int32_t *counts, const uint16_t *shared, size_t ns) {
+    size_t n = st->n;
+    for (size_t ii = 0; ii < ns; ii++)
+        for (size_t jj = ii + 1; jj < ns; jj++) {
+            size_t i = shared[ii], j = shared[jj];
+            uint64_t ai = (uint64_t)counts[i], aj = (uint64_t)counts[j];
+            st->chord[i * n + j] += ai * aj;                                        /* :396 long double += u64 */
+            /* :397  u64 += double  ==  (u64)((double)u64 + sqrt((double)(ai*aj))) */
+            st->hell[i * n + j] = (uint64_t)((double)st->hell[i * n + j] + sqrt((double)(ai * aj)));
+            st->kul[i * n + j] += ai < aj ? ai : aj;                                /* :398 only [i][j], i<j */
+        }
+}
+static inline uint64_t or_whit_term(double ai, double aj, uint64_t Ni, uint64_t Nj) {
+    /* :481  abs((int)((u_int64_t)(ai*N_j) - (u_int64_t)(aj*N_i)))  then u64 += int */
+    uint64_t d = (uint64_t)(ai * (double)Nj) - (uint64_t)(aj * (double)Ni);
+    int t = (int)d;
+    int r = (t == INT_MIN) ? INT_MIN : abs(t);
+    return (uint64_t)(int64_t)r;
+}
+static void or_update_complex(or_stats *st, const int32_t *counts, const uint16_t *shared, size_t ns) {
+    size_t n = st->n;
+    const uint64_t *Nk = st->Nk;
+    for (size_t i = 0; i < n; i++) {
+        if (counts[i]) {                                                        /* :418 */
+            for (size_t j = i + 1; j < n; j++) {
+                double ai = counts[i], aj = counts[j];
+                double d1, d2;
+                double yX = aj * (double)Nk[i], xY = ai * (double)Nk[j];
+                double xi = ai / (double)Nk[i];
+                d1 = xi * log((2 * xY) / (xY + yX));                            /* :440 / :453 */
+                if (aj) { double xj = aj / (double)Nk[j]; d2 = xj * log((2 * yX) / (xY + yX)); }   /* :445-446 */
+                else d2 = 0;
+                st->kl[i * n + j] += d1 + d2;                                   /* :477 */
+                st->canb[i * n + j] = (uint64_t)((double)st->canb[i * n + j] + fabs(ai - aj) / (ai + aj)); /* :479 */
+                st->whit[i * n + j] += or_whit_term(ai, aj, Nk[i], Nk[j]);      /* :481 */
+            }
+        } else {                                                                /* :488-515, counts[i]==0 */
+            for (size_t jj = 0; jj < ns; jj++) {
+                size_t j = shared[jj];
+                if (i > j) continue;
+                double ai = counts[i], aj = counts[j];
+                double xY = ai * (double)Nk[j], yX = aj * (double)Nk[i];
+                double xj = aj / (double)Nk[j];
+                double d2 = xj * log((2 * yX) / (xY + yX));                     /* :504 */
+                st->kl[i * n + j] += 0 + d2;                                    /* :506 */
+                st->canb[i * n + j] = (uint64_t)((double)st->canb[i * n + j] + fabs(ai - aj) / (ai + aj));
+                st->whit[i * n + j] += or_whit_term(ai, aj, Nk[i], Nk[j]);      /* :512 */
+            }
+        }
+    }
+}
+/* updateDistance :341-354, gated by SimkaMergeAlgorithm::insert, ref: src/SimkaMerge.cpp:1307-1326 */
+static void or_insert(or_stats *st, const int32_t *counts, size_t nb_having, uint16_t *shared) {
+    st->nb_distinct += 1;                                                       /* :1315 */
+    if (st->complex_ || nb_having > 1) {                                        /* :1317 */
+        if (nb_having > 1) st->nb_shared += 1;                                  /* :1319-1321 */
+        size_t ns = 0;
+        for (int i = 0; i < st->n; i++) if (counts[i]) shared[ns++] = (uint16_t)i;
+        or_update_default(st, counts, shared, ns);
+        if (st->simple) or_update_simple(st, counts, shared, ns);
+        if (st->complex_) or_update_complex(st, counts, shared, ns);
+    }
+}
+
+/* ------------------------------------------------------------------------- */
+/* [a6] N-way merge of one partition   ref: src/SimkaMerge.cpp:1164-1264      */
+/* The reference's partition = f(minimizer); distances do not depend on the   */
+/* choice (ref: tests/simple_test.py:125-133), here partition = mix(kmer)%P.  */
+/* ------------------------------------------------------------------------- */
+static inline uint64_t or_mix(uint64_t x) {
+    x ^= x >> 33; x *= 0xff51afd7ed558ccdULL; x ^= x >> 33; x *= 0xc4ceb9fe1a85ec53ULL; x ^= x >> 33; return x;
+}
+typedef struct { uint64_t kmer; int bank; } heap_item;
+static void heap_sift_down(heap_item *h, size_t n, size_t i) {
+    for (;;) {
+        size_t l = 2 * i + 1, r = l + 1, m = i;
+        if (l < n && (h[l].kmer < h[m].kmer || (h[l].kmer == h[m].kmer && h[l].bank < h[m].bank))) m = l;
+        if (r < n && (h[r].kmer < h[m].kmer || (h[r].kmer == h[m].kmer && h[r].bank < h[m].bank))) m = r;
+        if (m == i) return;
+        heap_item t = h[i]; h[i] = h[m]; h[m] = t; i = m;
+    }
+}
+static void or_merge_partition(const oracle *o, or_stats *st, unsigned part, unsigned nparts) {
+    int n = o->n;
+    size_t *pos = (size_t *)calloc(n, sizeof(size_t));
+    heap_item *heap = (heap_item *)malloc(n * sizeof(heap_item));
+    int32_t *counts = (int32_t *)calloc(n, sizeof(int32_t));     /* CountVector (CountNumber = int32) */
+    uint16_t *shared = (uint16_t *)malloc(n * sizeof(uint16_t));
+    size_t hn = 0;
+#define OR_ADVANCE(b) while (pos[b] < o->s[b].nsolid && nparts > 1 && or_mix(o->s[b].kmer[pos[b]]) % nparts != part) pos[b]++
+    for (int b = 0; b < n; b++) {
+        OR_ADVANCE(b);
+        if (pos[b] < o->s[b].nsolid) { heap[hn].kmer = o->s[b].kmer[pos[b]]; heap[hn].bank = b; hn++; }
+    }
+    for (size_t i = hn; i-- > 0;) heap_sift_down(heap, hn, i);
+    while (hn) {
+        uint64_t cur = heap[0].kmer;
+        size_t nb_having = 0;
+        memset(counts, 0, n * sizeof(int32_t));                   /* SimkaCounterBuilderMerge::init :293-297 */
+        while (hn && heap[0].kmer == cur) {
+            int b = heap[0].bank;
+            counts[b] += (int32_t)o->s[b].count[pos[b]];          /* increase :301 */
+            nb_having++;
+            pos[b]++;
+            OR_ADVANCE(b);
+            if (pos[b] < o->s[b].nsolid) heap[0].kmer = o->s[b].kmer[pos[b]];
+            else heap[0] = heap[--hn];
+            heap_sift_down(heap, hn, 0);
+        }
+        or_insert(st, counts, nb_having, shared);                 /* :1240 / :1263 */
+    }
+#undef OR_ADVANCE
+    free(pos); free(heap); free(counts); free(shared);
+}
+
+/* ------------------------------------------------------------------------- */
+/* [a10] final distances   ref: src/core/SimkaDistance.cpp:920-1226           */
+/* ------------------------------------------------------------------------- */
+static void or_abc(const or_stats *st, size_t i, size_t j, size_t sym, uint64_t *a, uint64_t *b, uint64_t *c) {
+    *a = st->a[sym]; *b = st->D[i] - *a; *c = st->D[j] - *a;                     /* :920-926 */
+}
+static double d_ab_braycurtis(const or_stats *st, size_t i, size_t j, size_t sym) {     /* :928-939 */
+    double union_ = st->Nk[i] + st->Nk[j];
+    if (union_ == 0) return 1;
+    double intersection = 2 * st->bc[sym];
+    return 1 - intersection / union_;
+}
+static double d_ab_chord(const or_stats *st, size_t i, size_t j) {                      /* :942-959 */
+    double den = st->sqrtN2[i] * st->sqrtN2[j];
+    if (den == 0) return sqrt(2);
+    long double r = sqrtl(2 - 2 * st->chord[i * st->n + j] / den);
+    return r;
+}
+static double d_ab_hellinger(const or_stats *st, size_t i, size_t j) {                  /* :962-972 */
+    double union_ = sqrt((double)st->Nk[i]) * sqrt((double)st->Nk[j]);
+    if (union_ == 0) return sqrt(2);
+    double intersection = 2 * st->hell[i * st->n + j];
+    return sqrt(2 - (intersection / union_));
+}
+static double d_ab_whittaker(const or_stats *st, size_t i, size_t j) {                  /* :988-998 */
+    long double union_ = st->Nk[i] * st->Nk[j];
+    if (union_ == 0) return 1;
+    long double intersection = st->whit[i * st->n + j];
+    double w = 0.5 * (intersection / union_);
+    return w;
+}
+static double d_ab_kl(const or_stats *st, size_t i, size_t j) {                         /* :1001-1007 */
+    if (st->kl[i * st->n + j] == 0) return 1;
+    return sqrtl(0.5 * st->kl[i * st->n + j]);
+}
+static double d_ab_canberra(const or_stats *st, size_t i, size_t j, uint64_t ua, uint64_t ub, uint64_t uc) { /* :1010-1021 */
+    double a = (double)ua, b = (double)ub, c = (double)uc;
+    if ((a + b + c) == 0) return 1;
+    return (1 / (a + b + c)) * st->canb[i * st->n + j];
+}
+static double d_ab_kulczynski(const or_stats *st, size_t i, size_t j) {                 /* :1024-1038 */
+    if (st->Nk[i] == 0 || st->Nk[j] == 0) return 1;
+    long double n1 = (double)st->kul[i * st->n + j] / (double)st->Nk[i];
+    long double n2 = (double)st->kul[j * st->n + i] / (double)st->Nk[j];   /* never written for j>i: 0 */
+    double r = 1 - 0.5 * (n1 + n2);
+    return r;
+}
+static double d_ab_jaccard_simka(const or_stats *st, size_t i, size_t j, int asym) {    /* :1041-1065 */
+    double A1 = st->S[i * st->n + j], B1 = st->S[j * st->n + i], A0 = st->Nk[i], B0 = st->Nk[j];
+    double num, den;
+    if (!asym) { num = A1 + B1; den = A0 + B0; } else { num = A1; den = A0; }
+    if (den == 0) return 1;
+    return 1 - num / den;
+}
+static double d_ab_ochiai(const or_stats *st, size_t i, size_t j) {                     /* :1068-1078 */
+    double A1 = st->S[i * st->n + j], B1 = st->S[j * st->n + i], A0 = st->Nk[i], B0 = st->Nk[j];
+    if (A0 == 0 || B0 == 0) return 1;
+    return 1 - sqrt(A1 / A0) * sqrt(B1 / B0);
+}
+static double d_ab_sorensen(const or_stats *st, size_t i, size_t j) {                   /* :1081-1096 */
+    double A1 = st->S[i * st->n + j], B1 = st->S[j * st->n + i], A0 = st->Nk[i], B0 = st->Nk[j];
+    double num = 2 * A1 * B1, den = A0 * B1 + A1 * B0;
+    if (den == 0) return 1;
+    return 1 - num / den;
+}
+static double d_ab_jaccard(const or_stats *st, size_t i, size_t j) {                    /* :1099-1115 */
+    double A1 = st->S[i * st->n + j], B1 = st->S[j * st->n + i], A0 = st->Nk[i], B0 = st->Nk[j];
+    double num = A1 * B1, den = A0 * B1 + A1 * B0 - A1 * B1;
+    if (den == 0) return 1;
+    return 1 - num / den;
+}
+static double d_pa_chord(uint64_t ua, uint64_t ub, uint64_t uc) {                       /* :1117-1127 */
+    double a = ua, b = ub, c = uc;
+    double p1 = sqrt((a + b) * (a + c));
+    if (p1 == 0) return sqrt(2);
+    return sqrt(2 * (1 - a / p1));
+}
+static double d_pa_whittaker(uint64_t ua, uint64_t ub, uint64_t uc) {                   /* :1129-1145 */
+    double a = ua, b = ub, c = uc;
+    if (a + b == 0 || a + c == 0) return 1;
+    double p1 = b / (a + b), p2 = c / (a + c), p3 = a / (a + b), p4 = a / (a + c);
+    return 0.5 * (p1 + p2 + fabs(p3 - p4));
+}
+static double d_pa_kulczynski(uint64_t ua, uint64_t ub, uint64_t uc) {                  /* :1156-1170 */
+    double a = ua, b = ub, c = uc;
+    if (a + b == 0 || a + c == 0) return 1;
+    return 1 - 0.5 * (a / (a + b) + a / (a + c));
+}
+static double d_pa_braycurtis(uint64_t ua, uint64_t ub, uint64_t uc) {                  /* :1172-1183 */
+    double a = ua, b = ub, c = uc;
+    if ((2 * a + b + c) == 0) return 1;
+    return (b + c) / (2 * a + b + c);
+}
+static double d_pa_ochiai(uint64_t ua, uint64_t ub, uint64_t uc) {                      /* :1188-1198 */
+    double a = ua, b = ub, c = uc;
+    float val = sqrt((a + b) * (a + c));            /* float32 temporary, as in the reference */
+    if (val == 0) return 1;
+    return 1 - (a / val);
+}
+static double d_pa_jaccard(uint64_t ua, uint64_t ub, uint64_t uc) {                     /* :1200-1208 */
+    double a = ua, b = ub, c = uc;
+    if ((a + b + c) == 0) return 1;
+    return (b + c) / (a + b + c);
+}
+static double d_pa_jaccard_simka(const or_stats *st, size_t i, size_t j, size_t sym, int asym) { /* :1210-1226 */
+    double num, den;
+    (void)j;
+    if (!asym) { num = 2 * st->a[sym]; den = st->D[i] + st->D[j]; }
+    else { num = st->a[sym]; den = st->D[i]; }
+    if (den == 0) return 1;
+    return 1 - num / den;
+}
+
+/* matrix names in reference output order, ref: src/core/SimkaDistance.cpp:617-647 */
+static const char *OR_MATRIX_NAMES[] = {
+    "mat_presenceAbsence_chord", "mat_presenceAbsence_whittaker", "mat_presenceAbsence_kulczynski",
+    "mat_presenceAbsence_braycurtis", "mat_presenceAbsence_jaccard", "mat_presenceAbsence_simka-jaccard",
+    "mat_presenceAbsence_simka-jaccard_asym", "mat_presenceAbsence_ochiai",
+    "mat_abundance_simka-jaccard", "mat_abundance_simka-jaccard_asym", "mat_abundance_ab-ochiai",
+    "mat_abundance_ab-sorensen", "mat_abundance_ab-jaccard", "mat_abundance_braycurtis", "mat_abundance_jaccard",
+    "mat_abundance_chord", "mat_abundance_hellinger", "mat_abundance_kulczynski",          /* -simple-dist  */
+    "mat_abundance_whittaker", "mat_abundance_jensenshannon", "mat_abundance_canberra" };  /* -complex-dist */
+#define OR_NB_MATRICES 21
+
+/* Build matrix `which` (index into OR_MATRIX_NAMES) as float32 cells,
+ * ref: src/core/SimkaDistance.hpp:155-475 (zero-filled, loops over i<j only). */
+static void or_matrix(const or_stats *st, int which, float *m) {
+    size_t n = st->n;
+    memset(m, 0, n * n * sizeof(float));
+    if (which == 14) {   /* computeJaccardDistanceFromBrayCurtis, .hpp:463-475: every cell, from the FLOAT BC matrix */
+        float *bcm = (float *)malloc(n * n * sizeof(float));
+        or_matrix(st, 13, bcm);
+        for (size_t i = 0; i < n * n; i++) { double B = bcm[i]; double J = (2 * B) / (1 + B); m[i] = J; }
+        free(bcm);
+        return;
+    }
+    for (size_t i = 0; i < n; i++)
+        for (size_t j = i + 1; j < n; j++) {
+            size_t sym = or_sym(n, i, j);
+            uint64_t a, b, c;
+            or_abc(st, i, j, sym, &a, &b, &c);
+            double dij = 0, dji = 0; int asym = 0;
+            switch (which) {
+                case 0: dij = d_pa_chord(a, b, c); break;
+                case 1: dij = d_pa_whittaker(a, b, c); break;
+                case 2: dij = d_pa_kulczynski(a, b, c); break;
+                case 3: dij = d_pa_braycurtis(a, b, c); break;
+                case 4: dij = d_pa_jaccard(a, b, c); break;
+                case 5: dij = d_pa_jaccard_simka(st, i, j, sym, 0); break;
+                case 6: dij = d_pa_jaccard_simka(st, i, j, sym, 1); dji = d_pa_jaccard_simka(st, j, i, sym, 1); asym = 1; break;
+                case 7: dij = d_pa_ochiai(a, b, c); break;
+                case 8: dij = d_ab_jaccard_simka(st, i, j, 0); break;
+                case 9: dij = d_ab_jaccard_simka(st, i, j, 1); dji = d_ab_jaccard_simka(st, j, i, 1); asym = 1; break;
+                case 10: dij = d_ab_ochiai(st, i, j); break;
+                case 11: dij = d_ab_sorensen(st, i, j); break;
+                case 12: dij = d_ab_jaccard(st, i, j); break;
+                case 13: dij = d_ab_braycurtis(st, i, j, sym); break;
+                case 15: dij = d_ab_chord(st, i, j); break;
+                case 16: dij = d_ab_hellinger(st, i, j); break;
+                case 17: dij = d_ab_kulczynski(st, i, j); break;
+                case 18: dij = d_ab_whittaker(st, i, j); break;
+                case 19: dij = d_ab_kl(st, i, j); break;
+                case 20: dij = d_ab_canberra(st, i, j, a, b, c); break;
+            }
+            m[i * n + j] = (float)dij;
+            m[j * n + i] = (float)(asym ? dji : dij);
+        }
+}
+
+/* [a11] CSV   ref: src/core/SimkaDistance.cpp:653-699 */
+static int or_dump_matrix(const oracle *o, const char *dir, const char *name, const float *m, int gz) {
+    char path[4096];
+    snprintf(path, sizeof path, "%s/%s.csv%s", dir, name, gz ? ".gz" : "");
+    strbuf s = {0};
+    char cell[64];
+    for (int i = 0; i < o->n; i++) { sb_app(&s, ";", 1); sb_app(&s, o->s[i].id, strlen(o->s[i].id)); }
+    sb_app(&s, "\n", 1);
+    for (int i = 0; i < o->n; i++) {
+        sb_app(&s, o->s[i].id, strlen(o->s[i].id));
+        for (int j = 0; j < o->n; j++) {
+            int l = snprintf(cell, sizeof cell, ";%f", (double)m[(size_t)i * o->n + j]);
+            sb_app(&s, cell, (size_t)l);
+        }
+        sb_app(&s, "\n", 1);
+    }
+    int rc = 0;
+    if (gz) { gzFile g = gzopen(path, "wb"); if (!g) rc = -1; else { gzwrite(g, s.b, (unsigned)s.n); gzclose(g); } }
+    else { FILE *f = fopen(path, "wb"); if (!f) rc = -1; else { fwrite(s.b, 1, s.n, f); fclose(f); } }
+    free(s.b);
+    return rc;
+}
+
+/* ------------------------------------------------------------------------- */
+/* public (test-only) API, used through ctypes                                */
+/* ------------------------------------------------------------------------- */
+OR_API oracle *oracle_new(void) { return (oracle *)calloc(1, sizeof(oracle)); }
+
+OR_API void oracle_free(oracle *o) {
+    if (!o) return;
+    for (int i = 0; i < o->n; i++) {
+        free(o->s[i].id);
+        for (int f = 0; f < o->s[i].nfiles; f++) free(o->s[i].files[f]);
+        free(o->s[i].files); free(o->s[i].kmer); free(o->s[i].count);
+    }
+    free(o->s); or_stats_free(o->stats); free(o);
+}
+OR_API const char *oracle_error(const oracle *o) { return o->err; }
+OR_API int oracle_load_input(oracle *o, const char *input_txt) { return or_parse_input(o, input_txt); }
+OR_API int oracle_nb_samples(const oracle *o) { return o->n; }
+OR_API const char *oracle_sample_id(const oracle *o, int i) { return o->s[i].id; }
+OR_API int oracle_sample_nb_files(const oracle *o, int i) { return o->s[i].nfiles; }
+OR_API const char *oracle_sample_file(const oracle *o, int i, int f) { return o->s[i].files[f]; }
+OR_API int oracle_sample_nb_paired(const oracle *o, int i) { return o->s[i].nb_paired; }
+
+/* in-memory sample: `bases` = concatenated ASCII reads, offsets[nreads+1]; pointers must outlive oracle_run */
+OR_API int oracle_add_sample_mem(oracle *o, const char *id, const char *bases, const uint64_t *offsets, uint64_t nreads) {
+    o->s = (or_sample *)realloc(o->s, (o->n + 1) * sizeof(or_sample));
+    or_sample *s = &o->s[o->n++];
+    memset(s, 0, sizeof *s);
+    s->id = strdup(id); s->bases = bases; s->offsets = offsets; s->nreads_mem = nreads; s->nb_paired = 1;
+    return o->n - 1;
+}
+
+/* count every sample, merge the partitions p of `nparts` with p % shard_count == shard_index, reduce.
+ * (shard_count=1: everything.)  threads<=1 -> serial. */
+OR_API int oracle_run_shard(oracle *o, int k, uint32_t amin, uint32_t amax, int simple, int complex_, unsigned nparts, int threads,
+                            unsigned shard_index, unsigned shard_count) {
+    if (k < 1 || k > 32) { snprintf(o->err, sizeof o->err, "oracle: k must be in [1,32]"); return -1; }
+    o->k = k; o->amin = amin; o->amax = amax > 999999999u ? 999999999u : amax;  /* ref: src/core/SimkaAlgorithm.cpp:188 */
+    if (nparts < 1) nparts = 1;
+    int rc = 0;
+    for (int i = 0; i < o->n; i++) { free(o->s[i].kmer); free(o->s[i].count); o->s[i].kmer = NULL; o->s[i].count = NULL; }
+#ifdef _OPENMP
+    if (threads < 1) threads = 1;
+#pragma omp parallel for schedule(dynamic, 1) num_threads(threads)
+#endif
+    for (int i = 0; i < o->n; i++) { if (or_count_sample(o, &o->s[i]) != 0) rc = -1; }
+    if (rc) return rc;
+    or_stats_free(o->stats);
+    o->stats = or_stats_new(o, simple, complex_);
+    or_stats **ps = (or_stats **)calloc(nparts, sizeof(or_stats *));
+#ifdef _OPENMP
+#pragma omp parallel for schedule(dynamic, 1) num_threads(threads)
+#endif
+    for (unsigned p = 0; p < nparts; p++) {
+        if (shard_count > 1 && p % shard_count != shard_index) continue;
+        ps[p] = or_stats_new(o, simple, complex_); or_merge_partition(o, ps[p], p, nparts);
+    }
+    for (unsigned p = 0; p < nparts; p++) if (ps[p]) { or_stats_add(o->stats, ps[p]); or_stats_free(ps[p]); }  /* stats(), ref: src/SimkaPotara.hpp:1152-1187 */
+    free(ps);
+    (void)threads;
+    return 0;
+}
+OR_API int oracle_run(oracle *o, int k, uint32_t amin, uint32_t amax, int simple, int complex_, unsigned nparts, int threads) {
+    return oracle_run_shard(o, k, amin, amax, simple, complex_, nparts, threads, 0, 1);
+}
+/* D,N,Q restricted to the k-mers of one shard's partitions: out[i*3 + {0:D 1:N 2:Q}] (they add up over shards) */
+OR_API void oracle_get_shard_totals(const oracle *o, unsigned nparts, unsigned shard_index, unsigned shard_count, uint64_t *out) {
+    for (int i = 0; i < o->n; i++) {
+        const or_sample *s = &o->s[i];
+        uint64_t D = 0, N = 0, Q = 0;
+        for (size_t j = 0; j < s->nsolid; j++) {
+            unsigned p = nparts > 1 ? (unsigned)(or_mix(s->kmer[j]) % nparts) : 0;
+            if (shard_count > 1 && p % shard_count != shard_index) continue;
+            uint64_t c = s->count[j];
+            D += 1; N += c; Q += c * c;
+        }
+        out[i * 3 + 0] = D; out[i * 3 + 1] = N; out[i * 3 + 2] = Q;
+    }
+}
+
+/* per-sample totals: out[i*6 + {0:nbReads 1:K_occ 2:D_all 3:D 4:N 5:Q}] */
+OR_API void oracle_get_totals(const oracle *o, uint64_t *out) {
+    for (int i = 0; i < o->n; i++) {
+        const or_sample *s = &o->s[i];
+        out[i * 6 + 0] = s->nb_reads; out[i * 6 + 1] = s->k_occ; out[i * 6 + 2] = s->d_all;
+        out[i * 6 + 3] = s->D; out[i * 6 + 4] = s->N; out[i * 6 + 5] = s->Q;
+    }
+}
+OR_API void oracle_get_global(const oracle *o, uint64_t *out) { out[0] = o->stats->nb_distinct; out[1] = o->stats->nb_shared; }
+/* accumulators as dense N x N u64 ([i][j], i<j carries the sym ones too); which:
+ * 0 S, 1 a (sym->[i][j]), 2 bc (sym->[i][j]), 3 chord (long double -> u64, exact below 2^64),
+ * 4 hell, 5 kul, 6 whit, 7 canb */
+OR_API void oracle_get_acc_u64(const oracle *o, int which, uint64_t *out) {
+    const or_stats *st = o->stats; size_t n = st->n;
+    memset(out, 0, n * n * 8);
+    for (size_t i = 0; i < n; i++) for (size_t j = 0; j < n; j++) {
+        uint64_t v = 0;
+        switch (which) {
+            case 0: v = st->S[i * n + j]; break;
+            case 1: v = (i < j) ? st->a[or_sym(n, i, j)] : 0; break;
+            case 2: v = (i < j) ? st->bc[or_sym(n, i, j)] : 0; break;
+            case 3: v = (uint64_t)st->chord[i * n + j]; break;
+            case 4: v = st->hell[i * n + j]; break;
+            case 5: v = st->kul[i * n + j]; break;
+            case 6: v = st->whit[i * n + j]; break;
+            case 7: v = st->canb[i * n + j]; break;
+        }
+        out[i * n + j] = v;
+    }
+}
+OR_API void oracle_get_kl(const oracle *o, double *out) {
+    size_t n = o->stats->n;
+    for (size_t i = 0; i < n * n; i++) out[i] = (double)o->stats->kl[i];
+}
+OR_API int oracle_nb_matrices(void) { return OR_NB_MATRICES; }
+OR_API const char *oracle_matrix_name(int which) { return OR_MATRIX_NAMES[which]; }
+OR_API void oracle_get_matrix(const oracle *o, int which, float *out) { or_matrix(o->stats, which, out); }
+
+/* solid spectrum of one sample (sorted canonical k-mers, A0C1T2G3 code) -- for kernel-level tests */
+OR_API uint64_t oracle_sample_nsolid(const oracle *o, int i) { return o->s[i].nsolid; }
+OR_API void oracle_get_sample_solid(const oracle *o, int i, uint64_t *kmers, uint32_t *counts) {
+    memcpy(kmers, o->s[i].kmer, o->s[i].nsolid * 8); memcpy(counts, o->s[i].count, o->s[i].nsolid * 4);
+}
+
+/* outputMatrix, ref: src/core/SimkaDistance.cpp:603-649 */
+OR_API int oracle_write_matrices(const oracle *o, const char *dir, int gz) {
+    size_t n = o->n;
+    float *m = (float *)malloc(n * n * sizeof(float));
+    int rc = 0;
+    for (int w = 0; w < OR_NB_MATRICES; w++) {
+        if (w >= 15 && w <= 17 && !o->stats->simple) continue;
+        if (w >= 18 && !o->stats->complex_) continue;
+        or_matrix(o->stats, w, m);
+        if (or_dump_matrix(o, dir, OR_MATRIX_NAMES[w], m, gz) != 0) rc = -1;
+    }
+    free(m);
+    return rc;
+}
+
+#ifdef ORACLE_MAIN
+/* minimal CLI: simka_oracle -in X -out DIR [-kmer-size K] [-abundance-min M] [-abundance-max M]
+ *              [-simple-dist] [-complex-dist] [-nb-partitions P] [-nb-cores T] [-gz] */
+int main(int argc, char **argv) {
+    const char *in = NULL, *out = "./simka_results";
+    int k = 21, simple = 0, complex_ = 0, gz = 0, threads = 1; unsigned P = 1; uint32_t amin = 2, amax = 999999999u;
+    for (int i = 1; i < argc; i++) {
+        if (!strcmp(argv[i], "-in") && i + 1 < argc) in = argv[++i];
+        else if (!strcmp(argv[i], "-out") && i + 1 < argc) out = argv[++i];
+        else if (!strcmp(argv[i], "-kmer-size") && i + 1 < argc) k = atoi(argv[++i]);
+        else if (!strcmp(argv[i], "-abundance-min") && i + 1 < argc) amin = (uint32_t)strtoul(argv[++i], 0, 10);
+        else if (!strcmp(argv[i], "-abundance-max") && i + 1 < argc) amax = (uint32_t)strtoul(argv[++i], 0, 10);
+        else if (!strcmp(argv[i], "-nb-partitions") && i + 1 < argc) P = (unsigned)atoi(argv[++i]);
+        else if (!strcmp(argv[i], "-nb-cores") && i + 1 < argc) threads = atoi(argv[++i]);
+        else if (!strcmp(argv[i], "-simple-dist")) simple = 1;
+        else if (!strcmp(argv[i], "-complex-dist")) complex_ = 1;
+        else if (!strcmp(argv[i], "-gz")) gz = 1;
+    }
+    if (!in) { fprintf(stderr, "usage: simka_oracle -in input.txt -out dir ...\n"); return 1; }
+    oracle *o = oracle_new();
+    if (oracle_load_input(o, in) != 0 || oracle_run(o, k, amin, amax, simple, complex_, P, threads) != 0) {
+        fprintf(stderr, "%s\n", oracle_error(o)); return 1;
+    }
+    if (oracle_write_matrices(o, out, gz) != 0) { fprintf(stderr, "cannot write to %s\n", out); return 1; }
+    oracle_free(o);
+    return 0;
+}
+#endif

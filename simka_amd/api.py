@@ -1,0 +1,384 @@
+"""ctypes binding of include/simka_hip.h plus a small host-side mirror of the reference flow.
+
+The reference drives the path as   simkaCount (per sample)  ->  simkaMerge (per partition)  ->
+SimkaStatistics += / outputMatrix   (ref: src/SimkaPotara.hpp:813-1187).  `SimkaContext` keeps that
+shape: count_sample() per sample, merge(), stats(), matrices()/write_matrices().
+
+There is no CPU fallback: if libsimka_hip.so is missing, or no HIP device is visible, this raises.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import build as _build
+
+SIMKA_OK = 0
+ERR_NAMES = {1: "INVALID", 2: "HIP", 3: "NOMEM", 4: "OVERFLOW", 5: "STATE", 6: "IO", 7: "UNSUPPORTED"}
+DIST_SIMPLE = 1
+DIST_COMPLEX = 2
+
+
+class SimkaError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("simka error %s (%d): %s" % (ERR_NAMES.get(code, "?"), code, msg))
+        self.code = code
+
+
+class Config(C.Structure):
+    _fields_ = [("struct_size", C.c_uint32), ("nb_samples", C.c_uint32), ("kmer_size", C.c_uint32),
+                ("abundance_min", C.c_uint32), ("abundance_max", C.c_uint32), ("dist_flags", C.c_uint32),
+                ("device", C.c_int32), ("shard_index", C.c_uint32), ("shard_count", C.c_uint32),
+                ("log2_partitions", C.c_uint32), ("log2_subranges", C.c_uint32), ("reserved0", C.c_uint32),
+                ("max_kmers_per_sample", C.c_uint64), ("solid_capacity", C.c_uint64), ("csr_capacity", C.c_uint64),
+                ("stream", C.c_void_p)]
+
+
+class Reads(C.Structure):
+    _fields_ = [("packed", C.c_void_p), ("nb_bases", C.c_uint64), ("nb_reads", C.c_uint64), ("offsets", C.c_void_p),
+                ("fixed_len", C.c_uint32), ("on_device", C.c_uint32), ("nb_input_reads", C.c_uint64)]
+
+
+class SampleTotals(C.Structure):
+    _fields_ = [("nb_reads", C.c_uint64), ("nb_distinct", C.c_uint64), ("nb_kmers", C.c_uint64), ("sum_sq", C.c_uint64),
+                ("kmer_occurrences", C.c_uint64), ("distinct_all", C.c_uint64)]
+
+
+_U64P = C.POINTER(C.c_uint64)
+
+
+class StatsView(C.Structure):
+    _fields_ = [("nb_samples", C.c_uint32), ("dist_flags", C.c_uint32), ("nb_pairs", C.c_uint64),
+                ("nb_distinct", _U64P), ("nb_kmers", _U64P), ("sum_sq", _U64P), ("shared_ij", _U64P), ("shared_ji", _U64P),
+                ("distinct_shared", _U64P), ("bray_curtis", _U64P), ("chord", _U64P), ("hellinger", _U64P),
+                ("whittaker", _U64P), ("canberra", _U64P), ("kl", C.POINTER(C.c_double)),
+                ("nb_distinct_kmers", C.c_uint64), ("nb_shared_kmers", C.c_uint64)]
+
+
+_lib = None
+
+
+def load_library(build_if_missing=True):
+    """dlopen libsimka_hip.so (building it first if the sources are newer). Raises if unavailable."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = _build.LIB_PATH
+    if build_if_missing and not os.path.exists(path):
+        _build.build()
+    if not os.path.exists(path):
+        raise RuntimeError("libsimka_hip.so is missing (%s): run `python -m simka_amd.build`; there is no CPU fallback" % path)
+    lib = C.CDLL(path)
+    vp, u32, u64, i32 = C.c_void_p, C.c_uint32, C.c_uint64, C.c_int
+    sigs = {
+        "simka_abi_version": (i32, []),
+        "simka_create": (i32, [C.POINTER(Config), C.POINTER(vp)]),
+        "simka_destroy": (None, [vp]),
+        "simka_last_error": (C.c_char_p, [vp]),
+        "simka_sync": (i32, [vp]),
+        "simka_count_sample": (i32, [vp, u32, C.POINTER(Reads)]),
+        "simka_get_sample_totals": (i32, [vp, u32, C.POINTER(SampleTotals)]),
+        "simka_merge": (i32, [vp]),
+        "simka_stats_device_buffer": (i32, [vp, C.POINTER(vp), C.POINTER(u64)]),
+        "simka_stats_download": (i32, [vp, vp, u64, C.POINTER(StatsView)]),
+        "simka_stats_describe": (i32, [u32, u32, vp, u64, C.POINTER(StatsView)]),
+        "simka_stats_nb_u64": (u64, [u32, u32]),
+        "simka_nb_matrices": (i32, []),
+        "simka_matrix_name": (C.c_char_p, [i32]),
+        "simka_matrix_enabled": (i32, [i32, u32]),
+        "simka_compute_matrix": (i32, [C.POINTER(StatsView), i32, vp]),
+        "simka_write_matrix_csv": (i32, [C.c_char_p, C.c_char_p, C.POINTER(C.c_char_p), u32, vp, i32]),
+        "simka_pack_read": (C.c_int64, [C.c_char_p, u64, vp, C.POINTER(u64), vp]),
+        "simka_profile_enable": (i32, [vp, i32]),
+        "simka_profile_reset": (i32, [vp]),
+        "simka_profile_nb_kernels": (i32, [vp]),
+        "simka_profile_get": (i32, [vp, i32, C.POINTER(C.c_char_p), C.POINTER(u64), C.POINTER(C.c_double)]),
+        "simka_get_geometry": (i32, [vp, C.POINTER(u32), C.POINTER(u32), C.POINTER(u32), C.POINTER(u64), C.POINTER(u64)]),
+        "simka_synth_genomes": (i32, [vp, vp, u32, u64, u64]),
+        "simka_synth_reads": (i32, [vp, vp, u64, u32, vp, u64, u64, vp, vp, u32, u64, u32]),
+    }
+    for name, (res, args) in sigs.items():
+        fn = getattr(lib, name)
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def matrix_names(dist_flags=DIST_SIMPLE | DIST_COMPLEX):
+    lib = load_library()
+    return [lib.simka_matrix_name(w).decode() for w in range(lib.simka_nb_matrices()) if lib.simka_matrix_enabled(w, dist_flags)]
+
+
+class Stats:
+    """Host copy of the flat accumulator buffer + typed views (== SimkaStatistics)."""
+
+    def __init__(self, nb_samples, dist_flags, flat):
+        self.lib = load_library()
+        self.nb_samples = int(nb_samples)
+        self.dist_flags = int(dist_flags)
+        self.flat = np.ascontiguousarray(flat, dtype=np.uint64)
+        self.view = StatsView()
+        rc = self.lib.simka_stats_describe(self.nb_samples, self.dist_flags, self.flat.ctypes.data, self.flat.size,
+                                           C.byref(self.view))
+        if rc != SIMKA_OK:
+            raise SimkaError(rc, "simka_stats_describe")
+
+    def _arr(self, ptr, n):
+        if not ptr:
+            return None
+        return np.ctypeslib.as_array(ptr, shape=(n,)).copy()
+
+    def per_sample(self):
+        n = self.nb_samples
+        return {"D": self._arr(self.view.nb_distinct, n), "N": self._arr(self.view.nb_kmers, n), "Q": self._arr(self.view.sum_sq, n)}
+
+    def pairs(self):
+        p = int(self.view.nb_pairs)
+        v = self.view
+        out = {"S_ij": self._arr(v.shared_ij, p), "S_ji": self._arr(v.shared_ji, p), "a": self._arr(v.distinct_shared, p),
+               "bc": self._arr(v.bray_curtis, p)}
+        if self.dist_flags & DIST_SIMPLE:
+            out["chord"] = self._arr(v.chord, p)
+            out["hell"] = self._arr(v.hellinger, p)
+        return out
+
+    def dense(self, name):
+        """pair array -> N x N (upper triangle i<j filled; S_ji goes to the lower triangle of 'S')."""
+        n = self.nb_samples
+        iu = np.triu_indices(n, 1)
+        pr = self.pairs()
+        m = np.zeros((n, n), dtype=np.uint64)
+        if name == "S":
+            m[iu] = pr["S_ij"]
+            m.T[iu] = pr["S_ji"]
+        else:
+            m[iu] = pr[name]
+        return m
+
+    def matrix(self, which):
+        n = self.nb_samples
+        out = np.zeros((n, n), dtype=np.float32)
+        rc = self.lib.simka_compute_matrix(C.byref(self.view), which, out.ctypes.data)
+        if rc != SIMKA_OK:
+            raise SimkaError(rc, "simka_compute_matrix(%d)" % which)
+        return out
+
+    def matrices(self):
+        lib = self.lib
+        return {lib.simka_matrix_name(w).decode(): self.matrix(w) for w in range(lib.simka_nb_matrices())
+                if lib.simka_matrix_enabled(w, self.dist_flags)}
+
+    def write_matrices(self, outdir, sample_ids, gz=True):
+        """SimkaStatistics::outputMatrix (ref: src/core/SimkaDistance.cpp:603-649)."""
+        os.makedirs(outdir, exist_ok=True)
+        ids = (C.c_char_p * len(sample_ids))(*[s.encode() for s in sample_ids])
+        for name, m in self.matrices().items():
+            m = np.ascontiguousarray(m)
+            rc = self.lib.simka_write_matrix_csv(outdir.encode(), name.encode(), ids, len(sample_ids), m.ctypes.data, 1 if gz else 0)
+            if rc != SIMKA_OK:
+                raise SimkaError(rc, "simka_write_matrix_csv(%s)" % name)
+
+
+class SimkaContext:
+    def __init__(self, nb_samples, kmer_size=21, abundance_min=2, abundance_max=999999999, simple_dist=False,
+                 complex_dist=False, device=0, shard_index=0, shard_count=1, max_kmers_per_sample=0, log2_partitions=0,
+                 log2_subranges=0, solid_capacity=0, csr_capacity=0, stream=None):
+        self.lib = load_library()
+        cfg = Config()
+        cfg.struct_size = C.sizeof(Config)
+        cfg.nb_samples = nb_samples
+        cfg.kmer_size = kmer_size
+        cfg.abundance_min = abundance_min
+        cfg.abundance_max = abundance_max
+        cfg.dist_flags = (DIST_SIMPLE if simple_dist else 0) | (DIST_COMPLEX if complex_dist else 0)
+        cfg.device = device
+        cfg.shard_index = shard_index
+        cfg.shard_count = shard_count
+        cfg.max_kmers_per_sample = max_kmers_per_sample
+        cfg.log2_partitions = log2_partitions
+        cfg.log2_subranges = log2_subranges
+        cfg.solid_capacity = solid_capacity
+        cfg.csr_capacity = csr_capacity
+        cfg.stream = stream
+        self.cfg = cfg
+        self.nb_samples = nb_samples
+        self.dist_flags = cfg.dist_flags
+        h = C.c_void_p()
+        rc = self.lib.simka_create(C.byref(cfg), C.byref(h))
+        if rc != SIMKA_OK:
+            raise SimkaError(rc, self.lib.simka_last_error(None).decode())
+        self.h = h
+        self._keep = []
+
+    def _check(self, rc):
+        if rc != SIMKA_OK:
+            raise SimkaError(rc, self.lib.simka_last_error(self.h).decode())
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.simka_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    # -- count side -------------------------------------------------------------------------
+    def count_sample(self, index, packed, nb_bases, nb_reads, fixed_len=0, offsets=None, on_device=False, nb_input_reads=0):
+        """`packed`/`offsets`: numpy uint64 arrays (host) or integer device pointers (on_device=True)."""
+        r = Reads()
+        if on_device:
+            r.packed = int(packed)
+            r.offsets = int(offsets) if offsets is not None else None
+        else:
+            packed = np.ascontiguousarray(packed, dtype=np.uint64)
+            self._keep = [packed]
+            r.packed = packed.ctypes.data
+            if offsets is not None:
+                offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
+                self._keep.append(offsets)
+                r.offsets = offsets.ctypes.data
+        r.nb_bases = int(nb_bases)
+        r.nb_reads = int(nb_reads)
+        r.fixed_len = int(fixed_len)
+        r.on_device = 1 if on_device else 0
+        r.nb_input_reads = int(nb_input_reads)
+        self._check(self.lib.simka_count_sample(self.h, index, C.byref(r)))
+
+    def sample_totals(self, index):
+        t = SampleTotals()
+        self._check(self.lib.simka_get_sample_totals(self.h, index, C.byref(t)))
+        return {"nb_reads": t.nb_reads, "D": t.nb_distinct, "N": t.nb_kmers, "Q": t.sum_sq, "K_occ": t.kmer_occurrences,
+                "D_all": t.distinct_all}
+
+    # -- merge side -------------------------------------------------------------------------
+    def merge(self):
+        self._check(self.lib.simka_merge(self.h))
+
+    def sync(self):
+        self._check(self.lib.simka_sync(self.h))
+
+    def stats_device_buffer(self):
+        p = C.c_void_p()
+        n = C.c_uint64()
+        self._check(self.lib.simka_stats_device_buffer(self.h, C.byref(p), C.byref(n)))
+        return p.value, n.value
+
+    def stats(self):
+        n = self.lib.simka_stats_nb_u64(self.nb_samples, self.dist_flags)
+        flat = np.zeros(n, dtype=np.uint64)
+        self._check(self.lib.simka_stats_download(self.h, flat.ctypes.data, n, None))
+        return Stats(self.nb_samples, self.dist_flags, flat)
+
+    # -- profiling --------------------------------------------------------------------------
+    def profile_enable(self, on=True):
+        self._check(self.lib.simka_profile_enable(self.h, 1 if on else 0))
+
+    def profile_reset(self):
+        self._check(self.lib.simka_profile_reset(self.h))
+
+    def profile(self):
+        out = {}
+        for w in range(self.lib.simka_profile_nb_kernels(self.h)):
+            name = C.c_char_p()
+            n = C.c_uint64()
+            ms = C.c_double()
+            self._check(self.lib.simka_profile_get(self.h, w, C.byref(name), C.byref(n), C.byref(ms)))
+            out[name.value.decode()] = (n.value, ms.value)
+        return out
+
+    def geometry(self):
+        l1, l2, t = C.c_uint32(), C.c_uint32(), C.c_uint32()
+        a, c = C.c_uint64(), C.c_uint64()
+        self._check(self.lib.simka_get_geometry(self.h, C.byref(l1), C.byref(l2), C.byref(t), C.byref(a), C.byref(c)))
+        return {"log2_level1": l1.value, "log2_level2": l2.value, "log2_subranges": t.value, "arena_capacity": a.value,
+                "csr_capacity": c.value}
+
+
+# ---- host-side ingest (FASTA/FASTQ, plain or gz) for the Python entry points -------------------
+def read_sequences(path):
+    """Yield the sequences of a FASTA (multi-line) or FASTQ (4-line) file, plain or gzip."""
+    import gzip
+    with open(path, "rb") as fh:
+        magic = fh.read(2)
+    opener = gzip.open if magic == b"\x1f\x8b" else open
+    with opener(path, "rb") as fh:
+        first = fh.read(1)
+        if not first:
+            return
+        rest = fh.read()
+    data = first + rest
+    lines = data.split(b"\n")
+    if first == b">":
+        seq = []
+        started = False
+        for ln in lines:
+            ln = ln.rstrip(b"\r")
+            if ln.startswith(b">"):
+                if started:
+                    yield b"".join(seq)
+                seq = []
+                started = True
+            elif started:
+                seq.append(ln)
+        if started:
+            yield b"".join(seq)
+    elif first == b"@":
+        i = 0
+        while i + 1 < len(lines):
+            if lines[i].startswith(b"@"):
+                yield lines[i + 1].rstrip(b"\r")
+                i += 4
+            else:
+                i += 1
+    else:
+        raise ValueError("unrecognised sequence file: %s" % path)
+
+
+def pack_reads(seqs):
+    """2-bit pack an iterable of byte strings with simka_pack_read. Returns (packed, offsets, nb_bases, nb_input_reads)."""
+    lib = load_library()
+    seqs = list(seqs)
+    total = sum(len(s) for s in seqs)
+    packed = np.zeros(total // 32 + 3, dtype=np.uint64)
+    offsets = np.zeros(total + len(seqs) + 2, dtype=np.uint64)
+    nb = C.c_uint64(0)
+    nfrag = 0
+    for s in seqs:
+        r = lib.simka_pack_read(s, len(s), packed.ctypes.data, C.byref(nb), offsets.ctypes.data + 8 * nfrag)
+        if r < 0:
+            raise SimkaError(1, "simka_pack_read")
+        nfrag += r
+    offsets[nfrag] = nb.value
+    return packed[: nb.value // 32 + 3], offsets[: nfrag + 1].copy(), nb.value, len(seqs)
+
+
+def parse_input_file(path):
+    """The -in grammar (ref: src/core/SimkaAlgorithm.cpp:245-351): ID: f1 , f2 ; g1 , g2"""
+    base = os.path.dirname(os.path.realpath(path))
+    samples = []
+    with open(path) as fh:
+        for line in fh:
+            line = line.replace(" ", "").rstrip("\r\n")
+            if not line:
+                continue
+            parts = line.split(":")
+            if len(parts) < 2:
+                raise ValueError("Syntax error in input file")
+            sid, rest = parts[0], parts[1]
+            paired = [p for p in rest.split(";") if p != ""]
+            files = []
+            for part in paired:
+                for fn in [f for f in part.split(",") if f != ""]:
+                    files.append(fn if fn.startswith("/") else os.path.join(base, fn))
+            samples.append({"id": sid, "files": files, "nb_paired": len(paired)})
+    return samples

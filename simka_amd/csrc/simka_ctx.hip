@@ -1,0 +1,570 @@
+// simka_ctx.hip -- the C ABI of include/simka_hip.h: context, device memory, kernel sequencing.
+// This is the only translation unit that launches kernels; simka_host.cpp holds the pure-host
+// pieces (finalisation, CSV, packing).
+#include <hip/hip_runtime.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+#include <string>
+#include <vector>
+#include <algorithm>
+
+#include "../../include/simka_hip.h"
+#include "simka_kernels.hip"
+
+#define SIMKA_EXPORT extern "C" __attribute__((visibility("default")))
+
+// kernel ids for the profiler
+enum { KID_SCAN_HIST = 0, KID_LAYOUT, KID_SCAN_SCATTER, KID_SPLIT, KID_COUNT, KID_PART_TOTALS, KID_REGROUP, KID_GROUP,
+       KID_PAIRS, KID_REDUCE, KID_NB };
+static const char *const KID_NAMES[KID_NB] = { "k_scan<hist>", "k_layout", "k_scan<scatter>", "k_split", "k_count",
+                                               "k_part_totals", "k_regroup", "k_group", "k_pairs", "k_reduce_slabs" };
+
+static thread_local std::string g_create_error;
+
+struct simka_ctx {
+    simka_config cfg;
+    SimkaKeyCfg key;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    int num_cus = 256;
+    bool geometry_ready = false;
+    uint32_t B1 = 1, B2 = 1;
+    uint64_t nparts = 1;
+    std::string err;
+
+    // per-sample scratch
+    uint64_t *d_reads = nullptr; uint64_t reads_cap = 0;      // staging for host reads (words)
+    uint64_t *d_offsets = nullptr; uint64_t offsets_cap = 0;
+    uint64_t *d_l1 = nullptr; uint64_t l1_cap = 0;            // level-1 buckets (keys)
+    ull *d_b1_count = nullptr, *d_b1_start = nullptr, *d_b1_cursor = nullptr;
+    uint32_t *d_chunk_first = nullptr;
+    uint16_t *d_chunk_off = nullptr; uint64_t chunk_cap = 0;  // chunks
+    // solid spectra of all samples
+    ull *d_solid_keys = nullptr; uint32_t *d_solid_counts = nullptr; uint64_t arena_cap = 0;
+    ull *d_arena_cursor = nullptr, *d_sample_base = nullptr;
+    uint32_t *d_foff = nullptr, *d_fcnt = nullptr;            // [N][nparts]
+    // statistics
+    uint64_t *d_stats = nullptr; uint64_t stats_n = 0;
+    uint32_t *d_err = nullptr;
+    // merge buffers
+    ull *d_part_total = nullptr, *d_part_off = nullptr;
+    ull *d_mkeys = nullptr, *d_mvals = nullptr, *d_entries = nullptr; uint32_t *d_groups = nullptr;
+    uint32_t *d_fb_off = nullptr; SimkaSpan *d_spans = nullptr; ull *d_cursors = nullptr; ull *d_slabs = nullptr;
+    uint64_t merge_cap = 0, fb_cap = 0, span_cap = 0, slab_words = 0;
+
+    std::vector<uint8_t> counted;
+    std::vector<uint64_t> nb_reads;
+    bool merged = false;
+
+    // profiling
+    bool profiling = false;
+    struct Ev { int kid; hipEvent_t a, b; };
+    std::vector<Ev> events;
+    double prof_ms[KID_NB] = {0};
+    uint64_t prof_n[KID_NB] = {0};
+
+    int fail(int code, const char *fmt, ...) {
+        char buf[1024];
+        va_list ap; va_start(ap, fmt); vsnprintf(buf, sizeof buf, fmt, ap); va_end(ap);
+        err = buf;
+        return code;
+    }
+};
+
+#define HIPCHK(call)                                                                             \
+    do {                                                                                         \
+        hipError_t e_ = (call);                                                                  \
+        if (e_ != hipSuccess) return ctx->fail(SIMKA_ERR_HIP, "%s failed: %s", #call, hipGetErrorString(e_)); \
+    } while (0)
+
+template <typename F>
+static inline void launch_timed(simka_ctx *ctx, int kid, F &&f) {
+    if (ctx->profiling) {
+        simka_ctx::Ev ev; ev.kid = kid;
+        (void)hipEventCreate(&ev.a); (void)hipEventCreate(&ev.b);
+        (void)hipEventRecord(ev.a, ctx->stream);
+        f();
+        (void)hipEventRecord(ev.b, ctx->stream);
+        ctx->events.push_back(ev);
+    } else f();
+}
+
+static void profile_collect(simka_ctx *ctx) {
+    for (auto &ev : ctx->events) {
+        float ms = 0;
+        (void)hipEventSynchronize(ev.b);
+        (void)hipEventElapsedTime(&ms, ev.a, ev.b);
+        ctx->prof_ms[ev.kid] += ms; ctx->prof_n[ev.kid]++;
+        (void)hipEventDestroy(ev.a); (void)hipEventDestroy(ev.b);
+    }
+    ctx->events.clear();
+}
+
+template <typename T>
+static hipError_t dev_alloc(T **p, uint64_t n) { return hipMalloc((void **)p, std::max<uint64_t>(n, 1) * sizeof(T)); }
+
+static uint32_t ceil_log2_u64(uint64_t x) { uint32_t l = 0; while (((uint64_t)1 << l) < x && l < 63) l++; return l; }
+
+// ---- flat statistics layout ---------------------------------------------------------------
+static inline uint32_t stats_nacc(uint32_t flags) { return (flags & SIMKA_DIST_SIMPLE) ? 6u : 4u; }
+static inline uint64_t stats_off_tot(uint32_t N, uint32_t t) { return 8 + (uint64_t)t * N; }
+static inline uint64_t stats_off_acc(uint32_t N, uint32_t a) { return 8 + (uint64_t)SIMKA_NB_TOTALS * N + (uint64_t)a * ((uint64_t)N * (N - 1) / 2); }
+
+SIMKA_EXPORT uint64_t simka_stats_nb_u64(uint32_t N, uint32_t flags) { return stats_off_acc(N, stats_nacc(flags)); }
+
+SIMKA_EXPORT int simka_stats_describe(uint32_t N, uint32_t flags, const uint64_t *h, uint64_t n, simka_stats_view *v) {
+    if (!h || !v || N == 0 || n < simka_stats_nb_u64(N, flags)) return SIMKA_ERR_INVALID;
+    memset(v, 0, sizeof *v);
+    v->nb_samples = N; v->dist_flags = flags; v->nb_pairs = (uint64_t)N * (N - 1) / 2;
+    v->nb_distinct_kmers = h[0]; v->nb_shared_kmers = h[1];
+    v->nb_distinct = h + stats_off_tot(N, SIMKA_TOT_D);
+    v->nb_kmers = h + stats_off_tot(N, SIMKA_TOT_N);
+    v->sum_sq = h + stats_off_tot(N, SIMKA_TOT_Q);
+    v->shared_ij = h + stats_off_acc(N, SIMKA_ACC_SIJ);
+    v->shared_ji = h + stats_off_acc(N, SIMKA_ACC_SJI);
+    v->distinct_shared = h + stats_off_acc(N, SIMKA_ACC_A);
+    v->bray_curtis = h + stats_off_acc(N, SIMKA_ACC_BC);
+    if (flags & SIMKA_DIST_SIMPLE) {
+        v->chord = h + stats_off_acc(N, SIMKA_ACC_CHORD);
+        v->hellinger = h + stats_off_acc(N, SIMKA_ACC_HELL);
+    }
+    return SIMKA_OK;
+}
+
+// ---- lifecycle ----------------------------------------------------------------------------
+SIMKA_EXPORT int simka_abi_version(void) { return SIMKA_ABI_VERSION; }
+
+SIMKA_EXPORT const char *simka_last_error(const simka_ctx *ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
+
+static int set_lds_attr(simka_ctx *ctx) {
+    const int big = 160 * 1024;
+    HIPCHK(hipFuncSetAttribute((const void *)k_scan<true>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
+    HIPCHK(hipFuncSetAttribute((const void *)k_scan<false>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
+    HIPCHK(hipFuncSetAttribute((const void *)k_layout, hipFuncAttributeMaxDynamicSharedMemorySize, big));
+    HIPCHK(hipFuncSetAttribute((const void *)k_split, hipFuncAttributeMaxDynamicSharedMemorySize, big));
+    HIPCHK(hipFuncSetAttribute((const void *)k_count, hipFuncAttributeMaxDynamicSharedMemorySize, big));
+    HIPCHK(hipFuncSetAttribute((const void *)k_group, hipFuncAttributeMaxDynamicSharedMemorySize, big));
+    HIPCHK(hipFuncSetAttribute((const void *)k_pairs, hipFuncAttributeMaxDynamicSharedMemorySize, big));
+    return SIMKA_OK;
+}
+
+// partition geometry from the largest sample's k-mer count (all samples must share it: the merge
+// joins partition p of every sample, as simkaMerge joins solid/part_p/ of every sample)
+static int setup_geometry(simka_ctx *ctx, uint64_t max_kmers) {
+    const simka_config &c = ctx->cfg;
+    SimkaKeyCfg &k = ctx->key;
+    uint32_t pb = c.log2_partitions;
+    if (pb == 0) {
+        const uint64_t per_shard = std::max<uint64_t>(1, max_kmers / std::max(1u, c.shard_count));
+        pb = ceil_log2_u64((per_shard + SIMKA_TARGET_PER_PART - 1) / SIMKA_TARGET_PER_PART);
+        pb += ceil_log2_u64(c.shard_count);
+    }
+    if (pb > 20) pb = 20;
+    if (pb > k.W) pb = k.W;
+    uint32_t l1 = (pb + 1) / 2;
+    const uint32_t min_l1 = std::min<uint32_t>(pb, ceil_log2_u64(c.shard_count));   // shards are level-1 buckets
+    if (l1 < min_l1) l1 = min_l1;
+    if (l1 > 10) l1 = 10;
+    uint32_t l2 = pb - l1;
+    if (l2 > 10) { l2 = 10; }
+    k.l1 = l1; k.l2 = l2; k.pb = l1 + l2; k.t = 0;
+    ctx->B1 = 1u << l1; ctx->B2 = 1u << l2; ctx->nparts = (uint64_t)1 << k.pb;
+
+    const uint32_t N = c.nb_samples;
+    HIPCHK(dev_alloc(&ctx->d_b1_count, ctx->B1 + 1));
+    HIPCHK(dev_alloc(&ctx->d_b1_start, ctx->B1 + 1));
+    HIPCHK(dev_alloc(&ctx->d_b1_cursor, ctx->B1 + 1));
+    HIPCHK(dev_alloc(&ctx->d_chunk_first, ctx->B1 + 1));
+    HIPCHK(dev_alloc(&ctx->d_foff, (uint64_t)N * ctx->nparts));
+    HIPCHK(dev_alloc(&ctx->d_fcnt, (uint64_t)N * ctx->nparts));
+    HIPCHK(hipMemsetAsync(ctx->d_foff, 0, (uint64_t)N * ctx->nparts * 4, ctx->stream));
+    HIPCHK(hipMemsetAsync(ctx->d_fcnt, 0, (uint64_t)N * ctx->nparts * 4, ctx->stream));
+    HIPCHK(dev_alloc(&ctx->d_part_total, ctx->nparts + 1));
+    HIPCHK(dev_alloc(&ctx->d_part_off, ctx->nparts + 1));
+
+    // solid arena: explicit, or a share of what is free now
+    uint64_t cap = c.solid_capacity;
+    if (cap == 0) {
+        size_t fr = 0, tot = 0;
+        HIPCHK(hipMemGetInfo(&fr, &tot));
+        const uint64_t want = (uint64_t)N * std::max<uint64_t>(max_kmers, 1);   // worst case: every occurrence distinct & solid
+        const uint64_t budget = (uint64_t)(fr * 0.45) / 12;
+        cap = std::min(want, budget);
+    }
+    ctx->arena_cap = cap;
+    HIPCHK(dev_alloc(&ctx->d_solid_keys, cap));
+    HIPCHK(dev_alloc(&ctx->d_solid_counts, cap));
+    ctx->geometry_ready = true;
+    return SIMKA_OK;
+}
+
+SIMKA_EXPORT int simka_create(const simka_config *cfg, simka_ctx **out) {
+    if (!cfg || !out) { g_create_error = "simka_create: null argument"; return SIMKA_ERR_INVALID; }
+    if (cfg->struct_size != sizeof(simka_config)) { g_create_error = "simka_create: struct_size mismatch (ABI)"; return SIMKA_ERR_INVALID; }
+    if (cfg->nb_samples == 0 || cfg->nb_samples > 65535) { g_create_error = "simka_create: nb_samples must be in [1,65535]"; return SIMKA_ERR_INVALID; }
+    if (cfg->kmer_size < 1 || cfg->kmer_size > 31) { g_create_error = "simka_create: kmer_size must be in [1,31] on the device path"; return SIMKA_ERR_INVALID; }
+    if (cfg->shard_count == 0 || cfg->shard_index >= cfg->shard_count) { g_create_error = "simka_create: bad shard_index/shard_count"; return SIMKA_ERR_INVALID; }
+    if (cfg->dist_flags & SIMKA_DIST_COMPLEX) { g_create_error = "simka_create: -complex-dist is not available on the device path yet"; return SIMKA_ERR_UNSUPPORTED; }
+    if (cfg->log2_subranges > 8) { g_create_error = "simka_create: log2_subranges must be <= 8"; return SIMKA_ERR_INVALID; }
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
+        g_create_error = "simka_create: no HIP device available (the HIP path has no CPU fallback)";
+        return SIMKA_ERR_HIP;
+    }
+    if (cfg->device < 0 || cfg->device >= ndev) { g_create_error = "simka_create: bad device ordinal"; return SIMKA_ERR_INVALID; }
+    simka_ctx *ctx = new simka_ctx();
+    ctx->cfg = *cfg;
+    if (ctx->cfg.abundance_max > 999999999u) ctx->cfg.abundance_max = 999999999u;   // ref: src/core/SimkaAlgorithm.cpp:188
+    auto bail = [&](int rc) { g_create_error = ctx->err; simka_destroy(ctx); return rc; };
+    if (hipSetDevice(cfg->device) != hipSuccess) { ctx->err = "hipSetDevice failed"; return bail(SIMKA_ERR_HIP); }
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, cfg->device) == hipSuccess) ctx->num_cus = prop.multiProcessorCount;
+    if (cfg->stream) ctx->stream = (hipStream_t)cfg->stream;
+    else { if (hipStreamCreate(&ctx->stream) != hipSuccess) { ctx->err = "hipStreamCreate failed"; return bail(SIMKA_ERR_HIP); } ctx->own_stream = true; }
+
+    SimkaKeyCfg &k = ctx->key;
+    memset(&k, 0, sizeof k);
+    k.k = cfg->kmer_size; k.W = 2 * cfg->kmer_size; k.mask = (1ull << k.W) - 1ull; k.xs = (k.W + 1) / 2;
+    k.shard_index = cfg->shard_index; k.shard_count = cfg->shard_count;
+
+    int rc = set_lds_attr(ctx);
+    if (rc) return bail(rc);
+    const uint32_t N = cfg->nb_samples;
+    ctx->stats_n = simka_stats_nb_u64(N, cfg->dist_flags);
+    auto chk = [&](hipError_t e, const char *what) { if (e != hipSuccess) { ctx->err = std::string(what) + ": " + hipGetErrorString(e); return false; } return true; };
+    if (!chk(dev_alloc(&ctx->d_stats, ctx->stats_n), "hipMalloc(stats)")) return bail(SIMKA_ERR_NOMEM);
+    if (!chk(hipMemsetAsync(ctx->d_stats, 0, ctx->stats_n * 8, ctx->stream), "memset(stats)")) return bail(SIMKA_ERR_HIP);
+    if (!chk(dev_alloc(&ctx->d_err, 4), "hipMalloc(err)")) return bail(SIMKA_ERR_NOMEM);
+    if (!chk(hipMemsetAsync(ctx->d_err, 0, 16, ctx->stream), "memset(err)")) return bail(SIMKA_ERR_HIP);
+    if (!chk(dev_alloc(&ctx->d_arena_cursor, 2), "hipMalloc(cursor)")) return bail(SIMKA_ERR_NOMEM);
+    if (!chk(hipMemsetAsync(ctx->d_arena_cursor, 0, 16, ctx->stream), "memset(cursor)")) return bail(SIMKA_ERR_HIP);
+    if (!chk(dev_alloc(&ctx->d_sample_base, N + 1), "hipMalloc(sample_base)")) return bail(SIMKA_ERR_NOMEM);
+    if (!chk(dev_alloc(&ctx->d_cursors, 4), "hipMalloc(cursors)")) return bail(SIMKA_ERR_NOMEM);
+    ctx->counted.assign(N, 0);
+    ctx->nb_reads.assign(N, 0);
+    if (cfg->max_kmers_per_sample) { rc = setup_geometry(ctx, cfg->max_kmers_per_sample); if (rc) return bail(rc); }
+    *out = ctx;
+    return SIMKA_OK;
+}
+
+SIMKA_EXPORT void simka_destroy(simka_ctx *ctx) {
+    if (!ctx) return;
+    if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+    for (auto &ev : ctx->events) { (void)hipEventDestroy(ev.a); (void)hipEventDestroy(ev.b); }
+    void *ptrs[] = { ctx->d_reads, ctx->d_offsets, ctx->d_l1, ctx->d_b1_count, ctx->d_b1_start, ctx->d_b1_cursor,
+                     ctx->d_chunk_first, ctx->d_chunk_off, ctx->d_solid_keys, ctx->d_solid_counts, ctx->d_arena_cursor,
+                     ctx->d_sample_base, ctx->d_foff, ctx->d_fcnt, ctx->d_stats, ctx->d_err, ctx->d_part_total,
+                     ctx->d_part_off, ctx->d_mkeys, ctx->d_mvals, ctx->d_entries, ctx->d_groups, ctx->d_fb_off,
+                     ctx->d_spans, ctx->d_cursors, ctx->d_slabs };
+    for (void *p : ptrs) if (p) (void)hipFree(p);
+    if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+}
+
+SIMKA_EXPORT int simka_sync(simka_ctx *ctx) {
+    if (!ctx) return SIMKA_ERR_INVALID;
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    return SIMKA_OK;
+}
+
+static int check_device_error(simka_ctx *ctx) {
+    uint32_t e = 0;
+    HIPCHK(hipMemcpyAsync(&e, ctx->d_err, 4, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    if (e & SIMKA_DEVERR_TABLE_OVERFLOW) return ctx->fail(SIMKA_ERR_OVERFLOW, "a partition holds more distinct k-mers than its LDS table (%d slots): raise log2_partitions / max_kmers_per_sample", K2_TABLE);
+    if (e & SIMKA_DEVERR_ARENA_FULL) return ctx->fail(SIMKA_ERR_NOMEM, "solid-spectrum arena exhausted (%llu records): raise solid_capacity", (unsigned long long)ctx->arena_cap);
+    if (e & SIMKA_DEVERR_SAMPLE_TOO_BIG) return ctx->fail(SIMKA_ERR_OVERFLOW, "a sample holds more than 2^32 solid k-mers");
+    if (e & SIMKA_DEVERR_GROUP_OVERFLOW) return ctx->fail(SIMKA_ERR_OVERFLOW, "merge: a sub-range could not be split below the LDS capacity");
+    if (e & SIMKA_DEVERR_CSR_FULL) return ctx->fail(SIMKA_ERR_NOMEM, "merge: group buffer exhausted");
+    return SIMKA_OK;
+}
+
+template <typename T>
+static int ensure_cap(simka_ctx *ctx, T **p, uint64_t *cap, uint64_t need) {
+    if (*cap >= need && *p) return SIMKA_OK;
+    if (*p) { HIPCHK(hipStreamSynchronize(ctx->stream)); HIPCHK(hipFree(*p)); *p = nullptr; *cap = 0; }
+    const uint64_t n = need + need / 8 + 16;
+    hipError_t e = dev_alloc(p, n);
+    if (e != hipSuccess) return ctx->fail(SIMKA_ERR_NOMEM, "hipMalloc of %llu bytes failed: %s", (unsigned long long)(n * sizeof(T)), hipGetErrorString(e));
+    *cap = n;
+    return SIMKA_OK;
+}
+
+// ---- count side ---------------------------------------------------------------------------
+SIMKA_EXPORT int simka_count_sample(simka_ctx *ctx, uint32_t sample, const simka_reads *r) {
+    if (!ctx || !r) return SIMKA_ERR_INVALID;
+    const uint32_t N = ctx->cfg.nb_samples;
+    if (sample >= N) return ctx->fail(SIMKA_ERR_INVALID, "simka_count_sample: sample index %u out of range", sample);
+    if (ctx->counted[sample]) return ctx->fail(SIMKA_ERR_STATE, "simka_count_sample: sample %u was already counted", sample);
+    if (ctx->merged) return ctx->fail(SIMKA_ERR_STATE, "simka_count_sample: merge already ran");
+    if (r->nb_bases && !r->packed) return ctx->fail(SIMKA_ERR_INVALID, "simka_count_sample: packed is NULL");
+    if (!r->fixed_len && r->nb_bases && !r->offsets) return ctx->fail(SIMKA_ERR_INVALID, "simka_count_sample: offsets required when fixed_len==0");
+    if (r->fixed_len && r->nb_bases != r->nb_reads * (uint64_t)r->fixed_len) return ctx->fail(SIMKA_ERR_INVALID, "simka_count_sample: nb_bases != nb_reads*fixed_len");
+    HIPCHK(hipSetDevice(ctx->cfg.device));
+    int rc;
+    if (!ctx->geometry_ready) { rc = setup_geometry(ctx, std::max<uint64_t>(r->nb_bases, 1)); if (rc) return rc; }
+    ctx->nb_reads[sample] = r->nb_input_reads ? r->nb_input_reads : r->nb_reads;
+    ctx->counted[sample] = 1;
+    if (r->nb_bases == 0) {   // empty sample: tables stay zero, sample_base = cursor
+        HIPCHK(hipMemcpyAsync(ctx->d_sample_base + sample, ctx->d_arena_cursor, 8, hipMemcpyDeviceToDevice, ctx->stream));
+        return SIMKA_OK;
+    }
+    const uint64_t nb_words = (r->nb_bases + 31) / 32;
+    SimkaScanArgs a;
+    a.nb_bases = r->nb_bases; a.nb_words = nb_words; a.nb_reads = r->nb_reads; a.fixed_len = r->fixed_len;
+    if (r->on_device) { a.packed = r->packed; a.offsets = r->offsets; }
+    else {
+        rc = ensure_cap(ctx, &ctx->d_reads, &ctx->reads_cap, nb_words + 2); if (rc) return rc;
+        HIPCHK(hipMemcpyAsync(ctx->d_reads, r->packed, nb_words * 8, hipMemcpyHostToDevice, ctx->stream));
+        a.packed = ctx->d_reads; a.offsets = nullptr;
+        if (!r->fixed_len) {
+            rc = ensure_cap(ctx, &ctx->d_offsets, &ctx->offsets_cap, r->nb_reads + 1); if (rc) return rc;
+            HIPCHK(hipMemcpyAsync(ctx->d_offsets, r->offsets, (r->nb_reads + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
+            a.offsets = ctx->d_offsets;
+        }
+        HIPCHK(hipStreamSynchronize(ctx->stream));   // the host buffers may be reused by the caller right away
+    }
+    const SimkaKeyCfg key = ctx->key;
+    const uint32_t B1 = ctx->B1, B2 = ctx->B2;
+    rc = ensure_cap(ctx, &ctx->d_l1, &ctx->l1_cap, r->nb_bases); if (rc) return rc;
+    const uint64_t max_chunks = r->nb_bases / K2_CHUNK + B1 + 1;
+    if (key.l2) { rc = ensure_cap(ctx, &ctx->d_chunk_off, &ctx->chunk_cap, max_chunks * (B2 + 1)); if (rc) return rc; }
+
+    ull *kocc = (ull *)ctx->d_stats + stats_off_tot(N, SIMKA_TOT_KOCC) + sample;
+    const uint64_t tile = (uint64_t)K1_BLOCK * K1_SEG;
+    const uint32_t grid1 = (uint32_t)((r->nb_bases + tile - 1) / tile);
+    const size_t lds_hist = SIMKA_LDS_HEAD + (size_t)B1 * 16 + K1_BLOCK * 4;
+    const size_t lds_scat = lds_hist + (size_t)tile * 8;
+
+    HIPCHK(hipMemsetAsync(ctx->d_b1_count, 0, (B1 + 1) * 8, ctx->stream));
+    launch_timed(ctx, KID_SCAN_HIST, [&] {
+        hipLaunchKernelGGL((k_scan<false>), dim3(grid1), dim3(K1_BLOCK), lds_hist, ctx->stream, a, key, ctx->d_b1_count,
+                           ctx->d_b1_cursor, ctx->d_l1, kocc);
+    });
+    launch_timed(ctx, KID_LAYOUT, [&] {
+        hipLaunchKernelGGL(k_layout, dim3(1), dim3(256), SIMKA_LDS_HEAD + (size_t)B1 * 8, ctx->stream, ctx->d_b1_count,
+                           ctx->d_b1_start, ctx->d_b1_cursor, ctx->d_chunk_first, B1, ctx->d_arena_cursor,
+                           ctx->d_sample_base + sample);
+    });
+    launch_timed(ctx, KID_SCAN_SCATTER, [&] {
+        hipLaunchKernelGGL((k_scan<true>), dim3(grid1), dim3(K1_BLOCK), lds_scat, ctx->stream, a, key, ctx->d_b1_count,
+                           ctx->d_b1_cursor, ctx->d_l1, kocc);
+    });
+    if (key.l2) {
+        const size_t lds_split = SIMKA_LDS_HEAD + (size_t)B2 * 4 + K2_BLOCK * 4 + (size_t)K2_CHUNK * 8;
+        launch_timed(ctx, KID_SPLIT, [&] {
+            hipLaunchKernelGGL(k_split, dim3((uint32_t)max_chunks), dim3(K2_BLOCK), lds_split, ctx->stream, ctx->d_l1,
+                               ctx->d_b1_start, ctx->d_chunk_first, ctx->d_chunk_off, key);
+        });
+    }
+    SimkaCountOut o;
+    o.arena_cursor = ctx->d_arena_cursor; o.sample_base = ctx->d_sample_base + sample; o.arena_cap = ctx->arena_cap;
+    o.solid_keys = ctx->d_solid_keys; o.solid_counts = ctx->d_solid_counts;
+    o.foff = ctx->d_foff + (uint64_t)sample * ctx->nparts; o.fcnt = ctx->d_fcnt + (uint64_t)sample * ctx->nparts;
+    o.totals = (ull *)ctx->d_stats + stats_off_tot(N, 0); o.sample = sample; o.nb_samples = N; o.err = ctx->d_err;
+    // lanes per chunk segment ~ expected segment length (chunk / #level-2 buckets)
+    uint32_t gs_log2 = key.l2 ? ceil_log2_u64(std::max<uint32_t>(1, K2_CHUNK >> key.l2)) : 9;
+    gs_log2 = std::min<uint32_t>(std::max<uint32_t>(gs_log2, 2), 9);
+    const size_t lds_count = SIMKA_LDS_HEAD + (size_t)K2_TABLE * 12;
+    launch_timed(ctx, KID_COUNT, [&] {
+        hipLaunchKernelGGL(k_count, dim3((uint32_t)ctx->nparts), dim3(K2_BLOCK), lds_count, ctx->stream, ctx->d_l1,
+                           ctx->d_b1_start, ctx->d_chunk_first, ctx->d_chunk_off, key, gs_log2, ctx->cfg.abundance_min,
+                           ctx->cfg.abundance_max, o);
+    });
+    HIPCHK(hipGetLastError());
+    return SIMKA_OK;
+}
+
+SIMKA_EXPORT int simka_get_sample_totals(simka_ctx *ctx, uint32_t sample, simka_sample_totals *out) {
+    if (!ctx || !out) return SIMKA_ERR_INVALID;
+    const uint32_t N = ctx->cfg.nb_samples;
+    if (sample >= N || !ctx->counted[sample]) return ctx->fail(SIMKA_ERR_STATE, "simka_get_sample_totals: sample %u not counted", sample);
+    int rc = check_device_error(ctx);
+    if (rc) return rc;
+    uint64_t t[SIMKA_NB_TOTALS];
+    for (int i = 0; i < SIMKA_NB_TOTALS; i++)
+        HIPCHK(hipMemcpyAsync(&t[i], ctx->d_stats + stats_off_tot(N, i) + sample, 8, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    out->nb_reads = ctx->nb_reads[sample];
+    out->nb_distinct = t[SIMKA_TOT_D]; out->nb_kmers = t[SIMKA_TOT_N]; out->sum_sq = t[SIMKA_TOT_Q];
+    out->kmer_occurrences = t[SIMKA_TOT_KOCC]; out->distinct_all = t[SIMKA_TOT_DALL];
+    return SIMKA_OK;
+}
+
+// ---- merge side ---------------------------------------------------------------------------
+SIMKA_EXPORT int simka_merge(simka_ctx *ctx) {
+    if (!ctx) return SIMKA_ERR_INVALID;
+    const uint32_t N = ctx->cfg.nb_samples;
+    for (uint32_t s = 0; s < N; s++) if (!ctx->counted[s]) return ctx->fail(SIMKA_ERR_STATE, "simka_merge: sample %u has not been counted", s);
+    if (ctx->merged) return ctx->fail(SIMKA_ERR_STATE, "simka_merge: already merged");
+    HIPCHK(hipSetDevice(ctx->cfg.device));
+    int rc = check_device_error(ctx);
+    if (rc) return rc;
+    ctx->merged = true;
+    if (!ctx->geometry_ready || N < 2) return SIMKA_OK;   // nothing to pair up
+    const uint64_t nparts = ctx->nparts;
+
+    // records per partition over all samples -> host scan (also drives the batching)
+    launch_timed(ctx, KID_PART_TOTALS, [&] {
+        hipLaunchKernelGGL(k_part_totals, dim3((uint32_t)((nparts + 255) / 256)), dim3(256), 0, ctx->stream, ctx->d_fcnt, N,
+                           nparts, ctx->d_part_total);
+    });
+    std::vector<ull> ptot(nparts), poff(nparts + 1);
+    HIPCHK(hipMemcpyAsync(ptot.data(), ctx->d_part_total, nparts * 8, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    ull total = 0, maxpart = 0, nonempty = 0;
+    for (uint64_t p = 0; p < nparts; p++) { poff[p] = total; total += ptot[p]; maxpart = std::max(maxpart, ptot[p]); nonempty += ptot[p] ? 1 : 0; }
+    poff[nparts] = total;
+    if (total == 0) return SIMKA_OK;
+    HIPCHK(hipMemcpyAsync(ctx->d_part_off, poff.data(), (nparts + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
+
+    // sub-range bits: ~K3_CAP/2 records per k_group block
+    SimkaKeyCfg key = ctx->key;
+    uint32_t t = ctx->cfg.log2_subranges;
+    if (t == 0) t = ceil_log2_u64((total / std::max<ull>(nonempty, 1) + K3_CAP / 2 - 1) / (K3_CAP / 2));
+    t = std::min<uint32_t>(t, 8);
+    t = std::min<uint32_t>(t, key.W - key.pb);
+    key.t = t; ctx->key.t = t;
+    const uint32_t nsub = 1u << t;
+
+    // bounded merge buffers, processed in batches of consecutive partitions
+    uint64_t cap = ctx->cfg.csr_capacity ? ctx->cfg.csr_capacity : std::min<uint64_t>(total, (uint64_t)1 << 27);
+    cap = std::max<uint64_t>(cap, maxpart);
+    if (cap >= ((uint64_t)1 << 32)) cap = ((uint64_t)1 << 32) - 1;
+    if (maxpart > cap) return ctx->fail(SIMKA_ERR_NOMEM, "simka_merge: one partition holds %llu records, more than the merge buffer", maxpart);
+    const uint64_t max_parts_batch = std::min<uint64_t>(nparts, (uint64_t)1 << 16);
+    const uint64_t fb_cap = max_parts_batch * nsub;
+    const uint64_t span_cap = fb_cap * 2 + 4096;
+    if (ctx->merge_cap < cap) {
+        void *old[] = { ctx->d_mkeys, ctx->d_mvals, ctx->d_entries, ctx->d_groups };
+        for (void *p : old) if (p) HIPCHK(hipFree(p));
+        ctx->d_mkeys = ctx->d_mvals = ctx->d_entries = nullptr; ctx->d_groups = nullptr;
+        if (dev_alloc(&ctx->d_mkeys, cap) != hipSuccess || dev_alloc(&ctx->d_mvals, cap) != hipSuccess ||
+            dev_alloc(&ctx->d_entries, cap) != hipSuccess || dev_alloc(&ctx->d_groups, cap) != hipSuccess)
+            return ctx->fail(SIMKA_ERR_NOMEM, "simka_merge: cannot allocate merge buffers for %llu records", (unsigned long long)cap);
+        ctx->merge_cap = cap;
+    }
+    if (ctx->fb_cap < fb_cap) { if (ctx->d_fb_off) HIPCHK(hipFree(ctx->d_fb_off)); ctx->d_fb_off = nullptr; HIPCHK(dev_alloc(&ctx->d_fb_off, fb_cap + 1)); ctx->fb_cap = fb_cap; }
+    if (ctx->span_cap < span_cap) { if (ctx->d_spans) HIPCHK(hipFree(ctx->d_spans)); ctx->d_spans = nullptr; HIPCHK(dev_alloc(&ctx->d_spans, span_cap)); ctx->span_cap = span_cap; }
+
+    // pair-accumulator tiling: all N(N-1)/2 cells in LDS when they fit, else T x T sample tiles
+    SimkaPairCfg pc;
+    pc.nb_samples = N; pc.nacc = stats_nacc(ctx->cfg.dist_flags); pc.nb_pairs = (uint64_t)N * (N - 1) / 2;
+    const size_t lds_fixed = SIMKA_LDS_HEAD + (size_t)K3_CAP * 8 + (size_t)K3_CAP * 4 + (size_t)(K3_CAP + 1) * 4 + K4_BLOCK * 4 + 64;
+    const size_t lds_budget = 160 * 1024 - lds_fixed;
+    const uint64_t max_cells = lds_budget / (4 * pc.nacc);
+    if (pc.nb_pairs <= max_cells) { pc.tile = N; pc.ntiles = 1; pc.ncell = (uint32_t)pc.nb_pairs; }
+    else {
+        uint32_t T = 1; while ((uint64_t)(T + 1) * (T + 1) <= max_cells) T++;
+        pc.tile = T; pc.ntiles = (N + T - 1) / T; pc.ncell = T * T;
+    }
+    pc.ncell_pad = (pc.ncell + 3u) & ~3u;
+    const uint32_t ntp = pc.ntiles * (pc.ntiles + 1) / 2;
+    const size_t lds_pairs = lds_fixed + (size_t)pc.nacc * pc.ncell_pad * 4;
+    const uint32_t per_cu = (uint32_t)std::min<size_t>(4, std::max<size_t>(1, (160 * 1024) / lds_pairs));
+    const uint32_t nblk = (uint32_t)ctx->num_cus * per_cu;
+    const uint64_t slab_words = (uint64_t)ntp * nblk * pc.nacc * pc.ncell_pad;
+    if (ctx->slab_words < slab_words) { if (ctx->d_slabs) HIPCHK(hipFree(ctx->d_slabs)); ctx->d_slabs = nullptr; HIPCHK(dev_alloc(&ctx->d_slabs, slab_words)); ctx->slab_words = slab_words; }
+    HIPCHK(hipMemsetAsync(ctx->d_slabs, 0, slab_words * 8, ctx->stream));
+
+    SimkaMergeIn in;
+    in.solid_keys = ctx->d_solid_keys; in.solid_counts = ctx->d_solid_counts; in.sample_base = ctx->d_sample_base;
+    in.foff = ctx->d_foff; in.fcnt = ctx->d_fcnt; in.nb_samples = N; in.nparts = nparts;
+    SimkaCsrOut co;
+    co.entries = ctx->d_entries; co.groups = ctx->d_groups; co.spans = ctx->d_spans; co.cursors = ctx->d_cursors;
+    co.cap_entries = cap; co.cap_groups = cap; co.cap_spans = span_cap; co.glob = (ull *)ctx->d_stats; co.err = ctx->d_err;
+    const uint32_t min_share = 2;   // -complex-dist would need 1 (ref: src/SimkaMerge.cpp:1317)
+    const size_t lds_group = SIMKA_LDS_HEAD + (size_t)K3_TABLE * 8 + (size_t)K3_CAP * 8 + (size_t)K3_TABLE * 12 + K3_BLOCK * 4 + (size_t)K3_CAP * 2;
+    ull *acc = (ull *)ctx->d_stats + stats_off_acc(N, 0);
+
+    uint64_t pb = 0;
+    while (pb < nparts) {
+        uint64_t pe = pb; ull recs = 0;
+        while (pe < nparts && pe - pb < max_parts_batch && recs + ptot[pe] <= cap) { recs += ptot[pe]; pe++; }
+        if (pe == pb) return ctx->fail(SIMKA_ERR_NOMEM, "simka_merge: batching failed at partition %llu", (unsigned long long)pb);
+        if (recs) {
+            const uint32_t np = (uint32_t)(pe - pb);
+            const uint32_t nfb = np * nsub;
+            HIPCHK(hipMemsetAsync(ctx->d_cursors, 0, 32, ctx->stream));
+            launch_timed(ctx, KID_REGROUP, [&] {
+                hipLaunchKernelGGL(k_regroup, dim3(np), dim3(K3_BLOCK), 0, ctx->stream, in, key, pb, ctx->d_part_off, poff[pb],
+                                   ctx->d_fb_off, ctx->d_mkeys, ctx->d_mvals);
+            });
+            launch_timed(ctx, KID_GROUP, [&] {
+                hipLaunchKernelGGL(k_group, dim3(nfb), dim3(K3_BLOCK), lds_group, ctx->stream, ctx->d_mkeys, ctx->d_mvals,
+                                   ctx->d_fb_off, nfb, (uint32_t)recs, key, min_share, co);
+            });
+            launch_timed(ctx, KID_PAIRS, [&] {
+                hipLaunchKernelGGL(k_pairs, dim3(nblk, ntp), dim3(K4_BLOCK), lds_pairs, ctx->stream, ctx->d_spans, ctx->d_cursors,
+                                   ctx->d_entries, ctx->d_groups, pc, acc, ctx->d_slabs);
+            });
+        }
+        pb = pe;
+    }
+    launch_timed(ctx, KID_REDUCE, [&] {
+        hipLaunchKernelGGL(k_reduce_slabs, dim3((pc.nacc * pc.ncell_pad + 255) / 256, ntp), dim3(256), 0, ctx->stream,
+                           ctx->d_slabs, nblk, pc, acc);
+    });
+    HIPCHK(hipGetLastError());
+    return check_device_error(ctx);
+}
+
+// ---- statistics ---------------------------------------------------------------------------
+SIMKA_EXPORT int simka_stats_device_buffer(simka_ctx *ctx, void **p, uint64_t *n) {
+    if (!ctx || !p || !n) return SIMKA_ERR_INVALID;
+    *p = ctx->d_stats; *n = ctx->stats_n;
+    return SIMKA_OK;
+}
+
+SIMKA_EXPORT int simka_stats_download(simka_ctx *ctx, uint64_t *h, uint64_t n, simka_stats_view *view) {
+    if (!ctx || !h) return SIMKA_ERR_INVALID;
+    if (n < ctx->stats_n) return ctx->fail(SIMKA_ERR_INVALID, "simka_stats_download: buffer too small (%llu < %llu)", (unsigned long long)n, (unsigned long long)ctx->stats_n);
+    HIPCHK(hipMemcpyAsync(h, ctx->d_stats, ctx->stats_n * 8, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    if (view) return simka_stats_describe(ctx->cfg.nb_samples, ctx->cfg.dist_flags, h, n, view);
+    return SIMKA_OK;
+}
+
+// ---- profiling / introspection ------------------------------------------------------------
+SIMKA_EXPORT int simka_profile_enable(simka_ctx *ctx, int on) { if (!ctx) return SIMKA_ERR_INVALID; ctx->profiling = on != 0; return SIMKA_OK; }
+SIMKA_EXPORT int simka_profile_reset(simka_ctx *ctx) {
+    if (!ctx) return SIMKA_ERR_INVALID;
+    profile_collect(ctx);
+    for (int i = 0; i < KID_NB; i++) { ctx->prof_ms[i] = 0; ctx->prof_n[i] = 0; }
+    return SIMKA_OK;
+}
+SIMKA_EXPORT int simka_profile_nb_kernels(simka_ctx *) { return KID_NB; }
+SIMKA_EXPORT int simka_profile_get(simka_ctx *ctx, int which, const char **name, uint64_t *n, double *ms) {
+    if (!ctx || which < 0 || which >= KID_NB) return SIMKA_ERR_INVALID;
+    profile_collect(ctx);
+    if (name) *name = KID_NAMES[which];
+    if (n) *n = ctx->prof_n[which];
+    if (ms) *ms = ctx->prof_ms[which];
+    return SIMKA_OK;
+}
+SIMKA_EXPORT int simka_get_geometry(simka_ctx *ctx, uint32_t *l1, uint32_t *l2, uint32_t *t, uint64_t *arena, uint64_t *csr) {
+    if (!ctx) return SIMKA_ERR_INVALID;
+    if (l1) *l1 = ctx->key.l1; if (l2) *l2 = ctx->key.l2; if (t) *t = ctx->key.t;
+    if (arena) *arena = ctx->arena_cap; if (csr) *csr = ctx->merge_cap;
+    return SIMKA_OK;
+}
+
+// ---- synthetic reads ----------------------------------------------------------------------
+SIMKA_EXPORT int simka_synth_genomes(void *stream, uint64_t *d_pool, uint32_t nb_genomes, uint64_t genome_words, uint64_t seed) {
+    const uint64_t n = (uint64_t)nb_genomes * genome_words;
+    if (!d_pool || n == 0) return SIMKA_ERR_INVALID;
+    hipLaunchKernelGGL(k_synth_genomes, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, d_pool, nb_genomes,
+                       genome_words, seed);
+    return hipGetLastError() == hipSuccess ? SIMKA_OK : SIMKA_ERR_HIP;
+}
+SIMKA_EXPORT int simka_synth_reads(void *stream, uint64_t *d_packed, uint64_t nb_reads, uint32_t read_len, const uint64_t *d_pool,
+                                   uint64_t genome_words, uint64_t genome_len, const uint32_t *d_ids, const uint32_t *d_cdf,
+                                   uint32_t nb_sel, uint64_t seed, uint32_t err_thr) {
+    if (!d_packed || !d_pool || !d_ids || !d_cdf || nb_sel == 0 || read_len == 0 || genome_len < read_len) return SIMKA_ERR_INVALID;
+    const uint64_t nw = (nb_reads * (uint64_t)read_len + 31) / 32;
+    if (nw == 0) return SIMKA_OK;
+    hipLaunchKernelGGL(k_synth_reads, dim3((uint32_t)((nw + 255) / 256)), dim3(256), 0, (hipStream_t)stream, d_packed, nb_reads,
+                       read_len, d_pool, genome_words, genome_len, d_ids, d_cdf, nb_sel, seed, err_thr);
+    return hipGetLastError() == hipSuccess ? SIMKA_OK : SIMKA_ERR_HIP;
+}

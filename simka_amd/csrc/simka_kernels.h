@@ -1,0 +1,97 @@
+// simka_kernels.h -- launch geometry and argument blocks shared by the kernels and the host driver.
+#pragma once
+#include <stdint.h>
+#include "simka_device.h"
+
+// scalars of every dynamic-LDS kernel live in the first SIMKA_LDS_HEAD bytes of the region
+#define SIMKA_LDS_HEAD 512
+
+// K1  k_scan
+#define K1_BLOCK 512          // 8 waves
+#define K1_SEG 16             // k-mer start positions per thread (window = SEG + k - 1 <= 64 bases)
+// K2  k_split / k_count
+#define K2_BLOCK 512
+#define K2_CHUNK 8192         // keys per chunk (fits u16 offsets, 64 KB LDS stage)
+#define K2_TABLE 8192         // LDS hash-table slots per partition (64 KB keys + 32 KB counts)
+#define SIMKA_TARGET_PER_PART 4096   // sizing: k-mer occurrences per partition (<= 50% table load even if all distinct)
+// K3  k_regroup / k_group
+#define K3_BLOCK 256
+#define K3_CAP 2048           // records hashed per round
+#define K3_TABLE 4096         // = 2*K3_CAP slots
+// K4  k_pairs
+#define K4_BLOCK 512
+
+// per-sample totals row (device), additive over shards
+#define SIMKA_NB_TOTALS 5
+#define SIMKA_TOT_D 0
+#define SIMKA_TOT_N 1
+#define SIMKA_TOT_Q 2
+#define SIMKA_TOT_DALL 3
+#define SIMKA_TOT_KOCC 4
+
+// pair accumulators, order in the flat statistics buffer
+#define SIMKA_ACC_SIJ 0
+#define SIMKA_ACC_SJI 1
+#define SIMKA_ACC_A 2
+#define SIMKA_ACC_BC 3
+#define SIMKA_ACC_CHORD 4
+#define SIMKA_ACC_HELL 5
+
+// device error word bits
+#define SIMKA_DEVERR_TABLE_OVERFLOW 1u
+#define SIMKA_DEVERR_ARENA_FULL 2u
+#define SIMKA_DEVERR_SAMPLE_TOO_BIG 4u
+#define SIMKA_DEVERR_GROUP_OVERFLOW 8u
+#define SIMKA_DEVERR_CSR_FULL 16u
+
+struct SimkaScanArgs {
+    const uint64_t *packed;
+    uint64_t nb_bases, nb_words;
+    const uint64_t *offsets;
+    uint64_t nb_reads;
+    uint32_t fixed_len;
+};
+
+struct SimkaCountOut {
+    unsigned long long *arena_cursor;
+    const unsigned long long *sample_base;   // &sample_base[sample]
+    unsigned long long arena_cap;
+    unsigned long long *solid_keys;
+    uint32_t *solid_counts;
+    uint32_t *foff, *fcnt;                   // this sample's rows [nparts]
+    unsigned long long *totals;              // [SIMKA_NB_TOTALS][N]
+    uint32_t sample, nb_samples;
+    uint32_t *err;
+};
+
+struct SimkaMergeIn {
+    const unsigned long long *solid_keys;
+    const uint32_t *solid_counts;
+    const unsigned long long *sample_base;   // [N]
+    const uint32_t *foff, *fcnt;             // [N][nparts]
+    uint32_t nb_samples;
+    uint64_t nparts;
+};
+
+struct SimkaSpan {
+    unsigned long long ebase, gbase;
+    uint32_t nent, ngrp;
+};
+
+struct SimkaCsrOut {
+    unsigned long long *entries;             // (sample<<32 | count)
+    uint32_t *groups;                        // (entry offset within span << 16 | size)
+    SimkaSpan *spans;
+    unsigned long long *cursors;             // [0] entries, [1] groups, [2] spans
+    unsigned long long cap_entries, cap_groups, cap_spans;
+    unsigned long long *glob;                // [0] nb distinct k-mers, [1] nb shared k-mers
+    uint32_t *err;
+};
+
+struct SimkaPairCfg {
+    uint32_t nb_samples;
+    uint32_t tile, ntiles;       // sample tile edge, #tiles
+    uint32_t nacc;               // 4 (default) or 6 (simple)
+    uint32_t ncell, ncell_pad;   // LDS cells per accumulator
+    uint64_t nb_pairs;           // N(N-1)/2
+};

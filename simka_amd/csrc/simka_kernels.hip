@@ -1,0 +1,742 @@
+// simka_kernels.hip -- hand-written gfx950 (CDNA4, wave64) kernels of the Simka hot path.
+//
+// Data flow per sample (count side, replaces gatb SortingCountAlgorithm + the
+// SimkaCompressedProcessor plugin, ref: src/SimkaCount.cpp:291-297, src/minikc/MiniKC.hpp:54-79):
+//
+//   packed reads --k_scan<false>--> level-1 histogram --k_layout--> bucket offsets
+//                --k_scan<true>---> level-1 buckets of keys (LDS-staged multisplit, coalesced runs)
+//                --k_split--------> every 8192-key chunk partitioned IN PLACE by level-2 bits
+//                --k_count--------> per partition: LDS hash table (CAS insert) -> abundance filter
+//                                   -> solid (key,count) records in the HBM arena + D/N/Q totals
+//
+// Merge side over all samples (replaces SimkaMergeAlgorithm::execute's heap merge and
+// SimkaCountProcessorSimple::updateDistance*, ref: src/SimkaMerge.cpp:1164-1326,
+// src/core/SimkaAlgorithm.hpp:341-402):
+//
+//   k_regroup : gather one partition's records from the N samples, order them by sub-range
+//   k_group   : per sub-range LDS hash grouping -> CSR groups (k-mer -> [(sample,count)...])
+//   k_pairs   : persistent blocks, LDS-privatised pair accumulators, all s(s-1)/2 pairs per group
+//   k_reduce_slabs : per-block partial accumulators -> the flat u64 statistics buffer
+//
+// Everything is integer work on HBM / LDS; no MFMA.  Block sizes are multiples of the 64-lane
+// wavefront; every global access pattern that carries real traffic is a contiguous run.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "simka_device.h"
+#include "simka_kernels.h"
+
+typedef unsigned long long ull;
+
+// --------------------------------------------------------------------------------------------
+// block-wide exclusive scan of a u32 array living in LDS (n items, in place); returns the total.
+// Caller must have synchronised after the last write to a[].  tmp has BLOCK entries.
+// --------------------------------------------------------------------------------------------
+template <int BLOCK>
+__device__ __forceinline__ uint32_t block_excl_scan(uint32_t *a, uint32_t n, uint32_t *tmp) {
+    const uint32_t tid = threadIdx.x;
+    const uint32_t ipt = (n + BLOCK - 1) / BLOCK;
+    const uint32_t b = tid * ipt;
+    const uint32_t e = (b + ipt < n) ? b + ipt : n;
+    uint32_t s = 0;
+    for (uint32_t i = b; i < e; i++) s += a[i];
+    tmp[tid] = s;
+    __syncthreads();
+    for (uint32_t off = 1; off < BLOCK; off <<= 1) {
+        uint32_t v = (tid >= off) ? tmp[tid - off] : 0u;
+        __syncthreads();
+        tmp[tid] += v;
+        __syncthreads();
+    }
+    const uint32_t total = tmp[BLOCK - 1];
+    uint32_t run = tmp[tid] - s;
+    for (uint32_t i = b; i < e; i++) { uint32_t v = a[i]; a[i] = run; run += v; }
+    __syncthreads();
+    return total;
+}
+
+// --------------------------------------------------------------------------------------------
+// K1  k_scan: packed reads -> canonical k-mer keys -> level-1 histogram / level-1 buckets
+// One thread owns K1_SEG consecutive k-mer START positions of the concatenated base array and
+// rolls forward/reverse-complement words over its 64-base register window.
+// --------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t window_base(uint64_t A, uint64_t B, uint32_t i) {
+    const uint64_t w = (i < 32u) ? A : B;
+    return (uint32_t)(w >> ((i & 31u) * 2u)) & 3u;
+}
+
+template <bool SCATTER>
+__global__ void __launch_bounds__(K1_BLOCK)
+k_scan(SimkaScanArgs a, SimkaKeyCfg cfg, ull *b1_count, ull *b1_cursor, uint64_t *l1_keys, ull *kocc) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const uint32_t B1 = 1u << cfg.l1;
+    // all LDS lives in the dynamic region (16-B aligned base, guide G17); head = scalars
+    uint32_t &s_nvalid = *(uint32_t *)smem;
+    uint32_t *hist = (uint32_t *)(smem + SIMKA_LDS_HEAD);   // [B1]
+    uint32_t *loff = hist + B1;                        // [B1]
+    uint32_t *tmp = loff + B1;                         // [K1_BLOCK]
+    ull *gbase = (ull *)(tmp + K1_BLOCK);              // [B1]
+    uint64_t *stage = (uint64_t *)(gbase + B1);        // [K1_BLOCK*K1_SEG]   (SCATTER only)
+
+    const uint32_t tid = threadIdx.x;
+    for (uint32_t i = tid; i < B1; i += K1_BLOCK) hist[i] = 0;
+    if (tid == 0) s_nvalid = 0;
+    __syncthreads();
+
+    const uint64_t w0 = ((uint64_t)blockIdx.x * K1_BLOCK + tid) * K1_SEG;
+    uint64_t keys[K1_SEG];
+    uint32_t ranks[K1_SEG];
+    uint32_t nvalid = 0;
+#pragma unroll
+    for (int q = 0; q < K1_SEG; q++) { keys[q] = SIMKA_EMPTY_KEY; ranks[q] = 0; }
+
+    if (w0 < a.nb_bases) {
+        const uint64_t wi = w0 >> 5;
+        const uint32_t sh = (uint32_t)(w0 & 31u) * 2u;
+        const uint64_t lastw = a.nb_words - 1;
+        const uint64_t W0 = a.packed[wi < lastw ? wi : lastw];
+        const uint64_t W1 = a.packed[wi + 1 < lastw ? wi + 1 : lastw];
+        const uint64_t W2 = a.packed[wi + 2 < lastw ? wi + 2 : lastw];
+        const uint64_t A = sh ? ((W0 >> sh) | (W1 << (64u - sh))) : W0;
+        const uint64_t B = sh ? ((W1 >> sh) | (W2 << (64u - sh))) : W1;
+
+        // the read (fragment) that contains base w0, and where the next one starts
+        uint64_t rd, next;
+        if (a.fixed_len) {
+            rd = w0 / a.fixed_len;
+            next = (rd + 1) * (uint64_t)a.fixed_len;
+        } else {
+            uint64_t lo = 0, hi = a.nb_reads;
+            while (hi - lo > 1) {
+                const uint64_t mid = (lo + hi) >> 1;
+                if (a.offsets[mid] <= w0) lo = mid; else hi = mid;
+            }
+            rd = lo;
+            next = a.offsets[rd + 1];
+        }
+
+        const uint32_t k = cfg.k;
+        const uint32_t rshift = 2u * (k - 1u);
+        uint64_t fwd = 0, rev = 0;
+        uint32_t cnt = 0;   // bases rolled since the last read start (or since w0)
+        // warm-up: the k-1 bases before the first k-mer end
+        for (uint32_t i = 0; i + 1 < k; i++) {
+            const uint64_t x = w0 + i;
+            if (x >= a.nb_bases) break;
+            while (x >= next) { rd++; next = a.fixed_len ? next + a.fixed_len : a.offsets[rd + 1]; cnt = 0; }
+            const uint32_t c = window_base(A, B, i);
+            fwd = ((fwd << 2) | c) & cfg.mask;
+            rev = (rev >> 2) | ((uint64_t)(c ^ 2u) << rshift);
+            cnt++;
+        }
+#pragma unroll
+        for (int q = 0; q < K1_SEG; q++) {
+            const uint64_t x = w0 + (k - 1u) + (uint32_t)q;     // last base of the k-mer starting at w0+q
+            if (x < a.nb_bases) {
+                while (x >= next) { rd++; next = a.fixed_len ? next + a.fixed_len : a.offsets[rd + 1]; cnt = 0; }
+                const uint32_t c = window_base(A, B, (k - 1u) + (uint32_t)q);
+                fwd = ((fwd << 2) | c) & cfg.mask;
+                rev = (rev >> 2) | ((uint64_t)(c ^ 2u) << rshift);
+                cnt++;
+                if (cnt >= k) {
+                    const uint64_t canon = fwd < rev ? fwd : rev;
+                    const uint64_t key = simka_mix(canon, cfg.mask, cfg.xs);
+                    const uint32_t b1 = simka_key_l1(key, cfg);
+                    if (simka_owns_l1(b1, cfg)) {
+                        nvalid++;
+                        if (SCATTER) { keys[q] = key; ranks[q] = atomicAdd(&hist[b1], 1u); }
+                        else atomicAdd(&hist[b1], 1u);
+                    }
+                }
+            }
+        }
+    }
+
+    if (!SCATTER) {
+        if (nvalid) atomicAdd(&s_nvalid, nvalid);
+        __syncthreads();
+        for (uint32_t b = tid; b < B1; b += K1_BLOCK) {
+            const uint32_t h = hist[b];
+            if (h) atomicAdd(&b1_count[b], (ull)h);
+        }
+        if (tid == 0 && s_nvalid) atomicAdd(kocc, (ull)s_nvalid);
+        return;
+    }
+
+    __syncthreads();
+    for (uint32_t b = tid; b < B1; b += K1_BLOCK) {
+        const uint32_t h = hist[b];
+        loff[b] = h;
+        gbase[b] = h ? atomicAdd(&b1_cursor[b], (ull)h) : 0ull;   // reserve this tile's run in bucket b
+    }
+    __syncthreads();
+    const uint32_t total = block_excl_scan<K1_BLOCK>(loff, B1, tmp);
+#pragma unroll
+    for (int q = 0; q < K1_SEG; q++) {
+        if (keys[q] != SIMKA_EMPTY_KEY) stage[loff[simka_key_l1(keys[q], cfg)] + ranks[q]] = keys[q];
+    }
+    __syncthreads();
+    // coalesced copy-out: consecutive staged slots of one bucket go to consecutive HBM addresses
+    for (uint32_t t = tid; t < total; t += K1_BLOCK) {
+        const uint64_t key = stage[t];
+        const uint32_t b = simka_key_l1(key, cfg);
+        l1_keys[gbase[b] + (t - loff[b])] = key;
+    }
+}
+
+// --------------------------------------------------------------------------------------------
+// k_layout: level-1 counts -> bucket starts, scatter cursors, chunk table.  One block.
+// --------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+k_layout(const ull *b1_count, ull *b1_start, ull *b1_cursor, uint32_t *chunk_first, uint32_t B1, ull *arena_cursor,
+         ull *sample_base) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    ull *cnt = (ull *)(smem + SIMKA_LDS_HEAD);   // [B1]
+    for (uint32_t b = threadIdx.x; b < B1; b += blockDim.x) cnt[b] = b1_count[b];
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        ull run = 0;
+        uint32_t crun = 0;
+        for (uint32_t b = 0; b < B1; b++) {
+            const ull c = cnt[b];
+            b1_start[b] = run; b1_cursor[b] = run; chunk_first[b] = crun;
+            run += c;
+            crun += (uint32_t)((c + K2_CHUNK - 1) / K2_CHUNK);
+        }
+        b1_start[B1] = run; chunk_first[B1] = crun;
+        *sample_base = *arena_cursor;   // where this sample's solid records start in the arena
+    }
+}
+
+// --------------------------------------------------------------------------------------------
+// K2a  k_split: partition every K2_CHUNK-key chunk of a level-1 bucket by its level-2 bits,
+// in place (keys travel global -> registers -> LDS stage -> same global range), and record the
+// chunk's level-2 offsets.  k_count later reads segment b2 of every chunk of bucket b1.
+// --------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(K2_BLOCK)
+k_split(uint64_t *l1_keys, const ull *b1_start, const uint32_t *chunk_first, uint16_t *chunk_off, SimkaKeyCfg cfg) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const uint32_t B1 = 1u << cfg.l1, B2 = 1u << cfg.l2;
+    uint32_t &s_b1 = *(uint32_t *)smem;
+    uint32_t *hist = (uint32_t *)(smem + SIMKA_LDS_HEAD);   // [B2]
+    uint32_t *tmp = hist + B2;                      // [K2_BLOCK]
+    uint64_t *stage = (uint64_t *)(tmp + K2_BLOCK); // [K2_CHUNK]
+
+    const uint32_t c = blockIdx.x;
+    if (c >= chunk_first[B1]) return;
+    const uint32_t tid = threadIdx.x;
+    if (tid == 0) {
+        uint32_t lo = 0, hi = B1;   // largest b with chunk_first[b] <= c  (empty buckets repeat a value)
+        while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (chunk_first[mid] <= c) lo = mid; else hi = mid; }
+        s_b1 = lo;
+    }
+    for (uint32_t i = tid; i < B2; i += K2_BLOCK) hist[i] = 0;
+    __syncthreads();
+    const uint32_t b1 = s_b1;
+    const ull s = b1_start[b1] + (ull)(c - chunk_first[b1]) * K2_CHUNK;
+    const ull bend = b1_start[b1 + 1];
+    const uint32_t n = (uint32_t)((bend - s < (ull)K2_CHUNK) ? (bend - s) : (ull)K2_CHUNK);
+
+    constexpr int PER = K2_CHUNK / K2_BLOCK;
+    uint64_t keys[PER];
+    uint32_t ranks[PER];
+#pragma unroll
+    for (int q = 0; q < PER; q++) {
+        const uint32_t idx = (uint32_t)q * K2_BLOCK + tid;
+        keys[q] = SIMKA_EMPTY_KEY; ranks[q] = 0;
+        if (idx < n) {
+            keys[q] = l1_keys[s + idx];
+            ranks[q] = atomicAdd(&hist[simka_key_l2(keys[q], cfg)], 1u);
+        }
+    }
+    __syncthreads();
+    block_excl_scan<K2_BLOCK>(hist, B2, tmp);
+    uint16_t *co = chunk_off + (size_t)c * (B2 + 1);
+    for (uint32_t i = tid; i < B2; i += K2_BLOCK) co[i] = (uint16_t)hist[i];
+    if (tid == 0) co[B2] = (uint16_t)n;
+#pragma unroll
+    for (int q = 0; q < PER; q++)
+        if (keys[q] != SIMKA_EMPTY_KEY) stage[hist[simka_key_l2(keys[q], cfg)] + ranks[q]] = keys[q];
+    __syncthreads();
+    for (uint32_t idx = tid; idx < n; idx += K2_BLOCK) l1_keys[s + idx] = stage[idx];
+}
+
+// --------------------------------------------------------------------------------------------
+// K2b  k_count: one block per partition.  Streams the partition's keys into an LDS hash table
+// (64-bit CAS insert + counter), then applies SimkaCompressedProcessor::process
+// (ref: src/minikc/MiniKC.hpp:54-79): abundance filter, emit (k-mer,count), nbDistinct++,
+// nbKmers+=c, chord+=c^2.  Records go to the HBM arena; the reference gzips them to
+// solid/part_<p>/__p__<i>.gz.
+// --------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(K2_BLOCK)
+k_count(const uint64_t *l1_keys, const ull *b1_start, const uint32_t *chunk_first, const uint16_t *chunk_off,
+        SimkaKeyCfg cfg, uint32_t gs_log2, uint32_t amin, uint32_t amax, SimkaCountOut o) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    ull *s_tot = (ull *)smem;                         // [4] D_all, D, N, Q
+    ull &s_base = *(ull *)(smem + 32);
+    uint32_t &s_nsolid = *(uint32_t *)(smem + 40);
+    uint32_t &s_cur = *(uint32_t *)(smem + 44);
+    uint32_t &s_ovf = *(uint32_t *)(smem + 48);
+    ull *tkeys = (ull *)(smem + SIMKA_LDS_HEAD);      // [K2_TABLE]
+    uint32_t *tcnt = (uint32_t *)(tkeys + K2_TABLE);  // [K2_TABLE]
+
+    const uint32_t B2 = 1u << cfg.l2;
+    const uint32_t part = blockIdx.x;
+    const uint32_t b1 = part >> cfg.l2, b2 = part & (B2 - 1u);
+    if (!simka_owns_l1(b1, cfg)) return;
+    const uint32_t tid = threadIdx.x;
+    for (uint32_t i = tid; i < K2_TABLE; i += K2_BLOCK) { tkeys[i] = SIMKA_EMPTY_KEY; tcnt[i] = 0; }
+    if (tid < 4) s_tot[tid] = 0;
+    if (tid == 0) { s_nsolid = 0; s_cur = 0; s_ovf = 0; }
+    __syncthreads();
+
+    // ---- stream the keys of partition (b1,b2): segment b2 of every chunk of bucket b1
+    const uint32_t c0 = chunk_first[b1], c1 = chunk_first[b1 + 1];
+    const ull base = b1_start[b1], bend = b1_start[b1 + 1];
+    const uint32_t GS = 1u << gs_log2;
+    const uint32_t g = tid >> gs_log2, lane = tid & (GS - 1u), ngroups = K2_BLOCK >> gs_log2;
+    for (uint32_t c = c0 + g; c < c1; c += ngroups) {
+        const ull cbase = base + (ull)(c - c0) * K2_CHUNK;
+        uint32_t s, e;
+        if (cfg.l2 == 0) { s = 0; e = (uint32_t)((bend - cbase < (ull)K2_CHUNK) ? (bend - cbase) : (ull)K2_CHUNK); }
+        else { const uint16_t *co = chunk_off + (size_t)c * (B2 + 1); s = co[b2]; e = co[b2 + 1]; }
+        for (uint32_t i = s + lane; i < e; i += GS) {
+            const ull key = l1_keys[cbase + i];
+            uint32_t slot = simka_slot_hash(key) & (K2_TABLE - 1u);
+            uint32_t probe = 0;
+            for (; probe < K2_TABLE; probe++) {
+                const ull prev = atomicCAS(&tkeys[slot], SIMKA_EMPTY_KEY, key);
+                if (prev == SIMKA_EMPTY_KEY || prev == key) { atomicAdd(&tcnt[slot], 1u); break; }
+                slot = (slot + 1u) & (K2_TABLE - 1u);
+            }
+            if (probe == K2_TABLE) s_ovf = 1;
+        }
+    }
+    __syncthreads();
+    if (s_ovf) { if (tid == 0) atomicOr(o.err, SIMKA_DEVERR_TABLE_OVERFLOW); return; }
+
+    // ---- filter + totals
+    ull dall = 0, D = 0, N = 0, Q = 0;
+    for (uint32_t i = tid; i < K2_TABLE; i += K2_BLOCK) {
+        const uint32_t c = tcnt[i];
+        if (c) {
+            dall++;
+            if (!(c < amin || c > amax)) { D++; N += c; Q += (ull)c * (ull)c; }
+        }
+    }
+    if (dall) atomicAdd(&s_tot[0], dall);
+    if (D) { atomicAdd(&s_tot[1], D); atomicAdd(&s_tot[2], N); atomicAdd(&s_tot[3], Q); atomicAdd(&s_nsolid, (uint32_t)D); }
+    __syncthreads();
+    const uint32_t nsolid = s_nsolid;
+    if (tid == 0) {
+        ull *t = o.totals + o.sample;   // column layout: totals[T * nb_samples + sample]
+        const size_t ns = o.nb_samples;
+        if (s_tot[0]) atomicAdd(&t[SIMKA_TOT_DALL * ns], s_tot[0]);
+        if (s_tot[1]) { atomicAdd(&t[SIMKA_TOT_D * ns], s_tot[1]); atomicAdd(&t[SIMKA_TOT_N * ns], s_tot[2]); atomicAdd(&t[SIMKA_TOT_Q * ns], s_tot[3]); }
+        ull b = 0;
+        uint32_t ok = 1;
+        if (nsolid) {
+            b = atomicAdd(o.arena_cursor, (ull)nsolid);
+            const ull rel = b - *o.sample_base;
+            if (b + nsolid > o.arena_cap) { atomicOr(o.err, SIMKA_DEVERR_ARENA_FULL); ok = 0; }
+            else if (rel + nsolid > 0xffffffffull) { atomicOr(o.err, SIMKA_DEVERR_SAMPLE_TOO_BIG); ok = 0; }
+            o.foff[part] = (uint32_t)rel;
+        } else o.foff[part] = 0;
+        o.fcnt[part] = ok ? nsolid : 0u;
+        s_base = b;
+        s_ovf = ok ? 0u : 1u;
+    }
+    __syncthreads();
+    if (s_ovf || nsolid == 0) return;
+    const ull ab = s_base;
+    for (uint32_t i = tid; i < K2_TABLE; i += K2_BLOCK) {
+        const uint32_t c = tcnt[i];
+        if (c && !(c < amin || c > amax)) {
+            const uint32_t pos = atomicAdd(&s_cur, 1u);
+            o.solid_keys[ab + pos] = tkeys[i];
+            o.solid_counts[ab + pos] = c;
+        }
+    }
+}
+
+// per-partition record totals over all samples (input of the host-side partition scan)
+__global__ void __launch_bounds__(256)
+k_part_totals(const uint32_t *fcnt, uint32_t nb_samples, uint64_t nparts, ull *part_total) {
+    const uint64_t p = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= nparts) return;
+    ull s = 0;
+    for (uint32_t i = 0; i < nb_samples; i++) s += fcnt[(size_t)i * nparts + p];
+    part_total[p] = s;
+}
+
+// --------------------------------------------------------------------------------------------
+// K3  k_regroup: bring partition p's records of all N samples together, ordered by sub-range.
+// (the reference opens the N files solid/part_p/__p__*.gz, ref: src/SimkaMerge.cpp:1082-1103)
+// --------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(K3_BLOCK)
+k_regroup(SimkaMergeIn in, SimkaKeyCfg cfg, uint64_t part_begin, const ull *part_off, ull batch_base,
+          uint32_t *fb_off, ull *mkeys, ull *mvals) {
+    __shared__ uint32_t hist[256];
+    __shared__ uint32_t tmp[K3_BLOCK];
+    const uint32_t nsub = 1u << cfg.t;
+    const uint64_t p = part_begin + blockIdx.x;
+    const uint32_t tid = threadIdx.x;
+    for (uint32_t i = tid; i < nsub; i += K3_BLOCK) hist[i] = 0;
+    __syncthreads();
+    const uint32_t GS = 16, g = tid / GS, lane = tid % GS, ngroups = K3_BLOCK / GS;
+    for (uint32_t s = g; s < in.nb_samples; s += ngroups) {
+        const uint32_t n = in.fcnt[(size_t)s * in.nparts + p];
+        const ull b = in.sample_base[s] + in.foff[(size_t)s * in.nparts + p];
+        for (uint32_t i = lane; i < n; i += GS) atomicAdd(&hist[simka_key_sub(in.solid_keys[b + i], cfg)], 1u);
+    }
+    __syncthreads();
+    block_excl_scan<K3_BLOCK>(hist, nsub, tmp);
+    const uint32_t rel = (uint32_t)(part_off[p] - batch_base);
+    for (uint32_t i = tid; i < nsub; i += K3_BLOCK) fb_off[(size_t)blockIdx.x * nsub + i] = rel + hist[i];
+    __syncthreads();
+    for (uint32_t s = g; s < in.nb_samples; s += ngroups) {
+        const uint32_t n = in.fcnt[(size_t)s * in.nparts + p];
+        const ull b = in.sample_base[s] + in.foff[(size_t)s * in.nparts + p];
+        for (uint32_t i = lane; i < n; i += GS) {
+            const ull key = in.solid_keys[b + i];
+            const uint32_t pos = rel + atomicAdd(&hist[simka_key_sub(key, cfg)], 1u);
+            mkeys[pos] = key;
+            mvals[pos] = ((ull)s << 32) | (ull)in.solid_counts[b + i];
+        }
+    }
+}
+
+// --------------------------------------------------------------------------------------------
+// K3a  k_group: the N-way merge.  Where the reference pops a min-heap to collect the abundance
+// vector of one k-mer (ref: src/SimkaMerge.cpp:1198-1263), a block hashes the records of one
+// sub-range into LDS, which groups equal k-mers; groups with >= min_share samples are emitted
+// as CSR (the gate of SimkaMergeAlgorithm::insert, ref: src/SimkaMerge.cpp:1307-1326).
+// --------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(K3_BLOCK)
+k_group(const ull *mkeys, const ull *mvals, const uint32_t *fb_off, uint32_t nfb, uint32_t batch_total,
+        SimkaKeyCfg cfg, uint32_t min_share, SimkaCsrOut o) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    ull &s_ebase = *(ull *)smem;
+    ull &s_gbase = *(ull *)(smem + 8);
+    uint32_t &s_nrec = *(uint32_t *)(smem + 16);
+    uint32_t &s_ovf = *(uint32_t *)(smem + 20);
+    uint32_t &s_ndist = *(uint32_t *)(smem + 24);
+    uint32_t &s_nshared = *(uint32_t *)(smem + 28);
+    int &s_sp = *(int *)(smem + 32);
+    uint32_t *s_stack = (uint32_t *)(smem + 64);           // [2*24]
+    ull *tkeys = (ull *)(smem + SIMKA_LDS_HEAD);           // [K3_TABLE]
+    ull *rval = tkeys + K3_TABLE;                          // [K3_CAP]
+    uint32_t *scnt = (uint32_t *)(rval + K3_CAP);          // [K3_TABLE] group size
+    uint32_t *goff = scnt + K3_TABLE;                      // [K3_TABLE] entry offset of the group
+    uint32_t *gidx = goff + K3_TABLE;                      // [K3_TABLE] group index, later fill cursor
+    uint32_t *tmp = gidx + K3_TABLE;                       // [K3_BLOCK]
+    uint16_t *rslot = (uint16_t *)(tmp + K3_BLOCK);        // [K3_CAP]
+
+    const uint32_t fb = blockIdx.x;
+    const uint32_t rb = fb_off[fb];
+    const uint32_t re = (fb + 1 < nfb) ? fb_off[fb + 1] : batch_total;
+    const uint32_t R = re - rb;
+    if (R == 0) return;
+    const uint32_t tid = threadIdx.x;
+    // bits still unused below partition + sub-range bits: available to split an overfull sub-range
+    const uint32_t free_bits = cfg.W - cfg.pb - cfg.t;
+    uint32_t e0 = 0;
+    while (((R >> e0) > (K3_CAP * 3u) / 4u) && e0 < free_bits) e0++;
+    if (tid == 0) { s_ndist = 0; s_nshared = 0; }
+    __syncthreads();
+    const uint32_t nvals0 = 1u << e0;
+    for (uint32_t v0 = 0; v0 < nvals0; v0++) {
+        if (tid == 0) { s_sp = 1; s_stack[0] = e0; s_stack[1] = v0; }
+        __syncthreads();
+        while (true) {
+            __syncthreads();
+            if (s_sp == 0) break;
+            const uint32_t e = s_stack[2 * (s_sp - 1)], val = s_stack[2 * (s_sp - 1) + 1];
+            __syncthreads();
+            if (tid == 0) { s_sp--; s_nrec = 0; s_ovf = 0; }
+            for (uint32_t i = tid; i < K3_TABLE; i += K3_BLOCK) { tkeys[i] = SIMKA_EMPTY_KEY; scnt[i] = 0; }
+            __syncthreads();
+            // ---- hash the records of this (sub-)range
+            const uint32_t selshift = free_bits - e;
+            for (uint32_t i = rb + tid; i < re; i += K3_BLOCK) {
+                const ull key = mkeys[i];
+                if (e && (uint32_t)((key >> selshift) & ((1ull << e) - 1ull)) != val) continue;
+                const uint32_t idx = atomicAdd(&s_nrec, 1u);
+                if (idx >= K3_CAP) { s_ovf = 1; continue; }
+                uint32_t slot = simka_slot_hash(key) & (K3_TABLE - 1u);
+                for (;;) {   // table has 2*K3_CAP slots and at most K3_CAP records: always terminates
+                    const ull prev = atomicCAS(&tkeys[slot], SIMKA_EMPTY_KEY, key);
+                    if (prev == SIMKA_EMPTY_KEY || prev == key) break;
+                    slot = (slot + 1u) & (K3_TABLE - 1u);
+                }
+                atomicAdd(&scnt[slot], 1u);
+                rslot[idx] = (uint16_t)slot;
+                rval[idx] = mvals[i];
+            }
+            __syncthreads();
+            if (s_ovf) {
+                if (e >= free_bits) { if (tid == 0) atomicOr(o.err, SIMKA_DEVERR_GROUP_OVERFLOW); return; }
+                if (tid == 0) {   // refine: two children with one more selector bit
+                    if (s_sp + 2 > 24) { atomicOr(o.err, SIMKA_DEVERR_GROUP_OVERFLOW); s_ovf = 2; }
+                    else {
+                        s_stack[2 * s_sp] = e + 1; s_stack[2 * s_sp + 1] = val * 2u + 1u; s_sp++;
+                        s_stack[2 * s_sp] = e + 1; s_stack[2 * s_sp + 1] = val * 2u; s_sp++;
+                    }
+                }
+                __syncthreads();
+                if (s_ovf == 2) return;
+                continue;
+            }
+            const uint32_t nrec = s_nrec;
+            if (nrec == 0) continue;
+            // ---- group geometry: entries/groups prefix over table slots
+            uint32_t ndist = 0, nshared = 0;
+            for (uint32_t i = tid; i < K3_TABLE; i += K3_BLOCK) {
+                const uint32_t c = scnt[i];
+                if (c) ndist++;
+                if (c > 1) nshared++;
+                const uint32_t keep = (c >= min_share) ? 1u : 0u;
+                goff[i] = keep ? c : 0u;
+                gidx[i] = keep;
+            }
+            if (ndist) atomicAdd(&s_ndist, ndist);
+            if (nshared) atomicAdd(&s_nshared, nshared);
+            __syncthreads();
+            const uint32_t nent = block_excl_scan<K3_BLOCK>(goff, K3_TABLE, tmp);
+            const uint32_t ngrp = block_excl_scan<K3_BLOCK>(gidx, K3_TABLE, tmp);
+            if (ngrp == 0) continue;
+            if (tid == 0) {
+                const ull eb = atomicAdd(&o.cursors[0], (ull)nent);
+                const ull gb = atomicAdd(&o.cursors[1], (ull)ngrp);
+                const ull sid = atomicAdd(&o.cursors[2], 1ull);
+                if (eb + nent > o.cap_entries || gb + ngrp > o.cap_groups || sid >= o.cap_spans) {
+                    atomicOr(o.err, SIMKA_DEVERR_CSR_FULL); s_ovf = 2;
+                } else {
+                    SimkaSpan sp; sp.ebase = eb; sp.gbase = gb; sp.nent = nent; sp.ngrp = ngrp;
+                    o.spans[sid] = sp;
+                }
+                s_ebase = eb; s_gbase = gb;
+            }
+            __syncthreads();
+            if (s_ovf == 2) return;
+            const ull eb = s_ebase, gb = s_gbase;
+            for (uint32_t i = tid; i < K3_TABLE; i += K3_BLOCK) {
+                const uint32_t c = scnt[i];
+                if (c >= min_share) o.groups[gb + gidx[i]] = (goff[i] << 16) | c;
+            }
+            __syncthreads();
+            for (uint32_t i = tid; i < K3_TABLE; i += K3_BLOCK) gidx[i] = 0;   // now the per-group fill cursor
+            __syncthreads();
+            for (uint32_t i = tid; i < nrec; i += K3_BLOCK) {
+                const uint32_t slot = rslot[i];
+                if (scnt[slot] >= min_share) {
+                    const uint32_t pos = goff[slot] + atomicAdd(&gidx[slot], 1u);
+                    o.entries[eb + pos] = rval[i];
+                }
+            }
+        }
+    }
+    __syncthreads();
+    if (tid == 0) {
+        if (s_ndist) atomicAdd(&o.glob[0], (ull)s_ndist);      // _nbDistinctKmers  (:1315)
+        if (s_nshared) atomicAdd(&o.glob[1], (ull)s_nshared);  // _nbSharedKmers    (:1319-1321)
+    }
+}
+
+// --------------------------------------------------------------------------------------------
+// K3b  k_pairs: SimkaCountProcessorSimple::updateDistanceDefault / updateDistanceSimple
+// (ref: src/core/SimkaAlgorithm.hpp:356-402).  For every group (one k-mer, s samples) all
+// s(s-1)/2 pairs i<j update
+//     S[i][j]+=ci  S[j][i]+=cj  a[ij]+=1  bc[ij]+=min(ci,cj)        (default)
+//     chord[ij]+=ci*cj  hell[ij]+=floor(sqrt(ci*cj))                 (simple; kul == bc)
+// into u32 LDS accumulators private to the block; a wrap of the low word carries 2^32 straight
+// into the global u64 cell, so the sums are exact.  Blocks are persistent over the span list.
+// --------------------------------------------------------------------------------------------
+__device__ __forceinline__ void acc_add(uint32_t *l, ull *g, uint32_t v) {
+    const uint32_t old = atomicAdd(l, v);
+    if ((uint32_t)(old + v) < old) atomicAdd(g, 1ull << 32);
+}
+
+__device__ __forceinline__ void tri_unrank(uint32_t idx, uint32_t s, uint32_t &x, uint32_t &y) {
+    // pairs (x<y) of s items, row-major; row x starts at x*s - x*(x+1)/2
+    const double fs = 2.0 * (double)s - 1.0;
+    double disc = fs * fs - 8.0 * (double)idx;
+    if (disc < 0) disc = 0;
+    long long xi = (long long)((fs - sqrt(disc)) * 0.5);
+    const long long S = (long long)s, id = (long long)idx;
+    if (xi < 0) xi = 0;
+    if (xi > S - 2) xi = S - 2;
+    while (xi > 0 && (xi * S - xi * (xi + 1) / 2) > id) xi--;
+    while (xi + 1 <= S - 2 && ((xi + 1) * S - (xi + 1) * (xi + 2) / 2) <= id) xi++;
+    x = (uint32_t)xi;
+    y = (uint32_t)(id - (xi * S - xi * (xi + 1) / 2) + xi + 1);
+}
+
+__global__ void __launch_bounds__(K4_BLOCK)
+k_pairs(const SimkaSpan *spans, const ull *cursors, const ull *entries, const uint32_t *groups, SimkaPairCfg pc,
+        ull *acc, ull *slabs) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    uint32_t *lacc = (uint32_t *)(smem + SIMKA_LDS_HEAD);       // [nacc][ncell_pad]
+    ull *ent = (ull *)(lacc + (size_t)pc.nacc * pc.ncell_pad);  // [K3_CAP]
+    uint32_t *gdesc = (uint32_t *)(ent + K3_CAP);               // [K3_CAP]   (start<<16 | size)
+    uint32_t *gpref = gdesc + K3_CAP;                           // [K3_CAP+1] pair prefix
+    uint32_t *tmp = gpref + K3_CAP + 1;                         // [K4_BLOCK]
+
+    const uint32_t tid = threadIdx.x;
+    const uint32_t N = pc.nb_samples, T = pc.tile;
+    // tile pair (I<=J) of this block row
+    uint32_t I = 0, J = 0;
+    {
+        uint32_t r = blockIdx.y;
+        for (I = 0; I < pc.ntiles; I++) { const uint32_t row = pc.ntiles - I; if (r < row) { J = I + r; break; } r -= row; }
+    }
+    const uint32_t ncell = pc.ncell;
+    for (uint32_t i = tid; i < pc.nacc * pc.ncell_pad; i += K4_BLOCK) lacc[i] = 0;
+    __syncthreads();
+
+    const ull nspans = cursors[2];
+    for (ull sp = blockIdx.x; sp < nspans; sp += gridDim.x) {
+        const SimkaSpan span = spans[sp];
+        for (uint32_t i = tid; i < span.nent; i += K4_BLOCK) ent[i] = entries[span.ebase + i];
+        for (uint32_t i = tid; i < span.ngrp; i += K4_BLOCK) {
+            const uint32_t d = groups[span.gbase + i];
+            gdesc[i] = d;
+            const uint32_t s = d & 0xffffu;
+            gpref[i] = s * (s - 1u) / 2u;
+        }
+        __syncthreads();
+        const uint32_t P = block_excl_scan<K4_BLOCK>(gpref, span.ngrp, tmp);
+        if (tid == 0) gpref[span.ngrp] = P;
+        __syncthreads();
+        const uint32_t chunk = (P + K4_BLOCK - 1) / K4_BLOCK;
+        uint32_t p = tid * chunk;
+        const uint32_t pend = (p + chunk < P) ? p + chunk : P;
+        if (p < pend) {
+            uint32_t lo = 0, hi = span.ngrp;    // largest g with gpref[g] <= p
+            while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (gpref[mid] <= p) lo = mid; else hi = mid; }
+            uint32_t g = lo;
+            while (g + 1 < span.ngrp && gpref[g + 1] <= p) g++;   // skip groups without pairs
+            uint32_t d = gdesc[g];
+            uint32_t gs = d >> 16, s = d & 0xffffu, x, y;
+            tri_unrank(p - gpref[g], s, x, y);
+            for (; p < pend; p++) {
+                const ull ex = ent[gs + x], ey = ent[gs + y];
+                uint32_t si = (uint32_t)(ex >> 32), sj = (uint32_t)(ey >> 32);
+                uint32_t ci = (uint32_t)ex, cj = (uint32_t)ey;
+                if (si > sj) { uint32_t t_ = si; si = sj; sj = t_; t_ = ci; ci = cj; cj = t_; }
+                // tile filter (single tile: always true)
+                const uint32_t ti = si / T, tj = sj / T;
+                if (ti == I && tj == J) {
+                    const uint32_t li = si - I * T, lj = sj - J * T;
+                    const uint32_t cell = (pc.ntiles == 1) ? (uint32_t)simka_pair_index(li, lj, N)
+                                          : (I == J ? (uint32_t)simka_pair_index(li, lj, T) : li * T + lj);
+                    const ull pg = simka_pair_index(si, sj, N);
+                    acc_add(&lacc[SIMKA_ACC_SIJ * pc.ncell_pad + cell], &acc[SIMKA_ACC_SIJ * pc.nb_pairs + pg], ci);
+                    acc_add(&lacc[SIMKA_ACC_SJI * pc.ncell_pad + cell], &acc[SIMKA_ACC_SJI * pc.nb_pairs + pg], cj);
+                    atomicAdd(&lacc[SIMKA_ACC_A * pc.ncell_pad + cell], 1u);
+                    acc_add(&lacc[SIMKA_ACC_BC * pc.ncell_pad + cell], &acc[SIMKA_ACC_BC * pc.nb_pairs + pg], ci < cj ? ci : cj);
+                    if (pc.nacc > 4) {
+                        const ull prod = (ull)ci * (ull)cj;
+                        acc_add(&lacc[SIMKA_ACC_CHORD * pc.ncell_pad + cell], &acc[SIMKA_ACC_CHORD * pc.nb_pairs + pg], (uint32_t)prod);
+                        if (prod >> 32) atomicAdd(&acc[SIMKA_ACC_CHORD * pc.nb_pairs + pg], (prod >> 32) << 32);
+                        acc_add(&lacc[SIMKA_ACC_HELL * pc.ncell_pad + cell], &acc[SIMKA_ACC_HELL * pc.nb_pairs + pg], (uint32_t)simka_isqrt(prod));
+                    }
+                }
+                // next pair of the span
+                y++;
+                if (y == s) {
+                    x++; y = x + 1;
+                    if (y >= s) {   // group exhausted
+                        g++;
+                        while (g < span.ngrp && (gdesc[g] & 0xffffu) < 2u) g++;
+                        if (g >= span.ngrp) break;
+                        d = gdesc[g]; gs = d >> 16; s = d & 0xffffu; x = 0; y = 1;
+                    }
+                }
+            }
+        }
+        __syncthreads();
+    }
+    // ---- fold this block's private accumulators into its slab (plain read-modify-write: the slab
+    // row belongs to this block alone); k_reduce_slabs sums the rows at the end of the merge
+    ull *slab = slabs + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * pc.nacc * pc.ncell_pad;
+    for (uint32_t i = tid; i < pc.nacc * pc.ncell_pad; i += K4_BLOCK) {
+        const uint32_t v = lacc[i];
+        if (v) slab[i] += v;
+    }
+    (void)ncell;
+}
+
+// slabs[tilepair][block][acc][cell] -> acc[a][pair(i,j)]
+__global__ void __launch_bounds__(256)
+k_reduce_slabs(const ull *slabs, uint32_t nblocks, SimkaPairCfg pc, ull *acc) {
+    const uint32_t tp = blockIdx.y;
+    uint32_t I = 0, J = 0;
+    {
+        uint32_t r = tp;
+        for (I = 0; I < pc.ntiles; I++) { const uint32_t row = pc.ntiles - I; if (r < row) { J = I + r; break; } r -= row; }
+    }
+    const uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= pc.nacc * pc.ncell_pad) return;
+    const uint32_t a = idx / pc.ncell_pad, cell = idx % pc.ncell_pad;
+    if (cell >= pc.ncell) return;
+    const uint32_t N = pc.nb_samples, T = pc.tile;
+    // cell -> (i,j)
+    uint32_t i, j;
+    if (pc.ntiles == 1) { tri_unrank(cell, N, i, j); }
+    else if (I == J) { uint32_t li, lj; if (cell >= T * (T - 1u) / 2u) return; tri_unrank(cell, T, li, lj); i = I * T + li; j = J * T + lj; }
+    else { i = I * T + cell / T; j = J * T + cell % T; }
+    if (i >= N || j >= N || i >= j) return;
+    ull s = 0;
+    const size_t stride = (size_t)pc.nacc * pc.ncell_pad;
+    const ull *base = slabs + (size_t)tp * nblocks * stride + idx;
+    for (uint32_t b = 0; b < nblocks; b++) s += base[(size_t)b * stride];
+    if (s) atomicAdd(&acc[(size_t)a * pc.nb_pairs + simka_pair_index(i, j, N)], s);
+}
+
+// --------------------------------------------------------------------------------------------
+// synthetic data (bench / test utility): genome pool and error-bearing reads, 2-bit packed
+// --------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+k_synth_genomes(uint64_t *pool, uint32_t nb_genomes, uint64_t genome_words, uint64_t seed) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (uint64_t)nb_genomes * genome_words) return;
+    const uint64_t gidx = i / genome_words, w = i % genome_words;
+    pool[i] = simka_rng(seed ^ (gidx * 0xD1B54A32D192ED03ULL), w);   // 32 i.i.d. uniform bases per word
+}
+
+// one thread per OUTPUT word (32 bases), which may straddle two reads
+__global__ void __launch_bounds__(256)
+k_synth_reads(uint64_t *packed, uint64_t nb_reads, uint32_t L, const uint64_t *pool, uint64_t genome_words,
+              uint64_t genome_len, const uint32_t *genome_ids, const uint32_t *cdf, uint32_t nb_sel, uint64_t seed,
+              uint32_t err_thr) {
+    const uint64_t w = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint64_t nb_bases = nb_reads * (uint64_t)L;
+    if (w * 32 >= nb_bases) return;
+    uint64_t out = 0;
+    uint64_t cur_read = ~0ull, gbase = 0, start = 0;
+    uint32_t strand = 0;
+    for (uint32_t bi = 0; bi < 32; bi++) {
+        const uint64_t b = w * 32 + bi;
+        if (b >= nb_bases) break;
+        const uint64_t r = b / L;
+        const uint32_t i = (uint32_t)(b - r * L);
+        if (r != cur_read) {
+            cur_read = r;
+            const uint64_t h0 = simka_rng(seed, 2 * r);
+            const uint64_t h1 = simka_rng(seed, 2 * r + 1);
+            const uint32_t u = (uint32_t)(h0 >> 32);
+            uint32_t sel = 0;
+            while (sel + 1 < nb_sel && u >= cdf[sel]) sel++;     // cdf[] = cumulative weights * 2^32
+            gbase = (uint64_t)genome_ids[sel] * genome_words;
+            start = ((h0 & 0xffffffffull) * (genome_len - L + 1)) >> 32;
+            strand = (uint32_t)(h1 & 1u);
+        }
+        const uint64_t gp = strand ? (start + (L - 1u - i)) : (start + i);
+        uint32_t c = (uint32_t)(pool[gbase + (gp >> 5)] >> ((gp & 31u) * 2u)) & 3u;
+        if (strand) c ^= 2u;
+        const uint64_t he = simka_rng(seed ^ 0xA5A5A5A5A5A5A5A5ULL, b);
+        if ((uint32_t)(he & 0xffffu) < err_thr) c = (c + 1u + (uint32_t)((he >> 16) % 3u)) & 3u;   // substitution
+        out |= (uint64_t)c << (bi * 2u);
+    }
+    packed[w] = out;
+}

@@ -1,0 +1,132 @@
+"""-m gpu: the HIP path (through the C ABI) against the CPU oracle and the reference's golden CSVs."""
+import filecmp
+import glob
+import gzip
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+CONFIGS = [(21, 0), (21, 2), (31, 0), (31, 2)]
+
+
+def _load_example(golden_dir):
+    import simka_amd
+    samples = simka_amd.parse_input_file(os.path.join(golden_dir, "example", "simka_input.txt"))
+    packed = []
+    for s in samples:
+        seqs = []
+        for f in s["files"]:
+            seqs += list(simka_amd.read_sequences(f))
+        packed.append(simka_amd.pack_reads(seqs))
+    return samples, packed
+
+
+def _run_gpu(packed, k, amin, simple=True, **kw):
+    import simka_amd
+    ctx = simka_amd.SimkaContext(len(packed), kmer_size=k, abundance_min=amin, simple_dist=simple, **kw)
+    for i, (pk, off, nb, nin) in enumerate(packed):
+        ctx.count_sample(i, pk, nb, len(off) - 1, offsets=off, nb_input_reads=nin)
+    totals = [ctx.sample_totals(i) for i in range(len(packed))]
+    ctx.merge()
+    st = ctx.stats()
+    ctx.close()
+    return totals, st
+
+
+def _check_vs_oracle(totals, st, orc, simple=True):
+    ot = orc.totals()
+    for i, t in enumerate(totals):
+        for key in ("K_occ", "D_all", "D", "N", "Q"):
+            assert int(t[key]) == int(ot[key][i]), (i, key, t[key], ot[key][i])
+    n = orc.n
+    iu = np.triu_indices(n, 1)
+    pr = st.pairs()
+    S = orc.acc("S")
+    assert np.array_equal(pr["S_ij"], S[iu])
+    assert np.array_equal(pr["S_ji"], S.T[iu])
+    assert np.array_equal(pr["a"], orc.acc("a")[iu])
+    assert np.array_equal(pr["bc"], orc.acc("bc")[iu])
+    if simple:
+        assert np.array_equal(pr["chord"], orc.acc("chord")[iu])
+        assert np.array_equal(pr["hell"], orc.acc("hell")[iu])
+        assert np.array_equal(pr["bc"], orc.acc("kul")[iu])     # kul[i][j] == bc identity
+    d, s = orc.global_counts()
+    assert (int(st.view.nb_distinct_kmers), int(st.view.nb_shared_kmers)) == (d, s)
+
+
+@pytest.mark.parametrize("k,amin", CONFIGS)
+def test_example_accumulators_and_csv(gpu_required, oracle_mod, golden_dir, tmp_path, k, amin):
+    """C1: example/simka_input.txt -- integer accumulators bit-exact vs the oracle, CSV bytes == tests/truth."""
+    samples, packed = _load_example(golden_dir)
+    totals, st = _run_gpu(packed, k, amin, simple=True)
+    orc = oracle_mod.Oracle()
+    orc.load_input(os.path.join(golden_dir, "example", "simka_input.txt"))
+    orc.run(k, amin, simple=True)
+    _check_vs_oracle(totals, st, orc)
+    out = str(tmp_path / "res")
+    st.write_matrices(out, [s["id"] for s in samples], gz=True)
+    truth = os.path.join(golden_dir, "truth", "results_k%d_t%d" % (k, amin))
+    compared = 0
+    for gzf in glob.glob(os.path.join(out, "*.csv.gz")):
+        name = os.path.basename(gzf)[:-3]
+        ref = os.path.join(truth, name)
+        if not os.path.exists(ref):
+            continue            # mat_abundance_jaccard is not pinned by the reference either
+        with gzip.open(gzf, "rb") as f, open(ref, "rb") as g:
+            assert f.read() == g.read(), name
+        compared += 1
+    assert compared == 17       # 20 goldens minus the 3 -complex-dist matrices
+
+
+def _synthetic(n_samples, nb_reads, read_len, seed_shift=0):
+    from simka_amd import synth
+    g = synth.genome_len_for(nb_reads, read_len)
+    pool, gw = synth.genome_pool_cpu(g)
+    out = []
+    for s in range(n_samples):
+        ids, cdf = synth.sample_profile(s + seed_shift)
+        pk = synth.reads_cpu(nb_reads, read_len, pool, gw, g, ids, cdf, synth.sample_seed(s + seed_shift))
+        out.append(pk)
+    return out
+
+
+@pytest.mark.parametrize("k,amin,n,R,L,kw", [
+    (21, 2, 6, 3000, 100, {}),
+    (31, 1, 4, 2000, 150, {}),
+    (21, 2, 6, 3000, 100, {"log2_partitions": 6}),          # two-level partitioning (k_split path)
+    (21, 2, 6, 3000, 100, {"log2_partitions": 4, "log2_subranges": 3}),
+    (15, 2, 5, 2500, 80, {"log2_partitions": 3}),
+])
+def test_synthetic_vs_oracle(gpu_required, oracle_mod, k, amin, n, R, L, kw):
+    from simka_amd import synth
+    packed = _synthetic(n, R, L)
+    inputs = [(np.concatenate([pk, np.zeros(2, dtype=np.uint64)]), np.arange(R + 1, dtype=np.uint64) * L, R * L, R) for pk in packed]
+    totals, st = _run_gpu(inputs, k, amin, simple=True, **kw)
+    orc = oracle_mod.Oracle()
+    for s, pk in enumerate(packed):
+        orc.add_sample_ascii("S%d" % s, synth.unpack_ascii(pk, R * L), np.arange(R + 1, dtype=np.uint64) * L)
+    orc.run(k, amin, simple=True)
+    _check_vs_oracle(totals, st, orc)
+    # floating-point distances: <= 1e-6 relative (north_star tolerance) -- here they are float32-identical
+    for w, name in enumerate(orc.matrix_names()):
+        if name in st.matrices():
+            np.testing.assert_allclose(st.matrices()[name], orc.matrix(w), rtol=1e-6, atol=0)
+
+
+def test_fixed_len_equals_offsets(gpu_required):
+    """fixed_len fast path == explicit offsets."""
+    R, L = 4000, 100
+    packed = _synthetic(3, R, L, seed_shift=10)
+    a = [(np.concatenate([pk, np.zeros(2, dtype=np.uint64)]), np.arange(R + 1, dtype=np.uint64) * L, R * L, R) for pk in packed]
+    _, st1 = _run_gpu(a, 21, 2)
+    import simka_amd
+    ctx = simka_amd.SimkaContext(3, kmer_size=21, abundance_min=2, simple_dist=True)
+    for i, pk in enumerate(packed):
+        ctx.count_sample(i, np.concatenate([pk, np.zeros(2, dtype=np.uint64)]), R * L, R, fixed_len=L)
+    ctx.merge()
+    st2 = ctx.stats()
+    ctx.close()
+    assert np.array_equal(st1.flat, st2.flat)
