@@ -1,0 +1,103 @@
+"""The oracle is only trusted because it reproduces the reference's own golden vectors:
+tests/golden/truth == /root/reference/tests/truth (80 CSVs, byte-for-byte as tests/simple_test.py:29-68),
+plus the integer known answers of SURVEY.md Appendix A.6 and the partition invariance that
+tests/simple_test.py:125-133 checks."""
+import glob
+import os
+
+import numpy as np
+import pytest
+
+CONFIGS = [(21, 0), (21, 2), (31, 0), (31, 2)]
+
+
+def _oracle(oracle_mod, golden_dir, k, amin, **kw):
+    o = oracle_mod.Oracle()
+    o.load_input(os.path.join(golden_dir, "example", "simka_input.txt"))
+    o.run(k, amin, simple=True, complex_=True, **kw)
+    return o
+
+
+@pytest.mark.parametrize("k,amin", CONFIGS)
+def test_oracle_reproduces_golden_csv(oracle_mod, golden_dir, tmp_path, k, amin):
+    o = _oracle(oracle_mod, golden_dir, k, amin)
+    out = str(tmp_path / "o")
+    o.write_matrices(out, gz=False)
+    truth = sorted(glob.glob(os.path.join(golden_dir, "truth", "results_k%d_t%d" % (k, amin), "*.csv")))
+    assert len(truth) == 20
+    for ref in truth:
+        with open(ref, "rb") as f, open(os.path.join(out, os.path.basename(ref)), "rb") as g:
+            assert f.read() == g.read(), os.path.basename(ref)
+
+
+def test_input_grammar(oracle_mod, golden_dir):
+    """ref: src/core/SimkaAlgorithm.cpp:245-351 -- 5 samples, E = A,A ; B,B (2 paired parts, 4 files)."""
+    o = oracle_mod.Oracle()
+    o.load_input(os.path.join(golden_dir, "example", "simka_input.txt"))
+    assert o.ids() == ["A", "B", "C", "D", "E"]
+    assert [len(o.files(i)) for i in range(5)] == [1, 1, 1, 2, 4]
+    assert [o.nb_paired(i) for i in range(5)] == [1, 1, 1, 2, 2]
+    assert all(os.path.isabs(f) and os.path.exists(f) for i in range(5) for f in o.files(i))
+
+
+# per-sample (K_occ, D_all) and (D, N, Q)
+A6 = {
+    (21, 0): ([(8910, 4320), (9180, 8100), (8820, 8460), (13140, 11790), (36180, 8100)],
+              [(4320, 8910, 18630), (8100, 9180, 11520), (8460, 8820, 9720), (11790, 13140, 17640), (8100, 36180, 212040)], (12600, 12420)),
+    (21, 2): ([(8910, 4320), (9180, 8100), (8820, 8460), (13140, 11790), (36180, 8100)],
+              [(4320, 8910, 18630), (990, 2070, 4410), (270, 630, 1530), (990, 2340, 6840), (8100, 36180, 212040)], (8100, 4320)),
+    (31, 0): ([(7920, 3840), (8160, 7200), (7840, 7520), (11680, 10480), (32160, 7200)],
+              [(3840, 7920, 16560), (7200, 8160, 10240), (7520, 7840, 8640), (10480, 11680, 15680), (7200, 32160, 188480)], (11200, 11040)),
+    (31, 2): ([(7920, 3840), (8160, 7200), (7840, 7520), (11680, 10480), (32160, 7200)],
+              [(3840, 7920, 16560), (880, 1840, 3920), (240, 560, 1360), (880, 2080, 6080), (7200, 32160, 188480)], (7200, 3840)),
+}
+# pair AB: a ; bc ; S_ij/S_ji ; chord ; hell
+A6_AB = {(21, 0): (4320, 5400, 8910, 5400, 11430, 5400), (21, 2): (990, 2070, 2250, 2070, 4770, 2070),
+         (31, 0): (3840, 4800, 7920, 4800, 10160, 4800), (31, 2): (880, 1840, 2000, 1840, 4240, 1840)}
+
+
+@pytest.mark.parametrize("k,amin", CONFIGS)
+def test_oracle_integer_known_answers(oracle_mod, golden_dir, k, amin):
+    o = _oracle(oracle_mod, golden_dir, k, amin)
+    t = o.totals()
+    pre, post, glob_ = A6[(k, amin)]
+    assert [(int(a), int(b)) for a, b in zip(t["K_occ"], t["D_all"])] == pre
+    assert [(int(a), int(b), int(c)) for a, b, c in zip(t["D"], t["N"], t["Q"])] == post
+    assert o.global_counts() == glob_
+    S = o.acc("S")
+    ab = (int(o.acc("a")[0, 1]), int(o.acc("bc")[0, 1]), int(S[0, 1]), int(S[1, 0]), int(o.acc("chord")[0, 1]), int(o.acc("hell")[0, 1]))
+    assert ab == A6_AB[(k, amin)]
+    # identities of Appendix A.6
+    D = t["D"].astype(np.int64)
+    a = o.acc("a").astype(np.int64)
+    iu = np.triu_indices(5, 1)
+    assert np.array_equal(o.acc("kul")[iu], o.acc("bc")[iu])
+    assert np.array_equal(o.acc("canb")[iu].astype(np.int64), (D[:, None] + D[None, :] - 2 * a)[iu])
+
+
+@pytest.mark.parametrize("nparts,threads", [(7, 1), (16, 4)])
+def test_oracle_partition_invariance(oracle_mod, golden_dir, nparts, threads):
+    """ref: tests/simple_test.py:125-133 -- a different partition / job count must give the same matrices."""
+    a = _oracle(oracle_mod, golden_dir, 31, 2)
+    b = _oracle(oracle_mod, golden_dir, 31, 2, nparts=nparts, threads=threads)
+    for name in ("S", "a", "bc", "chord", "hell", "kul", "whit", "canb"):
+        assert np.array_equal(a.acc(name), b.acc(name)), name
+    for w in range(len(a.matrix_names())):
+        assert np.array_equal(a.matrix(w), b.matrix(w))
+
+
+def test_oracle_edge_cases(oracle_mod):
+    """Unpinned by the goldens; gatb-conventional behaviour: non-ACGT windows skipped,
+    case-insensitive, reads shorter than k and empty samples contribute nothing."""
+    o = oracle_mod.Oracle()
+    reads = [b"ACGTNACGTACGTA", b"acgtacgtacgta", b"ACG", b""]
+    cat = np.frombuffer(b"".join(reads), dtype=np.uint8)
+    off = np.cumsum([0] + [len(r) for r in reads]).astype(np.uint64)
+    o.add_sample_ascii("x", cat, off)
+    o.add_sample_ascii("empty", np.zeros(0, dtype=np.uint8), np.zeros(1, dtype=np.uint64))
+    o.run(5, 1, simple=True, complex_=True)
+    t = o.totals()
+    # read 1: windows of 5 without N: "ACGTA CGTAC GTACG TACGT ACGTA" (5) ; read 2: 13-5+1 = 9 ; read 3/4: none
+    assert int(t["K_occ"][0]) == 5 + 9
+    assert int(t["K_occ"][1]) == 0 and int(t["D"][1]) == 0
+    assert np.all(o.matrix(4)[0, 1] == 1.0)      # jaccard with an empty sample: guard -> 1
