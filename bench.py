@@ -1,0 +1,235 @@
+#!/usr/bin/env python3
+"""bench.py -- distinct k-mers/s of the whole Simka hot path (count -> merge -> N x N matrices) on MI355X.
+
+A "step" = one full job over synthetic reads that are already resident in HBM (2-bit packed):
+simka_reset, simka_count_sample x N, simka_merge, [all-reduce of the accumulators over ranks],
+download, host finalisation into the float32 distance matrices.
+
+    python bench.py --gpus N --steps K --warmup W [--workload c2|c3|c3_10 ...]
+
+For N>1 run under torch.distributed.run (one rank per GPU, backend nccl = RCCL): the partition space is
+sharded over ranks (strong scaling: the job is fixed, `value` is the whole-job rate).
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0     # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s is the measured copy ceiling
+
+WORKLOADS = {
+    # BASELINE.json configs[1]
+    "c2": dict(n=10, reads=1_000_000, L=100, k=21, amin=2, simple=False,
+               desc="10 synthetic samples x 1M 100 bp reads, k=21, Bray-Curtis + Jaccard"),
+    # BASELINE.json configs[2] (the configuration the metric/targets are quoted on)
+    "c3": dict(n=100, reads=10_000_000, L=150, k=31, amin=2, simple=True,
+               desc="100 samples x 10M 150 bp reads, k=31, -simple-dist, abundance-min 2"),
+    # 1/10-scale C3 (same shape, 1M reads per sample)
+    "c3_10": dict(n=100, reads=1_000_000, L=150, k=31, amin=2, simple=True,
+                  desc="100 samples x 1M 150 bp reads (C3 at 1/10 read depth), k=31, -simple-dist"),
+}
+
+
+def gen_device_samples(lib, torch, wl, dev):
+    """genome pool + per-sample reads, generated on the GPU (k_synth_*), 2-bit packed int64 tensors."""
+    from simka_amd import synth
+    R, L, n = wl["reads"], wl["L"], wl["n"]
+    g = synth.genome_len_for(R, L)
+    gw = (g + 31) // 32
+    pool = torch.empty(synth.NB_GENOMES * gw, dtype=torch.int64, device=dev)
+    rc = lib.simka_synth_genomes(None, pool.data_ptr(), synth.NB_GENOMES, gw, synth.POOL_SEED)
+    assert rc == 0
+    nw = (R * L + 31) // 32
+    reads = []
+    for s in range(n):
+        ids, cdf = synth.sample_profile(s)
+        d_ids = torch.from_numpy(ids.astype(np.int32)).to(dev)
+        d_cdf = torch.from_numpy(cdf.view(np.int32)).to(dev)
+        t = torch.zeros(nw + 2, dtype=torch.int64, device=dev)
+        rc = lib.simka_synth_reads(None, t.data_ptr(), R, L, pool.data_ptr(), gw, g, d_ids.data_ptr(), d_cdf.data_ptr(),
+                                   synth.NB_SEL, synth.sample_seed(s), synth.ERR_THRESHOLD16)
+        assert rc == 0
+        torch.cuda.synchronize()
+        reads.append(t)
+    return pool, reads
+
+
+def cpu_baseline(wl, lib, torch, dev, seconds_budget=15.0):
+    """The oracle (CPU restatement of Simka's algorithm, kind="port") timed on a BOUNDED sample of the same
+    workload: same generator, same coverage model, fewer samples / reads (generated on the GPU, then downloaded)."""
+    import subprocess
+    subprocess.run(["make", "-s", "-C", os.path.join(ROOT, "oracle")], check=True)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_lib
+    from simka_amd import synth
+    cores = os.cpu_count() or 1
+    n = min(wl["n"], max(2, min(cores, 32)))
+    threads = min(cores, 64)
+    L, k = wl["L"], wl["k"]
+    # the oracle sustains ~2.5M k-mer occurrences per core-second (sort-count + heap merge)
+    R = int(min(wl["reads"], max(2000, seconds_budget * 2.5e6 * min(threads, n) / (n * (L - k + 1)))))
+    sub = dict(wl, n=n, reads=R)
+    _, reads = gen_device_samples(lib, torch, sub, dev)
+    o = oracle_lib.Oracle()
+    offs = np.arange(R + 1, dtype=np.uint64) * L
+    for s in range(n):
+        pk = reads[s].cpu().numpy().view(np.uint64)
+        o.add_sample_ascii("S%d" % s, synth.unpack_ascii(pk[: (R * L + 31) // 32], R * L), offs)
+    del reads
+    t0 = time.perf_counter()
+    o.run(k, wl["amin"], simple=wl["simple"], nparts=max(threads * 4, 1), threads=threads)
+    for w in range(len(o.matrix_names())):
+        if w < 15 or (wl["simple"] and w < 18):
+            o.matrix(w)
+    dt = time.perf_counter() - t0
+    tot = o.totals()
+    return {"value": float(tot["D_all"].sum()) / dt, "unit": "distinct k-mers/s", "cores": threads, "kind": "port",
+            "sample": "%d samples x %d reads x %d bp, k=%d, same generator/coverage (%.1f s CPU wall, %.3g k-mer occurrences/s)" %
+                      (n, R, L, k, dt, float(tot["K_occ"].sum()) / dt),
+            "seconds": dt}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--workload", default=os.environ.get("SIMKA_BENCH_WORKLOAD", "c2"), choices=sorted(WORKLOADS))
+    ap.add_argument("--reads", type=int, default=0, help="override reads per sample")
+    ap.add_argument("--samples", type=int, default=0, help="override number of samples")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--log2-partitions", type=int, default=0)
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    import simka_amd
+    from simka_amd import dist as sdist
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device: the simka_amd path has no CPU fallback")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    wl = dict(WORKLOADS[args.workload])
+    if args.reads:
+        wl["reads"] = args.reads
+    if args.samples:
+        wl["n"] = args.samples
+    n, R, L, k = wl["n"], wl["reads"], wl["L"], wl["k"]
+    lib = simka_amd.load_library()
+    pool, reads = gen_device_samples(lib, torch, wl, dev)
+    nb_bases = R * L
+    kocc_per_sample = R * (L - k + 1)
+
+    ctx = simka_amd.SimkaContext(n, kmer_size=k, abundance_min=wl["amin"], simple_dist=wl["simple"], device=local,
+                                 shard_index=rank, shard_count=world, max_kmers_per_sample=kocc_per_sample,
+                                 log2_partitions=args.log2_partitions)
+
+    def step():
+        ctx.reset()
+        for s in range(n):
+            ctx.count_sample(s, reads[s].data_ptr(), nb_bases, R, fixed_len=L, on_device=True)
+        ctx.merge()
+        sdist.allreduce_stats_device(ctx)          # one RCCL all-reduce of the flat u64 accumulators (no-op at N=1)
+        st = ctx.stats()
+        mats = st.matrices()
+        return st, mats
+
+    for _ in range(args.warmup):
+        step()
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    ctx.profile_reset()
+    ctx.profile_enable(True)
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        st, mats = step()
+    fence()
+    dt = time.perf_counter() - t0
+    ctx.profile_enable(False)
+    if world > 1:
+        tdt = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(tdt, op=dist.ReduceOp.MAX)
+        dt = float(tdt.item())
+    prof = ctx.profile()
+    geo = ctx.geometry()
+
+    ps = st.per_sample()
+    K_dist = float(ps["D_all"].sum())     # distinct canonical k-mers before the filter, summed over samples (whole job)
+    K_occ = float(ps["K_occ"].sum())
+    K_solid = float(ps["D"].sum())
+    ms_per_step = dt / args.steps * 1e3
+    value = K_dist / (dt / args.steps)
+
+    # ---- roofline (DESIGN.md "Algorithmic bytes"): SURVEY 8(d) terms attributed to the kernel that moves them
+    share = 1.0 / world                    # each rank owns 1/world of the key space
+    alg_bytes_per_step = {
+        "k_scan<hist>": n * nb_bases / 4.0,
+        "k_scan<scatter>": n * nb_bases / 4.0 + 8.0 * K_occ * share,
+        "k_split": 0.0,
+        "k_count": 8.0 * K_occ * share + 12.0 * K_dist * share,
+        "k_regroup": 12.0 * K_solid * share,
+        "k_group": 0.0, "k_pairs": 0.0, "k_layout": 0.0, "k_part_totals": 0.0, "k_reduce_slabs": 0.0,
+    }
+    kern_ms = {kname: ms for kname, (cnt, ms) in prof.items()}
+    total_kernel_ms = sum(kern_ms.values())
+    dom = max(kern_ms, key=lambda kk: kern_ms[kk])
+    dom_launches, dom_ms = prof[dom]
+    dom_bytes_per_launch = alg_bytes_per_step.get(dom, 0.0) * args.steps / max(dom_launches, 1)
+    dom_avg_ms = dom_ms / max(dom_launches, 1)
+    achieved = dom_bytes_per_launch / (dom_avg_ms * 1e-3) / 1e9 if dom_avg_ms > 0 else 0.0
+    b_alg = (n * nb_bases / 4.0 + 16.0 * K_occ + 12.0 * K_dist + 12.0 * K_solid) * share
+    path_gbs = b_alg * args.steps / (total_kernel_ms * 1e-3) / 1e9 if total_kernel_ms > 0 else 0.0
+    roofline = {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                "avg_launch_ms": dom_avg_ms, "launches": dom_launches, "alg_bytes_per_launch": dom_bytes_per_launch,
+                "path_achieved": path_gbs, "path_frac": path_gbs / HBM_PEAK_GBS, "path_alg_bytes_per_step": b_alg,
+                "kernel_ms_per_step": {kk: v / args.steps for kk, v in kern_ms.items()}}
+
+    out = {
+        "metric": "distinct k-mers/s end-to-end (count + merge + N x N matrices)", "value": value, "unit": "distinct k-mers/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
+        "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "u64", "data": "synthetic",
+        "config": {"workload": "%s: %s" % (args.workload, wl["desc"]), "samples": n, "reads_per_sample": R, "read_len": L,
+                   "kmer_size": k, "abundance_min": wl["amin"], "simple_dist": wl["simple"],
+                   "parallelism": "partition shards x%d + 1 all-reduce" % world if world > 1 else "1 GPU",
+                   "kmer_occurrences": K_occ, "distinct_kmers": K_dist, "solid_kmers": K_solid,
+                   "kmer_occurrences_per_s": K_occ / (dt / args.steps), "geometry": geo},
+        "roofline": roofline,
+    }
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        try:
+            out["cpu_baseline"] = cpu_baseline(wl, lib, torch, dev)
+        except Exception as e:       # the baseline is a report, never a reason to lose the GPU number
+            out["cpu_baseline"] = {"value": None, "unit": "distinct k-mers/s", "cores": os.cpu_count(), "kind": "port",
+                                   "sample": "failed: %r" % (e,)}
+    if rank == 0:
+        print(json.dumps(out))
+    ctx.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

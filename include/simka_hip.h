@@ -117,6 +117,9 @@ void simka_destroy(simka_ctx *ctx);
 const char *simka_last_error(const simka_ctx *ctx);
 /* block until everything issued on the ctx's stream has finished */
 int  simka_sync(simka_ctx *ctx);
+/* forget all samples and zero the accumulators, keeping every device allocation (a new job with the
+ * same configuration; the reference's equivalent is wiping -out-tmp, ref: src/SimkaPotara.hpp:288-325) */
+int  simka_reset(simka_ctx *ctx);
 
 /* ---- count side ---------------------------------------------------------------------------
  * Replaces one `simkaCount` job: gatb SortingCountAlgorithm (k-mer extraction, canonical 2-bit

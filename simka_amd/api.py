@@ -76,6 +76,7 @@ def load_library(build_if_missing=True):
         "simka_destroy": (None, [vp]),
         "simka_last_error": (C.c_char_p, [vp]),
         "simka_sync": (i32, [vp]),
+        "simka_reset": (i32, [vp]),
         "simka_count_sample": (i32, [vp, u32, C.POINTER(Reads)]),
         "simka_get_sample_totals": (i32, [vp, u32, C.POINTER(SampleTotals)]),
         "simka_merge": (i32, [vp]),
@@ -131,7 +132,8 @@ class Stats:
 
     def per_sample(self):
         n = self.nb_samples
-        return {"D": self._arr(self.view.nb_distinct, n), "N": self._arr(self.view.nb_kmers, n), "Q": self._arr(self.view.sum_sq, n)}
+        return {"D": self._arr(self.view.nb_distinct, n), "N": self._arr(self.view.nb_kmers, n), "Q": self._arr(self.view.sum_sq, n),
+                "D_all": self.flat[8 + 3 * n: 8 + 4 * n].copy(), "K_occ": self.flat[8 + 4 * n: 8 + 5 * n].copy()}
 
     def pairs(self):
         p = int(self.view.nb_pairs)
@@ -266,6 +268,9 @@ class SimkaContext:
 
     def sync(self):
         self._check(self.lib.simka_sync(self.h))
+
+    def reset(self):
+        self._check(self.lib.simka_reset(self.h))
 
     def stats_device_buffer(self):
         p = C.c_void_p()

@@ -268,6 +268,23 @@ SIMKA_EXPORT int simka_sync(simka_ctx *ctx) {
     return SIMKA_OK;
 }
 
+SIMKA_EXPORT int simka_reset(simka_ctx *ctx) {
+    if (!ctx) return SIMKA_ERR_INVALID;
+    HIPCHK(hipSetDevice(ctx->cfg.device));
+    const uint32_t N = ctx->cfg.nb_samples;
+    HIPCHK(hipMemsetAsync(ctx->d_stats, 0, ctx->stats_n * 8, ctx->stream));
+    HIPCHK(hipMemsetAsync(ctx->d_err, 0, 16, ctx->stream));
+    HIPCHK(hipMemsetAsync(ctx->d_arena_cursor, 0, 16, ctx->stream));
+    if (ctx->geometry_ready) {
+        HIPCHK(hipMemsetAsync(ctx->d_foff, 0, (uint64_t)N * ctx->nparts * 4, ctx->stream));
+        HIPCHK(hipMemsetAsync(ctx->d_fcnt, 0, (uint64_t)N * ctx->nparts * 4, ctx->stream));
+    }
+    std::fill(ctx->counted.begin(), ctx->counted.end(), 0);
+    std::fill(ctx->nb_reads.begin(), ctx->nb_reads.end(), 0);
+    ctx->merged = false;
+    return SIMKA_OK;
+}
+
 static int check_device_error(simka_ctx *ctx) {
     uint32_t e = 0;
     HIPCHK(hipMemcpyAsync(&e, ctx->d_err, 4, hipMemcpyDeviceToHost, ctx->stream));
