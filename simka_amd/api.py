@@ -63,6 +63,12 @@ def load_library(build_if_missing=True):
     global _lib
     if _lib is not None:
         return _lib
+    try:
+        # torch wheels bundle their own libamdhip64: import it FIRST so that this process ends up with a single
+        # HIP runtime (loading /opt/rocm's copy before torch's leaves two runtimes fighting over the device)
+        import torch  # noqa: F401
+    except Exception:
+        pass
     path = _build.LIB_PATH
     if build_if_missing and not os.path.exists(path):
         _build.build()

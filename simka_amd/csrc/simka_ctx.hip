@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 #include <stdarg.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 #include <string>
 #include <vector>
@@ -163,9 +164,10 @@ static int setup_geometry(simka_ctx *ctx, uint64_t max_kmers) {
     if (pb > 20) pb = 20;
     if (pb > k.W) pb = k.W;
     uint32_t l1 = (pb + 1) / 2;
+    if (getenv("SIMKA_L1")) l1 = std::min<uint32_t>(pb, (uint32_t)atoi(getenv("SIMKA_L1")));   // experiments
     const uint32_t min_l1 = std::min<uint32_t>(pb, ceil_log2_u64(c.shard_count));   // shards are level-1 buckets
     if (l1 < min_l1) l1 = min_l1;
-    if (l1 > 10) l1 = 10;
+    if (l1 > 11) l1 = 11;
     uint32_t l2 = pb - l1;
     if (l2 > 10) { l2 = 10; }
     k.l1 = l1; k.l2 = l2; k.pb = l1 + l2; k.t = 0;
@@ -380,14 +382,25 @@ SIMKA_EXPORT int simka_count_sample(simka_ctx *ctx, uint32_t sample, const simka
     o.solid_keys = ctx->d_solid_keys; o.solid_counts = ctx->d_solid_counts;
     o.foff = ctx->d_foff + (uint64_t)sample * ctx->nparts; o.fcnt = ctx->d_fcnt + (uint64_t)sample * ctx->nparts;
     o.totals = (ull *)ctx->d_stats + stats_off_tot(N, 0); o.sample = sample; o.nb_samples = N; o.err = ctx->d_err;
-    // lanes per chunk segment ~ expected segment length (chunk / #level-2 buckets)
-    uint32_t gs_log2 = key.l2 ? ceil_log2_u64(std::max<uint32_t>(1, K2_CHUNK >> key.l2)) : 9;
-    gs_log2 = std::min<uint32_t>(std::max<uint32_t>(gs_log2, 2), 9);
-    const size_t lds_count = SIMKA_LDS_HEAD + (size_t)K2_TABLE * 12;
+    o.phase = nullptr;
+#ifdef SIMKA_PHASE_PROF
+    static ull *d_phase = nullptr;
+    if (!d_phase) { hipMalloc((void **)&d_phase, 64); hipMemset(d_phase, 0, 64); }
+    o.phase = d_phase;
+    if (sample == N - 1) {
+        ull hph[6]; hipStreamSynchronize(ctx->stream); hipMemcpy(hph, d_phase, 48, hipMemcpyDeviceToHost);
+        fprintf(stderr, "[phase] clear %llu meta %llu keys %llu stats %llu emit %llu tail %llu (wall_clock64 ticks, summed over blocks, samples so far)\n", hph[0], hph[1], hph[2], hph[3], hph[4], hph[5]);
+    }
+#endif
+    // tuning knobs (experiments): table size and resident blocks per CU
+    static const uint32_t tlog = getenv("SIMKA_K2_TABLE_LOG2") ? (uint32_t)atoi(getenv("SIMKA_K2_TABLE_LOG2")) : (uint32_t)K2_TABLE_LOG2;
+    const size_t lds_count = SIMKA_LDS_HEAD + ((size_t)12 << tlog) + (size_t)(2 * K2_MAXSEG + 1) * 4;
+    static const uint32_t bpc = getenv("SIMKA_K2_BLOCKS_PER_CU") ? (uint32_t)atoi(getenv("SIMKA_K2_BLOCKS_PER_CU")) : (uint32_t)std::max<size_t>(1, (160 * 1024) / lds_count);
     launch_timed(ctx, KID_COUNT, [&] {
-        hipLaunchKernelGGL(k_count, dim3((uint32_t)ctx->nparts), dim3(K2_BLOCK), lds_count, ctx->stream, ctx->d_l1,
-                           ctx->d_b1_start, ctx->d_chunk_first, ctx->d_chunk_off, key, gs_log2, ctx->cfg.abundance_min,
-                           ctx->cfg.abundance_max, o);
+        const uint32_t grid_count = (uint32_t)std::min<uint64_t>(ctx->nparts, (uint64_t)ctx->num_cus * bpc);
+        hipLaunchKernelGGL(k_count, dim3(grid_count), dim3(K2C_BLOCK), lds_count, ctx->stream, ctx->d_l1,
+                           ctx->d_b1_start, ctx->d_chunk_first, ctx->d_chunk_off, key, tlog,
+                           ctx->cfg.abundance_min, ctx->cfg.abundance_max, o);
     });
     HIPCHK(hipGetLastError());
     return SIMKA_OK;

@@ -10,9 +10,17 @@
 #define K1_BLOCK 512          // 8 waves
 #define K1_SEG 16             // k-mer start positions per thread (window = SEG + k - 1 <= 64 bases)
 // K2  k_split / k_count
-#define K2_BLOCK 512
+#define K2_BLOCK 512          // k_split
+#define K2C_BLOCK 256         // k_count
 #define K2_CHUNK 8192         // keys per chunk (fits u16 offsets, 64 KB LDS stage)
-#define K2_TABLE 8192         // LDS hash-table slots per partition (64 KB keys + 32 KB counts)
+#define K2_TABLE_LOG2 11      // LDS hash-table slots per partition: 4096 (32 KB keys + 16 KB counts) -> 3 blocks/CU
+#define K2_TABLE (1 << K2_TABLE_LOG2)
+#define K2_MAXSEG 512         // chunk segments gathered per batch in k_count
+#define K2_SLAB 2048          // arena records reserved per global atomic by a k_count block
+#ifndef K2_UNROLL
+#define K2_UNROLL 8
+#endif
+//          // independent key loads in flight per thread
 #define SIMKA_TARGET_PER_PART 4096   // sizing: k-mer occurrences per partition (<= 50% table load even if all distinct)
 // K3  k_regroup / k_group
 #define K3_BLOCK 256
@@ -62,6 +70,7 @@ struct SimkaCountOut {
     unsigned long long *totals;              // [SIMKA_NB_TOTALS][N]
     uint32_t sample, nb_samples;
     uint32_t *err;
+    unsigned long long *phase;               // debug phase timers (SIMKA_PHASE_PROF builds), else NULL
 };
 
 struct SimkaMergeIn {

@@ -33,23 +33,26 @@ typedef unsigned long long ull;
 // --------------------------------------------------------------------------------------------
 template <int BLOCK>
 __device__ __forceinline__ uint32_t block_excl_scan(uint32_t *a, uint32_t n, uint32_t *tmp) {
-    const uint32_t tid = threadIdx.x;
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    constexpr uint32_t NW = BLOCK / 64;
     const uint32_t ipt = (n + BLOCK - 1) / BLOCK;
     const uint32_t b = tid * ipt;
     const uint32_t e = (b + ipt < n) ? b + ipt : n;
     uint32_t s = 0;
     for (uint32_t i = b; i < e; i++) s += a[i];
-    tmp[tid] = s;
-    __syncthreads();
-    for (uint32_t off = 1; off < BLOCK; off <<= 1) {
-        uint32_t v = (tid >= off) ? tmp[tid - off] : 0u;
-        __syncthreads();
-        tmp[tid] += v;
-        __syncthreads();
+    uint32_t v = s;                                   // inclusive scan across the 64 lanes of the wave
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t t = __shfl_up(v, o, 64);
+        if (lane >= (uint32_t)o) v += t;
     }
-    const uint32_t total = tmp[BLOCK - 1];
-    uint32_t run = tmp[tid] - s;
-    for (uint32_t i = b; i < e; i++) { uint32_t v = a[i]; a[i] = run; run += v; }
+    if (lane == 63u) tmp[wave] = v;
+    __syncthreads();
+    uint32_t wpre = 0, total = 0;
+#pragma unroll
+    for (uint32_t w = 0; w < NW; w++) { const uint32_t t = tmp[w]; if (w < wave) wpre += t; total += t; }
+    uint32_t run = wpre + v - s;
+    for (uint32_t i = b; i < e; i++) { const uint32_t x = a[i]; a[i] = run; run += x; }
     __syncthreads();
     return total;
 }
@@ -266,95 +269,227 @@ k_split(uint64_t *l1_keys, const ull *b1_start, const uint32_t *chunk_first, uin
 // (ref: src/minikc/MiniKC.hpp:54-79): abundance filter, emit (k-mer,count), nbDistinct++,
 // nbKmers+=c, chord+=c^2.  Records go to the HBM arena; the reference gzips them to
 // solid/part_<p>/__p__<i>.gz.
+//
+// Loads are made independent before they are issued: the segment bounds of every chunk are
+// gathered in parallel and prefix-summed in LDS, then each thread walks FLAT key indices, so a
+// block keeps BLOCK x UNROLL global loads in flight.  A table that fills up (more distinct keys
+// than slots) is handled by re-running the partition in 2,4,.. rounds on extra key bits.
 // --------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(K2_BLOCK)
+__device__ __forceinline__ bool table_insert(ull *tkeys, uint32_t *tcnt, uint32_t tmask, ull key) {
+    uint32_t slot = simka_slot_hash(key) & tmask;
+    for (uint32_t probe = 0; probe <= tmask; probe++) {
+        const ull prev = atomicCAS(&tkeys[slot], SIMKA_EMPTY_KEY, key);
+        if (prev == SIMKA_EMPTY_KEY || prev == key) { atomicAdd(&tcnt[slot], 1u); return true; }
+        slot = (slot + 1u) & tmask;
+    }
+    return false;
+}
+
+// reserve `ns` arena records for one partition out of the block's private slab (thread 0 only)
+__device__ __forceinline__ ull slab_take(ull &slab_pos, ull &slab_end, uint32_t ns, const SimkaCountOut &o, ull sample_base, uint32_t &ok) {
+    if (slab_pos + ns > slab_end) {
+        const ull want = ns > (uint32_t)K2_SLAB ? (ull)ns : (ull)K2_SLAB;
+        slab_pos = atomicAdd(o.arena_cursor, want);
+        slab_end = slab_pos + want;
+        if (slab_end > o.arena_cap) { atomicOr(o.err, SIMKA_DEVERR_ARENA_FULL); ok = 0; slab_end = slab_pos; return 0; }
+    }
+    const ull b = slab_pos;
+    slab_pos += ns;
+    if (b - sample_base + ns > 0xffffffffull) { atomicOr(o.err, SIMKA_DEVERR_SAMPLE_TOO_BIG); ok = 0; }
+    return b;
+}
+
+__global__ void __launch_bounds__(K2C_BLOCK)
 k_count(const uint64_t *l1_keys, const ull *b1_start, const uint32_t *chunk_first, const uint16_t *chunk_off,
-        SimkaKeyCfg cfg, uint32_t gs_log2, uint32_t amin, uint32_t amax, SimkaCountOut o) {
+        SimkaKeyCfg cfg, uint32_t table_log2, uint32_t amin, uint32_t amax, SimkaCountOut o) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    ull *s_tot = (ull *)smem;                         // [4] D_all, D, N, Q
+    ull *s_tot = (ull *)smem;                         // [4] D_all, D, N, Q of the whole block
     ull &s_base = *(ull *)(smem + 32);
-    uint32_t &s_nsolid = *(uint32_t *)(smem + 40);
-    uint32_t &s_cur = *(uint32_t *)(smem + 44);
-    uint32_t &s_ovf = *(uint32_t *)(smem + 48);
-    ull *tkeys = (ull *)(smem + SIMKA_LDS_HEAD);      // [K2_TABLE]
-    uint32_t *tcnt = (uint32_t *)(tkeys + K2_TABLE);  // [K2_TABLE]
+    ull &s_slab_pos = *(ull *)(smem + 40);
+    ull &s_slab_end = *(ull *)(smem + 48);
+    uint32_t &s_nsolid = *(uint32_t *)(smem + 56);
+    uint32_t &s_cur = *(uint32_t *)(smem + 60);
+    uint32_t &s_ovf = *(uint32_t *)(smem + 64);
+    uint32_t *tmp = (uint32_t *)(smem + 128);         // [K2C_BLOCK/64] scan scratch
+    const uint32_t TS = 1u << table_log2, tmask = TS - 1u;
+    ull *tkeys = (ull *)(smem + SIMKA_LDS_HEAD);      // [TS]
+    uint32_t *tcnt = (uint32_t *)(tkeys + TS);        // [TS]
+    uint32_t *segpre = tcnt + TS;                     // [K2_MAXSEG+1] flat index of each chunk's segment
+    uint32_t *segbeg = segpre + K2_MAXSEG + 1;        // [K2_MAXSEG]   first key of the segment inside its chunk
 
     const uint32_t B2 = 1u << cfg.l2;
-    const uint32_t part = blockIdx.x;
-    const uint32_t b1 = part >> cfg.l2, b2 = part & (B2 - 1u);
-    if (!simka_owns_l1(b1, cfg)) return;
+    const uint32_t nparts = 1u << cfg.pb;
     const uint32_t tid = threadIdx.x;
-    for (uint32_t i = tid; i < K2_TABLE; i += K2_BLOCK) { tkeys[i] = SIMKA_EMPTY_KEY; tcnt[i] = 0; }
+    const uint32_t free_bits = cfg.W - cfg.pb;
     if (tid < 4) s_tot[tid] = 0;
-    if (tid == 0) { s_nsolid = 0; s_cur = 0; s_ovf = 0; }
-    __syncthreads();
+    if (tid == 0) { s_slab_pos = 0; s_slab_end = 0; }
+    ull bt_dall = 0, bt_D = 0, bt_N = 0, bt_Q = 0;     // per-thread totals over all partitions of this block
+    const ull sample_base = *o.sample_base;
+#ifdef SIMKA_PHASE_PROF
+    ull ph[6] = {0, 0, 0, 0, 0, 0}; ull t_prev = wall_clock64();
+#define PH(i) do { __syncthreads(); const ull t_now = wall_clock64(); ph[i] += t_now - t_prev; t_prev = t_now; } while (0)
+#else
+#define PH(i) do { } while (0)
+#endif
 
-    // ---- stream the keys of partition (b1,b2): segment b2 of every chunk of bucket b1
-    const uint32_t c0 = chunk_first[b1], c1 = chunk_first[b1 + 1];
-    const ull base = b1_start[b1], bend = b1_start[b1 + 1];
-    const uint32_t GS = 1u << gs_log2;
-    const uint32_t g = tid >> gs_log2, lane = tid & (GS - 1u), ngroups = K2_BLOCK >> gs_log2;
-    for (uint32_t c = c0 + g; c < c1; c += ngroups) {
-        const ull cbase = base + (ull)(c - c0) * K2_CHUNK;
-        uint32_t s, e;
-        if (cfg.l2 == 0) { s = 0; e = (uint32_t)((bend - cbase < (ull)K2_CHUNK) ? (bend - cbase) : (ull)K2_CHUNK); }
-        else { const uint16_t *co = chunk_off + (size_t)c * (B2 + 1); s = co[b2]; e = co[b2 + 1]; }
-        for (uint32_t i = s + lane; i < e; i += GS) {
-            const ull key = l1_keys[cbase + i];
-            uint32_t slot = simka_slot_hash(key) & (K2_TABLE - 1u);
-            uint32_t probe = 0;
-            for (; probe < K2_TABLE; probe++) {
-                const ull prev = atomicCAS(&tkeys[slot], SIMKA_EMPTY_KEY, key);
-                if (prev == SIMKA_EMPTY_KEY || prev == key) { atomicAdd(&tcnt[slot], 1u); break; }
-                slot = (slot + 1u) & (K2_TABLE - 1u);
+    // persistent block: partitions blockIdx.x, +gridDim.x, ...  (neighbouring blocks work on neighbouring
+    // level-2 columns of the same level-1 bucket, so the chunk-offset rows stay hot in L2)
+    for (uint32_t part = blockIdx.x; part < nparts; part += gridDim.x) {
+        const uint32_t b1 = part >> cfg.l2, b2 = part & (B2 - 1u);
+        if (!simka_owns_l1(b1, cfg)) continue;
+        const uint32_t c0 = chunk_first[b1], c1 = chunk_first[b1 + 1];
+        const ull base = b1_start[b1], bend = b1_start[b1 + 1];
+        __syncthreads();
+        if (tid == 0) { s_nsolid = 0; s_cur = 0; s_ovf = 0; }
+
+        // rounds: 1 unless the table overflows.  pass 0 counts (and emits when there is one round), pass 1 emits.
+        uint32_t nr_log2 = 0;
+        ull emit_base = 0;
+        bool part_done = false;
+        for (int pass = 0; pass < 2 && !part_done; pass++) {
+            bool restart = false;
+            ull dall = 0, D = 0, N = 0, Q = 0;
+            for (uint32_t r = 0; r < (1u << nr_log2); r++) {
+                __syncthreads();
+                {   // clear the table with 16-byte LDS stores
+                    ulonglong2 *k2 = (ulonglong2 *)tkeys; uint4 *c4 = (uint4 *)tcnt;
+                    const ulonglong2 ek = make_ulonglong2(SIMKA_EMPTY_KEY, SIMKA_EMPTY_KEY);
+                    const uint4 z = make_uint4(0, 0, 0, 0);
+                    for (uint32_t i = tid; i < TS / 2; i += K2C_BLOCK) k2[i] = ek;
+                    for (uint32_t i = tid; i < TS / 4; i += K2C_BLOCK) c4[i] = z;
+                }
+                PH(0);
+                // stream the chunks of bucket b1 in batches of K2_MAXSEG chunks
+                for (uint32_t cb = c0; cb < c1; cb += K2_MAXSEG) {
+                    const uint32_t nch = (c1 - cb < (uint32_t)K2_MAXSEG) ? c1 - cb : (uint32_t)K2_MAXSEG;
+                    __syncthreads();
+                    for (uint32_t i = tid; i < nch; i += K2C_BLOCK) {
+                        const uint32_t c = cb + i;
+                        uint32_t sb, se;
+                        if (cfg.l2 == 0) {
+                            const ull cbase = base + (ull)(c - c0) * K2_CHUNK;
+                            sb = 0; se = (uint32_t)((bend - cbase < (ull)K2_CHUNK) ? (bend - cbase) : (ull)K2_CHUNK);
+                        } else {
+                            const uint16_t *co = chunk_off + (size_t)c * (B2 + 1) + b2;
+                            sb = co[0]; se = co[1];
+                        }
+                        segbeg[i] = sb; segpre[i] = se - sb;
+                    }
+                    __syncthreads();
+                    const uint32_t n = block_excl_scan<K2C_BLOCK>(segpre, nch, tmp);
+                    if (tid == 0) segpre[nch] = n;
+                    __syncthreads();
+                    PH(1);
+                    for (uint32_t i0 = tid; i0 < n; i0 += K2C_BLOCK * K2_UNROLL) {
+                        ull keyv[K2_UNROLL];
+#pragma unroll
+                        for (int u = 0; u < K2_UNROLL; u++) {
+                            const uint32_t i = i0 + (uint32_t)u * K2C_BLOCK;
+                            keyv[u] = SIMKA_EMPTY_KEY;
+                            if (i < n) {
+                                uint32_t lo = 0, hi = nch;       // largest ch with segpre[ch] <= i
+                                while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (segpre[mid] <= i) lo = mid; else hi = mid; }
+                                const ull addr = base + (ull)(cb - c0 + lo) * K2_CHUNK + segbeg[lo] + (i - segpre[lo]);
+                                keyv[u] = l1_keys[addr];
+                            }
+                        }
+#pragma unroll
+                        for (int u = 0; u < K2_UNROLL; u++) {
+                            const ull key = keyv[u];
+                            if (key == SIMKA_EMPTY_KEY) continue;
+                            if (nr_log2 && (uint32_t)((key >> (free_bits - nr_log2)) & ((1ull << nr_log2) - 1ull)) != r) continue;
+                            if (!table_insert(tkeys, tcnt, tmask, key)) s_ovf = 1;
+                        }
+                    }
+                }
+                __syncthreads();
+                PH(2);
+                if (s_ovf) { restart = true; break; }
+                if (pass == 0) {
+                    // SimkaCompressedProcessor::process over the table
+                    const uint4 *c4 = (const uint4 *)tcnt;
+                    for (uint32_t i = tid; i < TS / 4; i += K2C_BLOCK) {
+                        const uint4 q = c4[i];
+                        const uint32_t cs[4] = { q.x, q.y, q.z, q.w };
+#pragma unroll
+                        for (int j = 0; j < 4; j++) {
+                            const uint32_t c = cs[j];
+                            if (c) { dall++; if (!(c < amin || c > amax)) { D++; N += c; Q += (ull)c * (ull)c; } }
+                        }
+                    }
+                    if (nr_log2 == 0) {   // single round: reserve now, emit from the live table
+                        if (D) atomicAdd(&s_nsolid, (uint32_t)D);
+                        __syncthreads();
+                        if (tid == 0) {
+                            const uint32_t ns = s_nsolid;
+                            uint32_t ok = 1;
+                            const ull bb = ns ? slab_take(s_slab_pos, s_slab_end, ns, o, sample_base, ok) : sample_base;
+                            o.foff[part] = ok ? (uint32_t)(bb - sample_base) : 0u;
+                            o.fcnt[part] = ok ? ns : 0u;
+                            s_base = bb; s_ovf = ok ? 0u : 2u;
+                        }
+                        __syncthreads();
+                        emit_base = s_base;
+                    }
+                }
+                PH(3);
+                if ((pass == 1 || nr_log2 == 0) && s_ovf != 2u) {
+                    const uint4 *c4 = (const uint4 *)tcnt;
+                    for (uint32_t i = tid; i < TS / 4; i += K2C_BLOCK) {
+                        const uint4 q = c4[i];
+                        const uint32_t cs[4] = { q.x, q.y, q.z, q.w };
+#pragma unroll
+                        for (int j = 0; j < 4; j++) {
+                            const uint32_t c = cs[j];
+                            if (c && !(c < amin || c > amax)) {
+                                const uint32_t pos = atomicAdd(&s_cur, 1u);
+                                o.solid_keys[emit_base + pos] = tkeys[i * 4 + j];
+                                o.solid_counts[emit_base + pos] = c;
+                            }
+                        }
+                    }
+                }
             }
-            if (probe == K2_TABLE) s_ovf = 1;
+            PH(4);
+            if (restart) {
+                __syncthreads();
+                if (nr_log2 >= free_bits || nr_log2 >= 12) { if (tid == 0) atomicOr(o.err, SIMKA_DEVERR_TABLE_OVERFLOW); part_done = true; continue; }
+                if (tid == 0) s_ovf = 0;
+                nr_log2++; pass = -1;       // start over with twice the rounds (nothing was emitted yet)
+                continue;
+            }
+            if (pass == 0) {
+                bt_dall += dall; bt_D += D; bt_N += N; bt_Q += Q;
+                if (nr_log2 == 0) { part_done = true; continue; }     // single round: already emitted
+                // multi-round: reserve the arena space for all rounds, then run the emitting pass
+                if (D) atomicAdd(&s_nsolid, (uint32_t)D);
+                __syncthreads();
+                if (tid == 0) {
+                    const uint32_t ns = s_nsolid;
+                    uint32_t ok = 1;
+                    const ull bb = ns ? slab_take(s_slab_pos, s_slab_end, ns, o, sample_base, ok) : sample_base;
+                    o.foff[part] = ok ? (uint32_t)(bb - sample_base) : 0u;
+                    o.fcnt[part] = ok ? ns : 0u;
+                    s_base = bb; s_ovf = ok ? 0u : 2u;
+                }
+                __syncthreads();
+                if (s_ovf == 2u || s_nsolid == 0) { part_done = true; continue; }
+                emit_base = s_base;
+            }
         }
     }
+#ifdef SIMKA_PHASE_PROF
+    if (tid == 0 && o.phase) for (int i = 0; i < 6; i++) atomicAdd(&o.phase[i], ph[i]);
+#endif
+    // block totals -> per-sample totals (column layout: totals[T * nb_samples + sample]); one set of atomics per block
+    if (bt_dall) atomicAdd(&s_tot[0], bt_dall);
+    if (bt_D) { atomicAdd(&s_tot[1], bt_D); atomicAdd(&s_tot[2], bt_N); atomicAdd(&s_tot[3], bt_Q); }
     __syncthreads();
-    if (s_ovf) { if (tid == 0) atomicOr(o.err, SIMKA_DEVERR_TABLE_OVERFLOW); return; }
-
-    // ---- filter + totals
-    ull dall = 0, D = 0, N = 0, Q = 0;
-    for (uint32_t i = tid; i < K2_TABLE; i += K2_BLOCK) {
-        const uint32_t c = tcnt[i];
-        if (c) {
-            dall++;
-            if (!(c < amin || c > amax)) { D++; N += c; Q += (ull)c * (ull)c; }
-        }
-    }
-    if (dall) atomicAdd(&s_tot[0], dall);
-    if (D) { atomicAdd(&s_tot[1], D); atomicAdd(&s_tot[2], N); atomicAdd(&s_tot[3], Q); atomicAdd(&s_nsolid, (uint32_t)D); }
-    __syncthreads();
-    const uint32_t nsolid = s_nsolid;
     if (tid == 0) {
-        ull *t = o.totals + o.sample;   // column layout: totals[T * nb_samples + sample]
-        const size_t ns = o.nb_samples;
-        if (s_tot[0]) atomicAdd(&t[SIMKA_TOT_DALL * ns], s_tot[0]);
-        if (s_tot[1]) { atomicAdd(&t[SIMKA_TOT_D * ns], s_tot[1]); atomicAdd(&t[SIMKA_TOT_N * ns], s_tot[2]); atomicAdd(&t[SIMKA_TOT_Q * ns], s_tot[3]); }
-        ull b = 0;
-        uint32_t ok = 1;
-        if (nsolid) {
-            b = atomicAdd(o.arena_cursor, (ull)nsolid);
-            const ull rel = b - *o.sample_base;
-            if (b + nsolid > o.arena_cap) { atomicOr(o.err, SIMKA_DEVERR_ARENA_FULL); ok = 0; }
-            else if (rel + nsolid > 0xffffffffull) { atomicOr(o.err, SIMKA_DEVERR_SAMPLE_TOO_BIG); ok = 0; }
-            o.foff[part] = (uint32_t)rel;
-        } else o.foff[part] = 0;
-        o.fcnt[part] = ok ? nsolid : 0u;
-        s_base = b;
-        s_ovf = ok ? 0u : 1u;
-    }
-    __syncthreads();
-    if (s_ovf || nsolid == 0) return;
-    const ull ab = s_base;
-    for (uint32_t i = tid; i < K2_TABLE; i += K2_BLOCK) {
-        const uint32_t c = tcnt[i];
-        if (c && !(c < amin || c > amax)) {
-            const uint32_t pos = atomicAdd(&s_cur, 1u);
-            o.solid_keys[ab + pos] = tkeys[i];
-            o.solid_counts[ab + pos] = c;
-        }
+        ull *t = o.totals + o.sample;
+        const size_t ns_ = o.nb_samples;
+        if (s_tot[0]) atomicAdd(&t[SIMKA_TOT_DALL * ns_], s_tot[0]);
+        if (s_tot[1]) { atomicAdd(&t[SIMKA_TOT_D * ns_], s_tot[1]); atomicAdd(&t[SIMKA_TOT_N * ns_], s_tot[2]); atomicAdd(&t[SIMKA_TOT_Q * ns_], s_tot[3]); }
     }
 }
 

@@ -99,6 +99,8 @@ def _synthetic(n_samples, nb_reads, read_len, seed_shift=0):
     (21, 2, 6, 3000, 100, {"log2_partitions": 6}),          # two-level partitioning (k_split path)
     (21, 2, 6, 3000, 100, {"log2_partitions": 4, "log2_subranges": 3}),
     (15, 2, 5, 2500, 80, {"log2_partitions": 3}),
+    (21, 2, 6, 3000, 100, {"log2_partitions": 2}),          # partitions far above the LDS table: multi-round k_count
+    (31, 1, 3, 3000, 120, {"log2_partitions": 1, "log2_subranges": 1}),   # ... and over-full k_group sub-ranges
 ])
 def test_synthetic_vs_oracle(gpu_required, oracle_mod, k, amin, n, R, L, kw):
     from simka_amd import synth
