@@ -1,0 +1,422 @@
+// simka_cli.cpp -- `simka`: drop-in host driver over the C ABI of libsimka_hip.so.
+//
+// Same command line, -in grammar and mat_*.csv.gz outputs as the reference driver
+// (ref: src/SimkaPotara.cpp:29-53,147-163, src/core/Simka.cpp:25-117, src/SimkaPotara.hpp:259-326).
+// Where the reference forks one simkaCount process per sample and one simkaMerge process per
+// partition and synchronises through files, this driver calls simka_count_sample() per sample and
+// simka_merge() once, on 1..G GPUs (partition shards), and sums the shards' accumulators.
+#include <errno.h>
+#include <math.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <sys/stat.h>
+#include <unistd.h>
+#include <zlib.h>
+
+#include <algorithm>
+#include <fstream>
+#include <iostream>
+#include <sstream>
+#include <string>
+#include <vector>
+
+#include "../../include/simka_hip.h"
+
+namespace {
+
+struct Options {
+    std::string in, out = "./simka_results", out_tmp;
+    bool keep_tmp = false, data_info = false, simple = false, complex_ = false;
+    int kmer_size = 21;
+    long long abundance_min = 2, abundance_max = 999999999LL;
+    double kmer_shannon = 0;            // parsed, no-op in the reference too (ref: src/core/SimkaAlgorithm.hpp:226-232)
+    long long max_reads = -1;           // -1 all, 0 estimate, m>0 first m reads per paired part
+    long long min_read_size = 0;
+    double min_shannon = 0;
+    int nb_cores = 0;
+    long long max_memory = 5000;
+    int verbose = 1;
+    int nb_gpus = 1, first_gpu = 0;     // new: devices to shard the partition space over
+};
+
+struct Sample {
+    std::string id;
+    std::vector<std::vector<std::string>> parts;   // ';'-separated paired parts, each a ','-list of files
+};
+
+[[noreturn]] void die(const std::string &msg, int code = 1) {
+    std::cerr << msg << std::endl;
+    exit(code);
+}
+
+bool exists(const std::string &p) { struct stat st; return stat(p.c_str(), &st) == 0; }
+
+void mkdir_p(const std::string &p) {
+    if (p.empty() || exists(p)) return;
+    const size_t slash = p.find_last_of('/');
+    if (slash != std::string::npos && slash > 0) mkdir_p(p.substr(0, slash));
+    if (mkdir(p.c_str(), 0777) != 0 && errno != EEXIST) die("Error: can't create output directory (" + p + ")");
+}
+
+void usage() {
+    std::cout <<
+        "[Simka options]\n"
+        "       -in               (1 arg) :    input file of samples. One sample per line: id1: filename1...\n"
+        "       -out              (1 arg) :    output directory for result files (distance matrices)  [default './simka_results']\n"
+        "       -out-tmp          (1 arg) :    output directory for temporary files\n"
+        "       -keep-tmp         (0 arg) :    keep temporary files\n"
+        "       -data-info        (0 arg) :    compute (and display) information before running Simka, such as the number of reads per dataset\n"
+        "   [distance options]\n"
+        "       -simple-dist      (0 arg) :    compute all simple distances (Chord, Hellinger...)\n"
+        "       -complex-dist     (0 arg) :    compute all complex distances (Jensen-Shannon...)\n"
+        "   [kmer options]\n"
+        "       -kmer-size        (1 arg) :    size of a kmer  [default '21']\n"
+        "       -abundance-min    (1 arg) :    min abundance a kmer need to be considered  [default '2']\n"
+        "       -abundance-max    (1 arg) :    max abundance a kmer can have to be considered  [default '999999999']\n"
+        "       -kmer-shannon-index (1 arg) :    minimal Shannon index a kmer should have to be kept. Float in [0,2]  [default '0']\n"
+        "   [read options]\n"
+        "       -max-reads        (1 arg) :    maximum number of reads per sample to process. Can be -1: use all reads. Can be 0: estimate it  [default '-1']\n"
+        "       -min-read-size    (1 arg) :    minimal size a read should have to be kept  [default '0']\n"
+        "       -min-shannon-index (1 arg) :    minimal Shannon index a read should have to be kept. Float in [0,2]  [default '0']\n"
+        "   [core options]\n"
+        "       -nb-cores         (1 arg) :    number of cores  [default '0']\n"
+        "       -max-memory       (1 arg) :    max memory (MB)  [default '5000']\n"
+        "       -max-count        (1 arg) :    accepted for compatibility (no job processes here)\n"
+        "       -max-merge        (1 arg) :    accepted for compatibility\n"
+        "   [gpu options]\n"
+        "       -nb-gpus          (1 arg) :    MI355X devices to shard the k-mer partition space over  [default '1']\n"
+        "       -gpu              (1 arg) :    first device ordinal  [default '0']\n"
+        "       -verbose          (1 arg) :    verbosity level  [default '1']\n";
+}
+
+Options parse_args(int argc, char **argv) {
+    Options o;
+    auto need = [&](int &i) -> std::string {
+        if (i + 1 >= argc) { std::cout << "ERROR: option " << argv[i] << " needs an argument" << std::endl; usage(); exit(1); }
+        return argv[++i];
+    };
+    for (int i = 1; i < argc; i++) {
+        const std::string a = argv[i];
+        if (a == "-in") o.in = need(i);
+        else if (a == "-out") o.out = need(i);
+        else if (a == "-out-tmp") o.out_tmp = need(i);
+        else if (a == "-keep-tmp") o.keep_tmp = true;
+        else if (a == "-data-info") o.data_info = true;
+        else if (a == "-simple-dist") o.simple = true;
+        else if (a == "-complex-dist") o.complex_ = true;
+        else if (a == "-kmer-size") o.kmer_size = atoi(need(i).c_str());
+        else if (a == "-abundance-min") o.abundance_min = atoll(need(i).c_str());
+        else if (a == "-abundance-max") o.abundance_max = atoll(need(i).c_str());
+        else if (a == "-kmer-shannon-index") o.kmer_shannon = atof(need(i).c_str());
+        else if (a == "-max-reads") o.max_reads = atoll(need(i).c_str());
+        else if (a == "-min-read-size") o.min_read_size = atoll(need(i).c_str());
+        else if (a == "-min-shannon-index") o.min_shannon = atof(need(i).c_str());
+        else if (a == "-nb-cores") o.nb_cores = atoi(need(i).c_str());
+        else if (a == "-max-memory") o.max_memory = atoll(need(i).c_str());
+        else if (a == "-verbose") o.verbose = atoi(need(i).c_str());
+        else if (a == "-nb-gpus") o.nb_gpus = atoi(need(i).c_str());
+        else if (a == "-gpu") o.first_gpu = atoi(need(i).c_str());
+        else if (a == "-max-count" || a == "-max-merge" || a == "-count-cmd" || a == "-merge-cmd" || a == "-count-file" ||
+                 a == "-merge-file" || a == "-minimizer-size" || a == "-solidity-kind" || a == "-max-disk" ||
+                 a == "-minimizer-type" || a == "-repartition-type" || a == "-storage-type" || a == "-histo-max")
+            (void)need(i);   // cluster / DSK knobs: accepted, meaningless without job processes or disk partitions
+        else if (a == "-help" || a == "-h" || a == "--help") { usage(); exit(0); }
+        else if (a == "-version") { std::cout << "simka (MI355X) 0.1.0" << std::endl; exit(0); }
+        else { std::cout << "ERROR: Unknown parameter '" << a << "'" << std::endl; usage(); exit(1); }
+    }
+    if (o.in.empty()) { std::cout << "ERROR: Option '-in' is mandatory" << std::endl; usage(); exit(1); }
+    if (o.out_tmp.empty()) { std::cout << "ERROR: Option '-out-tmp' is mandatory" << std::endl; usage(); exit(1); }
+    return o;
+}
+
+// ---- -in grammar (ref: src/core/SimkaAlgorithm.cpp:245-351) ---------------------------------
+std::vector<Sample> parse_input(const std::string &path) {
+    std::ifstream f(path.c_str());
+    if (!f) die("ERROR: Input filename does not exist");
+    char *rp = realpath(path.c_str(), nullptr);
+    std::string dir = rp ? rp : path;
+    free(rp);
+    const size_t slash = dir.find_last_of('/');
+    dir = slash == std::string::npos ? "." : dir.substr(0, slash);
+    std::vector<Sample> samples;
+    std::string line;
+    while (std::getline(f, line)) {
+        line.erase(std::remove(line.begin(), line.end(), ' '), line.end());
+        line.erase(std::remove(line.begin(), line.end(), '\r'), line.end());
+        if (line.empty()) continue;
+        std::vector<std::string> fields;
+        { std::stringstream ss(line); std::string p; while (std::getline(ss, p, ':')) fields.push_back(p); }
+        if (fields.size() < 2) { std::cout << "Syntax error in input file" << std::endl; exit(1); }
+        Sample s; s.id = fields[0];
+        std::stringstream ps(fields[1]); std::string part;
+        while (std::getline(ps, part, ';')) {
+            std::vector<std::string> files;
+            std::stringstream fs(part); std::string fn;
+            while (std::getline(fs, fn, ',')) { if (fn.empty()) continue; files.push_back(fn[0] == '/' ? fn : dir + "/" + fn); }
+            s.parts.push_back(files);
+        }
+        samples.push_back(s);
+    }
+    return samples;
+}
+
+// ---- sequence files: FASTA (multi-line) / FASTQ (4-line), plain or gz -------------------------
+class SeqReader {
+public:
+    explicit SeqReader(const std::string &path) : g_(gzopen(path.c_str(), "rb")), path_(path) {
+        if (g_) gzbuffer(g_, 1 << 20);
+    }
+    ~SeqReader() { if (g_) gzclose(g_); }
+    bool ok() const { return g_ != nullptr; }
+    // next sequence into `seq`; false at end of file
+    bool next(std::string &seq) {
+        seq.clear();
+        std::string line;
+        if (!have_pending_ && !getline(pending_)) return false;
+        have_pending_ = false;
+        while (pending_.empty()) if (!getline(pending_)) return false;
+        if (pending_[0] == '>') {
+            while (getline(line)) {
+                if (!line.empty() && line[0] == '>') { pending_ = line; have_pending_ = true; break; }
+                seq += line;
+            }
+            return true;
+        }
+        if (pending_[0] == '@') {
+            size_t qual = 0;
+            while (getline(line)) { if (!line.empty() && line[0] == '+') break; seq += line; }
+            while (qual < seq.size() && getline(line)) qual += line.size();
+            return true;
+        }
+        die("ERROR: unrecognised sequence file: " + path_);
+    }
+
+private:
+    bool getline(std::string &out) {
+        out.clear();
+        char buf[1 << 16];
+        bool any = false;
+        while (gzgets(g_, buf, sizeof buf)) {
+            any = true;
+            size_t l = strlen(buf);
+            const bool full = l > 0 && buf[l - 1] == '\n';
+            while (l > 0 && (buf[l - 1] == '\n' || buf[l - 1] == '\r')) l--;
+            out.append(buf, l);
+            if (full) break;
+        }
+        return any;
+    }
+    gzFile g_;
+    std::string path_, pending_;
+    bool have_pending_ = false;
+};
+
+// read filters (ref: src/core/SimkaCommons.hpp:317-436)
+float shannon_index(const std::string &s) {
+    static int tab[128];
+    static bool init = false;
+    if (!init) { memset(tab, 0, sizeof tab); tab['C'] = 1; tab['T'] = 2; tab['G'] = 3; tab['N'] = 4; init = true; }
+    std::vector<float> freq(5, 0.f);
+    for (unsigned char c : s) freq[c < 128 ? tab[c] : 0] += 1.0f;
+    float index = 0;
+    for (float &f : freq) { f /= (float)s.size(); if (f != 0) index += f * log(f) / log(2); }
+    return fabsf(index);
+}
+bool read_passes(const std::string &s, const Options &o) {
+    if (o.min_read_size && (long long)s.size() < o.min_read_size) return false;
+    if (o.min_shannon != 0 && !(shannon_index(s) >= o.min_shannon)) return false;
+    return true;
+}
+
+// number of filter-passing reads of a sample divided by its paired parts (computeMaxReads, ref: src/core/SimkaAlgorithm.cpp:377-445)
+uint64_t count_reads(const Sample &s) {
+    uint64_t n = 0; std::string seq;
+    for (auto &part : s.parts) for (auto &fn : part) { SeqReader r(fn); if (!r.ok()) return 0; while (r.next(seq)) n++; }
+    return s.parts.empty() ? 0 : n / s.parts.size();
+}
+
+struct Packed {
+    std::vector<uint64_t> words, offsets;
+    uint64_t nb_bases = 0, nb_frag = 0, nb_reads = 0;
+};
+
+// SimkaInputIterator (ref: src/core/SimkaCommons.hpp:159-314): files of a part in order; with -max-reads m the part
+// stops once its counter reaches m -- the first read delivered by each file does not advance the counter.
+bool load_sample(const Sample &s, const Options &o, uint64_t max_reads, Packed &out) {
+    out = Packed();
+    std::string seq;
+    for (auto &part : s.parts) {
+        uint64_t counter = 0; bool part_done = false;
+        for (size_t fi = 0; fi < part.size() && !part_done; fi++) {
+            SeqReader r(part[fi]);
+            if (!r.ok()) return false;
+            bool first_of_file = true;
+            while (r.next(seq)) {
+                if (!read_passes(seq, o)) continue;
+                if (!first_of_file) { counter++; if (max_reads && counter >= max_reads) { part_done = true; break; } }
+                first_of_file = false;
+                out.nb_reads++;
+                const uint64_t need_words = (out.nb_bases + seq.size()) / 32 + 3;
+                if (out.words.size() < need_words) out.words.resize(need_words * 2);
+                if (out.offsets.size() < out.nb_frag + seq.size() / 2 + 4) out.offsets.resize((out.nb_frag + seq.size() / 2 + 4) * 2);
+                const int64_t nf = simka_pack_read(seq.data(), seq.size(), out.words.data(), &out.nb_bases, out.offsets.data() + out.nb_frag);
+                if (nf < 0) return false;
+                out.nb_frag += (uint64_t)nf;
+            }
+        }
+    }
+    if (out.offsets.size() < out.nb_frag + 1) out.offsets.resize(out.nb_frag + 1);
+    out.offsets[out.nb_frag] = out.nb_bases;
+    if (out.words.size() < out.nb_bases / 32 + 3) out.words.resize(out.nb_bases / 32 + 3);
+    return true;
+}
+
+void check(simka_ctx *ctx, int rc, const char *what) {
+    if (rc == SIMKA_OK) return;
+    std::cout << "EXCEPTION: " << what << ": " << simka_last_error(ctx) << std::endl;
+    exit(EXIT_FAILURE);
+}
+
+}  // namespace
+
+int main(int argc, char **argv) {
+    Options o = parse_args(argc, argv);
+    // ref: src/SimkaPotara.hpp:376-387
+    if (o.max_memory < 2000) std::cout << "WARNING: running Simka with low memory is risky. Simka may hang because of that. Consider running with -max-memory X where X > 2000" << std::endl;
+    if (o.max_memory < 500) { std::cout << "Please run Simka with higher memory usage than 500 MB" << std::endl; return 1; }
+    if (!exists(o.in)) die("ERROR: Input filename does not exist");
+    if (o.kmer_size < 1 || o.kmer_size > 31) die("ERROR: -kmer-size must be in [1,31] (k >= 32 is not available on the MI355X path yet)");
+    if (o.complex_) die("ERROR: -complex-dist is not available on the MI355X path yet");
+    if (o.nb_gpus < 1) die("ERROR: -nb-gpus must be >= 1");
+    if (o.abundance_min < 0) o.abundance_min = 0;
+    o.abundance_max = std::min<long long>(std::max<long long>(o.abundance_max, 0), 999999999LL);
+    o.min_shannon = std::min(std::max(o.min_shannon, 0.0), 2.0);
+
+    mkdir_p(o.out);
+    mkdir_p(o.out_tmp);
+    const std::string tmp = o.out_tmp + "/simka_output_temp";     // ref: src/core/SimkaAlgorithm.cpp:234-239
+    mkdir_p(tmp);
+
+    if (o.verbose) std::cout << std::endl << "Creating input" << std::endl;
+    std::vector<Sample> samples = parse_input(o.in);
+    const uint32_t N = (uint32_t)samples.size();
+    if (N == 0) die("ERROR: no sample in the input file");
+    if (o.verbose) std::cout << "\tNb input datasets: " << N << std::endl << std::endl;
+    for (auto &s : samples) for (auto &p : s.parts) for (auto &fn : p)
+        if (!exists(fn)) die("ERROR: Can't open dataset: " + s.id);
+    {   // datasetIds, as the reference leaves it in the temp dir (ref: src/SimkaPotara.hpp:445-456)
+        std::ofstream ids((tmp + "/datasetIds").c_str());
+        for (auto &s : samples) ids << s.id << "\n";
+    }
+
+    // -max-reads (ref: src/core/SimkaAlgorithm.cpp:377-445)
+    uint64_t max_reads = 0;
+    if (o.max_reads == 0 || o.data_info) {
+        uint64_t total = 0, mn = ~0ull, mx = 0;
+        for (auto &s : samples) { const uint64_t n = count_reads(s); total += n; mn = std::min(mn, n); mx = std::max(mx, n); }
+        const uint64_t mean = total / N;
+        if (o.verbose) {
+            std::cout << "Smaller sample contains: " << mn << " reads" << std::endl;
+            std::cout << "Larger sample contains: " << mx << " reads" << std::endl;
+            std::cout << "Whole dataset contains a mean of: " << mean << " reads" << std::endl << std::endl;
+        }
+        if (o.max_reads == 0) max_reads = (mn + mean) / 2;
+    }
+    if (o.max_reads > 0) max_reads = (uint64_t)o.max_reads;
+    if (o.verbose) {
+        if (max_reads) std::cout << "Reads per sample used up to: " << max_reads << std::endl << std::endl;
+        else std::cout << "Reads per sample used: all" << std::endl << std::endl;
+    }
+
+    // contexts: one per GPU, partition space sharded
+    const uint32_t G = (uint32_t)o.nb_gpus;
+    std::vector<simka_ctx *> ctx(G, nullptr);
+    const uint32_t flags = (o.simple ? SIMKA_DIST_SIMPLE : 0u);
+    for (uint32_t g = 0; g < G; g++) {
+        simka_config cfg;
+        memset(&cfg, 0, sizeof cfg);
+        cfg.struct_size = sizeof cfg;
+        cfg.nb_samples = N; cfg.kmer_size = (uint32_t)o.kmer_size;
+        cfg.abundance_min = (uint32_t)std::min<long long>(o.abundance_min, 0xffffffffLL);
+        cfg.abundance_max = (uint32_t)o.abundance_max;
+        cfg.dist_flags = flags; cfg.device = o.first_gpu + (int)g; cfg.shard_index = g; cfg.shard_count = G;
+        // partition geometry from the largest input (2-bit bases <= file bytes)
+        uint64_t biggest = 0;
+        for (auto &s : samples) { uint64_t b = 0; for (auto &p : s.parts) for (auto &fn : p) { struct stat st; if (stat(fn.c_str(), &st) == 0) b += (uint64_t)st.st_size * (fn.size() > 3 && fn.substr(fn.size() - 3) == ".gz" ? 5 : 1); } biggest = std::max(biggest, b); }
+        cfg.max_kmers_per_sample = std::max<uint64_t>(biggest, 1);
+        int rc = simka_create(&cfg, &ctx[g]);
+        if (rc != SIMKA_OK) { std::cout << "EXCEPTION: " << simka_last_error(nullptr) << std::endl; return EXIT_FAILURE; }
+    }
+
+    // count (ref: SimkaPotaraAlgorithm::count, src/SimkaPotara.hpp:813-972)
+    if (o.verbose) std::cout << "Counting k-mers... (log files are " << tmp << "/log/count_*)" << std::endl;
+    std::vector<simka_sample_totals> totals(N);
+    Packed pk;
+    for (uint32_t i = 0; i < N; i++) {
+        if (!load_sample(samples[i], o, max_reads, pk)) die("ERROR: Can't open dataset: " + samples[i].id);
+        simka_reads r;
+        memset(&r, 0, sizeof r);
+        r.packed = pk.words.data(); r.nb_bases = pk.nb_bases; r.nb_reads = pk.nb_frag; r.offsets = pk.offsets.data();
+        r.fixed_len = 0; r.on_device = 0; r.nb_input_reads = pk.nb_reads;
+        for (uint32_t g = 0; g < G; g++) check(ctx[g], simka_count_sample(ctx[g], i, &r), "simka_count_sample");
+    }
+    for (uint32_t i = 0; i < N; i++) {
+        simka_sample_totals sum; memset(&sum, 0, sizeof sum);
+        for (uint32_t g = 0; g < G; g++) {
+            simka_sample_totals t;
+            check(ctx[g], simka_get_sample_totals(ctx[g], i, &t), "simka_get_sample_totals");
+            sum.nb_reads = t.nb_reads; sum.nb_distinct += t.nb_distinct; sum.nb_kmers += t.nb_kmers; sum.sum_sq += t.sum_sq;
+            sum.kmer_occurrences += t.kmer_occurrences; sum.distinct_all += t.distinct_all;
+        }
+        totals[i] = sum;
+    }
+    if (o.keep_tmp) {   // count_synchro/<ID>.ok with the reference's 4 lines (ref: src/SimkaCount.cpp:303-317)
+        mkdir_p(tmp + "/count_synchro");
+        for (uint32_t i = 0; i < N; i++) {
+            std::ofstream ok((tmp + "/count_synchro/" + samples[i].id + ".ok").c_str());
+            ok << totals[i].nb_reads << "\n" << totals[i].nb_distinct << "\n" << totals[i].nb_kmers << "\n" << totals[i].sum_sq << "\n";
+        }
+    }
+    if (o.verbose) {
+        std::cout << std::endl << "Nb reads / distinct k-mers / k-mers per sample (after the abundance filter):" << std::endl;
+        for (uint32_t i = 0; i < N; i++)
+            std::cout << "\t" << samples[i].id << ": " << totals[i].nb_reads << " / " << totals[i].nb_distinct << " / " << totals[i].nb_kmers << std::endl;
+    }
+
+    // merge + reduce (ref: SimkaPotaraAlgorithm::merge / stats, src/SimkaPotara.hpp:974-1187)
+    if (o.verbose) std::cout << std::endl << "Merging k-mer counts and computing distances..." << std::endl;
+    for (uint32_t g = 0; g < G; g++) check(ctx[g], simka_merge(ctx[g]), "simka_merge");
+    const uint64_t nw = simka_stats_nb_u64(N, flags);
+    std::vector<uint64_t> flat(nw, 0), shard(nw, 0);
+    for (uint32_t g = 0; g < G; g++) {          // SimkaStatistics::operator+= over the shards
+        check(ctx[g], simka_stats_download(ctx[g], shard.data(), nw, nullptr), "simka_stats_download");
+        for (uint64_t w = 0; w < nw; w++) flat[w] += shard[w];
+    }
+    simka_stats_view view;
+    if (simka_stats_describe(N, flags, flat.data(), nw, &view) != SIMKA_OK) die("EXCEPTION: simka_stats_describe");
+
+    // outputMatrix (ref: src/core/SimkaDistance.cpp:603-649)
+    std::vector<const char *> ids(N);
+    for (uint32_t i = 0; i < N; i++) ids[i] = samples[i].id.c_str();
+    std::vector<float> m((size_t)N * N);
+    for (int w = 0; w < simka_nb_matrices(); w++) {
+        if (!simka_matrix_enabled(w, flags)) continue;
+        if (simka_compute_matrix(&view, w, m.data()) != SIMKA_OK) die("EXCEPTION: simka_compute_matrix");
+        if (simka_write_matrix_csv(o.out.c_str(), simka_matrix_name(w), ids.data(), N, m.data(), 1) != SIMKA_OK)
+            die(std::string("EXCEPTION: cannot write ") + simka_matrix_name(w) + " to " + o.out);
+    }
+    if (o.verbose) {
+        std::cout << std::endl << "Stats" << std::endl;
+        std::cout << "\tDistinct k-mers (union of samples): " << view.nb_distinct_kmers << std::endl;
+        std::cout << "\tShared distinct k-mers: " << view.nb_shared_kmers << std::endl;
+        std::cout << std::endl << "Output dir: " << o.out << std::endl << std::endl;
+    }
+    for (uint32_t g = 0; g < G; g++) simka_destroy(ctx[g]);
+    if (!o.keep_tmp) {
+        unlink((tmp + "/datasetIds").c_str());
+        rmdir(tmp.c_str());
+    }
+    return EXIT_SUCCESS;
+}

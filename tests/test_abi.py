@@ -109,3 +109,25 @@ def test_stats_layout_roundtrip(simka_lib):
     assert list(st.per_sample()["D"]) == list(range(8, 8 + n))
     assert st.pairs()["S_ij"][0] == 8 + 5 * n
     assert st.dense("S")[0, 1] == 8 + 5 * n and st.dense("S")[1, 0] == 8 + 5 * n + n * (n - 1) // 2
+
+
+def test_cli_error_conventions(simka_lib):
+    """Reference conventions (src/SimkaPotara.hpp:376-387, src/core/SimkaAlgorithm.cpp:207-210): validation failures exit(1)
+    with a message; without a GPU the driver fails loudly (EXCEPTION: ..., EXIT_FAILURE) instead of falling back."""
+    import subprocess
+    import torch
+    from simka_amd import build as b
+    b.build()
+    inp = os.path.join(ROOT, "tests", "golden", "example", "simka_input.txt")
+    r = subprocess.run([b.CLI_PATH, "-in", "/nonexistent/input.txt", "-out-tmp", "/tmp"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+    assert r.returncode == 1 and "ERROR: Input filename does not exist" in r.stderr
+    r = subprocess.run([b.CLI_PATH, "-in", inp, "-out-tmp", "/tmp/simka_cli_t", "-max-memory", "100"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+    assert r.returncode == 1 and "Please run Simka with higher memory usage than 500 MB" in r.stdout
+    r = subprocess.run([b.CLI_PATH, "-out-tmp", "/tmp"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+    assert r.returncode == 1 and "-in" in r.stdout
+    r = subprocess.run([b.CLI_PATH, "-in", inp, "-out-tmp", "/tmp", "-bogus"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+    assert r.returncode == 1 and "Unknown parameter" in r.stdout
+    if not torch.cuda.is_available():
+        r = subprocess.run([b.CLI_PATH, "-in", inp, "-out", "/tmp/simka_cli_o", "-out-tmp", "/tmp/simka_cli_t", "-verbose", "0"],
+                           stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+        assert r.returncode == 1 and "EXCEPTION" in r.stdout and "no CPU fallback" in r.stdout

@@ -132,3 +132,32 @@ def test_fixed_len_equals_offsets(gpu_required):
     st2 = ctx.stats()
     ctx.close()
     assert np.array_equal(st1.flat, st2.flat)
+
+
+@pytest.mark.parametrize("k,amin", CONFIGS)
+def test_cli_drop_in_on_example(gpu_required, golden_dir, tmp_path, k, amin):
+    """The `simka` host driver, invoked as tests/simple_test.py:94 invokes the reference binary; outputs compared as
+    tests/simple_test.py:29-68 does (gunzip, string-equal with tests/truth, files present in both dirs)."""
+    import subprocess
+    from simka_amd import build as b
+    out, tmp = str(tmp_path / "out"), str(tmp_path / "tmp")
+    cmd = [b.CLI_PATH, "-in", os.path.join(golden_dir, "example", "simka_input.txt"), "-out", out, "-out-tmp", tmp,
+           "-simple-dist", "-kmer-size", str(k), "-abundance-min", str(amin), "-verbose", "0"]
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    assert r.returncode == 0, r.stdout
+    truth = os.path.join(golden_dir, "truth", "results_k%d_t%d" % (k, amin))
+    n = 0
+    for gzf in glob.glob(os.path.join(out, "*.csv.gz")):
+        ref = os.path.join(truth, os.path.basename(gzf)[:-3])
+        if os.path.exists(ref):
+            with gzip.open(gzf, "rb") as f, open(ref, "rb") as g:
+                assert f.read() == g.read(), os.path.basename(gzf)
+            n += 1
+    assert n == 17
+    # resource-invariance of the reference's test (tests/simple_test.py:125-133): other core/memory settings, same bytes
+    out2 = str(tmp_path / "out2")
+    r = subprocess.run(cmd[:4] + [out2] + cmd[5:] + ["-nb-cores", "2", "-max-memory", "2000"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    assert r.returncode == 0, r.stdout
+    for gzf in glob.glob(os.path.join(out, "*.csv.gz")):
+        with gzip.open(gzf, "rb") as f, gzip.open(os.path.join(out2, os.path.basename(gzf)), "rb") as g:
+            assert f.read() == g.read()
