@@ -33,7 +33,7 @@ enum {
     SIMKA_ERR_OVERFLOW = 4,    /* a partition exceeded its LDS table: re-create with more partitions */
     SIMKA_ERR_STATE = 5,       /* call order violated (e.g. merge before every sample was counted) */
     SIMKA_ERR_IO = 6,          /* file could not be read / written */
-    SIMKA_ERR_UNSUPPORTED = 7  /* feature not available on the device path yet */
+    SIMKA_ERR_UNSUPPORTED = 7  /* feature not available on the device path (e.g. k >= 32) */
 };
 
 /* -simple-dist / -complex-dist   ref: src/core/Simka.cpp:25-117, src/core/SimkaAlgorithm.cpp:178-179 */
@@ -146,9 +146,22 @@ int simka_stats_device_buffer(simka_ctx *ctx, void **device_ptr, uint64_t *nb_u6
 /* download (synchronises) into a host buffer of nb_u64 words and describe it */
 int simka_stats_download(simka_ctx *ctx, uint64_t *host_buf, uint64_t nb_u64, simka_stats_view *view);
 /* describe an arbitrary host copy of the flat buffer (e.g. after the caller's all-reduce) */
-int simka_stats_describe(uint32_t nb_samples, uint32_t dist_flags, const uint64_t *host_buf, uint64_t nb_u64,
-                         simka_stats_view *view);
+int simka_stats_describe(uint32_t nb_samples, uint32_t dist_flags, uint64_t *host_buf, uint64_t nb_u64,
+                         simka_stats_view *view);   /* with SIMKA_DIST_COMPLEX it also fills the derived tail (canberra, kl) */
 uint64_t simka_stats_nb_u64(uint32_t nb_samples, uint32_t dist_flags);
+/* word offsets of the flat buffer: out[8] = { #pair arrays, first pair array, first totals row, derived tail,
+ * nb_pairs, words of the head (header + pair arrays), total words, 0 }.  Layout:
+ * [8 header | S_ij S_ji a bc (chord hell) (whittaker klfix) x nb_pairs | D N Q D_all K_occ x N | canberra, kl(f64) x nb_pairs] */
+int simka_stats_layout(uint32_t nb_samples, uint32_t dist_flags, uint64_t out[8]);
+/* the two device ranges of the buffer.  Sharded (multi-GPU) protocol: with SIMKA_DIST_COMPLEX all-reduce `totals`
+ * BEFORE simka_merge (the per-k-mer complex terms need the global N_i; the reference reads them from
+ * every count_synchro/<ID>.ok in SimkaStatistics' constructor, ref: src/core/SimkaDistance.cpp:116-151) and `head`
+ * after it; without it one all-reduce of simka_stats_device_buffer() after simka_merge is enough. */
+int simka_stats_device_ranges(simka_ctx *ctx, void **head, uint64_t *nb_head, void **totals, uint64_t *nb_totals);
+/* host round trip of the 5 x N per-sample totals rows (D, N, Q, D_all, K_occ): lets a driver without a collective
+ * library make the totals global across its contexts before simka_merge (synchronise) */
+int simka_totals_download(simka_ctx *ctx, uint64_t *out_5n);
+int simka_totals_upload(simka_ctx *ctx, const uint64_t *in_5n);
 
 /* ---- finalisation (host) ------------------------------------------------------------------
  * SimkaDistance: the 21 distance matrices as float32 cells (ref: src/core/SimkaDistance.cpp:920-1226,

@@ -90,6 +90,10 @@ def load_library(build_if_missing=True):
         "simka_stats_download": (i32, [vp, vp, u64, C.POINTER(StatsView)]),
         "simka_stats_describe": (i32, [u32, u32, vp, u64, C.POINTER(StatsView)]),
         "simka_stats_nb_u64": (u64, [u32, u32]),
+        "simka_stats_layout": (i32, [u32, u32, C.POINTER(u64)]),
+        "simka_stats_device_ranges": (i32, [vp, C.POINTER(vp), C.POINTER(u64), C.POINTER(vp), C.POINTER(u64)]),
+        "simka_totals_download": (i32, [vp, vp]),
+        "simka_totals_upload": (i32, [vp, vp]),
         "simka_nb_matrices": (i32, []),
         "simka_matrix_name": (C.c_char_p, [i32]),
         "simka_matrix_enabled": (i32, [i32, u32]),
@@ -117,6 +121,15 @@ def matrix_names(dist_flags=DIST_SIMPLE | DIST_COMPLEX):
     return [lib.simka_matrix_name(w).decode() for w in range(lib.simka_nb_matrices()) if lib.simka_matrix_enabled(w, dist_flags)]
 
 
+def stats_layout(nb_samples, dist_flags):
+    """word offsets of the flat statistics buffer (simka_stats_layout)."""
+    out = (C.c_uint64 * 8)()
+    rc = load_library().simka_stats_layout(nb_samples, dist_flags, out)
+    if rc != SIMKA_OK:
+        raise SimkaError(rc, "simka_stats_layout")
+    return {"nacc": out[0], "acc0": out[1], "tot0": out[2], "derived": out[3], "nb_pairs": out[4], "head": out[5], "total": out[6]}
+
+
 class Stats:
     """Host copy of the flat accumulator buffer + typed views (== SimkaStatistics)."""
 
@@ -124,7 +137,11 @@ class Stats:
         self.lib = load_library()
         self.nb_samples = int(nb_samples)
         self.dist_flags = int(dist_flags)
-        self.flat = np.ascontiguousarray(flat, dtype=np.uint64)
+        self.layout = stats_layout(self.nb_samples, self.dist_flags)
+        flat = np.ascontiguousarray(flat, dtype=np.uint64)
+        if flat.size < self.layout["total"]:       # a buffer without the host-derived tail (e.g. straight from an all-reduce)
+            flat = np.concatenate([flat, np.zeros(self.layout["total"] - flat.size, dtype=np.uint64)])
+        self.flat = flat.copy()
         self.view = StatsView()
         rc = self.lib.simka_stats_describe(self.nb_samples, self.dist_flags, self.flat.ctypes.data, self.flat.size,
                                            C.byref(self.view))
@@ -138,8 +155,9 @@ class Stats:
 
     def per_sample(self):
         n = self.nb_samples
+        t0 = self.layout["tot0"]
         return {"D": self._arr(self.view.nb_distinct, n), "N": self._arr(self.view.nb_kmers, n), "Q": self._arr(self.view.sum_sq, n),
-                "D_all": self.flat[8 + 3 * n: 8 + 4 * n].copy(), "K_occ": self.flat[8 + 4 * n: 8 + 5 * n].copy()}
+                "D_all": self.flat[t0 + 3 * n: t0 + 4 * n].copy(), "K_occ": self.flat[t0 + 4 * n: t0 + 5 * n].copy()}
 
     def pairs(self):
         p = int(self.view.nb_pairs)
@@ -149,6 +167,10 @@ class Stats:
         if self.dist_flags & DIST_SIMPLE:
             out["chord"] = self._arr(v.chord, p)
             out["hell"] = self._arr(v.hellinger, p)
+        if self.dist_flags & DIST_COMPLEX:
+            out["whit"] = self._arr(v.whittaker, p)
+            out["canb"] = self._arr(v.canberra, p)
+            out["kl"] = np.ctypeslib.as_array(v.kl, shape=(p,)).copy()
         return out
 
     def dense(self, name):
@@ -283,6 +305,22 @@ class SimkaContext:
         n = C.c_uint64()
         self._check(self.lib.simka_stats_device_buffer(self.h, C.byref(p), C.byref(n)))
         return p.value, n.value
+
+    def stats_device_ranges(self):
+        """((head_ptr, head_words), (totals_ptr, totals_words)) -- see simka_stats_device_ranges."""
+        hp, tp = C.c_void_p(), C.c_void_p()
+        hn, tn = C.c_uint64(), C.c_uint64()
+        self._check(self.lib.simka_stats_device_ranges(self.h, C.byref(hp), C.byref(hn), C.byref(tp), C.byref(tn)))
+        return (hp.value, hn.value), (tp.value, tn.value)
+
+    def totals_download(self):
+        out = np.zeros(5 * self.nb_samples, dtype=np.uint64)
+        self._check(self.lib.simka_totals_download(self.h, out.ctypes.data))
+        return out
+
+    def totals_upload(self, arr):
+        arr = np.ascontiguousarray(arr, dtype=np.uint64)
+        self._check(self.lib.simka_totals_upload(self.h, arr.ctypes.data))
 
     def stats(self):
         n = self.lib.simka_stats_nb_u64(self.nb_samples, self.dist_flags)

@@ -288,7 +288,6 @@ int main(int argc, char **argv) {
     if (o.max_memory < 500) { std::cout << "Please run Simka with higher memory usage than 500 MB" << std::endl; return 1; }
     if (!exists(o.in)) die("ERROR: Input filename does not exist");
     if (o.kmer_size < 1 || o.kmer_size > 31) die("ERROR: -kmer-size must be in [1,31] (k >= 32 is not available on the MI355X path yet)");
-    if (o.complex_) die("ERROR: -complex-dist is not available on the MI355X path yet");
     if (o.nb_gpus < 1) die("ERROR: -nb-gpus must be >= 1");
     if (o.abundance_min < 0) o.abundance_min = 0;
     o.abundance_max = std::min<long long>(std::max<long long>(o.abundance_max, 0), 999999999LL);
@@ -333,7 +332,7 @@ int main(int argc, char **argv) {
     // contexts: one per GPU, partition space sharded
     const uint32_t G = (uint32_t)o.nb_gpus;
     std::vector<simka_ctx *> ctx(G, nullptr);
-    const uint32_t flags = (o.simple ? SIMKA_DIST_SIMPLE : 0u);
+    const uint32_t flags = (o.simple ? SIMKA_DIST_SIMPLE : 0u) | (o.complex_ ? SIMKA_DIST_COMPLEX : 0u);
     for (uint32_t g = 0; g < G; g++) {
         simka_config cfg;
         memset(&cfg, 0, sizeof cfg);
@@ -387,12 +386,20 @@ int main(int argc, char **argv) {
 
     // merge + reduce (ref: SimkaPotaraAlgorithm::merge / stats, src/SimkaPotara.hpp:974-1187)
     if (o.verbose) std::cout << std::endl << "Merging k-mer counts and computing distances..." << std::endl;
+    if (G > 1) {   // make the per-sample totals global on every shard before the merge (-complex-dist needs N_i)
+        std::vector<uint64_t> tsum(5 * (size_t)N, 0), t(5 * (size_t)N);
+        for (uint32_t g = 0; g < G; g++) { check(ctx[g], simka_totals_download(ctx[g], t.data()), "simka_totals_download"); for (size_t w = 0; w < t.size(); w++) tsum[w] += t[w]; }
+        for (uint32_t g = 0; g < G; g++) check(ctx[g], simka_totals_upload(ctx[g], tsum.data()), "simka_totals_upload");
+    }
     for (uint32_t g = 0; g < G; g++) check(ctx[g], simka_merge(ctx[g]), "simka_merge");
     const uint64_t nw = simka_stats_nb_u64(N, flags);
+    uint64_t lay[8];
+    simka_stats_layout(N, flags, lay);
     std::vector<uint64_t> flat(nw, 0), shard(nw, 0);
-    for (uint32_t g = 0; g < G; g++) {          // SimkaStatistics::operator+= over the shards
+    for (uint32_t g = 0; g < G; g++) {          // SimkaStatistics::operator+= over the shards (totals are already global)
         check(ctx[g], simka_stats_download(ctx[g], shard.data(), nw, nullptr), "simka_stats_download");
-        for (uint64_t w = 0; w < nw; w++) flat[w] += shard[w];
+        for (uint64_t w = 0; w < lay[5]; w++) flat[w] += shard[w];
+        if (g == 0) for (uint64_t w = lay[5]; w < nw; w++) flat[w] = shard[w];
     }
     simka_stats_view view;
     if (simka_stats_describe(N, flags, flat.data(), nw, &view) != SIMKA_OK) die("EXCEPTION: simka_stats_describe");

@@ -53,6 +53,8 @@ struct simka_ctx {
     ull *d_mkeys = nullptr, *d_mvals = nullptr, *d_entries = nullptr; uint32_t *d_groups = nullptr;
     uint32_t *d_fb_off = nullptr; SimkaSpan *d_spans = nullptr; ull *d_cursors = nullptr; ull *d_slabs = nullptr;
     uint64_t merge_cap = 0, fb_cap = 0, span_cap = 0, slab_words = 0;
+    // -complex-dist: per-sample histogram of solid counts + list of the counts above the histogram
+    ull *d_hist = nullptr; uint32_t *d_ovf_list = nullptr; ull *d_ovf_cursor = nullptr; uint64_t ovf_cap = 0;
 
     std::vector<uint8_t> counted;
     std::vector<uint64_t> nb_reads;
@@ -108,20 +110,38 @@ static hipError_t dev_alloc(T **p, uint64_t n) { return hipMalloc((void **)p, st
 static uint32_t ceil_log2_u64(uint64_t x) { uint32_t l = 0; while (((uint64_t)1 << l) < x && l < 63) l++; return l; }
 
 // ---- flat statistics layout ---------------------------------------------------------------
-static inline uint32_t stats_nacc(uint32_t flags) { return (flags & SIMKA_DIST_SIMPLE) ? 6u : 4u; }
-static inline uint64_t stats_off_tot(uint32_t N, uint32_t t) { return 8 + (uint64_t)t * N; }
-static inline uint64_t stats_off_acc(uint32_t N, uint32_t a) { return 8 + (uint64_t)SIMKA_NB_TOTALS * N + (uint64_t)a * ((uint64_t)N * (N - 1) / 2); }
+//   [0,8) header | pair arrays nacc x P | per-sample totals 5 x N | host-derived (complex): canberra P, kl(f64) P
+// Totals sit AFTER the pair arrays so that a multi-GPU caller can all-reduce them on their own before the
+// merge (needed by -complex-dist) and the head [0, 8 + nacc*P) after it.
+static inline uint32_t stats_nacc32(uint32_t flags) { return (flags & SIMKA_DIST_SIMPLE) ? 6u : 4u; }
+static inline uint32_t stats_nacc64(uint32_t flags) { return (flags & SIMKA_DIST_COMPLEX) ? 2u : 0u; }
+static inline uint32_t stats_nacc(uint32_t flags) { return stats_nacc32(flags) + stats_nacc64(flags); }
+static inline uint64_t stats_pairs(uint32_t N) { return (uint64_t)N * (N - 1) / 2; }
+static inline uint64_t stats_off_acc(uint32_t N, uint32_t a) { return 8 + (uint64_t)a * stats_pairs(N); }
+static inline uint64_t stats_off_tot(uint32_t N, uint32_t flags, uint32_t t) { return stats_off_acc(N, stats_nacc(flags)) + (uint64_t)t * N; }
+static inline uint64_t stats_off_derived(uint32_t N, uint32_t flags) { return stats_off_tot(N, flags, SIMKA_NB_TOTALS); }
 
-SIMKA_EXPORT uint64_t simka_stats_nb_u64(uint32_t N, uint32_t flags) { return stats_off_acc(N, stats_nacc(flags)); }
+SIMKA_EXPORT uint64_t simka_stats_nb_u64(uint32_t N, uint32_t flags) {
+    return stats_off_derived(N, flags) + ((flags & SIMKA_DIST_COMPLEX) ? 2 * stats_pairs(N) : 0);
+}
 
-SIMKA_EXPORT int simka_stats_describe(uint32_t N, uint32_t flags, const uint64_t *h, uint64_t n, simka_stats_view *v) {
+// out[0..7] = { nacc, offset of pair array 0, offset of totals row 0, offset of derived, nb_pairs, head words, total words, 0 }
+SIMKA_EXPORT int simka_stats_layout(uint32_t N, uint32_t flags, uint64_t *out) {
+    if (!out || N == 0) return SIMKA_ERR_INVALID;
+    out[0] = stats_nacc(flags); out[1] = stats_off_acc(N, 0); out[2] = stats_off_tot(N, flags, 0); out[3] = stats_off_derived(N, flags);
+    out[4] = stats_pairs(N); out[5] = stats_off_tot(N, flags, 0); out[6] = simka_stats_nb_u64(N, flags); out[7] = 0;
+    return SIMKA_OK;
+}
+
+SIMKA_EXPORT int simka_stats_describe(uint32_t N, uint32_t flags, uint64_t *h, uint64_t n, simka_stats_view *v) {
     if (!h || !v || N == 0 || n < simka_stats_nb_u64(N, flags)) return SIMKA_ERR_INVALID;
     memset(v, 0, sizeof *v);
-    v->nb_samples = N; v->dist_flags = flags; v->nb_pairs = (uint64_t)N * (N - 1) / 2;
+    const uint64_t P = stats_pairs(N);
+    v->nb_samples = N; v->dist_flags = flags; v->nb_pairs = P;
     v->nb_distinct_kmers = h[0]; v->nb_shared_kmers = h[1];
-    v->nb_distinct = h + stats_off_tot(N, SIMKA_TOT_D);
-    v->nb_kmers = h + stats_off_tot(N, SIMKA_TOT_N);
-    v->sum_sq = h + stats_off_tot(N, SIMKA_TOT_Q);
+    v->nb_distinct = h + stats_off_tot(N, flags, SIMKA_TOT_D);
+    v->nb_kmers = h + stats_off_tot(N, flags, SIMKA_TOT_N);
+    v->sum_sq = h + stats_off_tot(N, flags, SIMKA_TOT_Q);
     v->shared_ij = h + stats_off_acc(N, SIMKA_ACC_SIJ);
     v->shared_ji = h + stats_off_acc(N, SIMKA_ACC_SJI);
     v->distinct_shared = h + stats_off_acc(N, SIMKA_ACC_A);
@@ -129,6 +149,29 @@ SIMKA_EXPORT int simka_stats_describe(uint32_t N, uint32_t flags, const uint64_t
     if (flags & SIMKA_DIST_SIMPLE) {
         v->chord = h + stats_off_acc(N, SIMKA_ACC_CHORD);
         v->hellinger = h + stats_off_acc(N, SIMKA_ACC_HELL);
+    }
+    if (flags & SIMKA_DIST_COMPLEX) {
+        // derive what updateDistanceComplex accumulates k-mer by k-mer (ref: src/core/SimkaAlgorithm.hpp:404-516) from the
+        // both-present sums of the device plus closed forms of the one-sided terms (identities of SURVEY.md App. A.6):
+        //   canberra[i][j]  = #k-mers present in exactly one of i,j = D_i + D_j - 2a            (each adds floor(0+1) = 1)
+        //   KL[i][j]        = both-present sum + ln2 * ((N_i - S_ij)/N_i + (N_j - S_ji)/N_j)     (one-sided log term is ln 2)
+        const uint32_t a32 = stats_nacc32(flags);
+        v->whittaker = h + stats_off_acc(N, a32 + 0);
+        const int64_t *klfix = (const int64_t *)(h + stats_off_acc(N, a32 + 1));
+        uint64_t *canb = h + stats_off_derived(N, flags);
+        double *kl = (double *)(canb + P);
+        const long double ln2 = logl(2.0L);
+        uint64_t cell = 0;
+        for (uint64_t i = 0; i < N; i++)
+            for (uint64_t j = i + 1; j < N; j++, cell++) {
+                canb[cell] = v->nb_distinct[i] + v->nb_distinct[j] - 2 * v->distinct_shared[cell];
+                const long double Ni = (long double)v->nb_kmers[i], Nj = (long double)v->nb_kmers[j];
+                long double one = 0;
+                if (v->nb_kmers[i]) one += (long double)(v->nb_kmers[i] - v->shared_ij[cell]) / Ni;
+                if (v->nb_kmers[j]) one += (long double)(v->nb_kmers[j] - v->shared_ji[cell]) / Nj;
+                kl[cell] = (double)((long double)klfix[cell] / (long double)SIMKA_KL_SCALE + ln2 * one);
+            }
+        v->canberra = canb; v->kl = kl;
     }
     return SIMKA_OK;
 }
@@ -207,7 +250,6 @@ SIMKA_EXPORT int simka_create(const simka_config *cfg, simka_ctx **out) {
     if (cfg->nb_samples == 0 || cfg->nb_samples > 65535) { g_create_error = "simka_create: nb_samples must be in [1,65535]"; return SIMKA_ERR_INVALID; }
     if (cfg->kmer_size < 1 || cfg->kmer_size > 31) { g_create_error = "simka_create: kmer_size must be in [1,31] on the device path"; return SIMKA_ERR_INVALID; }
     if (cfg->shard_count == 0 || cfg->shard_index >= cfg->shard_count) { g_create_error = "simka_create: bad shard_index/shard_count"; return SIMKA_ERR_INVALID; }
-    if (cfg->dist_flags & SIMKA_DIST_COMPLEX) { g_create_error = "simka_create: -complex-dist is not available on the device path yet"; return SIMKA_ERR_UNSUPPORTED; }
     if (cfg->log2_subranges > 8) { g_create_error = "simka_create: log2_subranges must be <= 8"; return SIMKA_ERR_INVALID; }
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
@@ -243,6 +285,14 @@ SIMKA_EXPORT int simka_create(const simka_config *cfg, simka_ctx **out) {
     if (!chk(hipMemsetAsync(ctx->d_arena_cursor, 0, 16, ctx->stream), "memset(cursor)")) return bail(SIMKA_ERR_HIP);
     if (!chk(dev_alloc(&ctx->d_sample_base, N + 1), "hipMalloc(sample_base)")) return bail(SIMKA_ERR_NOMEM);
     if (!chk(dev_alloc(&ctx->d_cursors, 4), "hipMalloc(cursors)")) return bail(SIMKA_ERR_NOMEM);
+    if (cfg->dist_flags & SIMKA_DIST_COMPLEX) {
+        ctx->ovf_cap = (uint64_t)1 << 22;
+        if (!chk(dev_alloc(&ctx->d_hist, (uint64_t)N * SIMKA_HIST_MAX), "hipMalloc(hist)")) return bail(SIMKA_ERR_NOMEM);
+        if (!chk(dev_alloc(&ctx->d_ovf_list, 2 * ctx->ovf_cap), "hipMalloc(ovf)")) return bail(SIMKA_ERR_NOMEM);
+        if (!chk(dev_alloc(&ctx->d_ovf_cursor, 2), "hipMalloc(ovf cursor)")) return bail(SIMKA_ERR_NOMEM);
+        if (!chk(hipMemsetAsync(ctx->d_hist, 0, (uint64_t)N * SIMKA_HIST_MAX * 8, ctx->stream), "memset(hist)")) return bail(SIMKA_ERR_HIP);
+        if (!chk(hipMemsetAsync(ctx->d_ovf_cursor, 0, 16, ctx->stream), "memset(ovf)")) return bail(SIMKA_ERR_HIP);
+    }
     ctx->counted.assign(N, 0);
     ctx->nb_reads.assign(N, 0);
     if (cfg->max_kmers_per_sample) { rc = setup_geometry(ctx, cfg->max_kmers_per_sample); if (rc) return bail(rc); }
@@ -258,7 +308,7 @@ SIMKA_EXPORT void simka_destroy(simka_ctx *ctx) {
                      ctx->d_chunk_first, ctx->d_chunk_off, ctx->d_solid_keys, ctx->d_solid_counts, ctx->d_arena_cursor,
                      ctx->d_sample_base, ctx->d_foff, ctx->d_fcnt, ctx->d_stats, ctx->d_err, ctx->d_part_total,
                      ctx->d_part_off, ctx->d_mkeys, ctx->d_mvals, ctx->d_entries, ctx->d_groups, ctx->d_fb_off,
-                     ctx->d_spans, ctx->d_cursors, ctx->d_slabs };
+                     ctx->d_spans, ctx->d_cursors, ctx->d_slabs, ctx->d_hist, ctx->d_ovf_list, ctx->d_ovf_cursor };
     for (void *p : ptrs) if (p) (void)hipFree(p);
     if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
@@ -280,6 +330,10 @@ SIMKA_EXPORT int simka_reset(simka_ctx *ctx) {
     if (ctx->geometry_ready) {
         HIPCHK(hipMemsetAsync(ctx->d_foff, 0, (uint64_t)N * ctx->nparts * 4, ctx->stream));
         HIPCHK(hipMemsetAsync(ctx->d_fcnt, 0, (uint64_t)N * ctx->nparts * 4, ctx->stream));
+    }
+    if (ctx->d_hist) {
+        HIPCHK(hipMemsetAsync(ctx->d_hist, 0, (uint64_t)N * SIMKA_HIST_MAX * 8, ctx->stream));
+        HIPCHK(hipMemsetAsync(ctx->d_ovf_cursor, 0, 16, ctx->stream));
     }
     std::fill(ctx->counted.begin(), ctx->counted.end(), 0);
     std::fill(ctx->nb_reads.begin(), ctx->nb_reads.end(), 0);
@@ -350,7 +404,7 @@ SIMKA_EXPORT int simka_count_sample(simka_ctx *ctx, uint32_t sample, const simka
     const uint64_t max_chunks = r->nb_bases / K2_CHUNK + B1 + 1;
     if (key.l2) { rc = ensure_cap(ctx, &ctx->d_chunk_off, &ctx->chunk_cap, max_chunks * (B2 + 1)); if (rc) return rc; }
 
-    ull *kocc = (ull *)ctx->d_stats + stats_off_tot(N, SIMKA_TOT_KOCC) + sample;
+    ull *kocc = (ull *)ctx->d_stats + stats_off_tot(N, ctx->cfg.dist_flags, SIMKA_TOT_KOCC) + sample;
     const uint64_t tile = (uint64_t)K1_BLOCK * K1_SEG;
     const uint32_t grid1 = (uint32_t)((r->nb_bases + tile - 1) / tile);
     const size_t lds_hist = SIMKA_LDS_HEAD + (size_t)B1 * 16 + K1_BLOCK * 4;
@@ -381,8 +435,9 @@ SIMKA_EXPORT int simka_count_sample(simka_ctx *ctx, uint32_t sample, const simka
     o.arena_cursor = ctx->d_arena_cursor; o.sample_base = ctx->d_sample_base + sample; o.arena_cap = ctx->arena_cap;
     o.solid_keys = ctx->d_solid_keys; o.solid_counts = ctx->d_solid_counts;
     o.foff = ctx->d_foff + (uint64_t)sample * ctx->nparts; o.fcnt = ctx->d_fcnt + (uint64_t)sample * ctx->nparts;
-    o.totals = (ull *)ctx->d_stats + stats_off_tot(N, 0); o.sample = sample; o.nb_samples = N; o.err = ctx->d_err;
+    o.totals = (ull *)ctx->d_stats + stats_off_tot(N, ctx->cfg.dist_flags, 0); o.sample = sample; o.nb_samples = N; o.err = ctx->d_err;
     o.phase = nullptr;
+    o.hist = ctx->d_hist; o.ovf_list = ctx->d_ovf_list; o.ovf_cursor = ctx->d_ovf_cursor; o.ovf_cap = ctx->ovf_cap;
 #ifdef SIMKA_PHASE_PROF
     static ull *d_phase = nullptr;
     if (!d_phase) { hipMalloc((void **)&d_phase, 64); hipMemset(d_phase, 0, 64); }
@@ -394,7 +449,7 @@ SIMKA_EXPORT int simka_count_sample(simka_ctx *ctx, uint32_t sample, const simka
 #endif
     // tuning knobs (experiments): table size and resident blocks per CU
     static const uint32_t tlog = getenv("SIMKA_K2_TABLE_LOG2") ? (uint32_t)atoi(getenv("SIMKA_K2_TABLE_LOG2")) : (uint32_t)K2_TABLE_LOG2;
-    const size_t lds_count = SIMKA_LDS_HEAD + ((size_t)12 << tlog) + (size_t)(2 * K2_MAXSEG + 1) * 4;
+    const size_t lds_count = SIMKA_LDS_HEAD + ((size_t)12 << tlog) + (size_t)(2 * K2_MAXSEG + 1) * 4 + (ctx->d_hist ? (size_t)SIMKA_HIST_MAX * 4 : 0);
     static const uint32_t bpc = getenv("SIMKA_K2_BLOCKS_PER_CU") ? (uint32_t)atoi(getenv("SIMKA_K2_BLOCKS_PER_CU")) : (uint32_t)std::max<size_t>(1, (160 * 1024) / lds_count);
     launch_timed(ctx, KID_COUNT, [&] {
         const uint32_t grid_count = (uint32_t)std::min<uint64_t>(ctx->nparts, (uint64_t)ctx->num_cus * bpc);
@@ -414,7 +469,7 @@ SIMKA_EXPORT int simka_get_sample_totals(simka_ctx *ctx, uint32_t sample, simka_
     if (rc) return rc;
     uint64_t t[SIMKA_NB_TOTALS];
     for (int i = 0; i < SIMKA_NB_TOTALS; i++)
-        HIPCHK(hipMemcpyAsync(&t[i], ctx->d_stats + stats_off_tot(N, i) + sample, 8, hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(hipMemcpyAsync(&t[i], ctx->d_stats + stats_off_tot(N, ctx->cfg.dist_flags, i) + sample, 8, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));
     out->nb_reads = ctx->nb_reads[sample];
     out->nb_distinct = t[SIMKA_TOT_D]; out->nb_kmers = t[SIMKA_TOT_N]; out->sum_sq = t[SIMKA_TOT_Q];
@@ -479,11 +534,15 @@ SIMKA_EXPORT int simka_merge(simka_ctx *ctx) {
     if (ctx->span_cap < span_cap) { if (ctx->d_spans) HIPCHK(hipFree(ctx->d_spans)); ctx->d_spans = nullptr; HIPCHK(dev_alloc(&ctx->d_spans, span_cap)); ctx->span_cap = span_cap; }
 
     // pair-accumulator tiling: all N(N-1)/2 cells in LDS when they fit, else T x T sample tiles
+    const uint32_t flags = ctx->cfg.dist_flags;
     SimkaPairCfg pc;
-    pc.nb_samples = N; pc.nacc = stats_nacc(ctx->cfg.dist_flags); pc.nb_pairs = (uint64_t)N * (N - 1) / 2;
+    pc.nb_samples = N; pc.nacc32 = stats_nacc32(flags); pc.nacc64 = stats_nacc64(flags); pc.nacc = pc.nacc32 + pc.nacc64;
+    pc.simple = (flags & SIMKA_DIST_SIMPLE) ? 1u : 0u;
+    pc.nb_pairs = (uint64_t)N * (N - 1) / 2;
+    pc.tot_n = (const ull *)ctx->d_stats + stats_off_tot(N, flags, SIMKA_TOT_N);   // GLOBAL N_i: all-reduced by the caller when sharded
     const size_t lds_fixed = SIMKA_LDS_HEAD + (size_t)K3_CAP * 8 + (size_t)K3_CAP * 4 + (size_t)(K3_CAP + 1) * 4 + K4_BLOCK * 4 + 64;
     const size_t lds_budget = 160 * 1024 - lds_fixed;
-    const uint64_t max_cells = lds_budget / (4 * pc.nacc);
+    const uint64_t max_cells = lds_budget / (4 * pc.nacc32 + 8 * pc.nacc64);
     if (pc.nb_pairs <= max_cells) { pc.tile = N; pc.ntiles = 1; pc.ncell = (uint32_t)pc.nb_pairs; }
     else {
         uint32_t T = 1; while ((uint64_t)(T + 1) * (T + 1) <= max_cells) T++;
@@ -491,7 +550,7 @@ SIMKA_EXPORT int simka_merge(simka_ctx *ctx) {
     }
     pc.ncell_pad = (pc.ncell + 3u) & ~3u;
     const uint32_t ntp = pc.ntiles * (pc.ntiles + 1) / 2;
-    const size_t lds_pairs = lds_fixed + (size_t)pc.nacc * pc.ncell_pad * 4;
+    const size_t lds_pairs = lds_fixed + (size_t)pc.ncell_pad * (4 * pc.nacc32 + 8 * pc.nacc64);
     const uint32_t per_cu = (uint32_t)std::min<size_t>(4, std::max<size_t>(1, (160 * 1024) / lds_pairs));
     const uint32_t nblk = (uint32_t)ctx->num_cus * per_cu;
     const uint64_t slab_words = (uint64_t)ntp * nblk * pc.nacc * pc.ncell_pad;
@@ -537,13 +596,71 @@ SIMKA_EXPORT int simka_merge(simka_ctx *ctx) {
                            ctx->d_slabs, nblk, pc, acc);
     });
     HIPCHK(hipGetLastError());
-    return check_device_error(ctx);
+    int rcd = check_device_error(ctx);
+    if (rcd) return rcd;
+    if (flags & SIMKA_DIST_COMPLEX) {
+        // Whittaker's one-sided terms  sum_{k-mers of i} g(c, N_j),  g(c,M) = |(int)(u64)(c*M)|  (ref: src/core/SimkaAlgorithm.hpp:481,512),
+        // from this shard's histogram of solid counts and the GLOBAL N_j; k_pairs already subtracted g for the both-present pairs.
+        std::vector<ull> hist((size_t)N * SIMKA_HIST_MAX), totn(N), whit(pc.nb_pairs);
+        ull novf = 0;
+        HIPCHK(hipMemcpyAsync(hist.data(), ctx->d_hist, hist.size() * 8, hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(hipMemcpyAsync(totn.data(), pc.tot_n, (size_t)N * 8, hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(hipMemcpyAsync(&novf, ctx->d_ovf_cursor, 8, hipMemcpyDeviceToHost, ctx->stream));
+        ull *d_whit = (ull *)ctx->d_stats + stats_off_acc(N, pc.nacc32 + 0);
+        HIPCHK(hipMemcpyAsync(whit.data(), d_whit, pc.nb_pairs * 8, hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(hipStreamSynchronize(ctx->stream));
+        if (novf > ctx->ovf_cap) return ctx->fail(SIMKA_ERR_OVERFLOW, "more than %llu k-mers with a count >= %d: complex-dist histogram list exhausted", (unsigned long long)ctx->ovf_cap, SIMKA_HIST_MAX);
+        std::vector<uint32_t> ovf(2 * novf);
+        if (novf) HIPCHK(hipMemcpy(ovf.data(), ctx->d_ovf_list, novf * 8, hipMemcpyDeviceToHost));
+        std::vector<std::vector<std::pair<uint32_t, ull>>> cnts(N);        // per sample: (count, #k-mers)
+        for (uint32_t i = 0; i < N; i++)
+            for (uint32_t cc = 0; cc < SIMKA_HIST_MAX; cc++) if (hist[(size_t)i * SIMKA_HIST_MAX + cc]) cnts[i].push_back({cc, hist[(size_t)i * SIMKA_HIST_MAX + cc]});
+        for (ull w = 0; w < novf; w++) cnts[ovf[2 * w]].push_back({ovf[2 * w + 1], 1});
+        auto gsum = [&](uint32_t i, uint32_t j) {
+            ull acc_ = 0;
+            const double M = (double)totn[j];
+            for (auto &pr : cnts[i]) {
+                const int t_ = (int)(ull)((double)pr.first * M);
+                const int r_ = (t_ == (int)0x80000000) ? t_ : (t_ < 0 ? -t_ : t_);
+                acc_ += (ull)(long long)r_ * pr.second;
+            }
+            return acc_;
+        };
+        uint64_t cell = 0;
+        for (uint32_t i = 0; i < N; i++) for (uint32_t j = i + 1; j < N; j++, cell++) whit[cell] += gsum(i, j) + gsum(j, i);
+        HIPCHK(hipMemcpyAsync(d_whit, whit.data(), pc.nb_pairs * 8, hipMemcpyHostToDevice, ctx->stream));
+        HIPCHK(hipStreamSynchronize(ctx->stream));
+    }
+    return SIMKA_OK;
 }
 
 // ---- statistics ---------------------------------------------------------------------------
 SIMKA_EXPORT int simka_stats_device_buffer(simka_ctx *ctx, void **p, uint64_t *n) {
     if (!ctx || !p || !n) return SIMKA_ERR_INVALID;
-    *p = ctx->d_stats; *n = ctx->stats_n;
+    *p = ctx->d_stats; *n = stats_off_derived(ctx->cfg.nb_samples, ctx->cfg.dist_flags);   // pair arrays + totals (derived tail is host-only)
+    return SIMKA_OK;
+}
+
+SIMKA_EXPORT int simka_stats_device_ranges(simka_ctx *ctx, void **head, uint64_t *nb_head, void **totals, uint64_t *nb_totals) {
+    if (!ctx || !head || !nb_head || !totals || !nb_totals) return SIMKA_ERR_INVALID;
+    const uint32_t N = ctx->cfg.nb_samples, fl = ctx->cfg.dist_flags;
+    *head = ctx->d_stats; *nb_head = stats_off_tot(N, fl, 0);
+    *totals = ctx->d_stats + stats_off_tot(N, fl, 0); *nb_totals = (uint64_t)SIMKA_NB_TOTALS * N;
+    return SIMKA_OK;
+}
+
+SIMKA_EXPORT int simka_totals_download(simka_ctx *ctx, uint64_t *out) {
+    if (!ctx || !out) return SIMKA_ERR_INVALID;
+    const uint32_t N = ctx->cfg.nb_samples;
+    HIPCHK(hipMemcpyAsync(out, ctx->d_stats + stats_off_tot(N, ctx->cfg.dist_flags, 0), (size_t)SIMKA_NB_TOTALS * N * 8, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    return SIMKA_OK;
+}
+SIMKA_EXPORT int simka_totals_upload(simka_ctx *ctx, const uint64_t *in) {
+    if (!ctx || !in) return SIMKA_ERR_INVALID;
+    const uint32_t N = ctx->cfg.nb_samples;
+    HIPCHK(hipMemcpyAsync(ctx->d_stats + stats_off_tot(N, ctx->cfg.dist_flags, 0), in, (size_t)SIMKA_NB_TOTALS * N * 8, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
     return SIMKA_OK;
 }
 

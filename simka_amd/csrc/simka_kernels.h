@@ -42,8 +42,13 @@
 #define SIMKA_ACC_SJI 1
 #define SIMKA_ACC_A 2
 #define SIMKA_ACC_BC 3
-#define SIMKA_ACC_CHORD 4
+#define SIMKA_ACC_CHORD 4      // simple (present iff SIMKA_DIST_SIMPLE)
 #define SIMKA_ACC_HELL 5
+// complex: two more arrays after the simple ones (index = nacc32 + {0,1}); 64-bit LDS cells
+//   WHIT : sum over both-present pairs of  w(ci,cj) - g(ci,Nj) - g(cj,Ni)   (two's complement), + host bias
+//   KLFIX: sum over both-present pairs of the KL term, fixed point 2^-52 (two's complement)
+#define SIMKA_KL_SCALE 4503599627370496.0   // 2^52
+#define SIMKA_HIST_MAX 1024    // per-sample histogram of solid counts (complex): exact bins below, list above
 
 // device error word bits
 #define SIMKA_DEVERR_TABLE_OVERFLOW 1u
@@ -71,6 +76,10 @@ struct SimkaCountOut {
     uint32_t sample, nb_samples;
     uint32_t *err;
     unsigned long long *phase;               // debug phase timers (SIMKA_PHASE_PROF builds), else NULL
+    unsigned long long *hist;                // [N][SIMKA_HIST_MAX] histogram of solid counts, NULL unless complex
+    uint32_t *ovf_list;                      // (sample,count) pairs for counts >= SIMKA_HIST_MAX
+    unsigned long long *ovf_cursor;
+    unsigned long long ovf_cap;
 };
 
 struct SimkaMergeIn {
@@ -100,7 +109,11 @@ struct SimkaCsrOut {
 struct SimkaPairCfg {
     uint32_t nb_samples;
     uint32_t tile, ntiles;       // sample tile edge, #tiles
-    uint32_t nacc;               // 4 (default) or 6 (simple)
+    uint32_t nacc;               // all accumulator arrays: nacc32 + nacc64
+    uint32_t nacc32;             // 4 (default) or 6 (simple): u32 LDS cells
+    uint32_t nacc64;             // 0 or 2 (complex): u64 LDS cells
+    uint32_t simple;             // chord/hell present
     uint32_t ncell, ncell_pad;   // LDS cells per accumulator
     uint64_t nb_pairs;           // N(N-1)/2
+    const unsigned long long *tot_n;   // [N] per-sample N_i (GLOBAL totals), complex only
 };

@@ -316,6 +316,8 @@ k_count(const uint64_t *l1_keys, const ull *b1_start, const uint32_t *chunk_firs
     uint32_t *tcnt = (uint32_t *)(tkeys + TS);        // [TS]
     uint32_t *segpre = tcnt + TS;                     // [K2_MAXSEG+1] flat index of each chunk's segment
     uint32_t *segbeg = segpre + K2_MAXSEG + 1;        // [K2_MAXSEG]   first key of the segment inside its chunk
+    uint32_t *lhist = segbeg + K2_MAXSEG;             // [SIMKA_HIST_MAX] solid-count histogram (complex only)
+    if (o.hist) for (uint32_t i = threadIdx.x; i < SIMKA_HIST_MAX; i += K2C_BLOCK) lhist[i] = 0;
 
     const uint32_t B2 = 1u << cfg.l2;
     const uint32_t nparts = 1u << cfg.pb;
@@ -445,6 +447,13 @@ k_count(const uint64_t *l1_keys, const ull *b1_start, const uint32_t *chunk_firs
                                 const uint32_t pos = atomicAdd(&s_cur, 1u);
                                 o.solid_keys[emit_base + pos] = tkeys[i * 4 + j];
                                 o.solid_counts[emit_base + pos] = c;
+                                if (o.hist) {
+                                    if (c < SIMKA_HIST_MAX) atomicAdd(&lhist[c], 1u);
+                                    else {
+                                        const ull w = atomicAdd(o.ovf_cursor, 1ull);
+                                        if (w < o.ovf_cap) { o.ovf_list[2 * w] = o.sample; o.ovf_list[2 * w + 1] = c; }
+                                    }
+                                }
                             }
                         }
                     }
@@ -481,6 +490,11 @@ k_count(const uint64_t *l1_keys, const ull *b1_start, const uint32_t *chunk_firs
 #ifdef SIMKA_PHASE_PROF
     if (tid == 0 && o.phase) for (int i = 0; i < 6; i++) atomicAdd(&o.phase[i], ph[i]);
 #endif
+    if (o.hist) {
+        __syncthreads();
+        for (uint32_t i = tid; i < SIMKA_HIST_MAX; i += K2C_BLOCK)
+            if (lhist[i]) atomicAdd(&o.hist[(size_t)o.sample * SIMKA_HIST_MAX + i], (ull)lhist[i]);
+    }
     // block totals -> per-sample totals (column layout: totals[T * nb_samples + sample]); one set of atomics per block
     if (bt_dall) atomicAdd(&s_tot[0], bt_dall);
     if (bt_D) { atomicAdd(&s_tot[1], bt_D); atomicAdd(&s_tot[2], bt_N); atomicAdd(&s_tot[3], bt_Q); }
@@ -686,6 +700,13 @@ k_group(const ull *mkeys, const ull *mvals, const uint32_t *fb_off, uint32_t nfb
 // into u32 LDS accumulators private to the block; a wrap of the low word carries 2^32 straight
 // into the global u64 cell, so the sums are exact.  Blocks are persistent over the span list.
 // --------------------------------------------------------------------------------------------
+// |(int)(u64)| as the reference computes it: abs((int)(...)) then u64 += int  (ref: src/core/SimkaAlgorithm.hpp:481)
+__device__ __forceinline__ ull simka_whit_abs(ull d) {
+    const int t = (int)d;
+    const int r = (t == (int)0x80000000) ? t : (t < 0 ? -t : t);
+    return (ull)(long long)r;
+}
+
 __device__ __forceinline__ void acc_add(uint32_t *l, ull *g, uint32_t v) {
     const uint32_t old = atomicAdd(l, v);
     if ((uint32_t)(old + v) < old) atomicAdd(g, 1ull << 32);
@@ -710,8 +731,9 @@ __global__ void __launch_bounds__(K4_BLOCK)
 k_pairs(const SimkaSpan *spans, const ull *cursors, const ull *entries, const uint32_t *groups, SimkaPairCfg pc,
         ull *acc, ull *slabs) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    uint32_t *lacc = (uint32_t *)(smem + SIMKA_LDS_HEAD);       // [nacc][ncell_pad]
-    ull *ent = (ull *)(lacc + (size_t)pc.nacc * pc.ncell_pad);  // [K3_CAP]
+    ull *lacc64 = (ull *)(smem + SIMKA_LDS_HEAD);               // [nacc64][ncell_pad]  (whit, klfix)
+    uint32_t *lacc = (uint32_t *)(lacc64 + (size_t)pc.nacc64 * pc.ncell_pad);   // [nacc32][ncell_pad]
+    ull *ent = (ull *)(lacc + (size_t)pc.nacc32 * pc.ncell_pad);  // [K3_CAP]
     uint32_t *gdesc = (uint32_t *)(ent + K3_CAP);               // [K3_CAP]   (start<<16 | size)
     uint32_t *gpref = gdesc + K3_CAP;                           // [K3_CAP+1] pair prefix
     uint32_t *tmp = gpref + K3_CAP + 1;                         // [K4_BLOCK]
@@ -725,7 +747,8 @@ k_pairs(const SimkaSpan *spans, const ull *cursors, const ull *entries, const ui
         for (I = 0; I < pc.ntiles; I++) { const uint32_t row = pc.ntiles - I; if (r < row) { J = I + r; break; } r -= row; }
     }
     const uint32_t ncell = pc.ncell;
-    for (uint32_t i = tid; i < pc.nacc * pc.ncell_pad; i += K4_BLOCK) lacc[i] = 0;
+    for (uint32_t i = tid; i < pc.nacc32 * pc.ncell_pad; i += K4_BLOCK) lacc[i] = 0;
+    for (uint32_t i = tid; i < pc.nacc64 * pc.ncell_pad; i += K4_BLOCK) lacc64[i] = 0;
     __syncthreads();
 
     const ull nspans = cursors[2];
@@ -769,7 +792,18 @@ k_pairs(const SimkaSpan *spans, const ull *cursors, const ull *entries, const ui
                     acc_add(&lacc[SIMKA_ACC_SJI * pc.ncell_pad + cell], &acc[SIMKA_ACC_SJI * pc.nb_pairs + pg], cj);
                     atomicAdd(&lacc[SIMKA_ACC_A * pc.ncell_pad + cell], 1u);
                     acc_add(&lacc[SIMKA_ACC_BC * pc.ncell_pad + cell], &acc[SIMKA_ACC_BC * pc.nb_pairs + pg], ci < cj ? ci : cj);
-                    if (pc.nacc > 4) {
+                    if (pc.nacc64) {
+                        // updateDistanceComplex restricted to both-present pairs (ref: src/core/SimkaAlgorithm.hpp:437-446,477-481);
+                        // the one-sided terms are closed forms of S / totals / count histograms, added on the host
+                        const double Ni = (double)pc.tot_n[si], Nj = (double)pc.tot_n[sj];
+                        const double ai = (double)ci, aj = (double)cj;
+                        const double xY = ai * Nj, yX = aj * Ni;
+                        const double d = (ai / Ni) * log((2 * xY) / (xY + yX)) + (aj / Nj) * log((2 * yX) / (xY + yX));
+                        atomicAdd(&lacc64[1 * pc.ncell_pad + cell], (ull)(long long)llrint(d * SIMKA_KL_SCALE));
+                        const ull uX = (ull)xY, uY = (ull)yX;
+                        atomicAdd(&lacc64[0 * pc.ncell_pad + cell], simka_whit_abs(uX - uY) - simka_whit_abs(uX) - simka_whit_abs(uY));
+                    }
+                    if (pc.simple) {
                         const ull prod = (ull)ci * (ull)cj;
                         acc_add(&lacc[SIMKA_ACC_CHORD * pc.ncell_pad + cell], &acc[SIMKA_ACC_CHORD * pc.nb_pairs + pg], (uint32_t)prod);
                         if (prod >> 32) atomicAdd(&acc[SIMKA_ACC_CHORD * pc.nb_pairs + pg], (prod >> 32) << 32);
@@ -794,9 +828,13 @@ k_pairs(const SimkaSpan *spans, const ull *cursors, const ull *entries, const ui
     // ---- fold this block's private accumulators into its slab (plain read-modify-write: the slab
     // row belongs to this block alone); k_reduce_slabs sums the rows at the end of the merge
     ull *slab = slabs + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * pc.nacc * pc.ncell_pad;
-    for (uint32_t i = tid; i < pc.nacc * pc.ncell_pad; i += K4_BLOCK) {
+    for (uint32_t i = tid; i < pc.nacc32 * pc.ncell_pad; i += K4_BLOCK) {
         const uint32_t v = lacc[i];
         if (v) slab[i] += v;
+    }
+    for (uint32_t i = tid; i < pc.nacc64 * pc.ncell_pad; i += K4_BLOCK) {
+        const ull v = lacc64[i];
+        if (v) slab[(size_t)pc.nacc32 * pc.ncell_pad + i] += v;
     }
     (void)ncell;
 }

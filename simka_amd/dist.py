@@ -33,17 +33,34 @@ def allreduce_stats_host(flat_u64):
     return t.numpy().view(np.uint64).copy()
 
 
-def allreduce_stats_device(ctx):
-    """In-place all-reduce of the ctx's DEVICE statistics buffer (no host bounce): the buffer is wrapped as an
-    int64 CUDA tensor through __cuda_array_interface__ and handed to RCCL."""
-    if not (dist.is_initialized() and dist.get_world_size() > 1):
-        return
-    ptr, n = ctx.stats_device_buffer()
-    ctx.sync()
-
+def _allreduce_device_words(ptr, n):
     class _Wrap:
         __cuda_array_interface__ = {"shape": (n,), "typestr": "<i8", "data": (ptr, False), "version": 2}
 
     t = torch.as_tensor(_Wrap(), device="cuda")
     dist.all_reduce(t, op=dist.ReduceOp.SUM)
     torch.cuda.synchronize()
+
+
+def allreduce_stats_device(ctx, totals_already_reduced=False):
+    """In-place all-reduce of the ctx's DEVICE statistics buffer (no host bounce): the buffer is wrapped as an
+    int64 CUDA tensor through __cuda_array_interface__ and handed to RCCL.  After allreduce_totals_device() only the
+    head (header + pair arrays) is reduced, so the totals are not summed twice."""
+    if not (dist.is_initialized() and dist.get_world_size() > 1):
+        return
+    ctx.sync()
+    if totals_already_reduced:
+        (hp, hn), _ = ctx.stats_device_ranges()
+        _allreduce_device_words(hp, hn)
+    else:
+        ptr, n = ctx.stats_device_buffer()
+        _allreduce_device_words(ptr, n)
+
+
+def allreduce_totals_device(ctx):
+    """-complex-dist, sharded: make the per-sample totals global BEFORE simka_merge."""
+    if not (dist.is_initialized() and dist.get_world_size() > 1):
+        return
+    ctx.sync()
+    _, (tp, tn) = ctx.stats_device_ranges()
+    _allreduce_device_words(tp, tn)

@@ -140,16 +140,31 @@ class Oracle:
         self.l.oracle_get_sample_solid(self.h, i, k.ctypes.data, c.ctypes.data)
         return k[:n], c[:n]
 
-    def flat_stats(self, simple, nparts=1, shard_index=0, shard_count=1):
-        """Pack the oracle accumulators into the product's flat u64 layout (include/simka_hip.h, simka_stats_view)."""
+    def flat_stats(self, simple, complex_=False, nparts=1, shard_index=0, shard_count=1):
+        """Pack the oracle accumulators into the product's flat u64 layout (include/simka_hip.h, simka_stats_layout):
+        [8 header | S_ij S_ji a bc (chord hell) (whit klfix) x P | D N Q D_all K_occ x N | (canb, kl f64 x P: host-derived)]"""
         n = self.n
         iu = np.triu_indices(n, 1)
+        P = len(iu[0])
         tot = self.shard_totals(nparts, shard_index, shard_count) if shard_count > 1 else self.totals()
+        full = self.totals()
         S = self.acc("S")
-        parts = [np.zeros(8, dtype=np.uint64), tot["D"], tot["N"], tot["Q"], np.zeros(n, dtype=np.uint64), np.zeros(n, dtype=np.uint64),
-                 S[iu], S.T[iu], self.acc("a")[iu], self.acc("bc")[iu]]
+        parts = [np.zeros(8, dtype=np.uint64), S[iu], S.T[iu], self.acc("a")[iu], self.acc("bc")[iu]]
         if simple:
             parts += [self.acc("chord")[iu], self.acc("hell")[iu]]
+        if complex_:
+            # klfix = the both-present part of KL in 2^-52 fixed point (what the device accumulates)
+            Nk = full["N"].astype(np.float64)
+            kl = self.kl()[iu].astype(np.longdouble)
+            one = np.zeros(P, dtype=np.longdouble)
+            for c, (i, j) in enumerate(zip(*iu)):
+                one[c] = np.log(np.longdouble(2)) * (np.longdouble(int(tot["N"][i]) - int(S[i, j])) / np.longdouble(Nk[i]) +
+                                                     np.longdouble(int(tot["N"][j]) - int(S[j, i])) / np.longdouble(Nk[j]))
+            klfix = np.rint((kl - one) * np.longdouble(2.0 ** 52)).astype(np.int64).view(np.uint64)
+            parts += [self.acc("whit")[iu], klfix]
+        parts += [tot["D"], tot["N"], tot["Q"], np.zeros(n, dtype=np.uint64), np.zeros(n, dtype=np.uint64)]
+        if complex_:
+            parts += [np.zeros(2 * P, dtype=np.uint64)]
         flat = np.concatenate([np.asarray(p, dtype=np.uint64) for p in parts])
         d, s = self.global_counts()
         flat[0], flat[1] = d, s

@@ -68,12 +68,12 @@ def test_matrix_catalogue_matches_reference_order(simka_lib, oracle_mod):
 @pytest.mark.parametrize("k,amin", CONFIGS)
 def test_host_finalisation_and_csv_vs_goldens(simka_lib, oracle_mod, golden_dir, tmp_path, k, amin):
     """Feed the ORACLE's integer accumulators through the PRODUCT's host finalisation + CSV writer:
-    the 17 non-complex goldens must come out byte-exact (SimkaDistance.cpp:603-699,920-1226)."""
+    all 20 goldens must come out byte-exact (SimkaDistance.cpp:603-699,920-1226)."""
     import simka_amd
     o = oracle_mod.Oracle()
     o.load_input(os.path.join(golden_dir, "example", "simka_input.txt"))
-    o.run(k, amin, simple=True)
-    st = simka_amd.Stats(o.n, simka_amd.DIST_SIMPLE, o.flat_stats(simple=True))
+    o.run(k, amin, simple=True, complex_=True)
+    st = simka_amd.Stats(o.n, simka_amd.DIST_SIMPLE | simka_amd.DIST_COMPLEX, o.flat_stats(simple=True, complex_=True))
     out = str(tmp_path / "csv")
     st.write_matrices(out, o.ids(), gz=True)
     truth = os.path.join(golden_dir, "truth", "results_k%d_t%d" % (k, amin))
@@ -84,7 +84,10 @@ def test_host_finalisation_and_csv_vs_goldens(simka_lib, oracle_mod, golden_dir,
             with gzip.open(gzf, "rb") as f, open(ref, "rb") as g:
                 assert f.read() == g.read(), os.path.basename(gzf)
             n += 1
-    assert n == 17
+    assert n == 20
+    iu = np.triu_indices(o.n, 1)
+    assert np.array_equal(st.pairs()["canb"], o.acc("canb")[iu])          # D_i + D_j - 2a identity
+    np.testing.assert_allclose(st.pairs()["kl"], o.kl()[iu], rtol=1e-12)
     for w, name in enumerate(o.matrix_names()):     # unpinned mat_abundance_jaccard too: equal to the oracle's
         if name in st.matrices():
             assert np.array_equal(st.matrices()[name], o.matrix(w)), name
@@ -102,13 +105,16 @@ def test_pack_read_splits_at_non_acgt(simka_lib):
 def test_stats_layout_roundtrip(simka_lib):
     import simka_amd
     n = 7
+    P = n * (n - 1) // 2
     size = simka_lib.simka_stats_nb_u64(n, simka_amd.DIST_SIMPLE)
-    assert size == 8 + 5 * n + 6 * (n * (n - 1) // 2)
+    assert size == 8 + 6 * P + 5 * n
+    assert simka_lib.simka_stats_nb_u64(n, 3) == 8 + 8 * P + 5 * n + 2 * P
     flat = np.arange(size, dtype=np.uint64)
     st = simka_amd.Stats(n, simka_amd.DIST_SIMPLE, flat)
-    assert list(st.per_sample()["D"]) == list(range(8, 8 + n))
-    assert st.pairs()["S_ij"][0] == 8 + 5 * n
-    assert st.dense("S")[0, 1] == 8 + 5 * n and st.dense("S")[1, 0] == 8 + 5 * n + n * (n - 1) // 2
+    assert st.layout == {"nacc": 6, "acc0": 8, "tot0": 8 + 6 * P, "derived": 8 + 6 * P + 5 * n, "nb_pairs": P, "head": 8 + 6 * P, "total": size}
+    assert list(st.per_sample()["D"]) == list(range(8 + 6 * P, 8 + 6 * P + n))
+    assert st.pairs()["S_ij"][0] == 8
+    assert st.dense("S")[0, 1] == 8 and st.dense("S")[1, 0] == 8 + P
 
 
 def test_cli_error_conventions(simka_lib):

@@ -24,9 +24,9 @@ def _load_example(golden_dir):
     return samples, packed
 
 
-def _run_gpu(packed, k, amin, simple=True, **kw):
+def _run_gpu(packed, k, amin, simple=True, complex_=True, **kw):
     import simka_amd
-    ctx = simka_amd.SimkaContext(len(packed), kmer_size=k, abundance_min=amin, simple_dist=simple, **kw)
+    ctx = simka_amd.SimkaContext(len(packed), kmer_size=k, abundance_min=amin, simple_dist=simple, complex_dist=complex_, **kw)
     for i, (pk, off, nb, nin) in enumerate(packed):
         ctx.count_sample(i, pk, nb, len(off) - 1, offsets=off, nb_input_reads=nin)
     totals = [ctx.sample_totals(i) for i in range(len(packed))]
@@ -36,7 +36,7 @@ def _run_gpu(packed, k, amin, simple=True, **kw):
     return totals, st
 
 
-def _check_vs_oracle(totals, st, orc, simple=True):
+def _check_vs_oracle(totals, st, orc, simple=True, complex_=True):
     ot = orc.totals()
     for i, t in enumerate(totals):
         for key in ("K_occ", "D_all", "D", "N", "Q"):
@@ -53,6 +53,10 @@ def _check_vs_oracle(totals, st, orc, simple=True):
         assert np.array_equal(pr["chord"], orc.acc("chord")[iu])
         assert np.array_equal(pr["hell"], orc.acc("hell")[iu])
         assert np.array_equal(pr["bc"], orc.acc("kul")[iu])     # kul[i][j] == bc identity
+    if complex_:
+        assert np.array_equal(pr["whit"], orc.acc("whit")[iu])      # incl. the reference's int32-cast quirk
+        assert np.array_equal(pr["canb"], orc.acc("canb")[iu])
+        np.testing.assert_allclose(pr["kl"], orc.kl()[iu], rtol=1e-9, atol=1e-15)
     d, s = orc.global_counts()
     assert (int(st.view.nb_distinct_kmers), int(st.view.nb_shared_kmers)) == (d, s)
 
@@ -64,7 +68,7 @@ def test_example_accumulators_and_csv(gpu_required, oracle_mod, golden_dir, tmp_
     totals, st = _run_gpu(packed, k, amin, simple=True)
     orc = oracle_mod.Oracle()
     orc.load_input(os.path.join(golden_dir, "example", "simka_input.txt"))
-    orc.run(k, amin, simple=True)
+    orc.run(k, amin, simple=True, complex_=True)
     _check_vs_oracle(totals, st, orc)
     out = str(tmp_path / "res")
     st.write_matrices(out, [s["id"] for s in samples], gz=True)
@@ -78,7 +82,7 @@ def test_example_accumulators_and_csv(gpu_required, oracle_mod, golden_dir, tmp_
         with gzip.open(gzf, "rb") as f, open(ref, "rb") as g:
             assert f.read() == g.read(), name
         compared += 1
-    assert compared == 17       # 20 goldens minus the 3 -complex-dist matrices
+    assert compared == 20       # every golden of the configuration, -simple-dist and -complex-dist included
 
 
 def _synthetic(n_samples, nb_reads, read_len, seed_shift=0):
@@ -110,7 +114,7 @@ def test_synthetic_vs_oracle(gpu_required, oracle_mod, k, amin, n, R, L, kw):
     orc = oracle_mod.Oracle()
     for s, pk in enumerate(packed):
         orc.add_sample_ascii("S%d" % s, synth.unpack_ascii(pk, R * L), np.arange(R + 1, dtype=np.uint64) * L)
-    orc.run(k, amin, simple=True)
+    orc.run(k, amin, simple=True, complex_=True)
     _check_vs_oracle(totals, st, orc)
     # floating-point distances: <= 1e-6 relative (north_star tolerance) -- here they are float32-identical
     for w, name in enumerate(orc.matrix_names()):
@@ -125,7 +129,7 @@ def test_fixed_len_equals_offsets(gpu_required):
     a = [(np.concatenate([pk, np.zeros(2, dtype=np.uint64)]), np.arange(R + 1, dtype=np.uint64) * L, R * L, R) for pk in packed]
     _, st1 = _run_gpu(a, 21, 2)
     import simka_amd
-    ctx = simka_amd.SimkaContext(3, kmer_size=21, abundance_min=2, simple_dist=True)
+    ctx = simka_amd.SimkaContext(3, kmer_size=21, abundance_min=2, simple_dist=True, complex_dist=True)
     for i, pk in enumerate(packed):
         ctx.count_sample(i, np.concatenate([pk, np.zeros(2, dtype=np.uint64)]), R * L, R, fixed_len=L)
     ctx.merge()
@@ -142,7 +146,7 @@ def test_cli_drop_in_on_example(gpu_required, golden_dir, tmp_path, k, amin):
     from simka_amd import build as b
     out, tmp = str(tmp_path / "out"), str(tmp_path / "tmp")
     cmd = [b.CLI_PATH, "-in", os.path.join(golden_dir, "example", "simka_input.txt"), "-out", out, "-out-tmp", tmp,
-           "-simple-dist", "-kmer-size", str(k), "-abundance-min", str(amin), "-verbose", "0"]
+           "-simple-dist", "-complex-dist", "-kmer-size", str(k), "-abundance-min", str(amin), "-verbose", "0"]
     r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
     assert r.returncode == 0, r.stdout
     truth = os.path.join(golden_dir, "truth", "results_k%d_t%d" % (k, amin))
@@ -153,7 +157,7 @@ def test_cli_drop_in_on_example(gpu_required, golden_dir, tmp_path, k, amin):
             with gzip.open(gzf, "rb") as f, open(ref, "rb") as g:
                 assert f.read() == g.read(), os.path.basename(gzf)
             n += 1
-    assert n == 17
+    assert n == 20
     # resource-invariance of the reference's test (tests/simple_test.py:125-133): other core/memory settings, same bytes
     out2 = str(tmp_path / "out2")
     r = subprocess.run(cmd[:4] + [out2] + cmd[5:] + ["-nb-cores", "2", "-max-memory", "2000"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
