@@ -66,7 +66,9 @@ typedef struct simka_config {
  * code A=0 C=1 T=2 G=3 (= (ascii>>1)&3, the tree's own convention, ref: src/core/SimkaCommons.hpp:400-411).
  * Reads are concatenated without padding.  Non-ACGT letters never reach the device: the host
  * packer splits a read at them (a k-mer window containing one is skipped, gatb Kmer model).
- * `packed` must be readable for 16 bytes past the last word. */
+ * `packed` must be readable for 16 bytes past the last word.  Host buffers may be reused as soon as
+ * simka_count_sample returns; DEVICE buffers must stay valid until the next synchronising call on the
+ * context (simka_get_sample_totals / simka_merge / simka_sync) has returned. */
 typedef struct simka_reads {
     const uint64_t *packed;
     uint64_t nb_bases;           /* total bases over all fragments */

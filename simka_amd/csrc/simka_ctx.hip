@@ -38,7 +38,11 @@ struct simka_ctx {
     uint64_t *d_reads = nullptr; uint64_t reads_cap = 0;      // staging for host reads (words)
     uint64_t *d_offsets = nullptr; uint64_t offsets_cap = 0;
     uint64_t *d_l1 = nullptr; uint64_t l1_cap = 0;            // level-1 buckets (keys)
-    ull *d_b1_count = nullptr, *d_b1_start = nullptr, *d_b1_cursor = nullptr;
+    ull *d_b1_count = nullptr, *d_b1_start = nullptr, *d_b1_end = nullptr, *d_b1_cursor = nullptr;
+    uint32_t *d_l1_ovf = nullptr;                             // [N] capacity-mode scatter overflow flag per sample
+    uint64_t nb_exact_fallbacks = 0;
+    struct Pending { uint32_t sample; SimkaScanArgs a; };     // device-resident samples whose flag has not been read yet
+    std::vector<Pending> pending;
     uint32_t *d_chunk_first = nullptr;
     uint16_t *d_chunk_off = nullptr; uint64_t chunk_cap = 0;  // chunks
     // solid spectra of all samples
@@ -219,6 +223,9 @@ static int setup_geometry(simka_ctx *ctx, uint64_t max_kmers) {
     const uint32_t N = c.nb_samples;
     HIPCHK(dev_alloc(&ctx->d_b1_count, ctx->B1 + 1));
     HIPCHK(dev_alloc(&ctx->d_b1_start, ctx->B1 + 1));
+    HIPCHK(dev_alloc(&ctx->d_b1_end, ctx->B1 + 1));
+    HIPCHK(dev_alloc(&ctx->d_l1_ovf, c.nb_samples + 1));
+    HIPCHK(hipMemsetAsync(ctx->d_l1_ovf, 0, (size_t)(c.nb_samples + 1) * 4, ctx->stream));
     HIPCHK(dev_alloc(&ctx->d_b1_cursor, ctx->B1 + 1));
     HIPCHK(dev_alloc(&ctx->d_chunk_first, ctx->B1 + 1));
     HIPCHK(dev_alloc(&ctx->d_foff, (uint64_t)N * ctx->nparts));
@@ -304,7 +311,7 @@ SIMKA_EXPORT void simka_destroy(simka_ctx *ctx) {
     if (!ctx) return;
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     for (auto &ev : ctx->events) { (void)hipEventDestroy(ev.a); (void)hipEventDestroy(ev.b); }
-    void *ptrs[] = { ctx->d_reads, ctx->d_offsets, ctx->d_l1, ctx->d_b1_count, ctx->d_b1_start, ctx->d_b1_cursor,
+    void *ptrs[] = { ctx->d_reads, ctx->d_offsets, ctx->d_l1, ctx->d_b1_count, ctx->d_b1_start, ctx->d_b1_end, ctx->d_l1_ovf, ctx->d_b1_cursor,
                      ctx->d_chunk_first, ctx->d_chunk_off, ctx->d_solid_keys, ctx->d_solid_counts, ctx->d_arena_cursor,
                      ctx->d_sample_base, ctx->d_foff, ctx->d_fcnt, ctx->d_stats, ctx->d_err, ctx->d_part_total,
                      ctx->d_part_off, ctx->d_mkeys, ctx->d_mvals, ctx->d_entries, ctx->d_groups, ctx->d_fb_off,
@@ -335,6 +342,8 @@ SIMKA_EXPORT int simka_reset(simka_ctx *ctx) {
         HIPCHK(hipMemsetAsync(ctx->d_hist, 0, (uint64_t)N * SIMKA_HIST_MAX * 8, ctx->stream));
         HIPCHK(hipMemsetAsync(ctx->d_ovf_cursor, 0, 16, ctx->stream));
     }
+    ctx->pending.clear();
+    if (ctx->d_l1_ovf) HIPCHK(hipMemsetAsync(ctx->d_l1_ovf, 0, (size_t)(N + 1) * 4, ctx->stream));
     std::fill(ctx->counted.begin(), ctx->counted.end(), 0);
     std::fill(ctx->nb_reads.begin(), ctx->nb_reads.end(), 0);
     ctx->merged = false;
@@ -361,6 +370,111 @@ static int ensure_cap(simka_ctx *ctx, T **p, uint64_t *cap, uint64_t need) {
     hipError_t e = dev_alloc(p, n);
     if (e != hipSuccess) return ctx->fail(SIMKA_ERR_NOMEM, "hipMalloc of %llu bytes failed: %s", (unsigned long long)(n * sizeof(T)), hipGetErrorString(e));
     *cap = n;
+    return SIMKA_OK;
+}
+
+// enqueue the count-side kernels of one sample.  exact=false: capacity-sized level-1 buckets, no histogram pass; the
+// kernels after the scatter skip themselves if it flags an overflow, and resolve_pending() redoes the sample exactly.
+static int run_count_kernels(simka_ctx *ctx, uint32_t sample, const SimkaScanArgs &a, bool exact) {
+    const uint32_t N = ctx->cfg.nb_samples;
+    int rc;
+    const SimkaKeyCfg key = ctx->key;
+    const uint32_t B1 = ctx->B1, B2 = ctx->B2;
+    ull *kocc = (ull *)ctx->d_stats + stats_off_tot(N, ctx->cfg.dist_flags, SIMKA_TOT_KOCC) + sample;
+    const uint64_t tile = (uint64_t)K1_BLOCK * K1_SEG;
+    const uint32_t grid1 = (uint32_t)((a.nb_bases + tile - 1) / tile);
+    const size_t lds_hist = SIMKA_LDS_HEAD + (size_t)B1 * 16 + K1_BLOCK * 4;
+    const size_t lds_scat = lds_hist + (size_t)tile * 8;
+    const size_t lds_lay = SIMKA_LDS_HEAD + (size_t)B1 * 8;
+    uint32_t *flag = ctx->d_l1_ovf + sample;
+    const uint32_t *skip = exact ? nullptr : flag;
+    auto layout = [&](uint32_t mode, ull capb) {
+        launch_timed(ctx, KID_LAYOUT, [&] {
+            hipLaunchKernelGGL(k_layout, dim3(1), dim3(256), lds_lay, ctx->stream, ctx->d_b1_count, ctx->d_b1_start, ctx->d_b1_end,
+                               ctx->d_b1_cursor, ctx->d_chunk_first, B1, ctx->d_arena_cursor, ctx->d_sample_base + sample, mode, capb,
+                               kocc, skip);
+        });
+    };
+    // Level-1 buckets.  Keys are hash-partitioned, so bucket sizes concentrate around K_occ/B1: size every bucket for that
+    // (+10 % + slack) and scatter directly.  Only if a bucket overflows (heavy repeats) is the sample redone with the exact
+    // histogram -> scan -> scatter sequence.
+    static const bool force_exact = getenv("SIMKA_EXACT_SIZING") != nullptr;
+    if (force_exact) exact = true, skip = nullptr;
+    uint64_t max_chunks;
+    if (!exact) {
+        const uint64_t kocc_upper = a.fixed_len ? (a.fixed_len >= key.k ? a.nb_reads * (uint64_t)(a.fixed_len - key.k + 1) : 0) : a.nb_bases;
+        const uint64_t per_bucket = kocc_upper / B1;
+        const uint64_t capb = per_bucket + per_bucket / 10 + 2048;
+        rc = ensure_cap(ctx, &ctx->d_l1, &ctx->l1_cap, capb * B1); if (rc) return rc;
+        max_chunks = (capb * B1) / K2_CHUNK + B1 + 1;
+        layout(1, capb);
+        launch_timed(ctx, KID_SCAN_SCATTER, [&] {
+            hipLaunchKernelGGL((k_scan<true>), dim3(grid1), dim3(K1_BLOCK), lds_scat, ctx->stream, a, key, ctx->d_b1_count,
+                               ctx->d_b1_cursor, ctx->d_l1, kocc, ctx->d_b1_end, flag);
+        });
+        layout(2, capb);
+        simka_ctx::Pending p; p.sample = sample; p.a = a;
+        ctx->pending.push_back(p);
+    } else {
+        rc = ensure_cap(ctx, &ctx->d_l1, &ctx->l1_cap, a.nb_bases); if (rc) return rc;
+        max_chunks = a.nb_bases / K2_CHUNK + B1 + 1;
+        HIPCHK(hipMemsetAsync(ctx->d_b1_count, 0, (B1 + 1) * 8, ctx->stream));
+        launch_timed(ctx, KID_SCAN_HIST, [&] {
+            hipLaunchKernelGGL((k_scan<false>), dim3(grid1), dim3(K1_BLOCK), lds_hist, ctx->stream, a, key, ctx->d_b1_count,
+                               ctx->d_b1_cursor, ctx->d_l1, kocc, (const ull *)nullptr, (uint32_t *)nullptr);
+        });
+        layout(0, 0);
+        launch_timed(ctx, KID_SCAN_SCATTER, [&] {
+            hipLaunchKernelGGL((k_scan<true>), dim3(grid1), dim3(K1_BLOCK), lds_scat, ctx->stream, a, key, ctx->d_b1_count,
+                               ctx->d_b1_cursor, ctx->d_l1, kocc, (const ull *)nullptr, (uint32_t *)nullptr);
+        });
+    }
+    if (key.l2) {
+        rc = ensure_cap(ctx, &ctx->d_chunk_off, &ctx->chunk_cap, max_chunks * (B2 + 1)); if (rc) return rc;
+        const size_t lds_split = SIMKA_LDS_HEAD + (size_t)B2 * 4 + K2_BLOCK * 4 + (size_t)K2_CHUNK * 8;
+        launch_timed(ctx, KID_SPLIT, [&] {
+            hipLaunchKernelGGL(k_split, dim3((uint32_t)max_chunks), dim3(K2_BLOCK), lds_split, ctx->stream, ctx->d_l1,
+                               ctx->d_b1_start, ctx->d_b1_end, ctx->d_chunk_first, ctx->d_chunk_off, key, skip);
+        });
+    }
+    SimkaCountOut o;
+    o.arena_cursor = ctx->d_arena_cursor; o.sample_base = ctx->d_sample_base + sample; o.arena_cap = ctx->arena_cap;
+    o.solid_keys = ctx->d_solid_keys; o.solid_counts = ctx->d_solid_counts;
+    o.foff = ctx->d_foff + (uint64_t)sample * ctx->nparts; o.fcnt = ctx->d_fcnt + (uint64_t)sample * ctx->nparts;
+    o.totals = (ull *)ctx->d_stats + stats_off_tot(N, ctx->cfg.dist_flags, 0); o.sample = sample; o.nb_samples = N; o.err = ctx->d_err;
+    o.phase = nullptr;
+    o.hist = ctx->d_hist; o.ovf_list = ctx->d_ovf_list; o.ovf_cursor = ctx->d_ovf_cursor; o.ovf_cap = ctx->ovf_cap;
+    // tuning knobs (experiments): table size and resident blocks per CU
+    static const uint32_t tlog = getenv("SIMKA_K2_TABLE_LOG2") ? (uint32_t)atoi(getenv("SIMKA_K2_TABLE_LOG2")) : (uint32_t)K2_TABLE_LOG2;
+    const size_t lds_count = SIMKA_LDS_HEAD + ((size_t)12 << tlog) + (size_t)(2 * K2_MAXSEG + 1) * 4 + (ctx->d_hist ? (size_t)SIMKA_HIST_MAX * 4 : 0);
+    static const uint32_t bpc = getenv("SIMKA_K2_BLOCKS_PER_CU") ? (uint32_t)atoi(getenv("SIMKA_K2_BLOCKS_PER_CU")) : (uint32_t)std::max<size_t>(1, (160 * 1024) / lds_count);
+    launch_timed(ctx, KID_COUNT, [&] {
+        const uint32_t grid_count = (uint32_t)std::min<uint64_t>(ctx->nparts, (uint64_t)ctx->num_cus * bpc);
+        hipLaunchKernelGGL(k_count, dim3(grid_count), dim3(K2C_BLOCK), lds_count, ctx->stream, ctx->d_l1,
+                           ctx->d_b1_start, ctx->d_b1_end, ctx->d_chunk_first, ctx->d_chunk_off, key, tlog,
+                           ctx->cfg.abundance_min, ctx->cfg.abundance_max, o, skip);
+    });
+    HIPCHK(hipGetLastError());
+    return SIMKA_OK;
+}
+
+// read the overflow flags of the samples enqueued in capacity mode; redo the flagged ones exactly (their later kernels
+// skipped themselves, so no state was touched).  Synchronises.
+static int resolve_pending(simka_ctx *ctx) {
+    if (ctx->pending.empty()) return SIMKA_OK;
+    const uint32_t N = ctx->cfg.nb_samples;
+    std::vector<uint32_t> flags(N);
+    HIPCHK(hipMemcpyAsync(flags.data(), ctx->d_l1_ovf, (size_t)N * 4, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    std::vector<simka_ctx::Pending> todo;
+    todo.swap(ctx->pending);
+    for (auto &p : todo) {
+        if (!flags[p.sample]) continue;
+        ctx->nb_exact_fallbacks++;
+        HIPCHK(hipMemsetAsync(ctx->d_l1_ovf + p.sample, 0, 4, ctx->stream));
+        int rc = run_count_kernels(ctx, p.sample, p.a, true);
+        if (rc) return rc;
+    }
     return SIMKA_OK;
 }
 
@@ -398,66 +512,9 @@ SIMKA_EXPORT int simka_count_sample(simka_ctx *ctx, uint32_t sample, const simka
         }
         HIPCHK(hipStreamSynchronize(ctx->stream));   // the host buffers may be reused by the caller right away
     }
-    const SimkaKeyCfg key = ctx->key;
-    const uint32_t B1 = ctx->B1, B2 = ctx->B2;
-    rc = ensure_cap(ctx, &ctx->d_l1, &ctx->l1_cap, r->nb_bases); if (rc) return rc;
-    const uint64_t max_chunks = r->nb_bases / K2_CHUNK + B1 + 1;
-    if (key.l2) { rc = ensure_cap(ctx, &ctx->d_chunk_off, &ctx->chunk_cap, max_chunks * (B2 + 1)); if (rc) return rc; }
-
-    ull *kocc = (ull *)ctx->d_stats + stats_off_tot(N, ctx->cfg.dist_flags, SIMKA_TOT_KOCC) + sample;
-    const uint64_t tile = (uint64_t)K1_BLOCK * K1_SEG;
-    const uint32_t grid1 = (uint32_t)((r->nb_bases + tile - 1) / tile);
-    const size_t lds_hist = SIMKA_LDS_HEAD + (size_t)B1 * 16 + K1_BLOCK * 4;
-    const size_t lds_scat = lds_hist + (size_t)tile * 8;
-
-    HIPCHK(hipMemsetAsync(ctx->d_b1_count, 0, (B1 + 1) * 8, ctx->stream));
-    launch_timed(ctx, KID_SCAN_HIST, [&] {
-        hipLaunchKernelGGL((k_scan<false>), dim3(grid1), dim3(K1_BLOCK), lds_hist, ctx->stream, a, key, ctx->d_b1_count,
-                           ctx->d_b1_cursor, ctx->d_l1, kocc);
-    });
-    launch_timed(ctx, KID_LAYOUT, [&] {
-        hipLaunchKernelGGL(k_layout, dim3(1), dim3(256), SIMKA_LDS_HEAD + (size_t)B1 * 8, ctx->stream, ctx->d_b1_count,
-                           ctx->d_b1_start, ctx->d_b1_cursor, ctx->d_chunk_first, B1, ctx->d_arena_cursor,
-                           ctx->d_sample_base + sample);
-    });
-    launch_timed(ctx, KID_SCAN_SCATTER, [&] {
-        hipLaunchKernelGGL((k_scan<true>), dim3(grid1), dim3(K1_BLOCK), lds_scat, ctx->stream, a, key, ctx->d_b1_count,
-                           ctx->d_b1_cursor, ctx->d_l1, kocc);
-    });
-    if (key.l2) {
-        const size_t lds_split = SIMKA_LDS_HEAD + (size_t)B2 * 4 + K2_BLOCK * 4 + (size_t)K2_CHUNK * 8;
-        launch_timed(ctx, KID_SPLIT, [&] {
-            hipLaunchKernelGGL(k_split, dim3((uint32_t)max_chunks), dim3(K2_BLOCK), lds_split, ctx->stream, ctx->d_l1,
-                               ctx->d_b1_start, ctx->d_chunk_first, ctx->d_chunk_off, key);
-        });
-    }
-    SimkaCountOut o;
-    o.arena_cursor = ctx->d_arena_cursor; o.sample_base = ctx->d_sample_base + sample; o.arena_cap = ctx->arena_cap;
-    o.solid_keys = ctx->d_solid_keys; o.solid_counts = ctx->d_solid_counts;
-    o.foff = ctx->d_foff + (uint64_t)sample * ctx->nparts; o.fcnt = ctx->d_fcnt + (uint64_t)sample * ctx->nparts;
-    o.totals = (ull *)ctx->d_stats + stats_off_tot(N, ctx->cfg.dist_flags, 0); o.sample = sample; o.nb_samples = N; o.err = ctx->d_err;
-    o.phase = nullptr;
-    o.hist = ctx->d_hist; o.ovf_list = ctx->d_ovf_list; o.ovf_cursor = ctx->d_ovf_cursor; o.ovf_cap = ctx->ovf_cap;
-#ifdef SIMKA_PHASE_PROF
-    static ull *d_phase = nullptr;
-    if (!d_phase) { hipMalloc((void **)&d_phase, 64); hipMemset(d_phase, 0, 64); }
-    o.phase = d_phase;
-    if (sample == N - 1) {
-        ull hph[6]; hipStreamSynchronize(ctx->stream); hipMemcpy(hph, d_phase, 48, hipMemcpyDeviceToHost);
-        fprintf(stderr, "[phase] clear %llu meta %llu keys %llu stats %llu emit %llu tail %llu (wall_clock64 ticks, summed over blocks, samples so far)\n", hph[0], hph[1], hph[2], hph[3], hph[4], hph[5]);
-    }
-#endif
-    // tuning knobs (experiments): table size and resident blocks per CU
-    static const uint32_t tlog = getenv("SIMKA_K2_TABLE_LOG2") ? (uint32_t)atoi(getenv("SIMKA_K2_TABLE_LOG2")) : (uint32_t)K2_TABLE_LOG2;
-    const size_t lds_count = SIMKA_LDS_HEAD + ((size_t)12 << tlog) + (size_t)(2 * K2_MAXSEG + 1) * 4 + (ctx->d_hist ? (size_t)SIMKA_HIST_MAX * 4 : 0);
-    static const uint32_t bpc = getenv("SIMKA_K2_BLOCKS_PER_CU") ? (uint32_t)atoi(getenv("SIMKA_K2_BLOCKS_PER_CU")) : (uint32_t)std::max<size_t>(1, (160 * 1024) / lds_count);
-    launch_timed(ctx, KID_COUNT, [&] {
-        const uint32_t grid_count = (uint32_t)std::min<uint64_t>(ctx->nparts, (uint64_t)ctx->num_cus * bpc);
-        hipLaunchKernelGGL(k_count, dim3(grid_count), dim3(K2C_BLOCK), lds_count, ctx->stream, ctx->d_l1,
-                           ctx->d_b1_start, ctx->d_chunk_first, ctx->d_chunk_off, key, tlog,
-                           ctx->cfg.abundance_min, ctx->cfg.abundance_max, o);
-    });
-    HIPCHK(hipGetLastError());
+    rc = run_count_kernels(ctx, sample, a, false);
+    if (rc) return rc;
+    if (!r->on_device) return resolve_pending(ctx);     // staged host reads are overwritten by the next sample: settle now
     return SIMKA_OK;
 }
 
@@ -465,7 +522,9 @@ SIMKA_EXPORT int simka_get_sample_totals(simka_ctx *ctx, uint32_t sample, simka_
     if (!ctx || !out) return SIMKA_ERR_INVALID;
     const uint32_t N = ctx->cfg.nb_samples;
     if (sample >= N || !ctx->counted[sample]) return ctx->fail(SIMKA_ERR_STATE, "simka_get_sample_totals: sample %u not counted", sample);
-    int rc = check_device_error(ctx);
+    int rc = resolve_pending(ctx);
+    if (rc) return rc;
+    rc = check_device_error(ctx);
     if (rc) return rc;
     uint64_t t[SIMKA_NB_TOTALS];
     for (int i = 0; i < SIMKA_NB_TOTALS; i++)
@@ -484,7 +543,9 @@ SIMKA_EXPORT int simka_merge(simka_ctx *ctx) {
     for (uint32_t s = 0; s < N; s++) if (!ctx->counted[s]) return ctx->fail(SIMKA_ERR_STATE, "simka_merge: sample %u has not been counted", s);
     if (ctx->merged) return ctx->fail(SIMKA_ERR_STATE, "simka_merge: already merged");
     HIPCHK(hipSetDevice(ctx->cfg.device));
-    int rc = check_device_error(ctx);
+    int rc = resolve_pending(ctx);
+    if (rc) return rc;
+    rc = check_device_error(ctx);
     if (rc) return rc;
     ctx->merged = true;
     if (!ctx->geometry_ready || N < 2) return SIMKA_OK;   // nothing to pair up
@@ -520,13 +581,15 @@ SIMKA_EXPORT int simka_merge(simka_ctx *ctx) {
     if (maxpart > cap) return ctx->fail(SIMKA_ERR_NOMEM, "simka_merge: one partition holds %llu records, more than the merge buffer", maxpart);
     const uint64_t max_parts_batch = std::min<uint64_t>(nparts, (uint64_t)1 << 16);
     const uint64_t fb_cap = max_parts_batch * nsub;
-    const uint64_t span_cap = fb_cap * 2 + 4096;
+    const uint32_t grid_group = (uint32_t)ctx->num_cus * 3;
+    const uint64_t span_cap = fb_cap * 2 + 4096 + (uint64_t)grid_group * K3_SLAB_SPAN;
+    const uint64_t csr_cap = cap + (uint64_t)grid_group * K3_SLAB_ENT;     // slab reservation leaves unused tails
     if (ctx->merge_cap < cap) {
         void *old[] = { ctx->d_mkeys, ctx->d_mvals, ctx->d_entries, ctx->d_groups };
         for (void *p : old) if (p) HIPCHK(hipFree(p));
         ctx->d_mkeys = ctx->d_mvals = ctx->d_entries = nullptr; ctx->d_groups = nullptr;
         if (dev_alloc(&ctx->d_mkeys, cap) != hipSuccess || dev_alloc(&ctx->d_mvals, cap) != hipSuccess ||
-            dev_alloc(&ctx->d_entries, cap) != hipSuccess || dev_alloc(&ctx->d_groups, cap) != hipSuccess)
+            dev_alloc(&ctx->d_entries, csr_cap) != hipSuccess || dev_alloc(&ctx->d_groups, csr_cap) != hipSuccess)
             return ctx->fail(SIMKA_ERR_NOMEM, "simka_merge: cannot allocate merge buffers for %llu records", (unsigned long long)cap);
         ctx->merge_cap = cap;
     }
@@ -562,9 +625,9 @@ SIMKA_EXPORT int simka_merge(simka_ctx *ctx) {
     in.foff = ctx->d_foff; in.fcnt = ctx->d_fcnt; in.nb_samples = N; in.nparts = nparts;
     SimkaCsrOut co;
     co.entries = ctx->d_entries; co.groups = ctx->d_groups; co.spans = ctx->d_spans; co.cursors = ctx->d_cursors;
-    co.cap_entries = cap; co.cap_groups = cap; co.cap_spans = span_cap; co.glob = (ull *)ctx->d_stats; co.err = ctx->d_err;
+    co.cap_entries = csr_cap; co.cap_groups = csr_cap; co.cap_spans = span_cap; co.glob = (ull *)ctx->d_stats; co.err = ctx->d_err;
     const uint32_t min_share = 2;   // -complex-dist would need 1 (ref: src/SimkaMerge.cpp:1317)
-    const size_t lds_group = SIMKA_LDS_HEAD + (size_t)K3_TABLE * 8 + (size_t)K3_CAP * 8 + (size_t)K3_TABLE * 12 + K3_BLOCK * 4 + (size_t)K3_CAP * 2;
+    const size_t lds_group = SIMKA_LDS_HEAD + (size_t)K3_TABLE * 8 + (size_t)K3_CAP * 8 + (size_t)K3_TABLE * 8 + (size_t)K3_CAP * 2;
     ull *acc = (ull *)ctx->d_stats + stats_off_acc(N, 0);
 
     uint64_t pb = 0;
@@ -581,7 +644,7 @@ SIMKA_EXPORT int simka_merge(simka_ctx *ctx) {
                                    ctx->d_fb_off, ctx->d_mkeys, ctx->d_mvals);
             });
             launch_timed(ctx, KID_GROUP, [&] {
-                hipLaunchKernelGGL(k_group, dim3(nfb), dim3(K3_BLOCK), lds_group, ctx->stream, ctx->d_mkeys, ctx->d_mvals,
+                hipLaunchKernelGGL(k_group, dim3(std::min<uint32_t>(nfb, grid_group)), dim3(K3_BLOCK), lds_group, ctx->stream, ctx->d_mkeys, ctx->d_mvals,
                                    ctx->d_fb_off, nfb, (uint32_t)recs, key, min_share, co);
             });
             launch_timed(ctx, KID_PAIRS, [&] {
@@ -651,6 +714,7 @@ SIMKA_EXPORT int simka_stats_device_ranges(simka_ctx *ctx, void **head, uint64_t
 
 SIMKA_EXPORT int simka_totals_download(simka_ctx *ctx, uint64_t *out) {
     if (!ctx || !out) return SIMKA_ERR_INVALID;
+    { int rcp = resolve_pending(ctx); if (rcp) return rcp; }
     const uint32_t N = ctx->cfg.nb_samples;
     HIPCHK(hipMemcpyAsync(out, ctx->d_stats + stats_off_tot(N, ctx->cfg.dist_flags, 0), (size_t)SIMKA_NB_TOTALS * N * 8, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));

@@ -24,8 +24,12 @@
 #define SIMKA_TARGET_PER_PART 4096   // sizing: k-mer occurrences per partition (<= 50% table load even if all distinct)
 // K3  k_regroup / k_group
 #define K3_BLOCK 256
-#define K3_CAP 2048           // records hashed per round
-#define K3_TABLE 4096         // = 2*K3_CAP slots
+#define K3_CAP 1024           // records hashed per round
+#define K3_TABLE 2048         // = 2*K3_CAP slots
+#define K3_UNROLL 4           // K3_BLOCK*K3_UNROLL = K3_CAP: a whole sub-range in one batch of independent loads
+#define K3_SLAB_ENT 8192      // CSR entries / groups / span slots reserved per global atomic by a k_group block
+#define K3_SLAB_GRP 4096
+#define K3_SLAB_SPAN 32
 // K4  k_pairs
 #define K4_BLOCK 512
 

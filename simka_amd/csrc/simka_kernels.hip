@@ -69,7 +69,8 @@ __device__ __forceinline__ uint32_t window_base(uint64_t A, uint64_t B, uint32_t
 
 template <bool SCATTER>
 __global__ void __launch_bounds__(K1_BLOCK)
-k_scan(SimkaScanArgs a, SimkaKeyCfg cfg, ull *b1_count, ull *b1_cursor, uint64_t *l1_keys, ull *kocc) {
+k_scan(SimkaScanArgs a, SimkaKeyCfg cfg, ull *b1_count, ull *b1_cursor, uint64_t *l1_keys, ull *kocc, const ull *b1_limit,
+       uint32_t *ovf_flag) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const uint32_t B1 = 1u << cfg.l1;
     // all LDS lives in the dynamic region (16-B aligned base, guide G17); head = scalars
@@ -155,13 +156,11 @@ k_scan(SimkaScanArgs a, SimkaKeyCfg cfg, ull *b1_count, ull *b1_cursor, uint64_t
     }
 
     if (!SCATTER) {
-        if (nvalid) atomicAdd(&s_nvalid, nvalid);
         __syncthreads();
         for (uint32_t b = tid; b < B1; b += K1_BLOCK) {
             const uint32_t h = hist[b];
             if (h) atomicAdd(&b1_count[b], (ull)h);
         }
-        if (tid == 0 && s_nvalid) atomicAdd(kocc, (ull)s_nvalid);
         return;
     }
 
@@ -169,7 +168,10 @@ k_scan(SimkaScanArgs a, SimkaKeyCfg cfg, ull *b1_count, ull *b1_cursor, uint64_t
     for (uint32_t b = tid; b < B1; b += K1_BLOCK) {
         const uint32_t h = hist[b];
         loff[b] = h;
-        gbase[b] = h ? atomicAdd(&b1_cursor[b], (ull)h) : 0ull;   // reserve this tile's run in bucket b
+        ull gb = h ? atomicAdd(&b1_cursor[b], (ull)h) : 0ull;     // reserve this tile's run in bucket b
+        // capacity-sized buckets (no histogram pass): a run that does not fit flags the sample for the exact path
+        if (b1_limit && h && gb + h > b1_limit[b]) { *ovf_flag = 1u; gb = ~0ull; }
+        gbase[b] = gb;
     }
     __syncthreads();
     const uint32_t total = block_excl_scan<K1_BLOCK>(loff, B1, tmp);
@@ -182,31 +184,44 @@ k_scan(SimkaScanArgs a, SimkaKeyCfg cfg, ull *b1_count, ull *b1_cursor, uint64_t
     for (uint32_t t = tid; t < total; t += K1_BLOCK) {
         const uint64_t key = stage[t];
         const uint32_t b = simka_key_l1(key, cfg);
-        l1_keys[gbase[b] + (t - loff[b])] = key;
+        const ull gb = gbase[b];
+        if (gb != ~0ull) l1_keys[gb + (t - loff[b])] = key;
     }
 }
 
 // --------------------------------------------------------------------------------------------
-// k_layout: level-1 counts -> bucket starts, scatter cursors, chunk table.  One block.
+// k_layout: level-1 bucket geometry.  One block.
+//   mode 0 (exact, after the histogram pass): starts/ends/cursors from the counts, chunk table
+//   mode 1 (capacity, before the scatter): bucket b owns [b*cap, (b+1)*cap), cursor at its start
+//   mode 2 (capacity, after the scatter): ends from the cursors, chunk table
 // --------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256)
-k_layout(const ull *b1_count, ull *b1_start, ull *b1_cursor, uint32_t *chunk_first, uint32_t B1, ull *arena_cursor,
-         ull *sample_base) {
+k_layout(const ull *b1_count, ull *b1_start, ull *b1_end, ull *b1_cursor, uint32_t *chunk_first, uint32_t B1, ull *arena_cursor,
+         ull *sample_base, uint32_t mode, ull cap, ull *kocc, const uint32_t *skip_flag) {
+    if (mode == 2 && skip_flag && *skip_flag) return;      // the capacity-mode scatter overflowed: the sample is redone exactly
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     ull *cnt = (ull *)(smem + SIMKA_LDS_HEAD);   // [B1]
-    for (uint32_t b = threadIdx.x; b < B1; b += blockDim.x) cnt[b] = b1_count[b];
+    if (mode == 1) {
+        for (uint32_t b = threadIdx.x; b < B1; b += blockDim.x) { b1_start[b] = (ull)b * cap; b1_cursor[b] = (ull)b * cap; b1_end[b] = (ull)(b + 1) * cap; }
+        if (threadIdx.x == 0) *sample_base = *arena_cursor;
+        return;
+    }
+    for (uint32_t b = threadIdx.x; b < B1; b += blockDim.x) cnt[b] = (mode == 0) ? b1_count[b] : (b1_cursor[b] - b1_start[b]);
     __syncthreads();
     if (threadIdx.x == 0) {
         ull run = 0;
         uint32_t crun = 0;
         for (uint32_t b = 0; b < B1; b++) {
             const ull c = cnt[b];
-            b1_start[b] = run; b1_cursor[b] = run; chunk_first[b] = crun;
+            if (mode == 0) { b1_start[b] = run; b1_cursor[b] = run; b1_end[b] = run + c; }
+            else b1_end[b] = b1_start[b] + c;
+            chunk_first[b] = crun;
             run += c;
             crun += (uint32_t)((c + K2_CHUNK - 1) / K2_CHUNK);
         }
-        b1_start[B1] = run; chunk_first[B1] = crun;
-        *sample_base = *arena_cursor;   // where this sample's solid records start in the arena
+        chunk_first[B1] = crun;
+        *kocc = run;                                   // k-mer occurrences of this shard = sum of its bucket sizes
+        if (mode == 0) *sample_base = *arena_cursor;   // where this sample's solid records start in the arena
     }
 }
 
@@ -216,7 +231,9 @@ k_layout(const ull *b1_count, ull *b1_start, ull *b1_cursor, uint32_t *chunk_fir
 // chunk's level-2 offsets.  k_count later reads segment b2 of every chunk of bucket b1.
 // --------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(K2_BLOCK)
-k_split(uint64_t *l1_keys, const ull *b1_start, const uint32_t *chunk_first, uint16_t *chunk_off, SimkaKeyCfg cfg) {
+k_split(uint64_t *l1_keys, const ull *b1_start, const ull *b1_end, const uint32_t *chunk_first, uint16_t *chunk_off, SimkaKeyCfg cfg,
+        const uint32_t *skip_flag) {
+    if (skip_flag && *skip_flag) return;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const uint32_t B1 = 1u << cfg.l1, B2 = 1u << cfg.l2;
     uint32_t &s_b1 = *(uint32_t *)smem;
@@ -236,7 +253,7 @@ k_split(uint64_t *l1_keys, const ull *b1_start, const uint32_t *chunk_first, uin
     __syncthreads();
     const uint32_t b1 = s_b1;
     const ull s = b1_start[b1] + (ull)(c - chunk_first[b1]) * K2_CHUNK;
-    const ull bend = b1_start[b1 + 1];
+    const ull bend = b1_end[b1];
     const uint32_t n = (uint32_t)((bend - s < (ull)K2_CHUNK) ? (bend - s) : (ull)K2_CHUNK);
 
     constexpr int PER = K2_CHUNK / K2_BLOCK;
@@ -300,8 +317,9 @@ __device__ __forceinline__ ull slab_take(ull &slab_pos, ull &slab_end, uint32_t 
 }
 
 __global__ void __launch_bounds__(K2C_BLOCK)
-k_count(const uint64_t *l1_keys, const ull *b1_start, const uint32_t *chunk_first, const uint16_t *chunk_off,
-        SimkaKeyCfg cfg, uint32_t table_log2, uint32_t amin, uint32_t amax, SimkaCountOut o) {
+k_count(const uint64_t *l1_keys, const ull *b1_start, const ull *b1_end, const uint32_t *chunk_first, const uint16_t *chunk_off,
+        SimkaKeyCfg cfg, uint32_t table_log2, uint32_t amin, uint32_t amax, SimkaCountOut o, const uint32_t *skip_flag) {
+    if (skip_flag && *skip_flag) return;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     ull *s_tot = (ull *)smem;                         // [4] D_all, D, N, Q of the whole block
     ull &s_base = *(ull *)(smem + 32);
@@ -340,7 +358,7 @@ k_count(const uint64_t *l1_keys, const ull *b1_start, const uint32_t *chunk_firs
         const uint32_t b1 = part >> cfg.l2, b2 = part & (B2 - 1u);
         if (!simka_owns_l1(b1, cfg)) continue;
         const uint32_t c0 = chunk_first[b1], c1 = chunk_first[b1 + 1];
-        const ull base = b1_start[b1], bend = b1_start[b1 + 1];
+        const ull base = b1_start[b1], bend = b1_end[b1];
         __syncthreads();
         if (tid == 0) { s_nsolid = 0; s_cur = 0; s_ovf = 0; }
 
@@ -559,127 +577,143 @@ k_regroup(SimkaMergeIn in, SimkaKeyCfg cfg, uint64_t part_begin, const ull *part
 // vector of one k-mer (ref: src/SimkaMerge.cpp:1198-1263), a block hashes the records of one
 // sub-range into LDS, which groups equal k-mers; groups with >= min_share samples are emitted
 // as CSR (the gate of SimkaMergeAlgorithm::insert, ref: src/SimkaMerge.cpp:1307-1326).
+// Persistent blocks (3 per CU) walk the sub-ranges; output space (entries / groups / span slots) is
+// reserved in slabs, one global atomic per slab instead of three per sub-range.
 // --------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(K3_BLOCK)
 k_group(const ull *mkeys, const ull *mvals, const uint32_t *fb_off, uint32_t nfb, uint32_t batch_total,
         SimkaKeyCfg cfg, uint32_t min_share, SimkaCsrOut o) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    ull &s_ebase = *(ull *)smem;
-    ull &s_gbase = *(ull *)(smem + 8);
-    uint32_t &s_nrec = *(uint32_t *)(smem + 16);
-    uint32_t &s_ovf = *(uint32_t *)(smem + 20);
-    uint32_t &s_ndist = *(uint32_t *)(smem + 24);
-    uint32_t &s_nshared = *(uint32_t *)(smem + 28);
-    int &s_sp = *(int *)(smem + 32);
-    uint32_t *s_stack = (uint32_t *)(smem + 64);           // [2*24]
+    ull *s_slab = (ull *)smem;                              // [6] ent pos/end, grp pos/end, span pos/end
+    ull &s_ebase = *(ull *)(smem + 48);
+    ull &s_gbase = *(ull *)(smem + 56);
+    uint32_t &s_nrec = *(uint32_t *)(smem + 64);
+    uint32_t &s_ovf = *(uint32_t *)(smem + 68);
+    uint32_t &s_ndist = *(uint32_t *)(smem + 72);
+    uint32_t &s_nshared = *(uint32_t *)(smem + 76);
+    int &s_sp = *(int *)(smem + 80);
+    uint32_t *tmp = (uint32_t *)(smem + 96);               // [K3_BLOCK/64]
+    uint32_t *s_stack = (uint32_t *)(smem + 128);          // [2*24]
     ull *tkeys = (ull *)(smem + SIMKA_LDS_HEAD);           // [K3_TABLE]
     ull *rval = tkeys + K3_TABLE;                          // [K3_CAP]
     uint32_t *scnt = (uint32_t *)(rval + K3_CAP);          // [K3_TABLE] group size
-    uint32_t *goff = scnt + K3_TABLE;                      // [K3_TABLE] entry offset of the group
-    uint32_t *gidx = goff + K3_TABLE;                      // [K3_TABLE] group index, later fill cursor
-    uint32_t *tmp = gidx + K3_TABLE;                       // [K3_BLOCK]
-    uint16_t *rslot = (uint16_t *)(tmp + K3_BLOCK);        // [K3_CAP]
+    uint32_t *gpk = scnt + K3_TABLE;                       // [K3_TABLE] packed prefix: entries | groups << 20; later the fill cursor
+    uint16_t *rslot = (uint16_t *)(gpk + K3_TABLE);        // [K3_CAP]
 
-    const uint32_t fb = blockIdx.x;
-    const uint32_t rb = fb_off[fb];
-    const uint32_t re = (fb + 1 < nfb) ? fb_off[fb + 1] : batch_total;
-    const uint32_t R = re - rb;
-    if (R == 0) return;
     const uint32_t tid = threadIdx.x;
-    // bits still unused below partition + sub-range bits: available to split an overfull sub-range
-    const uint32_t free_bits = cfg.W - cfg.pb - cfg.t;
-    uint32_t e0 = 0;
-    while (((R >> e0) > (K3_CAP * 3u) / 4u) && e0 < free_bits) e0++;
+    const uint32_t free_bits = cfg.W - cfg.pb - cfg.t;     // bits left to split an over-full sub-range
+    if (tid < 6) s_slab[tid] = 0;
     if (tid == 0) { s_ndist = 0; s_nshared = 0; }
     __syncthreads();
-    const uint32_t nvals0 = 1u << e0;
-    for (uint32_t v0 = 0; v0 < nvals0; v0++) {
-        if (tid == 0) { s_sp = 1; s_stack[0] = e0; s_stack[1] = v0; }
-        __syncthreads();
-        while (true) {
+
+    for (uint32_t fb = blockIdx.x; fb < nfb; fb += gridDim.x) {
+        const uint32_t rb = fb_off[fb];
+        const uint32_t re = (fb + 1 < nfb) ? fb_off[fb + 1] : batch_total;
+        const uint32_t R = re - rb;
+        if (R == 0) continue;
+        uint32_t e0 = 0;
+        while (((R >> e0) > (K3_CAP * 3u) / 4u) && e0 < free_bits) e0++;
+        const uint32_t nvals0 = 1u << e0;
+        for (uint32_t v0 = 0; v0 < nvals0; v0++) {
             __syncthreads();
-            if (s_sp == 0) break;
-            const uint32_t e = s_stack[2 * (s_sp - 1)], val = s_stack[2 * (s_sp - 1) + 1];
-            __syncthreads();
-            if (tid == 0) { s_sp--; s_nrec = 0; s_ovf = 0; }
-            for (uint32_t i = tid; i < K3_TABLE; i += K3_BLOCK) { tkeys[i] = SIMKA_EMPTY_KEY; scnt[i] = 0; }
-            __syncthreads();
-            // ---- hash the records of this (sub-)range
-            const uint32_t selshift = free_bits - e;
-            for (uint32_t i = rb + tid; i < re; i += K3_BLOCK) {
-                const ull key = mkeys[i];
-                if (e && (uint32_t)((key >> selshift) & ((1ull << e) - 1ull)) != val) continue;
-                const uint32_t idx = atomicAdd(&s_nrec, 1u);
-                if (idx >= K3_CAP) { s_ovf = 1; continue; }
-                uint32_t slot = simka_slot_hash(key) & (K3_TABLE - 1u);
-                for (;;) {   // table has 2*K3_CAP slots and at most K3_CAP records: always terminates
-                    const ull prev = atomicCAS(&tkeys[slot], SIMKA_EMPTY_KEY, key);
-                    if (prev == SIMKA_EMPTY_KEY || prev == key) break;
-                    slot = (slot + 1u) & (K3_TABLE - 1u);
+            if (tid == 0) { s_sp = 1; s_stack[0] = e0; s_stack[1] = v0; }
+            while (true) {
+                __syncthreads();
+                if (s_sp == 0) break;
+                const uint32_t e = s_stack[2 * (s_sp - 1)], val = s_stack[2 * (s_sp - 1) + 1];
+                __syncthreads();
+                if (tid == 0) { s_sp--; s_nrec = 0; s_ovf = 0; }
+                {
+                    ulonglong2 *k2 = (ulonglong2 *)tkeys; uint4 *c4 = (uint4 *)scnt;
+                    const ulonglong2 ek = make_ulonglong2(SIMKA_EMPTY_KEY, SIMKA_EMPTY_KEY);
+                    const uint4 z = make_uint4(0, 0, 0, 0);
+                    for (uint32_t i = tid; i < K3_TABLE / 2; i += K3_BLOCK) k2[i] = ek;
+                    for (uint32_t i = tid; i < K3_TABLE / 4; i += K3_BLOCK) c4[i] = z;
                 }
-                atomicAdd(&scnt[slot], 1u);
-                rslot[idx] = (uint16_t)slot;
-                rval[idx] = mvals[i];
-            }
-            __syncthreads();
-            if (s_ovf) {
-                if (e >= free_bits) { if (tid == 0) atomicOr(o.err, SIMKA_DEVERR_GROUP_OVERFLOW); return; }
-                if (tid == 0) {   // refine: two children with one more selector bit
-                    if (s_sp + 2 > 24) { atomicOr(o.err, SIMKA_DEVERR_GROUP_OVERFLOW); s_ovf = 2; }
-                    else {
-                        s_stack[2 * s_sp] = e + 1; s_stack[2 * s_sp + 1] = val * 2u + 1u; s_sp++;
-                        s_stack[2 * s_sp] = e + 1; s_stack[2 * s_sp + 1] = val * 2u; s_sp++;
+                __syncthreads();
+                // ---- hash the records of this (sub-)range; K3_UNROLL independent loads per thread
+                const uint32_t selshift = free_bits - e;
+                for (uint32_t i0 = rb + tid; i0 < re; i0 += K3_BLOCK * K3_UNROLL) {
+                    ull kk[K3_UNROLL], vv[K3_UNROLL];
+#pragma unroll
+                    for (int u = 0; u < K3_UNROLL; u++) {
+                        const uint32_t i = i0 + (uint32_t)u * K3_BLOCK;
+                        kk[u] = SIMKA_EMPTY_KEY; vv[u] = 0;
+                        if (i < re) { kk[u] = mkeys[i]; vv[u] = mvals[i]; }
+                    }
+#pragma unroll
+                    for (int u = 0; u < K3_UNROLL; u++) {
+                        const ull key = kk[u];
+                        if (key == SIMKA_EMPTY_KEY) continue;
+                        if (e && (uint32_t)((key >> selshift) & ((1ull << e) - 1ull)) != val) continue;
+                        const uint32_t idx = atomicAdd(&s_nrec, 1u);
+                        if (idx >= K3_CAP) { s_ovf = 1; continue; }
+                        uint32_t slot = simka_slot_hash(key) & (K3_TABLE - 1u);
+                        for (;;) {   // 2*K3_CAP slots, at most K3_CAP records: always terminates
+                            const ull prev = atomicCAS(&tkeys[slot], SIMKA_EMPTY_KEY, key);
+                            if (prev == SIMKA_EMPTY_KEY || prev == key) break;
+                            slot = (slot + 1u) & (K3_TABLE - 1u);
+                        }
+                        atomicAdd(&scnt[slot], 1u);
+                        rslot[idx] = (uint16_t)slot;
+                        rval[idx] = vv[u];
                     }
                 }
                 __syncthreads();
-                if (s_ovf == 2) return;
-                continue;
-            }
-            const uint32_t nrec = s_nrec;
-            if (nrec == 0) continue;
-            // ---- group geometry: entries/groups prefix over table slots
-            uint32_t ndist = 0, nshared = 0;
-            for (uint32_t i = tid; i < K3_TABLE; i += K3_BLOCK) {
-                const uint32_t c = scnt[i];
-                if (c) ndist++;
-                if (c > 1) nshared++;
-                const uint32_t keep = (c >= min_share) ? 1u : 0u;
-                goff[i] = keep ? c : 0u;
-                gidx[i] = keep;
-            }
-            if (ndist) atomicAdd(&s_ndist, ndist);
-            if (nshared) atomicAdd(&s_nshared, nshared);
-            __syncthreads();
-            const uint32_t nent = block_excl_scan<K3_BLOCK>(goff, K3_TABLE, tmp);
-            const uint32_t ngrp = block_excl_scan<K3_BLOCK>(gidx, K3_TABLE, tmp);
-            if (ngrp == 0) continue;
-            if (tid == 0) {
-                const ull eb = atomicAdd(&o.cursors[0], (ull)nent);
-                const ull gb = atomicAdd(&o.cursors[1], (ull)ngrp);
-                const ull sid = atomicAdd(&o.cursors[2], 1ull);
-                if (eb + nent > o.cap_entries || gb + ngrp > o.cap_groups || sid >= o.cap_spans) {
-                    atomicOr(o.err, SIMKA_DEVERR_CSR_FULL); s_ovf = 2;
-                } else {
-                    SimkaSpan sp; sp.ebase = eb; sp.gbase = gb; sp.nent = nent; sp.ngrp = ngrp;
-                    o.spans[sid] = sp;
+                if (s_ovf) {
+                    if (e >= free_bits) { if (tid == 0) atomicOr(o.err, SIMKA_DEVERR_GROUP_OVERFLOW); break; }
+                    if (tid == 0) {   // refine: two children with one more selector bit
+                        if (s_sp + 2 > 24) { atomicOr(o.err, SIMKA_DEVERR_GROUP_OVERFLOW); s_sp = 0; }
+                        else {
+                            s_stack[2 * s_sp] = e + 1; s_stack[2 * s_sp + 1] = val * 2u + 1u; s_sp++;
+                            s_stack[2 * s_sp] = e + 1; s_stack[2 * s_sp + 1] = val * 2u; s_sp++;
+                        }
+                    }
+                    continue;
                 }
-                s_ebase = eb; s_gbase = gb;
-            }
-            __syncthreads();
-            if (s_ovf == 2) return;
-            const ull eb = s_ebase, gb = s_gbase;
-            for (uint32_t i = tid; i < K3_TABLE; i += K3_BLOCK) {
-                const uint32_t c = scnt[i];
-                if (c >= min_share) o.groups[gb + gidx[i]] = (goff[i] << 16) | c;
-            }
-            __syncthreads();
-            for (uint32_t i = tid; i < K3_TABLE; i += K3_BLOCK) gidx[i] = 0;   // now the per-group fill cursor
-            __syncthreads();
-            for (uint32_t i = tid; i < nrec; i += K3_BLOCK) {
-                const uint32_t slot = rslot[i];
-                if (scnt[slot] >= min_share) {
-                    const uint32_t pos = goff[slot] + atomicAdd(&gidx[slot], 1u);
-                    o.entries[eb + pos] = rval[i];
+                const uint32_t nrec = s_nrec;
+                if (nrec == 0) continue;
+                // ---- group geometry: one packed prefix over the table slots (entries | groups << 20)
+                uint32_t ndist = 0, nshared = 0;
+                for (uint32_t i = tid; i < K3_TABLE; i += K3_BLOCK) {
+                    const uint32_t c = scnt[i];
+                    if (c) ndist++;
+                    if (c > 1) nshared++;
+                    gpk[i] = (c >= min_share) ? (c | (1u << 20)) : 0u;
+                }
+                if (ndist) atomicAdd(&s_ndist, ndist);
+                if (nshared) atomicAdd(&s_nshared, nshared);
+                __syncthreads();
+                const uint32_t tot = block_excl_scan<K3_BLOCK>(gpk, K3_TABLE, tmp);
+                const uint32_t nent = tot & 0xfffffu, ngrp = tot >> 20;
+                if (ngrp == 0) continue;
+                if (tid == 0) {
+                    // slab reservations: one global atomic per K3_SLAB_* items
+                    uint32_t ok = 1;
+                    if (s_slab[0] + nent > s_slab[1]) { s_slab[0] = atomicAdd(&o.cursors[0], (ull)K3_SLAB_ENT); s_slab[1] = s_slab[0] + K3_SLAB_ENT; if (s_slab[1] > o.cap_entries) ok = 0; }
+                    if (s_slab[2] + ngrp > s_slab[3]) { s_slab[2] = atomicAdd(&o.cursors[1], (ull)K3_SLAB_GRP); s_slab[3] = s_slab[2] + K3_SLAB_GRP; if (s_slab[3] > o.cap_groups) ok = 0; }
+                    if (s_slab[4] + 1 > s_slab[5]) { s_slab[4] = atomicAdd(&o.cursors[2], (ull)K3_SLAB_SPAN); s_slab[5] = s_slab[4] + K3_SLAB_SPAN; if (s_slab[5] > o.cap_spans) ok = 0; }
+                    if (!ok) { atomicOr(o.err, SIMKA_DEVERR_CSR_FULL); s_ovf = 2; }
+                    else {
+                        SimkaSpan sp; sp.ebase = s_slab[0]; sp.gbase = s_slab[2]; sp.nent = nent; sp.ngrp = ngrp;
+                        o.spans[s_slab[4]] = sp;
+                        s_ebase = s_slab[0]; s_gbase = s_slab[2];
+                        s_slab[0] += nent; s_slab[2] += ngrp; s_slab[4] += 1;
+                    }
+                }
+                __syncthreads();
+                if (s_ovf == 2) continue;
+                const ull eb = s_ebase, gb = s_gbase;
+                for (uint32_t i = tid; i < K3_TABLE; i += K3_BLOCK) {
+                    const uint32_t c = scnt[i];
+                    if (c >= min_share) o.groups[gb + (gpk[i] >> 20)] = ((gpk[i] & 0xfffffu) << 16) | c;
+                }
+                __syncthreads();
+                for (uint32_t i = tid; i < K3_TABLE; i += K3_BLOCK) gpk[i] &= 0xfffffu;   // now: entry offset, advanced as fill cursor
+                __syncthreads();
+                for (uint32_t i = tid; i < nrec; i += K3_BLOCK) {
+                    const uint32_t slot = rslot[i];
+                    if (scnt[slot] >= min_share) o.entries[eb + atomicAdd(&gpk[slot], 1u)] = rval[i];
                 }
             }
         }
@@ -689,6 +723,8 @@ k_group(const ull *mkeys, const ull *mvals, const uint32_t *fb_off, uint32_t nfb
         if (s_ndist) atomicAdd(&o.glob[0], (ull)s_ndist);      // _nbDistinctKmers  (:1315)
         if (s_nshared) atomicAdd(&o.glob[1], (ull)s_nshared);  // _nbSharedKmers    (:1319-1321)
     }
+    // unused span slots of this block's last slab: mark empty
+    for (ull i = s_slab[4] + tid; i < s_slab[5]; i += K3_BLOCK) { SimkaSpan sp; sp.ebase = 0; sp.gbase = 0; sp.nent = 0; sp.ngrp = 0; o.spans[i] = sp; }
 }
 
 // --------------------------------------------------------------------------------------------
@@ -754,6 +790,7 @@ k_pairs(const SimkaSpan *spans, const ull *cursors, const ull *entries, const ui
     const ull nspans = cursors[2];
     for (ull sp = blockIdx.x; sp < nspans; sp += gridDim.x) {
         const SimkaSpan span = spans[sp];
+        if (span.ngrp == 0) continue;     // unused slot of a k_group span slab
         for (uint32_t i = tid; i < span.nent; i += K4_BLOCK) ent[i] = entries[span.ebase + i];
         for (uint32_t i = tid; i < span.ngrp; i += K4_BLOCK) {
             const uint32_t d = groups[span.gbase + i];

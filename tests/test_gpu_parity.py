@@ -8,6 +8,7 @@ import numpy as np
 import pytest
 
 pytestmark = pytest.mark.gpu
+ROOT_DIR = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 CONFIGS = [(21, 0), (21, 2), (31, 0), (31, 2)]
 
@@ -165,3 +166,45 @@ def test_cli_drop_in_on_example(gpu_required, golden_dir, tmp_path, k, amin):
     for gzf in glob.glob(os.path.join(out, "*.csv.gz")):
         with gzip.open(gzf, "rb") as f, gzip.open(os.path.join(out2, os.path.basename(gzf)), "rb") as g:
             assert f.read() == g.read()
+
+
+def test_heavy_repeat_sample_takes_exact_path(gpu_required, oracle_mod):
+    """A poly-A sample puts every k-mer into ONE level-1 bucket: the capacity-sized scatter must flag the overflow and the
+    sample be redone with the exact histogram path; low-complexity and ordinary samples mix in one run."""
+    from simka_amd import synth
+    R, L, k = 2000, 100, 21
+    packed = _synthetic(2, R, L, seed_shift=20)
+    polya = np.zeros((R * L + 31) // 32, dtype=np.uint64)                       # code 0 = 'A'
+    rep = synth.unpack_ascii(packed[0], R * L).copy()
+    rep[: R * L // 2] = np.frombuffer(b"ACGT" * (R * L // 8), dtype=np.uint8)   # half tandem repeat, half random
+    import simka_amd
+    rep_packed, rep_off, rep_nb, _ = simka_amd.pack_reads([rep[i * L:(i + 1) * L].tobytes() for i in range(R)])
+    offs = np.arange(R + 1, dtype=np.uint64) * L
+    inputs = [(np.concatenate([polya, np.zeros(2, dtype=np.uint64)]), offs, R * L, R),
+              (np.concatenate([packed[0], np.zeros(2, dtype=np.uint64)]), offs, R * L, R),
+              (rep_packed, rep_off, rep_nb, R),
+              (np.concatenate([packed[1], np.zeros(2, dtype=np.uint64)]), offs, R * L, R)]
+    totals, st = _run_gpu(inputs, k, 2)
+    orc = oracle_mod.Oracle()
+    orc.add_sample_ascii("polyA", np.full(R * L, ord("A"), dtype=np.uint8), offs)
+    orc.add_sample_ascii("s0", synth.unpack_ascii(packed[0], R * L), offs)
+    orc.add_sample_ascii("rep", rep, offs)
+    orc.add_sample_ascii("s1", synth.unpack_ascii(packed[1], R * L), offs)
+    orc.run(k, 2, simple=True, complex_=True)
+    _check_vs_oracle(totals, st, orc)
+    assert int(totals[0]["D"]) == 1 and int(totals[0]["N"]) == R * (L - k + 1)
+
+
+def test_exact_sizing_env_matches_capacity_sizing(gpu_required, monkeypatch):
+    R, L = 3000, 100
+    packed = _synthetic(3, R, L, seed_shift=30)
+    a = [(np.concatenate([pk, np.zeros(2, dtype=np.uint64)]), np.arange(R + 1, dtype=np.uint64) * L, R * L, R) for pk in packed]
+    _, st1 = _run_gpu(a, 21, 2, log2_partitions=6)
+    import subprocess, sys, json
+    code = ("import os,sys,numpy as np;os.environ['SIMKA_EXACT_SIZING']='1';sys.path.insert(0,%r);sys.path.insert(0,%r);"
+            "import test_gpu_parity as t;R,L=3000,100;p=t._synthetic(3,R,L,seed_shift=30);"
+            "a=[(np.concatenate([pk,np.zeros(2,dtype=np.uint64)]),np.arange(R+1,dtype=np.uint64)*L,R*L,R) for pk in p];"
+            "_,st=t._run_gpu(a,21,2,log2_partitions=6);np.save(sys.argv[1],st.flat)") % (ROOT_DIR, os.path.join(ROOT_DIR, "tests"))
+    out = os.path.join(os.environ.get("TMPDIR", "/tmp"), "simka_exact_flat.npy")
+    subprocess.run([sys.executable, "-c", code, out], check=True)
+    assert np.array_equal(np.load(out), st1.flat)
