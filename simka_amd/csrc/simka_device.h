@@ -37,7 +37,6 @@ struct SimkaKeyCfg {
 // Bijection on W-bit integers: every step (xor-shift-right, odd multiply mod 2^W) is invertible.
 // The closing multiply makes the top (partition) bits depend on every input bit.
 SIMKA_HD uint64_t simka_mix(uint64_t x, uint64_t mask, uint32_t xs) {
-    x ^= x >> xs;
     x = (x * SIMKA_MIX_M1) & mask;
     x ^= x >> xs;
     x = (x * SIMKA_MIX_M2) & mask;
@@ -57,7 +56,13 @@ SIMKA_HD uint32_t simka_key_sub(uint64_t key, const SimkaKeyCfg &c) {
 // slot hash for the LDS tables: top bits of a 64-bit multiply see every key bit
 SIMKA_HD uint32_t simka_slot_hash(uint64_t key) { return (uint32_t)((key * 0xd6e8feb86659fd93ULL) >> 40); }
 
-SIMKA_HD bool simka_owns_l1(uint32_t b1, const SimkaKeyCfg &c) { return (b1 % c.shard_count) == c.shard_index; }
+// shard ownership of a level-1 bucket: b1 % shard_count == shard_index (mask when the count is a power of two --
+// an integer division per k-mer costs ~30 instructions in the scan kernels)
+SIMKA_HD bool simka_owns_l1(uint32_t b1, const SimkaKeyCfg &c) {
+    if (c.shard_count == 1u) return true;
+    if ((c.shard_count & (c.shard_count - 1u)) == 0u) return (b1 & (c.shard_count - 1u)) == c.shard_index;
+    return (b1 % c.shard_count) == c.shard_index;
+}
 
 // floor(sqrt(x)) exactly, x < 2^64.  The reference adds sqrt((double)(ci*cj)) to a u64, i.e.
 // floor of the correctly-rounded double sqrt (ref: src/core/SimkaAlgorithm.hpp:397), which equals

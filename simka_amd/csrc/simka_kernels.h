@@ -8,7 +8,7 @@
 
 // K1  k_scan
 #define K1_BLOCK 512          // 8 waves
-#define K1_SEG 16             // k-mer start positions per thread (window = SEG + k - 1 <= 64 bases)
+#define K1_SEG 16             // k-mer start positions per thread (window = SEG + k - 1 <= 64 bases holds for k <= 33)
 // K2  k_split / k_count
 #define K2_BLOCK 512          // k_split
 #define K2C_BLOCK 256         // k_count

@@ -88,10 +88,12 @@ k_scan(SimkaScanArgs a, SimkaKeyCfg cfg, ull *b1_count, ull *b1_cursor, uint64_t
 
     const uint64_t w0 = ((uint64_t)blockIdx.x * K1_BLOCK + tid) * K1_SEG;
     uint64_t keys[K1_SEG];
-    uint32_t ranks[K1_SEG];
+    uint32_t ranks[K1_SEG / 2];      // rank inside the tile's bucket run (< 8192): two u16 per register
     uint32_t nvalid = 0;
 #pragma unroll
-    for (int q = 0; q < K1_SEG; q++) { keys[q] = SIMKA_EMPTY_KEY; ranks[q] = 0; }
+    for (int q = 0; q < K1_SEG; q++) keys[q] = SIMKA_EMPTY_KEY;
+#pragma unroll
+    for (int q = 0; q < K1_SEG / 2; q++) ranks[q] = 0;
 
     if (w0 < a.nb_bases) {
         const uint64_t wi = w0 >> 5;
@@ -147,7 +149,7 @@ k_scan(SimkaScanArgs a, SimkaKeyCfg cfg, ull *b1_count, ull *b1_cursor, uint64_t
                     const uint32_t b1 = simka_key_l1(key, cfg);
                     if (simka_owns_l1(b1, cfg)) {
                         nvalid++;
-                        if (SCATTER) { keys[q] = key; ranks[q] = atomicAdd(&hist[b1], 1u); }
+                        if (SCATTER) { keys[q] = key; ranks[q >> 1] |= atomicAdd(&hist[b1], 1u) << ((q & 1) * 16); }
                         else atomicAdd(&hist[b1], 1u);
                     }
                 }
@@ -177,7 +179,7 @@ k_scan(SimkaScanArgs a, SimkaKeyCfg cfg, ull *b1_count, ull *b1_cursor, uint64_t
     const uint32_t total = block_excl_scan<K1_BLOCK>(loff, B1, tmp);
 #pragma unroll
     for (int q = 0; q < K1_SEG; q++) {
-        if (keys[q] != SIMKA_EMPTY_KEY) stage[loff[simka_key_l1(keys[q], cfg)] + ranks[q]] = keys[q];
+        if (keys[q] != SIMKA_EMPTY_KEY) stage[loff[simka_key_l1(keys[q], cfg)] + ((ranks[q >> 1] >> ((q & 1) * 16)) & 0xffffu)] = keys[q];
     }
     __syncthreads();
     // coalesced copy-out: consecutive staged slots of one bucket go to consecutive HBM addresses
