@@ -16,9 +16,9 @@
 #define SIMKA_EXPORT extern "C" __attribute__((visibility("default")))
 
 // kernel ids for the profiler
-enum { KID_SCAN_HIST = 0, KID_LAYOUT, KID_SCAN_SCATTER, KID_SPLIT, KID_COUNT, KID_PART_TOTALS, KID_REGROUP, KID_GROUP,
+enum { KID_SCAN_HIST = 0, KID_LAYOUT, KID_SCAN_SCATTER, KID_SPLIT, KID_COUNT_FAST, KID_COUNT, KID_PART_TOTALS, KID_REGROUP, KID_GROUP,
        KID_PAIRS, KID_REDUCE, KID_NB };
-static const char *const KID_NAMES[KID_NB] = { "k_scan<hist>", "k_layout", "k_scan<scatter>", "k_split", "k_count",
+static const char *const KID_NAMES[KID_NB] = { "k_scan<hist>", "k_layout", "k_scan<scatter>", "k_split", "k_count_fast", "k_count",
                                                "k_part_totals", "k_regroup", "k_group", "k_pairs", "k_reduce_slabs" };
 
 static thread_local std::string g_create_error;
@@ -44,7 +44,11 @@ struct simka_ctx {
     struct Pending { uint32_t sample; SimkaScanArgs a; };     // device-resident samples whose flag has not been read yet
     std::vector<Pending> pending;
     uint32_t *d_chunk_first = nullptr;
-    uint16_t *d_chunk_off = nullptr; uint64_t chunk_cap = 0;  // chunks
+    ull *d_l2 = nullptr; uint64_t l2_cap = 0;                 // level-2 partition regions (keys)
+    uint32_t *d_p_count = nullptr, *d_p_valid = nullptr;      // [nparts]
+    ull *d_spill_keys = nullptr; uint64_t spill_cap = 0; uint32_t *d_spill_part = nullptr; uint64_t spill_part_cap = 0;
+    ull *d_spill_cursor = nullptr;
+    uint32_t *d_redo_list = nullptr; ull *d_redo_count = nullptr;   // partitions k_count_fast hands to k_count
     // solid spectra of all samples
     ull *d_solid_keys = nullptr; uint32_t *d_solid_counts = nullptr; uint64_t arena_cap = 0;
     ull *d_arena_cursor = nullptr, *d_sample_base = nullptr;
@@ -192,6 +196,7 @@ static int set_lds_attr(simka_ctx *ctx) {
     HIPCHK(hipFuncSetAttribute((const void *)k_layout, hipFuncAttributeMaxDynamicSharedMemorySize, big));
     HIPCHK(hipFuncSetAttribute((const void *)k_split, hipFuncAttributeMaxDynamicSharedMemorySize, big));
     HIPCHK(hipFuncSetAttribute((const void *)k_count, hipFuncAttributeMaxDynamicSharedMemorySize, big));
+    HIPCHK(hipFuncSetAttribute((const void *)k_count_fast, hipFuncAttributeMaxDynamicSharedMemorySize, big));
     HIPCHK(hipFuncSetAttribute((const void *)k_group, hipFuncAttributeMaxDynamicSharedMemorySize, big));
     HIPCHK(hipFuncSetAttribute((const void *)k_pairs, hipFuncAttributeMaxDynamicSharedMemorySize, big));
     return SIMKA_OK;
@@ -232,6 +237,11 @@ static int setup_geometry(simka_ctx *ctx, uint64_t max_kmers) {
     HIPCHK(dev_alloc(&ctx->d_fcnt, (uint64_t)N * ctx->nparts));
     HIPCHK(hipMemsetAsync(ctx->d_foff, 0, (uint64_t)N * ctx->nparts * 4, ctx->stream));
     HIPCHK(hipMemsetAsync(ctx->d_fcnt, 0, (uint64_t)N * ctx->nparts * 4, ctx->stream));
+    HIPCHK(dev_alloc(&ctx->d_p_count, ctx->nparts + 1));
+    HIPCHK(dev_alloc(&ctx->d_p_valid, ctx->nparts + 1));
+    HIPCHK(dev_alloc(&ctx->d_spill_cursor, 2));
+    HIPCHK(dev_alloc(&ctx->d_redo_list, ctx->nparts + 1));
+    HIPCHK(dev_alloc(&ctx->d_redo_count, 2));
     HIPCHK(dev_alloc(&ctx->d_part_total, ctx->nparts + 1));
     HIPCHK(dev_alloc(&ctx->d_part_off, ctx->nparts + 1));
 
@@ -312,7 +322,8 @@ SIMKA_EXPORT void simka_destroy(simka_ctx *ctx) {
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     for (auto &ev : ctx->events) { (void)hipEventDestroy(ev.a); (void)hipEventDestroy(ev.b); }
     void *ptrs[] = { ctx->d_reads, ctx->d_offsets, ctx->d_l1, ctx->d_b1_count, ctx->d_b1_start, ctx->d_b1_end, ctx->d_l1_ovf, ctx->d_b1_cursor,
-                     ctx->d_chunk_first, ctx->d_chunk_off, ctx->d_solid_keys, ctx->d_solid_counts, ctx->d_arena_cursor,
+                     ctx->d_chunk_first, ctx->d_l2, ctx->d_p_count, ctx->d_p_valid, ctx->d_spill_keys, ctx->d_spill_part,
+                     ctx->d_spill_cursor, ctx->d_redo_list, ctx->d_redo_count, ctx->d_solid_keys, ctx->d_solid_counts, ctx->d_arena_cursor,
                      ctx->d_sample_base, ctx->d_foff, ctx->d_fcnt, ctx->d_stats, ctx->d_err, ctx->d_part_total,
                      ctx->d_part_off, ctx->d_mkeys, ctx->d_mvals, ctx->d_entries, ctx->d_groups, ctx->d_fb_off,
                      ctx->d_spans, ctx->d_cursors, ctx->d_slabs, ctx->d_hist, ctx->d_ovf_list, ctx->d_ovf_cursor };
@@ -386,8 +397,8 @@ static int run_count_kernels(simka_ctx *ctx, uint32_t sample, const SimkaScanArg
     const size_t lds_hist = SIMKA_LDS_HEAD + (size_t)B1 * 16 + K1_BLOCK * 4;
     const size_t lds_scat = lds_hist + (size_t)tile * 8;
     const size_t lds_lay = SIMKA_LDS_HEAD + (size_t)B1 * 8;
-    uint32_t *flag = ctx->d_l1_ovf + sample;
-    const uint32_t *skip = exact ? nullptr : flag;
+    uint32_t *flag = ctx->d_l1_ovf + sample;       // bit 0: level-1 bucket overflow, bit 1: spill buffer overflow
+    const uint32_t *skip = flag;
     auto layout = [&](uint32_t mode, ull capb) {
         launch_timed(ctx, KID_LAYOUT, [&] {
             hipLaunchKernelGGL(k_layout, dim3(1), dim3(256), lds_lay, ctx->stream, ctx->d_b1_count, ctx->d_b1_start, ctx->d_b1_end,
@@ -399,7 +410,7 @@ static int run_count_kernels(simka_ctx *ctx, uint32_t sample, const SimkaScanArg
     // (+10 % + slack) and scatter directly.  Only if a bucket overflows (heavy repeats) is the sample redone with the exact
     // histogram -> scan -> scatter sequence.
     static const bool force_exact = getenv("SIMKA_EXACT_SIZING") != nullptr;
-    if (force_exact) exact = true, skip = nullptr;
+    if (force_exact) exact = true;
     uint64_t max_chunks;
     if (!exact) {
         const uint64_t kocc_upper = a.fixed_len ? (a.fixed_len >= key.k ? a.nb_reads * (uint64_t)(a.fixed_len - key.k + 1) : 0) : a.nb_bases;
@@ -429,12 +440,30 @@ static int run_count_kernels(simka_ctx *ctx, uint32_t sample, const SimkaScanArg
                                ctx->d_b1_cursor, ctx->d_l1, kocc, (const ull *)nullptr, (uint32_t *)nullptr);
         });
     }
-    if (key.l2) {
-        rc = ensure_cap(ctx, &ctx->d_chunk_off, &ctx->chunk_cap, max_chunks * (B2 + 1)); if (rc) return rc;
-        const size_t lds_split = SIMKA_LDS_HEAD + (size_t)B2 * 4 + K2_BLOCK * 4 + (size_t)K2_CHUNK * 8;
+    (void)max_chunks;
+    // ---- level 2: partition-contiguous regions, capacity-sized, + spill buffer
+    const uint64_t kocc_up = a.fixed_len ? (a.fixed_len >= key.k ? a.nb_reads * (uint64_t)(a.fixed_len - key.k + 1) : 0) : a.nb_bases;
+    const uint64_t owned_parts = std::max<uint64_t>(1, ctx->nparts / std::min<uint64_t>(ctx->cfg.shard_count, B1));
+    const uint64_t mean2 = kocc_up / owned_parts;
+    SimkaL2 l2;
+    l2.cap2 = mean2 + mean2 / 2 + 256;
+    rc = ensure_cap(ctx, &ctx->d_l2, &ctx->l2_cap, l2.cap2 * ctx->nparts); if (rc) return rc;
+    const uint64_t spill_need = exact ? std::max<uint64_t>(kocc_up, 1) : std::max<uint64_t>((uint64_t)1 << 20, kocc_up / 64);
+    rc = ensure_cap(ctx, &ctx->d_spill_keys, &ctx->spill_cap, spill_need); if (rc) return rc;
+    rc = ensure_cap(ctx, &ctx->d_spill_part, &ctx->spill_part_cap, spill_need); if (rc) return rc;
+    l2.l2_keys = ctx->d_l2; l2.p_count = ctx->d_p_count; l2.p_valid = ctx->d_p_valid;
+    l2.spill_keys = ctx->d_spill_keys; l2.spill_part = ctx->d_spill_part; l2.spill_cursor = ctx->d_spill_cursor;
+    l2.spill_cap = std::min(ctx->spill_cap, ctx->spill_part_cap);
+    HIPCHK(hipMemsetAsync(ctx->d_p_count, 0, ctx->nparts * 4, ctx->stream));
+    HIPCHK(hipMemsetAsync(ctx->d_p_valid, 0xff, ctx->nparts * 4, ctx->stream));
+    HIPCHK(hipMemsetAsync(ctx->d_spill_cursor, 0, 8, ctx->stream));
+    HIPCHK(hipMemsetAsync(ctx->d_redo_count, 0, 8, ctx->stream));
+    {
+        const uint64_t nchunks_max = (exact ? a.nb_bases : ctx->l1_cap) / K2_CHUNK + B1 + 1;
+        const size_t lds_split = SIMKA_LDS_HEAD + (size_t)B2 * 12 + 64 + (size_t)K2_CHUNK * 8;
         launch_timed(ctx, KID_SPLIT, [&] {
-            hipLaunchKernelGGL(k_split, dim3((uint32_t)max_chunks), dim3(K2_BLOCK), lds_split, ctx->stream, ctx->d_l1,
-                               ctx->d_b1_start, ctx->d_b1_end, ctx->d_chunk_first, ctx->d_chunk_off, key, skip);
+            hipLaunchKernelGGL(k_split, dim3((uint32_t)nchunks_max), dim3(K2_BLOCK), lds_split, ctx->stream, ctx->d_l1,
+                               ctx->d_b1_start, ctx->d_b1_end, ctx->d_chunk_first, key, l2, flag);
         });
     }
     SimkaCountOut o;
@@ -444,15 +473,25 @@ static int run_count_kernels(simka_ctx *ctx, uint32_t sample, const SimkaScanArg
     o.totals = (ull *)ctx->d_stats + stats_off_tot(N, ctx->cfg.dist_flags, 0); o.sample = sample; o.nb_samples = N; o.err = ctx->d_err;
     o.phase = nullptr;
     o.hist = ctx->d_hist; o.ovf_list = ctx->d_ovf_list; o.ovf_cursor = ctx->d_ovf_cursor; o.ovf_cap = ctx->ovf_cap;
-    // tuning knobs (experiments): table size and resident blocks per CU
     static const uint32_t tlog = getenv("SIMKA_K2_TABLE_LOG2") ? (uint32_t)atoi(getenv("SIMKA_K2_TABLE_LOG2")) : (uint32_t)K2_TABLE_LOG2;
-    const size_t lds_count = SIMKA_LDS_HEAD + ((size_t)12 << tlog) + (size_t)(2 * K2_MAXSEG + 1) * 4 + (ctx->d_hist ? (size_t)SIMKA_HIST_MAX * 4 : 0);
-    static const uint32_t bpc = getenv("SIMKA_K2_BLOCKS_PER_CU") ? (uint32_t)atoi(getenv("SIMKA_K2_BLOCKS_PER_CU")) : (uint32_t)std::max<size_t>(1, (160 * 1024) / lds_count);
+    static const bool slow_only = getenv("SIMKA_K2_SLOW") != nullptr;
+    const size_t hist_lds = ctx->d_hist ? (size_t)SIMKA_HIST_MAX * 4 : 0;
+    if (!slow_only) {
+        const size_t lds_fast = SIMKA_LDS_HEAD + (size_t)K2F_TABLE * 12 + (size_t)K2F_BLOCK * 4 + hist_lds;
+        static const uint32_t bpc_f = getenv("SIMKA_K2F_BLOCKS_PER_CU") ? (uint32_t)atoi(getenv("SIMKA_K2F_BLOCKS_PER_CU")) : 4u;
+        launch_timed(ctx, KID_COUNT_FAST, [&] {
+            hipLaunchKernelGGL(k_count_fast, dim3((uint32_t)std::min<uint64_t>(ctx->nparts, (uint64_t)ctx->num_cus * bpc_f)), dim3(K2F_BLOCK),
+                               lds_fast, ctx->stream, key, l2, ctx->cfg.abundance_min, ctx->cfg.abundance_max, o, flag,
+                               ctx->d_redo_list, ctx->d_redo_count);
+        });
+    }
+    const size_t lds_count = SIMKA_LDS_HEAD + ((size_t)12 << tlog) + hist_lds;
     launch_timed(ctx, KID_COUNT, [&] {
-        const uint32_t grid_count = (uint32_t)std::min<uint64_t>(ctx->nparts, (uint64_t)ctx->num_cus * bpc);
-        hipLaunchKernelGGL(k_count, dim3(grid_count), dim3(K2C_BLOCK), lds_count, ctx->stream, ctx->d_l1,
-                           ctx->d_b1_start, ctx->d_b1_end, ctx->d_chunk_first, ctx->d_chunk_off, key, tlog,
-                           ctx->cfg.abundance_min, ctx->cfg.abundance_max, o, skip);
+        const uint32_t grid_count = slow_only ? (uint32_t)std::min<uint64_t>(ctx->nparts, (uint64_t)ctx->num_cus * 4) : (uint32_t)ctx->num_cus;
+        hipLaunchKernelGGL(k_count, dim3(grid_count), dim3(K2C_BLOCK), lds_count, ctx->stream, key, l2, tlog,
+                           ctx->cfg.abundance_min, ctx->cfg.abundance_max, o, flag,
+                           slow_only ? (const uint32_t *)nullptr : (const uint32_t *)ctx->d_redo_list,
+                           slow_only ? (const ull *)nullptr : (const ull *)ctx->d_redo_count);
     });
     HIPCHK(hipGetLastError());
     return SIMKA_OK;

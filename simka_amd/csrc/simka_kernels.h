@@ -15,7 +15,11 @@
 #define K2_CHUNK 8192         // keys per chunk (fits u16 offsets, 64 KB LDS stage)
 #define K2_TABLE_LOG2 11      // LDS hash-table slots per partition: 4096 (32 KB keys + 16 KB counts) -> 3 blocks/CU
 #define K2_TABLE (1 << K2_TABLE_LOG2)
-#define K2_MAXSEG 512         // chunk segments gathered per batch in k_count
+#define K2_MAXSEG_UNUSED 512         // chunk segments gathered per batch in k_count
+// k_count_fast
+#define K2F_BLOCK 512
+#define K2F_TABLE 2048        // slots (24 KB); TS/BLOCK = 4 slots per thread in the summary pass
+#define K2F_UNROLL 8          // keys prefetched per thread: partitions up to BLOCK*UNROLL = 4096 keys take the fast path
 #define K2_SLAB 2048          // arena records reserved per global atomic by a k_count block
 #ifndef K2_UNROLL
 #define K2_UNROLL 8
@@ -84,6 +88,18 @@ struct SimkaCountOut {
     uint32_t *ovf_list;                      // (sample,count) pairs for counts >= SIMKA_HIST_MAX
     unsigned long long *ovf_cursor;
     unsigned long long ovf_cap;
+};
+
+// level-2 partition regions of one sample (k_split -> k_count)
+struct SimkaL2 {
+    unsigned long long *l2_keys;             // [nparts][cap2]
+    unsigned long long cap2;                 // keys a region can hold
+    uint32_t *p_count;                       // [nparts] keys routed to the partition (may exceed cap2: spilled)
+    uint32_t *p_valid;                       // [nparts] first overflowing position (0xffffffff: none)
+    unsigned long long *spill_keys;          // runs that did not fit their region ...
+    uint32_t *spill_part;                    // ... and their partition
+    unsigned long long *spill_cursor;
+    unsigned long long spill_cap;
 };
 
 struct SimkaMergeIn {

@@ -228,20 +228,25 @@ k_layout(const ull *b1_count, ull *b1_start, ull *b1_end, ull *b1_cursor, uint32
 }
 
 // --------------------------------------------------------------------------------------------
-// K2a  k_split: partition every K2_CHUNK-key chunk of a level-1 bucket by its level-2 bits,
-// in place (keys travel global -> registers -> LDS stage -> same global range), and record the
-// chunk's level-2 offsets.  k_count later reads segment b2 of every chunk of bucket b1.
+// K2a  k_split: level-2 scatter.  One block takes a K2_CHUNK-key chunk of a level-1 bucket, orders it
+// by level-2 bits in LDS (keys stay in registers, LDS rank by returning ds_add) and appends each of the
+// B2 runs to its partition's region of l2_keys with ONE global atomic per run, so every partition ends
+// up contiguous in HBM and k_count streams it with perfectly coalesced loads.
+// Regions are capacity-sized (cap2 = 1.5 x mean + slack; the hash spreads keys evenly).  A run that does
+// not fit goes to the spill buffer with its partition id and the partition is finished by the general
+// kernel; if even the spill buffer overflows the sample is flagged and redone with a full-size one.
 // --------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(K2_BLOCK)
-k_split(uint64_t *l1_keys, const ull *b1_start, const ull *b1_end, const uint32_t *chunk_first, uint16_t *chunk_off, SimkaKeyCfg cfg,
-        const uint32_t *skip_flag) {
-    if (skip_flag && *skip_flag) return;
+k_split(const uint64_t *l1_keys, const ull *b1_start, const ull *b1_end, const uint32_t *chunk_first, SimkaKeyCfg cfg,
+        SimkaL2 l2, uint32_t *flag) {
+    if (*flag) return;                               // the level-1 scatter overflowed: the sample is redone exactly
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const uint32_t B1 = 1u << cfg.l1, B2 = 1u << cfg.l2;
     uint32_t &s_b1 = *(uint32_t *)smem;
-    uint32_t *hist = (uint32_t *)(smem + SIMKA_LDS_HEAD);   // [B2]
-    uint32_t *tmp = hist + B2;                      // [K2_BLOCK]
-    uint64_t *stage = (uint64_t *)(tmp + K2_BLOCK); // [K2_CHUNK]
+    uint32_t *hist = (uint32_t *)(smem + SIMKA_LDS_HEAD);   // [B2] counts, then exclusive offsets
+    uint32_t *tmp = hist + B2;                      // [K2_BLOCK/64 .. ] scan scratch
+    ull *gpos = (ull *)(tmp + 16);                  // [B2] destination of each run (bit 63: spill buffer)
+    uint64_t *stage = (uint64_t *)(gpos + B2);      // [K2_CHUNK]
 
     const uint32_t c = blockIdx.x;
     if (c >= chunk_first[B1]) return;
@@ -271,28 +276,50 @@ k_split(uint64_t *l1_keys, const ull *b1_start, const ull *b1_end, const uint32_
         }
     }
     __syncthreads();
+    for (uint32_t b = tid; b < B2; b += K2_BLOCK) {
+        const uint32_t h = hist[b];
+        ull g = 0;
+        if (h) {
+            const uint32_t part = (b1 << cfg.l2) | b;
+            const uint32_t pos = atomicAdd(&l2.p_count[part], h);          // reserve the run in partition `part`
+            if ((ull)pos + h <= l2.cap2) g = (ull)part * l2.cap2 + pos;
+            else {
+                atomicMin(&l2.p_valid[part], pos);                          // region holds [0,pos) only; the rest is spilled
+                const ull sp = atomicAdd(l2.spill_cursor, (ull)h);
+                if (sp + h > l2.spill_cap) { atomicOr(flag, 2u); g = ~0ull; }
+                else g = (1ull << 63) | sp;
+            }
+        }
+        gpos[b] = g;
+    }
+    __syncthreads();
     block_excl_scan<K2_BLOCK>(hist, B2, tmp);
-    uint16_t *co = chunk_off + (size_t)c * (B2 + 1);
-    for (uint32_t i = tid; i < B2; i += K2_BLOCK) co[i] = (uint16_t)hist[i];
-    if (tid == 0) co[B2] = (uint16_t)n;
 #pragma unroll
     for (int q = 0; q < PER; q++)
         if (keys[q] != SIMKA_EMPTY_KEY) stage[hist[simka_key_l2(keys[q], cfg)] + ranks[q]] = keys[q];
     __syncthreads();
-    for (uint32_t idx = tid; idx < n; idx += K2_BLOCK) l1_keys[s + idx] = stage[idx];
+    for (uint32_t idx = tid; idx < n; idx += K2_BLOCK) {
+        const uint64_t key = stage[idx];
+        const uint32_t b = simka_key_l2(key, cfg);
+        const ull g = gpos[b];
+        const uint32_t off = idx - hist[b];
+        if (g == ~0ull) continue;
+        if (g >> 63) { const ull sp = (g & ~(1ull << 63)) + off; l2.spill_keys[sp] = key; l2.spill_part[sp] = (b1 << cfg.l2) | b; }
+        else l2.l2_keys[g + off] = key;
+    }
 }
 
 // --------------------------------------------------------------------------------------------
-// K2b  k_count: one block per partition.  Streams the partition's keys into an LDS hash table
-// (64-bit CAS insert + counter), then applies SimkaCompressedProcessor::process
-// (ref: src/minikc/MiniKC.hpp:54-79): abundance filter, emit (k-mer,count), nbDistinct++,
-// nbKmers+=c, chord+=c^2.  Records go to the HBM arena; the reference gzips them to
-// solid/part_<p>/__p__<i>.gz.
+// K2b  k_count: one partition = one LDS hash table (64-bit CAS insert + counter), then
+// SimkaCompressedProcessor::process (ref: src/minikc/MiniKC.hpp:54-79): abundance filter, emit
+// (k-mer,count), nbDistinct++, nbKmers+=c, chord+=c^2.  Records go to the HBM arena where the reference
+// gzips them to solid/part_<p>/__p__<i>.gz.
 //
-// Loads are made independent before they are issued: the segment bounds of every chunk are
-// gathered in parallel and prefix-summed in LDS, then each thread walks FLAT key indices, so a
-// block keeps BLOCK x UNROLL global loads in flight.  A table that fills up (more distinct keys
-// than slots) is handled by re-running the partition in 2,4,.. rounds on extra key bits.
+// k_count_fast: persistent blocks, partition p = contiguous keys l2_keys[p*cap2 .. +n): every thread issues
+// K2F_UNROLL coalesced independent loads; the loads of partition p+1 are issued BEFORE the summary pass of
+// partition p (HBM latency hides behind LDS work); summary = one pass in which each thread owns 4 table
+// slots, a block scan places its solid records and the thread clears exactly those slots.
+// Partitions that spilled, exceed the prefetch window or over-fill the table go to the redo list.
 // --------------------------------------------------------------------------------------------
 __device__ __forceinline__ bool table_insert(ull *tkeys, uint32_t *tcnt, uint32_t tmask, ull key) {
     uint32_t slot = simka_slot_hash(key) & tmask;
@@ -318,10 +345,143 @@ __device__ __forceinline__ ull slab_take(ull &slab_pos, ull &slab_end, uint32_t 
     return b;
 }
 
+__device__ __forceinline__ void count_hist(const SimkaCountOut &o, uint32_t *lhist, uint32_t c) {
+    if (c < SIMKA_HIST_MAX) atomicAdd(&lhist[c], 1u);
+    else { const ull w = atomicAdd(o.ovf_cursor, 1ull); if (w < o.ovf_cap) { o.ovf_list[2 * w] = o.sample; o.ovf_list[2 * w + 1] = c; } }
+}
+
+__global__ void __launch_bounds__(K2F_BLOCK)
+k_count_fast(SimkaKeyCfg cfg, SimkaL2 l2, uint32_t amin, uint32_t amax, SimkaCountOut o, const uint32_t *flag,
+             uint32_t *redo_list, ull *redo_count) {
+    if (*flag) return;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    ull *s_tot = (ull *)smem;                         // [4]
+    ull &s_base = *(ull *)(smem + 32);
+    ull &s_slab_pos = *(ull *)(smem + 40);
+    ull &s_slab_end = *(ull *)(smem + 48);
+    uint32_t &s_ok = *(uint32_t *)(smem + 56);
+    uint32_t *tmp = (uint32_t *)(smem + 128);         // [K2F_BLOCK/64]
+    constexpr uint32_t TS = K2F_TABLE, tmask = TS - 1u, SPT = TS / K2F_BLOCK;   // slots per thread
+    ull *tkeys = (ull *)(smem + SIMKA_LDS_HEAD);      // [TS]
+    uint32_t *tcnt = (uint32_t *)(tkeys + TS);        // [TS]
+    uint32_t *spos = tcnt + TS;                       // [K2F_BLOCK]
+    uint32_t *lhist = spos + K2F_BLOCK;               // [SIMKA_HIST_MAX] (complex only)
+
+    const uint32_t tid = threadIdx.x;
+    const uint32_t nparts = 1u << cfg.pb;
+    const ull sample_base = *o.sample_base;
+    {   // the table starts clean; afterwards every thread re-cleans the slots it read
+        ulonglong2 *k2 = (ulonglong2 *)tkeys; uint4 *c4 = (uint4 *)tcnt;
+        for (uint32_t i = tid; i < TS / 2; i += K2F_BLOCK) k2[i] = make_ulonglong2(SIMKA_EMPTY_KEY, SIMKA_EMPTY_KEY);
+        for (uint32_t i = tid; i < TS / 4; i += K2F_BLOCK) c4[i] = make_uint4(0, 0, 0, 0);
+    }
+    if (o.hist) for (uint32_t i = tid; i < SIMKA_HIST_MAX; i += K2F_BLOCK) lhist[i] = 0;
+    if (tid < 4) s_tot[tid] = 0;
+    if (tid == 0) { s_slab_pos = 0; s_slab_end = 0; }
+    ull bt_dall = 0, bt_D = 0, bt_N = 0, bt_Q = 0;
+
+    ull kk[K2F_UNROLL];
+    // issue the loads of partition p (n keys) -- only partitions the fast path can take in one batch
+#define K2F_LOAD(p, n)                                                                        \
+    _Pragma("unroll") for (int u = 0; u < K2F_UNROLL; u++) {                                  \
+        const uint32_t i = tid + (uint32_t)u * K2F_BLOCK;                                     \
+        kk[u] = (i < (n)) ? l2.l2_keys[(ull)(p) * l2.cap2 + i] : SIMKA_EMPTY_KEY;             \
+    }
+    uint32_t part = blockIdx.x;
+    uint32_t n = 0;
+    bool fastp = false;
+    if (part < nparts) {
+        n = l2.p_count[part];
+        fastp = n <= (uint32_t)(K2F_BLOCK * K2F_UNROLL) && (ull)n <= l2.cap2;
+        if (fastp) { K2F_LOAD(part, n) }
+    }
+    __syncthreads();
+    while (part < nparts) {
+        const uint32_t next = part + gridDim.x;
+        uint32_t n_next = 0;
+        bool fast_next = false;
+        if (next < nparts) { n_next = l2.p_count[next]; fast_next = n_next <= (uint32_t)(K2F_BLOCK * K2F_UNROLL) && (ull)n_next <= l2.cap2; }
+        if (n == 0) { part = next; n = n_next; fastp = fast_next; if (fastp) { K2F_LOAD(part, n) } continue; }
+        if (!fastp) {     // spilled or larger than one batch: the general kernel finishes it
+            if (tid == 0) { const ull w = atomicAdd(redo_count, 1ull); redo_list[w] = part; }
+            part = next; n = n_next; fastp = fast_next; if (fastp) { K2F_LOAD(part, n) }
+            continue;
+        }
+        // ---- insert the prefetched keys
+#pragma unroll
+        for (int u = 0; u < K2F_UNROLL; u++) {
+            const ull key = kk[u];
+            if (key != SIMKA_EMPTY_KEY) table_insert(tkeys, tcnt, tmask, key);
+        }
+        __syncthreads();
+        // ---- prefetch the next partition while this one is summarised
+        if (fast_next) { K2F_LOAD(next, n_next) }
+        // ---- one pass over this thread's slots: SimkaCompressedProcessor::process
+        uint32_t cs[SPT]; ull ks[SPT];
+        uint32_t nsol = 0, ndall = 0;
+        ull D = 0, N = 0, Q = 0;
+#pragma unroll
+        for (uint32_t q = 0; q < SPT; q++) {
+            const uint32_t sl = tid * SPT + q;
+            cs[q] = tcnt[sl]; ks[q] = tkeys[sl];
+            if (cs[q]) { tcnt[sl] = 0; tkeys[sl] = SIMKA_EMPTY_KEY; }     // leave the table clean for the next partition
+            const uint32_t c = cs[q];
+            if (c) { ndall++; if (!(c < amin || c > amax)) { D++; N += c; Q += (ull)c * (ull)c; nsol++; } else cs[q] = 0; }
+        }
+        spos[tid] = nsol | (ndall << 16);
+        __syncthreads();
+        const uint32_t tot = block_excl_scan<K2F_BLOCK>(spos, K2F_BLOCK, tmp);
+        const uint32_t total = tot & 0xffffu, dall_tot = tot >> 16;
+        const bool ovf = dall_tot > (TS * 7u) / 8u;       // (nearly) full: probing may have dropped keys -> redo in rounds
+        if (tid == 0) {
+            uint32_t ok = 1;
+            if (ovf) { const ull w = atomicAdd(redo_count, 1ull); redo_list[w] = part; ok = 0; }
+            else {
+                const ull bb = total ? slab_take(s_slab_pos, s_slab_end, total, o, sample_base, ok) : sample_base;
+                o.foff[part] = ok ? (uint32_t)(bb - sample_base) : 0u;
+                o.fcnt[part] = ok ? total : 0u;
+                s_base = bb;
+            }
+            s_ok = ok;
+        }
+        __syncthreads();
+        if (s_ok) {
+            bt_dall += ndall; bt_D += D; bt_N += N; bt_Q += Q;
+            ull pos = s_base + (spos[tid] & 0xffffu);
+#pragma unroll
+            for (uint32_t q = 0; q < SPT; q++) {
+                if (cs[q]) {
+                    o.solid_keys[pos] = ks[q]; o.solid_counts[pos] = cs[q]; pos++;
+                    if (o.hist) count_hist(o, lhist, cs[q]);
+                }
+            }
+        }
+        part = next; n = n_next; fastp = fast_next;
+    }
+#undef K2F_LOAD
+    if (o.hist) {
+        __syncthreads();
+        for (uint32_t i = tid; i < SIMKA_HIST_MAX; i += K2F_BLOCK)
+            if (lhist[i]) atomicAdd(&o.hist[(size_t)o.sample * SIMKA_HIST_MAX + i], (ull)lhist[i]);
+    }
+    if (bt_dall) atomicAdd(&s_tot[0], bt_dall);
+    if (bt_D) { atomicAdd(&s_tot[1], bt_D); atomicAdd(&s_tot[2], bt_N); atomicAdd(&s_tot[3], bt_Q); }
+    __syncthreads();
+    if (tid == 0) {
+        ull *t = o.totals + o.sample;
+        const size_t ns_ = o.nb_samples;
+        if (s_tot[0]) atomicAdd(&t[SIMKA_TOT_DALL * ns_], s_tot[0]);
+        if (s_tot[1]) { atomicAdd(&t[SIMKA_TOT_D * ns_], s_tot[1]); atomicAdd(&t[SIMKA_TOT_N * ns_], s_tot[2]); atomicAdd(&t[SIMKA_TOT_Q * ns_], s_tot[3]); }
+    }
+}
+
+// k_count: the general kernel for the partitions on the redo list (spilled, very large, or more distinct keys than
+// table slots): streams the region + the partition's spill entries, and re-runs in 2,4,.. rounds on extra key bits
+// until every round fits the table.  pass 0 counts (and emits when one round suffices), pass 1 emits.
 __global__ void __launch_bounds__(K2C_BLOCK)
-k_count(const uint64_t *l1_keys, const ull *b1_start, const ull *b1_end, const uint32_t *chunk_first, const uint16_t *chunk_off,
-        SimkaKeyCfg cfg, uint32_t table_log2, uint32_t amin, uint32_t amax, SimkaCountOut o, const uint32_t *skip_flag) {
-    if (skip_flag && *skip_flag) return;
+k_count(SimkaKeyCfg cfg, SimkaL2 l2, uint32_t table_log2, uint32_t amin, uint32_t amax, SimkaCountOut o, const uint32_t *flag,
+        const uint32_t *part_list, const ull *part_count) {
+    if (*flag) return;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     ull *s_tot = (ull *)smem;                         // [4] D_all, D, N, Q of the whole block
     ull &s_base = *(ull *)(smem + 32);
@@ -330,41 +490,32 @@ k_count(const uint64_t *l1_keys, const ull *b1_start, const ull *b1_end, const u
     uint32_t &s_nsolid = *(uint32_t *)(smem + 56);
     uint32_t &s_cur = *(uint32_t *)(smem + 60);
     uint32_t &s_ovf = *(uint32_t *)(smem + 64);
-    uint32_t *tmp = (uint32_t *)(smem + 128);         // [K2C_BLOCK/64] scan scratch
     const uint32_t TS = 1u << table_log2, tmask = TS - 1u;
     ull *tkeys = (ull *)(smem + SIMKA_LDS_HEAD);      // [TS]
     uint32_t *tcnt = (uint32_t *)(tkeys + TS);        // [TS]
-    uint32_t *segpre = tcnt + TS;                     // [K2_MAXSEG+1] flat index of each chunk's segment
-    uint32_t *segbeg = segpre + K2_MAXSEG + 1;        // [K2_MAXSEG]   first key of the segment inside its chunk
-    uint32_t *lhist = segbeg + K2_MAXSEG;             // [SIMKA_HIST_MAX] solid-count histogram (complex only)
+    uint32_t *lhist = tcnt + TS;                      // [SIMKA_HIST_MAX] solid-count histogram (complex only)
     if (o.hist) for (uint32_t i = threadIdx.x; i < SIMKA_HIST_MAX; i += K2C_BLOCK) lhist[i] = 0;
 
-    const uint32_t B2 = 1u << cfg.l2;
     const uint32_t nparts = 1u << cfg.pb;
     const uint32_t tid = threadIdx.x;
     const uint32_t free_bits = cfg.W - cfg.pb;
     if (tid < 4) s_tot[tid] = 0;
     if (tid == 0) { s_slab_pos = 0; s_slab_end = 0; }
-    ull bt_dall = 0, bt_D = 0, bt_N = 0, bt_Q = 0;     // per-thread totals over all partitions of this block
+    ull bt_dall = 0, bt_D = 0, bt_N = 0, bt_Q = 0;
     const ull sample_base = *o.sample_base;
-#ifdef SIMKA_PHASE_PROF
-    ull ph[6] = {0, 0, 0, 0, 0, 0}; ull t_prev = wall_clock64();
-#define PH(i) do { __syncthreads(); const ull t_now = wall_clock64(); ph[i] += t_now - t_prev; t_prev = t_now; } while (0)
-#else
-#define PH(i) do { } while (0)
-#endif
+    const uint32_t nwork = part_list ? (uint32_t)(*part_count < (ull)nparts ? *part_count : (ull)nparts) : nparts;
 
-    // persistent block: partitions blockIdx.x, +gridDim.x, ...  (neighbouring blocks work on neighbouring
-    // level-2 columns of the same level-1 bucket, so the chunk-offset rows stay hot in L2)
-    for (uint32_t part = blockIdx.x; part < nparts; part += gridDim.x) {
-        const uint32_t b1 = part >> cfg.l2, b2 = part & (B2 - 1u);
-        if (!simka_owns_l1(b1, cfg)) continue;
-        const uint32_t c0 = chunk_first[b1], c1 = chunk_first[b1 + 1];
-        const ull base = b1_start[b1], bend = b1_end[b1];
+    for (uint32_t wi = blockIdx.x; wi < nwork; wi += gridDim.x) {
+        const uint32_t part = part_list ? part_list[wi] : wi;
+        const uint32_t pc = l2.p_count[part];
+        if (pc == 0) continue;
+        const uint32_t pv = l2.p_valid[part];
+        const uint32_t nreg = (uint32_t)((ull)(pv < pc ? pv : pc) < l2.cap2 ? (pv < pc ? pv : pc) : (uint32_t)l2.cap2);   // keys in the region
+        const ull nspill = (pc > nreg) ? *l2.spill_cursor : 0ull;                                                     // scan the spill buffer
+        const ull *reg = l2.l2_keys + (ull)part * l2.cap2;
         __syncthreads();
         if (tid == 0) { s_nsolid = 0; s_cur = 0; s_ovf = 0; }
 
-        // rounds: 1 unless the table overflows.  pass 0 counts (and emits when there is one round), pass 1 emits.
         uint32_t nr_log2 = 0;
         ull emit_base = 0;
         bool part_done = false;
@@ -380,55 +531,32 @@ k_count(const uint64_t *l1_keys, const ull *b1_start, const ull *b1_end, const u
                     for (uint32_t i = tid; i < TS / 2; i += K2C_BLOCK) k2[i] = ek;
                     for (uint32_t i = tid; i < TS / 4; i += K2C_BLOCK) c4[i] = z;
                 }
-                PH(0);
-                // stream the chunks of bucket b1 in batches of K2_MAXSEG chunks
-                for (uint32_t cb = c0; cb < c1; cb += K2_MAXSEG) {
-                    const uint32_t nch = (c1 - cb < (uint32_t)K2_MAXSEG) ? c1 - cb : (uint32_t)K2_MAXSEG;
-                    __syncthreads();
-                    for (uint32_t i = tid; i < nch; i += K2C_BLOCK) {
-                        const uint32_t c = cb + i;
-                        uint32_t sb, se;
-                        if (cfg.l2 == 0) {
-                            const ull cbase = base + (ull)(c - c0) * K2_CHUNK;
-                            sb = 0; se = (uint32_t)((bend - cbase < (ull)K2_CHUNK) ? (bend - cbase) : (ull)K2_CHUNK);
-                        } else {
-                            const uint16_t *co = chunk_off + (size_t)c * (B2 + 1) + b2;
-                            sb = co[0]; se = co[1];
-                        }
-                        segbeg[i] = sb; segpre[i] = se - sb;
+                __syncthreads();
+                const uint32_t rsh = free_bits - nr_log2;
+                for (uint32_t i0 = tid; i0 < nreg; i0 += K2C_BLOCK * K2_UNROLL) {
+                    ull keyv[K2_UNROLL];
+#pragma unroll
+                    for (int u = 0; u < K2_UNROLL; u++) {
+                        const uint32_t i = i0 + (uint32_t)u * K2C_BLOCK;
+                        keyv[u] = (i < nreg) ? reg[i] : SIMKA_EMPTY_KEY;
                     }
-                    __syncthreads();
-                    const uint32_t n = block_excl_scan<K2C_BLOCK>(segpre, nch, tmp);
-                    if (tid == 0) segpre[nch] = n;
-                    __syncthreads();
-                    PH(1);
-                    for (uint32_t i0 = tid; i0 < n; i0 += K2C_BLOCK * K2_UNROLL) {
-                        ull keyv[K2_UNROLL];
 #pragma unroll
-                        for (int u = 0; u < K2_UNROLL; u++) {
-                            const uint32_t i = i0 + (uint32_t)u * K2C_BLOCK;
-                            keyv[u] = SIMKA_EMPTY_KEY;
-                            if (i < n) {
-                                uint32_t lo = 0, hi = nch;       // largest ch with segpre[ch] <= i
-                                while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (segpre[mid] <= i) lo = mid; else hi = mid; }
-                                const ull addr = base + (ull)(cb - c0 + lo) * K2_CHUNK + segbeg[lo] + (i - segpre[lo]);
-                                keyv[u] = l1_keys[addr];
-                            }
-                        }
-#pragma unroll
-                        for (int u = 0; u < K2_UNROLL; u++) {
-                            const ull key = keyv[u];
-                            if (key == SIMKA_EMPTY_KEY) continue;
-                            if (nr_log2 && (uint32_t)((key >> (free_bits - nr_log2)) & ((1ull << nr_log2) - 1ull)) != r) continue;
-                            if (!table_insert(tkeys, tcnt, tmask, key)) s_ovf = 1;
-                        }
+                    for (int u = 0; u < K2_UNROLL; u++) {
+                        const ull key = keyv[u];
+                        if (key == SIMKA_EMPTY_KEY) continue;
+                        if (nr_log2 && (uint32_t)((key >> rsh) & ((1ull << nr_log2) - 1ull)) != r) continue;
+                        if (!table_insert(tkeys, tcnt, tmask, key)) s_ovf = 1;
                     }
                 }
+                for (ull i = tid; i < nspill; i += K2C_BLOCK) {
+                    if (l2.spill_part[i] != part) continue;
+                    const ull key = l2.spill_keys[i];
+                    if (nr_log2 && (uint32_t)((key >> rsh) & ((1ull << nr_log2) - 1ull)) != r) continue;
+                    if (!table_insert(tkeys, tcnt, tmask, key)) s_ovf = 1;
+                }
                 __syncthreads();
-                PH(2);
                 if (s_ovf) { restart = true; break; }
                 if (pass == 0) {
-                    // SimkaCompressedProcessor::process over the table
                     const uint4 *c4 = (const uint4 *)tcnt;
                     for (uint32_t i = tid; i < TS / 4; i += K2C_BLOCK) {
                         const uint4 q = c4[i];
@@ -454,7 +582,6 @@ k_count(const uint64_t *l1_keys, const ull *b1_start, const ull *b1_end, const u
                         emit_base = s_base;
                     }
                 }
-                PH(3);
                 if ((pass == 1 || nr_log2 == 0) && s_ovf != 2u) {
                     const uint4 *c4 = (const uint4 *)tcnt;
                     for (uint32_t i = tid; i < TS / 4; i += K2C_BLOCK) {
@@ -467,22 +594,15 @@ k_count(const uint64_t *l1_keys, const ull *b1_start, const ull *b1_end, const u
                                 const uint32_t pos = atomicAdd(&s_cur, 1u);
                                 o.solid_keys[emit_base + pos] = tkeys[i * 4 + j];
                                 o.solid_counts[emit_base + pos] = c;
-                                if (o.hist) {
-                                    if (c < SIMKA_HIST_MAX) atomicAdd(&lhist[c], 1u);
-                                    else {
-                                        const ull w = atomicAdd(o.ovf_cursor, 1ull);
-                                        if (w < o.ovf_cap) { o.ovf_list[2 * w] = o.sample; o.ovf_list[2 * w + 1] = c; }
-                                    }
-                                }
+                                if (o.hist) count_hist(o, lhist, c);
                             }
                         }
                     }
                 }
             }
-            PH(4);
             if (restart) {
                 __syncthreads();
-                if (nr_log2 >= free_bits || nr_log2 >= 12) { if (tid == 0) atomicOr(o.err, SIMKA_DEVERR_TABLE_OVERFLOW); part_done = true; continue; }
+                if (nr_log2 >= free_bits || nr_log2 >= 16) { if (tid == 0) atomicOr(o.err, SIMKA_DEVERR_TABLE_OVERFLOW); part_done = true; continue; }
                 if (tid == 0) s_ovf = 0;
                 nr_log2++; pass = -1;       // start over with twice the rounds (nothing was emitted yet)
                 continue;
@@ -490,7 +610,6 @@ k_count(const uint64_t *l1_keys, const ull *b1_start, const ull *b1_end, const u
             if (pass == 0) {
                 bt_dall += dall; bt_D += D; bt_N += N; bt_Q += Q;
                 if (nr_log2 == 0) { part_done = true; continue; }     // single round: already emitted
-                // multi-round: reserve the arena space for all rounds, then run the emitting pass
                 if (D) atomicAdd(&s_nsolid, (uint32_t)D);
                 __syncthreads();
                 if (tid == 0) {
@@ -507,15 +626,11 @@ k_count(const uint64_t *l1_keys, const ull *b1_start, const ull *b1_end, const u
             }
         }
     }
-#ifdef SIMKA_PHASE_PROF
-    if (tid == 0 && o.phase) for (int i = 0; i < 6; i++) atomicAdd(&o.phase[i], ph[i]);
-#endif
     if (o.hist) {
         __syncthreads();
         for (uint32_t i = tid; i < SIMKA_HIST_MAX; i += K2C_BLOCK)
             if (lhist[i]) atomicAdd(&o.hist[(size_t)o.sample * SIMKA_HIST_MAX + i], (ull)lhist[i]);
     }
-    // block totals -> per-sample totals (column layout: totals[T * nb_samples + sample]); one set of atomics per block
     if (bt_dall) atomicAdd(&s_tot[0], bt_dall);
     if (bt_D) { atomicAdd(&s_tot[1], bt_D); atomicAdd(&s_tot[2], bt_N); atomicAdd(&s_tot[3], bt_Q); }
     __syncthreads();
