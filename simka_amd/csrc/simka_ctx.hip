@@ -41,6 +41,8 @@ struct simka_ctx {
     ull *d_b1_count = nullptr, *d_b1_start = nullptr, *d_b1_end = nullptr, *d_b1_cursor = nullptr;
     uint32_t *d_l1_ovf = nullptr;                             // [N] capacity-mode scatter overflow flag per sample
     uint64_t nb_exact_fallbacks = 0;
+    int small_table = -1;                                     // -1 undecided, else use K2F_TABLE_SMALL in k_count_fast
+    uint32_t nb_counted_this_run = 0;
     struct Pending { uint32_t sample; SimkaScanArgs a; };     // device-resident samples whose flag has not been read yet
     std::vector<Pending> pending;
     uint32_t *d_chunk_first = nullptr;
@@ -196,9 +198,12 @@ static int set_lds_attr(simka_ctx *ctx) {
     HIPCHK(hipFuncSetAttribute((const void *)k_layout, hipFuncAttributeMaxDynamicSharedMemorySize, big));
     HIPCHK(hipFuncSetAttribute((const void *)k_split, hipFuncAttributeMaxDynamicSharedMemorySize, big));
     HIPCHK(hipFuncSetAttribute((const void *)k_count, hipFuncAttributeMaxDynamicSharedMemorySize, big));
-    HIPCHK(hipFuncSetAttribute((const void *)k_count_fast, hipFuncAttributeMaxDynamicSharedMemorySize, big));
+    HIPCHK(hipFuncSetAttribute((const void *)k_count_fast<K2F_TABLE_BIG>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
+    HIPCHK(hipFuncSetAttribute((const void *)k_count_fast<K2F_TABLE_SMALL>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
     HIPCHK(hipFuncSetAttribute((const void *)k_group, hipFuncAttributeMaxDynamicSharedMemorySize, big));
-    HIPCHK(hipFuncSetAttribute((const void *)k_pairs, hipFuncAttributeMaxDynamicSharedMemorySize, big));
+    HIPCHK(hipFuncSetAttribute((const void *)k_pairs<true, K4_BLOCK_BIG>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
+    HIPCHK(hipFuncSetAttribute((const void *)k_pairs<true, K4_BLOCK_SMALL>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
+    HIPCHK(hipFuncSetAttribute((const void *)k_pairs<false, K4_BLOCK_BIG>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
     return SIMKA_OK;
 }
 
@@ -219,9 +224,13 @@ static int setup_geometry(simka_ctx *ctx, uint64_t max_kmers) {
     if (getenv("SIMKA_L1")) l1 = std::min<uint32_t>(pb, (uint32_t)atoi(getenv("SIMKA_L1")));   // experiments
     const uint32_t min_l1 = std::min<uint32_t>(pb, ceil_log2_u64(c.shard_count));   // shards are level-1 buckets
     if (l1 < min_l1) l1 = min_l1;
+    // level 1 is scattered from 8192-position tiles (k_scan), level 2 from 8192-key chunks (k_split): keep level 1 at
+    // <= 512 buckets (>= ~100-byte runs, 2 blocks/CU of LDS) and give the rest to level 2
+    if (l1 > 9 && !getenv("SIMKA_L1")) l1 = 9;
+    if (l1 < min_l1) l1 = min_l1;
     if (l1 > 11) l1 = 11;
     uint32_t l2 = pb - l1;
-    if (l2 > 10) { l2 = 10; }
+    if (l2 > 11) { l2 = 11; }
     k.l1 = l1; k.l2 = l2; k.pb = l1 + l2; k.t = 0;
     ctx->B1 = 1u << l1; ctx->B2 = 1u << l2; ctx->nparts = (uint64_t)1 << k.pb;
 
@@ -250,7 +259,8 @@ static int setup_geometry(simka_ctx *ctx, uint64_t max_kmers) {
     if (cap == 0) {
         size_t fr = 0, tot = 0;
         HIPCHK(hipMemGetInfo(&fr, &tot));
-        const uint64_t want = (uint64_t)N * std::max<uint64_t>(max_kmers, 1);   // worst case: every occurrence distinct & solid
+        // worst case: every occurrence distinct & solid, plus the unused tails of the per-block slab reservations
+        const uint64_t want = (uint64_t)N * (std::max<uint64_t>(max_kmers, 1) + (uint64_t)ctx->num_cus * 6 * K2_SLAB);
         const uint64_t budget = (uint64_t)(fr * 0.45) / 12;
         cap = std::min(want, budget);
     }
@@ -354,6 +364,7 @@ SIMKA_EXPORT int simka_reset(simka_ctx *ctx) {
         HIPCHK(hipMemsetAsync(ctx->d_ovf_cursor, 0, 16, ctx->stream));
     }
     ctx->pending.clear();
+    ctx->nb_counted_this_run = 0;
     if (ctx->d_l1_ovf) HIPCHK(hipMemsetAsync(ctx->d_l1_ovf, 0, (size_t)(N + 1) * 4, ctx->stream));
     std::fill(ctx->counted.begin(), ctx->counted.end(), 0);
     std::fill(ctx->nb_reads.begin(), ctx->nb_reads.end(), 0);
@@ -477,12 +488,17 @@ static int run_count_kernels(simka_ctx *ctx, uint32_t sample, const SimkaScanArg
     static const bool slow_only = getenv("SIMKA_K2_SLOW") != nullptr;
     const size_t hist_lds = ctx->d_hist ? (size_t)SIMKA_HIST_MAX * 4 : 0;
     if (!slow_only) {
-        const size_t lds_fast = SIMKA_LDS_HEAD + (size_t)K2F_TABLE * 12 + (size_t)K2F_BLOCK * 4 + hist_lds;
-        static const uint32_t bpc_f = getenv("SIMKA_K2F_BLOCKS_PER_CU") ? (uint32_t)atoi(getenv("SIMKA_K2F_BLOCKS_PER_CU")) : 4u;
+        const bool small = ctx->small_table == 1;
+        const size_t lds_fast = SIMKA_LDS_HEAD + (size_t)(small ? K2F_TABLE_SMALL : K2F_TABLE_BIG) * 12 + (size_t)K2F_BLOCK * 4 + hist_lds;
+        const uint32_t bpc_f = (uint32_t)std::min<size_t>(4, (160 * 1024) / lds_fast);
+        const dim3 gridf((uint32_t)std::min<uint64_t>(ctx->nparts, (uint64_t)ctx->num_cus * bpc_f));
         launch_timed(ctx, KID_COUNT_FAST, [&] {
-            hipLaunchKernelGGL(k_count_fast, dim3((uint32_t)std::min<uint64_t>(ctx->nparts, (uint64_t)ctx->num_cus * bpc_f)), dim3(K2F_BLOCK),
-                               lds_fast, ctx->stream, key, l2, ctx->cfg.abundance_min, ctx->cfg.abundance_max, o, flag,
-                               ctx->d_redo_list, ctx->d_redo_count);
+            if (small)
+                hipLaunchKernelGGL((k_count_fast<K2F_TABLE_SMALL>), gridf, dim3(K2F_BLOCK), lds_fast, ctx->stream, key, l2, ctx->cfg.abundance_min,
+                                   ctx->cfg.abundance_max, o, flag, ctx->d_redo_list, ctx->d_redo_count);
+            else
+                hipLaunchKernelGGL((k_count_fast<K2F_TABLE_BIG>), gridf, dim3(K2F_BLOCK), lds_fast, ctx->stream, key, l2, ctx->cfg.abundance_min,
+                                   ctx->cfg.abundance_max, o, flag, ctx->d_redo_list, ctx->d_redo_count);
         });
     }
     const size_t lds_count = SIMKA_LDS_HEAD + ((size_t)12 << tlog) + hist_lds;
@@ -553,6 +569,16 @@ SIMKA_EXPORT int simka_count_sample(simka_ctx *ctx, uint32_t sample, const simka
     }
     rc = run_count_kernels(ctx, sample, a, false);
     if (rc) return rc;
+    if (ctx->nb_counted_this_run++ == 0 && ctx->cfg.nb_samples > 1) {
+        // table size of k_count_fast for the rest of the run, from this sample's distinct ratio (one sync per run)
+        rc = resolve_pending(ctx); if (rc) return rc;
+        uint64_t da = 0, ko = 0;
+        const uint32_t fl = ctx->cfg.dist_flags;
+        HIPCHK(hipMemcpyAsync(&da, ctx->d_stats + stats_off_tot(N, fl, SIMKA_TOT_DALL) + sample, 8, hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(hipMemcpyAsync(&ko, ctx->d_stats + stats_off_tot(N, fl, SIMKA_TOT_KOCC) + sample, 8, hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(hipStreamSynchronize(ctx->stream));
+        ctx->small_table = (ko > 0 && (double)da / (double)ko < 0.40) ? 1 : 0;
+    }
     if (!r->on_device) return resolve_pending(ctx);     // staged host reads are overwritten by the next sample: settle now
     return SIMKA_OK;
 }
@@ -642,7 +668,7 @@ SIMKA_EXPORT int simka_merge(simka_ctx *ctx) {
     pc.simple = (flags & SIMKA_DIST_SIMPLE) ? 1u : 0u;
     pc.nb_pairs = (uint64_t)N * (N - 1) / 2;
     pc.tot_n = (const ull *)ctx->d_stats + stats_off_tot(N, flags, SIMKA_TOT_N);   // GLOBAL N_i: all-reduced by the caller when sharded
-    const size_t lds_fixed = SIMKA_LDS_HEAD + (size_t)K3_CAP * 8 + (size_t)K3_CAP * 4 + (size_t)(K3_CAP + 1) * 4 + K4_BLOCK * 4 + 64;
+    const size_t lds_fixed = SIMKA_LDS_HEAD + (size_t)K3_CAP * 8 + (size_t)K3_CAP * 4 + (size_t)(K3_CAP + 1) * 4 + 64 + 64;
     const size_t lds_budget = 160 * 1024 - lds_fixed;
     const uint64_t max_cells = lds_budget / (4 * pc.nacc32 + 8 * pc.nacc64);
     if (pc.nb_pairs <= max_cells) { pc.tile = N; pc.ntiles = 1; pc.ncell = (uint32_t)pc.nb_pairs; }
@@ -653,7 +679,8 @@ SIMKA_EXPORT int simka_merge(simka_ctx *ctx) {
     pc.ncell_pad = (pc.ncell + 3u) & ~3u;
     const uint32_t ntp = pc.ntiles * (pc.ntiles + 1) / 2;
     const size_t lds_pairs = lds_fixed + (size_t)pc.ncell_pad * (4 * pc.nacc32 + 8 * pc.nacc64);
-    const uint32_t per_cu = (uint32_t)std::min<size_t>(4, std::max<size_t>(1, (160 * 1024) / lds_pairs));
+    const bool small_block = pc.ntiles == 1 && N <= 32;     // few pairs per span: more, smaller blocks
+    const uint32_t per_cu = (uint32_t)std::min<size_t>(small_block ? 6 : 2, std::max<size_t>(1, (160 * 1024) / lds_pairs));
     const uint32_t nblk = (uint32_t)ctx->num_cus * per_cu;
     const uint64_t slab_words = (uint64_t)ntp * nblk * pc.nacc * pc.ncell_pad;
     if (ctx->slab_words < slab_words) { if (ctx->d_slabs) HIPCHK(hipFree(ctx->d_slabs)); ctx->d_slabs = nullptr; HIPCHK(dev_alloc(&ctx->d_slabs, slab_words)); ctx->slab_words = slab_words; }
@@ -687,8 +714,15 @@ SIMKA_EXPORT int simka_merge(simka_ctx *ctx) {
                                    ctx->d_fb_off, nfb, (uint32_t)recs, key, min_share, co);
             });
             launch_timed(ctx, KID_PAIRS, [&] {
-                hipLaunchKernelGGL(k_pairs, dim3(nblk, ntp), dim3(K4_BLOCK), lds_pairs, ctx->stream, ctx->d_spans, ctx->d_cursors,
-                                   ctx->d_entries, ctx->d_groups, pc, acc, ctx->d_slabs);
+                if (small_block)
+                    hipLaunchKernelGGL((k_pairs<true, K4_BLOCK_SMALL>), dim3(nblk, ntp), dim3(K4_BLOCK_SMALL), lds_pairs, ctx->stream, ctx->d_spans,
+                                       ctx->d_cursors, ctx->d_entries, ctx->d_groups, pc, acc, ctx->d_slabs);
+                else if (pc.ntiles == 1)
+                    hipLaunchKernelGGL((k_pairs<true, K4_BLOCK_BIG>), dim3(nblk, ntp), dim3(K4_BLOCK_BIG), lds_pairs, ctx->stream, ctx->d_spans,
+                                       ctx->d_cursors, ctx->d_entries, ctx->d_groups, pc, acc, ctx->d_slabs);
+                else
+                    hipLaunchKernelGGL((k_pairs<false, K4_BLOCK_BIG>), dim3(nblk, ntp), dim3(K4_BLOCK_BIG), lds_pairs, ctx->stream, ctx->d_spans,
+                                       ctx->d_cursors, ctx->d_entries, ctx->d_groups, pc, acc, ctx->d_slabs);
             });
         }
         pb = pe;

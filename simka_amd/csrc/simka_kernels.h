@@ -18,14 +18,17 @@
 #define K2_MAXSEG_UNUSED 512         // chunk segments gathered per batch in k_count
 // k_count_fast
 #define K2F_BLOCK 512
-#define K2F_TABLE 2048        // slots (24 KB); TS/BLOCK = 4 slots per thread in the summary pass
+#define K2F_TABLE_BIG 4096    // slots (48 KB): safe even if every k-mer of a partition is distinct
+#define K2F_TABLE_SMALL 2048  // slots (24 KB): when the first sample shows mostly repeated k-mers (high coverage)
 #define K2F_UNROLL 8          // keys prefetched per thread: partitions up to BLOCK*UNROLL = 4096 keys take the fast path
-#define K2_SLAB 2048          // arena records reserved per global atomic by a k_count block
+#define K2_SLAB 512           // arena records reserved per global atomic by a k_count block
 #ifndef K2_UNROLL
 #define K2_UNROLL 8
 #endif
 //          // independent key loads in flight per thread
-#define SIMKA_TARGET_PER_PART 4096   // sizing: k-mer occurrences per partition (<= 50% table load even if all distinct)
+#ifndef SIMKA_TARGET_PER_PART
+#define SIMKA_TARGET_PER_PART 3072   // sizing: k-mer occurrences per partition: below 7/8 of the 4096-slot table even if ALL are distinct
+#endif
 // K3  k_regroup / k_group
 #define K3_BLOCK 256
 #define K3_CAP 1024           // records hashed per round
@@ -35,7 +38,8 @@
 #define K3_SLAB_GRP 4096
 #define K3_SLAB_SPAN 32
 // K4  k_pairs
-#define K4_BLOCK 512
+#define K4_BLOCK_BIG 1024
+#define K4_BLOCK_SMALL 256
 
 // per-sample totals row (device), additive over shards
 #define SIMKA_NB_TOTALS 5
@@ -114,6 +118,7 @@ struct SimkaMergeIn {
 struct SimkaSpan {
     unsigned long long ebase, gbase;
     uint32_t nent, ngrp;
+    uint32_t maxc, pad;                      // largest count among the span's records (overflow bound of k_pairs)
 };
 
 struct SimkaCsrOut {

@@ -350,6 +350,7 @@ __device__ __forceinline__ void count_hist(const SimkaCountOut &o, uint32_t *lhi
     else { const ull w = atomicAdd(o.ovf_cursor, 1ull); if (w < o.ovf_cap) { o.ovf_list[2 * w] = o.sample; o.ovf_list[2 * w + 1] = c; } }
 }
 
+template <uint32_t TS>
 __global__ void __launch_bounds__(K2F_BLOCK)
 k_count_fast(SimkaKeyCfg cfg, SimkaL2 l2, uint32_t amin, uint32_t amax, SimkaCountOut o, const uint32_t *flag,
              uint32_t *redo_list, ull *redo_count) {
@@ -361,7 +362,7 @@ k_count_fast(SimkaKeyCfg cfg, SimkaL2 l2, uint32_t amin, uint32_t amax, SimkaCou
     ull &s_slab_end = *(ull *)(smem + 48);
     uint32_t &s_ok = *(uint32_t *)(smem + 56);
     uint32_t *tmp = (uint32_t *)(smem + 128);         // [K2F_BLOCK/64]
-    constexpr uint32_t TS = K2F_TABLE, tmask = TS - 1u, SPT = TS / K2F_BLOCK;   // slots per thread
+    constexpr uint32_t tmask = TS - 1u, SPT = TS / K2F_BLOCK;   // slots per thread
     ull *tkeys = (ull *)(smem + SIMKA_LDS_HEAD);      // [TS]
     uint32_t *tcnt = (uint32_t *)(tkeys + TS);        // [TS]
     uint32_t *spos = tcnt + TS;                       // [K2F_BLOCK]
@@ -392,7 +393,7 @@ k_count_fast(SimkaKeyCfg cfg, SimkaL2 l2, uint32_t amin, uint32_t amax, SimkaCou
     bool fastp = false;
     if (part < nparts) {
         n = l2.p_count[part];
-        fastp = n <= (uint32_t)(K2F_BLOCK * K2F_UNROLL) && (ull)n <= l2.cap2;
+        fastp = (ull)n <= l2.cap2;          // not spilled
         if (fastp) { K2F_LOAD(part, n) }
     }
     __syncthreads();
@@ -400,9 +401,9 @@ k_count_fast(SimkaKeyCfg cfg, SimkaL2 l2, uint32_t amin, uint32_t amax, SimkaCou
         const uint32_t next = part + gridDim.x;
         uint32_t n_next = 0;
         bool fast_next = false;
-        if (next < nparts) { n_next = l2.p_count[next]; fast_next = n_next <= (uint32_t)(K2F_BLOCK * K2F_UNROLL) && (ull)n_next <= l2.cap2; }
+        if (next < nparts) { n_next = l2.p_count[next]; fast_next = (ull)n_next <= l2.cap2; }
         if (n == 0) { part = next; n = n_next; fastp = fast_next; if (fastp) { K2F_LOAD(part, n) } continue; }
-        if (!fastp) {     // spilled or larger than one batch: the general kernel finishes it
+        if (!fastp) {     // spilled: the general kernel finishes it
             if (tid == 0) { const ull w = atomicAdd(redo_count, 1ull); redo_list[w] = part; }
             part = next; n = n_next; fastp = fast_next; if (fastp) { K2F_LOAD(part, n) }
             continue;
@@ -413,6 +414,8 @@ k_count_fast(SimkaKeyCfg cfg, SimkaL2 l2, uint32_t amin, uint32_t amax, SimkaCou
             const ull key = kk[u];
             if (key != SIMKA_EMPTY_KEY) table_insert(tkeys, tcnt, tmask, key);
         }
+        for (uint32_t i = K2F_BLOCK * K2F_UNROLL + tid; i < n; i += K2F_BLOCK)      // beyond the prefetch window (rare)
+            table_insert(tkeys, tcnt, tmask, l2.l2_keys[(ull)part * l2.cap2 + i]);
         __syncthreads();
         // ---- prefetch the next partition while this one is summarised
         if (fast_next) { K2F_LOAD(next, n_next) }
@@ -709,6 +712,7 @@ k_group(const ull *mkeys, const ull *mvals, const uint32_t *fb_off, uint32_t nfb
     uint32_t &s_ndist = *(uint32_t *)(smem + 72);
     uint32_t &s_nshared = *(uint32_t *)(smem + 76);
     int &s_sp = *(int *)(smem + 80);
+    uint32_t &s_maxc = *(uint32_t *)(smem + 84);
     uint32_t *tmp = (uint32_t *)(smem + 96);               // [K3_BLOCK/64]
     uint32_t *s_stack = (uint32_t *)(smem + 128);          // [2*24]
     ull *tkeys = (ull *)(smem + SIMKA_LDS_HEAD);           // [K3_TABLE]
@@ -739,7 +743,7 @@ k_group(const ull *mkeys, const ull *mvals, const uint32_t *fb_off, uint32_t nfb
                 if (s_sp == 0) break;
                 const uint32_t e = s_stack[2 * (s_sp - 1)], val = s_stack[2 * (s_sp - 1) + 1];
                 __syncthreads();
-                if (tid == 0) { s_sp--; s_nrec = 0; s_ovf = 0; }
+                if (tid == 0) { s_sp--; s_nrec = 0; s_ovf = 0; s_maxc = 0; }
                 {
                     ulonglong2 *k2 = (ulonglong2 *)tkeys; uint4 *c4 = (uint4 *)scnt;
                     const ulonglong2 ek = make_ulonglong2(SIMKA_EMPTY_KEY, SIMKA_EMPTY_KEY);
@@ -750,6 +754,7 @@ k_group(const ull *mkeys, const ull *mvals, const uint32_t *fb_off, uint32_t nfb
                 __syncthreads();
                 // ---- hash the records of this (sub-)range; K3_UNROLL independent loads per thread
                 const uint32_t selshift = free_bits - e;
+                uint32_t mymax = 0;
                 for (uint32_t i0 = rb + tid; i0 < re; i0 += K3_BLOCK * K3_UNROLL) {
                     ull kk[K3_UNROLL], vv[K3_UNROLL];
 #pragma unroll
@@ -774,8 +779,12 @@ k_group(const ull *mkeys, const ull *mvals, const uint32_t *fb_off, uint32_t nfb
                         atomicAdd(&scnt[slot], 1u);
                         rslot[idx] = (uint16_t)slot;
                         rval[idx] = vv[u];
+                        if ((uint32_t)vv[u] > mymax) mymax = (uint32_t)vv[u];
                     }
                 }
+#pragma unroll
+                for (int o_ = 32; o_ > 0; o_ >>= 1) { const uint32_t t_ = __shfl_xor(mymax, o_, 64); mymax = t_ > mymax ? t_ : mymax; }
+                if ((tid & 63u) == 0 && mymax) atomicMax(&s_maxc, mymax);
                 __syncthreads();
                 if (s_ovf) {
                     if (e >= free_bits) { if (tid == 0) atomicOr(o.err, SIMKA_DEVERR_GROUP_OVERFLOW); break; }
@@ -812,7 +821,7 @@ k_group(const ull *mkeys, const ull *mvals, const uint32_t *fb_off, uint32_t nfb
                     if (s_slab[4] + 1 > s_slab[5]) { s_slab[4] = atomicAdd(&o.cursors[2], (ull)K3_SLAB_SPAN); s_slab[5] = s_slab[4] + K3_SLAB_SPAN; if (s_slab[5] > o.cap_spans) ok = 0; }
                     if (!ok) { atomicOr(o.err, SIMKA_DEVERR_CSR_FULL); s_ovf = 2; }
                     else {
-                        SimkaSpan sp; sp.ebase = s_slab[0]; sp.gbase = s_slab[2]; sp.nent = nent; sp.ngrp = ngrp;
+                        SimkaSpan sp; sp.ebase = s_slab[0]; sp.gbase = s_slab[2]; sp.nent = nent; sp.ngrp = ngrp; sp.maxc = s_maxc; sp.pad = 0;
                         o.spans[s_slab[4]] = sp;
                         s_ebase = s_slab[0]; s_gbase = s_slab[2];
                         s_slab[0] += nent; s_slab[2] += ngrp; s_slab[4] += 1;
@@ -841,7 +850,7 @@ k_group(const ull *mkeys, const ull *mvals, const uint32_t *fb_off, uint32_t nfb
         if (s_nshared) atomicAdd(&o.glob[1], (ull)s_nshared);  // _nbSharedKmers    (:1319-1321)
     }
     // unused span slots of this block's last slab: mark empty
-    for (ull i = s_slab[4] + tid; i < s_slab[5]; i += K3_BLOCK) { SimkaSpan sp; sp.ebase = 0; sp.gbase = 0; sp.nent = 0; sp.ngrp = 0; o.spans[i] = sp; }
+    for (ull i = s_slab[4] + tid; i < s_slab[5]; i += K3_BLOCK) { SimkaSpan sp; sp.ebase = 0; sp.gbase = 0; sp.nent = 0; sp.ngrp = 0; sp.maxc = 0; sp.pad = 0; o.spans[i] = sp; }
 }
 
 // --------------------------------------------------------------------------------------------
@@ -860,11 +869,6 @@ __device__ __forceinline__ ull simka_whit_abs(ull d) {
     return (ull)(long long)r;
 }
 
-__device__ __forceinline__ void acc_add(uint32_t *l, ull *g, uint32_t v) {
-    const uint32_t old = atomicAdd(l, v);
-    if ((uint32_t)(old + v) < old) atomicAdd(g, 1ull << 32);
-}
-
 __device__ __forceinline__ void tri_unrank(uint32_t idx, uint32_t s, uint32_t &x, uint32_t &y) {
     // pairs (x<y) of s items, row-major; row x starts at x*s - x*(x+1)/2
     const double fs = 2.0 * (double)s - 1.0;
@@ -880,6 +884,28 @@ __device__ __forceinline__ void tri_unrank(uint32_t idx, uint32_t s, uint32_t &x
     y = (uint32_t)(id - (xi * S - xi * (xi + 1) / 2) + xi + 1);
 }
 
+// floor(sqrt(x)) for the Hellinger term: 32-bit fast path, exact
+__device__ __forceinline__ uint32_t pair_isqrt(ull x) {
+    if (x >> 32) return (uint32_t)simka_isqrt(x);
+    const uint32_t v = (uint32_t)x;
+    uint32_t r = (uint32_t)__fsqrt_rn((float)v);
+    if (r > 65535u) r = 65535u;
+    if (r * r > v) r--;
+    else if (r < 65535u && (r + 1u) * (r + 1u) <= v) r++;
+    return r;
+}
+
+// fold the block's private LDS accumulators into its slab row and zero them
+template <int K4_BLOCK>
+__device__ __forceinline__ void pairs_flush(uint32_t *lacc, ull *lacc64, ull *slab, const SimkaPairCfg &pc) {
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < pc.nacc32 * pc.ncell_pad; i += K4_BLOCK) { const uint32_t v = lacc[i]; if (v) { slab[i] += v; lacc[i] = 0; } }
+    for (uint32_t i = threadIdx.x; i < pc.nacc64 * pc.ncell_pad; i += K4_BLOCK) { const ull v = lacc64[i]; if (v) { slab[(size_t)pc.nacc32 * pc.ncell_pad + i] += v; lacc64[i] = 0; } }
+    __syncthreads();
+}
+
+// K4_BLOCK: 1024 threads when the (i,j) space is large (many pairs per span), 256 for few samples
+template <bool SINGLE, int K4_BLOCK>
 __global__ void __launch_bounds__(K4_BLOCK)
 k_pairs(const SimkaSpan *spans, const ull *cursors, const ull *entries, const uint32_t *groups, SimkaPairCfg pc,
         ull *acc, ull *slabs) {
@@ -889,31 +915,36 @@ k_pairs(const SimkaSpan *spans, const ull *cursors, const ull *entries, const ui
     ull *ent = (ull *)(lacc + (size_t)pc.nacc32 * pc.ncell_pad);  // [K3_CAP]
     uint32_t *gdesc = (uint32_t *)(ent + K3_CAP);               // [K3_CAP]   (start<<16 | size)
     uint32_t *gpref = gdesc + K3_CAP;                           // [K3_CAP+1] pair prefix
-    uint32_t *tmp = gpref + K3_CAP + 1;                         // [K4_BLOCK]
+    uint32_t *tmp = gpref + K3_CAP + 1;                         // [K4_BLOCK/64]
 
     const uint32_t tid = threadIdx.x;
-    const uint32_t N = pc.nb_samples, T = pc.tile;
-    // tile pair (I<=J) of this block row
-    uint32_t I = 0, J = 0;
-    {
+    const uint32_t N = pc.nb_samples, T = pc.tile, CP = pc.ncell_pad;
+    uint32_t I = 0, J = 0;                                      // tile pair (I<=J) of this block row
+    if (!SINGLE) {
         uint32_t r = blockIdx.y;
         for (I = 0; I < pc.ntiles; I++) { const uint32_t row = pc.ntiles - I; if (r < row) { J = I + r; break; } r -= row; }
     }
-    const uint32_t ncell = pc.ncell;
-    for (uint32_t i = tid; i < pc.nacc32 * pc.ncell_pad; i += K4_BLOCK) lacc[i] = 0;
-    for (uint32_t i = tid; i < pc.nacc64 * pc.ncell_pad; i += K4_BLOCK) lacc64[i] = 0;
+    for (uint32_t i = tid; i < pc.nacc32 * CP; i += K4_BLOCK) lacc[i] = 0;
+    for (uint32_t i = tid; i < pc.nacc64 * CP; i += K4_BLOCK) lacc64[i] = 0;
+    ull *slab = slabs + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * pc.nacc * CP;
+    // every LDS cell is a u32 fed by NON-returning atomics: a cell receives at most one add per group, so
+    // `bound` (sum over spans of #groups x largest count) < 2^32 guarantees no wrap; flush before it could.
+    ull bound = 0;
     __syncthreads();
 
     const ull nspans = cursors[2];
     for (ull sp = blockIdx.x; sp < nspans; sp += gridDim.x) {
         const SimkaSpan span = spans[sp];
         if (span.ngrp == 0) continue;     // unused slot of a k_group span slab
+        const ull add = (ull)span.ngrp * (ull)span.maxc;
+        if (bound + add >= 0xffffffffull) { pairs_flush<K4_BLOCK>(lacc, lacc64, slab, pc); bound = 0; }
+        bound += add;
         for (uint32_t i = tid; i < span.nent; i += K4_BLOCK) ent[i] = entries[span.ebase + i];
         for (uint32_t i = tid; i < span.ngrp; i += K4_BLOCK) {
             const uint32_t d = groups[span.gbase + i];
             gdesc[i] = d;
-            const uint32_t s = d & 0xffffu;
-            gpref[i] = s * (s - 1u) / 2u;
+            const uint32_t s_ = d & 0xffffu;
+            gpref[i] = s_ * (s_ - 1u) / 2u;
         }
         __syncthreads();
         const uint32_t P = block_excl_scan<K4_BLOCK>(gpref, span.ngrp, tmp);
@@ -928,69 +959,68 @@ k_pairs(const SimkaSpan *spans, const ull *cursors, const ull *entries, const ui
             uint32_t g = lo;
             while (g + 1 < span.ngrp && gpref[g + 1] <= p) g++;   // skip groups without pairs
             uint32_t d = gdesc[g];
-            uint32_t gs = d >> 16, s = d & 0xffffu, x, y;
-            tri_unrank(p - gpref[g], s, x, y);
+            uint32_t gs = d >> 16, s_ = d & 0xffffu, x, y;
+            tri_unrank(p - gpref[g], s_, x, y);
+            ull ex = ent[gs + x];
             for (; p < pend; p++) {
-                const ull ex = ent[gs + x], ey = ent[gs + y];
+                const ull ey = ent[gs + y];
                 uint32_t si = (uint32_t)(ex >> 32), sj = (uint32_t)(ey >> 32);
                 uint32_t ci = (uint32_t)ex, cj = (uint32_t)ey;
                 if (si > sj) { uint32_t t_ = si; si = sj; sj = t_; t_ = ci; ci = cj; cj = t_; }
-                // tile filter (single tile: always true)
-                const uint32_t ti = si / T, tj = sj / T;
-                if (ti == I && tj == J) {
+                bool mine = true;
+                uint32_t cell;
+                if (SINGLE) cell = si * N - ((si * (si + 1u)) >> 1) + (sj - si - 1u);      // N <= 65535: fits 32 bits
+                else {
+                    const uint32_t ti = si / T, tj = sj / T;
+                    mine = (ti == I && tj == J);
                     const uint32_t li = si - I * T, lj = sj - J * T;
-                    const uint32_t cell = (pc.ntiles == 1) ? (uint32_t)simka_pair_index(li, lj, N)
-                                          : (I == J ? (uint32_t)simka_pair_index(li, lj, T) : li * T + lj);
-                    const ull pg = simka_pair_index(si, sj, N);
-                    acc_add(&lacc[SIMKA_ACC_SIJ * pc.ncell_pad + cell], &acc[SIMKA_ACC_SIJ * pc.nb_pairs + pg], ci);
-                    acc_add(&lacc[SIMKA_ACC_SJI * pc.ncell_pad + cell], &acc[SIMKA_ACC_SJI * pc.nb_pairs + pg], cj);
-                    atomicAdd(&lacc[SIMKA_ACC_A * pc.ncell_pad + cell], 1u);
-                    acc_add(&lacc[SIMKA_ACC_BC * pc.ncell_pad + cell], &acc[SIMKA_ACC_BC * pc.nb_pairs + pg], ci < cj ? ci : cj);
+                    cell = (I == J) ? (li * T - ((li * (li + 1u)) >> 1) + (lj - li - 1u)) : li * T + lj;
+                }
+                if (mine) {
+                    atomicAdd(&lacc[SIMKA_ACC_SIJ * CP + cell], ci);
+                    atomicAdd(&lacc[SIMKA_ACC_SJI * CP + cell], cj);
+                    atomicAdd(&lacc[SIMKA_ACC_A * CP + cell], 1u);
+                    atomicAdd(&lacc[SIMKA_ACC_BC * CP + cell], ci < cj ? ci : cj);
+                    if (pc.simple) {
+                        const ull prod = (ull)ci * (ull)cj;
+                        // chord products can exceed any per-span bound: keep the carry path (returning atomic)
+                        const uint32_t lo32 = (uint32_t)prod;
+                        const uint32_t old = atomicAdd(&lacc[SIMKA_ACC_CHORD * CP + cell], lo32);
+                        if ((uint32_t)(old + lo32) < old || (prod >> 32)) {
+                            const ull pg = simka_pair_index(si, sj, N);
+                            atomicAdd(&acc[SIMKA_ACC_CHORD * pc.nb_pairs + pg], (((uint32_t)(old + lo32) < old) ? (1ull << 32) : 0ull) + ((prod >> 32) << 32));
+                        }
+                        atomicAdd(&lacc[SIMKA_ACC_HELL * CP + cell], pair_isqrt(prod));
+                    }
                     if (pc.nacc64) {
                         // updateDistanceComplex restricted to both-present pairs (ref: src/core/SimkaAlgorithm.hpp:437-446,477-481);
                         // the one-sided terms are closed forms of S / totals / count histograms, added on the host
                         const double Ni = (double)pc.tot_n[si], Nj = (double)pc.tot_n[sj];
                         const double ai = (double)ci, aj = (double)cj;
                         const double xY = ai * Nj, yX = aj * Ni;
-                        const double d = (ai / Ni) * log((2 * xY) / (xY + yX)) + (aj / Nj) * log((2 * yX) / (xY + yX));
-                        atomicAdd(&lacc64[1 * pc.ncell_pad + cell], (ull)(long long)llrint(d * SIMKA_KL_SCALE));
+                        const double dd = (ai / Ni) * log((2 * xY) / (xY + yX)) + (aj / Nj) * log((2 * yX) / (xY + yX));
+                        atomicAdd(&lacc64[1 * CP + cell], (ull)(long long)llrint(dd * SIMKA_KL_SCALE));
                         const ull uX = (ull)xY, uY = (ull)yX;
-                        atomicAdd(&lacc64[0 * pc.ncell_pad + cell], simka_whit_abs(uX - uY) - simka_whit_abs(uX) - simka_whit_abs(uY));
-                    }
-                    if (pc.simple) {
-                        const ull prod = (ull)ci * (ull)cj;
-                        acc_add(&lacc[SIMKA_ACC_CHORD * pc.ncell_pad + cell], &acc[SIMKA_ACC_CHORD * pc.nb_pairs + pg], (uint32_t)prod);
-                        if (prod >> 32) atomicAdd(&acc[SIMKA_ACC_CHORD * pc.nb_pairs + pg], (prod >> 32) << 32);
-                        acc_add(&lacc[SIMKA_ACC_HELL * pc.ncell_pad + cell], &acc[SIMKA_ACC_HELL * pc.nb_pairs + pg], (uint32_t)simka_isqrt(prod));
+                        atomicAdd(&lacc64[0 * CP + cell], simka_whit_abs(uX - uY) - simka_whit_abs(uX) - simka_whit_abs(uY));
                     }
                 }
                 // next pair of the span
                 y++;
-                if (y == s) {
+                if (y == s_) {
                     x++; y = x + 1;
-                    if (y >= s) {   // group exhausted
+                    if (y >= s_) {   // group exhausted
                         g++;
                         while (g < span.ngrp && (gdesc[g] & 0xffffu) < 2u) g++;
                         if (g >= span.ngrp) break;
-                        d = gdesc[g]; gs = d >> 16; s = d & 0xffffu; x = 0; y = 1;
+                        d = gdesc[g]; gs = d >> 16; s_ = d & 0xffffu; x = 0; y = 1;
                     }
+                    ex = ent[gs + x];
                 }
             }
         }
         __syncthreads();
     }
-    // ---- fold this block's private accumulators into its slab (plain read-modify-write: the slab
-    // row belongs to this block alone); k_reduce_slabs sums the rows at the end of the merge
-    ull *slab = slabs + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * pc.nacc * pc.ncell_pad;
-    for (uint32_t i = tid; i < pc.nacc32 * pc.ncell_pad; i += K4_BLOCK) {
-        const uint32_t v = lacc[i];
-        if (v) slab[i] += v;
-    }
-    for (uint32_t i = tid; i < pc.nacc64 * pc.ncell_pad; i += K4_BLOCK) {
-        const ull v = lacc64[i];
-        if (v) slab[(size_t)pc.nacc32 * pc.ncell_pad + i] += v;
-    }
-    (void)ncell;
+    pairs_flush<K4_BLOCK>(lacc, lacc64, slab, pc);
 }
 
 // slabs[tilepair][block][acc][cell] -> acc[a][pair(i,j)]
