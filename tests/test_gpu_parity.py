@@ -208,3 +208,72 @@ def test_exact_sizing_env_matches_capacity_sizing(gpu_required, monkeypatch):
     out = os.path.join(os.environ.get("TMPDIR", "/tmp"), "simka_exact_flat.npy")
     subprocess.run([sys.executable, "-c", code, out], check=True)
     assert np.array_equal(np.load(out), st1.flat)
+
+
+def _random_reads_packed(R, L, seed):
+    """i.i.d. uniform bases: essentially every k-mer distinct (the low-coverage extreme)."""
+    rng = np.random.default_rng(seed)
+    codes = rng.integers(0, 4, size=R * L, dtype=np.uint64)
+    nw = (R * L + 31) // 32
+    codes = np.concatenate([codes, np.zeros(nw * 32 - R * L, dtype=np.uint64)]).reshape(nw, 32)
+    return np.bitwise_or.reduce(codes << (np.arange(32, dtype=np.uint64) * np.uint64(2))[None, :], axis=1)
+
+
+@pytest.mark.parametrize("order", ["low_first", "high_first"])
+def test_low_coverage_all_distinct_partitions(gpu_required, oracle_mod, order):
+    """Partitions whose k-mers are (almost) all distinct need the big LDS table; when the table size picked from the first
+    sample is too small for a later one, the over-full partitions must be finished by the general kernel."""
+    from simka_amd import synth
+    R, L, k = 6000, 100, 21
+    hi = _synthetic(2, R, L, seed_shift=40)
+    lo = [_random_reads_packed(R, L, 7), _random_reads_packed(R, L, 8)]
+    lo[1][: len(lo[1]) // 2] = lo[0][: len(lo[0]) // 2]          # share half of the reads so that pairs exist
+    packed = (lo + hi) if order == "low_first" else (hi + lo)
+    offs = np.arange(R + 1, dtype=np.uint64) * L
+    inputs = [(np.concatenate([pk, np.zeros(2, dtype=np.uint64)]), offs, R * L, R) for pk in packed]
+    totals, st = _run_gpu(inputs, k, 1)
+    orc = oracle_mod.Oracle()
+    for s, pk in enumerate(packed):
+        orc.add_sample_ascii("S%d" % s, synth.unpack_ascii(pk, R * L), offs)
+    orc.run(k, 1, simple=True, complex_=True)
+    _check_vs_oracle(totals, st, orc)
+
+
+def test_cli_fastq_gz_inputs(gpu_required, golden_dir, tmp_path):
+    """Same sequences as the example, delivered as FASTQ / FASTQ.gz / FASTA.gz: the matrices must not change."""
+    import subprocess
+    import simka_amd
+    from simka_amd import build as b
+    ex = os.path.join(golden_dir, "example")
+    d = tmp_path / "in"
+    d.mkdir()
+
+    def seqs(name):
+        return list(simka_amd.read_sequences(os.path.join(ex, name)))
+
+    def fastq(path, ss, gz):
+        txt = b"".join(b"@r%d\n%s\n+\n%s\n" % (i, s, b"I" * len(s)) for i, s in enumerate(ss))
+        (gzip.open if gz else open)(path, "wb").write(txt)
+
+    fastq(str(d / "A.fastq"), seqs("A.fasta"), False)
+    fastq(str(d / "B.fq.gz"), seqs("B.fasta"), True)
+    with gzip.open(str(d / "C.fasta.gz"), "wb") as f:
+        f.write(open(os.path.join(ex, "C.fasta"), "rb").read())
+    for n in ("D_paired_1.fasta", "D_paired_2.fasta"):
+        (d / n).write_bytes(open(os.path.join(ex, n), "rb").read())
+    (d / "input.txt").write_text("A: A.fastq\nB: B.fq.gz\nC: C.fasta.gz\nD: D_paired_1.fasta ; D_paired_2.fasta\n"
+                                 "E: A.fastq , A.fastq ; B.fq.gz , B.fq.gz\n")
+    out = str(tmp_path / "out")
+    r = subprocess.run([b.CLI_PATH, "-in", str(d / "input.txt"), "-out", out, "-out-tmp", str(tmp_path / "tmp"), "-simple-dist",
+                        "-complex-dist", "-kmer-size", "31", "-abundance-min", "2", "-verbose", "0"],
+                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    assert r.returncode == 0, r.stdout
+    truth = os.path.join(golden_dir, "truth", "results_k31_t2")
+    n = 0
+    for gzf in glob.glob(os.path.join(out, "*.csv.gz")):
+        ref = os.path.join(truth, os.path.basename(gzf)[:-3])
+        if os.path.exists(ref):
+            with gzip.open(gzf, "rb") as f, open(ref, "rb") as g:
+                assert f.read() == g.read(), os.path.basename(gzf)
+            n += 1
+    assert n == 20
