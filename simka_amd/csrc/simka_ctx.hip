@@ -93,6 +93,14 @@ struct simka_ctx {
 
 template <typename F>
 static inline void launch_timed(simka_ctx *ctx, int kid, F &&f) {
+    static const bool dbg = getenv("SIMKA_DEBUG_SYNC") != nullptr;     // synchronise after every launch, name the kernel
+    if (dbg) {
+        fprintf(stderr, "[simka] launch %s\n", KID_NAMES[kid]); fflush(stderr);
+        f();
+        hipError_t e = hipStreamSynchronize(ctx->stream);
+        fprintf(stderr, "[simka]   -> %s\n", hipGetErrorString(e)); fflush(stderr);
+        return;
+    }
     if (ctx->profiling) {
         simka_ctx::Ev ev; ev.kid = kid;
         (void)hipEventCreate(&ev.a); (void)hipEventCreate(&ev.b);

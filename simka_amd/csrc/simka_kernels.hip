@@ -147,11 +147,14 @@ k_scan(SimkaScanArgs a, SimkaKeyCfg cfg, ull *b1_count, ull *b1_cursor, uint64_t
                     const uint64_t canon = fwd < rev ? fwd : rev;
                     const uint64_t key = simka_mix(canon, cfg.mask, cfg.xs);
                     const uint32_t b1 = simka_key_l1(key, cfg);
-                    if (simka_owns_l1(b1, cfg)) {
-                        nvalid++;
-                        if (SCATTER) { keys[q] = key; ranks[q >> 1] |= atomicAdd(&hist[b1], 1u) << ((q & 1) * 16); }
-                        else atomicAdd(&hist[b1], 1u);
-                    }
+                    const bool mine = simka_owns_l1(b1, cfg);
+                    if (SCATTER) {
+                        uint32_t rk = 0;
+                        if (mine) rk = atomicAdd(&hist[b1], 1u);
+                        keys[q] = mine ? key : SIMKA_EMPTY_KEY;
+                        ranks[q >> 1] |= rk << ((q & 1) * 16);
+                    } else if (mine) atomicAdd(&hist[b1], 1u);
+                    nvalid += mine ? 1u : 0u;
                 }
             }
         }
@@ -187,6 +190,12 @@ k_scan(SimkaScanArgs a, SimkaKeyCfg cfg, ull *b1_count, ull *b1_cursor, uint64_t
         const uint64_t key = stage[t];
         const uint32_t b = simka_key_l1(key, cfg);
         const ull gb = gbase[b];
+#ifdef SIMKA_DEBUG_BOUNDS
+        if (gb != ~0ull && (b >= B1 || gb + (t - loff[b]) >= a.nb_words * 64)) {
+            printf("k_scan OOB: blk %u t %u total %u b %u gb %llu loff %u key %llx hist %u\n", blockIdx.x, t, total, b, gb, loff[b], (ull)key, hist[b < B1 ? b : 0]);
+            continue;
+        }
+#endif
         if (gb != ~0ull) l1_keys[gb + (t - loff[b])] = key;
     }
 }

@@ -1,0 +1,125 @@
+"""-m gpu: BASELINE.json configs[1] at FULL size (10 samples x 1M x 100 bp, k=21) through size-independent properties --
+the oracle needs minutes there, so parity is checked by invariants the domain offers:
+  * conservation: with -abundance-min 1 every occurrence is counted: N_i = K_occ_i = R*(L-k+1), Q_i >= N_i, D_i = D_all_i
+  * idempotence: a duplicated sample is at distance 0 (a = D, bc = N, S_ij = S_ji = N) and indistinguishable from its twin
+  * shard additivity: the two halves of the partition space (shard 0/2, 1/2) sum to the unsharded accumulators, bit for bit
+    (the reference checks the same by varying its job/partition counts, tests/simple_test.py:125-133)
+  * geometry invariance: another partition count gives identical accumulators
+  * symmetry / ranges of the final matrices
+"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+N, R, L, K = 10, 1_000_000, 100, 21
+
+
+@pytest.fixture(scope="module")
+def device_reads(gpu_required):
+    torch = gpu_required
+    import simka_amd
+    from simka_amd import synth
+    lib = simka_amd.load_library()
+    dev = torch.device("cuda", 0)
+    g = synth.genome_len_for(R, L)
+    gw = (g + 31) // 32
+    pool = torch.empty(synth.NB_GENOMES * gw, dtype=torch.int64, device=dev)
+    assert lib.simka_synth_genomes(None, pool.data_ptr(), synth.NB_GENOMES, gw, synth.POOL_SEED) == 0
+    reads = []
+    for s in range(N - 1):
+        ids, cdf = synth.sample_profile(s)
+        d_ids = torch.from_numpy(ids.astype(np.int32)).to(dev)
+        d_cdf = torch.from_numpy(cdf.view(np.int32)).to(dev)
+        t = torch.zeros((R * L + 31) // 32 + 2, dtype=torch.int64, device=dev)
+        assert lib.simka_synth_reads(None, t.data_ptr(), R, L, pool.data_ptr(), gw, g, d_ids.data_ptr(), d_cdf.data_ptr(), synth.NB_SEL,
+                                     synth.sample_seed(s), synth.ERR_THRESHOLD16) == 0
+        torch.cuda.synchronize()
+        reads.append(t)
+    reads.append(reads[0].clone())          # sample 9 is a copy of sample 0
+    # the device generator equals the numpy one (spot check of the first words of sample 3)
+    ids, cdf = synth.sample_profile(3)
+    pool_cpu, gw_cpu = synth.genome_pool_cpu(g)
+    assert gw_cpu == gw
+    ref = synth.reads_cpu(2000, L, pool_cpu, gw, g, ids, cdf, synth.sample_seed(3))
+    got = reads[3][: len(ref) - 1].cpu().numpy().view(np.uint64)
+    assert np.array_equal(got, ref[: len(ref) - 1])
+    return reads
+
+
+def _run(reads, amin, **kw):
+    import simka_amd
+    ctx = simka_amd.SimkaContext(N, kmer_size=K, abundance_min=amin, simple_dist=True, complex_dist=True,
+                                 max_kmers_per_sample=R * (L - K + 1), **kw)
+    for s in range(N):
+        ctx.count_sample(s, reads[s].data_ptr(), R * L, R, fixed_len=L, on_device=True)
+    if kw.get("shard_count", 1) > 1 and "totals" in kw:
+        pass
+    return ctx
+
+
+def test_conservation_and_duplicate_sample(device_reads):
+    ctx = _run(device_reads, 1)
+    ctx.merge()
+    st = ctx.stats()
+    ctx.close()
+    ps, pr = st.per_sample(), st.pairs()
+    occ = R * (L - K + 1)
+    assert np.all(ps["K_occ"] == occ) and np.all(ps["N"] == occ)          # every occurrence counted exactly once
+    assert np.array_equal(ps["D"], ps["D_all"]) and np.all(ps["Q"] >= ps["N"])
+    assert np.all(ps["D"] > 0.15 * occ) and np.all(ps["D"] < 0.5 * occ)   # 20x coverage + 1 % errors
+    cell = N - 2                                                           # pair (0, 9) in i<j order
+    assert pr["a"][cell] == ps["D"][0] and pr["bc"][cell] == ps["N"][0]
+    assert pr["S_ij"][cell] == ps["N"][0] and pr["S_ji"][cell] == ps["N"][0]
+    assert pr["chord"][cell] == ps["Q"][0] and pr["canb"][cell] == 0
+    m = st.matrices()
+    for name in ("mat_abundance_braycurtis", "mat_presenceAbsence_jaccard", "mat_abundance_chord", "mat_abundance_hellinger"):
+        assert abs(float(m[name][0, 9])) < 1e-6, name
+        assert np.allclose(m[name][0, 1:9], m[name][9, 1:9], atol=0)      # the twin sees everyone else identically
+    for name, mat in m.items():
+        assert np.all(np.isfinite(mat)) and np.all(np.diag(mat) == 0), name
+        if "asym" not in name:
+            assert np.array_equal(mat, mat.T), name
+    assert np.all(m["mat_abundance_braycurtis"] <= 1.0) and np.all(m["mat_presenceAbsence_jaccard"] <= 1.0)
+    # identities between accumulators: a <= min(D), bc <= S_ij, S_ij <= N_i
+    iu = np.triu_indices(N, 1)
+    D, Nn = ps["D"].astype(np.int64), ps["N"].astype(np.int64)
+    assert np.all(pr["a"].astype(np.int64) <= np.minimum(D[iu[0]], D[iu[1]]))
+    assert np.all(pr["bc"] <= pr["S_ij"]) and np.all(pr["bc"] <= pr["S_ji"])
+    assert np.all(pr["S_ij"].astype(np.int64) <= Nn[iu[0]]) and np.all(pr["S_ji"].astype(np.int64) <= Nn[iu[1]])
+
+
+def test_shard_additivity_and_geometry_invariance(device_reads):
+    import simka_amd
+    full = _run(device_reads, 2)
+    full.merge()
+    ref = full.stats()
+    full.close()
+    lay = ref.layout
+    # two shards on the same GPU, totals made global before the merge (complex-dist protocol), heads summed after
+    shards = [_run(device_reads, 2, shard_index=i, shard_count=2) for i in range(2)]
+    tot = sum(c.totals_download().astype(np.uint64) for c in shards)
+    for c in shards:
+        c.totals_upload(tot)
+        c.merge()
+    flats = [c.stats().flat for c in shards]
+    for c in shards:
+        c.close()
+    head = lay["head"]
+    summed = flats[0].copy()
+    summed[:head] = flats[0][:head] + flats[1][:head]
+    st = simka_amd.Stats(N, 3, summed[: lay["derived"]])
+    P = lay["nb_pairs"]
+    klo = lay["acc0"] + 7 * P
+    assert np.array_equal(st.flat[:klo], ref.flat[:klo])                   # every integer accumulator, bit for bit
+    assert np.array_equal(st.flat[klo + P: lay["derived"]], ref.flat[klo + P: lay["derived"]])
+    assert np.max(np.abs(st.flat[klo:klo + P].view(np.int64) - ref.flat[klo:klo + P].view(np.int64))) <= 64   # KL fixed point: rounding of 2 sums
+    for name, m in ref.matrices().items():
+        np.testing.assert_allclose(st.matrices()[name], m, rtol=1e-6, atol=1e-7)
+    # another partition geometry
+    other = _run(device_reads, 2, log2_partitions=13)
+    other.merge()
+    st2 = other.stats()
+    other.close()
+    assert np.array_equal(st2.flat[:klo], ref.flat[:klo])
+    assert np.array_equal(st2.flat[klo + P: lay["derived"]], ref.flat[klo + P: lay["derived"]])

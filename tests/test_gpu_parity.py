@@ -277,3 +277,42 @@ def test_cli_fastq_gz_inputs(gpu_required, golden_dir, tmp_path):
                 assert f.read() == g.read(), os.path.basename(gzf)
             n += 1
     assert n == 20
+
+
+@pytest.mark.parametrize("shards", [2, 3])
+def test_sharded_contexts_sum_to_unsharded(gpu_required, oracle_mod, shards):
+    """Partition shards (power-of-two and not) on one GPU: per-sample totals and every pair accumulator add up to the
+    single-context result, which equals the oracle."""
+    import simka_amd
+    from simka_amd import synth
+    n, R, L, k = 4, 5000, 100, 21
+    packed = _synthetic(n, R, L, seed_shift=50)
+    offs = np.arange(R + 1, dtype=np.uint64) * L
+    inputs = [(np.concatenate([pk, np.zeros(2, dtype=np.uint64)]), offs, R * L, R) for pk in packed]
+    _, ref = _run_gpu(inputs, k, 2)
+    ctxs = []
+    for i in range(shards):
+        c = simka_amd.SimkaContext(n, kmer_size=k, abundance_min=2, simple_dist=True, complex_dist=True, shard_index=i, shard_count=shards)
+        for s, (pk, off, nb, nin) in enumerate(inputs):
+            c.count_sample(s, pk, nb, len(off) - 1, offsets=off, nb_input_reads=nin)
+        ctxs.append(c)
+    tot = sum(c.totals_download().astype(np.uint64) for c in ctxs)
+    flats = []
+    for c in ctxs:
+        c.totals_upload(tot)
+        c.merge()
+        flats.append(c.stats().flat)
+        c.close()
+    lay = ref.layout
+    head = sum(f[: lay["head"]].astype(np.uint64) for f in flats)
+    P = lay["nb_pairs"]
+    klo = lay["acc0"] + 7 * P
+    assert np.array_equal(head[:klo], ref.flat[:klo])
+    assert np.max(np.abs(head[klo:klo + P].view(np.int64) - ref.flat[klo:klo + P].view(np.int64))) <= 8 * shards
+    assert np.array_equal(flats[0][lay["tot0"]: lay["derived"]], ref.flat[lay["tot0"]: lay["derived"]])     # global totals
+    orc = oracle_mod.Oracle()
+    for s, pk in enumerate(packed):
+        orc.add_sample_ascii("S%d" % s, synth.unpack_ascii(pk, R * L), offs)
+    orc.run(k, 2, simple=True, complex_=True)
+    iu = np.triu_indices(n, 1)
+    assert np.array_equal(ref.pairs()["a"], orc.acc("a")[iu]) and np.array_equal(ref.pairs()["whit"], orc.acc("whit")[iu])
