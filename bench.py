@@ -181,13 +181,20 @@ def main():
     ms_per_step = dt / args.steps * 1e3
     value = K_dist / (dt / args.steps)
 
-    # ---- roofline (DESIGN.md "Algorithmic bytes"): SURVEY 8(d) terms attributed to the kernel that moves them
+    # ---- roofline (DESIGN.md section 4 "Algorithmic bytes"): every term of SURVEY 8(d)'s
+    # B_alg = R*L/4 + 16*K_occ + 12*K_dist + 12*K_solid is attributed to exactly one kernel -- the one that moves it:
+    #   k_scan<scatter>: reads the packed bases, WRITES each 8-byte k-mer once      -> R*L/4 + 8*K_occ
+    #   k_split        : READS each 8-byte k-mer once for partitioning             -> 8*K_occ   (its re-write and k_count's
+    #                    re-read, another 16 B/occurrence, are overhead of the two-level design and count for nothing)
+    #   k_count_fast   : emits the counted (u64,u32) records                       -> 12*K_dist
+    #   k_regroup      : reads the solid records once in the merge                 -> 12*K_solid
     share = 1.0 / world                    # each rank owns 1/world of the key space
     alg_bytes_per_step = {
-        "k_scan<hist>": n * nb_bases / 4.0,
+        "k_scan<hist>": 0.0,
         "k_scan<scatter>": n * nb_bases / 4.0 + 8.0 * K_occ * share,
-        "k_split": 0.0,
-        "k_count": 8.0 * K_occ * share + 12.0 * K_dist * share,
+        "k_split": 8.0 * K_occ * share,
+        "k_count_fast": 12.0 * K_dist * share,
+        "k_count": 0.0,
         "k_regroup": 12.0 * K_solid * share,
         "k_group": 0.0, "k_pairs": 0.0, "k_layout": 0.0, "k_part_totals": 0.0, "k_reduce_slabs": 0.0,
     }
@@ -198,10 +205,27 @@ def main():
     dom_bytes_per_launch = alg_bytes_per_step.get(dom, 0.0) * args.steps / max(dom_launches, 1)
     dom_avg_ms = dom_ms / max(dom_launches, 1)
     achieved = dom_bytes_per_launch / (dom_avg_ms * 1e-3) / 1e9 if dom_avg_ms > 0 else 0.0
-    b_alg = (n * nb_bases / 4.0 + 16.0 * K_occ + 12.0 * K_dist + 12.0 * K_solid) * share
+    b_alg = n * nb_bases / 4.0 + (16.0 * K_occ + 12.0 * K_dist + 12.0 * K_solid) * share
     path_gbs = b_alg * args.steps / (total_kernel_ms * 1e-3) / 1e9 if total_kernel_ms > 0 else 0.0
+    # HBM bytes per launch of the dominant kernel from the PMC passes committed under profiles/ (scripts/pmc_traffic.sh:
+    # FETCH_SIZE and WRITE_SIZE in separate rocprofv3 runs, FETCH_SIZE x2 on gfx950); only when it is the same workload
+    traffic = None
+    traffic_src = None
+    try:
+        tf = os.path.join(ROOT, "profiles", "r01_%s_hbm_traffic.json" % args.workload)
+        if world == 1 and not args.reads and not args.samples and os.path.exists(tf):
+            tk = json.load(open(tf))["kernels"]
+            alias = {"k_scan<scatter>": ["k_scan<true>"], "k_scan<hist>": ["k_scan<false>"],
+                     "k_count_fast": ["k_count_fast<2048u>", "k_count_fast<4096u>"]}
+            for cand in [dom] + alias.get(dom, []):
+                if cand in tk:
+                    traffic = tk[cand]["traffic_bytes_per_launch"]
+                    traffic_src = os.path.relpath(tf, ROOT)
+                    break
+    except Exception:
+        traffic = None
     roofline = {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                 "avg_launch_ms": dom_avg_ms, "launches": dom_launches, "alg_bytes_per_launch": dom_bytes_per_launch,
                 "path_achieved": path_gbs, "path_frac": path_gbs / HBM_PEAK_GBS, "path_alg_bytes_per_step": b_alg,
                 "kernel_ms_per_step": {kk: v / args.steps for kk, v in kern_ms.items()}}
