@@ -201,8 +201,10 @@ SIMKA_EXPORT const char *simka_last_error(const simka_ctx *ctx) { return ctx ? c
 
 static int set_lds_attr(simka_ctx *ctx) {
     const int big = 160 * 1024;
-    HIPCHK(hipFuncSetAttribute((const void *)k_scan<true>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
-    HIPCHK(hipFuncSetAttribute((const void *)k_scan<false>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
+    HIPCHK(hipFuncSetAttribute((const void *)k_scan<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
+    HIPCHK(hipFuncSetAttribute((const void *)k_scan<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
+    HIPCHK(hipFuncSetAttribute((const void *)k_scan<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
+    HIPCHK(hipFuncSetAttribute((const void *)k_scan<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
     HIPCHK(hipFuncSetAttribute((const void *)k_layout, hipFuncAttributeMaxDynamicSharedMemorySize, big));
     HIPCHK(hipFuncSetAttribute((const void *)k_split, hipFuncAttributeMaxDynamicSharedMemorySize, big));
     HIPCHK(hipFuncSetAttribute((const void *)k_count, hipFuncAttributeMaxDynamicSharedMemorySize, big));
@@ -413,9 +415,9 @@ static int run_count_kernels(simka_ctx *ctx, uint32_t sample, const SimkaScanArg
     ull *kocc = (ull *)ctx->d_stats + stats_off_tot(N, ctx->cfg.dist_flags, SIMKA_TOT_KOCC) + sample;
     const uint64_t tile = (uint64_t)K1_BLOCK * K1_SEG;
     const uint32_t grid1 = (uint32_t)((a.nb_bases + tile - 1) / tile);
-    const size_t lds_hist = SIMKA_LDS_HEAD + (size_t)B1 * 16 + K1_BLOCK * 4;
+    const size_t lds_hist = SIMKA_LDS_HEAD + (size_t)B1 * 16 + 8 + K1_BLOCK * 4;
     const size_t lds_scat = lds_hist + (size_t)tile * 8;
-    const size_t lds_lay = SIMKA_LDS_HEAD + (size_t)B1 * 8;
+    const size_t lds_lay = SIMKA_LDS_HEAD + (size_t)B1 * 12 + 128;
     uint32_t *flag = ctx->d_l1_ovf + sample;       // bit 0: level-1 bucket overflow, bit 1: spill buffer overflow
     const uint32_t *skip = flag;
     auto layout = [&](uint32_t mode, ull capb) {
@@ -439,8 +441,12 @@ static int run_count_kernels(simka_ctx *ctx, uint32_t sample, const SimkaScanArg
         max_chunks = (capb * B1) / K2_CHUNK + B1 + 1;
         layout(1, capb);
         launch_timed(ctx, KID_SCAN_SCATTER, [&] {
-            hipLaunchKernelGGL((k_scan<true>), dim3(grid1), dim3(K1_BLOCK), lds_scat, ctx->stream, a, key, ctx->d_b1_count,
-                               ctx->d_b1_cursor, ctx->d_l1, kocc, ctx->d_b1_end, flag);
+            if (a.fixed_len)
+                hipLaunchKernelGGL((k_scan<true, true>), dim3(grid1), dim3(K1_BLOCK), lds_scat, ctx->stream, a, key, ctx->d_b1_count,
+                                   ctx->d_b1_cursor, ctx->d_l1, kocc, ctx->d_b1_end, flag);
+            else
+                hipLaunchKernelGGL((k_scan<true, false>), dim3(grid1), dim3(K1_BLOCK), lds_scat, ctx->stream, a, key, ctx->d_b1_count,
+                                   ctx->d_b1_cursor, ctx->d_l1, kocc, ctx->d_b1_end, flag);
         });
         layout(2, capb);
         simka_ctx::Pending p; p.sample = sample; p.a = a;
@@ -450,13 +456,21 @@ static int run_count_kernels(simka_ctx *ctx, uint32_t sample, const SimkaScanArg
         max_chunks = a.nb_bases / K2_CHUNK + B1 + 1;
         HIPCHK(hipMemsetAsync(ctx->d_b1_count, 0, (B1 + 1) * 8, ctx->stream));
         launch_timed(ctx, KID_SCAN_HIST, [&] {
-            hipLaunchKernelGGL((k_scan<false>), dim3(grid1), dim3(K1_BLOCK), lds_hist, ctx->stream, a, key, ctx->d_b1_count,
-                               ctx->d_b1_cursor, ctx->d_l1, kocc, (const ull *)nullptr, (uint32_t *)nullptr);
+            if (a.fixed_len)
+                hipLaunchKernelGGL((k_scan<false, true>), dim3(grid1), dim3(K1_BLOCK), lds_hist, ctx->stream, a, key, ctx->d_b1_count,
+                                   ctx->d_b1_cursor, ctx->d_l1, kocc, (const ull *)nullptr, (uint32_t *)nullptr);
+            else
+                hipLaunchKernelGGL((k_scan<false, false>), dim3(grid1), dim3(K1_BLOCK), lds_hist, ctx->stream, a, key, ctx->d_b1_count,
+                                   ctx->d_b1_cursor, ctx->d_l1, kocc, (const ull *)nullptr, (uint32_t *)nullptr);
         });
         layout(0, 0);
         launch_timed(ctx, KID_SCAN_SCATTER, [&] {
-            hipLaunchKernelGGL((k_scan<true>), dim3(grid1), dim3(K1_BLOCK), lds_scat, ctx->stream, a, key, ctx->d_b1_count,
-                               ctx->d_b1_cursor, ctx->d_l1, kocc, (const ull *)nullptr, (uint32_t *)nullptr);
+            if (a.fixed_len)
+                hipLaunchKernelGGL((k_scan<true, true>), dim3(grid1), dim3(K1_BLOCK), lds_scat, ctx->stream, a, key, ctx->d_b1_count,
+                                   ctx->d_b1_cursor, ctx->d_l1, kocc, (const ull *)nullptr, (uint32_t *)nullptr);
+            else
+                hipLaunchKernelGGL((k_scan<true, false>), dim3(grid1), dim3(K1_BLOCK), lds_scat, ctx->stream, a, key, ctx->d_b1_count,
+                                   ctx->d_b1_cursor, ctx->d_l1, kocc, (const ull *)nullptr, (uint32_t *)nullptr);
         });
     }
     (void)max_chunks;

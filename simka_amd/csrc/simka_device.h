@@ -36,12 +36,13 @@ struct SimkaKeyCfg {
 
 // Bijection on W-bit integers: every step (xor-shift-right, odd multiply mod 2^W) is invertible.
 // The closing multiply makes the top (partition) bits depend on every input bit.
+// multiply (bit i <- bits <= i), fold the high half down, multiply again: every output bit -- in particular the top
+// (partition) bits -- depends on every input bit.  Two 64-bit multiplies: the scan kernel is instruction-bound.
 SIMKA_HD uint64_t simka_mix(uint64_t x, uint64_t mask, uint32_t xs) {
     x = (x * SIMKA_MIX_M1) & mask;
     x ^= x >> xs;
     x = (x * SIMKA_MIX_M2) & mask;
     x ^= x >> xs;
-    x = (x * SIMKA_MIX_M3) & mask;
     return x;
 }
 

@@ -67,29 +67,26 @@ __device__ __forceinline__ uint32_t window_base(uint64_t A, uint64_t B, uint32_t
     return (uint32_t)(w >> ((i & 31u) * 2u)) & 3u;
 }
 
-template <bool SCATTER>
+template <bool SCATTER, bool FIXED>
 __global__ void __launch_bounds__(K1_BLOCK)
 k_scan(SimkaScanArgs a, SimkaKeyCfg cfg, ull *b1_count, ull *b1_cursor, uint64_t *l1_keys, ull *kocc, const ull *b1_limit,
        uint32_t *ovf_flag) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const uint32_t B1 = 1u << cfg.l1;
-    // all LDS lives in the dynamic region (16-B aligned base, guide G17); head = scalars
-    uint32_t &s_nvalid = *(uint32_t *)smem;
-    uint32_t *hist = (uint32_t *)(smem + SIMKA_LDS_HEAD);   // [B1]
-    uint32_t *loff = hist + B1;                        // [B1]
+    // all LDS lives in the dynamic region (16-B aligned base, guide G17)
+    uint32_t *hist = (uint32_t *)(smem + SIMKA_LDS_HEAD);   // [B1+1]: slot B1 swallows the atomics of invalid positions
+    uint32_t *loff = hist + B1 + 2;                    // [B1]
     uint32_t *tmp = loff + B1;                         // [K1_BLOCK]
     ull *gbase = (ull *)(tmp + K1_BLOCK);              // [B1]
     uint64_t *stage = (uint64_t *)(gbase + B1);        // [K1_BLOCK*K1_SEG]   (SCATTER only)
 
     const uint32_t tid = threadIdx.x;
-    for (uint32_t i = tid; i < B1; i += K1_BLOCK) hist[i] = 0;
-    if (tid == 0) s_nvalid = 0;
+    for (uint32_t i = tid; i < B1 + 2; i += K1_BLOCK) hist[i] = 0;
     __syncthreads();
 
     const uint64_t w0 = ((uint64_t)blockIdx.x * K1_BLOCK + tid) * K1_SEG;
     uint64_t keys[K1_SEG];
     uint32_t ranks[K1_SEG / 2];      // rank inside the tile's bucket run (< 8192): two u16 per register
-    uint32_t nvalid = 0;
 #pragma unroll
     for (int q = 0; q < K1_SEG; q++) keys[q] = SIMKA_EMPTY_KEY;
 #pragma unroll
@@ -107,7 +104,7 @@ k_scan(SimkaScanArgs a, SimkaKeyCfg cfg, ull *b1_count, ull *b1_cursor, uint64_t
 
         // the read (fragment) that contains base w0, and where the next one starts
         uint64_t rd, next;
-        if (a.fixed_len) {
+        if (FIXED) {
             rd = w0 / a.fixed_len;
             next = (rd + 1) * (uint64_t)a.fixed_len;
         } else {
@@ -119,45 +116,41 @@ k_scan(SimkaScanArgs a, SimkaKeyCfg cfg, ull *b1_count, ull *b1_cursor, uint64_t
             rd = lo;
             next = a.offsets[rd + 1];
         }
+        // positions are handled relative to w0 in 32 bits: nrel = first position of the next read, erel = end of data
+        const uint32_t SPAN = K1_SEG + 32u;                                  // > SEG + k - 1
+        uint32_t nrel = (next - w0 < (uint64_t)SPAN) ? (uint32_t)(next - w0) : SPAN;
+        const uint32_t erel = (a.nb_bases - w0 < (uint64_t)SPAN) ? (uint32_t)(a.nb_bases - w0) : SPAN;
 
         const uint32_t k = cfg.k;
         const uint32_t rshift = 2u * (k - 1u);
         uint64_t fwd = 0, rev = 0;
         uint32_t cnt = 0;   // bases rolled since the last read start (or since w0)
-        // warm-up: the k-1 bases before the first k-mer end
-        for (uint32_t i = 0; i + 1 < k; i++) {
-            const uint64_t x = w0 + i;
-            if (x >= a.nb_bases) break;
-            while (x >= next) { rd++; next = a.fixed_len ? next + a.fixed_len : a.offsets[rd + 1]; cnt = 0; }
-            const uint32_t c = window_base(A, B, i);
-            fwd = ((fwd << 2) | c) & cfg.mask;
-            rev = (rev >> 2) | ((uint64_t)(c ^ 2u) << rshift);
-            cnt++;
+        // one step per base i (relative position): straight-line, validity by selects
+#define K1_STEP(i)                                                                                          \
+        {                                                                                                   \
+            if (FIXED) { const bool nb_ = (i) >= nrel; nrel = nb_ ? nrel + a.fixed_len : nrel; cnt = nb_ ? 0u : cnt; } \
+            else while ((i) >= nrel && rd + 1 < a.nb_reads) { rd++; const uint64_t nx_ = a.offsets[rd + 1] - w0; nrel = nx_ < (uint64_t)SPAN ? (uint32_t)nx_ : SPAN; cnt = 0; if (nx_ >= (uint64_t)SPAN) break; } \
+            const uint32_t c_ = window_base(A, B, (i));                                                     \
+            fwd = ((fwd << 2) | c_) & cfg.mask;                                                             \
+            rev = (rev >> 2) | ((uint64_t)(c_ ^ 2u) << rshift);                                             \
+            cnt++;                                                                                          \
         }
+        for (uint32_t i = 0; i + 1 < k; i++) K1_STEP(i)
 #pragma unroll
         for (int q = 0; q < K1_SEG; q++) {
-            const uint64_t x = w0 + (k - 1u) + (uint32_t)q;     // last base of the k-mer starting at w0+q
-            if (x < a.nb_bases) {
-                while (x >= next) { rd++; next = a.fixed_len ? next + a.fixed_len : a.offsets[rd + 1]; cnt = 0; }
-                const uint32_t c = window_base(A, B, (k - 1u) + (uint32_t)q);
-                fwd = ((fwd << 2) | c) & cfg.mask;
-                rev = (rev >> 2) | ((uint64_t)(c ^ 2u) << rshift);
-                cnt++;
-                if (cnt >= k) {
-                    const uint64_t canon = fwd < rev ? fwd : rev;
-                    const uint64_t key = simka_mix(canon, cfg.mask, cfg.xs);
-                    const uint32_t b1 = simka_key_l1(key, cfg);
-                    const bool mine = simka_owns_l1(b1, cfg);
-                    if (SCATTER) {
-                        uint32_t rk = 0;
-                        if (mine) rk = atomicAdd(&hist[b1], 1u);
-                        keys[q] = mine ? key : SIMKA_EMPTY_KEY;
-                        ranks[q >> 1] |= rk << ((q & 1) * 16);
-                    } else if (mine) atomicAdd(&hist[b1], 1u);
-                    nvalid += mine ? 1u : 0u;
-                }
+            const uint32_t i = (k - 1u) + (uint32_t)q;                      // last base of the k-mer starting at w0+q
+            K1_STEP(i)
+            const uint64_t canon = fwd < rev ? fwd : rev;
+            const uint64_t key = simka_mix(canon, cfg.mask, cfg.xs);
+            const uint32_t b1 = simka_key_l1(key, cfg);
+            const bool ok = (cnt >= k) & (i < erel) & simka_owns_l1(b1, cfg);
+            const uint32_t rk = atomicAdd(&hist[ok ? b1 : B1], 1u);         // invalid positions hit the trash slot: no branch
+            if (SCATTER) {
+                keys[q] = ok ? key : SIMKA_EMPTY_KEY;
+                ranks[q >> 1] |= (ok ? rk : 0u) << ((q & 1) * 16);
             }
         }
+#undef K1_STEP
     }
 
     if (!SCATTER) {
@@ -217,21 +210,38 @@ k_layout(const ull *b1_count, ull *b1_start, ull *b1_end, ull *b1_cursor, uint32
         if (threadIdx.x == 0) *sample_base = *arena_cursor;
         return;
     }
-    for (uint32_t b = threadIdx.x; b < B1; b += blockDim.x) cnt[b] = (mode == 0) ? b1_count[b] : (b1_cursor[b] - b1_start[b]);
+    // exclusive scans of the bucket sizes (mode 0: starts) and of the chunk counts, 256 threads
+    uint32_t *csz = (uint32_t *)(cnt + B1);          // [B1] chunks per bucket -> first chunk
+    uint32_t *tmp = csz + B1;                        // scan scratch
+    ull *wsum = (ull *)(tmp + 8);                    // [4] per-wave sums of the 64-bit scan
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    const uint32_t ipt = (B1 + 255u) / 256u;
+    const uint32_t b0 = tid * ipt, e0 = (b0 + ipt < B1) ? b0 + ipt : B1;
+    ull mine = 0;
+    for (uint32_t b = b0; b < e0; b++) {
+        const ull c = (mode == 0) ? b1_count[b] : (b1_cursor[b] - b1_start[b]);
+        cnt[b] = c; csz[b] = (uint32_t)((c + K2_CHUNK - 1) / K2_CHUNK);
+        mine += c;
+    }
+    ull v = mine;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const ull t = __shfl_up(v, o, 64); if (lane >= (uint32_t)o) v += t; }
+    if (lane == 63u) wsum[wave] = v;
     __syncthreads();
-    if (threadIdx.x == 0) {
-        ull run = 0;
-        uint32_t crun = 0;
-        for (uint32_t b = 0; b < B1; b++) {
-            const ull c = cnt[b];
-            if (mode == 0) { b1_start[b] = run; b1_cursor[b] = run; b1_end[b] = run + c; }
-            else b1_end[b] = b1_start[b] + c;
-            chunk_first[b] = crun;
-            run += c;
-            crun += (uint32_t)((c + K2_CHUNK - 1) / K2_CHUNK);
-        }
-        chunk_first[B1] = crun;
-        *kocc = run;                                   // k-mer occurrences of this shard = sum of its bucket sizes
+    ull wpre = 0, total = 0;
+    for (uint32_t w = 0; w < 4; w++) { const ull t = wsum[w]; if (w < wave) wpre += t; total += t; }
+    ull run = wpre + v - mine;
+    for (uint32_t b = b0; b < e0; b++) {
+        const ull c = cnt[b];
+        if (mode == 0) { b1_start[b] = run; b1_cursor[b] = run; b1_end[b] = run + c; }
+        else b1_end[b] = b1_start[b] + c;
+        run += c;
+    }
+    const uint32_t nchunks = block_excl_scan<256>(csz, B1, tmp);
+    for (uint32_t b = tid; b < B1; b += 256) chunk_first[b] = csz[b];
+    if (tid == 0) {
+        chunk_first[B1] = nchunks;
+        *kocc = total;                                 // k-mer occurrences of this shard = sum of its bucket sizes
         if (mode == 0) *sample_base = *arena_cursor;   // where this sample's solid records start in the arena
     }
 }
