@@ -579,6 +579,9 @@ SIMKA_EXPORT int simka_count_sample(simka_ctx *ctx, uint32_t sample, const simka
     a.nb_bases = r->nb_bases; a.nb_words = nb_words; a.nb_reads = r->nb_reads; a.fixed_len = r->fixed_len;
     if (r->on_device) { a.packed = r->packed; a.offsets = r->offsets; }
     else {
+        // the staging buffers still hold the previous host-provided sample: settle it (overflow flags, exact redo)
+        // before they are overwritten.  Until this point its kernels ran concurrently with the caller's file parsing.
+        rc = resolve_pending(ctx); if (rc) return rc;
         rc = ensure_cap(ctx, &ctx->d_reads, &ctx->reads_cap, nb_words + 2); if (rc) return rc;
         HIPCHK(hipMemcpyAsync(ctx->d_reads, r->packed, nb_words * 8, hipMemcpyHostToDevice, ctx->stream));
         a.packed = ctx->d_reads; a.offsets = nullptr;
@@ -601,7 +604,6 @@ SIMKA_EXPORT int simka_count_sample(simka_ctx *ctx, uint32_t sample, const simka
         HIPCHK(hipStreamSynchronize(ctx->stream));
         ctx->small_table = (ko > 0 && (double)da / (double)ko < 0.40) ? 1 : 0;
     }
-    if (!r->on_device) return resolve_pending(ctx);     // staged host reads are overwritten by the next sample: settle now
     return SIMKA_OK;
 }
 

@@ -316,3 +316,31 @@ def test_sharded_contexts_sum_to_unsharded(gpu_required, oracle_mod, shards):
     orc.run(k, 2, simple=True, complex_=True)
     iu = np.triu_indices(n, 1)
     assert np.array_equal(ref.pairs()["a"], orc.acc("a")[iu]) and np.array_equal(ref.pairs()["whit"], orc.acc("whit")[iu])
+
+
+@pytest.mark.parametrize("n,simple,complex_", [(140, True, True), (110, True, False), (135, False, False)])
+def test_many_samples_tiled_pair_accumulators(gpu_required, oracle_mod, n, simple, complex_):
+    """More samples than one LDS tile of pair cells: k_pairs<false> walks (I,J) sample tiles.  Samples share genomes, so
+    groups span many samples and tiles."""
+    import simka_amd
+    from simka_amd import synth
+    R, L, k = 400, 100, 21
+    g = synth.genome_len_for(R * 4, L)
+    pool, gw = synth.genome_pool_cpu(g)
+    offs = np.arange(R + 1, dtype=np.uint64) * L
+    packed = []
+    for s in range(n):
+        ids, cdf = synth.sample_profile(s % 7)                    # 7 community profiles, different reads
+        packed.append(synth.reads_cpu(R, L, pool, gw, g, ids, cdf, synth.sample_seed(s)))
+    ctx = simka_amd.SimkaContext(n, kmer_size=k, abundance_min=1, simple_dist=simple, complex_dist=complex_)
+    for s, pk in enumerate(packed):
+        ctx.count_sample(s, np.concatenate([pk, np.zeros(2, dtype=np.uint64)]), R * L, R, fixed_len=L)
+    totals = [ctx.sample_totals(i) for i in range(n)]
+    ctx.merge()
+    st = ctx.stats()
+    ctx.close()
+    orc = oracle_mod.Oracle()
+    for s, pk in enumerate(packed):
+        orc.add_sample_ascii("S%d" % s, synth.unpack_ascii(pk, R * L), offs)
+    orc.run(k, 1, simple=simple, complex_=complex_, nparts=8, threads=8)
+    _check_vs_oracle(totals, st, orc, simple=simple, complex_=complex_)
