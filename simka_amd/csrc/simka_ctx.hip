@@ -415,7 +415,7 @@ static int run_count_kernels(simka_ctx *ctx, uint32_t sample, const SimkaScanArg
     ull *kocc = (ull *)ctx->d_stats + stats_off_tot(N, ctx->cfg.dist_flags, SIMKA_TOT_KOCC) + sample;
     const uint64_t tile = (uint64_t)K1_BLOCK * K1_SEG;
     const uint32_t grid1 = (uint32_t)((a.nb_bases + tile - 1) / tile);
-    const size_t lds_hist = SIMKA_LDS_HEAD + (size_t)B1 * 16 + 8 + K1_BLOCK * 4;
+    const size_t lds_hist = SIMKA_LDS_HEAD + (size_t)B1 * 16 + 128 + K1_BLOCK * 4;
     const size_t lds_scat = lds_hist + (size_t)tile * 8;
     const size_t lds_lay = SIMKA_LDS_HEAD + (size_t)B1 * 12 + 128;
     uint32_t *flag = ctx->d_l1_ovf + sample;       // bit 0: level-1 bucket overflow, bit 1: spill buffer overflow

@@ -7,7 +7,7 @@
 #define SIMKA_LDS_HEAD 512
 
 // K1  k_scan
-#define K1_BLOCK 512          // 8 waves
+#define K1_BLOCK 1024         // 16 waves: 16384-position tiles -> long bucket runs (run length is what the scatter is bound by)
 #define K1_SEG 16             // k-mer start positions per thread (window = SEG + k - 1 <= 64 bases holds for k <= 33)
 // K2  k_split / k_count
 #define K2_BLOCK 512          // k_split

@@ -74,14 +74,14 @@ k_scan(SimkaScanArgs a, SimkaKeyCfg cfg, ull *b1_count, ull *b1_cursor, uint64_t
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const uint32_t B1 = 1u << cfg.l1;
     // all LDS lives in the dynamic region (16-B aligned base, guide G17)
-    uint32_t *hist = (uint32_t *)(smem + SIMKA_LDS_HEAD);   // [B1+1]: slot B1 swallows the atomics of invalid positions
-    uint32_t *loff = hist + B1 + 2;                    // [B1]
+    uint32_t *hist = (uint32_t *)(smem + SIMKA_LDS_HEAD);   // [B1+32]: slots B1.. swallow the atomics of invalid positions
+    uint32_t *loff = hist + B1 + 32;                   // [B1]
     uint32_t *tmp = loff + B1;                         // [K1_BLOCK]
     ull *gbase = (ull *)(tmp + K1_BLOCK);              // [B1]
     uint64_t *stage = (uint64_t *)(gbase + B1);        // [K1_BLOCK*K1_SEG]   (SCATTER only)
 
     const uint32_t tid = threadIdx.x;
-    for (uint32_t i = tid; i < B1 + 2; i += K1_BLOCK) hist[i] = 0;
+    for (uint32_t i = tid; i < B1 + 32; i += K1_BLOCK) hist[i] = 0;
     __syncthreads();
 
     const uint64_t w0 = ((uint64_t)blockIdx.x * K1_BLOCK + tid) * K1_SEG;
@@ -121,36 +121,36 @@ k_scan(SimkaScanArgs a, SimkaKeyCfg cfg, ull *b1_count, ull *b1_cursor, uint64_t
         uint32_t nrel = (next - w0 < (uint64_t)SPAN) ? (uint32_t)(next - w0) : SPAN;
         const uint32_t erel = (a.nb_bases - w0 < (uint64_t)SPAN) ? (uint32_t)(a.nb_bases - w0) : SPAN;
 
+        // No rolling update: the forward k-mer starting at window base q is a static funnel shift of (A,B); its reverse
+        // complement is a static funnel shift of the reverse-complemented window (R0,R1), built ONCE per thread.
+        //   R = revcomp(window bases 0 .. Wn-1), Wn = SEG + k - 1: base p of R = complement(window base Wn-1-p), so the
+        //   reverse complement of the k-mer at q starts at base SEG-1-q of R -- independent of k.
         const uint32_t k = cfg.k;
-        const uint32_t rshift = 2u * (k - 1u);
-        uint64_t fwd = 0, rev = 0;
-        uint32_t cnt = 0;   // bases rolled since the last read start (or since w0)
-        // one step per base i (relative position): straight-line, validity by selects
-#define K1_STEP(i)                                                                                          \
-        {                                                                                                   \
-            if (FIXED) { const bool nb_ = (i) >= nrel; nrel = nb_ ? nrel + a.fixed_len : nrel; cnt = nb_ ? 0u : cnt; } \
-            else while ((i) >= nrel && rd + 1 < a.nb_reads) { rd++; const uint64_t nx_ = a.offsets[rd + 1] - w0; nrel = nx_ < (uint64_t)SPAN ? (uint32_t)nx_ : SPAN; cnt = 0; if (nx_ >= (uint64_t)SPAN) break; } \
-            const uint32_t c_ = window_base(A, B, (i));                                                     \
-            fwd = ((fwd << 2) | c_) & cfg.mask;                                                             \
-            rev = (rev >> 2) | ((uint64_t)(c_ ^ 2u) << rshift);                                             \
-            cnt++;                                                                                          \
-        }
-        for (uint32_t i = 0; i + 1 < k; i++) K1_STEP(i)
+        const uint64_t M5 = 0x5555555555555555ull, MA = 0xAAAAAAAAAAAAAAAAull;
+        uint64_t ra = __brevll(A), rb = __brevll(B);
+        ra = (((ra >> 1) & M5) | ((ra & M5) << 1)) ^ MA;                     // bases 31..0 complemented (code ^ 2)
+        rb = (((rb >> 1) & M5) | ((rb & M5) << 1)) ^ MA;                     // bases 63..32
+        const uint32_t rs = 2u * (64u - (K1_SEG + k - 1u));                  // 36 .. 96 bits: drop the bases beyond Wn
+        const uint64_t R0 = (rs >= 64u) ? (ra >> (rs - 64u)) : ((rb >> rs) | (ra << (64u - rs)));
+        const uint64_t R1 = (rs >= 64u) ? 0ull : (ra >> rs);
 #pragma unroll
         for (int q = 0; q < K1_SEG; q++) {
-            const uint32_t i = (k - 1u) + (uint32_t)q;                      // last base of the k-mer starting at w0+q
-            K1_STEP(i)
+            if (FIXED) { const bool nb_ = (uint32_t)q >= nrel; nrel = nb_ ? nrel + a.fixed_len : nrel; }
+            else while ((uint32_t)q >= nrel && rd + 1 < a.nb_reads) { rd++; const uint64_t nx_ = a.offsets[rd + 1] - w0; nrel = nx_ < (uint64_t)SPAN ? (uint32_t)nx_ : SPAN; if (nx_ >= (uint64_t)SPAN) break; }
+            const uint32_t s1 = 2u * (uint32_t)q, s2 = 2u * (uint32_t)(K1_SEG - 1 - q);     // compile-time after unrolling
+            const uint64_t fwd = (s1 ? ((A >> s1) | (B << (64u - s1))) : A) & cfg.mask;
+            const uint64_t rev = (s2 ? ((R0 >> s2) | (R1 << (64u - s2))) : R0) & cfg.mask;
             const uint64_t canon = fwd < rev ? fwd : rev;
             const uint64_t key = simka_mix(canon, cfg.mask, cfg.xs);
             const uint32_t b1 = simka_key_l1(key, cfg);
-            const bool ok = (cnt >= k) & (i < erel) & simka_owns_l1(b1, cfg);
-            const uint32_t rk = atomicAdd(&hist[ok ? b1 : B1], 1u);         // invalid positions hit the trash slot: no branch
+            // the k-mer [q, q+k) must end inside its read (and inside the data)
+            const bool ok = ((uint32_t)q + k <= nrel) & ((uint32_t)q < erel) & simka_owns_l1(b1, cfg);
+            const uint32_t rk = atomicAdd(&hist[ok ? b1 : B1 + (tid & 31u)], 1u);   // invalid positions hit a trash slot: no branch
             if (SCATTER) {
                 keys[q] = ok ? key : SIMKA_EMPTY_KEY;
                 ranks[q >> 1] |= (ok ? rk : 0u) << ((q & 1) * 16);
             }
         }
-#undef K1_STEP
     }
 
     if (!SCATTER) {
@@ -948,7 +948,7 @@ k_pairs(const SimkaSpan *spans, const ull *cursors, const ull *entries, const ui
     ull *slab = slabs + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * pc.nacc * CP;
     // every LDS cell is a u32 fed by NON-returning atomics: a cell receives at most one add per group, so
     // `bound` (sum over spans of #groups x largest count) < 2^32 guarantees no wrap; flush before it could.
-    ull bound = 0;
+    ull bound = 0, bound_q = 0;      // bound_q: same for the chord products (#groups x maxcount^2)
     __syncthreads();
 
     const ull nspans = cursors[2];
@@ -956,8 +956,12 @@ k_pairs(const SimkaSpan *spans, const ull *cursors, const ull *entries, const ui
         const SimkaSpan span = spans[sp];
         if (span.ngrp == 0) continue;     // unused slot of a k_group span slab
         const ull add = (ull)span.ngrp * (ull)span.maxc;
-        if (bound + add >= 0xffffffffull) { pairs_flush<K4_BLOCK>(lacc, lacc64, slab, pc); bound = 0; }
+        const ull addq = (ull)span.ngrp * (ull)span.maxc * (ull)span.maxc;
+        // chord: non-returning adds as long as the span's products cannot wrap a cell; else the carry path (returning atomic)
+        const bool chord_fast = span.maxc < 46341u && addq < 0xffffffffull;
+        if (bound + add >= 0xffffffffull || (chord_fast && bound_q + addq >= 0xffffffffull)) { pairs_flush<K4_BLOCK>(lacc, lacc64, slab, pc); bound = 0; bound_q = 0; }
         bound += add;
+        if (chord_fast) bound_q += addq;
         for (uint32_t i = tid; i < span.nent; i += K4_BLOCK) ent[i] = entries[span.ebase + i];
         for (uint32_t i = tid; i < span.ngrp; i += K4_BLOCK) {
             const uint32_t d = groups[span.gbase + i];
@@ -1002,12 +1006,14 @@ k_pairs(const SimkaSpan *spans, const ull *cursors, const ull *entries, const ui
                     atomicAdd(&lacc[SIMKA_ACC_BC * CP + cell], ci < cj ? ci : cj);
                     if (pc.simple) {
                         const ull prod = (ull)ci * (ull)cj;
-                        // chord products can exceed any per-span bound: keep the carry path (returning atomic)
                         const uint32_t lo32 = (uint32_t)prod;
-                        const uint32_t old = atomicAdd(&lacc[SIMKA_ACC_CHORD * CP + cell], lo32);
-                        if ((uint32_t)(old + lo32) < old || (prod >> 32)) {
-                            const ull pg = simka_pair_index(si, sj, N);
-                            atomicAdd(&acc[SIMKA_ACC_CHORD * pc.nb_pairs + pg], (((uint32_t)(old + lo32) < old) ? (1ull << 32) : 0ull) + ((prod >> 32) << 32));
+                        if (chord_fast) atomicAdd(&lacc[SIMKA_ACC_CHORD * CP + cell], lo32);
+                        else {   // huge counts: a wrap of the low word (or a product >= 2^32) carries into the global u64 cell
+                            const uint32_t old = atomicAdd(&lacc[SIMKA_ACC_CHORD * CP + cell], lo32);
+                            if ((uint32_t)(old + lo32) < old || (prod >> 32)) {
+                                const ull pg = simka_pair_index(si, sj, N);
+                                atomicAdd(&acc[SIMKA_ACC_CHORD * pc.nb_pairs + pg], (((uint32_t)(old + lo32) < old) ? (1ull << 32) : 0ull) + ((prod >> 32) << 32));
+                            }
                         }
                         atomicAdd(&lacc[SIMKA_ACC_HELL * CP + cell], pair_isqrt(prod));
                     }
