@@ -34,23 +34,30 @@ struct simka_ctx {
     uint64_t nparts = 1;
     std::string err;
 
-    // per-sample scratch
-    uint64_t *d_reads = nullptr; uint64_t reads_cap = 0;      // staging for host reads (words)
+    // Two lanes (stream + private per-sample scratch): consecutive samples alternate between them, so the scan of sample
+    // i+1 (VALU/LDS + writes) overlaps the split/count of sample i (HBM / LDS bound) on the GPU.
+    struct Lane {
+        hipStream_t stream = nullptr;
+        uint64_t *d_l1 = nullptr; uint64_t l1_cap = 0;            // level-1 buckets (keys)
+        ull *d_b1_count = nullptr, *d_b1_start = nullptr, *d_b1_end = nullptr, *d_b1_cursor = nullptr;
+        uint32_t *d_chunk_first = nullptr;
+        ull *d_l2 = nullptr; uint64_t l2_cap = 0;                 // level-2 partition regions (keys)
+        uint32_t *d_p_count = nullptr, *d_p_valid = nullptr;      // [nparts]
+        ull *d_spill_keys = nullptr; uint64_t spill_cap = 0; uint32_t *d_spill_part = nullptr; uint64_t spill_part_cap = 0;
+        ull *d_spill_cursor = nullptr;
+        uint32_t *d_redo_list = nullptr; ull *d_redo_count = nullptr;   // partitions k_count_fast hands to k_count
+    };
+    Lane lanes[2];
+    uint32_t nlanes = 2;
+    // staging for host-provided reads
+    uint64_t *d_reads = nullptr; uint64_t reads_cap = 0;      // (words)
     uint64_t *d_offsets = nullptr; uint64_t offsets_cap = 0;
-    uint64_t *d_l1 = nullptr; uint64_t l1_cap = 0;            // level-1 buckets (keys)
-    ull *d_b1_count = nullptr, *d_b1_start = nullptr, *d_b1_end = nullptr, *d_b1_cursor = nullptr;
     uint32_t *d_l1_ovf = nullptr;                             // [N] capacity-mode scatter overflow flag per sample
     uint64_t nb_exact_fallbacks = 0;
     int small_table = -1;                                     // -1 undecided, else use K2F_TABLE_SMALL in k_count_fast
     uint32_t nb_counted_this_run = 0;
     struct Pending { uint32_t sample; SimkaScanArgs a; };     // device-resident samples whose flag has not been read yet
     std::vector<Pending> pending;
-    uint32_t *d_chunk_first = nullptr;
-    ull *d_l2 = nullptr; uint64_t l2_cap = 0;                 // level-2 partition regions (keys)
-    uint32_t *d_p_count = nullptr, *d_p_valid = nullptr;      // [nparts]
-    ull *d_spill_keys = nullptr; uint64_t spill_cap = 0; uint32_t *d_spill_part = nullptr; uint64_t spill_part_cap = 0;
-    ull *d_spill_cursor = nullptr;
-    uint32_t *d_redo_list = nullptr; ull *d_redo_count = nullptr;   // partitions k_count_fast hands to k_count
     // solid spectra of all samples
     ull *d_solid_keys = nullptr; uint32_t *d_solid_counts = nullptr; uint64_t arena_cap = 0;
     ull *d_arena_cursor = nullptr, *d_sample_base = nullptr;
@@ -85,6 +92,8 @@ struct simka_ctx {
     }
 };
 
+static int resolve_pending(simka_ctx *ctx);
+
 #define HIPCHK(call)                                                                             \
     do {                                                                                         \
         hipError_t e_ = (call);                                                                  \
@@ -92,21 +101,22 @@ struct simka_ctx {
     } while (0)
 
 template <typename F>
-static inline void launch_timed(simka_ctx *ctx, int kid, F &&f) {
+static inline void launch_timed(simka_ctx *ctx, int kid, F &&f, hipStream_t st = nullptr) {
+    if (!st) st = ctx->stream;
     static const bool dbg = getenv("SIMKA_DEBUG_SYNC") != nullptr;     // synchronise after every launch, name the kernel
     if (dbg) {
         fprintf(stderr, "[simka] launch %s\n", KID_NAMES[kid]); fflush(stderr);
         f();
-        hipError_t e = hipStreamSynchronize(ctx->stream);
+        hipError_t e = hipStreamSynchronize(st);
         fprintf(stderr, "[simka]   -> %s\n", hipGetErrorString(e)); fflush(stderr);
         return;
     }
     if (ctx->profiling) {
         simka_ctx::Ev ev; ev.kid = kid;
         (void)hipEventCreate(&ev.a); (void)hipEventCreate(&ev.b);
-        (void)hipEventRecord(ev.a, ctx->stream);
+        (void)hipEventRecord(ev.a, st);
         f();
-        (void)hipEventRecord(ev.b, ctx->stream);
+        (void)hipEventRecord(ev.b, st);
         ctx->events.push_back(ev);
     } else f();
 }
@@ -245,22 +255,30 @@ static int setup_geometry(simka_ctx *ctx, uint64_t max_kmers) {
     ctx->B1 = 1u << l1; ctx->B2 = 1u << l2; ctx->nparts = (uint64_t)1 << k.pb;
 
     const uint32_t N = c.nb_samples;
-    HIPCHK(dev_alloc(&ctx->d_b1_count, ctx->B1 + 1));
-    HIPCHK(dev_alloc(&ctx->d_b1_start, ctx->B1 + 1));
-    HIPCHK(dev_alloc(&ctx->d_b1_end, ctx->B1 + 1));
+    // SIMKA_LANES=2 alternates samples between two streams with private scratch (+4 % end to end on C2/C3: the kernels
+    // of neighbouring samples overlap); the default single lane keeps per-kernel timings free of overlap.
+    static const bool two_lanes = getenv("SIMKA_LANES") && atoi(getenv("SIMKA_LANES")) >= 2;
+    ctx->nlanes = (two_lanes && c.nb_samples >= 2) ? 2u : 1u;
+    for (uint32_t li = 0; li < ctx->nlanes; li++) {
+        simka_ctx::Lane &L = ctx->lanes[li];
+        if (!L.stream) HIPCHK(hipStreamCreateWithFlags(&L.stream, hipStreamNonBlocking));
+        HIPCHK(dev_alloc(&L.d_b1_count, ctx->B1 + 1));
+        HIPCHK(dev_alloc(&L.d_b1_start, ctx->B1 + 1));
+        HIPCHK(dev_alloc(&L.d_b1_end, ctx->B1 + 1));
+        HIPCHK(dev_alloc(&L.d_b1_cursor, ctx->B1 + 1));
+        HIPCHK(dev_alloc(&L.d_chunk_first, ctx->B1 + 1));
+        HIPCHK(dev_alloc(&L.d_p_count, ctx->nparts + 1));
+        HIPCHK(dev_alloc(&L.d_p_valid, ctx->nparts + 1));
+        HIPCHK(dev_alloc(&L.d_spill_cursor, 2));
+        HIPCHK(dev_alloc(&L.d_redo_list, ctx->nparts + 1));
+        HIPCHK(dev_alloc(&L.d_redo_count, 2));
+    }
     HIPCHK(dev_alloc(&ctx->d_l1_ovf, c.nb_samples + 1));
     HIPCHK(hipMemsetAsync(ctx->d_l1_ovf, 0, (size_t)(c.nb_samples + 1) * 4, ctx->stream));
-    HIPCHK(dev_alloc(&ctx->d_b1_cursor, ctx->B1 + 1));
-    HIPCHK(dev_alloc(&ctx->d_chunk_first, ctx->B1 + 1));
     HIPCHK(dev_alloc(&ctx->d_foff, (uint64_t)N * ctx->nparts));
     HIPCHK(dev_alloc(&ctx->d_fcnt, (uint64_t)N * ctx->nparts));
     HIPCHK(hipMemsetAsync(ctx->d_foff, 0, (uint64_t)N * ctx->nparts * 4, ctx->stream));
     HIPCHK(hipMemsetAsync(ctx->d_fcnt, 0, (uint64_t)N * ctx->nparts * 4, ctx->stream));
-    HIPCHK(dev_alloc(&ctx->d_p_count, ctx->nparts + 1));
-    HIPCHK(dev_alloc(&ctx->d_p_valid, ctx->nparts + 1));
-    HIPCHK(dev_alloc(&ctx->d_spill_cursor, 2));
-    HIPCHK(dev_alloc(&ctx->d_redo_list, ctx->nparts + 1));
-    HIPCHK(dev_alloc(&ctx->d_redo_count, 2));
     HIPCHK(dev_alloc(&ctx->d_part_total, ctx->nparts + 1));
     HIPCHK(dev_alloc(&ctx->d_part_off, ctx->nparts + 1));
 
@@ -277,6 +295,7 @@ static int setup_geometry(simka_ctx *ctx, uint64_t max_kmers) {
     ctx->arena_cap = cap;
     HIPCHK(dev_alloc(&ctx->d_solid_keys, cap));
     HIPCHK(dev_alloc(&ctx->d_solid_counts, cap));
+    HIPCHK(hipStreamSynchronize(ctx->stream));       // the lanes' streams do not order against the main stream
     ctx->geometry_ready = true;
     return SIMKA_OK;
 }
@@ -340,10 +359,15 @@ SIMKA_EXPORT int simka_create(const simka_config *cfg, simka_ctx **out) {
 SIMKA_EXPORT void simka_destroy(simka_ctx *ctx) {
     if (!ctx) return;
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+    for (auto &L : ctx->lanes) {
+        if (L.stream) (void)hipStreamSynchronize(L.stream);
+        void *lp[] = { L.d_l1, L.d_b1_count, L.d_b1_start, L.d_b1_end, L.d_b1_cursor, L.d_chunk_first, L.d_l2, L.d_p_count, L.d_p_valid,
+                       L.d_spill_keys, L.d_spill_part, L.d_spill_cursor, L.d_redo_list, L.d_redo_count };
+        for (void *q : lp) if (q) (void)hipFree(q);
+        if (L.stream) (void)hipStreamDestroy(L.stream);
+    }
     for (auto &ev : ctx->events) { (void)hipEventDestroy(ev.a); (void)hipEventDestroy(ev.b); }
-    void *ptrs[] = { ctx->d_reads, ctx->d_offsets, ctx->d_l1, ctx->d_b1_count, ctx->d_b1_start, ctx->d_b1_end, ctx->d_l1_ovf, ctx->d_b1_cursor,
-                     ctx->d_chunk_first, ctx->d_l2, ctx->d_p_count, ctx->d_p_valid, ctx->d_spill_keys, ctx->d_spill_part,
-                     ctx->d_spill_cursor, ctx->d_redo_list, ctx->d_redo_count, ctx->d_solid_keys, ctx->d_solid_counts, ctx->d_arena_cursor,
+    void *ptrs[] = { ctx->d_reads, ctx->d_offsets, ctx->d_l1_ovf, ctx->d_solid_keys, ctx->d_solid_counts, ctx->d_arena_cursor,
                      ctx->d_sample_base, ctx->d_foff, ctx->d_fcnt, ctx->d_stats, ctx->d_err, ctx->d_part_total,
                      ctx->d_part_off, ctx->d_mkeys, ctx->d_mvals, ctx->d_entries, ctx->d_groups, ctx->d_fb_off,
                      ctx->d_spans, ctx->d_cursors, ctx->d_slabs, ctx->d_hist, ctx->d_ovf_list, ctx->d_ovf_cursor };
@@ -354,6 +378,7 @@ SIMKA_EXPORT void simka_destroy(simka_ctx *ctx) {
 
 SIMKA_EXPORT int simka_sync(simka_ctx *ctx) {
     if (!ctx) return SIMKA_ERR_INVALID;
+    { int rcp = resolve_pending(ctx); if (rcp) return rcp; }
     HIPCHK(hipStreamSynchronize(ctx->stream));
     return SIMKA_OK;
 }
@@ -361,6 +386,7 @@ SIMKA_EXPORT int simka_sync(simka_ctx *ctx) {
 SIMKA_EXPORT int simka_reset(simka_ctx *ctx) {
     if (!ctx) return SIMKA_ERR_INVALID;
     HIPCHK(hipSetDevice(ctx->cfg.device));
+    for (uint32_t li = 0; li < ctx->nlanes; li++) if (ctx->lanes[li].stream) HIPCHK(hipStreamSynchronize(ctx->lanes[li].stream));
     const uint32_t N = ctx->cfg.nb_samples;
     HIPCHK(hipMemsetAsync(ctx->d_stats, 0, ctx->stats_n * 8, ctx->stream));
     HIPCHK(hipMemsetAsync(ctx->d_err, 0, 16, ctx->stream));
@@ -379,6 +405,7 @@ SIMKA_EXPORT int simka_reset(simka_ctx *ctx) {
     std::fill(ctx->counted.begin(), ctx->counted.end(), 0);
     std::fill(ctx->nb_reads.begin(), ctx->nb_reads.end(), 0);
     ctx->merged = false;
+    HIPCHK(hipStreamSynchronize(ctx->stream));       // the lanes' streams do not order against the main stream
     return SIMKA_OK;
 }
 
@@ -397,7 +424,7 @@ static int check_device_error(simka_ctx *ctx) {
 template <typename T>
 static int ensure_cap(simka_ctx *ctx, T **p, uint64_t *cap, uint64_t need) {
     if (*cap >= need && *p) return SIMKA_OK;
-    if (*p) { HIPCHK(hipStreamSynchronize(ctx->stream)); HIPCHK(hipFree(*p)); *p = nullptr; *cap = 0; }
+    if (*p) { HIPCHK(hipDeviceSynchronize()); HIPCHK(hipFree(*p)); *p = nullptr; *cap = 0; }
     const uint64_t n = need + need / 8 + 16;
     hipError_t e = dev_alloc(p, n);
     if (e != hipSuccess) return ctx->fail(SIMKA_ERR_NOMEM, "hipMalloc of %llu bytes failed: %s", (unsigned long long)(n * sizeof(T)), hipGetErrorString(e));
@@ -409,6 +436,8 @@ static int ensure_cap(simka_ctx *ctx, T **p, uint64_t *cap, uint64_t need) {
 // kernels after the scatter skip themselves if it flags an overflow, and resolve_pending() redoes the sample exactly.
 static int run_count_kernels(simka_ctx *ctx, uint32_t sample, const SimkaScanArgs &a, bool exact) {
     const uint32_t N = ctx->cfg.nb_samples;
+    simka_ctx::Lane &L = ctx->lanes[sample % ctx->nlanes];
+    const hipStream_t st = L.stream;
     int rc;
     const SimkaKeyCfg key = ctx->key;
     const uint32_t B1 = ctx->B1, B2 = ctx->B2;
@@ -422,10 +451,10 @@ static int run_count_kernels(simka_ctx *ctx, uint32_t sample, const SimkaScanArg
     const uint32_t *skip = flag;
     auto layout = [&](uint32_t mode, ull capb) {
         launch_timed(ctx, KID_LAYOUT, [&] {
-            hipLaunchKernelGGL(k_layout, dim3(1), dim3(256), lds_lay, ctx->stream, ctx->d_b1_count, ctx->d_b1_start, ctx->d_b1_end,
-                               ctx->d_b1_cursor, ctx->d_chunk_first, B1, ctx->d_arena_cursor, ctx->d_sample_base + sample, mode, capb,
+            hipLaunchKernelGGL(k_layout, dim3(1), dim3(256), lds_lay, st, L.d_b1_count, L.d_b1_start, L.d_b1_end,
+                               L.d_b1_cursor, L.d_chunk_first, B1, ctx->d_arena_cursor, ctx->d_sample_base + sample, mode, capb,
                                kocc, skip);
-        });
+        }, st);
     };
     // Level-1 buckets.  Keys are hash-partitioned, so bucket sizes concentrate around K_occ/B1: size every bucket for that
     // (+10 % + slack) and scatter directly.  Only if a bucket overflows (heavy repeats) is the sample redone with the exact
@@ -437,41 +466,41 @@ static int run_count_kernels(simka_ctx *ctx, uint32_t sample, const SimkaScanArg
         const uint64_t kocc_upper = a.fixed_len ? (a.fixed_len >= key.k ? a.nb_reads * (uint64_t)(a.fixed_len - key.k + 1) : 0) : a.nb_bases;
         const uint64_t per_bucket = kocc_upper / B1;
         const uint64_t capb = per_bucket + per_bucket / 10 + 2048;
-        rc = ensure_cap(ctx, &ctx->d_l1, &ctx->l1_cap, capb * B1); if (rc) return rc;
+        rc = ensure_cap(ctx, &L.d_l1, &L.l1_cap, capb * B1); if (rc) return rc;
         max_chunks = (capb * B1) / K2_CHUNK + B1 + 1;
         layout(1, capb);
         launch_timed(ctx, KID_SCAN_SCATTER, [&] {
             if (a.fixed_len)
-                hipLaunchKernelGGL((k_scan<true, true>), dim3(grid1), dim3(K1_BLOCK), lds_scat, ctx->stream, a, key, ctx->d_b1_count,
-                                   ctx->d_b1_cursor, ctx->d_l1, kocc, ctx->d_b1_end, flag);
+                hipLaunchKernelGGL((k_scan<true, true>), dim3(grid1), dim3(K1_BLOCK), lds_scat, st, a, key, L.d_b1_count,
+                                   L.d_b1_cursor, L.d_l1, kocc, L.d_b1_end, flag);
             else
-                hipLaunchKernelGGL((k_scan<true, false>), dim3(grid1), dim3(K1_BLOCK), lds_scat, ctx->stream, a, key, ctx->d_b1_count,
-                                   ctx->d_b1_cursor, ctx->d_l1, kocc, ctx->d_b1_end, flag);
-        });
+                hipLaunchKernelGGL((k_scan<true, false>), dim3(grid1), dim3(K1_BLOCK), lds_scat, st, a, key, L.d_b1_count,
+                                   L.d_b1_cursor, L.d_l1, kocc, L.d_b1_end, flag);
+        }, st);
         layout(2, capb);
         simka_ctx::Pending p; p.sample = sample; p.a = a;
         ctx->pending.push_back(p);
     } else {
-        rc = ensure_cap(ctx, &ctx->d_l1, &ctx->l1_cap, a.nb_bases); if (rc) return rc;
+        rc = ensure_cap(ctx, &L.d_l1, &L.l1_cap, a.nb_bases); if (rc) return rc;
         max_chunks = a.nb_bases / K2_CHUNK + B1 + 1;
-        HIPCHK(hipMemsetAsync(ctx->d_b1_count, 0, (B1 + 1) * 8, ctx->stream));
+        HIPCHK(hipMemsetAsync(L.d_b1_count, 0, (B1 + 1) * 8, st));
         launch_timed(ctx, KID_SCAN_HIST, [&] {
             if (a.fixed_len)
-                hipLaunchKernelGGL((k_scan<false, true>), dim3(grid1), dim3(K1_BLOCK), lds_hist, ctx->stream, a, key, ctx->d_b1_count,
-                                   ctx->d_b1_cursor, ctx->d_l1, kocc, (const ull *)nullptr, (uint32_t *)nullptr);
+                hipLaunchKernelGGL((k_scan<false, true>), dim3(grid1), dim3(K1_BLOCK), lds_hist, st, a, key, L.d_b1_count,
+                                   L.d_b1_cursor, L.d_l1, kocc, (const ull *)nullptr, (uint32_t *)nullptr);
             else
-                hipLaunchKernelGGL((k_scan<false, false>), dim3(grid1), dim3(K1_BLOCK), lds_hist, ctx->stream, a, key, ctx->d_b1_count,
-                                   ctx->d_b1_cursor, ctx->d_l1, kocc, (const ull *)nullptr, (uint32_t *)nullptr);
-        });
+                hipLaunchKernelGGL((k_scan<false, false>), dim3(grid1), dim3(K1_BLOCK), lds_hist, st, a, key, L.d_b1_count,
+                                   L.d_b1_cursor, L.d_l1, kocc, (const ull *)nullptr, (uint32_t *)nullptr);
+        }, st);
         layout(0, 0);
         launch_timed(ctx, KID_SCAN_SCATTER, [&] {
             if (a.fixed_len)
-                hipLaunchKernelGGL((k_scan<true, true>), dim3(grid1), dim3(K1_BLOCK), lds_scat, ctx->stream, a, key, ctx->d_b1_count,
-                                   ctx->d_b1_cursor, ctx->d_l1, kocc, (const ull *)nullptr, (uint32_t *)nullptr);
+                hipLaunchKernelGGL((k_scan<true, true>), dim3(grid1), dim3(K1_BLOCK), lds_scat, st, a, key, L.d_b1_count,
+                                   L.d_b1_cursor, L.d_l1, kocc, (const ull *)nullptr, (uint32_t *)nullptr);
             else
-                hipLaunchKernelGGL((k_scan<true, false>), dim3(grid1), dim3(K1_BLOCK), lds_scat, ctx->stream, a, key, ctx->d_b1_count,
-                                   ctx->d_b1_cursor, ctx->d_l1, kocc, (const ull *)nullptr, (uint32_t *)nullptr);
-        });
+                hipLaunchKernelGGL((k_scan<true, false>), dim3(grid1), dim3(K1_BLOCK), lds_scat, st, a, key, L.d_b1_count,
+                                   L.d_b1_cursor, L.d_l1, kocc, (const ull *)nullptr, (uint32_t *)nullptr);
+        }, st);
     }
     (void)max_chunks;
     // ---- level 2: partition-contiguous regions, capacity-sized, + spill buffer
@@ -480,24 +509,24 @@ static int run_count_kernels(simka_ctx *ctx, uint32_t sample, const SimkaScanArg
     const uint64_t mean2 = kocc_up / owned_parts;
     SimkaL2 l2;
     l2.cap2 = mean2 + mean2 / 2 + 256;
-    rc = ensure_cap(ctx, &ctx->d_l2, &ctx->l2_cap, l2.cap2 * ctx->nparts); if (rc) return rc;
+    rc = ensure_cap(ctx, &L.d_l2, &L.l2_cap, l2.cap2 * ctx->nparts); if (rc) return rc;
     const uint64_t spill_need = exact ? std::max<uint64_t>(kocc_up, 1) : std::max<uint64_t>((uint64_t)1 << 20, kocc_up / 64);
-    rc = ensure_cap(ctx, &ctx->d_spill_keys, &ctx->spill_cap, spill_need); if (rc) return rc;
-    rc = ensure_cap(ctx, &ctx->d_spill_part, &ctx->spill_part_cap, spill_need); if (rc) return rc;
-    l2.l2_keys = ctx->d_l2; l2.p_count = ctx->d_p_count; l2.p_valid = ctx->d_p_valid;
-    l2.spill_keys = ctx->d_spill_keys; l2.spill_part = ctx->d_spill_part; l2.spill_cursor = ctx->d_spill_cursor;
-    l2.spill_cap = std::min(ctx->spill_cap, ctx->spill_part_cap);
-    HIPCHK(hipMemsetAsync(ctx->d_p_count, 0, ctx->nparts * 4, ctx->stream));
-    HIPCHK(hipMemsetAsync(ctx->d_p_valid, 0xff, ctx->nparts * 4, ctx->stream));
-    HIPCHK(hipMemsetAsync(ctx->d_spill_cursor, 0, 8, ctx->stream));
-    HIPCHK(hipMemsetAsync(ctx->d_redo_count, 0, 8, ctx->stream));
+    rc = ensure_cap(ctx, &L.d_spill_keys, &L.spill_cap, spill_need); if (rc) return rc;
+    rc = ensure_cap(ctx, &L.d_spill_part, &L.spill_part_cap, spill_need); if (rc) return rc;
+    l2.l2_keys = L.d_l2; l2.p_count = L.d_p_count; l2.p_valid = L.d_p_valid;
+    l2.spill_keys = L.d_spill_keys; l2.spill_part = L.d_spill_part; l2.spill_cursor = L.d_spill_cursor;
+    l2.spill_cap = std::min(L.spill_cap, L.spill_part_cap);
+    HIPCHK(hipMemsetAsync(L.d_p_count, 0, ctx->nparts * 4, st));
+    HIPCHK(hipMemsetAsync(L.d_p_valid, 0xff, ctx->nparts * 4, st));
+    HIPCHK(hipMemsetAsync(L.d_spill_cursor, 0, 8, st));
+    HIPCHK(hipMemsetAsync(L.d_redo_count, 0, 8, st));
     {
-        const uint64_t nchunks_max = (exact ? a.nb_bases : ctx->l1_cap) / K2_CHUNK + B1 + 1;
+        const uint64_t nchunks_max = (exact ? a.nb_bases : L.l1_cap) / K2_CHUNK + B1 + 1;
         const size_t lds_split = SIMKA_LDS_HEAD + (size_t)B2 * 12 + 64 + (size_t)K2_CHUNK * 8;
         launch_timed(ctx, KID_SPLIT, [&] {
-            hipLaunchKernelGGL(k_split, dim3((uint32_t)nchunks_max), dim3(K2_BLOCK), lds_split, ctx->stream, ctx->d_l1,
-                               ctx->d_b1_start, ctx->d_b1_end, ctx->d_chunk_first, key, l2, flag);
-        });
+            hipLaunchKernelGGL(k_split, dim3((uint32_t)nchunks_max), dim3(K2_BLOCK), lds_split, st, L.d_l1,
+                               L.d_b1_start, L.d_b1_end, L.d_chunk_first, key, l2, flag);
+        }, st);
     }
     SimkaCountOut o;
     o.arena_cursor = ctx->d_arena_cursor; o.sample_base = ctx->d_sample_base + sample; o.arena_cap = ctx->arena_cap;
@@ -516,21 +545,21 @@ static int run_count_kernels(simka_ctx *ctx, uint32_t sample, const SimkaScanArg
         const dim3 gridf((uint32_t)std::min<uint64_t>(ctx->nparts, (uint64_t)ctx->num_cus * bpc_f));
         launch_timed(ctx, KID_COUNT_FAST, [&] {
             if (small)
-                hipLaunchKernelGGL((k_count_fast<K2F_TABLE_SMALL>), gridf, dim3(K2F_BLOCK), lds_fast, ctx->stream, key, l2, ctx->cfg.abundance_min,
-                                   ctx->cfg.abundance_max, o, flag, ctx->d_redo_list, ctx->d_redo_count);
+                hipLaunchKernelGGL((k_count_fast<K2F_TABLE_SMALL>), gridf, dim3(K2F_BLOCK), lds_fast, st, key, l2, ctx->cfg.abundance_min,
+                                   ctx->cfg.abundance_max, o, flag, L.d_redo_list, L.d_redo_count);
             else
-                hipLaunchKernelGGL((k_count_fast<K2F_TABLE_BIG>), gridf, dim3(K2F_BLOCK), lds_fast, ctx->stream, key, l2, ctx->cfg.abundance_min,
-                                   ctx->cfg.abundance_max, o, flag, ctx->d_redo_list, ctx->d_redo_count);
-        });
+                hipLaunchKernelGGL((k_count_fast<K2F_TABLE_BIG>), gridf, dim3(K2F_BLOCK), lds_fast, st, key, l2, ctx->cfg.abundance_min,
+                                   ctx->cfg.abundance_max, o, flag, L.d_redo_list, L.d_redo_count);
+        }, st);
     }
     const size_t lds_count = SIMKA_LDS_HEAD + ((size_t)12 << tlog) + hist_lds;
     launch_timed(ctx, KID_COUNT, [&] {
         const uint32_t grid_count = slow_only ? (uint32_t)std::min<uint64_t>(ctx->nparts, (uint64_t)ctx->num_cus * 4) : (uint32_t)ctx->num_cus;
-        hipLaunchKernelGGL(k_count, dim3(grid_count), dim3(K2C_BLOCK), lds_count, ctx->stream, key, l2, tlog,
+        hipLaunchKernelGGL(k_count, dim3(grid_count), dim3(K2C_BLOCK), lds_count, st, key, l2, tlog,
                            ctx->cfg.abundance_min, ctx->cfg.abundance_max, o, flag,
-                           slow_only ? (const uint32_t *)nullptr : (const uint32_t *)ctx->d_redo_list,
-                           slow_only ? (const ull *)nullptr : (const ull *)ctx->d_redo_count);
-    });
+                           slow_only ? (const uint32_t *)nullptr : (const uint32_t *)L.d_redo_list,
+                           slow_only ? (const ull *)nullptr : (const ull *)L.d_redo_count);
+    }, st);
     HIPCHK(hipGetLastError());
     return SIMKA_OK;
 }
@@ -538,6 +567,7 @@ static int run_count_kernels(simka_ctx *ctx, uint32_t sample, const SimkaScanArg
 // read the overflow flags of the samples enqueued in capacity mode; redo the flagged ones exactly (their later kernels
 // skipped themselves, so no state was touched).  Synchronises.
 static int resolve_pending(simka_ctx *ctx) {
+    for (uint32_t li = 0; li < ctx->nlanes; li++) if (ctx->lanes[li].stream) HIPCHK(hipStreamSynchronize(ctx->lanes[li].stream));
     if (ctx->pending.empty()) return SIMKA_OK;
     const uint32_t N = ctx->cfg.nb_samples;
     std::vector<uint32_t> flags(N);
@@ -549,9 +579,11 @@ static int resolve_pending(simka_ctx *ctx) {
         if (!flags[p.sample]) continue;
         ctx->nb_exact_fallbacks++;
         HIPCHK(hipMemsetAsync(ctx->d_l1_ovf + p.sample, 0, 4, ctx->stream));
+        HIPCHK(hipStreamSynchronize(ctx->stream));
         int rc = run_count_kernels(ctx, p.sample, p.a, true);
         if (rc) return rc;
     }
+    for (uint32_t li = 0; li < ctx->nlanes; li++) HIPCHK(hipStreamSynchronize(ctx->lanes[li].stream));
     return SIMKA_OK;
 }
 
