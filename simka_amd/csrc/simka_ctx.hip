@@ -524,7 +524,7 @@ static int run_count_kernels(simka_ctx *ctx, uint32_t sample, const SimkaScanArg
         const uint64_t nchunks_max = (exact ? a.nb_bases : L.l1_cap) / K2_CHUNK + B1 + 1;
         const size_t lds_split = SIMKA_LDS_HEAD + (size_t)B2 * 12 + 64 + (size_t)K2_CHUNK * 8;
         launch_timed(ctx, KID_SPLIT, [&] {
-            hipLaunchKernelGGL(k_split, dim3((uint32_t)nchunks_max), dim3(K2_BLOCK), lds_split, st, L.d_l1,
+            hipLaunchKernelGGL(k_split, dim3((uint32_t)std::min<uint64_t>(nchunks_max, (uint64_t)ctx->num_cus * 2)), dim3(K2_BLOCK), lds_split, st, L.d_l1,
                                L.d_b1_start, L.d_b1_end, L.d_chunk_first, key, l2, flag);
         }, st);
     }

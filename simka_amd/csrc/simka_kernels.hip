@@ -261,70 +261,89 @@ k_split(const uint64_t *l1_keys, const ull *b1_start, const ull *b1_end, const u
     if (*flag) return;                               // the level-1 scatter overflowed: the sample is redone exactly
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const uint32_t B1 = 1u << cfg.l1, B2 = 1u << cfg.l2;
-    uint32_t &s_b1 = *(uint32_t *)smem;
+    ull *s_chunk = (ull *)smem;                      // [2][3] (start, n, b1) of the current / next chunk
     uint32_t *hist = (uint32_t *)(smem + SIMKA_LDS_HEAD);   // [B2] counts, then exclusive offsets
-    uint32_t *tmp = hist + B2;                      // [K2_BLOCK/64 .. ] scan scratch
+    uint32_t *tmp = hist + B2;                      // [16] scan scratch
     ull *gpos = (ull *)(tmp + 16);                  // [B2] destination of each run (bit 63: spill buffer)
     uint64_t *stage = (uint64_t *)(gpos + B2);      // [K2_CHUNK]
 
-    const uint32_t c = blockIdx.x;
-    if (c >= chunk_first[B1]) return;
     const uint32_t tid = threadIdx.x;
-    if (tid == 0) {
+    const uint32_t nchunks = chunk_first[B1];
+    constexpr int PER = K2_CHUNK / K2_BLOCK;
+    // chunk c -> (first key, #keys, level-1 bucket): thread 0, into slot `w`
+    auto locate = [&](uint32_t c, uint32_t w) {
         uint32_t lo = 0, hi = B1;   // largest b with chunk_first[b] <= c  (empty buckets repeat a value)
         while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (chunk_first[mid] <= c) lo = mid; else hi = mid; }
-        s_b1 = lo;
-    }
-    for (uint32_t i = tid; i < B2; i += K2_BLOCK) hist[i] = 0;
+        const ull st = b1_start[lo] + (ull)(c - chunk_first[lo]) * K2_CHUNK;
+        const ull be = b1_end[lo];
+        s_chunk[w * 3 + 0] = st; s_chunk[w * 3 + 1] = (be - st < (ull)K2_CHUNK) ? (be - st) : (ull)K2_CHUNK; s_chunk[w * 3 + 2] = lo;
+    };
+    // persistent block: chunks blockIdx.x, +gridDim.x, ...; the keys of the NEXT chunk are loaded into registers while the
+    // current one is ranked, staged and written out
+    uint32_t c = blockIdx.x;
+    if (c >= nchunks) return;
+    if (tid == 0) locate(c, 0);
     __syncthreads();
-    const uint32_t b1 = s_b1;
-    const ull s = b1_start[b1] + (ull)(c - chunk_first[b1]) * K2_CHUNK;
-    const ull bend = b1_end[b1];
-    const uint32_t n = (uint32_t)((bend - s < (ull)K2_CHUNK) ? (bend - s) : (ull)K2_CHUNK);
-
-    constexpr int PER = K2_CHUNK / K2_BLOCK;
-    uint64_t keys[PER];
-    uint32_t ranks[PER];
+    uint64_t keys[PER], nkeys[PER];
+    {
+        const ull st = s_chunk[0]; const uint32_t n = (uint32_t)s_chunk[1];
 #pragma unroll
-    for (int q = 0; q < PER; q++) {
-        const uint32_t idx = (uint32_t)q * K2_BLOCK + tid;
-        keys[q] = SIMKA_EMPTY_KEY; ranks[q] = 0;
-        if (idx < n) {
-            keys[q] = l1_keys[s + idx];
-            ranks[q] = atomicAdd(&hist[simka_key_l2(keys[q], cfg)], 1u);
-        }
+        for (int q = 0; q < PER; q++) { const uint32_t idx = (uint32_t)q * K2_BLOCK + tid; keys[q] = (idx < n) ? l1_keys[st + idx] : SIMKA_EMPTY_KEY; }
     }
-    __syncthreads();
-    for (uint32_t b = tid; b < B2; b += K2_BLOCK) {
-        const uint32_t h = hist[b];
-        ull g = 0;
-        if (h) {
-            const uint32_t part = (b1 << cfg.l2) | b;
-            const uint32_t pos = atomicAdd(&l2.p_count[part], h);          // reserve the run in partition `part`
-            if ((ull)pos + h <= l2.cap2) g = (ull)part * l2.cap2 + pos;
-            else {
-                atomicMin(&l2.p_valid[part], pos);                          // region holds [0,pos) only; the rest is spilled
-                const ull sp = atomicAdd(l2.spill_cursor, (ull)h);
-                if (sp + h > l2.spill_cap) { atomicOr(flag, 2u); g = ~0ull; }
-                else g = (1ull << 63) | sp;
+    for (uint32_t it = 0; c < nchunks; it++, c += gridDim.x) {
+        const uint32_t w = it & 1u;
+        const uint32_t n = (uint32_t)s_chunk[w * 3 + 1], b1 = (uint32_t)s_chunk[w * 3 + 2];
+        const uint32_t cn = c + gridDim.x;
+        if (tid == 0 && cn < nchunks) locate(cn, w ^ 1u);
+        for (uint32_t i = tid; i < B2; i += K2_BLOCK) hist[i] = 0;
+        __syncthreads();
+        if (cn < nchunks) {      // prefetch
+            const ull st = s_chunk[(w ^ 1u) * 3 + 0]; const uint32_t nn = (uint32_t)s_chunk[(w ^ 1u) * 3 + 1];
+#pragma unroll
+            for (int q = 0; q < PER; q++) { const uint32_t idx = (uint32_t)q * K2_BLOCK + tid; nkeys[q] = (idx < nn) ? l1_keys[st + idx] : SIMKA_EMPTY_KEY; }
+        }
+        uint32_t ranks[PER];
+#pragma unroll
+        for (int q = 0; q < PER; q++) {
+            const bool ok = keys[q] != SIMKA_EMPTY_KEY;
+            const uint32_t rk = atomicAdd(&hist[ok ? simka_key_l2(keys[q], cfg) : 0u], ok ? 1u : 0u);
+            ranks[q] = rk;
+        }
+        __syncthreads();
+        for (uint32_t b = tid; b < B2; b += K2_BLOCK) {
+            const uint32_t h = hist[b];
+            ull g = 0;
+            if (h) {
+                const uint32_t part = (b1 << cfg.l2) | b;
+                const uint32_t pos = atomicAdd(&l2.p_count[part], h);          // reserve the run in partition `part`
+                if ((ull)pos + h <= l2.cap2) g = (ull)part * l2.cap2 + pos;
+                else {
+                    atomicMin(&l2.p_valid[part], pos);                          // region holds [0,pos) only; the rest is spilled
+                    const ull sp = atomicAdd(l2.spill_cursor, (ull)h);
+                    if (sp + h > l2.spill_cap) { atomicOr(flag, 2u); g = ~0ull; }
+                    else g = (1ull << 63) | sp;
+                }
             }
+            gpos[b] = g;
         }
-        gpos[b] = g;
-    }
-    __syncthreads();
-    block_excl_scan<K2_BLOCK>(hist, B2, tmp);
+        __syncthreads();
+        block_excl_scan<K2_BLOCK>(hist, B2, tmp);
 #pragma unroll
-    for (int q = 0; q < PER; q++)
-        if (keys[q] != SIMKA_EMPTY_KEY) stage[hist[simka_key_l2(keys[q], cfg)] + ranks[q]] = keys[q];
-    __syncthreads();
-    for (uint32_t idx = tid; idx < n; idx += K2_BLOCK) {
-        const uint64_t key = stage[idx];
-        const uint32_t b = simka_key_l2(key, cfg);
-        const ull g = gpos[b];
-        const uint32_t off = idx - hist[b];
-        if (g == ~0ull) continue;
-        if (g >> 63) { const ull sp = (g & ~(1ull << 63)) + off; l2.spill_keys[sp] = key; l2.spill_part[sp] = (b1 << cfg.l2) | b; }
-        else l2.l2_keys[g + off] = key;
+        for (int q = 0; q < PER; q++)
+            if (keys[q] != SIMKA_EMPTY_KEY) stage[hist[simka_key_l2(keys[q], cfg)] + ranks[q]] = keys[q];
+        __syncthreads();
+        for (uint32_t idx = tid; idx < n; idx += K2_BLOCK) {
+            const uint64_t key = stage[idx];
+            const uint32_t b = simka_key_l2(key, cfg);
+            const ull g = gpos[b];
+            const uint32_t off = idx - hist[b];
+            if (g == ~0ull) continue;
+            if (g >> 63) { const ull sp = (g & ~(1ull << 63)) + off; l2.spill_keys[sp] = key; l2.spill_part[sp] = (b1 << cfg.l2) | b; }
+            else l2.l2_keys[g + off] = key;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < PER; q++) keys[q] = nkeys[q];
     }
 }
 
