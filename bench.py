@@ -181,19 +181,17 @@ def main():
     ms_per_step = dt / args.steps * 1e3
     value = K_dist / (dt / args.steps)
 
-    # ---- roofline (DESIGN.md section 4 "Algorithmic bytes"): every term of SURVEY 8(d)'s
-    # B_alg = R*L/4 + 16*K_occ + 12*K_dist + 12*K_solid is attributed to exactly one kernel -- the one that moves it:
-    #   k_scan<scatter>: reads the packed bases, WRITES each 8-byte k-mer once      -> R*L/4 + 8*K_occ
-    #   k_split        : READS each 8-byte k-mer once for partitioning             -> 8*K_occ   (its re-write and k_count's
-    #                    re-read, another 16 B/occurrence, are overhead of the two-level design and count for nothing)
-    #   k_count_fast   : emits the counted (u64,u32) records                       -> 12*K_dist
-    #   k_regroup      : reads the solid records once in the merge                 -> 12*K_solid
+    # ---- roofline (DESIGN.md section 4 "Algorithmic bytes").  SURVEY 8(d): B_alg = R*L/4 + 16*K_occ + 12*K_dist + 12*K_solid,
+    # where 16*K_occ = "write + read each 8-byte k-mer once".  This design moves every k-mer through FOUR 8-byte transfers
+    # (scatter write, split read, split write, count read), so each transfer earns half credit (4 B); the kernels' shares
+    # still add up to exactly B_alg:
+    #   k_scan<scatter>: R*L/4 + 4*K_occ      k_split: 8*K_occ      k_count_fast: 4*K_occ + 12*K_dist      k_regroup: 12*K_solid
     share = 1.0 / world                    # each rank owns 1/world of the key space
     alg_bytes_per_step = {
         "k_scan<hist>": 0.0,
-        "k_scan<scatter>": n * nb_bases / 4.0 + 8.0 * K_occ * share,
+        "k_scan<scatter>": n * nb_bases / 4.0 + 4.0 * K_occ * share,
         "k_split": 8.0 * K_occ * share,
-        "k_count_fast": 12.0 * K_dist * share,
+        "k_count_fast": 4.0 * K_occ * share + 12.0 * K_dist * share,
         "k_count": 0.0,
         "k_regroup": 12.0 * K_solid * share,
         "k_group": 0.0, "k_pairs": 0.0, "k_layout": 0.0, "k_part_totals": 0.0, "k_reduce_slabs": 0.0,
@@ -211,24 +209,36 @@ def main():
     # FETCH_SIZE and WRITE_SIZE in separate rocprofv3 runs, FETCH_SIZE x2 on gfx950); only when it is the same workload
     traffic = None
     traffic_src = None
+    tk = {}
+    alias = {"k_scan<scatter>": ["k_scan<true, true>", "k_scan<true, false>", "k_scan<true>"], "k_scan<hist>": ["k_scan<false, true>", "k_scan<false>"],
+             "k_count_fast": ["k_count_fast<2048u>", "k_count_fast<4096u>"], "k_pairs": ["k_pairs<true, 256>", "k_pairs<true, 1024>", "k_pairs<false, 1024>"]}
+
+    def measured_traffic(kname):
+        for cand in [kname] + alias.get(kname, []):
+            if cand in tk:
+                return tk[cand]["traffic_bytes_per_launch"]
+        return None
     try:
         tf = os.path.join(ROOT, "profiles", "r01_%s_hbm_traffic.json" % args.workload)
         if world == 1 and not args.reads and not args.samples and os.path.exists(tf):
             tk = json.load(open(tf))["kernels"]
-            alias = {"k_scan<scatter>": ["k_scan<true>"], "k_scan<hist>": ["k_scan<false>"],
-                     "k_count_fast": ["k_count_fast<2048u>", "k_count_fast<4096u>"]}
-            for cand in [dom] + alias.get(dom, []):
-                if cand in tk:
-                    traffic = tk[cand]["traffic_bytes_per_launch"]
-                    traffic_src = os.path.relpath(tf, ROOT)
-                    break
+            traffic = measured_traffic(dom)
+            traffic_src = os.path.relpath(tf, ROOT)
     except Exception:
         traffic = None
+    per_kernel = {}
+    for kname, (cnt, ms) in prof.items():
+        if cnt == 0:
+            continue
+        ab = alg_bytes_per_step.get(kname, 0.0)
+        per_kernel[kname] = {"launches_per_step": cnt / args.steps, "ms_per_step": ms / args.steps,
+                             "alg_bytes_per_step": ab, "alg_GBps": (ab * args.steps / (ms * 1e-3) / 1e9) if ms > 0 else 0.0,
+                             "hbm_traffic_bytes_per_launch": measured_traffic(kname)}
     roofline = {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                 "avg_launch_ms": dom_avg_ms, "launches": dom_launches, "alg_bytes_per_launch": dom_bytes_per_launch,
                 "path_achieved": path_gbs, "path_frac": path_gbs / HBM_PEAK_GBS, "path_alg_bytes_per_step": b_alg,
-                "kernel_ms_per_step": {kk: v / args.steps for kk, v in kern_ms.items()}}
+                "kernel_ms_per_step": {kk: v / args.steps for kk, v in kern_ms.items()}, "kernels": per_kernel}
 
     out = {
         "metric": "distinct k-mers/s end-to-end (count + merge + N x N matrices)", "value": value, "unit": "distinct k-mers/s",
