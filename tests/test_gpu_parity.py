@@ -344,3 +344,79 @@ def test_many_samples_tiled_pair_accumulators(gpu_required, oracle_mod, n, simpl
         orc.add_sample_ascii("S%d" % s, synth.unpack_ascii(pk, R * L), offs)
     orc.run(k, 1, simple=simple, complex_=complex_, nparts=8, threads=8)
     _check_vs_oracle(totals, st, orc, simple=simple, complex_=complex_)
+
+
+def _run_cli(args, out):
+    import subprocess
+    from simka_amd import build as b
+    r = subprocess.run([b.CLI_PATH] + args + ["-out", out, "-verbose", "0"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    assert r.returncode == 0, r.stdout
+    res = {}
+    for gzf in sorted(glob.glob(os.path.join(out, "*.csv.gz"))):
+        with gzip.open(gzf, "rb") as f:
+            res[os.path.basename(gzf)] = f.read()
+    assert len(res) == 18
+    return res
+
+
+def test_cli_max_reads_equals_truncated_inputs(gpu_required, golden_dir, tmp_path):
+    """-max-reads m: the first m reads of every ';'-part (SimkaInputIterator, ref: src/core/SimkaCommons.hpp:239-289) --
+    same matrices as running on files truncated to m reads.  (The example's parts reach m inside their first file.)"""
+    import simka_amd
+    ex = os.path.join(golden_dir, "example")
+    m = 10
+    d = tmp_path / "trunc"
+    d.mkdir()
+    for name in ("A", "B", "C", "D_paired_1", "D_paired_2"):
+        seqs = list(simka_amd.read_sequences(os.path.join(ex, name + ".fasta")))[:m]
+        (d / (name + ".fasta")).write_bytes(b"".join(b">%d\n%s\n" % (i, s) for i, s in enumerate(seqs)))
+    (d / "input.txt").write_text("A: A.fasta\nB: B.fasta\nC: C.fasta\nD: D_paired_1.fasta ; D_paired_2.fasta\nE: A.fasta ; B.fasta\n")
+    common = ["-out-tmp", str(tmp_path / "tmp"), "-simple-dist", "-kmer-size", "21", "-abundance-min", "1"]
+    a = _run_cli(["-in", os.path.join(ex, "simka_input.txt"), "-max-reads", str(m)] + common, str(tmp_path / "o1"))
+    b = _run_cli(["-in", str(d / "input.txt")] + common, str(tmp_path / "o2"))
+    assert a == b
+
+
+def test_cli_read_filters_equal_prefiltered_inputs(gpu_required, tmp_path):
+    """-min-read-size / -min-shannon-index (SimkaSequenceFilter, ref: src/core/SimkaCommons.hpp:317-436)."""
+    import math
+    rng = np.random.default_rng(5)
+
+    def shannon(s):
+        n = len(s)
+        tot = 0.0
+        for ch in b"ACGT":
+            f = s.count(bytes([ch])) / n
+            if f:
+                tot += f * math.log(f) / math.log(2)
+        return abs(tot)
+
+    def reads(seed):
+        r = np.random.default_rng(seed)
+        base = bytes(r.choice(list(b"ACGT"), size=3000).tolist())
+        out = []
+        for i in range(300):
+            ln = int(r.integers(40, 130))
+            st = int(r.integers(0, 3000 - ln))
+            s = base[st:st + ln]
+            if i % 7 == 0:
+                s = b"A" * (ln - 6) + b"CGTACG"          # low complexity
+            if i % 11 == 0:
+                s = (b"AC" * ln)[:ln]                     # Shannon index 1.0
+            out.append(s)
+        return out
+
+    raw, flt = tmp_path / "raw", tmp_path / "flt"
+    raw.mkdir(); flt.mkdir()
+    for name, seed in (("X", 1), ("Y", 2), ("Z", 1)):
+        rs = reads(seed) if name != "Z" else reads(1)[100:] + reads(2)[:100]
+        keep = [s for s in rs if len(s) >= 80 and shannon(s) >= 1.5]
+        assert 20 < len(keep) < len(rs)
+        (raw / (name + ".fa")).write_bytes(b"".join(b">r\n%s\n" % s for s in rs))
+        (flt / (name + ".fa")).write_bytes(b"".join(b">r\n%s\n" % s for s in keep))
+    for dd in (raw, flt):
+        (dd / "in.txt").write_text("X: X.fa\nY: Y.fa\nZ: Z.fa\n")
+    common = ["-out-tmp", str(tmp_path / "tmp"), "-simple-dist", "-kmer-size", "15", "-abundance-min", "1"]
+    a = _run_cli(["-in", str(raw / "in.txt"), "-min-read-size", "80", "-min-shannon-index", "1.5"] + common, str(tmp_path / "o1"))
+    b = _run_cli(["-in", str(flt / "in.txt")] + common, str(tmp_path / "o2"))
+    assert a == b
