@@ -16,7 +16,11 @@
 #include <zlib.h>
 
 #include <algorithm>
+#include <atomic>
+#include <condition_variable>
 #include <fstream>
+#include <mutex>
+#include <thread>
 #include <iostream>
 #include <sstream>
 #include <string>
@@ -39,6 +43,7 @@ struct Options {
     long long max_memory = 5000;
     int verbose = 1;
     int nb_gpus = 1, first_gpu = 0;     // new: devices to shard the partition space over
+    bool parse_only = false;            // new: stop after reading + packing the inputs (ingest benchmark, no GPU needed)
 };
 
 struct Sample {
@@ -118,6 +123,7 @@ Options parse_args(int argc, char **argv) {
         else if (a == "-verbose") o.verbose = atoi(need(i).c_str());
         else if (a == "-nb-gpus") o.nb_gpus = atoi(need(i).c_str());
         else if (a == "-gpu") o.first_gpu = atoi(need(i).c_str());
+        else if (a == "-parse-only") o.parse_only = true;
         else if (a == "-max-count" || a == "-max-merge" || a == "-count-cmd" || a == "-merge-cmd" || a == "-count-file" ||
                  a == "-merge-file" || a == "-minimizer-size" || a == "-solidity-kind" || a == "-max-disk" ||
                  a == "-minimizer-type" || a == "-repartition-type" || a == "-storage-type" || a == "-histo-max")
@@ -273,6 +279,62 @@ bool load_sample(const Sample &s, const Options &o, uint64_t max_reads, Packed &
     return true;
 }
 
+// Host ingest: worker threads parse + 2-bit pack upcoming samples (one sample per thread, gz
+// decompression included) while the main thread hands finished samples to the GPU in input order.  At most `window`
+// samples are in flight, which bounds host memory.
+class SampleLoader {
+public:
+    SampleLoader(const std::vector<Sample> &samples, const Options &o, uint64_t max_reads, unsigned threads, unsigned window)
+        : samples_(samples), o_(o), max_reads_(max_reads), window_(std::max(1u, window)), slots_(samples.size()), state_(samples.size(), 0) {
+        threads = std::max(1u, std::min<unsigned>(threads, (unsigned)samples.size()));
+        for (unsigned t = 0; t < threads; t++) workers_.emplace_back([this] { run(); });
+    }
+    ~SampleLoader() {
+        { std::lock_guard<std::mutex> g(m_); stop_ = true; }
+        cv_.notify_all();
+        for (auto &w : workers_) w.join();
+    }
+    // blocks until sample i is packed; false if it could not be read
+    bool get(size_t i, Packed *&out) {
+        std::unique_lock<std::mutex> g(m_);
+        cv_.wait(g, [&] { return state_[i] != 0; });
+        out = &slots_[i];
+        return state_[i] > 0;
+    }
+    void release(size_t i) {
+        { std::lock_guard<std::mutex> g(m_); slots_[i] = Packed(); consumed_ = i + 1; }
+        cv_.notify_all();
+    }
+
+private:
+    void run() {
+        for (;;) {
+            size_t i;
+            {
+                std::unique_lock<std::mutex> g(m_);
+                cv_.wait(g, [&] { return stop_ || next_ >= samples_.size() || next_ < consumed_ + window_; });
+                if (stop_ || next_ >= samples_.size()) return;
+                i = next_++;
+            }
+            Packed pk;
+            const bool ok = load_sample(samples_[i], o_, max_reads_, pk);
+            { std::lock_guard<std::mutex> g(m_); slots_[i] = std::move(pk); state_[i] = ok ? 1 : -1; }
+            cv_.notify_all();
+        }
+    }
+    const std::vector<Sample> &samples_;
+    const Options &o_;
+    uint64_t max_reads_;
+    size_t window_;
+    std::vector<Packed> slots_;
+    std::vector<int> state_;
+    std::vector<std::thread> workers_;
+    std::mutex m_;
+    std::condition_variable cv_;
+    size_t next_ = 0, consumed_ = 0;
+    bool stop_ = false;
+};
+
 void check(simka_ctx *ctx, int rc, const char *what) {
     if (rc == SIMKA_OK) return;
     std::cout << "EXCEPTION: " << what << ": " << simka_last_error(ctx) << std::endl;
@@ -329,6 +391,20 @@ int main(int argc, char **argv) {
         else std::cout << "Reads per sample used: all" << std::endl << std::endl;
     }
 
+    const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
+    const unsigned nthreads = o.nb_cores > 0 ? (unsigned)o.nb_cores : hw;      // -nb-cores 0 = all (ref: src/core/Simka.cpp:88)
+    if (o.parse_only) {
+        SampleLoader loader(samples, o, max_reads, nthreads, nthreads + 2);
+        uint64_t bases = 0, reads = 0;
+        for (uint32_t i = 0; i < N; i++) {
+            Packed *pk0;
+            if (!loader.get(i, pk0)) die("ERROR: Can't open dataset: " + samples[i].id);
+            bases += pk0->nb_bases; reads += pk0->nb_reads;
+            loader.release(i);
+        }
+        std::cout << "parsed " << reads << " reads, " << bases << " bases with " << std::min<unsigned>(nthreads, N) << " threads" << std::endl;
+        return EXIT_SUCCESS;
+    }
     // contexts: one per GPU, partition space sharded
     const uint32_t G = (uint32_t)o.nb_gpus;
     std::vector<simka_ctx *> ctx(G, nullptr);
@@ -352,14 +428,17 @@ int main(int argc, char **argv) {
     // count (ref: SimkaPotaraAlgorithm::count, src/SimkaPotara.hpp:813-972)
     if (o.verbose) std::cout << "Counting k-mers... (log files are " << tmp << "/log/count_*)" << std::endl;
     std::vector<simka_sample_totals> totals(N);
-    Packed pk;
+    SampleLoader loader(samples, o, max_reads, nthreads, nthreads + 2);
     for (uint32_t i = 0; i < N; i++) {
-        if (!load_sample(samples[i], o, max_reads, pk)) die("ERROR: Can't open dataset: " + samples[i].id);
+        Packed *pkp;
+        if (!loader.get(i, pkp)) die("ERROR: Can't open dataset: " + samples[i].id);
+        Packed &pk = *pkp;
         simka_reads r;
         memset(&r, 0, sizeof r);
         r.packed = pk.words.data(); r.nb_bases = pk.nb_bases; r.nb_reads = pk.nb_frag; r.offsets = pk.offsets.data();
         r.fixed_len = 0; r.on_device = 0; r.nb_input_reads = pk.nb_reads;
         for (uint32_t g = 0; g < G; g++) check(ctx[g], simka_count_sample(ctx[g], i, &r), "simka_count_sample");
+        loader.release(i);     // host buffers may be reused as soon as simka_count_sample returns
     }
     for (uint32_t i = 0; i < N; i++) {
         simka_sample_totals sum; memset(&sum, 0, sizeof sum);
