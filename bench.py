@@ -34,6 +34,9 @@ WORKLOADS = {
     # 1/10-scale C3 (same shape, 1M reads per sample)
     "c3_10": dict(n=100, reads=1_000_000, L=150, k=31, amin=2, simple=True,
                   desc="100 samples x 1M 150 bp reads (C3 at 1/10 read depth), k=31, -simple-dist"),
+    # BASELINE.json configs[4] shape at 1/50 read depth: the tiled (N > LDS tile) pair accumulator + -complex-dist
+    "c5_50": dict(n=500, reads=100_000, L=150, k=31, amin=2, simple=True, complex=True,
+                  desc="500 samples x 100k 150 bp reads (C5 at 1/50 read depth), k=31, -simple-dist -complex-dist"),
 }
 
 
@@ -135,7 +138,8 @@ def main():
     nb_bases = R * L
     kocc_per_sample = R * (L - k + 1)
 
-    ctx = simka_amd.SimkaContext(n, kmer_size=k, abundance_min=wl["amin"], simple_dist=wl["simple"], device=local,
+    ctx = simka_amd.SimkaContext(n, kmer_size=k, abundance_min=wl["amin"], simple_dist=wl["simple"],
+                                 complex_dist=wl.get("complex", False), device=local,
                                  shard_index=rank, shard_count=world, max_kmers_per_sample=kocc_per_sample,
                                  log2_partitions=args.log2_partitions)
 
@@ -143,8 +147,11 @@ def main():
         ctx.reset()
         for s in range(n):
             ctx.count_sample(s, reads[s].data_ptr(), nb_bases, R, fixed_len=L, on_device=True)
+        if wl.get("complex") and world > 1:        # -complex-dist terms need the GLOBAL per-sample totals inside the merge
+            sdist.allreduce_totals_device(ctx)
         ctx.merge()
-        sdist.allreduce_stats_device(ctx)          # one RCCL all-reduce of the flat u64 accumulators (no-op at N=1)
+        # one RCCL all-reduce of the flat u64 accumulators (no-op at N=1)
+        sdist.allreduce_stats_device(ctx, totals_already_reduced=bool(wl.get("complex")) and world > 1)
         st = ctx.stats()
         mats = st.matrices()
         return st, mats

@@ -221,9 +221,9 @@ static int set_lds_attr(simka_ctx *ctx) {
     HIPCHK(hipFuncSetAttribute((const void *)k_count_fast<K2F_TABLE_BIG>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
     HIPCHK(hipFuncSetAttribute((const void *)k_count_fast<K2F_TABLE_SMALL>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
     HIPCHK(hipFuncSetAttribute((const void *)k_group, hipFuncAttributeMaxDynamicSharedMemorySize, big));
-    HIPCHK(hipFuncSetAttribute((const void *)k_pairs<true, K4_BLOCK_BIG>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
-    HIPCHK(hipFuncSetAttribute((const void *)k_pairs<true, K4_BLOCK_SMALL>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
     HIPCHK(hipFuncSetAttribute((const void *)k_pairs<false, K4_BLOCK_BIG>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
+    HIPCHK(hipFuncSetAttribute((const void *)k_pairs<false, K4_BLOCK_SMALL>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
+    HIPCHK(hipFuncSetAttribute((const void *)k_pairs<true, K4_BLOCK_BIG>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
     return SIMKA_OK;
 }
 
@@ -724,17 +724,31 @@ SIMKA_EXPORT int simka_merge(simka_ctx *ctx) {
     pc.simple = (flags & SIMKA_DIST_SIMPLE) ? 1u : 0u;
     pc.nb_pairs = (uint64_t)N * (N - 1) / 2;
     pc.tot_n = (const ull *)ctx->d_stats + stats_off_tot(N, flags, SIMKA_TOT_N);   // GLOBAL N_i: all-reduced by the caller when sharded
-    const size_t lds_fixed = SIMKA_LDS_HEAD + (size_t)K3_CAP * 8 + (size_t)K3_CAP * 4 + (size_t)(K3_CAP + 1) * 4 + 64 + 64;
-    const size_t lds_budget = 160 * 1024 - lds_fixed;
-    const uint64_t max_cells = lds_budget / (4 * pc.nacc32 + 8 * pc.nacc64);
-    if (pc.nb_pairs <= max_cells) { pc.tile = N; pc.ntiles = 1; pc.ncell = (uint32_t)pc.nb_pairs; }
-    else {
+    // LDS of k_pairs: head | packed cells | ent | (complex: p, p ln p, tile N table) | gdesc | gpref | tmp | (tiled: gdescB, epre, idxA, idxB)
+    // The span capacity EC (entries staged per iteration) takes what the cells leave: longer spans amortise the per-span cost.
+    const bool cplx = pc.nacc64 != 0;
+    auto lds_single = [&](size_t ec) { return SIMKA_LDS_HEAD + ec * 8 + (cplx ? ec * 16 + SIMKA_PAIR_TN * 8 : 0) + (ec / 2) * 4 + (ec / 2 + 2) * 4 + 32 * 4 + 64; };
+    auto lds_tiled = [&](size_t ec) { return lds_single(ec) + (ec / 2) * 4 + (ec + 2) * 4 + ec * 4; };
+    const size_t lds_max = 160 * 1024;
+    const size_t cell_bytes = 4 * pc.nacc32 + 8 * pc.nacc64;
+    size_t lds_fixed;
+    if (lds_single(K3_CAP) + (pc.nb_pairs + 4) * cell_bytes <= lds_max && (!cplx || N <= SIMKA_PAIR_TN)) {
+        pc.tile = N; pc.ntiles = 1; pc.ncell = (uint32_t)pc.nb_pairs;
+        pc.span_cap = K3_CAP;
+        const uint32_t span_max = N <= 32 ? 2 * K3_CAP : SIMKA_SPAN_MAX;      // few samples: small blocks, several per CU
+        while (pc.span_cap + K3_CAP <= span_max && lds_single(pc.span_cap + K3_CAP) + (pc.nb_pairs + 4) * cell_bytes <= lds_max) pc.span_cap += K3_CAP;
+        lds_fixed = lds_single(pc.span_cap);
+    } else {
+        pc.span_cap = 2 * K3_CAP;       // tiled: larger spans cost tile edge (more tile pairs replaying the spans)
+        lds_fixed = lds_tiled(pc.span_cap);
+        const uint64_t max_cells = (lds_max - lds_fixed) / cell_bytes - 4;     // ncell_pad rounds up to a multiple of 4
         uint32_t T = 1; while ((uint64_t)(T + 1) * (T + 1) <= max_cells) T++;
+        if (cplx && T > SIMKA_PAIR_TN / 2) T = SIMKA_PAIR_TN / 2;
         pc.tile = T; pc.ntiles = (N + T - 1) / T; pc.ncell = T * T;
     }
     pc.ncell_pad = (pc.ncell + 3u) & ~3u;
     const uint32_t ntp = pc.ntiles * (pc.ntiles + 1) / 2;
-    const size_t lds_pairs = lds_fixed + (size_t)pc.ncell_pad * (4 * pc.nacc32 + 8 * pc.nacc64);
+    const size_t lds_pairs = lds_fixed + (size_t)pc.ncell_pad * cell_bytes;
     const bool small_block = pc.ntiles == 1 && N <= 32;     // few pairs per span: more, smaller blocks
     const uint32_t per_cu = (uint32_t)std::min<size_t>(small_block ? 6 : 2, std::max<size_t>(1, (160 * 1024) / lds_pairs));
     const uint32_t nblk = (uint32_t)ctx->num_cus * per_cu;
@@ -747,7 +761,7 @@ SIMKA_EXPORT int simka_merge(simka_ctx *ctx) {
     in.foff = ctx->d_foff; in.fcnt = ctx->d_fcnt; in.nb_samples = N; in.nparts = nparts;
     SimkaCsrOut co;
     co.entries = ctx->d_entries; co.groups = ctx->d_groups; co.spans = ctx->d_spans; co.cursors = ctx->d_cursors;
-    co.cap_entries = csr_cap; co.cap_groups = csr_cap; co.cap_spans = span_cap; co.glob = (ull *)ctx->d_stats; co.err = ctx->d_err;
+    co.cap_entries = csr_cap; co.cap_groups = csr_cap; co.cap_spans = span_cap; co.span_cap = pc.span_cap; co.glob = (ull *)ctx->d_stats; co.err = ctx->d_err;
     const uint32_t min_share = 2;   // -complex-dist would need 1 (ref: src/SimkaMerge.cpp:1317)
     const size_t lds_group = SIMKA_LDS_HEAD + (size_t)K3_TABLE * 8 + (size_t)K3_CAP * 8 + (size_t)K3_TABLE * 8 + (size_t)K3_CAP * 2;
     ull *acc = (ull *)ctx->d_stats + stats_off_acc(N, 0);
@@ -771,13 +785,13 @@ SIMKA_EXPORT int simka_merge(simka_ctx *ctx) {
             });
             launch_timed(ctx, KID_PAIRS, [&] {
                 if (small_block)
-                    hipLaunchKernelGGL((k_pairs<true, K4_BLOCK_SMALL>), dim3(nblk, ntp), dim3(K4_BLOCK_SMALL), lds_pairs, ctx->stream, ctx->d_spans,
+                    hipLaunchKernelGGL((k_pairs<false, K4_BLOCK_SMALL>), dim3(nblk, ntp), dim3(K4_BLOCK_SMALL), lds_pairs, ctx->stream, ctx->d_spans,
                                        ctx->d_cursors, ctx->d_entries, ctx->d_groups, pc, acc, ctx->d_slabs);
                 else if (pc.ntiles == 1)
-                    hipLaunchKernelGGL((k_pairs<true, K4_BLOCK_BIG>), dim3(nblk, ntp), dim3(K4_BLOCK_BIG), lds_pairs, ctx->stream, ctx->d_spans,
+                    hipLaunchKernelGGL((k_pairs<false, K4_BLOCK_BIG>), dim3(nblk, ntp), dim3(K4_BLOCK_BIG), lds_pairs, ctx->stream, ctx->d_spans,
                                        ctx->d_cursors, ctx->d_entries, ctx->d_groups, pc, acc, ctx->d_slabs);
                 else
-                    hipLaunchKernelGGL((k_pairs<false, K4_BLOCK_BIG>), dim3(nblk, ntp), dim3(K4_BLOCK_BIG), lds_pairs, ctx->stream, ctx->d_spans,
+                    hipLaunchKernelGGL((k_pairs<true, K4_BLOCK_BIG>), dim3(nblk, ntp), dim3(K4_BLOCK_BIG), lds_pairs, ctx->stream, ctx->d_spans,
                                        ctx->d_cursors, ctx->d_entries, ctx->d_groups, pc, acc, ctx->d_slabs);
             });
         }

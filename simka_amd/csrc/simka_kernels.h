@@ -31,11 +31,11 @@
 #endif
 // K3  k_regroup / k_group
 #define K3_BLOCK 256
-#define K3_CAP 1024           // records hashed per round
+#define K3_CAP 1024           // records hashed per round = entries per span
 #define K3_TABLE 2048         // = 2*K3_CAP slots
 #define K3_UNROLL 4           // K3_BLOCK*K3_UNROLL = K3_CAP: a whole sub-range in one batch of independent loads
-#define K3_SLAB_ENT 8192      // CSR entries / groups / span slots reserved per global atomic by a k_group block
-#define K3_SLAB_GRP 4096
+#define K3_SLAB_ENT 32768     // CSR entries / groups / span slots reserved per global atomic by a k_group block
+#define K3_SLAB_GRP 16384
 #define K3_SLAB_SPAN 32
 // K4  k_pairs
 #define K4_BLOCK_BIG 1024
@@ -127,9 +127,13 @@ struct SimkaCsrOut {
     SimkaSpan *spans;
     unsigned long long *cursors;             // [0] entries, [1] groups, [2] spans
     unsigned long long cap_entries, cap_groups, cap_spans;
+    uint32_t span_cap;                       // a span grows up to this many entries (SimkaPairCfg::span_cap)
     unsigned long long *glob;                // [0] nb distinct k-mers, [1] nb shared k-mers
     uint32_t *err;
 };
+
+#define SIMKA_SPAN_MAX 4096        // largest span (entries) k_group may build / k_pairs can stage
+#define SIMKA_PAIR_TN 256          // k_pairs, complex: LDS table of per-sample N (one tile, or tile I + tile J)
 
 struct SimkaPairCfg {
     uint32_t nb_samples;
@@ -139,6 +143,7 @@ struct SimkaPairCfg {
     uint32_t nacc64;             // 0 or 2 (complex): u64 LDS cells
     uint32_t simple;             // chord/hell present
     uint32_t ncell, ncell_pad;   // LDS cells per accumulator
+    uint32_t span_cap;           // entries per span (multiple of K3_CAP, <= SIMKA_SPAN_MAX)
     uint64_t nb_pairs;           // N(N-1)/2
     const unsigned long long *tot_n;   // [N] per-sample N_i (GLOBAL totals), complex only
 };

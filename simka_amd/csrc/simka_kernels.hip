@@ -753,6 +753,11 @@ k_group(const ull *mkeys, const ull *mvals, const uint32_t *fb_off, uint32_t nfb
     uint32_t &s_maxc = *(uint32_t *)(smem + 84);
     uint32_t *tmp = (uint32_t *)(smem + 96);               // [K3_BLOCK/64]
     uint32_t *s_stack = (uint32_t *)(smem + 128);          // [2*24]
+    ull &s_open = *(ull *)(smem + 336);                    // slot of the block's open span (~0: none)
+    uint32_t &s_open_nent = *(uint32_t *)(smem + 344);     // its entries / groups / largest count so far
+    uint32_t &s_open_ngrp = *(uint32_t *)(smem + 348);
+    uint32_t &s_open_maxc = *(uint32_t *)(smem + 352);
+    uint32_t &s_soff = *(uint32_t *)(smem + 356);          // entry offset of this round inside its span
     ull *tkeys = (ull *)(smem + SIMKA_LDS_HEAD);           // [K3_TABLE]
     ull *rval = tkeys + K3_TABLE;                          // [K3_CAP]
     uint32_t *scnt = (uint32_t *)(rval + K3_CAP);          // [K3_TABLE] group size
@@ -762,7 +767,7 @@ k_group(const ull *mkeys, const ull *mvals, const uint32_t *fb_off, uint32_t nfb
     const uint32_t tid = threadIdx.x;
     const uint32_t free_bits = cfg.W - cfg.pb - cfg.t;     // bits left to split an over-full sub-range
     if (tid < 6) s_slab[tid] = 0;
-    if (tid == 0) { s_ndist = 0; s_nshared = 0; }
+    if (tid == 0) { s_ndist = 0; s_nshared = 0; s_open = ~0ull; s_open_nent = 0; s_open_ngrp = 0; s_open_maxc = 0; }
     __syncthreads();
 
     for (uint32_t fb = blockIdx.x; fb < nfb; fb += gridDim.x) {
@@ -852,25 +857,32 @@ k_group(const ull *mkeys, const ull *mvals, const uint32_t *fb_off, uint32_t nfb
                 const uint32_t nent = tot & 0xfffffu, ngrp = tot >> 20;
                 if (ngrp == 0) continue;
                 if (tid == 0) {
-                    // slab reservations: one global atomic per K3_SLAB_* items
-                    uint32_t ok = 1;
-                    if (s_slab[0] + nent > s_slab[1]) { s_slab[0] = atomicAdd(&o.cursors[0], (ull)K3_SLAB_ENT); s_slab[1] = s_slab[0] + K3_SLAB_ENT; if (s_slab[1] > o.cap_entries) ok = 0; }
-                    if (s_slab[2] + ngrp > s_slab[3]) { s_slab[2] = atomicAdd(&o.cursors[1], (ull)K3_SLAB_GRP); s_slab[3] = s_slab[2] + K3_SLAB_GRP; if (s_slab[3] > o.cap_groups) ok = 0; }
-                    if (s_slab[4] + 1 > s_slab[5]) { s_slab[4] = atomicAdd(&o.cursors[2], (ull)K3_SLAB_SPAN); s_slab[5] = s_slab[4] + K3_SLAB_SPAN; if (s_slab[5] > o.cap_spans) ok = 0; }
+                    // slab reservations: one global atomic per K3_SLAB_* items.  A round whose output lands right behind the
+                    // block's open span (same slabs) EXTENDS that span up to o.span_cap entries: k_pairs pays its per-span
+                    // overhead (scans, barriers, pair-range search) once per span, so longer spans are cheaper.
+                    uint32_t ok = 1, fresh = 0;
+                    if (s_slab[0] + nent > s_slab[1]) { s_slab[0] = atomicAdd(&o.cursors[0], (ull)K3_SLAB_ENT); s_slab[1] = s_slab[0] + K3_SLAB_ENT; fresh = 1; if (s_slab[1] > o.cap_entries) ok = 0; }
+                    if (s_slab[2] + ngrp > s_slab[3]) { s_slab[2] = atomicAdd(&o.cursors[1], (ull)K3_SLAB_GRP); s_slab[3] = s_slab[2] + K3_SLAB_GRP; fresh = 1; if (s_slab[3] > o.cap_groups) ok = 0; }
+                    const bool extend = !fresh && s_open != ~0ull && s_open_nent + nent <= o.span_cap && s_open_ngrp + ngrp <= o.span_cap / 2u;
+                    if (!extend && s_slab[4] + 1 > s_slab[5]) { s_slab[4] = atomicAdd(&o.cursors[2], (ull)K3_SLAB_SPAN); s_slab[5] = s_slab[4] + K3_SLAB_SPAN; if (s_slab[5] > o.cap_spans) ok = 0; }
                     if (!ok) { atomicOr(o.err, SIMKA_DEVERR_CSR_FULL); s_ovf = 2; }
                     else {
-                        SimkaSpan sp; sp.ebase = s_slab[0]; sp.gbase = s_slab[2]; sp.nent = nent; sp.ngrp = ngrp; sp.maxc = s_maxc; sp.pad = 0;
-                        o.spans[s_slab[4]] = sp;
+                        if (!extend) { s_open = s_slab[4]; s_slab[4] += 1; s_open_nent = 0; s_open_ngrp = 0; s_open_maxc = 0; }
+                        s_soff = s_open_nent;
                         s_ebase = s_slab[0]; s_gbase = s_slab[2];
-                        s_slab[0] += nent; s_slab[2] += ngrp; s_slab[4] += 1;
+                        s_open_nent += nent; s_open_ngrp += ngrp; s_open_maxc = s_maxc > s_open_maxc ? s_maxc : s_open_maxc;
+                        SimkaSpan sp; sp.ebase = s_slab[0] - s_soff; sp.gbase = s_slab[2] - (s_open_ngrp - ngrp); sp.nent = s_open_nent; sp.ngrp = s_open_ngrp; sp.maxc = s_open_maxc; sp.pad = 0;
+                        o.spans[s_open] = sp;
+                        s_slab[0] += nent; s_slab[2] += ngrp;
                     }
                 }
                 __syncthreads();
                 if (s_ovf == 2) continue;
                 const ull eb = s_ebase, gb = s_gbase;
+                const uint32_t soff = s_soff;
                 for (uint32_t i = tid; i < K3_TABLE; i += K3_BLOCK) {
                     const uint32_t c = scnt[i];
-                    if (c >= min_share) o.groups[gb + (gpk[i] >> 20)] = ((gpk[i] & 0xfffffu) << 16) | c;
+                    if (c >= min_share) o.groups[gb + (gpk[i] >> 20)] = (((gpk[i] & 0xfffffu) + soff) << 16) | c;    // start is relative to the span
                 }
                 __syncthreads();
                 for (uint32_t i = tid; i < K3_TABLE; i += K3_BLOCK) gpk[i] &= 0xfffffu;   // now: entry offset, advanced as fill cursor
@@ -933,138 +945,234 @@ __device__ __forceinline__ uint32_t pair_isqrt(ull x) {
     return r;
 }
 
-// fold the block's private LDS accumulators into its slab row and zero them
+// LDS cells of the 32-bit accumulators are PACKED two per u64 -- (S_ij | S_ji<<32), (a | bc<<32), (chord | hell<<32) --
+// so one non-returning ds_add_u64 feeds two accumulators.  Every half stays < 2^32 between flushes (`bound`), so the
+// low half never carries into the high one.
+// fold the block's private LDS accumulators into its slab row ([nacc][ncell_pad] u64) and zero them
 template <int K4_BLOCK>
-__device__ __forceinline__ void pairs_flush(uint32_t *lacc, ull *lacc64, ull *slab, const SimkaPairCfg &pc) {
+__device__ __forceinline__ void pairs_flush(ull *pk, ull *c64, ull *slab, const SimkaPairCfg &pc) {
     __syncthreads();
-    for (uint32_t i = threadIdx.x; i < pc.nacc32 * pc.ncell_pad; i += K4_BLOCK) { const uint32_t v = lacc[i]; if (v) { slab[i] += v; lacc[i] = 0; } }
-    for (uint32_t i = threadIdx.x; i < pc.nacc64 * pc.ncell_pad; i += K4_BLOCK) { const ull v = lacc64[i]; if (v) { slab[(size_t)pc.nacc32 * pc.ncell_pad + i] += v; lacc64[i] = 0; } }
+    const uint32_t CP = pc.ncell_pad, npk = pc.nacc32 >> 1;
+    for (uint32_t a = 0; a < npk; a++)
+        for (uint32_t c = threadIdx.x; c < CP; c += K4_BLOCK) {
+            const ull v = pk[a * CP + c];
+            if (v) { slab[(2u * a) * CP + c] += (uint32_t)v; slab[(2u * a + 1u) * CP + c] += v >> 32; pk[a * CP + c] = 0; }
+        }
+    for (uint32_t i = threadIdx.x; i < pc.nacc64 * CP; i += K4_BLOCK) { const ull v = c64[i]; if (v) { slab[(size_t)pc.nacc32 * CP + i] += v; c64[i] = 0; } }
     __syncthreads();
 }
 
+// TILED=false: all N(N-1)/2 cells live in LDS (one "tile" = every sample).  TILED=true: block row blockIdx.y owns the
+// sample-tile pair (I<=J); each span's entries are COMPACTED to the members of tile I (list A) and tile J (list B) with
+// one packed block scan, so a block enumerates exactly the pairs it owns (A x A triangle on the diagonal, A x B
+// rectangle off it) instead of filtering all of them.
 // K4_BLOCK: 1024 threads when the (i,j) space is large (many pairs per span), 256 for few samples
-template <bool SINGLE, int K4_BLOCK>
+template <bool TILED, int K4_BLOCK>
 __global__ void __launch_bounds__(K4_BLOCK)
 k_pairs(const SimkaSpan *spans, const ull *cursors, const ull *entries, const uint32_t *groups, SimkaPairCfg pc,
         ull *acc, ull *slabs) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    ull *lacc64 = (ull *)(smem + SIMKA_LDS_HEAD);               // [nacc64][ncell_pad]  (whit, klfix)
-    uint32_t *lacc = (uint32_t *)(lacc64 + (size_t)pc.nacc64 * pc.ncell_pad);   // [nacc32][ncell_pad]
-    ull *ent = (ull *)(lacc + (size_t)pc.nacc32 * pc.ncell_pad);  // [K3_CAP]
-    uint32_t *gdesc = (uint32_t *)(ent + K3_CAP);               // [K3_CAP]   (start<<16 | size)
-    uint32_t *gpref = gdesc + K3_CAP;                           // [K3_CAP+1] pair prefix
-    uint32_t *tmp = gpref + K3_CAP + 1;                         // [K4_BLOCK/64]
+    const uint32_t CP = pc.ncell_pad, npk = pc.nacc32 >> 1;
+    const bool cplx = pc.nacc64 != 0;
+    ull *pk = (ull *)(smem + SIMKA_LDS_HEAD);                    // [npk][CP]     packed u32 pairs
+    ull *c64 = pk + (size_t)npk * CP;                            // [nacc64][CP]  (whit, klfix)
+    // a span holds <= EC = pc.span_cap entries in <= GC = EC/2 groups (every group has >= 2 entries)
+    const uint32_t EC = pc.span_cap, GC = EC / 2u;
+    ull *ent = c64 + (size_t)pc.nacc64 * CP;                     // [EC]          (sample<<32 | count)
+    double *ep = (double *)(ent + EC);                           // [EC]          complex: p = c / N_sample
+    double *eplp = ep + (cplx ? EC : 0);                         // [EC]          complex: p * ln p
+    double *tn = eplp + (cplx ? EC : 0);                         // [SIMKA_PAIR_TN] complex: N of the samples of tile I, then tile J
+    uint32_t *gdesc = (uint32_t *)(tn + (cplx ? SIMKA_PAIR_TN : 0));   // [GC]      list A of the group: (start<<16 | size)
+    uint32_t *gpref = gdesc + GC;                                // [GC+2]        pair prefix
+    uint32_t *tmp = gpref + GC + 2;                              // [32]
+    uint32_t *gdescB = tmp + 32;                                 // tiled: [GC]   list B of the group
+    uint32_t *epre = gdescB + GC;                                // tiled: [EC+2] packed scan of the tile-membership flags
+    uint16_t *idxA = (uint16_t *)(epre + EC + 2);                // tiled: [EC]   entry indices of tile I members
+    uint16_t *idxB = idxA + EC;                                  // tiled: [EC]   entry indices of tile J members
 
     const uint32_t tid = threadIdx.x;
-    const uint32_t N = pc.nb_samples, T = pc.tile, CP = pc.ncell_pad;
-    uint32_t I = 0, J = 0;                                      // tile pair (I<=J) of this block row
-    if (!SINGLE) {
+    const uint32_t N = pc.nb_samples, T = pc.tile;
+    uint32_t I = 0, J = 0;                                       // tile pair (I<=J) of this block row
+    if (TILED) {
         uint32_t r = blockIdx.y;
         for (I = 0; I < pc.ntiles; I++) { const uint32_t row = pc.ntiles - I; if (r < row) { J = I + r; break; } r -= row; }
     }
-    for (uint32_t i = tid; i < pc.nacc32 * CP; i += K4_BLOCK) lacc[i] = 0;
-    for (uint32_t i = tid; i < pc.nacc64 * CP; i += K4_BLOCK) lacc64[i] = 0;
+    const bool rect = TILED && I != J;
+    const uint32_t baseI = I * T, baseJ = J * T;
+    const uint32_t TD = TILED ? T : N;                           // edge of the triangular cell index
+    for (uint32_t i = tid; i < npk * CP; i += K4_BLOCK) pk[i] = 0;
+    for (uint32_t i = tid; i < pc.nacc64 * CP; i += K4_BLOCK) c64[i] = 0;
+    if (cplx) {
+        for (uint32_t i = tid; i < TD; i += K4_BLOCK) {
+            tn[i] = (baseI + i < N) ? (double)pc.tot_n[baseI + i] : 1.0;
+            if (rect) tn[T + i] = (baseJ + i < N) ? (double)pc.tot_n[baseJ + i] : 1.0;
+        }
+    }
     ull *slab = slabs + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * pc.nacc * CP;
-    // every LDS cell is a u32 fed by NON-returning atomics: a cell receives at most one add per group, so
+    // every packed half is fed by NON-returning atomics and receives at most one add per group, so
     // `bound` (sum over spans of #groups x largest count) < 2^32 guarantees no wrap; flush before it could.
     ull bound = 0, bound_q = 0;      // bound_q: same for the chord products (#groups x maxcount^2)
-    __syncthreads();
 
     const ull nspans = cursors[2];
-    for (ull sp = blockIdx.x; sp < nspans; sp += gridDim.x) {
-        const SimkaSpan span = spans[sp];
-        if (span.ngrp == 0) continue;     // unused slot of a k_group span slab
-        const ull add = (ull)span.ngrp * (ull)span.maxc;
-        const ull addq = (ull)span.ngrp * (ull)span.maxc * (ull)span.maxc;
-        // chord: non-returning adds as long as the span's products cannot wrap a cell; else the carry path (returning atomic)
-        const bool chord_fast = span.maxc < 46341u && addq < 0xffffffffull;
-        if (bound + add >= 0xffffffffull || (chord_fast && bound_q + addq >= 0xffffffffull)) { pairs_flush<K4_BLOCK>(lacc, lacc64, slab, pc); bound = 0; bound_q = 0; }
+    // software pipeline over this block's spans: descriptor two iterations ahead, entries/groups one iteration ahead
+    // (registers), so the global-load latency of span i+1 hides behind the pair loop of span i.
+    // A span has <= SIMKA_SPAN_MAX entries: up to 4 per thread for 1024-thread blocks, 16 for 256-thread ones.
+    constexpr int EPT = (SIMKA_SPAN_MAX + K4_BLOCK - 1) / K4_BLOCK;     // entries (and group descriptors) per thread
+    SimkaSpan span, nspan;
+    span.ngrp = 0; span.nent = 0; nspan.ngrp = 0; nspan.nent = 0;
+    ull sp = blockIdx.x;
+    if (sp < nspans) span = spans[sp];
+    if (sp + gridDim.x < nspans) nspan = spans[sp + gridDim.x];
+    ull pre_e[EPT]; uint32_t pre_g[EPT];
+#pragma unroll
+    for (int q = 0; q < EPT; q++) {
+        const uint32_t i = tid + (uint32_t)q * K4_BLOCK;
+        pre_e[q] = (i < span.nent) ? entries[span.ebase + i] : 0ull;
+        pre_g[q] = (i < span.ngrp) ? groups[span.gbase + i] : 0u;
+    }
+    for (; sp < nspans; sp += gridDim.x) {
+        // ---- current span: registers -> LDS
+        __syncthreads();
+        const SimkaSpan cur = span;
+#pragma unroll
+        for (int q = 0; q < EPT; q++) {
+            const uint32_t i = tid + (uint32_t)q * K4_BLOCK;
+            if (i < cur.nent) {
+                const ull e = pre_e[q];
+                ent[i] = e;
+                const uint32_t si = (uint32_t)(e >> 32);
+                uint32_t fl = 0, loc = si;                       // membership flags (A | B<<16), index into tn
+                if (TILED) {
+                    const uint32_t li = si - baseI, lj = si - baseJ;
+                    if (li < T) { fl = 1u; loc = li; }
+                    else if (rect && lj < T) { fl = 1u << 16; loc = T + lj; }
+                    epre[i] = fl;
+                }
+                if (cplx && (!TILED || fl)) {
+                    const double p = (double)(uint32_t)e / tn[loc];
+                    ep[i] = p; eplp[i] = p * log(p);
+                }
+            }
+            if (i < cur.ngrp) { gdesc[i] = pre_g[q]; if (!TILED) { const uint32_t s_ = pre_g[q] & 0xffffu; gpref[i] = s_ * (s_ - 1u) / 2u; } }
+        }
+        // ---- issue the loads of the next span, fetch the descriptor after it
+        span = nspan;
+        nspan.ngrp = 0; nspan.nent = 0;
+        if (sp + 2 * (ull)gridDim.x < nspans) nspan = spans[sp + 2 * (ull)gridDim.x];
+#pragma unroll
+        for (int q = 0; q < EPT; q++) {
+            const uint32_t i = tid + (uint32_t)q * K4_BLOCK;
+            pre_e[q] = (i < span.nent) ? entries[span.ebase + i] : 0ull;
+            pre_g[q] = (i < span.ngrp) ? groups[span.gbase + i] : 0u;
+        }
+        if (cur.ngrp == 0) continue;     // unused slot of a k_group span slab (uniform)
+        const ull add = (ull)cur.ngrp * (ull)cur.maxc;
+        const ull addq = (ull)cur.ngrp * (ull)cur.maxc * (ull)cur.maxc;
+        // chord: packed non-returning adds as long as the span's products cannot wrap a half cell; else straight into the global u64 cell
+        const bool chord_fast = cur.maxc < 46341u && addq < 0xffffffffull;
+        if (bound + add >= 0xffffffffull || (chord_fast && bound_q + addq >= 0xffffffffull)) { pairs_flush<K4_BLOCK>(pk, c64, slab, pc); bound = 0; bound_q = 0; }
         bound += add;
         if (chord_fast) bound_q += addq;
-        for (uint32_t i = tid; i < span.nent; i += K4_BLOCK) ent[i] = entries[span.ebase + i];
-        for (uint32_t i = tid; i < span.ngrp; i += K4_BLOCK) {
-            const uint32_t d = groups[span.gbase + i];
-            gdesc[i] = d;
-            const uint32_t s_ = d & 0xffffu;
-            gpref[i] = s_ * (s_ - 1u) / 2u;
-        }
         __syncthreads();
-        const uint32_t P = block_excl_scan<K4_BLOCK>(gpref, span.ngrp, tmp);
-        if (tid == 0) gpref[span.ngrp] = P;
+        if (TILED) {
+            // compact the tile members: one scan of the packed flags gives every entry its slot in list A / list B
+            const uint32_t tot = block_excl_scan<K4_BLOCK>(epre, cur.nent, tmp);
+            if (tid == 0) epre[cur.nent] = tot;
+#pragma unroll
+            for (int q = 0; q < EPT; q++) {
+                const uint32_t i = tid + (uint32_t)q * K4_BLOCK;
+                if (i < cur.nent) {
+                    const uint32_t si = (uint32_t)(ent[i] >> 32);
+                    const uint32_t pos = epre[i];
+                    if (si - baseI < T) idxA[pos & 0xffffu] = (uint16_t)i;
+                    else if (rect && si - baseJ < T) idxB[pos >> 16] = (uint16_t)i;
+                }
+            }
+            __syncthreads();
+#pragma unroll
+            for (int q = 0; q < EPT; q++) {
+                const uint32_t g = tid + (uint32_t)q * K4_BLOCK;
+                if (g < cur.ngrp) {
+                    const uint32_t d = gdesc[g];
+                    const uint32_t p0 = epre[d >> 16], p1 = epre[(d >> 16) + (d & 0xffffu)];
+                    const uint32_t a0 = p0 & 0xffffu, nA = (p1 & 0xffffu) - a0, b0 = p0 >> 16, nB = (p1 >> 16) - b0;
+                    gdesc[g] = (a0 << 16) | nA;
+                    gdescB[g] = (b0 << 16) | nB;
+                    gpref[g] = rect ? nA * nB : nA * (nA - 1u) / 2u;      // nA = 0 gives 0 either way (0 * 0xffffffff / 2 = 0)
+                }
+            }
+            __syncthreads();
+        }
+        const uint32_t P = block_excl_scan<K4_BLOCK>(gpref, cur.ngrp, tmp);
+        if (tid == 0) gpref[cur.ngrp] = P;
         __syncthreads();
         const uint32_t chunk = (P + K4_BLOCK - 1) / K4_BLOCK;
         uint32_t p = tid * chunk;
         const uint32_t pend = (p + chunk < P) ? p + chunk : P;
         if (p < pend) {
-            uint32_t lo = 0, hi = span.ngrp;    // largest g with gpref[g] <= p
+            uint32_t lo = 0, hi = cur.ngrp;    // largest g with gpref[g] <= p
             while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (gpref[mid] <= p) lo = mid; else hi = mid; }
             uint32_t g = lo;
-            while (g + 1 < span.ngrp && gpref[g + 1] <= p) g++;   // skip groups without pairs
+            while (g + 1 < cur.ngrp && gpref[g + 1] <= p) g++;   // skip groups without pairs
             uint32_t d = gdesc[g];
-            uint32_t gs = d >> 16, s_ = d & 0xffffu, x, y;
-            tri_unrank(p - gpref[g], s_, x, y);
-            ull ex = ent[gs + x];
+            uint32_t a0 = d >> 16, nA = d & 0xffffu, b0 = 0, nB = 0, x, y;
+            if (rect) {
+                const uint32_t dB = gdescB[g]; b0 = dB >> 16; nB = dB & 0xffffu;
+                const uint32_t r = p - gpref[g];
+                x = r / nB; y = r - x * nB;
+            } else tri_unrank(p - gpref[g], nA, x, y);
+            uint32_t ix = TILED ? (uint32_t)idxA[a0 + x] : a0 + x;
+            ull ex = ent[ix];
             for (; p < pend; p++) {
-                const ull ey = ent[gs + y];
+                const uint32_t iy = rect ? (uint32_t)idxB[b0 + y] : (TILED ? (uint32_t)idxA[a0 + y] : a0 + y);
+                const ull ey = ent[iy];
                 uint32_t si = (uint32_t)(ex >> 32), sj = (uint32_t)(ey >> 32);
                 uint32_t ci = (uint32_t)ex, cj = (uint32_t)ey;
-                if (si > sj) { uint32_t t_ = si; si = sj; sj = t_; t_ = ci; ci = cj; cj = t_; }
-                bool mine = true;
-                uint32_t cell;
-                if (SINGLE) cell = si * N - ((si * (si + 1u)) >> 1) + (sj - si - 1u);      // N <= 65535: fits 32 bits
-                else {
-                    const uint32_t ti = si / T, tj = sj / T;
-                    mine = (ti == I && tj == J);
-                    const uint32_t li = si - I * T, lj = sj - J * T;
-                    cell = (I == J) ? (li * T - ((li * (li + 1u)) >> 1) + (lj - li - 1u)) : li * T + lj;
+                // off-diagonal tiles: every member of A precedes every member of B.  Elsewhere order the pair.
+                if (!rect && si > sj) { uint32_t t_ = si; si = sj; sj = t_; t_ = ci; ci = cj; cj = t_; }
+                const uint32_t li = si - baseI, lj = sj - baseJ;
+                const uint32_t cell = rect ? li * T + lj : li * TD - ((li * (li + 1u)) >> 1) + (lj - li - 1u);   // TD <= 65535: fits 32 bits
+                atomicAdd(&pk[0 * CP + cell], (ull)ci | ((ull)cj << 32));                       // S_ij | S_ji
+                atomicAdd(&pk[1 * CP + cell], 1ull | ((ull)(ci < cj ? ci : cj) << 32));         // a | bc
+                if (pc.simple) {
+                    const ull prod = (ull)ci * (ull)cj;
+                    const ull hell = (ull)pair_isqrt(prod) << 32;
+                    if (chord_fast) atomicAdd(&pk[2 * CP + cell], (ull)(uint32_t)prod | hell);  // chord | hell
+                    else {   // huge counts: the product goes straight to the global u64 cell
+                        atomicAdd(&pk[2 * CP + cell], hell);
+                        atomicAdd(&acc[SIMKA_ACC_CHORD * pc.nb_pairs + simka_pair_index(si, sj, N)], prod);
+                    }
                 }
-                if (mine) {
-                    atomicAdd(&lacc[SIMKA_ACC_SIJ * CP + cell], ci);
-                    atomicAdd(&lacc[SIMKA_ACC_SJI * CP + cell], cj);
-                    atomicAdd(&lacc[SIMKA_ACC_A * CP + cell], 1u);
-                    atomicAdd(&lacc[SIMKA_ACC_BC * CP + cell], ci < cj ? ci : cj);
-                    if (pc.simple) {
-                        const ull prod = (ull)ci * (ull)cj;
-                        const uint32_t lo32 = (uint32_t)prod;
-                        if (chord_fast) atomicAdd(&lacc[SIMKA_ACC_CHORD * CP + cell], lo32);
-                        else {   // huge counts: a wrap of the low word (or a product >= 2^32) carries into the global u64 cell
-                            const uint32_t old = atomicAdd(&lacc[SIMKA_ACC_CHORD * CP + cell], lo32);
-                            if ((uint32_t)(old + lo32) < old || (prod >> 32)) {
-                                const ull pg = simka_pair_index(si, sj, N);
-                                atomicAdd(&acc[SIMKA_ACC_CHORD * pc.nb_pairs + pg], (((uint32_t)(old + lo32) < old) ? (1ull << 32) : 0ull) + ((prod >> 32) << 32));
-                            }
-                        }
-                        atomicAdd(&lacc[SIMKA_ACC_HELL * CP + cell], pair_isqrt(prod));
-                    }
-                    if (pc.nacc64) {
-                        // updateDistanceComplex restricted to both-present pairs (ref: src/core/SimkaAlgorithm.hpp:437-446,477-481);
-                        // the one-sided terms are closed forms of S / totals / count histograms, added on the host
-                        const double Ni = (double)pc.tot_n[si], Nj = (double)pc.tot_n[sj];
-                        const double ai = (double)ci, aj = (double)cj;
-                        const double xY = ai * Nj, yX = aj * Ni;
-                        const double dd = (ai / Ni) * log((2 * xY) / (xY + yX)) + (aj / Nj) * log((2 * yX) / (xY + yX));
-                        atomicAdd(&lacc64[1 * CP + cell], (ull)(long long)llrint(dd * SIMKA_KL_SCALE));
-                        const ull uX = (ull)xY, uY = (ull)yX;
-                        atomicAdd(&lacc64[0 * CP + cell], simka_whit_abs(uX - uY) - simka_whit_abs(uX) - simka_whit_abs(uY));
-                    }
+                if (cplx) {
+                    // updateDistanceComplex restricted to both-present pairs (ref: src/core/SimkaAlgorithm.hpp:437-446,477-481);
+                    // the one-sided terms are closed forms of S / totals / count histograms, added on the host.
+                    // KL: with p = ci/Ni, q = cj/Nj the reference's  p ln(2p/(p+q)) + q ln(2q/(p+q))  equals
+                    // p ln p + q ln q - (p+q) ln((p+q)/2): one logarithm per pair, the p ln p terms are per entry.
+                    const double h = ep[ix] + ep[iy];
+                    const double dd = eplp[ix] + eplp[iy] - h * log(h * 0.5);
+                    atomicAdd(&c64[1 * CP + cell], (ull)(long long)llrint(dd * SIMKA_KL_SCALE));
+                    const ull uX = (ull)((double)ci * tn[(rect ? T : 0u) + lj]), uY = (ull)((double)cj * tn[li]);
+                    atomicAdd(&c64[0 * CP + cell], simka_whit_abs(uX - uY) - simka_whit_abs(uX) - simka_whit_abs(uY));
                 }
                 // next pair of the span
                 y++;
-                if (y == s_) {
-                    x++; y = x + 1;
-                    if (y >= s_) {   // group exhausted
+                if (rect ? (y == nB) : (y == nA)) {
+                    x++; y = rect ? 0u : x + 1u;
+                    if (rect ? (x == nA) : (y >= nA)) {   // group exhausted
                         g++;
-                        while (g < span.ngrp && (gdesc[g] & 0xffffu) < 2u) g++;
-                        if (g >= span.ngrp) break;
-                        d = gdesc[g]; gs = d >> 16; s_ = d & 0xffffu; x = 0; y = 1;
+                        while (g < cur.ngrp && gpref[g + 1] == gpref[g]) g++;   // groups without pairs for this tile pair
+                        if (g >= cur.ngrp) break;
+                        d = gdesc[g]; a0 = d >> 16; nA = d & 0xffffu; x = 0; y = rect ? 0u : 1u;
+                        if (rect) { const uint32_t dB = gdescB[g]; b0 = dB >> 16; nB = dB & 0xffffu; }
                     }
-                    ex = ent[gs + x];
+                    ix = TILED ? (uint32_t)idxA[a0 + x] : a0 + x;
+                    ex = ent[ix];
                 }
             }
         }
-        __syncthreads();
     }
-    pairs_flush<K4_BLOCK>(lacc, lacc64, slab, pc);
+    __syncthreads();
+    pairs_flush<K4_BLOCK>(pk, c64, slab, pc);
 }
 
 // slabs[tilepair][block][acc][cell] -> acc[a][pair(i,j)]
