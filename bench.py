@@ -201,7 +201,7 @@ def main():
         "k_count_fast": 4.0 * K_occ * share + 12.0 * K_dist * share,
         "k_count": 0.0,
         "k_regroup": 12.0 * K_solid * share,
-        "k_group": 0.0, "k_pairs": 0.0, "k_layout": 0.0, "k_part_totals": 0.0, "k_reduce_slabs": 0.0,
+        "k_group": 0.0, "k_pairs": 0.0, "k_layout": 0.0, "k_part_totals": 0.0, "k_pairs_global": 0.0,
     }
     kern_ms = {kname: ms for kname, (cnt, ms) in prof.items()}
     total_kernel_ms = sum(kern_ms.values())

@@ -17,9 +17,9 @@
 
 // kernel ids for the profiler
 enum { KID_SCAN_HIST = 0, KID_LAYOUT, KID_SCAN_SCATTER, KID_SPLIT, KID_COUNT_FAST, KID_COUNT, KID_PART_TOTALS, KID_REGROUP, KID_GROUP,
-       KID_PAIRS, KID_REDUCE, KID_NB };
+       KID_PAIRS, KID_PAIRS_GLOBAL, KID_NB };
 static const char *const KID_NAMES[KID_NB] = { "k_scan<hist>", "k_layout", "k_scan<scatter>", "k_split", "k_count_fast", "k_count",
-                                               "k_part_totals", "k_regroup", "k_group", "k_pairs", "k_reduce_slabs" };
+                                               "k_part_totals", "k_regroup", "k_group", "k_pairs", "k_pairs_global" };
 
 static thread_local std::string g_create_error;
 
@@ -68,8 +68,8 @@ struct simka_ctx {
     // merge buffers
     ull *d_part_total = nullptr, *d_part_off = nullptr;
     ull *d_mkeys = nullptr, *d_mvals = nullptr, *d_entries = nullptr; uint32_t *d_groups = nullptr;
-    uint32_t *d_fb_off = nullptr; SimkaSpan *d_spans = nullptr; ull *d_cursors = nullptr; ull *d_slabs = nullptr;
-    uint64_t merge_cap = 0, fb_cap = 0, span_cap = 0, slab_words = 0;
+    uint32_t *d_fb_off = nullptr; SimkaSpan *d_spans = nullptr; ull *d_cursors = nullptr; SimkaSpan *d_huge = nullptr;
+    uint64_t merge_cap = 0, fb_cap = 0, span_cap = 0, huge_cap = 0;
     // -complex-dist: per-sample histogram of solid counts + list of the counts above the histogram
     ull *d_hist = nullptr; uint32_t *d_ovf_list = nullptr; ull *d_ovf_cursor = nullptr; uint64_t ovf_cap = 0;
 
@@ -370,7 +370,7 @@ SIMKA_EXPORT void simka_destroy(simka_ctx *ctx) {
     void *ptrs[] = { ctx->d_reads, ctx->d_offsets, ctx->d_l1_ovf, ctx->d_solid_keys, ctx->d_solid_counts, ctx->d_arena_cursor,
                      ctx->d_sample_base, ctx->d_foff, ctx->d_fcnt, ctx->d_stats, ctx->d_err, ctx->d_part_total,
                      ctx->d_part_off, ctx->d_mkeys, ctx->d_mvals, ctx->d_entries, ctx->d_groups, ctx->d_fb_off,
-                     ctx->d_spans, ctx->d_cursors, ctx->d_slabs, ctx->d_hist, ctx->d_ovf_list, ctx->d_ovf_cursor };
+                     ctx->d_spans, ctx->d_cursors, ctx->d_huge, ctx->d_hist, ctx->d_ovf_list, ctx->d_ovf_cursor };
     for (void *p : ptrs) if (p) (void)hipFree(p);
     if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
@@ -752,16 +752,16 @@ SIMKA_EXPORT int simka_merge(simka_ctx *ctx) {
     const bool small_block = pc.ntiles == 1 && N <= 32;     // few pairs per span: more, smaller blocks
     const uint32_t per_cu = (uint32_t)std::min<size_t>(small_block ? 6 : 2, std::max<size_t>(1, (160 * 1024) / lds_pairs));
     const uint32_t nblk = (uint32_t)ctx->num_cus * per_cu;
-    const uint64_t slab_words = (uint64_t)ntp * nblk * pc.nacc * pc.ncell_pad;
-    if (ctx->slab_words < slab_words) { if (ctx->d_slabs) HIPCHK(hipFree(ctx->d_slabs)); ctx->d_slabs = nullptr; HIPCHK(dev_alloc(&ctx->d_slabs, slab_words)); ctx->slab_words = slab_words; }
-    HIPCHK(hipMemsetAsync(ctx->d_slabs, 0, slab_words * 8, ctx->stream));
+    // k-mers shared by more than K3_CAP samples (possible only when N > K3_CAP) leave k_group on a list of their own
+    const uint64_t huge_cap = N > K3_CAP ? cap / K3_CAP + 16 : 1;
+    if (ctx->huge_cap < huge_cap) { if (ctx->d_huge) HIPCHK(hipFree(ctx->d_huge)); ctx->d_huge = nullptr; HIPCHK(dev_alloc(&ctx->d_huge, huge_cap)); ctx->huge_cap = huge_cap; }
 
     SimkaMergeIn in;
     in.solid_keys = ctx->d_solid_keys; in.solid_counts = ctx->d_solid_counts; in.sample_base = ctx->d_sample_base;
     in.foff = ctx->d_foff; in.fcnt = ctx->d_fcnt; in.nb_samples = N; in.nparts = nparts;
     SimkaCsrOut co;
     co.entries = ctx->d_entries; co.groups = ctx->d_groups; co.spans = ctx->d_spans; co.cursors = ctx->d_cursors;
-    co.cap_entries = csr_cap; co.cap_groups = csr_cap; co.cap_spans = span_cap; co.span_cap = pc.span_cap; co.glob = (ull *)ctx->d_stats; co.err = ctx->d_err;
+    co.cap_entries = csr_cap; co.cap_groups = csr_cap; co.cap_spans = span_cap; co.span_cap = pc.span_cap; co.huge = ctx->d_huge; co.cap_huge = huge_cap; co.glob = (ull *)ctx->d_stats; co.err = ctx->d_err;
     const uint32_t min_share = 2;   // -complex-dist would need 1 (ref: src/SimkaMerge.cpp:1317)
     const size_t lds_group = SIMKA_LDS_HEAD + (size_t)K3_TABLE * 8 + (size_t)K3_CAP * 8 + (size_t)K3_TABLE * 8 + (size_t)K3_CAP * 2;
     ull *acc = (ull *)ctx->d_stats + stats_off_acc(N, 0);
@@ -786,21 +786,21 @@ SIMKA_EXPORT int simka_merge(simka_ctx *ctx) {
             launch_timed(ctx, KID_PAIRS, [&] {
                 if (small_block)
                     hipLaunchKernelGGL((k_pairs<false, K4_BLOCK_SMALL>), dim3(nblk, ntp), dim3(K4_BLOCK_SMALL), lds_pairs, ctx->stream, ctx->d_spans,
-                                       ctx->d_cursors, ctx->d_entries, ctx->d_groups, pc, acc, ctx->d_slabs);
+                                       ctx->d_cursors, ctx->d_entries, ctx->d_groups, pc, acc);
                 else if (pc.ntiles == 1)
                     hipLaunchKernelGGL((k_pairs<false, K4_BLOCK_BIG>), dim3(nblk, ntp), dim3(K4_BLOCK_BIG), lds_pairs, ctx->stream, ctx->d_spans,
-                                       ctx->d_cursors, ctx->d_entries, ctx->d_groups, pc, acc, ctx->d_slabs);
+                                       ctx->d_cursors, ctx->d_entries, ctx->d_groups, pc, acc);
                 else
                     hipLaunchKernelGGL((k_pairs<true, K4_BLOCK_BIG>), dim3(nblk, ntp), dim3(K4_BLOCK_BIG), lds_pairs, ctx->stream, ctx->d_spans,
-                                       ctx->d_cursors, ctx->d_entries, ctx->d_groups, pc, acc, ctx->d_slabs);
+                                       ctx->d_cursors, ctx->d_entries, ctx->d_groups, pc, acc);
             });
+            if (N > K3_CAP)
+                launch_timed(ctx, KID_PAIRS_GLOBAL, [&] {
+                    hipLaunchKernelGGL(k_pairs_global, dim3(64, 64), dim3(256), 0, ctx->stream, ctx->d_huge, ctx->d_cursors, ctx->d_entries, pc, acc);
+                });
         }
         pb = pe;
     }
-    launch_timed(ctx, KID_REDUCE, [&] {
-        hipLaunchKernelGGL(k_reduce_slabs, dim3((pc.nacc * pc.ncell_pad + 255) / 256, ntp), dim3(256), 0, ctx->stream,
-                           ctx->d_slabs, nblk, pc, acc);
-    });
     HIPCHK(hipGetLastError());
     int rcd = check_device_error(ctx);
     if (rcd) return rcd;

@@ -125,8 +125,9 @@ struct SimkaCsrOut {
     unsigned long long *entries;             // (sample<<32 | count)
     uint32_t *groups;                        // (entry offset within span << 16 | size)
     SimkaSpan *spans;
-    unsigned long long *cursors;             // [0] entries, [1] groups, [2] spans
-    unsigned long long cap_entries, cap_groups, cap_spans;
+    SimkaSpan *huge;                         // groups shared by more than K3_CAP samples, one span each (k_pairs_global)
+    unsigned long long *cursors;             // [0] entries, [1] groups, [2] spans, [3] huge spans
+    unsigned long long cap_entries, cap_groups, cap_spans, cap_huge;
     uint32_t span_cap;                       // a span grows up to this many entries (SimkaPairCfg::span_cap)
     unsigned long long *glob;                // [0] nb distinct k-mers, [1] nb shared k-mers
     uint32_t *err;

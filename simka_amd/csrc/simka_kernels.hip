@@ -16,7 +16,7 @@
 //   k_regroup : gather one partition's records from the N samples, order them by sub-range
 //   k_group   : per sub-range LDS hash grouping -> CSR groups (k-mer -> [(sample,count)...])
 //   k_pairs   : persistent blocks, LDS-privatised pair accumulators, all s(s-1)/2 pairs per group
-//   k_reduce_slabs : per-block partial accumulators -> the flat u64 statistics buffer
+//   k_pairs_global : the same for k-mers shared by more samples than one span holds (global u64 atomics)
 //
 // Everything is integer work on HBM / LDS; no MFMA.  Block sizes are multiples of the 64-lane
 // wavefront; every global access pattern that carries real traffic is a contiguous run.
@@ -830,7 +830,33 @@ k_group(const ull *mkeys, const ull *mvals, const uint32_t *fb_off, uint32_t nfb
                 if ((tid & 63u) == 0 && mymax) atomicMax(&s_maxc, mymax);
                 __syncthreads();
                 if (s_ovf) {
-                    if (e >= free_bits) { if (tid == 0) atomicOr(o.err, SIMKA_DEVERR_GROUP_OVERFLOW); break; }
+                    if (e >= free_bits) {
+                        // Every key bit is fixed: the selected records are ONE k-mer shared by more than K3_CAP samples.  Such a
+                        // group cannot be staged in LDS; it becomes a span of its own on the huge list (k_pairs_global).
+                        const uint32_t s_ = s_nrec;
+                        __syncthreads();
+                        if (tid == 0) {
+                            const ull eb_ = atomicAdd(&o.cursors[0], (ull)s_), hs = atomicAdd(&o.cursors[3], 1ull);
+                            if (eb_ + s_ > o.cap_entries || hs >= o.cap_huge) { atomicOr(o.err, SIMKA_DEVERR_CSR_FULL); s_ovf = 2; }
+                            else {
+                                SimkaSpan sp; sp.ebase = eb_; sp.gbase = 0; sp.nent = s_; sp.ngrp = 1; sp.maxc = 0; sp.pad = 0;
+                                o.huge[hs] = sp;
+                                s_ebase = eb_; s_ndist++; s_nshared++;
+                            }
+                            s_nrec = 0;      // now the fill cursor
+                        }
+                        __syncthreads();
+                        if (s_ovf != 2) {
+                            const ull eb_ = s_ebase;
+                            for (uint32_t i = rb + tid; i < re; i += K3_BLOCK) {
+                                const ull key = mkeys[i];
+                                if (key == SIMKA_EMPTY_KEY) continue;
+                                if (e && (uint32_t)((key >> selshift) & ((1ull << e) - 1ull)) != val) continue;
+                                o.entries[eb_ + atomicAdd(&s_nrec, 1u)] = mvals[i];
+                            }
+                        }
+                        continue;
+                    }
                     if (tid == 0) {   // refine: two children with one more selector bit
                         if (s_sp + 2 > 24) { atomicOr(o.err, SIMKA_DEVERR_GROUP_OVERFLOW); s_sp = 0; }
                         else {
@@ -948,17 +974,39 @@ __device__ __forceinline__ uint32_t pair_isqrt(ull x) {
 // LDS cells of the 32-bit accumulators are PACKED two per u64 -- (S_ij | S_ji<<32), (a | bc<<32), (chord | hell<<32) --
 // so one non-returning ds_add_u64 feeds two accumulators.  Every half stays < 2^32 between flushes (`bound`), so the
 // low half never carries into the high one.
-// fold the block's private LDS accumulators into its slab row ([nacc][ncell_pad] u64) and zero them
-template <int K4_BLOCK>
-__device__ __forceinline__ void pairs_flush(ull *pk, ull *c64, ull *slab, const SimkaPairCfg &pc) {
+// fold the block's private LDS accumulators into the global u64 accumulators acc[a][pair] (atomics) and zero them.
+// Blocks start at different cells so that concurrent flushes do not queue on the same addresses.
+template <bool TILED, int K4_BLOCK>
+__device__ __forceinline__ void pairs_flush(ull *pk, ull *c64, ull *acc, const SimkaPairCfg &pc, bool rect, uint32_t baseI, uint32_t baseJ) {
     __syncthreads();
-    const uint32_t CP = pc.ncell_pad, npk = pc.nacc32 >> 1;
-    for (uint32_t a = 0; a < npk; a++)
-        for (uint32_t c = threadIdx.x; c < CP; c += K4_BLOCK) {
-            const ull v = pk[a * CP + c];
-            if (v) { slab[(2u * a) * CP + c] += (uint32_t)v; slab[(2u * a + 1u) * CP + c] += v >> 32; pk[a * CP + c] = 0; }
+    const uint32_t CP = pc.ncell_pad, npk = pc.nacc32 >> 1, N = pc.nb_samples, T = pc.tile;
+    const ull NP = pc.nb_pairs;
+    const uint32_t rot = (uint32_t)(((ull)blockIdx.x * 2654435761ull) % CP);
+    for (uint32_t c0 = threadIdx.x; c0 < CP; c0 += K4_BLOCK) {
+        uint32_t c = c0 + rot; if (c >= CP) c -= CP;
+        const ull v1 = pk[1 * CP + c];            // (a | bc): a counts every update of the cell
+        const ull w0 = pc.nacc64 ? c64[c] : 0ull, w1 = pc.nacc64 ? c64[CP + c] : 0ull;
+        if (!(v1 | w0 | w1)) continue;
+        ull pg = c;                               // untiled: the cell index IS the pair index
+        if (TILED) {
+            uint32_t li, lj;
+            if (rect) { li = c / T; lj = c - li * T; } else tri_unrank(c, T, li, lj);
+            pg = simka_pair_index(baseI + li, baseJ + lj, N);
         }
-    for (uint32_t i = threadIdx.x; i < pc.nacc64 * CP; i += K4_BLOCK) { const ull v = c64[i]; if (v) { slab[(size_t)pc.nacc32 * CP + i] += v; c64[i] = 0; } }
+        const ull v0 = pk[c];
+        atomicAdd(&acc[SIMKA_ACC_SIJ * NP + pg], (ull)(uint32_t)v0); atomicAdd(&acc[SIMKA_ACC_SJI * NP + pg], v0 >> 32);
+        atomicAdd(&acc[SIMKA_ACC_A * NP + pg], (ull)(uint32_t)v1); atomicAdd(&acc[SIMKA_ACC_BC * NP + pg], v1 >> 32);
+        pk[c] = 0; pk[CP + c] = 0;
+        if (npk > 2) {
+            const ull v2 = pk[2 * CP + c];
+            atomicAdd(&acc[SIMKA_ACC_CHORD * NP + pg], (ull)(uint32_t)v2); atomicAdd(&acc[SIMKA_ACC_HELL * NP + pg], v2 >> 32);
+            pk[2 * CP + c] = 0;
+        }
+        if (pc.nacc64) {
+            atomicAdd(&acc[(ull)pc.nacc32 * NP + pg], w0); atomicAdd(&acc[((ull)pc.nacc32 + 1) * NP + pg], w1);
+            c64[c] = 0; c64[CP + c] = 0;
+        }
+    }
     __syncthreads();
 }
 
@@ -970,7 +1018,7 @@ __device__ __forceinline__ void pairs_flush(ull *pk, ull *c64, ull *slab, const 
 template <bool TILED, int K4_BLOCK>
 __global__ void __launch_bounds__(K4_BLOCK)
 k_pairs(const SimkaSpan *spans, const ull *cursors, const ull *entries, const uint32_t *groups, SimkaPairCfg pc,
-        ull *acc, ull *slabs) {
+        ull *acc) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const uint32_t CP = pc.ncell_pad, npk = pc.nacc32 >> 1;
     const bool cplx = pc.nacc64 != 0;
@@ -1008,7 +1056,6 @@ k_pairs(const SimkaSpan *spans, const ull *cursors, const ull *entries, const ui
             if (rect) tn[T + i] = (baseJ + i < N) ? (double)pc.tot_n[baseJ + i] : 1.0;
         }
     }
-    ull *slab = slabs + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * pc.nacc * CP;
     // every packed half is fed by NON-returning atomics and receives at most one add per group, so
     // `bound` (sum over spans of #groups x largest count) < 2^32 guarantees no wrap; flush before it could.
     ull bound = 0, bound_q = 0;      // bound_q: same for the chord products (#groups x maxcount^2)
@@ -1070,7 +1117,7 @@ k_pairs(const SimkaSpan *spans, const ull *cursors, const ull *entries, const ui
         const ull addq = (ull)cur.ngrp * (ull)cur.maxc * (ull)cur.maxc;
         // chord: packed non-returning adds as long as the span's products cannot wrap a half cell; else straight into the global u64 cell
         const bool chord_fast = cur.maxc < 46341u && addq < 0xffffffffull;
-        if (bound + add >= 0xffffffffull || (chord_fast && bound_q + addq >= 0xffffffffull)) { pairs_flush<K4_BLOCK>(pk, c64, slab, pc); bound = 0; bound_q = 0; }
+        if (bound + add >= 0xffffffffull || (chord_fast && bound_q + addq >= 0xffffffffull)) { pairs_flush<TILED, K4_BLOCK>(pk, c64, acc, pc, rect, baseI, baseJ); bound = 0; bound_q = 0; }
         bound += add;
         if (chord_fast) bound_q += addq;
         __syncthreads();
@@ -1172,34 +1219,57 @@ k_pairs(const SimkaSpan *spans, const ull *cursors, const ull *entries, const ui
         }
     }
     __syncthreads();
-    pairs_flush<K4_BLOCK>(pk, c64, slab, pc);
+    pairs_flush<TILED, K4_BLOCK>(pk, c64, acc, pc, rect, baseI, baseJ);
 }
 
-// slabs[tilepair][block][acc][cell] -> acc[a][pair(i,j)]
+// K3c  k_pairs_global: groups shared by more than K3_CAP samples (k_group's huge list).  Pairs are enumerated from the
+// CSR entries in global memory and every update is a global u64 atomic; same arithmetic as k_pairs.
+// grid: x = slices of one group's pair space, y = groups (strided).
 __global__ void __launch_bounds__(256)
-k_reduce_slabs(const ull *slabs, uint32_t nblocks, SimkaPairCfg pc, ull *acc) {
-    const uint32_t tp = blockIdx.y;
-    uint32_t I = 0, J = 0;
-    {
-        uint32_t r = tp;
-        for (I = 0; I < pc.ntiles; I++) { const uint32_t row = pc.ntiles - I; if (r < row) { J = I + r; break; } r -= row; }
+k_pairs_global(const SimkaSpan *huge, const ull *cursors, const ull *entries, SimkaPairCfg pc, ull *acc) {
+    const ull nh = cursors[3];
+    const uint32_t N = pc.nb_samples;
+    const ull NP = pc.nb_pairs;
+    for (ull h = blockIdx.y; h < nh; h += gridDim.y) {
+        const SimkaSpan sp = huge[h];
+        const ull *ent = entries + sp.ebase;
+        const uint32_t s_ = sp.nent;                               // <= 65535 samples: s(s-1)/2 < 2^32
+        const uint32_t P = (uint32_t)(((ull)s_ * (s_ - 1u)) >> 1);
+        const uint32_t nthr = gridDim.x * 256u;
+        const uint32_t chunk = (P + nthr - 1u) / nthr;
+        const ull p0 = (ull)(blockIdx.x * 256u + threadIdx.x) * chunk;
+        if (p0 >= P) continue;
+        const uint32_t pend = (p0 + chunk < P) ? (uint32_t)p0 + chunk : P;
+        uint32_t x, y;
+        tri_unrank((uint32_t)p0, s_, x, y);
+        ull ex = ent[x];
+        for (uint32_t p = (uint32_t)p0; p < pend; p++) {
+            const ull ey = ent[y];
+            uint32_t si = (uint32_t)(ex >> 32), sj = (uint32_t)(ey >> 32);
+            uint32_t ci = (uint32_t)ex, cj = (uint32_t)ey;
+            if (si > sj) { uint32_t t_ = si; si = sj; sj = t_; t_ = ci; ci = cj; cj = t_; }
+            const ull pg = simka_pair_index(si, sj, N);
+            atomicAdd(&acc[SIMKA_ACC_SIJ * NP + pg], (ull)ci);
+            atomicAdd(&acc[SIMKA_ACC_SJI * NP + pg], (ull)cj);
+            atomicAdd(&acc[SIMKA_ACC_A * NP + pg], 1ull);
+            atomicAdd(&acc[SIMKA_ACC_BC * NP + pg], (ull)(ci < cj ? ci : cj));
+            if (pc.simple) {
+                const ull prod = (ull)ci * (ull)cj;
+                atomicAdd(&acc[SIMKA_ACC_CHORD * NP + pg], prod);
+                atomicAdd(&acc[SIMKA_ACC_HELL * NP + pg], (ull)pair_isqrt(prod));
+            }
+            if (pc.nacc64) {
+                const double Ni = (double)pc.tot_n[si], Nj = (double)pc.tot_n[sj];
+                const double pi_ = (double)ci / Ni, pj_ = (double)cj / Nj, hh = pi_ + pj_;
+                const double dd = pi_ * log(pi_) + pj_ * log(pj_) - hh * log(hh * 0.5);       // same form as k_pairs
+                atomicAdd(&acc[((ull)pc.nacc32 + 1) * NP + pg], (ull)(long long)llrint(dd * SIMKA_KL_SCALE));
+                const ull uX = (ull)((double)ci * Nj), uY = (ull)((double)cj * Ni);
+                atomicAdd(&acc[(ull)pc.nacc32 * NP + pg], simka_whit_abs(uX - uY) - simka_whit_abs(uX) - simka_whit_abs(uY));
+            }
+            y++;
+            if (y == s_) { x++; y = x + 1u; ex = ent[x < s_ ? x : s_ - 1u]; }
+        }
     }
-    const uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= pc.nacc * pc.ncell_pad) return;
-    const uint32_t a = idx / pc.ncell_pad, cell = idx % pc.ncell_pad;
-    if (cell >= pc.ncell) return;
-    const uint32_t N = pc.nb_samples, T = pc.tile;
-    // cell -> (i,j)
-    uint32_t i, j;
-    if (pc.ntiles == 1) { tri_unrank(cell, N, i, j); }
-    else if (I == J) { uint32_t li, lj; if (cell >= T * (T - 1u) / 2u) return; tri_unrank(cell, T, li, lj); i = I * T + li; j = J * T + lj; }
-    else { i = I * T + cell / T; j = J * T + cell % T; }
-    if (i >= N || j >= N || i >= j) return;
-    ull s = 0;
-    const size_t stride = (size_t)pc.nacc * pc.ncell_pad;
-    const ull *base = slabs + (size_t)tp * nblocks * stride + idx;
-    for (uint32_t b = 0; b < nblocks; b++) s += base[(size_t)b * stride];
-    if (s) atomicAdd(&acc[(size_t)a * pc.nb_pairs + simka_pair_index(i, j, N)], s);
 }
 
 // --------------------------------------------------------------------------------------------

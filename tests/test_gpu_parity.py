@@ -318,20 +318,21 @@ def test_sharded_contexts_sum_to_unsharded(gpu_required, oracle_mod, shards):
     assert np.array_equal(ref.pairs()["a"], orc.acc("a")[iu]) and np.array_equal(ref.pairs()["whit"], orc.acc("whit")[iu])
 
 
-@pytest.mark.parametrize("n,simple,complex_", [(140, True, True), (110, True, False), (135, False, False)])
+@pytest.mark.parametrize("n,simple,complex_", [(140, True, True), (110, True, False), (135, False, False),
+                                               (1100, False, False), (2500, True, False)])   # groups larger than one hash round / one span
 def test_many_samples_tiled_pair_accumulators(gpu_required, oracle_mod, n, simple, complex_):
     """More samples than one LDS tile of pair cells: k_pairs<false> walks (I,J) sample tiles.  Samples share genomes, so
     groups span many samples and tiles."""
     import simka_amd
     from simka_amd import synth
-    R, L, k = 400, 100, 21
+    R, L, k = (400 if n < 1000 else 60), 100, 21
     g = synth.genome_len_for(R * 4, L)
     pool, gw = synth.genome_pool_cpu(g)
     offs = np.arange(R + 1, dtype=np.uint64) * L
     packed = []
     for s in range(n):
         ids, cdf = synth.sample_profile(s % 7)                    # 7 community profiles, different reads
-        packed.append(synth.reads_cpu(R, L, pool, gw, g, ids, cdf, synth.sample_seed(s)))
+        packed.append(synth.reads_cpu(R, L, pool, gw, g, ids, cdf, synth.sample_seed(s if n < 1000 else s % 40)))
     ctx = simka_amd.SimkaContext(n, kmer_size=k, abundance_min=1, simple_dist=simple, complex_dist=complex_)
     for s, pk in enumerate(packed):
         ctx.count_sample(s, np.concatenate([pk, np.zeros(2, dtype=np.uint64)]), R * L, R, fixed_len=L)
@@ -344,6 +345,34 @@ def test_many_samples_tiled_pair_accumulators(gpu_required, oracle_mod, n, simpl
         orc.add_sample_ascii("S%d" % s, synth.unpack_ascii(pk, R * L), offs)
     orc.run(k, 1, simple=simple, complex_=complex_, nparts=8, threads=8)
     _check_vs_oracle(totals, st, orc, simple=simple, complex_=complex_)
+
+
+def test_kmer_shared_by_more_samples_than_a_span(gpu_required, oracle_mod):
+    """1100 samples drawn from 3 read sets that share genomes: groups of 360..1100 entries.  Groups above K3_CAP (1024)
+    records cannot be hashed in one k_group round: they take the huge-group list and k_pairs_global."""
+    import simka_amd
+    from simka_amd import synth
+    n, R, L, k = 1100, 20, 100, 21
+    g = synth.genome_len_for(R * 4, L)
+    pool, gw = synth.genome_pool_cpu(g)
+    offs = np.arange(R + 1, dtype=np.uint64) * L
+    ids, cdf = synth.sample_profile(0)
+    sets = [synth.reads_cpu(R, L, pool, gw, g, ids, cdf, synth.sample_seed(v)) for v in range(3)]
+    sets[1][: len(sets[0]) // 2] = sets[0][: len(sets[0]) // 2]      # sets 0 and 1 share half their reads, set 2 a quarter
+    sets[2][: len(sets[0]) // 4] = sets[0][: len(sets[0]) // 4]
+    packed = [sets[s % 3] for s in range(n)]
+    ctx = simka_amd.SimkaContext(n, kmer_size=k, abundance_min=1, simple_dist=True, complex_dist=True)
+    for s, pk in enumerate(packed):
+        ctx.count_sample(s, np.concatenate([pk, np.zeros(2, dtype=np.uint64)]), R * L, R, fixed_len=L)
+    totals = [ctx.sample_totals(i) for i in range(n)]
+    ctx.merge()
+    st = ctx.stats()
+    ctx.close()
+    orc = oracle_mod.Oracle()
+    for s, pk in enumerate(packed):
+        orc.add_sample_ascii("S%d" % s, synth.unpack_ascii(pk, R * L), offs)
+    orc.run(k, 1, simple=True, complex_=True, nparts=8, threads=8)
+    _check_vs_oracle(totals, st, orc, simple=True, complex_=True)
 
 
 def _run_cli(args, out):
