@@ -1,0 +1,49 @@
+#!/usr/bin/env python3
+"""Per-kernel HBM traffic from two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE), as MI355X_MICROARCH.md prescribes:
+separate passes, counters in KiB, FETCH_SIZE doubled on gfx950 (128-B requests are counted as 64 B on wide coalesced
+reads).  usage: traffic_summary.py <dir with fetch_<wl>_counter_collection.csv / write_<wl>_...> <wl> <out.json>"""
+import csv, json, re, sys
+from collections import defaultdict
+
+
+def short(name):
+    m = re.match(r"(?:void )?([A-Za-z_0-9]+(?:<[^>]*>)?)", name)
+    return m.group(1) if m else name
+
+
+def per_kernel(path, counter):
+    tot, cnt = defaultdict(float), defaultdict(int)
+    with open(path) as f:
+        for r in csv.DictReader(f):
+            if r["Counter_Name"] != counter:
+                continue
+            k = short(r["Kernel_Name"])
+            tot[k] += float(r["Counter_Value"]) * 1024.0      # KiB -> bytes
+            cnt[k] += 1
+    return tot, cnt
+
+
+def main():
+    d, wl, out = sys.argv[1], sys.argv[2], sys.argv[3]
+    ft, fc = per_kernel("%s/fetch_%s_counter_collection.csv" % (d, wl), "FETCH_SIZE")
+    wt, wc = per_kernel("%s/write_%s_counter_collection.csv" % (d, wl), "WRITE_SIZE")
+    kernels = {}
+    for k in sorted(ft):
+        if not k.startswith("k_") or k.startswith("k_synth"):
+            continue
+        n = fc[k]
+        fr = ft[k] / n
+        wr = wt.get(k, 0.0) / max(wc.get(k, 0), 1)
+        kernels[k] = {"launches": n, "fetch_bytes_raw_per_launch": fr, "fetch_bytes_x2_per_launch": 2 * fr,
+                      "write_bytes_per_launch": wr, "traffic_bytes_per_launch": 2 * fr + wr}
+    json.dump({"workload": wl,
+               "note": "per-launch averages over the whole bench run (warmup + timed step); FETCH_SIZE and WRITE_SIZE collected in "
+                       "separate rocprofv3 --pmc passes (KiB -> bytes); FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 counts "
+                       "128-B requests as 64 B on wide coalesced reads); WRITE_SIZE uncalibrated",
+               "kernels": kernels}, open(out, "w"), indent=1)
+    for k, v in kernels.items():
+        print("%-24s launches %4d  traffic/launch %.1f MB" % (k, v["launches"], v["traffic_bytes_per_launch"] / 1e6))
+
+
+if __name__ == "__main__":
+    main()
