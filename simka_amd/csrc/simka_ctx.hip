@@ -216,10 +216,13 @@ static int set_lds_attr(simka_ctx *ctx) {
     HIPCHK(hipFuncSetAttribute((const void *)k_scan<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
     HIPCHK(hipFuncSetAttribute((const void *)k_scan<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
     HIPCHK(hipFuncSetAttribute((const void *)k_layout, hipFuncAttributeMaxDynamicSharedMemorySize, big));
-    HIPCHK(hipFuncSetAttribute((const void *)k_split, hipFuncAttributeMaxDynamicSharedMemorySize, big));
+    HIPCHK(hipFuncSetAttribute((const void *)k_split<false>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
+    HIPCHK(hipFuncSetAttribute((const void *)k_split<true>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
     HIPCHK(hipFuncSetAttribute((const void *)k_count, hipFuncAttributeMaxDynamicSharedMemorySize, big));
-    HIPCHK(hipFuncSetAttribute((const void *)k_count_fast<K2F_TABLE_BIG>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
-    HIPCHK(hipFuncSetAttribute((const void *)k_count_fast<K2F_TABLE_SMALL>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
+    HIPCHK(hipFuncSetAttribute((const void *)k_count_fast<K2F_TABLE_BIG, false>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
+    HIPCHK(hipFuncSetAttribute((const void *)k_count_fast<K2F_TABLE_SMALL, false>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
+    HIPCHK(hipFuncSetAttribute((const void *)k_count_fast<K2F_TABLE_BIG, true>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
+    HIPCHK(hipFuncSetAttribute((const void *)k_count_fast<K2F_TABLE_SMALL, true>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
     HIPCHK(hipFuncSetAttribute((const void *)k_group, hipFuncAttributeMaxDynamicSharedMemorySize, big));
     HIPCHK(hipFuncSetAttribute((const void *)k_pairs<false, K4_BLOCK_BIG>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
     HIPCHK(hipFuncSetAttribute((const void *)k_pairs<false, K4_BLOCK_SMALL>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
@@ -244,9 +247,9 @@ static int setup_geometry(simka_ctx *ctx, uint64_t max_kmers) {
     if (getenv("SIMKA_L1")) l1 = std::min<uint32_t>(pb, (uint32_t)atoi(getenv("SIMKA_L1")));   // experiments
     const uint32_t min_l1 = std::min<uint32_t>(pb, ceil_log2_u64(c.shard_count));   // shards are level-1 buckets
     if (l1 < min_l1) l1 = min_l1;
-    // level 1 is scattered from 8192-position tiles (k_scan), level 2 from 8192-key chunks (k_split): keep level 1 at
-    // <= 512 buckets (>= ~100-byte runs, 2 blocks/CU of LDS) and give the rest to level 2
-    if (l1 > 9 && !getenv("SIMKA_L1")) l1 = 9;
+    // level 1 is scattered from 16384-position tiles (k_scan), level 2 from 8192-key chunks (k_split): split the bits
+    // evenly (measured on C3, pb = 19: l1 = 10 beats 9 by 3.6 % end to end, 8 loses 2.5 %), at most 1024 level-1 buckets
+    if (l1 > 10 && !getenv("SIMKA_L1")) l1 = 10;
     if (l1 < min_l1) l1 = min_l1;
     if (l1 > 11) l1 = 11;
     uint32_t l2 = pb - l1;
@@ -514,6 +517,10 @@ static int run_count_kernels(simka_ctx *ctx, uint32_t sample, const SimkaScanArg
     rc = ensure_cap(ctx, &L.d_spill_keys, &L.spill_cap, spill_need); if (rc) return rc;
     rc = ensure_cap(ctx, &L.d_spill_part, &L.spill_part_cap, spill_need); if (rc) return rc;
     l2.l2_keys = L.d_l2; l2.p_count = L.d_p_count; l2.p_valid = L.d_p_valid;
+    // level-2 regions hold 4-byte remainders when the partition bits leave <= 31 of the key (k <= 23 at the usual geometry)
+    static const bool wide_only = getenv("SIMKA_WIDE_KEYS") != nullptr;
+    l2.rem_bits = key.W - key.pb;
+    l2.narrow = (!wide_only && l2.rem_bits <= 31u) ? 1u : 0u;
     l2.spill_keys = L.d_spill_keys; l2.spill_part = L.d_spill_part; l2.spill_cursor = L.d_spill_cursor;
     l2.spill_cap = std::min(L.spill_cap, L.spill_part_cap);
     HIPCHK(hipMemsetAsync(L.d_p_count, 0, ctx->nparts * 4, st));
@@ -524,8 +531,9 @@ static int run_count_kernels(simka_ctx *ctx, uint32_t sample, const SimkaScanArg
         const uint64_t nchunks_max = (exact ? a.nb_bases : L.l1_cap) / K2_CHUNK + B1 + 1;
         const size_t lds_split = SIMKA_LDS_HEAD + (size_t)B2 * 12 + 64 + (size_t)K2_CHUNK * 8;
         launch_timed(ctx, KID_SPLIT, [&] {
-            hipLaunchKernelGGL(k_split, dim3((uint32_t)std::min<uint64_t>(nchunks_max, (uint64_t)ctx->num_cus * 2)), dim3(K2_BLOCK), lds_split, st, L.d_l1,
-                               L.d_b1_start, L.d_b1_end, L.d_chunk_first, key, l2, flag);
+            const dim3 grid((uint32_t)std::min<uint64_t>(nchunks_max, (uint64_t)ctx->num_cus * 2));
+            if (l2.narrow) hipLaunchKernelGGL(k_split<true>, grid, dim3(K2_BLOCK), lds_split, st, L.d_l1, L.d_b1_start, L.d_b1_end, L.d_chunk_first, key, l2, flag);
+            else hipLaunchKernelGGL(k_split<false>, grid, dim3(K2_BLOCK), lds_split, st, L.d_l1, L.d_b1_start, L.d_b1_end, L.d_chunk_first, key, l2, flag);
         }, st);
     }
     SimkaCountOut o;
@@ -540,16 +548,16 @@ static int run_count_kernels(simka_ctx *ctx, uint32_t sample, const SimkaScanArg
     const size_t hist_lds = ctx->d_hist ? (size_t)SIMKA_HIST_MAX * 4 : 0;
     if (!slow_only) {
         const bool small = ctx->small_table == 1;
-        const size_t lds_fast = SIMKA_LDS_HEAD + (size_t)(small ? K2F_TABLE_SMALL : K2F_TABLE_BIG) * 12 + (size_t)K2F_BLOCK * 4 + hist_lds;
+        const size_t lds_fast = SIMKA_LDS_HEAD + (size_t)(small ? K2F_TABLE_SMALL : K2F_TABLE_BIG) * (l2.narrow ? 8 : 12) + (size_t)K2F_BLOCK * 4 + hist_lds;
         const uint32_t bpc_f = (uint32_t)std::min<size_t>(4, (160 * 1024) / lds_fast);
         const dim3 gridf((uint32_t)std::min<uint64_t>(ctx->nparts, (uint64_t)ctx->num_cus * bpc_f));
         launch_timed(ctx, KID_COUNT_FAST, [&] {
-            if (small)
-                hipLaunchKernelGGL((k_count_fast<K2F_TABLE_SMALL>), gridf, dim3(K2F_BLOCK), lds_fast, st, key, l2, ctx->cfg.abundance_min,
-                                   ctx->cfg.abundance_max, o, flag, L.d_redo_list, L.d_redo_count);
-            else
-                hipLaunchKernelGGL((k_count_fast<K2F_TABLE_BIG>), gridf, dim3(K2F_BLOCK), lds_fast, st, key, l2, ctx->cfg.abundance_min,
-                                   ctx->cfg.abundance_max, o, flag, L.d_redo_list, L.d_redo_count);
+            auto go = [&](auto kern) {
+                hipLaunchKernelGGL(kern, gridf, dim3(K2F_BLOCK), lds_fast, st, key, l2, ctx->cfg.abundance_min, ctx->cfg.abundance_max, o, flag,
+                                   L.d_redo_list, L.d_redo_count);
+            };
+            if (small) { if (l2.narrow) go(k_count_fast<K2F_TABLE_SMALL, true>); else go(k_count_fast<K2F_TABLE_SMALL, false>); }
+            else { if (l2.narrow) go(k_count_fast<K2F_TABLE_BIG, true>); else go(k_count_fast<K2F_TABLE_BIG, false>); }
         }, st);
     }
     const size_t lds_count = SIMKA_LDS_HEAD + ((size_t)12 << tlog) + hist_lds;

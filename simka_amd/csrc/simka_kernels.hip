@@ -22,6 +22,7 @@
 // wavefront; every global access pattern that carries real traffic is a contiguous run.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <type_traits>
 #include "simka_device.h"
 #include "simka_kernels.h"
 
@@ -255,6 +256,7 @@ k_layout(const ull *b1_count, ull *b1_start, ull *b1_end, ull *b1_cursor, uint32
 // not fit goes to the spill buffer with its partition id and the partition is finished by the general
 // kernel; if even the spill buffer overflows the sample is flagged and redone with a full-size one.
 // --------------------------------------------------------------------------------------------
+template <bool NARROW>
 __global__ void __launch_bounds__(K2_BLOCK)
 k_split(const uint64_t *l1_keys, const ull *b1_start, const ull *b1_end, const uint32_t *chunk_first, SimkaKeyCfg cfg,
         SimkaL2 l2, uint32_t *flag) {
@@ -269,6 +271,7 @@ k_split(const uint64_t *l1_keys, const ull *b1_start, const ull *b1_end, const u
 
     const uint32_t tid = threadIdx.x;
     const uint32_t nchunks = chunk_first[B1];
+    const uint32_t rem_mask = NARROW ? ((1u << l2.rem_bits) - 1u) : 0u;
     constexpr int PER = K2_CHUNK / K2_BLOCK;
     // chunk c -> (first key, #keys, level-1 bucket): thread 0, into slot `w`
     auto locate = [&](uint32_t c, uint32_t w) {
@@ -339,6 +342,7 @@ k_split(const uint64_t *l1_keys, const ull *b1_start, const ull *b1_end, const u
             const uint32_t off = idx - hist[b];
             if (g == ~0ull) continue;
             if (g >> 63) { const ull sp = (g & ~(1ull << 63)) + off; l2.spill_keys[sp] = key; l2.spill_part[sp] = (b1 << cfg.l2) | b; }
+            else if (NARROW) ((uint32_t *)l2.l2_keys)[g + off] = (uint32_t)key & rem_mask;    // the partition bits are implicit
             else l2.l2_keys[g + off] = key;
         }
         __syncthreads();
@@ -368,6 +372,17 @@ __device__ __forceinline__ bool table_insert(ull *tkeys, uint32_t *tcnt, uint32_
     }
     return false;
 }
+// narrow keys (W - pb <= 31 bits: the partition is implicit): 32-bit table, 32-bit multiplicative slot hash
+#define SIMKA_EMPTY_KEY32 0xffffffffu
+__device__ __forceinline__ bool table_insert(uint32_t *tkeys, uint32_t *tcnt, uint32_t tmask, uint32_t key) {
+    uint32_t slot = ((key * 0x9E3779B1u) >> 16) & tmask;
+    for (uint32_t probe = 0; probe <= tmask; probe++) {
+        const uint32_t prev = atomicCAS(&tkeys[slot], SIMKA_EMPTY_KEY32, key);
+        if (prev == SIMKA_EMPTY_KEY32 || prev == key) { atomicAdd(&tcnt[slot], 1u); return true; }
+        slot = (slot + 1u) & tmask;
+    }
+    return false;
+}
 
 // reserve `ns` arena records for one partition out of the block's private slab (thread 0 only)
 __device__ __forceinline__ ull slab_take(ull &slab_pos, ull &slab_end, uint32_t ns, const SimkaCountOut &o, ull sample_base, uint32_t &ok) {
@@ -388,7 +403,7 @@ __device__ __forceinline__ void count_hist(const SimkaCountOut &o, uint32_t *lhi
     else { const ull w = atomicAdd(o.ovf_cursor, 1ull); if (w < o.ovf_cap) { o.ovf_list[2 * w] = o.sample; o.ovf_list[2 * w + 1] = c; } }
 }
 
-template <uint32_t TS>
+template <uint32_t TS, bool NARROW>
 __global__ void __launch_bounds__(K2F_BLOCK)
 k_count_fast(SimkaKeyCfg cfg, SimkaL2 l2, uint32_t amin, uint32_t amax, SimkaCountOut o, const uint32_t *flag,
              uint32_t *redo_list, ull *redo_count) {
@@ -401,17 +416,20 @@ k_count_fast(SimkaKeyCfg cfg, SimkaL2 l2, uint32_t amin, uint32_t amax, SimkaCou
     uint32_t &s_ok = *(uint32_t *)(smem + 56);
     uint32_t *tmp = (uint32_t *)(smem + 128);         // [K2F_BLOCK/64]
     constexpr uint32_t tmask = TS - 1u, SPT = TS / K2F_BLOCK;   // slots per thread
-    ull *tkeys = (ull *)(smem + SIMKA_LDS_HEAD);      // [TS]
+    using KT = typename std::conditional<NARROW, uint32_t, ull>::type;     // level-2 key as stored: remainder only, or whole key
+    constexpr KT KEMPTY = (KT)~(KT)0;
+    KT *tkeys = (KT *)(smem + SIMKA_LDS_HEAD);        // [TS]
     uint32_t *tcnt = (uint32_t *)(tkeys + TS);        // [TS]
     uint32_t *spos = tcnt + TS;                       // [K2F_BLOCK]
     uint32_t *lhist = spos + K2F_BLOCK;               // [SIMKA_HIST_MAX] (complex only)
+    const KT *l2k = (const KT *)l2.l2_keys;
 
     const uint32_t tid = threadIdx.x;
     const uint32_t nparts = 1u << cfg.pb;
     const ull sample_base = *o.sample_base;
     {   // the table starts clean; afterwards every thread re-cleans the slots it read
-        ulonglong2 *k2 = (ulonglong2 *)tkeys; uint4 *c4 = (uint4 *)tcnt;
-        for (uint32_t i = tid; i < TS / 2; i += K2F_BLOCK) k2[i] = make_ulonglong2(SIMKA_EMPTY_KEY, SIMKA_EMPTY_KEY);
+        uint4 *k4 = (uint4 *)tkeys; uint4 *c4 = (uint4 *)tcnt;
+        for (uint32_t i = tid; i < TS * sizeof(KT) / 16; i += K2F_BLOCK) k4[i] = make_uint4(~0u, ~0u, ~0u, ~0u);
         for (uint32_t i = tid; i < TS / 4; i += K2F_BLOCK) c4[i] = make_uint4(0, 0, 0, 0);
     }
     if (o.hist) for (uint32_t i = tid; i < SIMKA_HIST_MAX; i += K2F_BLOCK) lhist[i] = 0;
@@ -419,12 +437,12 @@ k_count_fast(SimkaKeyCfg cfg, SimkaL2 l2, uint32_t amin, uint32_t amax, SimkaCou
     if (tid == 0) { s_slab_pos = 0; s_slab_end = 0; }
     ull bt_dall = 0, bt_D = 0, bt_N = 0, bt_Q = 0;
 
-    ull kk[K2F_UNROLL];
+    KT kk[K2F_UNROLL];
     // issue the loads of partition p (n keys) -- only partitions the fast path can take in one batch
 #define K2F_LOAD(p, n)                                                                        \
     _Pragma("unroll") for (int u = 0; u < K2F_UNROLL; u++) {                                  \
         const uint32_t i = tid + (uint32_t)u * K2F_BLOCK;                                     \
-        kk[u] = (i < (n)) ? l2.l2_keys[(ull)(p) * l2.cap2 + i] : SIMKA_EMPTY_KEY;             \
+        kk[u] = (i < (n)) ? l2k[(ull)(p) * l2.cap2 + i] : KEMPTY;                             \
     }
     uint32_t part = blockIdx.x;
     uint32_t n = 0;
@@ -449,23 +467,23 @@ k_count_fast(SimkaKeyCfg cfg, SimkaL2 l2, uint32_t amin, uint32_t amax, SimkaCou
         // ---- insert the prefetched keys
 #pragma unroll
         for (int u = 0; u < K2F_UNROLL; u++) {
-            const ull key = kk[u];
-            if (key != SIMKA_EMPTY_KEY) table_insert(tkeys, tcnt, tmask, key);
+            const KT key = kk[u];
+            if (key != KEMPTY) table_insert(tkeys, tcnt, tmask, key);
         }
         for (uint32_t i = K2F_BLOCK * K2F_UNROLL + tid; i < n; i += K2F_BLOCK)      // beyond the prefetch window (rare)
-            table_insert(tkeys, tcnt, tmask, l2.l2_keys[(ull)part * l2.cap2 + i]);
+            table_insert(tkeys, tcnt, tmask, l2k[(ull)part * l2.cap2 + i]);
         __syncthreads();
         // ---- prefetch the next partition while this one is summarised
         if (fast_next) { K2F_LOAD(next, n_next) }
         // ---- one pass over this thread's slots: SimkaCompressedProcessor::process
-        uint32_t cs[SPT]; ull ks[SPT];
+        uint32_t cs[SPT]; KT ks[SPT];
         uint32_t nsol = 0, ndall = 0;
         ull D = 0, N = 0, Q = 0;
 #pragma unroll
         for (uint32_t q = 0; q < SPT; q++) {
             const uint32_t sl = tid * SPT + q;
             cs[q] = tcnt[sl]; ks[q] = tkeys[sl];
-            if (cs[q]) { tcnt[sl] = 0; tkeys[sl] = SIMKA_EMPTY_KEY; }     // leave the table clean for the next partition
+            if (cs[q]) { tcnt[sl] = 0; tkeys[sl] = KEMPTY; }     // leave the table clean for the next partition
             const uint32_t c = cs[q];
             if (c) { ndall++; if (!(c < amin || c > amax)) { D++; N += c; Q += (ull)c * (ull)c; nsol++; } else cs[q] = 0; }
         }
@@ -489,10 +507,11 @@ k_count_fast(SimkaKeyCfg cfg, SimkaL2 l2, uint32_t amin, uint32_t amax, SimkaCou
         if (s_ok) {
             bt_dall += ndall; bt_D += D; bt_N += N; bt_Q += Q;
             ull pos = s_base + (spos[tid] & 0xffffu);
+            const ull khigh = NARROW ? ((ull)part << l2.rem_bits) : 0ull;         // the arena holds whole keys
 #pragma unroll
             for (uint32_t q = 0; q < SPT; q++) {
                 if (cs[q]) {
-                    o.solid_keys[pos] = ks[q]; o.solid_counts[pos] = cs[q]; pos++;
+                    o.solid_keys[pos] = khigh | (ull)ks[q]; o.solid_counts[pos] = cs[q]; pos++;
                     if (o.hist) count_hist(o, lhist, cs[q]);
                 }
             }
@@ -554,6 +573,8 @@ k_count(SimkaKeyCfg cfg, SimkaL2 l2, uint32_t table_log2, uint32_t amin, uint32_
         const uint32_t nreg = (uint32_t)((ull)(pv < pc ? pv : pc) < l2.cap2 ? (pv < pc ? pv : pc) : (uint32_t)l2.cap2);   // keys in the region
         const ull nspill = (pc > nreg) ? *l2.spill_cursor : 0ull;                                                     // scan the spill buffer
         const ull *reg = l2.l2_keys + (ull)part * l2.cap2;
+        const uint32_t *reg32 = (const uint32_t *)l2.l2_keys + (ull)part * l2.cap2;       // narrow level-2 keys: remainder only
+        const ull khigh = (ull)part << l2.rem_bits;
         __syncthreads();
         if (tid == 0) { s_nsolid = 0; s_cur = 0; s_ovf = 0; }
 
@@ -579,7 +600,7 @@ k_count(SimkaKeyCfg cfg, SimkaL2 l2, uint32_t table_log2, uint32_t amin, uint32_
 #pragma unroll
                     for (int u = 0; u < K2_UNROLL; u++) {
                         const uint32_t i = i0 + (uint32_t)u * K2C_BLOCK;
-                        keyv[u] = (i < nreg) ? reg[i] : SIMKA_EMPTY_KEY;
+                        keyv[u] = (i < nreg) ? (l2.narrow ? (khigh | (ull)reg32[i]) : reg[i]) : SIMKA_EMPTY_KEY;
                     }
 #pragma unroll
                     for (int u = 0; u < K2_UNROLL; u++) {
