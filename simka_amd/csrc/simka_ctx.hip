@@ -520,6 +520,8 @@ static int run_count_kernels(simka_ctx *ctx, uint32_t sample, const SimkaScanArg
     // level-2 regions hold 4-byte remainders when the partition bits leave <= 31 of the key (k <= 23 at the usual geometry)
     static const bool wide_only = getenv("SIMKA_WIDE_KEYS") != nullptr;
     l2.rem_bits = key.W - key.pb;
+    static const bool direct = getenv("SIMKA_SPLIT_DIRECT") != nullptr;
+    l2.direct = direct ? 1u : 0u;
     l2.narrow = (!wide_only && l2.rem_bits <= 31u) ? 1u : 0u;
     l2.spill_keys = L.d_spill_keys; l2.spill_part = L.d_spill_part; l2.spill_cursor = L.d_spill_cursor;
     l2.spill_cap = std::min(L.spill_cap, L.spill_part_cap);

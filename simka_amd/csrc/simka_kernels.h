@@ -10,7 +10,7 @@
 #define K1_BLOCK 1024         // 16 waves: 16384-position tiles -> long bucket runs (run length is what the scatter is bound by)
 #define K1_SEG 16             // k-mer start positions per thread (window = SEG + k - 1 <= 64 bases holds for k <= 33)
 // K2  k_split / k_count
-#define K2_BLOCK 512          // k_split
+#define K2_BLOCK 1024         // k_split
 #define K2C_BLOCK 256         // k_count
 #define K2_CHUNK 8192         // keys per chunk (fits u16 offsets, 64 KB LDS stage)
 #define K2_TABLE_LOG2 11      // LDS hash-table slots per partition: 4096 (32 KB keys + 16 KB counts) -> 3 blocks/CU
@@ -97,6 +97,7 @@ struct SimkaCountOut {
 // level-2 partition regions of one sample (k_split -> k_count)
 struct SimkaL2 {
     unsigned long long *l2_keys;             // [nparts][cap2]  (u32 remainders when `narrow`)
+    uint32_t direct;                         // experiment: k_split writes without LDS staging
     uint32_t narrow, rem_bits;               // W - pb <= 31: regions hold the low rem_bits of each key, the partition is implicit
     unsigned long long cap2;                 // keys a region can hold
     uint32_t *p_count;                       // [nparts] keys routed to the partition (may exceed cap2: spilled)
