@@ -133,6 +133,24 @@ int simka_count_sample(simka_ctx *ctx, uint32_t sample_index, const simka_reads 
 /* totals of a counted sample (synchronises). Replaces reading count_synchro/<ID>.ok. */
 int simka_get_sample_totals(simka_ctx *ctx, uint32_t sample_index, simka_sample_totals *out);
 
+/* ---- -keep-tmp: a counted sample's solid spectrum, out of the context and back ---------------
+ * The reference keeps solid/part_<p>/__p__<i>.gz + count_synchro/<ID>.ok in the temp dir and skips the samples whose
+ * .ok file exists when run again with more samples (ref: src/SimkaPotara.hpp:837-842, src/SimkaCount.cpp:279-317,
+ * README.md:205-206).  Here the spectrum of sample i (this shard's partitions, partition-major) is exported to caller
+ * buffers and imported into a later context with the SAME kmer_size, abundance filter, shard and partition count
+ * instead of calling simka_count_sample. */
+typedef struct simka_spectrum_info {
+    uint64_t nb_records;         /* solid k-mers of the sample on this shard */
+    uint64_t nb_partitions;      /* 2^log2_partitions */
+} simka_spectrum_info;
+int simka_sample_spectrum_info(simka_ctx *ctx, uint32_t sample_index, simka_spectrum_info *out);
+/* part_counts[nb_partitions], keys[nb_records] (the library's internal key of each k-mer), counts[nb_records] */
+int simka_export_sample(simka_ctx *ctx, uint32_t sample_index, uint32_t *part_counts, uint64_t *keys, uint32_t *counts);
+/* totals: what simka_get_sample_totals returned for the exported sample.  A context that has not counted anything yet
+ * takes its partition count from nb_partitions. */
+int simka_import_sample(simka_ctx *ctx, uint32_t sample_index, const simka_sample_totals *totals, const uint32_t *part_counts,
+                        uint64_t nb_partitions, const uint64_t *keys, const uint32_t *counts, uint64_t nb_records);
+
 /* ---- merge side ---------------------------------------------------------------------------
  * Replaces every `simkaMerge` job: the N-way k-mer merge (ref: src/SimkaMerge.cpp:1164-1264),
  * its gate (ref: :1307-1326) and SimkaCountProcessorSimple::process -> updateDistance*

@@ -44,6 +44,10 @@ class SampleTotals(C.Structure):
                 ("kmer_occurrences", C.c_uint64), ("distinct_all", C.c_uint64)]
 
 
+class SpectrumInfo(C.Structure):
+    _fields_ = [("nb_records", C.c_uint64), ("nb_partitions", C.c_uint64)]
+
+
 _U64P = C.POINTER(C.c_uint64)
 
 
@@ -85,6 +89,9 @@ def load_library(build_if_missing=True):
         "simka_reset": (i32, [vp]),
         "simka_count_sample": (i32, [vp, u32, C.POINTER(Reads)]),
         "simka_get_sample_totals": (i32, [vp, u32, C.POINTER(SampleTotals)]),
+        "simka_sample_spectrum_info": (i32, [vp, u32, C.POINTER(SpectrumInfo)]),
+        "simka_export_sample": (i32, [vp, u32, vp, vp, vp]),
+        "simka_import_sample": (i32, [vp, u32, C.POINTER(SampleTotals), vp, u64, vp, vp, u64]),
         "simka_merge": (i32, [vp]),
         "simka_stats_device_buffer": (i32, [vp, C.POINTER(vp), C.POINTER(u64)]),
         "simka_stats_download": (i32, [vp, vp, u64, C.POINTER(StatsView)]),
@@ -289,6 +296,25 @@ class SimkaContext:
         self._check(self.lib.simka_get_sample_totals(self.h, index, C.byref(t)))
         return {"nb_reads": t.nb_reads, "D": t.nb_distinct, "N": t.nb_kmers, "Q": t.sum_sq, "K_occ": t.kmer_occurrences,
                 "D_all": t.distinct_all}
+
+    # -- -keep-tmp: spectra out of / into the context -----------------------------------------
+    def export_sample(self, index):
+        """(totals, part_counts u32[nparts], keys u64[n], counts u32[n]) of a counted sample -- what -keep-tmp persists."""
+        info = SpectrumInfo()
+        self._check(self.lib.simka_sample_spectrum_info(self.h, index, C.byref(info)))
+        pc = np.zeros(info.nb_partitions, dtype=np.uint32)
+        keys = np.zeros(max(info.nb_records, 1), dtype=np.uint64)
+        counts = np.zeros(max(info.nb_records, 1), dtype=np.uint32)
+        self._check(self.lib.simka_export_sample(self.h, index, pc.ctypes.data, keys.ctypes.data, counts.ctypes.data))
+        return self.sample_totals(index), pc, keys[:info.nb_records], counts[:info.nb_records]
+
+    def import_sample(self, index, totals, part_counts, keys, counts):
+        t = SampleTotals(totals["nb_reads"], totals["D"], totals["N"], totals["Q"], totals["K_occ"], totals["D_all"])
+        pc = np.ascontiguousarray(part_counts, dtype=np.uint32)
+        k = np.ascontiguousarray(keys, dtype=np.uint64)
+        c = np.ascontiguousarray(counts, dtype=np.uint32)
+        self._check(self.lib.simka_import_sample(self.h, index, C.byref(t), pc.ctypes.data, len(pc), k.ctypes.data if len(k) else None,
+                                                 c.ctypes.data if len(c) else None, len(k)))
 
     # -- merge side -------------------------------------------------------------------------
     def merge(self):

@@ -284,8 +284,10 @@ bool load_sample(const Sample &s, const Options &o, uint64_t max_reads, Packed &
 // samples are in flight, which bounds host memory.
 class SampleLoader {
 public:
-    SampleLoader(const std::vector<Sample> &samples, const Options &o, uint64_t max_reads, unsigned threads, unsigned window)
-        : samples_(samples), o_(o), max_reads_(max_reads), window_(std::max(1u, window)), slots_(samples.size()), state_(samples.size(), 0) {
+    // skip[i] != 0: sample i is not read at all (-keep-tmp found its spectrum); get() returns immediately with an empty slot
+    SampleLoader(const std::vector<Sample> &samples, const Options &o, uint64_t max_reads, unsigned threads, unsigned window,
+                 const std::vector<char> &skip = std::vector<char>())
+        : samples_(samples), o_(o), max_reads_(max_reads), window_(std::max(1u, window)), slots_(samples.size()), state_(samples.size(), 0), skip_(skip) {
         threads = std::max(1u, std::min<unsigned>(threads, (unsigned)samples.size()));
         for (unsigned t = 0; t < threads; t++) workers_.emplace_back([this] { run(); });
     }
@@ -317,7 +319,7 @@ private:
                 i = next_++;
             }
             Packed pk;
-            const bool ok = load_sample(samples_[i], o_, max_reads_, pk);
+            const bool ok = (i < skip_.size() && skip_[i]) ? true : load_sample(samples_[i], o_, max_reads_, pk);
             { std::lock_guard<std::mutex> g(m_); slots_[i] = std::move(pk); state_[i] = ok ? 1 : -1; }
             cv_.notify_all();
         }
@@ -328,12 +330,95 @@ private:
     size_t window_;
     std::vector<Packed> slots_;
     std::vector<int> state_;
+    std::vector<char> skip_;
     std::vector<std::thread> workers_;
     std::mutex m_;
     std::condition_variable cv_;
     size_t next_ = 0, consumed_ = 0;
     bool stop_ = false;
 };
+
+// ---- -keep-tmp: <tmp>/solid/<ID>.g<g>of<G>.spec, one per (sample, GPU shard) -----------------------------------------------
+// The reference keeps solid/part_<p>/__p__<i>.gz + count_synchro/<ID>.ok and skips the samples whose .ok exists
+// (ref: src/SimkaPotara.hpp:837-842).  Here: the sample's solid spectrum as simka_export_sample() returns it, behind a
+// header that pins everything the spectrum depends on (k, abundance filter, read policies, the input files, the shard).
+struct SpecHeader {
+    char magic[8];                       // "SIMKSPC1"
+    uint64_t abi, kmer_size, abundance_min, abundance_max, shard_index, shard_count, nb_partitions, nb_records, signature;
+    simka_sample_totals totals;
+};
+
+uint64_t fnv1a(uint64_t h, const void *p, size_t n) {
+    const unsigned char *b = (const unsigned char *)p;
+    for (size_t i = 0; i < n; i++) { h ^= b[i]; h *= 0x100000001b3ULL; }
+    return h;
+}
+
+// everything besides (k, abundance filter, shard) that decides a sample's spectrum: read policies and the files themselves
+uint64_t sample_signature(const Sample &s, const Options &o, uint64_t max_reads) {
+    uint64_t h = 0xcbf29ce484222325ULL;
+    const uint64_t pol[3] = { max_reads, (uint64_t)o.min_read_size, 0 };
+    h = fnv1a(h, pol, 16);
+    h = fnv1a(h, &o.min_shannon, sizeof o.min_shannon);
+    for (auto &p : s.parts) {
+        h = fnv1a(h, ";", 1);
+        for (auto &fn : p) {
+            struct stat st;
+            uint64_t meta[2] = { 0, 0 };
+            if (stat(fn.c_str(), &st) == 0) { meta[0] = (uint64_t)st.st_size; meta[1] = (uint64_t)st.st_mtime; }
+            h = fnv1a(h, fn.data(), fn.size());
+            h = fnv1a(h, meta, sizeof meta);
+        }
+    }
+    return h;
+}
+
+std::string spec_path(const std::string &tmp, const Sample &s, uint32_t g, uint32_t G) {
+    std::ostringstream os;
+    os << tmp << "/solid/" << s.id << ".g" << g << "of" << G << ".spec";
+    return os.str();
+}
+
+bool read_spec_header(const std::string &path, SpecHeader &h) {
+    FILE *f = fopen(path.c_str(), "rb");
+    if (!f) return false;
+    const bool ok = fread(&h, sizeof h, 1, f) == 1 && memcmp(h.magic, "SIMKSPC1", 8) == 0;
+    fclose(f);
+    return ok;
+}
+
+bool spec_matches(const SpecHeader &h, const Options &o, uint32_t g, uint32_t G, uint64_t sig) {
+    return h.abi == (uint64_t)simka_abi_version() && h.kmer_size == (uint64_t)o.kmer_size && h.abundance_min == (uint64_t)o.abundance_min &&
+           h.abundance_max == (uint64_t)o.abundance_max && h.shard_index == g && h.shard_count == G && h.signature == sig &&
+           h.nb_partitions && !(h.nb_partitions & (h.nb_partitions - 1));
+}
+
+struct Spectrum { SpecHeader h; std::vector<uint32_t> part_counts, counts; std::vector<uint64_t> keys; };
+
+bool read_spec(const std::string &path, Spectrum &sp) {
+    FILE *f = fopen(path.c_str(), "rb");
+    if (!f) return false;
+    bool ok = fread(&sp.h, sizeof sp.h, 1, f) == 1 && memcmp(sp.h.magic, "SIMKSPC1", 8) == 0;
+    if (ok) {
+        sp.part_counts.resize(sp.h.nb_partitions); sp.keys.resize(sp.h.nb_records); sp.counts.resize(sp.h.nb_records);
+        ok = fread(sp.part_counts.data(), 4, sp.part_counts.size(), f) == sp.part_counts.size() &&
+             fread(sp.keys.data(), 8, sp.keys.size(), f) == sp.keys.size() && fread(sp.counts.data(), 4, sp.counts.size(), f) == sp.counts.size();
+    }
+    fclose(f);
+    return ok;
+}
+
+bool write_spec(const std::string &path, const Spectrum &sp) {
+    const std::string part = path + ".part";          // complete files only: written aside, then renamed
+    FILE *f = fopen(part.c_str(), "wb");
+    if (!f) return false;
+    bool ok = fwrite(&sp.h, sizeof sp.h, 1, f) == 1 && fwrite(sp.part_counts.data(), 4, sp.part_counts.size(), f) == sp.part_counts.size() &&
+              fwrite(sp.keys.data(), 8, sp.keys.size(), f) == sp.keys.size() && fwrite(sp.counts.data(), 4, sp.counts.size(), f) == sp.counts.size();
+    ok = (fclose(f) == 0) && ok;
+    if (ok) ok = rename(part.c_str(), path.c_str()) == 0;
+    if (!ok) unlink(part.c_str());
+    return ok;
+}
 
 void check(simka_ctx *ctx, int rc, const char *what) {
     if (rc == SIMKA_OK) return;
@@ -407,6 +492,27 @@ int main(int argc, char **argv) {
     }
     // contexts: one per GPU, partition space sharded
     const uint32_t G = (uint32_t)o.nb_gpus;
+    // -keep-tmp: samples whose spectrum (every shard's file) is in the temp dir and still valid are not read again
+    std::vector<char> reuse(N, 0);
+    std::vector<uint64_t> sig(N, 0);
+    uint64_t kept_partitions = 0;
+    if (o.keep_tmp) {
+        mkdir_p(tmp + "/solid");
+        for (uint32_t i = 0; i < N; i++) {
+            sig[i] = sample_signature(samples[i], o, max_reads);
+            bool ok = true;
+            uint64_t np = 0;
+            for (uint32_t g = 0; g < G && ok; g++) {
+                SpecHeader h;
+                ok = read_spec_header(spec_path(tmp, samples[i], g, G), h) && spec_matches(h, o, g, G, sig[i]) && (np == 0 || np == h.nb_partitions);
+                if (ok) np = h.nb_partitions;
+            }
+            if (ok && kept_partitions && np != kept_partitions) ok = false;      // all samples of a run share one partitioning
+            if (ok) { reuse[i] = 1; kept_partitions = np; }
+        }
+    }
+    uint32_t kept_log2 = 0;
+    while (((uint64_t)1 << kept_log2) < kept_partitions) kept_log2++;
     std::vector<simka_ctx *> ctx(G, nullptr);
     const uint32_t flags = (o.simple ? SIMKA_DIST_SIMPLE : 0u) | (o.complex_ ? SIMKA_DIST_COMPLEX : 0u);
     for (uint32_t g = 0; g < G; g++) {
@@ -421,6 +527,7 @@ int main(int argc, char **argv) {
         uint64_t biggest = 0;
         for (auto &s : samples) { uint64_t b = 0; for (auto &p : s.parts) for (auto &fn : p) { struct stat st; if (stat(fn.c_str(), &st) == 0) b += (uint64_t)st.st_size * (fn.size() > 3 && fn.substr(fn.size() - 3) == ".gz" ? 5 : 1); } biggest = std::max(biggest, b); }
         cfg.max_kmers_per_sample = std::max<uint64_t>(biggest, 1);
+        if (kept_partitions) cfg.log2_partitions = kept_log2;      // new samples join the partitioning of the kept spectra
         int rc = simka_create(&cfg, &ctx[g]);
         if (rc != SIMKA_OK) { std::cout << "EXCEPTION: " << simka_last_error(nullptr) << std::endl; return EXIT_FAILURE; }
     }
@@ -428,10 +535,21 @@ int main(int argc, char **argv) {
     // count (ref: SimkaPotaraAlgorithm::count, src/SimkaPotara.hpp:813-972)
     if (o.verbose) std::cout << "Counting k-mers... (log files are " << tmp << "/log/count_*)" << std::endl;
     std::vector<simka_sample_totals> totals(N);
-    SampleLoader loader(samples, o, max_reads, nthreads, nthreads + 2);
+    SampleLoader loader(samples, o, max_reads, nthreads, nthreads + 2, reuse);
     for (uint32_t i = 0; i < N; i++) {
         Packed *pkp;
         if (!loader.get(i, pkp)) die("ERROR: Can't open dataset: " + samples[i].id);
+        if (reuse[i]) {     // ref: src/SimkaPotara.hpp:837-842 (count_synchro/<ID>.ok exists -> the sample is not recounted)
+            for (uint32_t g = 0; g < G; g++) {
+                Spectrum sp;
+                if (!read_spec(spec_path(tmp, samples[i], g, G), sp)) die("ERROR: cannot read " + spec_path(tmp, samples[i], g, G) + " (remove it to recount the sample)");
+                check(ctx[g], simka_import_sample(ctx[g], i, &sp.h.totals, sp.part_counts.data(), sp.h.nb_partitions, sp.keys.data(), sp.counts.data(),
+                                                  sp.h.nb_records), "simka_import_sample");
+            }
+            if (o.verbose) std::cout << "\t" << samples[i].id << ": k-mer spectrum reused from " << tmp << "/solid" << std::endl;
+            loader.release(i);
+            continue;
+        }
         Packed &pk = *pkp;
         simka_reads r;
         memset(&r, 0, sizeof r);
@@ -439,6 +557,23 @@ int main(int argc, char **argv) {
         r.fixed_len = 0; r.on_device = 0; r.nb_input_reads = pk.nb_reads;
         for (uint32_t g = 0; g < G; g++) check(ctx[g], simka_count_sample(ctx[g], i, &r), "simka_count_sample");
         loader.release(i);     // host buffers may be reused as soon as simka_count_sample returns
+        if (o.keep_tmp) {      // persist the spectrum so that a later run with more samples skips this one
+            for (uint32_t g = 0; g < G; g++) {
+                Spectrum sp;
+                simka_spectrum_info info;
+                check(ctx[g], simka_sample_spectrum_info(ctx[g], i, &info), "simka_sample_spectrum_info");
+                sp.part_counts.resize(info.nb_partitions); sp.keys.resize(info.nb_records); sp.counts.resize(info.nb_records);
+                check(ctx[g], simka_export_sample(ctx[g], i, sp.part_counts.data(), sp.keys.data(), sp.counts.data()), "simka_export_sample");
+                memset(&sp.h, 0, sizeof sp.h);
+                memcpy(sp.h.magic, "SIMKSPC1", 8);
+                sp.h.abi = (uint64_t)simka_abi_version(); sp.h.kmer_size = (uint64_t)o.kmer_size;
+                sp.h.abundance_min = (uint64_t)o.abundance_min; sp.h.abundance_max = (uint64_t)o.abundance_max;
+                sp.h.shard_index = g; sp.h.shard_count = G; sp.h.nb_partitions = info.nb_partitions; sp.h.nb_records = info.nb_records;
+                sp.h.signature = sig[i];
+                check(ctx[g], simka_get_sample_totals(ctx[g], i, &sp.h.totals), "simka_get_sample_totals");
+                if (!write_spec(spec_path(tmp, samples[i], g, G), sp)) die("ERROR: cannot write " + spec_path(tmp, samples[i], g, G));
+            }
+        }
     }
     for (uint32_t i = 0; i < N; i++) {
         simka_sample_totals sum; memset(&sum, 0, sizeof sum);

@@ -520,8 +520,6 @@ static int run_count_kernels(simka_ctx *ctx, uint32_t sample, const SimkaScanArg
     // level-2 regions hold 4-byte remainders when the partition bits leave <= 31 of the key (k <= 23 at the usual geometry)
     static const bool wide_only = getenv("SIMKA_WIDE_KEYS") != nullptr;
     l2.rem_bits = key.W - key.pb;
-    static const bool direct = getenv("SIMKA_SPLIT_DIRECT") != nullptr;
-    l2.direct = direct ? 1u : 0u;
     l2.narrow = (!wide_only && l2.rem_bits <= 31u) ? 1u : 0u;
     l2.spill_keys = L.d_spill_keys; l2.spill_part = L.d_spill_part; l2.spill_cursor = L.d_spill_cursor;
     l2.spill_cap = std::min(L.spill_cap, L.spill_part_cap);
@@ -664,6 +662,132 @@ SIMKA_EXPORT int simka_get_sample_totals(simka_ctx *ctx, uint32_t sample, simka_
     out->nb_reads = ctx->nb_reads[sample];
     out->nb_distinct = t[SIMKA_TOT_D]; out->nb_kmers = t[SIMKA_TOT_N]; out->sum_sq = t[SIMKA_TOT_Q];
     out->kmer_occurrences = t[SIMKA_TOT_KOCC]; out->distinct_all = t[SIMKA_TOT_DALL];
+    return SIMKA_OK;
+}
+
+// ---- -keep-tmp: spectra out of / into the context --------------------------------------------
+static int spectrum_rows(simka_ctx *ctx, uint32_t sample, const char *who, std::vector<uint32_t> &foff, std::vector<uint32_t> &fcnt) {
+    const uint32_t N = ctx->cfg.nb_samples;
+    if (sample >= N || !ctx->counted[sample]) return ctx->fail(SIMKA_ERR_STATE, "%s: sample %u not counted", who, sample);
+    HIPCHK(hipSetDevice(ctx->cfg.device));
+    int rc = resolve_pending(ctx);
+    if (rc) return rc;
+    rc = check_device_error(ctx);
+    if (rc) return rc;
+    foff.assign(ctx->nparts, 0); fcnt.assign(ctx->nparts, 0);
+    if (!ctx->geometry_ready) return SIMKA_OK;        // only empty samples so far
+    HIPCHK(hipMemcpyAsync(foff.data(), ctx->d_foff + (uint64_t)sample * ctx->nparts, ctx->nparts * 4, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipMemcpyAsync(fcnt.data(), ctx->d_fcnt + (uint64_t)sample * ctx->nparts, ctx->nparts * 4, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    return SIMKA_OK;
+}
+
+SIMKA_EXPORT int simka_sample_spectrum_info(simka_ctx *ctx, uint32_t sample, simka_spectrum_info *out) {
+    if (!ctx || !out) return SIMKA_ERR_INVALID;
+    std::vector<uint32_t> foff, fcnt;
+    const int rc = spectrum_rows(ctx, sample, "simka_sample_spectrum_info", foff, fcnt);
+    if (rc) return rc;
+    uint64_t n = 0;
+    for (uint32_t c : fcnt) n += c;
+    out->nb_records = n; out->nb_partitions = ctx->nparts;
+    return SIMKA_OK;
+}
+
+SIMKA_EXPORT int simka_export_sample(simka_ctx *ctx, uint32_t sample, uint32_t *part_counts, uint64_t *keys, uint32_t *counts) {
+    if (!ctx || !part_counts) return SIMKA_ERR_INVALID;
+    std::vector<uint32_t> foff, fcnt;
+    int rc = spectrum_rows(ctx, sample, "simka_export_sample", foff, fcnt);
+    if (rc) return rc;
+    std::vector<ull> off(ctx->nparts + 1, 0);
+    for (uint64_t p = 0; p < ctx->nparts; p++) { part_counts[p] = fcnt[p]; off[p + 1] = off[p] + fcnt[p]; }
+    const uint64_t n = off[ctx->nparts];
+    if (n == 0) return SIMKA_OK;
+    if (!keys || !counts) return ctx->fail(SIMKA_ERR_INVALID, "simka_export_sample: keys / counts are NULL");
+    // gather the partition segments (slab-reserved, so with gaps) into one run on the device, then two copies
+    ull *d_off = nullptr, *d_keys = nullptr; uint32_t *d_counts = nullptr;
+    auto cleanup = [&] { if (d_off) (void)hipFree(d_off); if (d_keys) (void)hipFree(d_keys); if (d_counts) (void)hipFree(d_counts); };
+    if (dev_alloc(&d_off, ctx->nparts + 1) != hipSuccess || dev_alloc(&d_keys, n) != hipSuccess || dev_alloc(&d_counts, n) != hipSuccess) {
+        cleanup();
+        return ctx->fail(SIMKA_ERR_NOMEM, "simka_export_sample: cannot allocate %llu records", (unsigned long long)n);
+    }
+    hipError_t e = hipMemcpyAsync(d_off, off.data(), (ctx->nparts + 1) * 8, hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(k_gather_sample, dim3((uint32_t)std::min<uint64_t>(ctx->nparts, (uint64_t)ctx->num_cus * 8)), dim3(256), 0, ctx->stream,
+                           ctx->d_solid_keys, ctx->d_solid_counts, ctx->d_sample_base + sample, ctx->d_foff + (uint64_t)sample * ctx->nparts,
+                           ctx->d_fcnt + (uint64_t)sample * ctx->nparts, d_off, (uint32_t)ctx->nparts, d_keys, d_counts);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpyAsync(keys, d_keys, n * 8, hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(counts, d_counts, n * 4, hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    cleanup();
+    if (e != hipSuccess) return ctx->fail(SIMKA_ERR_HIP, "simka_export_sample: %s", hipGetErrorString(e));
+    return SIMKA_OK;
+}
+
+SIMKA_EXPORT int simka_import_sample(simka_ctx *ctx, uint32_t sample, const simka_sample_totals *totals, const uint32_t *part_counts,
+                                     uint64_t nb_partitions, const uint64_t *keys, const uint32_t *counts, uint64_t nb_records) {
+    if (!ctx || !totals || !part_counts) return SIMKA_ERR_INVALID;
+    const uint32_t N = ctx->cfg.nb_samples, fl = ctx->cfg.dist_flags;
+    if (sample >= N) return ctx->fail(SIMKA_ERR_INVALID, "simka_import_sample: sample index %u out of range", sample);
+    if (ctx->counted[sample]) return ctx->fail(SIMKA_ERR_STATE, "simka_import_sample: sample %u was already counted", sample);
+    if (ctx->merged) return ctx->fail(SIMKA_ERR_STATE, "simka_import_sample: merge already ran");
+    if (nb_records && (!keys || !counts)) return ctx->fail(SIMKA_ERR_INVALID, "simka_import_sample: keys / counts are NULL");
+    if (nb_partitions == 0 || (nb_partitions & (nb_partitions - 1))) return ctx->fail(SIMKA_ERR_INVALID, "simka_import_sample: nb_partitions must be a power of two");
+    HIPCHK(hipSetDevice(ctx->cfg.device));
+    int rc;
+    if (!ctx->geometry_ready) {
+        ctx->cfg.log2_partitions = ceil_log2_u64(nb_partitions);     // the spectrum fixes the partition count of this run
+        rc = setup_geometry(ctx, std::max<uint64_t>({ ctx->cfg.max_kmers_per_sample, totals->kmer_occurrences, nb_records, 1 }));
+        if (rc) return rc;
+    }
+    if (ctx->nparts != nb_partitions)
+        return ctx->fail(SIMKA_ERR_INVALID, "simka_import_sample: spectrum has %llu partitions, this run %llu (pass log2_partitions of the exporting run)",
+                         (unsigned long long)nb_partitions, (unsigned long long)ctx->nparts);
+    std::vector<uint32_t> foff(ctx->nparts);
+    uint64_t run = 0;
+    for (uint64_t p = 0; p < ctx->nparts; p++) { foff[p] = (uint32_t)run; run += part_counts[p]; }
+    if (run != nb_records || nb_records > 0xffffffffull) return ctx->fail(SIMKA_ERR_INVALID, "simka_import_sample: part_counts sum to %llu, nb_records is %llu", (unsigned long long)run, (unsigned long long)nb_records);
+    rc = resolve_pending(ctx);          // the arena cursor is only advanced by kernels: settle them first
+    if (rc) return rc;
+    ull cursor = 0;
+    HIPCHK(hipMemcpyAsync(&cursor, ctx->d_arena_cursor, 8, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    if (cursor + nb_records > ctx->arena_cap)
+        return ctx->fail(SIMKA_ERR_NOMEM, "solid-spectrum arena exhausted (%llu records): raise solid_capacity", (unsigned long long)ctx->arena_cap);
+    const ull next = cursor + nb_records;
+    if (nb_records) {
+        HIPCHK(hipMemcpyAsync(ctx->d_solid_keys + cursor, keys, nb_records * 8, hipMemcpyHostToDevice, ctx->stream));
+        HIPCHK(hipMemcpyAsync(ctx->d_solid_counts + cursor, counts, nb_records * 4, hipMemcpyHostToDevice, ctx->stream));
+    }
+    HIPCHK(hipMemcpyAsync(ctx->d_sample_base + sample, &cursor, 8, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(hipMemcpyAsync(ctx->d_arena_cursor, &next, 8, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(hipMemcpyAsync(ctx->d_foff + (uint64_t)sample * ctx->nparts, foff.data(), ctx->nparts * 4, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(hipMemcpyAsync(ctx->d_fcnt + (uint64_t)sample * ctx->nparts, part_counts, ctx->nparts * 4, hipMemcpyHostToDevice, ctx->stream));
+    ull t[SIMKA_NB_TOTALS];
+    t[SIMKA_TOT_D] = totals->nb_distinct; t[SIMKA_TOT_N] = totals->nb_kmers; t[SIMKA_TOT_Q] = totals->sum_sq;
+    t[SIMKA_TOT_DALL] = totals->distinct_all; t[SIMKA_TOT_KOCC] = totals->kmer_occurrences;
+    for (int i = 0; i < SIMKA_NB_TOTALS; i++)
+        HIPCHK(hipMemcpyAsync(ctx->d_stats + stats_off_tot(N, fl, i) + sample, &t[i], 8, hipMemcpyHostToDevice, ctx->stream));
+    std::vector<ull> hist;
+    std::vector<uint32_t> ovf;
+    ull novf = 0;
+    if (ctx->d_hist) {   // -complex-dist: the histogram of solid counts (Whittaker's one-sided terms) is a function of `counts`
+        hist.assign(SIMKA_HIST_MAX, 0);
+        for (uint64_t i = 0; i < nb_records; i++) { const uint32_t c = counts[i]; if (c < SIMKA_HIST_MAX) hist[c]++; else { ovf.push_back(sample); ovf.push_back(c); } }
+        HIPCHK(hipMemcpyAsync(ctx->d_hist + (uint64_t)sample * SIMKA_HIST_MAX, hist.data(), SIMKA_HIST_MAX * 8, hipMemcpyHostToDevice, ctx->stream));
+        if (!ovf.empty()) {
+            HIPCHK(hipMemcpyAsync(&novf, ctx->d_ovf_cursor, 8, hipMemcpyDeviceToHost, ctx->stream));
+            HIPCHK(hipStreamSynchronize(ctx->stream));
+            const ull add = ovf.size() / 2;
+            if (novf + add <= ctx->ovf_cap) HIPCHK(hipMemcpyAsync(ctx->d_ovf_list + 2 * novf, ovf.data(), ovf.size() * 4, hipMemcpyHostToDevice, ctx->stream));
+            novf += add;      // past the capacity simka_merge reports the overflow, as for counted samples
+            HIPCHK(hipMemcpyAsync(ctx->d_ovf_cursor, &novf, 8, hipMemcpyHostToDevice, ctx->stream));
+        }
+    }
+    HIPCHK(hipStreamSynchronize(ctx->stream));       // host buffers (caller's and ours) may go away
+    ctx->nb_reads[sample] = totals->nb_reads;
+    ctx->counted[sample] = 1;
     return SIMKA_OK;
 }
 

@@ -97,7 +97,6 @@ struct SimkaCountOut {
 // level-2 partition regions of one sample (k_split -> k_count)
 struct SimkaL2 {
     unsigned long long *l2_keys;             // [nparts][cap2]  (u32 remainders when `narrow`)
-    uint32_t direct;                         // experiment: k_split writes without LDS staging
     uint32_t narrow, rem_bits;               // W - pb <= 31: regions hold the low rem_bits of each key, the partition is implicit
     unsigned long long cap2;                 // keys a region can hold
     uint32_t *p_count;                       // [nparts] keys routed to the partition (may exceed cap2: spilled)

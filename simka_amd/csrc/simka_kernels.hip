@@ -330,39 +330,22 @@ k_split(const uint64_t *l1_keys, const ull *b1_start, const ull *b1_end, const u
             gpos[b] = g;
         }
         __syncthreads();
-        if (l2.direct) {
-            // EXPERIMENT: no LDS staging -- every key goes straight to its slot of the run (L2 merges the partial lines)
-#pragma unroll
-            for (int q = 0; q < PER; q++) {
-                const uint64_t key = keys[q];
-                if (key == SIMKA_EMPTY_KEY) continue;
-                const uint32_t b = simka_key_l2(key, cfg);
-                const ull g = gpos[b];
-                const uint32_t off = ranks[q];
-                if (g == ~0ull) continue;
-                if (g >> 63) { const ull sp = (g & ~(1ull << 63)) + off; l2.spill_keys[sp] = key; l2.spill_part[sp] = (b1 << cfg.l2) | b; }
-                else if (NARROW) ((uint32_t *)l2.l2_keys)[g + off] = (uint32_t)key & rem_mask;
-                else l2.l2_keys[g + off] = key;
-            }
-            __syncthreads();
-        } else {
         block_excl_scan<K2_BLOCK>(hist, B2, tmp);
 #pragma unroll
-            for (int q = 0; q < PER; q++)
-                if (keys[q] != SIMKA_EMPTY_KEY) stage[hist[simka_key_l2(keys[q], cfg)] + ranks[q]] = keys[q];
-            __syncthreads();
-            for (uint32_t idx = tid; idx < n; idx += K2_BLOCK) {
-                const uint64_t key = stage[idx];
-                const uint32_t b = simka_key_l2(key, cfg);
-                const ull g = gpos[b];
-                const uint32_t off = idx - hist[b];
-                if (g == ~0ull) continue;
-                if (g >> 63) { const ull sp = (g & ~(1ull << 63)) + off; l2.spill_keys[sp] = key; l2.spill_part[sp] = (b1 << cfg.l2) | b; }
-                else if (NARROW) ((uint32_t *)l2.l2_keys)[g + off] = (uint32_t)key & rem_mask;    // the partition bits are implicit
-                else l2.l2_keys[g + off] = key;
-            }
-            __syncthreads();
+        for (int q = 0; q < PER; q++)
+            if (keys[q] != SIMKA_EMPTY_KEY) stage[hist[simka_key_l2(keys[q], cfg)] + ranks[q]] = keys[q];
+        __syncthreads();
+        for (uint32_t idx = tid; idx < n; idx += K2_BLOCK) {
+            const uint64_t key = stage[idx];
+            const uint32_t b = simka_key_l2(key, cfg);
+            const ull g = gpos[b];
+            const uint32_t off = idx - hist[b];
+            if (g == ~0ull) continue;
+            if (g >> 63) { const ull sp = (g & ~(1ull << 63)) + off; l2.spill_keys[sp] = key; l2.spill_part[sp] = (b1 << cfg.l2) | b; }
+            else if (NARROW) ((uint32_t *)l2.l2_keys)[g + off] = (uint32_t)key & rem_mask;    // the partition bits are implicit
+            else l2.l2_keys[g + off] = key;
         }
+        __syncthreads();
 #pragma unroll
         for (int q = 0; q < PER; q++) keys[q] = nkeys[q];
     }
@@ -1307,6 +1290,20 @@ k_pairs_global(const SimkaSpan *huge, const ull *cursors, const ull *entries, Si
             y++;
             if (y == s_) { x++; y = x + 1u; ex = ent[x < s_ ? x : s_ - 1u]; }
         }
+    }
+}
+
+// --------------------------------------------------------------------------------------------
+// k_gather_sample: the arena records of one sample, partition-major and gap-free (simka_export_sample)
+// --------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+k_gather_sample(const ull *solid_keys, const uint32_t *solid_counts, const ull *sample_base, const uint32_t *foff, const uint32_t *fcnt,
+                const ull *out_off, uint32_t nparts, ull *out_keys, uint32_t *out_counts) {
+    const ull base = *sample_base;
+    for (uint32_t p = blockIdx.x; p < nparts; p += gridDim.x) {
+        const uint32_t n = fcnt[p];
+        const ull src = base + foff[p], dst = out_off[p];
+        for (uint32_t i = threadIdx.x; i < n; i += 256) { out_keys[dst + i] = solid_keys[src + i]; out_counts[dst + i] = solid_counts[src + i]; }
     }
 }
 

@@ -449,3 +449,83 @@ def test_cli_read_filters_equal_prefiltered_inputs(gpu_required, tmp_path):
     a = _run_cli(["-in", str(raw / "in.txt"), "-min-read-size", "80", "-min-shannon-index", "1.5"] + common, str(tmp_path / "o1"))
     b = _run_cli(["-in", str(flt / "in.txt")] + common, str(tmp_path / "o2"))
     assert a == b
+
+
+def test_export_import_sample_equals_recounting(gpu_required):
+    """-keep-tmp at the C ABI: spectra exported from one context and imported into a fresh one (which then counts the
+    remaining samples) give the same flat statistics, bit for bit, as counting everything -- including -complex-dist
+    (the count histogram of an imported sample is rebuilt from its counts) and an empty sample."""
+    import simka_amd
+    R, L, k = 2500, 100, 21
+    packed = _synthetic(5, R, L, seed_shift=3)
+    offs = np.arange(R + 1, dtype=np.uint64) * L
+    inputs = [(np.concatenate([pk, np.zeros(2, dtype=np.uint64)]), offs, R * L, R) for pk in packed]
+    inputs[2] = (np.zeros(2, dtype=np.uint64), np.zeros(1, dtype=np.uint64), 0, 0)          # an empty sample travels too
+    kw = dict(kmer_size=k, abundance_min=2, simple_dist=True, complex_dist=True)
+
+    def count(ctx, i):
+        pk, off, nb, nin = inputs[i]
+        ctx.count_sample(i, pk, nb, len(off) - 1, offsets=off, nb_input_reads=nin)
+
+    with simka_amd.SimkaContext(5, **kw) as a:
+        for i in range(5):
+            count(a, i)
+        spectra = [a.export_sample(i) for i in range(4)]
+        a.merge()
+        ref = a.stats().flat.copy()
+        geo = a.geometry()
+    assert sum(int(s[1].sum()) for s in spectra) == sum(len(s[2]) for s in spectra) > 0
+    # a later run: samples 0..3 come from their spectra (the first import fixes the partition count), sample 4 is counted
+    with simka_amd.SimkaContext(5, **kw) as b:
+        for i in range(4):
+            b.import_sample(i, *spectra[i])
+        count(b, 4)
+        assert [b.sample_totals(i) for i in range(4)] == [s[0] for s in spectra]
+        b.merge()
+        got = b.stats().flat.copy()
+        assert b.geometry()["log2_level1"] + b.geometry()["log2_level2"] == geo["log2_level1"] + geo["log2_level2"]
+    assert np.array_equal(ref, got)
+    # mismatching partition count is refused
+    with simka_amd.SimkaContext(5, log2_partitions=geo["log2_level1"] + geo["log2_level2"] + 1, **kw) as c:
+        count(c, 4)
+        with pytest.raises(simka_amd.api.SimkaError):
+            c.import_sample(0, *spectra[0])
+
+
+def test_cli_keep_tmp_adds_samples_without_recounting(gpu_required, golden_dir, tmp_path):
+    """README.md:205-206 of the reference: run with -keep-tmp, add samples to the input file, run again -- the old samples are
+    not recounted and the result equals a run from scratch (here: the goldens)."""
+    import subprocess
+    from simka_amd import build as b
+    ex = os.path.join(golden_dir, "example")
+    lines = [l for l in open(os.path.join(ex, "simka_input.txt")).read().splitlines() if l.strip()]
+    fix = lambda l: l.split(":")[0] + ": " + " ; ".join(",".join(os.path.join(ex, f.strip()) for f in part.split(",")) for part in l.split(":", 1)[1].split(";"))
+    first, full = str(tmp_path / "in3.txt"), str(tmp_path / "in5.txt")
+    open(first, "w").write("\n".join(fix(l) for l in lines[:3]) + "\n")
+    open(full, "w").write("\n".join(fix(l) for l in lines) + "\n")
+    tmp = str(tmp_path / "tmp")
+    base = [b.CLI_PATH, "-out-tmp", tmp, "-keep-tmp", "-simple-dist", "-complex-dist", "-kmer-size", "21", "-abundance-min", "2"]
+    r = subprocess.run(base + ["-in", first, "-out", str(tmp_path / "out3")], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    assert r.returncode == 0, r.stdout
+    assert "reused" not in r.stdout
+    specs = sorted(os.listdir(os.path.join(tmp, "simka_output_temp", "solid")))
+    assert len(specs) == 3 and all(s.endswith(".g0of1.spec") for s in specs)
+    r = subprocess.run(base + ["-in", full, "-out", str(tmp_path / "out5")], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    assert r.returncode == 0, r.stdout
+    assert r.stdout.count("k-mer spectrum reused") == 3, r.stdout
+    truth = os.path.join(golden_dir, "truth", "results_k21_t2")
+    n = 0
+    for gzf in glob.glob(os.path.join(str(tmp_path / "out5"), "*.csv.gz")):
+        ref = os.path.join(truth, os.path.basename(gzf)[:-3])
+        if os.path.exists(ref):
+            with gzip.open(gzf, "rb") as f, open(ref, "rb") as g:
+                assert f.read() == g.read(), os.path.basename(gzf)
+            n += 1
+    assert n == 20
+    # other parameters: the kept spectra do not apply, everything is recounted (and still right)
+    r = subprocess.run(base[:-1] + ["0", "-in", full, "-out", str(tmp_path / "out5b")], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    assert r.returncode == 0, r.stdout
+    assert "reused" not in r.stdout
+    with gzip.open(os.path.join(str(tmp_path / "out5b"), "mat_abundance_braycurtis.csv.gz"), "rb") as f, \
+            open(os.path.join(golden_dir, "truth", "results_k21_t0", "mat_abundance_braycurtis.csv"), "rb") as g:
+        assert f.read() == g.read()
