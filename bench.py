@@ -40,8 +40,9 @@ WORKLOADS = {
 }
 
 
-def gen_device_samples(lib, torch, wl, dev):
-    """genome pool + per-sample reads, generated on the GPU (k_synth_*), 2-bit packed int64 tensors."""
+def gen_device_samples(lib, torch, wl, dev, which=None):
+    """genome pool + per-sample reads, generated on the GPU (k_synth_*), 2-bit packed int64 tensors.
+    which: the samples this rank needs (None = all); the others stay None."""
     from simka_amd import synth
     R, L, n = wl["reads"], wl["L"], wl["n"]
     g = synth.genome_len_for(R, L)
@@ -52,6 +53,9 @@ def gen_device_samples(lib, torch, wl, dev):
     nw = (R * L + 31) // 32
     reads = []
     for s in range(n):
+        if which is not None and s not in which:
+            reads.append(None)
+            continue
         ids, cdf = synth.sample_profile(s)
         d_ids = torch.from_numpy(ids.astype(np.int32)).to(dev)
         d_cdf = torch.from_numpy(cdf.view(np.int32)).to(dev)
@@ -109,6 +113,9 @@ def main():
     ap.add_argument("--samples", type=int, default=0, help="override number of samples")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--log2-partitions", type=int, default=0)
+    ap.add_argument("--mgpu", default=os.environ.get("SIMKA_BENCH_MGPU", "sample"), choices=["sample", "partition"],
+                    help="N > 1: 'sample' = samples counted on rank s %% N, spectra exchanged by partition range (all-to-all), "
+                         "'partition' = every rank scans everything and keeps its partition shard (no exchange)")
     args = ap.parse_args()
 
     import torch
@@ -121,11 +128,17 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device: the simka_amd path has no CPU fallback")
+    local = local % torch.cuda.device_count()        # tests run two ranks on one GPU (gloo)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
+    backend = os.environ.get("SIMKA_BENCH_BACKEND", "nccl")      # "nccl" IS RCCL on ROCm; gloo only for single-GPU tests of the N>1 path
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
+    by_sample = world > 1 and args.mgpu == "sample"
 
     wl = dict(WORKLOADS[args.workload])
     if args.reads:
@@ -134,24 +147,32 @@ def main():
         wl["n"] = args.samples
     n, R, L, k = wl["n"], wl["reads"], wl["L"], wl["k"]
     lib = simka_amd.load_library()
-    pool, reads = gen_device_samples(lib, torch, wl, dev)
+    pool, reads = gen_device_samples(lib, torch, wl, dev, which=set(sdist.samples_of(rank, world, n)) if by_sample else None)
     nb_bases = R * L
     kocc_per_sample = R * (L - k + 1)
 
     ctx = simka_amd.SimkaContext(n, kmer_size=k, abundance_min=wl["amin"], simple_dist=wl["simple"],
                                  complex_dist=wl.get("complex", False), device=local,
-                                 shard_index=rank, shard_count=world, max_kmers_per_sample=kocc_per_sample,
-                                 log2_partitions=args.log2_partitions)
+                                 shard_index=0 if by_sample else rank, shard_count=1 if by_sample else world,
+                                 max_kmers_per_sample=kocc_per_sample, log2_partitions=args.log2_partitions)
+
+    def count(s):
+        ctx.count_sample(s, reads[s].data_ptr(), nb_bases, R, fixed_len=L, on_device=True)
 
     def step():
-        ctx.reset()
-        for s in range(n):
-            ctx.count_sample(s, reads[s].data_ptr(), nb_bases, R, fixed_len=L, on_device=True)
-        if wl.get("complex") and world > 1:        # -complex-dist terms need the GLOBAL per-sample totals inside the merge
-            sdist.allreduce_totals_device(ctx)
-        ctx.merge()
-        # one RCCL all-reduce of the flat u64 accumulators (no-op at N=1)
-        sdist.allreduce_stats_device(ctx, totals_already_reduced=bool(wl.get("complex")) and world > 1)
+        if by_sample:
+            # rank r counts the samples s % N == r over the whole key space, the solid spectra move to the rank that merges
+            # their partition range (RCCL all-to-all), the pair accumulators are all-reduced (simka_amd/dist.py)
+            sdist.count_exchange_merge(ctx, count, n, dev)
+        else:
+            ctx.reset()
+            for s in range(n):
+                count(s)
+            if wl.get("complex") and world > 1:        # -complex-dist terms need the GLOBAL per-sample totals inside the merge
+                sdist.allreduce_totals_device(ctx)
+            ctx.merge()
+            # one RCCL all-reduce of the flat u64 accumulators (no-op at N=1)
+            sdist.allreduce_stats_device(ctx, totals_already_reduced=bool(wl.get("complex")) and world > 1)
         st = ctx.stats()
         mats = st.matrices()
         return st, mats
@@ -175,7 +196,7 @@ def main():
     dt = time.perf_counter() - t0
     ctx.profile_enable(False)
     if world > 1:
-        tdt = torch.tensor([dt], dtype=torch.float64, device=dev)
+        tdt = torch.tensor([dt], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
         dist.all_reduce(tdt, op=dist.ReduceOp.MAX)
         dt = float(tdt.item())
     prof = ctx.profile()
@@ -193,10 +214,11 @@ def main():
     # (scatter write, split read, split write, count read), so each transfer earns half credit (4 B); the kernels' shares
     # still add up to exactly B_alg:
     #   k_scan<scatter>: R*L/4 + 4*K_occ      k_split: 8*K_occ      k_count_fast: 4*K_occ + 12*K_dist      k_regroup: 12*K_solid
-    share = 1.0 / world                    # each rank owns 1/world of the key space
+    share = 1.0 / world                    # each rank owns 1/world of the key space (or counts 1/world of the samples)
+    scan_reads = n * nb_bases / 4.0 * (share if by_sample else 1.0)       # partition shards: every rank reads every base
     alg_bytes_per_step = {
         "k_scan<hist>": 0.0,
-        "k_scan<scatter>": n * nb_bases / 4.0 + 4.0 * K_occ * share,
+        "k_scan<scatter>": scan_reads + 4.0 * K_occ * share,
         "k_split": 8.0 * K_occ * share,
         "k_count_fast": 4.0 * K_occ * share + 12.0 * K_dist * share,
         "k_count": 0.0,
@@ -210,7 +232,7 @@ def main():
     dom_bytes_per_launch = alg_bytes_per_step.get(dom, 0.0) * args.steps / max(dom_launches, 1)
     dom_avg_ms = dom_ms / max(dom_launches, 1)
     achieved = dom_bytes_per_launch / (dom_avg_ms * 1e-3) / 1e9 if dom_avg_ms > 0 else 0.0
-    b_alg = n * nb_bases / 4.0 + (16.0 * K_occ + 12.0 * K_dist + 12.0 * K_solid) * share
+    b_alg = scan_reads + (16.0 * K_occ + 12.0 * K_dist + 12.0 * K_solid) * share
     path_gbs = b_alg * args.steps / (total_kernel_ms * 1e-3) / 1e9 if total_kernel_ms > 0 else 0.0
     # HBM bytes per launch of the dominant kernel from the PMC passes committed under profiles/ (scripts/pmc_traffic.sh:
     # FETCH_SIZE and WRITE_SIZE in separate rocprofv3 runs, FETCH_SIZE x2 on gfx950); only when it is the same workload
@@ -253,9 +275,12 @@ def main():
         "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "u64", "data": "synthetic",
         "config": {"workload": "%s: %s" % (args.workload, wl["desc"]), "samples": n, "reads_per_sample": R, "read_len": L,
                    "kmer_size": k, "abundance_min": wl["amin"], "simple_dist": wl["simple"],
-                   "parallelism": "partition shards x%d + 1 all-reduce" % world if world > 1 else "1 GPU",
+                   "parallelism": ("1 GPU" if world == 1 else "samples x%d -> all-to-all of solid spectra by partition range -> 1 all-reduce" % world
+                                   if by_sample else "partition shards x%d + 1 all-reduce" % world),
                    "kmer_occurrences": K_occ, "distinct_kmers": K_dist, "solid_kmers": K_solid,
-                   "kmer_occurrences_per_s": K_occ / (dt / args.steps), "geometry": geo},
+                   "kmer_occurrences_per_s": K_occ / (dt / args.steps), "geometry": geo,
+                   # sha1 of every distance matrix (float32 bytes, by name): equal across --gpus N for the same workload
+                   "matrix_checksum": __import__("hashlib").sha1(b"".join(np.ascontiguousarray(mats[m]).tobytes() for m in sorted(mats))).hexdigest()[:16]},
         "roofline": roofline,
     }
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

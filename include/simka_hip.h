@@ -151,6 +151,27 @@ int simka_export_sample(simka_ctx *ctx, uint32_t sample_index, uint32_t *part_co
 int simka_import_sample(simka_ctx *ctx, uint32_t sample_index, const simka_sample_totals *totals, const uint32_t *part_counts,
                         uint64_t nb_partitions, const uint64_t *keys, const uint32_t *counts, uint64_t nb_records);
 
+/* The same with keys / counts in DEVICE memory of the context's GPU (part_counts stays a host array): the multi-GPU exchange
+ * -- samples counted on one rank, merged by partition range on another; the reference's counterpart is every simkaMerge job
+ * reading partition p of every sample's solid/ directory (ref: src/SimkaMerge.cpp:1164-1264) -- moves spectra between
+ * GPUs with RCCL without touching the host.  The buffers must hold nb_records (simka_sample_spectrum_info) elements. */
+int simka_export_sample_device(simka_ctx *ctx, uint32_t sample_index, uint32_t *part_counts, void *d_keys, void *d_counts);
+int simka_import_sample_device(simka_ctx *ctx, uint32_t sample_index, const simka_sample_totals *totals, const uint32_t *part_counts,
+                               uint64_t nb_partitions, const void *d_keys, const void *d_counts, uint64_t nb_records);
+
+/* Batch forms (one synchronisation for many samples; what simka_amd/dist.py's exchange uses):
+ *  - info:   part_counts[nb][nb_partitions] and totals[nb] of counted samples;
+ *  - gather: the caller chooses where each (sample, partition) run goes in its device buffers through
+ *            out_offsets[nb][nb_partitions] (e.g. destination-rank-major, ready to be sent);
+ *  - import: d_keys / d_counts hold nb_records records (< 2^32) of the partitions [part_lo, part_lo + part_width): the run of
+ *            partition part_lo + p of samples[i] starts at in_offsets[i][p] and has part_counts[i][p] records (both matrices
+ *            are [nb][part_width]); the block is copied into the context once. */
+int simka_samples_spectrum_info(simka_ctx *ctx, const uint32_t *samples, uint32_t nb, uint32_t *part_counts, simka_sample_totals *totals);
+int simka_gather_samples_device(simka_ctx *ctx, const uint32_t *samples, uint32_t nb, const uint64_t *out_offsets, void *d_keys, void *d_counts);
+int simka_import_samples_device(simka_ctx *ctx, const uint32_t *samples, uint32_t nb, const simka_sample_totals *totals,
+                                uint64_t part_lo, uint64_t part_width, const uint32_t *part_counts, const uint64_t *in_offsets,
+                                uint64_t nb_partitions, const void *d_keys, const void *d_counts, uint64_t nb_records);
+
 /* ---- merge side ---------------------------------------------------------------------------
  * Replaces every `simkaMerge` job: the N-way k-mer merge (ref: src/SimkaMerge.cpp:1164-1264),
  * its gate (ref: :1307-1326) and SimkaCountProcessorSimple::process -> updateDistance*

@@ -92,6 +92,11 @@ def load_library(build_if_missing=True):
         "simka_sample_spectrum_info": (i32, [vp, u32, C.POINTER(SpectrumInfo)]),
         "simka_export_sample": (i32, [vp, u32, vp, vp, vp]),
         "simka_import_sample": (i32, [vp, u32, C.POINTER(SampleTotals), vp, u64, vp, vp, u64]),
+        "simka_export_sample_device": (i32, [vp, u32, vp, vp, vp]),
+        "simka_import_sample_device": (i32, [vp, u32, C.POINTER(SampleTotals), vp, u64, vp, vp, u64]),
+        "simka_samples_spectrum_info": (i32, [vp, vp, u32, vp, vp]),
+        "simka_gather_samples_device": (i32, [vp, vp, u32, vp, vp, vp]),
+        "simka_import_samples_device": (i32, [vp, vp, u32, vp, u64, u64, vp, vp, u64, vp, vp, u64]),
         "simka_merge": (i32, [vp]),
         "simka_stats_device_buffer": (i32, [vp, C.POINTER(vp), C.POINTER(u64)]),
         "simka_stats_download": (i32, [vp, vp, u64, C.POINTER(StatsView)]),
@@ -315,6 +320,57 @@ class SimkaContext:
         c = np.ascontiguousarray(counts, dtype=np.uint32)
         self._check(self.lib.simka_import_sample(self.h, index, C.byref(t), pc.ctypes.data, len(pc), k.ctypes.data if len(k) else None,
                                                  c.ctypes.data if len(c) else None, len(k)))
+
+    def export_sample_device(self, index, device):
+        """export_sample with keys (int64) / counts (int32) as torch tensors on the context's GPU (multi-GPU exchange)."""
+        import torch
+        info = SpectrumInfo()
+        self._check(self.lib.simka_sample_spectrum_info(self.h, index, C.byref(info)))
+        pc = np.zeros(info.nb_partitions, dtype=np.uint32)
+        keys = torch.empty(info.nb_records, dtype=torch.int64, device=device)
+        counts = torch.empty(info.nb_records, dtype=torch.int32, device=device)
+        self._check(self.lib.simka_export_sample_device(self.h, index, pc.ctypes.data, keys.data_ptr() if info.nb_records else None,
+                                                        counts.data_ptr() if info.nb_records else None))
+        return self.sample_totals(index), pc, keys, counts
+
+    def import_sample_device(self, index, totals, part_counts, keys, counts):
+        """keys / counts: torch tensors on the context's GPU (or slices of one)."""
+        t = SampleTotals(totals["nb_reads"], totals["D"], totals["N"], totals["Q"], totals["K_occ"], totals["D_all"])
+        pc = np.ascontiguousarray(part_counts, dtype=np.uint32)
+        n = int(keys.numel())
+        self._check(self.lib.simka_import_sample_device(self.h, index, C.byref(t), pc.ctypes.data, len(pc), keys.data_ptr() if n else None,
+                                                        counts.data_ptr() if n else None, n))
+
+    # batch forms: one synchronisation for many samples (simka_amd/dist.py)
+    def nb_partitions(self):
+        g = self.geometry()
+        return 1 << (g["log2_level1"] + g["log2_level2"])
+
+    def samples_spectrum_info(self, samples):
+        """-> (part_counts u32 [nb, nparts], totals SampleTotals array) of counted samples."""
+        idx = np.ascontiguousarray(samples, dtype=np.uint32)
+        pc = np.zeros((len(idx), self.nb_partitions()), dtype=np.uint32)
+        tot = (SampleTotals * max(len(idx), 1))()
+        self._check(self.lib.simka_samples_spectrum_info(self.h, idx.ctypes.data, len(idx), pc.ctypes.data, C.addressof(tot)))
+        return pc, tot
+
+    def gather_samples_device(self, samples, out_offsets, keys, counts):
+        """Copy run (sample j, partition p) to keys/counts[out_offsets[j, p] ...] (torch tensors on this GPU)."""
+        idx = np.ascontiguousarray(samples, dtype=np.uint32)
+        off = np.ascontiguousarray(out_offsets, dtype=np.uint64)
+        if len(idx) == 0 or keys.numel() == 0:
+            return
+        self._check(self.lib.simka_gather_samples_device(self.h, idx.ctypes.data, len(idx), off.ctypes.data, keys.data_ptr(), counts.data_ptr()))
+
+    def import_samples_device(self, samples, totals, part_lo, part_counts, in_offsets, nb_partitions, keys, counts):
+        """part_counts / in_offsets: [nb, width] for the partitions [part_lo, part_lo + width); totals: SampleTotals array."""
+        idx = np.ascontiguousarray(samples, dtype=np.uint32)
+        pc = np.ascontiguousarray(part_counts, dtype=np.uint32)
+        off = np.ascontiguousarray(in_offsets, dtype=np.uint64)
+        n = int(keys.numel())
+        self._check(self.lib.simka_import_samples_device(self.h, idx.ctypes.data, len(idx), C.addressof(totals), part_lo, pc.shape[1], pc.ctypes.data,
+                                                         off.ctypes.data, nb_partitions, keys.data_ptr() if n else None,
+                                                         counts.data_ptr() if n else None, n))
 
     # -- merge side -------------------------------------------------------------------------
     def merge(self):

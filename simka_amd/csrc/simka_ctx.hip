@@ -71,6 +71,7 @@ struct simka_ctx {
     uint32_t *d_fb_off = nullptr; SimkaSpan *d_spans = nullptr; ull *d_cursors = nullptr; SimkaSpan *d_huge = nullptr;
     uint64_t merge_cap = 0, fb_cap = 0, span_cap = 0, huge_cap = 0;
     // -complex-dist: per-sample histogram of solid counts + list of the counts above the histogram
+    ull *d_xoff = nullptr; uint64_t xoff_cap = 0;               // simka_gather_samples_device: destination offsets
     ull *d_hist = nullptr; uint32_t *d_ovf_list = nullptr; ull *d_ovf_cursor = nullptr; uint64_t ovf_cap = 0;
 
     std::vector<uint8_t> counted;
@@ -373,7 +374,7 @@ SIMKA_EXPORT void simka_destroy(simka_ctx *ctx) {
     void *ptrs[] = { ctx->d_reads, ctx->d_offsets, ctx->d_l1_ovf, ctx->d_solid_keys, ctx->d_solid_counts, ctx->d_arena_cursor,
                      ctx->d_sample_base, ctx->d_foff, ctx->d_fcnt, ctx->d_stats, ctx->d_err, ctx->d_part_total,
                      ctx->d_part_off, ctx->d_mkeys, ctx->d_mvals, ctx->d_entries, ctx->d_groups, ctx->d_fb_off,
-                     ctx->d_spans, ctx->d_cursors, ctx->d_huge, ctx->d_hist, ctx->d_ovf_list, ctx->d_ovf_cursor };
+                     ctx->d_spans, ctx->d_cursors, ctx->d_huge, ctx->d_xoff, ctx->d_hist, ctx->d_ovf_list, ctx->d_ovf_cursor };
     for (void *p : ptrs) if (p) (void)hipFree(p);
     if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
@@ -693,22 +694,22 @@ SIMKA_EXPORT int simka_sample_spectrum_info(simka_ctx *ctx, uint32_t sample, sim
     return SIMKA_OK;
 }
 
-SIMKA_EXPORT int simka_export_sample(simka_ctx *ctx, uint32_t sample, uint32_t *part_counts, uint64_t *keys, uint32_t *counts) {
+static int export_sample(simka_ctx *ctx, uint32_t sample, uint32_t *part_counts, void *keys, void *counts, bool on_device, const char *who) {
     if (!ctx || !part_counts) return SIMKA_ERR_INVALID;
     std::vector<uint32_t> foff, fcnt;
-    int rc = spectrum_rows(ctx, sample, "simka_export_sample", foff, fcnt);
+    int rc = spectrum_rows(ctx, sample, who, foff, fcnt);
     if (rc) return rc;
     std::vector<ull> off(ctx->nparts + 1, 0);
     for (uint64_t p = 0; p < ctx->nparts; p++) { part_counts[p] = fcnt[p]; off[p + 1] = off[p] + fcnt[p]; }
     const uint64_t n = off[ctx->nparts];
     if (n == 0) return SIMKA_OK;
-    if (!keys || !counts) return ctx->fail(SIMKA_ERR_INVALID, "simka_export_sample: keys / counts are NULL");
-    // gather the partition segments (slab-reserved, so with gaps) into one run on the device, then two copies
-    ull *d_off = nullptr, *d_keys = nullptr; uint32_t *d_counts = nullptr;
-    auto cleanup = [&] { if (d_off) (void)hipFree(d_off); if (d_keys) (void)hipFree(d_keys); if (d_counts) (void)hipFree(d_counts); };
-    if (dev_alloc(&d_off, ctx->nparts + 1) != hipSuccess || dev_alloc(&d_keys, n) != hipSuccess || dev_alloc(&d_counts, n) != hipSuccess) {
+    if (!keys || !counts) return ctx->fail(SIMKA_ERR_INVALID, "%s: keys / counts are NULL", who);
+    // gather the partition segments (slab-reserved, so with gaps) into one partition-major run on the device
+    ull *d_off = nullptr, *d_keys = on_device ? (ull *)keys : nullptr; uint32_t *d_counts = on_device ? (uint32_t *)counts : nullptr;
+    auto cleanup = [&] { if (d_off) (void)hipFree(d_off); if (!on_device) { if (d_keys) (void)hipFree(d_keys); if (d_counts) (void)hipFree(d_counts); } };
+    if (dev_alloc(&d_off, ctx->nparts + 1) != hipSuccess || (!on_device && (dev_alloc(&d_keys, n) != hipSuccess || dev_alloc(&d_counts, n) != hipSuccess))) {
         cleanup();
-        return ctx->fail(SIMKA_ERR_NOMEM, "simka_export_sample: cannot allocate %llu records", (unsigned long long)n);
+        return ctx->fail(SIMKA_ERR_NOMEM, "%s: cannot allocate %llu records", who, (unsigned long long)n);
     }
     hipError_t e = hipMemcpyAsync(d_off, off.data(), (ctx->nparts + 1) * 8, hipMemcpyHostToDevice, ctx->stream);
     if (e == hipSuccess) {
@@ -717,22 +718,30 @@ SIMKA_EXPORT int simka_export_sample(simka_ctx *ctx, uint32_t sample, uint32_t *
                            ctx->d_fcnt + (uint64_t)sample * ctx->nparts, d_off, (uint32_t)ctx->nparts, d_keys, d_counts);
         e = hipGetLastError();
     }
-    if (e == hipSuccess) e = hipMemcpyAsync(keys, d_keys, n * 8, hipMemcpyDeviceToHost, ctx->stream);
-    if (e == hipSuccess) e = hipMemcpyAsync(counts, d_counts, n * 4, hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess && !on_device) e = hipMemcpyAsync(keys, d_keys, n * 8, hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess && !on_device) e = hipMemcpyAsync(counts, d_counts, n * 4, hipMemcpyDeviceToHost, ctx->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
     cleanup();
-    if (e != hipSuccess) return ctx->fail(SIMKA_ERR_HIP, "simka_export_sample: %s", hipGetErrorString(e));
+    if (e != hipSuccess) return ctx->fail(SIMKA_ERR_HIP, "%s: %s", who, hipGetErrorString(e));
     return SIMKA_OK;
 }
 
-SIMKA_EXPORT int simka_import_sample(simka_ctx *ctx, uint32_t sample, const simka_sample_totals *totals, const uint32_t *part_counts,
-                                     uint64_t nb_partitions, const uint64_t *keys, const uint32_t *counts, uint64_t nb_records) {
+SIMKA_EXPORT int simka_export_sample(simka_ctx *ctx, uint32_t sample, uint32_t *part_counts, uint64_t *keys, uint32_t *counts) {
+    return export_sample(ctx, sample, part_counts, keys, counts, false, "simka_export_sample");
+}
+
+SIMKA_EXPORT int simka_export_sample_device(simka_ctx *ctx, uint32_t sample, uint32_t *part_counts, void *d_keys, void *d_counts) {
+    return export_sample(ctx, sample, part_counts, d_keys, d_counts, true, "simka_export_sample_device");
+}
+
+static int import_sample(simka_ctx *ctx, uint32_t sample, const simka_sample_totals *totals, const uint32_t *part_counts,
+                         uint64_t nb_partitions, const void *keys, const void *counts_any, uint64_t nb_records, bool on_device) {
     if (!ctx || !totals || !part_counts) return SIMKA_ERR_INVALID;
     const uint32_t N = ctx->cfg.nb_samples, fl = ctx->cfg.dist_flags;
     if (sample >= N) return ctx->fail(SIMKA_ERR_INVALID, "simka_import_sample: sample index %u out of range", sample);
     if (ctx->counted[sample]) return ctx->fail(SIMKA_ERR_STATE, "simka_import_sample: sample %u was already counted", sample);
     if (ctx->merged) return ctx->fail(SIMKA_ERR_STATE, "simka_import_sample: merge already ran");
-    if (nb_records && (!keys || !counts)) return ctx->fail(SIMKA_ERR_INVALID, "simka_import_sample: keys / counts are NULL");
+    if (nb_records && (!keys || !counts_any)) return ctx->fail(SIMKA_ERR_INVALID, "simka_import_sample: keys / counts are NULL");
     if (nb_partitions == 0 || (nb_partitions & (nb_partitions - 1))) return ctx->fail(SIMKA_ERR_INVALID, "simka_import_sample: nb_partitions must be a power of two");
     HIPCHK(hipSetDevice(ctx->cfg.device));
     int rc;
@@ -756,9 +765,10 @@ SIMKA_EXPORT int simka_import_sample(simka_ctx *ctx, uint32_t sample, const simk
     if (cursor + nb_records > ctx->arena_cap)
         return ctx->fail(SIMKA_ERR_NOMEM, "solid-spectrum arena exhausted (%llu records): raise solid_capacity", (unsigned long long)ctx->arena_cap);
     const ull next = cursor + nb_records;
+    const hipMemcpyKind kind = on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
     if (nb_records) {
-        HIPCHK(hipMemcpyAsync(ctx->d_solid_keys + cursor, keys, nb_records * 8, hipMemcpyHostToDevice, ctx->stream));
-        HIPCHK(hipMemcpyAsync(ctx->d_solid_counts + cursor, counts, nb_records * 4, hipMemcpyHostToDevice, ctx->stream));
+        HIPCHK(hipMemcpyAsync(ctx->d_solid_keys + cursor, keys, nb_records * 8, kind, ctx->stream));
+        HIPCHK(hipMemcpyAsync(ctx->d_solid_counts + cursor, counts_any, nb_records * 4, kind, ctx->stream));
     }
     HIPCHK(hipMemcpyAsync(ctx->d_sample_base + sample, &cursor, 8, hipMemcpyHostToDevice, ctx->stream));
     HIPCHK(hipMemcpyAsync(ctx->d_arena_cursor, &next, 8, hipMemcpyHostToDevice, ctx->stream));
@@ -772,6 +782,14 @@ SIMKA_EXPORT int simka_import_sample(simka_ctx *ctx, uint32_t sample, const simk
     std::vector<ull> hist;
     std::vector<uint32_t> ovf;
     ull novf = 0;
+    std::vector<uint32_t> counts_host;
+    const uint32_t *counts = on_device ? nullptr : (const uint32_t *)counts_any;
+    if (ctx->d_hist && on_device && nb_records) {
+        counts_host.resize(nb_records);
+        HIPCHK(hipMemcpyAsync(counts_host.data(), counts_any, nb_records * 4, hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(hipStreamSynchronize(ctx->stream));
+        counts = counts_host.data();
+    }
     if (ctx->d_hist) {   // -complex-dist: the histogram of solid counts (Whittaker's one-sided terms) is a function of `counts`
         hist.assign(SIMKA_HIST_MAX, 0);
         for (uint64_t i = 0; i < nb_records; i++) { const uint32_t c = counts[i]; if (c < SIMKA_HIST_MAX) hist[c]++; else { ovf.push_back(sample); ovf.push_back(c); } }
@@ -788,6 +806,178 @@ SIMKA_EXPORT int simka_import_sample(simka_ctx *ctx, uint32_t sample, const simk
     HIPCHK(hipStreamSynchronize(ctx->stream));       // host buffers (caller's and ours) may go away
     ctx->nb_reads[sample] = totals->nb_reads;
     ctx->counted[sample] = 1;
+    return SIMKA_OK;
+}
+
+SIMKA_EXPORT int simka_import_sample(simka_ctx *ctx, uint32_t sample, const simka_sample_totals *totals, const uint32_t *part_counts,
+                                     uint64_t nb_partitions, const uint64_t *keys, const uint32_t *counts, uint64_t nb_records) {
+    return import_sample(ctx, sample, totals, part_counts, nb_partitions, keys, counts, nb_records, false);
+}
+
+SIMKA_EXPORT int simka_import_sample_device(simka_ctx *ctx, uint32_t sample, const simka_sample_totals *totals, const uint32_t *part_counts,
+                                            uint64_t nb_partitions, const void *d_keys, const void *d_counts, uint64_t nb_records) {
+    return import_sample(ctx, sample, totals, part_counts, nb_partitions, d_keys, d_counts, nb_records, true);
+}
+
+// ---- batch forms (multi-GPU exchange) ---------------------------------------------------------
+SIMKA_EXPORT int simka_samples_spectrum_info(simka_ctx *ctx, const uint32_t *samples, uint32_t nb, uint32_t *part_counts, simka_sample_totals *totals) {
+    if (!ctx || (nb && (!samples || !part_counts || !totals))) return SIMKA_ERR_INVALID;
+    const uint32_t N = ctx->cfg.nb_samples, fl = ctx->cfg.dist_flags;
+    for (uint32_t j = 0; j < nb; j++)
+        if (samples[j] >= N || !ctx->counted[samples[j]]) return ctx->fail(SIMKA_ERR_STATE, "simka_samples_spectrum_info: sample %u not counted", samples[j]);
+    HIPCHK(hipSetDevice(ctx->cfg.device));
+    int rc = resolve_pending(ctx);
+    if (rc) return rc;
+    rc = check_device_error(ctx);
+    if (rc) return rc;
+    std::vector<ull> tot((size_t)SIMKA_NB_TOTALS * N, 0);
+    HIPCHK(hipMemcpyAsync(tot.data(), ctx->d_stats + stats_off_tot(N, fl, 0), tot.size() * 8, hipMemcpyDeviceToHost, ctx->stream));
+    for (uint32_t j = 0; j < nb; j++) {
+        if (ctx->geometry_ready) HIPCHK(hipMemcpyAsync(part_counts + (size_t)j * ctx->nparts, ctx->d_fcnt + (uint64_t)samples[j] * ctx->nparts, ctx->nparts * 4, hipMemcpyDeviceToHost, ctx->stream));
+        else memset(part_counts + (size_t)j * ctx->nparts, 0, ctx->nparts * 4);
+    }
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    for (uint32_t j = 0; j < nb; j++) {
+        const uint32_t s = samples[j];
+        totals[j].nb_reads = ctx->nb_reads[s];
+        totals[j].nb_distinct = tot[(size_t)SIMKA_TOT_D * N + s]; totals[j].nb_kmers = tot[(size_t)SIMKA_TOT_N * N + s];
+        totals[j].sum_sq = tot[(size_t)SIMKA_TOT_Q * N + s]; totals[j].kmer_occurrences = tot[(size_t)SIMKA_TOT_KOCC * N + s];
+        totals[j].distinct_all = tot[(size_t)SIMKA_TOT_DALL * N + s];
+    }
+    return SIMKA_OK;
+}
+
+SIMKA_EXPORT int simka_gather_samples_device(simka_ctx *ctx, const uint32_t *samples, uint32_t nb, const uint64_t *out_offsets, void *d_keys, void *d_counts) {
+    if (!ctx) return SIMKA_ERR_INVALID;
+    if (nb == 0 || !ctx->geometry_ready) return SIMKA_OK;
+    if (!samples || !out_offsets || !d_keys || !d_counts) return ctx->fail(SIMKA_ERR_INVALID, "simka_gather_samples_device: NULL argument");
+    const uint32_t N = ctx->cfg.nb_samples;
+    for (uint32_t j = 0; j < nb; j++)
+        if (samples[j] >= N || !ctx->counted[samples[j]]) return ctx->fail(SIMKA_ERR_STATE, "simka_gather_samples_device: sample %u not counted", samples[j]);
+    HIPCHK(hipSetDevice(ctx->cfg.device));
+    int rc = resolve_pending(ctx);
+    if (rc) return rc;
+    rc = ensure_cap(ctx, &ctx->d_xoff, &ctx->xoff_cap, (uint64_t)nb * ctx->nparts + (nb + 1) / 2 + 1); if (rc) return rc;
+    uint32_t *d_samples = (uint32_t *)(ctx->d_xoff + (uint64_t)nb * ctx->nparts);
+    HIPCHK(hipMemcpyAsync(ctx->d_xoff, out_offsets, (uint64_t)nb * ctx->nparts * 8, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(hipMemcpyAsync(d_samples, samples, (size_t)nb * 4, hipMemcpyHostToDevice, ctx->stream));
+    hipLaunchKernelGGL(k_gather_samples, dim3((uint32_t)std::min<uint64_t>(ctx->nparts, (uint64_t)ctx->num_cus * 4), nb), dim3(256), 0, ctx->stream,
+                       ctx->d_solid_keys, ctx->d_solid_counts, ctx->d_sample_base, ctx->d_foff, ctx->d_fcnt, d_samples, ctx->d_xoff,
+                       (uint32_t)ctx->nparts, (ull *)d_keys, (uint32_t *)d_counts);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(ctx->stream));       // the caller hands the buffers to RCCL on another stream
+    return SIMKA_OK;
+}
+
+SIMKA_EXPORT int simka_import_samples_device(simka_ctx *ctx, const uint32_t *samples, uint32_t nb, const simka_sample_totals *totals,
+                                             uint64_t part_lo, uint64_t part_width, const uint32_t *part_counts, const uint64_t *in_offsets,
+                                             uint64_t nb_partitions, const void *d_keys, const void *d_counts, uint64_t nb_records) {
+    if (!ctx || (nb && (!samples || !totals || !part_counts || !in_offsets))) return SIMKA_ERR_INVALID;
+    const uint32_t N = ctx->cfg.nb_samples, fl = ctx->cfg.dist_flags;
+    if (ctx->merged) return ctx->fail(SIMKA_ERR_STATE, "simka_import_samples_device: merge already ran");
+    for (uint32_t j = 0; j < nb; j++) {
+        if (samples[j] >= N) return ctx->fail(SIMKA_ERR_INVALID, "simka_import_samples_device: sample index %u out of range", samples[j]);
+        if (ctx->counted[samples[j]]) return ctx->fail(SIMKA_ERR_STATE, "simka_import_samples_device: sample %u was already counted", samples[j]);
+    }
+    if (nb_records && (!d_keys || !d_counts)) return ctx->fail(SIMKA_ERR_INVALID, "simka_import_samples_device: keys / counts are NULL");
+    if (nb_records > 0xffffffffull) return ctx->fail(SIMKA_ERR_INVALID, "simka_import_samples_device: more than 2^32-1 records in one block");
+    if (nb_partitions == 0 || (nb_partitions & (nb_partitions - 1))) return ctx->fail(SIMKA_ERR_INVALID, "simka_import_samples_device: nb_partitions must be a power of two");
+    if (part_lo + part_width > nb_partitions) return ctx->fail(SIMKA_ERR_INVALID, "simka_import_samples_device: partition range outside [0, nb_partitions)");
+    if (nb == 0) return SIMKA_OK;
+    HIPCHK(hipSetDevice(ctx->cfg.device));
+    int rc;
+    if (!ctx->geometry_ready) {
+        ctx->cfg.log2_partitions = ceil_log2_u64(nb_partitions);
+        uint64_t hint = std::max<uint64_t>(ctx->cfg.max_kmers_per_sample, 1);
+        for (uint32_t j = 0; j < nb; j++) hint = std::max<uint64_t>(hint, totals[j].kmer_occurrences);
+        rc = setup_geometry(ctx, hint); if (rc) return rc;
+    }
+    if (ctx->nparts != nb_partitions)
+        return ctx->fail(SIMKA_ERR_INVALID, "simka_import_samples_device: spectra have %llu partitions, this run %llu", (unsigned long long)nb_partitions, (unsigned long long)ctx->nparts);
+    const uint64_t P = ctx->nparts, w = part_width, pmin = part_lo;
+    uint64_t sum = 0;
+    for (uint32_t j = 0; j < nb; j++)
+        for (uint64_t p = 0; p < w; p++) {
+            const uint32_t c = part_counts[(size_t)j * w + p];
+            if (!c) continue;
+            if (in_offsets[(size_t)j * w + p] + c > nb_records) return ctx->fail(SIMKA_ERR_INVALID, "simka_import_samples_device: run (%u,%llu) lies outside the block", j, (unsigned long long)(pmin + p));
+            sum += c;
+        }
+    if (sum != nb_records) return ctx->fail(SIMKA_ERR_INVALID, "simka_import_samples_device: part_counts sum to %llu, nb_records is %llu", (unsigned long long)sum, (unsigned long long)nb_records);
+    rc = resolve_pending(ctx); if (rc) return rc;
+    ull cursor = 0;
+    HIPCHK(hipMemcpyAsync(&cursor, ctx->d_arena_cursor, 8, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    if (cursor + nb_records > ctx->arena_cap)
+        return ctx->fail(SIMKA_ERR_NOMEM, "solid-spectrum arena exhausted (%llu records): raise solid_capacity", (unsigned long long)ctx->arena_cap);
+    const ull next = cursor + nb_records;
+    if (nb_records) {
+        HIPCHK(hipMemcpyAsync(ctx->d_solid_keys + cursor, d_keys, nb_records * 8, hipMemcpyDeviceToDevice, ctx->stream));
+        HIPCHK(hipMemcpyAsync(ctx->d_solid_counts + cursor, d_counts, nb_records * 4, hipMemcpyDeviceToDevice, ctx->stream));
+    }
+    HIPCHK(hipMemcpyAsync(ctx->d_arena_cursor, &next, 8, hipMemcpyHostToDevice, ctx->stream));
+    // every sample of the block shares sample_base = cursor; foff is the run's offset inside the block
+    bool consecutive = true;
+    for (uint32_t j = 1; j < nb; j++) if (samples[j] != samples[0] + j) consecutive = false;
+    std::vector<uint32_t> hfo((size_t)nb * std::max<uint64_t>(w, 1));
+    const uint32_t *hfc_p = part_counts;
+    for (uint32_t j = 0; j < nb; j++)
+        for (uint64_t p = 0; p < w; p++)
+            hfo[(size_t)j * w + p] = part_counts[(size_t)j * w + p] ? (uint32_t)in_offsets[(size_t)j * w + p] : 0u;
+    std::vector<ull> bases(nb, cursor);
+    if (consecutive) {
+        if (w) {
+            HIPCHK(hipMemcpy2DAsync(ctx->d_foff + (uint64_t)samples[0] * P + pmin, P * 4, hfo.data(), w * 4, w * 4, nb, hipMemcpyHostToDevice, ctx->stream));
+            HIPCHK(hipMemcpy2DAsync(ctx->d_fcnt + (uint64_t)samples[0] * P + pmin, P * 4, hfc_p, w * 4, w * 4, nb, hipMemcpyHostToDevice, ctx->stream));
+        }
+        HIPCHK(hipMemcpyAsync(ctx->d_sample_base + samples[0], bases.data(), (size_t)nb * 8, hipMemcpyHostToDevice, ctx->stream));
+    } else {
+        for (uint32_t j = 0; j < nb; j++) {
+            if (w) {
+                HIPCHK(hipMemcpyAsync(ctx->d_foff + (uint64_t)samples[j] * P + pmin, hfo.data() + (size_t)j * w, w * 4, hipMemcpyHostToDevice, ctx->stream));
+                HIPCHK(hipMemcpyAsync(ctx->d_fcnt + (uint64_t)samples[j] * P + pmin, hfc_p + (size_t)j * w, w * 4, hipMemcpyHostToDevice, ctx->stream));
+            }
+            HIPCHK(hipMemcpyAsync(ctx->d_sample_base + samples[j], &bases[j], 8, hipMemcpyHostToDevice, ctx->stream));
+        }
+    }
+    // totals: rows of N values; read-modify-write the whole block once
+    std::vector<ull> tot((size_t)SIMKA_NB_TOTALS * N);
+    HIPCHK(hipMemcpyAsync(tot.data(), ctx->d_stats + stats_off_tot(N, fl, 0), tot.size() * 8, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    for (uint32_t j = 0; j < nb; j++) {
+        const uint32_t s = samples[j];
+        tot[(size_t)SIMKA_TOT_D * N + s] = totals[j].nb_distinct; tot[(size_t)SIMKA_TOT_N * N + s] = totals[j].nb_kmers;
+        tot[(size_t)SIMKA_TOT_Q * N + s] = totals[j].sum_sq; tot[(size_t)SIMKA_TOT_KOCC * N + s] = totals[j].kmer_occurrences;
+        tot[(size_t)SIMKA_TOT_DALL * N + s] = totals[j].distinct_all;
+    }
+    HIPCHK(hipMemcpyAsync(ctx->d_stats + stats_off_tot(N, fl, 0), tot.data(), tot.size() * 8, hipMemcpyHostToDevice, ctx->stream));
+    std::vector<ull> hist;
+    std::vector<uint32_t> ovf, hc;
+    if (ctx->d_hist) {   // -complex-dist: per-sample histogram of the imported solid counts (Whittaker's one-sided terms)
+        hc.resize(std::max<uint64_t>(nb_records, 1));
+        if (nb_records) HIPCHK(hipMemcpyAsync(hc.data(), d_counts, nb_records * 4, hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(hipStreamSynchronize(ctx->stream));
+        hist.assign((size_t)nb * SIMKA_HIST_MAX, 0);
+        for (uint32_t j = 0; j < nb; j++)
+            for (uint64_t p = 0; p < w; p++) {
+                const uint32_t c = part_counts[(size_t)j * w + p];
+                const uint64_t o = in_offsets[(size_t)j * w + p];
+                for (uint32_t i = 0; i < c; i++) { const uint32_t v = hc[o + i]; if (v < SIMKA_HIST_MAX) hist[(size_t)j * SIMKA_HIST_MAX + v]++; else { ovf.push_back(samples[j]); ovf.push_back(v); } }
+            }
+        for (uint32_t j = 0; j < nb; j++)
+            HIPCHK(hipMemcpyAsync(ctx->d_hist + (uint64_t)samples[j] * SIMKA_HIST_MAX, hist.data() + (size_t)j * SIMKA_HIST_MAX, SIMKA_HIST_MAX * 8, hipMemcpyHostToDevice, ctx->stream));
+        if (!ovf.empty()) {
+            ull novf = 0;
+            HIPCHK(hipMemcpyAsync(&novf, ctx->d_ovf_cursor, 8, hipMemcpyDeviceToHost, ctx->stream));
+            HIPCHK(hipStreamSynchronize(ctx->stream));
+            const ull add = ovf.size() / 2;
+            if (novf + add <= ctx->ovf_cap) HIPCHK(hipMemcpyAsync(ctx->d_ovf_list + 2 * novf, ovf.data(), ovf.size() * 4, hipMemcpyHostToDevice, ctx->stream));
+            novf += add;
+            HIPCHK(hipMemcpyAsync(ctx->d_ovf_cursor, &novf, 8, hipMemcpyHostToDevice, ctx->stream));
+        }
+    }
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    for (uint32_t j = 0; j < nb; j++) { ctx->nb_reads[samples[j]] = totals[j].nb_reads; ctx->counted[samples[j]] = 1; }
     return SIMKA_OK;
 }
 

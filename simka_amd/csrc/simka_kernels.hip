@@ -1307,6 +1307,21 @@ k_gather_sample(const ull *solid_keys, const uint32_t *solid_counts, const ull *
     }
 }
 
+// many samples at once (blockIdx.y = sample slot), destination offsets chosen by the caller per (sample, partition)
+__global__ void __launch_bounds__(256)
+k_gather_samples(const ull *solid_keys, const uint32_t *solid_counts, const ull *sample_base, const uint32_t *foff, const uint32_t *fcnt,
+                 const uint32_t *samples, const ull *out_off, uint32_t nparts, ull *out_keys, uint32_t *out_counts) {
+    const uint32_t j = blockIdx.y, s = samples[j];
+    const ull base = sample_base[s];
+    const uint32_t *fo = foff + (size_t)s * nparts, *fc = fcnt + (size_t)s * nparts;
+    const ull *oo = out_off + (size_t)j * nparts;
+    for (uint32_t p = blockIdx.x; p < nparts; p += gridDim.x) {
+        const uint32_t n = fc[p];
+        const ull src = base + fo[p], dst = oo[p];
+        for (uint32_t i = threadIdx.x; i < n; i += 256) { out_keys[dst + i] = solid_keys[src + i]; out_counts[dst + i] = solid_counts[src + i]; }
+    }
+}
+
 // --------------------------------------------------------------------------------------------
 // synthetic data (bench / test utility): genome pool and error-bearing reads, 2-bit packed
 // --------------------------------------------------------------------------------------------

@@ -1,11 +1,17 @@
-"""Multi-GPU: one process per GPU, partitions of the key space sharded over ranks, ONE all-reduce.
+"""Multi-GPU: one process per GPU.  Two ways to split the job, both ending in ONE all-reduce of the flat u64 accumulators
+(SimkaStatistics::operator+=, ref: src/core/SimkaDistance.cpp:156-213; RCCL over xGMI with the "nccl" backend, gloo in the
+CPU tests; integer sums, so the result is order-independent):
 
-Every rank scans all reads and keeps the level-1 partitions p with p % world == rank (SimkaKeyCfg
-shard_index/shard_count); count, merge and pair accumulation are then rank-local, exactly as one
-simkaMerge process per partition is independent in the reference (ref: src/SimkaPotara.hpp:974-1124).
-The only exchange is the reduction of the flat u64 accumulator buffer -- SimkaStatistics::operator+=
-(ref: src/core/SimkaDistance.cpp:156-213) -- as a single all-reduce(sum): RCCL over xGMI with the
-"nccl" backend on GPUs, gloo in the CPU tests.  Integer sums: the result is order-independent.
+* partition shards (shard_index/shard_count of the context): every rank scans all reads and keeps the level-1 partitions
+  p with p % world == rank; count, merge and pair accumulation are rank-local, exactly as one simkaMerge process per
+  partition is independent in the reference (ref: src/SimkaPotara.hpp:974-1124).  No exchange besides the all-reduce, but
+  the scan is replicated (measured: one rank of 8 still needs 44 % of the single-GPU step on C2).
+
+* sample shards + spectrum exchange (`exchange_spectra`): rank r counts the samples s with s % world == r over the WHOLE
+  key space (the reference: one simkaCount job per sample), then the solid spectra move to the rank that owns their
+  partition range with one all-to-all (the reference: every simkaMerge job reads partition p of every sample's solid/
+  directory, ref: src/SimkaMerge.cpp:1164-1264), the merge is rank-local per partition range, and the accumulators are
+  all-reduced.  Nothing is replicated; the exchange moves 12 bytes per SOLID k-mer, a small fraction of the counting traffic.
 """
 import numpy as np
 import torch
@@ -38,7 +44,12 @@ def _allreduce_device_words(ptr, n):
         __cuda_array_interface__ = {"shape": (n,), "typestr": "<i8", "data": (ptr, False), "version": 2}
 
     t = torch.as_tensor(_Wrap(), device="cuda")
-    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    if dist.get_backend() == "gloo":          # tests: ranks without RCCL (e.g. two processes on one GPU) bounce through the host
+        h = t.cpu()
+        dist.all_reduce(h, op=dist.ReduceOp.SUM)
+        t.copy_(h)
+    else:
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
     torch.cuda.synchronize()
 
 
@@ -64,3 +75,200 @@ def allreduce_totals_device(ctx):
     ctx.sync()
     _, (tp, tn) = ctx.stats_device_ranges()
     _allreduce_device_words(tp, tn)
+
+
+# ---- sample shards + spectrum exchange ---------------------------------------------------------------------------------
+def samples_of(rank, world, nb_samples):
+    """Samples counted by `rank`: s % world == rank (ascending)."""
+    return list(range(rank, nb_samples, world))
+
+
+def partition_bounds(nparts, world):
+    """Rank g merges the partitions [bounds[g], bounds[g+1])."""
+    return [(nparts * g) // world for g in range(world + 1)]
+
+
+def pack_spectra(local, nparts, world, nb_samples, rank, device=None):
+    """Phase A, per rank.  local: {sample: (totals dict, part_counts u32[nparts], keys int64 tensor, counts int32 tensor)} for
+    samples_of(rank).  Spectra are partition-major, so the records bound for rank g are ONE slice per sample.
+    Returns (meta int32 [world, maxn, width], totals int64 [maxn, 6], keys_send, counts_send, send_splits)."""
+    bounds = partition_bounds(nparts, world)
+    width = max(bounds[g + 1] - bounds[g] for g in range(world))
+    maxn = (nb_samples + world - 1) // world
+    mine = samples_of(rank, world, nb_samples)
+    meta = np.zeros((world, maxn, max(width, 1)), dtype=np.int32)
+    totals = np.zeros((maxn, 6), dtype=np.int64)
+    key_parts, count_parts, send_splits = [], [], []
+    offs = {}
+    for j, s in enumerate(mine):
+        t, pc, _, _ = local[s]
+        totals[j] = [t["nb_reads"], t["D"], t["N"], t["Q"], t["K_occ"], t["D_all"]]
+        offs[s] = np.concatenate([[0], np.cumsum(pc.astype(np.int64))])
+        for g in range(world):
+            meta[g, j, : bounds[g + 1] - bounds[g]] = pc[bounds[g]: bounds[g + 1]].astype(np.int32)
+    for g in range(world):
+        n_g = 0
+        for s in mine:
+            lo, hi = int(offs[s][bounds[g]]), int(offs[s][bounds[g + 1]])
+            if hi > lo:
+                key_parts.append(local[s][2][lo:hi]); count_parts.append(local[s][3][lo:hi])
+            n_g += hi - lo
+        send_splits.append(n_g)
+    ref = next(iter(local.values())) if local else None
+    if key_parts:
+        keys_send, counts_send = torch.cat(key_parts), torch.cat(count_parts)
+    else:
+        dev = device if device is not None else (ref[2].device if ref is not None else "cpu")
+        keys_send, counts_send = torch.empty(0, dtype=torch.int64, device=dev), torch.empty(0, dtype=torch.int32, device=dev)
+    return meta, totals, keys_send, counts_send, send_splits
+
+
+def recv_splits_of(meta_recv):
+    """Phase B.  meta_recv int32 [world(source), maxn, width]: records each source rank sends to this rank."""
+    return [int(meta_recv[r].astype(np.int64).sum()) for r in range(meta_recv.shape[0])]
+
+
+def unpack_spectra(meta_recv, totals_all, keys_recv, counts_recv, nparts, world, nb_samples, rank):
+    """Phase C.  -> [(sample, totals dict, part_counts u32[nparts] (zero outside this rank's range), keys, counts)] for ALL
+    samples: what this rank imports before the merge.  totals_all int64 [world, maxn, 6]."""
+    bounds = partition_bounds(nparts, world)
+    lo, hi = bounds[rank], bounds[rank + 1]
+    out, pos = [], 0
+    for r in range(world):
+        for j, s in enumerate(samples_of(r, world, nb_samples)):
+            pc = np.zeros(nparts, dtype=np.uint32)
+            pc[lo:hi] = meta_recv[r, j, : hi - lo].astype(np.uint32)
+            n = int(pc.astype(np.int64).sum())
+            tt = totals_all[r, j]
+            t = {"nb_reads": int(tt[0]), "D": int(tt[1]), "N": int(tt[2]), "Q": int(tt[3]), "K_occ": int(tt[4]), "D_all": int(tt[5])}
+            out.append((s, t, pc, keys_recv[pos: pos + n], counts_recv[pos: pos + n]))
+            pos += n
+    assert pos == int(keys_recv.numel())
+    return out
+
+
+def _comm_device(t_dev):
+    """gloo moves host tensors; nccl (RCCL) device tensors."""
+    return torch.device("cpu") if dist.get_backend() == "gloo" else t_dev
+
+
+def exchange_spectra(local, nparts, nb_samples, device):
+    """All three phases with torch.distributed in between: one all-to-all of the per-range record counts, one all-gather of the
+    per-sample totals, one all-to-all each for keys and counts (uneven splits)."""
+    rank, world = dist.get_rank(), dist.get_world_size()
+    meta, totals, ks, cs, send_splits = pack_spectra(local, nparts, world, nb_samples, rank, device)
+    cdev = _comm_device(device)
+    meta_t = torch.from_numpy(meta).to(cdev)
+    meta_r = torch.empty_like(meta_t)
+    dist.all_to_all_single(meta_r, meta_t)
+    tot_t = torch.from_numpy(totals).to(cdev)
+    tot_list = [torch.empty_like(tot_t) for _ in range(world)]
+    dist.all_gather(tot_list, tot_t)
+    tot_all = torch.stack(tot_list)
+    meta_recv = meta_r.cpu().numpy()
+    recv_splits = recv_splits_of(meta_recv)
+    ks, cs = ks.to(cdev), cs.to(cdev)
+    kr = torch.empty(sum(recv_splits), dtype=torch.int64, device=cdev)
+    cr = torch.empty(sum(recv_splits), dtype=torch.int32, device=cdev)
+    dist.all_to_all_single(kr, ks, recv_splits, send_splits)
+    dist.all_to_all_single(cr, cs, recv_splits, send_splits)
+    return unpack_spectra(meta_recv, tot_all.cpu().numpy(), kr.to(device), cr.to(device), nparts, world, nb_samples, rank)
+
+
+def _excl_cumsum_rows(m):
+    """row-wise exclusive prefix sums of a 2-D integer array, as int64"""
+    c = np.cumsum(m.astype(np.int64), axis=1)
+    return c - m.astype(np.int64)
+
+
+def count_exchange_merge(ctx, count_fn, nb_samples, device):
+    """One sample-sharded job on this rank: count my samples (count_fn(sample)), exchange, import every sample's slice of my
+    partition range, merge, all-reduce the pair accumulators.  `ctx` is created with shard_count=1.  Single process: plain path.
+    Batch ABI: one gather into a destination-major send buffer, three collectives (counts, keys, counts of k-mers) + the
+    totals all-gather, one import of the received block."""
+    from .api import SampleTotals
+    world = dist.get_world_size() if dist.is_initialized() else 1
+    rank = dist.get_rank() if world > 1 else 0
+    ctx.reset()
+    if world == 1:
+        for s in range(nb_samples):
+            count_fn(s)
+        ctx.merge()
+        return
+    cdev = _comm_device(device)
+    mine = samples_of(rank, world, nb_samples)
+    for s in mine:
+        count_fn(s)
+    np_t = torch.tensor([ctx.nb_partitions() if mine else 0], dtype=torch.int64, device=cdev)
+    dist.all_reduce(np_t, op=dist.ReduceOp.MAX)          # ranks without samples learn the partition count
+    P = int(np_t.item())
+    bounds = partition_bounds(P, world)
+    width = max(bounds[g + 1] - bounds[g] for g in range(world))
+    maxn = (nb_samples + world - 1) // world
+    # ---- send side: destination-major layout [g][my sample j][partitions of g]
+    meta = np.zeros((world, maxn, width), dtype=np.int32)
+    tot_send = np.zeros((maxn, 6), dtype=np.int64)
+    send_splits = [0] * world
+    if mine:
+        pc, tot = ctx.samples_spectrum_info(mine)
+        out_off = np.zeros(pc.shape, dtype=np.uint64)
+        pos = 0
+        for g in range(world):
+            lo, hi = bounds[g], bounds[g + 1]
+            seg = pc[:, lo:hi]
+            rows = seg.astype(np.int64).sum(axis=1)
+            starts = pos + np.concatenate([[0], np.cumsum(rows)[:-1]])
+            out_off[:, lo:hi] = (_excl_cumsum_rows(seg) + starts[:, None]).astype(np.uint64)
+            meta[g, : len(mine), : hi - lo] = seg.astype(np.int32)
+            send_splits[g] = int(rows.sum())
+            pos += send_splits[g]
+        for j in range(len(mine)):
+            t = tot[j]
+            tot_send[j] = [t.nb_reads, t.nb_distinct, t.nb_kmers, t.sum_sq, t.kmer_occurrences, t.distinct_all]
+        ks = torch.empty(pos, dtype=torch.int64, device=device)
+        cs = torch.empty(pos, dtype=torch.int32, device=device)
+        ctx.gather_samples_device(mine, out_off, ks, cs)
+    else:
+        ks = torch.empty(0, dtype=torch.int64, device=device)
+        cs = torch.empty(0, dtype=torch.int32, device=device)
+    # ---- the exchange
+    meta_t = torch.from_numpy(meta).to(cdev)
+    meta_r = torch.empty_like(meta_t)
+    dist.all_to_all_single(meta_r, meta_t)
+    tot_t = torch.from_numpy(tot_send).to(cdev)
+    tot_list = [torch.empty_like(tot_t) for _ in range(world)]
+    dist.all_gather(tot_list, tot_t)
+    meta_recv = meta_r.cpu().numpy()                     # [source rank][its sample j][my partitions]
+    recv_splits = recv_splits_of(meta_recv)
+    kr = torch.empty(sum(recv_splits), dtype=torch.int64, device=cdev)
+    cr = torch.empty(sum(recv_splits), dtype=torch.int32, device=cdev)
+    dist.all_to_all_single(kr, ks.to(cdev), recv_splits, send_splits)
+    dist.all_to_all_single(cr, cs.to(cdev), recv_splits, send_splits)
+    kr, cr = kr.to(device), cr.to(device)
+    ks = cs = None
+    # ---- receive side: block layout [r][j][my partitions]; samples in ascending order for the import
+    lo, hi = bounds[rank], bounds[rank + 1]
+    w = hi - lo
+    pc_in = np.zeros((nb_samples, max(w, 1)), dtype=np.uint32)
+    off_in = np.zeros((nb_samples, max(w, 1)), dtype=np.uint64)
+    tot_in = (SampleTotals * nb_samples)()
+    tot_all = torch.stack(tot_list).cpu().numpy()
+    pos = 0
+    for r in range(world):
+        ss = samples_of(r, world, nb_samples)
+        if not ss:
+            continue
+        seg = meta_recv[r, : len(ss), :w]
+        rows = seg.astype(np.int64).sum(axis=1)
+        starts = pos + np.concatenate([[0], np.cumsum(rows)[:-1]])
+        pc_in[ss, :w] = seg.astype(np.uint32)
+        off_in[ss, :w] = (_excl_cumsum_rows(seg) + starts[:, None]).astype(np.uint64)
+        pos += int(rows.sum())
+        for j, s in enumerate(ss):
+            tt = tot_all[r, j]
+            tot_in[s] = SampleTotals(int(tt[0]), int(tt[1]), int(tt[2]), int(tt[3]), int(tt[4]), int(tt[5]))
+    assert pos == int(kr.numel())
+    ctx.reset()
+    ctx.import_samples_device(np.arange(nb_samples), tot_in, lo, pc_in[:, :max(w, 0)] if w else pc_in[:, :0], off_in[:, :w] if w else off_in[:, :0], P, kr, cr)
+    ctx.merge()
+    allreduce_stats_device(ctx, totals_already_reduced=True)      # imported totals are already global on every rank

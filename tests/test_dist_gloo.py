@@ -76,3 +76,74 @@ def test_shard_plan():
     assert sdist.shard_of(rank=3, world=8) == (3, 8)
     with pytest.raises(ValueError):
         sdist.shard_of(rank=8, world=8)
+
+
+# ---- sample shards + spectrum exchange (simka_amd/dist.py::exchange_spectra) on gloo ------------------------------------
+_NPARTS = 16
+
+
+def _partition_major(kmers, counts):
+    part = ((kmers * np.uint64(0x9E3779B97F4A7C15)) >> np.uint64(60)).astype(np.int64)      # 16 partitions
+    order = np.lexsort((kmers, part))
+    return np.bincount(part, minlength=_NPARTS).astype(np.uint32), kmers[order], counts[order], part[order]
+
+
+def _exchange_worker(rank, world, port, outdir):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import torch.distributed as dist
+    import oracle_lib
+    from simka_amd import dist as sdist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    o = oracle_lib.Oracle()
+    o.load_input(os.path.join(ROOT, "tests", "golden", "example", "simka_input.txt"))
+    o.run(21, 2)
+    n = o.n
+    tot = o.totals()
+    spectra = [_partition_major(*o.sample_solid(i)) for i in range(n)]
+    tdict = lambda i: {key: int(tot[key][i]) for key in ("nb_reads", "D", "N", "Q", "K_occ", "D_all")}
+    # this rank "counted" the samples s % world == rank
+    local = {s: (tdict(s), spectra[s][0], torch.from_numpy(spectra[s][1].view(np.int64).copy()), torch.from_numpy(spectra[s][2].astype(np.int32)))
+             for s in sdist.samples_of(rank, world, n)}
+    incoming = sdist.exchange_spectra(local, _NPARTS, n, torch.device("cpu"))
+    lo, hi = sdist.partition_bounds(_NPARTS, world)[rank: rank + 2]
+    assert sorted(x[0] for x in incoming) == list(range(n))
+    a = np.zeros((n, n), dtype=np.int64)
+    sets = {}
+    for s, t, pc, k, c in incoming:
+        pcs, ks, cs, parts = spectra[s]
+        sel = (parts >= lo) & (parts < hi)
+        assert t == tdict(s)
+        assert np.array_equal(pc[lo:hi], pcs[lo:hi]) and pc[:lo].sum() == 0 and pc[hi:].sum() == 0
+        assert np.array_equal(k.numpy().view(np.uint64), ks[sel]) and np.array_equal(c.numpy().astype(np.uint32), cs[sel])
+        sets[s] = k.numpy()
+    for i in range(n):          # the rank-local "merge" of its partition range: distinct shared k-mers per pair
+        for j in range(i + 1, n):
+            a[i, j] = len(np.intersect1d(sets[i], sets[j], assume_unique=True))
+    at = torch.from_numpy(a)
+    dist.all_reduce(at)
+    if rank == 0:
+        np.save(os.path.join(outdir, "a.npy"), at.numpy())
+        np.save(os.path.join(outdir, "a_ref.npy"), o.acc("a").astype(np.int64))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_spectrum_exchange_routes_partition_ranges(oracle_mod, tmp_path, world):
+    """Samples counted on rank s % world, merged by partition range: after exchange_spectra every rank holds, for ALL samples,
+    exactly the records of its partition range (and the global per-sample totals); the rank-local pair counts all-reduce to the
+    oracle's matrix.  world 3: uneven partition ranges and sample counts (5 samples)."""
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    out = str(tmp_path / "xchg")
+    os.makedirs(out)
+    mp.spawn(_exchange_worker, args=(world, port, out), nprocs=world, join=True)
+    a, ref = np.load(os.path.join(out, "a.npy")), np.load(os.path.join(out, "a_ref.npy"))
+    iu = np.triu_indices(a.shape[0], 1)
+    assert np.array_equal(a[iu], ref[iu])

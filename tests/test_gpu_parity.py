@@ -529,3 +529,64 @@ def test_cli_keep_tmp_adds_samples_without_recounting(gpu_required, golden_dir, 
     with gzip.open(os.path.join(str(tmp_path / "out5b"), "mat_abundance_braycurtis.csv.gz"), "rb") as f, \
             open(os.path.join(golden_dir, "truth", "results_k21_t0", "mat_abundance_braycurtis.csv"), "rb") as g:
         assert f.read() == g.read()
+
+
+@pytest.mark.parametrize("world,complex_", [(2, True), (3, False), (8, False)])
+def test_sample_shards_then_partition_range_merge(gpu_required, world, complex_):
+    """The N-GPU job of simka_amd/dist.py::count_exchange_merge, emulated on one GPU: `world` contexts each count the samples
+    s % world == r and export them on the device; the pack / unpack phases route every sample's slice of partition range g to
+    context g (the all-to-all is done by hand here, by torch.distributed on gloo in tests/test_dist_gloo.py); each context
+    imports, merges, and the heads sum to the single-context result bit for bit; totals are global everywhere."""
+    import torch
+    import simka_amd
+    from simka_amd import dist as sdist
+    dev = torch.device("cuda:0")
+    n, R, L, k = 7, 3000, 100, 21
+    packed = _synthetic(n, R, L, seed_shift=11)
+    offs = np.arange(R + 1, dtype=np.uint64) * L
+    kw = dict(kmer_size=k, abundance_min=2, simple_dist=True, complex_dist=complex_, max_kmers_per_sample=R * (L - k + 1))
+
+    def count(ctx, s):
+        ctx.count_sample(s, np.concatenate([packed[s], np.zeros(2, dtype=np.uint64)]), R * L, R, fixed_len=L)
+
+    with simka_amd.SimkaContext(n, **kw) as c:
+        for s in range(n):
+            count(c, s)
+        c.merge()
+        ref = c.stats()
+    lay = simka_amd.api.stats_layout(n, ref.dist_flags)
+    head = lay["head"]
+    # phase A on every rank
+    sends = []
+    nparts = None
+    for r in range(world):
+        with simka_amd.SimkaContext(n, **kw) as c:
+            mine = sdist.samples_of(r, world, n)
+            for s in mine:
+                count(c, s)
+            local = {s: c.export_sample_device(s, dev) for s in mine}
+        if local:
+            nparts = len(next(iter(local.values()))[1])
+        sends.append(local)
+    packs = [sdist.pack_spectra(sends[r], nparts, world, n, r, dev) for r in range(world)]
+    tot_all = np.stack([p[1] for p in packs])
+    total = np.zeros(head, dtype=np.uint64)
+    for g in range(world):
+        # the all-to-all, by hand: rank g receives block g of every rank's meta and the g-th split of its key / count buffers
+        meta_recv = np.stack([packs[r][0][g] for r in range(world)])
+        kr, cr = [], []
+        for r in range(world):
+            splits = packs[r][4]
+            lo = sum(splits[:g])
+            kr.append(packs[r][2][lo: lo + splits[g]]); cr.append(packs[r][3][lo: lo + splits[g]])
+        assert sdist.recv_splits_of(meta_recv) == [int(x.numel()) for x in kr]
+        incoming = sdist.unpack_spectra(meta_recv, tot_all, torch.cat(kr), torch.cat(cr), nparts, world, n, g)
+        with simka_amd.SimkaContext(n, **kw) as c:
+            for s, t, pc, kk, cc in incoming:
+                c.import_sample_device(s, t, pc, kk, cc)
+            c.merge()
+            st = c.stats()
+        total += st.flat[:head]
+        tail = slice(head, lay["derived"])
+        assert np.array_equal(st.flat[tail], ref.flat[tail])                # per-sample totals: global on every rank
+    assert np.array_equal(total, ref.flat[:head])
