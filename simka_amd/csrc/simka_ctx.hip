@@ -210,12 +210,17 @@ SIMKA_EXPORT int simka_abi_version(void) { return SIMKA_ABI_VERSION; }
 
 SIMKA_EXPORT const char *simka_last_error(const simka_ctx *ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
 
+// k_scan<SCATTER, FIXED, SHARDED>
+using ScanFn = void (*)(SimkaScanArgs, SimkaKeyCfg, ull *, ull *, uint64_t *, ull *, const ull *, uint32_t *);
+static ScanFn scan_kernel(bool scatter, bool fixed, bool sharded) {
+    static const ScanFn t[8] = { k_scan<false, false, false>, k_scan<false, false, true>, k_scan<false, true, false>, k_scan<false, true, true>,
+                                 k_scan<true, false, false>,  k_scan<true, false, true>,  k_scan<true, true, false>,  k_scan<true, true, true> };
+    return t[(scatter ? 4 : 0) | (fixed ? 2 : 0) | (sharded ? 1 : 0)];
+}
+
 static int set_lds_attr(simka_ctx *ctx) {
     const int big = 160 * 1024;
-    HIPCHK(hipFuncSetAttribute((const void *)k_scan<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
-    HIPCHK(hipFuncSetAttribute((const void *)k_scan<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
-    HIPCHK(hipFuncSetAttribute((const void *)k_scan<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
-    HIPCHK(hipFuncSetAttribute((const void *)k_scan<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
+    for (int v = 0; v < 8; v++) HIPCHK(hipFuncSetAttribute((const void *)scan_kernel(v & 4, v & 2, v & 1), hipFuncAttributeMaxDynamicSharedMemorySize, big));
     HIPCHK(hipFuncSetAttribute((const void *)k_layout, hipFuncAttributeMaxDynamicSharedMemorySize, big));
     HIPCHK(hipFuncSetAttribute((const void *)k_split<false>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
     HIPCHK(hipFuncSetAttribute((const void *)k_split<true>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
@@ -464,6 +469,7 @@ static int run_count_kernels(simka_ctx *ctx, uint32_t sample, const SimkaScanArg
     // (+10 % + slack) and scatter directly.  Only if a bucket overflows (heavy repeats) is the sample redone with the exact
     // histogram -> scan -> scatter sequence.
     static const bool force_exact = getenv("SIMKA_EXACT_SIZING") != nullptr;
+    const bool sharded = ctx->cfg.shard_count > 1;
     if (force_exact) exact = true;
     uint64_t max_chunks;
     if (!exact) {
@@ -474,12 +480,8 @@ static int run_count_kernels(simka_ctx *ctx, uint32_t sample, const SimkaScanArg
         max_chunks = (capb * B1) / K2_CHUNK + B1 + 1;
         layout(1, capb);
         launch_timed(ctx, KID_SCAN_SCATTER, [&] {
-            if (a.fixed_len)
-                hipLaunchKernelGGL((k_scan<true, true>), dim3(grid1), dim3(K1_BLOCK), lds_scat, st, a, key, L.d_b1_count,
-                                   L.d_b1_cursor, L.d_l1, kocc, L.d_b1_end, flag);
-            else
-                hipLaunchKernelGGL((k_scan<true, false>), dim3(grid1), dim3(K1_BLOCK), lds_scat, st, a, key, L.d_b1_count,
-                                   L.d_b1_cursor, L.d_l1, kocc, L.d_b1_end, flag);
+            hipLaunchKernelGGL(scan_kernel(true, a.fixed_len != 0, sharded), dim3(grid1), dim3(K1_BLOCK), lds_scat, st, a, key, L.d_b1_count,
+                               L.d_b1_cursor, L.d_l1, kocc, (const ull *)L.d_b1_end, flag);
         }, st);
         layout(2, capb);
         simka_ctx::Pending p; p.sample = sample; p.a = a;
@@ -489,21 +491,13 @@ static int run_count_kernels(simka_ctx *ctx, uint32_t sample, const SimkaScanArg
         max_chunks = a.nb_bases / K2_CHUNK + B1 + 1;
         HIPCHK(hipMemsetAsync(L.d_b1_count, 0, (B1 + 1) * 8, st));
         launch_timed(ctx, KID_SCAN_HIST, [&] {
-            if (a.fixed_len)
-                hipLaunchKernelGGL((k_scan<false, true>), dim3(grid1), dim3(K1_BLOCK), lds_hist, st, a, key, L.d_b1_count,
-                                   L.d_b1_cursor, L.d_l1, kocc, (const ull *)nullptr, (uint32_t *)nullptr);
-            else
-                hipLaunchKernelGGL((k_scan<false, false>), dim3(grid1), dim3(K1_BLOCK), lds_hist, st, a, key, L.d_b1_count,
-                                   L.d_b1_cursor, L.d_l1, kocc, (const ull *)nullptr, (uint32_t *)nullptr);
+            hipLaunchKernelGGL(scan_kernel(false, a.fixed_len != 0, sharded), dim3(grid1), dim3(K1_BLOCK), lds_hist, st, a, key, L.d_b1_count,
+                               L.d_b1_cursor, L.d_l1, kocc, (const ull *)nullptr, (uint32_t *)nullptr);
         }, st);
         layout(0, 0);
         launch_timed(ctx, KID_SCAN_SCATTER, [&] {
-            if (a.fixed_len)
-                hipLaunchKernelGGL((k_scan<true, true>), dim3(grid1), dim3(K1_BLOCK), lds_scat, st, a, key, L.d_b1_count,
-                                   L.d_b1_cursor, L.d_l1, kocc, (const ull *)nullptr, (uint32_t *)nullptr);
-            else
-                hipLaunchKernelGGL((k_scan<true, false>), dim3(grid1), dim3(K1_BLOCK), lds_scat, st, a, key, L.d_b1_count,
-                                   L.d_b1_cursor, L.d_l1, kocc, (const ull *)nullptr, (uint32_t *)nullptr);
+            hipLaunchKernelGGL(scan_kernel(true, a.fixed_len != 0, sharded), dim3(grid1), dim3(K1_BLOCK), lds_scat, st, a, key, L.d_b1_count,
+                               L.d_b1_cursor, L.d_l1, kocc, (const ull *)nullptr, (uint32_t *)nullptr);
         }, st);
     }
     (void)max_chunks;

@@ -68,7 +68,9 @@ __device__ __forceinline__ uint32_t window_base(uint64_t A, uint64_t B, uint32_t
     return (uint32_t)(w >> ((i & 31u) * 2u)) & 3u;
 }
 
-template <bool SCATTER, bool FIXED>
+// SHARDED: the context owns a subset of the level-1 buckets (partition shards); otherwise every k-mer is kept and the
+// ownership test (with its integer modulo for non power-of-two shard counts) is not even compiled in.
+template <bool SCATTER, bool FIXED, bool SHARDED>
 __global__ void __launch_bounds__(K1_BLOCK)
 k_scan(SimkaScanArgs a, SimkaKeyCfg cfg, ull *b1_count, ull *b1_cursor, uint64_t *l1_keys, ull *kocc, const ull *b1_limit,
        uint32_t *ovf_flag) {
@@ -145,7 +147,7 @@ k_scan(SimkaScanArgs a, SimkaKeyCfg cfg, ull *b1_count, ull *b1_cursor, uint64_t
             const uint64_t key = simka_mix(canon, cfg.mask, cfg.xs);
             const uint32_t b1 = simka_key_l1(key, cfg);
             // the k-mer [q, q+k) must end inside its read (and inside the data)
-            const bool ok = ((uint32_t)q + k <= nrel) & ((uint32_t)q < erel) & simka_owns_l1(b1, cfg);
+            const bool ok = ((uint32_t)q + k <= nrel) & ((uint32_t)q < erel) & (SHARDED ? simka_owns_l1(b1, cfg) : true);
             const uint32_t rk = atomicAdd(&hist[ok ? b1 : B1 + (tid & 31u)], 1u);   // invalid positions hit a trash slot: no branch
             if (SCATTER) {
                 keys[q] = ok ? key : SIMKA_EMPTY_KEY;
