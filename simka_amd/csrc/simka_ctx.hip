@@ -1004,10 +1004,10 @@ SIMKA_EXPORT int simka_merge(simka_ctx *ctx) {
     if (total == 0) return SIMKA_OK;
     HIPCHK(hipMemcpyAsync(ctx->d_part_off, poff.data(), (nparts + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
 
-    // sub-range bits: ~K3_CAP/2 records per k_group block
+    // sub-range bits: at most K3_TARGET records per k_group round on average (a round hashes up to K3_CAP)
     SimkaKeyCfg key = ctx->key;
     uint32_t t = ctx->cfg.log2_subranges;
-    if (t == 0) t = ceil_log2_u64((total / std::max<ull>(nonempty, 1) + K3_CAP / 2 - 1) / (K3_CAP / 2));
+    if (t == 0) t = ceil_log2_u64((total / std::max<ull>(nonempty, 1) + K3_TARGET - 1) / K3_TARGET);
     t = std::min<uint32_t>(t, 8);
     t = std::min<uint32_t>(t, key.W - key.pb);
     key.t = t; ctx->key.t = t;
@@ -1081,7 +1081,7 @@ SIMKA_EXPORT int simka_merge(simka_ctx *ctx) {
     co.entries = ctx->d_entries; co.groups = ctx->d_groups; co.spans = ctx->d_spans; co.cursors = ctx->d_cursors;
     co.cap_entries = csr_cap; co.cap_groups = csr_cap; co.cap_spans = span_cap; co.span_cap = pc.span_cap; co.huge = ctx->d_huge; co.cap_huge = huge_cap; co.glob = (ull *)ctx->d_stats; co.err = ctx->d_err;
     const uint32_t min_share = 2;   // -complex-dist would need 1 (ref: src/SimkaMerge.cpp:1317)
-    const size_t lds_group = SIMKA_LDS_HEAD + (size_t)K3_TABLE * 8 + (size_t)K3_CAP * 8 + (size_t)K3_TABLE * 8 + (size_t)K3_CAP * 2;
+    const size_t lds_group = SIMKA_LDS_HEAD + (size_t)K3_TABLE * 8 + (size_t)K3_CAP * 8 + (size_t)K3_TABLE * 8 + (size_t)K3_CAP * 2 + (size_t)K3_STACK * 16;
     ull *acc = (ull *)ctx->d_stats + stats_off_acc(N, 0);
 
     uint64_t pb = 0;

@@ -775,7 +775,6 @@ k_group(const ull *mkeys, const ull *mvals, const uint32_t *fb_off, uint32_t nfb
     int &s_sp = *(int *)(smem + 80);
     uint32_t &s_maxc = *(uint32_t *)(smem + 84);
     uint32_t *tmp = (uint32_t *)(smem + 96);               // [K3_BLOCK/64]
-    uint32_t *s_stack = (uint32_t *)(smem + 128);          // [2*24]
     ull &s_open = *(ull *)(smem + 336);                    // slot of the block's open span (~0: none)
     uint32_t &s_open_nent = *(uint32_t *)(smem + 344);     // its entries / groups / largest count so far
     uint32_t &s_open_ngrp = *(uint32_t *)(smem + 348);
@@ -786,6 +785,7 @@ k_group(const ull *mkeys, const ull *mvals, const uint32_t *fb_off, uint32_t nfb
     uint32_t *scnt = (uint32_t *)(rval + K3_CAP);          // [K3_TABLE] group size
     uint32_t *gpk = scnt + K3_TABLE;                       // [K3_TABLE] packed prefix: entries | groups << 20; later the fill cursor
     uint16_t *rslot = (uint16_t *)(gpk + K3_TABLE);        // [K3_CAP]
+    ull *s_stack = (ull *)(rslot + K3_CAP);                // [2*K3_STACK] (selector bits, value) of the refinement DFS: one level per key bit
 
     const uint32_t tid = threadIdx.x;
     const uint32_t free_bits = cfg.W - cfg.pb - cfg.t;     // bits left to split an over-full sub-range
@@ -799,7 +799,7 @@ k_group(const ull *mkeys, const ull *mvals, const uint32_t *fb_off, uint32_t nfb
         const uint32_t R = re - rb;
         if (R == 0) continue;
         uint32_t e0 = 0;
-        while (((R >> e0) > (K3_CAP * 3u) / 4u) && e0 < free_bits) e0++;
+        while (((R >> e0) > K3_PRESPLIT) && e0 < free_bits) e0++;
         const uint32_t nvals0 = 1u << e0;
         for (uint32_t v0 = 0; v0 < nvals0; v0++) {
             __syncthreads();
@@ -807,7 +807,8 @@ k_group(const ull *mkeys, const ull *mvals, const uint32_t *fb_off, uint32_t nfb
             while (true) {
                 __syncthreads();
                 if (s_sp == 0) break;
-                const uint32_t e = s_stack[2 * (s_sp - 1)], val = s_stack[2 * (s_sp - 1) + 1];
+                const uint32_t e = (uint32_t)s_stack[2 * (s_sp - 1)];
+                const ull val = s_stack[2 * (s_sp - 1) + 1];          // up to free_bits (> 32) selector bits
                 __syncthreads();
                 if (tid == 0) { s_sp--; s_nrec = 0; s_ovf = 0; s_maxc = 0; }
                 {
@@ -833,7 +834,7 @@ k_group(const ull *mkeys, const ull *mvals, const uint32_t *fb_off, uint32_t nfb
                     for (int u = 0; u < K3_UNROLL; u++) {
                         const ull key = kk[u];
                         if (key == SIMKA_EMPTY_KEY) continue;
-                        if (e && (uint32_t)((key >> selshift) & ((1ull << e) - 1ull)) != val) continue;
+                        if (e && ((key >> selshift) & ((1ull << e) - 1ull)) != val) continue;
                         const uint32_t idx = atomicAdd(&s_nrec, 1u);
                         if (idx >= K3_CAP) { s_ovf = 1; continue; }
                         uint32_t slot = simka_slot_hash(key) & (K3_TABLE - 1u);
@@ -874,17 +875,17 @@ k_group(const ull *mkeys, const ull *mvals, const uint32_t *fb_off, uint32_t nfb
                             for (uint32_t i = rb + tid; i < re; i += K3_BLOCK) {
                                 const ull key = mkeys[i];
                                 if (key == SIMKA_EMPTY_KEY) continue;
-                                if (e && (uint32_t)((key >> selshift) & ((1ull << e) - 1ull)) != val) continue;
+                                if (e && ((key >> selshift) & ((1ull << e) - 1ull)) != val) continue;
                                 o.entries[eb_ + atomicAdd(&s_nrec, 1u)] = mvals[i];
                             }
                         }
                         continue;
                     }
                     if (tid == 0) {   // refine: two children with one more selector bit
-                        if (s_sp + 2 > 24) { atomicOr(o.err, SIMKA_DEVERR_GROUP_OVERFLOW); s_sp = 0; }
+                        if (s_sp + 2 > K3_STACK) { atomicOr(o.err, SIMKA_DEVERR_GROUP_OVERFLOW); s_sp = 0; }
                         else {
-                            s_stack[2 * s_sp] = e + 1; s_stack[2 * s_sp + 1] = val * 2u + 1u; s_sp++;
-                            s_stack[2 * s_sp] = e + 1; s_stack[2 * s_sp + 1] = val * 2u; s_sp++;
+                            s_stack[2 * s_sp] = e + 1; s_stack[2 * s_sp + 1] = val * 2ull + 1ull; s_sp++;
+                            s_stack[2 * s_sp] = e + 1; s_stack[2 * s_sp + 1] = val * 2ull; s_sp++;
                         }
                     }
                     continue;
@@ -930,11 +931,10 @@ k_group(const ull *mkeys, const ull *mvals, const uint32_t *fb_off, uint32_t nfb
                 const ull eb = s_ebase, gb = s_gbase;
                 const uint32_t soff = s_soff;
                 for (uint32_t i = tid; i < K3_TABLE; i += K3_BLOCK) {
-                    const uint32_t c = scnt[i];
-                    if (c >= min_share) o.groups[gb + (gpk[i] >> 20)] = (((gpk[i] & 0xfffffu) + soff) << 16) | c;    // start is relative to the span
+                    const uint32_t c = scnt[i], g_ = gpk[i];
+                    if (c >= min_share) o.groups[gb + (g_ >> 20)] = (((g_ & 0xfffffu) + soff) << 16) | c;    // start is relative to the span
+                    gpk[i] = g_ & 0xfffffu;               // now: entry offset, advanced as fill cursor
                 }
-                __syncthreads();
-                for (uint32_t i = tid; i < K3_TABLE; i += K3_BLOCK) gpk[i] &= 0xfffffu;   // now: entry offset, advanced as fill cursor
                 __syncthreads();
                 for (uint32_t i = tid; i < nrec; i += K3_BLOCK) {
                     const uint32_t slot = rslot[i];
