@@ -166,19 +166,25 @@ k_scan(SimkaScanArgs a, SimkaKeyCfg cfg, ull *b1_count, ull *b1_cursor, uint64_t
     }
 
     __syncthreads();
-    for (uint32_t b = tid; b < B1; b += K1_BLOCK) {
-        const uint32_t h = hist[b];
-        loff[b] = h;
-        ull gb = h ? atomicAdd(&b1_cursor[b], (ull)h) : 0ull;     // reserve this tile's run in bucket b
-        // capacity-sized buckets (no histogram pass): a run that does not fit flags the sample for the exact path
-        if (b1_limit && h && gb + h > b1_limit[b]) { *ovf_flag = 1u; gb = ~0ull; }
-        gbase[b] = gb;
+    // reserve this tile's run in every bucket: one returning global atomic per bucket (B1 <= K1_BLOCK: one per thread).  Its
+    // result is only needed by the copy-out, so it stays in a register while the block scans and stages (latency hidden).
+    static_assert(K1_BLOCK >= 1024, "one level-1 bucket per thread");
+    ull gb = 0; uint32_t myh = 0;
+    if (tid < B1) {
+        myh = hist[tid];
+        loff[tid] = myh;
+        if (myh) gb = atomicAdd(&b1_cursor[tid], (ull)myh);
     }
     __syncthreads();
     const uint32_t total = block_excl_scan<K1_BLOCK>(loff, B1, tmp);
 #pragma unroll
     for (int q = 0; q < K1_SEG; q++) {
         if (keys[q] != SIMKA_EMPTY_KEY) stage[loff[simka_key_l1(keys[q], cfg)] + ((ranks[q >> 1] >> ((q & 1) * 16)) & 0xffffu)] = keys[q];
+    }
+    if (tid < B1) {
+        // capacity-sized buckets (no histogram pass): a run that does not fit flags the sample for the exact path
+        if (b1_limit && myh && gb + myh > b1_limit[tid]) { *ovf_flag = 1u; gb = ~0ull; }
+        gbase[tid] = gb;
     }
     __syncthreads();
     // coalesced copy-out: consecutive staged slots of one bucket go to consecutive HBM addresses
@@ -315,27 +321,41 @@ k_split(const uint64_t *l1_keys, const ull *b1_start, const ull *b1_end, const u
             ranks[q] = rk;
         }
         __syncthreads();
-        for (uint32_t b = tid; b < B2; b += K2_BLOCK) {
-            const uint32_t h = hist[b];
-            ull g = 0;
-            if (h) {
-                const uint32_t part = (b1 << cfg.l2) | b;
-                const uint32_t pos = atomicAdd(&l2.p_count[part], h);          // reserve the run in partition `part`
-                if ((ull)pos + h <= l2.cap2) g = (ull)part * l2.cap2 + pos;
-                else {
-                    atomicMin(&l2.p_valid[part], pos);                          // region holds [0,pos) only; the rest is spilled
-                    const ull sp = atomicAdd(l2.spill_cursor, (ull)h);
-                    if (sp + h > l2.spill_cap) { atomicOr(flag, 2u); g = ~0ull; }
-                    else g = (1ull << 63) | sp;
-                }
+        // reserve the runs (B2 <= 2048 buckets, <= 2 per thread): returning global atomics whose results are only needed by
+        // the copy-out -- they stay in registers while the block scans and stages
+        uint32_t rh[2] = { 0, 0 }, rpos[2] = { 0, 0 };
+#pragma unroll
+        for (int u = 0; u < 2; u++) {
+            const uint32_t b = tid + (uint32_t)u * K2_BLOCK;
+            if (b < B2) {
+                rh[u] = hist[b];
+                if (rh[u]) rpos[u] = atomicAdd(&l2.p_count[(b1 << cfg.l2) | b], rh[u]);     // reserve the run in its partition
             }
-            gpos[b] = g;
         }
         __syncthreads();
         block_excl_scan<K2_BLOCK>(hist, B2, tmp);
 #pragma unroll
         for (int q = 0; q < PER; q++)
             if (keys[q] != SIMKA_EMPTY_KEY) stage[hist[simka_key_l2(keys[q], cfg)] + ranks[q]] = keys[q];
+#pragma unroll
+        for (int u = 0; u < 2; u++) {
+            const uint32_t b = tid + (uint32_t)u * K2_BLOCK;
+            if (b < B2) {
+                const uint32_t h = rh[u], pos = rpos[u];
+                ull g = 0;
+                if (h) {
+                    const uint32_t part = (b1 << cfg.l2) | b;
+                    if ((ull)pos + h <= l2.cap2) g = (ull)part * l2.cap2 + pos;
+                    else {
+                        atomicMin(&l2.p_valid[part], pos);                          // region holds [0,pos) only; the rest is spilled
+                        const ull sp = atomicAdd(l2.spill_cursor, (ull)h);
+                        if (sp + h > l2.spill_cap) { atomicOr(flag, 2u); g = ~0ull; }
+                        else g = (1ull << 63) | sp;
+                    }
+                }
+                gpos[b] = g;
+            }
+        }
         __syncthreads();
         for (uint32_t idx = tid; idx < n; idx += K2_BLOCK) {
             const uint64_t key = stage[idx];
