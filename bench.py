@@ -239,14 +239,19 @@ def main():
     traffic = None
     traffic_src = None
     tk = {}
-    alias = {"k_scan<scatter>": ["k_scan<true, true>", "k_scan<true, false>", "k_scan<true>"], "k_scan<hist>": ["k_scan<false, true>", "k_scan<false>"],
-             "k_count_fast": ["k_count_fast<2048u>", "k_count_fast<4096u>"], "k_pairs": ["k_pairs<true, 256>", "k_pairs<true, 1024>", "k_pairs<false, 1024>"]}
+    # rocprofv3 reports template instances; the library's profiler reports one name per kernel family
+    def family(name):
+        if name.startswith("k_scan<"):
+            return "k_scan<scatter>" if name.startswith("k_scan<true") else "k_scan<hist>"
+        return name.split("<")[0]
 
     def measured_traffic(kname):
-        for cand in [kname] + alias.get(kname, []):
-            if cand in tk:
-                return tk[cand]["traffic_bytes_per_launch"]
-        return None
+        """launch-weighted mean HBM bytes per launch over the template instances of the family"""
+        tot, n = 0.0, 0
+        for cand, v in tk.items():
+            if family(cand) == kname:
+                tot += v["traffic_bytes_per_launch"] * v["launches"]; n += v["launches"]
+        return tot / n if n else None
     try:
         tf = os.path.join(ROOT, "profiles", "r01_%s_hbm_traffic.json" % args.workload)
         if world == 1 and not args.reads and not args.samples and os.path.exists(tf):

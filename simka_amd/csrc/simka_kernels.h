@@ -32,8 +32,8 @@
 // K3  k_regroup / k_group
 #define K3_BLOCK 256
 #define K3_CAP 1024           // records hashed per round = entries per span
-#define K3_TARGET 800         // mean records per sub-range the merge aims for (sub-range bits t)
-#define K3_PRESPLIT 928       // a sub-range above this is split on one more key bit before hashing
+#define K3_TARGET 940         // mean records per sub-range the merge aims for (sub-range bits t)
+#define K3_PRESPLIT 1024      // a sub-range above this is split on one more key bit before hashing
 #define K3_STACK 72           // refinement stack of k_group: deeper than the 62 key bits
 #define K3_TABLE 2048         // = 2*K3_CAP slots
 #define K3_UNROLL 4           // K3_BLOCK*K3_UNROLL = K3_CAP: a whole sub-range in one batch of independent loads
