@@ -537,6 +537,20 @@ static int run_count_kernels(simka_ctx *ctx, uint32_t sample, const SimkaScanArg
     o.foff = ctx->d_foff + (uint64_t)sample * ctx->nparts; o.fcnt = ctx->d_fcnt + (uint64_t)sample * ctx->nparts;
     o.totals = (ull *)ctx->d_stats + stats_off_tot(N, ctx->cfg.dist_flags, 0); o.sample = sample; o.nb_samples = N; o.err = ctx->d_err;
     o.phase = nullptr;
+#ifdef SIMKA_PHASE_PROF
+    {   // debug build: per-phase wall_clock64 ticks of thread 0 of every k_count_fast block, printed per sample
+        static ull *d_phase = nullptr;
+        if (!d_phase) { HIPCHK(hipMalloc(&d_phase, 64)); HIPCHK(hipMemset(d_phase, 0, 64)); }
+        else {
+            HIPCHK(hipDeviceSynchronize());
+            ull h[8]; HIPCHK(hipMemcpy(h, d_phase, 64, hipMemcpyDeviceToHost)); HIPCHK(hipMemset(d_phase, 0, 64));
+            ull t_ = 0; for (ull v : h) t_ += v;
+            fprintf(stderr, "k_count_fast phases %%: gap %.1f loadwait %.1f insert %.1f sync %.1f summary %.1f scan %.1f reserve %.1f emit %.1f\n",
+                    100.0 * h[0] / t_, 100.0 * h[1] / t_, 100.0 * h[2] / t_, 100.0 * h[3] / t_, 100.0 * h[4] / t_, 100.0 * h[5] / t_, 100.0 * h[6] / t_, 100.0 * h[7] / t_);
+        }
+        o.phase = d_phase;
+    }
+#endif
     o.hist = ctx->d_hist; o.ovf_list = ctx->d_ovf_list; o.ovf_cursor = ctx->d_ovf_cursor; o.ovf_cap = ctx->ovf_cap;
     static const uint32_t tlog = getenv("SIMKA_K2_TABLE_LOG2") ? (uint32_t)atoi(getenv("SIMKA_K2_TABLE_LOG2")) : (uint32_t)K2_TABLE_LOG2;
     static const bool slow_only = getenv("SIMKA_K2_SLOW") != nullptr;

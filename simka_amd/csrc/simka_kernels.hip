@@ -425,6 +425,18 @@ __device__ __forceinline__ void count_hist(const SimkaCountOut &o, uint32_t *lhi
     else { const ull w = atomicAdd(o.ovf_cursor, 1ull); if (w < o.ovf_cap) { o.ovf_list[2 * w] = o.sample; o.ovf_list[2 * w + 1] = c; } }
 }
 
+#ifdef SIMKA_PHASE_PROF
+#define PH_DECL ull ph_t = wall_clock64(), ph_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#define PH(i) { const ull n_ = wall_clock64(); ph_acc[i] += n_ - ph_t; ph_t = n_; }
+#define PH_WAITVM __builtin_amdgcn_s_waitcnt(0x0070);   /* vmcnt(0): separate the load wait from the insert phase */
+#define PH_FLUSH if (threadIdx.x == 0 && o.phase) { for (int i_ = 0; i_ < 8; i_++) atomicAdd(&o.phase[i_], ph_acc[i_]); }
+#else
+#define PH_DECL
+#define PH(i)
+#define PH_WAITVM
+#define PH_FLUSH
+#endif
+
 template <uint32_t TS, bool NARROW>
 __global__ void __launch_bounds__(K2F_BLOCK)
 k_count_fast(SimkaKeyCfg cfg, SimkaL2 l2, uint32_t amin, uint32_t amax, SimkaCountOut o, const uint32_t *flag,
@@ -433,9 +445,8 @@ k_count_fast(SimkaKeyCfg cfg, SimkaL2 l2, uint32_t amin, uint32_t amax, SimkaCou
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     ull *s_tot = (ull *)smem;                         // [4]
     ull &s_base = *(ull *)(smem + 32);
-    ull &s_slab_pos = *(ull *)(smem + 40);
-    ull &s_slab_end = *(ull *)(smem + 48);
     uint32_t &s_ok = *(uint32_t *)(smem + 56);
+    ull *s_slab = (ull *)(smem + 64);                 // [2][2] (pos, end) of the block's arena slab, double-buffered by iteration parity
     uint32_t *tmp = (uint32_t *)(smem + 128);         // [K2F_BLOCK/64]
     constexpr uint32_t tmask = TS - 1u, SPT = TS / K2F_BLOCK;   // slots per thread
     using KT = typename std::conditional<NARROW, uint32_t, ull>::type;     // level-2 key as stored: remainder only, or whole key
@@ -455,8 +466,8 @@ k_count_fast(SimkaKeyCfg cfg, SimkaL2 l2, uint32_t amin, uint32_t amax, SimkaCou
         for (uint32_t i = tid; i < TS / 4; i += K2F_BLOCK) c4[i] = make_uint4(0, 0, 0, 0);
     }
     if (o.hist) for (uint32_t i = tid; i < SIMKA_HIST_MAX; i += K2F_BLOCK) lhist[i] = 0;
-    if (tid < 4) s_tot[tid] = 0;
-    if (tid == 0) { s_slab_pos = 0; s_slab_end = 0; }
+    if (tid < 4) { s_tot[tid] = 0; s_slab[tid] = 0; }
+    uint32_t iter = 0;
     ull bt_dall = 0, bt_D = 0, bt_N = 0, bt_Q = 0;
 
     KT kk[K2F_UNROLL];
@@ -475,6 +486,7 @@ k_count_fast(SimkaKeyCfg cfg, SimkaL2 l2, uint32_t amin, uint32_t amax, SimkaCou
         if (fastp) { K2F_LOAD(part, n) }
     }
     __syncthreads();
+    PH_DECL
     while (part < nparts) {
         const uint32_t next = part + gridDim.x;
         uint32_t n_next = 0;
@@ -487,6 +499,7 @@ k_count_fast(SimkaKeyCfg cfg, SimkaL2 l2, uint32_t amin, uint32_t amax, SimkaCou
             continue;
         }
         // ---- insert the prefetched keys
+        PH(0) PH_WAITVM PH(1)
 #pragma unroll
         for (int u = 0; u < K2F_UNROLL; u++) {
             const KT key = kk[u];
@@ -494,7 +507,9 @@ k_count_fast(SimkaKeyCfg cfg, SimkaL2 l2, uint32_t amin, uint32_t amax, SimkaCou
         }
         for (uint32_t i = K2F_BLOCK * K2F_UNROLL + tid; i < n; i += K2F_BLOCK)      // beyond the prefetch window (rare)
             table_insert(tkeys, tcnt, tmask, l2k[(ull)part * l2.cap2 + i]);
+        PH(2)
         __syncthreads();
+        PH(3)
         // ---- prefetch the next partition while this one is summarised
         if (fast_next) { K2F_LOAD(next, n_next) }
         // ---- one pass over this thread's slots: SimkaCompressedProcessor::process
@@ -510,25 +525,47 @@ k_count_fast(SimkaKeyCfg cfg, SimkaL2 l2, uint32_t amin, uint32_t amax, SimkaCou
             if (c) { ndall++; if (!(c < amin || c > amax)) { D++; N += c; Q += (ull)c * (ull)c; nsol++; } else cs[q] = 0; }
         }
         spos[tid] = nsol | (ndall << 16);
+        PH(4)
         __syncthreads();
         const uint32_t tot = block_excl_scan<K2F_BLOCK>(spos, K2F_BLOCK, tmp);
+        PH(5)
         const uint32_t total = tot & 0xffffu, dall_tot = tot >> 16;
         const bool ovf = dall_tot > (TS * 7u) / 8u;       // (nearly) full: probing may have dropped keys -> redo in rounds
-        if (tid == 0) {
-            uint32_t ok = 1;
-            if (ovf) { const ull w = atomicAdd(redo_count, 1ull); redo_list[w] = part; ok = 0; }
-            else {
-                const ull bb = total ? slab_take(s_slab_pos, s_slab_end, total, o, sample_base, ok) : sample_base;
-                o.foff[part] = ok ? (uint32_t)(bb - sample_base) : 0u;
-                o.fcnt[part] = ok ? total : 0u;
-                s_base = bb;
+        // arena space for the solid records: the block's slab state is double-buffered in LDS, so in the common case (the
+        // run fits the current slab) every thread derives the base itself and no barrier is needed before the emit
+        const uint32_t par = iter & 1u;
+        iter++;
+        const ull sp_ = s_slab[par * 2u], se_ = s_slab[par * 2u + 1u];
+        const bool fits = !ovf && (total == 0 || (sp_ + total <= se_ && sp_ - sample_base + total <= 0xffffffffull));
+        ull base_ = sample_base;
+        bool ok_ = true;
+        if (fits) {
+            if (total) base_ = sp_;
+            if (tid == 0) {
+                s_slab[(par ^ 1u) * 2u] = sp_ + total; s_slab[(par ^ 1u) * 2u + 1u] = se_;
+                o.foff[part] = (uint32_t)(base_ - sample_base); o.fcnt[part] = total;
             }
-            s_ok = ok;
+        } else {
+            if (tid == 0) {
+                uint32_t ok = 1;
+                ull slab_pos = sp_, slab_end = se_;
+                if (ovf) { const ull w = atomicAdd(redo_count, 1ull); redo_list[w] = part; ok = 0; }
+                else {
+                    const ull bb = slab_take(slab_pos, slab_end, total, o, sample_base, ok);
+                    o.foff[part] = ok ? (uint32_t)(bb - sample_base) : 0u;
+                    o.fcnt[part] = ok ? total : 0u;
+                    s_base = bb;
+                }
+                s_slab[(par ^ 1u) * 2u] = slab_pos; s_slab[(par ^ 1u) * 2u + 1u] = slab_end;
+                s_ok = ok;
+            }
+            __syncthreads();
+            base_ = s_base; ok_ = s_ok != 0;
         }
-        __syncthreads();
-        if (s_ok) {
+        PH(6)
+        if (ok_) {
             bt_dall += ndall; bt_D += D; bt_N += N; bt_Q += Q;
-            ull pos = s_base + (spos[tid] & 0xffffu);
+            ull pos = base_ + (spos[tid] & 0xffffu);
             const ull khigh = NARROW ? ((ull)part << l2.rem_bits) : 0ull;         // the arena holds whole keys
 #pragma unroll
             for (uint32_t q = 0; q < SPT; q++) {
@@ -538,8 +575,10 @@ k_count_fast(SimkaKeyCfg cfg, SimkaL2 l2, uint32_t amin, uint32_t amax, SimkaCou
                 }
             }
         }
+        PH(7)
         part = next; n = n_next; fastp = fast_next;
     }
+    PH_FLUSH
 #undef K2F_LOAD
     if (o.hist) {
         __syncthreads();
