@@ -1001,7 +1001,11 @@ SIMKA_EXPORT int simka_merge(simka_ctx *ctx) {
     rc = check_device_error(ctx);
     if (rc) return rc;
     ctx->merged = true;
-    if (!ctx->geometry_ready || N < 2) return SIMKA_OK;   // nothing to pair up
+    if (!ctx->geometry_ready) return SIMKA_OK;            // only empty samples
+    if (N < 2) {   // nothing to pair up: the union of k-mers is the sample's own solid spectrum, none of it shared
+        HIPCHK(hipMemcpyAsync(ctx->d_stats, ctx->d_stats + stats_off_tot(N, ctx->cfg.dist_flags, SIMKA_TOT_D), 8, hipMemcpyDeviceToDevice, ctx->stream));
+        return SIMKA_OK;
+    }
     const uint64_t nparts = ctx->nparts;
 
     // records per partition over all samples -> host scan (also drives the batching)

@@ -106,6 +106,10 @@ def _synthetic(n_samples, nb_reads, read_len, seed_shift=0):
     (15, 2, 5, 2500, 80, {"log2_partitions": 3}),
     (21, 2, 6, 3000, 100, {"log2_partitions": 2}),          # partitions far above the LDS table: multi-round k_count
     (31, 1, 3, 3000, 120, {"log2_partitions": 1, "log2_subranges": 1}),   # ... and over-full k_group sub-ranges
+    (1, 1, 3, 500, 60, {}), (2, 2, 3, 500, 60, {}), (5, 1, 4, 800, 60, {}),    # tiny k: 4 / 16 / 1024 possible k-mers, huge counts
+    (9, 2, 4, 2000, 100, {"abundance_max": 40}),                          # -abundance-max cuts the frequent k-mers
+    (21, 2, 1, 3000, 100, {}),                                            # one sample: no pairs, 1 x 1 matrices
+    (31, 2, 3, 400, 30, {}),                                              # reads shorter than k: nothing to count
 ])
 def test_synthetic_vs_oracle(gpu_required, oracle_mod, k, amin, n, R, L, kw):
     from simka_amd import synth
@@ -115,7 +119,7 @@ def test_synthetic_vs_oracle(gpu_required, oracle_mod, k, amin, n, R, L, kw):
     orc = oracle_mod.Oracle()
     for s, pk in enumerate(packed):
         orc.add_sample_ascii("S%d" % s, synth.unpack_ascii(pk, R * L), np.arange(R + 1, dtype=np.uint64) * L)
-    orc.run(k, amin, simple=True, complex_=True)
+    orc.run(k, amin, amax=kw.get("abundance_max", 999999999), simple=True, complex_=True)
     _check_vs_oracle(totals, st, orc)
     # floating-point distances: <= 1e-6 relative (north_star tolerance) -- here they are float32-identical
     for w, name in enumerate(orc.matrix_names()):
