@@ -4,7 +4,8 @@
 // (ref: src/SimkaPotara.cpp:29-53,147-163, src/core/Simka.cpp:25-117, src/SimkaPotara.hpp:259-326).
 // Where the reference forks one simkaCount process per sample and one simkaMerge process per
 // partition and synchronises through files, this driver calls simka_count_sample() per sample and
-// simka_merge() once, on 1..G GPUs (partition shards), and sums the shards' accumulators.
+// simka_merge() once; on G GPUs the samples are spread over the GPUs for counting, their spectra
+// exchanged by partition range, and the GPUs' pair accumulators summed.
 #include <errno.h>
 #include <math.h>
 #include <stdint.h>
@@ -42,7 +43,8 @@ struct Options {
     int nb_cores = 0;
     long long max_memory = 5000;
     int verbose = 1;
-    int nb_gpus = 1, first_gpu = 0;     // new: devices to shard the partition space over
+    int nb_gpus = 1, first_gpu = 0;     // new: GPUs to spread the samples (count) and the partition ranges (merge) over
+    bool same_gpu = false;              // new (tests): all -nb-gpus contexts on GPU -gpu
     bool parse_only = false;            // new: stop after reading + packing the inputs (ingest benchmark, no GPU needed)
 };
 
@@ -91,7 +93,7 @@ void usage() {
         "       -max-count        (1 arg) :    accepted for compatibility (no job processes here)\n"
         "       -max-merge        (1 arg) :    accepted for compatibility\n"
         "   [gpu options]\n"
-        "       -nb-gpus          (1 arg) :    MI355X devices to shard the k-mer partition space over  [default '1']\n"
+        "       -nb-gpus          (1 arg) :    MI355X devices: samples are counted on GPU i % n, partition ranges merged per GPU  [default '1']\n"
         "       -gpu              (1 arg) :    first device ordinal  [default '0']\n"
         "       -verbose          (1 arg) :    verbosity level  [default '1']\n";
 }
@@ -123,6 +125,7 @@ Options parse_args(int argc, char **argv) {
         else if (a == "-verbose") o.verbose = atoi(need(i).c_str());
         else if (a == "-nb-gpus") o.nb_gpus = atoi(need(i).c_str());
         else if (a == "-gpu") o.first_gpu = atoi(need(i).c_str());
+        else if (a == "-gpu-shared") o.same_gpu = true;
         else if (a == "-parse-only") o.parse_only = true;
         else if (a == "-max-count" || a == "-max-merge" || a == "-count-cmd" || a == "-merge-cmd" || a == "-count-file" ||
                  a == "-merge-file" || a == "-minimizer-size" || a == "-solidity-kind" || a == "-max-disk" ||
@@ -490,9 +493,13 @@ int main(int argc, char **argv) {
         std::cout << "parsed " << reads << " reads, " << bases << " bases with " << std::min<unsigned>(nthreads, N) << " threads" << std::endl;
         return EXIT_SUCCESS;
     }
-    // contexts: one per GPU, partition space sharded
+    // Contexts.  One GPU: a single context counts and merges.  G GPUs: sample i is counted over the WHOLE key space by a
+    // one-sample context on GPU i % G (the reference: one simkaCount job per sample), its solid spectrum is exported, and
+    // the slice of partition range [P*g/G, P*(g+1)/G) is imported into the merge context of GPU g (the reference: every
+    // simkaMerge job reads partition p of every sample's solid/ directory, ref: src/SimkaMerge.cpp:1164-1264).
     const uint32_t G = (uint32_t)o.nb_gpus;
-    // -keep-tmp: samples whose spectrum (every shard's file) is in the temp dir and still valid are not read again
+    const uint32_t flags = (o.simple ? SIMKA_DIST_SIMPLE : 0u) | (o.complex_ ? SIMKA_DIST_COMPLEX : 0u);
+    // -keep-tmp: samples whose spectrum is in the temp dir and still valid are not read again
     std::vector<char> reuse(N, 0);
     std::vector<uint64_t> sig(N, 0);
     uint64_t kept_partitions = 0;
@@ -500,91 +507,118 @@ int main(int argc, char **argv) {
         mkdir_p(tmp + "/solid");
         for (uint32_t i = 0; i < N; i++) {
             sig[i] = sample_signature(samples[i], o, max_reads);
-            bool ok = true;
-            uint64_t np = 0;
-            for (uint32_t g = 0; g < G && ok; g++) {
-                SpecHeader h;
-                ok = read_spec_header(spec_path(tmp, samples[i], g, G), h) && spec_matches(h, o, g, G, sig[i]) && (np == 0 || np == h.nb_partitions);
-                if (ok) np = h.nb_partitions;
-            }
-            if (ok && kept_partitions && np != kept_partitions) ok = false;      // all samples of a run share one partitioning
-            if (ok) { reuse[i] = 1; kept_partitions = np; }
+            SpecHeader h;
+            bool ok = read_spec_header(spec_path(tmp, samples[i], 0, 1), h) && spec_matches(h, o, 0, 1, sig[i]);
+            if (ok && kept_partitions && h.nb_partitions != kept_partitions) ok = false;      // all samples of a run share one partitioning
+            if (ok) { reuse[i] = 1; kept_partitions = h.nb_partitions; }
         }
     }
-    uint32_t kept_log2 = 0;
-    while (((uint64_t)1 << kept_log2) < kept_partitions) kept_log2++;
-    std::vector<simka_ctx *> ctx(G, nullptr);
-    const uint32_t flags = (o.simple ? SIMKA_DIST_SIMPLE : 0u) | (o.complex_ ? SIMKA_DIST_COMPLEX : 0u);
-    for (uint32_t g = 0; g < G; g++) {
+    // partition geometry from the largest input (2-bit bases <= file bytes); fixed up front: every context must agree
+    uint64_t biggest = 1;
+    for (auto &s : samples) { uint64_t b = 0; for (auto &p : s.parts) for (auto &fn : p) { struct stat st; if (stat(fn.c_str(), &st) == 0) b += (uint64_t)st.st_size * (fn.size() > 3 && fn.substr(fn.size() - 3) == ".gz" ? 5 : 1); } biggest = std::max(biggest, b); }
+    uint32_t log2_parts = simka_default_log2_partitions(biggest, (uint32_t)o.kmer_size);
+    if (kept_partitions) { log2_parts = 0; while (((uint64_t)1 << log2_parts) < kept_partitions) log2_parts++; }      // new samples join the kept partitioning
+    const uint64_t P = (uint64_t)1 << log2_parts;
+    auto make_ctx = [&](uint32_t nb_samples, int device) {
         simka_config cfg;
         memset(&cfg, 0, sizeof cfg);
         cfg.struct_size = sizeof cfg;
-        cfg.nb_samples = N; cfg.kmer_size = (uint32_t)o.kmer_size;
+        cfg.nb_samples = nb_samples; cfg.kmer_size = (uint32_t)o.kmer_size;
         cfg.abundance_min = (uint32_t)std::min<long long>(o.abundance_min, 0xffffffffLL);
         cfg.abundance_max = (uint32_t)o.abundance_max;
-        cfg.dist_flags = flags; cfg.device = o.first_gpu + (int)g; cfg.shard_index = g; cfg.shard_count = G;
-        // partition geometry from the largest input (2-bit bases <= file bytes)
-        uint64_t biggest = 0;
-        for (auto &s : samples) { uint64_t b = 0; for (auto &p : s.parts) for (auto &fn : p) { struct stat st; if (stat(fn.c_str(), &st) == 0) b += (uint64_t)st.st_size * (fn.size() > 3 && fn.substr(fn.size() - 3) == ".gz" ? 5 : 1); } biggest = std::max(biggest, b); }
-        cfg.max_kmers_per_sample = std::max<uint64_t>(biggest, 1);
-        if (kept_partitions) cfg.log2_partitions = kept_log2;      // new samples join the partitioning of the kept spectra
-        int rc = simka_create(&cfg, &ctx[g]);
-        if (rc != SIMKA_OK) { std::cout << "EXCEPTION: " << simka_last_error(nullptr) << std::endl; return EXIT_FAILURE; }
+        cfg.dist_flags = flags; cfg.device = device; cfg.shard_index = 0; cfg.shard_count = 1;
+        cfg.max_kmers_per_sample = biggest; cfg.log2_partitions = log2_parts;
+        simka_ctx *c = nullptr;
+        if (simka_create(&cfg, &c) != SIMKA_OK) { std::cout << "EXCEPTION: " << simka_last_error(nullptr) << std::endl; exit(EXIT_FAILURE); }
+        return c;
+    };
+    auto device_of = [&](uint32_t g) { return o.first_gpu + (o.same_gpu ? 0 : (int)g); };
+    std::vector<simka_ctx *> ctx(G, nullptr), cctx(G, nullptr);        // merge contexts; G > 1: one-sample counting contexts
+    for (uint32_t g = 0; g < G; g++) {
+        ctx[g] = make_ctx(N, device_of(g));
+        if (G > 1) cctx[g] = make_ctx(1, device_of(g));
     }
+    std::vector<std::mutex> ctx_lock(G);
+    // a sample's whole spectrum -> the merge context of every GPU (its partition range only)
+    auto distribute = [&](uint32_t i, const Spectrum &sp) {
+        if (sp.h.nb_partitions != P) die("ERROR: spectrum of " + samples[i].id + " has another partition count (remove " + tmp + "/solid to recount)");
+        std::vector<uint64_t> off(P + 1, 0);
+        for (uint64_t p = 0; p < P; p++) off[p + 1] = off[p] + sp.part_counts[p];
+        for (uint32_t g = 0; g < G; g++) {
+            const uint64_t lo = P * g / G, hi = P * (g + 1) / G;
+            std::vector<uint32_t> pc(P, 0);
+            std::copy(sp.part_counts.begin() + lo, sp.part_counts.begin() + hi, pc.begin() + lo);
+            const uint64_t n = off[hi] - off[lo];
+            std::lock_guard<std::mutex> lk(ctx_lock[g]);
+            check(ctx[g], simka_import_sample(ctx[g], i, &sp.h.totals, pc.data(), P, n ? sp.keys.data() + off[lo] : nullptr,
+                                              n ? sp.counts.data() + off[lo] : nullptr, n), "simka_import_sample");
+        }
+    };
+    auto export_from = [&](simka_ctx *c, uint32_t index, uint32_t i, Spectrum &sp) {
+        simka_spectrum_info info;
+        check(c, simka_sample_spectrum_info(c, index, &info), "simka_sample_spectrum_info");
+        sp.part_counts.resize(info.nb_partitions); sp.keys.resize(info.nb_records); sp.counts.resize(info.nb_records);
+        check(c, simka_export_sample(c, index, sp.part_counts.data(), sp.keys.data(), sp.counts.data()), "simka_export_sample");
+        memset(&sp.h, 0, sizeof sp.h);
+        memcpy(sp.h.magic, "SIMKSPC1", 8);
+        sp.h.abi = (uint64_t)simka_abi_version(); sp.h.kmer_size = (uint64_t)o.kmer_size;
+        sp.h.abundance_min = (uint64_t)o.abundance_min; sp.h.abundance_max = (uint64_t)o.abundance_max;
+        sp.h.shard_index = 0; sp.h.shard_count = 1; sp.h.nb_partitions = info.nb_partitions; sp.h.nb_records = info.nb_records;
+        sp.h.signature = sig[i];
+        check(c, simka_get_sample_totals(c, index, &sp.h.totals), "simka_get_sample_totals");
+    };
 
     // count (ref: SimkaPotaraAlgorithm::count, src/SimkaPotara.hpp:813-972)
     if (o.verbose) std::cout << "Counting k-mers... (log files are " << tmp << "/log/count_*)" << std::endl;
     std::vector<simka_sample_totals> totals(N);
-    SampleLoader loader(samples, o, max_reads, nthreads, nthreads + 2, reuse);
-    for (uint32_t i = 0; i < N; i++) {
-        Packed *pkp;
-        if (!loader.get(i, pkp)) die("ERROR: Can't open dataset: " + samples[i].id);
-        if (reuse[i]) {     // ref: src/SimkaPotara.hpp:837-842 (count_synchro/<ID>.ok exists -> the sample is not recounted)
-            for (uint32_t g = 0; g < G; g++) {
+    SampleLoader loader(samples, o, max_reads, nthreads, nthreads + 2 * G, reuse);
+    std::mutex out_lock;
+    // worker g handles the samples i % G == g on GPU g (G == 1: everything, in order, in this thread)
+    auto worker = [&](uint32_t g) {
+        for (uint32_t i = g; i < N; i += G) {
+            Packed *pkp;
+            if (!loader.get(i, pkp)) die("ERROR: Can't open dataset: " + samples[i].id);
+            if (reuse[i]) {     // ref: src/SimkaPotara.hpp:837-842 (count_synchro/<ID>.ok exists -> the sample is not recounted)
                 Spectrum sp;
-                if (!read_spec(spec_path(tmp, samples[i], g, G), sp)) die("ERROR: cannot read " + spec_path(tmp, samples[i], g, G) + " (remove it to recount the sample)");
-                check(ctx[g], simka_import_sample(ctx[g], i, &sp.h.totals, sp.part_counts.data(), sp.h.nb_partitions, sp.keys.data(), sp.counts.data(),
-                                                  sp.h.nb_records), "simka_import_sample");
+                const std::string path = spec_path(tmp, samples[i], 0, 1);
+                if (!read_spec(path, sp)) die("ERROR: cannot read " + path + " (remove it to recount the sample)");
+                distribute(i, sp);
+                if (o.verbose) { std::lock_guard<std::mutex> lk(out_lock); std::cout << "\t" << samples[i].id << ": k-mer spectrum reused from " << tmp << "/solid" << std::endl; }
+                loader.release(i);
+                continue;
             }
-            if (o.verbose) std::cout << "\t" << samples[i].id << ": k-mer spectrum reused from " << tmp << "/solid" << std::endl;
-            loader.release(i);
-            continue;
-        }
-        Packed &pk = *pkp;
-        simka_reads r;
-        memset(&r, 0, sizeof r);
-        r.packed = pk.words.data(); r.nb_bases = pk.nb_bases; r.nb_reads = pk.nb_frag; r.offsets = pk.offsets.data();
-        r.fixed_len = 0; r.on_device = 0; r.nb_input_reads = pk.nb_reads;
-        for (uint32_t g = 0; g < G; g++) check(ctx[g], simka_count_sample(ctx[g], i, &r), "simka_count_sample");
-        loader.release(i);     // host buffers may be reused as soon as simka_count_sample returns
-        if (o.keep_tmp) {      // persist the spectrum so that a later run with more samples skips this one
-            for (uint32_t g = 0; g < G; g++) {
+            Packed &pk = *pkp;
+            simka_reads r;
+            memset(&r, 0, sizeof r);
+            r.packed = pk.words.data(); r.nb_bases = pk.nb_bases; r.nb_reads = pk.nb_frag; r.offsets = pk.offsets.data();
+            r.fixed_len = 0; r.on_device = 0; r.nb_input_reads = pk.nb_reads;
+            if (G == 1) {
+                check(ctx[0], simka_count_sample(ctx[0], i, &r), "simka_count_sample");
+                loader.release(i);     // host buffers may be reused as soon as simka_count_sample returns
+                if (o.keep_tmp) {      // persist the spectrum so that a later run with more samples skips this one
+                    Spectrum sp;
+                    export_from(ctx[0], i, i, sp);
+                    if (!write_spec(spec_path(tmp, samples[i], 0, 1), sp)) die("ERROR: cannot write " + spec_path(tmp, samples[i], 0, 1));
+                }
+            } else {
+                check(cctx[g], simka_count_sample(cctx[g], 0, &r), "simka_count_sample");
+                loader.release(i);
                 Spectrum sp;
-                simka_spectrum_info info;
-                check(ctx[g], simka_sample_spectrum_info(ctx[g], i, &info), "simka_sample_spectrum_info");
-                sp.part_counts.resize(info.nb_partitions); sp.keys.resize(info.nb_records); sp.counts.resize(info.nb_records);
-                check(ctx[g], simka_export_sample(ctx[g], i, sp.part_counts.data(), sp.keys.data(), sp.counts.data()), "simka_export_sample");
-                memset(&sp.h, 0, sizeof sp.h);
-                memcpy(sp.h.magic, "SIMKSPC1", 8);
-                sp.h.abi = (uint64_t)simka_abi_version(); sp.h.kmer_size = (uint64_t)o.kmer_size;
-                sp.h.abundance_min = (uint64_t)o.abundance_min; sp.h.abundance_max = (uint64_t)o.abundance_max;
-                sp.h.shard_index = g; sp.h.shard_count = G; sp.h.nb_partitions = info.nb_partitions; sp.h.nb_records = info.nb_records;
-                sp.h.signature = sig[i];
-                check(ctx[g], simka_get_sample_totals(ctx[g], i, &sp.h.totals), "simka_get_sample_totals");
-                if (!write_spec(spec_path(tmp, samples[i], g, G), sp)) die("ERROR: cannot write " + spec_path(tmp, samples[i], g, G));
+                export_from(cctx[g], 0, i, sp);
+                check(cctx[g], simka_reset(cctx[g]), "simka_reset");
+                distribute(i, sp);
+                if (o.keep_tmp && !write_spec(spec_path(tmp, samples[i], 0, 1), sp)) die("ERROR: cannot write " + spec_path(tmp, samples[i], 0, 1));
             }
         }
+    };
+    if (G == 1) worker(0);
+    else {
+        std::vector<std::thread> th;
+        for (uint32_t g = 0; g < G; g++) th.emplace_back(worker, g);
+        for (auto &t : th) t.join();
+        for (uint32_t g = 0; g < G; g++) simka_destroy(cctx[g]);
     }
-    for (uint32_t i = 0; i < N; i++) {
-        simka_sample_totals sum; memset(&sum, 0, sizeof sum);
-        for (uint32_t g = 0; g < G; g++) {
-            simka_sample_totals t;
-            check(ctx[g], simka_get_sample_totals(ctx[g], i, &t), "simka_get_sample_totals");
-            sum.nb_reads = t.nb_reads; sum.nb_distinct += t.nb_distinct; sum.nb_kmers += t.nb_kmers; sum.sum_sq += t.sum_sq;
-            sum.kmer_occurrences += t.kmer_occurrences; sum.distinct_all += t.distinct_all;
-        }
-        totals[i] = sum;
-    }
+    for (uint32_t i = 0; i < N; i++) check(ctx[0], simka_get_sample_totals(ctx[0], i, &totals[i]), "simka_get_sample_totals");   // global on every context
     if (o.keep_tmp) {   // count_synchro/<ID>.ok with the reference's 4 lines (ref: src/SimkaCount.cpp:303-317)
         mkdir_p(tmp + "/count_synchro");
         for (uint32_t i = 0; i < N; i++) {
@@ -600,12 +634,11 @@ int main(int argc, char **argv) {
 
     // merge + reduce (ref: SimkaPotaraAlgorithm::merge / stats, src/SimkaPotara.hpp:974-1187)
     if (o.verbose) std::cout << std::endl << "Merging k-mer counts and computing distances..." << std::endl;
-    if (G > 1) {   // make the per-sample totals global on every shard before the merge (-complex-dist needs N_i)
-        std::vector<uint64_t> tsum(5 * (size_t)N, 0), t(5 * (size_t)N);
-        for (uint32_t g = 0; g < G; g++) { check(ctx[g], simka_totals_download(ctx[g], t.data()), "simka_totals_download"); for (size_t w = 0; w < t.size(); w++) tsum[w] += t[w]; }
-        for (uint32_t g = 0; g < G; g++) check(ctx[g], simka_totals_upload(ctx[g], tsum.data()), "simka_totals_upload");
+    {   // every GPU merges its partition range (imported totals are already global: -complex-dist needs N_i)
+        std::vector<std::thread> th;
+        for (uint32_t g = 0; g < G; g++) th.emplace_back([&, g] { check(ctx[g], simka_merge(ctx[g]), "simka_merge"); });
+        for (auto &t : th) t.join();
     }
-    for (uint32_t g = 0; g < G; g++) check(ctx[g], simka_merge(ctx[g]), "simka_merge");
     const uint64_t nw = simka_stats_nb_u64(N, flags);
     uint64_t lay[8];
     simka_stats_layout(N, flags, lay);

@@ -236,17 +236,24 @@ static int set_lds_attr(simka_ctx *ctx) {
     return SIMKA_OK;
 }
 
+// ~SIMKA_TARGET_PER_PART k-mer occurrences of the largest sample per partition (one LDS table of k_count_fast)
+static uint32_t default_log2_partitions(uint64_t max_kmers, uint32_t shard_count) {
+    const uint64_t per_shard = std::max<uint64_t>(1, max_kmers / std::max(1u, shard_count));
+    uint32_t pb = ceil_log2_u64((per_shard + SIMKA_TARGET_PER_PART - 1) / SIMKA_TARGET_PER_PART) + ceil_log2_u64(std::max(1u, shard_count));
+    return std::min(pb, 20u);
+}
+
+SIMKA_EXPORT uint32_t simka_default_log2_partitions(uint64_t max_kmers_per_sample, uint32_t kmer_size) {
+    return std::max(1u, std::min(default_log2_partitions(max_kmers_per_sample, 1), 2u * kmer_size));
+}
+
 // partition geometry from the largest sample's k-mer count (all samples must share it: the merge
 // joins partition p of every sample, as simkaMerge joins solid/part_p/ of every sample)
 static int setup_geometry(simka_ctx *ctx, uint64_t max_kmers) {
     const simka_config &c = ctx->cfg;
     SimkaKeyCfg &k = ctx->key;
     uint32_t pb = c.log2_partitions;
-    if (pb == 0) {
-        const uint64_t per_shard = std::max<uint64_t>(1, max_kmers / std::max(1u, c.shard_count));
-        pb = ceil_log2_u64((per_shard + SIMKA_TARGET_PER_PART - 1) / SIMKA_TARGET_PER_PART);
-        pb += ceil_log2_u64(c.shard_count);
-    }
+    if (pb == 0) pb = default_log2_partitions(max_kmers, c.shard_count);
     if (pb > 20) pb = 20;
     if (pb > k.W) pb = k.W;
     uint32_t l1 = (pb + 1) / 2;

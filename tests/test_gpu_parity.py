@@ -594,3 +594,32 @@ def test_sample_shards_then_partition_range_merge(gpu_required, world, complex_)
         tail = slice(head, lay["derived"])
         assert np.array_equal(st.flat[tail], ref.flat[tail])                # per-sample totals: global on every rank
     assert np.array_equal(total, ref.flat[:head])
+
+
+@pytest.mark.parametrize("gpus", [2, 3])
+def test_cli_multi_gpu_sample_shards_on_one_device(gpu_required, golden_dir, tmp_path, gpus):
+    """`simka -nb-gpus G`: samples counted by one-sample contexts (GPU i % G), spectra exported and imported by partition range
+    into G merge contexts, heads summed on the host.  -gpu-shared puts all contexts on one device so the path runs here;
+    the goldens must come out byte for byte, -complex-dist included, and a -keep-tmp rerun with another G reuses the spectra."""
+    import subprocess
+    from simka_amd import build as b
+    tmp = str(tmp_path / "tmp")
+    base = [b.CLI_PATH, "-in", os.path.join(golden_dir, "example", "simka_input.txt"), "-out-tmp", tmp, "-simple-dist", "-complex-dist",
+            "-kmer-size", "31", "-abundance-min", "2", "-keep-tmp", "-gpu-shared"]
+    truth = os.path.join(golden_dir, "truth", "results_k31_t2")
+
+    def run(out, g):
+        r = subprocess.run(base + ["-out", out, "-nb-gpus", str(g)], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+        assert r.returncode == 0, r.stdout
+        n = 0
+        for gzf in glob.glob(os.path.join(out, "*.csv.gz")):
+            ref = os.path.join(truth, os.path.basename(gzf)[:-3])
+            if os.path.exists(ref):
+                with gzip.open(gzf, "rb") as f, open(ref, "rb") as h:
+                    assert f.read() == h.read(), os.path.basename(gzf)
+                n += 1
+        assert n == 20
+        return r.stdout
+
+    assert "reused" not in run(str(tmp_path / "o1"), gpus)
+    assert run(str(tmp_path / "o2"), 5 - gpus).count("k-mer spectrum reused") == 5        # other GPU count, same spectra
