@@ -113,6 +113,8 @@ def main():
     ap.add_argument("--samples", type=int, default=0, help="override number of samples")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--log2-partitions", type=int, default=0)
+    ap.add_argument("--offsets", action="store_true", help="hand the reads over with an offsets array (variable-length layout, what the "
+                    "simka driver uses) instead of fixed_len")
     ap.add_argument("--mgpu", default=os.environ.get("SIMKA_BENCH_MGPU", "sample"), choices=["sample", "partition"],
                     help="N > 1: 'sample' = samples counted on rank s %% N, spectra exchanged by partition range (all-to-all), "
                          "'partition' = every rank scans everything and keeps its partition shard (no exchange)")
@@ -156,8 +158,13 @@ def main():
                                  shard_index=0 if by_sample else rank, shard_count=1 if by_sample else world,
                                  max_kmers_per_sample=kocc_per_sample, log2_partitions=args.log2_partitions)
 
+    d_offsets = torch.arange(0, (R + 1) * L, L, dtype=torch.int64, device=dev) if args.offsets else None
+
     def count(s):
-        ctx.count_sample(s, reads[s].data_ptr(), nb_bases, R, fixed_len=L, on_device=True)
+        if args.offsets:
+            ctx.count_sample(s, reads[s].data_ptr(), nb_bases, R, offsets=d_offsets.data_ptr(), on_device=True)
+        else:
+            ctx.count_sample(s, reads[s].data_ptr(), nb_bases, R, fixed_len=L, on_device=True)
 
     def step():
         if by_sample:

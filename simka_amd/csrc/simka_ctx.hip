@@ -41,6 +41,7 @@ struct simka_ctx {
         uint64_t *d_l1 = nullptr; uint64_t l1_cap = 0;            // level-1 buckets (keys)
         ull *d_b1_count = nullptr, *d_b1_start = nullptr, *d_b1_end = nullptr, *d_b1_cursor = nullptr;
         uint32_t *d_chunk_first = nullptr;
+        uint32_t *d_tile_r0 = nullptr; uint64_t tile_r0_cap = 0;  // variable-length reads: first read of every scan tile
         ull *d_l2 = nullptr; uint64_t l2_cap = 0;                 // level-2 partition regions (keys)
         uint32_t *d_p_count = nullptr, *d_p_valid = nullptr;      // [nparts]
         ull *d_spill_keys = nullptr; uint64_t spill_cap = 0; uint32_t *d_spill_part = nullptr; uint64_t spill_part_cap = 0;
@@ -377,7 +378,7 @@ SIMKA_EXPORT void simka_destroy(simka_ctx *ctx) {
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     for (auto &L : ctx->lanes) {
         if (L.stream) (void)hipStreamSynchronize(L.stream);
-        void *lp[] = { L.d_l1, L.d_b1_count, L.d_b1_start, L.d_b1_end, L.d_b1_cursor, L.d_chunk_first, L.d_l2, L.d_p_count, L.d_p_valid,
+        void *lp[] = { L.d_l1, L.d_b1_count, L.d_b1_start, L.d_b1_end, L.d_b1_cursor, L.d_chunk_first, L.d_tile_r0, L.d_l2, L.d_p_count, L.d_p_valid,
                        L.d_spill_keys, L.d_spill_part, L.d_spill_cursor, L.d_redo_list, L.d_redo_count };
         for (void *q : lp) if (q) (void)hipFree(q);
         if (L.stream) (void)hipStreamDestroy(L.stream);
@@ -450,18 +451,26 @@ static int ensure_cap(simka_ctx *ctx, T **p, uint64_t *cap, uint64_t need) {
 
 // enqueue the count-side kernels of one sample.  exact=false: capacity-sized level-1 buckets, no histogram pass; the
 // kernels after the scatter skip themselves if it flags an overflow, and resolve_pending() redoes the sample exactly.
-static int run_count_kernels(simka_ctx *ctx, uint32_t sample, const SimkaScanArgs &a, bool exact) {
+static int run_count_kernels(simka_ctx *ctx, uint32_t sample, const SimkaScanArgs &a_in, bool exact) {
     const uint32_t N = ctx->cfg.nb_samples;
     simka_ctx::Lane &L = ctx->lanes[sample % ctx->nlanes];
     const hipStream_t st = L.stream;
     int rc;
+    SimkaScanArgs a = a_in;
+    a.tile_r0 = nullptr;
     const SimkaKeyCfg key = ctx->key;
     const uint32_t B1 = ctx->B1, B2 = ctx->B2;
     ull *kocc = (ull *)ctx->d_stats + stats_off_tot(N, ctx->cfg.dist_flags, SIMKA_TOT_KOCC) + sample;
     const uint64_t tile = (uint64_t)K1_BLOCK * K1_SEG;
     const uint32_t grid1 = (uint32_t)((a.nb_bases + tile - 1) / tile);
-    const size_t lds_hist = SIMKA_LDS_HEAD + (size_t)B1 * 16 + 128 + K1_BLOCK * 4;
+    const size_t lds_rtab = a.fixed_len ? 0 : (size_t)K1_RTAB * 4;
+    const size_t lds_hist = SIMKA_LDS_HEAD + (size_t)B1 * 16 + 128 + K1_BLOCK * 4 + lds_rtab;
     const size_t lds_scat = lds_hist + (size_t)tile * 8;
+    if (!a.fixed_len && a.nb_reads && grid1) {      // where every tile starts in the read list (one binary search per tile, not per thread)
+        rc = ensure_cap(ctx, &L.d_tile_r0, &L.tile_r0_cap, (uint64_t)grid1 + 2); if (rc) return rc;
+        hipLaunchKernelGGL(k_tile_reads, dim3((grid1 + 1 + 255) / 256), dim3(256), 0, st, a.offsets, a.nb_reads, a.nb_bases, grid1, tile, L.d_tile_r0);
+        a.tile_r0 = L.d_tile_r0;
+    }
     const size_t lds_lay = SIMKA_LDS_HEAD + (size_t)B1 * 12 + 128;
     uint32_t *flag = ctx->d_l1_ovf + sample;       // bit 0: level-1 bucket overflow, bit 1: spill buffer overflow
     const uint32_t *skip = flag;

@@ -8,7 +8,8 @@
 
 // K1  k_scan
 #define K1_BLOCK 1024         // 16 waves: 16384-position tiles -> long bucket runs (run length is what the scatter is bound by)
-#define K1_SEG 16             // k-mer start positions per thread (window = SEG + k - 1 <= 64 bases holds for k <= 33)
+#define K1_SEG 16
+#define K1_RTAB 2048          // k_scan, variable-length reads: read starts of one tile staged in LDS (else global binary search)             // k-mer start positions per thread (window = SEG + k - 1 <= 64 bases holds for k <= 33)
 // K2  k_split / k_count
 #define K2_BLOCK 1024         // k_split
 #define K2C_BLOCK 256         // k_count
@@ -78,6 +79,7 @@ struct SimkaScanArgs {
     const uint64_t *offsets;
     uint64_t nb_reads;
     uint32_t fixed_len;
+    const uint32_t *tile_r0;                 // variable-length reads: index of the read holding the first base of every scan tile (k_tile_reads)
 };
 
 struct SimkaCountOut {

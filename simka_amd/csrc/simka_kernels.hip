@@ -68,6 +68,19 @@ __device__ __forceinline__ uint32_t window_base(uint64_t A, uint64_t B, uint32_t
     return (uint32_t)(w >> ((i & 31u) * 2u)) & 3u;
 }
 
+// k_tile_reads: variable-length reads.  tile_r0[b] = index of the read that holds base b * tile (largest r with
+// offsets[r] <= b * tile), one thread per tile; k_scan stages the read starts of its tile in LDS from it.
+__global__ void __launch_bounds__(256)
+k_tile_reads(const uint64_t *offsets, uint64_t nb_reads, uint64_t nb_bases, uint32_t ntiles, uint64_t tile, uint32_t *tile_r0) {
+    const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b > ntiles) return;
+    const uint64_t pos = (uint64_t)b * tile;
+    uint64_t lo = 0, hi = nb_reads;
+    if (pos >= nb_bases) { tile_r0[b] = (uint32_t)(nb_reads ? nb_reads - 1 : 0); return; }
+    while (hi - lo > 1) { const uint64_t mid = (lo + hi) >> 1; if (offsets[mid] <= pos) lo = mid; else hi = mid; }
+    tile_r0[b] = (uint32_t)lo;
+}
+
 // SHARDED: the context owns a subset of the level-1 buckets (partition shards); otherwise every k-mer is kept and the
 // ownership test (with its integer modulo for non power-of-two shard counts) is not even compiled in.
 template <bool SCATTER, bool FIXED, bool SHARDED>
@@ -82,9 +95,29 @@ k_scan(SimkaScanArgs a, SimkaKeyCfg cfg, ull *b1_count, ull *b1_cursor, uint64_t
     uint32_t *tmp = loff + B1;                         // [K1_BLOCK]
     ull *gbase = (ull *)(tmp + K1_BLOCK);              // [B1]
     uint64_t *stage = (uint64_t *)(gbase + B1);        // [K1_BLOCK*K1_SEG]   (SCATTER only)
+    uint32_t *rtab = (uint32_t *)(stage + (SCATTER ? K1_BLOCK * K1_SEG : 0));   // [K1_RTAB] (!FIXED) read starts after the tile's first base, relative to it
 
     const uint32_t tid = threadIdx.x;
     for (uint32_t i = tid; i < B1 + 32; i += K1_BLOCK) hist[i] = 0;
+    // variable-length reads: the starts of the reads that begin inside this tile (+ look-ahead), relative to the tile start
+    const uint64_t T0 = (uint64_t)blockIdx.x * (K1_BLOCK * K1_SEG);
+    uint32_t ntab = 0;              // 0: table not usable (too many reads in the tile) -> global binary search per thread
+    if (!FIXED && a.tile_r0) {
+        const uint64_t r0 = a.tile_r0[blockIdx.x], r1 = a.tile_r0[blockIdx.x + 1];
+        // entries offsets[r0+1 .. r1+64] (clamped to offsets[nb_reads] = nb_bases): every read start in (T0, T0 + tile + look-ahead]
+        uint64_t last = r1 + 64;
+        if (last > a.nb_reads) last = a.nb_reads;
+        const uint64_t cnt = last > r0 ? last - r0 : 0;
+        // (zero-length reads could put more than 64 starts into the look-ahead: then the last staged start is too close)
+        const bool covers = cnt > 0 && (last == a.nb_reads || a.offsets[last] - T0 > (uint64_t)(K1_BLOCK * K1_SEG + K1_SEG + 32u));
+        if (covers && cnt <= K1_RTAB) {
+            ntab = (uint32_t)cnt;
+            for (uint32_t i = tid; i < ntab; i += K1_BLOCK) {
+                const uint64_t d = a.offsets[r0 + 1 + i] - T0;
+                rtab[i] = d < 0xffffffffull ? (uint32_t)d : 0xffffffffu;
+            }
+        }
+    }
     __syncthreads();
 
     const uint64_t w0 = ((uint64_t)blockIdx.x * K1_BLOCK + tid) * K1_SEG;
@@ -107,9 +140,18 @@ k_scan(SimkaScanArgs a, SimkaKeyCfg cfg, ull *b1_count, ull *b1_cursor, uint64_t
 
         // the read (fragment) that contains base w0, and where the next one starts
         uint64_t rd, next;
+        uint32_t ti = 0;                 // (!FIXED, staged table) index of the next read start
         if (FIXED) {
             rd = w0 / a.fixed_len;
             next = (rd + 1) * (uint64_t)a.fixed_len;
+        } else if (ntab) {
+            // first staged read start beyond w0 (the table holds every start in (T0, w0 + look-ahead])
+            const uint32_t w0rel = (uint32_t)(w0 - T0);
+            uint32_t lo = 0, hi = ntab;          // smallest i with rtab[i] > w0rel; rtab[ntab-1] > w0rel unless the data end there
+            while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (rtab[mid] > w0rel) hi = mid; else lo = mid + 1; }
+            ti = lo < ntab ? lo : ntab - 1u;
+            rd = 0;
+            next = T0 + rtab[ti];
         } else {
             uint64_t lo = 0, hi = a.nb_reads;
             while (hi - lo > 1) {
@@ -139,6 +181,7 @@ k_scan(SimkaScanArgs a, SimkaKeyCfg cfg, ull *b1_count, ull *b1_cursor, uint64_t
 #pragma unroll
         for (int q = 0; q < K1_SEG; q++) {
             if (FIXED) { const bool nb_ = (uint32_t)q >= nrel; nrel = nb_ ? nrel + a.fixed_len : nrel; }
+            else if (ntab) while ((uint32_t)q >= nrel && ti + 1u < ntab) { ti++; const uint64_t nx_ = T0 + rtab[ti] - w0; nrel = nx_ < (uint64_t)SPAN ? (uint32_t)nx_ : SPAN; if (nx_ >= (uint64_t)SPAN) break; }
             else while ((uint32_t)q >= nrel && rd + 1 < a.nb_reads) { rd++; const uint64_t nx_ = a.offsets[rd + 1] - w0; nrel = nx_ < (uint64_t)SPAN ? (uint32_t)nx_ : SPAN; if (nx_ >= (uint64_t)SPAN) break; }
             const uint32_t s1 = 2u * (uint32_t)q, s2 = 2u * (uint32_t)(K1_SEG - 1 - q);     // compile-time after unrolling
             const uint64_t fwd = (s1 ? ((A >> s1) | (B << (64u - s1))) : A) & cfg.mask;
