@@ -521,20 +521,21 @@ k_count_fast(SimkaKeyCfg cfg, SimkaL2 l2, uint32_t amin, uint32_t amax, SimkaCou
         kk[u] = (i < (n)) ? l2k[(ull)(p) * l2.cap2 + i] : KEMPTY;                             \
     }
     uint32_t part = blockIdx.x;
-    uint32_t n = 0;
+    uint32_t n = 0, n_ahead = 0;            // key counts of this partition and of the next one: loaded one iteration early
     bool fastp = false;
     if (part < nparts) {
         n = l2.p_count[part];
         fastp = (ull)n <= l2.cap2;          // not spilled
         if (fastp) { K2F_LOAD(part, n) }
+        if (part + gridDim.x < nparts) n_ahead = l2.p_count[part + gridDim.x];
     }
     __syncthreads();
     PH_DECL
     while (part < nparts) {
         const uint32_t next = part + gridDim.x;
-        uint32_t n_next = 0;
-        bool fast_next = false;
-        if (next < nparts) { n_next = l2.p_count[next]; fast_next = (ull)n_next <= l2.cap2; }
+        const uint32_t n_next = n_ahead;
+        const bool fast_next = next < nparts && (ull)n_next <= l2.cap2;
+        n_ahead = (next + gridDim.x < nparts) ? l2.p_count[next + gridDim.x] : 0u;      // consumed in the next iteration
         if (n == 0) { part = next; n = n_next; fastp = fast_next; if (fastp) { K2F_LOAD(part, n) } continue; }
         if (!fastp) {     // spilled: the general kernel finishes it
             if (tid == 0) { const ull w = atomicAdd(redo_count, 1ull); redo_list[w] = part; }
@@ -584,10 +585,10 @@ k_count_fast(SimkaKeyCfg cfg, SimkaL2 l2, uint32_t amin, uint32_t amax, SimkaCou
         bool ok_ = true;
         if (fits) {
             if (total) base_ = sp_;
-            if (tid == 0) {
-                s_slab[(par ^ 1u) * 2u] = sp_ + total; s_slab[(par ^ 1u) * 2u + 1u] = se_;
-                o.foff[part] = (uint32_t)(base_ - sample_base); o.fcnt[part] = total;
-            }
+            // the bookkeeping is spread over three waves so that no single wave becomes the straggler of the next barrier
+            if (tid == 0) { s_slab[(par ^ 1u) * 2u] = sp_ + total; s_slab[(par ^ 1u) * 2u + 1u] = se_; }
+            if (tid == 64) o.foff[part] = (uint32_t)(base_ - sample_base);
+            if (tid == 128) o.fcnt[part] = total;
         } else {
             if (tid == 0) {
                 uint32_t ok = 1;
