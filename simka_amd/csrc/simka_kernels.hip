@@ -178,14 +178,18 @@ k_scan(SimkaScanArgs a, SimkaKeyCfg cfg, ull *b1_count, ull *b1_cursor, uint64_t
         const uint32_t rs = 2u * (64u - (K1_SEG + k - 1u));                  // 36 .. 96 bits: drop the bases beyond Wn
         const uint64_t R0 = (rs >= 64u) ? (ra >> (rs - 64u)) : ((rb >> rs) | (ra << (64u - rs)));
         const uint64_t R1 = (rs >= 64u) ? 0ull : (ra >> rs);
+        const uint32_t aw[3] = { (uint32_t)A, (uint32_t)(A >> 32), (uint32_t)B };            // bases 0..47 of the window: positions q < 16 need 94 bits
+        const uint32_t rw[3] = { (uint32_t)R0, (uint32_t)(R0 >> 32), (uint32_t)R1 };
 #pragma unroll
         for (int q = 0; q < K1_SEG; q++) {
             if (FIXED) { const bool nb_ = (uint32_t)q >= nrel; nrel = nb_ ? nrel + a.fixed_len : nrel; }
             else if (ntab) while ((uint32_t)q >= nrel && ti + 1u < ntab) { ti++; const uint64_t nx_ = T0 + rtab[ti] - w0; nrel = nx_ < (uint64_t)SPAN ? (uint32_t)nx_ : SPAN; if (nx_ >= (uint64_t)SPAN) break; }
             else while ((uint32_t)q >= nrel && rd + 1 < a.nb_reads) { rd++; const uint64_t nx_ = a.offsets[rd + 1] - w0; nrel = nx_ < (uint64_t)SPAN ? (uint32_t)nx_ : SPAN; if (nx_ >= (uint64_t)SPAN) break; }
-            const uint32_t s1 = 2u * (uint32_t)q, s2 = 2u * (uint32_t)(K1_SEG - 1 - q);     // compile-time after unrolling
-            const uint64_t fwd = (s1 ? ((A >> s1) | (B << (64u - s1))) : A) & cfg.mask;
-            const uint64_t rev = (s2 ? ((R0 >> s2) | (R1 << (64u - s2))) : R0) & cfg.mask;
+            // compile-time shifts < 32 bits after unrolling: each 64-bit extract is two v_alignbit_b32 over the 32-bit window words
+            const uint32_t s1 = 2u * (uint32_t)q, s2 = 2u * (uint32_t)(K1_SEG - 1 - q);
+            static_assert(2 * (K1_SEG - 1) < 32, "funnel shifts stay inside one 32-bit word");
+            const uint64_t fwd = (((uint64_t)__builtin_amdgcn_alignbit(aw[2], aw[1], s1) << 32) | __builtin_amdgcn_alignbit(aw[1], aw[0], s1)) & cfg.mask;
+            const uint64_t rev = (((uint64_t)__builtin_amdgcn_alignbit(rw[2], rw[1], s2) << 32) | __builtin_amdgcn_alignbit(rw[1], rw[0], s2)) & cfg.mask;
             const uint64_t canon = fwd < rev ? fwd : rev;
             const uint64_t key = simka_mix(canon, cfg.mask, cfg.xs);
             const uint32_t b1 = simka_key_l1(key, cfg);
@@ -211,12 +215,17 @@ k_scan(SimkaScanArgs a, SimkaKeyCfg cfg, ull *b1_count, ull *b1_cursor, uint64_t
     __syncthreads();
     // reserve this tile's run in every bucket: one returning global atomic per bucket (B1 <= K1_BLOCK: one per thread).  Its
     // result is only needed by the copy-out, so it stays in a register while the block scans and stages (latency hidden).
-    static_assert(K1_BLOCK >= 1024, "one level-1 bucket per thread");
-    ull gb = 0; uint32_t myh = 0;
-    if (tid < B1) {
-        myh = hist[tid];
-        loff[tid] = myh;
-        if (myh) gb = atomicAdd(&b1_cursor[tid], (ull)myh);
+    constexpr int NBK = (1024 + K1_BLOCK - 1) / K1_BLOCK;       // level-1 buckets per thread (B1 <= 1024)
+    ull gb[NBK]; uint32_t myh[NBK];
+#pragma unroll
+    for (int u = 0; u < NBK; u++) {
+        const uint32_t b = tid + (uint32_t)u * K1_BLOCK;
+        gb[u] = 0; myh[u] = 0;
+        if (b < B1) {
+            myh[u] = hist[b];
+            loff[b] = myh[u];
+            if (myh[u]) gb[u] = atomicAdd(&b1_cursor[b], (ull)myh[u]);
+        }
     }
     __syncthreads();
     const uint32_t total = block_excl_scan<K1_BLOCK>(loff, B1, tmp);
@@ -224,10 +233,14 @@ k_scan(SimkaScanArgs a, SimkaKeyCfg cfg, ull *b1_count, ull *b1_cursor, uint64_t
     for (int q = 0; q < K1_SEG; q++) {
         if (keys[q] != SIMKA_EMPTY_KEY) stage[loff[simka_key_l1(keys[q], cfg)] + ((ranks[q >> 1] >> ((q & 1) * 16)) & 0xffffu)] = keys[q];
     }
-    if (tid < B1) {
-        // capacity-sized buckets (no histogram pass): a run that does not fit flags the sample for the exact path
-        if (b1_limit && myh && gb + myh > b1_limit[tid]) { *ovf_flag = 1u; gb = ~0ull; }
-        gbase[tid] = gb;
+#pragma unroll
+    for (int u = 0; u < NBK; u++) {
+        const uint32_t b = tid + (uint32_t)u * K1_BLOCK;
+        if (b < B1) {
+            // capacity-sized buckets (no histogram pass): a run that does not fit flags the sample for the exact path
+            if (b1_limit && myh[u] && gb[u] + myh[u] > b1_limit[b]) { *ovf_flag = 1u; gb[u] = ~0ull; }
+            gbase[b] = gb[u];
+        }
     }
     __syncthreads();
     // coalesced copy-out: consecutive staged slots of one bucket go to consecutive HBM addresses
