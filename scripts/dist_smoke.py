@@ -1,4 +1,6 @@
-"""1-rank nccl smoke of the sharded protocol used on N GPUs: totals all-reduce -> merge -> head all-reduce (complex-dist)."""
+"""1-rank RCCL smoke of the N-GPU protocols on ONE GPU: (a) partition shards: totals all-reduce -> merge -> head all-reduce;
+(b) sample shards: the whole exchange path (all_to_all_single / all_gather on the nccl backend, rank 0 sending to itself,
+SIMKA_FORCE_EXCHANGE=1) -- both must reproduce the plain single-context statistics bit for bit."""
 import os, sys
 import numpy as np
 import torch
@@ -7,20 +9,31 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import simka_amd
 from simka_amd import dist as sdist, synth
 rank, world, local = int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1)), int(os.environ.get("LOCAL_RANK", 0))
+os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29531")
 torch.cuda.set_device(local)
-dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+dev = torch.device("cuda", local)
+dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 n, R, L, k = 4, 5000, 100, 21
 g = synth.genome_len_for(R, L)
 pool, gw = synth.genome_pool_cpu(g)
-ctx = simka_amd.SimkaContext(n, kmer_size=k, abundance_min=2, simple_dist=True, complex_dist=True, device=local, shard_index=rank, shard_count=world)
+packed = []
 for s in range(n):
     ids, cdf = synth.sample_profile(s)
-    pk = synth.reads_cpu(R, L, pool, gw, g, ids, cdf, synth.sample_seed(s))
-    ctx.count_sample(s, np.concatenate([pk, np.zeros(2, dtype=np.uint64)]), R * L, R, fixed_len=L)
+    packed.append(np.concatenate([synth.reads_cpu(R, L, pool, gw, g, ids, cdf, synth.sample_seed(s)), np.zeros(2, dtype=np.uint64)]))
+kw = dict(kmer_size=k, abundance_min=2, simple_dist=True, complex_dist=True, device=local)
+ctx = simka_amd.SimkaContext(n, shard_index=rank, shard_count=world, **kw)
+for s in range(n):
+    ctx.count_sample(s, packed[s], R * L, R, fixed_len=L)
 sdist.allreduce_totals_device(ctx)
 ctx.merge()
 sdist.allreduce_stats_device(ctx, totals_already_reduced=True)
-st = ctx.stats()
+a = ctx.stats().flat.copy()
+ctx.close()
+os.environ["SIMKA_FORCE_EXCHANGE"] = "1"
+ctx = simka_amd.SimkaContext(n, max_kmers_per_sample=R * (L - k + 1), **kw)
+sdist.count_exchange_merge(ctx, lambda s: ctx.count_sample(s, packed[s], R * L, R, fixed_len=L), n, dev)
+b = ctx.stats().flat.copy()
+ctx.close()
 if rank == 0:
-    print("dist smoke ok", world, int(st.flat[0]), int(st.flat[1]), float(st.matrices()["mat_abundance_jensenshannon"][0, 1]))
+    print("dist smoke", "ok" if (world > 1 or np.array_equal(a, b)) else "MISMATCH", world, int(a[0]), int(b[0]), int(a[1]), int(b[1]))
 dist.barrier(); dist.destroy_process_group()

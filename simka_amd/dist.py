@@ -13,6 +13,8 @@ CPU tests; integer sums, so the result is order-independent):
   directory, ref: src/SimkaMerge.cpp:1164-1264), the merge is rank-local per partition range, and the accumulators are
   all-reduced.  Nothing is replicated; the exchange moves 12 bytes per SOLID k-mer, a small fraction of the counting traffic.
 """
+import os
+
 import numpy as np
 import torch
 import torch.distributed as dist
@@ -188,9 +190,9 @@ def count_exchange_merge(ctx, count_fn, nb_samples, device):
     totals all-gather, one import of the received block."""
     from .api import SampleTotals
     world = dist.get_world_size() if dist.is_initialized() else 1
-    rank = dist.get_rank() if world > 1 else 0
+    rank = dist.get_rank() if dist.is_initialized() else 0
     ctx.reset()
-    if world == 1:
+    if world == 1 and not (dist.is_initialized() and os.environ.get("SIMKA_FORCE_EXCHANGE")):
         for s in range(nb_samples):
             count_fn(s)
         ctx.merge()

@@ -623,3 +623,15 @@ def test_cli_multi_gpu_sample_shards_on_one_device(gpu_required, golden_dir, tmp
 
     assert "reused" not in run(str(tmp_path / "o1"), gpus)
     assert run(str(tmp_path / "o2"), 5 - gpus).count("k-mer spectrum reused") == 5        # other GPU count, same spectra
+
+
+def test_rccl_single_rank_runs_both_multi_gpu_protocols(gpu_required):
+    """scripts/dist_smoke.py: torch.distributed on the real "nccl" (= RCCL) backend with one rank -- the partition-shard protocol
+    and the whole sample-shard exchange (all_to_all_single with uneven splits, all_gather, head all-reduce; rank 0 sends to
+    itself) reproduce the single-context statistics bit for bit, -complex-dist included."""
+    import subprocess
+    env = dict(os.environ, RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT="29533")
+    import sys
+    r = subprocess.run([sys.executable, os.path.join(ROOT_DIR, "scripts", "dist_smoke.py")], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
+                       text=True, timeout=300)
+    assert r.returncode == 0 and "dist smoke ok" in r.stdout, r.stdout[-2000:]
