@@ -635,3 +635,32 @@ def test_rccl_single_rank_runs_both_multi_gpu_protocols(gpu_required):
     r = subprocess.run([sys.executable, os.path.join(ROOT_DIR, "scripts", "dist_smoke.py")], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
                        text=True, timeout=300)
     assert r.returncode == 0 and "dist smoke ok" in r.stdout, r.stdout[-2000:]
+
+
+def test_capacity_errors_are_reported_not_silent(gpu_required):
+    """A solid-spectrum arena / merge buffer that is too small is an error code with a message (the reference would fill the
+    disk), never a silently truncated result; the context stays usable after simka_reset."""
+    import simka_amd
+    R, L, k = 3000, 100, 21
+    packed = _synthetic(3, R, L, seed_shift=40)
+    offs = np.arange(R + 1, dtype=np.uint64) * L
+    inputs = [(np.concatenate([pk, np.zeros(2, dtype=np.uint64)]), offs, R * L, R) for pk in packed]
+
+    def run(ctx):
+        for i, (pk, off, nb, nin) in enumerate(inputs):
+            ctx.count_sample(i, pk, nb, len(off) - 1, offsets=off, nb_input_reads=nin)
+        ctx.merge()
+        return ctx.stats().flat.copy()
+
+    with simka_amd.SimkaContext(3, kmer_size=k, abundance_min=1) as good:
+        ref = run(good)
+    with simka_amd.SimkaContext(3, kmer_size=k, abundance_min=1, solid_capacity=20000) as c:     # ~240k solid k-mers per sample
+        with pytest.raises(simka_amd.api.SimkaError) as e:
+            run(c)
+        assert "arena" in str(e.value)
+    with simka_amd.SimkaContext(3, kmer_size=k, abundance_min=1) as c:
+        assert np.array_equal(run(c), ref)
+        c.reset()
+        assert np.array_equal(run(c), ref)          # a context is reusable run after run
+        with pytest.raises(simka_amd.api.SimkaError):
+            c.count_sample(0, *inputs[0][:1], inputs[0][2], R, offsets=offs)     # after the merge: state error, not a crash
