@@ -44,7 +44,7 @@ struct simka_ctx {
         uint32_t *d_tile_r0 = nullptr; uint64_t tile_r0_cap = 0;  // variable-length reads: first read of every scan tile
         ull *d_l2 = nullptr; uint64_t l2_cap = 0;                 // level-2 partition regions (keys)
         uint32_t *d_p_count = nullptr, *d_p_valid = nullptr;      // [nparts]
-        ull *d_spill_keys = nullptr; uint64_t spill_cap = 0; uint32_t *d_spill_part = nullptr; uint64_t spill_part_cap = 0;
+        ull *d_spill_keys = nullptr; uint64_t spill_cap = 0; SimkaSpillRun *d_spill_runs = nullptr; uint64_t spill_run_cap = 0;
         ull *d_spill_cursor = nullptr;
         uint32_t *d_redo_list = nullptr; ull *d_redo_count = nullptr;   // partitions k_count_fast hands to k_count
     };
@@ -379,7 +379,7 @@ SIMKA_EXPORT void simka_destroy(simka_ctx *ctx) {
     for (auto &L : ctx->lanes) {
         if (L.stream) (void)hipStreamSynchronize(L.stream);
         void *lp[] = { L.d_l1, L.d_b1_count, L.d_b1_start, L.d_b1_end, L.d_b1_cursor, L.d_chunk_first, L.d_tile_r0, L.d_l2, L.d_p_count, L.d_p_valid,
-                       L.d_spill_keys, L.d_spill_part, L.d_spill_cursor, L.d_redo_list, L.d_redo_count };
+                       L.d_spill_keys, L.d_spill_runs, L.d_spill_cursor, L.d_redo_list, L.d_redo_count };
         for (void *q : lp) if (q) (void)hipFree(q);
         if (L.stream) (void)hipStreamDestroy(L.stream);
     }
@@ -526,17 +526,19 @@ static int run_count_kernels(simka_ctx *ctx, uint32_t sample, const SimkaScanArg
     rc = ensure_cap(ctx, &L.d_l2, &L.l2_cap, l2.cap2 * ctx->nparts); if (rc) return rc;
     const uint64_t spill_need = exact ? std::max<uint64_t>(kocc_up, 1) : std::max<uint64_t>((uint64_t)1 << 20, kocc_up / 64);
     rc = ensure_cap(ctx, &L.d_spill_keys, &L.spill_cap, spill_need); if (rc) return rc;
-    rc = ensure_cap(ctx, &L.d_spill_part, &L.spill_part_cap, spill_need); if (rc) return rc;
+    // a run = the keys one 8192-key chunk sends to one partition: at most (#chunks x B2) runs, never more than spilled keys
+    const uint64_t run_need = std::min<uint64_t>(spill_need, (kocc_up / K2_CHUNK + B1 + 1) * (uint64_t)B2);
+    rc = ensure_cap(ctx, &L.d_spill_runs, &L.spill_run_cap, run_need); if (rc) return rc;
     l2.l2_keys = L.d_l2; l2.p_count = L.d_p_count; l2.p_valid = L.d_p_valid;
     // level-2 regions hold 4-byte remainders when the partition bits leave <= 31 of the key (k <= 23 at the usual geometry)
     static const bool wide_only = getenv("SIMKA_WIDE_KEYS") != nullptr;
     l2.rem_bits = key.W - key.pb;
     l2.narrow = (!wide_only && l2.rem_bits <= 31u) ? 1u : 0u;
-    l2.spill_keys = L.d_spill_keys; l2.spill_part = L.d_spill_part; l2.spill_cursor = L.d_spill_cursor;
-    l2.spill_cap = std::min(L.spill_cap, L.spill_part_cap);
+    l2.spill_keys = L.d_spill_keys; l2.spill_runs = L.d_spill_runs; l2.spill_cursor = L.d_spill_cursor;
+    l2.spill_cap = L.spill_cap; l2.spill_run_cap = L.spill_run_cap;
     HIPCHK(hipMemsetAsync(L.d_p_count, 0, ctx->nparts * 4, st));
     HIPCHK(hipMemsetAsync(L.d_p_valid, 0xff, ctx->nparts * 4, st));
-    HIPCHK(hipMemsetAsync(L.d_spill_cursor, 0, 8, st));
+    HIPCHK(hipMemsetAsync(L.d_spill_cursor, 0, 16, st));
     HIPCHK(hipMemsetAsync(L.d_redo_count, 0, 8, st));
     {
         const uint64_t nchunks_max = (exact ? a.nb_bases : L.l1_cap) / K2_CHUNK + B1 + 1;
@@ -585,7 +587,7 @@ static int run_count_kernels(simka_ctx *ctx, uint32_t sample, const SimkaScanArg
             else { if (l2.narrow) go(k_count_fast<K2F_TABLE_BIG, true>); else go(k_count_fast<K2F_TABLE_BIG, false>); }
         }, st);
     }
-    const size_t lds_count = SIMKA_LDS_HEAD + ((size_t)12 << tlog) + hist_lds;
+    const size_t lds_count = SIMKA_LDS_HEAD + ((size_t)12 << tlog) + (size_t)K2C_MATCH * 4 + hist_lds;
     launch_timed(ctx, KID_COUNT, [&] {
         const uint32_t grid_count = slow_only ? (uint32_t)std::min<uint64_t>(ctx->nparts, (uint64_t)ctx->num_cus * 4) : (uint32_t)ctx->num_cus;
         hipLaunchKernelGGL(k_count, dim3(grid_count), dim3(K2C_BLOCK), lds_count, st, key, l2, tlog,

@@ -100,6 +100,10 @@ struct SimkaCountOut {
 };
 
 // level-2 partition regions of one sample (k_split -> k_count)
+// a run of one partition's keys in the spill buffer
+struct SimkaSpillRun { unsigned long long start; uint32_t part, len; };
+#define K2C_MATCH 4096         // k_count: spill runs of one partition listed in LDS (more: the run list is re-scanned every round)
+
 struct SimkaL2 {
     unsigned long long *l2_keys;             // [nparts][cap2]  (u32 remainders when `narrow`)
     uint32_t narrow, rem_bits;               // W - pb <= 31: regions hold the low rem_bits of each key, the partition is implicit
@@ -107,9 +111,9 @@ struct SimkaL2 {
     uint32_t *p_count;                       // [nparts] keys routed to the partition (may exceed cap2: spilled)
     uint32_t *p_valid;                       // [nparts] first overflowing position (0xffffffff: none)
     unsigned long long *spill_keys;          // runs that did not fit their region ...
-    uint32_t *spill_part;                    // ... and their partition
-    unsigned long long *spill_cursor;
-    unsigned long long spill_cap;
+    SimkaSpillRun *spill_runs;               // ... one descriptor per run (k_count reads only the runs of its partition)
+    unsigned long long *spill_cursor;        // [0] keys, [1] runs
+    unsigned long long spill_cap, spill_run_cap;
 };
 
 struct SimkaMergeIn {

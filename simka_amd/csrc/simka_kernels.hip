@@ -404,9 +404,10 @@ k_split(const uint64_t *l1_keys, const ull *b1_start, const ull *b1_end, const u
                     if ((ull)pos + h <= l2.cap2) g = (ull)part * l2.cap2 + pos;
                     else {
                         atomicMin(&l2.p_valid[part], pos);                          // region holds [0,pos) only; the rest is spilled
-                        const ull sp = atomicAdd(l2.spill_cursor, (ull)h);
-                        if (sp + h > l2.spill_cap) { atomicOr(flag, 2u); g = ~0ull; }
-                        else g = (1ull << 63) | sp;
+                        const ull sp = atomicAdd(&l2.spill_cursor[0], (ull)h);
+                        const ull sr = atomicAdd(&l2.spill_cursor[1], 1ull);
+                        if (sp + h > l2.spill_cap || sr >= l2.spill_run_cap) { atomicOr(flag, 2u); g = ~0ull; }
+                        else { SimkaSpillRun run; run.start = sp; run.part = part; run.len = h; l2.spill_runs[sr] = run; g = (1ull << 63) | sp; }
                     }
                 }
                 gpos[b] = g;
@@ -419,7 +420,7 @@ k_split(const uint64_t *l1_keys, const ull *b1_start, const ull *b1_end, const u
             const ull g = gpos[b];
             const uint32_t off = idx - hist[b];
             if (g == ~0ull) continue;
-            if (g >> 63) { const ull sp = (g & ~(1ull << 63)) + off; l2.spill_keys[sp] = key; l2.spill_part[sp] = (b1 << cfg.l2) | b; }
+            if (g >> 63) l2.spill_keys[(g & ~(1ull << 63)) + off] = key;
             else if (NARROW) ((uint32_t *)l2.l2_keys)[g + off] = (uint32_t)key & rem_mask;    // the partition bits are implicit
             else l2.l2_keys[g + off] = key;
         }
@@ -671,7 +672,9 @@ k_count(SimkaKeyCfg cfg, SimkaL2 l2, uint32_t table_log2, uint32_t amin, uint32_
     const uint32_t TS = 1u << table_log2, tmask = TS - 1u;
     ull *tkeys = (ull *)(smem + SIMKA_LDS_HEAD);      // [TS]
     uint32_t *tcnt = (uint32_t *)(tkeys + TS);        // [TS]
-    uint32_t *lhist = tcnt + TS;                      // [SIMKA_HIST_MAX] solid-count histogram (complex only)
+    uint32_t *mlist = tcnt + TS;                      // [K2C_MATCH] spill runs of the current partition
+    uint32_t *lhist = mlist + K2C_MATCH;              // [SIMKA_HIST_MAX] solid-count histogram (complex only)
+    uint32_t &s_nmatch = *(uint32_t *)(smem + 68);
     if (o.hist) for (uint32_t i = threadIdx.x; i < SIMKA_HIST_MAX; i += K2C_BLOCK) lhist[i] = 0;
 
     const uint32_t nparts = 1u << cfg.pb;
@@ -689,12 +692,19 @@ k_count(SimkaKeyCfg cfg, SimkaL2 l2, uint32_t table_log2, uint32_t amin, uint32_
         if (pc == 0) continue;
         const uint32_t pv = l2.p_valid[part];
         const uint32_t nreg = (uint32_t)((ull)(pv < pc ? pv : pc) < l2.cap2 ? (pv < pc ? pv : pc) : (uint32_t)l2.cap2);   // keys in the region
-        const ull nspill = (pc > nreg) ? *l2.spill_cursor : 0ull;                                                     // scan the spill buffer
+        const uint32_t nruns = (pc > nreg) ? (uint32_t)(l2.spill_cursor[1] < l2.spill_run_cap ? l2.spill_cursor[1] : l2.spill_run_cap) : 0u;   // spill runs to look through
         const ull *reg = l2.l2_keys + (ull)part * l2.cap2;
         const uint32_t *reg32 = (const uint32_t *)l2.l2_keys + (ull)part * l2.cap2;       // narrow level-2 keys: remainder only
         const ull khigh = (ull)part << l2.rem_bits;
         __syncthreads();
-        if (tid == 0) { s_nsolid = 0; s_cur = 0; s_ovf = 0; }
+        if (tid == 0) { s_nsolid = 0; s_cur = 0; s_ovf = 0; s_nmatch = 0; }
+        __syncthreads();
+        // the spill runs of this partition, found once (the rounds below re-read only these)
+        for (uint32_t i = tid; i < nruns; i += K2C_BLOCK)
+            if (l2.spill_runs[i].part == part) { const uint32_t m = atomicAdd(&s_nmatch, 1u); if (m < K2C_MATCH) mlist[m] = i; }
+        __syncthreads();
+        const uint32_t nmatch_all = s_nmatch;
+        const bool listed = nmatch_all <= K2C_MATCH;
 
         uint32_t nr_log2 = 0;
         ull emit_base = 0;
@@ -728,11 +738,14 @@ k_count(SimkaKeyCfg cfg, SimkaL2 l2, uint32_t table_log2, uint32_t amin, uint32_
                         if (!table_insert(tkeys, tcnt, tmask, key)) s_ovf = 1;
                     }
                 }
-                for (ull i = tid; i < nspill; i += K2C_BLOCK) {
-                    if (l2.spill_part[i] != part) continue;
-                    const ull key = l2.spill_keys[i];
-                    if (nr_log2 && (uint32_t)((key >> rsh) & ((1ull << nr_log2) - 1ull)) != r) continue;
-                    if (!table_insert(tkeys, tcnt, tmask, key)) s_ovf = 1;
+                for (uint32_t m = 0; m < (listed ? nmatch_all : nruns); m++) {
+                    const SimkaSpillRun run = l2.spill_runs[listed ? mlist[m] : m];
+                    if (run.part != part) continue;                       // (unlisted: every run is looked at)
+                    for (uint32_t j = tid; j < run.len; j += K2C_BLOCK) {
+                        const ull key = l2.spill_keys[run.start + j];
+                        if (nr_log2 && (uint32_t)((key >> rsh) & ((1ull << nr_log2) - 1ull)) != r) continue;
+                        if (!table_insert(tkeys, tcnt, tmask, key)) s_ovf = 1;
+                    }
                 }
                 __syncthreads();
                 if (s_ovf) { restart = true; break; }

@@ -664,3 +664,25 @@ def test_capacity_errors_are_reported_not_silent(gpu_required):
         assert np.array_equal(run(c), ref)          # a context is reusable run after run
         with pytest.raises(simka_amd.api.SimkaError):
             c.count_sample(0, *inputs[0][:1], inputs[0][2], R, offsets=offs)     # after the merge: state error, not a crash
+
+
+@pytest.mark.parametrize("copies,pb", [(3000, 8), (3000, 11), (5500, 6)])
+def test_hot_reads_overflow_regions_into_spill_runs(gpu_required, oracle_mod, copies, pb):
+    """Adapter-like input: half (or nearly all) of a sample's reads are copies of ONE read, so ~80 k-mers carry thousands of
+    occurrences each and overflow their capacity-sized level-2 regions.  The excess goes to the spill buffer as runs; k_count
+    finds the runs of its partition through the run list.  Exact vs the oracle, next to an ordinary sample."""
+    import simka_amd
+    from simka_amd import synth
+    R, L, k = 6000, 100, 21
+    packed = _synthetic(2, R, L, seed_shift=60)
+    a = synth.unpack_ascii(packed[0], R * L).reshape(R, L).copy()
+    a[100:100 + copies] = a[7]
+    hot, off, nb, _ = simka_amd.pack_reads([row.tobytes() for row in a])
+    offs = np.arange(R + 1, dtype=np.uint64) * L
+    inputs = [(hot, off, nb, R), (np.concatenate([packed[1], np.zeros(2, dtype=np.uint64)]), offs, R * L, R)]
+    totals, st = _run_gpu(inputs, k, 2, log2_partitions=pb)
+    orc = oracle_mod.Oracle()
+    orc.add_sample_ascii("hot", a.reshape(-1), offs)
+    orc.add_sample_ascii("plain", synth.unpack_ascii(packed[1], R * L), offs)
+    orc.run(k, 2, simple=True, complex_=True)
+    _check_vs_oracle(totals, st, orc)
