@@ -539,7 +539,7 @@ static int run_count_kernels(simka_ctx *ctx, uint32_t sample, const SimkaScanArg
     HIPCHK(hipMemsetAsync(L.d_p_count, 0, ctx->nparts * 4, st));
     HIPCHK(hipMemsetAsync(L.d_p_valid, 0xff, ctx->nparts * 4, st));
     HIPCHK(hipMemsetAsync(L.d_spill_cursor, 0, 16, st));
-    HIPCHK(hipMemsetAsync(L.d_redo_count, 0, 8, st));
+    HIPCHK(hipMemsetAsync(L.d_redo_count, 0, 16, st));
     {
         const uint64_t nchunks_max = (exact ? a.nb_bases : L.l1_cap) / K2_CHUNK + B1 + 1;
         const size_t lds_split = SIMKA_LDS_HEAD + (size_t)B2 * 12 + 64 + (size_t)K2_CHUNK * 8;
@@ -575,16 +575,18 @@ static int run_count_kernels(simka_ctx *ctx, uint32_t sample, const SimkaScanArg
     const size_t hist_lds = ctx->d_hist ? (size_t)SIMKA_HIST_MAX * 4 : 0;
     if (!slow_only) {
         const bool small = ctx->small_table == 1;
-        const size_t lds_fast = SIMKA_LDS_HEAD + (size_t)(small ? K2F_TABLE_SMALL : K2F_TABLE_BIG) * (l2.narrow ? 8 : 12) + (size_t)K2F_BLOCK * 4 + hist_lds;
-        const uint32_t bpc_f = (uint32_t)std::min<size_t>(4, (160 * 1024) / lds_fast);
-        const dim3 gridf((uint32_t)std::min<uint64_t>(ctx->nparts, (uint64_t)ctx->num_cus * bpc_f));
+        // the table size chosen for the run (from the first sample); partitions it cannot hold (more distinct keys than slots:
+        // a key gives up after K2F_PROBES probes) and spilled partitions go to the general kernel through the redo list
         launch_timed(ctx, KID_COUNT_FAST, [&] {
-            auto go = [&](auto kern) {
-                hipLaunchKernelGGL(kern, gridf, dim3(K2F_BLOCK), lds_fast, st, key, l2, ctx->cfg.abundance_min, ctx->cfg.abundance_max, o, flag,
-                                   L.d_redo_list, L.d_redo_count);
+            auto go = [&](auto kern, size_t lds) {
+                const uint32_t bpc = (uint32_t)std::min<size_t>(4, (160 * 1024) / lds);
+                hipLaunchKernelGGL(kern, dim3((uint32_t)std::min<uint64_t>(ctx->nparts, (uint64_t)ctx->num_cus * bpc)), dim3(K2F_BLOCK), lds, st, key, l2,
+                                   ctx->cfg.abundance_min, ctx->cfg.abundance_max, o, flag, L.d_redo_list, L.d_redo_count);
             };
-            if (small) { if (l2.narrow) go(k_count_fast<K2F_TABLE_SMALL, true>); else go(k_count_fast<K2F_TABLE_SMALL, false>); }
-            else { if (l2.narrow) go(k_count_fast<K2F_TABLE_BIG, true>); else go(k_count_fast<K2F_TABLE_BIG, false>); }
+            const size_t lds_small = SIMKA_LDS_HEAD + (size_t)K2F_TABLE_SMALL * (l2.narrow ? 8 : 12) + (size_t)K2F_BLOCK * 4 + hist_lds;
+            const size_t lds_big = SIMKA_LDS_HEAD + (size_t)K2F_TABLE_BIG * (l2.narrow ? 8 : 12) + (size_t)K2F_BLOCK * 4 + hist_lds;
+            if (small) { if (l2.narrow) go(k_count_fast<K2F_TABLE_SMALL, true>, lds_small); else go(k_count_fast<K2F_TABLE_SMALL, false>, lds_small); }
+            else { if (l2.narrow) go(k_count_fast<K2F_TABLE_BIG, true>, lds_big); else go(k_count_fast<K2F_TABLE_BIG, false>, lds_big); }
         }, st);
     }
     const size_t lds_count = SIMKA_LDS_HEAD + ((size_t)12 << tlog) + (size_t)K2C_MATCH * 4 + hist_lds;

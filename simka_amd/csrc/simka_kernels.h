@@ -14,13 +14,14 @@
 #define K2_BLOCK 1024         // k_split
 #define K2C_BLOCK 256         // k_count
 #define K2_CHUNK 8192         // keys per chunk (fits u16 offsets, 64 KB LDS stage)
-#define K2_TABLE_LOG2 11      // LDS hash-table slots per partition: 4096 (32 KB keys + 16 KB counts) -> 3 blocks/CU
+#define K2_TABLE_LOG2 13      // k_count (general kernel, one block per CU): 8192 slots -- a partition the fast tables could not hold fits in one round
 #define K2_TABLE (1 << K2_TABLE_LOG2)
 #define K2_MAXSEG_UNUSED 512         // chunk segments gathered per batch in k_count
 // k_count_fast
 #define K2F_BLOCK 512
 #define K2F_TABLE_BIG 4096    // slots (48 KB): safe even if every k-mer of a partition is distinct
 #define K2F_TABLE_SMALL 2048  // slots (24 KB): when the first sample shows mostly repeated k-mers (high coverage)
+#define K2F_PROBES 128         // k_count_fast: probes before a key gives up (table too small -> next kernel of the cascade)
 #define K2F_UNROLL 8          // keys prefetched per thread: partitions up to BLOCK*UNROLL = 4096 keys take the fast path
 #define K2_SLAB 512           // arena records reserved per global atomic by a k_count block
 #ifndef K2_UNROLL

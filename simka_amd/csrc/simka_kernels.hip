@@ -463,6 +463,21 @@ __device__ __forceinline__ bool table_insert(uint32_t *tkeys, uint32_t *tcnt, ui
     return false;
 }
 
+// fast path: give up after K2F_PROBES slots -- the table is (nearly) full, the partition goes to the general kernel
+template <typename KT>
+__device__ __forceinline__ bool table_insert_capped(KT *tkeys, uint32_t *tcnt, uint32_t tmask, KT key) {
+    constexpr KT EMPTY = (KT)~(KT)0;
+    uint32_t slot;
+    if (sizeof(KT) == 4) slot = (((uint32_t)key * 0x9E3779B1u) >> 16) & tmask; else slot = simka_slot_hash((ull)key) & tmask;
+#pragma unroll 4
+    for (uint32_t probe = 0; probe < K2F_PROBES; probe++) {
+        const KT prev = atomicCAS(&tkeys[slot], EMPTY, key);
+        if (prev == EMPTY || prev == key) { atomicAdd(&tcnt[slot], 1u); return true; }
+        slot = (slot + 1u) & tmask;
+    }
+    return false;
+}
+
 // reserve `ns` arena records for one partition out of the block's private slab (thread 0 only)
 __device__ __forceinline__ ull slab_take(ull &slab_pos, ull &slab_end, uint32_t ns, const SimkaCountOut &o, ull sample_base, uint32_t &ok) {
     if (slab_pos + ns > slab_end) {
@@ -503,6 +518,7 @@ k_count_fast(SimkaKeyCfg cfg, SimkaL2 l2, uint32_t amin, uint32_t amax, SimkaCou
     ull *s_tot = (ull *)smem;                         // [4]
     ull &s_base = *(ull *)(smem + 32);
     uint32_t &s_ok = *(uint32_t *)(smem + 56);
+    uint32_t &s_fail = *(uint32_t *)(smem + 60);
     ull *s_slab = (ull *)(smem + 64);                 // [2][2] (pos, end) of the block's arena slab, double-buffered by iteration parity
     uint32_t *tmp = (uint32_t *)(smem + 128);         // [K2F_BLOCK/64]
     constexpr uint32_t tmask = TS - 1u, SPT = TS / K2F_BLOCK;   // slots per thread
@@ -524,6 +540,7 @@ k_count_fast(SimkaKeyCfg cfg, SimkaL2 l2, uint32_t amin, uint32_t amax, SimkaCou
     }
     if (o.hist) for (uint32_t i = tid; i < SIMKA_HIST_MAX; i += K2F_BLOCK) lhist[i] = 0;
     if (tid < 4) { s_tot[tid] = 0; s_slab[tid] = 0; }
+    if (tid == 0) s_fail = 0u;
     uint32_t iter = 0;
     ull bt_dall = 0, bt_D = 0, bt_N = 0, bt_Q = 0;
 
@@ -558,13 +575,15 @@ k_count_fast(SimkaKeyCfg cfg, SimkaL2 l2, uint32_t amin, uint32_t amax, SimkaCou
         }
         // ---- insert the prefetched keys
         PH(0) PH_WAITVM PH(1)
+        bool placed = true;
 #pragma unroll
         for (int u = 0; u < K2F_UNROLL; u++) {
             const KT key = kk[u];
-            if (key != KEMPTY) table_insert(tkeys, tcnt, tmask, key);
+            if (key != KEMPTY) placed &= table_insert_capped<KT>(tkeys, tcnt, tmask, key);
         }
         for (uint32_t i = K2F_BLOCK * K2F_UNROLL + tid; i < n; i += K2F_BLOCK)      // beyond the prefetch window (rare)
-            table_insert(tkeys, tcnt, tmask, l2k[(ull)part * l2.cap2 + i]);
+            placed &= table_insert_capped<KT>(tkeys, tcnt, tmask, l2k[(ull)part * l2.cap2 + i]);
+        if (!placed) s_fail = 1u;           // a key found no slot within K2F_PROBES: the table is too small for this partition
         PH(2)
         __syncthreads();
         PH(3)
@@ -588,7 +607,7 @@ k_count_fast(SimkaKeyCfg cfg, SimkaL2 l2, uint32_t amin, uint32_t amax, SimkaCou
         const uint32_t tot = block_excl_scan<K2F_BLOCK>(spos, K2F_BLOCK, tmp);
         PH(5)
         const uint32_t total = tot & 0xffffu, dall_tot = tot >> 16;
-        const bool ovf = dall_tot > (TS * 7u) / 8u;       // (nearly) full: probing may have dropped keys -> redo in rounds
+        const bool ovf = dall_tot > (TS * 7u) / 8u || s_fail != 0u;     // (nearly) full or keys dropped -> the general kernel
         // arena space for the solid records: the block's slab state is double-buffered in LDS, so in the common case (the
         // run fits the current slab) every thread derives the base itself and no barrier is needed before the emit
         const uint32_t par = iter & 1u;
@@ -634,6 +653,7 @@ k_count_fast(SimkaKeyCfg cfg, SimkaL2 l2, uint32_t amin, uint32_t amax, SimkaCou
             }
         }
         PH(7)
+        if (ovf) { __syncthreads(); if (tid == 0) s_fail = 0u; }      // (uniform) everyone has read the flag
         part = next; n = n_next; fastp = fast_next;
     }
     PH_FLUSH
