@@ -57,7 +57,7 @@ struct simka_ctx {
     uint64_t nb_exact_fallbacks = 0;
     int small_table = -1;                                     // -1 undecided, else use K2F_TABLE_SMALL in k_count_fast
     uint32_t nb_counted_this_run = 0;
-    struct Pending { uint32_t sample; SimkaScanArgs a; };     // device-resident samples whose flag has not been read yet
+    struct Pending { uint32_t sample; SimkaScanArgs a; uint32_t pass = 0, npass = 1; };     // device-resident samples whose flag has not been read yet
     std::vector<Pending> pending;
     // solid spectra of all samples
     ull *d_solid_keys = nullptr; uint32_t *d_solid_counts = nullptr; uint64_t arena_cap = 0;
@@ -451,15 +451,20 @@ static int ensure_cap(simka_ctx *ctx, T **p, uint64_t *cap, uint64_t need) {
 
 // enqueue the count-side kernels of one sample.  exact=false: capacity-sized level-1 buckets, no histogram pass; the
 // kernels after the scatter skip themselves if it flags an overflow, and resolve_pending() redoes the sample exactly.
-static int run_count_kernels(simka_ctx *ctx, uint32_t sample, const SimkaScanArgs &a_in, bool exact) {
+static int run_count_kernels(simka_ctx *ctx, uint32_t sample, const SimkaScanArgs &a_in, bool exact, uint32_t pass = 0, uint32_t npass = 1) {
     const uint32_t N = ctx->cfg.nb_samples;
     simka_ctx::Lane &L = ctx->lanes[sample % ctx->nlanes];
     const hipStream_t st = L.stream;
     int rc;
     SimkaScanArgs a = a_in;
     a.tile_r0 = nullptr;
-    const SimkaKeyCfg key = ctx->key;
+    // A sample too deep for the scratch buffers is counted in `npass` passes over its reads; pass j keeps the level-1 buckets
+    // b with b % (shards * npass) == shard + shards * j, i.e. it behaves like one of shards * npass partition shards.
+    SimkaKeyCfg key = ctx->key;
+    if (npass > 1) { key.shard_index = ctx->key.shard_index + ctx->key.shard_count * pass; key.shard_count = ctx->key.shard_count * npass; }
     const uint32_t B1 = ctx->B1, B2 = ctx->B2;
+    const uint32_t own_b1 = (B1 + key.shard_count - 1) / key.shard_count;       // level-1 buckets this shard / pass owns (at most)
+    const uint32_t later = pass ? 4u : 0u;                                      // k_layout: occurrences add up, arena base stays
     ull *kocc = (ull *)ctx->d_stats + stats_off_tot(N, ctx->cfg.dist_flags, SIMKA_TOT_KOCC) + sample;
     const uint64_t tile = (uint64_t)K1_BLOCK * K1_SEG;
     const uint32_t grid1 = (uint32_t)((a.nb_bases + tile - 1) / tile);
@@ -477,33 +482,33 @@ static int run_count_kernels(simka_ctx *ctx, uint32_t sample, const SimkaScanArg
     auto layout = [&](uint32_t mode, ull capb) {
         launch_timed(ctx, KID_LAYOUT, [&] {
             hipLaunchKernelGGL(k_layout, dim3(1), dim3(256), lds_lay, st, L.d_b1_count, L.d_b1_start, L.d_b1_end,
-                               L.d_b1_cursor, L.d_chunk_first, B1, ctx->d_arena_cursor, ctx->d_sample_base + sample, mode, capb,
-                               kocc, skip);
+                               L.d_b1_cursor, L.d_chunk_first, B1, ctx->d_arena_cursor, ctx->d_sample_base + sample, mode | later, capb,
+                               kocc, skip, key);
         }, st);
     };
     // Level-1 buckets.  Keys are hash-partitioned, so bucket sizes concentrate around K_occ/B1: size every bucket for that
     // (+10 % + slack) and scatter directly.  Only if a bucket overflows (heavy repeats) is the sample redone with the exact
     // histogram -> scan -> scatter sequence.
     static const bool force_exact = getenv("SIMKA_EXACT_SIZING") != nullptr;
-    const bool sharded = ctx->cfg.shard_count > 1;
+    const bool sharded = key.shard_count > 1;
     if (force_exact) exact = true;
     uint64_t max_chunks;
     if (!exact) {
         const uint64_t kocc_upper = a.fixed_len ? (a.fixed_len >= key.k ? a.nb_reads * (uint64_t)(a.fixed_len - key.k + 1) : 0) : a.nb_bases;
         const uint64_t per_bucket = kocc_upper / B1;
         const uint64_t capb = per_bucket + per_bucket / 10 + 2048;
-        rc = ensure_cap(ctx, &L.d_l1, &L.l1_cap, capb * B1); if (rc) return rc;
-        max_chunks = (capb * B1) / K2_CHUNK + B1 + 1;
+        rc = ensure_cap(ctx, &L.d_l1, &L.l1_cap, capb * own_b1); if (rc) return rc;      // owned buckets only, packed by rank
+        max_chunks = (capb * own_b1) / K2_CHUNK + B1 + 1;
         layout(1, capb);
         launch_timed(ctx, KID_SCAN_SCATTER, [&] {
             hipLaunchKernelGGL(scan_kernel(true, a.fixed_len != 0, sharded), dim3(grid1), dim3(K1_BLOCK), lds_scat, st, a, key, L.d_b1_count,
                                L.d_b1_cursor, L.d_l1, kocc, (const ull *)L.d_b1_end, flag);
         }, st);
         layout(2, capb);
-        simka_ctx::Pending p; p.sample = sample; p.a = a;
+        simka_ctx::Pending p; p.sample = sample; p.a = a; p.pass = pass; p.npass = npass;
         ctx->pending.push_back(p);
     } else {
-        rc = ensure_cap(ctx, &L.d_l1, &L.l1_cap, a.nb_bases); if (rc) return rc;
+        if (!sharded) { rc = ensure_cap(ctx, &L.d_l1, &L.l1_cap, a.nb_bases); if (rc) return rc; }
         max_chunks = a.nb_bases / K2_CHUNK + B1 + 1;
         HIPCHK(hipMemsetAsync(L.d_b1_count, 0, (B1 + 1) * 8, st));
         launch_timed(ctx, KID_SCAN_HIST, [&] {
@@ -511,6 +516,12 @@ static int run_count_kernels(simka_ctx *ctx, uint32_t sample, const SimkaScanArg
                                L.d_b1_cursor, L.d_l1, kocc, (const ull *)nullptr, (uint32_t *)nullptr);
         }, st);
         layout(0, 0);
+        if (sharded) {   // this shard's share of the keys is known only now: size the bucket buffer from the chunk count (rare path)
+            uint32_t nch = 0;
+            HIPCHK(hipMemcpyAsync(&nch, L.d_chunk_first + B1, 4, hipMemcpyDeviceToHost, st));
+            HIPCHK(hipStreamSynchronize(st));
+            rc = ensure_cap(ctx, &L.d_l1, &L.l1_cap, (uint64_t)nch * K2_CHUNK + 1); if (rc) return rc;
+        }
         launch_timed(ctx, KID_SCAN_SCATTER, [&] {
             hipLaunchKernelGGL(scan_kernel(true, a.fixed_len != 0, sharded), dim3(grid1), dim3(K1_BLOCK), lds_scat, st, a, key, L.d_b1_count,
                                L.d_b1_cursor, L.d_l1, kocc, (const ull *)nullptr, (uint32_t *)nullptr);
@@ -519,12 +530,13 @@ static int run_count_kernels(simka_ctx *ctx, uint32_t sample, const SimkaScanArg
     (void)max_chunks;
     // ---- level 2: partition-contiguous regions, capacity-sized, + spill buffer
     const uint64_t kocc_up = a.fixed_len ? (a.fixed_len >= key.k ? a.nb_reads * (uint64_t)(a.fixed_len - key.k + 1) : 0) : a.nb_bases;
-    const uint64_t owned_parts = std::max<uint64_t>(1, ctx->nparts / std::min<uint64_t>(ctx->cfg.shard_count, B1));
-    const uint64_t mean2 = kocc_up / owned_parts;
+    // every owned partition receives ~K_occ / nparts keys; regions exist for the owned partitions only (simka_region_index)
+    const uint64_t mean2 = kocc_up / ctx->nparts;
     SimkaL2 l2;
     l2.cap2 = mean2 + mean2 / 2 + 256;
-    rc = ensure_cap(ctx, &L.d_l2, &L.l2_cap, l2.cap2 * ctx->nparts); if (rc) return rc;
-    const uint64_t spill_need = exact ? std::max<uint64_t>(kocc_up, 1) : std::max<uint64_t>((uint64_t)1 << 20, kocc_up / 64);
+    rc = ensure_cap(ctx, &L.d_l2, &L.l2_cap, l2.cap2 * own_b1 * B2); if (rc) return rc;
+    const uint64_t spill_need = exact ? std::max<uint64_t>(sharded ? std::min<uint64_t>(kocc_up, 2 * (kocc_up / key.shard_count) + ((uint64_t)1 << 20)) : kocc_up, 1)
+                                      : std::max<uint64_t>((uint64_t)1 << 20, kocc_up / 64);
     rc = ensure_cap(ctx, &L.d_spill_keys, &L.spill_cap, spill_need); if (rc) return rc;
     // a run = the keys one 8192-key chunk sends to one partition: at most (#chunks x B2) runs, never more than spilled keys
     const uint64_t run_need = std::min<uint64_t>(spill_need, (kocc_up / K2_CHUNK + B1 + 1) * (uint64_t)B2);
@@ -617,7 +629,7 @@ static int resolve_pending(simka_ctx *ctx) {
         ctx->nb_exact_fallbacks++;
         HIPCHK(hipMemsetAsync(ctx->d_l1_ovf + p.sample, 0, 4, ctx->stream));
         HIPCHK(hipStreamSynchronize(ctx->stream));
-        int rc = run_count_kernels(ctx, p.sample, p.a, true);
+        int rc = run_count_kernels(ctx, p.sample, p.a, true, p.pass, p.npass);
         if (rc) return rc;
     }
     for (uint32_t li = 0; li < ctx->nlanes; li++) HIPCHK(hipStreamSynchronize(ctx->lanes[li].stream));
@@ -661,8 +673,27 @@ SIMKA_EXPORT int simka_count_sample(simka_ctx *ctx, uint32_t sample, const simka
         }
         HIPCHK(hipStreamSynchronize(ctx->stream));   // the host buffers may be reused by the caller right away
     }
-    rc = run_count_kernels(ctx, sample, a, false);
-    if (rc) return rc;
+    // scratch per k-mer occurrence: 8.8 B of level-1 buckets + 6..12 B of level-2 regions.  A sample whose share does not fit
+    // a third of the device is counted in several passes over its reads, each keeping a subset of the level-1 buckets.
+    uint32_t npass = 1;
+    {
+        static const char *force = getenv("SIMKA_FORCE_PASSES");          // tests
+        const uint32_t max_pass = std::max<uint32_t>(1, ctx->B1 / std::max<uint32_t>(1, ctx->cfg.shard_count));
+        if (force) npass = (uint32_t)atoi(force);
+        else {
+            size_t fr = 0, tot = 0;
+            HIPCHK(hipMemGetInfo(&fr, &tot));
+            const uint64_t kocc_up = r->fixed_len ? r->nb_reads * (uint64_t)r->fixed_len : r->nb_bases;
+            const double need = (double)kocc_up * 21.0 / std::max<uint32_t>(1, ctx->cfg.shard_count);
+            while (need / npass > 0.30 * (double)tot && npass < max_pass) npass *= 2;
+        }
+        npass = std::max<uint32_t>(1, std::min(npass, max_pass));
+    }
+    for (uint32_t j = 0; j < npass; j++) {
+        rc = run_count_kernels(ctx, sample, a, false, j, npass);
+        if (rc) return rc;
+        if (npass > 1) { rc = resolve_pending(ctx); if (rc) return rc; }       // the passes share the scratch buffers
+    }
     if (ctx->nb_counted_this_run++ == 0 && ctx->cfg.nb_samples > 1) {
         // table size of k_count_fast for the rest of the run, from this sample's distinct ratio (one sync per run)
         rc = resolve_pending(ctx); if (rc) return rc;

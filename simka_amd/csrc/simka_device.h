@@ -62,6 +62,19 @@ SIMKA_HD bool simka_owns_l1(uint32_t b1, const SimkaKeyCfg &c) {
     return (b1 % c.shard_count) == c.shard_index;
 }
 
+// rank of an OWNED level-1 bucket among the buckets of its shard (b1 = shard_index + rank * shard_count), and of an owned
+// partition among the shard's partitions: level-1 buckets and level-2 regions are laid out by these, so a shard (or one pass
+// over a sample that is counted in several passes) allocates only its share
+SIMKA_HD uint32_t simka_bucket_rank(uint32_t b1, const SimkaKeyCfg &c) {
+    if (c.shard_count == 1u) return b1;
+    if ((c.shard_count & (c.shard_count - 1u)) == 0u) return b1 >> (31u - __builtin_clz(c.shard_count));
+    return b1 / c.shard_count;
+}
+SIMKA_HD uint64_t simka_region_index(uint32_t part, const SimkaKeyCfg &c) {
+    if (c.shard_count == 1u) return part;
+    return ((uint64_t)simka_bucket_rank(part >> c.l2, c) << c.l2) | (part & ((1u << c.l2) - 1u));
+}
+
 // floor(sqrt(x)) exactly, x < 2^64.  The reference adds sqrt((double)(ci*cj)) to a u64, i.e.
 // floor of the correctly-rounded double sqrt (ref: src/core/SimkaAlgorithm.hpp:397), which equals
 // this for x < 2^52.

@@ -266,13 +266,21 @@ k_scan(SimkaScanArgs a, SimkaKeyCfg cfg, ull *b1_count, ull *b1_cursor, uint64_t
 // --------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256)
 k_layout(const ull *b1_count, ull *b1_start, ull *b1_end, ull *b1_cursor, uint32_t *chunk_first, uint32_t B1, ull *arena_cursor,
-         ull *sample_base, uint32_t mode, ull cap, ull *kocc, const uint32_t *skip_flag) {
+         ull *sample_base, uint32_t mode_flags, ull cap, ull *kocc, const uint32_t *skip_flag, SimkaKeyCfg cfg) {
+    // mode_flags bit 2: a later pass over the same sample (its occurrences add up, its arena base stays)
+    const uint32_t mode = mode_flags & 3u;
+    const bool later_pass = (mode_flags & 4u) != 0u;
     if (mode == 2 && skip_flag && *skip_flag) return;      // the capacity-mode scatter overflowed: the sample is redone exactly
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     ull *cnt = (ull *)(smem + SIMKA_LDS_HEAD);   // [B1]
     if (mode == 1) {
-        for (uint32_t b = threadIdx.x; b < B1; b += blockDim.x) { b1_start[b] = (ull)b * cap; b1_cursor[b] = (ull)b * cap; b1_end[b] = (ull)(b + 1) * cap; }
-        if (threadIdx.x == 0) *sample_base = *arena_cursor;
+        // owned buckets get `cap` keys each, packed by their rank inside the shard; the others stay empty
+        for (uint32_t b = threadIdx.x; b < B1; b += blockDim.x) {
+            const bool own = simka_owns_l1(b, cfg);
+            const ull st = (ull)simka_bucket_rank(b, cfg) * cap;
+            b1_start[b] = own ? st : 0ull; b1_cursor[b] = own ? st : 0ull; b1_end[b] = own ? st + cap : 0ull;
+        }
+        if (threadIdx.x == 0 && !later_pass) *sample_base = *arena_cursor;
         return;
     }
     // exclusive scans of the bucket sizes (mode 0: starts) and of the chunk counts, 256 threads
@@ -306,8 +314,8 @@ k_layout(const ull *b1_count, ull *b1_start, ull *b1_end, ull *b1_cursor, uint32
     for (uint32_t b = tid; b < B1; b += 256) chunk_first[b] = csz[b];
     if (tid == 0) {
         chunk_first[B1] = nchunks;
-        *kocc = total;                                 // k-mer occurrences of this shard = sum of its bucket sizes
-        if (mode == 0) *sample_base = *arena_cursor;   // where this sample's solid records start in the arena
+        *kocc = (later_pass ? *kocc : 0ull) + total;   // k-mer occurrences of this shard = sum of its bucket sizes
+        if (mode == 0 && !later_pass) *sample_base = *arena_cursor;   // where this sample's solid records start in the arena
     }
 }
 
@@ -401,7 +409,7 @@ k_split(const uint64_t *l1_keys, const ull *b1_start, const ull *b1_end, const u
                 ull g = 0;
                 if (h) {
                     const uint32_t part = (b1 << cfg.l2) | b;
-                    if ((ull)pos + h <= l2.cap2) g = (ull)part * l2.cap2 + pos;
+                    if ((ull)pos + h <= l2.cap2) g = simka_region_index(part, cfg) * l2.cap2 + pos;
                     else {
                         atomicMin(&l2.p_valid[part], pos);                          // region holds [0,pos) only; the rest is spilled
                         const ull sp = atomicAdd(&l2.spill_cursor[0], (ull)h);
@@ -546,11 +554,12 @@ k_count_fast(SimkaKeyCfg cfg, SimkaL2 l2, uint32_t amin, uint32_t amax, SimkaCou
 
     KT kk[K2F_UNROLL];
     // issue the loads of partition p (n keys) -- only partitions the fast path can take in one batch
-#define K2F_LOAD(p, n)                                                                        \
+#define K2F_LOAD(p, n) {                                                                      \
+    const ull rb_ = simka_region_index(p, cfg) * l2.cap2;                                     \
     _Pragma("unroll") for (int u = 0; u < K2F_UNROLL; u++) {                                  \
         const uint32_t i = tid + (uint32_t)u * K2F_BLOCK;                                     \
-        kk[u] = (i < (n)) ? l2k[(ull)(p) * l2.cap2 + i] : KEMPTY;                             \
-    }
+        kk[u] = (i < (n)) ? l2k[rb_ + i] : KEMPTY;                                            \
+    } }
     uint32_t part = blockIdx.x;
     uint32_t n = 0, n_ahead = 0;            // key counts of this partition and of the next one: loaded one iteration early
     bool fastp = false;
@@ -582,7 +591,7 @@ k_count_fast(SimkaKeyCfg cfg, SimkaL2 l2, uint32_t amin, uint32_t amax, SimkaCou
             if (key != KEMPTY) placed &= table_insert_capped<KT>(tkeys, tcnt, tmask, key);
         }
         for (uint32_t i = K2F_BLOCK * K2F_UNROLL + tid; i < n; i += K2F_BLOCK)      // beyond the prefetch window (rare)
-            placed &= table_insert_capped<KT>(tkeys, tcnt, tmask, l2k[(ull)part * l2.cap2 + i]);
+            placed &= table_insert_capped<KT>(tkeys, tcnt, tmask, l2k[simka_region_index(part, cfg) * l2.cap2 + i]);
         if (!placed) s_fail = 1u;           // a key found no slot within K2F_PROBES: the table is too small for this partition
         PH(2)
         __syncthreads();
@@ -713,8 +722,8 @@ k_count(SimkaKeyCfg cfg, SimkaL2 l2, uint32_t table_log2, uint32_t amin, uint32_
         const uint32_t pv = l2.p_valid[part];
         const uint32_t nreg = (uint32_t)((ull)(pv < pc ? pv : pc) < l2.cap2 ? (pv < pc ? pv : pc) : (uint32_t)l2.cap2);   // keys in the region
         const uint32_t nruns = (pc > nreg) ? (uint32_t)(l2.spill_cursor[1] < l2.spill_run_cap ? l2.spill_cursor[1] : l2.spill_run_cap) : 0u;   // spill runs to look through
-        const ull *reg = l2.l2_keys + (ull)part * l2.cap2;
-        const uint32_t *reg32 = (const uint32_t *)l2.l2_keys + (ull)part * l2.cap2;       // narrow level-2 keys: remainder only
+        const ull *reg = l2.l2_keys + simka_region_index(part, cfg) * l2.cap2;
+        const uint32_t *reg32 = (const uint32_t *)l2.l2_keys + simka_region_index(part, cfg) * l2.cap2;       // narrow level-2 keys: remainder only
         const ull khigh = (ull)part << l2.rem_bits;
         __syncthreads();
         if (tid == 0) { s_nsolid = 0; s_cur = 0; s_ovf = 0; s_nmatch = 0; }

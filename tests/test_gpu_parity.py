@@ -686,3 +686,23 @@ def test_hot_reads_overflow_regions_into_spill_runs(gpu_required, oracle_mod, co
     orc.add_sample_ascii("plain", synth.unpack_ascii(packed[1], R * L), offs)
     orc.run(k, 2, simple=True, complex_=True)
     _check_vs_oracle(totals, st, orc)
+
+
+def test_deep_samples_counted_in_passes(gpu_required):
+    """A sample too deep for the scratch buffers is counted in several passes over its reads, each keeping a subset of the
+    level-1 buckets (SIMKA_FORCE_PASSES forces that here).  Same statistics bit for bit as one pass -- including a sample whose
+    poly-A third overflows a level-1 bucket, so one of the passes is redone with exact sizing."""
+    import subprocess, sys
+
+    def digest(passes):
+        env = dict(os.environ)
+        if passes:
+            env["SIMKA_FORCE_PASSES"] = str(passes)
+        r = subprocess.run([sys.executable, os.path.join(ROOT_DIR, "tests", "flat_digest.py")], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=300)
+        lines = [l for l in r.stdout.splitlines() if l.startswith("DIGEST")]
+        assert r.returncode == 0 and lines, r.stdout[-2000:]
+        return lines[0]
+
+    one = digest(0)
+    for p in (2, 3, 8):
+        assert digest(p) == one, p
