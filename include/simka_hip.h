@@ -232,6 +232,8 @@ int simka_profile_get(simka_ctx *ctx, int which, const char **name, uint64_t *nb
 /* log2 of the partition count a context would pick for samples of up to max_kmers_per_sample k-mer occurrences (what
  * simka_config::log2_partitions == 0 resolves to): contexts that exchange spectra must be created with the SAME explicit value */
 uint32_t simka_default_log2_partitions(uint64_t max_kmers_per_sample, uint32_t kmer_size);
+/* free / total memory of a device in bytes (hipMemGetInfo), for callers that plan how many partition ranges to merge at once */
+int simka_device_memory(int device, uint64_t *free_bytes, uint64_t *total_bytes);
 /* sizes chosen by the ctx (partition bits etc.), for DESIGN/bench reporting */
 int simka_get_geometry(simka_ctx *ctx, uint32_t *log2_level1, uint32_t *log2_level2, uint32_t *log2_subranges,
                        uint64_t *arena_capacity, uint64_t *csr_capacity);

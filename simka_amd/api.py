@@ -97,6 +97,8 @@ def load_library(build_if_missing=True):
         "simka_samples_spectrum_info": (i32, [vp, vp, u32, vp, vp]),
         "simka_gather_samples_device": (i32, [vp, vp, u32, vp, vp, vp]),
         "simka_import_samples_device": (i32, [vp, vp, u32, vp, u64, u64, vp, vp, u64, vp, vp, u64]),
+        "simka_device_memory": (i32, [i32, C.POINTER(u64), C.POINTER(u64)]),
+        "simka_default_log2_partitions": (u32, [u64, u32]),
         "simka_merge": (i32, [vp]),
         "simka_stats_device_buffer": (i32, [vp, C.POINTER(vp), C.POINTER(u64)]),
         "simka_stats_download": (i32, [vp, vp, u64, C.POINTER(StatsView)]),

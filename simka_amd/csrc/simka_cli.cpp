@@ -45,6 +45,8 @@ struct Options {
     int verbose = 1;
     int nb_gpus = 1, first_gpu = 0;     // new: GPUs to spread the samples (count) and the partition ranges (merge) over
     bool same_gpu = false;              // new (tests): all -nb-gpus contexts on GPU -gpu
+    long long solid_capacity = 0;       // new (tests): records of the solid-spectrum arena of every context (0: from the free memory)
+    int merge_ranges = 0;               // new: >0 keeps the spectra in host memory and merges in that many partition ranges per GPU
     bool parse_only = false;            // new: stop after reading + packing the inputs (ingest benchmark, no GPU needed)
 };
 
@@ -94,6 +96,7 @@ void usage() {
         "       -max-merge        (1 arg) :    accepted for compatibility\n"
         "   [gpu options]\n"
         "       -nb-gpus          (1 arg) :    MI355X devices: samples are counted on GPU i % n, partition ranges merged per GPU  [default '1']\n"
+        "       -merge-ranges     (1 arg) :    keep the k-mer spectra in host memory and merge in this many partition ranges per GPU (0: only when GPU memory requires it)  [default '0']\n"
         "       -gpu              (1 arg) :    first device ordinal  [default '0']\n"
         "       -verbose          (1 arg) :    verbosity level  [default '1']\n";
 }
@@ -126,6 +129,8 @@ Options parse_args(int argc, char **argv) {
         else if (a == "-nb-gpus") o.nb_gpus = atoi(need(i).c_str());
         else if (a == "-gpu") o.first_gpu = atoi(need(i).c_str());
         else if (a == "-gpu-shared") o.same_gpu = true;
+        else if (a == "-merge-ranges") o.merge_ranges = atoi(need(i).c_str());
+        else if (a == "-solid-capacity") o.solid_capacity = atoll(need(i).c_str());
         else if (a == "-parse-only") o.parse_only = true;
         else if (a == "-max-count" || a == "-max-merge" || a == "-count-cmd" || a == "-merge-cmd" || a == "-count-file" ||
                  a == "-merge-file" || a == "-minimizer-size" || a == "-solidity-kind" || a == "-max-disk" ||
@@ -528,97 +533,179 @@ int main(int argc, char **argv) {
         cfg.abundance_max = (uint32_t)o.abundance_max;
         cfg.dist_flags = flags; cfg.device = device; cfg.shard_index = 0; cfg.shard_count = 1;
         cfg.max_kmers_per_sample = biggest; cfg.log2_partitions = log2_parts;
+        cfg.solid_capacity = (uint64_t)std::max<long long>(0, o.solid_capacity);
         simka_ctx *c = nullptr;
         if (simka_create(&cfg, &c) != SIMKA_OK) { std::cout << "EXCEPTION: " << simka_last_error(nullptr) << std::endl; exit(EXIT_FAILURE); }
         return c;
     };
     auto device_of = [&](uint32_t g) { return o.first_gpu + (o.same_gpu ? 0 : (int)g); };
-    std::vector<simka_ctx *> ctx(G, nullptr), cctx(G, nullptr);        // merge contexts; G > 1: one-sample counting contexts
-    for (uint32_t g = 0; g < G; g++) {
-        ctx[g] = make_ctx(N, device_of(g));
-        if (G > 1) cctx[g] = make_ctx(1, device_of(g));
-    }
-    std::vector<std::mutex> ctx_lock(G);
-    // a sample's whole spectrum -> the merge context of every GPU (its partition range only)
-    auto distribute = [&](uint32_t i, const Spectrum &sp) {
-        if (sp.h.nb_partitions != P) die("ERROR: spectrum of " + samples[i].id + " has another partition count (remove " + tmp + "/solid to recount)");
-        std::vector<uint64_t> off(P + 1, 0);
-        for (uint64_t p = 0; p < P; p++) off[p + 1] = off[p] + sp.part_counts[p];
-        for (uint32_t g = 0; g < G; g++) {
-            const uint64_t lo = P * g / G, hi = P * (g + 1) / G;
-            std::vector<uint32_t> pc(P, 0);
-            std::copy(sp.part_counts.begin() + lo, sp.part_counts.begin() + hi, pc.begin() + lo);
-            const uint64_t n = off[hi] - off[lo];
-            std::lock_guard<std::mutex> lk(ctx_lock[g]);
-            check(ctx[g], simka_import_sample(ctx[g], i, &sp.h.totals, pc.data(), P, n ? sp.keys.data() + off[lo] : nullptr,
-                                              n ? sp.counts.data() + off[lo] : nullptr, n), "simka_import_sample");
-        }
+    const uint64_t nw = simka_stats_nb_u64(N, flags);
+    uint64_t lay[8];
+    simka_stats_layout(N, flags, lay);
+    std::vector<uint64_t> flat(nw, 0);
+    std::vector<simka_sample_totals> totals(N);
+    std::mutex out_lock;
+    auto fatal = [&](simka_ctx *c, const char *what) {
+        std::lock_guard<std::mutex> lk(out_lock);
+        std::cout << "EXCEPTION: " << what << ": " << simka_last_error(c) << std::endl;
+        exit(EXIT_FAILURE);
     };
-    auto export_from = [&](simka_ctx *c, uint32_t index, uint32_t i, Spectrum &sp) {
+    auto export_from = [&](simka_ctx *c, uint32_t index, uint32_t i, Spectrum &sp) -> int {
         simka_spectrum_info info;
-        check(c, simka_sample_spectrum_info(c, index, &info), "simka_sample_spectrum_info");
+        int rc = simka_sample_spectrum_info(c, index, &info);
+        if (rc != SIMKA_OK) return rc;
         sp.part_counts.resize(info.nb_partitions); sp.keys.resize(info.nb_records); sp.counts.resize(info.nb_records);
-        check(c, simka_export_sample(c, index, sp.part_counts.data(), sp.keys.data(), sp.counts.data()), "simka_export_sample");
+        rc = simka_export_sample(c, index, sp.part_counts.data(), sp.keys.data(), sp.counts.data());
+        if (rc != SIMKA_OK) return rc;
         memset(&sp.h, 0, sizeof sp.h);
         memcpy(sp.h.magic, "SIMKSPC1", 8);
         sp.h.abi = (uint64_t)simka_abi_version(); sp.h.kmer_size = (uint64_t)o.kmer_size;
         sp.h.abundance_min = (uint64_t)o.abundance_min; sp.h.abundance_max = (uint64_t)o.abundance_max;
         sp.h.shard_index = 0; sp.h.shard_count = 1; sp.h.nb_partitions = info.nb_partitions; sp.h.nb_records = info.nb_records;
         sp.h.signature = sig[i];
-        check(c, simka_get_sample_totals(c, index, &sp.h.totals), "simka_get_sample_totals");
+        return simka_get_sample_totals(c, index, &sp.h.totals);
     };
-
-    // count (ref: SimkaPotaraAlgorithm::count, src/SimkaPotara.hpp:813-972)
+    auto fill_reads = [](const Packed &pk, simka_reads &r) {
+        memset(&r, 0, sizeof r);
+        r.packed = pk.words.data(); r.nb_bases = pk.nb_bases; r.nb_reads = pk.nb_frag; r.offsets = pk.offsets.data();
+        r.fixed_len = 0; r.on_device = 0; r.nb_input_reads = pk.nb_reads;
+    };
+    auto say_reused = [&](uint32_t i) {
+        if (!o.verbose) return;
+        std::lock_guard<std::mutex> lk(out_lock);
+        std::cout << "\t" << samples[i].id << ": k-mer spectrum reused from " << tmp << "/solid" << std::endl;
+    };
     if (o.verbose) std::cout << "Counting k-mers... (log files are " << tmp << "/log/count_*)" << std::endl;
-    std::vector<simka_sample_totals> totals(N);
-    SampleLoader loader(samples, o, max_reads, nthreads, nthreads + 2 * G, reuse);
-    std::mutex out_lock;
-    // worker g handles the samples i % G == g on GPU g (G == 1: everything, in order, in this thread)
-    auto worker = [&](uint32_t g) {
-        for (uint32_t i = g; i < N; i += G) {
+
+    // ---- DIRECT: one GPU, every solid spectrum stays in its HBM arena; count, merge, download.
+    // Returns SIMKA_ERR_NOMEM when the spectra do not fit the arena: the caller then takes the host-spectra path below.
+    auto direct_run = [&]() -> int {
+        simka_ctx *c = make_ctx(N, device_of(0));
+        SampleLoader loader(samples, o, max_reads, nthreads, nthreads + 2, reuse);
+        int rc = SIMKA_OK;
+        auto soft = [&](int r, const char *what) { if (r == SIMKA_OK) return true; if (r != SIMKA_ERR_NOMEM) fatal(c, what); rc = r; return false; };
+        for (uint32_t i = 0; i < N && rc == SIMKA_OK; i++) {
             Packed *pkp;
             if (!loader.get(i, pkp)) die("ERROR: Can't open dataset: " + samples[i].id);
             if (reuse[i]) {     // ref: src/SimkaPotara.hpp:837-842 (count_synchro/<ID>.ok exists -> the sample is not recounted)
                 Spectrum sp;
                 const std::string path = spec_path(tmp, samples[i], 0, 1);
                 if (!read_spec(path, sp)) die("ERROR: cannot read " + path + " (remove it to recount the sample)");
-                distribute(i, sp);
-                if (o.verbose) { std::lock_guard<std::mutex> lk(out_lock); std::cout << "\t" << samples[i].id << ": k-mer spectrum reused from " << tmp << "/solid" << std::endl; }
+                if (sp.h.nb_partitions != P) die("ERROR: spectrum of " + samples[i].id + " has another partition count (remove " + tmp + "/solid to recount)");
+                if (soft(simka_import_sample(c, i, &sp.h.totals, sp.part_counts.data(), P, sp.keys.data(), sp.counts.data(), sp.h.nb_records), "simka_import_sample")) say_reused(i);
                 loader.release(i);
                 continue;
             }
-            Packed &pk = *pkp;
             simka_reads r;
-            memset(&r, 0, sizeof r);
-            r.packed = pk.words.data(); r.nb_bases = pk.nb_bases; r.nb_reads = pk.nb_frag; r.offsets = pk.offsets.data();
-            r.fixed_len = 0; r.on_device = 0; r.nb_input_reads = pk.nb_reads;
-            if (G == 1) {
-                check(ctx[0], simka_count_sample(ctx[0], i, &r), "simka_count_sample");
-                loader.release(i);     // host buffers may be reused as soon as simka_count_sample returns
-                if (o.keep_tmp) {      // persist the spectrum so that a later run with more samples skips this one
-                    Spectrum sp;
-                    export_from(ctx[0], i, i, sp);
-                    if (!write_spec(spec_path(tmp, samples[i], 0, 1), sp)) die("ERROR: cannot write " + spec_path(tmp, samples[i], 0, 1));
-                }
-            } else {
-                check(cctx[g], simka_count_sample(cctx[g], 0, &r), "simka_count_sample");
-                loader.release(i);
+            fill_reads(*pkp, r);
+            const bool ok = soft(simka_count_sample(c, i, &r), "simka_count_sample");
+            loader.release(i);     // host buffers may be reused as soon as simka_count_sample returns
+            if (ok && o.keep_tmp) {      // persist the spectrum so that a later run with more samples skips this one
                 Spectrum sp;
-                export_from(cctx[g], 0, i, sp);
-                check(cctx[g], simka_reset(cctx[g]), "simka_reset");
-                distribute(i, sp);
-                if (o.keep_tmp && !write_spec(spec_path(tmp, samples[i], 0, 1), sp)) die("ERROR: cannot write " + spec_path(tmp, samples[i], 0, 1));
+                if (soft(export_from(c, i, i, sp), "simka_export_sample") && !write_spec(spec_path(tmp, samples[i], 0, 1), sp))
+                    die("ERROR: cannot write " + spec_path(tmp, samples[i], 0, 1));
             }
         }
+        for (uint32_t i = 0; i < N && rc == SIMKA_OK; i++) soft(simka_get_sample_totals(c, i, &totals[i]), "simka_get_sample_totals");
+        if (rc == SIMKA_OK) soft(simka_merge(c), "simka_merge");
+        if (rc == SIMKA_OK) soft(simka_stats_download(c, flat.data(), nw, nullptr), "simka_stats_download");
+        simka_destroy(c);
+        return rc;
     };
-    if (G == 1) worker(0);
-    else {
+
+    // ---- HOST SPECTRA: G GPUs and/or spectra larger than one arena.  Phase 1: sample i is counted over the whole key space by
+    // a one-sample context on GPU i % G and its spectrum is taken to host memory.  Phase 2: the partition space is cut into
+    // V = G * R ranges; GPU g imports the slice of range v = g, g + G, ... of every sample, merges it and adds its pair
+    // accumulators to the total (the reference: one simkaMerge job per partition, summed by SimkaStatistics::operator+=).
+    auto host_run = [&](uint32_t want_ranges) {
+        std::vector<Spectrum> spectra(N);
+        {
+            std::vector<simka_ctx *> cctx(G);
+            for (uint32_t g = 0; g < G; g++) cctx[g] = make_ctx(1, device_of(g));
+            SampleLoader loader(samples, o, max_reads, nthreads, nthreads + 2 * G, reuse);
+            auto worker = [&](uint32_t g) {
+                for (uint32_t i = g; i < N; i += G) {
+                    Packed *pkp;
+                    if (!loader.get(i, pkp)) die("ERROR: Can't open dataset: " + samples[i].id);
+                    Spectrum &sp = spectra[i];
+                    if (reuse[i]) {
+                        const std::string path = spec_path(tmp, samples[i], 0, 1);
+                        if (!read_spec(path, sp)) die("ERROR: cannot read " + path + " (remove it to recount the sample)");
+                        say_reused(i);
+                        loader.release(i);
+                    } else {
+                        simka_reads r;
+                        fill_reads(*pkp, r);
+                        if (simka_count_sample(cctx[g], 0, &r) != SIMKA_OK) fatal(cctx[g], "simka_count_sample");
+                        loader.release(i);
+                        if (export_from(cctx[g], 0, i, sp) != SIMKA_OK) fatal(cctx[g], "simka_export_sample");
+                        if (simka_reset(cctx[g]) != SIMKA_OK) fatal(cctx[g], "simka_reset");
+                        if (o.keep_tmp && !write_spec(spec_path(tmp, samples[i], 0, 1), sp)) die("ERROR: cannot write " + spec_path(tmp, samples[i], 0, 1));
+                    }
+                    if (sp.h.nb_partitions != P) die("ERROR: spectrum of " + samples[i].id + " has another partition count (remove " + tmp + "/solid to recount)");
+                    totals[i] = sp.h.totals;
+                }
+            };
+            std::vector<std::thread> th;
+            for (uint32_t g = 0; g < G; g++) th.emplace_back(worker, g);
+            for (auto &t : th) t.join();
+            for (uint32_t g = 0; g < G; g++) simka_destroy(cctx[g]);
+        }
+        // ranges per GPU: as many as it takes for one range of all samples to fit the arena (12 B per solid k-mer in 40 % of HBM)
+        uint64_t total_records = 0;
+        for (auto &sp : spectra) total_records += sp.h.nb_records;
+        uint64_t fr = 0, tot = 0;
+        simka_device_memory(device_of(0), &fr, &tot);
+        uint64_t cap_records = std::max<uint64_t>(1, (uint64_t)(0.40 * (double)fr) / 12);
+        if (o.solid_capacity > 0) cap_records = std::min<uint64_t>(cap_records, (uint64_t)o.solid_capacity * 8 / 10);
+        uint64_t R = want_ranges ? want_ranges : std::max<uint64_t>(1, ((total_records + total_records / 8) / G + cap_records - 1) / cap_records);
+        uint64_t V = std::min<uint64_t>(P, (uint64_t)G * R);
+        if (o.verbose && V > G) std::cout << "Merging in " << V << " partition ranges (" << total_records << " solid k-mers)" << std::endl;
+        if (o.verbose) std::cout << std::endl << "Merging k-mer counts and computing distances..." << std::endl;
+        std::mutex acc_lock;
+        bool have_tail = false;
+        auto merger = [&](uint32_t g) {
+            simka_ctx *c = make_ctx(N, device_of(g));
+            std::vector<uint64_t> shard(nw), off(P + 1);
+            std::vector<uint32_t> pc(P);
+            bool first = true;
+            for (uint64_t v = g; v < V; v += G) {
+                if (!first && simka_reset(c) != SIMKA_OK) fatal(c, "simka_reset");
+                first = false;
+                const uint64_t lo = P * v / V, hi = P * (v + 1) / V;
+                for (uint32_t i = 0; i < N; i++) {
+                    const Spectrum &sp = spectra[i];
+                    uint64_t before = 0, n = 0;
+                    for (uint64_t p = 0; p < lo; p++) before += sp.part_counts[p];
+                    std::fill(pc.begin(), pc.end(), 0u);
+                    for (uint64_t p = lo; p < hi; p++) { pc[p] = sp.part_counts[p]; n += pc[p]; }
+                    if (simka_import_sample(c, i, &sp.h.totals, pc.data(), P, n ? sp.keys.data() + before : nullptr, n ? sp.counts.data() + before : nullptr, n) != SIMKA_OK)
+                        fatal(c, "simka_import_sample");
+                }
+                if (simka_merge(c) != SIMKA_OK) fatal(c, "simka_merge");
+                if (simka_stats_download(c, shard.data(), nw, nullptr) != SIMKA_OK) fatal(c, "simka_stats_download");
+                std::lock_guard<std::mutex> lk(acc_lock);          // SimkaStatistics::operator+= over the ranges (imported totals are global)
+                for (uint64_t w = 0; w < lay[5]; w++) flat[w] += shard[w];
+                if (!have_tail) { for (uint64_t w = lay[5]; w < nw; w++) flat[w] = shard[w]; have_tail = true; }
+            }
+            simka_destroy(c);
+        };
         std::vector<std::thread> th;
-        for (uint32_t g = 0; g < G; g++) th.emplace_back(worker, g);
+        for (uint32_t g = 0; g < G; g++) th.emplace_back(merger, g);
         for (auto &t : th) t.join();
-        for (uint32_t g = 0; g < G; g++) simka_destroy(cctx[g]);
+    };
+
+    bool host_mode = G > 1 || o.merge_ranges > 0;
+    if (!host_mode) {
+        const int rc = direct_run();
+        if (rc == SIMKA_ERR_NOMEM) {
+            if (o.verbose) std::cout << "The solid k-mer spectra do not fit the GPU memory at once: recounting with the spectra in host memory and merging by partition ranges" << std::endl;
+            std::fill(flat.begin(), flat.end(), 0);
+            if (o.keep_tmp) for (uint32_t i = 0; i < N; i++) { SpecHeader h; if (read_spec_header(spec_path(tmp, samples[i], 0, 1), h) && spec_matches(h, o, 0, 1, sig[i]) && h.nb_partitions == P) reuse[i] = 1; }
+            host_mode = true;
+        }
     }
-    for (uint32_t i = 0; i < N; i++) check(ctx[0], simka_get_sample_totals(ctx[0], i, &totals[i]), "simka_get_sample_totals");   // global on every context
+    if (host_mode) host_run((uint32_t)std::max(0, o.merge_ranges));
     if (o.keep_tmp) {   // count_synchro/<ID>.ok with the reference's 4 lines (ref: src/SimkaCount.cpp:303-317)
         mkdir_p(tmp + "/count_synchro");
         for (uint32_t i = 0; i < N; i++) {
@@ -630,23 +717,6 @@ int main(int argc, char **argv) {
         std::cout << std::endl << "Nb reads / distinct k-mers / k-mers per sample (after the abundance filter):" << std::endl;
         for (uint32_t i = 0; i < N; i++)
             std::cout << "\t" << samples[i].id << ": " << totals[i].nb_reads << " / " << totals[i].nb_distinct << " / " << totals[i].nb_kmers << std::endl;
-    }
-
-    // merge + reduce (ref: SimkaPotaraAlgorithm::merge / stats, src/SimkaPotara.hpp:974-1187)
-    if (o.verbose) std::cout << std::endl << "Merging k-mer counts and computing distances..." << std::endl;
-    {   // every GPU merges its partition range (imported totals are already global: -complex-dist needs N_i)
-        std::vector<std::thread> th;
-        for (uint32_t g = 0; g < G; g++) th.emplace_back([&, g] { check(ctx[g], simka_merge(ctx[g]), "simka_merge"); });
-        for (auto &t : th) t.join();
-    }
-    const uint64_t nw = simka_stats_nb_u64(N, flags);
-    uint64_t lay[8];
-    simka_stats_layout(N, flags, lay);
-    std::vector<uint64_t> flat(nw, 0), shard(nw, 0);
-    for (uint32_t g = 0; g < G; g++) {          // SimkaStatistics::operator+= over the shards (totals are already global)
-        check(ctx[g], simka_stats_download(ctx[g], shard.data(), nw, nullptr), "simka_stats_download");
-        for (uint64_t w = 0; w < lay[5]; w++) flat[w] += shard[w];
-        if (g == 0) for (uint64_t w = lay[5]; w < nw; w++) flat[w] = shard[w];
     }
     simka_stats_view view;
     if (simka_stats_describe(N, flags, flat.data(), nw, &view) != SIMKA_OK) die("EXCEPTION: simka_stats_describe");
@@ -667,7 +737,6 @@ int main(int argc, char **argv) {
         std::cout << "\tShared distinct k-mers: " << view.nb_shared_kmers << std::endl;
         std::cout << std::endl << "Output dir: " << o.out << std::endl << std::endl;
     }
-    for (uint32_t g = 0; g < G; g++) simka_destroy(ctx[g]);
     if (!o.keep_tmp) {
         unlink((tmp + "/datasetIds").c_str());
         rmdir(tmp.c_str());

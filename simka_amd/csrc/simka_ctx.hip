@@ -1284,6 +1284,14 @@ SIMKA_EXPORT int simka_profile_get(simka_ctx *ctx, int which, const char **name,
     if (ms) *ms = ctx->prof_ms[which];
     return SIMKA_OK;
 }
+SIMKA_EXPORT int simka_device_memory(int device, uint64_t *free_bytes, uint64_t *total_bytes) {
+    size_t fr = 0, tot = 0;
+    if (hipSetDevice(device) != hipSuccess || hipMemGetInfo(&fr, &tot) != hipSuccess) return SIMKA_ERR_HIP;
+    if (free_bytes) *free_bytes = fr;
+    if (total_bytes) *total_bytes = tot;
+    return SIMKA_OK;
+}
+
 SIMKA_EXPORT int simka_get_geometry(simka_ctx *ctx, uint32_t *l1, uint32_t *l2, uint32_t *t, uint64_t *arena, uint64_t *csr) {
     if (!ctx) return SIMKA_ERR_INVALID;
     if (l1) *l1 = ctx->key.l1; if (l2) *l2 = ctx->key.l2; if (t) *t = ctx->key.t;

@@ -706,3 +706,31 @@ def test_deep_samples_counted_in_passes(gpu_required):
     one = digest(0)
     for p in (2, 3, 8):
         assert digest(p) == one, p
+
+
+def test_cli_spectra_larger_than_the_arena_merge_by_partition_ranges(gpu_required, golden_dir, tmp_path):
+    """When the solid spectra of all samples do not fit the HBM arena (here: -solid-capacity far too small) the driver notices the
+    NOMEM, recounts with one-sample contexts, keeps the spectra in host memory and merges the partition space range by range;
+    -merge-ranges asks for that directly.  Byte-identical CSVs either way."""
+    import subprocess
+    from simka_amd import build as b
+    base = [b.CLI_PATH, "-in", os.path.join(golden_dir, "example", "simka_input.txt"), "-out-tmp", str(tmp_path / "tmp"), "-simple-dist",
+            "-complex-dist", "-kmer-size", "21", "-abundance-min", "0"]
+    truth = os.path.join(golden_dir, "truth", "results_k21_t0")
+
+    def run(out, extra):
+        r = subprocess.run(base + ["-out", out] + extra, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+        assert r.returncode == 0, r.stdout
+        n = 0
+        for gzf in glob.glob(os.path.join(out, "*.csv.gz")):
+            ref = os.path.join(truth, os.path.basename(gzf)[:-3])
+            if os.path.exists(ref):
+                with gzip.open(gzf, "rb") as f, open(ref, "rb") as h:
+                    assert f.read() == h.read(), os.path.basename(gzf)
+                n += 1
+        assert n == 20
+        return r.stdout
+
+    assert "partition ranges" in run(str(tmp_path / "o1"), ["-merge-ranges", "3"])
+    log = run(str(tmp_path / "o2"), ["-solid-capacity", "20000"])          # the 5 samples hold ~45000 solid k-mers
+    assert "do not fit the GPU memory" in log and "partition ranges" in log
