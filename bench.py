@@ -209,6 +209,26 @@ def main():
     prof = ctx.profile()
     geo = ctx.geometry()
 
+    # ---- timing boundaries of SURVEY 8(d), measured outside the timed region (per step, this rank)
+    def timed(f, reps=3):
+        torch.cuda.synchronize(); t = time.perf_counter()
+        for _ in range(reps):
+            f()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t) / reps * 1e3
+    t_finalise = timed(lambda: ctx.stats().matrices())                       # download + 15..21 matrices on the host
+    one = next(r for r in reads if r is not None)
+    pinned = torch.empty(one.numel(), dtype=torch.int64).pin_memory()
+    scratch = torch.empty_like(one)
+    nmine = sum(1 for r in reads if r is not None) if by_sample else n
+    t_h2d = timed(lambda: scratch.copy_(pinned, non_blocking=True)) * nmine      # packed reads host -> HBM (pinned), not part of `value`
+    t_allreduce = None
+    if world > 1:
+        ptr, nwords = ctx.stats_device_buffer()
+        buf = torch.zeros(nwords, dtype=torch.int64, device=dev if backend == "nccl" else "cpu")
+        t_allreduce = timed(lambda: dist.all_reduce(buf))
+    del pinned, scratch
+
     ps = st.per_sample()
     K_dist = float(ps["D_all"].sum())     # distinct canonical k-mers before the filter, summed over samples (whole job)
     K_occ = float(ps["K_occ"].sum())
@@ -281,6 +301,14 @@ def main():
                 "path_achieved": path_gbs, "path_frac": path_gbs / HBM_PEAK_GBS, "path_alg_bytes_per_step": b_alg,
                 "kernel_ms_per_step": {kk: v / args.steps for kk, v in kern_ms.items()}, "kernels": per_kernel}
 
+    pair_updates = float(st.pairs()["a"].sum())            # sum over k-mers of s(s-1)/2 = sum over pairs of the shared distinct k-mers
+    if "k_pairs" in per_kernel and per_kernel["k_pairs"]["ms_per_step"] > 0:
+        per_kernel["k_pairs"]["pair_updates_per_step"] = pair_updates
+        per_kernel["k_pairs"]["pair_updates_per_s"] = pair_updates / world / (per_kernel["k_pairs"]["ms_per_step"] * 1e-3)
+    timing = {"device_kernels_ms": total_kernel_ms / args.steps, "finalise_ms": t_finalise, "h2d_packed_reads_ms": t_h2d,
+              "allreduce_ms": t_allreduce, "step_ms": ms_per_step,
+              "note": "per step on rank 0; h2d = the packed reads of this rank's samples from pinned host memory (inputs are resident in HBM in the timed "
+                      "region); e2e from FASTA: scripts/cli_e2e.py (DESIGN.md section 8)"}
     out = {
         "metric": "distinct k-mers/s end-to-end (count + merge + N x N matrices)", "value": value, "unit": "distinct k-mers/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
@@ -294,6 +322,7 @@ def main():
                    # sha1 of every distance matrix (float32 bytes, by name): equal across --gpus N for the same workload
                    "matrix_checksum": __import__("hashlib").sha1(b"".join(np.ascontiguousarray(mats[m]).tobytes() for m in sorted(mats))).hexdigest()[:16]},
         "roofline": roofline,
+        "timing": timing,
     }
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         try:
