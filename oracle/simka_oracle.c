@@ -46,31 +46,34 @@
 /* ------------------------------------------------------------------------- */
 /* small utilities                                                            */
 /* ------------------------------------------------------------------------- */
-typedef struct { uint64_t *v; size_t n, cap; } u64vec;
+/* a k-mer of up to 63 bases: 126 bits.  (k <= 31 fits 64 bits, as Kmer<span=32> of the reference; k >= 32 is its
+ * span=64 instantiation, KSIZE_LIST of the reference's CMakeLists.txt) */
+typedef unsigned __int128 kmer_t;
+typedef struct { kmer_t *v; size_t n, cap; } u64vec;
 
-static void u64vec_push(u64vec *a, uint64_t x) {
+static void u64vec_push(u64vec *a, kmer_t x) {
     if (a->n == a->cap) {
         a->cap = a->cap ? a->cap * 2 : 1024;
-        a->v = (uint64_t *)realloc(a->v, a->cap * sizeof(uint64_t));
+        a->v = (kmer_t *)realloc(a->v, a->cap * sizeof(kmer_t));
         if (!a->v) { fprintf(stderr, "oracle: out of memory\n"); abort(); }
     }
     a->v[a->n++] = x;
 }
 
-/* LSD radix sort of 64-bit keys, `bits` significant bits. */
-static void radix_sort_u64(uint64_t *a, size_t n, int bits) {
+/* LSD radix sort of k-mers, `bits` significant bits. */
+static void radix_sort_u64(kmer_t *a, size_t n, int bits) {
     if (n < 2) return;
-    uint64_t *tmp = (uint64_t *)malloc(n * sizeof(uint64_t));
-    uint64_t *src = a, *dst = tmp;
+    kmer_t *tmp = (kmer_t *)malloc(n * sizeof(kmer_t));
+    kmer_t *src = a, *dst = tmp;
     for (int shift = 0; shift < bits; shift += 8) {
         size_t hist[257];
         memset(hist, 0, sizeof(hist));
-        for (size_t i = 0; i < n; i++) hist[((src[i] >> shift) & 0xff) + 1]++;
+        for (size_t i = 0; i < n; i++) hist[(size_t)((src[i] >> shift) & 0xff) + 1]++;
         for (int d = 0; d < 256; d++) hist[d + 1] += hist[d];
-        for (size_t i = 0; i < n; i++) dst[hist[(src[i] >> shift) & 0xff]++] = src[i];
-        uint64_t *t = src; src = dst; dst = t;
+        for (size_t i = 0; i < n; i++) dst[hist[(size_t)((src[i] >> shift) & 0xff)]++] = src[i];
+        kmer_t *t = src; src = dst; dst = t;
     }
-    if (src != a) memcpy(a, src, n * sizeof(uint64_t));
+    if (src != a) memcpy(a, src, n * sizeof(kmer_t));
     free(tmp);
 }
 
@@ -92,14 +95,14 @@ static inline int or_code(unsigned char c) {
 
 /* Append the canonical k-mers of one read to `out`; returns #k-mers appended. */
 static size_t or_kmers_of_read(const char *seq, size_t len, int k, u64vec *out) {
-    const uint64_t mask = (k == 32) ? ~0ull : ((1ull << (2 * k)) - 1);
-    uint64_t fwd = 0, rev = 0;
+    const kmer_t mask = (((kmer_t)1) << (2 * k)) - 1;       /* k <= 63 */
+    kmer_t fwd = 0, rev = 0;
     size_t valid = 0, emitted = 0;
     for (size_t i = 0; i < len; i++) {
         int c = or_code((unsigned char)seq[i]);
         if (c < 0) { valid = 0; fwd = rev = 0; continue; }
-        fwd = ((fwd << 2) | (uint64_t)c) & mask;
-        rev = (rev >> 2) | ((uint64_t)(c ^ 2) << (2 * (k - 1)));
+        fwd = ((fwd << 2) | (kmer_t)c) & mask;
+        rev = (rev >> 2) | ((kmer_t)(c ^ 2) << (2 * (k - 1)));
         if (++valid >= (size_t)k) {
             u64vec_push(out, fwd < rev ? fwd : rev);
             emitted++;
@@ -121,7 +124,7 @@ typedef struct {
     uint64_t k_occ;         /* k-mer occurrences */
     uint64_t d_all;         /* distinct canonical k-mers before the abundance filter */
     /* [a4] solid spectrum, sorted by k-mer */
-    uint64_t *kmer; uint32_t *count; size_t nsolid;
+    kmer_t *kmer; uint32_t *count; size_t nsolid;
     /* [a5] totals after filter */
     uint64_t D, N, Q;
 } or_sample;
@@ -275,7 +278,7 @@ static int or_count_sample(oracle *o, or_sample *s) {
      * count (the merge's min-heap assumes sorted streams, ref: src/SimkaMerge.cpp:1198-1263) */
     radix_sort_u64(km.v, km.n, 2 * o->k);
     size_t nd = 0, ns = 0;
-    s->kmer = (uint64_t *)malloc((km.n ? km.n : 1) * sizeof(uint64_t));
+    s->kmer = (kmer_t *)malloc((km.n ? km.n : 1) * sizeof(kmer_t));
     s->count = (uint32_t *)malloc((km.n ? km.n : 1) * sizeof(uint32_t));
     s->D = s->N = s->Q = 0;
     for (size_t i = 0; i < km.n;) {
@@ -293,7 +296,7 @@ static int or_count_sample(oracle *o, or_sample *s) {
         i = j;
     }
     s->d_all = nd; s->nsolid = ns;
-    s->kmer = (uint64_t *)realloc(s->kmer, (ns ? ns : 1) * sizeof(uint64_t));
+    s->kmer = (kmer_t *)realloc(s->kmer, (ns ? ns : 1) * sizeof(kmer_t));
     s->count = (uint32_t *)realloc(s->count, (ns ? ns : 1) * sizeof(uint32_t));
     free(km.v);
     return 0;
@@ -424,10 +427,11 @@ static void or_insert(or_stats *st, const int32_t *counts, size_t nb_having, uin
 /* The reference's partition = f(minimizer); distances do not depend on the   */
 /* choice (ref: tests/simple_test.py:125-133), here partition = mix(kmer)%P.  */
 /* ------------------------------------------------------------------------- */
-static inline uint64_t or_mix(uint64_t x) {
+static inline uint64_t or_mix(kmer_t km) {
+    uint64_t x = (uint64_t)km ^ ((uint64_t)(km >> 64) * 0x9E3779B97F4A7C15ULL);      /* fold the high word in (k >= 33) */
     x ^= x >> 33; x *= 0xff51afd7ed558ccdULL; x ^= x >> 33; x *= 0xc4ceb9fe1a85ec53ULL; x ^= x >> 33; return x;
 }
-typedef struct { uint64_t kmer; int bank; } heap_item;
+typedef struct { kmer_t kmer; int bank; } heap_item;
 static void heap_sift_down(heap_item *h, size_t n, size_t i) {
     for (;;) {
         size_t l = 2 * i + 1, r = l + 1, m = i;
@@ -451,7 +455,7 @@ static void or_merge_partition(const oracle *o, or_stats *st, unsigned part, uns
     }
     for (size_t i = hn; i-- > 0;) heap_sift_down(heap, hn, i);
     while (hn) {
-        uint64_t cur = heap[0].kmer;
+        kmer_t cur = heap[0].kmer;
         size_t nb_having = 0;
         memset(counts, 0, n * sizeof(int32_t));                   /* SimkaCounterBuilderMerge::init :293-297 */
         while (hn && heap[0].kmer == cur) {
@@ -697,7 +701,7 @@ OR_API int oracle_add_sample_mem(oracle *o, const char *id, const char *bases, c
  * (shard_count=1: everything.)  threads<=1 -> serial. */
 OR_API int oracle_run_shard(oracle *o, int k, uint32_t amin, uint32_t amax, int simple, int complex_, unsigned nparts, int threads,
                             unsigned shard_index, unsigned shard_count) {
-    if (k < 1 || k > 32) { snprintf(o->err, sizeof o->err, "oracle: k must be in [1,32]"); return -1; }
+    if (k < 1 || k > 63) { snprintf(o->err, sizeof o->err, "oracle: k must be in [1,63]"); return -1; }
     o->k = k; o->amin = amin; o->amax = amax > 999999999u ? 999999999u : amax;  /* ref: src/core/SimkaAlgorithm.cpp:188 */
     if (nparts < 1) nparts = 1;
     int rc = 0;
@@ -782,7 +786,8 @@ OR_API void oracle_get_matrix(const oracle *o, int which, float *out) { or_matri
 /* solid spectrum of one sample (sorted canonical k-mers, A0C1T2G3 code) -- for kernel-level tests */
 OR_API uint64_t oracle_sample_nsolid(const oracle *o, int i) { return o->s[i].nsolid; }
 OR_API void oracle_get_sample_solid(const oracle *o, int i, uint64_t *kmers, uint32_t *counts) {
-    memcpy(kmers, o->s[i].kmer, o->s[i].nsolid * 8); memcpy(counts, o->s[i].count, o->s[i].nsolid * 4);
+    for (size_t j = 0; j < o->s[i].nsolid; j++) kmers[j] = (uint64_t)o->s[i].kmer[j];      /* low 64 bits: the whole k-mer for k <= 32 */
+    memcpy(counts, o->s[i].count, o->s[i].nsolid * 4);
 }
 
 /* outputMatrix, ref: src/core/SimkaDistance.cpp:603-649 */
