@@ -1040,6 +1040,67 @@ SIMKA_EXPORT int simka_import_samples_device(simka_ctx *ctx, const uint32_t *sam
     return SIMKA_OK;
 }
 
+// ---- pair accumulation: shared by the hash merge (k_group's CSR) and the sort merge of the wide-k path -------------------
+struct PairLaunch { SimkaPairCfg pc; size_t lds_pairs = 0; uint32_t ntp = 1, nblk = 1; bool small_block = false; };
+
+static void pair_setup(simka_ctx *ctx, PairLaunch &pl) {
+    // pair-accumulator tiling: all N(N-1)/2 cells in LDS when they fit, else T x T sample tiles
+    const uint32_t flags = ctx->cfg.dist_flags;
+    const uint32_t N = ctx->cfg.nb_samples;
+    SimkaPairCfg &pc = pl.pc;
+    pc.nb_samples = N; pc.nacc32 = stats_nacc32(flags); pc.nacc64 = stats_nacc64(flags); pc.nacc = pc.nacc32 + pc.nacc64;
+    pc.simple = (flags & SIMKA_DIST_SIMPLE) ? 1u : 0u;
+    pc.nb_pairs = (uint64_t)N * (N - 1) / 2;
+    pc.tot_n = (const ull *)ctx->d_stats + stats_off_tot(N, flags, SIMKA_TOT_N);   // GLOBAL N_i: all-reduced by the caller when sharded
+    // LDS of k_pairs: head | packed cells | ent | (complex: p, p ln p, tile N table) | gdesc | gpref | tmp | (tiled: gdescB, epre, idxA, idxB)
+    // The span capacity EC (entries staged per iteration) takes what the cells leave: longer spans amortise the per-span cost.
+    const bool cplx = pc.nacc64 != 0;
+    auto lds_single = [&](size_t ec) { return SIMKA_LDS_HEAD + ec * 8 + (cplx ? ec * 16 + SIMKA_PAIR_TN * 8 : 0) + (ec / 2) * 4 + (ec / 2 + 2) * 4 + 32 * 4 + 64; };
+    auto lds_tiled = [&](size_t ec) { return lds_single(ec) + (ec / 2) * 4 + (ec + 2) * 4 + ec * 4; };
+    const size_t lds_max = 160 * 1024;
+    const size_t cell_bytes = 4 * pc.nacc32 + 8 * pc.nacc64;
+    size_t lds_fixed;
+    if (lds_single(K3_CAP) + (pc.nb_pairs + 4) * cell_bytes <= lds_max && (!cplx || N <= SIMKA_PAIR_TN)) {
+        pc.tile = N; pc.ntiles = 1; pc.ncell = (uint32_t)pc.nb_pairs;
+        pc.span_cap = K3_CAP;
+        const uint32_t span_max = N <= 32 ? 2 * K3_CAP : SIMKA_SPAN_MAX;      // few samples: small blocks, several per CU
+        while (pc.span_cap + K3_CAP <= span_max && lds_single(pc.span_cap + K3_CAP) + (pc.nb_pairs + 4) * cell_bytes <= lds_max) pc.span_cap += K3_CAP;
+        lds_fixed = lds_single(pc.span_cap);
+    } else {
+        pc.span_cap = 2 * K3_CAP;       // tiled: larger spans cost tile edge (more tile pairs replaying the spans)
+        lds_fixed = lds_tiled(pc.span_cap);
+        const uint64_t max_cells = (lds_max - lds_fixed) / cell_bytes - 4;     // ncell_pad rounds up to a multiple of 4
+        uint32_t T = 1; while ((uint64_t)(T + 1) * (T + 1) <= max_cells) T++;
+        if (cplx && T > SIMKA_PAIR_TN / 2) T = SIMKA_PAIR_TN / 2;
+        pc.tile = T; pc.ntiles = (N + T - 1) / T; pc.ncell = T * T;
+    }
+    pc.ncell_pad = (pc.ncell + 3u) & ~3u;
+    pl.ntp = pc.ntiles * (pc.ntiles + 1) / 2;
+    pl.lds_pairs = lds_fixed + (size_t)pc.ncell_pad * cell_bytes;
+    pl.small_block = pc.ntiles == 1 && N <= 32;     // few pairs per span: more, smaller blocks
+    const uint32_t per_cu = (uint32_t)std::min<size_t>(pl.small_block ? 6 : 2, std::max<size_t>(1, (160 * 1024) / pl.lds_pairs));
+    pl.nblk = (uint32_t)ctx->num_cus * per_cu;
+}
+
+static void pair_launch(simka_ctx *ctx, const PairLaunch &pl, const SimkaSpan *spans, const ull *cursors, const ull *entries, const uint32_t *groups,
+                        const SimkaSpan *huge, ull *acc) {
+    const SimkaPairCfg &pc = pl.pc;
+    launch_timed(ctx, KID_PAIRS, [&] {
+        if (pl.small_block)
+            hipLaunchKernelGGL((k_pairs<false, K4_BLOCK_SMALL>), dim3(pl.nblk, pl.ntp), dim3(K4_BLOCK_SMALL), pl.lds_pairs, ctx->stream, spans, cursors, entries, groups, pc, acc);
+        else if (pc.ntiles == 1)
+            hipLaunchKernelGGL((k_pairs<false, K4_BLOCK_BIG>), dim3(pl.nblk, pl.ntp), dim3(K4_BLOCK_BIG), pl.lds_pairs, ctx->stream, spans, cursors, entries, groups, pc, acc);
+        else
+            hipLaunchKernelGGL((k_pairs<true, K4_BLOCK_BIG>), dim3(pl.nblk, pl.ntp), dim3(K4_BLOCK_BIG), pl.lds_pairs, ctx->stream, spans, cursors, entries, groups, pc, acc);
+    });
+    if (huge && pc.nb_samples > K3_CAP)
+        launch_timed(ctx, KID_PAIRS_GLOBAL, [&] {
+            hipLaunchKernelGGL(k_pairs_global, dim3(64, 64), dim3(256), 0, ctx->stream, huge, cursors, entries, pc, acc);
+        });
+}
+
+static int complex_finish(simka_ctx *ctx, const SimkaPairCfg &pc);
+
 // ---- merge side ---------------------------------------------------------------------------
 SIMKA_EXPORT int simka_merge(simka_ctx *ctx) {
     if (!ctx) return SIMKA_ERR_INVALID;
@@ -1104,41 +1165,10 @@ SIMKA_EXPORT int simka_merge(simka_ctx *ctx) {
     if (ctx->fb_cap < fb_cap) { if (ctx->d_fb_off) HIPCHK(hipFree(ctx->d_fb_off)); ctx->d_fb_off = nullptr; HIPCHK(dev_alloc(&ctx->d_fb_off, fb_cap + 1)); ctx->fb_cap = fb_cap; }
     if (ctx->span_cap < span_cap) { if (ctx->d_spans) HIPCHK(hipFree(ctx->d_spans)); ctx->d_spans = nullptr; HIPCHK(dev_alloc(&ctx->d_spans, span_cap)); ctx->span_cap = span_cap; }
 
-    // pair-accumulator tiling: all N(N-1)/2 cells in LDS when they fit, else T x T sample tiles
+    PairLaunch pl;
+    pair_setup(ctx, pl);
+    const SimkaPairCfg &pc = pl.pc;
     const uint32_t flags = ctx->cfg.dist_flags;
-    SimkaPairCfg pc;
-    pc.nb_samples = N; pc.nacc32 = stats_nacc32(flags); pc.nacc64 = stats_nacc64(flags); pc.nacc = pc.nacc32 + pc.nacc64;
-    pc.simple = (flags & SIMKA_DIST_SIMPLE) ? 1u : 0u;
-    pc.nb_pairs = (uint64_t)N * (N - 1) / 2;
-    pc.tot_n = (const ull *)ctx->d_stats + stats_off_tot(N, flags, SIMKA_TOT_N);   // GLOBAL N_i: all-reduced by the caller when sharded
-    // LDS of k_pairs: head | packed cells | ent | (complex: p, p ln p, tile N table) | gdesc | gpref | tmp | (tiled: gdescB, epre, idxA, idxB)
-    // The span capacity EC (entries staged per iteration) takes what the cells leave: longer spans amortise the per-span cost.
-    const bool cplx = pc.nacc64 != 0;
-    auto lds_single = [&](size_t ec) { return SIMKA_LDS_HEAD + ec * 8 + (cplx ? ec * 16 + SIMKA_PAIR_TN * 8 : 0) + (ec / 2) * 4 + (ec / 2 + 2) * 4 + 32 * 4 + 64; };
-    auto lds_tiled = [&](size_t ec) { return lds_single(ec) + (ec / 2) * 4 + (ec + 2) * 4 + ec * 4; };
-    const size_t lds_max = 160 * 1024;
-    const size_t cell_bytes = 4 * pc.nacc32 + 8 * pc.nacc64;
-    size_t lds_fixed;
-    if (lds_single(K3_CAP) + (pc.nb_pairs + 4) * cell_bytes <= lds_max && (!cplx || N <= SIMKA_PAIR_TN)) {
-        pc.tile = N; pc.ntiles = 1; pc.ncell = (uint32_t)pc.nb_pairs;
-        pc.span_cap = K3_CAP;
-        const uint32_t span_max = N <= 32 ? 2 * K3_CAP : SIMKA_SPAN_MAX;      // few samples: small blocks, several per CU
-        while (pc.span_cap + K3_CAP <= span_max && lds_single(pc.span_cap + K3_CAP) + (pc.nb_pairs + 4) * cell_bytes <= lds_max) pc.span_cap += K3_CAP;
-        lds_fixed = lds_single(pc.span_cap);
-    } else {
-        pc.span_cap = 2 * K3_CAP;       // tiled: larger spans cost tile edge (more tile pairs replaying the spans)
-        lds_fixed = lds_tiled(pc.span_cap);
-        const uint64_t max_cells = (lds_max - lds_fixed) / cell_bytes - 4;     // ncell_pad rounds up to a multiple of 4
-        uint32_t T = 1; while ((uint64_t)(T + 1) * (T + 1) <= max_cells) T++;
-        if (cplx && T > SIMKA_PAIR_TN / 2) T = SIMKA_PAIR_TN / 2;
-        pc.tile = T; pc.ntiles = (N + T - 1) / T; pc.ncell = T * T;
-    }
-    pc.ncell_pad = (pc.ncell + 3u) & ~3u;
-    const uint32_t ntp = pc.ntiles * (pc.ntiles + 1) / 2;
-    const size_t lds_pairs = lds_fixed + (size_t)pc.ncell_pad * cell_bytes;
-    const bool small_block = pc.ntiles == 1 && N <= 32;     // few pairs per span: more, smaller blocks
-    const uint32_t per_cu = (uint32_t)std::min<size_t>(small_block ? 6 : 2, std::max<size_t>(1, (160 * 1024) / lds_pairs));
-    const uint32_t nblk = (uint32_t)ctx->num_cus * per_cu;
     // k-mers shared by more than K3_CAP samples (possible only when N > K3_CAP) leave k_group on a list of their own
     const uint64_t huge_cap = N > K3_CAP ? cap / K3_CAP + 16 : 1;
     if (ctx->huge_cap < huge_cap) { if (ctx->d_huge) HIPCHK(hipFree(ctx->d_huge)); ctx->d_huge = nullptr; HIPCHK(dev_alloc(&ctx->d_huge, huge_cap)); ctx->huge_cap = huge_cap; }
@@ -1170,28 +1200,20 @@ SIMKA_EXPORT int simka_merge(simka_ctx *ctx) {
                 hipLaunchKernelGGL(k_group, dim3(std::min<uint32_t>(nfb, grid_group)), dim3(K3_BLOCK), lds_group, ctx->stream, ctx->d_mkeys, ctx->d_mvals,
                                    ctx->d_fb_off, nfb, (uint32_t)recs, key, min_share, co);
             });
-            launch_timed(ctx, KID_PAIRS, [&] {
-                if (small_block)
-                    hipLaunchKernelGGL((k_pairs<false, K4_BLOCK_SMALL>), dim3(nblk, ntp), dim3(K4_BLOCK_SMALL), lds_pairs, ctx->stream, ctx->d_spans,
-                                       ctx->d_cursors, ctx->d_entries, ctx->d_groups, pc, acc);
-                else if (pc.ntiles == 1)
-                    hipLaunchKernelGGL((k_pairs<false, K4_BLOCK_BIG>), dim3(nblk, ntp), dim3(K4_BLOCK_BIG), lds_pairs, ctx->stream, ctx->d_spans,
-                                       ctx->d_cursors, ctx->d_entries, ctx->d_groups, pc, acc);
-                else
-                    hipLaunchKernelGGL((k_pairs<true, K4_BLOCK_BIG>), dim3(nblk, ntp), dim3(K4_BLOCK_BIG), lds_pairs, ctx->stream, ctx->d_spans,
-                                       ctx->d_cursors, ctx->d_entries, ctx->d_groups, pc, acc);
-            });
-            if (N > K3_CAP)
-                launch_timed(ctx, KID_PAIRS_GLOBAL, [&] {
-                    hipLaunchKernelGGL(k_pairs_global, dim3(64, 64), dim3(256), 0, ctx->stream, ctx->d_huge, ctx->d_cursors, ctx->d_entries, pc, acc);
-                });
+            pair_launch(ctx, pl, ctx->d_spans, ctx->d_cursors, ctx->d_entries, ctx->d_groups, ctx->d_huge, acc);
         }
         pb = pe;
     }
     HIPCHK(hipGetLastError());
     int rcd = check_device_error(ctx);
     if (rcd) return rcd;
-    if (flags & SIMKA_DIST_COMPLEX) {
+    if (flags & SIMKA_DIST_COMPLEX) return complex_finish(ctx, pc);
+    return SIMKA_OK;
+}
+
+static int complex_finish(simka_ctx *ctx, const SimkaPairCfg &pc) {
+    const uint32_t N = ctx->cfg.nb_samples;
+    {
         // Whittaker's one-sided terms  sum_{k-mers of i} g(c, N_j),  g(c,M) = |(int)(u64)(c*M)|  (ref: src/core/SimkaAlgorithm.hpp:481,512),
         // from this shard's histogram of solid counts and the GLOBAL N_j; k_pairs already subtracted g for the both-present pairs.
         std::vector<ull> hist((size_t)N * SIMKA_HIST_MAX), totn(N), whit(pc.nb_pairs);
