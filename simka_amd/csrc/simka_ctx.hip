@@ -12,6 +12,7 @@
 
 #include "../../include/simka_hip.h"
 #include "simka_kernels.hip"
+#include "simka_wide.h"
 
 #define SIMKA_EXPORT extern "C" __attribute__((visibility("default")))
 
@@ -72,6 +73,7 @@ struct simka_ctx {
     uint32_t *d_fb_off = nullptr; SimkaSpan *d_spans = nullptr; ull *d_cursors = nullptr; SimkaSpan *d_huge = nullptr;
     uint64_t merge_cap = 0, fb_cap = 0, span_cap = 0, huge_cap = 0;
     // -complex-dist: per-sample histogram of solid counts + list of the counts above the histogram
+    SimkaWide *wide = nullptr;                                  // 32 <= k <= 63 (or SIMKA_SORT_PATH): the sort-based path of simka_wide.hip
     ull *d_xoff = nullptr; uint64_t xoff_cap = 0;               // simka_gather_samples_device: destination offsets
     ull *d_hist = nullptr; uint32_t *d_ovf_list = nullptr; ull *d_ovf_cursor = nullptr; uint64_t ovf_cap = 0;
 
@@ -321,7 +323,9 @@ SIMKA_EXPORT int simka_create(const simka_config *cfg, simka_ctx **out) {
     if (!cfg || !out) { g_create_error = "simka_create: null argument"; return SIMKA_ERR_INVALID; }
     if (cfg->struct_size != sizeof(simka_config)) { g_create_error = "simka_create: struct_size mismatch (ABI)"; return SIMKA_ERR_INVALID; }
     if (cfg->nb_samples == 0 || cfg->nb_samples > 65535) { g_create_error = "simka_create: nb_samples must be in [1,65535]"; return SIMKA_ERR_INVALID; }
-    if (cfg->kmer_size < 1 || cfg->kmer_size > 31) { g_create_error = "simka_create: kmer_size must be in [1,31] on the device path"; return SIMKA_ERR_INVALID; }
+    if (cfg->kmer_size < 1 || cfg->kmer_size > 63) { g_create_error = "simka_create: kmer_size must be in [1,63]"; return SIMKA_ERR_INVALID; }
+    const bool want_wide = cfg->kmer_size > 31 || getenv("SIMKA_SORT_PATH") != nullptr;
+    if (want_wide && cfg->shard_count > 1) { g_create_error = "simka_create: partition shards are not available for kmer_size >= 32 (sort-based path)"; return SIMKA_ERR_UNSUPPORTED; }
     if (cfg->shard_count == 0 || cfg->shard_index >= cfg->shard_count) { g_create_error = "simka_create: bad shard_index/shard_count"; return SIMKA_ERR_INVALID; }
     if (cfg->log2_subranges > 8) { g_create_error = "simka_create: log2_subranges must be <= 8"; return SIMKA_ERR_INVALID; }
     int ndev = 0;
@@ -342,7 +346,7 @@ SIMKA_EXPORT int simka_create(const simka_config *cfg, simka_ctx **out) {
 
     SimkaKeyCfg &k = ctx->key;
     memset(&k, 0, sizeof k);
-    k.k = cfg->kmer_size; k.W = 2 * cfg->kmer_size; k.mask = (1ull << k.W) - 1ull; k.xs = (k.W + 1) / 2;
+    k.k = cfg->kmer_size; k.W = 2 * cfg->kmer_size; k.mask = k.W >= 64 ? ~0ull : (1ull << k.W) - 1ull; k.xs = (k.W + 1) / 2;      // (hash path: W <= 62)
     k.shard_index = cfg->shard_index; k.shard_count = cfg->shard_count;
 
     int rc = set_lds_attr(ctx);
@@ -368,7 +372,9 @@ SIMKA_EXPORT int simka_create(const simka_config *cfg, simka_ctx **out) {
     }
     ctx->counted.assign(N, 0);
     ctx->nb_reads.assign(N, 0);
-    if (cfg->max_kmers_per_sample) { rc = setup_geometry(ctx, cfg->max_kmers_per_sample); if (rc) return bail(rc); }
+    if (want_wide) {
+        if (simka_wide_create(&ctx->wide, cfg->device, N, cfg->kmer_size, ctx->stream) != SIMKA_WIDE_OK) { ctx->err = "cannot create the wide-k state"; return bail(SIMKA_ERR_NOMEM); }
+    } else if (cfg->max_kmers_per_sample) { rc = setup_geometry(ctx, cfg->max_kmers_per_sample); if (rc) return bail(rc); }
     *out = ctx;
     return SIMKA_OK;
 }
@@ -376,6 +382,7 @@ SIMKA_EXPORT int simka_create(const simka_config *cfg, simka_ctx **out) {
 SIMKA_EXPORT void simka_destroy(simka_ctx *ctx) {
     if (!ctx) return;
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+    if (ctx->wide) { simka_wide_destroy(ctx->wide); ctx->wide = nullptr; }
     for (auto &L : ctx->lanes) {
         if (L.stream) (void)hipStreamSynchronize(L.stream);
         void *lp[] = { L.d_l1, L.d_b1_count, L.d_b1_start, L.d_b1_end, L.d_b1_cursor, L.d_chunk_first, L.d_tile_r0, L.d_l2, L.d_p_count, L.d_p_valid,
@@ -403,6 +410,7 @@ SIMKA_EXPORT int simka_sync(simka_ctx *ctx) {
 SIMKA_EXPORT int simka_reset(simka_ctx *ctx) {
     if (!ctx) return SIMKA_ERR_INVALID;
     HIPCHK(hipSetDevice(ctx->cfg.device));
+    if (ctx->wide) simka_wide_reset(ctx->wide);
     for (uint32_t li = 0; li < ctx->nlanes; li++) if (ctx->lanes[li].stream) HIPCHK(hipStreamSynchronize(ctx->lanes[li].stream));
     const uint32_t N = ctx->cfg.nb_samples;
     HIPCHK(hipMemsetAsync(ctx->d_stats, 0, ctx->stats_n * 8, ctx->stream));
@@ -636,6 +644,41 @@ static int resolve_pending(simka_ctx *ctx) {
     return SIMKA_OK;
 }
 
+// ---- 32 <= k <= 63: sort-based path (simka_wide.hip) --------------------------------------------
+static int wide_fail(simka_ctx *ctx, int wrc) {
+    const int rc = wrc == SIMKA_WIDE_ERR_NOMEM ? SIMKA_ERR_NOMEM : wrc == SIMKA_WIDE_ERR_LIMIT ? SIMKA_ERR_UNSUPPORTED : SIMKA_ERR_HIP;
+    return ctx->fail(rc, "%s", simka_wide_error(ctx->wide));
+}
+
+static int wide_count_sample(simka_ctx *ctx, uint32_t sample, const simka_reads *r) {
+    const uint32_t N = ctx->cfg.nb_samples, fl = ctx->cfg.dist_flags;
+    ctx->nb_reads[sample] = r->nb_input_reads ? r->nb_input_reads : r->nb_reads;
+    ctx->counted[sample] = 1;
+    if (r->nb_bases == 0) return SIMKA_OK;
+    const uint64_t nb_words = (r->nb_bases + 31) / 32;
+    const void *d_packed = r->packed, *d_offsets = r->offsets;
+    int rc;
+    if (!r->on_device) {
+        rc = ensure_cap(ctx, &ctx->d_reads, &ctx->reads_cap, nb_words + 2); if (rc) return rc;
+        HIPCHK(hipMemcpyAsync(ctx->d_reads, r->packed, nb_words * 8, hipMemcpyHostToDevice, ctx->stream));
+        d_packed = ctx->d_reads; d_offsets = nullptr;
+        if (!r->fixed_len) {
+            rc = ensure_cap(ctx, &ctx->d_offsets, &ctx->offsets_cap, r->nb_reads + 1); if (rc) return rc;
+            HIPCHK(hipMemcpyAsync(ctx->d_offsets, r->offsets, (r->nb_reads + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
+            d_offsets = ctx->d_offsets;
+        }
+    }
+    unsigned long long tot[SIMKA_NB_TOTALS];
+    const int wrc = simka_wide_count_sample(ctx->wide, sample, d_packed, r->nb_bases, nb_words, d_offsets, r->nb_reads, r->fixed_len, ctx->cfg.abundance_min,
+                                            ctx->cfg.abundance_max, tot, ctx->d_hist ? (void *)(ctx->d_hist + (uint64_t)sample * SIMKA_HIST_MAX) : nullptr,
+                                            ctx->d_ovf_list, ctx->d_ovf_cursor, ctx->ovf_cap);
+    if (wrc) return wide_fail(ctx, wrc);
+    for (int i = 0; i < SIMKA_NB_TOTALS; i++)
+        HIPCHK(hipMemcpyAsync(ctx->d_stats + stats_off_tot(N, fl, i) + sample, &tot[i], 8, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    return SIMKA_OK;
+}
+
 // ---- count side ---------------------------------------------------------------------------
 SIMKA_EXPORT int simka_count_sample(simka_ctx *ctx, uint32_t sample, const simka_reads *r) {
     if (!ctx || !r) return SIMKA_ERR_INVALID;
@@ -648,6 +691,7 @@ SIMKA_EXPORT int simka_count_sample(simka_ctx *ctx, uint32_t sample, const simka
     if (r->fixed_len && r->nb_bases != r->nb_reads * (uint64_t)r->fixed_len) return ctx->fail(SIMKA_ERR_INVALID, "simka_count_sample: nb_bases != nb_reads*fixed_len");
     HIPCHK(hipSetDevice(ctx->cfg.device));
     int rc;
+    if (ctx->wide) return wide_count_sample(ctx, sample, r);
     if (!ctx->geometry_ready) { rc = setup_geometry(ctx, std::max<uint64_t>(r->nb_bases, 1)); if (rc) return rc; }
     ctx->nb_reads[sample] = r->nb_input_reads ? r->nb_input_reads : r->nb_reads;
     ctx->counted[sample] = 1;
@@ -743,6 +787,7 @@ static int spectrum_rows(simka_ctx *ctx, uint32_t sample, const char *who, std::
 }
 
 SIMKA_EXPORT int simka_sample_spectrum_info(simka_ctx *ctx, uint32_t sample, simka_spectrum_info *out) {
+    if (ctx && ctx->wide) return ctx->fail(SIMKA_ERR_UNSUPPORTED, "simka_sample_spectrum_info: spectra of kmer_size >= 32 (sort-based path) cannot be exported / imported yet");
     if (!ctx || !out) return SIMKA_ERR_INVALID;
     std::vector<uint32_t> foff, fcnt;
     const int rc = spectrum_rows(ctx, sample, "simka_sample_spectrum_info", foff, fcnt);
@@ -754,6 +799,7 @@ SIMKA_EXPORT int simka_sample_spectrum_info(simka_ctx *ctx, uint32_t sample, sim
 }
 
 static int export_sample(simka_ctx *ctx, uint32_t sample, uint32_t *part_counts, void *keys, void *counts, bool on_device, const char *who) {
+    if (ctx && ctx->wide) return ctx->fail(SIMKA_ERR_UNSUPPORTED, "spectra of kmer_size >= 32 (sort-based path) cannot be exported / imported yet");
     if (!ctx || !part_counts) return SIMKA_ERR_INVALID;
     std::vector<uint32_t> foff, fcnt;
     int rc = spectrum_rows(ctx, sample, who, foff, fcnt);
@@ -795,6 +841,7 @@ SIMKA_EXPORT int simka_export_sample_device(simka_ctx *ctx, uint32_t sample, uin
 
 static int import_sample(simka_ctx *ctx, uint32_t sample, const simka_sample_totals *totals, const uint32_t *part_counts,
                          uint64_t nb_partitions, const void *keys, const void *counts_any, uint64_t nb_records, bool on_device) {
+    if (ctx && ctx->wide) return ctx->fail(SIMKA_ERR_UNSUPPORTED, "spectra of kmer_size >= 32 (sort-based path) cannot be exported / imported yet");
     if (!ctx || !totals || !part_counts) return SIMKA_ERR_INVALID;
     const uint32_t N = ctx->cfg.nb_samples, fl = ctx->cfg.dist_flags;
     if (sample >= N) return ctx->fail(SIMKA_ERR_INVALID, "simka_import_sample: sample index %u out of range", sample);
@@ -880,6 +927,7 @@ SIMKA_EXPORT int simka_import_sample_device(simka_ctx *ctx, uint32_t sample, con
 
 // ---- batch forms (multi-GPU exchange) ---------------------------------------------------------
 SIMKA_EXPORT int simka_samples_spectrum_info(simka_ctx *ctx, const uint32_t *samples, uint32_t nb, uint32_t *part_counts, simka_sample_totals *totals) {
+    if (ctx && ctx->wide) return ctx->fail(SIMKA_ERR_UNSUPPORTED, "simka_samples_spectrum_info: spectra of kmer_size >= 32 (sort-based path) cannot be exported / imported yet");
     if (!ctx || (nb && (!samples || !part_counts || !totals))) return SIMKA_ERR_INVALID;
     const uint32_t N = ctx->cfg.nb_samples, fl = ctx->cfg.dist_flags;
     for (uint32_t j = 0; j < nb; j++)
@@ -907,6 +955,7 @@ SIMKA_EXPORT int simka_samples_spectrum_info(simka_ctx *ctx, const uint32_t *sam
 }
 
 SIMKA_EXPORT int simka_gather_samples_device(simka_ctx *ctx, const uint32_t *samples, uint32_t nb, const uint64_t *out_offsets, void *d_keys, void *d_counts) {
+    if (ctx && ctx->wide) return ctx->fail(SIMKA_ERR_UNSUPPORTED, "simka_gather_samples_device: spectra of kmer_size >= 32 (sort-based path) cannot be exported / imported yet");
     if (!ctx) return SIMKA_ERR_INVALID;
     if (nb == 0 || !ctx->geometry_ready) return SIMKA_OK;
     if (!samples || !out_offsets || !d_keys || !d_counts) return ctx->fail(SIMKA_ERR_INVALID, "simka_gather_samples_device: NULL argument");
@@ -931,6 +980,7 @@ SIMKA_EXPORT int simka_gather_samples_device(simka_ctx *ctx, const uint32_t *sam
 SIMKA_EXPORT int simka_import_samples_device(simka_ctx *ctx, const uint32_t *samples, uint32_t nb, const simka_sample_totals *totals,
                                              uint64_t part_lo, uint64_t part_width, const uint32_t *part_counts, const uint64_t *in_offsets,
                                              uint64_t nb_partitions, const void *d_keys, const void *d_counts, uint64_t nb_records) {
+    if (ctx && ctx->wide) return ctx->fail(SIMKA_ERR_UNSUPPORTED, "simka_import_samples_device: spectra of kmer_size >= 32 (sort-based path) cannot be exported / imported yet");
     if (!ctx || (nb && (!samples || !totals || !part_counts || !in_offsets))) return SIMKA_ERR_INVALID;
     const uint32_t N = ctx->cfg.nb_samples, fl = ctx->cfg.dist_flags;
     if (ctx->merged) return ctx->fail(SIMKA_ERR_STATE, "simka_import_samples_device: merge already ran");
@@ -1083,9 +1133,9 @@ static void pair_setup(simka_ctx *ctx, PairLaunch &pl) {
 }
 
 static void pair_launch(simka_ctx *ctx, const PairLaunch &pl, const SimkaSpan *spans, const ull *cursors, const ull *entries, const uint32_t *groups,
-                        const SimkaSpan *huge, ull *acc) {
+                        const SimkaSpan *huge, ull *acc, bool have_spans = true) {
     const SimkaPairCfg &pc = pl.pc;
-    launch_timed(ctx, KID_PAIRS, [&] {
+    if (have_spans) launch_timed(ctx, KID_PAIRS, [&] {
         if (pl.small_block)
             hipLaunchKernelGGL((k_pairs<false, K4_BLOCK_SMALL>), dim3(pl.nblk, pl.ntp), dim3(K4_BLOCK_SMALL), pl.lds_pairs, ctx->stream, spans, cursors, entries, groups, pc, acc);
         else if (pc.ntiles == 1)
@@ -1093,7 +1143,7 @@ static void pair_launch(simka_ctx *ctx, const PairLaunch &pl, const SimkaSpan *s
         else
             hipLaunchKernelGGL((k_pairs<true, K4_BLOCK_BIG>), dim3(pl.nblk, pl.ntp), dim3(K4_BLOCK_BIG), pl.lds_pairs, ctx->stream, spans, cursors, entries, groups, pc, acc);
     });
-    if (huge && pc.nb_samples > K3_CAP)
+    if (huge)
         launch_timed(ctx, KID_PAIRS_GLOBAL, [&] {
             hipLaunchKernelGGL(k_pairs_global, dim3(64, 64), dim3(256), 0, ctx->stream, huge, cursors, entries, pc, acc);
         });
@@ -1113,6 +1163,24 @@ SIMKA_EXPORT int simka_merge(simka_ctx *ctx) {
     rc = check_device_error(ctx);
     if (rc) return rc;
     ctx->merged = true;
+    if (ctx->wide) {
+        if (N < 2) {
+            HIPCHK(hipMemcpyAsync(ctx->d_stats, ctx->d_stats + stats_off_tot(N, ctx->cfg.dist_flags, SIMKA_TOT_D), 8, hipMemcpyDeviceToDevice, ctx->stream));
+            return SIMKA_OK;
+        }
+        PairLaunch pl;
+        pair_setup(ctx, pl);
+        SimkaWideCsr csr;
+        const int wrc = simka_wide_merge(ctx->wide, pl.pc.span_cap, &csr);          // the N-way merge by sorting: CSR of the shared k-mers
+        if (wrc) return wide_fail(ctx, wrc);
+        const ull head[2] = { csr.nb_distinct, csr.nb_shared };
+        HIPCHK(hipMemcpyAsync(ctx->d_stats, head, 16, hipMemcpyHostToDevice, ctx->stream));
+        if (csr.nb_spans || csr.nb_huge) pair_launch(ctx, pl, csr.spans, csr.cursors, csr.entries, csr.groups, csr.nb_huge ? csr.huge : nullptr, (ull *)ctx->d_stats + stats_off_acc(N, 0), csr.nb_spans != 0);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipStreamSynchronize(ctx->stream));
+        if (ctx->cfg.dist_flags & SIMKA_DIST_COMPLEX) return complex_finish(ctx, pl.pc);
+        return SIMKA_OK;
+    }
     if (!ctx->geometry_ready) return SIMKA_OK;            // only empty samples
     if (N < 2) {   // nothing to pair up: the union of k-mers is the sample's own solid spectrum, none of it shared
         HIPCHK(hipMemcpyAsync(ctx->d_stats, ctx->d_stats + stats_off_tot(N, ctx->cfg.dist_flags, SIMKA_TOT_D), 8, hipMemcpyDeviceToDevice, ctx->stream));
@@ -1200,7 +1268,7 @@ SIMKA_EXPORT int simka_merge(simka_ctx *ctx) {
                 hipLaunchKernelGGL(k_group, dim3(std::min<uint32_t>(nfb, grid_group)), dim3(K3_BLOCK), lds_group, ctx->stream, ctx->d_mkeys, ctx->d_mvals,
                                    ctx->d_fb_off, nfb, (uint32_t)recs, key, min_share, co);
             });
-            pair_launch(ctx, pl, ctx->d_spans, ctx->d_cursors, ctx->d_entries, ctx->d_groups, ctx->d_huge, acc);
+            pair_launch(ctx, pl, ctx->d_spans, ctx->d_cursors, ctx->d_entries, ctx->d_groups, N > K3_CAP ? ctx->d_huge : nullptr, acc);
         }
         pb = pe;
     }

@@ -1,0 +1,26 @@
+// simka_wide.h -- internal interface of the sort-based path for 32 <= k <= 63 (simka_wide.hip), used by simka_ctx.hip.
+#pragma once
+#include <stdint.h>
+#include "simka_kernels.h"
+
+struct SimkaWide;
+
+enum { SIMKA_WIDE_OK = 0, SIMKA_WIDE_ERR_HIP = 1, SIMKA_WIDE_ERR_NOMEM = 2, SIMKA_WIDE_ERR_LIMIT = 3 };
+
+// the CSR of the groups shared by >= 2 samples, in the layout k_pairs consumes (owned by the wide state)
+struct SimkaWideCsr {
+    unsigned long long *entries; uint32_t *groups; SimkaSpan *spans; unsigned long long *cursors;
+    uint32_t nb_spans;
+    SimkaSpan *huge; uint32_t nb_huge;     // groups larger than a span (k_pairs_global)
+    uint64_t nb_distinct, nb_shared;       // union of the samples' solid k-mers / those in >= 2 samples
+};
+
+int simka_wide_create(SimkaWide **out, int device, uint32_t nb_samples, uint32_t k, void *stream);
+void simka_wide_destroy(SimkaWide *w);
+int simka_wide_reset(SimkaWide *w);
+const char *simka_wide_error(SimkaWide *w);
+// packed / offsets: DEVICE pointers.  totals5: D N Q D_all K_occ (SIMKA_TOT_* order), host.  d_hist_row etc.: -complex-dist (or NULL).
+int simka_wide_count_sample(SimkaWide *w, uint32_t sample, const void *packed, uint64_t nb_bases, uint64_t nb_words, const void *offsets, uint64_t nb_reads,
+                            uint32_t fixed_len, uint32_t amin, uint32_t amax, unsigned long long totals5[5], void *d_hist_row, void *d_ovf_list,
+                            void *d_ovf_cursor, uint64_t ovf_cap);
+int simka_wide_merge(SimkaWide *w, uint32_t span_cap, SimkaWideCsr *out);

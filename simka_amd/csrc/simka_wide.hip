@@ -1,0 +1,481 @@
+// simka_wide.hip -- 32 <= k <= 63: canonical k-mers are up to 126 bits (the reference's Kmer<span=64>
+// instantiation, KSIZE_LIST of its CMakeLists.txt).  They do not fit the 64-bit keys of the hash pipeline
+// (simka_kernels.hip), so this path keeps every k-mer as a (hi, lo) pair of 64-bit words and COUNTS BY SORTING:
+//
+//   count:  k_wscan (rolling forward / reverse-complement words per thread, ref: gatb ModelCanonical as used at
+//           src/minikc/MiniKC.hpp:152-158)  ->  two stable LSD radix sorts (lo, then hi)  ->  run heads  ->
+//           abundance filter + totals (SimkaCompressedProcessor::process, ref: src/minikc/MiniKC.hpp:54-79)  ->
+//           the sample's solid spectrum, sorted, appended to the wide arena
+//   merge:  all samples' solid records sorted by k-mer (the N-way merge, ref: src/SimkaMerge.cpp:1164-1264)  ->
+//           groups of >= 2 samples (the gate, ref: :1307-1326)  ->  the same CSR (entries / groups / spans) the hash
+//           merge builds, consumed by the same k_pairs kernel.
+//
+// The radix sorts and prefix sums are rocPRIM/hipCUB library calls (plain primitives); everything else is hand-written.
+// Much slower than the hash pipeline (C2: 266 ms against 12 ms per step; every base position goes through two 64-bit radix
+// sorts), exact, and an independent cross-check of it: with SIMKA_SORT_PATH=1 the k <= 31 tests run through this path and
+// must give bit-identical statistics (they do: goldens included).
+#include <hip/hip_runtime.h>
+#include <hipcub/hipcub.hpp>
+#include <stdint.h>
+#include <algorithm>
+#include <string>
+#include <vector>
+
+#include "simka_kernels.h"
+#include "simka_wide.h"
+
+typedef unsigned long long ull;
+
+#define WCHK(call)                                                                                   \
+    do {                                                                                             \
+        hipError_t e_ = (call);                                                                      \
+        if (e_ != hipSuccess) { w->err = std::string(#call) + " failed: " + hipGetErrorString(e_); return SIMKA_WIDE_ERR_HIP; } \
+    } while (0)
+
+struct SimkaWide {
+    int device = 0;
+    uint32_t nb_samples = 0, k = 0, W = 0;
+    hipStream_t stream = nullptr;
+    std::string err;
+    // wide arena: the solid spectra of all samples, each sorted by (hi, lo)
+    ull *a_hi = nullptr, *a_lo = nullptr; uint32_t *a_cnt = nullptr;
+    uint64_t a_cap = 0, a_used = 0;
+    std::vector<uint64_t> s_off, s_n;            // per sample: offset and number of solid records
+    // scratch (grown on demand)
+    void *scratch[12] = { nullptr }; uint64_t scratch_bytes[12] = { 0 };
+    // CSR handed to k_pairs (owned here, valid until the next reset / merge)
+    ull *entries = nullptr; uint32_t *groups = nullptr; SimkaSpan *spans = nullptr, *huge = nullptr; ull *cursors = nullptr;
+};
+
+template <typename T>
+static int wide_buf(SimkaWide *w, int slot, uint64_t n, T **out) {
+    const uint64_t need = n * sizeof(T) + 256;
+    if (w->scratch_bytes[slot] < need) {
+        if (w->scratch[slot]) { WCHK(hipStreamSynchronize(w->stream)); WCHK(hipFree(w->scratch[slot])); w->scratch[slot] = nullptr; w->scratch_bytes[slot] = 0; }
+        WCHK(hipMalloc(&w->scratch[slot], need + need / 8));
+        w->scratch_bytes[slot] = need + need / 8;
+    }
+    *out = (T *)w->scratch[slot];
+    return 0;
+}
+
+// --------------------------------------------------------------------------------------------
+// k_wscan: thread = WSEG consecutive END positions of the concatenated base array.  It warms up on the k-1 bases before
+// its first position (inside the same read), then rolls the forward and reverse-complement words one base at a time.
+// keys[e] = canonical k-mer ending at base e, or the sentinel (hi = 1 << (W-64) or 1, lo = 0), which sorts after
+// every valid key.
+// --------------------------------------------------------------------------------------------
+#define WSEG 32
+
+struct WideScanArgs { const uint64_t *packed; uint64_t nb_bases, nb_words; const uint64_t *offsets; uint64_t nb_reads; uint32_t fixed_len, k; };
+
+__device__ __forceinline__ uint32_t wbase(const uint64_t *packed, uint64_t p) { return (uint32_t)(packed[p >> 5] >> ((p & 31u) * 2u)) & 3u; }
+
+__global__ void __launch_bounds__(256)
+k_wscan(WideScanArgs a, ull sent_hi, ull *khi, ull *klo, ull *nvalid) {
+    const uint64_t p0 = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) * WSEG;
+    uint32_t nv = 0;
+    if (p0 < a.nb_bases) {
+    const uint32_t k = a.k;
+    // the read that holds base p0
+    uint64_t rd, rstart, rend;
+    if (a.fixed_len) { rd = p0 / a.fixed_len; rstart = rd * a.fixed_len; rend = rstart + a.fixed_len; }
+    else {
+        uint64_t lo = 0, hi = a.nb_reads;
+        while (hi - lo > 1) { const uint64_t mid = (lo + hi) >> 1; if (a.offsets[mid] <= p0) lo = mid; else hi = mid; }
+        rd = lo; rstart = a.offsets[rd]; rend = a.offsets[rd + 1];
+    }
+    // masks of the 2k-bit k-mer as (hi, lo)
+    const uint32_t W = 2u * k;
+    const ull mlo = W >= 64u ? ~0ull : ((1ull << W) - 1ull);
+    const ull mhi = W > 64u ? ((1ull << (W - 64u)) - 1ull) : 0ull;
+    const uint32_t top = 2u * (k - 1u);                      // bit position of the first base in the reverse-complement word
+    ull fh = 0, fl = 0, rh = 0, rl = 0;
+    uint32_t have = 0;                                        // bases of the current read inside the window (capped at k)
+    uint64_t p = p0 > rstart + (k - 1u) ? p0 - (k - 1u) : rstart;   // warm-up start
+    const uint64_t pend = p0 + WSEG < a.nb_bases ? p0 + WSEG : a.nb_bases;
+    for (; p < pend; p++) {
+        while (p >= rend) {        // next read (fixed length: arithmetic; else the offsets array)
+            rd++;
+            rstart = rend;
+            rend = a.fixed_len ? rstart + a.fixed_len : a.offsets[rd + 1];
+            have = 0; fh = fl = rh = rl = 0;
+        }
+        const ull c = wbase(a.packed, p);
+        // forward: (f << 2 | c) & mask
+        fh = ((fh << 2) | (fl >> 62)) & mhi;
+        fl = ((fl << 2) | c) & mlo;
+        // reverse complement: (r >> 2) | (c ^ 2) << 2(k-1)
+        rl = (rl >> 2) | (rh << 62);
+        rh >>= 2;
+        const ull cc = c ^ 2ull;
+        if (top >= 64u) rh |= cc << (top - 64u); else rl |= cc << top;
+        if (have < k) have++;
+        if (p >= p0) {
+            ull oh = sent_hi, ol = 0;
+            if (have >= k) {
+                const bool fsm = fh < rh || (fh == rh && fl < rl);
+                oh = fsm ? fh : rh; ol = fsm ? fl : rl;
+                nv++;
+            }
+            khi[p] = oh; klo[p] = ol;
+        }
+    }
+    }
+    // block-level count of valid k-mers
+    for (int o = 32; o > 0; o >>= 1) nv += __shfl_down(nv, o, 64);
+    if ((threadIdx.x & 63u) == 0 && nv) atomicAdd(nvalid, (ull)nv);
+}
+
+__global__ void __launch_bounds__(256)
+k_wgather(const ull *src, const uint32_t *idx, ull *dst, uint64_t n) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) dst[i] = src[idx[i]];
+}
+
+__global__ void __launch_bounds__(256)
+k_wiota(uint32_t *idx, uint64_t n) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) idx[i] = (uint32_t)i;
+}
+
+// head of a run of equal keys
+__global__ void __launch_bounds__(256)
+k_wheads(const ull *khi, const ull *klo, uint64_t n, uint32_t *flag) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    flag[i] = (i == 0 || khi[i] != khi[i - 1] || klo[i] != klo[i - 1]) ? 1u : 0u;
+}
+
+// start[rank of the run] = position of its head; start[nruns] = n
+__global__ void __launch_bounds__(256)
+k_wstarts(const uint32_t *flag, const uint32_t *rank, uint64_t n, uint32_t *start, const uint32_t *nruns_minus) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    if (flag[i]) start[rank[i]] = (uint32_t)i;
+    if (i == n - 1) start[rank[i] + flag[i]] = (uint32_t)n;
+    (void)nruns_minus;
+}
+
+// SimkaCompressedProcessor::process over the runs: abundance filter, totals, (complex) histogram of solid counts
+__global__ void __launch_bounds__(256)
+k_wfilter(const uint32_t *start, uint32_t nruns, uint32_t amin, uint32_t amax, uint32_t *sflag, ull *tot /* D N Q */,
+          ull *hist, uint32_t *ovf_list, ull *ovf_cursor, ull ovf_cap, uint32_t sample) {
+    const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+    ull D = 0, N = 0, Q = 0;
+    if (j < nruns) {
+        const uint32_t c = start[j + 1] - start[j];
+        const bool solid = !(c < amin || c > amax);
+        sflag[j] = solid ? 1u : 0u;
+        if (solid) {
+            D = 1; N = c; Q = (ull)c * (ull)c;
+            if (hist) {
+                if (c < SIMKA_HIST_MAX) atomicAdd(&hist[c], 1ull);
+                else { const ull wq = atomicAdd(ovf_cursor, 1ull); if (wq < ovf_cap) { ovf_list[2 * wq] = sample; ovf_list[2 * wq + 1] = c; } }
+            }
+        }
+    }
+    for (int o = 32; o > 0; o >>= 1) { D += __shfl_down(D, o, 64); N += __shfl_down(N, o, 64); Q += __shfl_down(Q, o, 64); }
+    if ((threadIdx.x & 63u) == 0 && D) { atomicAdd(&tot[0], D); atomicAdd(&tot[1], N); atomicAdd(&tot[2], Q); }
+}
+
+__global__ void __launch_bounds__(256)
+k_wemit(const ull *khi, const ull *klo, const uint32_t *start, const uint32_t *sflag, const uint32_t *srank, uint32_t nruns,
+        ull *ohi, ull *olo, uint32_t *ocnt) {
+    const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= nruns || !sflag[j]) return;
+    const uint32_t s = start[j], o = srank[j];
+    ohi[o] = khi[s]; olo[o] = klo[s]; ocnt[o] = start[j + 1] - s;
+}
+
+// ---- merge ----
+__global__ void __launch_bounds__(256)
+k_wvals(const uint32_t *cnt, uint64_t off, uint64_t n, uint32_t sample, ull *val) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) val[off + i] = ((ull)sample << 32) | cnt[off + i];
+}
+
+// groups: size, kept (>= 2 samples) flag, size of kept groups
+// huge != 0: flag / size of the groups LARGER than maxg (they get a span of their own on the huge list); else of the groups of 2..maxg samples
+__global__ void __launch_bounds__(256)
+k_wgsizes(const uint32_t *gstart, uint32_t ngroups, uint32_t maxg, uint32_t huge, uint32_t *kflag, uint32_t *ksize) {
+    const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= ngroups) return;
+    const uint32_t s = gstart[g + 1] - gstart[g];
+    const bool take = huge ? s > maxg : (s >= 2u && s <= maxg);
+    kflag[g] = take ? 1u : 0u;
+    ksize[g] = take ? s : 0u;
+}
+
+// a group shared by more samples than a span can hold: its entries behind the ordinary ones, one span on the huge list (k_pairs_global)
+__global__ void __launch_bounds__(256)
+k_whuge(const uint32_t *gstart, uint32_t ngroups, const uint32_t *hflag, const uint32_t *hrank, const uint32_t *hoff, const ull *val, ull ebase0,
+        ull *entries, SimkaSpan *huge) {
+    const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= ngroups || !hflag[g]) return;
+    const uint32_t b = gstart[g], s = gstart[g + 1] - b;
+    const ull e = ebase0 + hoff[g];
+    for (uint32_t t = 0; t < s; t++) entries[e + t] = val[b + t];
+    SimkaSpan sp; sp.ebase = e; sp.gbase = 0; sp.nent = s; sp.ngrp = 1; sp.maxc = 0; sp.pad = 0;
+    huge[hrank[g]] = sp;
+}
+
+// kept group r: entries copied, span bookkeeping (span = the groups whose first entry falls into [sp*C, (sp+1)*C))
+__global__ void __launch_bounds__(256)
+k_wgroups(const uint32_t *gstart, uint32_t ngroups, const uint32_t *kflag, const uint32_t *krank, const uint32_t *eoff, const ull *val,
+          uint32_t C, ull *entries, uint32_t *ge, uint32_t *gs, uint32_t *sp_first, uint32_t *sp_ngrp, uint32_t *sp_nent, uint32_t *sp_maxc) {
+    const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= ngroups || !kflag[g]) return;
+    const uint32_t b = gstart[g], s = gstart[g + 1] - b, r = krank[g], e = eoff[g], sp = e / C;
+    uint32_t maxc = 0;
+    for (uint32_t t = 0; t < s; t++) { const ull v = val[b + t]; entries[e + t] = v; const uint32_t c = (uint32_t)v; maxc = c > maxc ? c : maxc; }
+    ge[r] = e; gs[r] = s;
+    atomicMin(&sp_first[sp], r);
+    atomicAdd(&sp_ngrp[sp], 1u);
+    atomicAdd(&sp_nent[sp], s);
+    atomicMax(&sp_maxc[sp], maxc);
+}
+
+__global__ void __launch_bounds__(256)
+k_wspans(uint32_t nspans, const uint32_t *sp_first, const uint32_t *sp_ngrp, const uint32_t *sp_nent, const uint32_t *sp_maxc, const uint32_t *ge,
+         SimkaSpan *spans, ull *cursors) {
+    const uint32_t sp = blockIdx.x * blockDim.x + threadIdx.x;
+    if (sp == 0) { cursors[0] = 0; cursors[1] = 0; cursors[2] = nspans; }      // [3] (huge spans) is set by the host
+    if (sp >= nspans) return;
+    SimkaSpan s; s.ebase = 0; s.gbase = 0; s.nent = 0; s.ngrp = 0; s.maxc = 0; s.pad = 0;
+    if (sp_ngrp[sp]) { const uint32_t f = sp_first[sp]; s.ebase = ge[f]; s.gbase = f; s.nent = sp_nent[sp]; s.ngrp = sp_ngrp[sp]; s.maxc = sp_maxc[sp]; }
+    spans[sp] = s;
+}
+
+__global__ void __launch_bounds__(256)
+k_wgdesc(uint32_t nkept, const uint32_t *ge, const uint32_t *gs, const uint32_t *sp_first, uint32_t C, uint32_t *groups) {
+    const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= nkept) return;
+    const uint32_t sp = ge[r] / C;
+    groups[r] = ((ge[r] - ge[sp_first[sp]]) << 16) | gs[r];       // start inside the span | size
+}
+
+// --------------------------------------------------------------------------------------------
+static inline dim3 grid_for(uint64_t n) { return dim3((uint32_t)((n + 255) / 256)); }
+
+// stable sort of n (hi, lo) keys (+ optional 32-bit payload) by (hi, lo): LSD, lo first.  In: hi0/lo0(/p0); out: hi1/lo1(/p1).
+static int wide_sort(SimkaWide *w, uint64_t n, uint32_t hi_bits, ull *hi0, ull *lo0, ull *hi1, ull *lo1, ull *tmp_key, uint32_t *idx0, uint32_t *idx1) {
+    if (n == 0) return 0;
+    if (n >= ((uint64_t)1 << 31)) { w->err = "wide-k path: more than 2^31 k-mers in one sort (sample too deep for k >= 32)"; return SIMKA_WIDE_ERR_LIMIT; }
+    size_t tb = 0, tb2 = 0;
+    WCHK(hipcub::DeviceRadixSort::SortPairs(nullptr, tb, lo0, tmp_key, idx0, idx1, (int)n, 0, 64, w->stream));
+    WCHK(hipcub::DeviceRadixSort::SortPairs(nullptr, tb2, hi0, hi1, idx0, idx1, (int)n, 0, (int)hi_bits, w->stream));
+    char *tmp; int rc = wide_buf(w, 11, std::max(tb, tb2), &tmp); if (rc) return rc;
+    hipLaunchKernelGGL(k_wiota, grid_for(n), dim3(256), 0, w->stream, idx0, n);
+    tb = std::max(tb, tb2);
+    size_t t1 = tb;
+    WCHK(hipcub::DeviceRadixSort::SortPairs(tmp, t1, lo0, tmp_key, idx0, idx1, (int)n, 0, 64, w->stream));          // by lo; idx1 = permutation
+    hipLaunchKernelGGL(k_wgather, grid_for(n), dim3(256), 0, w->stream, hi0, idx1, lo1, n);                          // lo1 := hi in lo-order (scratch use)
+    t1 = tb;
+    WCHK(hipcub::DeviceRadixSort::SortPairs(tmp, t1, lo1, hi1, idx1, idx0, (int)n, 0, (int)hi_bits, w->stream));    // by hi (stable); idx0 = final permutation
+    hipLaunchKernelGGL(k_wgather, grid_for(n), dim3(256), 0, w->stream, lo0, idx0, lo1, n);
+    WCHK(hipGetLastError());
+    return 0;
+}
+
+int simka_wide_create(SimkaWide **out, int device, uint32_t nb_samples, uint32_t k, void *stream) {
+    SimkaWide *w = new SimkaWide();
+    w->device = device; w->nb_samples = nb_samples; w->k = k; w->W = 2 * k; w->stream = (hipStream_t)stream;
+    w->s_off.assign(nb_samples, 0); w->s_n.assign(nb_samples, 0);
+    *out = w;
+    return 0;
+}
+
+const char *simka_wide_error(SimkaWide *w) { return w ? w->err.c_str() : ""; }
+
+void simka_wide_destroy(SimkaWide *w) {
+    if (!w) return;
+    (void)hipStreamSynchronize(w->stream);
+    for (void *p : w->scratch) if (p) (void)hipFree(p);
+    void *own[] = { w->a_hi, w->a_lo, w->a_cnt, w->entries, w->groups, w->spans, w->huge, w->cursors };
+    for (void *p : own) if (p) (void)hipFree(p);
+    delete w;
+}
+
+int simka_wide_reset(SimkaWide *w) {
+    w->a_used = 0;
+    std::fill(w->s_off.begin(), w->s_off.end(), 0); std::fill(w->s_n.begin(), w->s_n.end(), 0);
+    return 0;
+}
+
+static int arena_reserve(SimkaWide *w, uint64_t extra) {
+    if (w->a_used + extra <= w->a_cap) return 0;
+    const uint64_t ncap = std::max<uint64_t>((w->a_used + extra) * 3 / 2, (uint64_t)1 << 20);
+    ull *nh = nullptr, *nl = nullptr; uint32_t *nc = nullptr;
+    if (hipMalloc(&nh, ncap * 8) != hipSuccess || hipMalloc(&nl, ncap * 8) != hipSuccess || hipMalloc(&nc, ncap * 4) != hipSuccess) {
+        if (nh) (void)hipFree(nh); if (nl) (void)hipFree(nl); if (nc) (void)hipFree(nc);
+        w->err = "wide-k path: cannot grow the solid-spectrum arena"; return SIMKA_WIDE_ERR_NOMEM;
+    }
+    if (w->a_used) {
+        WCHK(hipMemcpyAsync(nh, w->a_hi, w->a_used * 8, hipMemcpyDeviceToDevice, w->stream));
+        WCHK(hipMemcpyAsync(nl, w->a_lo, w->a_used * 8, hipMemcpyDeviceToDevice, w->stream));
+        WCHK(hipMemcpyAsync(nc, w->a_cnt, w->a_used * 4, hipMemcpyDeviceToDevice, w->stream));
+    }
+    WCHK(hipStreamSynchronize(w->stream));
+    if (w->a_hi) (void)hipFree(w->a_hi); if (w->a_lo) (void)hipFree(w->a_lo); if (w->a_cnt) (void)hipFree(w->a_cnt);
+    w->a_hi = nh; w->a_lo = nl; w->a_cnt = nc; w->a_cap = ncap;
+    return 0;
+}
+
+int simka_wide_count_sample(SimkaWide *w, uint32_t sample, const void *packed, uint64_t nb_bases, uint64_t nb_words, const void *offsets, uint64_t nb_reads,
+                            uint32_t fixed_len, uint32_t amin, uint32_t amax, unsigned long long totals5[5], void *d_hist_row, void *d_ovf_list,
+                            void *d_ovf_cursor, uint64_t ovf_cap) {
+    for (int i = 0; i < 5; i++) totals5[i] = 0;
+    w->s_off[sample] = w->a_used; w->s_n[sample] = 0;
+    if (nb_bases == 0) return 0;
+    const uint64_t n = nb_bases;
+    ull *hi0, *lo0, *hi1, *lo1, *tkey; uint32_t *idx0, *idx1; ull *d_small;
+    int rc;
+    if ((rc = wide_buf(w, 0, n, &hi0)) || (rc = wide_buf(w, 1, n, &lo0)) || (rc = wide_buf(w, 2, n, &hi1)) || (rc = wide_buf(w, 3, n, &lo1)) ||
+        (rc = wide_buf(w, 4, n, &tkey)) || (rc = wide_buf(w, 5, n + 2, &idx0)) || (rc = wide_buf(w, 6, n + 2, &idx1)) || (rc = wide_buf(w, 7, 16, &d_small))) return rc;
+    WCHK(hipMemsetAsync(d_small, 0, 16 * 8, w->stream));
+    const uint32_t hi_bits = (w->W > 64 ? w->W - 64 : 0) + 1;          // one more bit: the sentinel
+    const ull sent_hi = 1ull << (hi_bits - 1);
+    WideScanArgs a; a.packed = (const uint64_t *)packed; a.nb_bases = nb_bases; a.nb_words = nb_words; a.offsets = (const uint64_t *)offsets;
+    a.nb_reads = nb_reads; a.fixed_len = fixed_len; a.k = w->k;
+    hipLaunchKernelGGL(k_wscan, grid_for((n + WSEG - 1) / WSEG), dim3(256), 0, w->stream, a, sent_hi, hi0, lo0, d_small /* [0] = nvalid */);
+    if ((rc = wide_sort(w, n, hi_bits, hi0, lo0, hi1, lo1, tkey, idx0, idx1))) return rc;
+    ull nvalid = 0;
+    WCHK(hipMemcpyAsync(&nvalid, d_small, 8, hipMemcpyDeviceToHost, w->stream));
+    WCHK(hipStreamSynchronize(w->stream));
+    totals5[SIMKA_TOT_KOCC] = nvalid;
+    if (nvalid == 0) return 0;
+    // runs of equal keys among the first nvalid sorted entries (the sentinels sort last)
+    uint32_t *flag = idx0, *rank = idx1, *start, *sflag, *srank;
+    if ((rc = wide_buf(w, 8, nvalid + 2, &start)) || (rc = wide_buf(w, 9, nvalid + 2, &sflag)) || (rc = wide_buf(w, 10, nvalid + 2, &srank))) return rc;
+    hipLaunchKernelGGL(k_wheads, grid_for(nvalid), dim3(256), 0, w->stream, hi1, lo1, nvalid, flag);
+    size_t tb = 0;
+    WCHK(hipcub::DeviceScan::ExclusiveSum(nullptr, tb, flag, rank, (int)nvalid, w->stream));
+    char *tmp; if ((rc = wide_buf(w, 11, tb, &tmp))) return rc;
+    WCHK(hipcub::DeviceScan::ExclusiveSum(tmp, tb, flag, rank, (int)nvalid, w->stream));
+    hipLaunchKernelGGL(k_wstarts, grid_for(nvalid), dim3(256), 0, w->stream, flag, rank, nvalid, start, (const uint32_t *)nullptr);
+    uint32_t last_rank = 0, last_flag = 0;
+    WCHK(hipMemcpyAsync(&last_rank, rank + (nvalid - 1), 4, hipMemcpyDeviceToHost, w->stream));
+    WCHK(hipMemcpyAsync(&last_flag, flag + (nvalid - 1), 4, hipMemcpyDeviceToHost, w->stream));
+    WCHK(hipStreamSynchronize(w->stream));
+    const uint32_t nruns = last_rank + last_flag;
+    totals5[SIMKA_TOT_DALL] = nruns;
+    hipLaunchKernelGGL(k_wfilter, grid_for(nruns), dim3(256), 0, w->stream, start, nruns, amin, amax, sflag, d_small + 1, (ull *)d_hist_row, (uint32_t *)d_ovf_list,
+                       (ull *)d_ovf_cursor, (ull)ovf_cap, sample);
+    tb = 0;
+    WCHK(hipcub::DeviceScan::ExclusiveSum(nullptr, tb, sflag, srank, (int)nruns, w->stream));
+    if ((rc = wide_buf(w, 11, tb, &tmp))) return rc;
+    WCHK(hipcub::DeviceScan::ExclusiveSum(tmp, tb, sflag, srank, (int)nruns, w->stream));
+    ull dnq[3]; uint32_t lr = 0, lf = 0;
+    WCHK(hipMemcpyAsync(dnq, d_small + 1, 24, hipMemcpyDeviceToHost, w->stream));
+    WCHK(hipMemcpyAsync(&lr, srank + (nruns - 1), 4, hipMemcpyDeviceToHost, w->stream));
+    WCHK(hipMemcpyAsync(&lf, sflag + (nruns - 1), 4, hipMemcpyDeviceToHost, w->stream));
+    WCHK(hipStreamSynchronize(w->stream));
+    const uint64_t nsolid = (uint64_t)lr + lf;
+    totals5[SIMKA_TOT_D] = dnq[0]; totals5[SIMKA_TOT_N] = dnq[1]; totals5[SIMKA_TOT_Q] = dnq[2];
+    if ((rc = arena_reserve(w, nsolid))) return rc;
+    if (nsolid) hipLaunchKernelGGL(k_wemit, grid_for(nruns), dim3(256), 0, w->stream, hi1, lo1, start, sflag, srank, nruns, w->a_hi + w->a_used, w->a_lo + w->a_used,
+                                   w->a_cnt + w->a_used);
+    WCHK(hipGetLastError());
+    w->s_n[sample] = nsolid;
+    w->a_used += nsolid;
+    return 0;
+}
+
+int simka_wide_merge(SimkaWide *w, uint32_t span_cap, SimkaWideCsr *out) {
+    const uint64_t M = w->a_used;
+    const uint32_t N = w->nb_samples;
+    out->nb_distinct = 0; out->nb_shared = 0; out->entries = nullptr; out->groups = nullptr; out->spans = nullptr; out->cursors = nullptr; out->nb_spans = 0; out->huge = nullptr; out->nb_huge = 0;
+    if (M == 0) return 0;
+    const uint32_t maxg = std::min<uint32_t>(N, span_cap / 2 - 8);     // larger groups cannot share a span: huge list
+    int rc;
+    ull *val, *hi1, *lo1, *tkey, *val2; uint32_t *idx0, *idx1;
+    if ((rc = wide_buf(w, 0, M, &val)) || (rc = wide_buf(w, 1, M, &hi1)) || (rc = wide_buf(w, 2, M, &lo1)) || (rc = wide_buf(w, 3, M, &tkey)) ||
+        (rc = wide_buf(w, 4, M, &val2)) || (rc = wide_buf(w, 5, M + 2, &idx0)) || (rc = wide_buf(w, 6, M + 2, &idx1))) return rc;
+    for (uint32_t s = 0; s < N; s++)
+        if (w->s_n[s]) hipLaunchKernelGGL(k_wvals, grid_for(w->s_n[s]), dim3(256), 0, w->stream, w->a_cnt, w->s_off[s], w->s_n[s], s, val);
+    const uint32_t hi_bits = (w->W > 64 ? w->W - 64 : 0) + 1;
+    if ((rc = wide_sort(w, M, hi_bits, w->a_hi, w->a_lo, hi1, lo1, tkey, idx0, idx1))) return rc;     // idx0 = final permutation
+    hipLaunchKernelGGL(k_wgather, grid_for(M), dim3(256), 0, w->stream, val, idx0, val2, M);
+    // groups = runs of equal k-mers
+    uint32_t *flag = idx0, *rank = idx1, *gstart, *kflag, *ksize, *krank, *eoff;
+    if ((rc = wide_buf(w, 7, M + 2, &gstart)) || (rc = wide_buf(w, 8, M + 2, &kflag)) || (rc = wide_buf(w, 9, M + 2, &ksize))) return rc;
+    hipLaunchKernelGGL(k_wheads, grid_for(M), dim3(256), 0, w->stream, hi1, lo1, M, flag);
+    size_t tb = 0;
+    WCHK(hipcub::DeviceScan::ExclusiveSum(nullptr, tb, flag, rank, (int)M, w->stream));
+    char *tmp; if ((rc = wide_buf(w, 11, tb, &tmp))) return rc;
+    WCHK(hipcub::DeviceScan::ExclusiveSum(tmp, tb, flag, rank, (int)M, w->stream));
+    hipLaunchKernelGGL(k_wstarts, grid_for(M), dim3(256), 0, w->stream, flag, rank, M, gstart, (const uint32_t *)nullptr);
+    uint32_t lr = 0, lf = 0;
+    WCHK(hipMemcpyAsync(&lr, rank + (M - 1), 4, hipMemcpyDeviceToHost, w->stream));
+    WCHK(hipMemcpyAsync(&lf, flag + (M - 1), 4, hipMemcpyDeviceToHost, w->stream));
+    WCHK(hipStreamSynchronize(w->stream));
+    const uint32_t ngroups = lr + lf;
+    out->nb_distinct = ngroups;
+    // kept groups (2..maxg samples): rank and entry offset.  flag / rank (idx0 / idx1) are free again: reuse them.
+    krank = idx0; eoff = idx1;
+    auto scan_class = [&](uint32_t huge, uint32_t &count, uint64_t &nentries) -> int {
+        hipLaunchKernelGGL(k_wgsizes, grid_for(ngroups), dim3(256), 0, w->stream, gstart, ngroups, maxg, huge, kflag, ksize);
+        size_t tb2 = 0;
+        WCHK(hipcub::DeviceScan::ExclusiveSum(nullptr, tb2, kflag, krank, (int)ngroups, w->stream));
+        char *tmp2; int r2 = wide_buf(w, 11, tb2, &tmp2); if (r2) return r2;
+        WCHK(hipcub::DeviceScan::ExclusiveSum(tmp2, tb2, kflag, krank, (int)ngroups, w->stream));
+        WCHK(hipcub::DeviceScan::ExclusiveSum(tmp2, tb2, ksize, eoff, (int)ngroups, w->stream));
+        uint32_t a4[4] = { 0, 0, 0, 0 };
+        WCHK(hipMemcpyAsync(&a4[0], krank + (ngroups - 1), 4, hipMemcpyDeviceToHost, w->stream));
+        WCHK(hipMemcpyAsync(&a4[1], kflag + (ngroups - 1), 4, hipMemcpyDeviceToHost, w->stream));
+        WCHK(hipMemcpyAsync(&a4[2], eoff + (ngroups - 1), 4, hipMemcpyDeviceToHost, w->stream));
+        WCHK(hipMemcpyAsync(&a4[3], ksize + (ngroups - 1), 4, hipMemcpyDeviceToHost, w->stream));
+        WCHK(hipStreamSynchronize(w->stream));
+        count = a4[0] + a4[1]; nentries = (uint64_t)a4[2] + a4[3];
+        return 0;
+    };
+    uint32_t nhuge = 0, nkept = 0; uint64_t hent = 0, nent = 0;
+    if (maxg < N) { if ((rc = scan_class(1, nhuge, hent))) return rc; }
+    // CSR (owned by the wide state); the huge groups' entries follow the ordinary ones -- sizes are needed first: ordinary class last
+    void *old[] = { w->entries, w->groups, w->spans, w->huge, w->cursors };
+    for (void *p : old) if (p) WCHK(hipFree(p));
+    w->entries = nullptr; w->groups = nullptr; w->spans = nullptr; w->huge = nullptr; w->cursors = nullptr;
+    ull *h_entries = nullptr;
+    if (nhuge) {      // stage the huge groups now (the scan buffers are reused below)
+        WCHK(hipMalloc(&h_entries, (hent + 16) * 8));
+        WCHK(hipMalloc(&w->huge, ((uint64_t)nhuge + 4) * sizeof(SimkaSpan)));
+        hipLaunchKernelGGL(k_whuge, grid_for(ngroups), dim3(256), 0, w->stream, gstart, ngroups, kflag, krank, eoff, val2, 0ull, h_entries, w->huge);
+    }
+    if ((rc = scan_class(0, nkept, nent))) { if (h_entries) (void)hipFree(h_entries); return rc; }
+    out->nb_shared = (uint64_t)nkept + nhuge;
+    if (nkept == 0 && nhuge == 0) return 0;
+    const uint32_t C = span_cap - maxg - 8;                   // a span holds the groups that START inside a window of C entries: < span_cap entries
+    const uint32_t nspans = (uint32_t)((nent + C - 1) / C);
+    WCHK(hipMalloc(&w->entries, (nent + hent + 16) * 8)); WCHK(hipMalloc(&w->groups, ((uint64_t)nkept + 16) * 4));
+    WCHK(hipMalloc(&w->spans, ((uint64_t)nspans + 4) * sizeof(SimkaSpan))); WCHK(hipMalloc(&w->cursors, 64));
+    WCHK(hipMemsetAsync(w->cursors, 0, 64, w->stream));
+    if (nhuge) {      // the huge entries move behind the ordinary ones; their spans' ebase shifts by nent (k_pairs_global reads entries + ebase)
+        WCHK(hipMemcpyAsync(w->entries + nent, h_entries, hent * 8, hipMemcpyDeviceToDevice, w->stream));
+        std::vector<SimkaSpan> hs(nhuge);
+        WCHK(hipMemcpyAsync(hs.data(), w->huge, (size_t)nhuge * sizeof(SimkaSpan), hipMemcpyDeviceToHost, w->stream));
+        WCHK(hipStreamSynchronize(w->stream));
+        for (auto &sp : hs) sp.ebase += nent;
+        WCHK(hipMemcpyAsync(w->huge, hs.data(), (size_t)nhuge * sizeof(SimkaSpan), hipMemcpyHostToDevice, w->stream));
+        const ull nh = nhuge;
+        WCHK(hipMemcpyAsync(w->cursors + 3, &nh, 8, hipMemcpyHostToDevice, w->stream));
+        WCHK(hipStreamSynchronize(w->stream));
+        (void)hipFree(h_entries);
+    }
+    if (nkept) {
+        uint32_t *ge, *gs, *spb;
+        if ((rc = wide_buf(w, 0, (uint64_t)nkept + 2, &ge)) || (rc = wide_buf(w, 3, (uint64_t)nkept + 2, &gs)) || (rc = wide_buf(w, 10, (uint64_t)nspans * 4 + 8, &spb))) return rc;
+        uint32_t *sp_first = spb, *sp_ngrp = spb + nspans, *sp_nent = spb + 2 * (uint64_t)nspans, *sp_maxc = spb + 3 * (uint64_t)nspans;
+        WCHK(hipMemsetAsync(sp_first, 0xff, (size_t)nspans * 4, w->stream));
+        WCHK(hipMemsetAsync(sp_ngrp, 0, (size_t)nspans * 12, w->stream));
+        hipLaunchKernelGGL(k_wgroups, grid_for(ngroups), dim3(256), 0, w->stream, gstart, ngroups, kflag, krank, eoff, val2, C, w->entries, ge, gs, sp_first, sp_ngrp,
+                           sp_nent, sp_maxc);
+        hipLaunchKernelGGL(k_wspans, grid_for(nspans), dim3(256), 0, w->stream, nspans, sp_first, sp_ngrp, sp_nent, sp_maxc, ge, w->spans, w->cursors);
+        hipLaunchKernelGGL(k_wgdesc, grid_for(nkept), dim3(256), 0, w->stream, nkept, ge, gs, sp_first, C, w->groups);
+    }
+    WCHK(hipGetLastError());
+    WCHK(hipStreamSynchronize(w->stream));
+    out->huge = w->huge; out->nb_huge = nhuge;
+    out->entries = w->entries; out->groups = w->groups; out->spans = w->spans; out->cursors = w->cursors; out->nb_spans = nkept ? nspans : 0;
+    return 0;
+}

@@ -734,3 +734,45 @@ def test_cli_spectra_larger_than_the_arena_merge_by_partition_ranges(gpu_require
     assert "partition ranges" in run(str(tmp_path / "o1"), ["-merge-ranges", "3"])
     log = run(str(tmp_path / "o2"), ["-solid-capacity", "20000"])          # the 5 samples hold ~45000 solid k-mers
     assert "do not fit the GPU memory" in log and "partition ranges" in log
+
+
+@pytest.mark.parametrize("k,amin,n,R,L", [(21, 2, 5, 3000, 100), (31, 1, 4, 2000, 150), (9, 2, 3, 1500, 80), (32, 2, 4, 2500, 120),
+                                          (33, 1, 4, 2500, 120), (47, 2, 5, 2500, 150), (63, 1, 3, 2000, 150)])
+def test_sort_based_path_for_wide_kmers(gpu_required, oracle_mod, monkeypatch, k, amin, n, R, L):
+    """k >= 32 (k-mers of up to 126 bits, the reference's span-64 build) takes the sort-based path of simka_wide.hip; the same
+    path is forced for k <= 31 (SIMKA_SORT_PATH) as a cross-check of the hash pipeline.  Totals and every accumulator vs the
+    oracle (128-bit k-mers), -simple-dist and -complex-dist; variable-length layout for one case.  k >= 32 has no golden
+    vectors in the reference (parity unpinned): the oracle is the same code that reproduces the k = 21 / 31 goldens."""
+    from simka_amd import synth
+    monkeypatch.setenv("SIMKA_SORT_PATH", "1")
+    packed = _synthetic(n, R, L, seed_shift=70)
+    offs = np.arange(R + 1, dtype=np.uint64) * L
+    inputs = [(np.concatenate([pk, np.zeros(2, dtype=np.uint64)]), offs, R * L, R) for pk in packed]
+    totals, st = _run_gpu(inputs, k, amin, simple=True)
+    orc = oracle_mod.Oracle()
+    for s, pk in enumerate(packed):
+        orc.add_sample_ascii("S%d" % s, synth.unpack_ascii(pk, R * L), offs)
+    orc.run(k, amin, simple=True, complex_=True)
+    _check_vs_oracle(totals, st, orc)
+    for w, name in enumerate(orc.matrix_names()):
+        if name in st.matrices():
+            np.testing.assert_allclose(st.matrices()[name], orc.matrix(w), rtol=1e-6, atol=0)
+
+
+def test_example_goldens_through_the_sort_path(gpu_required, golden_dir, tmp_path, monkeypatch):
+    """The reference's own example (k = 31, abundance-min 2, all 20 matrices) through the sort-based path: the CSV bytes of
+    tests/truth must come out of BOTH pipelines."""
+    monkeypatch.setenv("SIMKA_SORT_PATH", "1")
+    samples, packed = _load_example(golden_dir)
+    totals, st = _run_gpu(packed, 31, 2, simple=True)
+    out = str(tmp_path / "res")
+    st.write_matrices(out, [s["id"] for s in samples], gz=True)
+    truth = os.path.join(golden_dir, "truth", "results_k31_t2")
+    n = 0
+    for gzf in glob.glob(os.path.join(out, "*.csv.gz")):
+        ref = os.path.join(truth, os.path.basename(gzf)[:-3])
+        if os.path.exists(ref):
+            with gzip.open(gzf, "rb") as f, open(ref, "rb") as g:
+                assert f.read() == g.read(), os.path.basename(gzf)
+            n += 1
+    assert n == 20
