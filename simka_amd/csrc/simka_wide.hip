@@ -161,20 +161,23 @@ k_wstarts(const uint32_t *flag, const uint32_t *rank, uint64_t n, uint32_t *star
 __global__ void __launch_bounds__(256)
 k_wfilter(const uint32_t *start, uint32_t nruns, uint32_t amin, uint32_t amax, uint32_t *sflag, ull *tot /* D N Q */,
           ull *hist, uint32_t *ovf_list, ull *ovf_cursor, ull ovf_cap, uint32_t sample) {
-    const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+    __shared__ uint32_t lhist[SIMKA_HIST_MAX];      // -complex-dist: the block's histogram of solid counts, flushed once
+    if (hist) { for (uint32_t i = threadIdx.x; i < SIMKA_HIST_MAX; i += blockDim.x) lhist[i] = 0; __syncthreads(); }
     ull D = 0, N = 0, Q = 0;
-    if (j < nruns) {
+    // grid-stride: a few thousand waves add their partial totals, not one wave per 64 runs (same-address atomics serialise)
+    for (uint32_t j = blockIdx.x * blockDim.x + threadIdx.x; j < nruns; j += gridDim.x * blockDim.x) {
         const uint32_t c = start[j + 1] - start[j];
         const bool solid = !(c < amin || c > amax);
         sflag[j] = solid ? 1u : 0u;
         if (solid) {
-            D = 1; N = c; Q = (ull)c * (ull)c;
+            D += 1; N += c; Q += (ull)c * (ull)c;
             if (hist) {
-                if (c < SIMKA_HIST_MAX) atomicAdd(&hist[c], 1ull);
+                if (c < SIMKA_HIST_MAX) atomicAdd(&lhist[c], 1u);
                 else { const ull wq = atomicAdd(ovf_cursor, 1ull); if (wq < ovf_cap) { ovf_list[2 * wq] = sample; ovf_list[2 * wq + 1] = c; } }
             }
         }
     }
+    if (hist) { __syncthreads(); for (uint32_t i = threadIdx.x; i < SIMKA_HIST_MAX; i += blockDim.x) if (lhist[i]) atomicAdd(&hist[i], (ull)lhist[i]); }
     for (int o = 32; o > 0; o >>= 1) { D += __shfl_down(D, o, 64); N += __shfl_down(N, o, 64); Q += __shfl_down(Q, o, 64); }
     if ((threadIdx.x & 63u) == 0 && D) { atomicAdd(&tot[0], D); atomicAdd(&tot[1], N); atomicAdd(&tot[2], Q); }
 }
@@ -360,7 +363,7 @@ int simka_wide_count_sample(SimkaWide *w, uint32_t sample, const void *packed, u
     WCHK(hipStreamSynchronize(w->stream));
     const uint32_t nruns = last_rank + last_flag;
     totals5[SIMKA_TOT_DALL] = nruns;
-    hipLaunchKernelGGL(k_wfilter, grid_for(nruns), dim3(256), 0, w->stream, start, nruns, amin, amax, sflag, d_small + 1, (ull *)d_hist_row, (uint32_t *)d_ovf_list,
+    hipLaunchKernelGGL(k_wfilter, dim3((uint32_t)std::min<uint64_t>((nruns + 255) / 256, 2048)), dim3(256), 0, w->stream, start, nruns, amin, amax, sflag, d_small + 1, (ull *)d_hist_row, (uint32_t *)d_ovf_list,
                        (ull *)d_ovf_cursor, (ull)ovf_cap, sample);
     tb = 0;
     WCHK(hipcub::DeviceScan::ExclusiveSum(nullptr, tb, sflag, srank, (int)nruns, w->stream));
