@@ -11,7 +11,7 @@
 //           merge builds, consumed by the same k_pairs kernel.
 //
 // The radix sorts and prefix sums are rocPRIM/hipCUB library calls (plain primitives); everything else is hand-written.
-// Much slower than the hash pipeline (C2: 266 ms against 12 ms per step; every base position goes through two 64-bit radix
+// Much slower than the hash pipeline (C2: ~150 ms against 12 ms per step; every base position goes through two 64-bit radix
 // sorts), exact, and an independent cross-check of it: with SIMKA_SORT_PATH=1 the k <= 31 tests run through this path and
 // must give bit-identical statistics (they do: goldens included).
 #include <hip/hip_runtime.h>
