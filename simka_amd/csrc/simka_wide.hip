@@ -281,6 +281,23 @@ static int wide_sort(SimkaWide *w, uint64_t n, uint32_t hi_bits, ull *hi0, ull *
     return 0;
 }
 
+// the same order without a permutation (count side): the other word rides along as the VALUE of each sort.
+// In: hi0/lo0 (+ scratch hi1/lo1); out: sorted by (hi, lo), back in hi0/lo0.
+static int wide_sort_words(SimkaWide *w, uint64_t n, uint32_t hi_bits, ull *hi0, ull *lo0, ull *hi1, ull *lo1) {
+    if (n == 0) return 0;
+    if (n >= ((uint64_t)1 << 31)) { w->err = "wide-k path: more than 2^31 k-mers in one sort (sample too deep for k >= 32)"; return SIMKA_WIDE_ERR_LIMIT; }
+    size_t tb = 0, tb2 = 0;
+    WCHK(hipcub::DeviceRadixSort::SortPairs(nullptr, tb, lo0, lo1, hi0, hi1, (int)n, 0, 64, w->stream));
+    WCHK(hipcub::DeviceRadixSort::SortPairs(nullptr, tb2, hi1, hi0, lo1, lo0, (int)n, 0, (int)hi_bits, w->stream));
+    tb = std::max(tb, tb2);
+    char *tmp; int rc = wide_buf(w, 11, tb, &tmp); if (rc) return rc;
+    size_t t1 = tb;
+    WCHK(hipcub::DeviceRadixSort::SortPairs(tmp, t1, lo0, lo1, hi0, hi1, (int)n, 0, 64, w->stream));              // by lo: (lo1, hi1)
+    t1 = tb;
+    WCHK(hipcub::DeviceRadixSort::SortPairs(tmp, t1, hi1, hi0, lo1, lo0, (int)n, 0, (int)hi_bits, w->stream));    // by hi, stable: (hi0, lo0)
+    return 0;
+}
+
 int simka_wide_create(SimkaWide **out, int device, uint32_t nb_samples, uint32_t k, void *stream) {
     SimkaWide *w = new SimkaWide();
     w->device = device; w->nb_samples = nb_samples; w->k = k; w->W = 2 * k; w->stream = (hipStream_t)stream;
@@ -342,7 +359,8 @@ int simka_wide_count_sample(SimkaWide *w, uint32_t sample, const void *packed, u
     WideScanArgs a; a.packed = (const uint64_t *)packed; a.nb_bases = nb_bases; a.nb_words = nb_words; a.offsets = (const uint64_t *)offsets;
     a.nb_reads = nb_reads; a.fixed_len = fixed_len; a.k = w->k;
     hipLaunchKernelGGL(k_wscan, grid_for((n + WSEG - 1) / WSEG), dim3(256), 0, w->stream, a, sent_hi, hi0, lo0, d_small /* [0] = nvalid */);
-    if ((rc = wide_sort(w, n, hi_bits, hi0, lo0, hi1, lo1, tkey, idx0, idx1))) return rc;
+    if ((rc = wide_sort_words(w, n, hi_bits, hi0, lo0, hi1, lo1))) return rc;
+    hi1 = hi0; lo1 = lo0;            // the sorted words
     ull nvalid = 0;
     WCHK(hipMemcpyAsync(&nvalid, d_small, 8, hipMemcpyDeviceToHost, w->stream));
     WCHK(hipStreamSynchronize(w->stream));
