@@ -11,7 +11,7 @@
 //           merge builds, consumed by the same k_pairs kernel.
 //
 // The radix sorts and prefix sums are rocPRIM/hipCUB library calls (plain primitives); everything else is hand-written.
-// Much slower than the hash pipeline (C2: ~150 ms against 12 ms per step; every base position goes through two 64-bit radix
+// Much slower than the hash pipeline (C2: ~100 ms against 12 ms per step; every base position goes through two 64-bit radix
 // sorts), exact, and an independent cross-check of it: with SIMKA_SORT_PATH=1 the k <= 31 tests run through this path and
 // must give bit-identical statistics (they do: goldens included).
 #include <hip/hip_runtime.h>
@@ -62,8 +62,7 @@ static int wide_buf(SimkaWide *w, int slot, uint64_t n, T **out) {
 // --------------------------------------------------------------------------------------------
 // k_wscan: thread = WSEG consecutive END positions of the concatenated base array.  It warms up on the k-1 bases before
 // its first position (inside the same read), then rolls the forward and reverse-complement words one base at a time.
-// keys[e] = canonical k-mer ending at base e, or the sentinel (hi = 1 << (W-64) or 1, lo = 0), which sorts after
-// every valid key.
+// Only whole k-mers are written, compacted (block scan of the per-thread counts + one global atomic per block).
 // --------------------------------------------------------------------------------------------
 #define WSEG 32
 
@@ -72,29 +71,50 @@ struct WideScanArgs { const uint64_t *packed; uint64_t nb_bases, nb_words; const
 __device__ __forceinline__ uint32_t wbase(const uint64_t *packed, uint64_t p) { return (uint32_t)(packed[p >> 5] >> ((p & 31u) * 2u)) & 3u; }
 
 __global__ void __launch_bounds__(256)
-k_wscan(WideScanArgs a, ull sent_hi, ull *khi, ull *klo, ull *nvalid) {
+k_wscan(WideScanArgs a, ull *khi, ull *klo, ull *nvalid) {
+    __shared__ uint32_t s_wave[4];
+    __shared__ ull s_base;
     const uint64_t p0 = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) * WSEG;
-    uint32_t nv = 0;
-    if (p0 < a.nb_bases) {
     const uint32_t k = a.k;
-    // the read that holds base p0
-    uint64_t rd, rstart, rend;
-    if (a.fixed_len) { rd = p0 / a.fixed_len; rstart = rd * a.fixed_len; rend = rstart + a.fixed_len; }
-    else {
-        uint64_t lo = 0, hi = a.nb_reads;
-        while (hi - lo > 1) { const uint64_t mid = (lo + hi) >> 1; if (a.offsets[mid] <= p0) lo = mid; else hi = mid; }
-        rd = lo; rstart = a.offsets[rd]; rend = a.offsets[rd + 1];
+    const bool active = p0 < a.nb_bases;
+    uint64_t rd = 0, rstart = 0, rend = 0;
+    const uint64_t pend = active ? (p0 + WSEG < a.nb_bases ? p0 + WSEG : a.nb_bases) : 0;
+    uint32_t cnt = 0;
+    if (active) {
+        // the read that holds base p0
+        if (a.fixed_len) { rd = p0 / a.fixed_len; rstart = rd * a.fixed_len; rend = rstart + a.fixed_len; }
+        else {
+            uint64_t lo = 0, hi = a.nb_reads;
+            while (hi - lo > 1) { const uint64_t mid = (lo + hi) >> 1; if (a.offsets[mid] <= p0) lo = mid; else hi = mid; }
+            rd = lo; rstart = a.offsets[rd]; rend = a.offsets[rd + 1];
+        }
+        // pass 1 (no bases touched): how many of my end positions close a whole k-mer inside one read
+        uint64_t rr = rd, rs = rstart, re = rend;
+        for (uint64_t p = p0; p < pend; p++) {
+            while (p >= re) { rr++; rs = re; re = a.fixed_len ? rs + a.fixed_len : a.offsets[rr + 1]; }
+            if (p - rs >= (uint64_t)(k - 1u)) cnt++;
+        }
     }
-    // masks of the 2k-bit k-mer as (hi, lo)
+    // output slots: block scan of the counts + one global atomic per block (the order of the keys is irrelevant: they get sorted)
+    uint32_t incl = cnt;
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    for (int o = 1; o < 64; o <<= 1) { const uint32_t t = __shfl_up(incl, o, 64); if (lane >= (uint32_t)o) incl += t; }
+    if (lane == 63u) s_wave[wave] = incl;
+    __syncthreads();
+    uint32_t wpre = 0, btot = 0;
+    for (uint32_t i = 0; i < 4; i++) { if (i < wave) wpre += s_wave[i]; btot += s_wave[i]; }
+    if (threadIdx.x == 0) s_base = btot ? atomicAdd(nvalid, (ull)btot) : 0ull;
+    __syncthreads();
+    if (!active || cnt == 0) return;
+    ull wr = s_base + wpre + incl - cnt;
+    // pass 2: roll the forward / reverse-complement words; warm up on the k-1 bases before my first position (same read)
     const uint32_t W = 2u * k;
     const ull mlo = W >= 64u ? ~0ull : ((1ull << W) - 1ull);
     const ull mhi = W > 64u ? ((1ull << (W - 64u)) - 1ull) : 0ull;
     const uint32_t top = 2u * (k - 1u);                      // bit position of the first base in the reverse-complement word
     ull fh = 0, fl = 0, rh = 0, rl = 0;
     uint32_t have = 0;                                        // bases of the current read inside the window (capped at k)
-    uint64_t p = p0 > rstart + (k - 1u) ? p0 - (k - 1u) : rstart;   // warm-up start
-    const uint64_t pend = p0 + WSEG < a.nb_bases ? p0 + WSEG : a.nb_bases;
-    for (; p < pend; p++) {
+    for (uint64_t p = p0 > rstart + (k - 1u) ? p0 - (k - 1u) : rstart; p < pend; p++) {
         while (p >= rend) {        // next read (fixed length: arithmetic; else the offsets array)
             rd++;
             rstart = rend;
@@ -102,29 +122,19 @@ k_wscan(WideScanArgs a, ull sent_hi, ull *khi, ull *klo, ull *nvalid) {
             have = 0; fh = fl = rh = rl = 0;
         }
         const ull c = wbase(a.packed, p);
-        // forward: (f << 2 | c) & mask
-        fh = ((fh << 2) | (fl >> 62)) & mhi;
+        fh = ((fh << 2) | (fl >> 62)) & mhi;                 // forward: (f << 2 | c) & mask
         fl = ((fl << 2) | c) & mlo;
-        // reverse complement: (r >> 2) | (c ^ 2) << 2(k-1)
-        rl = (rl >> 2) | (rh << 62);
+        rl = (rl >> 2) | (rh << 62);                         // reverse complement: (r >> 2) | (c ^ 2) << 2(k-1)
         rh >>= 2;
         const ull cc = c ^ 2ull;
         if (top >= 64u) rh |= cc << (top - 64u); else rl |= cc << top;
         if (have < k) have++;
-        if (p >= p0) {
-            ull oh = sent_hi, ol = 0;
-            if (have >= k) {
-                const bool fsm = fh < rh || (fh == rh && fl < rl);
-                oh = fsm ? fh : rh; ol = fsm ? fl : rl;
-                nv++;
-            }
-            khi[p] = oh; klo[p] = ol;
+        if (p >= p0 && have >= k) {
+            const bool fsm = fh < rh || (fh == rh && fl < rl);
+            khi[wr] = fsm ? fh : rh; klo[wr] = fsm ? fl : rl;
+            wr++;
         }
     }
-    }
-    // block-level count of valid k-mers
-    for (int o = 32; o > 0; o >>= 1) nv += __shfl_down(nv, o, 64);
-    if ((threadIdx.x & 63u) == 0 && nv) atomicAdd(nvalid, (ull)nv);
 }
 
 __global__ void __launch_bounds__(256)
@@ -282,17 +292,19 @@ static int wide_sort(SimkaWide *w, uint64_t n, uint32_t hi_bits, ull *hi0, ull *
 }
 
 // the same order without a permutation (count side): the other word rides along as the VALUE of each sort.
-// In: hi0/lo0 (+ scratch hi1/lo1); out: sorted by (hi, lo), back in hi0/lo0.
+// In: hi0/lo0 (+ scratch hi1/lo1); out: sorted by (hi, lo) -- back in hi0/lo0, or in hi1/lo1 when there is no high word to sort by.
 static int wide_sort_words(SimkaWide *w, uint64_t n, uint32_t hi_bits, ull *hi0, ull *lo0, ull *hi1, ull *lo1) {
     if (n == 0) return 0;
     if (n >= ((uint64_t)1 << 31)) { w->err = "wide-k path: more than 2^31 k-mers in one sort (sample too deep for k >= 32)"; return SIMKA_WIDE_ERR_LIMIT; }
+    const int lo_bits = (int)std::min<uint32_t>(64u, w->W);
     size_t tb = 0, tb2 = 0;
-    WCHK(hipcub::DeviceRadixSort::SortPairs(nullptr, tb, lo0, lo1, hi0, hi1, (int)n, 0, 64, w->stream));
-    WCHK(hipcub::DeviceRadixSort::SortPairs(nullptr, tb2, hi1, hi0, lo1, lo0, (int)n, 0, (int)hi_bits, w->stream));
+    WCHK(hipcub::DeviceRadixSort::SortPairs(nullptr, tb, lo0, lo1, hi0, hi1, (int)n, 0, lo_bits, w->stream));
+    if (hi_bits) WCHK(hipcub::DeviceRadixSort::SortPairs(nullptr, tb2, hi1, hi0, lo1, lo0, (int)n, 0, (int)hi_bits, w->stream));
     tb = std::max(tb, tb2);
     char *tmp; int rc = wide_buf(w, 11, tb, &tmp); if (rc) return rc;
     size_t t1 = tb;
-    WCHK(hipcub::DeviceRadixSort::SortPairs(tmp, t1, lo0, lo1, hi0, hi1, (int)n, 0, 64, w->stream));              // by lo: (lo1, hi1)
+    WCHK(hipcub::DeviceRadixSort::SortPairs(tmp, t1, lo0, lo1, hi0, hi1, (int)n, 0, lo_bits, w->stream));         // by lo: (lo1, hi1)
+    if (!hi_bits) return 0;                                                                                       // k <= 32: done, result in hi1 / lo1
     t1 = tb;
     WCHK(hipcub::DeviceRadixSort::SortPairs(tmp, t1, hi1, hi0, lo1, lo0, (int)n, 0, (int)hi_bits, w->stream));    // by hi, stable: (hi0, lo0)
     return 0;
@@ -349,24 +361,23 @@ int simka_wide_count_sample(SimkaWide *w, uint32_t sample, const void *packed, u
     w->s_off[sample] = w->a_used; w->s_n[sample] = 0;
     if (nb_bases == 0) return 0;
     const uint64_t n = nb_bases;
-    ull *hi0, *lo0, *hi1, *lo1, *tkey; uint32_t *idx0, *idx1; ull *d_small;
+    ull *hi0, *lo0, *hi1, *lo1; uint32_t *idx0, *idx1; ull *d_small;
     int rc;
     if ((rc = wide_buf(w, 0, n, &hi0)) || (rc = wide_buf(w, 1, n, &lo0)) || (rc = wide_buf(w, 2, n, &hi1)) || (rc = wide_buf(w, 3, n, &lo1)) ||
-        (rc = wide_buf(w, 4, n, &tkey)) || (rc = wide_buf(w, 5, n + 2, &idx0)) || (rc = wide_buf(w, 6, n + 2, &idx1)) || (rc = wide_buf(w, 7, 16, &d_small))) return rc;
+        (rc = wide_buf(w, 5, n + 2, &idx0)) || (rc = wide_buf(w, 6, n + 2, &idx1)) || (rc = wide_buf(w, 7, 16, &d_small))) return rc;
     WCHK(hipMemsetAsync(d_small, 0, 16 * 8, w->stream));
-    const uint32_t hi_bits = (w->W > 64 ? w->W - 64 : 0) + 1;          // one more bit: the sentinel
-    const ull sent_hi = 1ull << (hi_bits - 1);
     WideScanArgs a; a.packed = (const uint64_t *)packed; a.nb_bases = nb_bases; a.nb_words = nb_words; a.offsets = (const uint64_t *)offsets;
     a.nb_reads = nb_reads; a.fixed_len = fixed_len; a.k = w->k;
-    hipLaunchKernelGGL(k_wscan, grid_for((n + WSEG - 1) / WSEG), dim3(256), 0, w->stream, a, sent_hi, hi0, lo0, d_small /* [0] = nvalid */);
-    if ((rc = wide_sort_words(w, n, hi_bits, hi0, lo0, hi1, lo1))) return rc;
-    hi1 = hi0; lo1 = lo0;            // the sorted words
+    hipLaunchKernelGGL(k_wscan, grid_for((n + WSEG - 1) / WSEG), dim3(256), 0, w->stream, a, hi0, lo0, d_small /* [0] = nvalid */);
     ull nvalid = 0;
     WCHK(hipMemcpyAsync(&nvalid, d_small, 8, hipMemcpyDeviceToHost, w->stream));
     WCHK(hipStreamSynchronize(w->stream));
+    const uint32_t hi_bits = w->W > 64 ? w->W - 64 : 0;
+    if ((rc = wide_sort_words(w, nvalid, hi_bits, hi0, lo0, hi1, lo1))) return rc;
+    if (hi_bits) { hi1 = hi0; lo1 = lo0; }          // the sorted words (one sort only: they are in hi1 / lo1)
     totals5[SIMKA_TOT_KOCC] = nvalid;
     if (nvalid == 0) return 0;
-    // runs of equal keys among the first nvalid sorted entries (the sentinels sort last)
+    // runs of equal keys
     uint32_t *flag = idx0, *rank = idx1, *start, *sflag, *srank;
     if ((rc = wide_buf(w, 8, nvalid + 2, &start)) || (rc = wide_buf(w, 9, nvalid + 2, &sflag)) || (rc = wide_buf(w, 10, nvalid + 2, &srank))) return rc;
     hipLaunchKernelGGL(k_wheads, grid_for(nvalid), dim3(256), 0, w->stream, hi1, lo1, nvalid, flag);
