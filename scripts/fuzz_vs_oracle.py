@@ -1,0 +1,83 @@
+"""Randomised parity check: GPU path (hash pipeline, or the sort path for k >= 32) against the oracle on random small inputs --
+random k, abundance window, sample count, variable read lengths, N letters, lowercase, empty reads, partition geometry.
+usage: fuzz_vs_oracle.py [seconds] [seed]"""
+import os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import numpy as np
+import simka_amd, oracle_lib
+
+budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
+seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+np.set_printoptions(threshold=100000, linewidth=220)
+rng = np.random.default_rng(seed)
+t_end = time.time() + budget
+ncase = 0
+while time.time() < t_end:
+    k = int(rng.choice([1, 2, 3, 5, 8, 11, 15, 16, 17, 21, 25, 31, 32, 33, 40, 63]))
+    n = int(rng.integers(1, 9))
+    amin = int(rng.choice([0, 1, 2, 3])); amax = int(rng.choice([999999999, 999999999, 50, 5]))
+    simple = bool(rng.integers(0, 2)); cplx = bool(rng.integers(0, 2))
+    pb = int(rng.choice([0, 0, 1, 3, 6, 9]))
+    genome = rng.integers(0, 4, size=int(rng.integers(200, 4000)))
+    samples = []
+    for s in range(n):
+        reads = []
+        for r in range(int(rng.integers(0, 400))):
+            L = int(rng.integers(0, 180))
+            st = int(rng.integers(0, max(1, len(genome) - L)))
+            seq = np.frombuffer(b"ACTG", dtype=np.uint8)[genome[st:st + L]].copy()
+            if L and rng.random() < 0.3:            # substitutions, N, lowercase
+                for _ in range(int(rng.integers(1, 4))):
+                    seq[int(rng.integers(0, L))] = rng.choice(np.frombuffer(b"ACGTNnacgtRY", dtype=np.uint8))
+            if rng.random() < 0.5:
+                comp = {65: 84, 67: 71, 71: 67, 84: 65}
+                seq = np.array([comp.get(int(c), int(c)) for c in seq[::-1]], dtype=np.uint8)
+            reads.append(seq.tobytes())
+        samples.append(reads)
+    kw = {}
+    if pb and k <= 31:
+        kw["log2_partitions"] = min(pb, 2 * k)
+    ctx = simka_amd.SimkaContext(n, kmer_size=k, abundance_min=amin, abundance_max=amax, simple_dist=simple, complex_dist=cplx, **kw)
+    orc = oracle_lib.Oracle()
+    for s, reads in enumerate(samples):
+        packed, off, nb, nfrag = simka_amd.pack_reads(reads)
+        ctx.count_sample(s, packed, nb, len(off) - 1, offsets=off, nb_input_reads=len(reads))
+        ascii_ = np.frombuffer(b"".join(reads), dtype=np.uint8) if reads else np.zeros(0, dtype=np.uint8)
+        offs = np.concatenate([[0], np.cumsum([len(r) for r in reads])]).astype(np.uint64)
+        orc.add_sample_ascii("S%d" % s, ascii_, offs)
+    totals = [ctx.sample_totals(i) for i in range(n)]
+    ctx.merge(); st = ctx.stats(); ctx.close()
+    orc.run(k, amin, amax=amax, simple=simple, complex_=cplx)
+    ot = orc.totals()
+    tag = "case %d: k=%d n=%d amin=%d amax=%d simple=%d complex=%d pb=%d" % (ncase, k, n, amin, amax, simple, cplx, pb)
+    for i, t in enumerate(totals):
+        for key in ("nb_reads", "K_occ", "D_all", "D", "N", "Q"):
+            assert int(t[key]) == int(ot[key][i]), (tag, i, key, t[key], ot[key][i])
+    if n >= 2:
+        iu = np.triu_indices(n, 1); pr = st.pairs(); S = orc.acc("S")
+        assert np.array_equal(pr["S_ij"], S[iu]) and np.array_equal(pr["S_ji"], S.T[iu]), tag
+        assert np.array_equal(pr["a"], orc.acc("a")[iu]) and np.array_equal(pr["bc"], orc.acc("bc")[iu]), tag
+        if simple:
+            assert np.array_equal(pr["chord"], orc.acc("chord")[iu]) and np.array_equal(pr["hell"], orc.acc("hell")[iu]), tag
+        if cplx:
+            assert np.array_equal(pr["whit"], orc.acc("whit")[iu]) and np.array_equal(pr["canb"], orc.acc("canb")[iu]), tag
+            np.testing.assert_allclose(pr["kl"], orc.kl()[iu], rtol=1e-9, atol=1e-15, err_msg=tag)      # NaN (empty sample) must be NaN in both
+        mats = st.matrices()
+        # Jensen-Shannon is sqrt(kl / 2), and 1 when kl == 0 exactly (ref quirk): where the KL sum of two near-identical samples is
+        # rounding noise (|kl| < 1e-13) the reference's own result is an accident of its operation order -- those cells are skipped
+        noisy = np.zeros((n, n), dtype=bool)
+        if cplx:
+            klm = np.zeros((n, n)); klm[iu] = np.abs(orc.kl()[iu]); noisy = (klm + klm.T) < 1e-13
+            np.fill_diagonal(noisy, False)
+        for w, name in enumerate(orc.matrix_names()):
+            if name in mats and "jensenshannon" in name:
+                np.testing.assert_allclose(np.where(noisy, 0, mats[name]), np.where(noisy, 0, orc.matrix(w)), rtol=1e-6, atol=2e-9, err_msg=tag + " " + name)
+            elif name in mats:
+                # atol: near-identical samples (k = 1..3: a handful of k-mers) give Jensen-Shannon ~1e-7 out of terms that cancel to 1e-13 of
+                # their size; in double -- the reference's own d1/d2 are doubles -- that is ill-conditioned (1e-4 relative, 1e-10 absolute)
+                np.testing.assert_allclose(mats[name], orc.matrix(w), rtol=1e-6, atol=2e-9, err_msg=tag + " " + name)
+    d, sh = orc.global_counts()
+    assert (int(st.view.nb_distinct_kmers), int(st.view.nb_shared_kmers)) == (d, sh), (tag, int(st.view.nb_distinct_kmers), int(st.view.nb_shared_kmers), d, sh)
+    ncase += 1
+print("fuzz ok: %d random cases (seed %d)" % (ncase, seed))

@@ -198,9 +198,12 @@ SIMKA_EXPORT int simka_stats_describe(uint32_t N, uint32_t flags, uint64_t *h, u
             for (uint64_t j = i + 1; j < N; j++, cell++) {
                 canb[cell] = v->nb_distinct[i] + v->nb_distinct[j] - 2 * v->distinct_shared[cell];
                 const long double Ni = (long double)v->nb_kmers[i], Nj = (long double)v->nb_kmers[j];
+                // an empty sample next to a non-empty one: the reference divides 0 by N = 0 for every k-mer of the other sample
+                // (ref: src/core/SimkaAlgorithm.hpp:437-446,500-506), the sum is NaN -- the same 0/0 is left to happen here;
+                // two empty samples never reach updateDistanceComplex: 0
                 long double one = 0;
-                if (v->nb_kmers[i]) one += (long double)(v->nb_kmers[i] - v->shared_ij[cell]) / Ni;
-                if (v->nb_kmers[j]) one += (long double)(v->nb_kmers[j] - v->shared_ji[cell]) / Nj;
+                if (v->nb_kmers[i] || v->nb_kmers[j])
+                    one = (long double)(v->nb_kmers[i] - v->shared_ij[cell]) / Ni + (long double)(v->nb_kmers[j] - v->shared_ji[cell]) / Nj;
                 kl[cell] = (double)((long double)klfix[cell] / (long double)SIMKA_KL_SCALE + ln2 * one);
             }
         v->canberra = canb; v->kl = kl;

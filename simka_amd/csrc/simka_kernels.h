@@ -64,7 +64,7 @@
 // complex: two more arrays after the simple ones (index = nacc32 + {0,1}); 64-bit LDS cells
 //   WHIT : sum over both-present pairs of  w(ci,cj) - g(ci,Nj) - g(cj,Ni)   (two's complement), + host bias
 //   KLFIX: sum over both-present pairs of the KL term, fixed point 2^-52 (two's complement)
-#define SIMKA_KL_SCALE 4503599627370496.0   // 2^52
+#define SIMKA_KL_SCALE 1152921504606846976.0   // 2^60: a cell's both-present KL sum is < 2 ln 2, so the i64 sum stays below 2^61
 #define SIMKA_HIST_MAX 1024    // per-sample histogram of solid counts (complex): exact bins below, list above
 
 // device error word bits

@@ -1377,7 +1377,8 @@ k_pairs(const SimkaSpan *spans, const ull *cursors, const ull *entries, const ui
                     // KL: with p = ci/Ni, q = cj/Nj the reference's  p ln(2p/(p+q)) + q ln(2q/(p+q))  equals
                     // p ln p + q ln q - (p+q) ln((p+q)/2): one logarithm per pair, the p ln p terms are per entry.
                     const double h = ep[ix] + ep[iy];
-                    const double dd = eplp[ix] + eplp[iy] - h * log(h * 0.5);
+                    double dd = eplp[ix] + eplp[iy] - h * log(h * 0.5);
+                    dd = dd < 0.0 ? 0.0 : dd;            // >= 0 mathematically (Jensen); rounding noise must not drive a sum of near-identical samples negative
                     atomicAdd(&c64[1 * CP + cell], (ull)(long long)llrint(dd * SIMKA_KL_SCALE));
                     const ull uX = (ull)((double)ci * tn[(rect ? T : 0u) + lj]), uY = (ull)((double)cj * tn[li]);
                     atomicAdd(&c64[0 * CP + cell], simka_whit_abs(uX - uY) - simka_whit_abs(uX) - simka_whit_abs(uY));
@@ -1442,7 +1443,8 @@ k_pairs_global(const SimkaSpan *huge, const ull *cursors, const ull *entries, Si
             if (pc.nacc64) {
                 const double Ni = (double)pc.tot_n[si], Nj = (double)pc.tot_n[sj];
                 const double pi_ = (double)ci / Ni, pj_ = (double)cj / Nj, hh = pi_ + pj_;
-                const double dd = pi_ * log(pi_) + pj_ * log(pj_) - hh * log(hh * 0.5);       // same form as k_pairs
+                double dd = pi_ * log(pi_) + pj_ * log(pj_) - hh * log(hh * 0.5);       // same form as k_pairs
+                dd = dd < 0.0 ? 0.0 : dd;
                 atomicAdd(&acc[((ull)pc.nacc32 + 1) * NP + pg], (ull)(long long)llrint(dd * SIMKA_KL_SCALE));
                 const ull uX = (ull)((double)ci * Nj), uY = (ull)((double)cj * Ni);
                 atomicAdd(&acc[(ull)pc.nacc32 * NP + pg], simka_whit_abs(uX - uY) - simka_whit_abs(uX) - simka_whit_abs(uY));

@@ -153,14 +153,14 @@ class Oracle:
         if simple:
             parts += [self.acc("chord")[iu], self.acc("hell")[iu]]
         if complex_:
-            # klfix = the both-present part of KL in 2^-52 fixed point (what the device accumulates)
+            # klfix = the both-present part of KL in 2^-60 fixed point (what the device accumulates)
             Nk = full["N"].astype(np.float64)
             kl = self.kl()[iu].astype(np.longdouble)
             one = np.zeros(P, dtype=np.longdouble)
             for c, (i, j) in enumerate(zip(*iu)):
                 one[c] = np.log(np.longdouble(2)) * (np.longdouble(int(tot["N"][i]) - int(S[i, j])) / np.longdouble(Nk[i]) +
                                                      np.longdouble(int(tot["N"][j]) - int(S[j, i])) / np.longdouble(Nk[j]))
-            klfix = np.rint((kl - one) * np.longdouble(2.0 ** 52)).astype(np.int64).view(np.uint64)
+            klfix = np.rint((kl - one) * np.longdouble(2.0 ** 60)).astype(np.int64).view(np.uint64)
             parts += [self.acc("whit")[iu], klfix]
         parts += [tot["D"], tot["N"], tot["Q"], np.zeros(n, dtype=np.uint64), np.zeros(n, dtype=np.uint64)]
         if complex_:

@@ -776,3 +776,13 @@ def test_example_goldens_through_the_sort_path(gpu_required, golden_dir, tmp_pat
                 assert f.read() == g.read(), os.path.basename(gzf)
             n += 1
     assert n == 20
+
+
+def test_randomised_inputs_against_the_oracle(gpu_required, oracle_mod):
+    """scripts/fuzz_vs_oracle.py for 20 s: random k (1..63), abundance windows, sample counts, read lengths (0..180, shorter than k
+    included), N / IUPAC / lowercase letters, empty samples, partition geometries, distance families -- totals and every
+    accumulator bit-exact, matrices within 1e-6 (NaN where the reference's arithmetic gives NaN: an empty sample with -complex-dist)."""
+    import subprocess, sys
+    r = subprocess.run([sys.executable, os.path.join(ROOT_DIR, "scripts", "fuzz_vs_oracle.py"), "20", "12345"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
+                       text=True, timeout=600)
+    assert r.returncode == 0 and "fuzz ok" in r.stdout, r.stdout[-3000:]
