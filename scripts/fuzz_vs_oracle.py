@@ -38,6 +38,41 @@ while time.time() < t_end:
     kw = {}
     if pb and k <= 31:
         kw["log2_partitions"] = min(pb, 2 * k)
+    shards = int(rng.choice([1, 1, 2, 3])) if (k <= 31 and n >= 2) else 1
+    if shards > 1:
+        # partition shards: every shard sees every read and keeps its level-1 buckets; integer accumulators and totals add up
+        cplx = False
+        packs = [simka_amd.pack_reads(reads) for reads in samples]
+        acc = None; tot_sum = None
+        for si in range(shards):
+            c = simka_amd.SimkaContext(n, kmer_size=k, abundance_min=amin, abundance_max=amax, simple_dist=simple, shard_index=si, shard_count=shards, **kw)
+            for s, (packed, off, nb, nfrag) in enumerate(packs):
+                c.count_sample(s, packed, nb, len(off) - 1, offsets=off, nb_input_reads=len(samples[s]))
+            tt = [c.sample_totals(i) for i in range(n)]
+            c.merge(); stx = c.stats(); c.close()
+            pr_ = stx.pairs()
+            if acc is None:
+                acc = {key: np.array(v, dtype=np.uint64) for key, v in pr_.items() if key in ("S_ij", "S_ji", "a", "bc", "chord", "hell")}
+                tot_sum = [dict(t) for t in tt]
+            else:
+                for key in acc: acc[key] += np.array(pr_[key], dtype=np.uint64)
+                for i in range(n):
+                    for key in ("K_occ", "D_all", "D", "N", "Q"): tot_sum[i][key] += tt[i][key]
+        orc = oracle_lib.Oracle()
+        for s, reads in enumerate(samples):
+            ascii_ = np.frombuffer(b"".join(reads), dtype=np.uint8) if reads else np.zeros(0, dtype=np.uint8)
+            orc.add_sample_ascii("S%d" % s, ascii_, np.concatenate([[0], np.cumsum([len(r) for r in reads])]).astype(np.uint64))
+        orc.run(k, amin, amax=amax, simple=simple, complex_=False)
+        ot = orc.totals(); iu = np.triu_indices(n, 1); S = orc.acc("S")
+        tag = "case %d (shards %d): k=%d n=%d amin=%d amax=%d simple=%d pb=%d" % (ncase, shards, k, n, amin, amax, simple, pb)
+        for i in range(n):
+            for key in ("K_occ", "D_all", "D", "N", "Q"):
+                assert int(tot_sum[i][key]) == int(ot[key][i]), (tag, i, key)
+        assert np.array_equal(acc["S_ij"], S[iu]) and np.array_equal(acc["S_ji"], S.T[iu]) and np.array_equal(acc["a"], orc.acc("a")[iu]) and np.array_equal(acc["bc"], orc.acc("bc")[iu]), tag
+        if simple:
+            assert np.array_equal(acc["chord"], orc.acc("chord")[iu]) and np.array_equal(acc["hell"], orc.acc("hell")[iu]), tag
+        ncase += 1
+        continue
     ctx = simka_amd.SimkaContext(n, kmer_size=k, abundance_min=amin, abundance_max=amax, simple_dist=simple, complex_dist=cplx, **kw)
     orc = oracle_lib.Oracle()
     for s, reads in enumerate(samples):
