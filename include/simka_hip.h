@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define SIMKA_ABI_VERSION 1
+#define SIMKA_ABI_VERSION 2
 
 enum {
     SIMKA_OK = 0,
@@ -47,7 +47,7 @@ typedef struct simka_config {
     uint32_t struct_size;        /* = sizeof(simka_config) */
     uint32_t nb_samples;         /* N, SimkaStatistics::_nbBanks (1..65535) */
     uint32_t kmer_size;          /* -kmer-size, 1..63.  k <= 31 (one 64-bit word, Kmer<span=32>): the hash pipeline.  32..63 (two words,
-                                  * Kmer<span=64>): the sort-based path -- exact, ~8x slower, no shards / export / import yet */
+                                  * Kmer<span=64>): the sort-based path -- exact, ~8x slower, no partition shards / batch exchange forms yet */
     uint32_t abundance_min;      /* -abundance-min (ref: src/minikc/MiniKC.hpp:56) */
     uint32_t abundance_max;      /* -abundance-max, clamped to 999999999 (ref: src/core/SimkaAlgorithm.cpp:188) */
     uint32_t dist_flags;         /* SIMKA_DIST_* */
@@ -143,9 +143,11 @@ int simka_get_sample_totals(simka_ctx *ctx, uint32_t sample_index, simka_sample_
 typedef struct simka_spectrum_info {
     uint64_t nb_records;         /* solid k-mers of the sample on this shard */
     uint64_t nb_partitions;      /* 2^log2_partitions */
+    uint64_t key_words;          /* 64-bit words per key: 1 (kmer_size <= 31), 2 (32..63: keys[] holds nb_records high words, then
+                                  * nb_records low words; partition = top bits of the k-mer, the records are sorted by k-mer) */
 } simka_spectrum_info;
 int simka_sample_spectrum_info(simka_ctx *ctx, uint32_t sample_index, simka_spectrum_info *out);
-/* part_counts[nb_partitions], keys[nb_records] (the library's internal key of each k-mer), counts[nb_records] */
+/* part_counts[nb_partitions], keys[nb_records * key_words] (the library's internal key of each k-mer), counts[nb_records] */
 int simka_export_sample(simka_ctx *ctx, uint32_t sample_index, uint32_t *part_counts, uint64_t *keys, uint32_t *counts);
 /* totals: what simka_get_sample_totals returned for the exported sample.  A context that has not counted anything yet
  * takes its partition count from nb_partitions. */

@@ -45,7 +45,7 @@ class SampleTotals(C.Structure):
 
 
 class SpectrumInfo(C.Structure):
-    _fields_ = [("nb_records", C.c_uint64), ("nb_partitions", C.c_uint64)]
+    _fields_ = [("nb_records", C.c_uint64), ("nb_partitions", C.c_uint64), ("key_words", C.c_uint64)]
 
 
 _U64P = C.POINTER(C.c_uint64)
@@ -310,10 +310,11 @@ class SimkaContext:
         info = SpectrumInfo()
         self._check(self.lib.simka_sample_spectrum_info(self.h, index, C.byref(info)))
         pc = np.zeros(info.nb_partitions, dtype=np.uint32)
-        keys = np.zeros(max(info.nb_records, 1), dtype=np.uint64)
+        kw = max(int(info.key_words), 1)                 # 2 for kmer_size >= 32: high words, then low words
+        keys = np.zeros(max(info.nb_records * kw, 1), dtype=np.uint64)
         counts = np.zeros(max(info.nb_records, 1), dtype=np.uint32)
         self._check(self.lib.simka_export_sample(self.h, index, pc.ctypes.data, keys.ctypes.data, counts.ctypes.data))
-        return self.sample_totals(index), pc, keys[:info.nb_records], counts[:info.nb_records]
+        return self.sample_totals(index), pc, keys[:info.nb_records * kw], counts[:info.nb_records]
 
     def import_sample(self, index, totals, part_counts, keys, counts):
         t = SampleTotals(totals["nb_reads"], totals["D"], totals["N"], totals["Q"], totals["K_occ"], totals["D_all"])
@@ -321,7 +322,7 @@ class SimkaContext:
         k = np.ascontiguousarray(keys, dtype=np.uint64)
         c = np.ascontiguousarray(counts, dtype=np.uint32)
         self._check(self.lib.simka_import_sample(self.h, index, C.byref(t), pc.ctypes.data, len(pc), k.ctypes.data if len(k) else None,
-                                                 c.ctypes.data if len(c) else None, len(k)))
+                                                 c.ctypes.data if len(c) else None, len(c)))
 
     def export_sample_device(self, index, device):
         """export_sample with keys (int64) / counts (int32) as torch tensors on the context's GPU (multi-GPU exchange)."""
@@ -329,7 +330,7 @@ class SimkaContext:
         info = SpectrumInfo()
         self._check(self.lib.simka_sample_spectrum_info(self.h, index, C.byref(info)))
         pc = np.zeros(info.nb_partitions, dtype=np.uint32)
-        keys = torch.empty(info.nb_records, dtype=torch.int64, device=device)
+        keys = torch.empty(info.nb_records * max(int(info.key_words), 1), dtype=torch.int64, device=device)
         counts = torch.empty(info.nb_records, dtype=torch.int32, device=device)
         self._check(self.lib.simka_export_sample_device(self.h, index, pc.ctypes.data, keys.data_ptr() if info.nb_records else None,
                                                         counts.data_ptr() if info.nb_records else None))
@@ -339,7 +340,7 @@ class SimkaContext:
         """keys / counts: torch tensors on the context's GPU (or slices of one)."""
         t = SampleTotals(totals["nb_reads"], totals["D"], totals["N"], totals["Q"], totals["K_occ"], totals["D_all"])
         pc = np.ascontiguousarray(part_counts, dtype=np.uint32)
-        n = int(keys.numel())
+        n = int(counts.numel())
         self._check(self.lib.simka_import_sample_device(self.h, index, C.byref(t), pc.ctypes.data, len(pc), keys.data_ptr() if n else None,
                                                         counts.data_ptr() if n else None, n))
 

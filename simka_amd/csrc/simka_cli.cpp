@@ -351,8 +351,9 @@ private:
 // (ref: src/SimkaPotara.hpp:837-842).  Here: the sample's solid spectrum as simka_export_sample() returns it, behind a
 // header that pins everything the spectrum depends on (k, abundance filter, read policies, the input files, the shard).
 struct SpecHeader {
-    char magic[8];                       // "SIMKSPC1"
+    char magic[8];                       // "SIMKSPC2"
     uint64_t abi, kmer_size, abundance_min, abundance_max, shard_index, shard_count, nb_partitions, nb_records, signature;
+    uint64_t key_words;                  // 64-bit words per key: 1, or 2 for -kmer-size >= 32 (high words, then low words)
     simka_sample_totals totals;
 };
 
@@ -390,7 +391,7 @@ std::string spec_path(const std::string &tmp, const Sample &s, uint32_t g, uint3
 bool read_spec_header(const std::string &path, SpecHeader &h) {
     FILE *f = fopen(path.c_str(), "rb");
     if (!f) return false;
-    const bool ok = fread(&h, sizeof h, 1, f) == 1 && memcmp(h.magic, "SIMKSPC1", 8) == 0;
+    const bool ok = fread(&h, sizeof h, 1, f) == 1 && memcmp(h.magic, "SIMKSPC2", 8) == 0;
     fclose(f);
     return ok;
 }
@@ -406,9 +407,10 @@ struct Spectrum { SpecHeader h; std::vector<uint32_t> part_counts, counts; std::
 bool read_spec(const std::string &path, Spectrum &sp) {
     FILE *f = fopen(path.c_str(), "rb");
     if (!f) return false;
-    bool ok = fread(&sp.h, sizeof sp.h, 1, f) == 1 && memcmp(sp.h.magic, "SIMKSPC1", 8) == 0;
+    bool ok = fread(&sp.h, sizeof sp.h, 1, f) == 1 && memcmp(sp.h.magic, "SIMKSPC2", 8) == 0;
     if (ok) {
-        sp.part_counts.resize(sp.h.nb_partitions); sp.keys.resize(sp.h.nb_records); sp.counts.resize(sp.h.nb_records);
+        if (sp.h.key_words < 1 || sp.h.key_words > 2) { fclose(f); return false; }
+        sp.part_counts.resize(sp.h.nb_partitions); sp.keys.resize(sp.h.nb_records * sp.h.key_words); sp.counts.resize(sp.h.nb_records);
         ok = fread(sp.part_counts.data(), 4, sp.part_counts.size(), f) == sp.part_counts.size() &&
              fread(sp.keys.data(), 8, sp.keys.size(), f) == sp.keys.size() && fread(sp.counts.data(), 4, sp.counts.size(), f) == sp.counts.size();
     }
@@ -443,7 +445,6 @@ int main(int argc, char **argv) {
     if (o.max_memory < 500) { std::cout << "Please run Simka with higher memory usage than 500 MB" << std::endl; return 1; }
     if (!exists(o.in)) die("ERROR: Input filename does not exist");
     if (o.kmer_size < 1 || o.kmer_size > 63) die("ERROR: -kmer-size must be in [1,63]");
-    if (o.kmer_size > 31 && (o.nb_gpus > 1 || o.keep_tmp || o.merge_ranges > 0)) die("ERROR: -nb-gpus / -keep-tmp / -merge-ranges are not available for -kmer-size >= 32 yet");
     if (o.nb_gpus < 1) die("ERROR: -nb-gpus must be >= 1");
     if (o.abundance_min < 0) o.abundance_min = 0;
     o.abundance_max = std::min<long long>(std::max<long long>(o.abundance_max, 0), 999999999LL);
@@ -555,15 +556,15 @@ int main(int argc, char **argv) {
         simka_spectrum_info info;
         int rc = simka_sample_spectrum_info(c, index, &info);
         if (rc != SIMKA_OK) return rc;
-        sp.part_counts.resize(info.nb_partitions); sp.keys.resize(info.nb_records); sp.counts.resize(info.nb_records);
+        sp.part_counts.resize(info.nb_partitions); sp.keys.resize(info.nb_records * info.key_words); sp.counts.resize(info.nb_records);
         rc = simka_export_sample(c, index, sp.part_counts.data(), sp.keys.data(), sp.counts.data());
         if (rc != SIMKA_OK) return rc;
         memset(&sp.h, 0, sizeof sp.h);
-        memcpy(sp.h.magic, "SIMKSPC1", 8);
+        memcpy(sp.h.magic, "SIMKSPC2", 8);
         sp.h.abi = (uint64_t)simka_abi_version(); sp.h.kmer_size = (uint64_t)o.kmer_size;
         sp.h.abundance_min = (uint64_t)o.abundance_min; sp.h.abundance_max = (uint64_t)o.abundance_max;
         sp.h.shard_index = 0; sp.h.shard_count = 1; sp.h.nb_partitions = info.nb_partitions; sp.h.nb_records = info.nb_records;
-        sp.h.signature = sig[i];
+        sp.h.signature = sig[i]; sp.h.key_words = info.key_words;
         return simka_get_sample_totals(c, index, &sp.h.totals);
     };
     auto fill_reads = [](const Packed &pk, simka_reads &r) {
@@ -667,7 +668,7 @@ int main(int argc, char **argv) {
         bool have_tail = false;
         auto merger = [&](uint32_t g) {
             simka_ctx *c = make_ctx(N, device_of(g));
-            std::vector<uint64_t> shard(nw), off(P + 1);
+            std::vector<uint64_t> shard(nw), off(P + 1), kslice;
             std::vector<uint32_t> pc(P);
             bool first = true;
             for (uint64_t v = g; v < V; v += G) {
@@ -680,7 +681,14 @@ int main(int argc, char **argv) {
                     for (uint64_t p = 0; p < lo; p++) before += sp.part_counts[p];
                     std::fill(pc.begin(), pc.end(), 0u);
                     for (uint64_t p = lo; p < hi; p++) { pc[p] = sp.part_counts[p]; n += pc[p]; }
-                    if (simka_import_sample(c, i, &sp.h.totals, pc.data(), P, n ? sp.keys.data() + before : nullptr, n ? sp.counts.data() + before : nullptr, n) != SIMKA_OK)
+                    const uint64_t *kp = n ? sp.keys.data() + before : nullptr;
+                    if (n && sp.h.key_words == 2) {        // [hi x records][lo x records]: the slice of both halves, back to back
+                        kslice.resize(2 * n);
+                        std::copy(sp.keys.begin() + before, sp.keys.begin() + before + n, kslice.begin());
+                        std::copy(sp.keys.begin() + sp.h.nb_records + before, sp.keys.begin() + sp.h.nb_records + before + n, kslice.begin() + n);
+                        kp = kslice.data();
+                    }
+                    if (simka_import_sample(c, i, &sp.h.totals, pc.data(), P, kp, n ? sp.counts.data() + before : nullptr, n) != SIMKA_OK)
                         fatal(c, "simka_import_sample");
                 }
                 if (simka_merge(c) != SIMKA_OK) fatal(c, "simka_merge");

@@ -250,6 +250,7 @@ static uint32_t default_log2_partitions(uint64_t max_kmers, uint32_t shard_count
 }
 
 SIMKA_EXPORT uint32_t simka_default_log2_partitions(uint64_t max_kmers_per_sample, uint32_t kmer_size) {
+    if (kmer_size > 31) return std::min(std::max(8u, default_log2_partitions(max_kmers_per_sample, 1)), 16u);      // sort path: key-prefix ranges
     return std::max(1u, std::min(default_log2_partitions(max_kmers_per_sample, 1), 2u * kmer_size));
 }
 
@@ -789,9 +790,26 @@ static int spectrum_rows(simka_ctx *ctx, uint32_t sample, const char *who, std::
     return SIMKA_OK;
 }
 
+// wide-k spectra are sorted by k-mer; their "partitions" are key-prefix ranges (cfg.log2_partitions bits, 12 by default)
+static uint32_t wide_log2_parts(const simka_ctx *ctx) {
+    const uint32_t lp = ctx->cfg.log2_partitions ? ctx->cfg.log2_partitions : 12u;
+    return std::min<uint32_t>(std::min<uint32_t>(lp, 16u), 2u * ctx->cfg.kmer_size - 2u);
+}
+
+static int wide_check_counted(simka_ctx *ctx, uint32_t sample, const char *who) {
+    if (sample >= ctx->cfg.nb_samples || !ctx->counted[sample]) return ctx->fail(SIMKA_ERR_STATE, "%s: sample %u not counted", who, sample);
+    HIPCHK(hipSetDevice(ctx->cfg.device));
+    return SIMKA_OK;
+}
+
 SIMKA_EXPORT int simka_sample_spectrum_info(simka_ctx *ctx, uint32_t sample, simka_spectrum_info *out) {
-    if (ctx && ctx->wide) return ctx->fail(SIMKA_ERR_UNSUPPORTED, "simka_sample_spectrum_info: spectra of kmer_size >= 32 (sort-based path) cannot be exported / imported yet");
     if (!ctx || !out) return SIMKA_ERR_INVALID;
+    if (ctx->wide) {
+        const int rc = wide_check_counted(ctx, sample, "simka_sample_spectrum_info"); if (rc) return rc;
+        out->nb_records = simka_wide_sample_records(ctx->wide, sample); out->nb_partitions = (uint64_t)1 << wide_log2_parts(ctx); out->key_words = 2;
+        return SIMKA_OK;
+    }
+    out->key_words = 1;
     std::vector<uint32_t> foff, fcnt;
     const int rc = spectrum_rows(ctx, sample, "simka_sample_spectrum_info", foff, fcnt);
     if (rc) return rc;
@@ -802,8 +820,16 @@ SIMKA_EXPORT int simka_sample_spectrum_info(simka_ctx *ctx, uint32_t sample, sim
 }
 
 static int export_sample(simka_ctx *ctx, uint32_t sample, uint32_t *part_counts, void *keys, void *counts, bool on_device, const char *who) {
-    if (ctx && ctx->wide) return ctx->fail(SIMKA_ERR_UNSUPPORTED, "spectra of kmer_size >= 32 (sort-based path) cannot be exported / imported yet");
     if (!ctx || !part_counts) return SIMKA_ERR_INVALID;
+    if (ctx->wide) {
+        int rc = wide_check_counted(ctx, sample, who); if (rc) return rc;
+        int wrc = simka_wide_part_counts(ctx->wide, sample, wide_log2_parts(ctx), part_counts);
+        if (wrc) return wide_fail(ctx, wrc);
+        if (simka_wide_sample_records(ctx->wide, sample) == 0) return SIMKA_OK;
+        if (!keys || !counts) return ctx->fail(SIMKA_ERR_INVALID, "%s: keys / counts are NULL", who);
+        wrc = simka_wide_export(ctx->wide, sample, keys, counts, on_device ? 1 : 0);
+        return wrc ? wide_fail(ctx, wrc) : SIMKA_OK;
+    }
     std::vector<uint32_t> foff, fcnt;
     int rc = spectrum_rows(ctx, sample, who, foff, fcnt);
     if (rc) return rc;
@@ -844,7 +870,6 @@ SIMKA_EXPORT int simka_export_sample_device(simka_ctx *ctx, uint32_t sample, uin
 
 static int import_sample(simka_ctx *ctx, uint32_t sample, const simka_sample_totals *totals, const uint32_t *part_counts,
                          uint64_t nb_partitions, const void *keys, const void *counts_any, uint64_t nb_records, bool on_device) {
-    if (ctx && ctx->wide) return ctx->fail(SIMKA_ERR_UNSUPPORTED, "spectra of kmer_size >= 32 (sort-based path) cannot be exported / imported yet");
     if (!ctx || !totals || !part_counts) return SIMKA_ERR_INVALID;
     const uint32_t N = ctx->cfg.nb_samples, fl = ctx->cfg.dist_flags;
     if (sample >= N) return ctx->fail(SIMKA_ERR_INVALID, "simka_import_sample: sample index %u out of range", sample);
@@ -854,6 +879,41 @@ static int import_sample(simka_ctx *ctx, uint32_t sample, const simka_sample_tot
     if (nb_partitions == 0 || (nb_partitions & (nb_partitions - 1))) return ctx->fail(SIMKA_ERR_INVALID, "simka_import_sample: nb_partitions must be a power of two");
     HIPCHK(hipSetDevice(ctx->cfg.device));
     int rc;
+    if (ctx->wide) {      // sorted two-word keys [hi x n][lo x n]; the partition counts only have to add up
+        uint64_t sum = 0;
+        for (uint64_t p = 0; p < nb_partitions; p++) sum += part_counts[p];
+        if (sum != nb_records) return ctx->fail(SIMKA_ERR_INVALID, "simka_import_sample: part_counts sum to %llu, nb_records is %llu", (unsigned long long)sum, (unsigned long long)nb_records);
+        const int wrc = simka_wide_import(ctx->wide, sample, keys, counts_any, nb_records, on_device ? 1 : 0);
+        if (wrc) return wide_fail(ctx, wrc);
+        ull t[SIMKA_NB_TOTALS];
+        t[SIMKA_TOT_D] = totals->nb_distinct; t[SIMKA_TOT_N] = totals->nb_kmers; t[SIMKA_TOT_Q] = totals->sum_sq;
+        t[SIMKA_TOT_DALL] = totals->distinct_all; t[SIMKA_TOT_KOCC] = totals->kmer_occurrences;
+        for (int i = 0; i < SIMKA_NB_TOTALS; i++)
+            HIPCHK(hipMemcpyAsync(ctx->d_stats + stats_off_tot(N, fl, i) + sample, &t[i], 8, hipMemcpyHostToDevice, ctx->stream));
+        if (ctx->d_hist) {
+            std::vector<uint32_t> hc;
+            const uint32_t *cnts = (const uint32_t *)counts_any;
+            if (on_device && nb_records) { hc.resize(nb_records); HIPCHK(hipMemcpyAsync(hc.data(), counts_any, nb_records * 4, hipMemcpyDeviceToHost, ctx->stream)); HIPCHK(hipStreamSynchronize(ctx->stream)); cnts = hc.data(); }
+            std::vector<ull> hist(SIMKA_HIST_MAX, 0);
+            std::vector<uint32_t> ovf;
+            for (uint64_t i = 0; i < nb_records; i++) { const uint32_t c = cnts[i]; if (c < SIMKA_HIST_MAX) hist[c]++; else { ovf.push_back(sample); ovf.push_back(c); } }
+            HIPCHK(hipMemcpyAsync(ctx->d_hist + (uint64_t)sample * SIMKA_HIST_MAX, hist.data(), SIMKA_HIST_MAX * 8, hipMemcpyHostToDevice, ctx->stream));
+            if (!ovf.empty()) {
+                ull novf = 0;
+                HIPCHK(hipMemcpyAsync(&novf, ctx->d_ovf_cursor, 8, hipMemcpyDeviceToHost, ctx->stream));
+                HIPCHK(hipStreamSynchronize(ctx->stream));
+                const ull add = ovf.size() / 2;
+                if (novf + add <= ctx->ovf_cap) HIPCHK(hipMemcpyAsync(ctx->d_ovf_list + 2 * novf, ovf.data(), ovf.size() * 4, hipMemcpyHostToDevice, ctx->stream));
+                novf += add;
+                HIPCHK(hipMemcpyAsync(ctx->d_ovf_cursor, &novf, 8, hipMemcpyHostToDevice, ctx->stream));
+            }
+            HIPCHK(hipStreamSynchronize(ctx->stream));
+        }
+        HIPCHK(hipStreamSynchronize(ctx->stream));
+        ctx->nb_reads[sample] = totals->nb_reads;
+        ctx->counted[sample] = 1;
+        return SIMKA_OK;
+    }
     if (!ctx->geometry_ready) {
         ctx->cfg.log2_partitions = ceil_log2_u64(nb_partitions);     // the spectrum fixes the partition count of this run
         rc = setup_geometry(ctx, std::max<uint64_t>({ ctx->cfg.max_kmers_per_sample, totals->kmer_occurrences, nb_records, 1 }));

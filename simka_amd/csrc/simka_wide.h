@@ -24,3 +24,9 @@ int simka_wide_count_sample(SimkaWide *w, uint32_t sample, const void *packed, u
                             uint32_t fixed_len, uint32_t amin, uint32_t amax, unsigned long long totals5[5], void *d_hist_row, void *d_ovf_list,
                             void *d_ovf_cursor, uint64_t ovf_cap);
 int simka_wide_merge(SimkaWide *w, uint32_t span_cap, SimkaWideCsr *out);
+
+// spectra out of / into the wide arena: partition p of a (sorted) sample = the records whose top log2_parts key bits equal p
+int simka_wide_part_counts(SimkaWide *w, uint32_t sample, uint32_t log2_parts, uint32_t *host_counts);
+uint64_t simka_wide_sample_records(SimkaWide *w, uint32_t sample);
+int simka_wide_export(SimkaWide *w, uint32_t sample, void *keys_hi_then_lo, void *counts, int on_device);
+int simka_wide_import(SimkaWide *w, uint32_t sample, const void *keys_hi_then_lo, const void *counts, uint64_t n, int on_device);

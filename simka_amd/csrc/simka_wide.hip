@@ -511,3 +511,64 @@ int simka_wide_merge(SimkaWide *w, uint32_t span_cap, SimkaWideCsr *out) {
     out->entries = w->entries; out->groups = w->groups; out->spans = w->spans; out->cursors = w->cursors; out->nb_spans = nkept ? nspans : 0;
     return 0;
 }
+
+// --------------------------------------------------------------------------------------------
+// spectra out of / into the wide arena (-keep-tmp, -nb-gpus, -merge-ranges of the driver).  A sample's records are sorted by
+// k-mer, so "partition p" = the records whose top log2_parts bits of the 2k-bit k-mer equal p: contiguous, in order.
+// --------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+k_wpartbounds(const ull *hi, const ull *lo, uint64_t n, uint32_t W, uint32_t log2_parts, uint32_t *bound /* [P+1] */) {
+    const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t P = 1u << log2_parts;
+    if (p > P) return;
+    if (p == P) { bound[p] = (uint32_t)n; return; }
+    // first record whose prefix is >= p
+    uint64_t a = 0, b = n;
+    while (a < b) {
+        const uint64_t m = (a + b) >> 1;
+        const uint32_t sh = W - log2_parts;                       // prefix = key >> sh over the (hi, lo) pair
+        const ull pre = sh >= 64u ? (hi[m] >> (sh - 64u)) : ((hi[m] << (64u - sh)) | (lo[m] >> sh));
+        if (pre < (ull)p) a = m + 1; else b = m;
+    }
+    bound[p] = (uint32_t)a;
+}
+
+int simka_wide_part_counts(SimkaWide *w, uint32_t sample, uint32_t log2_parts, uint32_t *host_counts) {
+    const uint32_t P = 1u << log2_parts;
+    const uint64_t n = w->s_n[sample], off = w->s_off[sample];
+    if (n == 0) { std::fill(host_counts, host_counts + P, 0u); return 0; }
+    uint32_t *d_b; int rc = wide_buf(w, 7, (uint64_t)P + 2, &d_b); if (rc) return rc;
+    hipLaunchKernelGGL(k_wpartbounds, grid_for((uint64_t)P + 1), dim3(256), 0, w->stream, w->a_hi + off, w->a_lo + off, n, w->W, log2_parts, d_b);
+    std::vector<uint32_t> b((size_t)P + 1);
+    WCHK(hipMemcpyAsync(b.data(), d_b, ((size_t)P + 1) * 4, hipMemcpyDeviceToHost, w->stream));
+    WCHK(hipStreamSynchronize(w->stream));
+    for (uint32_t p = 0; p < P; p++) host_counts[p] = b[p + 1] - b[p];
+    return 0;
+}
+
+uint64_t simka_wide_sample_records(SimkaWide *w, uint32_t sample) { return w->s_n[sample]; }
+
+// keys: [hi x n][lo x n]
+int simka_wide_export(SimkaWide *w, uint32_t sample, void *keys, void *counts, int on_device) {
+    const uint64_t n = w->s_n[sample], off = w->s_off[sample];
+    if (n == 0) return 0;
+    const hipMemcpyKind kind = on_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost;
+    WCHK(hipMemcpyAsync(keys, w->a_hi + off, n * 8, kind, w->stream));
+    WCHK(hipMemcpyAsync((ull *)keys + n, w->a_lo + off, n * 8, kind, w->stream));
+    WCHK(hipMemcpyAsync(counts, w->a_cnt + off, n * 4, kind, w->stream));
+    WCHK(hipStreamSynchronize(w->stream));
+    return 0;
+}
+
+int simka_wide_import(SimkaWide *w, uint32_t sample, const void *keys, const void *counts, uint64_t n, int on_device) {
+    int rc = arena_reserve(w, n); if (rc) return rc;
+    w->s_off[sample] = w->a_used; w->s_n[sample] = n;
+    if (n == 0) return 0;
+    const hipMemcpyKind kind = on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
+    WCHK(hipMemcpyAsync(w->a_hi + w->a_used, keys, n * 8, kind, w->stream));
+    WCHK(hipMemcpyAsync(w->a_lo + w->a_used, (const ull *)keys + n, n * 8, kind, w->stream));
+    WCHK(hipMemcpyAsync(w->a_cnt + w->a_used, counts, n * 4, kind, w->stream));
+    WCHK(hipStreamSynchronize(w->stream));
+    w->a_used += n;
+    return 0;
+}

@@ -786,3 +786,46 @@ def test_randomised_inputs_against_the_oracle(gpu_required, oracle_mod):
     r = subprocess.run([sys.executable, os.path.join(ROOT_DIR, "scripts", "fuzz_vs_oracle.py"), "20", "12345"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
                        text=True, timeout=600)
     assert r.returncode == 0 and "fuzz ok" in r.stdout, r.stdout[-3000:]
+
+
+def test_wide_kmers_through_spectrum_export_paths(gpu_required, golden_dir, tmp_path):
+    """k = 33 (two-word keys, sort-based path): -keep-tmp reuse, -nb-gpus 2 / 3 (spectra exported, imported by key-prefix range into
+    per-GPU merge contexts) and -merge-ranges give the same CSV bytes as the plain single-context run, and the API round trip
+    export -> import reproduces the flat statistics."""
+    import subprocess
+    import simka_amd
+    from simka_amd import build as b
+    base = [b.CLI_PATH, "-in", os.path.join(golden_dir, "example", "simka_input.txt"), "-simple-dist", "-complex-dist", "-kmer-size", "33",
+            "-abundance-min", "1"]
+
+    def run(name, extra):
+        out = str(tmp_path / name)
+        r = subprocess.run(base + ["-out", out, "-out-tmp", str(tmp_path / ("tmp_" + name.split("_")[0]))] + extra, stdout=subprocess.PIPE,
+                           stderr=subprocess.STDOUT, text=True)
+        assert r.returncode == 0, r.stdout
+        res = {os.path.basename(f): gzip.open(f, "rb").read() for f in glob.glob(os.path.join(out, "*.csv.gz"))}
+        assert len(res) == 21
+        return res, r.stdout
+
+    ref, _ = run("plain", [])
+    assert run("g2", ["-nb-gpus", "2", "-gpu-shared"])[0] == ref
+    assert run("g3", ["-nb-gpus", "3", "-gpu-shared"])[0] == ref
+    assert run("ranges", ["-merge-ranges", "4"])[0] == ref
+    first, log1 = run("keep_a", ["-keep-tmp"])
+    again, log2 = run("keep_b", ["-keep-tmp"])
+    assert first == ref and again == ref and "reused" not in log1 and log2.count("k-mer spectrum reused") == 5
+    # API round trip
+    samples, packed = _load_example(golden_dir)
+    kw = dict(kmer_size=33, abundance_min=1, simple_dist=True, complex_dist=True)
+    with simka_amd.SimkaContext(len(packed), **kw) as a:
+        for i, (pk, off, nb, nin) in enumerate(packed):
+            a.count_sample(i, pk, nb, len(off) - 1, offsets=off, nb_input_reads=nin)
+        spectra = [a.export_sample(i) for i in range(len(packed))]
+        a.merge()
+        flat = a.stats().flat.copy()
+    assert all(len(s[2]) == 2 * len(s[3]) for s in spectra)
+    with simka_amd.SimkaContext(len(packed), **kw) as c:
+        for i in reversed(range(len(packed))):
+            c.import_sample(i, *spectra[i])
+        c.merge()
+        assert np.array_equal(c.stats().flat, flat)
