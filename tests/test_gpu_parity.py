@@ -829,3 +829,12 @@ def test_wide_kmers_through_spectrum_export_paths(gpu_required, golden_dir, tmp_
             c.import_sample(i, *spectra[i])
         c.merge()
         assert np.array_equal(c.stats().flat, flat)
+
+
+def test_hash_and_sort_pipelines_agree_at_scale(gpu_required):
+    """scripts/cross_check.py, 3 rounds: device-generated samples of 50k..300k reads with adapter-like hot reads and poly-A stretches
+    (spill runs, exact redo), random k / abundance-min / distance families -- the flat statistics of the two pipelines are identical."""
+    import subprocess, sys
+    r = subprocess.run([sys.executable, os.path.join(ROOT_DIR, "scripts", "cross_check.py"), "3", "11"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
+                       text=True, timeout=900)
+    assert r.returncode == 0 and "cross-check ok" in r.stdout, r.stdout[-3000:]
