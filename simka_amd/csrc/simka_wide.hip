@@ -114,14 +114,18 @@ k_wscan(WideScanArgs a, ull *khi, ull *klo, ull *nvalid) {
     const uint32_t top = 2u * (k - 1u);                      // bit position of the first base in the reverse-complement word
     ull fh = 0, fl = 0, rh = 0, rl = 0;
     uint32_t have = 0;                                        // bases of the current read inside the window (capped at k)
-    for (uint64_t p = p0 > rstart + (k - 1u) ? p0 - (k - 1u) : rstart; p < pend; p++) {
+    uint64_t p = p0 > rstart + (k - 1u) ? p0 - (k - 1u) : rstart;
+    ull word = a.packed[p >> 5] >> ((p & 31u) * 2u);        // the bases from p on, refilled every 32 bases
+    for (; p < pend; p++) {
         while (p >= rend) {        // next read (fixed length: arithmetic; else the offsets array)
             rd++;
             rstart = rend;
             rend = a.fixed_len ? rstart + a.fixed_len : a.offsets[rd + 1];
             have = 0; fh = fl = rh = rl = 0;
         }
-        const ull c = wbase(a.packed, p);
+        if ((p & 31u) == 0u) word = a.packed[p >> 5];
+        const ull c = word & 3ull;
+        word >>= 2;
         fh = ((fh << 2) | (fl >> 62)) & mhi;                 // forward: (f << 2 | c) & mask
         fl = ((fl << 2) | c) & mlo;
         rl = (rl >> 2) | (rh << 62);                         // reverse complement: (r >> 2) | (c ^ 2) << 2(k-1)
