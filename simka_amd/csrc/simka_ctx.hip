@@ -1154,6 +1154,17 @@ SIMKA_EXPORT int simka_import_samples_device(simka_ctx *ctx, const uint32_t *sam
 }
 
 // ---- pair accumulation: shared by the hash merge (k_group's CSR) and the sort merge of the wide-k path -------------------
+#ifdef SIMKA_PHASE_PROF
+static void pairs_phase_report() {
+    ull h[8];
+    if (hipDeviceSynchronize() != hipSuccess || hipMemcpyFromSymbol(h, HIP_SYMBOL(g_pairs_phase), 64) != hipSuccess) return;
+    ull t_ = 0; for (ull v : h) t_ += v;
+    if (t_) fprintf(stderr, "k_pairs phases %%: loop-top %.1f stage %.1f sync+flush %.1f compaction %.1f scan %.1f search %.1f pairs %.1f\n", 100.0 * h[0] / t_, 100.0 * h[1] / t_, 100.0 * h[2] / t_,
+                    100.0 * h[3] / t_, 100.0 * h[4] / t_, 100.0 * h[5] / t_, 100.0 * h[6] / t_);
+    memset(h, 0, 64); (void)hipMemcpyToSymbol(HIP_SYMBOL(g_pairs_phase), h, 64);
+}
+#endif
+
 struct PairLaunch { SimkaPairCfg pc; size_t lds_pairs = 0; uint32_t ntp = 1, nblk = 1; bool small_block = false; };
 
 static void pair_setup(simka_ctx *ctx, PairLaunch &pl) {
@@ -1206,6 +1217,9 @@ static void pair_launch(simka_ctx *ctx, const PairLaunch &pl, const SimkaSpan *s
         else
             hipLaunchKernelGGL((k_pairs<true, K4_BLOCK_BIG>), dim3(pl.nblk, pl.ntp), dim3(K4_BLOCK_BIG), pl.lds_pairs, ctx->stream, spans, cursors, entries, groups, pc, acc);
     });
+#ifdef SIMKA_PHASE_PROF
+    pairs_phase_report();
+#endif
     if (huge)
         launch_timed(ctx, KID_PAIRS_GLOBAL, [&] {
             hipLaunchKernelGGL(k_pairs_global, dim3(64, 64), dim3(256), 0, ctx->stream, huge, cursors, entries, pc, acc);
@@ -1213,6 +1227,7 @@ static void pair_launch(simka_ctx *ctx, const PairLaunch &pl, const SimkaSpan *s
 }
 
 static int complex_finish(simka_ctx *ctx, const SimkaPairCfg &pc);
+
 
 // ---- merge side ---------------------------------------------------------------------------
 SIMKA_EXPORT int simka_merge(simka_ctx *ctx) {

@@ -1191,6 +1191,17 @@ __device__ __forceinline__ void pairs_flush(ull *pk, ull *c64, ull *acc, const S
     __syncthreads();
 }
 
+#ifdef SIMKA_PHASE_PROF
+__device__ ull g_pairs_phase[8];
+#define PP_DECL ull pp_t = wall_clock64(), pp_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#define PP(i) { const ull n_ = wall_clock64(); pp_acc[i] += n_ - pp_t; pp_t = n_; }
+#define PP_FLUSH if (threadIdx.x == 0) { for (int i_ = 0; i_ < 8; i_++) atomicAdd(&g_pairs_phase[i_], pp_acc[i_]); }
+#else
+#define PP_DECL
+#define PP(i)
+#define PP_FLUSH
+#endif
+
 // TILED=false: all N(N-1)/2 cells live in LDS (one "tile" = every sample).  TILED=true: block row blockIdx.y owns the
 // sample-tile pair (I<=J); each span's entries are COMPACTED to the members of tile I (list A) and tile J (list B) with
 // one packed block scan, so a block enumerates exactly the pairs it owns (A x A triangle on the diagonal, A x B
@@ -1258,8 +1269,10 @@ k_pairs(const SimkaSpan *spans, const ull *cursors, const ull *entries, const ui
         pre_e[q] = (i < span.nent) ? entries[span.ebase + i] : 0ull;
         pre_g[q] = (i < span.ngrp) ? groups[span.gbase + i] : 0u;
     }
+    PP_DECL
     for (; sp < nspans; sp += gridDim.x) {
         // ---- current span: registers -> LDS
+        PP(0)
         __syncthreads();
         const SimkaSpan cur = span;
 #pragma unroll
@@ -1293,6 +1306,7 @@ k_pairs(const SimkaSpan *spans, const ull *cursors, const ull *entries, const ui
             pre_e[q] = (i < span.nent) ? entries[span.ebase + i] : 0ull;
             pre_g[q] = (i < span.ngrp) ? groups[span.gbase + i] : 0u;
         }
+        PP(1)
         if (cur.ngrp == 0) continue;     // unused slot of a k_group span slab (uniform)
         const ull add = (ull)cur.ngrp * (ull)cur.maxc;
         const ull addq = (ull)cur.ngrp * (ull)cur.maxc * (ull)cur.maxc;
@@ -1302,6 +1316,7 @@ k_pairs(const SimkaSpan *spans, const ull *cursors, const ull *entries, const ui
         bound += add;
         if (chord_fast) bound_q += addq;
         __syncthreads();
+        PP(2)
         if (TILED) {
             // compact the tile members: one scan of the packed flags gives every entry its slot in list A / list B
             const uint32_t tot = block_excl_scan<K4_BLOCK>(epre, cur.nent, tmp);
@@ -1331,9 +1346,11 @@ k_pairs(const SimkaSpan *spans, const ull *cursors, const ull *entries, const ui
             }
             __syncthreads();
         }
+        PP(3)
         const uint32_t P = block_excl_scan<K4_BLOCK>(gpref, cur.ngrp, tmp);
         if (tid == 0) gpref[cur.ngrp] = P;
         __syncthreads();
+        PP(4)
         const uint32_t chunk = (P + K4_BLOCK - 1) / K4_BLOCK;
         uint32_t p = tid * chunk;
         const uint32_t pend = (p + chunk < P) ? p + chunk : P;
@@ -1351,6 +1368,7 @@ k_pairs(const SimkaSpan *spans, const ull *cursors, const ull *entries, const ui
             } else tri_unrank(p - gpref[g], nA, x, y);
             uint32_t ix = TILED ? (uint32_t)idxA[a0 + x] : a0 + x;
             ull ex = ent[ix];
+            PP(5)
             for (; p < pend; p++) {
                 const uint32_t iy = rect ? (uint32_t)idxB[b0 + y] : (TILED ? (uint32_t)idxA[a0 + y] : a0 + y);
                 const ull ey = ent[iy];
@@ -1400,6 +1418,8 @@ k_pairs(const SimkaSpan *spans, const ull *cursors, const ull *entries, const ui
             }
         }
     }
+    PP(6)
+    PP_FLUSH
     __syncthreads();
     pairs_flush<TILED, K4_BLOCK>(pk, c64, acc, pc, rect, baseI, baseJ);
 }
