@@ -47,7 +47,7 @@ typedef struct simka_config {
     uint32_t struct_size;        /* = sizeof(simka_config) */
     uint32_t nb_samples;         /* N, SimkaStatistics::_nbBanks (1..65535) */
     uint32_t kmer_size;          /* -kmer-size, 1..63.  k <= 31 (one 64-bit word, Kmer<span=32>): the hash pipeline.  32..63 (two words,
-                                  * Kmer<span=64>): the sort-based path -- exact, ~8x slower, no partition shards / batch exchange forms yet */
+                                  * Kmer<span=64>): the sort-based path -- exact, ~8x slower, no partition shards yet */
     uint32_t abundance_min;      /* -abundance-min (ref: src/minikc/MiniKC.hpp:56) */
     uint32_t abundance_max;      /* -abundance-max, clamped to 999999999 (ref: src/core/SimkaAlgorithm.cpp:188) */
     uint32_t dist_flags;         /* SIMKA_DIST_* */
@@ -174,6 +174,14 @@ int simka_gather_samples_device(simka_ctx *ctx, const uint32_t *samples, uint32_
 int simka_import_samples_device(simka_ctx *ctx, const uint32_t *samples, uint32_t nb, const simka_sample_totals *totals,
                                 uint64_t part_lo, uint64_t part_width, const uint32_t *part_counts, const uint64_t *in_offsets,
                                 uint64_t nb_partitions, const void *d_keys, const void *d_counts, uint64_t nb_records);
+
+/* kmer_size >= 32 (key_words == 2): the batch gather / import with the high and the low key words in separate device buffers.
+ * A received block holds each sample's records contiguously and sorted (a sample comes from ONE rank): sample_offsets /
+ * sample_records say where.  simka_samples_spectrum_info is shared (its partitions are key-prefix ranges). */
+int simka_gather_samples_device_wide(simka_ctx *ctx, const uint32_t *samples, uint32_t nb, const uint64_t *out_offsets, void *d_keys_hi, void *d_keys_lo,
+                                     void *d_counts);
+int simka_import_samples_device_wide(simka_ctx *ctx, const uint32_t *samples, uint32_t nb, const simka_sample_totals *totals, const uint64_t *sample_offsets,
+                                     const uint64_t *sample_records, const void *d_keys_hi, const void *d_keys_lo, const void *d_counts);
 
 /* ---- merge side ---------------------------------------------------------------------------
  * Replaces every `simkaMerge` job: the N-way k-mer merge (ref: src/SimkaMerge.cpp:1164-1264),

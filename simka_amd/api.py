@@ -99,6 +99,8 @@ def load_library(build_if_missing=True):
         "simka_import_samples_device": (i32, [vp, vp, u32, vp, u64, u64, vp, vp, u64, vp, vp, u64]),
         "simka_device_memory": (i32, [i32, C.POINTER(u64), C.POINTER(u64)]),
         "simka_default_log2_partitions": (u32, [u64, u32]),
+        "simka_gather_samples_device_wide": (i32, [vp, vp, u32, vp, vp, vp, vp]),
+        "simka_import_samples_device_wide": (i32, [vp, vp, u32, vp, vp, vp, vp, vp, vp]),
         "simka_merge": (i32, [vp]),
         "simka_stats_device_buffer": (i32, [vp, C.POINTER(vp), C.POINTER(u64)]),
         "simka_stats_download": (i32, [vp, vp, u64, C.POINTER(StatsView)]),
@@ -345,14 +347,22 @@ class SimkaContext:
                                                         counts.data_ptr() if n else None, n))
 
     # batch forms: one synchronisation for many samples (simka_amd/dist.py)
-    def nb_partitions(self):
+    def spectrum_info(self, index):
+        """(nb_records, nb_partitions, key_words) of a counted sample"""
+        info = SpectrumInfo()
+        self._check(self.lib.simka_sample_spectrum_info(self.h, index, C.byref(info)))
+        return int(info.nb_records), int(info.nb_partitions), max(int(info.key_words), 1)
+
+    def nb_partitions(self, sample=None):
+        if sample is not None:
+            return self.spectrum_info(sample)[1]
         g = self.geometry()
         return 1 << (g["log2_level1"] + g["log2_level2"])
 
     def samples_spectrum_info(self, samples):
         """-> (part_counts u32 [nb, nparts], totals SampleTotals array) of counted samples."""
         idx = np.ascontiguousarray(samples, dtype=np.uint32)
-        pc = np.zeros((len(idx), self.nb_partitions()), dtype=np.uint32)
+        pc = np.zeros((len(idx), self.nb_partitions(int(idx[0]) if len(idx) else None)), dtype=np.uint32)
         tot = (SampleTotals * max(len(idx), 1))()
         self._check(self.lib.simka_samples_spectrum_info(self.h, idx.ctypes.data, len(idx), pc.ctypes.data, C.addressof(tot)))
         return pc, tot
@@ -364,6 +374,24 @@ class SimkaContext:
         if len(idx) == 0 or keys.numel() == 0:
             return
         self._check(self.lib.simka_gather_samples_device(self.h, idx.ctypes.data, len(idx), off.ctypes.data, keys.data_ptr(), counts.data_ptr()))
+
+    def gather_samples_device_wide(self, samples, out_offsets, keys_hi, keys_lo, counts):
+        """kmer_size >= 32: high and low key words go to separate tensors"""
+        idx = np.ascontiguousarray(samples, dtype=np.uint32)
+        off = np.ascontiguousarray(out_offsets, dtype=np.uint64)
+        if len(idx) == 0 or counts.numel() == 0:
+            return
+        self._check(self.lib.simka_gather_samples_device_wide(self.h, idx.ctypes.data, len(idx), off.ctypes.data, keys_hi.data_ptr(), keys_lo.data_ptr(),
+                                                              counts.data_ptr()))
+
+    def import_samples_device_wide(self, samples, totals, sample_offsets, sample_records, keys_hi, keys_lo, counts):
+        idx = np.ascontiguousarray(samples, dtype=np.uint32)
+        so = np.ascontiguousarray(sample_offsets, dtype=np.uint64)
+        sr = np.ascontiguousarray(sample_records, dtype=np.uint64)
+        n = int(counts.numel())
+        self._check(self.lib.simka_import_samples_device_wide(self.h, idx.ctypes.data, len(idx), C.addressof(totals), so.ctypes.data, sr.ctypes.data,
+                                                              keys_hi.data_ptr() if n else None, keys_lo.data_ptr() if n else None,
+                                                              counts.data_ptr() if n else None))
 
     def import_samples_device(self, samples, totals, part_lo, part_counts, in_offsets, nb_partitions, keys, counts):
         """part_counts / in_offsets: [nb, width] for the partitions [part_lo, part_lo + width); totals: SampleTotals array."""

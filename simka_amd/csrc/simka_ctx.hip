@@ -990,7 +990,6 @@ SIMKA_EXPORT int simka_import_sample_device(simka_ctx *ctx, uint32_t sample, con
 
 // ---- batch forms (multi-GPU exchange) ---------------------------------------------------------
 SIMKA_EXPORT int simka_samples_spectrum_info(simka_ctx *ctx, const uint32_t *samples, uint32_t nb, uint32_t *part_counts, simka_sample_totals *totals) {
-    if (ctx && ctx->wide) return ctx->fail(SIMKA_ERR_UNSUPPORTED, "simka_samples_spectrum_info: spectra of kmer_size >= 32 (sort-based path) cannot be exported / imported yet");
     if (!ctx || (nb && (!samples || !part_counts || !totals))) return SIMKA_ERR_INVALID;
     const uint32_t N = ctx->cfg.nb_samples, fl = ctx->cfg.dist_flags;
     for (uint32_t j = 0; j < nb; j++)
@@ -1003,7 +1002,10 @@ SIMKA_EXPORT int simka_samples_spectrum_info(simka_ctx *ctx, const uint32_t *sam
     std::vector<ull> tot((size_t)SIMKA_NB_TOTALS * N, 0);
     HIPCHK(hipMemcpyAsync(tot.data(), ctx->d_stats + stats_off_tot(N, fl, 0), tot.size() * 8, hipMemcpyDeviceToHost, ctx->stream));
     for (uint32_t j = 0; j < nb; j++) {
-        if (ctx->geometry_ready) HIPCHK(hipMemcpyAsync(part_counts + (size_t)j * ctx->nparts, ctx->d_fcnt + (uint64_t)samples[j] * ctx->nparts, ctx->nparts * 4, hipMemcpyDeviceToHost, ctx->stream));
+        if (ctx->wide) {      // sorted two-word spectra: partitions are key-prefix ranges
+            const int wrc = simka_wide_part_counts(ctx->wide, samples[j], wide_log2_parts(ctx), part_counts + ((size_t)j << wide_log2_parts(ctx)));
+            if (wrc) return wide_fail(ctx, wrc);
+        } else if (ctx->geometry_ready) HIPCHK(hipMemcpyAsync(part_counts + (size_t)j * ctx->nparts, ctx->d_fcnt + (uint64_t)samples[j] * ctx->nparts, ctx->nparts * 4, hipMemcpyDeviceToHost, ctx->stream));
         else memset(part_counts + (size_t)j * ctx->nparts, 0, ctx->nparts * 4);
     }
     HIPCHK(hipStreamSynchronize(ctx->stream));
@@ -1018,8 +1020,10 @@ SIMKA_EXPORT int simka_samples_spectrum_info(simka_ctx *ctx, const uint32_t *sam
 }
 
 SIMKA_EXPORT int simka_gather_samples_device(simka_ctx *ctx, const uint32_t *samples, uint32_t nb, const uint64_t *out_offsets, void *d_keys, void *d_counts) {
-    if (ctx && ctx->wide) return ctx->fail(SIMKA_ERR_UNSUPPORTED, "simka_gather_samples_device: spectra of kmer_size >= 32 (sort-based path) cannot be exported / imported yet");
     if (!ctx) return SIMKA_ERR_INVALID;
+    if (ctx->wide) {      // d_keys: [high words of every run][low words], the halves `total records` apart (given by the caller through nb_total)
+        return ctx->fail(SIMKA_ERR_INVALID, "simka_gather_samples_device: use simka_gather_samples_device_wide for kmer_size >= 32");
+    }
     if (nb == 0 || !ctx->geometry_ready) return SIMKA_OK;
     if (!samples || !out_offsets || !d_keys || !d_counts) return ctx->fail(SIMKA_ERR_INVALID, "simka_gather_samples_device: NULL argument");
     const uint32_t N = ctx->cfg.nb_samples;
@@ -1043,7 +1047,7 @@ SIMKA_EXPORT int simka_gather_samples_device(simka_ctx *ctx, const uint32_t *sam
 SIMKA_EXPORT int simka_import_samples_device(simka_ctx *ctx, const uint32_t *samples, uint32_t nb, const simka_sample_totals *totals,
                                              uint64_t part_lo, uint64_t part_width, const uint32_t *part_counts, const uint64_t *in_offsets,
                                              uint64_t nb_partitions, const void *d_keys, const void *d_counts, uint64_t nb_records) {
-    if (ctx && ctx->wide) return ctx->fail(SIMKA_ERR_UNSUPPORTED, "simka_import_samples_device: spectra of kmer_size >= 32 (sort-based path) cannot be exported / imported yet");
+    if (ctx && ctx->wide) return ctx->fail(SIMKA_ERR_INVALID, "simka_import_samples_device: use simka_import_samples_device_wide for kmer_size >= 32");
     if (!ctx || (nb && (!samples || !totals || !part_counts || !in_offsets))) return SIMKA_ERR_INVALID;
     const uint32_t N = ctx->cfg.nb_samples, fl = ctx->cfg.dist_flags;
     if (ctx->merged) return ctx->fail(SIMKA_ERR_STATE, "simka_import_samples_device: merge already ran");
@@ -1228,6 +1232,66 @@ static void pair_launch(simka_ctx *ctx, const PairLaunch &pl, const SimkaSpan *s
 
 static int complex_finish(simka_ctx *ctx, const SimkaPairCfg &pc);
 
+
+// the two-word forms of the batch gather / import (kmer_size >= 32): high and low words travel in separate buffers
+SIMKA_EXPORT int simka_gather_samples_device_wide(simka_ctx *ctx, const uint32_t *samples, uint32_t nb, const uint64_t *out_offsets, void *d_keys_hi,
+                                                  void *d_keys_lo, void *d_counts) {
+    if (!ctx || !ctx->wide) return SIMKA_ERR_INVALID;
+    if (nb == 0) return SIMKA_OK;
+    if (!samples || !out_offsets || !d_keys_hi || !d_keys_lo || !d_counts) return ctx->fail(SIMKA_ERR_INVALID, "simka_gather_samples_device_wide: NULL argument");
+    for (uint32_t j = 0; j < nb; j++)
+        if (samples[j] >= ctx->cfg.nb_samples || !ctx->counted[samples[j]]) return ctx->fail(SIMKA_ERR_STATE, "simka_gather_samples_device_wide: sample %u not counted", samples[j]);
+    HIPCHK(hipSetDevice(ctx->cfg.device));
+    const int wrc = simka_wide_gather(ctx->wide, samples, nb, wide_log2_parts(ctx), out_offsets, d_keys_hi, d_keys_lo, d_counts);
+    return wrc ? wide_fail(ctx, wrc) : SIMKA_OK;
+}
+
+SIMKA_EXPORT int simka_import_samples_device_wide(simka_ctx *ctx, const uint32_t *samples, uint32_t nb, const simka_sample_totals *totals,
+                                                  const uint64_t *sample_offsets, const uint64_t *sample_records, const void *d_keys_hi, const void *d_keys_lo,
+                                                  const void *d_counts) {
+    if (!ctx || !ctx->wide || (nb && (!samples || !totals || !sample_offsets || !sample_records))) return SIMKA_ERR_INVALID;
+    const uint32_t N = ctx->cfg.nb_samples, fl = ctx->cfg.dist_flags;
+    if (ctx->merged) return ctx->fail(SIMKA_ERR_STATE, "simka_import_samples_device_wide: merge already ran");
+    HIPCHK(hipSetDevice(ctx->cfg.device));
+    std::vector<ull> tot((size_t)SIMKA_NB_TOTALS * N);
+    HIPCHK(hipMemcpyAsync(tot.data(), ctx->d_stats + stats_off_tot(N, fl, 0), tot.size() * 8, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    for (uint32_t j = 0; j < nb; j++) {
+        const uint32_t s = samples[j];
+        if (s >= N) return ctx->fail(SIMKA_ERR_INVALID, "simka_import_samples_device_wide: sample index %u out of range", s);
+        if (ctx->counted[s]) return ctx->fail(SIMKA_ERR_STATE, "simka_import_samples_device_wide: sample %u was already counted", s);
+        const uint64_t o = sample_offsets[j], n = sample_records[j];
+        const int wrc = simka_wide_import_words(ctx->wide, s, (const ull *)d_keys_hi + o, (const ull *)d_keys_lo + o, (const uint32_t *)d_counts + o, n);
+        if (wrc) return wide_fail(ctx, wrc);
+        tot[(size_t)SIMKA_TOT_D * N + s] = totals[j].nb_distinct; tot[(size_t)SIMKA_TOT_N * N + s] = totals[j].nb_kmers;
+        tot[(size_t)SIMKA_TOT_Q * N + s] = totals[j].sum_sq; tot[(size_t)SIMKA_TOT_KOCC * N + s] = totals[j].kmer_occurrences;
+        tot[(size_t)SIMKA_TOT_DALL * N + s] = totals[j].distinct_all;
+        if (ctx->d_hist && n) {      // -complex-dist: histogram of the imported solid counts
+            std::vector<uint32_t> hc(n);
+            HIPCHK(hipMemcpyAsync(hc.data(), (const uint32_t *)d_counts + o, n * 4, hipMemcpyDeviceToHost, ctx->stream));
+            HIPCHK(hipStreamSynchronize(ctx->stream));
+            std::vector<ull> hist(SIMKA_HIST_MAX, 0);
+            std::vector<uint32_t> ovf;
+            for (uint32_t c : hc) { if (c < SIMKA_HIST_MAX) hist[c]++; else { ovf.push_back(s); ovf.push_back(c); } }
+            HIPCHK(hipMemcpyAsync(ctx->d_hist + (uint64_t)s * SIMKA_HIST_MAX, hist.data(), SIMKA_HIST_MAX * 8, hipMemcpyHostToDevice, ctx->stream));
+            if (!ovf.empty()) {
+                ull novf = 0;
+                HIPCHK(hipMemcpyAsync(&novf, ctx->d_ovf_cursor, 8, hipMemcpyDeviceToHost, ctx->stream));
+                HIPCHK(hipStreamSynchronize(ctx->stream));
+                const ull add = ovf.size() / 2;
+                if (novf + add <= ctx->ovf_cap) HIPCHK(hipMemcpyAsync(ctx->d_ovf_list + 2 * novf, ovf.data(), ovf.size() * 4, hipMemcpyHostToDevice, ctx->stream));
+                novf += add;
+                HIPCHK(hipMemcpyAsync(ctx->d_ovf_cursor, &novf, 8, hipMemcpyHostToDevice, ctx->stream));
+            }
+            HIPCHK(hipStreamSynchronize(ctx->stream));
+        }
+        ctx->nb_reads[s] = totals[j].nb_reads;
+        ctx->counted[s] = 1;
+    }
+    HIPCHK(hipMemcpyAsync(ctx->d_stats + stats_off_tot(N, fl, 0), tot.data(), tot.size() * 8, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    return SIMKA_OK;
+}
 
 // ---- merge side ---------------------------------------------------------------------------
 SIMKA_EXPORT int simka_merge(simka_ctx *ctx) {

@@ -30,3 +30,5 @@ int simka_wide_part_counts(SimkaWide *w, uint32_t sample, uint32_t log2_parts, u
 uint64_t simka_wide_sample_records(SimkaWide *w, uint32_t sample);
 int simka_wide_export(SimkaWide *w, uint32_t sample, void *keys_hi_then_lo, void *counts, int on_device);
 int simka_wide_import(SimkaWide *w, uint32_t sample, const void *keys_hi_then_lo, const void *counts, uint64_t n, int on_device);
+int simka_wide_gather(SimkaWide *w, const uint32_t *samples, uint32_t nb, uint32_t log2_parts, const uint64_t *out_offsets, void *d_hi, void *d_lo, void *d_counts);
+int simka_wide_import_words(SimkaWide *w, uint32_t sample, const void *d_hi, const void *d_lo, const void *d_counts, uint64_t n);

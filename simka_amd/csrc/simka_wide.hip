@@ -576,3 +576,46 @@ int simka_wide_import(SimkaWide *w, uint32_t sample, const void *keys, const voi
     w->a_used += n;
     return 0;
 }
+
+// ---- batch forms (multi-GPU exchange): many samples, caller-chosen destination of every (sample, partition) run -------------------
+__global__ void __launch_bounds__(256)
+k_wgather_runs(const ull *a_hi, const ull *a_lo, const uint32_t *a_cnt, ull s_off, const uint32_t *bound, const ull *out_off, uint32_t P,
+               ull *o_hi, ull *o_lo, uint32_t *o_cnt) {
+    for (uint32_t p = blockIdx.x; p < P; p += gridDim.x) {
+        const uint32_t b = bound[p], n = bound[p + 1] - b;
+        const ull src = s_off + b, dst = out_off[p];
+        for (uint32_t i = threadIdx.x; i < n; i += 256) { o_hi[dst + i] = a_hi[src + i]; o_lo[dst + i] = a_lo[src + i]; o_cnt[dst + i] = a_cnt[src + i]; }
+    }
+}
+
+// out_offsets: host [nb][P]; d_hi / d_lo / d_counts: device buffers addressed by those offsets
+int simka_wide_gather(SimkaWide *w, const uint32_t *samples, uint32_t nb, uint32_t log2_parts, const uint64_t *out_offsets, void *d_hi, void *d_lo, void *d_counts) {
+    const uint32_t P = 1u << log2_parts;
+    uint32_t *d_b; ull *d_off;
+    int rc;
+    if ((rc = wide_buf(w, 7, (uint64_t)P + 2, &d_b)) || (rc = wide_buf(w, 8, (uint64_t)P + 2, &d_off))) return rc;
+    for (uint32_t j = 0; j < nb; j++) {
+        const uint32_t s = samples[j];
+        const uint64_t n = w->s_n[s], off = w->s_off[s];
+        if (n == 0) continue;
+        hipLaunchKernelGGL(k_wpartbounds, grid_for((uint64_t)P + 1), dim3(256), 0, w->stream, w->a_hi + off, w->a_lo + off, n, w->W, log2_parts, d_b);
+        WCHK(hipMemcpyAsync(d_off, out_offsets + (size_t)j * P, (size_t)P * 8, hipMemcpyHostToDevice, w->stream));
+        hipLaunchKernelGGL(k_wgather_runs, dim3(std::min<uint32_t>(P, 1024u)), dim3(256), 0, w->stream, w->a_hi, w->a_lo, w->a_cnt, (ull)off, d_b, d_off, P,
+                           (ull *)d_hi, (ull *)d_lo, (uint32_t *)d_counts);
+        WCHK(hipStreamSynchronize(w->stream));          // d_off is reused by the next sample
+    }
+    WCHK(hipGetLastError());
+    return 0;
+}
+
+// one sample's (sorted) slice out of a received block: separate word arrays
+int simka_wide_import_words(SimkaWide *w, uint32_t sample, const void *d_hi, const void *d_lo, const void *d_counts, uint64_t n) {
+    int rc = arena_reserve(w, n); if (rc) return rc;
+    w->s_off[sample] = w->a_used; w->s_n[sample] = n;
+    if (n == 0) return 0;
+    WCHK(hipMemcpyAsync(w->a_hi + w->a_used, d_hi, n * 8, hipMemcpyDeviceToDevice, w->stream));
+    WCHK(hipMemcpyAsync(w->a_lo + w->a_used, d_lo, n * 8, hipMemcpyDeviceToDevice, w->stream));
+    WCHK(hipMemcpyAsync(w->a_cnt + w->a_used, d_counts, n * 4, hipMemcpyDeviceToDevice, w->stream));
+    w->a_used += n;
+    return 0;
+}

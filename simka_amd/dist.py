@@ -201,9 +201,10 @@ def count_exchange_merge(ctx, count_fn, nb_samples, device):
     mine = samples_of(rank, world, nb_samples)
     for s in mine:
         count_fn(s)
-    np_t = torch.tensor([ctx.nb_partitions() if mine else 0], dtype=torch.int64, device=cdev)
-    dist.all_reduce(np_t, op=dist.ReduceOp.MAX)          # ranks without samples learn the partition count
-    P = int(np_t.item())
+    info = ctx.spectrum_info(mine[0]) if mine else (0, 0, 0)
+    np_t = torch.tensor([info[1], info[2]], dtype=torch.int64, device=cdev)
+    dist.all_reduce(np_t, op=dist.ReduceOp.MAX)          # ranks without samples learn the partition count and the key width
+    P, kw = int(np_t[0].item()), int(np_t[1].item())      # kw = 2: kmer_size >= 32, high and low key words travel separately
     bounds = partition_bounds(P, world)
     width = max(bounds[g + 1] - bounds[g] for g in range(world))
     maxn = (nb_samples + world - 1) // world
@@ -228,10 +229,15 @@ def count_exchange_merge(ctx, count_fn, nb_samples, device):
             t = tot[j]
             tot_send[j] = [t.nb_reads, t.nb_distinct, t.nb_kmers, t.sum_sq, t.kmer_occurrences, t.distinct_all]
         ks = torch.empty(pos, dtype=torch.int64, device=device)
+        ks2 = torch.empty(pos if kw == 2 else 0, dtype=torch.int64, device=device)
         cs = torch.empty(pos, dtype=torch.int32, device=device)
-        ctx.gather_samples_device(mine, out_off, ks, cs)
+        if kw == 2:
+            ctx.gather_samples_device_wide(mine, out_off, ks, ks2, cs)
+        else:
+            ctx.gather_samples_device(mine, out_off, ks, cs)
     else:
         ks = torch.empty(0, dtype=torch.int64, device=device)
+        ks2 = torch.empty(0, dtype=torch.int64, device=device)
         cs = torch.empty(0, dtype=torch.int32, device=device)
     # ---- the exchange
     meta_t = torch.from_numpy(meta).to(cdev)
@@ -246,8 +252,13 @@ def count_exchange_merge(ctx, count_fn, nb_samples, device):
     cr = torch.empty(sum(recv_splits), dtype=torch.int32, device=cdev)
     dist.all_to_all_single(kr, ks.to(cdev), recv_splits, send_splits)
     dist.all_to_all_single(cr, cs.to(cdev), recv_splits, send_splits)
+    kr2 = None
+    if kw == 2:
+        kr2 = torch.empty(sum(recv_splits), dtype=torch.int64, device=cdev)
+        dist.all_to_all_single(kr2, ks2.to(cdev), recv_splits, send_splits)
+        kr2 = kr2.to(device)
     kr, cr = kr.to(device), cr.to(device)
-    ks = cs = None
+    ks = ks2 = cs = None
     # ---- receive side: block layout [r][j][my partitions]; samples in ascending order for the import
     lo, hi = bounds[rank], bounds[rank + 1]
     w = hi - lo
@@ -271,6 +282,13 @@ def count_exchange_merge(ctx, count_fn, nb_samples, device):
             tot_in[s] = SampleTotals(int(tt[0]), int(tt[1]), int(tt[2]), int(tt[3]), int(tt[4]), int(tt[5]))
     assert pos == int(kr.numel())
     ctx.reset()
+    if kw == 2:      # each sample's slice of my key-prefix range is one contiguous, sorted run of the received block
+        s_rec = pc_in.astype(np.int64).sum(axis=1)
+        s_off = off_in[:, 0].astype(np.int64) if w else np.zeros(nb_samples, dtype=np.int64)
+        ctx.import_samples_device_wide(np.arange(nb_samples), tot_in, s_off, s_rec, kr, kr2, cr)
+        ctx.merge()
+        allreduce_stats_device(ctx, totals_already_reduced=True)
+        return
     ctx.import_samples_device(np.arange(nb_samples), tot_in, lo, pc_in[:, :max(w, 0)] if w else pc_in[:, :0], off_in[:, :w] if w else off_in[:, :0], P, kr, cr)
     ctx.merge()
     allreduce_stats_device(ctx, totals_already_reduced=True)      # imported totals are already global on every rank
