@@ -34,6 +34,21 @@ ctx = simka_amd.SimkaContext(n, max_kmers_per_sample=R * (L - k + 1), **kw)
 sdist.count_exchange_merge(ctx, lambda s: ctx.count_sample(s, packed[s], R * L, R, fixed_len=L), n, dev)
 b = ctx.stats().flat.copy()
 ctx.close()
+# (c) the same exchange for k = 33 (two-word keys: high and low words in separate all-to-alls) against the plain wide-k run
+kw33 = dict(kw, kmer_size=33)
+os.environ.pop("SIMKA_FORCE_EXCHANGE")
+ctx = simka_amd.SimkaContext(n, **kw33)
+for s in range(n):
+    ctx.count_sample(s, packed[s], R * L, R, fixed_len=L)
+ctx.merge()
+c = ctx.stats().flat.copy()
+ctx.close()
+os.environ["SIMKA_FORCE_EXCHANGE"] = "1"
+ctx = simka_amd.SimkaContext(n, **kw33)
+sdist.count_exchange_merge(ctx, lambda s: ctx.count_sample(s, packed[s], R * L, R, fixed_len=L), n, dev)
+d = ctx.stats().flat.copy()
+ctx.close()
 if rank == 0:
-    print("dist smoke", "ok" if (world > 1 or np.array_equal(a, b)) else "MISMATCH", world, int(a[0]), int(b[0]), int(a[1]), int(b[1]))
+    good = world > 1 or (np.array_equal(a, b) and np.array_equal(c, d))
+    print("dist smoke", "ok" if good else "MISMATCH", world, int(a[0]), int(b[0]), int(a[1]), int(b[1]), int(c[0]), int(d[0]))
 dist.barrier(); dist.destroy_process_group()
