@@ -493,9 +493,13 @@ static int run_count_kernels(simka_ctx *ctx, uint32_t sample, const SimkaScanArg
     const uint32_t *skip = flag;
     auto layout = [&](uint32_t mode, ull capb) {
         launch_timed(ctx, KID_LAYOUT, [&] {
-            hipLaunchKernelGGL(k_layout, dim3(1), dim3(256), lds_lay, st, L.d_b1_count, L.d_b1_start, L.d_b1_end,
+            SimkaLaneClear clr;
+            clr.p_count = L.d_p_count; clr.p_valid = L.d_p_valid; clr.spill_cursor = L.d_spill_cursor; clr.redo_count = L.d_redo_count;
+            clr.nparts = (uint32_t)ctx->nparts;
+            const uint32_t clear_blocks = mode == 2u ? 0u : (uint32_t)std::min<uint64_t>(64, (ctx->nparts + 8191) / 8192);
+            hipLaunchKernelGGL(k_layout, dim3(1 + clear_blocks), dim3(256), lds_lay, st, L.d_b1_count, L.d_b1_start, L.d_b1_end,
                                L.d_b1_cursor, L.d_chunk_first, B1, ctx->d_arena_cursor, ctx->d_sample_base + sample, mode | later, capb,
-                               kocc, skip, key);
+                               kocc, skip, key, clr);
         }, st);
     };
     // Level-1 buckets.  Keys are hash-partitioned, so bucket sizes concentrate around K_occ/B1: size every bucket for that
@@ -560,10 +564,7 @@ static int run_count_kernels(simka_ctx *ctx, uint32_t sample, const SimkaScanArg
     l2.narrow = (!wide_only && l2.rem_bits <= 31u) ? 1u : 0u;
     l2.spill_keys = L.d_spill_keys; l2.spill_runs = L.d_spill_runs; l2.spill_cursor = L.d_spill_cursor;
     l2.spill_cap = L.spill_cap; l2.spill_run_cap = L.spill_run_cap;
-    HIPCHK(hipMemsetAsync(L.d_p_count, 0, ctx->nparts * 4, st));
-    HIPCHK(hipMemsetAsync(L.d_p_valid, 0xff, ctx->nparts * 4, st));
-    HIPCHK(hipMemsetAsync(L.d_spill_cursor, 0, 16, st));
-    HIPCHK(hipMemsetAsync(L.d_redo_count, 0, 16, st));
+    // (p_count, p_valid, the spill cursors and the redo count were reset by k_layout before the scatter)
     {
         const uint64_t nchunks_max = (exact ? a.nb_bases : L.l1_cap) / K2_CHUNK + B1 + 1;
         const size_t lds_split = SIMKA_LDS_HEAD + (size_t)B2 * 12 + 64 + (size_t)K2_CHUNK * 8;
@@ -742,8 +743,9 @@ SIMKA_EXPORT int simka_count_sample(simka_ctx *ctx, uint32_t sample, const simka
         if (rc) return rc;
         if (npass > 1) { rc = resolve_pending(ctx); if (rc) return rc; }       // the passes share the scratch buffers
     }
-    if (ctx->nb_counted_this_run++ == 0 && ctx->cfg.nb_samples > 1) {
-        // table size of k_count_fast for the rest of the run, from this sample's distinct ratio (one sync per run)
+    if (ctx->nb_counted_this_run++ == 0 && ctx->cfg.nb_samples > 1 && ctx->small_table < 0) {
+        // table size of k_count_fast for the rest of the context's life, from this sample's distinct ratio (one sync; a
+        // wrong guess for later samples only sends partitions through the redo list)
         rc = resolve_pending(ctx); if (rc) return rc;
         uint64_t da = 0, ko = 0;
         const uint32_t fl = ctx->cfg.dist_flags;

@@ -105,6 +105,13 @@ struct SimkaCountOut {
 struct SimkaSpillRun { unsigned long long start; uint32_t part, len; };
 #define K2C_MATCH 4096         // k_count: spill runs of one partition listed in LDS (more: the run list is re-scanned every round)
 
+// per-lane level-2 state that k_layout resets before a sample is scattered
+struct SimkaLaneClear {
+    uint32_t *p_count, *p_valid;             // [nparts]
+    unsigned long long *spill_cursor, *redo_count;   // [2] each
+    uint32_t nparts;
+};
+
 struct SimkaL2 {
     unsigned long long *l2_keys;             // [nparts][cap2]  (u32 remainders when `narrow`)
     uint32_t narrow, rem_bits;               // W - pb <= 31: regions hold the low rem_bits of each key, the partition is implicit

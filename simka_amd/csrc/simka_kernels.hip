@@ -259,17 +259,26 @@ k_scan(SimkaScanArgs a, SimkaKeyCfg cfg, ull *b1_count, ull *b1_cursor, uint64_t
 }
 
 // --------------------------------------------------------------------------------------------
-// k_layout: level-1 bucket geometry.  One block.
+// k_layout: level-1 bucket geometry (block 0; further blocks only clear the lane's partition counters).
 //   mode 0 (exact, after the histogram pass): starts/ends/cursors from the counts, chunk table
 //   mode 1 (capacity, before the scatter): bucket b owns [b*cap, (b+1)*cap), cursor at its start
 //   mode 2 (capacity, after the scatter): ends from the cursors, chunk table
 // --------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256)
 k_layout(const ull *b1_count, ull *b1_start, ull *b1_end, ull *b1_cursor, uint32_t *chunk_first, uint32_t B1, ull *arena_cursor,
-         ull *sample_base, uint32_t mode_flags, ull cap, ull *kocc, const uint32_t *skip_flag, SimkaKeyCfg cfg) {
+         ull *sample_base, uint32_t mode_flags, ull cap, ull *kocc, const uint32_t *skip_flag, SimkaKeyCfg cfg, SimkaLaneClear clr) {
     // mode_flags bit 2: a later pass over the same sample (its occurrences add up, its arena base stays)
     const uint32_t mode = mode_flags & 3u;
     const bool later_pass = (mode_flags & 4u) != 0u;
+    // the launch before the scatter (modes 0, 1) also resets the lane's level-2 state, instead of four memsets per sample:
+    // blocks 1.. clear the partition counters, block 0 the cursors
+    if (blockIdx.x > 0) {
+        const uint32_t per = (clr.nparts + gridDim.x - 2u) / (gridDim.x - 1u);
+        const uint32_t lo = (blockIdx.x - 1u) * per, hi = (lo + per < clr.nparts) ? lo + per : clr.nparts;
+        for (uint32_t i = lo + threadIdx.x; i < hi; i += blockDim.x) { clr.p_count[i] = 0u; clr.p_valid[i] = 0xffffffffu; }
+        return;
+    }
+    if (mode != 2u && clr.p_count && threadIdx.x < 2u) { clr.spill_cursor[threadIdx.x] = 0ull; clr.redo_count[threadIdx.x] = 0ull; }
     if (mode == 2 && skip_flag && *skip_flag) return;      // the capacity-mode scatter overflowed: the sample is redone exactly
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     ull *cnt = (ull *)(smem + SIMKA_LDS_HEAD);   // [B1]
