@@ -72,6 +72,9 @@ struct simka_ctx {
     ull *d_mkeys = nullptr, *d_mvals = nullptr, *d_entries = nullptr; uint32_t *d_groups = nullptr;
     uint32_t *d_fb_off = nullptr; SimkaSpan *d_spans = nullptr; ull *d_cursors = nullptr; SimkaSpan *d_huge = nullptr;
     uint64_t merge_cap = 0, fb_cap = 0, span_cap = 0, huge_cap = 0;
+    // tile-major copy of the CSR for the tiled pair kernel (N too large for one LDS tile): entries, (p, p ln p), segment offsets
+    ull *d_tm_ent = nullptr; double2 *d_tm_p = nullptr; uint32_t *d_tm_off = nullptr;
+    uint64_t tm_ent_cap = 0, tm_p_cap = 0, tm_off_cap = 0;
     // -complex-dist: per-sample histogram of solid counts + list of the counts above the histogram
     SimkaWide *wide = nullptr;                                  // 32 <= k <= 63 (or SIMKA_SORT_PATH): the sort-based path of simka_wide.hip
     ull *d_xoff = nullptr; uint64_t xoff_cap = 0;               // simka_gather_samples_device: destination offsets
@@ -239,6 +242,7 @@ static int set_lds_attr(simka_ctx *ctx) {
     HIPCHK(hipFuncSetAttribute((const void *)k_pairs<false, K4_BLOCK_BIG>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
     HIPCHK(hipFuncSetAttribute((const void *)k_pairs<false, K4_BLOCK_SMALL>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
     HIPCHK(hipFuncSetAttribute((const void *)k_pairs<true, K4_BLOCK_BIG>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
+    HIPCHK(hipFuncSetAttribute((const void *)k_pairs_tm, hipFuncAttributeMaxDynamicSharedMemorySize, big));
     return SIMKA_OK;
 }
 
@@ -398,7 +402,8 @@ SIMKA_EXPORT void simka_destroy(simka_ctx *ctx) {
     void *ptrs[] = { ctx->d_reads, ctx->d_offsets, ctx->d_l1_ovf, ctx->d_solid_keys, ctx->d_solid_counts, ctx->d_arena_cursor,
                      ctx->d_sample_base, ctx->d_foff, ctx->d_fcnt, ctx->d_stats, ctx->d_err, ctx->d_part_total,
                      ctx->d_part_off, ctx->d_mkeys, ctx->d_mvals, ctx->d_entries, ctx->d_groups, ctx->d_fb_off,
-                     ctx->d_spans, ctx->d_cursors, ctx->d_huge, ctx->d_xoff, ctx->d_hist, ctx->d_ovf_list, ctx->d_ovf_cursor };
+                     ctx->d_spans, ctx->d_cursors, ctx->d_huge, ctx->d_xoff, ctx->d_hist, ctx->d_ovf_list, ctx->d_ovf_cursor,
+                     ctx->d_tm_ent, ctx->d_tm_p, ctx->d_tm_off };
     for (void *p : ptrs) if (p) (void)hipFree(p);
     if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
@@ -1212,15 +1217,48 @@ static void pair_setup(simka_ctx *ctx, PairLaunch &pl) {
     pl.nblk = (uint32_t)ctx->num_cus * per_cu;
 }
 
+// grow-only device buffer of the tile-major path; false (and the buffer left as it was) when the allocation fails
+template <typename T>
+static bool tm_reserve(simka_ctx *ctx, T **p, uint64_t *cap, uint64_t need) {
+    if (*cap >= need && *p) return true;
+    if (*p) { (void)hipStreamSynchronize(ctx->stream); (void)hipFree(*p); *p = nullptr; *cap = 0; }
+    const uint64_t n = need + need / 4 + 64;
+    if (dev_alloc(p, n) != hipSuccess) { (void)hipGetLastError(); *p = nullptr; return false; }
+    *cap = n;
+    return true;
+}
+
+// nb_entries / nb_spans: what the CSR holds if the caller knows (sort-based merge); 0: read from the device cursors
 static void pair_launch(simka_ctx *ctx, const PairLaunch &pl, const SimkaSpan *spans, const ull *cursors, const ull *entries, const uint32_t *groups,
-                        const SimkaSpan *huge, ull *acc, bool have_spans = true) {
+                        const SimkaSpan *huge, ull *acc, bool have_spans = true, uint64_t nb_entries = 0, uint64_t nb_spans = 0) {
     const SimkaPairCfg &pc = pl.pc;
+    // N beyond one LDS tile: reorder the spans tile-major once (k_tile_major), then every tile pair stages only its two segments
+    static const bool legacy_tiled = getenv("SIMKA_PAIRS_LEGACY") != nullptr;
+    bool tile_major = have_spans && pc.ntiles > 1 && pc.ntiles <= KTM_NT_MAX && !legacy_tiled;
+    if (tile_major) {
+        if (!nb_spans) {      // (one small download per merge batch; the batches are large)
+            ull cur[4] = { 0, 0, 0, 0 };
+            if (hipMemcpyAsync(cur, cursors, 32, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess || hipStreamSynchronize(ctx->stream) != hipSuccess) tile_major = false;
+            nb_entries = cur[0]; nb_spans = cur[2];
+        }
+        if (tile_major && nb_spans == 0) have_spans = false;
+        const bool cplx = pc.nacc64 != 0;
+        if (tile_major && have_spans)
+            tile_major = tm_reserve(ctx, &ctx->d_tm_ent, &ctx->tm_ent_cap, nb_entries + 16) &&
+                         (!cplx || tm_reserve(ctx, &ctx->d_tm_p, &ctx->tm_p_cap, nb_entries + 16)) &&
+                         tm_reserve(ctx, &ctx->d_tm_off, &ctx->tm_off_cap, nb_spans * (uint64_t)(pc.ntiles + 1) + 16);
+    }
     if (have_spans) launch_timed(ctx, KID_PAIRS, [&] {
         if (pl.small_block)
             hipLaunchKernelGGL((k_pairs<false, K4_BLOCK_SMALL>), dim3(pl.nblk, pl.ntp), dim3(K4_BLOCK_SMALL), pl.lds_pairs, ctx->stream, spans, cursors, entries, groups, pc, acc);
         else if (pc.ntiles == 1)
             hipLaunchKernelGGL((k_pairs<false, K4_BLOCK_BIG>), dim3(pl.nblk, pl.ntp), dim3(K4_BLOCK_BIG), pl.lds_pairs, ctx->stream, spans, cursors, entries, groups, pc, acc);
-        else
+        else if (tile_major) {
+            const uint32_t grid_tm = (uint32_t)std::min<uint64_t>((nb_spans + KTM_WAVES - 1) / KTM_WAVES, (uint64_t)ctx->num_cus * 4);
+            hipLaunchKernelGGL(k_tile_major, dim3(grid_tm), dim3(64 * KTM_WAVES), 0, ctx->stream, spans, cursors, entries, groups, pc, ctx->d_tm_ent, ctx->d_tm_p, ctx->d_tm_off);
+            hipLaunchKernelGGL(k_pairs_tm, dim3(pl.nblk, pl.ntp), dim3(K4_BLOCK_BIG), pl.lds_pairs, ctx->stream, spans, cursors, (const ull *)ctx->d_tm_ent,
+                               (const double2 *)ctx->d_tm_p, (const uint32_t *)ctx->d_tm_off, pc, acc);
+        } else
             hipLaunchKernelGGL((k_pairs<true, K4_BLOCK_BIG>), dim3(pl.nblk, pl.ntp), dim3(K4_BLOCK_BIG), pl.lds_pairs, ctx->stream, spans, cursors, entries, groups, pc, acc);
     });
 #ifdef SIMKA_PHASE_PROF
@@ -1319,7 +1357,8 @@ SIMKA_EXPORT int simka_merge(simka_ctx *ctx) {
         if (wrc) return wide_fail(ctx, wrc);
         const ull head[2] = { csr.nb_distinct, csr.nb_shared };
         HIPCHK(hipMemcpyAsync(ctx->d_stats, head, 16, hipMemcpyHostToDevice, ctx->stream));
-        if (csr.nb_spans || csr.nb_huge) pair_launch(ctx, pl, csr.spans, csr.cursors, csr.entries, csr.groups, csr.nb_huge ? csr.huge : nullptr, (ull *)ctx->d_stats + stats_off_acc(N, 0), csr.nb_spans != 0);
+        if (csr.nb_spans || csr.nb_huge) pair_launch(ctx, pl, csr.spans, csr.cursors, csr.entries, csr.groups, csr.nb_huge ? csr.huge : nullptr, (ull *)ctx->d_stats + stats_off_acc(N, 0), csr.nb_spans != 0,
+                                                         csr.nb_entries, csr.nb_spans);
         HIPCHK(hipGetLastError());
         HIPCHK(hipStreamSynchronize(ctx->stream));
         if (ctx->cfg.dist_flags & SIMKA_DIST_COMPLEX) return complex_finish(ctx, pl.pc);

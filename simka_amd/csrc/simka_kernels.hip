@@ -1433,6 +1433,285 @@ k_pairs(const SimkaSpan *spans, const ull *cursors, const ull *entries, const ui
     pairs_flush<TILED, K4_BLOCK>(pk, c64, acc, pc, rect, baseI, baseJ);
 }
 
+// --------------------------------------------------------------------------------------------
+// Tiled pair accumulation over TILE-MAJOR spans.  k_pairs<true> re-stages every span for every sample-tile pair and
+// compacts it to the members of the two tiles each time.  Here a pre-pass reorders each span ONCE:
+//   k_tile_major: one wave per span, a stable counting sort of the span's entries by sample tile.  Entries keep their group
+//   order inside a tile segment, so the members a group has in one tile are contiguous; each entry carries its span-local
+//   group index (g << 48 | sample << 32 | count).  tm_off[span][t] = start of tile t's segment; complex: (p, p ln p) per entry,
+//   computed once instead of once per tile pair.
+//   k_pairs_tm: block row (I, J) stages only the two segments it owns; group runs are found from heads and tails (two 16-bit
+//   LDS stores per run, no scan over the entries, no index lists) and pairs are enumerated exactly as in k_pairs.
+// --------------------------------------------------------------------------------------------
+#define KTM_WAVES 4                 // k_tile_major: waves (= spans in flight) per block
+#define KTM_NT_MAX 256              // largest number of sample tiles the tile-major path handles
+
+__global__ void __launch_bounds__(64 * KTM_WAVES)
+k_tile_major(const SimkaSpan *spans, const ull *cursors, const ull *entries, const uint32_t *groups, SimkaPairCfg pc,
+             ull *tm_ent, double2 *tm_p, uint32_t *tm_off) {
+    __shared__ uint16_t s_gid[KTM_WAVES][SIMKA_SPAN_MAX];
+    __shared__ uint32_t s_tb[KTM_WAVES][KTM_NT_MAX + 4];
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    uint16_t *gid = s_gid[wave];
+    uint32_t *tb = s_tb[wave];
+    const uint32_t T = pc.tile, nt = pc.ntiles;
+    const ull nspans = cursors[2];
+    const ull lt_mask = (1ull << lane) - 1ull;
+    const bool cplx = pc.nacc64 != 0;
+    for (ull sp = (ull)blockIdx.x * KTM_WAVES + wave; sp < nspans; sp += (ull)gridDim.x * KTM_WAVES) {
+        const SimkaSpan span = spans[sp];
+        uint32_t *off = tm_off + sp * (nt + 1u);
+        if (span.ngrp == 0) { for (uint32_t t = lane; t <= nt; t += 64u) off[t] = 0u; continue; }
+        const ull *ent = entries + span.ebase;
+        // the group of every entry, the size of every tile segment
+        for (uint32_t t = lane; t <= nt; t += 64u) tb[t] = 0u;
+        for (uint32_t g = lane; g < span.ngrp; g += 64u) {
+            const uint32_t d = groups[span.gbase + g];
+            const uint32_t st = d >> 16, sz = d & 0xffffu;
+            for (uint32_t e = 0; e < sz; e++) gid[st + e] = (uint16_t)g;
+        }
+        for (uint32_t i = lane; i < span.nent; i += 64u) atomicAdd(&tb[(uint32_t)(ent[i] >> 32) / T], 1u);
+        // exclusive scan over the tiles (nt <= 256: four per lane)
+        {
+            const uint32_t t0 = lane * 4u;
+            uint32_t c[4], sum = 0;
+#pragma unroll
+            for (uint32_t q = 0; q < 4u; q++) { c[q] = (t0 + q < nt) ? tb[t0 + q] : 0u; sum += c[q]; }
+            uint32_t incl = sum;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) { const uint32_t v = __shfl_up(incl, o, 64); if (lane >= (uint32_t)o) incl += v; }
+            uint32_t run = incl - sum;
+#pragma unroll
+            for (uint32_t q = 0; q < 4u; q++) { if (t0 + q < nt) { tb[t0 + q] = run; off[t0 + q] = run; } run += c[q]; }
+            if (lane == 0) off[nt] = span.nent;
+        }
+        // stable placement: entries in index order, 64 at a time; lanes of the same tile take consecutive slots
+        for (uint32_t i0 = 0; i0 < span.nent; i0 += 64u) {
+            const uint32_t i = i0 + lane;
+            const bool valid = i < span.nent;
+            const ull e = valid ? ent[i] : 0ull;
+            const uint32_t smp = (uint32_t)(e >> 32);
+            const uint32_t tile = valid ? smp / T : 0xffffffffu;
+            uint32_t pos = 0;
+            ull remaining = __ballot(valid);
+            while (remaining) {
+                const uint32_t l0 = (uint32_t)__ffsll((long long)remaining) - 1u;
+                const uint32_t t0 = (uint32_t)__shfl((int)tile, (int)l0, 64);
+                const ull m = __ballot(valid && tile == t0);
+                const uint32_t base = tb[t0];
+                if (tile == t0 && valid) pos = base + (uint32_t)__popcll(m & lt_mask);
+                if (lane == l0) tb[t0] = base + (uint32_t)__popcll(m);
+                remaining &= ~m;
+            }
+            if (valid) {
+                tm_ent[span.ebase + pos] = ((ull)gid[i] << 48) | ((ull)(smp & 0xffffu) << 32) | (ull)(uint32_t)e;
+                if (cplx) {
+                    const double p = (double)(uint32_t)e / (double)pc.tot_n[smp];
+                    tm_p[span.ebase + pos] = make_double2(p, p * log(p));
+                }
+            }
+        }
+    }
+}
+
+__global__ void __launch_bounds__(K4_BLOCK_BIG)
+k_pairs_tm(const SimkaSpan *spans, const ull *cursors, const ull *tm_ent, const double2 *tm_p, const uint32_t *tm_off, SimkaPairCfg pc,
+           ull *acc) {
+    constexpr int K4_BLOCK = K4_BLOCK_BIG;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const uint32_t CP = pc.ncell_pad, npk = pc.nacc32 >> 1;
+    const bool cplx = pc.nacc64 != 0;
+    ull *pk = (ull *)(smem + SIMKA_LDS_HEAD);                    // [npk][CP]     packed u32 pairs
+    ull *c64 = pk + (size_t)npk * CP;                            // [nacc64][CP]  (whit, klfix)
+    const uint32_t EC = pc.span_cap, GC = EC / 2u;
+    ull *ent = c64 + (size_t)pc.nacc64 * CP;                     // [EC]          segment I, then segment J: (g<<48 | sample<<32 | count)
+    double *ep = (double *)(ent + EC);                           // [EC]          complex: p = c / N_sample
+    double *eplp = ep + (cplx ? EC : 0);                         // [EC]          complex: p * ln p
+    double *tn = eplp + (cplx ? EC : 0);                         // [SIMKA_PAIR_TN] complex: N of the samples of tile I, then tile J
+    uint32_t *gdesc = (uint32_t *)(tn + (cplx ? SIMKA_PAIR_TN : 0));   // [GC]      run of the group in segment I: (start<<16 | size)
+    uint32_t *gpref = gdesc + GC;                                // [GC+2]        pair prefix
+    uint32_t *tmp = gpref + GC + 2;                              // [32]
+    uint32_t *gdescB = tmp + 32;                                 // [GC]          run of the group in segment J
+    uint32_t *runA = gdescB + GC;                                // [GC]          (head | tail<<16) written by the run's first / last entry
+    uint32_t *runB = runA + GC;                                  // [GC]
+
+    const uint32_t tid = threadIdx.x;
+    const uint32_t N = pc.nb_samples, T = pc.tile, nt = pc.ntiles;
+    uint32_t I = 0, J = 0;                                       // tile pair (I<=J) of this block row
+    {
+        uint32_t r = blockIdx.y;
+        for (I = 0; I < nt; I++) { const uint32_t row = nt - I; if (r < row) { J = I + r; break; } r -= row; }
+    }
+    const bool rect = I != J;
+    const uint32_t baseI = I * T, baseJ = J * T;
+    for (uint32_t i = tid; i < npk * CP; i += K4_BLOCK) pk[i] = 0;
+    for (uint32_t i = tid; i < pc.nacc64 * CP; i += K4_BLOCK) c64[i] = 0;
+    if (cplx) {
+        for (uint32_t i = tid; i < T; i += K4_BLOCK) {
+            tn[i] = (baseI + i < N) ? (double)pc.tot_n[baseI + i] : 1.0;
+            if (rect) tn[T + i] = (baseJ + i < N) ? (double)pc.tot_n[baseJ + i] : 1.0;
+        }
+    }
+    ull bound = 0, bound_q = 0;
+
+    const ull nspans = cursors[2];
+    constexpr int EPT = (SIMKA_SPAN_MAX + K4_BLOCK - 1) / K4_BLOCK;
+    // pipeline: span descriptor + segment offsets two iterations ahead, the member entries one iteration ahead (registers)
+    struct Seg { uint32_t a0, na, b0, nb; };
+    auto seg_of = [&](ull s) -> Seg {
+        const uint32_t *o = tm_off + s * (nt + 1u);
+        Seg g; g.a0 = o[I]; g.na = o[I + 1u] - g.a0; g.b0 = 0; g.nb = 0;
+        if (rect) { g.b0 = o[J]; g.nb = o[J + 1u] - g.b0; }
+        return g;
+    };
+    SimkaSpan span, nspan;
+    Seg seg = {0, 0, 0, 0}, nseg = {0, 0, 0, 0};
+    span.ngrp = 0; span.nent = 0; nspan.ngrp = 0; nspan.nent = 0;
+    ull sp = blockIdx.x;
+    if (sp < nspans) { span = spans[sp]; seg = seg_of(sp); }
+    if (sp + gridDim.x < nspans) { nspan = spans[sp + gridDim.x]; nseg = seg_of(sp + gridDim.x); }
+    ull pre_e[EPT]; double2 pre_p[EPT];
+#define KTM_FETCH(S, G)                                                                       \
+    _Pragma("unroll") for (int q = 0; q < EPT; q++) {                                         \
+        const uint32_t i = tid + (uint32_t)q * K4_BLOCK;                                      \
+        pre_e[q] = 0ull; pre_p[q] = make_double2(0.0, 0.0);                                   \
+        if ((S).ngrp && i < (G).na + (G).nb) {                                                \
+            const ull src = (S).ebase + (i < (G).na ? (G).a0 + i : (G).b0 + (i - (G).na));    \
+            pre_e[q] = tm_ent[src];                                                           \
+            if (cplx) pre_p[q] = tm_p[src];                                                   \
+        }                                                                                     \
+    }
+    KTM_FETCH(span, seg)
+    PP_DECL
+    for (; sp < nspans; sp += gridDim.x) {
+        PP(6)
+        __syncthreads();
+        PP(0)
+        const SimkaSpan cur = span;
+        const Seg cs = seg;
+        const uint32_t nM = cur.ngrp ? cs.na + cs.nb : 0u;
+#pragma unroll
+        for (int q = 0; q < EPT; q++) {
+            const uint32_t i = tid + (uint32_t)q * K4_BLOCK;
+            if (i < nM) { ent[i] = pre_e[q]; if (cplx) { ep[i] = pre_p[q].x; eplp[i] = pre_p[q].y; } }
+            if (i < cur.ngrp) { runA[i] = 0u; runB[i] = 0u; }
+        }
+        span = nspan; seg = nseg;
+        nspan.ngrp = 0; nspan.nent = 0;
+        if (sp + 2 * (ull)gridDim.x < nspans) { nspan = spans[sp + 2 * (ull)gridDim.x]; nseg = seg_of(sp + 2 * (ull)gridDim.x); }
+        KTM_FETCH(span, seg)
+        PP(1)
+        // nothing to pair up in this span for this tile pair (uniform)
+        if (cur.ngrp == 0 || (rect ? (cs.na == 0u || cs.nb == 0u) : cs.na < 2u)) continue;
+        const ull add = (ull)cur.ngrp * (ull)cur.maxc;
+        const ull addq = (ull)cur.ngrp * (ull)cur.maxc * (ull)cur.maxc;
+        const bool chord_fast = cur.maxc < 46341u && addq < 0xffffffffull;
+        if (bound + add >= 0xffffffffull || (chord_fast && bound_q + addq >= 0xffffffffull)) { pairs_flush<true, K4_BLOCK>(pk, c64, acc, pc, rect, baseI, baseJ); bound = 0; bound_q = 0; }
+        bound += add;
+        if (chord_fast) bound_q += addq;
+        __syncthreads();
+        // group runs: the first entry of a run stores its index, the last one the index behind it
+#pragma unroll
+        for (int q = 0; q < EPT; q++) {
+            const uint32_t i = tid + (uint32_t)q * K4_BLOCK;
+            if (i < nM) {
+                const uint32_t g = (uint32_t)(ent[i] >> 48);
+                const bool inA = i < cs.na;
+                uint16_t *run = (uint16_t *)(inA ? runA : runB) + 2u * g;
+                const uint32_t lo = inA ? 0u : cs.na, hi = inA ? cs.na : nM;
+                if (i == lo || (uint32_t)(ent[i - 1u] >> 48) != g) run[0] = (uint16_t)i;
+                if (i + 1u == hi || (uint32_t)(ent[i + 1u] >> 48) != g) run[1] = (uint16_t)(i + 1u);
+            }
+        }
+        __syncthreads();
+        PP(2)
+#pragma unroll
+        for (int q = 0; q < EPT; q++) {
+            const uint32_t g = tid + (uint32_t)q * K4_BLOCK;
+            if (g < cur.ngrp) {
+                const uint32_t ra = runA[g], rb = runB[g];
+                const uint32_t a0 = ra & 0xffffu, nA = (ra >> 16) - a0, b0 = rb & 0xffffu, nB = (rb >> 16) - b0;
+                gdesc[g] = (a0 << 16) | nA;
+                gdescB[g] = (b0 << 16) | nB;
+                gpref[g] = rect ? nA * nB : nA * (nA - 1u) / 2u;      // nA = 0 gives 0 either way
+            }
+        }
+        __syncthreads();
+        PP(3)
+        const uint32_t P = block_excl_scan<K4_BLOCK>(gpref, cur.ngrp, tmp);
+        if (tid == 0) gpref[cur.ngrp] = P;
+        __syncthreads();
+        PP(4)
+        const uint32_t chunk = (P + K4_BLOCK - 1) / K4_BLOCK;
+        uint32_t p = tid * chunk;
+        const uint32_t pend = (p + chunk < P) ? p + chunk : P;
+        if (p < pend) {
+            uint32_t lo = 0, hi = cur.ngrp;    // largest g with gpref[g] <= p
+            while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (gpref[mid] <= p) lo = mid; else hi = mid; }
+            uint32_t g = lo;
+            while (g + 1 < cur.ngrp && gpref[g + 1] <= p) g++;   // skip groups without pairs
+            uint32_t d = gdesc[g];
+            uint32_t a0 = d >> 16, nA = d & 0xffffu, b0 = 0, nB = 0, x, y;
+            if (rect) {
+                const uint32_t dB = gdescB[g]; b0 = dB >> 16; nB = dB & 0xffffu;
+                const uint32_t r = p - gpref[g];
+                x = r / nB; y = r - x * nB;
+            } else tri_unrank(p - gpref[g], nA, x, y);
+            uint32_t ix = a0 + x;
+            ull ex = ent[ix];
+            PP(5)
+            for (; p < pend; p++) {
+                const uint32_t iy = rect ? b0 + y : a0 + y;
+                const ull ey = ent[iy];
+                uint32_t si = (uint32_t)(ex >> 32) & 0xffffu, sj = (uint32_t)(ey >> 32) & 0xffffu;
+                uint32_t ci = (uint32_t)ex, cj = (uint32_t)ey;
+                uint32_t jx = ix, jy = iy;                       // staged indices of the (i, j)-ordered pair
+                if (!rect && si > sj) { uint32_t t_ = si; si = sj; sj = t_; t_ = ci; ci = cj; cj = t_; jx = iy; jy = ix; }
+                const uint32_t li = si - baseI, lj = sj - baseJ;
+                const uint32_t cell = rect ? li * T + lj : li * T - ((li * (li + 1u)) >> 1) + (lj - li - 1u);
+                atomicAdd(&pk[0 * CP + cell], (ull)ci | ((ull)cj << 32));                       // S_ij | S_ji
+                atomicAdd(&pk[1 * CP + cell], 1ull | ((ull)(ci < cj ? ci : cj) << 32));         // a | bc
+                if (pc.simple) {
+                    const ull prod = (ull)ci * (ull)cj;
+                    const ull hell = (ull)pair_isqrt(prod) << 32;
+                    if (chord_fast) atomicAdd(&pk[2 * CP + cell], (ull)(uint32_t)prod | hell);  // chord | hell
+                    else {
+                        atomicAdd(&pk[2 * CP + cell], hell);
+                        atomicAdd(&acc[SIMKA_ACC_CHORD * pc.nb_pairs + simka_pair_index(si, sj, N)], prod);
+                    }
+                }
+                if (cplx) {
+                    // same arithmetic as k_pairs (ref: src/core/SimkaAlgorithm.hpp:437-446,477-481)
+                    const double h = ep[jx] + ep[jy];
+                    double dd = eplp[jx] + eplp[jy] - h * log(h * 0.5);
+                    dd = dd < 0.0 ? 0.0 : dd;
+                    atomicAdd(&c64[1 * CP + cell], (ull)(long long)llrint(dd * SIMKA_KL_SCALE));
+                    const ull uX = (ull)((double)ci * tn[(rect ? T : 0u) + lj]), uY = (ull)((double)cj * tn[li]);
+                    atomicAdd(&c64[0 * CP + cell], simka_whit_abs(uX - uY) - simka_whit_abs(uX) - simka_whit_abs(uY));
+                }
+                y++;
+                if (rect ? (y == nB) : (y == nA)) {
+                    x++; y = rect ? 0u : x + 1u;
+                    if (rect ? (x == nA) : (y >= nA)) {   // group exhausted
+                        g++;
+                        while (g < cur.ngrp && gpref[g + 1] == gpref[g]) g++;
+                        if (g >= cur.ngrp) break;
+                        d = gdesc[g]; a0 = d >> 16; nA = d & 0xffffu; x = 0; y = rect ? 0u : 1u;
+                        if (rect) { const uint32_t dB = gdescB[g]; b0 = dB >> 16; nB = dB & 0xffffu; }
+                    }
+                    ix = a0 + x;
+                    ex = ent[ix];
+                }
+            }
+        }
+    }
+#undef KTM_FETCH
+    PP(6)
+    PP_FLUSH
+    __syncthreads();
+    pairs_flush<true, K4_BLOCK>(pk, c64, acc, pc, rect, baseI, baseJ);
+}
+
 // K3c  k_pairs_global: groups shared by more than K3_CAP samples (k_group's huge list).  Pairs are enumerated from the
 // CSR entries in global memory and every update is a global u64 atomic; same arithmetic as k_pairs.
 // grid: x = slices of one group's pair space, y = groups (strided).

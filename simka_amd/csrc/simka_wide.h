@@ -11,6 +11,7 @@ enum { SIMKA_WIDE_OK = 0, SIMKA_WIDE_ERR_HIP = 1, SIMKA_WIDE_ERR_NOMEM = 2, SIMK
 struct SimkaWideCsr {
     unsigned long long *entries; uint32_t *groups; SimkaSpan *spans; unsigned long long *cursors;
     uint32_t nb_spans;
+    uint64_t nb_entries;                   // entries the spans cover (the huge groups' entries follow them)
     SimkaSpan *huge; uint32_t nb_huge;     // groups larger than a span (k_pairs_global)
     uint64_t nb_distinct, nb_shared;       // union of the samples' solid k-mers / those in >= 2 samples
 };

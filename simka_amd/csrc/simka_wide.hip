@@ -421,7 +421,7 @@ int simka_wide_count_sample(SimkaWide *w, uint32_t sample, const void *packed, u
 int simka_wide_merge(SimkaWide *w, uint32_t span_cap, SimkaWideCsr *out) {
     const uint64_t M = w->a_used;
     const uint32_t N = w->nb_samples;
-    out->nb_distinct = 0; out->nb_shared = 0; out->entries = nullptr; out->groups = nullptr; out->spans = nullptr; out->cursors = nullptr; out->nb_spans = 0; out->huge = nullptr; out->nb_huge = 0;
+    out->nb_distinct = 0; out->nb_shared = 0; out->entries = nullptr; out->groups = nullptr; out->spans = nullptr; out->cursors = nullptr; out->nb_spans = 0; out->nb_entries = 0; out->huge = nullptr; out->nb_huge = 0;
     if (M == 0) return 0;
     const uint32_t maxg = std::min<uint32_t>(N, span_cap / 2 - 8);     // larger groups cannot share a span: huge list
     int rc;
@@ -512,7 +512,7 @@ int simka_wide_merge(SimkaWide *w, uint32_t span_cap, SimkaWideCsr *out) {
     WCHK(hipGetLastError());
     WCHK(hipStreamSynchronize(w->stream));
     out->huge = w->huge; out->nb_huge = nhuge;
-    out->entries = w->entries; out->groups = w->groups; out->spans = w->spans; out->cursors = w->cursors; out->nb_spans = nkept ? nspans : 0;
+    out->entries = w->entries; out->groups = w->groups; out->spans = w->spans; out->cursors = w->cursors; out->nb_spans = nkept ? nspans : 0; out->nb_entries = nent;
     return 0;
 }
 

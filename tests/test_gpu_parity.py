@@ -737,7 +737,8 @@ def test_cli_spectra_larger_than_the_arena_merge_by_partition_ranges(gpu_require
 
 
 @pytest.mark.parametrize("k,amin,n,R,L", [(21, 2, 5, 3000, 100), (31, 1, 4, 2000, 150), (9, 2, 3, 1500, 80), (32, 2, 4, 2500, 120),
-                                          (33, 1, 4, 2500, 120), (47, 2, 5, 2500, 150), (63, 1, 3, 2000, 150)])
+                                          (33, 1, 4, 2500, 120), (47, 2, 5, 2500, 150), (63, 1, 3, 2000, 150),
+                                          (33, 1, 150, 120, 100)])     # more samples than one LDS tile: the tile-major pair kernel on the sorted CSR
 def test_sort_based_path_for_wide_kmers(gpu_required, oracle_mod, monkeypatch, k, amin, n, R, L):
     """k >= 32 (k-mers of up to 126 bits, the reference's span-64 build) takes the sort-based path of simka_wide.hip; the same
     path is forced for k <= 31 (SIMKA_SORT_PATH) as a cross-check of the hash pipeline.  Totals and every accumulator vs the
