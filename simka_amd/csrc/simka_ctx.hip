@@ -1178,7 +1178,10 @@ static void pairs_phase_report() {
 
 struct PairLaunch { SimkaPairCfg pc; size_t lds_pairs = 0; uint32_t ntp = 1, nblk = 1; bool small_block = false; };
 
-static void pair_setup(simka_ctx *ctx, PairLaunch &pl) {
+// is the tile-major pair kernel usable (decided per context: SIMKA_PAIRS_LEGACY=1 keeps the scan-and-compact kernel, tests / A-B)
+static bool tile_major_enabled() { static const bool legacy = getenv("SIMKA_PAIRS_LEGACY") != nullptr; return !legacy; }
+
+static void pair_setup(simka_ctx *ctx, PairLaunch &pl, bool legacy_layout = false, uint32_t force_span_cap = 0) {
     // pair-accumulator tiling: all N(N-1)/2 cells in LDS when they fit, else T x T sample tiles
     const uint32_t flags = ctx->cfg.dist_flags;
     const uint32_t N = ctx->cfg.nb_samples;
@@ -1191,7 +1194,9 @@ static void pair_setup(simka_ctx *ctx, PairLaunch &pl) {
     // The span capacity EC (entries staged per iteration) takes what the cells leave: longer spans amortise the per-span cost.
     const bool cplx = pc.nacc64 != 0;
     auto lds_single = [&](size_t ec) { return SIMKA_LDS_HEAD + ec * 8 + (cplx ? ec * 16 + SIMKA_PAIR_TN * 8 : 0) + (ec / 2) * 4 + (ec / 2 + 2) * 4 + 32 * 4 + 64; };
-    auto lds_tiled = [&](size_t ec) { return lds_single(ec) + (ec / 2) * 4 + (ec + 2) * 4 + ec * 4; };
+    // tiled: + gdescB + (scan-and-compact kernel: flag scan, two index lists | tile-major kernel: the two run tables)
+    const bool tm_layout = !legacy_layout && tile_major_enabled();
+    auto lds_tiled = [&](size_t ec) { return lds_single(ec) + (ec / 2) * 4 + (tm_layout ? (ec / 2) * 8 : (ec + 2) * 4 + ec * 4); };
     const size_t lds_max = 160 * 1024;
     const size_t cell_bytes = 4 * pc.nacc32 + 8 * pc.nacc64;
     size_t lds_fixed;
@@ -1203,6 +1208,8 @@ static void pair_setup(simka_ctx *ctx, PairLaunch &pl) {
         lds_fixed = lds_single(pc.span_cap);
     } else {
         pc.span_cap = 2 * K3_CAP;       // tiled: larger spans cost tile edge (more tile pairs replaying the spans)
+        if (tm_layout && getenv("SIMKA_TM_SPAN")) pc.span_cap = std::min<uint32_t>(SIMKA_SPAN_MAX, std::max<uint32_t>(K3_CAP, (uint32_t)atoi(getenv("SIMKA_TM_SPAN")) / K3_CAP * K3_CAP));   // experiments
+        if (force_span_cap) pc.span_cap = force_span_cap;                // the spans already exist
         lds_fixed = lds_tiled(pc.span_cap);
         const uint64_t max_cells = (lds_max - lds_fixed) / cell_bytes - 4;     // ncell_pad rounds up to a multiple of 4
         uint32_t T = 1; while ((uint64_t)(T + 1) * (T + 1) <= max_cells) T++;
@@ -1233,8 +1240,7 @@ static void pair_launch(simka_ctx *ctx, const PairLaunch &pl, const SimkaSpan *s
                         const SimkaSpan *huge, ull *acc, bool have_spans = true, uint64_t nb_entries = 0, uint64_t nb_spans = 0) {
     const SimkaPairCfg &pc = pl.pc;
     // N beyond one LDS tile: reorder the spans tile-major once (k_tile_major), then every tile pair stages only its two segments
-    static const bool legacy_tiled = getenv("SIMKA_PAIRS_LEGACY") != nullptr;
-    bool tile_major = have_spans && pc.ntiles > 1 && pc.ntiles <= KTM_NT_MAX && !legacy_tiled;
+    bool tile_major = have_spans && pc.ntiles > 1 && pc.ntiles <= KTM_NT_MAX && tile_major_enabled();
     if (tile_major) {
         if (!nb_spans) {      // (one small download per merge batch; the batches are large)
             ull cur[4] = { 0, 0, 0, 0 };
@@ -1258,8 +1264,13 @@ static void pair_launch(simka_ctx *ctx, const PairLaunch &pl, const SimkaSpan *s
             hipLaunchKernelGGL(k_tile_major, dim3(grid_tm), dim3(64 * KTM_WAVES), 0, ctx->stream, spans, cursors, entries, groups, pc, ctx->d_tm_ent, ctx->d_tm_p, ctx->d_tm_off);
             hipLaunchKernelGGL(k_pairs_tm, dim3(pl.nblk, pl.ntp), dim3(K4_BLOCK_BIG), pl.lds_pairs, ctx->stream, spans, cursors, (const ull *)ctx->d_tm_ent,
                                (const double2 *)ctx->d_tm_p, (const uint32_t *)ctx->d_tm_off, pc, acc);
-        } else
-            hipLaunchKernelGGL((k_pairs<true, K4_BLOCK_BIG>), dim3(pl.nblk, pl.ntp), dim3(K4_BLOCK_BIG), pl.lds_pairs, ctx->stream, spans, cursors, entries, groups, pc, acc);
+        } else {
+            // (the tile-major buffers could not be had, or too many tiles: the scan-and-compact kernel with its own LDS layout;
+            // the spans were built for pc.span_cap entries, which its tile geometry keeps)
+            PairLaunch lg = pl;
+            if (tile_major_enabled()) pair_setup(ctx, lg, true, pl.pc.span_cap);
+            hipLaunchKernelGGL((k_pairs<true, K4_BLOCK_BIG>), dim3(lg.nblk, lg.ntp), dim3(K4_BLOCK_BIG), lg.lds_pairs, ctx->stream, spans, cursors, entries, groups, lg.pc, acc);
+        }
     });
 #ifdef SIMKA_PHASE_PROF
     pairs_phase_report();
