@@ -1,8 +1,5 @@
-run() { echo "== $*"; env "$@" timeout 300 python bench.py --workload c5_50 --steps 3 --warmup 1 --no-cpu-baseline 2>/dev/null | python3 -c "
+run() { echo "== $*"; env "$@" timeout 300 python bench.py --workload ${WL:-c5_50} --steps 3 --warmup 1 --no-cpu-baseline 2>/dev/null | python3 -c "
 import json,sys
 d=json.loads(sys.stdin.readlines()[-1]); r=d['roofline']
 print('ms/step %.1f' % d['ms_per_step'], d['config'].get('matrix_checksum'), {k: round(v,1) for k,v in r['kernel_ms_per_step'].items() if v > 5})"; }
-run SIMKA_X=1
-run SIMKA_TM_SPAN=1024
-run SIMKA_TM_SPAN=3072
-run SIMKA_TM_SPAN=4096
+for v in "$@"; do run $v; done

@@ -1196,7 +1196,7 @@ static void pair_setup(simka_ctx *ctx, PairLaunch &pl, bool legacy_layout = fals
     auto lds_single = [&](size_t ec) { return SIMKA_LDS_HEAD + ec * 8 + (cplx ? ec * 16 + SIMKA_PAIR_TN * 8 : 0) + (ec / 2) * 4 + (ec / 2 + 2) * 4 + 32 * 4 + 64; };
     // tiled: + gdescB + (scan-and-compact kernel: flag scan, two index lists | tile-major kernel: the two run tables)
     const bool tm_layout = !legacy_layout && tile_major_enabled();
-    auto lds_tiled = [&](size_t ec) { return lds_single(ec) + (ec / 2) * 4 + (tm_layout ? (ec / 2) * 8 : (ec + 2) * 4 + ec * 4); };
+    auto lds_tiled = [&](size_t ec) { return lds_single(ec) + (ec / 2) * 4 + (tm_layout ? (ec / 2) * 8 + 2 * sizeof(KtmRange) + 64 /* range tables */ : (ec + 2) * 4 + ec * 4); };
     const size_t lds_max = 160 * 1024;
     const size_t cell_bytes = 4 * pc.nacc32 + 8 * pc.nacc64;
     size_t lds_fixed;

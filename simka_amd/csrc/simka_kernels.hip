@@ -1514,6 +1514,21 @@ k_tile_major(const SimkaSpan *spans, const ull *cursors, const ull *entries, con
     }
 }
 
+// One iteration of a block takes a BATCH of consecutive spans -- as many as fit the staging arrays (members of its two tiles
+// <= span_cap, groups <= span_cap / 2) out of a range of KTM_RANGE span slots -- so the fixed costs of an iteration (barriers,
+// the scan over the groups, the per-thread pair search) are shared by several spans' pairs.  Group ids are made batch-wide by
+// adding the number of groups of the spans staged before.
+#define KTM_RANGE 16
+struct KtmSpan { ull ebase; uint32_t ngrp, maxc, a0, na, b0, nb; };      // a span as tile pair (I, J) sees it
+struct KtmSlot { uint32_t st, mid, gbase, pad; };                        // staging start, start of the J members, first group id
+// a range of span slots cut into batches by thread 0: batch b = spans [bstart[b], bstart[b+1]), nm / ng / maxc per batch
+struct KtmRange {
+    KtmSpan d[KTM_RANGE];
+    KtmSlot sl[KTM_RANGE + 1];           // per span; sl[last of a batch + 1].st closes the batch (sentinel written per batch end)
+    uint32_t bstart[KTM_RANGE + 1], bnm[KTM_RANGE], bng[KTM_RANGE], bmaxc[KTM_RANGE];
+    uint32_t nbatch, cnt;
+};
+
 __global__ void __launch_bounds__(K4_BLOCK_BIG)
 k_pairs_tm(const SimkaSpan *spans, const ull *cursors, const ull *tm_ent, const double2 *tm_p, const uint32_t *tm_off, SimkaPairCfg pc,
            ull *acc) {
@@ -1524,7 +1539,7 @@ k_pairs_tm(const SimkaSpan *spans, const ull *cursors, const ull *tm_ent, const 
     ull *pk = (ull *)(smem + SIMKA_LDS_HEAD);                    // [npk][CP]     packed u32 pairs
     ull *c64 = pk + (size_t)npk * CP;                            // [nacc64][CP]  (whit, klfix)
     const uint32_t EC = pc.span_cap, GC = EC / 2u;
-    ull *ent = c64 + (size_t)pc.nacc64 * CP;                     // [EC]          segment I, then segment J: (g<<48 | sample<<32 | count)
+    ull *ent = c64 + (size_t)pc.nacc64 * CP;                     // [EC]          per staged span: segment I, then segment J: (g<<48 | sample<<32 | count)
     double *ep = (double *)(ent + EC);                           // [EC]          complex: p = c / N_sample
     double *eplp = ep + (cplx ? EC : 0);                         // [EC]          complex: p * ln p
     double *tn = eplp + (cplx ? EC : 0);                         // [SIMKA_PAIR_TN] complex: N of the samples of tile I, then tile J
@@ -1534,6 +1549,8 @@ k_pairs_tm(const SimkaSpan *spans, const ull *cursors, const ull *tm_ent, const 
     uint32_t *gdescB = tmp + 32;                                 // [GC]          run of the group in segment J
     uint32_t *runA = gdescB + GC;                                // [GC]          (head | tail<<16) written by the run's first / last entry
     uint32_t *runB = runA + GC;                                  // [GC]
+    // range tables, double-buffered (the last batch of a range is still being paired while the next range is laid out)
+    KtmRange *s_rng = (KtmRange *)(runB + GC);                   // [2]
 
     const uint32_t tid = threadIdx.x;
     const uint32_t N = pc.nb_samples, T = pc.tile, nt = pc.ntiles;
@@ -1555,70 +1572,138 @@ k_pairs_tm(const SimkaSpan *spans, const ull *cursors, const ull *tm_ent, const 
     ull bound = 0, bound_q = 0;
 
     const ull nspans = cursors[2];
+    const ull nranges = (nspans + KTM_RANGE - 1) / KTM_RANGE;
     constexpr int EPT = (SIMKA_SPAN_MAX + K4_BLOCK - 1) / K4_BLOCK;
-    // pipeline: span descriptor + segment offsets two iterations ahead, the member entries one iteration ahead (registers)
-    struct Seg { uint32_t a0, na, b0, nb; };
-    auto seg_of = [&](ull s) -> Seg {
-        const uint32_t *o = tm_off + s * (nt + 1u);
-        Seg g; g.a0 = o[I]; g.na = o[I + 1u] - g.a0; g.b0 = 0; g.nb = 0;
-        if (rect) { g.b0 = o[J]; g.nb = o[J + 1u] - g.b0; }
-        return g;
+    ull rq = blockIdx.x;                 // current range of span slots
+    uint32_t rbuf = 1, rnext = 0;        // table of the current range, next batch of it
+    bool started = false;
+    // lay out range rq in table `t`: the spans as this tile pair sees them (spans without a pair for it count as empty), cut
+    // into batches that fit the staging arrays.  Three barriers.
+    auto load_range = [&](uint32_t t) {
+        KtmRange *R = s_rng + t;
+        __syncthreads();
+        uint32_t cnt = 0;
+        if (rq < nranges) {
+            const ull s0 = rq * KTM_RANGE;
+            cnt = (uint32_t)((nspans - s0 < (ull)KTM_RANGE) ? (nspans - s0) : (ull)KTM_RANGE);
+            if (tid < cnt) {
+                const SimkaSpan sp = spans[s0 + tid];
+                const uint32_t *o = tm_off + (s0 + tid) * (nt + 1u);
+                KtmSpan d; d.ebase = sp.ebase; d.ngrp = sp.ngrp; d.maxc = sp.maxc; d.a0 = 0; d.na = 0; d.b0 = 0; d.nb = 0;
+                if (sp.ngrp) {
+                    d.a0 = o[I]; d.na = o[I + 1u] - d.a0;
+                    if (rect) { d.b0 = o[J]; d.nb = o[J + 1u] - d.b0; }
+                    if (rect ? (d.na == 0u || d.nb == 0u) : d.na < 2u) { d.ngrp = 0; d.na = 0; d.nb = 0; }      // nothing to pair up here
+                }
+                R->d[tid] = d;
+            }
+        }
+        __syncthreads();
+        if (tid == 0) {
+            uint32_t nb = 0, j = 0;
+            while (j < cnt) {
+                while (j < cnt && R->d[j].ngrp == 0u) { KtmSlot sl; sl.st = 0; sl.mid = 0; sl.gbase = 0; sl.pad = 0; R->sl[j] = sl; j++; }   // leading empty spans
+                if (j >= cnt) break;
+                uint32_t nm = 0, ng = 0, mc = 0;
+                R->bstart[nb] = j;
+                const uint32_t j0 = j;
+                while (j < cnt) {
+                    const KtmSpan d = R->d[j];
+                    const uint32_t m = d.na + d.nb;
+                    if (j > j0 && (nm + m > EC || ng + d.ngrp > GC)) break;
+                    KtmSlot sl; sl.st = nm; sl.mid = nm + d.na; sl.gbase = ng; sl.pad = 0; R->sl[j] = sl;
+                    nm += m; ng += d.ngrp; mc = d.maxc > mc ? d.maxc : mc;
+                    j++;
+                }
+                R->bnm[nb] = nm; R->bng[nb] = ng; R->bmaxc[nb] = mc;
+                nb++;
+            }
+            R->bstart[nb] = cnt;
+            R->nbatch = nb; R->cnt = cnt;
+        }
+        __syncthreads();
     };
-    SimkaSpan span, nspan;
-    Seg seg = {0, 0, 0, 0}, nseg = {0, 0, 0, 0};
-    span.ngrp = 0; span.nent = 0; nspan.ngrp = 0; nspan.nent = 0;
-    ull sp = blockIdx.x;
-    if (sp < nspans) { span = spans[sp]; seg = seg_of(sp); }
-    if (sp + gridDim.x < nspans) { nspan = spans[sp + gridDim.x]; nseg = seg_of(sp + gridDim.x); }
-    ull pre_e[EPT]; double2 pre_p[EPT];
-#define KTM_FETCH(S, G)                                                                       \
+    // the next batch (uniform): spans [bf, bl) of table rt
+    struct Batch { uint32_t rt, bf, bl, nm, ng, maxc; bool done; };
+    auto pick = [&]() -> Batch {
+        Batch b; b.rt = 0; b.bf = 0; b.bl = 0; b.nm = 0; b.ng = 0; b.maxc = 0; b.done = false;
+        bool flipped = false;             // the table of the batch in flight must survive: switch tables once per call, then
+        for (;;) {                        // ranges without a pair for this tile pair are laid out over each other
+            if (!started) { started = true; rbuf ^= 1u; flipped = true; load_range(rbuf); rnext = 0; }
+            else if (rnext >= s_rng[rbuf].nbatch) {
+                if (rq >= nranges) { b.done = true; return b; }
+                rq += gridDim.x;
+                if (!flipped) { rbuf ^= 1u; flipped = true; }
+                load_range(rbuf); rnext = 0;
+            }
+            const KtmRange *R = s_rng + rbuf;
+            if (R->cnt == 0u) { b.done = true; return b; }
+            if (rnext >= R->nbatch) continue;
+            b.rt = rbuf; b.bf = R->bstart[rnext]; b.bl = R->bstart[rnext + 1u];
+            // (a batch ends where the next one starts, or before the trailing empty spans: either way its members end at bnm)
+            b.nm = R->bnm[rnext]; b.ng = R->bng[rnext]; b.maxc = R->bmaxc[rnext];
+            rnext++;
+            return b;
+        }
+    };
+    ull pre_e[EPT]; double2 pre_p[EPT]; uint32_t pre_j[EPT];
+    // issue the loads of batch B; pre_j = the span (index in the range table) a staged entry belongs to
+#define KTM_FETCH(B) {                                                                        \
+    const KtmRange *R_ = s_rng + (B).rt;                                                      \
     _Pragma("unroll") for (int q = 0; q < EPT; q++) {                                         \
         const uint32_t i = tid + (uint32_t)q * K4_BLOCK;                                      \
-        pre_e[q] = 0ull; pre_p[q] = make_double2(0.0, 0.0);                                   \
-        if ((S).ngrp && i < (G).na + (G).nb) {                                                \
-            const ull src = (S).ebase + (i < (G).na ? (G).a0 + i : (G).b0 + (i - (G).na));    \
+        pre_e[q] = 0ull; pre_p[q] = make_double2(0.0, 0.0); pre_j[q] = 0u;                    \
+        if (i < (B).nm) {                                                                     \
+            uint32_t j = (B).bf;                                                              \
+            while (j + 1u < (B).bl && (R_->d[j].ngrp == 0u || i >= R_->sl[j].st + R_->d[j].na + R_->d[j].nb)) j++;   \
+            const KtmSlot sl = R_->sl[j];                                                     \
+            const KtmSpan d = R_->d[j];                                                       \
+            const ull src = d.ebase + (i < sl.mid ? d.a0 + (i - sl.st) : d.b0 + (i - sl.mid)); \
             pre_e[q] = tm_ent[src];                                                           \
             if (cplx) pre_p[q] = tm_p[src];                                                   \
+            pre_j[q] = j;                                                                     \
         }                                                                                     \
-    }
-    KTM_FETCH(span, seg)
+    } }
+    uint32_t it = 0;
+    Batch nxt = pick();
+    if (!nxt.done) KTM_FETCH(nxt)
     PP_DECL
-    for (; sp < nspans; sp += gridDim.x) {
+    for (; !nxt.done; it++) {
         PP(6)
         __syncthreads();
         PP(0)
-        const SimkaSpan cur = span;
-        const Seg cs = seg;
-        const uint32_t nM = cur.ngrp ? cs.na + cs.nb : 0u;
+        const Batch cur = nxt;
+        const KtmRange *CR = s_rng + cur.rt;
+        uint32_t cur_j[EPT];              // which span of the range my staged entries belong to
 #pragma unroll
         for (int q = 0; q < EPT; q++) {
             const uint32_t i = tid + (uint32_t)q * K4_BLOCK;
-            if (i < nM) { ent[i] = pre_e[q]; if (cplx) { ep[i] = pre_p[q].x; eplp[i] = pre_p[q].y; } }
-            if (i < cur.ngrp) { runA[i] = 0u; runB[i] = 0u; }
+            cur_j[q] = pre_j[q];
+            if (i < cur.nm) { ent[i] = pre_e[q] + ((ull)CR->sl[pre_j[q]].gbase << 48); if (cplx) { ep[i] = pre_p[q].x; eplp[i] = pre_p[q].y; } }
+            if (i < cur.ng) { runA[i] = 0u; runB[i] = 0u; }
         }
-        span = nspan; seg = nseg;
-        nspan.ngrp = 0; nspan.nent = 0;
-        if (sp + 2 * (ull)gridDim.x < nspans) { nspan = spans[sp + 2 * (ull)gridDim.x]; nseg = seg_of(sp + 2 * (ull)gridDim.x); }
-        KTM_FETCH(span, seg)
+        // the batch after this one (may lay out the next range into the other table: barriers), then issue its loads
+        nxt = pick();
+        if (!nxt.done) KTM_FETCH(nxt)
+        __syncthreads();                  // staging of `cur` complete
         PP(1)
-        // nothing to pair up in this span for this tile pair (uniform)
-        if (cur.ngrp == 0 || (rect ? (cs.na == 0u || cs.nb == 0u) : cs.na < 2u)) continue;
-        const ull add = (ull)cur.ngrp * (ull)cur.maxc;
-        const ull addq = (ull)cur.ngrp * (ull)cur.maxc * (ull)cur.maxc;
+        const ull add = (ull)cur.ng * (ull)cur.maxc;
+        const ull addq = (ull)cur.ng * (ull)cur.maxc * (ull)cur.maxc;
         const bool chord_fast = cur.maxc < 46341u && addq < 0xffffffffull;
         if (bound + add >= 0xffffffffull || (chord_fast && bound_q + addq >= 0xffffffffull)) { pairs_flush<true, K4_BLOCK>(pk, c64, acc, pc, rect, baseI, baseJ); bound = 0; bound_q = 0; }
         bound += add;
         if (chord_fast) bound_q += addq;
-        __syncthreads();
-        // group runs: the first entry of a run stores its index, the last one the index behind it
+        // group runs: the first entry of a run stores its index, the last one the index behind it.  Neighbouring segments of
+        // different spans never share a group id; the I and J segments of one span may, hence the explicit boundary.
 #pragma unroll
         for (int q = 0; q < EPT; q++) {
             const uint32_t i = tid + (uint32_t)q * K4_BLOCK;
-            if (i < nM) {
+            if (i < cur.nm) {
+                const KtmSlot sl = CR->sl[cur_j[q]];
                 const uint32_t g = (uint32_t)(ent[i] >> 48);
-                const bool inA = i < cs.na;
+                const bool inA = i < sl.mid;
                 uint16_t *run = (uint16_t *)(inA ? runA : runB) + 2u * g;
-                const uint32_t lo = inA ? 0u : cs.na, hi = inA ? cs.na : nM;
+                const uint32_t lo = inA ? sl.st : sl.mid, hi = inA ? sl.mid : sl.mid + CR->d[cur_j[q]].nb;
                 if (i == lo || (uint32_t)(ent[i - 1u] >> 48) != g) run[0] = (uint16_t)i;
                 if (i + 1u == hi || (uint32_t)(ent[i + 1u] >> 48) != g) run[1] = (uint16_t)(i + 1u);
             }
@@ -1628,7 +1713,7 @@ k_pairs_tm(const SimkaSpan *spans, const ull *cursors, const ull *tm_ent, const 
 #pragma unroll
         for (int q = 0; q < EPT; q++) {
             const uint32_t g = tid + (uint32_t)q * K4_BLOCK;
-            if (g < cur.ngrp) {
+            if (g < cur.ng) {
                 const uint32_t ra = runA[g], rb = runB[g];
                 const uint32_t a0 = ra & 0xffffu, nA = (ra >> 16) - a0, b0 = rb & 0xffffu, nB = (rb >> 16) - b0;
                 gdesc[g] = (a0 << 16) | nA;
@@ -1638,18 +1723,18 @@ k_pairs_tm(const SimkaSpan *spans, const ull *cursors, const ull *tm_ent, const 
         }
         __syncthreads();
         PP(3)
-        const uint32_t P = block_excl_scan<K4_BLOCK>(gpref, cur.ngrp, tmp);
-        if (tid == 0) gpref[cur.ngrp] = P;
+        const uint32_t P = block_excl_scan<K4_BLOCK>(gpref, cur.ng, tmp);
+        if (tid == 0) gpref[cur.ng] = P;
         __syncthreads();
         PP(4)
         const uint32_t chunk = (P + K4_BLOCK - 1) / K4_BLOCK;
         uint32_t p = tid * chunk;
         const uint32_t pend = (p + chunk < P) ? p + chunk : P;
         if (p < pend) {
-            uint32_t lo = 0, hi = cur.ngrp;    // largest g with gpref[g] <= p
+            uint32_t lo = 0, hi = cur.ng;    // largest g with gpref[g] <= p
             while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (gpref[mid] <= p) lo = mid; else hi = mid; }
             uint32_t g = lo;
-            while (g + 1 < cur.ngrp && gpref[g + 1] <= p) g++;   // skip groups without pairs
+            while (g + 1 < cur.ng && gpref[g + 1] <= p) g++;   // skip groups without pairs
             uint32_t d = gdesc[g];
             uint32_t a0 = d >> 16, nA = d & 0xffffu, b0 = 0, nB = 0, x, y;
             if (rect) {
@@ -1665,8 +1750,7 @@ k_pairs_tm(const SimkaSpan *spans, const ull *cursors, const ull *tm_ent, const 
                 const ull ey = ent[iy];
                 uint32_t si = (uint32_t)(ex >> 32) & 0xffffu, sj = (uint32_t)(ey >> 32) & 0xffffu;
                 uint32_t ci = (uint32_t)ex, cj = (uint32_t)ey;
-                uint32_t jx = ix, jy = iy;                       // staged indices of the (i, j)-ordered pair
-                if (!rect && si > sj) { uint32_t t_ = si; si = sj; sj = t_; t_ = ci; ci = cj; cj = t_; jx = iy; jy = ix; }
+                if (!rect && si > sj) { uint32_t t_ = si; si = sj; sj = t_; t_ = ci; ci = cj; cj = t_; }
                 const uint32_t li = si - baseI, lj = sj - baseJ;
                 const uint32_t cell = rect ? li * T + lj : li * T - ((li * (li + 1u)) >> 1) + (lj - li - 1u);
                 atomicAdd(&pk[0 * CP + cell], (ull)ci | ((ull)cj << 32));                       // S_ij | S_ji
@@ -1682,8 +1766,8 @@ k_pairs_tm(const SimkaSpan *spans, const ull *cursors, const ull *tm_ent, const 
                 }
                 if (cplx) {
                     // same arithmetic as k_pairs (ref: src/core/SimkaAlgorithm.hpp:437-446,477-481)
-                    const double h = ep[jx] + ep[jy];
-                    double dd = eplp[jx] + eplp[jy] - h * log(h * 0.5);
+                    const double h = ep[ix] + ep[iy];
+                    double dd = eplp[ix] + eplp[iy] - h * log(h * 0.5);
                     dd = dd < 0.0 ? 0.0 : dd;
                     atomicAdd(&c64[1 * CP + cell], (ull)(long long)llrint(dd * SIMKA_KL_SCALE));
                     const ull uX = (ull)((double)ci * tn[(rect ? T : 0u) + lj]), uY = (ull)((double)cj * tn[li]);
@@ -1694,8 +1778,8 @@ k_pairs_tm(const SimkaSpan *spans, const ull *cursors, const ull *tm_ent, const 
                     x++; y = rect ? 0u : x + 1u;
                     if (rect ? (x == nA) : (y >= nA)) {   // group exhausted
                         g++;
-                        while (g < cur.ngrp && gpref[g + 1] == gpref[g]) g++;
-                        if (g >= cur.ngrp) break;
+                        while (g < cur.ng && gpref[g + 1] == gpref[g]) g++;
+                        if (g >= cur.ng) break;
                         d = gdesc[g]; a0 = d >> 16; nA = d & 0xffffu; x = 0; y = rect ? 0u : 1u;
                         if (rect) { const uint32_t dB = gdescB[g]; b0 = dB >> 16; nB = dB & 0xffffu; }
                     }

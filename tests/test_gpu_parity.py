@@ -351,6 +351,41 @@ def test_many_samples_tiled_pair_accumulators(gpu_required, oracle_mod, n, simpl
     _check_vs_oracle(totals, st, orc, simple=simple, complex_=complex_)
 
 
+@pytest.mark.parametrize("n,complex_", [(330, True), (900, False)])
+def test_tiled_pairs_when_most_tile_pairs_share_nothing(gpu_required, oracle_mod, n, complex_):
+    """Samples in clusters of 10 that share reads only inside their cluster: almost every (span, sample-tile pair) has no pair
+    at all, whole ranges of spans are empty for a tile pair (the batching of the tile-major pair kernel skips them), and the
+    groups of a cluster sit inside one tile or straddle two."""
+    import simka_amd
+    from simka_amd import synth
+    R, L, k = 40, 100, 21
+    g = synth.genome_len_for(R * 4, L)
+    pool, gw = synth.genome_pool_cpu(g)
+    offs = np.arange(R + 1, dtype=np.uint64) * L
+    packed = []
+    ids, cdf = synth.sample_profile(0)
+    for s in range(n):
+        c = s // 10
+        base = synth.unpack_ascii(synth.reads_cpu(R, L, pool, gw, g, ids, cdf, synth.sample_seed(1000 + c)), R * L).copy()
+        own = synth.unpack_ascii(synth.reads_cpu(R, L, pool, gw, g, ids, cdf, synth.sample_seed(5000 + s)), R * L)
+        m = (s % 10) * 3 * L                                       # the first (s % 10) * 3 reads are the sample's own
+        base[:m] = own[:m]
+        packed.append(base)
+    ctx = simka_amd.SimkaContext(n, kmer_size=k, abundance_min=1, simple_dist=True, complex_dist=complex_)
+    for s, asc in enumerate(packed):
+        pk, off, nb, nin = simka_amd.pack_reads([asc[i * L:(i + 1) * L].tobytes() for i in range(R)])
+        ctx.count_sample(s, pk, nb, len(off) - 1, offsets=off, nb_input_reads=nin)
+    totals = [ctx.sample_totals(i) for i in range(n)]
+    ctx.merge()
+    st = ctx.stats()
+    ctx.close()
+    orc = oracle_mod.Oracle()
+    for s, asc in enumerate(packed):
+        orc.add_sample_ascii("S%d" % s, asc, offs)
+    orc.run(k, 1, simple=True, complex_=complex_, nparts=8, threads=8)
+    _check_vs_oracle(totals, st, orc, simple=True, complex_=complex_)
+
+
 def test_kmer_shared_by_more_samples_than_a_span(gpu_required, oracle_mod):
     """1100 samples drawn from 3 read sets that share genomes: groups of 360..1100 entries.  Groups above K3_CAP (1024)
     records cannot be hashed in one k_group round: they take the huge-group list and k_pairs_global."""
