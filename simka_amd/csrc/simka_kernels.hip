@@ -1518,7 +1518,7 @@ k_tile_major(const SimkaSpan *spans, const ull *cursors, const ull *entries, con
 // <= span_cap, groups <= span_cap / 2) out of a range of KTM_RANGE span slots -- so the fixed costs of an iteration (barriers,
 // the scan over the groups, the per-thread pair search) are shared by several spans' pairs.  Group ids are made batch-wide by
 // adding the number of groups of the spans staged before.
-#define KTM_RANGE 16
+#define KTM_RANGE 32
 struct KtmSpan { ull ebase; uint32_t ngrp, maxc, a0, na, b0, nb; };      // a span as tile pair (I, J) sees it
 struct KtmSlot { uint32_t st, mid, gbase, pad; };                        // staging start, start of the J members, first group id
 // a range of span slots cut into batches by thread 0: batch b = spans [bstart[b], bstart[b+1]), nm / ng / maxc per batch
