@@ -1240,7 +1240,9 @@ static void pair_launch(simka_ctx *ctx, const PairLaunch &pl, const SimkaSpan *s
                         const SimkaSpan *huge, ull *acc, bool have_spans = true, uint64_t nb_entries = 0, uint64_t nb_spans = 0) {
     const SimkaPairCfg &pc = pl.pc;
     // N beyond one LDS tile: reorder the spans tile-major once (k_tile_major), then every tile pair stages only its two segments
-    bool tile_major = have_spans && pc.ntiles > 1 && pc.ntiles <= KTM_NT_MAX && tile_major_enabled();
+    const char *nt_env = getenv("SIMKA_TM_MAX_TILES");          // tests: force the fallback below a smaller tile count
+    const uint32_t nt_max = nt_env ? std::min<uint32_t>(KTM_NT_MAX, (uint32_t)atoi(nt_env)) : (uint32_t)KTM_NT_MAX;
+    bool tile_major = have_spans && pc.ntiles > 1 && pc.ntiles <= nt_max && tile_major_enabled();
     if (tile_major) {
         if (!nb_spans) {      // (one small download per merge batch; the batches are large)
             ull cur[4] = { 0, 0, 0, 0 };

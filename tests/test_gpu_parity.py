@@ -351,13 +351,16 @@ def test_many_samples_tiled_pair_accumulators(gpu_required, oracle_mod, n, simpl
     _check_vs_oracle(totals, st, orc, simple=simple, complex_=complex_)
 
 
-@pytest.mark.parametrize("n,complex_", [(330, True), (900, False)])
-def test_tiled_pairs_when_most_tile_pairs_share_nothing(gpu_required, oracle_mod, n, complex_):
+@pytest.mark.parametrize("n,complex_,fallback", [(330, True, False), (900, False, False), (330, True, True)])
+def test_tiled_pairs_when_most_tile_pairs_share_nothing(gpu_required, oracle_mod, monkeypatch, n, complex_, fallback):
     """Samples in clusters of 10 that share reads only inside their cluster: almost every (span, sample-tile pair) has no pair
     at all, whole ranges of spans are empty for a tile pair (the batching of the tile-major pair kernel skips them), and the
-    groups of a cluster sit inside one tile or straddle two."""
+    groups of a cluster sit inside one tile or straddle two.  fallback: more tiles than the tile-major path takes (forced
+    here through SIMKA_TM_MAX_TILES): the scan-and-compact kernel runs with its own LDS geometry on the same spans."""
     import simka_amd
     from simka_amd import synth
+    if fallback:
+        monkeypatch.setenv("SIMKA_TM_MAX_TILES", "2")
     R, L, k = 40, 100, 21
     g = synth.genome_len_for(R * 4, L)
     pool, gw = synth.genome_pool_cpu(g)
