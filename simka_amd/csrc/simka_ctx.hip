@@ -1178,8 +1178,8 @@ static void pairs_phase_report() {
 
 struct PairLaunch { SimkaPairCfg pc; size_t lds_pairs = 0; uint32_t ntp = 1, nblk = 1; bool small_block = false; };
 
-// is the tile-major pair kernel usable (decided per context: SIMKA_PAIRS_LEGACY=1 keeps the scan-and-compact kernel, tests / A-B)
-static bool tile_major_enabled() { static const bool legacy = getenv("SIMKA_PAIRS_LEGACY") != nullptr; return !legacy; }
+// is the tile-major pair kernel usable (SIMKA_PAIRS_LEGACY=1 keeps the scan-and-compact kernel: tests / A-B; read at every merge)
+static bool tile_major_enabled() { return getenv("SIMKA_PAIRS_LEGACY") == nullptr; }
 
 static void pair_setup(simka_ctx *ctx, PairLaunch &pl, bool legacy_layout = false, uint32_t force_span_cap = 0) {
     // pair-accumulator tiling: all N(N-1)/2 cells in LDS when they fit, else T x T sample tiles

@@ -952,3 +952,13 @@ def test_full_size_size_independent_properties(gpu_required, workload, alt_pb):
             assert abs(v - want) < 1e-6, (name, mat[0, 1])
     i01 = int(np.flatnonzero((iu[0] == 0) & (iu[1] == 1))[0])
     assert dr["S_ij"][1] == dr["S_ij"][2] == pr["S_ij"][i01] and dr["bc"][1] == dr["bc"][2] == pr["bc"][i01]
+
+
+def test_tile_major_pair_kernels_agree_with_the_scan_and_compact_kernel(gpu_required):
+    """scripts/cross_check_tiled.py, 5 rounds: 130..800 samples (copies of D distinct device-generated ones, so groups of a few to
+    hundreds of samples), random k (hash and sort pipelines) / abundance-min / distance families -- the flat statistics of the
+    tile-major path, of k_pairs<TILED> and of the sort pipeline are identical."""
+    import subprocess, sys
+    r = subprocess.run([sys.executable, os.path.join(ROOT_DIR, "scripts", "cross_check_tiled.py"), "5", "21"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
+                       text=True, timeout=900)
+    assert r.returncode == 0 and "tiled cross-check ok" in r.stdout, r.stdout[-3000:]
