@@ -333,7 +333,6 @@ SIMKA_EXPORT int simka_create(const simka_config *cfg, simka_ctx **out) {
     if (cfg->nb_samples == 0 || cfg->nb_samples > 65535) { g_create_error = "simka_create: nb_samples must be in [1,65535]"; return SIMKA_ERR_INVALID; }
     if (cfg->kmer_size < 1 || cfg->kmer_size > 63) { g_create_error = "simka_create: kmer_size must be in [1,63]"; return SIMKA_ERR_INVALID; }
     const bool want_wide = cfg->kmer_size > 31 || getenv("SIMKA_SORT_PATH") != nullptr;
-    if (want_wide && cfg->shard_count > 1) { g_create_error = "simka_create: partition shards are not available for kmer_size >= 32 (sort-based path)"; return SIMKA_ERR_UNSUPPORTED; }
     if (cfg->shard_count == 0 || cfg->shard_index >= cfg->shard_count) { g_create_error = "simka_create: bad shard_index/shard_count"; return SIMKA_ERR_INVALID; }
     if (cfg->log2_subranges > 8) { g_create_error = "simka_create: log2_subranges must be <= 8"; return SIMKA_ERR_INVALID; }
     int ndev = 0;
@@ -382,6 +381,7 @@ SIMKA_EXPORT int simka_create(const simka_config *cfg, simka_ctx **out) {
     ctx->nb_reads.assign(N, 0);
     if (want_wide) {
         if (simka_wide_create(&ctx->wide, cfg->device, N, cfg->kmer_size, ctx->stream) != SIMKA_WIDE_OK) { ctx->err = "cannot create the wide-k state"; return bail(SIMKA_ERR_NOMEM); }
+        simka_wide_set_shard(ctx->wide, cfg->shard_index, cfg->shard_count);
     } else if (cfg->max_kmers_per_sample) { rc = setup_geometry(ctx, cfg->max_kmers_per_sample); if (rc) return bail(rc); }
     *out = ctx;
     return SIMKA_OK;

@@ -18,6 +18,8 @@ struct SimkaWideCsr {
 
 int simka_wide_create(SimkaWide **out, int device, uint32_t nb_samples, uint32_t k, void *stream);
 void simka_wide_destroy(SimkaWide *w);
+// partition shard of the k-mer space this state keeps (default: everything)
+void simka_wide_set_shard(SimkaWide *w, uint32_t shard_index, uint32_t shard_count);
 int simka_wide_reset(SimkaWide *w);
 const char *simka_wide_error(SimkaWide *w);
 // packed / offsets: DEVICE pointers.  totals5: D N Q D_all K_occ (SIMKA_TOT_* order), host.  d_hist_row etc.: -complex-dist (or NULL).

@@ -35,6 +35,7 @@ typedef unsigned long long ull;
 struct SimkaWide {
     int device = 0;
     uint32_t nb_samples = 0, k = 0, W = 0;
+    uint32_t shard_index = 0, shard_count = 1;   // partition shard: the k-mers this context keeps (wide_owns)
     hipStream_t stream = nullptr;
     std::string err;
     // wide arena: the solid spectra of all samples, each sorted by (hi, lo)
@@ -66,54 +67,31 @@ static int wide_buf(SimkaWide *w, int slot, uint64_t n, T **out) {
 // --------------------------------------------------------------------------------------------
 #define WSEG 32
 
-struct WideScanArgs { const uint64_t *packed; uint64_t nb_bases, nb_words; const uint64_t *offsets; uint64_t nb_reads; uint32_t fixed_len, k; };
+struct WideScanArgs { const uint64_t *packed; uint64_t nb_bases, nb_words; const uint64_t *offsets; uint64_t nb_reads; uint32_t fixed_len, k;
+                      uint32_t shard_index, shard_count; };
+
+// partition shards of the sort-based path: a canonical k-mer belongs to shard  mix(hi, lo) * G >> 32  (every context of a sharded run
+// scans all reads and keeps its own k-mers, as a shard of the hash pipeline keeps its level-1 buckets)
+__device__ __forceinline__ bool wide_owns(ull hi, ull lo, uint32_t shard_index, uint32_t shard_count) {
+    ull x = lo ^ (hi * 0x9E3779B97F4A7C15ull);
+    x ^= x >> 29; x *= 0xBF58476D1CE4E5B9ull; x ^= x >> 32;
+    return (uint32_t)(((x >> 32) * (ull)shard_count) >> 32) == shard_index;
+}
 
 __device__ __forceinline__ uint32_t wbase(const uint64_t *packed, uint64_t p) { return (uint32_t)(packed[p >> 5] >> ((p & 31u) * 2u)) & 3u; }
 
-__global__ void __launch_bounds__(256)
-k_wscan(WideScanArgs a, ull *khi, ull *klo, ull *nvalid) {
-    __shared__ uint32_t s_wave[4];
-    __shared__ ull s_base;
-    const uint64_t p0 = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) * WSEG;
+// roll the forward / reverse-complement words over the thread's positions [p0, pend); warm up on the k-1 bases before p0 (same
+// read).  EMIT: write the (owned) canonical k-mers from slot wr on; returns how many there are.
+template <bool EMIT, bool SHARDED>
+__device__ __forceinline__ uint32_t wroll(const WideScanArgs &a, uint64_t p0, uint64_t pend, uint64_t rd, uint64_t rstart, uint64_t rend, ull *khi, ull *klo, ull wr) {
     const uint32_t k = a.k;
-    const bool active = p0 < a.nb_bases;
-    uint64_t rd = 0, rstart = 0, rend = 0;
-    const uint64_t pend = active ? (p0 + WSEG < a.nb_bases ? p0 + WSEG : a.nb_bases) : 0;
-    uint32_t cnt = 0;
-    if (active) {
-        // the read that holds base p0
-        if (a.fixed_len) { rd = p0 / a.fixed_len; rstart = rd * a.fixed_len; rend = rstart + a.fixed_len; }
-        else {
-            uint64_t lo = 0, hi = a.nb_reads;
-            while (hi - lo > 1) { const uint64_t mid = (lo + hi) >> 1; if (a.offsets[mid] <= p0) lo = mid; else hi = mid; }
-            rd = lo; rstart = a.offsets[rd]; rend = a.offsets[rd + 1];
-        }
-        // pass 1 (no bases touched): how many of my end positions close a whole k-mer inside one read
-        uint64_t rr = rd, rs = rstart, re = rend;
-        for (uint64_t p = p0; p < pend; p++) {
-            while (p >= re) { rr++; rs = re; re = a.fixed_len ? rs + a.fixed_len : a.offsets[rr + 1]; }
-            if (p - rs >= (uint64_t)(k - 1u)) cnt++;
-        }
-    }
-    // output slots: block scan of the counts + one global atomic per block (the order of the keys is irrelevant: they get sorted)
-    uint32_t incl = cnt;
-    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-    for (int o = 1; o < 64; o <<= 1) { const uint32_t t = __shfl_up(incl, o, 64); if (lane >= (uint32_t)o) incl += t; }
-    if (lane == 63u) s_wave[wave] = incl;
-    __syncthreads();
-    uint32_t wpre = 0, btot = 0;
-    for (uint32_t i = 0; i < 4; i++) { if (i < wave) wpre += s_wave[i]; btot += s_wave[i]; }
-    if (threadIdx.x == 0) s_base = btot ? atomicAdd(nvalid, (ull)btot) : 0ull;
-    __syncthreads();
-    if (!active || cnt == 0) return;
-    ull wr = s_base + wpre + incl - cnt;
-    // pass 2: roll the forward / reverse-complement words; warm up on the k-1 bases before my first position (same read)
     const uint32_t W = 2u * k;
     const ull mlo = W >= 64u ? ~0ull : ((1ull << W) - 1ull);
     const ull mhi = W > 64u ? ((1ull << (W - 64u)) - 1ull) : 0ull;
     const uint32_t top = 2u * (k - 1u);                      // bit position of the first base in the reverse-complement word
     ull fh = 0, fl = 0, rh = 0, rl = 0;
     uint32_t have = 0;                                        // bases of the current read inside the window (capped at k)
+    uint32_t n = 0;
     uint64_t p = p0 > rstart + (k - 1u) ? p0 - (k - 1u) : rstart;
     ull word = a.packed[p >> 5] >> ((p & 31u) * 2u);        // the bases from p on, refilled every 32 bases
     for (; p < pend; p++) {
@@ -135,10 +113,58 @@ k_wscan(WideScanArgs a, ull *khi, ull *klo, ull *nvalid) {
         if (have < k) have++;
         if (p >= p0 && have >= k) {
             const bool fsm = fh < rh || (fh == rh && fl < rl);
-            khi[wr] = fsm ? fh : rh; klo[wr] = fsm ? fl : rl;
-            wr++;
+            const ull ch = fsm ? fh : rh, cl = fsm ? fl : rl;
+            if (!SHARDED || wide_owns(ch, cl, a.shard_index, a.shard_count)) {
+                if (EMIT) { khi[wr] = ch; klo[wr] = cl; wr++; }
+                n++;
+            }
         }
     }
+    return n;
+}
+
+template <bool SHARDED>
+__global__ void __launch_bounds__(256)
+k_wscan(WideScanArgs a, ull *khi, ull *klo, ull *nvalid) {
+    __shared__ uint32_t s_wave[4];
+    __shared__ ull s_base;
+    const uint64_t p0 = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) * WSEG;
+    const uint32_t k = a.k;
+    const bool active = p0 < a.nb_bases;
+    uint64_t rd = 0, rstart = 0, rend = 0;
+    const uint64_t pend = active ? (p0 + WSEG < a.nb_bases ? p0 + WSEG : a.nb_bases) : 0;
+    uint32_t cnt = 0;
+    if (active) {
+        // the read that holds base p0
+        if (a.fixed_len) { rd = p0 / a.fixed_len; rstart = rd * a.fixed_len; rend = rstart + a.fixed_len; }
+        else {
+            uint64_t lo = 0, hi = a.nb_reads;
+            while (hi - lo > 1) { const uint64_t mid = (lo + hi) >> 1; if (a.offsets[mid] <= p0) lo = mid; else hi = mid; }
+            rd = lo; rstart = a.offsets[rd]; rend = a.offsets[rd + 1];
+        }
+        if (SHARDED) cnt = wroll<false, true>(a, p0, pend, rd, rstart, rend, khi, klo, 0ull);      // ownership needs the k-mer itself
+        else {
+            // pass 1 (no bases touched): how many of my end positions close a whole k-mer inside one read
+            uint64_t rr = rd, rs = rstart, re = rend;
+            for (uint64_t p = p0; p < pend; p++) {
+                while (p >= re) { rr++; rs = re; re = a.fixed_len ? rs + a.fixed_len : a.offsets[rr + 1]; }
+                if (p - rs >= (uint64_t)(k - 1u)) cnt++;
+            }
+        }
+    }
+    // output slots: block scan of the counts + one global atomic per block (the order of the keys is irrelevant: they get sorted)
+    uint32_t incl = cnt;
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    for (int o = 1; o < 64; o <<= 1) { const uint32_t t = __shfl_up(incl, o, 64); if (lane >= (uint32_t)o) incl += t; }
+    if (lane == 63u) s_wave[wave] = incl;
+    __syncthreads();
+    uint32_t wpre = 0, btot = 0;
+    for (uint32_t i = 0; i < 4; i++) { if (i < wave) wpre += s_wave[i]; btot += s_wave[i]; }
+    if (threadIdx.x == 0) s_base = btot ? atomicAdd(nvalid, (ull)btot) : 0ull;
+    __syncthreads();
+    if (!active || cnt == 0) return;
+    // pass 2: write the k-mers
+    (void)wroll<true, SHARDED>(a, p0, pend, rd, rstart, rend, khi, klo, s_base + wpre + incl - cnt);
 }
 
 __global__ void __launch_bounds__(256)
@@ -322,6 +348,8 @@ int simka_wide_create(SimkaWide **out, int device, uint32_t nb_samples, uint32_t
     return 0;
 }
 
+void simka_wide_set_shard(SimkaWide *w, uint32_t shard_index, uint32_t shard_count) { w->shard_index = shard_index; w->shard_count = shard_count ? shard_count : 1; }
+
 const char *simka_wide_error(SimkaWide *w) { return w ? w->err.c_str() : ""; }
 
 void simka_wide_destroy(SimkaWide *w) {
@@ -371,8 +399,9 @@ int simka_wide_count_sample(SimkaWide *w, uint32_t sample, const void *packed, u
         (rc = wide_buf(w, 5, n + 2, &idx0)) || (rc = wide_buf(w, 6, n + 2, &idx1)) || (rc = wide_buf(w, 7, 16, &d_small))) return rc;
     WCHK(hipMemsetAsync(d_small, 0, 16 * 8, w->stream));
     WideScanArgs a; a.packed = (const uint64_t *)packed; a.nb_bases = nb_bases; a.nb_words = nb_words; a.offsets = (const uint64_t *)offsets;
-    a.nb_reads = nb_reads; a.fixed_len = fixed_len; a.k = w->k;
-    hipLaunchKernelGGL(k_wscan, grid_for((n + WSEG - 1) / WSEG), dim3(256), 0, w->stream, a, hi0, lo0, d_small /* [0] = nvalid */);
+    a.nb_reads = nb_reads; a.fixed_len = fixed_len; a.k = w->k; a.shard_index = w->shard_index; a.shard_count = w->shard_count;
+    if (w->shard_count > 1) hipLaunchKernelGGL(k_wscan<true>, grid_for((n + WSEG - 1) / WSEG), dim3(256), 0, w->stream, a, hi0, lo0, d_small /* [0] = nvalid */);
+    else hipLaunchKernelGGL(k_wscan<false>, grid_for((n + WSEG - 1) / WSEG), dim3(256), 0, w->stream, a, hi0, lo0, d_small /* [0] = nvalid */);
     ull nvalid = 0;
     WCHK(hipMemcpyAsync(&nvalid, d_small, 8, hipMemcpyDeviceToHost, w->stream));
     WCHK(hipStreamSynchronize(w->stream));

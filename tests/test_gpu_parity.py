@@ -283,13 +283,16 @@ def test_cli_fastq_gz_inputs(gpu_required, golden_dir, tmp_path):
     assert n == 20
 
 
-@pytest.mark.parametrize("shards", [2, 3])
-def test_sharded_contexts_sum_to_unsharded(gpu_required, oracle_mod, shards):
+@pytest.mark.parametrize("shards,k,sort_path", [(2, 21, False), (3, 21, False), (3, 33, False), (2, 47, False), (3, 21, True)])
+def test_sharded_contexts_sum_to_unsharded(gpu_required, oracle_mod, monkeypatch, shards, k, sort_path):
     """Partition shards (power-of-two and not) on one GPU: per-sample totals and every pair accumulator add up to the
-    single-context result, which equals the oracle."""
+    single-context result, which equals the oracle.  Hash pipeline (a shard keeps level-1 buckets) and sort-based pipeline
+    (k >= 32, or forced: a shard keeps the canonical k-mers that hash to it)."""
     import simka_amd
     from simka_amd import synth
-    n, R, L, k = 4, 5000, 100, 21
+    if sort_path:
+        monkeypatch.setenv("SIMKA_SORT_PATH", "1")
+    n, R, L = 4, 5000, 100
     packed = _synthetic(n, R, L, seed_shift=50)
     offs = np.arange(R + 1, dtype=np.uint64) * L
     inputs = [(np.concatenate([pk, np.zeros(2, dtype=np.uint64)]), offs, R * L, R) for pk in packed]
