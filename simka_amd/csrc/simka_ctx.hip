@@ -88,6 +88,8 @@ struct simka_ctx {
     bool profiling = false;
     struct Ev { int kid; hipEvent_t a, b; };
     std::vector<Ev> events;
+    std::vector<hipEvent_t> event_pool;                       // recycled profiling events
+    size_t mem_total = 0;                                     // hipMemGetInfo's total, read once
     double prof_ms[KID_NB] = {0};
     uint64_t prof_n[KID_NB] = {0};
 
@@ -120,7 +122,11 @@ static inline void launch_timed(simka_ctx *ctx, int kid, F &&f, hipStream_t st =
     }
     if (ctx->profiling) {
         simka_ctx::Ev ev; ev.kid = kid;
-        (void)hipEventCreate(&ev.a); (void)hipEventCreate(&ev.b);
+        auto take = [&](hipEvent_t *e) {      // events are recycled: creating two per launch shows up with many small samples
+            if (!ctx->event_pool.empty()) { *e = ctx->event_pool.back(); ctx->event_pool.pop_back(); }
+            else (void)hipEventCreate(e);
+        };
+        take(&ev.a); take(&ev.b);
         (void)hipEventRecord(ev.a, st);
         f();
         (void)hipEventRecord(ev.b, st);
@@ -134,7 +140,7 @@ static void profile_collect(simka_ctx *ctx) {
         (void)hipEventSynchronize(ev.b);
         (void)hipEventElapsedTime(&ms, ev.a, ev.b);
         ctx->prof_ms[ev.kid] += ms; ctx->prof_n[ev.kid]++;
-        (void)hipEventDestroy(ev.a); (void)hipEventDestroy(ev.b);
+        ctx->event_pool.push_back(ev.a); ctx->event_pool.push_back(ev.b);
     }
     ctx->events.clear();
 }
@@ -399,6 +405,7 @@ SIMKA_EXPORT void simka_destroy(simka_ctx *ctx) {
         if (L.stream) (void)hipStreamDestroy(L.stream);
     }
     for (auto &ev : ctx->events) { (void)hipEventDestroy(ev.a); (void)hipEventDestroy(ev.b); }
+    for (hipEvent_t e : ctx->event_pool) (void)hipEventDestroy(e);
     void *ptrs[] = { ctx->d_reads, ctx->d_offsets, ctx->d_l1_ovf, ctx->d_solid_keys, ctx->d_solid_counts, ctx->d_arena_cursor,
                      ctx->d_sample_base, ctx->d_foff, ctx->d_fcnt, ctx->d_stats, ctx->d_err, ctx->d_part_total,
                      ctx->d_part_off, ctx->d_mkeys, ctx->d_mvals, ctx->d_entries, ctx->d_groups, ctx->d_fb_off,
@@ -735,8 +742,8 @@ SIMKA_EXPORT int simka_count_sample(simka_ctx *ctx, uint32_t sample, const simka
         const uint32_t max_pass = std::max<uint32_t>(1, ctx->B1 / std::max<uint32_t>(1, ctx->cfg.shard_count));
         if (force) npass = (uint32_t)atoi(force);
         else {
-            size_t fr = 0, tot = 0;
-            HIPCHK(hipMemGetInfo(&fr, &tot));
+            if (!ctx->mem_total) { size_t fr = 0, tot_ = 0; HIPCHK(hipMemGetInfo(&fr, &tot_)); ctx->mem_total = tot_; }
+            const size_t tot = ctx->mem_total;
             const uint64_t kocc_up = r->fixed_len ? r->nb_reads * (uint64_t)r->fixed_len : r->nb_bases;
             const double need = (double)kocc_up * 21.0 / std::max<uint32_t>(1, ctx->cfg.shard_count);
             while (need / npass > 0.30 * (double)tot && npass < max_pass) npass *= 2;
