@@ -196,8 +196,21 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    # Two event records per launch cost GPU time (C2: 3 % of a step; with hundreds of small samples far more), so the timed
+    # region records events for the dominant kernel only -- the one the roofline object reports.  Which kernel that is, and
+    # the per-kernel table (kernel_ms_per_step, path_frac, timing.device_kernels_ms), come from an untimed pass of the same
+    # number of steps with every kernel timed.
     ctx.profile_reset()
     ctx.profile_enable(True)
+    fence()
+    for _ in range(args.steps):
+        step()
+    fence()
+    ctx.profile_enable(False)
+    prof_all = ctx.profile()
+    dom = max(prof_all, key=lambda kk: prof_all[kk][1])
+    ctx.profile_reset()
+    ctx.profile_enable(True, only=[dom])
     fence()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -209,7 +222,8 @@ def main():
         tdt = torch.tensor([dt], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
         dist.all_reduce(tdt, op=dist.ReduceOp.MAX)
         dt = float(tdt.item())
-    prof = ctx.profile()
+    prof_dom = ctx.profile()            # the timed region: launches and milliseconds of the dominant kernel
+    prof = prof_all
     geo = ctx.geometry()
 
     # ---- timing boundaries of SURVEY 8(d), measured outside the timed region (per step, this rank)
@@ -257,8 +271,7 @@ def main():
     }
     kern_ms = {kname: ms for kname, (cnt, ms) in prof.items()}
     total_kernel_ms = sum(kern_ms.values())
-    dom = max(kern_ms, key=lambda kk: kern_ms[kk])
-    dom_launches, dom_ms = prof[dom]
+    dom_launches, dom_ms = prof_dom[dom]
     dom_bytes_per_launch = alg_bytes_per_step.get(dom, 0.0) * args.steps / max(dom_launches, 1)
     dom_avg_ms = dom_ms / max(dom_launches, 1)
     achieved = dom_bytes_per_launch / (dom_avg_ms * 1e-3) / 1e9 if dom_avg_ms > 0 else 0.0
@@ -302,7 +315,9 @@ def main():
                 "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                 "avg_launch_ms": dom_avg_ms, "launches": dom_launches, "alg_bytes_per_launch": dom_bytes_per_launch,
                 "path_achieved": path_gbs, "path_frac": path_gbs / HBM_PEAK_GBS, "path_alg_bytes_per_step": b_alg,
-                "kernel_ms_per_step": {kk: v / args.steps for kk, v in kern_ms.items()}, "kernels": per_kernel}
+                "kernel_ms_per_step": {kk: v / args.steps for kk, v in kern_ms.items()}, "kernels": per_kernel,
+                "events": "timed region: HIP events around the %s launches only (avg_launch_ms, achieved); kernel_ms_per_step, kernels, path_* and "
+                          "timing.device_kernels_ms: an untimed pass of %d steps with every kernel timed" % (dom, args.steps)}
 
     pair_updates = float(st.pairs()["a"].sum())            # sum over k-mers of s(s-1)/2 = sum over pairs of the shared distinct k-mers
     if "k_pairs" in per_kernel and per_kernel["k_pairs"]["ms_per_step"] > 0:

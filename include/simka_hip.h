@@ -234,7 +234,9 @@ int simka_write_matrix_csv(const char *dir, const char *name, const char *const 
 int64_t simka_pack_read(const char *seq, uint64_t len, uint64_t *packed, uint64_t *nb_bases, uint64_t *offsets_out);
 
 /* ---- profiling ----------------------------------------------------------------------------
- * HIP-event timing of every kernel launched by the ctx, on the ctx's stream. */
+ * HIP-event timing of the kernels launched by the ctx, on the stream they are launched on.  on = 0: off; 1: every kernel;
+ * >= 2: only the kernels i (index of simka_profile_get) whose bit (i + 1) is set -- two event records per launch are not
+ * free, a caller timing a whole job can restrict them to the kernel it reports. */
 int simka_profile_enable(simka_ctx *ctx, int on);
 int simka_profile_reset(simka_ctx *ctx);
 int simka_profile_nb_kernels(simka_ctx *ctx);

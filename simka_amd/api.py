@@ -442,8 +442,19 @@ class SimkaContext:
         return Stats(self.nb_samples, self.dist_flags, flat)
 
     # -- profiling --------------------------------------------------------------------------
-    def profile_enable(self, on=True):
-        self._check(self.lib.simka_profile_enable(self.h, 1 if on else 0))
+    def profile_enable(self, on=True, only=None):
+        """only: kernel names (keys of profile()) to time; default every kernel"""
+        flag = 1 if on else 0
+        if on and only:
+            names = []
+            for w in range(self.lib.simka_profile_nb_kernels(self.h)):
+                name = C.c_char_p(); n = C.c_uint64(); ms = C.c_double()
+                self._check(self.lib.simka_profile_get(self.h, w, C.byref(name), C.byref(n), C.byref(ms)))
+                names.append(name.value.decode())
+            flag = 0
+            for k in only:
+                flag |= 1 << (names.index(k) + 1)
+        self._check(self.lib.simka_profile_enable(self.h, flag))
 
     def profile_reset(self):
         self._check(self.lib.simka_profile_reset(self.h))

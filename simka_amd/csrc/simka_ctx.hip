@@ -86,6 +86,7 @@ struct simka_ctx {
 
     // profiling
     bool profiling = false;
+    uint32_t prof_mask = ~0u;                                 // kernel ids (KID_*) whose launches are timed
     struct Ev { int kid; hipEvent_t a, b; };
     std::vector<Ev> events;
     std::vector<hipEvent_t> event_pool;                       // recycled profiling events
@@ -120,7 +121,7 @@ static inline void launch_timed(simka_ctx *ctx, int kid, F &&f, hipStream_t st =
         fprintf(stderr, "[simka]   -> %s\n", hipGetErrorString(e)); fflush(stderr);
         return;
     }
-    if (ctx->profiling) {
+    if (ctx->profiling && ((ctx->prof_mask >> kid) & 1u)) {
         simka_ctx::Ev ev; ev.kid = kid;
         auto take = [&](hipEvent_t *e) {      // events are recycled: creating two per launch shows up with many small samples
             if (!ctx->event_pool.empty()) { *e = ctx->event_pool.back(); ctx->event_pool.pop_back(); }
@@ -1561,7 +1562,12 @@ SIMKA_EXPORT int simka_stats_download(simka_ctx *ctx, uint64_t *h, uint64_t n, s
 }
 
 // ---- profiling / introspection ------------------------------------------------------------
-SIMKA_EXPORT int simka_profile_enable(simka_ctx *ctx, int on) { if (!ctx) return SIMKA_ERR_INVALID; ctx->profiling = on != 0; return SIMKA_OK; }
+SIMKA_EXPORT int simka_profile_enable(simka_ctx *ctx, int on) {
+    if (!ctx) return SIMKA_ERR_INVALID;
+    ctx->profiling = on != 0;
+    ctx->prof_mask = (on == 0 || on == 1) ? ~0u : ((uint32_t)on >> 1);      // on >= 2: bit (i + 1) selects kernel i of simka_profile_get
+    return SIMKA_OK;
+}
 SIMKA_EXPORT int simka_profile_reset(simka_ctx *ctx) {
     if (!ctx) return SIMKA_ERR_INVALID;
     profile_collect(ctx);
