@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define SIMKA_ABI_VERSION 2
+#define SIMKA_ABI_VERSION 3
 
 enum {
     SIMKA_OK = 0,
@@ -214,6 +214,34 @@ int simka_stats_device_ranges(simka_ctx *ctx, void **head, uint64_t *nb_head, vo
  * library make the totals global across its contexts before simka_merge (synchronise) */
 int simka_totals_download(simka_ctx *ctx, uint64_t *out_5n);
 int simka_totals_upload(simka_ctx *ctx, const uint64_t *in_5n);
+
+/* ---- cross-GPU reduction (RCCL over xGMI) -----------------------------------------------------
+ * The reference combines the per-partition SimkaStatistics of its simkaMerge jobs with operator+= after reading
+ * stats/part_<p>.gz (ref: src/core/SimkaDistance.cpp:156-213, src/SimkaPotara.hpp:1130-1187).  Here every GPU holds the
+ * accumulators of its shard in one flat u64 buffer and ONE ncclAllReduce(sum, uint64) on the context's stream combines
+ * them.  A simka_comm wraps one RCCL communicator: rank 0 calls simka_comm_unique_id, hands the 128 bytes to the other
+ * ranks by any means (MPI, torch.distributed, a file, shared memory between the threads of one process), every rank calls
+ * simka_comm_create.  One communicator per GPU; its calls must come from the thread that owns the context. */
+#define SIMKA_COMM_ID_BYTES 128
+typedef struct simka_comm simka_comm;
+int  simka_comm_unique_id(uint8_t id[SIMKA_COMM_ID_BYTES]);
+int  simka_comm_create(const uint8_t id[SIMKA_COMM_ID_BYTES], int nb_ranks, int rank, int device, simka_comm **out);
+void simka_comm_destroy(simka_comm *comm);
+const char *simka_comm_last_error(const simka_comm *comm);   /* comm==NULL: last simka_comm_create / _unique_id failure */
+int  simka_comm_info(const simka_comm *comm, int *rank, int *nb_ranks);
+/* sum the whole accumulator buffer (pair arrays + per-sample totals) of the context over the ranks, in place, asynchronously
+ * on the context's stream: SimkaStatistics::operator+= across GPUs.  Call after simka_merge. */
+int simka_stats_allreduce(simka_ctx *ctx, simka_comm *comm);
+/* the two-step protocol of SIMKA_DIST_COMPLEX (see simka_stats_device_ranges): totals BEFORE simka_merge, head after it */
+int simka_totals_allreduce(simka_ctx *ctx, simka_comm *comm);
+int simka_stats_allreduce_head(simka_ctx *ctx, simka_comm *comm);
+/* building blocks for callers that exchange solid spectra between GPUs (samples counted on one rank, merged by partition
+ * range on another; the reference's counterpart is every simkaMerge job reading solid/part_<p>/ of every sample,
+ * ref: src/SimkaMerge.cpp:1082-1103): an in-place u64 sum and an all-to-all with uneven splits over device buffers
+ * (grouped ncclSend/ncclRecv: point-to-point transfers, one per xGMI peer).  Counts / displacements in elements. */
+int simka_comm_allreduce_u64(simka_comm *comm, void *d_buf, uint64_t nb_u64, void *stream);
+int simka_comm_alltoallv(simka_comm *comm, const void *d_send, const uint64_t *send_counts, const uint64_t *send_displs, void *d_recv,
+                         const uint64_t *recv_counts, const uint64_t *recv_displs, uint32_t elem_bytes, void *stream);
 
 /* ---- finalisation (host) ------------------------------------------------------------------
  * SimkaDistance: the 21 distance matrices as float32 cells (ref: src/core/SimkaDistance.cpp:920-1226,

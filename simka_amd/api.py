@@ -110,6 +110,16 @@ def load_library(build_if_missing=True):
         "simka_stats_device_ranges": (i32, [vp, C.POINTER(vp), C.POINTER(u64), C.POINTER(vp), C.POINTER(u64)]),
         "simka_totals_download": (i32, [vp, vp]),
         "simka_totals_upload": (i32, [vp, vp]),
+        "simka_comm_unique_id": (i32, [vp]),
+        "simka_comm_create": (i32, [vp, i32, i32, i32, C.POINTER(vp)]),
+        "simka_comm_destroy": (None, [vp]),
+        "simka_comm_last_error": (C.c_char_p, [vp]),
+        "simka_comm_info": (i32, [vp, C.POINTER(i32), C.POINTER(i32)]),
+        "simka_stats_allreduce": (i32, [vp, vp]),
+        "simka_totals_allreduce": (i32, [vp, vp]),
+        "simka_stats_allreduce_head": (i32, [vp, vp]),
+        "simka_comm_allreduce_u64": (i32, [vp, vp, u64, vp]),
+        "simka_comm_alltoallv": (i32, [vp, vp, vp, vp, vp, vp, vp, u32, vp]),
         "simka_nb_matrices": (i32, []),
         "simka_matrix_name": (C.c_char_p, [i32]),
         "simka_matrix_enabled": (i32, [i32, u32]),
@@ -224,6 +234,61 @@ class Stats:
             rc = self.lib.simka_write_matrix_csv(outdir.encode(), name.encode(), ids, len(sample_ids), m.ctypes.data, 1 if gz else 0)
             if rc != SIMKA_OK:
                 raise SimkaError(rc, "simka_write_matrix_csv(%s)" % name)
+
+
+COMM_ID_BYTES = 128
+
+
+class Comm:
+    """One RCCL communicator behind the C ABI (simka_comm_*): rank 0 makes the id (Comm.unique_id()), every rank creates.
+    The cross-GPU reduction of the accumulators is then ctx.allreduce_stats(comm) -- SimkaStatistics::operator+= over xGMI."""
+
+    @staticmethod
+    def unique_id():
+        buf = (C.c_uint8 * COMM_ID_BYTES)()
+        lib = load_library()
+        rc = lib.simka_comm_unique_id(buf)
+        if rc != SIMKA_OK:
+            raise SimkaError(rc, lib.simka_comm_last_error(None).decode())
+        return bytes(buf)
+
+    def __init__(self, unique_id, nb_ranks, rank, device):
+        self.lib = load_library()
+        if len(unique_id) != COMM_ID_BYTES:
+            raise ValueError("unique id must be %d bytes" % COMM_ID_BYTES)
+        buf = (C.c_uint8 * COMM_ID_BYTES).from_buffer_copy(unique_id)
+        h = C.c_void_p()
+        rc = self.lib.simka_comm_create(buf, nb_ranks, rank, device, C.byref(h))
+        if rc != SIMKA_OK:
+            raise SimkaError(rc, self.lib.simka_comm_last_error(None).decode())
+        self.h, self.rank, self.nb_ranks = h, rank, nb_ranks
+
+    def _check(self, rc):
+        if rc != SIMKA_OK:
+            raise SimkaError(rc, self.lib.simka_comm_last_error(self.h).decode())
+
+    def allreduce_u64(self, device_ptr, nb_words, stream=None):
+        self._check(self.lib.simka_comm_allreduce_u64(self.h, device_ptr, nb_words, stream))
+
+    def alltoallv(self, send_ptr, send_counts, recv_ptr, recv_counts, elem_bytes, stream=None):
+        """uneven all-to-all over device buffers; blocks are laid out rank-major on both sides (displacements = prefix sums)"""
+        sc = np.ascontiguousarray(send_counts, dtype=np.uint64)
+        rcn = np.ascontiguousarray(recv_counts, dtype=np.uint64)
+        sd = np.concatenate([[0], np.cumsum(sc)[:-1]]).astype(np.uint64)
+        rd = np.concatenate([[0], np.cumsum(rcn)[:-1]]).astype(np.uint64)
+        self._check(self.lib.simka_comm_alltoallv(self.h, send_ptr, sc.ctypes.data, sd.ctypes.data, recv_ptr, rcn.ctypes.data, rd.ctypes.data,
+                                                  elem_bytes, stream))
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.simka_comm_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 class SimkaContext:
@@ -425,6 +490,12 @@ class SimkaContext:
         hn, tn = C.c_uint64(), C.c_uint64()
         self._check(self.lib.simka_stats_device_ranges(self.h, C.byref(hp), C.byref(hn), C.byref(tp), C.byref(tn)))
         return (hp.value, hn.value), (tp.value, tn.value)
+
+    def allreduce_stats(self, comm, which="all"):
+        """SimkaStatistics::operator+= across GPUs: ONE RCCL all-reduce of the flat u64 accumulators on the context's stream.
+        which: "all" (after merge), "totals" (before merge, -complex-dist), "head" (after merge when the totals are global)."""
+        fn = {"all": self.lib.simka_stats_allreduce, "totals": self.lib.simka_totals_allreduce, "head": self.lib.simka_stats_allreduce_head}[which]
+        self._check(fn(self.h, comm.h))
 
     def totals_download(self):
         out = np.zeros(5 * self.nb_samples, dtype=np.uint64)

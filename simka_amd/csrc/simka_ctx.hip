@@ -2,6 +2,7 @@
 // This is the only translation unit that launches kernels; simka_host.cpp holds the pure-host
 // pieces (finalisation, CSV, packing).
 #include <hip/hip_runtime.h>
+#include <rccl/rccl.h>
 #include <stdarg.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -1071,7 +1072,6 @@ SIMKA_EXPORT int simka_import_samples_device(simka_ctx *ctx, const uint32_t *sam
         if (ctx->counted[samples[j]]) return ctx->fail(SIMKA_ERR_STATE, "simka_import_samples_device: sample %u was already counted", samples[j]);
     }
     if (nb_records && (!d_keys || !d_counts)) return ctx->fail(SIMKA_ERR_INVALID, "simka_import_samples_device: keys / counts are NULL");
-    if (nb_records > 0xffffffffull) return ctx->fail(SIMKA_ERR_INVALID, "simka_import_samples_device: more than 2^32-1 records in one block");
     if (nb_partitions == 0 || (nb_partitions & (nb_partitions - 1))) return ctx->fail(SIMKA_ERR_INVALID, "simka_import_samples_device: nb_partitions must be a power of two");
     if (part_lo + part_width > nb_partitions) return ctx->fail(SIMKA_ERR_INVALID, "simka_import_samples_device: partition range outside [0, nb_partitions)");
     if (nb == 0) return SIMKA_OK;
@@ -1107,15 +1107,23 @@ SIMKA_EXPORT int simka_import_samples_device(simka_ctx *ctx, const uint32_t *sam
         HIPCHK(hipMemcpyAsync(ctx->d_solid_counts + cursor, d_counts, nb_records * 4, hipMemcpyDeviceToDevice, ctx->stream));
     }
     HIPCHK(hipMemcpyAsync(ctx->d_arena_cursor, &next, 8, hipMemcpyHostToDevice, ctx->stream));
-    // every sample of the block shares sample_base = cursor; foff is the run's offset inside the block
+    // sample_base of a sample = its first run in the block; foff (u32) is a run's offset from there, so only the runs of ONE
+    // sample must lie within 2^32 records of each other -- the block itself may be larger (C3 on two ranks: 3.7e9 records)
     bool consecutive = true;
     for (uint32_t j = 1; j < nb; j++) if (samples[j] != samples[0] + j) consecutive = false;
     std::vector<uint32_t> hfo((size_t)nb * std::max<uint64_t>(w, 1));
     const uint32_t *hfc_p = part_counts;
-    for (uint32_t j = 0; j < nb; j++)
-        for (uint64_t p = 0; p < w; p++)
-            hfo[(size_t)j * w + p] = part_counts[(size_t)j * w + p] ? (uint32_t)in_offsets[(size_t)j * w + p] : 0u;
     std::vector<ull> bases(nb, cursor);
+    for (uint32_t j = 0; j < nb; j++) {
+        uint64_t lo = ~0ull, hi = 0;
+        for (uint64_t p = 0; p < w; p++)
+            if (part_counts[(size_t)j * w + p]) { lo = std::min(lo, in_offsets[(size_t)j * w + p]); hi = std::max(hi, in_offsets[(size_t)j * w + p]); }
+        if (lo == ~0ull) lo = 0;
+        if (hi - lo > 0xffffffffull) return ctx->fail(SIMKA_ERR_INVALID, "simka_import_samples_device: the runs of sample %u span more than 2^32 records of the block", samples[j]);
+        bases[j] = cursor + lo;
+        for (uint64_t p = 0; p < w; p++)
+            hfo[(size_t)j * w + p] = part_counts[(size_t)j * w + p] ? (uint32_t)(in_offsets[(size_t)j * w + p] - lo) : 0u;
+    }
     if (consecutive) {
         if (w) {
             HIPCHK(hipMemcpy2DAsync(ctx->d_foff + (uint64_t)samples[0] * P + pmin, P * 4, hfo.data(), w * 4, w * 4, nb, hipMemcpyHostToDevice, ctx->stream));
@@ -1560,6 +1568,110 @@ SIMKA_EXPORT int simka_stats_download(simka_ctx *ctx, uint64_t *h, uint64_t n, s
     if (view) return simka_stats_describe(ctx->cfg.nb_samples, ctx->cfg.dist_flags, h, n, view);
     return SIMKA_OK;
 }
+
+// ---- RCCL: the cross-GPU reduction of SimkaStatistics (operator+=, ref: src/core/SimkaDistance.cpp:156-213) ------------
+// One communicator per GPU (one process per GPU, or one host thread per GPU inside `simka -nb-gpus`).  The accumulators of a
+// context are ONE flat u64 buffer, so the reduction is a single ncclAllReduce(sum, uint64) on the context's stream.
+struct simka_comm {
+    ncclComm_t comm = nullptr;
+    int rank = 0, nb_ranks = 1, device = 0;
+    std::string err;
+};
+static thread_local std::string g_comm_error;
+
+#define NCCLCHK(c, call)                                                                                   \
+    do {                                                                                                   \
+        ncclResult_t r_ = (call);                                                                          \
+        if (r_ != ncclSuccess) { (c)->err = std::string(#call) + " failed: " + ncclGetErrorString(r_); return SIMKA_ERR_HIP; } \
+    } while (0)
+
+SIMKA_EXPORT int simka_comm_unique_id(uint8_t *id) {
+    if (!id) return SIMKA_ERR_INVALID;
+    static_assert(sizeof(ncclUniqueId) == SIMKA_COMM_ID_BYTES, "SIMKA_COMM_ID_BYTES must be sizeof(ncclUniqueId)");
+    ncclUniqueId u;
+    const ncclResult_t r = ncclGetUniqueId(&u);
+    if (r != ncclSuccess) { g_comm_error = std::string("ncclGetUniqueId failed: ") + ncclGetErrorString(r); return SIMKA_ERR_HIP; }
+    memcpy(id, &u, sizeof u);
+    return SIMKA_OK;
+}
+
+SIMKA_EXPORT int simka_comm_create(const uint8_t *id, int nb_ranks, int rank, int device, simka_comm **out) {
+    if (!id || !out || nb_ranks < 1 || rank < 0 || rank >= nb_ranks) { g_comm_error = "simka_comm_create: bad argument"; return SIMKA_ERR_INVALID; }
+    if (hipSetDevice(device) != hipSuccess) { g_comm_error = "simka_comm_create: hipSetDevice failed"; return SIMKA_ERR_HIP; }
+    simka_comm *c = new simka_comm();
+    c->rank = rank; c->nb_ranks = nb_ranks; c->device = device;
+    ncclUniqueId u;
+    memcpy(&u, id, sizeof u);
+    const ncclResult_t r = ncclCommInitRank(&c->comm, nb_ranks, u, rank);
+    if (r != ncclSuccess) { g_comm_error = std::string("ncclCommInitRank failed: ") + ncclGetErrorString(r); delete c; return SIMKA_ERR_HIP; }
+    *out = c;
+    return SIMKA_OK;
+}
+
+SIMKA_EXPORT void simka_comm_destroy(simka_comm *c) {
+    if (!c) return;
+    if (c->comm) (void)ncclCommDestroy(c->comm);
+    delete c;
+}
+
+SIMKA_EXPORT const char *simka_comm_last_error(const simka_comm *c) { return c ? c->err.c_str() : g_comm_error.c_str(); }
+
+SIMKA_EXPORT int simka_comm_info(const simka_comm *c, int *rank, int *nb_ranks) {
+    if (!c) return SIMKA_ERR_INVALID;
+    if (rank) *rank = c->rank;
+    if (nb_ranks) *nb_ranks = c->nb_ranks;
+    return SIMKA_OK;
+}
+
+// in-place sum of n u64 words of device memory over the ranks, on `stream`
+SIMKA_EXPORT int simka_comm_allreduce_u64(simka_comm *c, void *d_buf, uint64_t n, void *stream) {
+    if (!c || (!d_buf && n)) return SIMKA_ERR_INVALID;
+    if (n == 0 || c->nb_ranks == 1) return SIMKA_OK;
+    NCCLCHK(c, ncclAllReduce(d_buf, d_buf, (size_t)n, ncclUint64, ncclSum, c->comm, (hipStream_t)stream));
+    return SIMKA_OK;
+}
+
+// all-to-all with uneven splits (elements of elem_bytes bytes; counts and displacements in elements, one per rank):
+// grouped ncclSend / ncclRecv, i.e. point-to-point transfers over the xGMI links, all in flight at once
+SIMKA_EXPORT int simka_comm_alltoallv(simka_comm *c, const void *d_send, const uint64_t *send_counts, const uint64_t *send_displs, void *d_recv,
+                                      const uint64_t *recv_counts, const uint64_t *recv_displs, uint32_t elem_bytes, void *stream) {
+    if (!c || !send_counts || !send_displs || !recv_counts || !recv_displs || !elem_bytes) return SIMKA_ERR_INVALID;
+    const hipStream_t st = (hipStream_t)stream;
+    const char *sb = (const char *)d_send; char *rb = (char *)d_recv;
+    NCCLCHK(c, ncclGroupStart());
+    for (int p = 0; p < c->nb_ranks; p++) {
+        // the local block moves with a device copy; RCCL handles the others
+        if (p == c->rank) continue;
+        if (send_counts[p]) NCCLCHK(c, ncclSend(sb + send_displs[p] * elem_bytes, (size_t)(send_counts[p] * elem_bytes), ncclUint8, p, c->comm, st));
+        if (recv_counts[p]) NCCLCHK(c, ncclRecv(rb + recv_displs[p] * elem_bytes, (size_t)(recv_counts[p] * elem_bytes), ncclUint8, p, c->comm, st));
+    }
+    NCCLCHK(c, ncclGroupEnd());
+    const int me = c->rank;
+    if (send_counts[me] != recv_counts[me]) { c->err = "simka_comm_alltoallv: local send and receive counts differ"; return SIMKA_ERR_INVALID; }
+    if (send_counts[me]) {
+        const hipError_t e = hipMemcpyAsync(rb + recv_displs[me] * elem_bytes, sb + send_displs[me] * elem_bytes, (size_t)(send_counts[me] * elem_bytes), hipMemcpyDeviceToDevice, st);
+        if (e != hipSuccess) { c->err = std::string("simka_comm_alltoallv: local copy failed: ") + hipGetErrorString(e); return SIMKA_ERR_HIP; }
+    }
+    return SIMKA_OK;
+}
+
+// which: 0 = the whole buffer (head + totals), 1 = head only (the totals are already global), 2 = the totals rows only
+static int stats_allreduce(simka_ctx *ctx, simka_comm *c, int which) {
+    if (!ctx || !c) return SIMKA_ERR_INVALID;
+    { int rcp = resolve_pending(ctx); if (rcp) return rcp; }          // every lane's work must be ordered before the collective
+    HIPCHK(hipSetDevice(ctx->cfg.device));
+    const uint32_t N = ctx->cfg.nb_samples, fl = ctx->cfg.dist_flags;
+    uint64_t *p = ctx->d_stats; uint64_t n = stats_off_derived(N, fl);
+    if (which == 1) n = stats_off_tot(N, fl, 0);
+    if (which == 2) { p = ctx->d_stats + stats_off_tot(N, fl, 0); n = (uint64_t)SIMKA_NB_TOTALS * N; }
+    if (ctx->wide) HIPCHK(hipStreamSynchronize(ctx->stream));
+    const int rc = simka_comm_allreduce_u64(c, p, n, ctx->stream);
+    if (rc) return ctx->fail(rc, "%s", c->err.c_str());
+    return SIMKA_OK;
+}
+SIMKA_EXPORT int simka_stats_allreduce(simka_ctx *ctx, simka_comm *c) { return stats_allreduce(ctx, c, 0); }
+SIMKA_EXPORT int simka_stats_allreduce_head(simka_ctx *ctx, simka_comm *c) { return stats_allreduce(ctx, c, 1); }
+SIMKA_EXPORT int simka_totals_allreduce(simka_ctx *ctx, simka_comm *c) { return stats_allreduce(ctx, c, 2); }
 
 // ---- profiling / introspection ------------------------------------------------------------
 SIMKA_EXPORT int simka_profile_enable(simka_ctx *ctx, int on) {

@@ -55,10 +55,29 @@ def _allreduce_device_words(ptr, n):
     torch.cuda.synchronize()
 
 
-def allreduce_stats_device(ctx, totals_already_reduced=False):
-    """In-place all-reduce of the ctx's DEVICE statistics buffer (no host bounce): the buffer is wrapped as an
-    int64 CUDA tensor through __cuda_array_interface__ and handed to RCCL.  After allreduce_totals_device() only the
-    head (header + pair arrays) is reduced, so the totals are not summed twice."""
+def create_comm(rank, world, device):
+    """The RCCL communicator of the C ABI (simka_comm_*), bootstrapped through torch.distributed: rank 0 makes the unique id,
+    the process group broadcasts its 128 bytes, every rank creates.  A 1-word all-reduce checks it end to end."""
+    from .api import Comm
+    box = [Comm.unique_id() if rank == 0 else None]
+    dist.broadcast_object_list(box, src=0)
+    comm = Comm(box[0], world, rank, device)
+    t = torch.ones(1, dtype=torch.int64, device=torch.device("cuda", device))
+    comm.allreduce_u64(t.data_ptr(), 1, torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    if int(t.item()) != world:
+        raise RuntimeError("simka_comm: the check all-reduce returned %d on a world of %d" % (int(t.item()), world))
+    return comm
+
+
+def allreduce_stats_device(ctx, totals_already_reduced=False, comm=None):
+    """In-place all-reduce of the ctx's DEVICE statistics buffer (no host bounce).  With `comm` (simka_amd.api.Comm) it is the C
+    ABI's simka_stats_allreduce: ncclAllReduce on the context's stream, no synchronisation.  Without it (gloo tests) the
+    buffer is wrapped as an int64 CUDA tensor through __cuda_array_interface__ and handed to torch.distributed.  After
+    allreduce_totals_device() only the head (header + pair arrays) is reduced, so the totals are not summed twice."""
+    if comm is not None:
+        ctx.allreduce_stats(comm, "head" if totals_already_reduced else "all")
+        return
     if not (dist.is_initialized() and dist.get_world_size() > 1):
         return
     ctx.sync()
@@ -70,8 +89,11 @@ def allreduce_stats_device(ctx, totals_already_reduced=False):
         _allreduce_device_words(ptr, n)
 
 
-def allreduce_totals_device(ctx):
+def allreduce_totals_device(ctx, comm=None):
     """-complex-dist, sharded: make the per-sample totals global BEFORE simka_merge."""
+    if comm is not None:
+        ctx.allreduce_stats(comm, "totals")
+        return
     if not (dist.is_initialized() and dist.get_world_size() > 1):
         return
     ctx.sync()
@@ -183,7 +205,7 @@ def _excl_cumsum_rows(m):
     return c - m.astype(np.int64)
 
 
-def count_exchange_merge(ctx, count_fn, nb_samples, device):
+def count_exchange_merge(ctx, count_fn, nb_samples, device, comm=None):
     """One sample-sharded job on this rank: count my samples (count_fn(sample)), exchange, import every sample's slice of my
     partition range, merge, all-reduce the pair accumulators.  `ctx` is created with shard_count=1.  Single process: plain path.
     Batch ABI: one gather into a destination-major send buffer, three collectives (counts, keys, counts of k-mers) + the
@@ -248,16 +270,29 @@ def count_exchange_merge(ctx, count_fn, nb_samples, device):
     dist.all_gather(tot_list, tot_t)
     meta_recv = meta_r.cpu().numpy()                     # [source rank][its sample j][my partitions]
     recv_splits = recv_splits_of(meta_recv)
-    kr = torch.empty(sum(recv_splits), dtype=torch.int64, device=cdev)
-    cr = torch.empty(sum(recv_splits), dtype=torch.int32, device=cdev)
-    dist.all_to_all_single(kr, ks.to(cdev), recv_splits, send_splits)
-    dist.all_to_all_single(cr, cs.to(cdev), recv_splits, send_splits)
     kr2 = None
-    if kw == 2:
-        kr2 = torch.empty(sum(recv_splits), dtype=torch.int64, device=cdev)
-        dist.all_to_all_single(kr2, ks2.to(cdev), recv_splits, send_splits)
-        kr2 = kr2.to(device)
-    kr, cr = kr.to(device), cr.to(device)
+    if comm is not None:
+        # the data path on RCCL through the C ABI: grouped ncclSend / ncclRecv between device buffers, on torch's current stream
+        stream = torch.cuda.current_stream().cuda_stream
+        kr = torch.empty(sum(recv_splits), dtype=torch.int64, device=device)
+        cr = torch.empty(sum(recv_splits), dtype=torch.int32, device=device)
+        ctx.sync()                                            # the gather ran on the context's stream
+        comm.alltoallv(ks.data_ptr(), send_splits, kr.data_ptr(), recv_splits, 8, stream)
+        comm.alltoallv(cs.data_ptr(), send_splits, cr.data_ptr(), recv_splits, 4, stream)
+        if kw == 2:
+            kr2 = torch.empty(sum(recv_splits), dtype=torch.int64, device=device)
+            comm.alltoallv(ks2.data_ptr(), send_splits, kr2.data_ptr(), recv_splits, 8, stream)
+        torch.cuda.synchronize()
+    else:
+        kr = torch.empty(sum(recv_splits), dtype=torch.int64, device=cdev)
+        cr = torch.empty(sum(recv_splits), dtype=torch.int32, device=cdev)
+        dist.all_to_all_single(kr, ks.to(cdev), recv_splits, send_splits)
+        dist.all_to_all_single(cr, cs.to(cdev), recv_splits, send_splits)
+        if kw == 2:
+            kr2 = torch.empty(sum(recv_splits), dtype=torch.int64, device=cdev)
+            dist.all_to_all_single(kr2, ks2.to(cdev), recv_splits, send_splits)
+            kr2 = kr2.to(device)
+        kr, cr = kr.to(device), cr.to(device)
     ks = ks2 = cs = None
     # ---- receive side: block layout [r][j][my partitions]; samples in ascending order for the import
     lo, hi = bounds[rank], bounds[rank + 1]
@@ -287,8 +322,8 @@ def count_exchange_merge(ctx, count_fn, nb_samples, device):
         s_off = off_in[:, 0].astype(np.int64) if w else np.zeros(nb_samples, dtype=np.int64)
         ctx.import_samples_device_wide(np.arange(nb_samples), tot_in, s_off, s_rec, kr, kr2, cr)
         ctx.merge()
-        allreduce_stats_device(ctx, totals_already_reduced=True)
+        allreduce_stats_device(ctx, totals_already_reduced=True, comm=comm)
         return
     ctx.import_samples_device(np.arange(nb_samples), tot_in, lo, pc_in[:, :max(w, 0)] if w else pc_in[:, :0], off_in[:, :w] if w else off_in[:, :0], P, kr, cr)
     ctx.merge()
-    allreduce_stats_device(ctx, totals_already_reduced=True)      # imported totals are already global on every rank
+    allreduce_stats_device(ctx, totals_already_reduced=True, comm=comm)      # imported totals are already global on every rank
