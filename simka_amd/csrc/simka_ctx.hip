@@ -13,21 +13,25 @@
 
 #include "../../include/simka_hip.h"
 #include "simka_kernels.hip"
+#include "simka_skm.hip"
 #include "simka_wide.h"
 
 #define SIMKA_EXPORT extern "C" __attribute__((visibility("default")))
 
 // kernel ids for the profiler
 enum { KID_SCAN_HIST = 0, KID_LAYOUT, KID_SCAN_SCATTER, KID_SPLIT, KID_COUNT_FAST, KID_COUNT, KID_PART_TOTALS, KID_REGROUP, KID_GROUP,
-       KID_PAIRS, KID_PAIRS_GLOBAL, KID_NB };
+       KID_PAIRS, KID_PAIRS_GLOBAL, KID_SKM_SCAN, KID_SKM_HIST2, KID_SKM_SCATTER2, KID_SKM_SPLIT3, KID_SKM_COUNT, KID_NB };
 static const char *const KID_NAMES[KID_NB] = { "k_scan<hist>", "k_layout", "k_scan<scatter>", "k_split", "k_count_fast", "k_count",
-                                               "k_part_totals", "k_regroup", "k_group", "k_pairs", "k_pairs_global" };
+                                               "k_part_totals", "k_regroup", "k_group", "k_pairs", "k_pairs_global",
+                                               "k_skm_scan", "k_skm_hist2", "k_skm_scatter2", "k_skm_split3", "k_skm_count" };
 
 static thread_local std::string g_create_error;
 
 struct simka_ctx {
     simka_config cfg;
     SimkaKeyCfg key;
+    SimkaSkmCfg skm;                 // super-k-mer pipeline (the count side for k <= 31)
+    bool use_skm = true;
     hipStream_t stream = nullptr;
     bool own_stream = false;
     int num_cus = 256;
@@ -49,6 +53,9 @@ struct simka_ctx {
         ull *d_spill_keys = nullptr; uint64_t spill_cap = 0; SimkaSpillRun *d_spill_runs = nullptr; uint64_t spill_run_cap = 0;
         ull *d_spill_cursor = nullptr;
         uint32_t *d_redo_list = nullptr; ull *d_redo_count = nullptr;   // partitions k_count_fast hands to k_count
+        // super-k-mer pipeline: two record buffers (level 1 / level 3 share one), level-2 counters, partition table
+        uint4 *d_skm_a = nullptr, *d_skm_b = nullptr; uint64_t skm_a_cap = 0, skm_b_cap = 0;
+        uint32_t *d_cnt2 = nullptr, *d_start2 = nullptr, *d_cursor2 = nullptr, *d_pstart = nullptr, *d_pcnt = nullptr;
     };
     Lane lanes[2];
     uint32_t nlanes = 2;
@@ -235,6 +242,15 @@ static ScanFn scan_kernel(bool scatter, bool fixed, bool sharded) {
     return t[(scatter ? 4 : 0) | (fixed ? 2 : 0) | (sharded ? 1 : 0)];
 }
 
+using SkmScanFn = void (*)(SimkaScanArgs, SimkaSkmCfg, ull *, ull *, uint4 *, const ull *, uint32_t *);
+static int skm_w_index(uint32_t W) { switch (W) { case 1: return 0; case 4: return 1; case 8: return 2; case 12: return 3; case 16: return 4; default: return 5; } }
+static SkmScanFn skm_scan_kernel(int wi, bool fixed, bool hist) {
+#define SKM_ROW(W) { k_skm_scan<W, false, false>, k_skm_scan<W, false, true>, k_skm_scan<W, true, false>, k_skm_scan<W, true, true> }
+    static const SkmScanFn t[6][4] = { SKM_ROW(1), SKM_ROW(4), SKM_ROW(8), SKM_ROW(12), SKM_ROW(16), SKM_ROW(20) };
+#undef SKM_ROW
+    return t[wi][(fixed ? 2 : 0) | (hist ? 1 : 0)];
+}
+
 static int set_lds_attr(simka_ctx *ctx) {
     const int big = 160 * 1024;
     for (int v = 0; v < 8; v++) HIPCHK(hipFuncSetAttribute((const void *)scan_kernel(v & 4, v & 2, v & 1), hipFuncAttributeMaxDynamicSharedMemorySize, big));
@@ -251,6 +267,8 @@ static int set_lds_attr(simka_ctx *ctx) {
     HIPCHK(hipFuncSetAttribute((const void *)k_pairs<false, K4_BLOCK_SMALL>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
     HIPCHK(hipFuncSetAttribute((const void *)k_pairs<true, K4_BLOCK_BIG>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
     HIPCHK(hipFuncSetAttribute((const void *)k_pairs_tm, hipFuncAttributeMaxDynamicSharedMemorySize, big));
+    for (int wi = 0; wi < 6; wi++) for (int v = 0; v < 4; v++) HIPCHK(hipFuncSetAttribute((const void *)skm_scan_kernel(wi, v & 2, v & 1), hipFuncAttributeMaxDynamicSharedMemorySize, big));
+    HIPCHK(hipFuncSetAttribute((const void *)k_skm_count, hipFuncAttributeMaxDynamicSharedMemorySize, big));
     return SIMKA_OK;
 }
 
@@ -288,6 +306,15 @@ static int setup_geometry(simka_ctx *ctx, uint64_t max_kmers) {
     if (l2 > 11) { l2 = 11; }
     k.l1 = l1; k.l2 = l2; k.pb = l1 + l2; k.t = 0;
     ctx->B1 = 1u << l1; ctx->B2 = 1u << l2; ctx->nparts = (uint64_t)1 << k.pb;
+    {   // super-k-mer pipeline: the same partition count over three levels (64 x <= 512 x 32)
+        SimkaSkmCfg &sk = ctx->skm;
+        sk.pb = k.pb;
+        sk.l1 = std::min<uint32_t>(sk.pb, 6);
+        sk.l3 = std::min<uint32_t>(sk.pb - sk.l1, 5);
+        sk.l2 = sk.pb - sk.l1 - sk.l3;
+        if (sk.l2 > 9) return ctx->fail(SIMKA_ERR_INVALID, "log2_partitions %u is beyond the three partitioning levels", sk.pb);
+        ctx->B1 = ctx->use_skm ? (1u << sk.l1) : ctx->B1;
+    }
 
     const uint32_t N = c.nb_samples;
     // SIMKA_LANES=2 alternates samples between two streams with private scratch (+4 % end to end on C2/C3: the kernels
@@ -307,6 +334,11 @@ static int setup_geometry(simka_ctx *ctx, uint64_t max_kmers) {
         HIPCHK(dev_alloc(&L.d_spill_cursor, 2));
         HIPCHK(dev_alloc(&L.d_redo_list, ctx->nparts + 1));
         HIPCHK(dev_alloc(&L.d_redo_count, 2));
+        if (ctx->use_skm) {
+            const uint64_t nsb = (uint64_t)1 << (ctx->skm.l1 + ctx->skm.l2);
+            HIPCHK(dev_alloc(&L.d_cnt2, nsb + 1)); HIPCHK(dev_alloc(&L.d_start2, nsb + 2)); HIPCHK(dev_alloc(&L.d_cursor2, nsb + 1));
+            HIPCHK(dev_alloc(&L.d_pstart, ctx->nparts + 1)); HIPCHK(dev_alloc(&L.d_pcnt, ctx->nparts + 1));
+        }
     }
     HIPCHK(dev_alloc(&ctx->d_l1_ovf, c.nb_samples + 1));
     HIPCHK(hipMemsetAsync(ctx->d_l1_ovf, 0, (size_t)(c.nb_samples + 1) * 4, ctx->stream));
@@ -363,6 +395,21 @@ SIMKA_EXPORT int simka_create(const simka_config *cfg, simka_ctx **out) {
     memset(&k, 0, sizeof k);
     k.k = cfg->kmer_size; k.W = 2 * cfg->kmer_size; k.mask = k.W >= 64 ? ~0ull : (1ull << k.W) - 1ull; k.xs = (k.W + 1) / 2;      // (hash path: W <= 62)
     k.shard_index = cfg->shard_index; k.shard_count = cfg->shard_count;
+    if (!want_wide) {
+        // minimizer geometry: W m-mers per k-mer from {20,16,12,8,4}, the largest that leaves m = k - W + 1 >= 10 (k <= 12: every
+        // k-mer is its own minimizer); a record holds n + k - 1 <= 51 bases
+        SimkaSkmCfg &sk = ctx->skm;
+        memset(&sk, 0, sizeof sk);
+        sk.k = cfg->kmer_size;
+        sk.W = 1;
+        for (uint32_t w : { 20u, 16u, 12u, 8u, 4u }) if (sk.k >= w + 9u) { sk.W = w; break; }
+        sk.m = sk.k - sk.W + 1;
+        sk.nmax = std::min<uint32_t>(32u, 52u - sk.k);
+        sk.mmask = (uint32_t)((1ull << (2 * sk.m)) - 1ull);
+        sk.kmask = k.mask;
+        sk.shard_index = cfg->shard_index; sk.shard_count = cfg->shard_count;
+        ctx->use_skm = getenv("SIMKA_OLD_COUNT") == nullptr;
+    } else ctx->use_skm = false;
 
     int rc = set_lds_attr(ctx);
     if (rc) return bail(rc);
@@ -402,7 +449,8 @@ SIMKA_EXPORT void simka_destroy(simka_ctx *ctx) {
     for (auto &L : ctx->lanes) {
         if (L.stream) (void)hipStreamSynchronize(L.stream);
         void *lp[] = { L.d_l1, L.d_b1_count, L.d_b1_start, L.d_b1_end, L.d_b1_cursor, L.d_chunk_first, L.d_tile_r0, L.d_l2, L.d_p_count, L.d_p_valid,
-                       L.d_spill_keys, L.d_spill_runs, L.d_spill_cursor, L.d_redo_list, L.d_redo_count };
+                       L.d_spill_keys, L.d_spill_runs, L.d_spill_cursor, L.d_redo_list, L.d_redo_count,
+                       L.d_skm_a, L.d_skm_b, L.d_cnt2, L.d_start2, L.d_cursor2, L.d_pstart, L.d_pcnt };
         for (void *q : lp) if (q) (void)hipFree(q);
         if (L.stream) (void)hipStreamDestroy(L.stream);
     }
@@ -477,7 +525,9 @@ static int ensure_cap(simka_ctx *ctx, T **p, uint64_t *cap, uint64_t need) {
 
 // enqueue the count-side kernels of one sample.  exact=false: capacity-sized level-1 buckets, no histogram pass; the
 // kernels after the scatter skip themselves if it flags an overflow, and resolve_pending() redoes the sample exactly.
+static int run_count_skm(simka_ctx *ctx, uint32_t sample, const SimkaScanArgs &a_in, bool exact, uint32_t pass, uint32_t npass);
 static int run_count_kernels(simka_ctx *ctx, uint32_t sample, const SimkaScanArgs &a_in, bool exact, uint32_t pass = 0, uint32_t npass = 1) {
+    if (ctx->use_skm) return run_count_skm(ctx, sample, a_in, exact, pass, npass);
     const uint32_t N = ctx->cfg.nb_samples;
     simka_ctx::Lane &L = ctx->lanes[sample % ctx->nlanes];
     const hipStream_t st = L.stream;
@@ -635,6 +685,112 @@ static int run_count_kernels(simka_ctx *ctx, uint32_t sample, const SimkaScanArg
                            ctx->cfg.abundance_min, ctx->cfg.abundance_max, o, flag,
                            slow_only ? (const uint32_t *)nullptr : (const uint32_t *)L.d_redo_list,
                            slow_only ? (const ull *)nullptr : (const ull *)L.d_redo_count);
+    }, st);
+    HIPCHK(hipGetLastError());
+    return SIMKA_OK;
+}
+
+// ---- super-k-mer pipeline: enqueue the count-side kernels of one sample (see simka_skm.hip) ----------------------------------
+// exact=false: capacity-sized level-1 buckets; if one overflows the later kernels skip themselves and resolve_pending() redoes
+// the sample with exact=true (a histogram-only scan first).
+static int run_count_skm(simka_ctx *ctx, uint32_t sample, const SimkaScanArgs &a_in, bool exact, uint32_t pass, uint32_t npass) {
+    const uint32_t N = ctx->cfg.nb_samples;
+    simka_ctx::Lane &L = ctx->lanes[sample % ctx->nlanes];
+    const hipStream_t st = L.stream;
+    int rc;
+    SimkaScanArgs a = a_in;
+    a.tile_r0 = nullptr;
+    SimkaSkmCfg sk = ctx->skm;
+    if (npass > 1) { sk.shard_index = ctx->skm.shard_index + ctx->skm.shard_count * pass; sk.shard_count = ctx->skm.shard_count * npass; }
+    const uint32_t B1 = 1u << sk.l1;
+    const uint32_t nsb = 1u << (sk.l1 + sk.l2);
+    const uint32_t ntiles = (uint32_t)((a.nb_bases + SKM_STRIDE - 1) / SKM_STRIDE);
+    if (!a.fixed_len && a.nb_reads && ntiles) {
+        rc = ensure_cap(ctx, &L.d_tile_r0, &L.tile_r0_cap, (uint64_t)ntiles + 2); if (rc) return rc;
+        hipLaunchKernelGGL(k_tile_reads, dim3((ntiles + 1 + 255) / 256), dim3(256), 0, st, a.offsets, a.nb_reads, a.nb_bases, ntiles, (uint64_t)SKM_STRIDE, L.d_tile_r0);
+        a.tile_r0 = L.d_tile_r0;
+    }
+    uint32_t *flag = ctx->d_l1_ovf + sample;
+    static const bool force_exact = getenv("SIMKA_EXACT_SIZING") != nullptr;
+    if (force_exact) exact = true;
+    const uint64_t kocc_up = a.fixed_len ? (a.fixed_len >= sk.k ? a.nb_reads * (uint64_t)(a.fixed_len - sk.k + 1) : 0) : a.nb_bases;
+    // records staged per tile: what a tile yields at the expected run length (W + 1) / 2, + 35 %
+    const uint32_t caprec = (uint32_t)std::min<uint64_t>(4096, std::max<uint64_t>(1280, (uint64_t)(SKM_STRIDE / ((sk.W + 1) / 2.0) * 1.35) / 128 * 128 + 128));
+    const int wi = skm_w_index(sk.W);
+    const bool fixed = a.fixed_len != 0;
+    auto scan_lds = [&](bool hist) {
+        return (size_t)SIMKA_LDS_HEAD + (SKM_TILE + 32) * 4 + (SKM_TILE / 16 + 8) * 4 + (SKM_BLOCK + 4) * 4 + 64 * 4 * 2 + 64 * 8 + (fixed ? 0 : SKM_RTAB * 4) + (hist ? 0 : (size_t)caprec * 16);
+    };
+    auto layout = [&](uint32_t mode, ull capb) {
+        launch_timed(ctx, KID_LAYOUT, [&] {
+            hipLaunchKernelGGL(k_skm_layout, dim3(1), dim3(256), 0, st, L.d_b1_count, L.d_b1_start, L.d_b1_end, L.d_b1_cursor, L.d_chunk_first, B1, mode, capb,
+                               ctx->d_arena_cursor, ctx->d_sample_base + sample, pass == 0 ? 1u : 0u, (const uint32_t *)flag, L.d_cnt2, nsb);
+        }, st);
+    };
+    auto scan = [&](bool hist, const ull *limit) {
+        launch_timed(ctx, hist ? KID_SCAN_HIST : KID_SKM_SCAN, [&] {
+            SimkaSkmCfg skc = sk;
+            skc.nmax = sk.nmax; skc.pb = sk.pb;
+            hipLaunchKernelGGL(skm_scan_kernel(wi, fixed, hist), dim3(ntiles), dim3(SKM_BLOCK), scan_lds(hist), st, a, skc, L.d_b1_count, L.d_b1_cursor, L.d_skm_a, limit,
+                               hist ? (uint32_t *)nullptr : flag);
+        }, st);
+    };
+    uint64_t rec_cap;
+    if (!exact) {
+        // expected records: one per (W + 1) / 2 k-mers; a bucket gets its share + 12 % + slack.  An overflow flags the sample.
+        const uint64_t est = (uint64_t)((double)kocc_up / std::max(1.0, (sk.W + 1) / 2.0) * 1.30 / sk.shard_count);
+        const uint64_t capb = est / B1 + est / B1 / 8 + 4096;
+        rec_cap = capb * B1;
+        rc = ensure_cap(ctx, &L.d_skm_a, &L.skm_a_cap, rec_cap); if (rc) return rc;
+        rc = ensure_cap(ctx, &L.d_skm_b, &L.skm_b_cap, rec_cap); if (rc) return rc;
+        layout(1, capb);
+        scan(false, (const ull *)L.d_b1_end);
+        layout(2, capb);
+        simka_ctx::Pending p; p.sample = sample; p.a = a_in; p.pass = pass; p.npass = npass;
+        ctx->pending.push_back(p);
+    } else {
+        HIPCHK(hipMemsetAsync(L.d_b1_count, 0, (size_t)(B1 + 1) * 8, st));
+        scan(true, nullptr);
+        std::vector<ull> cnt(B1);
+        HIPCHK(hipMemcpyAsync(cnt.data(), L.d_b1_count, (size_t)B1 * 8, hipMemcpyDeviceToHost, st));
+        HIPCHK(hipStreamSynchronize(st));
+        rec_cap = 16;
+        for (ull c : cnt) rec_cap += c;
+        if (rec_cap >= 0xffffffffull) return ctx->fail(SIMKA_ERR_OVERFLOW, "a sample yields more than 2^32 super-k-mer records in one pass");
+        rc = ensure_cap(ctx, &L.d_skm_a, &L.skm_a_cap, rec_cap); if (rc) return rc;
+        rc = ensure_cap(ctx, &L.d_skm_b, &L.skm_b_cap, rec_cap); if (rc) return rc;
+        layout(0, 0);
+        scan(false, (const ull *)L.d_b1_end);
+    }
+    if (rec_cap >= 0xffffffffull) return ctx->fail(SIMKA_ERR_OVERFLOW, "a sample needs more than 2^32 super-k-mer record slots in one pass");
+    const uint32_t grid2 = (uint32_t)ctx->num_cus * 4;
+    launch_timed(ctx, KID_SKM_HIST2, [&] {
+        hipLaunchKernelGGL(k_skm_hist2, dim3(grid2), dim3(SKM_L2_BLOCK), 0, st, (const uint4 *)L.d_skm_a, (const ull *)L.d_b1_start, (const ull *)L.d_b1_count,
+                           (const uint32_t *)L.d_chunk_first, sk, L.d_cnt2, (const uint32_t *)flag);
+        hipLaunchKernelGGL(k_skm_scan_counts, dim3(1), dim3(1024), 0, st, (const uint32_t *)L.d_cnt2, nsb, L.d_start2, L.d_cursor2, (const uint32_t *)flag);
+    }, st);
+    launch_timed(ctx, KID_SKM_SCATTER2, [&] {
+        hipLaunchKernelGGL(k_skm_scatter2, dim3(grid2), dim3(SKM_L2_BLOCK), 0, st, (const uint4 *)L.d_skm_a, (const ull *)L.d_b1_start, (const ull *)L.d_b1_count,
+                           (const uint32_t *)L.d_chunk_first, sk, L.d_cursor2, L.d_skm_b, (const uint32_t *)flag);
+    }, st);
+    launch_timed(ctx, KID_SKM_SPLIT3, [&] {
+        hipLaunchKernelGGL(k_skm_split3, dim3(std::min<uint32_t>(nsb, grid2)), dim3(SKM_L2_BLOCK), 0, st, (const uint4 *)L.d_skm_b, (const uint32_t *)L.d_start2, sk,
+                           L.d_skm_a, L.d_pstart, L.d_pcnt, (const uint32_t *)flag);
+    }, st);
+    SimkaCountOut o;
+    o.arena_cursor = ctx->d_arena_cursor; o.sample_base = ctx->d_sample_base + sample; o.arena_cap = ctx->arena_cap;
+    o.solid_keys = ctx->d_solid_keys; o.solid_counts = ctx->d_solid_counts;
+    o.foff = ctx->d_foff + (uint64_t)sample * ctx->nparts; o.fcnt = ctx->d_fcnt + (uint64_t)sample * ctx->nparts;
+    o.totals = (ull *)ctx->d_stats + stats_off_tot(N, ctx->cfg.dist_flags, 0); o.sample = sample; o.nb_samples = N; o.err = ctx->d_err;
+    o.phase = nullptr;
+    o.hist = ctx->d_hist; o.ovf_list = ctx->d_ovf_list; o.ovf_cursor = ctx->d_ovf_cursor; o.ovf_cap = ctx->ovf_cap;
+    ull *kocc = (ull *)ctx->d_stats + stats_off_tot(N, ctx->cfg.dist_flags, SIMKA_TOT_KOCC) + sample;
+    const size_t lds_count = (size_t)SIMKA_LDS_HEAD + (size_t)SKM_CNT_TS * 12 + (size_t)SKM_CNT_BATCH * 16 + (size_t)SKM_CNT_BLOCK * 4 + (ctx->d_hist ? (size_t)SIMKA_HIST_MAX * 4 : 0) +
+                             (size_t)SKM_CNT_BATCH * sk.nmax * 2 + 64;
+    launch_timed(ctx, KID_SKM_COUNT, [&] {
+        const uint32_t bpc = (uint32_t)std::max<size_t>(1, std::min<size_t>(3, (160 * 1024) / lds_count));
+        hipLaunchKernelGGL(k_skm_count, dim3((uint32_t)std::min<uint64_t>(ctx->nparts, (uint64_t)ctx->num_cus * bpc)), dim3(SKM_CNT_BLOCK), lds_count, st, (const uint4 *)L.d_skm_a,
+                           (const uint32_t *)L.d_pstart, (const uint32_t *)L.d_pcnt, sk, ctx->key, ctx->cfg.abundance_min, ctx->cfg.abundance_max, o, (const uint32_t *)flag, kocc);
     }, st);
     HIPCHK(hipGetLastError());
     return SIMKA_OK;

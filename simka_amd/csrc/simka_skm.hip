@@ -1,0 +1,672 @@
+// simka_skm.hip -- count side of the hot path as a SUPER-K-MER pipeline (gfx950, wave64).
+//
+// The reference's simkaCount runs gatb's SortingCountAlgorithm: reads are cut into super-k-mers (maximal runs of
+// consecutive k-mers that share their minimizer), the super-k-mers are written to one file per minimizer partition, every
+// partition is then counted on its own (ref: src/SimkaCount.cpp:291-297; minimizer size 7 forced at src/core/Simka.cpp:111;
+// the partition of a k-mer is a function of its minimizer, ref: src/minikc/MiniKC.hpp:237-253).  This file is the same
+// flow on the GPU, with HBM where the reference has its temp disk:
+//
+//   packed reads --k_skm_scan----> 16-byte super-k-mer records in level-1 buckets (by the top bits of the partition id)
+//                --k_skm_hist2 / k_skm_scatter2--> level-2 buckets, exactly sized (two passes over the small records)
+//                --k_skm_split3--> every partition contiguous, exact (start,count) table
+//                --k_skm_count---> per partition: records -> k-mers -> canonical -> LDS hash table -> abundance filter ->
+//                                  solid (k-mer,count) records in the HBM arena + D/N/Q totals (MiniKC.hpp:54-79)
+//
+// A k-mer occurrence costs ~1.6 bytes per level instead of 8, and the per-k-mer work of the partitioning levels (rank atomics,
+// staging) becomes per-record work (one record per ~10 k-mers).  Results do not depend on the minimizer scheme:
+// the order on m-mers, m itself and the minimizer -> partition map are free choices; ours:
+//   * m-mer order: a bijective multiply / xor-shift / multiply hash of the CANONICAL m-mer (min of the m-mer and its reverse
+//     complement), so a k-mer and its reverse complement agree on the minimizer VALUE, hence on the partition;
+//   * a record = maximal run of consecutive valid k-mers of a read with the same minimizer value, cut at SKM_NMAX k-mers;
+//   * partition id = top bits of a multiplicative hash of the minimizer value.
+//
+// Record (uint4, 128 bits):  bits [0,102) the run's bases, 2 bits each (n + k - 1 <= 51 bases)
+//                            bits [102,107) n - 1        bits [107,128) partition id (<= 21 bits)
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "simka_device.h"
+#include "simka_kernels.h"
+
+#ifndef SIMKA_SKM_HIP
+#define SIMKA_SKM_HIP
+
+typedef unsigned long long ull;
+
+#define SKM_TILE 8192            // m-mer positions hashed per block (entry i <-> base position Q0 + i)
+#define SKM_OWN_LO 32            // a tile emits the k-mers starting at entries [32, 8160): 254 words of 32 bases
+#define SKM_OWN_HI (SKM_TILE - 32)
+#define SKM_STRIDE (SKM_OWN_HI - SKM_OWN_LO)
+#define SKM_BLOCK 512
+#define SKM_SEG 16               // entries per thread
+#define SKM_CAPREC 2048          // records staged in LDS per tile (more: written one by one)
+#define SKM_MAXW 20
+#define SKM_RTAB 2048            // variable-length reads: read starts of one tile staged in LDS
+#define SKM_CHUNK 2048           // records per chunk of the level-2 kernels
+#define SKM_L2_BLOCK 512
+#define SKM_CNT_BLOCK 512
+#define SKM_CNT_TS 4096          // slots of the count kernel's LDS table
+#define SKM_CNT_BATCH 256        // records expanded per batch
+#define SKM_SORT_BITS 5          // solid records leave the count kernel ordered by the top 5 bits of the slot hash
+#define SKM_NSORT (1 << SKM_SORT_BITS)
+
+struct SimkaSkmCfg {
+    uint32_t k, W, m, nmax;          // k-mer size, m-mers per k-mer (k - m + 1), minimizer size, k-mers per record at most
+    uint32_t mmask;                  // 2^(2m) - 1
+    uint32_t pb, l1, l2, l3;         // log2 #partitions = l1 + l2 + l3
+    uint32_t shard_index, shard_count;   // this context keeps the partitions p with p % shard_count == shard_index
+    uint64_t kmask;                  // 2^(2k) - 1
+};
+
+SIMKA_HD uint32_t skm_mm_hash(uint32_t c, uint32_t mmask, uint32_t m) {
+    uint32_t h = (c * 0x9E3779B1u) & mmask;
+    h ^= h >> m;
+    return (h * 0x85EBCA6Bu) & mmask;
+}
+SIMKA_HD uint32_t skm_pid(uint32_t minhash, uint32_t pb) { return pb ? (uint32_t)((minhash * 0xC2B2AE35u) >> (32u - pb)) : 0u; }
+SIMKA_HD bool skm_owns(uint32_t pid, const SimkaSkmCfg &c) { return c.shard_count == 1u || (pid % c.shard_count) == c.shard_index; }
+SIMKA_HD uint32_t skm_rec_n(const uint4 &r) { return ((r.w >> 6) & 31u) + 1u; }
+SIMKA_HD uint32_t skm_rec_pid(const uint4 &r) { return r.w >> 11; }
+// 32-bit hash of a canonical k-mer: slot and sort order of the count kernel's table
+SIMKA_HD uint32_t skm_kmer_hash(uint64_t canon) { return (uint32_t)canon * 0x9E3779B1u + (uint32_t)(canon >> 32) * 0x85EBCA6Bu; }
+
+// reverse complement of the 32 bases of a word (code ^ 2 = complement)
+__device__ __forceinline__ uint64_t skm_revcomp64(uint64_t x) {
+    const uint64_t M5 = 0x5555555555555555ull;
+    uint64_t r = __brevll(x);
+    return (((r >> 1) & M5) | ((r & M5) << 1)) ^ 0xAAAAAAAAAAAAAAAAull;
+}
+
+// --------------------------------------------------------------------------------------------
+// k_skm_scan: reads -> super-k-mer records.
+//   phase 1: every thread hashes the canonical m-mers at its 16 entries -> LDS
+//   phase 2: sliding-window minimum over W entries (van Herk / Gil-Werman on the thread's 40 loaded values) -> the minimizer
+//            value of the k-mers at its 16 entries (+ the one before)
+//   phase 3: run starts / breaks as bit masks -> LDS; run length = distance to the next break (own mask + two neighbours);
+//            one record per <= nmax k-mers, bases cut out of the LDS-staged tile; per-bucket LDS histogram
+//   phase 4: one global atomic per bucket reserves the tile's run, records are stored at reserved base + LDS rank
+// HIST: only count the records per level-1 bucket (the exact-sizing fallback when a capacity-sized bucket overflowed).
+// --------------------------------------------------------------------------------------------
+template <int W, bool FIXED, bool HIST>
+__global__ void __launch_bounds__(SKM_BLOCK)
+k_skm_scan(SimkaScanArgs a, SimkaSkmCfg cfg, ull *b1_count, ull *b1_cursor, uint4 *l1_recs, const ull *b1_limit, uint32_t *ovf_flag) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    uint32_t &s_nrec = *(uint32_t *)(smem + 0);
+    uint32_t *hm = (uint32_t *)(smem + SIMKA_LDS_HEAD);             // [TILE + 32] m-mer hashes; after phase 2: partition ids of the k-mers
+    uint32_t *tb = hm + SKM_TILE + 32;                              // [TILE/16 + 8] the tile's bases, 16 per word
+    uint32_t *smask = tb + SKM_TILE / 16 + 8;                       // [BLOCK] start | brk << 16
+    uint32_t *hist = smask + SKM_BLOCK + 4;                         // [B1]   (smask has 4 pad words: all-break)
+    uint32_t *lcur = hist + 64;                                     // [B1]
+    ull *gbase = (ull *)(lcur + 64);                                // [B1]
+    uint32_t *rtab = (uint32_t *)(gbase + 64);                      // [SKM_RTAB] (!FIXED)
+    uint4 *stage = (uint4 *)(rtab + (FIXED ? 0 : SKM_RTAB));        // [CAPREC] (!HIST)
+
+    const uint32_t tid = threadIdx.x;
+    const uint32_t B1 = 1u << cfg.l1;
+    const long long Q0 = 32ll * ((long long)SKM_STRIDE / 32 * (long long)blockIdx.x - 1);     // base position of entry 0
+    if (tid == 0) s_nrec = 0;
+    if (tid < 64) { hist[tid] = 0; lcur[tid] = 0; }
+    if (tid < 4) smask[SKM_BLOCK + tid] = 0xffff0000u;
+    // ---- stage the tile's bases: 64-bit words Q0/32 .. (+ TILE/32 + 2)
+    {
+        const long long w0 = Q0 / 32;
+        for (uint32_t i = tid; i < SKM_TILE / 32 + 4; i += SKM_BLOCK) {
+            const long long wi = w0 + (long long)i;
+            uint64_t v = 0;
+            if (wi >= 0 && (uint64_t)wi < a.nb_words) v = a.packed[wi];
+            tb[2 * i] = (uint32_t)v; tb[2 * i + 1] = (uint32_t)(v >> 32);
+        }
+    }
+    // ---- variable-length reads: the read starts inside this tile (relative to max(Q0,0)), as k_scan does
+    const uint64_t T0 = Q0 < 0 ? 0ull : (uint64_t)Q0;
+    uint32_t ntab = 0;
+    if (!FIXED) {
+        const uint64_t r0 = a.tile_r0[blockIdx.x], r1 = a.tile_r0[blockIdx.x + 1];
+        uint64_t last = r1 + 64;
+        if (last > a.nb_reads) last = a.nb_reads;
+        const uint64_t cnt = last > r0 ? last - r0 : 0;
+        const bool covers = cnt > 0 && (last == a.nb_reads || a.offsets[last] - T0 > (uint64_t)(SKM_TILE + 64));
+        if (covers && cnt <= SKM_RTAB) {
+            ntab = (uint32_t)cnt;
+            for (uint32_t i = tid; i < ntab; i += SKM_BLOCK) {
+                const uint64_t d = a.offsets[r0 + 1 + i] - T0;
+                rtab[i] = d < 0xffffffffull ? (uint32_t)d : 0xffffffffu;
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---- phase 1: hashes of the canonical m-mers at entries 16t .. 16t+15
+    {
+        const uint32_t d0 = tb[tid], d1 = tb[tid + 1];
+        const uint64_t F = ((uint64_t)d1 << 32) | d0;                       // bases of entries 16t .. 16t+31
+        const uint64_t R = skm_revcomp64(F) >> (2u * (17u - cfg.m));        // m-mer at entry q of the window: (R >> 2(15-q)) & mmask
+        const uint32_t f0 = (uint32_t)F, f1 = (uint32_t)(F >> 32), r0_ = (uint32_t)R, r1_ = (uint32_t)(R >> 32);
+        uint32_t hv[SKM_SEG];
+#pragma unroll
+        for (int q = 0; q < SKM_SEG; q++) {
+            const uint32_t fw = __builtin_amdgcn_alignbit(f1, f0, 2 * q) & cfg.mmask;
+            const uint32_t rv = __builtin_amdgcn_alignbit(r1_, r0_, 2 * (15 - q)) & cfg.mmask;
+            hv[q] = skm_mm_hash(fw < rv ? fw : rv, cfg.mmask, cfg.m);
+        }
+        uint4 *dst = (uint4 *)(hm + SKM_SEG * tid);
+        dst[0] = make_uint4(hv[0], hv[1], hv[2], hv[3]); dst[1] = make_uint4(hv[4], hv[5], hv[6], hv[7]);
+        dst[2] = make_uint4(hv[8], hv[9], hv[10], hv[11]); dst[3] = make_uint4(hv[12], hv[13], hv[14], hv[15]);
+        if (tid < 8) ((uint4 *)(hm + SKM_TILE))[tid] = make_uint4(~0u, ~0u, ~0u, ~0u);       // pad read by the last threads
+    }
+    __syncthreads();
+
+    // ---- phase 2: minimizer value of the k-mers at entries e_j = 16t - 1 + j, j = 0..16 (window of W entries)
+    const bool owner = tid >= SKM_OWN_LO / SKM_SEG && tid < SKM_OWN_HI / SKM_SEG;
+    uint32_t mh[SKM_SEG + 1];
+    {
+        constexpr int NH = 40;                              // H[x] = hm[16t - 4 + x]; window j covers x in [3 + j, 3 + j + W)
+        uint32_t H[NH];
+        const uint4 *src = (const uint4 *)(hm + (tid ? SKM_SEG * tid - 4 : 0));      // (thread 0 owns nothing: any in-range address)
+#pragma unroll
+        for (int x = 0; x < NH / 4; x++) { const uint4 v = src[x]; H[4 * x] = v.x; H[4 * x + 1] = v.y; H[4 * x + 2] = v.z; H[4 * x + 3] = v.w; }
+        static_assert(3 + SKM_SEG + SKM_MAXW <= NH, "window fits the loaded values");
+        // suffix minima up to the end of each W-aligned block, prefix minima from its start
+        uint32_t suf[NH], pre[NH];
+#pragma unroll
+        for (int x = NH - 1; x >= 0; x--) suf[x] = (x % W == W - 1 || x == NH - 1) ? H[x] : (H[x] < suf[x + 1] ? H[x] : suf[x + 1]);
+#pragma unroll
+        for (int x = 0; x < NH; x++) pre[x] = (x % W == 0) ? H[x] : (H[x] < pre[x - 1] ? H[x] : pre[x - 1]);
+#pragma unroll
+        for (int j = 0; j <= SKM_SEG; j++) {
+            const int lo = 3 + j, hi = 3 + j + W - 1;
+            mh[j] = (lo % W == 0) ? pre[hi] : (suf[lo] < pre[hi] ? suf[lo] : pre[hi]);
+        }
+    }
+    // ---- validity of the k-mers at e_0 .. e_16: start inside the data, end inside their read
+    uint32_t valid = 0;
+    {
+        const long long P0 = Q0 + (long long)(SKM_SEG * tid) - 1;           // position of e_0
+        const uint32_t k = cfg.k;
+        if (FIXED) {
+            const uint32_t L = a.fixed_len;
+            uint32_t rel = P0 >= 0 ? (uint32_t)((uint64_t)P0 % L) : (L - (uint32_t)((uint64_t)(-P0) % L)) % L;     // offset of e_0 inside its read
+#pragma unroll
+            for (int j = 0; j <= SKM_SEG; j++) {
+                const long long P = P0 + j;
+                const bool ok = P >= 0 && (uint64_t)P < a.nb_bases && rel + k <= L;
+                valid |= (ok ? 1u : 0u) << j;
+                rel++; if (rel >= L) rel = 0;
+            }
+        } else if (owner && (uint64_t)(P0 < 0 ? 0 : P0) < a.nb_bases) {
+            // `next` = first read start beyond the current position: from the staged table (relative to T0) or the offsets array
+            const uint64_t w0 = P0 < 0 ? 0ull : (uint64_t)P0;
+            uint64_t rd = 0, next;
+            uint32_t ti = 0;
+            if (ntab) {
+                const uint32_t w0rel = (uint32_t)(w0 - T0);
+                uint32_t lo = 0, hi = ntab;          // smallest i with rtab[i] > w0rel
+                while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (rtab[mid] > w0rel) hi = mid; else lo = mid + 1; }
+                ti = lo;
+                next = ti < ntab ? T0 + rtab[ti] : a.nb_bases;
+            } else {
+                uint64_t lo = 0, hi = a.nb_reads;
+                while (hi - lo > 1) { const uint64_t mid = (lo + hi) >> 1; if (a.offsets[mid] <= w0) lo = mid; else hi = mid; }
+                rd = lo;
+                next = a.offsets[rd + 1];
+            }
+#pragma unroll
+            for (int j = 0; j <= SKM_SEG; j++) {
+                const long long P = P0 + j;
+                if (P >= 0 && (uint64_t)P < a.nb_bases) {
+                    while (next <= (uint64_t)P) {            // e_j starts a later read (empty reads: several steps)
+                        if (ntab) { ti++; next = ti < ntab ? T0 + rtab[ti] : a.nb_bases; }
+                        else { rd++; next = rd + 1 <= a.nb_reads ? a.offsets[rd + 1] : a.nb_bases; }
+                        if (next >= a.nb_bases) break;
+                    }
+                    if ((uint64_t)P + k <= next && (uint64_t)P < next) valid |= 1u << j;
+                }
+            }
+        }
+    }
+    // ---- phase 3a: run starts and breaks among e_1 .. e_16 (bit j-1)
+    uint32_t start = 0, brk = 0xffffu;
+    if (owner) {
+        brk = 0;
+#pragma unroll
+        for (int j = 1; j <= SKM_SEG; j++) {
+            const bool v = (valid >> j) & 1u, pv = (valid >> (j - 1)) & 1u;
+            const bool st = v && (!pv || mh[j] != mh[j - 1] || (j == 1 && tid == SKM_OWN_LO / SKM_SEG));   // a tile never continues a run
+            start |= (st ? 1u : 0u) << (j - 1);
+            brk |= ((st || !v) ? 1u : 0u) << (j - 1);
+        }
+    }
+    smask[tid] = start | (brk << 16);
+    __syncthreads();               // (A) hm is dead from here on
+    {
+        // a run without a break for 32 positions restarts at a thread's first entry, so the look-ahead below stays within 64 bits
+        const uint32_t p1 = tid >= 1 ? smask[tid - 1] >> 16 : 0xffffu, p2 = tid >= 2 ? smask[tid - 2] >> 16 : 0xffffu;
+        const bool forced = owner && ((valid >> 1) & 1u) && !(brk & 1u) && p1 == 0u && p2 == 0u;
+        // the partition ids of my k-mers go where my hashes were
+        if (owner) {
+#pragma unroll
+            for (int j = 1; j <= SKM_SEG; j++) hm[SKM_SEG * tid + j - 1] = skm_pid(mh[j], cfg.pb);
+        }
+        __syncthreads();           // every thread has read the masks of its predecessors
+        if (forced) { start |= 1u; brk |= 1u; smask[tid] = start | (brk << 16); }
+    }
+    __syncthreads();               // (B)
+    // ---- phase 3b: one record per <= nmax k-mers of every run that starts here
+    if (owner) {
+        const ull n1 = smask[tid + 1] >> 16, n2 = smask[tid + 2] >> 16, n3 = (smask[tid + 3] >> 16) & 1u;     // (tid + 3 <= 512: one pad word)
+        uint32_t todo = start;
+        while (todo) {
+            const uint32_t jb = __ffs(todo) - 1u;         // bit index: entry e = 16t + jb
+            todo &= todo - 1u;
+            const ull look = ((ull)(brk >> (jb + 1u))) | (n1 << (15u - jb)) | (n2 << (31u - jb)) | (n3 << (47u - jb));
+            uint32_t len = (uint32_t)__ffsll((long long)look);       // look != 0: a break within 48 positions is guaranteed
+            uint32_t e = SKM_SEG * tid + jb;
+            const uint32_t pid = hm[e];
+            if (!skm_owns(pid, cfg)) continue;
+            while (len) {
+                const uint32_t n = len < cfg.nmax ? len : cfg.nmax;
+                if (HIST) atomicAdd(&hist[cfg.pb ? pid >> (cfg.pb - cfg.l1) : 0u], 1u);
+                else {
+                    const uint32_t wi = e >> 4, sh = (e & 15u) * 2u;
+                    const uint32_t c0 = tb[wi], c1 = tb[wi + 1], c2 = tb[wi + 2], c3 = tb[wi + 3], c4 = tb[wi + 4];
+                    uint4 rec;
+                    rec.x = __builtin_amdgcn_alignbit(c1, c0, sh); rec.y = __builtin_amdgcn_alignbit(c2, c1, sh);
+                    rec.z = __builtin_amdgcn_alignbit(c3, c2, sh);
+                    rec.w = (__builtin_amdgcn_alignbit(c4, c3, sh) & 63u) | ((n - 1u) << 6) | (pid << 11);
+                    const uint32_t slot = atomicAdd(&s_nrec, 1u);
+                    const uint32_t b1 = cfg.pb ? pid >> (cfg.pb - cfg.l1) : 0u;
+                    if (slot < SKM_CAPREC) { stage[slot] = rec; atomicAdd(&hist[b1], 1u); }
+                    else {      // staging full (pathological tile): one global atomic per record
+                        const ull g = atomicAdd(&b1_cursor[b1], 1ull);
+                        if (b1_limit && g + 1 > b1_limit[b1]) *ovf_flag = 1u; else l1_recs[g] = rec;
+                    }
+                }
+                e += n; len -= n;
+            }
+        }
+    }
+    __syncthreads();               // (C)
+    if (HIST) {
+        if (tid < B1 && hist[tid]) atomicAdd(&b1_count[tid], (ull)hist[tid]);
+        return;
+    }
+    // ---- phase 4: reserve the tile's run in every bucket, store the records
+    if (tid < B1) {
+        const uint32_t h = hist[tid];
+        ull g = 0;
+        if (h) {
+            g = atomicAdd(&b1_cursor[tid], (ull)h);
+            if (b1_limit && g + h > b1_limit[tid]) { *ovf_flag = 1u; g = ~0ull; }
+        }
+        gbase[tid] = g;
+    }
+    __syncthreads();
+    const uint32_t nrec = s_nrec < SKM_CAPREC ? s_nrec : SKM_CAPREC;
+    for (uint32_t i = tid; i < nrec; i += SKM_BLOCK) {
+        const uint4 rec = stage[i];
+        const uint32_t b1 = cfg.pb ? skm_rec_pid(rec) >> (cfg.pb - cfg.l1) : 0u;
+        const ull g = gbase[b1];
+        const uint32_t rk = atomicAdd(&lcur[b1], 1u);
+        if (g != ~0ull) l1_recs[g + rk] = rec;
+    }
+}
+
+// --------------------------------------------------------------------------------------------
+// k_skm_layout: level-1 bucket geometry, one block.
+//   mode 1 (before the capacity-sized scatter): bucket b owns [b*cap, (b+1)*cap)
+//   mode 2 (after it): counts from the cursors; chunk table for the level-2 kernels; zero the level-2 counters
+//   mode 0 (exact, after the histogram pass): starts from the counts, then as mode 2
+// --------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+k_skm_layout(ull *b1_count, ull *b1_start, ull *b1_limit, ull *b1_cursor, uint32_t *chunk_first, uint32_t B1, uint32_t mode, ull cap,
+             ull *arena_cursor, ull *sample_base, uint32_t first_pass, const uint32_t *skip_flag, uint32_t *cnt2, uint32_t ncnt2) {
+    __shared__ ull s_cnt[64];
+    __shared__ uint32_t s_ch[65];
+    const uint32_t tid = threadIdx.x;
+    if (mode == 1u) {
+        if (tid < B1) { b1_start[tid] = (ull)tid * cap; b1_cursor[tid] = (ull)tid * cap; b1_limit[tid] = (ull)(tid + 1) * cap; }
+        if (tid == 0 && first_pass) *sample_base = *arena_cursor;
+        for (uint32_t i = tid; i < ncnt2; i += 256) cnt2[i] = 0;
+        return;
+    }
+    if (mode == 2u && skip_flag && *skip_flag) return;
+    if (tid < B1) s_cnt[tid] = mode == 0u ? b1_count[tid] : b1_cursor[tid] - b1_start[tid];
+    __syncthreads();
+    if (tid == 0) {
+        ull run = 0; uint32_t ch = 0;
+        for (uint32_t b = 0; b < B1; b++) {
+            const ull c = s_cnt[b];
+            if (mode == 0u) { b1_start[b] = run; b1_cursor[b] = run; b1_limit[b] = run + c; }
+            b1_count[b] = c;
+            s_ch[b] = ch;
+            ch += (uint32_t)((c + SKM_CHUNK - 1) / SKM_CHUNK);
+            run += c;
+        }
+        s_ch[B1] = ch;
+        if (mode == 0u && first_pass) *sample_base = *arena_cursor;
+    }
+    __syncthreads();
+    if (tid <= B1) chunk_first[tid] = s_ch[tid];
+    if (mode == 0u) for (uint32_t i = tid; i < ncnt2; i += 256) cnt2[i] = 0;
+}
+
+// chunk c of the level-1 buckets -> (first record, #records, bucket); thread 0, into s_chunk
+__device__ __forceinline__ void skm_locate(uint32_t c, const uint32_t *chunk_first, uint32_t B1, const ull *b1_start, const ull *b1_count, ull *s_chunk) {
+    uint32_t lo = 0, hi = B1;
+    while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (chunk_first[mid] <= c) lo = mid; else hi = mid; }
+    const ull off = (ull)(c - chunk_first[lo]) * SKM_CHUNK;
+    const ull n = b1_count[lo] - off;
+    s_chunk[0] = b1_start[lo] + off; s_chunk[1] = n < (ull)SKM_CHUNK ? n : (ull)SKM_CHUNK; s_chunk[2] = lo;
+}
+
+// k_skm_hist2: records per level-2 bucket (b1, b2), exact
+__global__ void __launch_bounds__(SKM_L2_BLOCK)
+k_skm_hist2(const uint4 *l1_recs, const ull *b1_start, const ull *b1_count, const uint32_t *chunk_first, SimkaSkmCfg cfg, uint32_t *cnt2, const uint32_t *flag) {
+    if (*flag) return;
+    __shared__ ull s_chunk[4];
+    __shared__ uint32_t lh[512];
+    const uint32_t tid = threadIdx.x, B1 = 1u << cfg.l1, F2 = 1u << cfg.l2;
+    const uint32_t nchunks = chunk_first[B1];
+    const uint32_t sh2 = cfg.l3, m2 = F2 - 1u;
+    for (uint32_t c = blockIdx.x; c < nchunks; c += gridDim.x) {
+        __syncthreads();
+        if (tid == 0) skm_locate(c, chunk_first, B1, b1_start, b1_count, s_chunk);
+        for (uint32_t i = tid; i < F2; i += SKM_L2_BLOCK) lh[i] = 0;
+        __syncthreads();
+        const ull st = s_chunk[0]; const uint32_t n = (uint32_t)s_chunk[1], b1 = (uint32_t)s_chunk[2];
+        for (uint32_t i = tid; i < n; i += SKM_L2_BLOCK) atomicAdd(&lh[(skm_rec_pid(l1_recs[st + i]) >> sh2) & m2], 1u);
+        __syncthreads();
+        for (uint32_t i = tid; i < F2; i += SKM_L2_BLOCK) if (lh[i]) atomicAdd(&cnt2[(b1 << cfg.l2) | i], lh[i]);
+    }
+}
+
+// exclusive scan of n u32 counters (one block): start[i], cursor[i] = start[i]; start[n] = total
+__global__ void __launch_bounds__(1024)
+k_skm_scan_counts(const uint32_t *cnt, uint32_t n, uint32_t *start, uint32_t *cursor, const uint32_t *flag) {
+    if (*flag) return;
+    __shared__ uint32_t wsum[16];
+    __shared__ uint32_t s_carry;
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    if (tid == 0) s_carry = 0;
+    __syncthreads();
+    for (uint32_t b0 = 0; b0 < n; b0 += 1024) {
+        const uint32_t i = b0 + tid;
+        const uint32_t v = i < n ? cnt[i] : 0u;
+        uint32_t x = v;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { const uint32_t t = __shfl_up(x, o, 64); if (lane >= (uint32_t)o) x += t; }
+        if (lane == 63u) wsum[wave] = x;
+        __syncthreads();
+        uint32_t wpre = 0, tot = 0;
+#pragma unroll
+        for (uint32_t w = 0; w < 16; w++) { const uint32_t t = wsum[w]; if (w < wave) wpre += t; tot += t; }
+        const uint32_t ex = s_carry + wpre + x - v;
+        if (i < n) { start[i] = ex; cursor[i] = ex; }
+        __syncthreads();
+        if (tid == 0) s_carry += tot;
+        __syncthreads();
+    }
+    if (tid == 0) start[n] = s_carry;
+}
+
+// k_skm_scatter2: level-1 buckets -> level-2 buckets (exact starts): LDS rank per record, one global atomic per run
+__global__ void __launch_bounds__(SKM_L2_BLOCK)
+k_skm_scatter2(const uint4 *l1_recs, const ull *b1_start, const ull *b1_count, const uint32_t *chunk_first, SimkaSkmCfg cfg, uint32_t *cursor2,
+               uint4 *l2_recs, const uint32_t *flag) {
+    if (*flag) return;
+    __shared__ ull s_chunk[4];
+    __shared__ uint32_t lh[512];
+    __shared__ uint32_t lbase[512];
+    const uint32_t tid = threadIdx.x, B1 = 1u << cfg.l1, F2 = 1u << cfg.l2;
+    const uint32_t nchunks = chunk_first[B1];
+    const uint32_t sh2 = cfg.l3, m2 = F2 - 1u;
+    constexpr int PER = SKM_CHUNK / SKM_L2_BLOCK;
+    for (uint32_t c = blockIdx.x; c < nchunks; c += gridDim.x) {
+        __syncthreads();
+        if (tid == 0) skm_locate(c, chunk_first, B1, b1_start, b1_count, s_chunk);
+        for (uint32_t i = tid; i < F2; i += SKM_L2_BLOCK) lh[i] = 0;
+        __syncthreads();
+        const ull st = s_chunk[0]; const uint32_t n = (uint32_t)s_chunk[1], b1 = (uint32_t)s_chunk[2];
+        uint4 rec[PER]; uint32_t rk[PER];
+#pragma unroll
+        for (int q = 0; q < PER; q++) { const uint32_t i = (uint32_t)q * SKM_L2_BLOCK + tid; if (i < n) rec[q] = l1_recs[st + i]; }
+#pragma unroll
+        for (int q = 0; q < PER; q++) { const uint32_t i = (uint32_t)q * SKM_L2_BLOCK + tid; rk[q] = i < n ? atomicAdd(&lh[(skm_rec_pid(rec[q]) >> sh2) & m2], 1u) : 0u; }
+        __syncthreads();
+        for (uint32_t i = tid; i < F2; i += SKM_L2_BLOCK) { const uint32_t h = lh[i]; lbase[i] = h ? atomicAdd(&cursor2[(b1 << cfg.l2) | i], h) : 0u; }
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < PER; q++) {
+            const uint32_t i = (uint32_t)q * SKM_L2_BLOCK + tid;
+            if (i < n) l2_recs[lbase[(skm_rec_pid(rec[q]) >> sh2) & m2] + rk[q]] = rec[q];
+        }
+    }
+}
+
+// k_skm_split3: one block per level-2 bucket: exact histogram of its 2^l3 partitions, then the scatter inside the bucket's range
+// (second read from L2 / Infinity Cache).  Writes the partition table (start, count).
+__global__ void __launch_bounds__(SKM_L2_BLOCK)
+k_skm_split3(const uint4 *l2_recs, const uint32_t *start2, SimkaSkmCfg cfg, uint4 *l3_recs, uint32_t *pstart, uint32_t *pcnt, const uint32_t *flag) {
+    if (*flag) return;
+    __shared__ uint32_t lh[64], lcur[64];
+    const uint32_t tid = threadIdx.x, F3 = 1u << cfg.l3, m3 = F3 - 1u;
+    const uint32_t nsb = 1u << (cfg.l1 + cfg.l2);
+    for (uint32_t sb = blockIdx.x; sb < nsb; sb += gridDim.x) {
+        __syncthreads();
+        if (tid < 64) lh[tid] = 0;
+        __syncthreads();
+        const uint32_t s = start2[sb], n = start2[sb + 1] - s;
+        for (uint32_t i = tid; i < n; i += SKM_L2_BLOCK) atomicAdd(&lh[skm_rec_pid(l2_recs[s + i]) & m3], 1u);
+        __syncthreads();
+        if (tid < 64) {
+            const uint32_t v = tid < F3 ? lh[tid] : 0u;
+            uint32_t x = v;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) { const uint32_t t = __shfl_up(x, o, 64); if (tid >= (uint32_t)o) x += t; }
+            if (tid < F3) { lcur[tid] = x - v; pstart[(sb << cfg.l3) | tid] = s + x - v; pcnt[(sb << cfg.l3) | tid] = v; }
+        }
+        __syncthreads();
+        for (uint32_t i = tid; i < n; i += SKM_L2_BLOCK) {
+            const uint4 rec = l2_recs[s + i];
+            const uint32_t rk = atomicAdd(&lcur[skm_rec_pid(rec) & m3], 1u);
+            l3_recs[s + rk] = rec;
+        }
+    }
+}
+
+// --------------------------------------------------------------------------------------------
+// k_skm_count: one partition at a time per (persistent) block.
+//   records -> LDS; a wave scan of the record lengths + one LDS atomic per wave gives every record a range of k-mer slots,
+//   map[slot] = (record, offset); then one LANE PER K-MER: cut the k-mer out of its record (funnel shift, no rolling state),
+//   reverse complement (brev), canonical, 32-bit slot hash, insert (64-bit CAS on the canonical k-mer + counter).
+//   Summary in slot order: slot = top bits of the hash, probing stays inside its 128-slot sort block, so the solid records
+//   leave ordered by the top SKM_SORT_BITS bits of the hash.
+//   A partition with more distinct k-mers than the table takes is redone in 2, 4, .. rounds on the top hash bits (first a
+//   counting pass over all rounds, then the emitting pass), so the records of a (sample, partition) stay ONE contiguous,
+//   ordered segment of the arena.
+// --------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint64_t skm_kmer_at(const uint4 &r, uint32_t j, const SimkaSkmCfg &cfg) {
+    const uint32_t s = 2u * j, wd = s >> 5, sh = s & 31u;
+    const uint32_t d3 = r.w & 63u;
+    const uint32_t a0 = wd ? r.y : r.x, a1 = wd ? r.z : r.y, a2 = wd ? d3 : r.z;
+    const uint32_t lo = __builtin_amdgcn_alignbit(a1, a0, sh), hi = __builtin_amdgcn_alignbit(a2, a1, sh);
+    return (((uint64_t)hi << 32) | lo) & cfg.kmask;
+}
+
+__global__ void __launch_bounds__(SKM_CNT_BLOCK)
+k_skm_count(const uint4 *recs, const uint32_t *pstart, const uint32_t *pcnt, SimkaSkmCfg cfg, SimkaKeyCfg kcfg, uint32_t amin, uint32_t amax, SimkaCountOut o,
+            const uint32_t *flag, ull *kocc_owned) {
+    if (*flag) return;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    ull *s_tot = (ull *)smem;                          // [5] D_all, D, N, Q, K_occ of the whole block
+    ull &s_base = *(ull *)(smem + 48);
+    ull &s_slab_pos = *(ull *)(smem + 56);
+    ull &s_slab_end = *(ull *)(smem + 64);
+    uint32_t &s_kt = *(uint32_t *)(smem + 72);         // k-mer slots handed out in the current batch
+    uint32_t &s_fail = *(uint32_t *)(smem + 76);
+    uint32_t &s_ok = *(uint32_t *)(smem + 80);
+    uint32_t *tmp = (uint32_t *)(smem + 128);          // [BLOCK/64]
+    ull *tkeys = (ull *)(smem + SIMKA_LDS_HEAD);       // [TS]
+    uint32_t *tcnt = (uint32_t *)(tkeys + SKM_CNT_TS); // [TS]
+    uint4 *lrec = (uint4 *)(tcnt + SKM_CNT_TS);        // [BATCH]
+    uint32_t *spos = (uint32_t *)(lrec + SKM_CNT_BATCH);     // [BLOCK]
+    uint32_t *lhist = spos + SKM_CNT_BLOCK;            // [SIMKA_HIST_MAX] (complex only)
+    uint16_t *map = (uint16_t *)(lhist + (o.hist ? SIMKA_HIST_MAX : 0));     // [BATCH * nmax]
+
+    const uint32_t tid = threadIdx.x, lane = tid & 63u;
+    const uint32_t nparts = 1u << cfg.pb;
+    constexpr uint32_t TS = SKM_CNT_TS, SPT = TS / SKM_CNT_BLOCK, TSL = 12;          // log2 TS
+    const ull sample_base = *o.sample_base;
+    for (uint32_t i = tid; i < TS; i += SKM_CNT_BLOCK) { tkeys[i] = SIMKA_EMPTY_KEY; tcnt[i] = 0; }
+    if (o.hist) for (uint32_t i = tid; i < SIMKA_HIST_MAX; i += SKM_CNT_BLOCK) lhist[i] = 0;
+    if (tid < 5) s_tot[tid] = 0;
+    if (tid == 0) { s_slab_pos = 0; s_slab_end = 0; s_fail = 0; }
+    ull bt_dall = 0, bt_D = 0, bt_N = 0, bt_Q = 0, bt_kocc = 0;
+    __syncthreads();
+
+    for (uint32_t part = blockIdx.x; part < nparts; part += gridDim.x) {
+        const uint32_t nrec = pcnt[part];
+        if (nrec == 0) continue;                       // (foff / fcnt of the sample were zeroed by the host)
+        const uint32_t rbase = pstart[part];
+        uint32_t rho = 0;                              // log2 #rounds
+        bool done = false;
+        while (!done) {
+            const uint32_t R = 1u << rho;
+            // pass 0: count (and, with a single round, emit); pass 1 (R > 1): emit
+            uint32_t total_solid = 0;
+            ull emit_pos = 0;
+            bool overflow = false;
+            ull pD_all = 0, pD = 0, pN = 0, pQ = 0, pK = 0;
+            for (uint32_t pass = 0; pass < (R > 1 ? 2u : 1u) && !overflow; pass++) {
+                const bool emit = (R == 1) || pass == 1;
+                if (pass == 1) {
+                    __syncthreads();
+                    if (tid == 0) {
+                        uint32_t ok = 1;
+                        const ull bb = total_solid ? slab_take(s_slab_pos, s_slab_end, total_solid, o, sample_base, ok) : sample_base;
+                        s_base = bb; s_ok = ok;
+                    }
+                    __syncthreads();
+                    if (!s_ok) { overflow = false; break; }
+                    emit_pos = s_base;
+                }
+                for (uint32_t r = 0; r < R && !overflow; r++) {
+                    // ---- insert the k-mers of the partition whose hash belongs to round r
+                    for (uint32_t b0 = 0; b0 < nrec; b0 += SKM_CNT_BATCH) {
+                        __syncthreads();
+                        if (tid == 0) s_kt = 0;
+                        __syncthreads();
+                        const uint32_t nb = nrec - b0 < (uint32_t)SKM_CNT_BATCH ? nrec - b0 : (uint32_t)SKM_CNT_BATCH;
+                        uint32_t len = 0;
+                        if (tid < nb) { const uint4 rc = recs[rbase + b0 + tid]; lrec[tid] = rc; len = skm_rec_n(rc); }
+                        uint32_t x = len;
+#pragma unroll
+                        for (int o_ = 1; o_ < 64; o_ <<= 1) { const uint32_t t = __shfl_up(x, o_, 64); if (lane >= (uint32_t)o_) x += t; }
+                        uint32_t wbase = 0;
+                        if (lane == 63u) wbase = atomicAdd(&s_kt, x);
+                        wbase = __shfl(wbase, 63, 64);
+                        const uint32_t off = wbase + x - len;
+                        for (uint32_t j = 0; j < len; j++) map[off + j] = (uint16_t)((tid << 5) | j);
+                        __syncthreads();
+                        const uint32_t kt = s_kt;
+                        if (r == 0 && pass == 0) pK += (tid == 0) ? kt : 0;
+                        for (uint32_t f = tid; f < kt; f += SKM_CNT_BLOCK) {
+                            const uint32_t e = map[f];
+                            const uint4 rc = lrec[e >> 5];
+                            const uint64_t fwd = skm_kmer_at(rc, e & 31u, cfg);
+                            const uint64_t rev = skm_revcomp64(fwd) >> (64u - 2u * cfg.k);
+                            const uint64_t canon = fwd < rev ? fwd : rev;
+                            const uint32_t h = skm_kmer_hash(canon);
+                            if (rho && (h >> (32u - rho)) != r) continue;
+                            const uint32_t hs = rho ? (h << rho) : h;
+                            uint32_t slot = hs >> (32u - TSL);
+                            // probing stays inside the sort block (128 << rho slots, the whole table from rho = 5 on)
+                            const uint32_t bmask = rho >= SKM_SORT_BITS ? (TS - 1u) : ((TS >> (SKM_SORT_BITS - rho)) - 1u);
+                            const uint32_t bbase = slot & ~bmask;
+                            bool placed = false;
+                            for (uint32_t probe = 0; probe <= bmask; probe++) {
+                                const ull prev = atomicCAS(&tkeys[slot], SIMKA_EMPTY_KEY, (ull)canon);
+                                if (prev == SIMKA_EMPTY_KEY || prev == (ull)canon) { atomicAdd(&tcnt[slot], 1u); placed = true; break; }
+                                slot = bbase | ((slot + 1u) & bmask);
+                            }
+                            if (!placed) s_fail = 1u;
+                        }
+                    }
+                    __syncthreads();
+                    // ---- summary of the round in slot order (SimkaCompressedProcessor::process, ref: src/minikc/MiniKC.hpp:54-79)
+                    uint32_t cs[SPT]; ull ks[SPT];
+                    uint32_t nsol = 0, ndall = 0;
+                    ull D = 0, N = 0, Q = 0;
+#pragma unroll
+                    for (uint32_t q = 0; q < SPT; q++) {
+                        const uint32_t sl = tid * SPT + q;
+                        cs[q] = tcnt[sl]; ks[q] = tkeys[sl];
+                        if (cs[q]) { tcnt[sl] = 0; tkeys[sl] = SIMKA_EMPTY_KEY; }
+                        const uint32_t c = cs[q];
+                        if (c) { ndall++; if (!(c < amin || c > amax)) { D++; N += c; Q += (ull)c * (ull)c; nsol++; } else cs[q] = 0; }
+                    }
+                    const bool failed = s_fail != 0u;
+                    spos[tid] = nsol;
+                    __syncthreads();
+                    const uint32_t tot = block_excl_scan<SKM_CNT_BLOCK>(spos, SKM_CNT_BLOCK, tmp);
+                    if (failed) { overflow = true; if (tid == 0) s_fail = 0u; continue; }     // (uniform) the table is clean again
+                    if (pass == 0) { pD_all += ndall; pD += D; pN += N; pQ += Q; total_solid += tot; }
+                    if (emit) {
+                        if (R == 1) {      // single round: reserve now
+                            if (tid == 0) {
+                                uint32_t ok = 1;
+                                const ull bb = tot ? slab_take(s_slab_pos, s_slab_end, tot, o, sample_base, ok) : sample_base;
+                                s_base = bb; s_ok = ok;
+                            }
+                            __syncthreads();
+                            emit_pos = s_base;
+                            if (!s_ok) { overflow = false; pD_all = pD = pN = pQ = 0; total_solid = 0; continue; }
+                        }
+                        ull pos = emit_pos + spos[tid];
+#pragma unroll
+                        for (uint32_t q = 0; q < SPT; q++) {
+                            if (cs[q]) {
+                                o.solid_keys[pos] = simka_mix(ks[q], kcfg.mask, kcfg.xs); o.solid_counts[pos] = cs[q]; pos++;
+                                if (o.hist) count_hist(o, lhist, cs[q]);
+                            }
+                        }
+                        if (R > 1) emit_pos += tot;
+                    }
+                }
+            }
+            __syncthreads();
+            if (overflow) {
+                if (rho >= 16u) { if (tid == 0) atomicOr(o.err, SIMKA_DEVERR_TABLE_OVERFLOW); done = true; }
+                else rho++;
+                continue;
+            }
+            // the partition is done: its segment and totals
+            if (tid == 0) {
+                const bool ok = total_solid == 0 || s_ok;
+                const ull seg = (R == 1) ? s_base : s_base;
+                o.foff[part] = (ok && total_solid) ? (uint32_t)(seg - sample_base) : 0u;
+                o.fcnt[part] = ok ? total_solid : 0u;
+            }
+            bt_dall += pD_all; bt_D += pD; bt_N += pN; bt_Q += pQ; bt_kocc += pK;
+            done = true;
+        }
+        __syncthreads();
+    }
+    if (o.hist) {
+        __syncthreads();
+        for (uint32_t i = tid; i < SIMKA_HIST_MAX; i += SKM_CNT_BLOCK)
+            if (lhist[i]) atomicAdd(&o.hist[(size_t)o.sample * SIMKA_HIST_MAX + i], (ull)lhist[i]);
+    }
+    if (bt_dall) atomicAdd(&s_tot[0], bt_dall);
+    if (bt_D) { atomicAdd(&s_tot[1], bt_D); atomicAdd(&s_tot[2], bt_N); atomicAdd(&s_tot[3], bt_Q); }
+    if (bt_kocc) atomicAdd(&s_tot[4], bt_kocc);
+    __syncthreads();
+    if (tid == 0) {
+        ull *t = o.totals + o.sample;
+        const size_t ns_ = o.nb_samples;
+        if (s_tot[0]) atomicAdd(&t[SIMKA_TOT_DALL * ns_], s_tot[0]);
+        if (s_tot[1]) { atomicAdd(&t[SIMKA_TOT_D * ns_], s_tot[1]); atomicAdd(&t[SIMKA_TOT_N * ns_], s_tot[2]); atomicAdd(&t[SIMKA_TOT_Q * ns_], s_tot[3]); }
+        if (s_tot[4] && kocc_owned) atomicAdd(kocc_owned, s_tot[4]);
+    }
+}
+
+#endif
