@@ -269,13 +269,15 @@ static int set_lds_attr(simka_ctx *ctx) {
     HIPCHK(hipFuncSetAttribute((const void *)k_pairs_tm, hipFuncAttributeMaxDynamicSharedMemorySize, big));
     for (int wi = 0; wi < 6; wi++) for (int v = 0; v < 4; v++) HIPCHK(hipFuncSetAttribute((const void *)skm_scan_kernel(wi, v & 2, v & 1), hipFuncAttributeMaxDynamicSharedMemorySize, big));
     HIPCHK(hipFuncSetAttribute((const void *)k_skm_count, hipFuncAttributeMaxDynamicSharedMemorySize, big));
+    HIPCHK(hipFuncSetAttribute((const void *)k_skm_count_fast, hipFuncAttributeMaxDynamicSharedMemorySize, big));
     return SIMKA_OK;
 }
 
 // ~SIMKA_TARGET_PER_PART k-mer occurrences of the largest sample per partition (one LDS table of k_count_fast)
 static uint32_t default_log2_partitions(uint64_t max_kmers, uint32_t shard_count) {
     const uint64_t per_shard = std::max<uint64_t>(1, max_kmers / std::max(1u, shard_count));
-    uint32_t pb = ceil_log2_u64((per_shard + SIMKA_TARGET_PER_PART - 1) / SIMKA_TARGET_PER_PART) + ceil_log2_u64(std::max(1u, shard_count));
+    static const uint64_t target = getenv("SIMKA_TARGET_PER_PART") ? (uint64_t)atoll(getenv("SIMKA_TARGET_PER_PART")) : (uint64_t)SIMKA_TARGET_PER_PART;   // experiments
+    uint32_t pb = ceil_log2_u64((per_shard + target - 1) / target) + ceil_log2_u64(std::max(1u, shard_count));
     return std::min(pb, 20u);
 }
 
@@ -719,12 +721,12 @@ static int run_count_skm(simka_ctx *ctx, uint32_t sample, const SimkaScanArgs &a
     const int wi = skm_w_index(sk.W);
     const bool fixed = a.fixed_len != 0;
     auto scan_lds = [&](bool hist) {
-        return (size_t)SIMKA_LDS_HEAD + (SKM_TILE + 32) * 4 + (SKM_TILE / 16 + 8) * 4 + (SKM_BLOCK + 4) * 4 + 64 * 4 * 2 + 64 * 8 + (fixed ? 0 : SKM_RTAB * 4) + (hist ? 0 : (size_t)caprec * 16);
+        return (size_t)SIMKA_LDS_HEAD + (size_t)16 * SKM_NT * 4 + (SKM_TILE / 16 + 8) * 4 + (SKM_BLOCK + 4) * 4 + 64 * 4 * 2 + 64 * 8 + (fixed ? 0 : SKM_RTAB * 4) + (hist ? 0 : (size_t)caprec * 16);
     };
     auto layout = [&](uint32_t mode, ull capb) {
         launch_timed(ctx, KID_LAYOUT, [&] {
             hipLaunchKernelGGL(k_skm_layout, dim3(1), dim3(256), 0, st, L.d_b1_count, L.d_b1_start, L.d_b1_end, L.d_b1_cursor, L.d_chunk_first, B1, mode, capb,
-                               ctx->d_arena_cursor, ctx->d_sample_base + sample, pass == 0 ? 1u : 0u, (const uint32_t *)flag, L.d_cnt2, nsb);
+                               ctx->d_arena_cursor, ctx->d_sample_base + sample, pass == 0 ? 1u : 0u, (const uint32_t *)flag, L.d_cnt2, nsb, L.d_redo_count);
         }, st);
     };
     auto scan = [&](bool hist, const ull *limit) {
@@ -785,12 +787,36 @@ static int run_count_skm(simka_ctx *ctx, uint32_t sample, const SimkaScanArgs &a
     o.phase = nullptr;
     o.hist = ctx->d_hist; o.ovf_list = ctx->d_ovf_list; o.ovf_cursor = ctx->d_ovf_cursor; o.ovf_cap = ctx->ovf_cap;
     ull *kocc = (ull *)ctx->d_stats + stats_off_tot(N, ctx->cfg.dist_flags, SIMKA_TOT_KOCC) + sample;
-    const size_t lds_count = (size_t)SIMKA_LDS_HEAD + (size_t)SKM_CNT_TS * 12 + (size_t)SKM_CNT_BATCH * 16 + (size_t)SKM_CNT_BLOCK * 4 + (ctx->d_hist ? (size_t)SIMKA_HIST_MAX * 4 : 0) +
-                             (size_t)SKM_CNT_BATCH * sk.nmax * 2 + 64;
-    launch_timed(ctx, KID_SKM_COUNT, [&] {
-        const uint32_t bpc = (uint32_t)std::max<size_t>(1, std::min<size_t>(3, (160 * 1024) / lds_count));
-        hipLaunchKernelGGL(k_skm_count, dim3((uint32_t)std::min<uint64_t>(ctx->nparts, (uint64_t)ctx->num_cus * bpc)), dim3(SKM_CNT_BLOCK), lds_count, st, (const uint4 *)L.d_skm_a,
-                           (const uint32_t *)L.d_pstart, (const uint32_t *)L.d_pcnt, sk, ctx->key, ctx->cfg.abundance_min, ctx->cfg.abundance_max, o, (const uint32_t *)flag, kocc);
+#ifdef SIMKA_PHASE_PROF
+    {   // debug build: per-phase wall_clock64 ticks of thread 0 of every k_skm_count_fast block, printed per sample
+        static ull *d_phase = nullptr;
+        if (!d_phase) { HIPCHK(hipMalloc(&d_phase, 64)); HIPCHK(hipMemset(d_phase, 0, 64)); }
+        else {
+            HIPCHK(hipDeviceSynchronize());
+            ull h[8]; HIPCHK(hipMemcpy(h, d_phase, 64, hipMemcpyDeviceToHost)); HIPCHK(hipMemset(d_phase, 0, 64));
+            ull t_ = 0; for (ull v : h) t_ += v;
+            if (t_) fprintf(stderr, "k_skm_count_fast phases %%: top %.1f map %.1f insert %.1f sync %.1f summary %.1f scan %.1f slab %.1f stores %.1f  (ticks/block %.0f)\n",
+                    100.0 * h[0] / t_, 100.0 * h[1] / t_, 100.0 * h[2] / t_, 100.0 * h[3] / t_, 100.0 * h[4] / t_, 100.0 * h[5] / t_, 100.0 * h[6] / t_, 100.0 * h[7] / t_, (double)t_ / (ctx->num_cus * 2));
+        }
+        o.phase = d_phase;
+    }
+#endif
+    const size_t hist_lds = ctx->d_hist ? (size_t)SIMKA_HIST_MAX * 4 : 0;
+    const size_t lds_fast = (size_t)SIMKA_LDS_HEAD + (size_t)SKM_CNT_TS * 12 + (size_t)SKM_CNT_BLOCK * 16 + (size_t)SKM_CNT_BLOCK * 4 + hist_lds + (size_t)SKM_CNT_BLOCK * sk.nmax * 2 + 64;
+    const size_t lds_count = (size_t)SIMKA_LDS_HEAD + (size_t)SKM_CNT_TS * 12 + (size_t)SKM_CNT_BATCH * 16 + (size_t)SKM_CNT_BLOCK * 4 + hist_lds + (size_t)SKM_CNT_BATCH * sk.nmax * 2 + 64;
+    static const bool general_only = getenv("SIMKA_SKM_GENERAL") != nullptr;      // tests: every partition through the general kernel
+    if (!general_only)
+        launch_timed(ctx, KID_SKM_COUNT, [&] {
+            const uint32_t bpc = (uint32_t)std::max<size_t>(1, std::min<size_t>(3, (160 * 1024) / lds_fast));
+            hipLaunchKernelGGL(k_skm_count_fast, dim3((uint32_t)std::min<uint64_t>(ctx->nparts, (uint64_t)ctx->num_cus * bpc)), dim3(SKM_CNT_BLOCK), lds_fast, st, (const uint4 *)L.d_skm_a,
+                               (const uint32_t *)L.d_pstart, (const uint32_t *)L.d_pcnt, sk, ctx->key, ctx->cfg.abundance_min, ctx->cfg.abundance_max, o, (const uint32_t *)flag, kocc,
+                               L.d_redo_list, L.d_redo_count);
+        }, st);
+    launch_timed(ctx, KID_COUNT, [&] {
+        const uint32_t grid = general_only ? (uint32_t)std::min<uint64_t>(ctx->nparts, (uint64_t)ctx->num_cus * 2) : (uint32_t)ctx->num_cus;
+        hipLaunchKernelGGL(k_skm_count, dim3(grid), dim3(SKM_CNT_BLOCK), lds_count, st, (const uint4 *)L.d_skm_a,
+                           (const uint32_t *)L.d_pstart, (const uint32_t *)L.d_pcnt, sk, ctx->key, ctx->cfg.abundance_min, ctx->cfg.abundance_max, o, (const uint32_t *)flag, kocc,
+                           general_only ? (const uint32_t *)nullptr : (const uint32_t *)L.d_redo_list, general_only ? (const ull *)nullptr : (const ull *)L.d_redo_count);
     }, st);
     HIPCHK(hipGetLastError());
     return SIMKA_OK;

@@ -32,6 +32,33 @@ typedef unsigned long long ull;
 // block-wide exclusive scan of a u32 array living in LDS (n items, in place); returns the total.
 // Caller must have synchronised after the last write to a[].  tmp has BLOCK entries.
 // --------------------------------------------------------------------------------------------
+// inclusive scan over the 64 lanes of a wave with DPP row shifts / broadcasts (VALU only: no LDS crossbar round trips)
+__device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v) {
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, false);      // row_shr:1
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, false);      // row_shr:2
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, false);      // row_shr:4
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, false);      // row_shr:8
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false);      // row_bcast:15 -> rows 1, 3
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false);      // row_bcast:31 -> rows 2, 3
+    return v;
+}
+
+// one value per thread: exclusive prefix over the block in `excl`, block total returned; ONE barrier (tmp: BLOCK/64 words,
+// not reused before the caller's next barrier)
+template <int BLOCK>
+__device__ __forceinline__ uint32_t block_excl_scan1(uint32_t v, uint32_t &excl, uint32_t *tmp) {
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    constexpr uint32_t NW = BLOCK / 64;
+    const uint32_t inc = wave_incl_scan(v);
+    if (lane == 63u) tmp[wave] = inc;
+    __syncthreads();
+    uint32_t wpre = 0, total = 0;
+#pragma unroll
+    for (uint32_t w = 0; w < NW; w++) { const uint32_t t = tmp[w]; if (w < wave) wpre += t; total += t; }
+    excl = wpre + inc - v;
+    return total;
+}
+
 template <int BLOCK>
 __device__ __forceinline__ uint32_t block_excl_scan(uint32_t *a, uint32_t n, uint32_t *tmp) {
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;

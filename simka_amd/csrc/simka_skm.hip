@@ -37,6 +37,7 @@ typedef unsigned long long ull;
 #define SKM_OWN_HI (SKM_TILE - 32)
 #define SKM_STRIDE (SKM_OWN_HI - SKM_OWN_LO)
 #define SKM_BLOCK 512
+#define SKM_NT (SKM_BLOCK + 4)    // thread columns of the chunk-major hash array (4 pad columns)
 #define SKM_SEG 16               // entries per thread
 #define SKM_CAPREC 2048          // records staged in LDS per tile (more: written one by one)
 #define SKM_MAXW 20
@@ -91,8 +92,11 @@ __global__ void __launch_bounds__(SKM_BLOCK)
 k_skm_scan(SimkaScanArgs a, SimkaSkmCfg cfg, ull *b1_count, ull *b1_cursor, uint4 *l1_recs, const ull *b1_limit, uint32_t *ovf_flag) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     uint32_t &s_nrec = *(uint32_t *)(smem + 0);
-    uint32_t *hm = (uint32_t *)(smem + SIMKA_LDS_HEAD);             // [TILE + 32] m-mer hashes; after phase 2: partition ids of the k-mers
-    uint32_t *tb = hm + SKM_TILE + 32;                              // [TILE/16 + 8] the tile's bases, 16 per word
+    // m-mer hashes, chunk-major: entry e = 16 t + 4 c + r lives at dword ((c * SKM_NT + t) * 4 + r), so the 16-byte accesses of
+    // consecutive lanes are consecutive in LDS (the thread-major layout made every wide access a 4-way bank conflict);
+    // after phase 2: partition ids of the k-mers
+    uint32_t *hm = (uint32_t *)(smem + SIMKA_LDS_HEAD);             // [4][SKM_NT][4]
+    uint32_t *tb = hm + 16 * SKM_NT;                              // [TILE/16 + 8] the tile's bases, 16 per word
     uint32_t *smask = tb + SKM_TILE / 16 + 8;                       // [BLOCK] start | brk << 16
     uint32_t *hist = smask + SKM_BLOCK + 4;                         // [B1]   (smask has 4 pad words: all-break)
     uint32_t *lcur = hist + 64;                                     // [B1]
@@ -148,10 +152,10 @@ k_skm_scan(SimkaScanArgs a, SimkaSkmCfg cfg, ull *b1_count, ull *b1_cursor, uint
             const uint32_t rv = __builtin_amdgcn_alignbit(r1_, r0_, 2 * (15 - q)) & cfg.mmask;
             hv[q] = skm_mm_hash(fw < rv ? fw : rv, cfg.mmask, cfg.m);
         }
-        uint4 *dst = (uint4 *)(hm + SKM_SEG * tid);
-        dst[0] = make_uint4(hv[0], hv[1], hv[2], hv[3]); dst[1] = make_uint4(hv[4], hv[5], hv[6], hv[7]);
-        dst[2] = make_uint4(hv[8], hv[9], hv[10], hv[11]); dst[3] = make_uint4(hv[12], hv[13], hv[14], hv[15]);
-        if (tid < 8) ((uint4 *)(hm + SKM_TILE))[tid] = make_uint4(~0u, ~0u, ~0u, ~0u);       // pad read by the last threads
+        uint4 *dst = (uint4 *)hm;
+        dst[0 * SKM_NT + tid] = make_uint4(hv[0], hv[1], hv[2], hv[3]); dst[1 * SKM_NT + tid] = make_uint4(hv[4], hv[5], hv[6], hv[7]);
+        dst[2 * SKM_NT + tid] = make_uint4(hv[8], hv[9], hv[10], hv[11]); dst[3 * SKM_NT + tid] = make_uint4(hv[12], hv[13], hv[14], hv[15]);
+        if (tid < 16) dst[(tid >> 2) * SKM_NT + SKM_BLOCK + (tid & 3u)] = make_uint4(~0u, ~0u, ~0u, ~0u);       // pad columns read by the last threads
     }
     __syncthreads();
 
@@ -161,9 +165,15 @@ k_skm_scan(SimkaScanArgs a, SimkaSkmCfg cfg, ull *b1_count, ull *b1_cursor, uint
     {
         constexpr int NH = 40;                              // H[x] = hm[16t - 4 + x]; window j covers x in [3 + j, 3 + j + W)
         uint32_t H[NH];
-        const uint4 *src = (const uint4 *)(hm + (tid ? SKM_SEG * tid - 4 : 0));      // (thread 0 owns nothing: any in-range address)
+        // chunks (t-1, 3), (t, 0..3), (t+1, 0..3), (t+2, 0)
+        const uint4 *src = (const uint4 *)hm;
+        const uint32_t tm = tid ? tid - 1u : 0u;             // (thread 0 owns nothing: any in-range column)
 #pragma unroll
-        for (int x = 0; x < NH / 4; x++) { const uint4 v = src[x]; H[4 * x] = v.x; H[4 * x + 1] = v.y; H[4 * x + 2] = v.z; H[4 * x + 3] = v.w; }
+        for (int x = 0; x < NH / 4; x++) {
+            const int cc = (x + 3) & 3, dt = (x + 3) / 4;    // x = 0 -> (t-1, 3); x = 1..4 -> (t, 0..3); ...
+            const uint4 v = src[cc * SKM_NT + tm + dt];
+            H[4 * x] = v.x; H[4 * x + 1] = v.y; H[4 * x + 2] = v.z; H[4 * x + 3] = v.w;
+        }
         static_assert(3 + SKM_SEG + SKM_MAXW <= NH, "window fits the loaded values");
         // suffix minima up to the end of each W-aligned block, prefix minima from its start
         uint32_t suf[NH], pre[NH];
@@ -244,7 +254,7 @@ k_skm_scan(SimkaScanArgs a, SimkaSkmCfg cfg, ull *b1_count, ull *b1_cursor, uint
         // the partition ids of my k-mers go where my hashes were
         if (owner) {
 #pragma unroll
-            for (int j = 1; j <= SKM_SEG; j++) hm[SKM_SEG * tid + j - 1] = skm_pid(mh[j], cfg.pb);
+            for (int j = 1; j <= SKM_SEG; j++) hm[(((j - 1) >> 2) * SKM_NT + tid) * 4 + ((j - 1) & 3)] = skm_pid(mh[j], cfg.pb);
         }
         __syncthreads();           // every thread has read the masks of its predecessors
         if (forced) { start |= 1u; brk |= 1u; smask[tid] = start | (brk << 16); }
@@ -260,7 +270,7 @@ k_skm_scan(SimkaScanArgs a, SimkaSkmCfg cfg, ull *b1_count, ull *b1_cursor, uint
             const ull look = ((ull)(brk >> (jb + 1u))) | (n1 << (15u - jb)) | (n2 << (31u - jb)) | (n3 << (47u - jb));
             uint32_t len = (uint32_t)__ffsll((long long)look);       // look != 0: a break within 48 positions is guaranteed
             uint32_t e = SKM_SEG * tid + jb;
-            const uint32_t pid = hm[e];
+            const uint32_t pid = hm[((((e & 15u) >> 2) * SKM_NT + (e >> 4)) << 2) | (e & 3u)];
             if (!skm_owns(pid, cfg)) continue;
             while (len) {
                 const uint32_t n = len < cfg.nmax ? len : cfg.nmax;
@@ -318,10 +328,11 @@ k_skm_scan(SimkaScanArgs a, SimkaSkmCfg cfg, ull *b1_count, ull *b1_cursor, uint
 // --------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256)
 k_skm_layout(ull *b1_count, ull *b1_start, ull *b1_limit, ull *b1_cursor, uint32_t *chunk_first, uint32_t B1, uint32_t mode, ull cap,
-             ull *arena_cursor, ull *sample_base, uint32_t first_pass, const uint32_t *skip_flag, uint32_t *cnt2, uint32_t ncnt2) {
+             ull *arena_cursor, ull *sample_base, uint32_t first_pass, const uint32_t *skip_flag, uint32_t *cnt2, uint32_t ncnt2, ull *redo_count) {
     __shared__ ull s_cnt[64];
     __shared__ uint32_t s_ch[65];
     const uint32_t tid = threadIdx.x;
+    if (mode != 2u && tid == 0) *redo_count = 0ull;
     if (mode == 1u) {
         if (tid < B1) { b1_start[tid] = (ull)tid * cap; b1_cursor[tid] = (ull)tid * cap; b1_limit[tid] = (ull)(tid + 1) * cap; }
         if (tid == 0 && first_pass) *sample_base = *arena_cursor;
@@ -494,7 +505,7 @@ __device__ __forceinline__ uint64_t skm_kmer_at(const uint4 &r, uint32_t j, cons
 
 __global__ void __launch_bounds__(SKM_CNT_BLOCK)
 k_skm_count(const uint4 *recs, const uint32_t *pstart, const uint32_t *pcnt, SimkaSkmCfg cfg, SimkaKeyCfg kcfg, uint32_t amin, uint32_t amax, SimkaCountOut o,
-            const uint32_t *flag, ull *kocc_owned) {
+            const uint32_t *flag, ull *kocc_owned, const uint32_t *part_list, const ull *part_count) {
     if (*flag) return;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     ull *s_tot = (ull *)smem;                          // [5] D_all, D, N, Q, K_occ of the whole block
@@ -523,7 +534,9 @@ k_skm_count(const uint4 *recs, const uint32_t *pstart, const uint32_t *pcnt, Sim
     ull bt_dall = 0, bt_D = 0, bt_N = 0, bt_Q = 0, bt_kocc = 0;
     __syncthreads();
 
-    for (uint32_t part = blockIdx.x; part < nparts; part += gridDim.x) {
+    const uint32_t nwork = part_list ? (uint32_t)(*part_count < (ull)nparts ? *part_count : (ull)nparts) : nparts;
+    for (uint32_t wi_ = blockIdx.x; wi_ < nwork; wi_ += gridDim.x) {
+        const uint32_t part = part_list ? part_list[wi_] : wi_;
         const uint32_t nrec = pcnt[part];
         if (nrec == 0) continue;                       // (foff / fcnt of the sample were zeroed by the host)
         const uint32_t rbase = pstart[part];
@@ -651,6 +664,246 @@ k_skm_count(const uint4 *recs, const uint32_t *pstart, const uint32_t *pcnt, Sim
         }
         __syncthreads();
     }
+    if (o.hist) {
+        __syncthreads();
+        for (uint32_t i = tid; i < SIMKA_HIST_MAX; i += SKM_CNT_BLOCK)
+            if (lhist[i]) atomicAdd(&o.hist[(size_t)o.sample * SIMKA_HIST_MAX + i], (ull)lhist[i]);
+    }
+    if (bt_dall) atomicAdd(&s_tot[0], bt_dall);
+    if (bt_D) { atomicAdd(&s_tot[1], bt_D); atomicAdd(&s_tot[2], bt_N); atomicAdd(&s_tot[3], bt_Q); }
+    if (bt_kocc) atomicAdd(&s_tot[4], bt_kocc);
+    __syncthreads();
+    if (tid == 0) {
+        ull *t = o.totals + o.sample;
+        const size_t ns_ = o.nb_samples;
+        if (s_tot[0]) atomicAdd(&t[SIMKA_TOT_DALL * ns_], s_tot[0]);
+        if (s_tot[1]) { atomicAdd(&t[SIMKA_TOT_D * ns_], s_tot[1]); atomicAdd(&t[SIMKA_TOT_N * ns_], s_tot[2]); atomicAdd(&t[SIMKA_TOT_Q * ns_], s_tot[3]); }
+        if (s_tot[4] && kocc_owned) atomicAdd(kocc_owned, s_tot[4]);
+    }
+}
+
+
+// --------------------------------------------------------------------------------------------
+// k_skm_count_fast: the common case of k_skm_count -- the partition's distinct k-mers fit the table in ONE round.
+//   * every wave expands its own 64 records (wave-private LDS copy of the records + map; no block barrier until all inserts are in);
+//   * the records of the NEXT partition are loaded (registers) before the summary of this one;
+//   * arena slab state double-buffered in LDS, so the emit needs no barrier of its own.
+// A partition whose inserts overflow a sort block of the table goes to the redo list (k_skm_count takes it in rounds).
+// --------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(SKM_CNT_BLOCK)
+k_skm_count_fast(const uint4 *recs, const uint32_t *pstart, const uint32_t *pcnt, SimkaSkmCfg cfg, SimkaKeyCfg kcfg, uint32_t amin, uint32_t amax, SimkaCountOut o,
+                 const uint32_t *flag, ull *kocc_owned, uint32_t *redo_list, ull *redo_count) {
+    if (*flag) return;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    ull *s_tot = (ull *)smem;                          // [5]
+    ull &s_base = *(ull *)(smem + 48);
+    uint32_t &s_fail = *(uint32_t *)(smem + 56);
+    uint32_t &s_ok = *(uint32_t *)(smem + 60);
+    ull *s_slab = (ull *)(smem + 64);                  // [2][2] (pos, end), double-buffered by iteration parity
+    uint32_t *tmp = (uint32_t *)(smem + 128);          // [BLOCK/64]
+    constexpr uint32_t TS = SKM_CNT_TS, SPT = TS / SKM_CNT_BLOCK, TSL = 12, NW = SKM_CNT_BLOCK / 64;
+    ull *tkeys = (ull *)(smem + SIMKA_LDS_HEAD);       // [TS]
+    uint32_t *tcnt = (uint32_t *)(tkeys + TS);         // [TS]
+    uint4 *lrec = (uint4 *)(tcnt + TS);                // [BLOCK]: 64 per wave
+    uint32_t *spos = (uint32_t *)(lrec + SKM_CNT_BLOCK);     // [BLOCK]
+    uint32_t *lhist = spos + SKM_CNT_BLOCK;            // [SIMKA_HIST_MAX] (complex only)
+    uint16_t *map = (uint16_t *)(lhist + (o.hist ? SIMKA_HIST_MAX : 0));     // [NW][64 * nmax]
+
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    const uint32_t nparts = 1u << cfg.pb;
+    const ull sample_base = *o.sample_base;
+    for (uint32_t i = tid; i < TS; i += SKM_CNT_BLOCK) { tkeys[i] = SIMKA_EMPTY_KEY; tcnt[i] = 0; }
+    if (o.hist) for (uint32_t i = tid; i < SIMKA_HIST_MAX; i += SKM_CNT_BLOCK) lhist[i] = 0;
+    if (tid < 5) s_tot[tid] = 0;
+    if (tid < 4) s_slab[tid] = 0;
+    if (tid == 0) s_fail = 0;
+    ull bt_dall = 0, bt_D = 0, bt_N = 0, bt_Q = 0, bt_kocc = 0;
+    PH_DECL
+    uint4 *wrec = lrec + wave * 64u;
+    uint16_t *wmap = map + wave * (64u * cfg.nmax);
+    constexpr uint32_t bmask = (TS >> SKM_SORT_BITS) - 1u;        // probing stays inside the 128-slot sort block
+
+    uint32_t part = blockIdx.x, iter = 0;
+    uint32_t nrec = 0, rbase = 0;
+    uint4 pre = make_uint4(0, 0, 0, 0);
+    auto prefetch = [&](uint32_t n_, uint32_t rb_) {
+        const uint32_t nb = n_ < (uint32_t)SKM_CNT_BLOCK ? n_ : (uint32_t)SKM_CNT_BLOCK;
+        const uint32_t per = (nb + NW - 1u) / NW;
+        if (lane < per && wave * per + lane < nb) pre = recs[rb_ + wave * per + lane];
+    };
+    if (part < nparts) { nrec = pcnt[part]; rbase = pstart[part]; prefetch(nrec, rbase); }
+    __syncthreads();
+    while (part < nparts) {
+        const uint32_t next = part + gridDim.x;
+        uint32_t nrec_n = 0, rbase_n = 0;
+        if (next < nparts) { nrec_n = pcnt[next]; rbase_n = pstart[next]; }
+        if (nrec == 0) {
+            part = next; nrec = nrec_n; rbase = rbase_n;
+            prefetch(nrec, rbase);
+            continue;
+        }
+        // ---- expand + insert: every wave takes an equal share of the records (at most 64 per batch)
+        PH(0)
+        ull my_k = 0;
+        for (uint32_t b0 = 0; b0 < nrec; b0 += SKM_CNT_BLOCK) {
+            const uint32_t nb = nrec - b0 < (uint32_t)SKM_CNT_BLOCK ? nrec - b0 : (uint32_t)SKM_CNT_BLOCK;
+            const uint32_t per = (nb + NW - 1u) / NW;                       // records of this wave: [b0 + wave*per, +per)
+            const uint32_t i = b0 + wave * per + lane;
+            const bool mine = lane < per && wave * per + lane < nb;
+            uint4 rc = pre;
+            if (b0) { if (mine) rc = recs[rbase + i]; }
+            uint32_t len = mine ? skm_rec_n(rc) : 0u;
+            wrec[lane] = rc;
+            const uint32_t x = wave_incl_scan(len);
+            const uint32_t kt = __builtin_amdgcn_readlane(x, 63);
+            const uint32_t off = x - len;
+            for (uint32_t j = 0; j < len; j++) wmap[off + j] = (uint16_t)((lane << 5) | j);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            if (lane == 0) my_k += kt;
+            PH(1)
+            // two k-mers per lane and iteration: their LDS round trips (map, record, CAS) overlap
+            for (uint32_t f = lane; f < kt; f += 128u) {
+                const bool two = f + 64u < kt;
+                const uint32_t e0 = wmap[f], e1 = wmap[two ? f + 64u : f];
+                const uint4 rx0 = wrec[e0 >> 5], rx1 = wrec[e1 >> 5];
+                const uint64_t fw0 = skm_kmer_at(rx0, e0 & 31u, cfg), fw1 = skm_kmer_at(rx1, e1 & 31u, cfg);
+                const uint64_t rv0 = skm_revcomp64(fw0) >> (64u - 2u * cfg.k), rv1 = skm_revcomp64(fw1) >> (64u - 2u * cfg.k);
+                const ull c0 = fw0 < rv0 ? fw0 : rv0, c1 = fw1 < rv1 ? fw1 : rv1;
+                uint32_t s0 = skm_kmer_hash(c0) >> (32u - TSL), s1 = skm_kmer_hash(c1) >> (32u - TSL);
+                const ull p0 = atomicCAS(&tkeys[s0], SIMKA_EMPTY_KEY, c0);
+                ull p1 = c1;
+                if (two) p1 = atomicCAS(&tkeys[s1], SIMKA_EMPTY_KEY, c1);
+                bool ok0 = p0 == SIMKA_EMPTY_KEY || p0 == c0, ok1 = !two || p1 == SIMKA_EMPTY_KEY || p1 == c1;
+                if (ok0) atomicAdd(&tcnt[s0], 1u);
+                if (two && ok1) atomicAdd(&tcnt[s1], 1u);
+                if (!ok0) {       // first slot taken by another k-mer: probe on inside the sort block
+                    const uint32_t bbase = s0 & ~bmask;
+                    for (uint32_t probe = 1; probe <= bmask && !ok0; probe++) {
+                        s0 = bbase | ((s0 + 1u) & bmask);
+                        const ull prev = atomicCAS(&tkeys[s0], SIMKA_EMPTY_KEY, c0);
+                        if (prev == SIMKA_EMPTY_KEY || prev == c0) { atomicAdd(&tcnt[s0], 1u); ok0 = true; }
+                    }
+                    if (!ok0) s_fail = 1u;
+                }
+                if (!ok1) {
+                    const uint32_t bbase = s1 & ~bmask;
+                    for (uint32_t probe = 1; probe <= bmask && !ok1; probe++) {
+                        s1 = bbase | ((s1 + 1u) & bmask);
+                        const ull prev = atomicCAS(&tkeys[s1], SIMKA_EMPTY_KEY, c1);
+                        if (prev == SIMKA_EMPTY_KEY || prev == c1) { atomicAdd(&tcnt[s1], 1u); ok1 = true; }
+                    }
+                    if (!ok1) s_fail = 1u;
+                }
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // the wave's map / records are rewritten by the next batch
+            PH(2)
+        }
+        __syncthreads();
+        PH(3)
+        // ---- the next partition's records travel while this one is summarised
+        {
+            const uint32_t nb = nrec_n < (uint32_t)SKM_CNT_BLOCK ? nrec_n : (uint32_t)SKM_CNT_BLOCK;
+            const uint32_t per = (nb + NW - 1u) / NW;
+            if (lane < per && wave * per + lane < nb) pre = recs[rbase_n + wave * per + lane];
+        }
+        // ---- summary in slot order (SimkaCompressedProcessor::process, ref: src/minikc/MiniKC.hpp:54-79)
+        uint32_t cs[SPT]; ull ks[SPT];
+        uint32_t nsol = 0, ndall = 0;
+        ull D = 0, N = 0, Q = 0;
+        {   // the thread's 8 slots: vector loads, then the slots are reset unconditionally (vector stores, no branches)
+            static_assert(SPT == 8, "8 slots per thread");
+            uint4 *c4 = (uint4 *)(tcnt + tid * SPT); ulonglong2 *k2 = (ulonglong2 *)(tkeys + tid * SPT);
+            const uint4 ca = c4[0], cb = c4[1];
+            const ulonglong2 ka = k2[0], kb = k2[1], kc = k2[2], kd = k2[3];
+            const uint4 z = make_uint4(0, 0, 0, 0); const ulonglong2 ek = make_ulonglong2(SIMKA_EMPTY_KEY, SIMKA_EMPTY_KEY);
+            c4[0] = z; c4[1] = z; k2[0] = ek; k2[1] = ek; k2[2] = ek; k2[3] = ek;
+            cs[0] = ca.x; cs[1] = ca.y; cs[2] = ca.z; cs[3] = ca.w; cs[4] = cb.x; cs[5] = cb.y; cs[6] = cb.z; cs[7] = cb.w;
+            ks[0] = ka.x; ks[1] = ka.y; ks[2] = kb.x; ks[3] = kb.y; ks[4] = kc.x; ks[5] = kc.y; ks[6] = kd.x; ks[7] = kd.y;
+        }
+#pragma unroll
+        for (uint32_t q = 0; q < SPT; q++) {
+            const uint32_t c = cs[q];
+            const bool any = c != 0u, sol = any && !(c < amin || c > amax);
+            ndall += any ? 1u : 0u;
+            nsol += sol ? 1u : 0u;
+            D += sol ? 1ull : 0ull; N += sol ? (ull)c : 0ull; Q += sol ? (ull)c * (ull)c : 0ull;
+            cs[q] = sol ? c : 0u;
+        }
+        const bool failed = s_fail != 0u;
+        // the wave's solid records, in slot order, go to its (now idle) map region: keys [0, cap), counts behind them
+        const uint32_t wcap = (64u * cfg.nmax * 2u) / 12u;                        // records the region takes
+        ull *wk = (ull *)wmap; uint32_t *wc = (uint32_t *)(wk + wcap);
+        const uint32_t winc = wave_incl_scan(nsol);
+        const uint32_t wtot = __builtin_amdgcn_readlane(winc, 63);
+        const bool staged = wtot <= wcap;
+        if (staged) {
+            uint32_t p = winc - nsol;
+#pragma unroll
+            for (uint32_t q = 0; q < SPT; q++) if (cs[q]) { wk[p] = ks[q]; wc[p] = cs[q]; p++; }
+        }
+        PH(4)
+        const uint32_t par = iter & 1u;
+        iter++;
+        // block-level offsets of the waves (one barrier)
+        if (lane == 63u) tmp[par * 16u + wave] = winc;
+        __syncthreads();
+        uint32_t wpre = 0, total = 0;
+#pragma unroll
+        for (uint32_t w = 0; w < NW; w++) { const uint32_t t = tmp[par * 16u + w]; if (w < wave) wpre += t; total += t; }
+        PH(5)
+        const ull sp_ = s_slab[par * 2u], se_ = s_slab[par * 2u + 1u];
+        const bool fits = !failed && (total == 0 || (sp_ + total <= se_ && sp_ - sample_base + total <= 0xffffffffull));
+        ull base_ = sample_base;
+        bool ok_ = !failed;
+        if (fits) {
+            if (total) base_ = sp_;
+            if (tid == 0) { s_slab[(par ^ 1u) * 2u] = sp_ + total; s_slab[(par ^ 1u) * 2u + 1u] = se_; }
+            if (tid == 64) o.foff[part] = (uint32_t)(base_ - sample_base);
+            if (tid == 128) o.fcnt[part] = total;
+        } else {
+            if (tid == 0) {
+                uint32_t ok = 1;
+                ull slab_pos = sp_, slab_end = se_;
+                if (failed) { const ull w = atomicAdd(redo_count, 1ull); redo_list[w] = part; ok = 0; s_fail = 0u; }
+                else {
+                    const ull bb = slab_take(slab_pos, slab_end, total, o, sample_base, ok);
+                    o.foff[part] = ok ? (uint32_t)(bb - sample_base) : 0u;
+                    o.fcnt[part] = ok ? total : 0u;
+                    s_base = bb;
+                }
+                s_slab[(par ^ 1u) * 2u] = slab_pos; s_slab[(par ^ 1u) * 2u + 1u] = slab_end;
+                s_ok = ok;
+            }
+            __syncthreads();
+            base_ = s_base; ok_ = s_ok != 0;
+        }
+        PH(6)
+        if (ok_) {
+            bt_dall += ndall; bt_D += D; bt_N += N; bt_Q += Q; bt_kocc += my_k;
+            if (staged) {      // one record per lane: coalesced stores, one key mix per record
+                for (uint32_t r = lane; r < wtot; r += 64u) {
+                    const ull key = wk[r]; const uint32_t c = wc[r];
+                    const ull pos = base_ + wpre + r;
+                    o.solid_keys[pos] = simka_mix(key, kcfg.mask, kcfg.xs); o.solid_counts[pos] = c;
+                    if (o.hist) count_hist(o, lhist, c);
+                }
+            } else {
+                ull pos = base_ + wpre + winc - nsol;
+#pragma unroll
+                for (uint32_t q = 0; q < SPT; q++) {
+                    if (cs[q]) {
+                        o.solid_keys[pos] = simka_mix(ks[q], kcfg.mask, kcfg.xs); o.solid_counts[pos] = cs[q]; pos++;
+                        if (o.hist) count_hist(o, lhist, cs[q]);
+                    }
+                }
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // the staging region becomes the wave's map again
+        PH(7)
+        part = next; nrec = nrec_n; rbase = rbase_n;
+    }
+    PH_FLUSH
     if (o.hist) {
         __syncthreads();
         for (uint32_t i = tid; i < SIMKA_HIST_MAX; i += SKM_CNT_BLOCK)
