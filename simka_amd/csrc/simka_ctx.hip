@@ -242,7 +242,7 @@ static ScanFn scan_kernel(bool scatter, bool fixed, bool sharded) {
     return t[(scatter ? 4 : 0) | (fixed ? 2 : 0) | (sharded ? 1 : 0)];
 }
 
-using SkmScanFn = void (*)(SimkaScanArgs, SimkaSkmCfg, ull *, ull *, uint4 *, const ull *, uint32_t *);
+using SkmScanFn = void (*)(SimkaScanArgs, SimkaSkmCfg, ull *, ull *, uint4 *, const ull *, uint32_t *, uint32_t);
 static int skm_w_index(uint32_t W) { switch (W) { case 1: return 0; case 4: return 1; case 8: return 2; case 12: return 3; case 16: return 4; default: return 5; } }
 static SkmScanFn skm_scan_kernel(int wi, bool fixed, bool hist) {
 #define SKM_ROW(W) { k_skm_scan<W, false, false>, k_skm_scan<W, false, true>, k_skm_scan<W, true, false>, k_skm_scan<W, true, true> }
@@ -321,7 +321,9 @@ static int setup_geometry(simka_ctx *ctx, uint64_t max_kmers) {
     const uint32_t N = c.nb_samples;
     // SIMKA_LANES=2 alternates samples between two streams with private scratch (+4 % end to end on C2/C3: the kernels
     // of neighbouring samples overlap); the default single lane keeps per-kernel timings free of overlap.
-    static const bool two_lanes = getenv("SIMKA_LANES") && atoi(getenv("SIMKA_LANES")) >= 2;
+    // samples alternate between two streams with private scratch: the scan of one sample overlaps the count of another (the
+    // kernels are bound by different things: c3_10 212.7 -> 181.9 ms/step); SIMKA_LANES=1 keeps per-kernel timings free of overlap
+    static const bool two_lanes = !(getenv("SIMKA_LANES") && atoi(getenv("SIMKA_LANES")) < 2);
     ctx->nlanes = (two_lanes && c.nb_samples >= 2) ? 2u : 1u;
     for (uint32_t li = 0; li < ctx->nlanes; li++) {
         simka_ctx::Lane &L = ctx->lanes[li];
@@ -721,7 +723,7 @@ static int run_count_skm(simka_ctx *ctx, uint32_t sample, const SimkaScanArgs &a
     const int wi = skm_w_index(sk.W);
     const bool fixed = a.fixed_len != 0;
     auto scan_lds = [&](bool hist) {
-        return (size_t)SIMKA_LDS_HEAD + (size_t)16 * SKM_NT * 4 + (SKM_TILE / 16 + 8) * 4 + (SKM_BLOCK + 4) * 4 + 64 * 4 * 2 + 64 * 8 + (fixed ? 0 : SKM_RTAB * 4) + (hist ? 0 : (size_t)caprec * 16);
+        return (size_t)SIMKA_LDS_HEAD + (size_t)16 * SKM_NT * 4 + (SKM_TILE / 16 + 8) * 4 + (SKM_BLOCK + 4) * 4 + 64 * 4 * 2 + 64 * 8 + (fixed ? 0 : SKM_RTAB * 4) + (size_t)SKM_TILE * 2 + (hist ? 0 : (size_t)caprec * 16);
     };
     auto layout = [&](uint32_t mode, ull capb) {
         launch_timed(ctx, KID_LAYOUT, [&] {
@@ -734,7 +736,7 @@ static int run_count_skm(simka_ctx *ctx, uint32_t sample, const SimkaScanArgs &a
             SimkaSkmCfg skc = sk;
             skc.nmax = sk.nmax; skc.pb = sk.pb;
             hipLaunchKernelGGL(skm_scan_kernel(wi, fixed, hist), dim3(ntiles), dim3(SKM_BLOCK), scan_lds(hist), st, a, skc, L.d_b1_count, L.d_b1_cursor, L.d_skm_a, limit,
-                               hist ? (uint32_t *)nullptr : flag);
+                               hist ? (uint32_t *)nullptr : flag, caprec);
         }, st);
     };
     uint64_t rec_cap;

@@ -39,7 +39,6 @@ typedef unsigned long long ull;
 #define SKM_BLOCK 512
 #define SKM_NT (SKM_BLOCK + 4)    // thread columns of the chunk-major hash array (4 pad columns)
 #define SKM_SEG 16               // entries per thread
-#define SKM_CAPREC 2048          // records staged in LDS per tile (more: written one by one)
 #define SKM_MAXW 20
 #define SKM_RTAB 2048            // variable-length reads: read starts of one tile staged in LDS
 #define SKM_CHUNK 2048           // records per chunk of the level-2 kernels
@@ -89,9 +88,10 @@ __device__ __forceinline__ uint64_t skm_revcomp64(uint64_t x) {
 // --------------------------------------------------------------------------------------------
 template <int W, bool FIXED, bool HIST>
 __global__ void __launch_bounds__(SKM_BLOCK)
-k_skm_scan(SimkaScanArgs a, SimkaSkmCfg cfg, ull *b1_count, ull *b1_cursor, uint4 *l1_recs, const ull *b1_limit, uint32_t *ovf_flag) {
+k_skm_scan(SimkaScanArgs a, SimkaSkmCfg cfg, ull *b1_count, ull *b1_cursor, uint4 *l1_recs, const ull *b1_limit, uint32_t *ovf_flag, uint32_t caprec) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    uint32_t &s_nrec = *(uint32_t *)(smem + 0);
+    uint32_t &s_nrec = *(uint32_t *)(smem + 0);        // extra records of long runs (beyond the first of a start)
+    uint32_t &s_nstart = *(uint32_t *)(smem + 4);
     // m-mer hashes, chunk-major: entry e = 16 t + 4 c + r lives at dword ((c * SKM_NT + t) * 4 + r), so the 16-byte accesses of
     // consecutive lanes are consecutive in LDS (the thread-major layout made every wide access a 4-way bank conflict);
     // after phase 2: partition ids of the k-mers
@@ -102,12 +102,13 @@ k_skm_scan(SimkaScanArgs a, SimkaSkmCfg cfg, ull *b1_count, ull *b1_cursor, uint
     uint32_t *lcur = hist + 64;                                     // [B1]
     ull *gbase = (ull *)(lcur + 64);                                // [B1]
     uint32_t *rtab = (uint32_t *)(gbase + 64);                      // [SKM_RTAB] (!FIXED)
-    uint4 *stage = (uint4 *)(rtab + (FIXED ? 0 : SKM_RTAB));        // [CAPREC] (!HIST)
+    uint16_t *slist = (uint16_t *)(rtab + (FIXED ? 0 : SKM_RTAB));  // [TILE] entry indices of the run starts
+    uint4 *stage = (uint4 *)(slist + SKM_TILE);                     // [caprec] (!HIST)
 
     const uint32_t tid = threadIdx.x;
     const uint32_t B1 = 1u << cfg.l1;
     const long long Q0 = 32ll * ((long long)SKM_STRIDE / 32 * (long long)blockIdx.x - 1);     // base position of entry 0
-    if (tid == 0) s_nrec = 0;
+    if (tid == 0) { s_nrec = 0; s_nstart = 0; }
     if (tid < 64) { hist[tid] = 0; lcur[tid] = 0; }
     if (tid < 4) smask[SKM_BLOCK + tid] = 0xffff0000u;
     // ---- stage the tile's bases: 64-bit words Q0/32 .. (+ TILE/32 + 2)
@@ -260,38 +261,50 @@ k_skm_scan(SimkaScanArgs a, SimkaSkmCfg cfg, ull *b1_count, ull *b1_cursor, uint
         if (forced) { start |= 1u; brk |= 1u; smask[tid] = start | (brk << 16); }
     }
     __syncthreads();               // (B)
-    // ---- phase 3b: one record per <= nmax k-mers of every run that starts here
-    if (owner) {
-        const ull n1 = smask[tid + 1] >> 16, n2 = smask[tid + 2] >> 16, n3 = (smask[tid + 3] >> 16) & 1u;     // (tid + 3 <= 512: one pad word)
-        uint32_t todo = start;
-        while (todo) {
-            const uint32_t jb = __ffs(todo) - 1u;         // bit index: entry e = 16t + jb
-            todo &= todo - 1u;
-            const ull look = ((ull)(brk >> (jb + 1u))) | (n1 << (15u - jb)) | (n2 << (31u - jb)) | (n3 << (47u - jb));
-            uint32_t len = (uint32_t)__ffsll((long long)look);       // look != 0: a break within 48 positions is guaranteed
-            uint32_t e = SKM_SEG * tid + jb;
-            const uint32_t pid = hm[((((e & 15u) >> 2) * SKM_NT + (e >> 4)) << 2) | (e & 3u)];
-            if (!skm_owns(pid, cfg)) continue;
-            while (len) {
-                const uint32_t n = len < cfg.nmax ? len : cfg.nmax;
-                if (HIST) atomicAdd(&hist[cfg.pb ? pid >> (cfg.pb - cfg.l1) : 0u], 1u);
-                else {
-                    const uint32_t wi = e >> 4, sh = (e & 15u) * 2u;
-                    const uint32_t c0 = tb[wi], c1 = tb[wi + 1], c2 = tb[wi + 2], c3 = tb[wi + 3], c4 = tb[wi + 4];
-                    uint4 rec;
-                    rec.x = __builtin_amdgcn_alignbit(c1, c0, sh); rec.y = __builtin_amdgcn_alignbit(c2, c1, sh);
-                    rec.z = __builtin_amdgcn_alignbit(c3, c2, sh);
-                    rec.w = (__builtin_amdgcn_alignbit(c4, c3, sh) & 63u) | ((n - 1u) << 6) | (pid << 11);
-                    const uint32_t slot = atomicAdd(&s_nrec, 1u);
-                    const uint32_t b1 = cfg.pb ? pid >> (cfg.pb - cfg.l1) : 0u;
-                    if (slot < SKM_CAPREC) { stage[slot] = rec; atomicAdd(&hist[b1], 1u); }
-                    else {      // staging full (pathological tile): one global atomic per record
-                        const ull g = atomicAdd(&b1_cursor[b1], 1ull);
-                        if (b1_limit && g + 1 > b1_limit[b1]) *ovf_flag = 1u; else l1_recs[g] = rec;
-                    }
+    // ---- phase 3b: the run starts of the tile as one list (entry indices), then ONE LANE PER START: a thread with five starts no
+    // longer holds its wave back
+    {
+        const uint32_t ns = owner ? (uint32_t)__popc(start) : 0u;
+        const uint32_t inc = wave_incl_scan(ns);
+        uint32_t wb = 0;
+        if ((tid & 63u) == 63u && inc) wb = atomicAdd(&s_nstart, inc);
+        wb = __builtin_amdgcn_readlane(wb, 63);
+        uint32_t p = wb + inc - ns, todo = owner ? start : 0u;
+        while (todo) { slist[p++] = (uint16_t)(SKM_SEG * tid + __ffs(todo) - 1u); todo &= todo - 1u; }
+    }
+    __syncthreads();
+    const uint32_t nstart = s_nstart;
+    for (uint32_t si = tid; si < nstart; si += SKM_BLOCK) {
+        uint32_t e = slist[si];
+        const uint32_t t_ = e >> 4, jb = e & 15u;
+        const uint32_t own_ = smask[t_] >> 16;
+        const ull n1 = smask[t_ + 1] >> 16, n2 = smask[t_ + 2] >> 16, n3 = (smask[t_ + 3] >> 16) & 1u;
+        const ull look = ((ull)(own_ >> (jb + 1u))) | (n1 << (15u - jb)) | (n2 << (31u - jb)) | (n3 << (47u - jb));
+        uint32_t len = (uint32_t)__ffsll((long long)look);       // look != 0: a break within 48 positions is guaranteed
+        const uint32_t pid = hm[((((e & 15u) >> 2) * SKM_NT + (e >> 4)) << 2) | (e & 3u)];
+        if (!skm_owns(pid, cfg)) { if (!HIST && si < caprec) stage[si] = make_uint4(~0u, ~0u, ~0u, ~0u); continue; }
+        const uint32_t b1 = cfg.pb ? pid >> (cfg.pb - cfg.l1) : 0u;
+        bool first = true;
+        while (len) {
+            const uint32_t n = len < cfg.nmax ? len : cfg.nmax;
+            if (HIST) atomicAdd(&hist[b1], 1u);
+            else {
+                const uint32_t wi = e >> 4, sh = (e & 15u) * 2u;
+                const uint32_t c0 = tb[wi], c1 = tb[wi + 1], c2 = tb[wi + 2], c3 = tb[wi + 3], c4 = tb[wi + 4];
+                uint4 rec;
+                rec.x = __builtin_amdgcn_alignbit(c1, c0, sh); rec.y = __builtin_amdgcn_alignbit(c2, c1, sh);
+                rec.z = __builtin_amdgcn_alignbit(c3, c2, sh);
+                rec.w = (__builtin_amdgcn_alignbit(c4, c3, sh) & 63u) | ((n - 1u) << 6) | (pid << 11);
+                // the first record of start si takes staging slot si; the (rare) further ones of a long run take slots from the top
+                const uint32_t slot = first ? si : caprec - 1u - atomicAdd(&s_nrec, 1u);
+                if (slot < caprec && (first || slot >= nstart)) { stage[slot] = rec; atomicAdd(&hist[b1], 1u); }
+                else {      // staging full (pathological tile): one global atomic per record
+                    const ull g = atomicAdd(&b1_cursor[b1], 1ull);
+                    if (b1_limit && g + 1 > b1_limit[b1]) *ovf_flag = 1u; else l1_recs[g] = rec;
                 }
-                e += n; len -= n;
             }
+            first = false;
+            e += n; len -= n;
         }
     }
     __syncthreads();               // (C)
@@ -310,9 +323,13 @@ k_skm_scan(SimkaScanArgs a, SimkaSkmCfg cfg, ull *b1_count, ull *b1_cursor, uint
         gbase[tid] = g;
     }
     __syncthreads();
-    const uint32_t nrec = s_nrec < SKM_CAPREC ? s_nrec : SKM_CAPREC;
-    for (uint32_t i = tid; i < nrec; i += SKM_BLOCK) {
-        const uint4 rec = stage[i];
+    // staged: slots [0, min(nstart, caprec)) (a start of a foreign shard left its slot empty: w == ~0) and the extra records at the top
+    const uint32_t nlow = nstart < caprec ? nstart : caprec;
+    const uint32_t nextra = s_nrec, room = caprec - nlow;
+    const uint32_t nhigh = nextra < room ? nextra : room;
+    for (uint32_t i = tid; i < nlow + nhigh; i += SKM_BLOCK) {
+        const uint4 rec = stage[i < nlow ? i : caprec - 1u - (i - nlow)];
+        if (rec.w == ~0u && rec.x == ~0u) continue;
         const uint32_t b1 = cfg.pb ? skm_rec_pid(rec) >> (cfg.pb - cfg.l1) : 0u;
         const ull g = gbase[b1];
         const uint32_t rk = atomicAdd(&lcur[b1], 1u);
