@@ -20,10 +20,10 @@
 
 // kernel ids for the profiler
 enum { KID_SCAN_HIST = 0, KID_LAYOUT, KID_SCAN_SCATTER, KID_SPLIT, KID_COUNT_FAST, KID_COUNT, KID_PART_TOTALS, KID_REGROUP, KID_GROUP,
-       KID_PAIRS, KID_PAIRS_GLOBAL, KID_SKM_SCAN, KID_SKM_HIST2, KID_SKM_SCATTER2, KID_SKM_SPLIT3, KID_SKM_COUNT, KID_NB };
+       KID_PAIRS, KID_PAIRS_GLOBAL, KID_SKM_SCAN, KID_SKM_SPLIT, KID_SKM_COUNT, KID_NB };
 static const char *const KID_NAMES[KID_NB] = { "k_scan<hist>", "k_layout", "k_scan<scatter>", "k_split", "k_count_fast", "k_count",
                                                "k_part_totals", "k_regroup", "k_group", "k_pairs", "k_pairs_global",
-                                               "k_skm_scan", "k_skm_hist2", "k_skm_scatter2", "k_skm_split3", "k_skm_count" };
+                                               "k_skm_scan", "k_skm_split", "k_skm_count" };
 
 static thread_local std::string g_create_error;
 
@@ -55,7 +55,7 @@ struct simka_ctx {
         uint32_t *d_redo_list = nullptr; ull *d_redo_count = nullptr;   // partitions k_count_fast hands to k_count
         // super-k-mer pipeline: two record buffers (level 1 / level 3 share one), level-2 counters, partition table
         uint4 *d_skm_a = nullptr, *d_skm_b = nullptr; uint64_t skm_a_cap = 0, skm_b_cap = 0;
-        uint32_t *d_cnt2 = nullptr, *d_start2 = nullptr, *d_cursor2 = nullptr, *d_pstart = nullptr, *d_pcnt = nullptr;
+        uint32_t *d_pstart = nullptr, *d_pcnt = nullptr;
     };
     Lane lanes[2];
     uint32_t nlanes = 2;
@@ -269,6 +269,7 @@ static int set_lds_attr(simka_ctx *ctx) {
     HIPCHK(hipFuncSetAttribute((const void *)k_pairs_tm, hipFuncAttributeMaxDynamicSharedMemorySize, big));
     for (int wi = 0; wi < 6; wi++) for (int v = 0; v < 4; v++) HIPCHK(hipFuncSetAttribute((const void *)skm_scan_kernel(wi, v & 2, v & 1), hipFuncAttributeMaxDynamicSharedMemorySize, big));
     HIPCHK(hipFuncSetAttribute((const void *)k_skm_count, hipFuncAttributeMaxDynamicSharedMemorySize, big));
+    HIPCHK(hipFuncSetAttribute((const void *)k_skm_split, hipFuncAttributeMaxDynamicSharedMemorySize, big));
     HIPCHK(hipFuncSetAttribute((const void *)k_skm_count_fast, hipFuncAttributeMaxDynamicSharedMemorySize, big));
     return SIMKA_OK;
 }
@@ -308,13 +309,13 @@ static int setup_geometry(simka_ctx *ctx, uint64_t max_kmers) {
     if (l2 > 11) { l2 = 11; }
     k.l1 = l1; k.l2 = l2; k.pb = l1 + l2; k.t = 0;
     ctx->B1 = 1u << l1; ctx->B2 = 1u << l2; ctx->nparts = (uint64_t)1 << k.pb;
-    {   // super-k-mer pipeline: the same partition count over three levels (64 x <= 512 x 32)
+    {   // super-k-mer pipeline: the same partition count over two levels (<= 256 level-1 buckets x <= 4096 partitions each)
         SimkaSkmCfg &sk = ctx->skm;
         sk.pb = k.pb;
-        sk.l1 = std::min<uint32_t>(sk.pb, 6);
-        sk.l3 = std::min<uint32_t>(sk.pb - sk.l1, 5);
-        sk.l2 = sk.pb - sk.l1 - sk.l3;
-        if (sk.l2 > 9) return ctx->fail(SIMKA_ERR_INVALID, "log2_partitions %u is beyond the three partitioning levels", sk.pb);
+        static const uint32_t l1_env = getenv("SIMKA_SKM_L1") ? (uint32_t)atoi(getenv("SIMKA_SKM_L1")) : 8u;      // experiments
+        sk.l1 = std::min<uint32_t>(sk.pb, std::min<uint32_t>(l1_env, 8u));
+        sk.l2 = sk.pb - sk.l1; sk.l3 = 0;
+        if (sk.l2 > 12) return ctx->fail(SIMKA_ERR_INVALID, "log2_partitions %u is beyond the two partitioning levels", sk.pb);
         ctx->B1 = ctx->use_skm ? (1u << sk.l1) : ctx->B1;
     }
 
@@ -338,11 +339,7 @@ static int setup_geometry(simka_ctx *ctx, uint64_t max_kmers) {
         HIPCHK(dev_alloc(&L.d_spill_cursor, 2));
         HIPCHK(dev_alloc(&L.d_redo_list, ctx->nparts + 1));
         HIPCHK(dev_alloc(&L.d_redo_count, 2));
-        if (ctx->use_skm) {
-            const uint64_t nsb = (uint64_t)1 << (ctx->skm.l1 + ctx->skm.l2);
-            HIPCHK(dev_alloc(&L.d_cnt2, nsb + 1)); HIPCHK(dev_alloc(&L.d_start2, nsb + 2)); HIPCHK(dev_alloc(&L.d_cursor2, nsb + 1));
-            HIPCHK(dev_alloc(&L.d_pstart, ctx->nparts + 1)); HIPCHK(dev_alloc(&L.d_pcnt, ctx->nparts + 1));
-        }
+        if (ctx->use_skm) { HIPCHK(dev_alloc(&L.d_pstart, ctx->nparts + 1)); HIPCHK(dev_alloc(&L.d_pcnt, ctx->nparts + 1)); }
     }
     HIPCHK(dev_alloc(&ctx->d_l1_ovf, c.nb_samples + 1));
     HIPCHK(hipMemsetAsync(ctx->d_l1_ovf, 0, (size_t)(c.nb_samples + 1) * 4, ctx->stream));
@@ -400,13 +397,16 @@ SIMKA_EXPORT int simka_create(const simka_config *cfg, simka_ctx **out) {
     k.k = cfg->kmer_size; k.W = 2 * cfg->kmer_size; k.mask = k.W >= 64 ? ~0ull : (1ull << k.W) - 1ull; k.xs = (k.W + 1) / 2;      // (hash path: W <= 62)
     k.shard_index = cfg->shard_index; k.shard_count = cfg->shard_count;
     if (!want_wide) {
-        // minimizer geometry: W m-mers per k-mer from {20,16,12,8,4}, the largest that leaves m = k - W + 1 >= 10 (k <= 12: every
-        // k-mer is its own minimizer); a record holds n + k - 1 <= 51 bases
+        // minimizer geometry: W m-mers per k-mer from {20,16,12,8,4}, the largest that leaves m = k - W + 1 >= 14 (k < 17: every
+        // k-mer is its own minimizer).  m must be large: the partition is a function of the minimizer, so 4^m / 2 minimizer
+        // classes -- of which only the low-hash tenth ever wins a window -- have to spread over up to 2^20 partitions (m = 12
+        // on C3's 2^19 partitions: one or two heavy classes per partition, sizes all over the place, 10 % of the partitions redone).
+        // A record holds n + k - 1 <= 51 bases.
         SimkaSkmCfg &sk = ctx->skm;
         memset(&sk, 0, sizeof sk);
         sk.k = cfg->kmer_size;
         sk.W = 1;
-        for (uint32_t w : { 20u, 16u, 12u, 8u, 4u }) if (sk.k >= w + 9u) { sk.W = w; break; }
+        for (uint32_t w : { 20u, 16u, 12u, 8u, 4u }) if (sk.k >= w + 13u) { sk.W = w; break; }
         sk.m = sk.k - sk.W + 1;
         sk.nmax = std::min<uint32_t>(32u, 52u - sk.k);
         sk.mmask = (uint32_t)((1ull << (2 * sk.m)) - 1ull);
@@ -454,7 +454,7 @@ SIMKA_EXPORT void simka_destroy(simka_ctx *ctx) {
         if (L.stream) (void)hipStreamSynchronize(L.stream);
         void *lp[] = { L.d_l1, L.d_b1_count, L.d_b1_start, L.d_b1_end, L.d_b1_cursor, L.d_chunk_first, L.d_tile_r0, L.d_l2, L.d_p_count, L.d_p_valid,
                        L.d_spill_keys, L.d_spill_runs, L.d_spill_cursor, L.d_redo_list, L.d_redo_count,
-                       L.d_skm_a, L.d_skm_b, L.d_cnt2, L.d_start2, L.d_cursor2, L.d_pstart, L.d_pcnt };
+                       L.d_skm_a, L.d_skm_b, L.d_pstart, L.d_pcnt };
         for (void *q : lp) if (q) (void)hipFree(q);
         if (L.stream) (void)hipStreamDestroy(L.stream);
     }
@@ -647,7 +647,7 @@ static int run_count_kernels(simka_ctx *ctx, uint32_t sample, const SimkaScanArg
     o.solid_keys = ctx->d_solid_keys; o.solid_counts = ctx->d_solid_counts;
     o.foff = ctx->d_foff + (uint64_t)sample * ctx->nparts; o.fcnt = ctx->d_fcnt + (uint64_t)sample * ctx->nparts;
     o.totals = (ull *)ctx->d_stats + stats_off_tot(N, ctx->cfg.dist_flags, 0); o.sample = sample; o.nb_samples = N; o.err = ctx->d_err;
-    o.phase = nullptr;
+    o.phase = nullptr; o.slab = 512; o.pad_ = 0;
 #ifdef SIMKA_PHASE_PROF
     {   // debug build: per-phase wall_clock64 ticks of thread 0 of every k_count_fast block, printed per sample
         static ull *d_phase = nullptr;
@@ -707,7 +707,6 @@ static int run_count_skm(simka_ctx *ctx, uint32_t sample, const SimkaScanArgs &a
     SimkaSkmCfg sk = ctx->skm;
     if (npass > 1) { sk.shard_index = ctx->skm.shard_index + ctx->skm.shard_count * pass; sk.shard_count = ctx->skm.shard_count * npass; }
     const uint32_t B1 = 1u << sk.l1;
-    const uint32_t nsb = 1u << (sk.l1 + sk.l2);
     const uint32_t ntiles = (uint32_t)((a.nb_bases + SKM_STRIDE - 1) / SKM_STRIDE);
     if (!a.fixed_len && a.nb_reads && ntiles) {
         rc = ensure_cap(ctx, &L.d_tile_r0, &L.tile_r0_cap, (uint64_t)ntiles + 2); if (rc) return rc;
@@ -723,12 +722,12 @@ static int run_count_skm(simka_ctx *ctx, uint32_t sample, const SimkaScanArgs &a
     const int wi = skm_w_index(sk.W);
     const bool fixed = a.fixed_len != 0;
     auto scan_lds = [&](bool hist) {
-        return (size_t)SIMKA_LDS_HEAD + (size_t)16 * SKM_NT * 4 + (SKM_TILE / 16 + 8) * 4 + (SKM_BLOCK + 4) * 4 + 64 * 4 * 2 + 64 * 8 + (fixed ? 0 : SKM_RTAB * 4) + (size_t)SKM_TILE * 2 + (hist ? 0 : (size_t)caprec * 16);
+        return (size_t)SIMKA_LDS_HEAD + (size_t)16 * SKM_NT * 4 + (SKM_TILE / 16 + 8) * 4 + (SKM_BLOCK + 4) * 4 + SKM_MAXB1 * 4 * 2 + SKM_MAXB1 * 8 + (fixed ? 0 : SKM_RTAB * 4) + (size_t)SKM_TILE * 2 + (hist ? 0 : (size_t)caprec * 16);
     };
     auto layout = [&](uint32_t mode, ull capb) {
         launch_timed(ctx, KID_LAYOUT, [&] {
-            hipLaunchKernelGGL(k_skm_layout, dim3(1), dim3(256), 0, st, L.d_b1_count, L.d_b1_start, L.d_b1_end, L.d_b1_cursor, L.d_chunk_first, B1, mode, capb,
-                               ctx->d_arena_cursor, ctx->d_sample_base + sample, pass == 0 ? 1u : 0u, (const uint32_t *)flag, L.d_cnt2, nsb, L.d_redo_count);
+            hipLaunchKernelGGL(k_skm_layout, dim3(1), dim3(SKM_MAXB1), 0, st, L.d_b1_count, L.d_b1_start, L.d_b1_end, L.d_b1_cursor, B1, mode, capb,
+                               ctx->d_arena_cursor, ctx->d_sample_base + sample, pass == 0 ? 1u : 0u, (const uint32_t *)flag, L.d_redo_count);
         }, st);
     };
     auto scan = [&](bool hist, const ull *limit) {
@@ -767,26 +766,21 @@ static int run_count_skm(simka_ctx *ctx, uint32_t sample, const SimkaScanArgs &a
         scan(false, (const ull *)L.d_b1_end);
     }
     if (rec_cap >= 0xffffffffull) return ctx->fail(SIMKA_ERR_OVERFLOW, "a sample needs more than 2^32 super-k-mer record slots in one pass");
-    const uint32_t grid2 = (uint32_t)ctx->num_cus * 4;
-    launch_timed(ctx, KID_SKM_HIST2, [&] {
-        hipLaunchKernelGGL(k_skm_hist2, dim3(grid2), dim3(SKM_L2_BLOCK), 0, st, (const uint4 *)L.d_skm_a, (const ull *)L.d_b1_start, (const ull *)L.d_b1_count,
-                           (const uint32_t *)L.d_chunk_first, sk, L.d_cnt2, (const uint32_t *)flag);
-        hipLaunchKernelGGL(k_skm_scan_counts, dim3(1), dim3(1024), 0, st, (const uint32_t *)L.d_cnt2, nsb, L.d_start2, L.d_cursor2, (const uint32_t *)flag);
-    }, st);
-    launch_timed(ctx, KID_SKM_SCATTER2, [&] {
-        hipLaunchKernelGGL(k_skm_scatter2, dim3(grid2), dim3(SKM_L2_BLOCK), 0, st, (const uint4 *)L.d_skm_a, (const ull *)L.d_b1_start, (const ull *)L.d_b1_count,
-                           (const uint32_t *)L.d_chunk_first, sk, L.d_cursor2, L.d_skm_b, (const uint32_t *)flag);
-    }, st);
-    launch_timed(ctx, KID_SKM_SPLIT3, [&] {
-        hipLaunchKernelGGL(k_skm_split3, dim3(std::min<uint32_t>(nsb, grid2)), dim3(SKM_L2_BLOCK), 0, st, (const uint4 *)L.d_skm_b, (const uint32_t *)L.d_start2, sk,
-                           L.d_skm_a, L.d_pstart, L.d_pcnt, (const uint32_t *)flag);
+    launch_timed(ctx, KID_SKM_SPLIT, [&] {
+        const size_t lds_split = ((size_t)1 << sk.l2) * 4 + 64 + ((size_t)1 << sk.l2) * 2 + 16 + (size_t)SKM_SPLIT_BLOCK * SKM_SPLIT_UNROLL * 16;
+        hipLaunchKernelGGL(k_skm_split, dim3(B1), dim3(SKM_SPLIT_BLOCK), lds_split, st, (const uint4 *)L.d_skm_a, (const ull *)L.d_b1_start, (const ull *)L.d_b1_count, sk,
+                           L.d_skm_b, L.d_pstart, L.d_pcnt, (const uint32_t *)flag);
     }, st);
     SimkaCountOut o;
     o.arena_cursor = ctx->d_arena_cursor; o.sample_base = ctx->d_sample_base + sample; o.arena_cap = ctx->arena_cap;
     o.solid_keys = ctx->d_solid_keys; o.solid_counts = ctx->d_solid_counts;
     o.foff = ctx->d_foff + (uint64_t)sample * ctx->nparts; o.fcnt = ctx->d_fcnt + (uint64_t)sample * ctx->nparts;
     o.totals = (ull *)ctx->d_stats + stats_off_tot(N, ctx->cfg.dist_flags, 0); o.sample = sample; o.nb_samples = N; o.err = ctx->d_err;
-    o.phase = nullptr;
+    o.phase = nullptr; o.pad_ = 0;
+    // slabs several partitions long (what is left of a slab when the next partition does not fit is lost), but never more than a
+    // small share of the arena per block
+    o.slab = (uint32_t)std::min<uint64_t>(std::min<uint64_t>(K2_SLAB, std::max<uint64_t>(256, kocc_up / 10 / ((uint64_t)ctx->num_cus * 4 * 8))),
+                                          std::max<uint64_t>(64, ctx->arena_cap / ((uint64_t)ctx->num_cus * 4 * 8)));
     o.hist = ctx->d_hist; o.ovf_list = ctx->d_ovf_list; o.ovf_cursor = ctx->d_ovf_cursor; o.ovf_cap = ctx->ovf_cap;
     ull *kocc = (ull *)ctx->d_stats + stats_off_tot(N, ctx->cfg.dist_flags, SIMKA_TOT_KOCC) + sample;
 #ifdef SIMKA_PHASE_PROF
@@ -804,19 +798,20 @@ static int run_count_skm(simka_ctx *ctx, uint32_t sample, const SimkaScanArgs &a
     }
 #endif
     const size_t hist_lds = ctx->d_hist ? (size_t)SIMKA_HIST_MAX * 4 : 0;
-    const size_t lds_fast = (size_t)SIMKA_LDS_HEAD + (size_t)SKM_CNT_TS * 12 + (size_t)SKM_CNT_BLOCK * 16 + (size_t)SKM_CNT_BLOCK * 4 + hist_lds + (size_t)SKM_CNT_BLOCK * sk.nmax * 2 + 64;
+    const size_t lds_fast = (size_t)SIMKA_LDS_HEAD + (size_t)SKM_FAST_TS * 12 + (size_t)SKM_FAST_BLOCK * 16 + hist_lds + (size_t)SKM_FAST_BLOCK * sk.nmax * 2 + 64;
     const size_t lds_count = (size_t)SIMKA_LDS_HEAD + (size_t)SKM_CNT_TS * 12 + (size_t)SKM_CNT_BATCH * 16 + (size_t)SKM_CNT_BLOCK * 4 + hist_lds + (size_t)SKM_CNT_BATCH * sk.nmax * 2 + 64;
     static const bool general_only = getenv("SIMKA_SKM_GENERAL") != nullptr;      // tests: every partition through the general kernel
     if (!general_only)
         launch_timed(ctx, KID_SKM_COUNT, [&] {
-            const uint32_t bpc = (uint32_t)std::max<size_t>(1, std::min<size_t>(3, (160 * 1024) / lds_fast));
-            hipLaunchKernelGGL(k_skm_count_fast, dim3((uint32_t)std::min<uint64_t>(ctx->nparts, (uint64_t)ctx->num_cus * bpc)), dim3(SKM_CNT_BLOCK), lds_fast, st, (const uint4 *)L.d_skm_a,
+            static const uint32_t bpc_env = getenv("SIMKA_SKM_BPC") ? (uint32_t)atoi(getenv("SIMKA_SKM_BPC")) : 0u;     // experiments
+            const uint32_t bpc = bpc_env ? bpc_env : (uint32_t)std::max<size_t>(1, std::min<size_t>(4, (160 * 1024) / lds_fast));
+            hipLaunchKernelGGL(k_skm_count_fast, dim3((uint32_t)std::min<uint64_t>(ctx->nparts, (uint64_t)ctx->num_cus * bpc)), dim3(SKM_FAST_BLOCK), lds_fast, st, (const uint4 *)L.d_skm_b,
                                (const uint32_t *)L.d_pstart, (const uint32_t *)L.d_pcnt, sk, ctx->key, ctx->cfg.abundance_min, ctx->cfg.abundance_max, o, (const uint32_t *)flag, kocc,
                                L.d_redo_list, L.d_redo_count);
         }, st);
     launch_timed(ctx, KID_COUNT, [&] {
         const uint32_t grid = general_only ? (uint32_t)std::min<uint64_t>(ctx->nparts, (uint64_t)ctx->num_cus * 2) : (uint32_t)ctx->num_cus;
-        hipLaunchKernelGGL(k_skm_count, dim3(grid), dim3(SKM_CNT_BLOCK), lds_count, st, (const uint4 *)L.d_skm_a,
+        hipLaunchKernelGGL(k_skm_count, dim3(grid), dim3(SKM_CNT_BLOCK), lds_count, st, (const uint4 *)L.d_skm_b,
                            (const uint32_t *)L.d_pstart, (const uint32_t *)L.d_pcnt, sk, ctx->key, ctx->cfg.abundance_min, ctx->cfg.abundance_max, o, (const uint32_t *)flag, kocc,
                            general_only ? (const uint32_t *)nullptr : (const uint32_t *)L.d_redo_list, general_only ? (const ull *)nullptr : (const ull *)L.d_redo_count);
     }, st);

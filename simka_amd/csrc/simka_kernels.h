@@ -23,7 +23,8 @@
 #define K2F_TABLE_SMALL 2048  // slots (24 KB): when the first sample shows mostly repeated k-mers (high coverage)
 #define K2F_PROBES 128         // k_count_fast: probes before a key gives up (table too small -> next kernel of the cascade)
 #define K2F_UNROLL 8          // keys prefetched per thread: partitions up to BLOCK*UNROLL = 4096 keys take the fast path
-#define K2_SLAB 512           // arena records reserved per global atomic by a k_count block
+#define K2_SLAB 4096          // arena records reserved per global atomic by a count block (a partition's solid records stay contiguous:
+                              // what is left of a slab when the next partition does not fit is lost, so slabs are several partitions long)
 #ifndef K2_UNROLL
 #define K2_UNROLL 8
 #endif
@@ -92,6 +93,7 @@ struct SimkaCountOut {
     uint32_t *foff, *fcnt;                   // this sample's rows [nparts]
     unsigned long long *totals;              // [SIMKA_NB_TOTALS][N]
     uint32_t sample, nb_samples;
+    uint32_t slab, pad_;                     // arena records a block reserves at a time
     uint32_t *err;
     unsigned long long *phase;               // debug phase timers (SIMKA_PHASE_PROF builds), else NULL
     unsigned long long *hist;                // [N][SIMKA_HIST_MAX] histogram of solid counts, NULL unless complex

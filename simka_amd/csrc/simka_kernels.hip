@@ -525,7 +525,7 @@ __device__ __forceinline__ bool table_insert_capped(KT *tkeys, uint32_t *tcnt, u
 // reserve `ns` arena records for one partition out of the block's private slab (thread 0 only)
 __device__ __forceinline__ ull slab_take(ull &slab_pos, ull &slab_end, uint32_t ns, const SimkaCountOut &o, ull sample_base, uint32_t &ok) {
     if (slab_pos + ns > slab_end) {
-        const ull want = ns > (uint32_t)K2_SLAB ? (ull)ns : (ull)K2_SLAB;
+        const ull want = ns > o.slab ? (ull)ns : (ull)o.slab;
         slab_pos = atomicAdd(o.arena_cursor, want);
         slab_end = slab_pos + want;
         if (slab_end > o.arena_cap) { atomicOr(o.err, SIMKA_DEVERR_ARENA_FULL); ok = 0; slab_end = slab_pos; return 0; }

@@ -37,6 +37,7 @@ typedef unsigned long long ull;
 #define SKM_OWN_HI (SKM_TILE - 32)
 #define SKM_STRIDE (SKM_OWN_HI - SKM_OWN_LO)
 #define SKM_BLOCK 512
+#define SKM_MAXB1 256            // level-1 buckets at most
 #define SKM_NT (SKM_BLOCK + 4)    // thread columns of the chunk-major hash array (4 pad columns)
 #define SKM_SEG 16               // entries per thread
 #define SKM_MAXW 20
@@ -46,7 +47,9 @@ typedef unsigned long long ull;
 #define SKM_CNT_BLOCK 512
 #define SKM_CNT_TS 4096          // slots of the count kernel's LDS table
 #define SKM_CNT_BATCH 256        // records expanded per batch
-#define SKM_SORT_BITS 5          // solid records leave the count kernel ordered by the top 5 bits of the slot hash
+#define SKM_FAST_BLOCK 256       // k_skm_count_fast: 4 waves, 2048 slots, four blocks per CU
+#define SKM_FAST_TS 2048
+#define SKM_SORT_BITS 3          // solid records leave the count kernel ordered by the top 3 bits of the slot hash
 #define SKM_NSORT (1 << SKM_SORT_BITS)
 
 struct SimkaSkmCfg {
@@ -99,9 +102,9 @@ k_skm_scan(SimkaScanArgs a, SimkaSkmCfg cfg, ull *b1_count, ull *b1_cursor, uint
     uint32_t *tb = hm + 16 * SKM_NT;                              // [TILE/16 + 8] the tile's bases, 16 per word
     uint32_t *smask = tb + SKM_TILE / 16 + 8;                       // [BLOCK] start | brk << 16
     uint32_t *hist = smask + SKM_BLOCK + 4;                         // [B1]   (smask has 4 pad words: all-break)
-    uint32_t *lcur = hist + 64;                                     // [B1]
-    ull *gbase = (ull *)(lcur + 64);                                // [B1]
-    uint32_t *rtab = (uint32_t *)(gbase + 64);                      // [SKM_RTAB] (!FIXED)
+    uint32_t *lcur = hist + SKM_MAXB1;                              // [B1]
+    ull *gbase = (ull *)(lcur + SKM_MAXB1);                         // [B1]
+    uint32_t *rtab = (uint32_t *)(gbase + SKM_MAXB1);               // [SKM_RTAB] (!FIXED)
     uint16_t *slist = (uint16_t *)(rtab + (FIXED ? 0 : SKM_RTAB));  // [TILE] entry indices of the run starts
     uint4 *stage = (uint4 *)(slist + SKM_TILE);                     // [caprec] (!HIST)
 
@@ -109,7 +112,7 @@ k_skm_scan(SimkaScanArgs a, SimkaSkmCfg cfg, ull *b1_count, ull *b1_cursor, uint
     const uint32_t B1 = 1u << cfg.l1;
     const long long Q0 = 32ll * ((long long)SKM_STRIDE / 32 * (long long)blockIdx.x - 1);     // base position of entry 0
     if (tid == 0) { s_nrec = 0; s_nstart = 0; }
-    if (tid < 64) { hist[tid] = 0; lcur[tid] = 0; }
+    if (tid < SKM_MAXB1) { hist[tid] = 0; lcur[tid] = 0; }
     if (tid < 4) smask[SKM_BLOCK + tid] = 0xffff0000u;
     // ---- stage the tile's bases: 64-bit words Q0/32 .. (+ TILE/32 + 2)
     {
@@ -340,164 +343,146 @@ k_skm_scan(SimkaScanArgs a, SimkaSkmCfg cfg, ull *b1_count, ull *b1_cursor, uint
 // --------------------------------------------------------------------------------------------
 // k_skm_layout: level-1 bucket geometry, one block.
 //   mode 1 (before the capacity-sized scatter): bucket b owns [b*cap, (b+1)*cap)
-//   mode 2 (after it): counts from the cursors; chunk table for the level-2 kernels; zero the level-2 counters
-//   mode 0 (exact, after the histogram pass): starts from the counts, then as mode 2
+//   mode 2 (after it): counts from the cursors
+//   mode 0 (exact, after the histogram pass): starts from the counts
 // --------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256)
-k_skm_layout(ull *b1_count, ull *b1_start, ull *b1_limit, ull *b1_cursor, uint32_t *chunk_first, uint32_t B1, uint32_t mode, ull cap,
-             ull *arena_cursor, ull *sample_base, uint32_t first_pass, const uint32_t *skip_flag, uint32_t *cnt2, uint32_t ncnt2, ull *redo_count) {
-    __shared__ ull s_cnt[64];
-    __shared__ uint32_t s_ch[65];
+__global__ void __launch_bounds__(SKM_MAXB1)
+k_skm_layout(ull *b1_count, ull *b1_start, ull *b1_limit, ull *b1_cursor, uint32_t B1, uint32_t mode, ull cap,
+             ull *arena_cursor, ull *sample_base, uint32_t first_pass, const uint32_t *skip_flag, ull *redo_count) {
+    __shared__ ull s_cnt[SKM_MAXB1];
     const uint32_t tid = threadIdx.x;
     if (mode != 2u && tid == 0) *redo_count = 0ull;
     if (mode == 1u) {
         if (tid < B1) { b1_start[tid] = (ull)tid * cap; b1_cursor[tid] = (ull)tid * cap; b1_limit[tid] = (ull)(tid + 1) * cap; }
         if (tid == 0 && first_pass) *sample_base = *arena_cursor;
-        for (uint32_t i = tid; i < ncnt2; i += 256) cnt2[i] = 0;
         return;
     }
-    if (mode == 2u && skip_flag && *skip_flag) return;
-    if (tid < B1) s_cnt[tid] = mode == 0u ? b1_count[tid] : b1_cursor[tid] - b1_start[tid];
+    if (mode == 2u) {
+        if (skip_flag && *skip_flag) return;
+        if (tid < B1) b1_count[tid] = b1_cursor[tid] - b1_start[tid];
+        return;
+    }
+    if (tid < B1) s_cnt[tid] = b1_count[tid];
     __syncthreads();
     if (tid == 0) {
-        ull run = 0; uint32_t ch = 0;
-        for (uint32_t b = 0; b < B1; b++) {
-            const ull c = s_cnt[b];
-            if (mode == 0u) { b1_start[b] = run; b1_cursor[b] = run; b1_limit[b] = run + c; }
-            b1_count[b] = c;
-            s_ch[b] = ch;
-            ch += (uint32_t)((c + SKM_CHUNK - 1) / SKM_CHUNK);
-            run += c;
-        }
-        s_ch[B1] = ch;
-        if (mode == 0u && first_pass) *sample_base = *arena_cursor;
-    }
-    __syncthreads();
-    if (tid <= B1) chunk_first[tid] = s_ch[tid];
-    if (mode == 0u) for (uint32_t i = tid; i < ncnt2; i += 256) cnt2[i] = 0;
-}
-
-// chunk c of the level-1 buckets -> (first record, #records, bucket); thread 0, into s_chunk
-__device__ __forceinline__ void skm_locate(uint32_t c, const uint32_t *chunk_first, uint32_t B1, const ull *b1_start, const ull *b1_count, ull *s_chunk) {
-    uint32_t lo = 0, hi = B1;
-    while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (chunk_first[mid] <= c) lo = mid; else hi = mid; }
-    const ull off = (ull)(c - chunk_first[lo]) * SKM_CHUNK;
-    const ull n = b1_count[lo] - off;
-    s_chunk[0] = b1_start[lo] + off; s_chunk[1] = n < (ull)SKM_CHUNK ? n : (ull)SKM_CHUNK; s_chunk[2] = lo;
-}
-
-// k_skm_hist2: records per level-2 bucket (b1, b2), exact
-__global__ void __launch_bounds__(SKM_L2_BLOCK)
-k_skm_hist2(const uint4 *l1_recs, const ull *b1_start, const ull *b1_count, const uint32_t *chunk_first, SimkaSkmCfg cfg, uint32_t *cnt2, const uint32_t *flag) {
-    if (*flag) return;
-    __shared__ ull s_chunk[4];
-    __shared__ uint32_t lh[512];
-    const uint32_t tid = threadIdx.x, B1 = 1u << cfg.l1, F2 = 1u << cfg.l2;
-    const uint32_t nchunks = chunk_first[B1];
-    const uint32_t sh2 = cfg.l3, m2 = F2 - 1u;
-    for (uint32_t c = blockIdx.x; c < nchunks; c += gridDim.x) {
-        __syncthreads();
-        if (tid == 0) skm_locate(c, chunk_first, B1, b1_start, b1_count, s_chunk);
-        for (uint32_t i = tid; i < F2; i += SKM_L2_BLOCK) lh[i] = 0;
-        __syncthreads();
-        const ull st = s_chunk[0]; const uint32_t n = (uint32_t)s_chunk[1], b1 = (uint32_t)s_chunk[2];
-        for (uint32_t i = tid; i < n; i += SKM_L2_BLOCK) atomicAdd(&lh[(skm_rec_pid(l1_recs[st + i]) >> sh2) & m2], 1u);
-        __syncthreads();
-        for (uint32_t i = tid; i < F2; i += SKM_L2_BLOCK) if (lh[i]) atomicAdd(&cnt2[(b1 << cfg.l2) | i], lh[i]);
+        ull run = 0;
+        for (uint32_t b = 0; b < B1; b++) { const ull c = s_cnt[b]; b1_start[b] = run; b1_cursor[b] = run; b1_limit[b] = run + c; run += c; }
+        if (first_pass) *sample_base = *arena_cursor;
     }
 }
 
-// exclusive scan of n u32 counters (one block): start[i], cursor[i] = start[i]; start[n] = total
-__global__ void __launch_bounds__(1024)
-k_skm_scan_counts(const uint32_t *cnt, uint32_t n, uint32_t *start, uint32_t *cursor, const uint32_t *flag) {
+// --------------------------------------------------------------------------------------------
+// k_skm_split: level-1 bucket -> its 2^l2 partitions, exactly sized, ONE block per bucket.
+//   pass 1: stream the bucket, LDS histogram of the partitions (non-returning atomics) -> exclusive scan -> partition table;
+//   pass 2: stream it again, LDS cursor per partition (returning atomic = final position), 16-byte stores into the bucket's
+//           range of the output buffer.
+// 256 buckets x one 1024-thread block each: every CU streams its own bucket (8.8 MB on C3) twice and writes it once --
+// 3 passes over the records where the three-level scheme (count, scatter, count + scatter) needed 6.
+// --------------------------------------------------------------------------------------------
+#define SKM_SPLIT_BLOCK 1024
+#define SKM_SPLIT_UNROLL 8
+__global__ void __launch_bounds__(SKM_SPLIT_BLOCK)
+k_skm_split(const uint4 *l1_recs, const ull *b1_start, const ull *b1_count, SimkaSkmCfg cfg, uint4 *out_recs, uint32_t *pstart, uint32_t *pcnt, const uint32_t *flag) {
     if (*flag) return;
-    __shared__ uint32_t wsum[16];
-    __shared__ uint32_t s_carry;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    uint32_t *lh = (uint32_t *)smem;                   // [F2] counts, then cursors
+    uint32_t *wsum = lh + (1u << (cfg.pb - cfg.l1));   // [16]
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
-    if (tid == 0) s_carry = 0;
+    const uint32_t l2 = cfg.pb - cfg.l1, F2 = 1u << l2, m2 = F2 - 1u;
+    const uint32_t b1 = blockIdx.x;
+    const ull st = b1_start[b1];
+    const ull n = b1_count[b1];
+    for (uint32_t i = tid; i < F2; i += SKM_SPLIT_BLOCK) lh[i] = 0;
     __syncthreads();
-    for (uint32_t b0 = 0; b0 < n; b0 += 1024) {
-        const uint32_t i = b0 + tid;
-        const uint32_t v = i < n ? cnt[i] : 0u;
-        uint32_t x = v;
+    constexpr uint32_t STEP = SKM_SPLIT_BLOCK * SKM_SPLIT_UNROLL;
+    {
+        uint32_t w[SKM_SPLIT_UNROLL], wn[SKM_SPLIT_UNROLL];
 #pragma unroll
-        for (int o = 1; o < 64; o <<= 1) { const uint32_t t = __shfl_up(x, o, 64); if (lane >= (uint32_t)o) x += t; }
-        if (lane == 63u) wsum[wave] = x;
-        __syncthreads();
-        uint32_t wpre = 0, tot = 0;
+        for (int u = 0; u < SKM_SPLIT_UNROLL; u++) { const ull i = (ull)u * SKM_SPLIT_BLOCK + tid; w[u] = i < n ? l1_recs[st + i].w : 0u; }
+        for (ull i0 = 0; i0 < n; i0 += STEP) {
 #pragma unroll
-        for (uint32_t w = 0; w < 16; w++) { const uint32_t t = wsum[w]; if (w < wave) wpre += t; tot += t; }
-        const uint32_t ex = s_carry + wpre + x - v;
-        if (i < n) { start[i] = ex; cursor[i] = ex; }
-        __syncthreads();
-        if (tid == 0) s_carry += tot;
-        __syncthreads();
-    }
-    if (tid == 0) start[n] = s_carry;
-}
-
-// k_skm_scatter2: level-1 buckets -> level-2 buckets (exact starts): LDS rank per record, one global atomic per run
-__global__ void __launch_bounds__(SKM_L2_BLOCK)
-k_skm_scatter2(const uint4 *l1_recs, const ull *b1_start, const ull *b1_count, const uint32_t *chunk_first, SimkaSkmCfg cfg, uint32_t *cursor2,
-               uint4 *l2_recs, const uint32_t *flag) {
-    if (*flag) return;
-    __shared__ ull s_chunk[4];
-    __shared__ uint32_t lh[512];
-    __shared__ uint32_t lbase[512];
-    const uint32_t tid = threadIdx.x, B1 = 1u << cfg.l1, F2 = 1u << cfg.l2;
-    const uint32_t nchunks = chunk_first[B1];
-    const uint32_t sh2 = cfg.l3, m2 = F2 - 1u;
-    constexpr int PER = SKM_CHUNK / SKM_L2_BLOCK;
-    for (uint32_t c = blockIdx.x; c < nchunks; c += gridDim.x) {
-        __syncthreads();
-        if (tid == 0) skm_locate(c, chunk_first, B1, b1_start, b1_count, s_chunk);
-        for (uint32_t i = tid; i < F2; i += SKM_L2_BLOCK) lh[i] = 0;
-        __syncthreads();
-        const ull st = s_chunk[0]; const uint32_t n = (uint32_t)s_chunk[1], b1 = (uint32_t)s_chunk[2];
-        uint4 rec[PER]; uint32_t rk[PER];
+            for (int u = 0; u < SKM_SPLIT_UNROLL; u++) { const ull i = i0 + STEP + (ull)u * SKM_SPLIT_BLOCK + tid; wn[u] = i < n ? l1_recs[st + i].w : 0u; }
 #pragma unroll
-        for (int q = 0; q < PER; q++) { const uint32_t i = (uint32_t)q * SKM_L2_BLOCK + tid; if (i < n) rec[q] = l1_recs[st + i]; }
+            for (int u = 0; u < SKM_SPLIT_UNROLL; u++) { const ull i = i0 + (ull)u * SKM_SPLIT_BLOCK + tid; if (i < n) atomicAdd(&lh[(w[u] >> 11) & m2], 1u); }
 #pragma unroll
-        for (int q = 0; q < PER; q++) { const uint32_t i = (uint32_t)q * SKM_L2_BLOCK + tid; rk[q] = i < n ? atomicAdd(&lh[(skm_rec_pid(rec[q]) >> sh2) & m2], 1u) : 0u; }
-        __syncthreads();
-        for (uint32_t i = tid; i < F2; i += SKM_L2_BLOCK) { const uint32_t h = lh[i]; lbase[i] = h ? atomicAdd(&cursor2[(b1 << cfg.l2) | i], h) : 0u; }
-        __syncthreads();
-#pragma unroll
-        for (int q = 0; q < PER; q++) {
-            const uint32_t i = (uint32_t)q * SKM_L2_BLOCK + tid;
-            if (i < n) l2_recs[lbase[(skm_rec_pid(rec[q]) >> sh2) & m2] + rk[q]] = rec[q];
+            for (int u = 0; u < SKM_SPLIT_UNROLL; u++) w[u] = wn[u];
         }
     }
-}
-
-// k_skm_split3: one block per level-2 bucket: exact histogram of its 2^l3 partitions, then the scatter inside the bucket's range
-// (second read from L2 / Infinity Cache).  Writes the partition table (start, count).
-__global__ void __launch_bounds__(SKM_L2_BLOCK)
-k_skm_split3(const uint4 *l2_recs, const uint32_t *start2, SimkaSkmCfg cfg, uint4 *l3_recs, uint32_t *pstart, uint32_t *pcnt, const uint32_t *flag) {
-    if (*flag) return;
-    __shared__ uint32_t lh[64], lcur[64];
-    const uint32_t tid = threadIdx.x, F3 = 1u << cfg.l3, m3 = F3 - 1u;
-    const uint32_t nsb = 1u << (cfg.l1 + cfg.l2);
-    for (uint32_t sb = blockIdx.x; sb < nsb; sb += gridDim.x) {
+    __syncthreads();
+    // exclusive scan of lh[F2] (F2 <= 4096: up to 4 per thread), partition table, cursors
+    {
+        const uint32_t per = (F2 + SKM_SPLIT_BLOCK - 1) / SKM_SPLIT_BLOCK;          // 1, 2 or 4
+        uint32_t v[4] = { 0, 0, 0, 0 }, sum = 0;
+        for (uint32_t q = 0; q < per; q++) { const uint32_t i = tid * per + q; v[q] = i < F2 ? lh[i] : 0u; sum += v[q]; }
+        const uint32_t inc = wave_incl_scan(sum);
+        if (lane == 63u) wsum[wave] = inc;
         __syncthreads();
-        if (tid < 64) lh[tid] = 0;
-        __syncthreads();
-        const uint32_t s = start2[sb], n = start2[sb + 1] - s;
-        for (uint32_t i = tid; i < n; i += SKM_L2_BLOCK) atomicAdd(&lh[skm_rec_pid(l2_recs[s + i]) & m3], 1u);
-        __syncthreads();
-        if (tid < 64) {
-            const uint32_t v = tid < F3 ? lh[tid] : 0u;
-            uint32_t x = v;
+        uint32_t wpre = 0;
 #pragma unroll
-            for (int o = 1; o < 64; o <<= 1) { const uint32_t t = __shfl_up(x, o, 64); if (tid >= (uint32_t)o) x += t; }
-            if (tid < F3) { lcur[tid] = x - v; pstart[(sb << cfg.l3) | tid] = s + x - v; pcnt[(sb << cfg.l3) | tid] = v; }
+        for (uint32_t w_ = 0; w_ < SKM_SPLIT_BLOCK / 64; w_++) { const uint32_t t = wsum[w_]; if (w_ < wave) wpre += t; }
+        uint32_t run = wpre + inc - sum;
+        for (uint32_t q = 0; q < per; q++) {
+            const uint32_t i = tid * per + q;
+            if (i < F2) {
+                const uint32_t p = (b1 << l2) | i;
+                pstart[p] = (uint32_t)st + run; pcnt[p] = v[q];
+                lh[i] = run;
+                run += v[q];
+            }
+        }
+    }
+    __syncthreads();
+    // pass 2, chunk by chunk (STEP records): the chunk is ordered by partition in LDS first, so that what goes to one partition
+    // leaves as ONE run (direct 16-byte stores into 2048 open partitions were written back line by line: 3.7x the bytes)
+    uint16_t *ch = (uint16_t *)(wsum + 16);            // [F2] records of the chunk per partition, then their start in the staging area
+    uint4 *stage = (uint4 *)(((uintptr_t)(ch + F2 + 8) + 15u) & ~(uintptr_t)15u);             // [STEP]
+    for (ull i0 = 0; i0 < n; i0 += STEP) {
+        for (uint32_t i = tid; i < (F2 + 1) / 2; i += SKM_SPLIT_BLOCK) ((uint32_t *)ch)[i] = 0;
+        uint4 rec[SKM_SPLIT_UNROLL]; uint32_t lr[SKM_SPLIT_UNROLL];
+#pragma unroll
+        for (int u = 0; u < SKM_SPLIT_UNROLL; u++) { const ull i = i0 + (ull)u * SKM_SPLIT_BLOCK + tid; if (i < n) rec[u] = l1_recs[st + i]; }
+        __syncthreads();
+        // rank inside the chunk's run of the partition: 16-bit counters, two per word (the returning atomic works on the word)
+#pragma unroll
+        for (int u = 0; u < SKM_SPLIT_UNROLL; u++) {
+            const ull i = i0 + (ull)u * SKM_SPLIT_BLOCK + tid;
+            lr[u] = 0;
+            if (i < n) {
+                const uint32_t b2 = skm_rec_pid(rec[u]) & m2, sh = (b2 & 1u) * 16u;
+                lr[u] = (atomicAdd((uint32_t *)ch + (b2 >> 1), 1u << sh) >> sh) & 0xffffu;
+            }
         }
         __syncthreads();
-        for (uint32_t i = tid; i < n; i += SKM_L2_BLOCK) {
-            const uint4 rec = l2_recs[s + i];
-            const uint32_t rk = atomicAdd(&lcur[skm_rec_pid(rec) & m3], 1u);
-            l3_recs[s + rk] = rec;
+        {   // exclusive scan of the chunk histogram (F2 <= 4096 counters, <= 4 per thread)
+            const uint32_t per = (F2 + SKM_SPLIT_BLOCK - 1) / SKM_SPLIT_BLOCK;
+            uint32_t v[4] = { 0, 0, 0, 0 }, sum = 0;
+            for (uint32_t q = 0; q < per; q++) { const uint32_t i = tid * per + q; v[q] = i < F2 ? ch[i] : 0u; sum += v[q]; }
+            const uint32_t inc = wave_incl_scan(sum);
+            if (lane == 63u) wsum[wave] = inc;
+            __syncthreads();
+            uint32_t wpre = 0;
+#pragma unroll
+            for (uint32_t w_ = 0; w_ < SKM_SPLIT_BLOCK / 64; w_++) { const uint32_t t = wsum[w_]; if (w_ < wave) wpre += t; }
+            uint32_t run = wpre + inc - sum;
+            for (uint32_t q = 0; q < per; q++) { const uint32_t i = tid * per + q; if (i < F2) { ch[i] = (uint16_t)run; run += v[q]; } }
         }
+        __syncthreads();
+#pragma unroll
+        for (int u = 0; u < SKM_SPLIT_UNROLL; u++) {
+            const ull i = i0 + (ull)u * SKM_SPLIT_BLOCK + tid;
+            if (i < n) stage[ch[skm_rec_pid(rec[u]) & m2] + lr[u]] = rec[u];
+        }
+        __syncthreads();
+        const uint32_t nc = (uint32_t)(n - i0 < (ull)STEP ? n - i0 : (ull)STEP);
+        for (uint32_t sidx = tid; sidx < nc; sidx += SKM_SPLIT_BLOCK) {
+            const uint4 r = stage[sidx];
+            const uint32_t b2 = skm_rec_pid(r) & m2;
+            out_recs[st + lh[b2] + (sidx - ch[b2])] = r;
+        }
+        __syncthreads();
+        // the partitions' cursors move past this chunk: count of partition i = start of i + 1 (or the chunk's end) - start of i
+        for (uint32_t i = tid; i < F2; i += SKM_SPLIT_BLOCK) lh[i] += (i + 1 < F2 ? (uint32_t)ch[i + 1] : nc) - (uint32_t)ch[i];
+        __syncthreads();
     }
 }
 
@@ -707,7 +692,7 @@ k_skm_count(const uint4 *recs, const uint32_t *pstart, const uint32_t *pcnt, Sim
 //   * arena slab state double-buffered in LDS, so the emit needs no barrier of its own.
 // A partition whose inserts overflow a sort block of the table goes to the redo list (k_skm_count takes it in rounds).
 // --------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(SKM_CNT_BLOCK)
+__global__ void __launch_bounds__(SKM_FAST_BLOCK)
 k_skm_count_fast(const uint4 *recs, const uint32_t *pstart, const uint32_t *pcnt, SimkaSkmCfg cfg, SimkaKeyCfg kcfg, uint32_t amin, uint32_t amax, SimkaCountOut o,
                  const uint32_t *flag, ull *kocc_owned, uint32_t *redo_list, ull *redo_count) {
     if (*flag) return;
@@ -718,19 +703,18 @@ k_skm_count_fast(const uint4 *recs, const uint32_t *pstart, const uint32_t *pcnt
     uint32_t &s_ok = *(uint32_t *)(smem + 60);
     ull *s_slab = (ull *)(smem + 64);                  // [2][2] (pos, end), double-buffered by iteration parity
     uint32_t *tmp = (uint32_t *)(smem + 128);          // [BLOCK/64]
-    constexpr uint32_t TS = SKM_CNT_TS, SPT = TS / SKM_CNT_BLOCK, TSL = 12, NW = SKM_CNT_BLOCK / 64;
+    constexpr uint32_t TS = SKM_FAST_TS, SPT = TS / SKM_FAST_BLOCK, TSL = 11, NW = SKM_FAST_BLOCK / 64;
     ull *tkeys = (ull *)(smem + SIMKA_LDS_HEAD);       // [TS]
     uint32_t *tcnt = (uint32_t *)(tkeys + TS);         // [TS]
     uint4 *lrec = (uint4 *)(tcnt + TS);                // [BLOCK]: 64 per wave
-    uint32_t *spos = (uint32_t *)(lrec + SKM_CNT_BLOCK);     // [BLOCK]
-    uint32_t *lhist = spos + SKM_CNT_BLOCK;            // [SIMKA_HIST_MAX] (complex only)
+    uint32_t *lhist = (uint32_t *)(lrec + SKM_FAST_BLOCK);     // [SIMKA_HIST_MAX] (complex only)
     uint16_t *map = (uint16_t *)(lhist + (o.hist ? SIMKA_HIST_MAX : 0));     // [NW][64 * nmax]
 
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     const uint32_t nparts = 1u << cfg.pb;
     const ull sample_base = *o.sample_base;
-    for (uint32_t i = tid; i < TS; i += SKM_CNT_BLOCK) { tkeys[i] = SIMKA_EMPTY_KEY; tcnt[i] = 0; }
-    if (o.hist) for (uint32_t i = tid; i < SIMKA_HIST_MAX; i += SKM_CNT_BLOCK) lhist[i] = 0;
+    for (uint32_t i = tid; i < TS; i += SKM_FAST_BLOCK) { tkeys[i] = SIMKA_EMPTY_KEY; tcnt[i] = 0; }
+    if (o.hist) for (uint32_t i = tid; i < SIMKA_HIST_MAX; i += SKM_FAST_BLOCK) lhist[i] = 0;
     if (tid < 5) s_tot[tid] = 0;
     if (tid < 4) s_slab[tid] = 0;
     if (tid == 0) s_fail = 0;
@@ -744,7 +728,7 @@ k_skm_count_fast(const uint4 *recs, const uint32_t *pstart, const uint32_t *pcnt
     uint32_t nrec = 0, rbase = 0;
     uint4 pre = make_uint4(0, 0, 0, 0);
     auto prefetch = [&](uint32_t n_, uint32_t rb_) {
-        const uint32_t nb = n_ < (uint32_t)SKM_CNT_BLOCK ? n_ : (uint32_t)SKM_CNT_BLOCK;
+        const uint32_t nb = n_ < (uint32_t)SKM_FAST_BLOCK ? n_ : (uint32_t)SKM_FAST_BLOCK;
         const uint32_t per = (nb + NW - 1u) / NW;
         if (lane < per && wave * per + lane < nb) pre = recs[rb_ + wave * per + lane];
     };
@@ -762,8 +746,8 @@ k_skm_count_fast(const uint4 *recs, const uint32_t *pstart, const uint32_t *pcnt
         // ---- expand + insert: every wave takes an equal share of the records (at most 64 per batch)
         PH(0)
         ull my_k = 0;
-        for (uint32_t b0 = 0; b0 < nrec; b0 += SKM_CNT_BLOCK) {
-            const uint32_t nb = nrec - b0 < (uint32_t)SKM_CNT_BLOCK ? nrec - b0 : (uint32_t)SKM_CNT_BLOCK;
+        for (uint32_t b0 = 0; b0 < nrec; b0 += SKM_FAST_BLOCK) {
+            const uint32_t nb = nrec - b0 < (uint32_t)SKM_FAST_BLOCK ? nrec - b0 : (uint32_t)SKM_FAST_BLOCK;
             const uint32_t per = (nb + NW - 1u) / NW;                       // records of this wave: [b0 + wave*per, +per)
             const uint32_t i = b0 + wave * per + lane;
             const bool mine = lane < per && wave * per + lane < nb;
@@ -820,7 +804,7 @@ k_skm_count_fast(const uint4 *recs, const uint32_t *pstart, const uint32_t *pcnt
         PH(3)
         // ---- the next partition's records travel while this one is summarised
         {
-            const uint32_t nb = nrec_n < (uint32_t)SKM_CNT_BLOCK ? nrec_n : (uint32_t)SKM_CNT_BLOCK;
+            const uint32_t nb = nrec_n < (uint32_t)SKM_FAST_BLOCK ? nrec_n : (uint32_t)SKM_FAST_BLOCK;
             const uint32_t per = (nb + NW - 1u) / NW;
             if (lane < per && wave * per + lane < nb) pre = recs[rbase_n + wave * per + lane];
         }
@@ -923,7 +907,7 @@ k_skm_count_fast(const uint4 *recs, const uint32_t *pstart, const uint32_t *pcnt
     PH_FLUSH
     if (o.hist) {
         __syncthreads();
-        for (uint32_t i = tid; i < SIMKA_HIST_MAX; i += SKM_CNT_BLOCK)
+        for (uint32_t i = tid; i < SIMKA_HIST_MAX; i += SKM_FAST_BLOCK)
             if (lhist[i]) atomicAdd(&o.hist[(size_t)o.sample * SIMKA_HIST_MAX + i], (ull)lhist[i]);
     }
     if (bt_dall) atomicAdd(&s_tot[0], bt_dall);
