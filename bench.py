@@ -191,44 +191,50 @@ def main():
         torch.cuda.synchronize()
 
     def run_mode(mode):
-        """warmup + an untimed pass with every kernel timed + the timed region, for one decomposition of the job"""
+        """one decomposition of the job: (a) an untimed pass on a ONE-lane context with every kernel timed (per-kernel table:
+        no overlap between kernels), (b) warmup + the timed region on the default context (samples alternate between two
+        streams), HIP events around the dominant kernel only"""
         by_sample = mode == "sample"
-        ctx = simka_amd.SimkaContext(n, kmer_size=k, abundance_min=wl["amin"], simple_dist=wl["simple"],
-                                     complex_dist=wl.get("complex", False), device=local,
-                                     shard_index=0 if mode != "partition" else rank, shard_count=1 if mode != "partition" else world,
-                                     max_kmers_per_sample=kocc_per_sample, log2_partitions=args.log2_partitions)
 
-        def count(s):
-            if args.offsets:
-                ctx.count_sample(s, reads[s].data_ptr(), nb_bases, R, offsets=d_offsets.data_ptr(), on_device=True)
-            else:
-                ctx.count_sample(s, reads[s].data_ptr(), nb_bases, R, fixed_len=L, on_device=True)
+        def make_ctx():
+            return simka_amd.SimkaContext(n, kmer_size=k, abundance_min=wl["amin"], simple_dist=wl["simple"],
+                                          complex_dist=wl.get("complex", False), device=local,
+                                          shard_index=0 if mode != "partition" else rank, shard_count=1 if mode != "partition" else world,
+                                          max_kmers_per_sample=kocc_per_sample, log2_partitions=args.log2_partitions)
 
-        def step():
-            if by_sample:
-                # rank r counts the samples s % N == r over the whole key space, the solid spectra move to the rank that merges
-                # their partition range (all-to-all), the pair accumulators are all-reduced (simka_amd/dist.py)
-                sdist.count_exchange_merge(ctx, count, n, dev, comm=comm)
-            else:
-                ctx.reset()
-                for s in range(n):
-                    count(s)
-                if wl.get("complex") and world > 1:        # -complex-dist terms need the GLOBAL per-sample totals inside the merge
-                    sdist.allreduce_totals_device(ctx, comm=comm)
-                ctx.merge()
-                # ONE RCCL all-reduce of the flat u64 accumulators (no-op at N=1)
-                sdist.allreduce_stats_device(ctx, totals_already_reduced=bool(wl.get("complex")) and world > 1, comm=comm)
-            st = ctx.stats()
-            mats = st.matrices()
-            return st, mats
+        def make_step(ctx):
+            def count(s):
+                if args.offsets:
+                    ctx.count_sample(s, reads[s].data_ptr(), nb_bases, R, offsets=d_offsets.data_ptr(), on_device=True)
+                else:
+                    ctx.count_sample(s, reads[s].data_ptr(), nb_bases, R, fixed_len=L, on_device=True)
 
-        for _ in range(args.warmup):
-            step()
-        # Two event records per launch cost GPU time (C2: 3 % of a step; with hundreds of small samples far more), so the timed
-        # region records events for the dominant kernel only -- the one the roofline object reports.  Which kernel that is, and
-        # the per-kernel table (kernel_ms_per_step, path_frac, timing.device_kernels_ms), come from an untimed pass with every
-        # kernel timed.
+            def step():
+                if by_sample:
+                    # rank r counts the samples s % N == r over the whole key space, the solid spectra move to the rank that merges
+                    # their partition range (all-to-all), the pair accumulators are all-reduced (simka_amd/dist.py)
+                    sdist.count_exchange_merge(ctx, count, n, dev, comm=comm)
+                else:
+                    ctx.reset()
+                    for s in range(n):
+                        count(s)
+                    if wl.get("complex") and world > 1:        # -complex-dist terms need the GLOBAL per-sample totals inside the merge
+                        sdist.allreduce_totals_device(ctx, comm=comm)
+                    ctx.merge()
+                    # ONE RCCL all-reduce of the flat u64 accumulators (no-op at N=1)
+                    sdist.allreduce_stats_device(ctx, totals_already_reduced=bool(wl.get("complex")) and world > 1, comm=comm)
+                st = ctx.stats()
+                mats = st.matrices()
+                return st, mats
+            return step
+
+        # ---- (a) per-kernel times, one lane
         prof_steps = min(args.steps, args.prof_steps) if args.prof_steps else args.steps
+        lanes_env = os.environ.get("SIMKA_LANES")
+        os.environ["SIMKA_LANES"] = "1"
+        ctx = make_ctx()
+        step = make_step(ctx)
+        step()
         ctx.profile_reset()
         ctx.profile_enable(True)
         fence()
@@ -237,7 +243,17 @@ def main():
         fence()
         ctx.profile_enable(False)
         prof_all = ctx.profile()
+        ctx.close()
+        if lanes_env is None:
+            del os.environ["SIMKA_LANES"]
+        else:
+            os.environ["SIMKA_LANES"] = lanes_env
         dom = max(prof_all, key=lambda kk: prof_all[kk][1])
+        # ---- (b) the timed region
+        ctx = make_ctx()
+        step = make_step(ctx)
+        for _ in range(args.warmup):
+            step()
         ctx.profile_reset()
         ctx.profile_enable(True, only=[dom])
         fence()
@@ -297,21 +313,17 @@ def main():
     ms_per_step = dt / args.steps * 1e3
     value = K_dist / (dt / args.steps)
 
-    # ---- roofline (DESIGN.md section 4 "Algorithmic bytes").  SURVEY 8(d): B_alg = R*L/4 + 16*K_occ + 12*K_dist + 12*K_solid,
-    # where 16*K_occ = "write + read each 8-byte k-mer once".  This design moves every k-mer through FOUR 8-byte transfers
-    # (scatter write, split read, split write, count read), so each transfer earns half credit (4 B); the kernels' shares
-    # still add up to exactly B_alg:
-    #   k_scan<scatter>: R*L/4 + 4*K_occ      k_split: 8*K_occ      k_count_fast: 4*K_occ + 12*K_dist      k_regroup: 12*K_solid
+    # ---- roofline (DESIGN.md section 4 "Algorithmic bytes").  SURVEY 8(d): B_alg = R*L/4 + 16*K_occ + 12*K_dist + 12*K_solid, where
+    # 16*K_occ = "write + read each 8-byte k-mer once for partitioning".  The super-k-mer pipeline partitions 16-byte records of
+    # ~8.5 k-mers instead (real traffic ~2 B per k-mer and level), so the kernels' MEASURED traffic is far below these
+    # design-independent bytes; the attribution follows the roles: the scan writes every k-mer once, the count kernel reads every
+    # k-mer once and writes the counted records, the merge reads the solid records once; k_skm_split is an extra level (0).
     share = 1.0 / world                    # each rank owns 1/world of the key space (or counts 1/world of the samples)
     scan_reads = n * nb_bases / 4.0 * (share if by_sample else 1.0)       # partition shards: every rank reads every base
     alg_bytes_per_step = {
-        "k_scan<hist>": 0.0,
-        "k_scan<scatter>": scan_reads + 4.0 * K_occ * share,
-        "k_split": 8.0 * K_occ * share,
-        "k_count_fast": 4.0 * K_occ * share + 12.0 * K_dist * share,
-        "k_count": 0.0,
+        "k_skm_scan": scan_reads + 8.0 * K_occ * share,
+        "k_skm_count_fast": 8.0 * K_occ * share + 12.0 * K_dist * share,
         "k_regroup": 12.0 * K_solid * share,
-        "k_group": 0.0, "k_pairs": 0.0, "k_layout": 0.0, "k_part_totals": 0.0, "k_pairs_global": 0.0,
     }
     kern_ms = {kname: ms for kname, (cnt, ms) in prof.items()}
     total_kernel_ms = sum(kern_ms.values())
@@ -320,7 +332,9 @@ def main():
     dom_avg_ms = dom_ms / max(dom_launches, 1)
     achieved = dom_bytes_per_launch / (dom_avg_ms * 1e-3) / 1e9 if dom_avg_ms > 0 else 0.0
     b_alg = scan_reads + (16.0 * K_occ + 12.0 * K_dist + 12.0 * K_solid) * share
-    path_gbs = b_alg * prof_steps / (total_kernel_ms * 1e-3) / 1e9 if total_kernel_ms > 0 else 0.0
+    # the whole path: B_alg over the step's wall time (kernels of neighbouring samples overlap on two streams, so the sum of the
+    # one-lane kernel times is an upper bound of the device time; it is reported as timing.device_kernels_ms)
+    path_gbs = b_alg / (dt / args.steps) / 1e9
     # HBM bytes per launch of the dominant kernel from the PMC passes committed under profiles/ (scripts/pmc_traffic.sh:
     # FETCH_SIZE and WRITE_SIZE in separate rocprofv3 runs, FETCH_SIZE x2 on gfx950); only when it is the same workload
     traffic = None
@@ -328,8 +342,8 @@ def main():
     tk = {}
     # rocprofv3 reports template instances; the library's profiler reports one name per kernel family
     def family(name):
-        if name.startswith("k_scan<"):
-            return "k_scan<scatter>" if name.startswith("k_scan<true") else "k_scan<hist>"
+        if name.startswith("k_skm_scan<"):
+            return "k_skm_scan<hist>" if name.rstrip(">").endswith("true") else "k_skm_scan"
         return name.split("<")[0]
 
     def measured_traffic(kname):
@@ -340,7 +354,7 @@ def main():
                 tot += v["traffic_bytes_per_launch"] * v["launches"]; n += v["launches"]
         return tot / n if n else None
     try:
-        tf = os.path.join(ROOT, "profiles", "r01_%s_hbm_traffic.json" % args.workload)
+        tf = os.path.join(ROOT, "profiles", "r02_%s_hbm_traffic.json" % args.workload)
         if world == 1 and not args.reads and not args.samples and os.path.exists(tf):
             tk = json.load(open(tf))["kernels"]
             traffic = measured_traffic(dom)
@@ -360,8 +374,9 @@ def main():
                 "avg_launch_ms": dom_avg_ms, "launches": dom_launches, "alg_bytes_per_launch": dom_bytes_per_launch,
                 "path_achieved": path_gbs, "path_frac": path_gbs / HBM_PEAK_GBS, "path_alg_bytes_per_step": b_alg,
                 "kernel_ms_per_step": {kk: v / prof_steps for kk, v in kern_ms.items()}, "kernels": per_kernel,
-                "events": "timed region: HIP events around the %s launches only (avg_launch_ms, achieved); kernel_ms_per_step, kernels, path_* and "
-                          "timing.device_kernels_ms: an untimed pass of %d steps with every kernel timed" % (dom, prof_steps)}
+                "events": "timed region: HIP events around the %s launches only (avg_launch_ms, achieved: samples alternate between two streams, "
+                          "so a launch may share the GPU with the other stream's kernels); path_*: B_alg over the timed step; kernel_ms_per_step, kernels "
+                          "and timing.device_kernels_ms: an untimed pass of %d steps on a one-stream context with every kernel timed" % (dom, prof_steps)}
 
     pair_updates = float(st.pairs()["a"].sum())            # sum over k-mers of s(s-1)/2 = sum over pairs of the shared distinct k-mers
     if "k_pairs" in per_kernel and per_kernel["k_pairs"]["ms_per_step"] > 0:

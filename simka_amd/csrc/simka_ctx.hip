@@ -19,11 +19,10 @@
 #define SIMKA_EXPORT extern "C" __attribute__((visibility("default")))
 
 // kernel ids for the profiler
-enum { KID_SCAN_HIST = 0, KID_LAYOUT, KID_SCAN_SCATTER, KID_SPLIT, KID_COUNT_FAST, KID_COUNT, KID_PART_TOTALS, KID_REGROUP, KID_GROUP,
-       KID_PAIRS, KID_PAIRS_GLOBAL, KID_SKM_SCAN, KID_SKM_SPLIT, KID_SKM_COUNT, KID_NB };
-static const char *const KID_NAMES[KID_NB] = { "k_scan<hist>", "k_layout", "k_scan<scatter>", "k_split", "k_count_fast", "k_count",
-                                               "k_part_totals", "k_regroup", "k_group", "k_pairs", "k_pairs_global",
-                                               "k_skm_scan", "k_skm_split", "k_skm_count" };
+enum { KID_SCAN_HIST = 0, KID_LAYOUT, KID_SKM_SCAN, KID_SKM_SPLIT, KID_SKM_COUNT, KID_COUNT, KID_PART_TOTALS, KID_REGROUP, KID_GROUP,
+       KID_PAIRS, KID_PAIRS_GLOBAL, KID_NB };
+static const char *const KID_NAMES[KID_NB] = { "k_skm_scan<hist>", "k_skm_layout", "k_skm_scan", "k_skm_split", "k_skm_count_fast", "k_skm_count",
+                                               "k_part_totals", "k_regroup", "k_group", "k_pairs", "k_pairs_global" };
 
 static thread_local std::string g_create_error;
 
@@ -31,12 +30,11 @@ struct simka_ctx {
     simka_config cfg;
     SimkaKeyCfg key;
     SimkaSkmCfg skm;                 // super-k-mer pipeline (the count side for k <= 31)
-    bool use_skm = true;
     hipStream_t stream = nullptr;
     bool own_stream = false;
     int num_cus = 256;
     bool geometry_ready = false;
-    uint32_t B1 = 1, B2 = 1;
+    uint32_t B1 = 1;
     uint64_t nparts = 1;
     std::string err;
 
@@ -44,15 +42,9 @@ struct simka_ctx {
     // i+1 (VALU/LDS + writes) overlaps the split/count of sample i (HBM / LDS bound) on the GPU.
     struct Lane {
         hipStream_t stream = nullptr;
-        uint64_t *d_l1 = nullptr; uint64_t l1_cap = 0;            // level-1 buckets (keys)
-        ull *d_b1_count = nullptr, *d_b1_start = nullptr, *d_b1_end = nullptr, *d_b1_cursor = nullptr;
-        uint32_t *d_chunk_first = nullptr;
+        ull *d_b1_count = nullptr, *d_b1_start = nullptr, *d_b1_end = nullptr, *d_b1_cursor = nullptr;   // level-1 buckets
         uint32_t *d_tile_r0 = nullptr; uint64_t tile_r0_cap = 0;  // variable-length reads: first read of every scan tile
-        ull *d_l2 = nullptr; uint64_t l2_cap = 0;                 // level-2 partition regions (keys)
-        uint32_t *d_p_count = nullptr, *d_p_valid = nullptr;      // [nparts]
-        ull *d_spill_keys = nullptr; uint64_t spill_cap = 0; SimkaSpillRun *d_spill_runs = nullptr; uint64_t spill_run_cap = 0;
-        ull *d_spill_cursor = nullptr;
-        uint32_t *d_redo_list = nullptr; ull *d_redo_count = nullptr;   // partitions k_count_fast hands to k_count
+        uint32_t *d_redo_list = nullptr; ull *d_redo_count = nullptr;   // partitions k_skm_count_fast hands to k_skm_count
         // super-k-mer pipeline: two record buffers (level 1 / level 3 share one), level-2 counters, partition table
         uint4 *d_skm_a = nullptr, *d_skm_b = nullptr; uint64_t skm_a_cap = 0, skm_b_cap = 0;
         uint32_t *d_pstart = nullptr, *d_pcnt = nullptr;
@@ -64,7 +56,6 @@ struct simka_ctx {
     uint64_t *d_offsets = nullptr; uint64_t offsets_cap = 0;
     uint32_t *d_l1_ovf = nullptr;                             // [N] capacity-mode scatter overflow flag per sample
     uint64_t nb_exact_fallbacks = 0;
-    int small_table = -1;                                     // -1 undecided, else use K2F_TABLE_SMALL in k_count_fast
     uint32_t nb_counted_this_run = 0;
     struct Pending { uint32_t sample; SimkaScanArgs a; uint32_t pass = 0, npass = 1; };     // device-resident samples whose flag has not been read yet
     std::vector<Pending> pending;
@@ -235,13 +226,6 @@ SIMKA_EXPORT int simka_abi_version(void) { return SIMKA_ABI_VERSION; }
 SIMKA_EXPORT const char *simka_last_error(const simka_ctx *ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
 
 // k_scan<SCATTER, FIXED, SHARDED>
-using ScanFn = void (*)(SimkaScanArgs, SimkaKeyCfg, ull *, ull *, uint64_t *, ull *, const ull *, uint32_t *);
-static ScanFn scan_kernel(bool scatter, bool fixed, bool sharded) {
-    static const ScanFn t[8] = { k_scan<false, false, false>, k_scan<false, false, true>, k_scan<false, true, false>, k_scan<false, true, true>,
-                                 k_scan<true, false, false>,  k_scan<true, false, true>,  k_scan<true, true, false>,  k_scan<true, true, true> };
-    return t[(scatter ? 4 : 0) | (fixed ? 2 : 0) | (sharded ? 1 : 0)];
-}
-
 using SkmScanFn = void (*)(SimkaScanArgs, SimkaSkmCfg, ull *, ull *, uint4 *, const ull *, uint32_t *, uint32_t);
 static int skm_w_index(uint32_t W) { switch (W) { case 1: return 0; case 4: return 1; case 8: return 2; case 12: return 3; case 16: return 4; default: return 5; } }
 static SkmScanFn skm_scan_kernel(int wi, bool fixed, bool hist) {
@@ -253,15 +237,6 @@ static SkmScanFn skm_scan_kernel(int wi, bool fixed, bool hist) {
 
 static int set_lds_attr(simka_ctx *ctx) {
     const int big = 160 * 1024;
-    for (int v = 0; v < 8; v++) HIPCHK(hipFuncSetAttribute((const void *)scan_kernel(v & 4, v & 2, v & 1), hipFuncAttributeMaxDynamicSharedMemorySize, big));
-    HIPCHK(hipFuncSetAttribute((const void *)k_layout, hipFuncAttributeMaxDynamicSharedMemorySize, big));
-    HIPCHK(hipFuncSetAttribute((const void *)k_split<false>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
-    HIPCHK(hipFuncSetAttribute((const void *)k_split<true>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
-    HIPCHK(hipFuncSetAttribute((const void *)k_count, hipFuncAttributeMaxDynamicSharedMemorySize, big));
-    HIPCHK(hipFuncSetAttribute((const void *)k_count_fast<K2F_TABLE_BIG, false>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
-    HIPCHK(hipFuncSetAttribute((const void *)k_count_fast<K2F_TABLE_SMALL, false>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
-    HIPCHK(hipFuncSetAttribute((const void *)k_count_fast<K2F_TABLE_BIG, true>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
-    HIPCHK(hipFuncSetAttribute((const void *)k_count_fast<K2F_TABLE_SMALL, true>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
     HIPCHK(hipFuncSetAttribute((const void *)k_group, hipFuncAttributeMaxDynamicSharedMemorySize, big));
     HIPCHK(hipFuncSetAttribute((const void *)k_pairs<false, K4_BLOCK_BIG>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
     HIPCHK(hipFuncSetAttribute((const void *)k_pairs<false, K4_BLOCK_SMALL>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
@@ -296,19 +271,8 @@ static int setup_geometry(simka_ctx *ctx, uint64_t max_kmers) {
     if (pb == 0) pb = default_log2_partitions(max_kmers, c.shard_count);
     if (pb > 20) pb = 20;
     if (pb > k.W) pb = k.W;
-    uint32_t l1 = (pb + 1) / 2;
-    if (getenv("SIMKA_L1")) l1 = std::min<uint32_t>(pb, (uint32_t)atoi(getenv("SIMKA_L1")));   // experiments
-    const uint32_t min_l1 = std::min<uint32_t>(pb, ceil_log2_u64(c.shard_count));   // shards are level-1 buckets
-    if (l1 < min_l1) l1 = min_l1;
-    // level 1 is scattered from 16384-position tiles (k_scan), level 2 from 8192-key chunks (k_split): split the bits
-    // evenly (measured on C3, pb = 19: l1 = 10 beats 9 by 3.6 % end to end, 8 loses 2.5 %), at most 1024 level-1 buckets
-    if (l1 > 10 && !getenv("SIMKA_L1")) l1 = 10;
-    if (l1 < min_l1) l1 = min_l1;
-    if (l1 > 11) l1 = 11;
-    uint32_t l2 = pb - l1;
-    if (l2 > 11) { l2 = 11; }
-    k.l1 = l1; k.l2 = l2; k.pb = l1 + l2; k.t = 0;
-    ctx->B1 = 1u << l1; ctx->B2 = 1u << l2; ctx->nparts = (uint64_t)1 << k.pb;
+    k.l1 = 0; k.l2 = 0; k.pb = pb; k.t = 0;
+    ctx->nparts = (uint64_t)1 << k.pb;
     {   // super-k-mer pipeline: the same partition count over two levels (<= 256 level-1 buckets x <= 4096 partitions each)
         SimkaSkmCfg &sk = ctx->skm;
         sk.pb = k.pb;
@@ -316,7 +280,7 @@ static int setup_geometry(simka_ctx *ctx, uint64_t max_kmers) {
         sk.l1 = std::min<uint32_t>(sk.pb, std::min<uint32_t>(l1_env, 8u));
         sk.l2 = sk.pb - sk.l1; sk.l3 = 0;
         if (sk.l2 > 12) return ctx->fail(SIMKA_ERR_INVALID, "log2_partitions %u is beyond the two partitioning levels", sk.pb);
-        ctx->B1 = ctx->use_skm ? (1u << sk.l1) : ctx->B1;
+        ctx->B1 = 1u << sk.l1;
     }
 
     const uint32_t N = c.nb_samples;
@@ -324,7 +288,7 @@ static int setup_geometry(simka_ctx *ctx, uint64_t max_kmers) {
     // of neighbouring samples overlap); the default single lane keeps per-kernel timings free of overlap.
     // samples alternate between two streams with private scratch: the scan of one sample overlaps the count of another (the
     // kernels are bound by different things: c3_10 212.7 -> 181.9 ms/step); SIMKA_LANES=1 keeps per-kernel timings free of overlap
-    static const bool two_lanes = !(getenv("SIMKA_LANES") && atoi(getenv("SIMKA_LANES")) < 2);
+    const bool two_lanes = !(getenv("SIMKA_LANES") && atoi(getenv("SIMKA_LANES")) < 2);      // (read per context: bench.py profiles with one lane)
     ctx->nlanes = (two_lanes && c.nb_samples >= 2) ? 2u : 1u;
     for (uint32_t li = 0; li < ctx->nlanes; li++) {
         simka_ctx::Lane &L = ctx->lanes[li];
@@ -333,13 +297,9 @@ static int setup_geometry(simka_ctx *ctx, uint64_t max_kmers) {
         HIPCHK(dev_alloc(&L.d_b1_start, ctx->B1 + 1));
         HIPCHK(dev_alloc(&L.d_b1_end, ctx->B1 + 1));
         HIPCHK(dev_alloc(&L.d_b1_cursor, ctx->B1 + 1));
-        HIPCHK(dev_alloc(&L.d_chunk_first, ctx->B1 + 1));
-        HIPCHK(dev_alloc(&L.d_p_count, ctx->nparts + 1));
-        HIPCHK(dev_alloc(&L.d_p_valid, ctx->nparts + 1));
-        HIPCHK(dev_alloc(&L.d_spill_cursor, 2));
         HIPCHK(dev_alloc(&L.d_redo_list, ctx->nparts + 1));
         HIPCHK(dev_alloc(&L.d_redo_count, 2));
-        if (ctx->use_skm) { HIPCHK(dev_alloc(&L.d_pstart, ctx->nparts + 1)); HIPCHK(dev_alloc(&L.d_pcnt, ctx->nparts + 1)); }
+        HIPCHK(dev_alloc(&L.d_pstart, ctx->nparts + 1)); HIPCHK(dev_alloc(&L.d_pcnt, ctx->nparts + 1));
     }
     HIPCHK(dev_alloc(&ctx->d_l1_ovf, c.nb_samples + 1));
     HIPCHK(hipMemsetAsync(ctx->d_l1_ovf, 0, (size_t)(c.nb_samples + 1) * 4, ctx->stream));
@@ -412,8 +372,7 @@ SIMKA_EXPORT int simka_create(const simka_config *cfg, simka_ctx **out) {
         sk.mmask = (uint32_t)((1ull << (2 * sk.m)) - 1ull);
         sk.kmask = k.mask;
         sk.shard_index = cfg->shard_index; sk.shard_count = cfg->shard_count;
-        ctx->use_skm = getenv("SIMKA_OLD_COUNT") == nullptr;
-    } else ctx->use_skm = false;
+    }
 
     int rc = set_lds_attr(ctx);
     if (rc) return bail(rc);
@@ -452,8 +411,7 @@ SIMKA_EXPORT void simka_destroy(simka_ctx *ctx) {
     if (ctx->wide) { simka_wide_destroy(ctx->wide); ctx->wide = nullptr; }
     for (auto &L : ctx->lanes) {
         if (L.stream) (void)hipStreamSynchronize(L.stream);
-        void *lp[] = { L.d_l1, L.d_b1_count, L.d_b1_start, L.d_b1_end, L.d_b1_cursor, L.d_chunk_first, L.d_tile_r0, L.d_l2, L.d_p_count, L.d_p_valid,
-                       L.d_spill_keys, L.d_spill_runs, L.d_spill_cursor, L.d_redo_list, L.d_redo_count,
+        void *lp[] = { L.d_b1_count, L.d_b1_start, L.d_b1_end, L.d_b1_cursor, L.d_tile_r0, L.d_redo_list, L.d_redo_count,
                        L.d_skm_a, L.d_skm_b, L.d_pstart, L.d_pcnt };
         for (void *q : lp) if (q) (void)hipFree(q);
         if (L.stream) (void)hipStreamDestroy(L.stream);
@@ -508,7 +466,7 @@ static int check_device_error(simka_ctx *ctx) {
     uint32_t e = 0;
     HIPCHK(hipMemcpyAsync(&e, ctx->d_err, 4, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));
-    if (e & SIMKA_DEVERR_TABLE_OVERFLOW) return ctx->fail(SIMKA_ERR_OVERFLOW, "a partition holds more distinct k-mers than its LDS table (%d slots): raise log2_partitions / max_kmers_per_sample", K2_TABLE);
+    if (e & SIMKA_DEVERR_TABLE_OVERFLOW) return ctx->fail(SIMKA_ERR_OVERFLOW, "a partition could not be counted in 2^16 rounds of its LDS table (%d slots)", SKM_CNT_TS);
     if (e & SIMKA_DEVERR_ARENA_FULL) return ctx->fail(SIMKA_ERR_NOMEM, "solid-spectrum arena exhausted (%llu records): raise solid_capacity", (unsigned long long)ctx->arena_cap);
     if (e & SIMKA_DEVERR_SAMPLE_TOO_BIG) return ctx->fail(SIMKA_ERR_OVERFLOW, "a sample holds more than 2^32 solid k-mers");
     if (e & SIMKA_DEVERR_GROUP_OVERFLOW) return ctx->fail(SIMKA_ERR_OVERFLOW, "merge: a sub-range could not be split below the LDS capacity");
@@ -529,175 +487,10 @@ static int ensure_cap(simka_ctx *ctx, T **p, uint64_t *cap, uint64_t need) {
 
 // enqueue the count-side kernels of one sample.  exact=false: capacity-sized level-1 buckets, no histogram pass; the
 // kernels after the scatter skip themselves if it flags an overflow, and resolve_pending() redoes the sample exactly.
-static int run_count_skm(simka_ctx *ctx, uint32_t sample, const SimkaScanArgs &a_in, bool exact, uint32_t pass, uint32_t npass);
-static int run_count_kernels(simka_ctx *ctx, uint32_t sample, const SimkaScanArgs &a_in, bool exact, uint32_t pass = 0, uint32_t npass = 1) {
-    if (ctx->use_skm) return run_count_skm(ctx, sample, a_in, exact, pass, npass);
-    const uint32_t N = ctx->cfg.nb_samples;
-    simka_ctx::Lane &L = ctx->lanes[sample % ctx->nlanes];
-    const hipStream_t st = L.stream;
-    int rc;
-    SimkaScanArgs a = a_in;
-    a.tile_r0 = nullptr;
-    // A sample too deep for the scratch buffers is counted in `npass` passes over its reads; pass j keeps the level-1 buckets
-    // b with b % (shards * npass) == shard + shards * j, i.e. it behaves like one of shards * npass partition shards.
-    SimkaKeyCfg key = ctx->key;
-    if (npass > 1) { key.shard_index = ctx->key.shard_index + ctx->key.shard_count * pass; key.shard_count = ctx->key.shard_count * npass; }
-    const uint32_t B1 = ctx->B1, B2 = ctx->B2;
-    const uint32_t own_b1 = (B1 + key.shard_count - 1) / key.shard_count;       // level-1 buckets this shard / pass owns (at most)
-    const uint32_t later = pass ? 4u : 0u;                                      // k_layout: occurrences add up, arena base stays
-    ull *kocc = (ull *)ctx->d_stats + stats_off_tot(N, ctx->cfg.dist_flags, SIMKA_TOT_KOCC) + sample;
-    const uint64_t tile = (uint64_t)K1_BLOCK * K1_SEG;
-    const uint32_t grid1 = (uint32_t)((a.nb_bases + tile - 1) / tile);
-    const size_t lds_rtab = a.fixed_len ? 0 : (size_t)K1_RTAB * 4;
-    const size_t lds_hist = SIMKA_LDS_HEAD + (size_t)B1 * 16 + 128 + K1_BLOCK * 4 + lds_rtab;
-    const size_t lds_scat = lds_hist + (size_t)tile * 8;
-    if (!a.fixed_len && a.nb_reads && grid1) {      // where every tile starts in the read list (one binary search per tile, not per thread)
-        rc = ensure_cap(ctx, &L.d_tile_r0, &L.tile_r0_cap, (uint64_t)grid1 + 2); if (rc) return rc;
-        hipLaunchKernelGGL(k_tile_reads, dim3((grid1 + 1 + 255) / 256), dim3(256), 0, st, a.offsets, a.nb_reads, a.nb_bases, grid1, tile, L.d_tile_r0);
-        a.tile_r0 = L.d_tile_r0;
-    }
-    const size_t lds_lay = SIMKA_LDS_HEAD + (size_t)B1 * 12 + 128;
-    uint32_t *flag = ctx->d_l1_ovf + sample;       // bit 0: level-1 bucket overflow, bit 1: spill buffer overflow
-    const uint32_t *skip = flag;
-    auto layout = [&](uint32_t mode, ull capb) {
-        launch_timed(ctx, KID_LAYOUT, [&] {
-            SimkaLaneClear clr;
-            clr.p_count = L.d_p_count; clr.p_valid = L.d_p_valid; clr.spill_cursor = L.d_spill_cursor; clr.redo_count = L.d_redo_count;
-            clr.nparts = (uint32_t)ctx->nparts;
-            const uint32_t clear_blocks = mode == 2u ? 0u : (uint32_t)std::min<uint64_t>(64, (ctx->nparts + 8191) / 8192);
-            hipLaunchKernelGGL(k_layout, dim3(1 + clear_blocks), dim3(256), lds_lay, st, L.d_b1_count, L.d_b1_start, L.d_b1_end,
-                               L.d_b1_cursor, L.d_chunk_first, B1, ctx->d_arena_cursor, ctx->d_sample_base + sample, mode | later, capb,
-                               kocc, skip, key, clr);
-        }, st);
-    };
-    // Level-1 buckets.  Keys are hash-partitioned, so bucket sizes concentrate around K_occ/B1: size every bucket for that
-    // (+10 % + slack) and scatter directly.  Only if a bucket overflows (heavy repeats) is the sample redone with the exact
-    // histogram -> scan -> scatter sequence.
-    static const bool force_exact = getenv("SIMKA_EXACT_SIZING") != nullptr;
-    const bool sharded = key.shard_count > 1;
-    if (force_exact) exact = true;
-    uint64_t max_chunks;
-    if (!exact) {
-        const uint64_t kocc_upper = a.fixed_len ? (a.fixed_len >= key.k ? a.nb_reads * (uint64_t)(a.fixed_len - key.k + 1) : 0) : a.nb_bases;
-        const uint64_t per_bucket = kocc_upper / B1;
-        const uint64_t capb = per_bucket + per_bucket / 10 + 2048;
-        rc = ensure_cap(ctx, &L.d_l1, &L.l1_cap, capb * own_b1); if (rc) return rc;      // owned buckets only, packed by rank
-        max_chunks = (capb * own_b1) / K2_CHUNK + B1 + 1;
-        layout(1, capb);
-        launch_timed(ctx, KID_SCAN_SCATTER, [&] {
-            hipLaunchKernelGGL(scan_kernel(true, a.fixed_len != 0, sharded), dim3(grid1), dim3(K1_BLOCK), lds_scat, st, a, key, L.d_b1_count,
-                               L.d_b1_cursor, L.d_l1, kocc, (const ull *)L.d_b1_end, flag);
-        }, st);
-        layout(2, capb);
-        simka_ctx::Pending p; p.sample = sample; p.a = a; p.pass = pass; p.npass = npass;
-        ctx->pending.push_back(p);
-    } else {
-        if (!sharded) { rc = ensure_cap(ctx, &L.d_l1, &L.l1_cap, a.nb_bases); if (rc) return rc; }
-        max_chunks = a.nb_bases / K2_CHUNK + B1 + 1;
-        HIPCHK(hipMemsetAsync(L.d_b1_count, 0, (B1 + 1) * 8, st));
-        launch_timed(ctx, KID_SCAN_HIST, [&] {
-            hipLaunchKernelGGL(scan_kernel(false, a.fixed_len != 0, sharded), dim3(grid1), dim3(K1_BLOCK), lds_hist, st, a, key, L.d_b1_count,
-                               L.d_b1_cursor, L.d_l1, kocc, (const ull *)nullptr, (uint32_t *)nullptr);
-        }, st);
-        layout(0, 0);
-        if (sharded) {   // this shard's share of the keys is known only now: size the bucket buffer from the chunk count (rare path)
-            uint32_t nch = 0;
-            HIPCHK(hipMemcpyAsync(&nch, L.d_chunk_first + B1, 4, hipMemcpyDeviceToHost, st));
-            HIPCHK(hipStreamSynchronize(st));
-            rc = ensure_cap(ctx, &L.d_l1, &L.l1_cap, (uint64_t)nch * K2_CHUNK + 1); if (rc) return rc;
-        }
-        launch_timed(ctx, KID_SCAN_SCATTER, [&] {
-            hipLaunchKernelGGL(scan_kernel(true, a.fixed_len != 0, sharded), dim3(grid1), dim3(K1_BLOCK), lds_scat, st, a, key, L.d_b1_count,
-                               L.d_b1_cursor, L.d_l1, kocc, (const ull *)nullptr, (uint32_t *)nullptr);
-        }, st);
-    }
-    (void)max_chunks;
-    // ---- level 2: partition-contiguous regions, capacity-sized, + spill buffer
-    const uint64_t kocc_up = a.fixed_len ? (a.fixed_len >= key.k ? a.nb_reads * (uint64_t)(a.fixed_len - key.k + 1) : 0) : a.nb_bases;
-    // every owned partition receives ~K_occ / nparts keys; regions exist for the owned partitions only (simka_region_index)
-    const uint64_t mean2 = kocc_up / ctx->nparts;
-    SimkaL2 l2;
-    l2.cap2 = mean2 + mean2 / 2 + 256;
-    rc = ensure_cap(ctx, &L.d_l2, &L.l2_cap, l2.cap2 * own_b1 * B2); if (rc) return rc;
-    const uint64_t spill_need = exact ? std::max<uint64_t>(sharded ? std::min<uint64_t>(kocc_up, 2 * (kocc_up / key.shard_count) + ((uint64_t)1 << 20)) : kocc_up, 1)
-                                      : std::max<uint64_t>((uint64_t)1 << 20, kocc_up / 64);
-    rc = ensure_cap(ctx, &L.d_spill_keys, &L.spill_cap, spill_need); if (rc) return rc;
-    // a run = the keys one 8192-key chunk sends to one partition: at most (#chunks x B2) runs, never more than spilled keys
-    const uint64_t run_need = std::min<uint64_t>(spill_need, (kocc_up / K2_CHUNK + B1 + 1) * (uint64_t)B2);
-    rc = ensure_cap(ctx, &L.d_spill_runs, &L.spill_run_cap, run_need); if (rc) return rc;
-    l2.l2_keys = L.d_l2; l2.p_count = L.d_p_count; l2.p_valid = L.d_p_valid;
-    // level-2 regions hold 4-byte remainders when the partition bits leave <= 31 of the key (k <= 23 at the usual geometry)
-    static const bool wide_only = getenv("SIMKA_WIDE_KEYS") != nullptr;
-    l2.rem_bits = key.W - key.pb;
-    l2.narrow = (!wide_only && l2.rem_bits <= 31u) ? 1u : 0u;
-    l2.spill_keys = L.d_spill_keys; l2.spill_runs = L.d_spill_runs; l2.spill_cursor = L.d_spill_cursor;
-    l2.spill_cap = L.spill_cap; l2.spill_run_cap = L.spill_run_cap;
-    // (p_count, p_valid, the spill cursors and the redo count were reset by k_layout before the scatter)
-    {
-        const uint64_t nchunks_max = (exact ? a.nb_bases : L.l1_cap) / K2_CHUNK + B1 + 1;
-        const size_t lds_split = SIMKA_LDS_HEAD + (size_t)B2 * 12 + 64 + (size_t)K2_CHUNK * 8;
-        launch_timed(ctx, KID_SPLIT, [&] {
-            const dim3 grid((uint32_t)std::min<uint64_t>(nchunks_max, (uint64_t)ctx->num_cus * 2));
-            if (l2.narrow) hipLaunchKernelGGL(k_split<true>, grid, dim3(K2_BLOCK), lds_split, st, L.d_l1, L.d_b1_start, L.d_b1_end, L.d_chunk_first, key, l2, flag);
-            else hipLaunchKernelGGL(k_split<false>, grid, dim3(K2_BLOCK), lds_split, st, L.d_l1, L.d_b1_start, L.d_b1_end, L.d_chunk_first, key, l2, flag);
-        }, st);
-    }
-    SimkaCountOut o;
-    o.arena_cursor = ctx->d_arena_cursor; o.sample_base = ctx->d_sample_base + sample; o.arena_cap = ctx->arena_cap;
-    o.solid_keys = ctx->d_solid_keys; o.solid_counts = ctx->d_solid_counts;
-    o.foff = ctx->d_foff + (uint64_t)sample * ctx->nparts; o.fcnt = ctx->d_fcnt + (uint64_t)sample * ctx->nparts;
-    o.totals = (ull *)ctx->d_stats + stats_off_tot(N, ctx->cfg.dist_flags, 0); o.sample = sample; o.nb_samples = N; o.err = ctx->d_err;
-    o.phase = nullptr; o.slab = 512; o.pad_ = 0;
-#ifdef SIMKA_PHASE_PROF
-    {   // debug build: per-phase wall_clock64 ticks of thread 0 of every k_count_fast block, printed per sample
-        static ull *d_phase = nullptr;
-        if (!d_phase) { HIPCHK(hipMalloc(&d_phase, 64)); HIPCHK(hipMemset(d_phase, 0, 64)); }
-        else {
-            HIPCHK(hipDeviceSynchronize());
-            ull h[8]; HIPCHK(hipMemcpy(h, d_phase, 64, hipMemcpyDeviceToHost)); HIPCHK(hipMemset(d_phase, 0, 64));
-            ull t_ = 0; for (ull v : h) t_ += v;
-            fprintf(stderr, "k_count_fast phases %%: gap %.1f loadwait %.1f insert %.1f sync %.1f summary %.1f scan %.1f reserve %.1f emit %.1f\n",
-                    100.0 * h[0] / t_, 100.0 * h[1] / t_, 100.0 * h[2] / t_, 100.0 * h[3] / t_, 100.0 * h[4] / t_, 100.0 * h[5] / t_, 100.0 * h[6] / t_, 100.0 * h[7] / t_);
-        }
-        o.phase = d_phase;
-    }
-#endif
-    o.hist = ctx->d_hist; o.ovf_list = ctx->d_ovf_list; o.ovf_cursor = ctx->d_ovf_cursor; o.ovf_cap = ctx->ovf_cap;
-    static const uint32_t tlog = getenv("SIMKA_K2_TABLE_LOG2") ? (uint32_t)atoi(getenv("SIMKA_K2_TABLE_LOG2")) : (uint32_t)K2_TABLE_LOG2;
-    static const bool slow_only = getenv("SIMKA_K2_SLOW") != nullptr;
-    const size_t hist_lds = ctx->d_hist ? (size_t)SIMKA_HIST_MAX * 4 : 0;
-    if (!slow_only) {
-        const bool small = ctx->small_table == 1;
-        // the table size chosen for the run (from the first sample); partitions it cannot hold (more distinct keys than slots:
-        // a key gives up after K2F_PROBES probes) and spilled partitions go to the general kernel through the redo list
-        launch_timed(ctx, KID_COUNT_FAST, [&] {
-            auto go = [&](auto kern, size_t lds) {
-                const uint32_t bpc = (uint32_t)std::min<size_t>(4, (160 * 1024) / lds);
-                hipLaunchKernelGGL(kern, dim3((uint32_t)std::min<uint64_t>(ctx->nparts, (uint64_t)ctx->num_cus * bpc)), dim3(K2F_BLOCK), lds, st, key, l2,
-                                   ctx->cfg.abundance_min, ctx->cfg.abundance_max, o, flag, L.d_redo_list, L.d_redo_count);
-            };
-            const size_t lds_small = SIMKA_LDS_HEAD + (size_t)K2F_TABLE_SMALL * (l2.narrow ? 8 : 12) + (size_t)K2F_BLOCK * 4 + hist_lds;
-            const size_t lds_big = SIMKA_LDS_HEAD + (size_t)K2F_TABLE_BIG * (l2.narrow ? 8 : 12) + (size_t)K2F_BLOCK * 4 + hist_lds;
-            if (small) { if (l2.narrow) go(k_count_fast<K2F_TABLE_SMALL, true>, lds_small); else go(k_count_fast<K2F_TABLE_SMALL, false>, lds_small); }
-            else { if (l2.narrow) go(k_count_fast<K2F_TABLE_BIG, true>, lds_big); else go(k_count_fast<K2F_TABLE_BIG, false>, lds_big); }
-        }, st);
-    }
-    const size_t lds_count = SIMKA_LDS_HEAD + ((size_t)12 << tlog) + (size_t)K2C_MATCH * 4 + hist_lds;
-    launch_timed(ctx, KID_COUNT, [&] {
-        const uint32_t grid_count = slow_only ? (uint32_t)std::min<uint64_t>(ctx->nparts, (uint64_t)ctx->num_cus * 4) : (uint32_t)ctx->num_cus;
-        hipLaunchKernelGGL(k_count, dim3(grid_count), dim3(K2C_BLOCK), lds_count, st, key, l2, tlog,
-                           ctx->cfg.abundance_min, ctx->cfg.abundance_max, o, flag,
-                           slow_only ? (const uint32_t *)nullptr : (const uint32_t *)L.d_redo_list,
-                           slow_only ? (const ull *)nullptr : (const ull *)L.d_redo_count);
-    }, st);
-    HIPCHK(hipGetLastError());
-    return SIMKA_OK;
-}
-
 // ---- super-k-mer pipeline: enqueue the count-side kernels of one sample (see simka_skm.hip) ----------------------------------
 // exact=false: capacity-sized level-1 buckets; if one overflows the later kernels skip themselves and resolve_pending() redoes
 // the sample with exact=true (a histogram-only scan first).
-static int run_count_skm(simka_ctx *ctx, uint32_t sample, const SimkaScanArgs &a_in, bool exact, uint32_t pass, uint32_t npass) {
+static int run_count_kernels(simka_ctx *ctx, uint32_t sample, const SimkaScanArgs &a_in, bool exact, uint32_t pass = 0, uint32_t npass = 1) {
     const uint32_t N = ctx->cfg.nb_samples;
     simka_ctx::Lane &L = ctx->lanes[sample % ctx->nlanes];
     const hipStream_t st = L.stream;
@@ -915,18 +708,19 @@ SIMKA_EXPORT int simka_count_sample(simka_ctx *ctx, uint32_t sample, const simka
         }
         HIPCHK(hipStreamSynchronize(ctx->stream));   // the host buffers may be reused by the caller right away
     }
-    // scratch per k-mer occurrence: 8.8 B of level-1 buckets + 6..12 B of level-2 regions.  A sample whose share does not fit
+    // scratch per k-mer occurrence: two buffers of 16-byte super-k-mer records, ~2 B per occurrence each at the expected run
+    // length (+ 30 % head room): say 6 B.  A sample whose share does not fit
     // a third of the device is counted in several passes over its reads, each keeping a subset of the level-1 buckets.
     uint32_t npass = 1;
     {
         static const char *force = getenv("SIMKA_FORCE_PASSES");          // tests
-        const uint32_t max_pass = std::max<uint32_t>(1, ctx->B1 / std::max<uint32_t>(1, ctx->cfg.shard_count));
+        const uint32_t max_pass = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(64, ctx->nparts / std::max<uint32_t>(1, ctx->cfg.shard_count)));
         if (force) npass = (uint32_t)atoi(force);
         else {
             if (!ctx->mem_total) { size_t fr = 0, tot_ = 0; HIPCHK(hipMemGetInfo(&fr, &tot_)); ctx->mem_total = tot_; }
             const size_t tot = ctx->mem_total;
             const uint64_t kocc_up = r->fixed_len ? r->nb_reads * (uint64_t)r->fixed_len : r->nb_bases;
-            const double need = (double)kocc_up * 21.0 / std::max<uint32_t>(1, ctx->cfg.shard_count);
+            const double need = (double)kocc_up * 6.0 / std::max<uint32_t>(1, ctx->cfg.shard_count);
             while (need / npass > 0.30 * (double)tot && npass < max_pass) npass *= 2;
         }
         npass = std::max<uint32_t>(1, std::min(npass, max_pass));
@@ -936,17 +730,7 @@ SIMKA_EXPORT int simka_count_sample(simka_ctx *ctx, uint32_t sample, const simka
         if (rc) return rc;
         if (npass > 1) { rc = resolve_pending(ctx); if (rc) return rc; }       // the passes share the scratch buffers
     }
-    if (ctx->nb_counted_this_run++ == 0 && ctx->cfg.nb_samples > 1 && ctx->small_table < 0) {
-        // table size of k_count_fast for the rest of the context's life, from this sample's distinct ratio (one sync; a
-        // wrong guess for later samples only sends partitions through the redo list)
-        rc = resolve_pending(ctx); if (rc) return rc;
-        uint64_t da = 0, ko = 0;
-        const uint32_t fl = ctx->cfg.dist_flags;
-        HIPCHK(hipMemcpyAsync(&da, ctx->d_stats + stats_off_tot(N, fl, SIMKA_TOT_DALL) + sample, 8, hipMemcpyDeviceToHost, ctx->stream));
-        HIPCHK(hipMemcpyAsync(&ko, ctx->d_stats + stats_off_tot(N, fl, SIMKA_TOT_KOCC) + sample, 8, hipMemcpyDeviceToHost, ctx->stream));
-        HIPCHK(hipStreamSynchronize(ctx->stream));
-        ctx->small_table = (ko > 0 && (double)da / (double)ko < 0.40) ? 1 : 0;
-    }
+    ctx->nb_counted_this_run++;
     return SIMKA_OK;
 }
 
@@ -1884,7 +1668,7 @@ SIMKA_EXPORT int simka_device_memory(int device, uint64_t *free_bytes, uint64_t 
 
 SIMKA_EXPORT int simka_get_geometry(simka_ctx *ctx, uint32_t *l1, uint32_t *l2, uint32_t *t, uint64_t *arena, uint64_t *csr) {
     if (!ctx) return SIMKA_ERR_INVALID;
-    if (l1) *l1 = ctx->key.l1; if (l2) *l2 = ctx->key.l2; if (t) *t = ctx->key.t;
+    if (l1) *l1 = ctx->wide ? ctx->key.l1 : ctx->skm.l1; if (l2) *l2 = ctx->wide ? ctx->key.l2 : ctx->skm.l2; if (t) *t = ctx->key.t;
     if (arena) *arena = ctx->arena_cap; if (csr) *csr = ctx->merge_cap;
     return SIMKA_OK;
 }

@@ -6,31 +6,12 @@
 // scalars of every dynamic-LDS kernel live in the first SIMKA_LDS_HEAD bytes of the region
 #define SIMKA_LDS_HEAD 512
 
-// K1  k_scan
-#define K1_BLOCK 1024         // 16 waves: 16384-position tiles -> long bucket runs (run length is what the scatter is bound by)
-#define K1_SEG 16
-#define K1_RTAB 2048          // k_scan, variable-length reads: read starts of one tile staged in LDS (else global binary search)             // k-mer start positions per thread (window = SEG + k - 1 <= 64 bases holds for k <= 33)
-// K2  k_split / k_count
-#define K2_BLOCK 1024         // k_split
-#define K2C_BLOCK 256         // k_count
-#define K2_CHUNK 8192         // keys per chunk (fits u16 offsets, 64 KB LDS stage)
-#define K2_TABLE_LOG2 13      // k_count (general kernel, one block per CU): 8192 slots -- a partition the fast tables could not hold fits in one round
-#define K2_TABLE (1 << K2_TABLE_LOG2)
-#define K2_MAXSEG_UNUSED 512         // chunk segments gathered per batch in k_count
-// k_count_fast
-#define K2F_BLOCK 512
-#define K2F_TABLE_BIG 4096    // slots (48 KB): safe even if every k-mer of a partition is distinct
-#define K2F_TABLE_SMALL 2048  // slots (24 KB): when the first sample shows mostly repeated k-mers (high coverage)
-#define K2F_PROBES 128         // k_count_fast: probes before a key gives up (table too small -> next kernel of the cascade)
-#define K2F_UNROLL 8          // keys prefetched per thread: partitions up to BLOCK*UNROLL = 4096 keys take the fast path
+// count side: see simka_skm.hip (SKM_* geometry)
 #define K2_SLAB 4096          // arena records reserved per global atomic by a count block (a partition's solid records stay contiguous:
                               // what is left of a slab when the next partition does not fit is lost, so slabs are several partitions long)
-#ifndef K2_UNROLL
-#define K2_UNROLL 8
-#endif
-//          // independent key loads in flight per thread
 #ifndef SIMKA_TARGET_PER_PART
-#define SIMKA_TARGET_PER_PART 3072   // sizing: k-mer occurrences per partition: below 7/8 of the 4096-slot table even if ALL are distinct
+#define SIMKA_TARGET_PER_PART 3072   // sizing: k-mer occurrences per partition (minimizer partitions vary ~3x around it; the fast count
+                                     // kernel's 2048-slot table takes ~1500 distinct k-mers, larger partitions go through k_skm_count)
 #endif
 // K3  k_regroup / k_group
 #define K3_BLOCK 256
@@ -100,30 +81,6 @@ struct SimkaCountOut {
     uint32_t *ovf_list;                      // (sample,count) pairs for counts >= SIMKA_HIST_MAX
     unsigned long long *ovf_cursor;
     unsigned long long ovf_cap;
-};
-
-// level-2 partition regions of one sample (k_split -> k_count)
-// a run of one partition's keys in the spill buffer
-struct SimkaSpillRun { unsigned long long start; uint32_t part, len; };
-#define K2C_MATCH 4096         // k_count: spill runs of one partition listed in LDS (more: the run list is re-scanned every round)
-
-// per-lane level-2 state that k_layout resets before a sample is scattered
-struct SimkaLaneClear {
-    uint32_t *p_count, *p_valid;             // [nparts]
-    unsigned long long *spill_cursor, *redo_count;   // [2] each
-    uint32_t nparts;
-};
-
-struct SimkaL2 {
-    unsigned long long *l2_keys;             // [nparts][cap2]  (u32 remainders when `narrow`)
-    uint32_t narrow, rem_bits;               // W - pb <= 31: regions hold the low rem_bits of each key, the partition is implicit
-    unsigned long long cap2;                 // keys a region can hold
-    uint32_t *p_count;                       // [nparts] keys routed to the partition (may exceed cap2: spilled)
-    uint32_t *p_valid;                       // [nparts] first overflowing position (0xffffffff: none)
-    unsigned long long *spill_keys;          // runs that did not fit their region ...
-    SimkaSpillRun *spill_runs;               // ... one descriptor per run (k_count reads only the runs of its partition)
-    unsigned long long *spill_cursor;        // [0] keys, [1] runs
-    unsigned long long spill_cap, spill_run_cap;
 };
 
 struct SimkaMergeIn {

@@ -1,13 +1,8 @@
 // simka_kernels.hip -- hand-written gfx950 (CDNA4, wave64) kernels of the Simka hot path.
 //
-// Data flow per sample (count side, replaces gatb SortingCountAlgorithm + the
-// SimkaCompressedProcessor plugin, ref: src/SimkaCount.cpp:291-297, src/minikc/MiniKC.hpp:54-79):
-//
-//   packed reads --k_scan<false>--> level-1 histogram --k_layout--> bucket offsets
-//                --k_scan<true>---> level-1 buckets of keys (LDS-staged multisplit, coalesced runs)
-//                --k_split--------> every 8192-key chunk partitioned IN PLACE by level-2 bits
-//                --k_count--------> per partition: LDS hash table (CAS insert) -> abundance filter
-//                                   -> solid (key,count) records in the HBM arena + D/N/Q totals
+// The count side (replaces gatb SortingCountAlgorithm + the SimkaCompressedProcessor plugin, ref: src/SimkaCount.cpp:291-297,
+// src/minikc/MiniKC.hpp:54-79) lives in simka_skm.hip (super-k-mer pipeline); this file holds the shared block primitives,
+// the arena helpers of the count kernels, and the merge side.
 //
 // Merge side over all samples (replaces SimkaMergeAlgorithm::execute's heap merge and
 // SimkaCountProcessorSimple::updateDistance*, ref: src/SimkaMerge.cpp:1164-1326,
@@ -85,18 +80,8 @@ __device__ __forceinline__ uint32_t block_excl_scan(uint32_t *a, uint32_t n, uin
     return total;
 }
 
-// --------------------------------------------------------------------------------------------
-// K1  k_scan: packed reads -> canonical k-mer keys -> level-1 histogram / level-1 buckets
-// One thread owns K1_SEG consecutive k-mer START positions of the concatenated base array and
-// rolls forward/reverse-complement words over its 64-base register window.
-// --------------------------------------------------------------------------------------------
-__device__ __forceinline__ uint32_t window_base(uint64_t A, uint64_t B, uint32_t i) {
-    const uint64_t w = (i < 32u) ? A : B;
-    return (uint32_t)(w >> ((i & 31u) * 2u)) & 3u;
-}
-
 // k_tile_reads: variable-length reads.  tile_r0[b] = index of the read that holds base b * tile (largest r with
-// offsets[r] <= b * tile), one thread per tile; k_scan stages the read starts of its tile in LDS from it.
+// offsets[r] <= b * tile), one thread per tile; k_skm_scan stages the read starts of its tile in LDS from it.
 __global__ void __launch_bounds__(256)
 k_tile_reads(const uint64_t *offsets, uint64_t nb_reads, uint64_t nb_bases, uint32_t ntiles, uint64_t tile, uint32_t *tile_r0) {
     const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
@@ -106,420 +91,6 @@ k_tile_reads(const uint64_t *offsets, uint64_t nb_reads, uint64_t nb_bases, uint
     if (pos >= nb_bases) { tile_r0[b] = (uint32_t)(nb_reads ? nb_reads - 1 : 0); return; }
     while (hi - lo > 1) { const uint64_t mid = (lo + hi) >> 1; if (offsets[mid] <= pos) lo = mid; else hi = mid; }
     tile_r0[b] = (uint32_t)lo;
-}
-
-// SHARDED: the context owns a subset of the level-1 buckets (partition shards); otherwise every k-mer is kept and the
-// ownership test (with its integer modulo for non power-of-two shard counts) is not even compiled in.
-template <bool SCATTER, bool FIXED, bool SHARDED>
-__global__ void __launch_bounds__(K1_BLOCK)
-k_scan(SimkaScanArgs a, SimkaKeyCfg cfg, ull *b1_count, ull *b1_cursor, uint64_t *l1_keys, ull *kocc, const ull *b1_limit,
-       uint32_t *ovf_flag) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const uint32_t B1 = 1u << cfg.l1;
-    // all LDS lives in the dynamic region (16-B aligned base, guide G17)
-    uint32_t *hist = (uint32_t *)(smem + SIMKA_LDS_HEAD);   // [B1+32]: slots B1.. swallow the atomics of invalid positions
-    uint32_t *loff = hist + B1 + 32;                   // [B1]
-    uint32_t *tmp = loff + B1;                         // [K1_BLOCK]
-    ull *gbase = (ull *)(tmp + K1_BLOCK);              // [B1]
-    uint64_t *stage = (uint64_t *)(gbase + B1);        // [K1_BLOCK*K1_SEG]   (SCATTER only)
-    uint32_t *rtab = (uint32_t *)(stage + (SCATTER ? K1_BLOCK * K1_SEG : 0));   // [K1_RTAB] (!FIXED) read starts after the tile's first base, relative to it
-
-    const uint32_t tid = threadIdx.x;
-    for (uint32_t i = tid; i < B1 + 32; i += K1_BLOCK) hist[i] = 0;
-    // variable-length reads: the starts of the reads that begin inside this tile (+ look-ahead), relative to the tile start
-    const uint64_t T0 = (uint64_t)blockIdx.x * (K1_BLOCK * K1_SEG);
-    uint32_t ntab = 0;              // 0: table not usable (too many reads in the tile) -> global binary search per thread
-    if (!FIXED && a.tile_r0) {
-        const uint64_t r0 = a.tile_r0[blockIdx.x], r1 = a.tile_r0[blockIdx.x + 1];
-        // entries offsets[r0+1 .. r1+64] (clamped to offsets[nb_reads] = nb_bases): every read start in (T0, T0 + tile + look-ahead]
-        uint64_t last = r1 + 64;
-        if (last > a.nb_reads) last = a.nb_reads;
-        const uint64_t cnt = last > r0 ? last - r0 : 0;
-        // (zero-length reads could put more than 64 starts into the look-ahead: then the last staged start is too close)
-        const bool covers = cnt > 0 && (last == a.nb_reads || a.offsets[last] - T0 > (uint64_t)(K1_BLOCK * K1_SEG + K1_SEG + 32u));
-        if (covers && cnt <= K1_RTAB) {
-            ntab = (uint32_t)cnt;
-            for (uint32_t i = tid; i < ntab; i += K1_BLOCK) {
-                const uint64_t d = a.offsets[r0 + 1 + i] - T0;
-                rtab[i] = d < 0xffffffffull ? (uint32_t)d : 0xffffffffu;
-            }
-        }
-    }
-    __syncthreads();
-
-    const uint64_t w0 = ((uint64_t)blockIdx.x * K1_BLOCK + tid) * K1_SEG;
-    uint64_t keys[K1_SEG];
-    uint32_t ranks[K1_SEG / 2];      // rank inside the tile's bucket run (< 8192): two u16 per register
-#pragma unroll
-    for (int q = 0; q < K1_SEG; q++) keys[q] = SIMKA_EMPTY_KEY;
-#pragma unroll
-    for (int q = 0; q < K1_SEG / 2; q++) ranks[q] = 0;
-
-    if (w0 < a.nb_bases) {
-        const uint64_t wi = w0 >> 5;
-        const uint32_t sh = (uint32_t)(w0 & 31u) * 2u;
-        const uint64_t lastw = a.nb_words - 1;
-        const uint64_t W0 = a.packed[wi < lastw ? wi : lastw];
-        const uint64_t W1 = a.packed[wi + 1 < lastw ? wi + 1 : lastw];
-        const uint64_t W2 = a.packed[wi + 2 < lastw ? wi + 2 : lastw];
-        const uint64_t A = sh ? ((W0 >> sh) | (W1 << (64u - sh))) : W0;
-        const uint64_t B = sh ? ((W1 >> sh) | (W2 << (64u - sh))) : W1;
-
-        // the read (fragment) that contains base w0, and where the next one starts
-        uint64_t rd, next;
-        uint32_t ti = 0;                 // (!FIXED, staged table) index of the next read start
-        if (FIXED) {
-            rd = w0 / a.fixed_len;
-            next = (rd + 1) * (uint64_t)a.fixed_len;
-        } else if (ntab) {
-            // first staged read start beyond w0 (the table holds every start in (T0, w0 + look-ahead])
-            const uint32_t w0rel = (uint32_t)(w0 - T0);
-            uint32_t lo = 0, hi = ntab;          // smallest i with rtab[i] > w0rel; rtab[ntab-1] > w0rel unless the data end there
-            while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (rtab[mid] > w0rel) hi = mid; else lo = mid + 1; }
-            ti = lo < ntab ? lo : ntab - 1u;
-            rd = 0;
-            next = T0 + rtab[ti];
-        } else {
-            uint64_t lo = 0, hi = a.nb_reads;
-            while (hi - lo > 1) {
-                const uint64_t mid = (lo + hi) >> 1;
-                if (a.offsets[mid] <= w0) lo = mid; else hi = mid;
-            }
-            rd = lo;
-            next = a.offsets[rd + 1];
-        }
-        // positions are handled relative to w0 in 32 bits: nrel = first position of the next read, erel = end of data
-        const uint32_t SPAN = K1_SEG + 32u;                                  // > SEG + k - 1
-        uint32_t nrel = (next - w0 < (uint64_t)SPAN) ? (uint32_t)(next - w0) : SPAN;
-        const uint32_t erel = (a.nb_bases - w0 < (uint64_t)SPAN) ? (uint32_t)(a.nb_bases - w0) : SPAN;
-
-        // No rolling update: the forward k-mer starting at window base q is a static funnel shift of (A,B); its reverse
-        // complement is a static funnel shift of the reverse-complemented window (R0,R1), built ONCE per thread.
-        //   R = revcomp(window bases 0 .. Wn-1), Wn = SEG + k - 1: base p of R = complement(window base Wn-1-p), so the
-        //   reverse complement of the k-mer at q starts at base SEG-1-q of R -- independent of k.
-        const uint32_t k = cfg.k;
-        const uint64_t M5 = 0x5555555555555555ull, MA = 0xAAAAAAAAAAAAAAAAull;
-        uint64_t ra = __brevll(A), rb = __brevll(B);
-        ra = (((ra >> 1) & M5) | ((ra & M5) << 1)) ^ MA;                     // bases 31..0 complemented (code ^ 2)
-        rb = (((rb >> 1) & M5) | ((rb & M5) << 1)) ^ MA;                     // bases 63..32
-        const uint32_t rs = 2u * (64u - (K1_SEG + k - 1u));                  // 36 .. 96 bits: drop the bases beyond Wn
-        const uint64_t R0 = (rs >= 64u) ? (ra >> (rs - 64u)) : ((rb >> rs) | (ra << (64u - rs)));
-        const uint64_t R1 = (rs >= 64u) ? 0ull : (ra >> rs);
-        const uint32_t aw[3] = { (uint32_t)A, (uint32_t)(A >> 32), (uint32_t)B };            // bases 0..47 of the window: positions q < 16 need 94 bits
-        const uint32_t rw[3] = { (uint32_t)R0, (uint32_t)(R0 >> 32), (uint32_t)R1 };
-#pragma unroll
-        for (int q = 0; q < K1_SEG; q++) {
-            if (FIXED) { const bool nb_ = (uint32_t)q >= nrel; nrel = nb_ ? nrel + a.fixed_len : nrel; }
-            else if (ntab) while ((uint32_t)q >= nrel && ti + 1u < ntab) { ti++; const uint64_t nx_ = T0 + rtab[ti] - w0; nrel = nx_ < (uint64_t)SPAN ? (uint32_t)nx_ : SPAN; if (nx_ >= (uint64_t)SPAN) break; }
-            else while ((uint32_t)q >= nrel && rd + 1 < a.nb_reads) { rd++; const uint64_t nx_ = a.offsets[rd + 1] - w0; nrel = nx_ < (uint64_t)SPAN ? (uint32_t)nx_ : SPAN; if (nx_ >= (uint64_t)SPAN) break; }
-            // compile-time shifts < 32 bits after unrolling: each 64-bit extract is two v_alignbit_b32 over the 32-bit window words
-            const uint32_t s1 = 2u * (uint32_t)q, s2 = 2u * (uint32_t)(K1_SEG - 1 - q);
-            static_assert(2 * (K1_SEG - 1) < 32, "funnel shifts stay inside one 32-bit word");
-            const uint64_t fwd = (((uint64_t)__builtin_amdgcn_alignbit(aw[2], aw[1], s1) << 32) | __builtin_amdgcn_alignbit(aw[1], aw[0], s1)) & cfg.mask;
-            const uint64_t rev = (((uint64_t)__builtin_amdgcn_alignbit(rw[2], rw[1], s2) << 32) | __builtin_amdgcn_alignbit(rw[1], rw[0], s2)) & cfg.mask;
-            const uint64_t canon = fwd < rev ? fwd : rev;
-            const uint64_t key = simka_mix(canon, cfg.mask, cfg.xs);
-            const uint32_t b1 = simka_key_l1(key, cfg);
-            // the k-mer [q, q+k) must end inside its read (and inside the data)
-            const bool ok = ((uint32_t)q + k <= nrel) & ((uint32_t)q < erel) & (SHARDED ? simka_owns_l1(b1, cfg) : true);
-            const uint32_t rk = atomicAdd(&hist[ok ? b1 : B1 + (tid & 31u)], 1u);   // invalid positions hit a trash slot: no branch
-            if (SCATTER) {
-                keys[q] = ok ? key : SIMKA_EMPTY_KEY;
-                ranks[q >> 1] |= (ok ? rk : 0u) << ((q & 1) * 16);
-            }
-        }
-    }
-
-    if (!SCATTER) {
-        __syncthreads();
-        for (uint32_t b = tid; b < B1; b += K1_BLOCK) {
-            const uint32_t h = hist[b];
-            if (h) atomicAdd(&b1_count[b], (ull)h);
-        }
-        return;
-    }
-
-    __syncthreads();
-    // reserve this tile's run in every bucket: one returning global atomic per bucket (B1 <= K1_BLOCK: one per thread).  Its
-    // result is only needed by the copy-out, so it stays in a register while the block scans and stages (latency hidden).
-    constexpr int NBK = (1024 + K1_BLOCK - 1) / K1_BLOCK;       // level-1 buckets per thread (B1 <= 1024)
-    ull gb[NBK]; uint32_t myh[NBK];
-#pragma unroll
-    for (int u = 0; u < NBK; u++) {
-        const uint32_t b = tid + (uint32_t)u * K1_BLOCK;
-        gb[u] = 0; myh[u] = 0;
-        if (b < B1) {
-            myh[u] = hist[b];
-            loff[b] = myh[u];
-            if (myh[u]) gb[u] = atomicAdd(&b1_cursor[b], (ull)myh[u]);
-        }
-    }
-    __syncthreads();
-    const uint32_t total = block_excl_scan<K1_BLOCK>(loff, B1, tmp);
-#pragma unroll
-    for (int q = 0; q < K1_SEG; q++) {
-        if (keys[q] != SIMKA_EMPTY_KEY) stage[loff[simka_key_l1(keys[q], cfg)] + ((ranks[q >> 1] >> ((q & 1) * 16)) & 0xffffu)] = keys[q];
-    }
-#pragma unroll
-    for (int u = 0; u < NBK; u++) {
-        const uint32_t b = tid + (uint32_t)u * K1_BLOCK;
-        if (b < B1) {
-            // capacity-sized buckets (no histogram pass): a run that does not fit flags the sample for the exact path
-            if (b1_limit && myh[u] && gb[u] + myh[u] > b1_limit[b]) { *ovf_flag = 1u; gb[u] = ~0ull; }
-            gbase[b] = gb[u];
-        }
-    }
-    __syncthreads();
-    // coalesced copy-out: consecutive staged slots of one bucket go to consecutive HBM addresses
-    for (uint32_t t = tid; t < total; t += K1_BLOCK) {
-        const uint64_t key = stage[t];
-        const uint32_t b = simka_key_l1(key, cfg);
-        const ull gb = gbase[b];
-#ifdef SIMKA_DEBUG_BOUNDS
-        if (gb != ~0ull && (b >= B1 || gb + (t - loff[b]) >= a.nb_words * 64)) {
-            printf("k_scan OOB: blk %u t %u total %u b %u gb %llu loff %u key %llx hist %u\n", blockIdx.x, t, total, b, gb, loff[b], (ull)key, hist[b < B1 ? b : 0]);
-            continue;
-        }
-#endif
-        if (gb != ~0ull) l1_keys[gb + (t - loff[b])] = key;
-    }
-}
-
-// --------------------------------------------------------------------------------------------
-// k_layout: level-1 bucket geometry (block 0; further blocks only clear the lane's partition counters).
-//   mode 0 (exact, after the histogram pass): starts/ends/cursors from the counts, chunk table
-//   mode 1 (capacity, before the scatter): bucket b owns [b*cap, (b+1)*cap), cursor at its start
-//   mode 2 (capacity, after the scatter): ends from the cursors, chunk table
-// --------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256)
-k_layout(const ull *b1_count, ull *b1_start, ull *b1_end, ull *b1_cursor, uint32_t *chunk_first, uint32_t B1, ull *arena_cursor,
-         ull *sample_base, uint32_t mode_flags, ull cap, ull *kocc, const uint32_t *skip_flag, SimkaKeyCfg cfg, SimkaLaneClear clr) {
-    // mode_flags bit 2: a later pass over the same sample (its occurrences add up, its arena base stays)
-    const uint32_t mode = mode_flags & 3u;
-    const bool later_pass = (mode_flags & 4u) != 0u;
-    // the launch before the scatter (modes 0, 1) also resets the lane's level-2 state, instead of four memsets per sample:
-    // blocks 1.. clear the partition counters, block 0 the cursors
-    if (blockIdx.x > 0) {
-        const uint32_t per = (clr.nparts + gridDim.x - 2u) / (gridDim.x - 1u);
-        const uint32_t lo = (blockIdx.x - 1u) * per, hi = (lo + per < clr.nparts) ? lo + per : clr.nparts;
-        for (uint32_t i = lo + threadIdx.x; i < hi; i += blockDim.x) { clr.p_count[i] = 0u; clr.p_valid[i] = 0xffffffffu; }
-        return;
-    }
-    if (mode != 2u && clr.p_count && threadIdx.x < 2u) { clr.spill_cursor[threadIdx.x] = 0ull; clr.redo_count[threadIdx.x] = 0ull; }
-    if (mode == 2 && skip_flag && *skip_flag) return;      // the capacity-mode scatter overflowed: the sample is redone exactly
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    ull *cnt = (ull *)(smem + SIMKA_LDS_HEAD);   // [B1]
-    if (mode == 1) {
-        // owned buckets get `cap` keys each, packed by their rank inside the shard; the others stay empty
-        for (uint32_t b = threadIdx.x; b < B1; b += blockDim.x) {
-            const bool own = simka_owns_l1(b, cfg);
-            const ull st = (ull)simka_bucket_rank(b, cfg) * cap;
-            b1_start[b] = own ? st : 0ull; b1_cursor[b] = own ? st : 0ull; b1_end[b] = own ? st + cap : 0ull;
-        }
-        if (threadIdx.x == 0 && !later_pass) *sample_base = *arena_cursor;
-        return;
-    }
-    // exclusive scans of the bucket sizes (mode 0: starts) and of the chunk counts, 256 threads
-    uint32_t *csz = (uint32_t *)(cnt + B1);          // [B1] chunks per bucket -> first chunk
-    uint32_t *tmp = csz + B1;                        // scan scratch
-    ull *wsum = (ull *)(tmp + 8);                    // [4] per-wave sums of the 64-bit scan
-    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
-    const uint32_t ipt = (B1 + 255u) / 256u;
-    const uint32_t b0 = tid * ipt, e0 = (b0 + ipt < B1) ? b0 + ipt : B1;
-    ull mine = 0;
-    for (uint32_t b = b0; b < e0; b++) {
-        const ull c = (mode == 0) ? b1_count[b] : (b1_cursor[b] - b1_start[b]);
-        cnt[b] = c; csz[b] = (uint32_t)((c + K2_CHUNK - 1) / K2_CHUNK);
-        mine += c;
-    }
-    ull v = mine;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) { const ull t = __shfl_up(v, o, 64); if (lane >= (uint32_t)o) v += t; }
-    if (lane == 63u) wsum[wave] = v;
-    __syncthreads();
-    ull wpre = 0, total = 0;
-    for (uint32_t w = 0; w < 4; w++) { const ull t = wsum[w]; if (w < wave) wpre += t; total += t; }
-    ull run = wpre + v - mine;
-    for (uint32_t b = b0; b < e0; b++) {
-        const ull c = cnt[b];
-        if (mode == 0) { b1_start[b] = run; b1_cursor[b] = run; b1_end[b] = run + c; }
-        else b1_end[b] = b1_start[b] + c;
-        run += c;
-    }
-    const uint32_t nchunks = block_excl_scan<256>(csz, B1, tmp);
-    for (uint32_t b = tid; b < B1; b += 256) chunk_first[b] = csz[b];
-    if (tid == 0) {
-        chunk_first[B1] = nchunks;
-        *kocc = (later_pass ? *kocc : 0ull) + total;   // k-mer occurrences of this shard = sum of its bucket sizes
-        if (mode == 0 && !later_pass) *sample_base = *arena_cursor;   // where this sample's solid records start in the arena
-    }
-}
-
-// --------------------------------------------------------------------------------------------
-// K2a  k_split: level-2 scatter.  One block takes a K2_CHUNK-key chunk of a level-1 bucket, orders it
-// by level-2 bits in LDS (keys stay in registers, LDS rank by returning ds_add) and appends each of the
-// B2 runs to its partition's region of l2_keys with ONE global atomic per run, so every partition ends
-// up contiguous in HBM and k_count streams it with perfectly coalesced loads.
-// Regions are capacity-sized (cap2 = 1.5 x mean + slack; the hash spreads keys evenly).  A run that does
-// not fit goes to the spill buffer with its partition id and the partition is finished by the general
-// kernel; if even the spill buffer overflows the sample is flagged and redone with a full-size one.
-// --------------------------------------------------------------------------------------------
-template <bool NARROW>
-__global__ void __launch_bounds__(K2_BLOCK)
-k_split(const uint64_t *l1_keys, const ull *b1_start, const ull *b1_end, const uint32_t *chunk_first, SimkaKeyCfg cfg,
-        SimkaL2 l2, uint32_t *flag) {
-    if (*flag) return;                               // the level-1 scatter overflowed: the sample is redone exactly
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const uint32_t B1 = 1u << cfg.l1, B2 = 1u << cfg.l2;
-    ull *s_chunk = (ull *)smem;                      // [2][3] (start, n, b1) of the current / next chunk
-    uint32_t *hist = (uint32_t *)(smem + SIMKA_LDS_HEAD);   // [B2] counts, then exclusive offsets
-    uint32_t *tmp = hist + B2;                      // [16] scan scratch
-    ull *gpos = (ull *)(tmp + 16);                  // [B2] destination of each run (bit 63: spill buffer)
-    uint64_t *stage = (uint64_t *)(gpos + B2);      // [K2_CHUNK]
-
-    const uint32_t tid = threadIdx.x;
-    const uint32_t nchunks = chunk_first[B1];
-    const uint32_t rem_mask = NARROW ? ((1u << l2.rem_bits) - 1u) : 0u;
-    constexpr int PER = K2_CHUNK / K2_BLOCK;
-    // chunk c -> (first key, #keys, level-1 bucket): thread 0, into slot `w`
-    auto locate = [&](uint32_t c, uint32_t w) {
-        uint32_t lo = 0, hi = B1;   // largest b with chunk_first[b] <= c  (empty buckets repeat a value)
-        while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (chunk_first[mid] <= c) lo = mid; else hi = mid; }
-        const ull st = b1_start[lo] + (ull)(c - chunk_first[lo]) * K2_CHUNK;
-        const ull be = b1_end[lo];
-        s_chunk[w * 3 + 0] = st; s_chunk[w * 3 + 1] = (be - st < (ull)K2_CHUNK) ? (be - st) : (ull)K2_CHUNK; s_chunk[w * 3 + 2] = lo;
-    };
-    // persistent block: chunks blockIdx.x, +gridDim.x, ...; the keys of the NEXT chunk are loaded into registers while the
-    // current one is ranked, staged and written out
-    uint32_t c = blockIdx.x;
-    if (c >= nchunks) return;
-    if (tid == 0) locate(c, 0);
-    __syncthreads();
-    uint64_t keys[PER], nkeys[PER];
-    {
-        const ull st = s_chunk[0]; const uint32_t n = (uint32_t)s_chunk[1];
-#pragma unroll
-        for (int q = 0; q < PER; q++) { const uint32_t idx = (uint32_t)q * K2_BLOCK + tid; keys[q] = (idx < n) ? l1_keys[st + idx] : SIMKA_EMPTY_KEY; }
-    }
-    for (uint32_t it = 0; c < nchunks; it++, c += gridDim.x) {
-        const uint32_t w = it & 1u;
-        const uint32_t n = (uint32_t)s_chunk[w * 3 + 1], b1 = (uint32_t)s_chunk[w * 3 + 2];
-        const uint32_t cn = c + gridDim.x;
-        if (tid == 0 && cn < nchunks) locate(cn, w ^ 1u);
-        for (uint32_t i = tid; i < B2; i += K2_BLOCK) hist[i] = 0;
-        __syncthreads();
-        if (cn < nchunks) {      // prefetch
-            const ull st = s_chunk[(w ^ 1u) * 3 + 0]; const uint32_t nn = (uint32_t)s_chunk[(w ^ 1u) * 3 + 1];
-#pragma unroll
-            for (int q = 0; q < PER; q++) { const uint32_t idx = (uint32_t)q * K2_BLOCK + tid; nkeys[q] = (idx < nn) ? l1_keys[st + idx] : SIMKA_EMPTY_KEY; }
-        }
-        uint32_t ranks[PER];
-#pragma unroll
-        for (int q = 0; q < PER; q++) {
-            const bool ok = keys[q] != SIMKA_EMPTY_KEY;
-            const uint32_t rk = atomicAdd(&hist[ok ? simka_key_l2(keys[q], cfg) : 0u], ok ? 1u : 0u);
-            ranks[q] = rk;
-        }
-        __syncthreads();
-        // reserve the runs (B2 <= 2048 buckets, <= 2 per thread): returning global atomics whose results are only needed by
-        // the copy-out -- they stay in registers while the block scans and stages
-        uint32_t rh[2] = { 0, 0 }, rpos[2] = { 0, 0 };
-#pragma unroll
-        for (int u = 0; u < 2; u++) {
-            const uint32_t b = tid + (uint32_t)u * K2_BLOCK;
-            if (b < B2) {
-                rh[u] = hist[b];
-                if (rh[u]) rpos[u] = atomicAdd(&l2.p_count[(b1 << cfg.l2) | b], rh[u]);     // reserve the run in its partition
-            }
-        }
-        __syncthreads();
-        block_excl_scan<K2_BLOCK>(hist, B2, tmp);
-#pragma unroll
-        for (int q = 0; q < PER; q++)
-            if (keys[q] != SIMKA_EMPTY_KEY) stage[hist[simka_key_l2(keys[q], cfg)] + ranks[q]] = keys[q];
-#pragma unroll
-        for (int u = 0; u < 2; u++) {
-            const uint32_t b = tid + (uint32_t)u * K2_BLOCK;
-            if (b < B2) {
-                const uint32_t h = rh[u], pos = rpos[u];
-                ull g = 0;
-                if (h) {
-                    const uint32_t part = (b1 << cfg.l2) | b;
-                    if ((ull)pos + h <= l2.cap2) g = simka_region_index(part, cfg) * l2.cap2 + pos;
-                    else {
-                        atomicMin(&l2.p_valid[part], pos);                          // region holds [0,pos) only; the rest is spilled
-                        const ull sp = atomicAdd(&l2.spill_cursor[0], (ull)h);
-                        const ull sr = atomicAdd(&l2.spill_cursor[1], 1ull);
-                        if (sp + h > l2.spill_cap || sr >= l2.spill_run_cap) { atomicOr(flag, 2u); g = ~0ull; }
-                        else { SimkaSpillRun run; run.start = sp; run.part = part; run.len = h; l2.spill_runs[sr] = run; g = (1ull << 63) | sp; }
-                    }
-                }
-                gpos[b] = g;
-            }
-        }
-        __syncthreads();
-        for (uint32_t idx = tid; idx < n; idx += K2_BLOCK) {
-            const uint64_t key = stage[idx];
-            const uint32_t b = simka_key_l2(key, cfg);
-            const ull g = gpos[b];
-            const uint32_t off = idx - hist[b];
-            if (g == ~0ull) continue;
-            if (g >> 63) l2.spill_keys[(g & ~(1ull << 63)) + off] = key;
-            else if (NARROW) ((uint32_t *)l2.l2_keys)[g + off] = (uint32_t)key & rem_mask;    // the partition bits are implicit
-            else l2.l2_keys[g + off] = key;
-        }
-        __syncthreads();
-#pragma unroll
-        for (int q = 0; q < PER; q++) keys[q] = nkeys[q];
-    }
-}
-
-// --------------------------------------------------------------------------------------------
-// K2b  k_count: one partition = one LDS hash table (64-bit CAS insert + counter), then
-// SimkaCompressedProcessor::process (ref: src/minikc/MiniKC.hpp:54-79): abundance filter, emit
-// (k-mer,count), nbDistinct++, nbKmers+=c, chord+=c^2.  Records go to the HBM arena where the reference
-// gzips them to solid/part_<p>/__p__<i>.gz.
-//
-// k_count_fast: persistent blocks, partition p = contiguous keys l2_keys[p*cap2 .. +n): every thread issues
-// K2F_UNROLL coalesced independent loads; the loads of partition p+1 are issued BEFORE the summary pass of
-// partition p (HBM latency hides behind LDS work); summary = one pass in which each thread owns 4 table
-// slots, a block scan places its solid records and the thread clears exactly those slots.
-// Partitions that spilled, exceed the prefetch window or over-fill the table go to the redo list.
-// --------------------------------------------------------------------------------------------
-__device__ __forceinline__ bool table_insert(ull *tkeys, uint32_t *tcnt, uint32_t tmask, ull key) {
-    uint32_t slot = simka_slot_hash(key) & tmask;
-    for (uint32_t probe = 0; probe <= tmask; probe++) {
-        const ull prev = atomicCAS(&tkeys[slot], SIMKA_EMPTY_KEY, key);
-        if (prev == SIMKA_EMPTY_KEY || prev == key) { atomicAdd(&tcnt[slot], 1u); return true; }
-        slot = (slot + 1u) & tmask;
-    }
-    return false;
-}
-// narrow keys (W - pb <= 31 bits: the partition is implicit): 32-bit table, 32-bit multiplicative slot hash
-#define SIMKA_EMPTY_KEY32 0xffffffffu
-__device__ __forceinline__ bool table_insert(uint32_t *tkeys, uint32_t *tcnt, uint32_t tmask, uint32_t key) {
-    uint32_t slot = ((key * 0x9E3779B1u) >> 16) & tmask;
-    for (uint32_t probe = 0; probe <= tmask; probe++) {
-        const uint32_t prev = atomicCAS(&tkeys[slot], SIMKA_EMPTY_KEY32, key);
-        if (prev == SIMKA_EMPTY_KEY32 || prev == key) { atomicAdd(&tcnt[slot], 1u); return true; }
-        slot = (slot + 1u) & tmask;
-    }
-    return false;
-}
-
-// fast path: give up after K2F_PROBES slots -- the table is (nearly) full, the partition goes to the general kernel
-template <typename KT>
-__device__ __forceinline__ bool table_insert_capped(KT *tkeys, uint32_t *tcnt, uint32_t tmask, KT key) {
-    constexpr KT EMPTY = (KT)~(KT)0;
-    uint32_t slot;
-    if (sizeof(KT) == 4) slot = (((uint32_t)key * 0x9E3779B1u) >> 16) & tmask; else slot = simka_slot_hash((ull)key) & tmask;
-#pragma unroll 4
-    for (uint32_t probe = 0; probe < K2F_PROBES; probe++) {
-        const KT prev = atomicCAS(&tkeys[slot], EMPTY, key);
-        if (prev == EMPTY || prev == key) { atomicAdd(&tcnt[slot], 1u); return true; }
-        slot = (slot + 1u) & tmask;
-    }
-    return false;
 }
 
 // reserve `ns` arena records for one partition out of the block's private slab (thread 0 only)
@@ -552,353 +123,6 @@ __device__ __forceinline__ void count_hist(const SimkaCountOut &o, uint32_t *lhi
 #define PH_WAITVM
 #define PH_FLUSH
 #endif
-
-template <uint32_t TS, bool NARROW>
-__global__ void __launch_bounds__(K2F_BLOCK)
-k_count_fast(SimkaKeyCfg cfg, SimkaL2 l2, uint32_t amin, uint32_t amax, SimkaCountOut o, const uint32_t *flag,
-             uint32_t *redo_list, ull *redo_count) {
-    if (*flag) return;
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    ull *s_tot = (ull *)smem;                         // [4]
-    ull &s_base = *(ull *)(smem + 32);
-    uint32_t &s_ok = *(uint32_t *)(smem + 56);
-    uint32_t &s_fail = *(uint32_t *)(smem + 60);
-    ull *s_slab = (ull *)(smem + 64);                 // [2][2] (pos, end) of the block's arena slab, double-buffered by iteration parity
-    uint32_t *tmp = (uint32_t *)(smem + 128);         // [K2F_BLOCK/64]
-    constexpr uint32_t tmask = TS - 1u, SPT = TS / K2F_BLOCK;   // slots per thread
-    using KT = typename std::conditional<NARROW, uint32_t, ull>::type;     // level-2 key as stored: remainder only, or whole key
-    constexpr KT KEMPTY = (KT)~(KT)0;
-    KT *tkeys = (KT *)(smem + SIMKA_LDS_HEAD);        // [TS]
-    uint32_t *tcnt = (uint32_t *)(tkeys + TS);        // [TS]
-    uint32_t *spos = tcnt + TS;                       // [K2F_BLOCK]
-    uint32_t *lhist = spos + K2F_BLOCK;               // [SIMKA_HIST_MAX] (complex only)
-    const KT *l2k = (const KT *)l2.l2_keys;
-
-    const uint32_t tid = threadIdx.x;
-    const uint32_t nparts = 1u << cfg.pb;
-    const ull sample_base = *o.sample_base;
-    {   // the table starts clean; afterwards every thread re-cleans the slots it read
-        uint4 *k4 = (uint4 *)tkeys; uint4 *c4 = (uint4 *)tcnt;
-        for (uint32_t i = tid; i < TS * sizeof(KT) / 16; i += K2F_BLOCK) k4[i] = make_uint4(~0u, ~0u, ~0u, ~0u);
-        for (uint32_t i = tid; i < TS / 4; i += K2F_BLOCK) c4[i] = make_uint4(0, 0, 0, 0);
-    }
-    if (o.hist) for (uint32_t i = tid; i < SIMKA_HIST_MAX; i += K2F_BLOCK) lhist[i] = 0;
-    if (tid < 4) { s_tot[tid] = 0; s_slab[tid] = 0; }
-    if (tid == 0) s_fail = 0u;
-    uint32_t iter = 0;
-    ull bt_dall = 0, bt_D = 0, bt_N = 0, bt_Q = 0;
-
-    KT kk[K2F_UNROLL];
-    // issue the loads of partition p (n keys) -- only partitions the fast path can take in one batch
-#define K2F_LOAD(p, n) {                                                                      \
-    const ull rb_ = simka_region_index(p, cfg) * l2.cap2;                                     \
-    _Pragma("unroll") for (int u = 0; u < K2F_UNROLL; u++) {                                  \
-        const uint32_t i = tid + (uint32_t)u * K2F_BLOCK;                                     \
-        kk[u] = (i < (n)) ? l2k[rb_ + i] : KEMPTY;                                            \
-    } }
-    uint32_t part = blockIdx.x;
-    uint32_t n = 0, n_ahead = 0;            // key counts of this partition and of the next one: loaded one iteration early
-    bool fastp = false;
-    if (part < nparts) {
-        n = l2.p_count[part];
-        fastp = (ull)n <= l2.cap2;          // not spilled
-        if (fastp) { K2F_LOAD(part, n) }
-        if (part + gridDim.x < nparts) n_ahead = l2.p_count[part + gridDim.x];
-    }
-    __syncthreads();
-    PH_DECL
-    while (part < nparts) {
-        const uint32_t next = part + gridDim.x;
-        const uint32_t n_next = n_ahead;
-        const bool fast_next = next < nparts && (ull)n_next <= l2.cap2;
-        n_ahead = (next + gridDim.x < nparts) ? l2.p_count[next + gridDim.x] : 0u;      // consumed in the next iteration
-        if (n == 0) { part = next; n = n_next; fastp = fast_next; if (fastp) { K2F_LOAD(part, n) } continue; }
-        if (!fastp) {     // spilled: the general kernel finishes it
-            if (tid == 0) { const ull w = atomicAdd(redo_count, 1ull); redo_list[w] = part; }
-            part = next; n = n_next; fastp = fast_next; if (fastp) { K2F_LOAD(part, n) }
-            continue;
-        }
-        // ---- insert the prefetched keys
-        PH(0) PH_WAITVM PH(1)
-        bool placed = true;
-#pragma unroll
-        for (int u = 0; u < K2F_UNROLL; u++) {
-            const KT key = kk[u];
-            if (key != KEMPTY) placed &= table_insert_capped<KT>(tkeys, tcnt, tmask, key);
-        }
-        for (uint32_t i = K2F_BLOCK * K2F_UNROLL + tid; i < n; i += K2F_BLOCK)      // beyond the prefetch window (rare)
-            placed &= table_insert_capped<KT>(tkeys, tcnt, tmask, l2k[simka_region_index(part, cfg) * l2.cap2 + i]);
-        if (!placed) s_fail = 1u;           // a key found no slot within K2F_PROBES: the table is too small for this partition
-        PH(2)
-        __syncthreads();
-        PH(3)
-        // ---- prefetch the next partition while this one is summarised
-        if (fast_next) { K2F_LOAD(next, n_next) }
-        // ---- one pass over this thread's slots: SimkaCompressedProcessor::process
-        uint32_t cs[SPT]; KT ks[SPT];
-        uint32_t nsol = 0, ndall = 0;
-        ull D = 0, N = 0, Q = 0;
-#pragma unroll
-        for (uint32_t q = 0; q < SPT; q++) {
-            const uint32_t sl = tid * SPT + q;
-            cs[q] = tcnt[sl]; ks[q] = tkeys[sl];
-            if (cs[q]) { tcnt[sl] = 0; tkeys[sl] = KEMPTY; }     // leave the table clean for the next partition
-            const uint32_t c = cs[q];
-            if (c) { ndall++; if (!(c < amin || c > amax)) { D++; N += c; Q += (ull)c * (ull)c; nsol++; } else cs[q] = 0; }
-        }
-        spos[tid] = nsol | (ndall << 16);
-        PH(4)
-        __syncthreads();
-        const uint32_t tot = block_excl_scan<K2F_BLOCK>(spos, K2F_BLOCK, tmp);
-        PH(5)
-        const uint32_t total = tot & 0xffffu, dall_tot = tot >> 16;
-        const bool ovf = dall_tot > (TS * 7u) / 8u || s_fail != 0u;     // (nearly) full or keys dropped -> the general kernel
-        // arena space for the solid records: the block's slab state is double-buffered in LDS, so in the common case (the
-        // run fits the current slab) every thread derives the base itself and no barrier is needed before the emit
-        const uint32_t par = iter & 1u;
-        iter++;
-        const ull sp_ = s_slab[par * 2u], se_ = s_slab[par * 2u + 1u];
-        const bool fits = !ovf && (total == 0 || (sp_ + total <= se_ && sp_ - sample_base + total <= 0xffffffffull));
-        ull base_ = sample_base;
-        bool ok_ = true;
-        if (fits) {
-            if (total) base_ = sp_;
-            // the bookkeeping is spread over three waves so that no single wave becomes the straggler of the next barrier
-            if (tid == 0) { s_slab[(par ^ 1u) * 2u] = sp_ + total; s_slab[(par ^ 1u) * 2u + 1u] = se_; }
-            if (tid == 64) o.foff[part] = (uint32_t)(base_ - sample_base);
-            if (tid == 128) o.fcnt[part] = total;
-        } else {
-            if (tid == 0) {
-                uint32_t ok = 1;
-                ull slab_pos = sp_, slab_end = se_;
-                if (ovf) { const ull w = atomicAdd(redo_count, 1ull); redo_list[w] = part; ok = 0; }
-                else {
-                    const ull bb = slab_take(slab_pos, slab_end, total, o, sample_base, ok);
-                    o.foff[part] = ok ? (uint32_t)(bb - sample_base) : 0u;
-                    o.fcnt[part] = ok ? total : 0u;
-                    s_base = bb;
-                }
-                s_slab[(par ^ 1u) * 2u] = slab_pos; s_slab[(par ^ 1u) * 2u + 1u] = slab_end;
-                s_ok = ok;
-            }
-            __syncthreads();
-            base_ = s_base; ok_ = s_ok != 0;
-        }
-        PH(6)
-        if (ok_) {
-            bt_dall += ndall; bt_D += D; bt_N += N; bt_Q += Q;
-            ull pos = base_ + (spos[tid] & 0xffffu);
-            const ull khigh = NARROW ? ((ull)part << l2.rem_bits) : 0ull;         // the arena holds whole keys
-#pragma unroll
-            for (uint32_t q = 0; q < SPT; q++) {
-                if (cs[q]) {
-                    o.solid_keys[pos] = khigh | (ull)ks[q]; o.solid_counts[pos] = cs[q]; pos++;
-                    if (o.hist) count_hist(o, lhist, cs[q]);
-                }
-            }
-        }
-        PH(7)
-        if (ovf) { __syncthreads(); if (tid == 0) s_fail = 0u; }      // (uniform) everyone has read the flag
-        part = next; n = n_next; fastp = fast_next;
-    }
-    PH_FLUSH
-#undef K2F_LOAD
-    if (o.hist) {
-        __syncthreads();
-        for (uint32_t i = tid; i < SIMKA_HIST_MAX; i += K2F_BLOCK)
-            if (lhist[i]) atomicAdd(&o.hist[(size_t)o.sample * SIMKA_HIST_MAX + i], (ull)lhist[i]);
-    }
-    if (bt_dall) atomicAdd(&s_tot[0], bt_dall);
-    if (bt_D) { atomicAdd(&s_tot[1], bt_D); atomicAdd(&s_tot[2], bt_N); atomicAdd(&s_tot[3], bt_Q); }
-    __syncthreads();
-    if (tid == 0) {
-        ull *t = o.totals + o.sample;
-        const size_t ns_ = o.nb_samples;
-        if (s_tot[0]) atomicAdd(&t[SIMKA_TOT_DALL * ns_], s_tot[0]);
-        if (s_tot[1]) { atomicAdd(&t[SIMKA_TOT_D * ns_], s_tot[1]); atomicAdd(&t[SIMKA_TOT_N * ns_], s_tot[2]); atomicAdd(&t[SIMKA_TOT_Q * ns_], s_tot[3]); }
-    }
-}
-
-// k_count: the general kernel for the partitions on the redo list (spilled, very large, or more distinct keys than
-// table slots): streams the region + the partition's spill entries, and re-runs in 2,4,.. rounds on extra key bits
-// until every round fits the table.  pass 0 counts (and emits when one round suffices), pass 1 emits.
-__global__ void __launch_bounds__(K2C_BLOCK)
-k_count(SimkaKeyCfg cfg, SimkaL2 l2, uint32_t table_log2, uint32_t amin, uint32_t amax, SimkaCountOut o, const uint32_t *flag,
-        const uint32_t *part_list, const ull *part_count) {
-    if (*flag) return;
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    ull *s_tot = (ull *)smem;                         // [4] D_all, D, N, Q of the whole block
-    ull &s_base = *(ull *)(smem + 32);
-    ull &s_slab_pos = *(ull *)(smem + 40);
-    ull &s_slab_end = *(ull *)(smem + 48);
-    uint32_t &s_nsolid = *(uint32_t *)(smem + 56);
-    uint32_t &s_cur = *(uint32_t *)(smem + 60);
-    uint32_t &s_ovf = *(uint32_t *)(smem + 64);
-    const uint32_t TS = 1u << table_log2, tmask = TS - 1u;
-    ull *tkeys = (ull *)(smem + SIMKA_LDS_HEAD);      // [TS]
-    uint32_t *tcnt = (uint32_t *)(tkeys + TS);        // [TS]
-    uint32_t *mlist = tcnt + TS;                      // [K2C_MATCH] spill runs of the current partition
-    uint32_t *lhist = mlist + K2C_MATCH;              // [SIMKA_HIST_MAX] solid-count histogram (complex only)
-    uint32_t &s_nmatch = *(uint32_t *)(smem + 68);
-    if (o.hist) for (uint32_t i = threadIdx.x; i < SIMKA_HIST_MAX; i += K2C_BLOCK) lhist[i] = 0;
-
-    const uint32_t nparts = 1u << cfg.pb;
-    const uint32_t tid = threadIdx.x;
-    const uint32_t free_bits = cfg.W - cfg.pb;
-    if (tid < 4) s_tot[tid] = 0;
-    if (tid == 0) { s_slab_pos = 0; s_slab_end = 0; }
-    ull bt_dall = 0, bt_D = 0, bt_N = 0, bt_Q = 0;
-    const ull sample_base = *o.sample_base;
-    const uint32_t nwork = part_list ? (uint32_t)(*part_count < (ull)nparts ? *part_count : (ull)nparts) : nparts;
-
-    for (uint32_t wi = blockIdx.x; wi < nwork; wi += gridDim.x) {
-        const uint32_t part = part_list ? part_list[wi] : wi;
-        const uint32_t pc = l2.p_count[part];
-        if (pc == 0) continue;
-        const uint32_t pv = l2.p_valid[part];
-        const uint32_t nreg = (uint32_t)((ull)(pv < pc ? pv : pc) < l2.cap2 ? (pv < pc ? pv : pc) : (uint32_t)l2.cap2);   // keys in the region
-        const uint32_t nruns = (pc > nreg) ? (uint32_t)(l2.spill_cursor[1] < l2.spill_run_cap ? l2.spill_cursor[1] : l2.spill_run_cap) : 0u;   // spill runs to look through
-        const ull *reg = l2.l2_keys + simka_region_index(part, cfg) * l2.cap2;
-        const uint32_t *reg32 = (const uint32_t *)l2.l2_keys + simka_region_index(part, cfg) * l2.cap2;       // narrow level-2 keys: remainder only
-        const ull khigh = (ull)part << l2.rem_bits;
-        __syncthreads();
-        if (tid == 0) { s_nsolid = 0; s_cur = 0; s_ovf = 0; s_nmatch = 0; }
-        __syncthreads();
-        // the spill runs of this partition, found once (the rounds below re-read only these)
-        for (uint32_t i = tid; i < nruns; i += K2C_BLOCK)
-            if (l2.spill_runs[i].part == part) { const uint32_t m = atomicAdd(&s_nmatch, 1u); if (m < K2C_MATCH) mlist[m] = i; }
-        __syncthreads();
-        const uint32_t nmatch_all = s_nmatch;
-        const bool listed = nmatch_all <= K2C_MATCH;
-
-        uint32_t nr_log2 = 0;
-        ull emit_base = 0;
-        bool part_done = false;
-        for (int pass = 0; pass < 2 && !part_done; pass++) {
-            bool restart = false;
-            ull dall = 0, D = 0, N = 0, Q = 0;
-            for (uint32_t r = 0; r < (1u << nr_log2); r++) {
-                __syncthreads();
-                {   // clear the table with 16-byte LDS stores
-                    ulonglong2 *k2 = (ulonglong2 *)tkeys; uint4 *c4 = (uint4 *)tcnt;
-                    const ulonglong2 ek = make_ulonglong2(SIMKA_EMPTY_KEY, SIMKA_EMPTY_KEY);
-                    const uint4 z = make_uint4(0, 0, 0, 0);
-                    for (uint32_t i = tid; i < TS / 2; i += K2C_BLOCK) k2[i] = ek;
-                    for (uint32_t i = tid; i < TS / 4; i += K2C_BLOCK) c4[i] = z;
-                }
-                __syncthreads();
-                const uint32_t rsh = free_bits - nr_log2;
-                for (uint32_t i0 = tid; i0 < nreg; i0 += K2C_BLOCK * K2_UNROLL) {
-                    ull keyv[K2_UNROLL];
-#pragma unroll
-                    for (int u = 0; u < K2_UNROLL; u++) {
-                        const uint32_t i = i0 + (uint32_t)u * K2C_BLOCK;
-                        keyv[u] = (i < nreg) ? (l2.narrow ? (khigh | (ull)reg32[i]) : reg[i]) : SIMKA_EMPTY_KEY;
-                    }
-#pragma unroll
-                    for (int u = 0; u < K2_UNROLL; u++) {
-                        const ull key = keyv[u];
-                        if (key == SIMKA_EMPTY_KEY) continue;
-                        if (nr_log2 && (uint32_t)((key >> rsh) & ((1ull << nr_log2) - 1ull)) != r) continue;
-                        if (!table_insert(tkeys, tcnt, tmask, key)) s_ovf = 1;
-                    }
-                }
-                for (uint32_t m = 0; m < (listed ? nmatch_all : nruns); m++) {
-                    const SimkaSpillRun run = l2.spill_runs[listed ? mlist[m] : m];
-                    if (run.part != part) continue;                       // (unlisted: every run is looked at)
-                    for (uint32_t j = tid; j < run.len; j += K2C_BLOCK) {
-                        const ull key = l2.spill_keys[run.start + j];
-                        if (nr_log2 && (uint32_t)((key >> rsh) & ((1ull << nr_log2) - 1ull)) != r) continue;
-                        if (!table_insert(tkeys, tcnt, tmask, key)) s_ovf = 1;
-                    }
-                }
-                __syncthreads();
-                if (s_ovf) { restart = true; break; }
-                if (pass == 0) {
-                    const uint4 *c4 = (const uint4 *)tcnt;
-                    for (uint32_t i = tid; i < TS / 4; i += K2C_BLOCK) {
-                        const uint4 q = c4[i];
-                        const uint32_t cs[4] = { q.x, q.y, q.z, q.w };
-#pragma unroll
-                        for (int j = 0; j < 4; j++) {
-                            const uint32_t c = cs[j];
-                            if (c) { dall++; if (!(c < amin || c > amax)) { D++; N += c; Q += (ull)c * (ull)c; } }
-                        }
-                    }
-                    if (nr_log2 == 0) {   // single round: reserve now, emit from the live table
-                        if (D) atomicAdd(&s_nsolid, (uint32_t)D);
-                        __syncthreads();
-                        if (tid == 0) {
-                            const uint32_t ns = s_nsolid;
-                            uint32_t ok = 1;
-                            const ull bb = ns ? slab_take(s_slab_pos, s_slab_end, ns, o, sample_base, ok) : sample_base;
-                            o.foff[part] = ok ? (uint32_t)(bb - sample_base) : 0u;
-                            o.fcnt[part] = ok ? ns : 0u;
-                            s_base = bb; s_ovf = ok ? 0u : 2u;
-                        }
-                        __syncthreads();
-                        emit_base = s_base;
-                    }
-                }
-                if ((pass == 1 || nr_log2 == 0) && s_ovf != 2u) {
-                    const uint4 *c4 = (const uint4 *)tcnt;
-                    for (uint32_t i = tid; i < TS / 4; i += K2C_BLOCK) {
-                        const uint4 q = c4[i];
-                        const uint32_t cs[4] = { q.x, q.y, q.z, q.w };
-#pragma unroll
-                        for (int j = 0; j < 4; j++) {
-                            const uint32_t c = cs[j];
-                            if (c && !(c < amin || c > amax)) {
-                                const uint32_t pos = atomicAdd(&s_cur, 1u);
-                                o.solid_keys[emit_base + pos] = tkeys[i * 4 + j];
-                                o.solid_counts[emit_base + pos] = c;
-                                if (o.hist) count_hist(o, lhist, c);
-                            }
-                        }
-                    }
-                }
-            }
-            if (restart) {
-                __syncthreads();
-                if (nr_log2 >= free_bits || nr_log2 >= 16) { if (tid == 0) atomicOr(o.err, SIMKA_DEVERR_TABLE_OVERFLOW); part_done = true; continue; }
-                if (tid == 0) s_ovf = 0;
-                nr_log2++; pass = -1;       // start over with twice the rounds (nothing was emitted yet)
-                continue;
-            }
-            if (pass == 0) {
-                bt_dall += dall; bt_D += D; bt_N += N; bt_Q += Q;
-                if (nr_log2 == 0) { part_done = true; continue; }     // single round: already emitted
-                if (D) atomicAdd(&s_nsolid, (uint32_t)D);
-                __syncthreads();
-                if (tid == 0) {
-                    const uint32_t ns = s_nsolid;
-                    uint32_t ok = 1;
-                    const ull bb = ns ? slab_take(s_slab_pos, s_slab_end, ns, o, sample_base, ok) : sample_base;
-                    o.foff[part] = ok ? (uint32_t)(bb - sample_base) : 0u;
-                    o.fcnt[part] = ok ? ns : 0u;
-                    s_base = bb; s_ovf = ok ? 0u : 2u;
-                }
-                __syncthreads();
-                if (s_ovf == 2u || s_nsolid == 0) { part_done = true; continue; }
-                emit_base = s_base;
-            }
-        }
-    }
-    if (o.hist) {
-        __syncthreads();
-        for (uint32_t i = tid; i < SIMKA_HIST_MAX; i += K2C_BLOCK)
-            if (lhist[i]) atomicAdd(&o.hist[(size_t)o.sample * SIMKA_HIST_MAX + i], (ull)lhist[i]);
-    }
-    if (bt_dall) atomicAdd(&s_tot[0], bt_dall);
-    if (bt_D) { atomicAdd(&s_tot[1], bt_D); atomicAdd(&s_tot[2], bt_N); atomicAdd(&s_tot[3], bt_Q); }
-    __syncthreads();
-    if (tid == 0) {
-        ull *t = o.totals + o.sample;
-        const size_t ns_ = o.nb_samples;
-        if (s_tot[0]) atomicAdd(&t[SIMKA_TOT_DALL * ns_], s_tot[0]);
-        if (s_tot[1]) { atomicAdd(&t[SIMKA_TOT_D * ns_], s_tot[1]); atomicAdd(&t[SIMKA_TOT_N * ns_], s_tot[2]); atomicAdd(&t[SIMKA_TOT_Q * ns_], s_tot[3]); }
-    }
-}
 
 // per-partition record totals over all samples (input of the host-side partition scan)
 __global__ void __launch_bounds__(256)
