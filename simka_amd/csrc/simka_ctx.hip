@@ -388,7 +388,7 @@ SIMKA_EXPORT int simka_create(const simka_config *cfg, simka_ctx **out) {
     if (!chk(dev_alloc(&ctx->d_sample_base, N + 1), "hipMalloc(sample_base)")) return bail(SIMKA_ERR_NOMEM);
     if (!chk(dev_alloc(&ctx->d_cursors, 4), "hipMalloc(cursors)")) return bail(SIMKA_ERR_NOMEM);
     if (cfg->dist_flags & SIMKA_DIST_COMPLEX) {
-        ctx->ovf_cap = (uint64_t)1 << 22;
+        ctx->ovf_cap = getenv("SIMKA_OVF_CAP") ? (uint64_t)atoll(getenv("SIMKA_OVF_CAP")) : (uint64_t)1 << 22;      // (tests shrink it)
         if (!chk(dev_alloc(&ctx->d_hist, (uint64_t)N * SIMKA_HIST_MAX), "hipMalloc(hist)")) return bail(SIMKA_ERR_NOMEM);
         if (!chk(dev_alloc(&ctx->d_ovf_list, 2 * ctx->ovf_cap), "hipMalloc(ovf)")) return bail(SIMKA_ERR_NOMEM);
         if (!chk(dev_alloc(&ctx->d_ovf_cursor, 2), "hipMalloc(ovf cursor)")) return bail(SIMKA_ERR_NOMEM);
@@ -1467,9 +1467,22 @@ static int complex_finish(simka_ctx *ctx, const SimkaPairCfg &pc) {
         ull *d_whit = (ull *)ctx->d_stats + stats_off_acc(N, pc.nacc32 + 0);
         HIPCHK(hipMemcpyAsync(whit.data(), d_whit, pc.nb_pairs * 8, hipMemcpyDeviceToHost, ctx->stream));
         HIPCHK(hipStreamSynchronize(ctx->stream));
-        if (novf > ctx->ovf_cap) return ctx->fail(SIMKA_ERR_OVERFLOW, "more than %llu k-mers with a count >= %d: complex-dist histogram list exhausted", (unsigned long long)ctx->ovf_cap, SIMKA_HIST_MAX);
         std::vector<uint32_t> ovf(2 * novf);
-        if (novf) HIPCHK(hipMemcpy(ovf.data(), ctx->d_ovf_list, novf * 8, hipMemcpyDeviceToHost));
+        if (novf > ctx->ovf_cap) {
+            // the fixed-size list overflowed (the cursor kept counting): rebuild it at its exact size from the resident spectra
+            if (ctx->wide) return ctx->fail(SIMKA_ERR_OVERFLOW, "more than %llu k-mers with a count >= %d: complex-dist histogram list exhausted (k >= 32)", (unsigned long long)ctx->ovf_cap, SIMKA_HIST_MAX);
+            uint32_t *d_list = nullptr; ull *d_cur = nullptr;
+            if (dev_alloc(&d_list, 2 * novf) != hipSuccess || dev_alloc(&d_cur, 1) != hipSuccess) { if (d_list) (void)hipFree(d_list); return ctx->fail(SIMKA_ERR_NOMEM, "cannot allocate the list of %llu large counts", (unsigned long long)novf); }
+            HIPCHK(hipMemsetAsync(d_cur, 0, 8, ctx->stream));
+            hipLaunchKernelGGL(k_big_counts, dim3((uint32_t)std::min<uint64_t>(ctx->nparts, 1024), N), dim3(256), 0, ctx->stream, (const uint32_t *)ctx->d_solid_counts,
+                               (const ull *)ctx->d_sample_base, (const uint32_t *)ctx->d_foff, (const uint32_t *)ctx->d_fcnt, (uint32_t)ctx->nparts, d_list, d_cur, novf);
+            ull got = 0;
+            HIPCHK(hipMemcpyAsync(&got, d_cur, 8, hipMemcpyDeviceToHost, ctx->stream));
+            HIPCHK(hipMemcpyAsync(ovf.data(), d_list, novf * 8, hipMemcpyDeviceToHost, ctx->stream));
+            HIPCHK(hipStreamSynchronize(ctx->stream));
+            (void)hipFree(d_list); (void)hipFree(d_cur);
+            if (got != novf) return ctx->fail(SIMKA_ERR_STATE, "complex-dist: %llu large counts on the list, %llu in the spectra", (unsigned long long)novf, (unsigned long long)got);
+        } else if (novf) HIPCHK(hipMemcpy(ovf.data(), ctx->d_ovf_list, novf * 8, hipMemcpyDeviceToHost));
         std::vector<std::vector<std::pair<uint32_t, ull>>> cnts(N);        // per sample: (count, #k-mers)
         for (uint32_t i = 0; i < N; i++)
             for (uint32_t cc = 0; cc < SIMKA_HIST_MAX; cc++) if (hist[(size_t)i * SIMKA_HIST_MAX + cc]) cnts[i].push_back({cc, hist[(size_t)i * SIMKA_HIST_MAX + cc]});

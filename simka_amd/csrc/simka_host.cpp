@@ -13,6 +13,7 @@
 #include <stdio.h>
 #include <string.h>
 #include <string>
+#include <algorithm>
 #include <vector>
 #include <zlib.h>
 
@@ -231,8 +232,16 @@ SIMKA_EXPORT int simka_write_matrix_csv(const char *dir, const char *name, const
     if (gz) {
         gzFile g = gzopen(path.c_str(), "wb");
         if (!g) return SIMKA_ERR_IO;
-        const int w = gzwrite(g, text.data(), (unsigned)text.size());
-        if (gzclose(g) != Z_OK || w != (int)text.size()) return SIMKA_ERR_IO;
+        // (gzwrite takes an unsigned length and returns an int: a matrix of ~15000 samples passes 2 GiB of text)
+        size_t done = 0;
+        bool ok = true;
+        while (ok && done < text.size()) {
+            const size_t chunk = std::min<size_t>(text.size() - done, (size_t)1 << 28);
+            const int w = gzwrite(g, text.data() + done, (unsigned)chunk);
+            if (w <= 0 || (size_t)w != chunk) ok = false;
+            done += chunk;
+        }
+        if (gzclose(g) != Z_OK || !ok) return SIMKA_ERR_IO;
     } else {
         FILE *f = fopen(path.c_str(), "wb");
         if (!f) return SIMKA_ERR_IO;

@@ -1099,6 +1099,27 @@ k_pairs_global(const SimkaSpan *huge, const ull *cursors, const ull *entries, Si
 }
 
 // --------------------------------------------------------------------------------------------
+// k_big_counts: (sample, count) of every solid record with count >= SIMKA_HIST_MAX, collected from the resident spectra.
+// -complex-dist keeps such counts on a list next to the per-sample histogram; the count kernels fill a fixed-size list, and
+// when it overflows (deep samples with high-copy sequences) the list is rebuilt here at its exact size.
+// --------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+k_big_counts(const uint32_t *solid_counts, const ull *sample_base, const uint32_t *foff, const uint32_t *fcnt, uint32_t nparts, uint32_t *list,
+             ull *cursor, ull cap) {
+    const uint32_t s = blockIdx.y;
+    const ull base = sample_base[s];
+    const uint32_t *fo = foff + (size_t)s * nparts, *fc = fcnt + (size_t)s * nparts;
+    for (uint32_t p = blockIdx.x; p < nparts; p += gridDim.x) {
+        const uint32_t n = fc[p];
+        const ull src = base + fo[p];
+        for (uint32_t i = threadIdx.x; i < n; i += 256) {
+            const uint32_t c = solid_counts[src + i];
+            if (c >= SIMKA_HIST_MAX) { const ull w = atomicAdd(cursor, 1ull); if (w < cap) { list[2 * w] = s; list[2 * w + 1] = c; } }
+        }
+    }
+}
+
+// --------------------------------------------------------------------------------------------
 // k_gather_sample: the arena records of one sample, partition-major and gap-free (simka_export_sample)
 // --------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256)

@@ -127,6 +127,25 @@ def test_synthetic_vs_oracle(gpu_required, oracle_mod, k, amin, n, R, L, kw):
             np.testing.assert_allclose(st.matrices()[name], orc.matrix(w), rtol=1e-6, atol=0)
 
 
+def test_complex_dist_list_of_large_counts_is_rebuilt_when_it_overflows(gpu_required, oracle_mod, monkeypatch):
+    """-complex-dist keeps counts >= 1024 on a fixed-size device list (Whittaker's one-sided terms); when it overflows the list
+    is rebuilt at its exact size from the resident spectra instead of failing after the merge (the reference has no such
+    limit).  Tiny k gives every k-mer a huge count; SIMKA_OVF_CAP shrinks the list to 2 entries."""
+    from simka_amd import synth
+    monkeypatch.setenv("SIMKA_OVF_CAP", "2")
+    k, amin, n, R, L = 5, 1, 4, 3000, 60
+    packed = _synthetic(n, R, L, seed_shift=3)
+    offs = np.arange(R + 1, dtype=np.uint64) * L
+    inputs = [(np.concatenate([pk, np.zeros(2, dtype=np.uint64)]), offs, R * L, R) for pk in packed]
+    totals, st = _run_gpu(inputs, k, amin, simple=True, complex_=True)
+    orc = oracle_mod.Oracle()
+    for s, pk in enumerate(packed):
+        orc.add_sample_ascii("S%d" % s, synth.unpack_ascii(pk, R * L), offs)
+    orc.run(k, amin, simple=True, complex_=True)
+    assert int(max(orc.totals()["N"])) // 512 >= 1024          # (counts far beyond the histogram's exact bins)
+    _check_vs_oracle(totals, st, orc)
+
+
 def test_fixed_len_equals_offsets(gpu_required):
     """fixed_len fast path == explicit offsets."""
     R, L = 4000, 100
