@@ -17,7 +17,9 @@
  *
  * Stages (SURVEY.md section 8a row names in brackets):
  *   [a1] or_parse_input        ref: src/core/SimkaAlgorithm.cpp:245-351
- *   [a2] or_read_file          ref: src/core/SimkaCommons.hpp:159-314 (default policy: all reads, no filter)
+ *   [a2] or_iter_* / or_filter ref: src/core/SimkaCommons.hpp:159-314 (SimkaInputIterator: -max-reads per paired part, the read m+1
+ *                                   that is fetched and overwritten, files-per-part = composition / nbPaired) and :317-436
+ *                                   (SimkaSequenceFilter: -min-read-size, -min-shannon-index), restated method by method
  *   [a3] or_count_sample       ref: src/SimkaCount.cpp:291-297 (gatb SortingCountAlgorithm: canonical k-mers,
  *                                   emitted in increasing order with their count; gatb-core 1.x, absent)
  *   [a4] or_filter_totals      ref: src/minikc/MiniKC.hpp:54-79
@@ -147,6 +149,7 @@ typedef struct {
 typedef struct {
     or_sample *s; int n;
     int k; uint32_t amin, amax;
+    uint64_t max_reads; uint64_t min_read_size; double min_shannon;   /* [a2] read policies (0 = off) */
     or_stats *stats;
     char err[512];
 } oracle;
@@ -211,94 +214,284 @@ static void sb_app(strbuf *s, const char *p, size_t n) {
     memcpy(s->b + s->n, p, n); s->n += n; s->b[s->n] = 0;
 }
 
-static int or_read_file(const char *path, int k, u64vec *out, uint64_t *nreads, uint64_t *kocc) {
-    gzFile g = gzopen(path, "rb");
-    if (!g) return -1;
-    gzbuffer(g, 1 << 20);
+/* one sequence file as gatb's Bank iterator: first() / next() / isDone() / item() */
+typedef struct {
+    const char *path; gzFile g;
+    strbuf seq, cur;            /* record being read / the current item */
+    int state;                  /* 0 none, 1 fasta seq, 2 fastq seq line next, 3 fastq '+' seen (skip quals) */
+    size_t qual_left;
+    int done;
+} or_bank;
+
+/* next record of the file into b->cur; 0 at the end of the file */
+static int or_bank_read(or_bank *b) {
     static __thread char buf[1 << 16];
-    strbuf seq = {0};
-    int state = 0;   /* 0 none, 1 fasta seq, 2 fastq seq line next, 3 fastq '+' seen (skip quals) */
-    size_t qual_left = 0;
-    while (gzgets(g, buf, sizeof buf)) {
+    while (gzgets(b->g, buf, sizeof buf)) {
         size_t l = strlen(buf);
         int full_line = (l > 0 && buf[l - 1] == '\n');
         while (l > 0 && (buf[l - 1] == '\n' || buf[l - 1] == '\r')) buf[--l] = 0;
-        if (state == 3) {           /* quality lines: consume as many chars as the sequence had */
-            if (l >= qual_left) { qual_left = 0; state = 0; } else qual_left -= l;
+        if (b->state == 3) {           /* quality lines: consume as many chars as the sequence had */
+            if (l >= b->qual_left) { b->qual_left = 0; b->state = 0; } else b->qual_left -= l;
             continue;
         }
-        if (state != 2 && buf[0] == '>') {
-            if (seq.n) { *kocc += or_kmers_of_read(seq.b, seq.n, k, out); (*nreads)++; seq.n = 0; }
-            else if (state == 1) (*nreads)++;
-            state = 1;
-            while (!full_line && gzgets(g, buf, sizeof buf)) { size_t m = strlen(buf); full_line = (m > 0 && buf[m - 1] == '\n'); }
+        if (b->state != 2 && buf[0] == '>') {
+            const int had = b->state == 1;
+            if (had) { b->cur.n = 0; sb_app(&b->cur, b->seq.b ? b->seq.b : "", b->seq.n); }
+            b->seq.n = 0; b->state = 1;
+            while (!full_line && gzgets(b->g, buf, sizeof buf)) { size_t m = strlen(buf); full_line = (m > 0 && buf[m - 1] == '\n'); }
+            if (had) return 1;          /* the record before this header (possibly empty) */
             continue;
         }
-        if (state == 0 && buf[0] == '@') {
-            state = 2; seq.n = 0;
-            while (!full_line && gzgets(g, buf, sizeof buf)) { size_t m = strlen(buf); full_line = (m > 0 && buf[m - 1] == '\n'); }
+        if (b->state == 0 && buf[0] == '@') {
+            b->state = 2; b->seq.n = 0;
+            while (!full_line && gzgets(b->g, buf, sizeof buf)) { size_t m = strlen(buf); full_line = (m > 0 && buf[m - 1] == '\n'); }
             continue;
         }
-        if (state == 2) {
-            if (buf[0] == '+' ) {
-                *kocc += or_kmers_of_read(seq.b ? seq.b : "", seq.n, k, out); (*nreads)++;
-                qual_left = seq.n; seq.n = 0; state = qual_left ? 3 : 0;
-                continue;
+        if (b->state == 2) {
+            if (buf[0] == '+') {
+                b->cur.n = 0; sb_app(&b->cur, b->seq.b ? b->seq.b : "", b->seq.n);
+                b->qual_left = b->seq.n; b->seq.n = 0; b->state = b->qual_left ? 3 : 0;
+                return 1;
             }
-            sb_app(&seq, buf, l);
+            sb_app(&b->seq, buf, l);
             continue;
         }
-        if (state == 1) sb_app(&seq, buf, l);
+        if (b->state == 1) sb_app(&b->seq, buf, l);
     }
-    if (state == 1) { if (seq.n) *kocc += or_kmers_of_read(seq.b, seq.n, k, out); (*nreads)++; }
-    free(seq.b);
-    gzclose(g);
+    if (b->state == 1) { b->cur.n = 0; sb_app(&b->cur, b->seq.b ? b->seq.b : "", b->seq.n); b->seq.n = 0; b->state = 0; return 1; }
     return 0;
+}
+static int or_bank_first(or_bank *b) {
+    if (b->g) gzclose(b->g);
+    b->g = gzopen(b->path, "rb");
+    if (!b->g) { b->done = 1; return -1; }
+    gzbuffer(b->g, 1 << 20);
+    b->state = 0; b->qual_left = 0; b->seq.n = 0;
+    b->done = !or_bank_read(b);
+    return 0;
+}
+static void or_bank_next(or_bank *b) { if (!b->done) b->done = !or_bank_read(b); }
+static void or_bank_close(or_bank *b) { if (b->g) gzclose(b->g); free(b->seq.b); free(b->cur.b); memset(b, 0, sizeof *b); }
+
+/* SimkaSequenceFilter::operator()   ref: src/core/SimkaCommons.hpp:359-436 */
+static float or_shannon_index(const char *seq, size_t n) {          /* getShannonIndex, :392-432 */
+    static const char nt2bin[128] = { ['C'] = 1, ['T'] = 2, ['G'] = 3, ['N'] = 4 };      /* nt2binTab :394-405: every other letter is 0 */
+    float freqs[5] = { 0, 0, 0, 0, 0 };
+    float index = 0;
+    for (size_t i = 0; i < n; i++) freqs[(int)nt2bin[(unsigned char)seq[i] & 127]] += 1.0f;
+    for (int i = 0; i < 5; i++) {
+        freqs[i] /= (float)n;
+        if (freqs[i] != 0) index += freqs[i] * log(freqs[i]) / log(2);
+    }
+    return fabsf(index);
+}
+static int or_filter(const oracle *o, const strbuf *seq) {
+    if (o->min_read_size != 0 && !(seq->n >= o->min_read_size)) return 0;                               /* isReadSizeValid :378-381 */
+    if (o->min_shannon != 0 && !(or_shannon_index(seq->b ? seq->b : "", seq->n) >= o->min_shannon)) return 0;   /* isShannonIndexValid :383-386 */
+    return 1;
+}
+
+/* SimkaInputIterator   ref: src/core/SimkaCommons.hpp:159-314, member for member */
+typedef struct {
+    const oracle *o;
+    or_bank *comp; size_t ncomp;        /* _mainref->getComposition(): every file of the sample, in the order listed */
+    or_bank *ref;                       /* _ref */
+    int isDone;
+    size_t currentBank, nbBanks, currentInternalBank, currentDataset, nbDatasets;
+    uint64_t maxReads, nbReadProcessed;
+    const strbuf *item;
+    int io_error;
+} or_iter;
+
+static int or_iter_is_finished(or_iter *it) {                       /* :183-189 */
+    if (it->currentDataset == it->nbDatasets) { it->isDone = 1; return 1; }
+    return 0;
+}
+static void or_iter_first(or_iter *it) {                            /* :224-236 */
+    if (or_bank_first(it->ref) != 0) it->io_error = 1;
+    while (!it->ref->done && !or_filter(it->o, &it->ref->cur)) or_bank_next(it->ref);
+    it->isDone = it->ref->done;
+    if (!it->isDone) it->item = &it->ref->cur;
+}
+static void or_iter_next_dataset(or_iter *it) {                     /* :191-208 */
+    it->currentDataset += 1;
+    if (or_iter_is_finished(it)) return;
+    it->currentBank = it->currentDataset * it->nbBanks;
+    it->currentInternalBank = 0;
+    it->nbReadProcessed = 0;
+    if (or_iter_is_finished(it)) return;
+    it->ref = &it->comp[it->currentBank];
+    it->isDone = 0;
+    or_iter_first(it);
+}
+static void or_iter_next_bank(or_iter *it) {                        /* :210-222 */
+    it->currentInternalBank += 1;
+    if (it->currentInternalBank == it->nbBanks) or_iter_next_dataset(it);
+    else {
+        it->isDone = 0;
+        it->currentBank += 1;
+        it->ref = &it->comp[it->currentBank];
+        or_iter_first(it);
+    }
+}
+static void or_iter_next(or_iter *it) {                             /* :238-288 */
+    if (or_iter_is_finished(it)) { it->isDone = 1; return; }
+    or_bank_next(it->ref);
+    while (!it->ref->done && !or_filter(it->o, &it->ref->cur)) or_bank_next(it->ref);
+    it->isDone = it->ref->done;
+    if (it->isDone) {
+        if (or_iter_is_finished(it)) return;
+        else {
+            or_iter_next_bank(it);
+            if (or_iter_is_finished(it)) return;
+        }
+    } else {
+        it->item = &it->ref->cur;
+        it->nbReadProcessed += 1;
+    }
+    if (it->maxReads && it->nbReadProcessed >= it->maxReads) {
+        if (or_iter_is_finished(it)) return;
+        else or_iter_next_dataset(it);
+    }
+}
+
+/* the reads a simkaCount job hands to the counter: SimkaPotaraBankFiltered over the sample's files (ref: src/SimkaCount.cpp:44-70,267-268) */
+static int or_read_sample_files(const oracle *o, or_sample *s, u64vec *out) {
+    or_iter it; memset(&it, 0, sizeof it);
+    it.o = o;
+    it.ncomp = (size_t)s->nfiles;
+    it.comp = (or_bank *)calloc(it.ncomp ? it.ncomp : 1, sizeof(or_bank));
+    for (size_t f = 0; f < it.ncomp; f++) it.comp[f].path = s->files[f];
+    /* constructor :165-181 */
+    it.ref = &it.comp[0];
+    it.isDone = 0;
+    it.nbDatasets = (size_t)(s->nb_paired > 0 ? s->nb_paired : 1);
+    it.nbBanks = it.ncomp / it.nbDatasets;          /* (integer division: every paired part is ASSUMED to list as many files) */
+    it.maxReads = o->max_reads;
+    int rc = 0;
+    if (it.ncomp == 0 || it.nbBanks == 0) rc = -1;
+    else
+        for (or_iter_first(&it); !it.isDone; or_iter_next(&it)) {
+            s->k_occ += or_kmers_of_read(it.item->b ? it.item->b : "", it.item->n, o->k, out);
+            s->nb_reads++;
+        }
+    if (it.io_error) rc = -1;
+    for (size_t f = 0; f < it.ncomp; f++) or_bank_close(&it.comp[f]);
+    free(it.comp);
+    return rc;
 }
 
 /* ------------------------------------------------------------------------- */
 /* [a3]+[a4]+[a5] per-sample counting, abundance filter, totals               */
 /* ------------------------------------------------------------------------- */
-static int or_count_sample(oracle *o, or_sample *s) {
-    u64vec km = {0};
-    s->nb_reads = 0; s->k_occ = 0;
-    if (s->bases) {
-        for (uint64_t r = 0; r < s->nreads_mem; r++) {
-            s->k_occ += or_kmers_of_read(s->bases + s->offsets[r], (size_t)(s->offsets[r + 1] - s->offsets[r]), o->k, &km);
-            s->nb_reads++;
-        }
-    } else {
-        for (int f = 0; f < s->nfiles; f++)
-            if (or_read_file(s->files[f], o->k, &km, &s->nb_reads, &s->k_occ) != 0) {
-                snprintf(o->err, sizeof o->err, "ERROR: Can't open dataset: %s", s->id);
-                free(km.v); return -1;
-            }
-    }
-    /* gatb DSK emits each distinct canonical k-mer once, in increasing order, with its
-     * count (the merge's min-heap assumes sorted streams, ref: src/SimkaMerge.cpp:1198-1263) */
-    radix_sort_u64(km.v, km.n, 2 * o->k);
-    size_t nd = 0, ns = 0;
-    s->kmer = (kmer_t *)malloc((km.n ? km.n : 1) * sizeof(kmer_t));
-    s->count = (uint32_t *)malloc((km.n ? km.n : 1) * sizeof(uint32_t));
-    s->D = s->N = s->Q = 0;
-    for (size_t i = 0; i < km.n;) {
+/* `threads` > 1: the k-mer space is cut into 4096 prefix ranges, sorted and counted by a team of threads (the reference's
+ * counterpart: gatb counts the partitions of one sample on all its cores).  The result is the same sorted spectrum. */
+#define OR_NB_RANGES 4096
+typedef struct { size_t nd, ns; uint64_t D, N, Q; } or_range_out;
+
+static void or_count_range(const oracle *o, kmer_t *v, size_t n, int sort_bits, or_range_out *r, kmer_t *ok, uint32_t *oc) {
+    radix_sort_u64(v, n, sort_bits);
+    memset(r, 0, sizeof *r);
+    for (size_t i = 0; i < n;) {
         size_t j = i + 1;
-        while (j < km.n && km.v[j] == km.v[i]) j++;
+        while (j < n && v[j] == v[i]) j++;
         uint64_t c = j - i;
-        nd++;
+        r->nd++;
         /* SimkaCompressedProcessor::process, ref: src/minikc/MiniKC.hpp:54-62 */
         if (!(c < o->amin || c > o->amax)) {
-            s->kmer[ns] = km.v[i]; s->count[ns] = (uint32_t)c; ns++;
-            s->D += 1;                  /* _nbDistinctKmerPerParts[partId] += 1 */
-            s->N += c;                  /* _nbKmerPerParts[partId] += count[0]  */
-            s->Q += (uint64_t)pow((double)c, 2);  /* _chordPerParts[partId] += pow(count[0], 2) */
+            if (ok) { ok[r->ns] = v[i]; oc[r->ns] = (uint32_t)c; }
+            r->ns++;
+            r->D += 1;                  /* _nbDistinctKmerPerParts[partId] += 1 */
+            r->N += c;                  /* _nbKmerPerParts[partId] += count[0]  */
+            r->Q += (uint64_t)pow((double)c, 2);  /* _chordPerParts[partId] += pow(count[0], 2) */
         }
         i = j;
     }
+}
+
+static int or_count_sample(oracle *o, or_sample *s, int threads) {
+    s->nb_reads = 0; s->k_occ = 0;
+    if (threads < 1) threads = 1;
+    const int W = 2 * o->k;
+    const int rb = W >= 12 ? 12 : 0;                       /* range = top 12 bits of the k-mer (one range for tiny k) */
+    const size_t NR = (size_t)1 << rb;
+    const int T = (s->bases && s->nreads_mem >= 64) ? threads : 1;        /* extraction threads (files are read by one iterator) */
+    u64vec *loc = (u64vec *)calloc((size_t)T, sizeof(u64vec));
+    uint64_t *tk = (uint64_t *)calloc((size_t)T, sizeof(uint64_t));
+    if (s->bases) {
+#ifdef _OPENMP
+#pragma omp parallel for schedule(static) num_threads(T)
+#endif
+        for (int t = 0; t < T; t++) {
+            const uint64_t r0 = s->nreads_mem * (uint64_t)t / (uint64_t)T, r1 = s->nreads_mem * (uint64_t)(t + 1) / (uint64_t)T;
+            for (uint64_t r = r0; r < r1; r++)
+                tk[t] += or_kmers_of_read(s->bases + s->offsets[r], (size_t)(s->offsets[r + 1] - s->offsets[r]), o->k, &loc[t]);
+        }
+        s->nb_reads = s->nreads_mem;
+        for (int t = 0; t < T; t++) s->k_occ += tk[t];
+    } else {
+        if (or_read_sample_files(o, s, &loc[0]) != 0) {
+            snprintf(o->err, sizeof o->err, "ERROR: Can't open dataset: %s", s->id);
+            free(loc[0].v); free(loc); free(tk); return -1;
+        }
+    }
+    size_t total = 0;
+    for (int t = 0; t < T; t++) total += loc[t].n;
+    /* gatb DSK emits each distinct canonical k-mer once, in increasing order, with its count (the merge's min-heap assumes
+     * sorted streams, ref: src/SimkaMerge.cpp:1198-1263): scatter by range, sort and count every range, concatenate */
+    size_t *hist = (size_t *)calloc((size_t)T * NR + 1, sizeof(size_t));
+#ifdef _OPENMP
+#pragma omp parallel for schedule(static) num_threads(T)
+#endif
+    for (int t = 0; t < T; t++)
+        for (size_t i = 0; i < loc[t].n; i++) hist[(size_t)t * NR + (rb ? (size_t)(loc[t].v[i] >> (W - rb)) : 0)]++;
+    size_t *rstart = (size_t *)malloc((NR + 1) * sizeof(size_t));
+    {
+        size_t run = 0;
+        for (size_t r = 0; r < NR; r++) {
+            rstart[r] = run;
+            for (int t = 0; t < T; t++) { const size_t c = hist[(size_t)t * NR + r]; hist[(size_t)t * NR + r] = run; run += c; }
+        }
+        rstart[NR] = run;
+    }
+    kmer_t *all = (kmer_t *)malloc((total ? total : 1) * sizeof(kmer_t));
+#ifdef _OPENMP
+#pragma omp parallel for schedule(static) num_threads(T)
+#endif
+    for (int t = 0; t < T; t++) {
+        size_t *cur = hist + (size_t)t * NR;
+        for (size_t i = 0; i < loc[t].n; i++) all[cur[rb ? (size_t)(loc[t].v[i] >> (W - rb)) : 0]++] = loc[t].v[i];
+        free(loc[t].v); loc[t].v = NULL;
+    }
+    free(loc); free(tk); free(hist);
+    or_range_out *ro = (or_range_out *)calloc(NR, sizeof(or_range_out));
+    /* pass 1: sort + count every range; pass 2: the solid records at their final place */
+#ifdef _OPENMP
+#pragma omp parallel for schedule(dynamic, 16) num_threads(threads)
+#endif
+    for (size_t r = 0; r < NR; r++) or_count_range(o, all + rstart[r], rstart[r + 1] - rstart[r], W - rb, &ro[r], NULL, NULL);
+    size_t nd = 0, ns = 0;
+    size_t *sstart = (size_t *)malloc((NR + 1) * sizeof(size_t));
+    s->D = s->N = s->Q = 0;
+    for (size_t r = 0; r < NR; r++) { sstart[r] = ns; nd += ro[r].nd; ns += ro[r].ns; s->D += ro[r].D; s->N += ro[r].N; s->Q += ro[r].Q; }
+    s->kmer = (kmer_t *)malloc((ns ? ns : 1) * sizeof(kmer_t));
+    s->count = (uint32_t *)malloc((ns ? ns : 1) * sizeof(uint32_t));
+#ifdef _OPENMP
+#pragma omp parallel for schedule(dynamic, 16) num_threads(threads)
+#endif
+    for (size_t r = 0; r < NR; r++) {
+        const kmer_t *v = all + rstart[r]; const size_t n = rstart[r + 1] - rstart[r];
+        size_t w = sstart[r];
+        for (size_t i = 0; i < n;) {            /* (the range is sorted already) */
+            size_t j = i + 1;
+            while (j < n && v[j] == v[i]) j++;
+            const uint64_t c = j - i;
+            if (!(c < o->amin || c > o->amax)) { s->kmer[w] = v[i]; s->count[w] = (uint32_t)c; w++; }
+            i = j;
+        }
+    }
     s->d_all = nd; s->nsolid = ns;
-    s->kmer = (kmer_t *)realloc(s->kmer, (ns ? ns : 1) * sizeof(kmer_t));
-    s->count = (uint32_t *)realloc(s->count, (ns ? ns : 1) * sizeof(uint32_t));
-    free(km.v);
+    free(all); free(ro); free(rstart); free(sstart);
     return 0;
 }
 
@@ -688,6 +881,30 @@ OR_API int oracle_sample_nb_files(const oracle *o, int i) { return o->s[i].nfile
 OR_API const char *oracle_sample_file(const oracle *o, int i, int f) { return o->s[i].files[f]; }
 OR_API int oracle_sample_nb_paired(const oracle *o, int i) { return o->s[i].nb_paired; }
 
+/* [a2] read policies of the run (apply to samples read from files): -max-reads m (0 = all), -min-read-size, -min-shannon-index */
+OR_API void oracle_set_read_policy(oracle *o, uint64_t max_reads, uint64_t min_read_size, double min_shannon) {
+    o->max_reads = max_reads; o->min_read_size = min_read_size; o->min_shannon = min_shannon;
+}
+/* -max-reads 0: (min + mean) / 2 of the samples' read counts divided by their paired parts (computeMaxReads, ref:
+ * src/core/SimkaAlgorithm.cpp:377-445).  The reference takes gatb's estimateNbItems() (an ESTIMATE from the head of the
+ * file, gatb-core absent); exact counts are used here. */
+OR_API uint64_t oracle_auto_max_reads(oracle *o) {
+    uint64_t total = 0, mn = (uint64_t)-1;
+    oracle tmp = *o; tmp.max_reads = 0; tmp.min_read_size = 0; tmp.min_shannon = 0;
+    for (int i = 0; i < o->n; i++) {
+        uint64_t n = 0;
+        for (int f = 0; f < o->s[i].nfiles; f++) {
+            or_bank b; memset(&b, 0, sizeof b); b.path = o->s[i].files[f];
+            for (or_bank_first(&b); !b.done; or_bank_next(&b)) n++;
+            or_bank_close(&b);
+        }
+        n /= (uint64_t)(o->s[i].nb_paired > 0 ? o->s[i].nb_paired : 1);
+        total += n; if (n < mn) mn = n;
+    }
+    (void)tmp;
+    return o->n ? (mn + total / (uint64_t)o->n) / 2 : 0;
+}
+
 /* in-memory sample: `bases` = concatenated ASCII reads, offsets[nreads+1]; pointers must outlive oracle_run */
 OR_API int oracle_add_sample_mem(oracle *o, const char *id, const char *bases, const uint64_t *offsets, uint64_t nreads) {
     o->s = (or_sample *)realloc(o->s, (o->n + 1) * sizeof(or_sample));
@@ -706,11 +923,17 @@ OR_API int oracle_run_shard(oracle *o, int k, uint32_t amin, uint32_t amax, int 
     if (nparts < 1) nparts = 1;
     int rc = 0;
     for (int i = 0; i < o->n; i++) { free(o->s[i].kmer); free(o->s[i].count); o->s[i].kmer = NULL; o->s[i].count = NULL; }
-#ifdef _OPENMP
     if (threads < 1) threads = 1;
+    /* at least as many samples as threads: one sample per thread (as the reference runs one simkaCount job per sample);
+     * fewer: the samples one after the other, each on all threads */
+    if (o->n >= threads || threads == 1) {
+#ifdef _OPENMP
 #pragma omp parallel for schedule(dynamic, 1) num_threads(threads)
 #endif
-    for (int i = 0; i < o->n; i++) { if (or_count_sample(o, &o->s[i]) != 0) rc = -1; }
+        for (int i = 0; i < o->n; i++) { if (or_count_sample(o, &o->s[i], 1) != 0) rc = -1; }
+    } else {
+        for (int i = 0; i < o->n; i++) { if (or_count_sample(o, &o->s[i], threads) != 0) rc = -1; }
+    }
     if (rc) return rc;
     or_stats_free(o->stats);
     o->stats = or_stats_new(o, simple, complex_);

@@ -25,6 +25,7 @@
 #include <iostream>
 #include <sstream>
 #include <string>
+#include <memory>
 #include <vector>
 
 #include "../../include/simka_hip.h"
@@ -256,31 +257,86 @@ struct Packed {
     uint64_t nb_bases = 0, nb_frag = 0, nb_reads = 0;
 };
 
-// SimkaInputIterator (ref: src/core/SimkaCommons.hpp:159-314): files of a part in order; with -max-reads m the part
-// stops once its counter reaches m -- the first read delivered by each file does not advance the counter.
+// SimkaInputIterator (ref: src/core/SimkaCommons.hpp:159-314), member for member, over the sample's files as gatb's bank
+// composition: with -max-reads m a paired part (";") delivers m filter-passing reads (read m+1 is fetched and then
+// overwritten by the first read of the next part, :277-287); the counter runs across the files (",") of a part, the first read
+// a file delivers does not advance it (:224-236); files-per-part is composition / nbPaired (:174), i.e. every part is
+// ASSUMED to list as many files -- with unequal parts the reference reads the wrong files, and so does this drop-in (with
+// a warning); an empty first file ends the sample (:224-236).
+struct InputIterator {
+    struct Bank {
+        std::string path; std::unique_ptr<SeqReader> r; std::string cur; bool done = true; bool failed = false;
+        void first() { r.reset(new SeqReader(path)); if (!r->ok()) { failed = true; done = true; return; } done = !r->next(cur); }
+        void next() { if (!done) done = !r->next(cur); }
+    };
+    std::vector<Bank> comp;
+    const Options &o;
+    Bank *ref = nullptr;
+    bool is_done = false, failed = false;
+    size_t current_bank = 0, nb_banks = 0, current_internal_bank = 0, current_dataset = 0, nb_datasets = 0;
+    uint64_t max_reads = 0, nb_read_processed = 0;
+    const std::string *item = nullptr;
+
+    InputIterator(const Sample &s, const Options &opt, uint64_t m) : o(opt) {
+        for (auto &part : s.parts) for (auto &fn : part) { Bank b; b.path = fn; comp.push_back(std::move(b)); }
+        nb_datasets = std::max<size_t>(1, s.parts.size());
+        nb_banks = comp.size() / nb_datasets;
+        max_reads = m;
+        ref = comp.empty() ? nullptr : &comp[0];
+    }
+    bool is_finished() { if (current_dataset == nb_datasets) { is_done = true; return true; } return false; }
+    void first() {
+        ref->first();
+        if (ref->failed) failed = true;
+        while (!ref->done && !read_passes(ref->cur, o)) ref->next();
+        is_done = ref->done;
+        if (!is_done) item = &ref->cur;
+    }
+    void next_dataset() {
+        current_dataset += 1;
+        if (is_finished()) return;
+        current_bank = current_dataset * nb_banks;
+        current_internal_bank = 0;
+        nb_read_processed = 0;
+        if (is_finished()) return;
+        ref = &comp[current_bank];
+        is_done = false;
+        first();
+    }
+    void next_bank() {
+        current_internal_bank += 1;
+        if (current_internal_bank == nb_banks) next_dataset();
+        else { is_done = false; current_bank += 1; ref = &comp[current_bank]; first(); }
+    }
+    void next() {
+        if (is_finished()) { is_done = true; return; }
+        ref->next();
+        while (!ref->done && !read_passes(ref->cur, o)) ref->next();
+        is_done = ref->done;
+        if (is_done) {
+            if (is_finished()) return;
+            next_bank();
+            if (is_finished()) return;
+        } else { item = &ref->cur; nb_read_processed += 1; }
+        if (max_reads && nb_read_processed >= max_reads) { if (is_finished()) return; next_dataset(); }
+    }
+};
+
 bool load_sample(const Sample &s, const Options &o, uint64_t max_reads, Packed &out) {
     out = Packed();
-    std::string seq;
-    for (auto &part : s.parts) {
-        uint64_t counter = 0; bool part_done = false;
-        for (size_t fi = 0; fi < part.size() && !part_done; fi++) {
-            SeqReader r(part[fi]);
-            if (!r.ok()) return false;
-            bool first_of_file = true;
-            while (r.next(seq)) {
-                if (!read_passes(seq, o)) continue;
-                if (!first_of_file) { counter++; if (max_reads && counter >= max_reads) { part_done = true; break; } }
-                first_of_file = false;
-                out.nb_reads++;
-                const uint64_t need_words = (out.nb_bases + seq.size()) / 32 + 3;
-                if (out.words.size() < need_words) out.words.resize(need_words * 2);
-                if (out.offsets.size() < out.nb_frag + seq.size() / 2 + 4) out.offsets.resize((out.nb_frag + seq.size() / 2 + 4) * 2);
-                const int64_t nf = simka_pack_read(seq.data(), seq.size(), out.words.data(), &out.nb_bases, out.offsets.data() + out.nb_frag);
-                if (nf < 0) return false;
-                out.nb_frag += (uint64_t)nf;
-            }
-        }
+    InputIterator it(s, o, max_reads);
+    if (it.comp.empty() || it.nb_banks == 0) return false;
+    for (it.first(); !it.is_done; it.next()) {
+        const std::string &seq = *it.item;
+        out.nb_reads++;
+        const uint64_t need_words = (out.nb_bases + seq.size()) / 32 + 3;
+        if (out.words.size() < need_words) out.words.resize(need_words * 2);
+        if (out.offsets.size() < out.nb_frag + seq.size() / 2 + 4) out.offsets.resize((out.nb_frag + seq.size() / 2 + 4) * 2);
+        const int64_t nf = simka_pack_read(seq.data(), seq.size(), out.words.data(), &out.nb_bases, out.offsets.data() + out.nb_frag);
+        if (nf < 0) return false;
+        out.nb_frag += (uint64_t)nf;
     }
+    if (it.failed) return false;
     if (out.offsets.size() < out.nb_frag + 1) out.offsets.resize(out.nb_frag + 1);
     out.offsets[out.nb_frag] = out.nb_bases;
     if (out.words.size() < out.nb_bases / 32 + 3) out.words.resize(out.nb_bases / 32 + 3);
@@ -462,6 +518,12 @@ int main(int argc, char **argv) {
     if (o.verbose) std::cout << "\tNb input datasets: " << N << std::endl << std::endl;
     for (auto &s : samples) for (auto &p : s.parts) for (auto &fn : p)
         if (!exists(fn)) die("ERROR: Can't open dataset: " + s.id);
+    for (auto &s : samples) {       // (ref: src/core/SimkaCommons.hpp:174 divides the file list evenly over the paired parts)
+        bool even = true;
+        for (auto &p : s.parts) if (p.size() != s.parts[0].size()) even = false;
+        if (!even) std::cerr << "WARNING: sample " << s.id << " lists a different number of files in its paired parts; like the reference, simka then takes "
+                             << "files-per-part = files / parts and reads the file list in that grouping (some files may be skipped)" << std::endl;
+    }
     {   // datasetIds, as the reference leaves it in the temp dir (ref: src/SimkaPotara.hpp:445-456)
         std::ofstream ids((tmp + "/datasetIds").c_str());
         for (auto &s : samples) ids << s.id << "\n";

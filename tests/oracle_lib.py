@@ -29,6 +29,9 @@ def lib():
         l.oracle_sample_file.argtypes = [vp, C.c_int, C.c_int]
         l.oracle_sample_nb_paired.argtypes = [vp, C.c_int]
         l.oracle_add_sample_mem.argtypes = [vp, C.c_char_p, vp, vp, C.c_uint64]
+        l.oracle_set_read_policy.argtypes = [vp, C.c_uint64, C.c_uint64, C.c_double]
+        l.oracle_auto_max_reads.restype = C.c_uint64
+        l.oracle_auto_max_reads.argtypes = [vp]
         l.oracle_run.argtypes = [vp, C.c_int, C.c_uint32, C.c_uint32, C.c_int, C.c_int, C.c_uint, C.c_int]
         l.oracle_run_shard.argtypes = [vp, C.c_int, C.c_uint32, C.c_uint32, C.c_int, C.c_int, C.c_uint, C.c_int, C.c_uint, C.c_uint]
         l.oracle_get_totals.argtypes = [vp, vp]
@@ -73,6 +76,14 @@ class Oracle:
         o = np.ascontiguousarray(offsets, dtype=np.uint64)
         self._keep += [a, o]
         return self.l.oracle_add_sample_mem(self.h, sid.encode(), a.ctypes.data, o.ctypes.data, len(o) - 1)
+
+    def set_read_policy(self, max_reads=0, min_read_size=0, min_shannon=0.0):
+        """-max-reads m (0 = all reads), -min-read-size, -min-shannon-index for the samples read from files (row a2)"""
+        self.l.oracle_set_read_policy(self.h, int(max_reads), int(min_read_size), float(min_shannon))
+
+    def auto_max_reads(self):
+        """what -max-reads 0 resolves to: (min + mean) / 2 of the reads per sample and paired part"""
+        return int(self.l.oracle_auto_max_reads(self.h))
 
     @property
     def n(self):

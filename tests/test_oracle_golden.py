@@ -101,3 +101,88 @@ def test_oracle_edge_cases(oracle_mod):
     assert int(t["K_occ"][0]) == 5 + 9
     assert int(t["K_occ"][1]) == 0 and int(t["D"][1]) == 0
     assert np.all(o.matrix(4)[0, 1] == 1.0)      # jaccard with an empty sample: guard -> 1
+
+
+# ---- row a2: SimkaInputIterator / SimkaSequenceFilter, traced by hand from ref: src/core/SimkaCommons.hpp:159-436 -------------
+def _write_reads(path, lens, letters=b"ACGT", seed=0):
+    """FASTA with reads of the given lengths (distinct pseudo-random content); returns the lengths"""
+    r = np.random.default_rng(seed)
+    with open(path, "wb") as f:
+        for i, ln in enumerate(lens):
+            f.write(b">r%d\n%s\n" % (i, bytes(r.choice(list(letters), size=ln).tolist())))
+    return list(lens)
+
+
+def _kocc(lens, k):
+    return sum(max(0, ln - k + 1) for ln in lens)
+
+
+def test_input_iterator_known_answers(oracle_mod, tmp_path):
+    k = 11
+    f1 = _write_reads(str(tmp_path / "f1.fa"), [30, 31], seed=1)
+    f2 = _write_reads(str(tmp_path / "f2.fa"), [40, 41, 42, 43, 44], seed=2)
+    g1 = _write_reads(str(tmp_path / "g1.fa"), [50, 51, 52, 53, 54], seed=3)
+    open(str(tmp_path / "empty.fa"), "wb").close()
+    (tmp_path / "in.txt").write_text(
+        "S1: f2.fa\n"                      # one part, one file
+        "S2: f1.fa , f2.fa\n"              # one part, two files: the counter runs across them
+        "S3: f2.fa ; g1.fa\n"              # two paired parts
+        "S4: f1.fa , f2.fa ; g1.fa\n"      # unequal parts: files-per-part = 3 / 2 = 1 -> part 0 = f1, part 1 = f2, g1 never read
+        "S5: empty.fa , f2.fa\n")          # an empty first file ends the sample (first(): _isDone = _ref->isDone())
+
+    def run(m, **pol):
+        o = oracle_mod.Oracle()
+        o.load_input(str(tmp_path / "in.txt"))
+        o.set_read_policy(max_reads=m, **pol)
+        o.run(k, 1)
+        t = o.totals()
+        return [int(x) for x in t["nb_reads"]], [int(x) for x in t["K_occ"]]
+
+    # all reads
+    nr, ko = run(0)
+    assert nr == [5, 7, 10, 7, 0]
+    assert ko == [_kocc(f2, k), _kocc(f1 + f2, k), _kocc(f2 + g1, k), _kocc(f1 + f2, k), 0]
+    # -max-reads 3: m reads per part; a file switch delivers one read the counter does not see (S2: f1r1 f1r2 | f2r1 f2r2 -> c=2, f2r3 -> c=3 stop)
+    nr, ko = run(3)
+    assert nr == [3, 4, 6, 5, 0]
+    assert ko[0] == _kocc(f2[:3], k)
+    assert ko[1] == _kocc(f1 + f2[:2], k)
+    assert ko[2] == _kocc(f2[:3] + g1[:3], k)
+    assert ko[3] == _kocc(f1 + f2[:3], k)        # part 0 = f1 (2 reads < m), part 1 = f2 (3 reads)
+    # -min-read-size 42 with -max-reads 2: only passing reads are delivered and counted
+    nr, ko = run(2, min_read_size=42)
+    assert nr[0] == 2 and ko[0] == _kocc([42, 43], k)
+    assert nr[2] == 4 and ko[2] == _kocc([42, 43, 50, 51], k)
+    # what -max-reads 0 resolves to: (min + mean) / 2 of the reads in ALL listed files / paired parts: per sample 5, 7, 5, 6, 5
+    o = oracle_mod.Oracle()
+    o.load_input(str(tmp_path / "in.txt"))
+    assert o.auto_max_reads() == (5 + (5 + 7 + 5 + 6 + 5) // 5) // 2
+
+
+def test_shannon_filter_known_answers(oracle_mod, tmp_path):
+    """getShannonIndex (ref: src/core/SimkaCommons.hpp:388-432): float frequencies of A / C / T / G / N (every other letter counts
+    as A), |sum f log2 f|; a read passes when index >= -min-shannon-index."""
+    k = 5
+    reads = [b"ACGT" * 10,           # 2.0
+             b"AC" * 20,             # 1.0
+             b"A" * 40,              # 0.0
+             b"AACC" * 5 + b"GGTT" * 5,   # 2.0
+             b"A" * 30 + b"C" * 10]  # 0.811
+    with open(str(tmp_path / "s.fa"), "wb") as f:
+        for i, s in enumerate(reads):
+            f.write(b">%d\n%s\n" % (i, s))
+    (tmp_path / "in.txt").write_text("S: s.fa\n")
+
+    def nreads(th):
+        o = oracle_mod.Oracle()
+        o.load_input(str(tmp_path / "in.txt"))
+        o.set_read_policy(min_shannon=th)
+        o.run(k, 1)
+        return int(o.totals()["nb_reads"][0])
+
+    assert nreads(0) == 5
+    assert nreads(0.5) == 4          # the homopolymer goes
+    assert nreads(0.9) == 3
+    assert nreads(1.0) == 3          # index 1.0 >= 1.0 passes
+    assert nreads(1.5) == 2
+    assert nreads(2.0) == 2
