@@ -7,6 +7,9 @@
 //   S2  CAS32 on the low word (returning) + add32, high word stored by the claimer, verified after the barrier
 //   S3  read32 first on the low word: match -> add32 ; empty -> CAS32 ; high word as S2
 //   S4  as S1 with the count packed into the key cell: cell = key<<20 | count: claim = CAS64(empty -> key<<20|1), repeat = ds_add_u64
+//   S5  two phases, no returning atomic on the common path: NON-returning ds_min_u64 of the key into its home slot, barrier,
+//       read64: the home slot holds my key -> add32; else (my key lost its home slot) CAS64 probing from the next slot on
+//   S6  as S5, but the losers of the first table go to a second, smaller table with another hash (min / barrier / read), CAS only after that
 // Prints ns per partition and inserts per cycle per CU (2.4 GHz nominal).
 #include <hip/hip_runtime.h>
 #include <stdio.h>
@@ -50,6 +53,7 @@ __global__ void __launch_bounds__(BLOCK) k_ins(ull *out, uint32_t rounds, uint32
         for (int u = 0; u < KPT; u++) {
             const ull key = keys[u];
             uint32_t slot = (uint32_t)((key * 0xd6e8feb86659fd93ULL) >> 40) & tmask;
+            if (S == 6) slot = (uint32_t)(((ull)(uint32_t)((key * 0xd6e8feb86659fd93ULL) >> 32) * (ull)(TS - TS / 4)) >> 32);
             if (S < 0) { tc[slot] = 1; tk[slot] = key; }
             else if (S == 0) {
                 for (int pr = 0; pr < 128; pr++) {
@@ -82,6 +86,9 @@ __global__ void __launch_bounds__(BLOCK) k_ins(ull *out, uint32_t rounds, uint32
                     slot = (slot + 1) & tmask;
                 }
                 vslot[u] = slot;
+            } else if (S == 5 || S == 6) {
+                (void)__hip_atomic_fetch_min(&tk[slot], key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                vslot[u] = slot;
             } else if (S == 4) {
                 const ull cell1 = (key << 20) | 1ull;       // 44 key bits in this toy; the real kernel would size it
                 for (int pr = 0; pr < 128; pr++) {
@@ -89,6 +96,49 @@ __global__ void __launch_bounds__(BLOCK) k_ins(ull *out, uint32_t rounds, uint32
                     if (cur == EMPTY64) { cur = atomicCAS(&tk[slot], EMPTY64, cell1); if (cur == EMPTY64) break; }
                     if ((cur >> 20) == (key & 0xfffffffffffULL)) { atomicAdd(&tk[slot], 1ull); break; }
                     slot = (slot + 1) & tmask;
+                }
+            }
+        }
+        if (S == 5) {
+            __syncthreads();
+#pragma unroll
+            for (int u = 0; u < KPT; u++) {
+                const ull key = keys[u];
+                uint32_t slot = vslot[u];
+                if (tk[slot] == key) { atomicAdd(&tc[slot], 1u); continue; }
+                for (int pr = 0; pr < 128; pr++) {
+                    slot = (slot + 1) & tmask;
+                    const ull prev = atomicCAS(&tk[slot], EMPTY64, key);
+                    if (prev == EMPTY64 || prev == key) { atomicAdd(&tc[slot], 1u); break; }
+                }
+            }
+        }
+        if (S == 6) {
+            // second table: the top quarter of the slots is reserved for the losers (first-level hash uses 3/4 of the table)
+            __syncthreads();
+            bool lost[KPT];
+#pragma unroll
+            for (int u = 0; u < KPT; u++) {
+                const ull key = keys[u];
+                lost[u] = tk[vslot[u]] != key;
+                if (!lost[u]) atomicAdd(&tc[vslot[u]], 1u);
+                else {
+                    const uint32_t s2 = (TS - TS / 4) + ((uint32_t)((key * 0x9E3779B97F4A7C15ULL) >> 44) & (TS / 4 - 1));
+                    (void)__hip_atomic_fetch_min(&tk[s2], key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    vslot[u] = s2;
+                }
+            }
+            __syncthreads();
+#pragma unroll
+            for (int u = 0; u < KPT; u++) {
+                if (!lost[u]) continue;
+                const ull key = keys[u];
+                uint32_t slot = vslot[u];
+                if (tk[slot] == key) { atomicAdd(&tc[slot], 1u); continue; }
+                for (int pr = 0; pr < 128; pr++) {       // probe inside the second table
+                    slot = (TS - TS / 4) + ((slot + 1) & (TS / 4 - 1));
+                    const ull prev = atomicCAS(&tk[slot], EMPTY64, key);
+                    if (prev == EMPTY64 || prev == key) { atomicAdd(&tc[slot], 1u); break; }
                 }
             }
         }
@@ -144,11 +194,15 @@ int main(int argc, char **argv) {
         run<2, 4096, 6>("S2 CAS32 lo + add, hi verified later", d, 3, hot, single);
         run<3, 4096, 6>("S3 read32, CAS32 if empty, add", d, 3, hot, single);
         run<4, 4096, 6>("S4 read64, packed key|count cell", d, 3, hot, single);
+        run<5, 4096, 6>("S5 min64 / barrier / read64, CAS for losers", d, 3, hot, single);
+        run<6, 4096, 6>("S6 min64 x2 tables, CAS after", d, 3, hot, single);
         if (pass == 0) {
         run<0, 2048, 6>("S0 small table", d, 4, hot, single);
         run<1, 2048, 6>("S1 small table", d, 4, hot, single);
         run<3, 2048, 6>("S3 small table", d, 4, hot, single);
         run<4, 2048, 6>("S4 small table", d, 4, hot, single);
+        run<5, 2048, 6>("S5 small table", d, 4, hot, single);
+        run<6, 2048, 6>("S6 small table", d, 4, hot, single);
         }
         run<-1, 8192, 12>("SN 8192 slots floor", d, 1, hot * 2, single);
         run<0, 8192, 12>("S0 8192 slots, 6144 keys", d, 1, hot * 2, single);

@@ -73,7 +73,7 @@ def load_library(build_if_missing=True):
         import torch  # noqa: F401
     except Exception:
         pass
-    path = _build.LIB_PATH
+    path = os.environ.get("SIMKA_LIB_OVERRIDE") or _build.LIB_PATH      # (experiments: an instrumented build of the same sources)
     if build_if_missing and not os.path.exists(path):
         _build.build()
     if not os.path.exists(path):

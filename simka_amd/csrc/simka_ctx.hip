@@ -579,11 +579,13 @@ static int run_count_kernels(simka_ctx *ctx, uint32_t sample, const SimkaScanArg
 #ifdef SIMKA_PHASE_PROF
     {   // debug build: per-phase wall_clock64 ticks of thread 0 of every k_skm_count_fast block, printed per sample
         static ull *d_phase = nullptr;
-        if (!d_phase) { HIPCHK(hipMalloc(&d_phase, 64)); HIPCHK(hipMemset(d_phase, 0, 64)); }
+        if (!d_phase) { HIPCHK(hipMalloc(&d_phase, 128)); HIPCHK(hipMemset(d_phase, 0, 128)); }
         else {
             HIPCHK(hipDeviceSynchronize());
-            ull h[8]; HIPCHK(hipMemcpy(h, d_phase, 64, hipMemcpyDeviceToHost)); HIPCHK(hipMemset(d_phase, 0, 64));
-            ull t_ = 0; for (ull v : h) t_ += v;
+            ull h[16]; HIPCHK(hipMemcpy(h, d_phase, 128, hipMemcpyDeviceToHost)); HIPCHK(hipMemset(d_phase, 0, 128));
+            if (h[12]) fprintf(stderr, "k_skm_count_fast counters: per wave and partition %.1f k-mers, %.1f queue entries left after the last batch, %.2f final drain passes\n",
+                               (double)h[8] / h[12], (double)h[14] / h[12], (double)h[13] / h[12]);
+            ull t_ = 0; for (int i_ = 0; i_ < 8; i_++) t_ += h[i_];
             if (t_) fprintf(stderr, "k_skm_count_fast phases %%: top %.1f map %.1f insert %.1f sync %.1f summary %.1f scan %.1f slab %.1f stores %.1f  (ticks/block %.0f)\n",
                     100.0 * h[0] / t_, 100.0 * h[1] / t_, 100.0 * h[2] / t_, 100.0 * h[3] / t_, 100.0 * h[4] / t_, 100.0 * h[5] / t_, 100.0 * h[6] / t_, 100.0 * h[7] / t_, (double)t_ / (ctx->num_cus * 2));
         }
@@ -591,7 +593,7 @@ static int run_count_kernels(simka_ctx *ctx, uint32_t sample, const SimkaScanArg
     }
 #endif
     const size_t hist_lds = ctx->d_hist ? (size_t)SIMKA_HIST_MAX * 4 : 0;
-    const size_t lds_fast = (size_t)SIMKA_LDS_HEAD + (size_t)SKM_FAST_TS * 12 + (size_t)SKM_FAST_BLOCK * 16 + hist_lds + (size_t)SKM_FAST_BLOCK * sk.nmax * 2 + 64;
+    const size_t lds_fast = (size_t)SIMKA_LDS_HEAD + (size_t)SKM_FAST_TS * 12 + (size_t)SKM_FAST_BLOCK * 16 + hist_lds + (size_t)(SKM_FAST_BLOCK / 64) * SKM_FAST_WREG + 64;
     const size_t lds_count = (size_t)SIMKA_LDS_HEAD + (size_t)SKM_CNT_TS * 12 + (size_t)SKM_CNT_BATCH * 16 + (size_t)SKM_CNT_BLOCK * 4 + hist_lds + (size_t)SKM_CNT_BATCH * sk.nmax * 2 + 64;
     static const bool general_only = getenv("SIMKA_SKM_GENERAL") != nullptr;      // tests: every partition through the general kernel
     if (!general_only)
@@ -1148,7 +1150,7 @@ SIMKA_EXPORT int simka_import_samples_device(simka_ctx *ctx, const uint32_t *sam
 static void pairs_phase_report() {
     ull h[8];
     if (hipDeviceSynchronize() != hipSuccess || hipMemcpyFromSymbol(h, HIP_SYMBOL(g_pairs_phase), 64) != hipSuccess) return;
-    ull t_ = 0; for (ull v : h) t_ += v;
+    ull t_ = 0; for (int i_ = 0; i_ < 8; i_++) t_ += h[i_];
     if (t_) fprintf(stderr, "k_pairs phases %%: loop-top %.1f stage %.1f sync+flush %.1f compaction %.1f scan %.1f search %.1f pairs %.1f\n", 100.0 * h[0] / t_, 100.0 * h[1] / t_, 100.0 * h[2] / t_,
                     100.0 * h[3] / t_, 100.0 * h[4] / t_, 100.0 * h[5] / t_, 100.0 * h[6] / t_);
     memset(h, 0, 64); (void)hipMemcpyToSymbol(HIP_SYMBOL(g_pairs_phase), h, 64);

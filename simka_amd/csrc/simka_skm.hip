@@ -49,6 +49,12 @@ typedef unsigned long long ull;
 #define SKM_CNT_BATCH 256        // records expanded per batch
 #define SKM_FAST_BLOCK 256       // k_skm_count_fast: 4 waves, 2048 slots, four blocks per CU
 #define SKM_FAST_TS 2048
+#ifndef SKM_FAST_U
+#define SKM_FAST_U 2             // k-mers per lane in flight in the insert loop (4: the queue grows and only three blocks fit a CU -- slower)
+#endif
+#define SKM_FAST_QCAP (64 + 64 * SKM_FAST_U)      // retry queue of a wave: what one iteration can add on top of an undrained rest
+#define SKM_FAST_BMW 32          // u64 words of a wave's record-start bitmap (64 records x nmax <= 32 k-mers)
+#define SKM_FAST_WREG ((SKM_FAST_BMW * 8 + SKM_FAST_QCAP * 10 + 15) / 16 * 16)     // bytes of a wave's private LDS region
 #define SKM_SORT_BITS 3          // solid records leave the count kernel ordered by the top 3 bits of the slot hash
 #define SKM_NSORT (1 << SKM_SORT_BITS)
 
@@ -687,7 +693,13 @@ k_skm_count(const uint4 *recs, const uint32_t *pstart, const uint32_t *pcnt, Sim
 
 // --------------------------------------------------------------------------------------------
 // k_skm_count_fast: the common case of k_skm_count -- the partition's distinct k-mers fit the table in ONE round.
-//   * every wave expands its own 64 records (wave-private LDS copy of the records + map; no block barrier until all inserts are in);
+//   * every wave expands its own 64 records: the records go to a wave-private LDS copy together with the index of their first
+//     k-mer among the wave's k-mers, and ONE bit per record marks that index in a bitmap.  K-mer f of the wave then finds its
+//     record with two mbcnt (records before f = set bits below f; the 64 bits of a chunk of k-mers are wave-uniform), cuts
+//     itself out of the record (funnel shift), reverse complement, canonical, slot hash;
+//   * SKM_FAST_U k-mers per lane are in flight through ONE straight-line insert (64-bit CAS + counter add).  A k-mer that finds
+//     its slot taken by another k-mer does not loop: ballot + mbcnt compact the losers into a wave-private retry queue (key, next
+//     slot), and the queue is drained 64 dense lanes at a time -- so a wave never idles 60 lanes while 4 keep probing;
 //   * the records of the NEXT partition are loaded (registers) before the summary of this one;
 //   * arena slab state double-buffered in LDS, so the emit needs no barrier of its own.
 // A partition whose inserts overflow a sort block of the table goes to the redo list (k_skm_count takes it in rounds).
@@ -708,7 +720,7 @@ k_skm_count_fast(const uint4 *recs, const uint32_t *pstart, const uint32_t *pcnt
     uint32_t *tcnt = (uint32_t *)(tkeys + TS);         // [TS]
     uint4 *lrec = (uint4 *)(tcnt + TS);                // [BLOCK]: 64 per wave
     uint32_t *lhist = (uint32_t *)(lrec + SKM_FAST_BLOCK);     // [SIMKA_HIST_MAX] (complex only)
-    uint16_t *map = (uint16_t *)(lhist + (o.hist ? SIMKA_HIST_MAX : 0));     // [NW][64 * nmax]
+    unsigned char *wreg0 = (unsigned char *)(lhist + (o.hist ? SIMKA_HIST_MAX : 0));     // [NW][SKM_FAST_WREG] wave-private regions
 
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     const uint32_t nparts = 1u << cfg.pb;
@@ -720,9 +732,59 @@ k_skm_count_fast(const uint4 *recs, const uint32_t *pstart, const uint32_t *pcnt
     if (tid == 0) s_fail = 0;
     ull bt_dall = 0, bt_D = 0, bt_N = 0, bt_Q = 0, bt_kocc = 0;
     PH_DECL
+#ifdef SIMKA_PHASE_PROF
+    ull dbg[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#define DBG_ADD(i, v) { if (lane == 0) dbg[(i) - 8] += (ull)(v); }
+#else
+#define DBG_ADD(i, v)
+#endif
     uint4 *wrec = lrec + wave * 64u;
-    uint16_t *wmap = map + wave * (64u * cfg.nmax);
-    constexpr uint32_t bmask = (TS >> SKM_SORT_BITS) - 1u;        // probing stays inside the 128-slot sort block
+    ull *bm64 = (ull *)(wreg0 + wave * SKM_FAST_WREG);              // [SKM_FAST_BMW] bit f set: a record starts at k-mer f
+    ull *qk = bm64 + SKM_FAST_BMW;                                  // [QCAP] retry queue: canonical k-mers ...
+    uint16_t *qm = (uint16_t *)(qk + SKM_FAST_QCAP);                // [QCAP] ... and the slot to try next
+    constexpr uint32_t bmask = (TS >> SKM_SORT_BITS) - 1u;        // probing stays inside the sort block (TS / 8 slots)
+    constexpr uint32_t U = SKM_FAST_U;
+    uint32_t qn = 0;                                                // entries in the queue (wave-uniform)
+    // one dense pass over the tail of the retry queue.  An entry = (k-mer, next slot to try | passes << 11).  The lane LOOKS at four
+    // slots ahead (plain reads, one LDS round trip): a slot that holds another k-mer keeps it for the rest of the partition, so
+    // it can be skipped without an atomic; the first slot that holds this k-mer takes a plain counter add, the first empty one a
+    // CAS.  Only a CAS lost to another k-mer, or four occupied slots, send the entry back -- the tail of a wave's queue empties in
+    // one or two passes instead of one pass per probe.  After 31 passes (124 slots) the k-mer gives up: redo list.
+    auto drain = [&]() {
+        const uint32_t n = qn < 64u ? qn : 64u;
+        const uint32_t e = qn - n + lane;
+        const bool a = lane < n;
+        ull key = 0; uint32_t meta = 0;
+        if (a) { key = qk[e]; meta = qm[e]; }
+        qn -= n;
+        bool again = false;
+        uint32_t slot = meta & (TS - 1u);
+        if (a) {
+            const uint32_t bb = slot & ~bmask;
+            const uint32_t s1 = bb | ((slot + 1u) & bmask), s2 = bb | ((slot + 2u) & bmask), s3 = bb | ((slot + 3u) & bmask);
+            const ull w0 = tkeys[slot], w1 = tkeys[s1], w2 = tkeys[s2], w3 = tkeys[s3];
+            const bool h0 = w0 == SIMKA_EMPTY_KEY || w0 == key, h1 = w1 == SIMKA_EMPTY_KEY || w1 == key, h2 = w2 == SIMKA_EMPTY_KEY || w2 == key, h3 = w3 == SIMKA_EMPTY_KEY || w3 == key;
+            const uint32_t st = h0 ? slot : h1 ? s1 : h2 ? s2 : s3;
+            const ull ws = h0 ? w0 : h1 ? w1 : h2 ? w2 : w3;
+            if (!(h0 || h1 || h2 || h3)) { again = true; slot = bb | ((slot + 4u) & bmask); }
+            else if (ws == key) atomicAdd(&tcnt[st], 1u);
+            else {
+                const ull prev = atomicCAS(&tkeys[st], SIMKA_EMPTY_KEY, key);
+                if (prev == SIMKA_EMPTY_KEY || prev == key) atomicAdd(&tcnt[st], 1u);
+                else { again = true; slot = bb | ((st + 1u) & bmask); }
+            }
+            if (again) {
+                const uint32_t passes = (meta >> 11) + 1u;
+                if (passes >= 32u) { s_fail = 1u; again = false; }
+                meta = slot | (passes << 11);
+            }
+        }
+        const ull am = __ballot(again);
+        if (am) {
+            if (again) { const uint32_t pos = qn + __builtin_amdgcn_mbcnt_hi((uint32_t)(am >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)am, 0u)); qk[pos] = key; qm[pos] = (uint16_t)meta; }
+            qn += (uint32_t)__popcll(am);
+        }
+    };
 
     uint32_t part = blockIdx.x, iter = 0;
     uint32_t nrec = 0, rbase = 0;
@@ -734,12 +796,18 @@ k_skm_count_fast(const uint4 *recs, const uint32_t *pstart, const uint32_t *pcnt
     };
     if (part < nparts) { nrec = pcnt[part]; rbase = pstart[part]; prefetch(nrec, rbase); }
     __syncthreads();
+    // (count, start) of the next partition travel as a VECTOR load of lanes 0 / 1: a scalar load of these wave-uniform words would
+    // share the LDS counter (lgkmcnt), and the first LDS wait of the insert phase would sit out its HBM latency
+    auto load_desc = [&](uint32_t p_) -> uint32_t {
+        uint32_t v = 0;
+        if (p_ < nparts && lane < 2u) { const uint32_t *src = lane == 0u ? pcnt : pstart; v = src[p_]; }
+        return v;
+    };
     while (part < nparts) {
         const uint32_t next = part + gridDim.x;
-        uint32_t nrec_n = 0, rbase_n = 0;
-        if (next < nparts) { nrec_n = pcnt[next]; rbase_n = pstart[next]; }
+        const uint32_t desc_n = load_desc(next);
         if (nrec == 0) {
-            part = next; nrec = nrec_n; rbase = rbase_n;
+            part = next; nrec = __builtin_amdgcn_readlane(desc_n, 0); rbase = __builtin_amdgcn_readlane(desc_n, 1);
             prefetch(nrec, rbase);
             continue;
         }
@@ -754,55 +822,82 @@ k_skm_count_fast(const uint4 *recs, const uint32_t *pstart, const uint32_t *pcnt
             uint4 rc = pre;
             if (b0) { if (mine) rc = recs[rbase + i]; }
             uint32_t len = mine ? skm_rec_n(rc) : 0u;
-            wrec[lane] = rc;
             const uint32_t x = wave_incl_scan(len);
             const uint32_t kt = __builtin_amdgcn_readlane(x, 63);
             const uint32_t off = x - len;
-            for (uint32_t j = 0; j < len; j++) wmap[off + j] = (uint16_t)((lane << 5) | j);
+            // the wave's copy of the record carries the index of its first k-mer where the partition id was
+            wrec[lane] = make_uint4(rc.x, rc.y, rc.z, (rc.w & 63u) | (off << 6));
+            if (lane < SKM_FAST_BMW) bm64[lane] = 0ull;
+            if (len) atomicOr((uint32_t *)bm64 + (off >> 5), 1u << (off & 31u));
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             if (lane == 0) my_k += kt;
             PH(1)
-            // two k-mers per lane and iteration: their LDS round trips (map, record, CAS) overlap
-            for (uint32_t f = lane; f < kt; f += 128u) {
-                const bool two = f + 64u < kt;
-                const uint32_t e0 = wmap[f], e1 = wmap[two ? f + 64u : f];
-                const uint4 rx0 = wrec[e0 >> 5], rx1 = wrec[e1 >> 5];
-                const uint64_t fw0 = skm_kmer_at(rx0, e0 & 31u, cfg), fw1 = skm_kmer_at(rx1, e1 & 31u, cfg);
-                const uint64_t rv0 = skm_revcomp64(fw0) >> (64u - 2u * cfg.k), rv1 = skm_revcomp64(fw1) >> (64u - 2u * cfg.k);
-                const ull c0 = fw0 < rv0 ? fw0 : rv0, c1 = fw1 < rv1 ? fw1 : rv1;
-                uint32_t s0 = skm_kmer_hash(c0) >> (32u - TSL), s1 = skm_kmer_hash(c1) >> (32u - TSL);
-                const ull p0 = atomicCAS(&tkeys[s0], SIMKA_EMPTY_KEY, c0);
-                ull p1 = c1;
-                if (two) p1 = atomicCAS(&tkeys[s1], SIMKA_EMPTY_KEY, c1);
-                bool ok0 = p0 == SIMKA_EMPTY_KEY || p0 == c0, ok1 = !two || p1 == SIMKA_EMPTY_KEY || p1 == c1;
-                if (ok0) atomicAdd(&tcnt[s0], 1u);
-                if (two && ok1) atomicAdd(&tcnt[s1], 1u);
-                if (!ok0) {       // first slot taken by another k-mer: probe on inside the sort block
-                    const uint32_t bbase = s0 & ~bmask;
-                    for (uint32_t probe = 1; probe <= bmask && !ok0; probe++) {
-                        s0 = bbase | ((s0 + 1u) & bmask);
-                        const ull prev = atomicCAS(&tkeys[s0], SIMKA_EMPTY_KEY, c0);
-                        if (prev == SIMKA_EMPTY_KEY || prev == c0) { atomicAdd(&tcnt[s0], 1u); ok0 = true; }
-                    }
-                    if (!ok0) s_fail = 1u;
+            // the whole bitmap in registers (word c in lane c): a chunk's 64 bits are then two readlanes away, no LDS round trip
+            ull bmreg = 0;
+            if (lane < SKM_FAST_BMW) bmreg = bm64[lane];
+            const uint32_t bmlo = (uint32_t)bmreg, bmhi = (uint32_t)(bmreg >> 32);
+            uint32_t rbefore = 0;                                      // records that start before the current chunk of 64 k-mers
+            // record of k-mer f0 + 64 u + lane, for the U chunks of one iteration; software pipeline: the reads of iteration i + 1
+            // are issued behind the CASes of iteration i (LDS returns in order), so an iteration exposes ONE round trip
+            uint4 rx[U]; bool act[U];
+            auto fetch = [&](uint32_t f0_) {
+#pragma unroll
+                for (uint32_t u = 0; u < U; u++) {
+                    const uint32_t c = (f0_ >> 6) + u;                  // (wave-uniform; c < SKM_FAST_BMW while f0_ < kt)
+                    act[u] = f0_ + 64u * u + lane < kt;
+                    const uint32_t mlo = __builtin_amdgcn_readlane(bmlo, c & (SKM_FAST_BMW - 1u)), mhi = __builtin_amdgcn_readlane(bmhi, c & (SKM_FAST_BMW - 1u));
+                    const uint32_t below = __builtin_amdgcn_mbcnt_hi(mhi, __builtin_amdgcn_mbcnt_lo(mlo, 0u));
+                    const uint32_t own = ((lane < 32u ? mlo : mhi) >> (lane & 31u)) & 1u;
+                    const uint32_t r = (rbefore + below + own - 1u) & 63u;      // (a lane beyond the last k-mer: any record)
+                    rbefore += (uint32_t)__popc(mlo) + (uint32_t)__popc(mhi);
+                    rx[u] = wrec[r];
                 }
-                if (!ok1) {
-                    const uint32_t bbase = s1 & ~bmask;
-                    for (uint32_t probe = 1; probe <= bmask && !ok1; probe++) {
-                        s1 = bbase | ((s1 + 1u) & bmask);
-                        const ull prev = atomicCAS(&tkeys[s1], SIMKA_EMPTY_KEY, c1);
-                        if (prev == SIMKA_EMPTY_KEY || prev == c1) { atomicAdd(&tcnt[s1], 1u); ok1 = true; }
-                    }
-                    if (!ok1) s_fail = 1u;
+            };
+            fetch(0);
+            for (uint32_t f0 = 0; f0 < kt; f0 += 64u * U) {
+                ull cu[U]; uint32_t su[U]; bool actc[U];
+                // cut, reverse complement, canonical, slot
+#pragma unroll
+                for (uint32_t u = 0; u < U; u++) {
+                    actc[u] = act[u];
+                    const uint64_t fw = skm_kmer_at(rx[u], (f0 + 64u * u + lane - (rx[u].w >> 6)) & 31u, cfg);
+                    const uint64_t rv = skm_revcomp64(fw) >> (64u - 2u * cfg.k);
+                    cu[u] = fw < rv ? fw : rv;
+                    su[u] = skm_kmer_hash(cu[u]) >> (32u - TSL);
                 }
+                // all U inserts in flight together, the next iteration's records behind them.  No lane is masked off: a lane
+                // beyond the wave's last k-mer swaps EMPTY for EMPTY and adds 0, so the whole step is straight-line code and every wait
+                // counts exactly the LDS operations it needs
+                ull pu[U];
+#pragma unroll
+                for (uint32_t u = 0; u < U; u++) { if (!actc[u]) cu[u] = SIMKA_EMPTY_KEY; pu[u] = atomicCAS(&tkeys[su[u]], SIMKA_EMPTY_KEY, cu[u]); }
+                fetch(f0 + 64u * U);                 // (beyond the last k-mer: no lane is active, every lane reads some record)
+#pragma unroll
+                for (uint32_t u = 0; u < U; u++) {
+                    const bool ok = pu[u] == SIMKA_EMPTY_KEY || pu[u] == cu[u];
+                    atomicAdd(&tcnt[su[u]], (actc[u] && ok) ? 1u : 0u);
+                    const bool lost = actc[u] && !ok;
+                    const ull lm = __ballot(lost);
+                    if (lm) {       // (bmask >= 1: the next slot is never the home slot)
+                        if (lost) {
+                            const uint32_t pos = qn + __builtin_amdgcn_mbcnt_hi((uint32_t)(lm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)lm, 0u));
+                            qk[pos] = cu[u]; qm[pos] = (uint16_t)((su[u] & ~bmask) | ((su[u] + 1u) & bmask));
+                        }
+                        qn += (uint32_t)__popcll(lm);
+                    }
+                }
+                while (qn >= 64u) drain();
             }
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // the wave's map / records are rewritten by the next batch
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // the wave's bitmap / records are rewritten by the next batch
             PH(2)
         }
+        DBG_ADD(8, my_k) DBG_ADD(12, 1) DBG_ADD(14, qn)
+        while (qn) { drain(); DBG_ADD(13, 1) }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __syncthreads();
         PH(3)
         // ---- the next partition's records travel while this one is summarised
+        const uint32_t nrec_n = __builtin_amdgcn_readlane(desc_n, 0), rbase_n = __builtin_amdgcn_readlane(desc_n, 1);
         {
             const uint32_t nb = nrec_n < (uint32_t)SKM_FAST_BLOCK ? nrec_n : (uint32_t)SKM_FAST_BLOCK;
             const uint32_t per = (nb + NW - 1u) / NW;
@@ -832,9 +927,9 @@ k_skm_count_fast(const uint4 *recs, const uint32_t *pstart, const uint32_t *pcnt
             cs[q] = sol ? c : 0u;
         }
         const bool failed = s_fail != 0u;
-        // the wave's solid records, in slot order, go to its (now idle) map region: keys [0, cap), counts behind them
-        const uint32_t wcap = (64u * cfg.nmax * 2u) / 12u;                        // records the region takes
-        ull *wk = (ull *)wmap; uint32_t *wc = (uint32_t *)(wk + wcap);
+        // the wave's solid records, in slot order, go to its (now empty) retry queue: keys [0, cap), counts behind them
+        constexpr uint32_t wcap = (SKM_FAST_QCAP * 10u) / 12u;                    // records the region takes
+        ull *wk = qk; uint32_t *wc = (uint32_t *)(wk + wcap);
         const uint32_t winc = wave_incl_scan(nsol);
         const uint32_t wtot = __builtin_amdgcn_readlane(winc, 63);
         const bool staged = wtot <= wcap;
@@ -900,11 +995,14 @@ k_skm_count_fast(const uint4 *recs, const uint32_t *pstart, const uint32_t *pcnt
                 }
             }
         }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // the staging region becomes the wave's map again
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // the staging region becomes the wave's retry queue again
         PH(7)
         part = next; nrec = nrec_n; rbase = rbase_n;
     }
     PH_FLUSH
+#ifdef SIMKA_PHASE_PROF
+    if (lane == 0 && o.phase) for (int i_ = 0; i_ < 8; i_++) atomicAdd(&o.phase[8 + i_], dbg[i_]);
+#endif
     if (o.hist) {
         __syncthreads();
         for (uint32_t i = tid; i < SIMKA_HIST_MAX; i += SKM_FAST_BLOCK)
