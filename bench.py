@@ -106,6 +106,51 @@ def cpu_baseline(wl, lib, torch, dev, seconds_budget=15.0):
             "seconds": dt}
 
 
+def e2e_from_fasta(wl, lib, torch, dev, max_samples=10, max_reads=1_000_000):
+    """t_e2e of SURVEY 8(d): FASTA files on disk -> distance-matrix CSVs through the C++ `simka` driver (parse + 2-bit pack on the
+    host cores, pinned double-buffered H2D, count, merge, matrices, gz CSVs), on a BOUNDED sample of the workload (same generator,
+    fewer samples / reads): written to a temp directory, run twice (the second run has the files in the page cache)."""
+    import shutil
+    import subprocess
+    import tempfile
+    from simka_amd import synth, build as b
+    n, R, L, k = min(wl["n"], max_samples), min(wl["reads"], max_reads), wl["L"], wl["k"]
+    sub = dict(wl, n=n, reads=R)
+    _, reads = gen_device_samples(lib, torch, sub, dev)
+    d = tempfile.mkdtemp(prefix="simka_e2e_")
+    try:
+        lines = []
+        for s in range(n):
+            pk = reads[s].cpu().numpy().view(np.uint64)
+            a = synth.unpack_ascii(pk[: (R * L + 31) // 32], R * L).reshape(R, L)
+            rec = np.empty((R, L + 4), dtype=np.uint8)          # ">r\n" + read + "\n"
+            rec[:, 0] = ord(">"); rec[:, 1] = ord("r"); rec[:, 2] = ord("\n"); rec[:, 3:3 + L] = a; rec[:, 3 + L] = ord("\n")
+            fn = os.path.join(d, "s%d.fasta" % s)
+            rec.tofile(fn)
+            lines.append("S%d: %s" % (s, fn))
+        del reads
+        open(os.path.join(d, "in.txt"), "w").write("\n".join(lines) + "\n")
+        size = sum(os.path.getsize(os.path.join(d, "s%d.fasta" % s)) for s in range(n))
+        cmd = [b.CLI_PATH, "-in", os.path.join(d, "in.txt"), "-out", os.path.join(d, "out"), "-out-tmp", os.path.join(d, "tmp"),
+               "-kmer-size", str(k), "-abundance-min", str(wl["amin"]), "-max-reads", "-1", "-verbose", "0"]
+        if wl["simple"]:
+            cmd.append("-simple-dist")
+        if wl.get("complex"):
+            cmd.append("-complex-dist")
+        ts = []
+        for _ in range(2):
+            t = time.perf_counter()
+            r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+            ts.append((time.perf_counter() - t) * 1e3)
+            if r.returncode != 0:
+                raise RuntimeError(r.stdout[-400:])
+        occ = float(n) * R * (L - k + 1)
+        return {"ms": min(ts), "ms_first_run": ts[0], "fasta_bytes": size, "kmer_occurrences_per_s": occ / (min(ts) * 1e-3),
+                "sample": "%d samples x %d reads x %d bp as FASTA files, k=%d, `simka` driver process start to CSVs written" % (n, R, L, k)}
+    finally:
+        shutil.rmtree(d, ignore_errors=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -116,6 +161,7 @@ def main():
     ap.add_argument("--reads", type=int, default=0, help="override reads per sample")
     ap.add_argument("--samples", type=int, default=0, help="override number of samples")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-e2e", action="store_true", help="skip the FASTA -> CSV leg (timing.e2e_from_fasta)")
     ap.add_argument("--prof-steps", type=int, default=3, help="steps of the untimed pass that times every kernel (0 = as many as --steps)")
     ap.add_argument("--log2-partitions", type=int, default=0)
     ap.add_argument("--offsets", action="store_true", help="hand the reads over with an offsets array (variable-length layout, what the "
@@ -385,7 +431,7 @@ def main():
     timing = {"device_kernels_ms": total_kernel_ms / prof_steps, "finalise_ms": t_finalise, "h2d_packed_reads_ms": t_h2d,
               "allreduce_ms": t_allreduce, "step_ms": ms_per_step,
               "note": "per step on rank 0; h2d = the packed reads of this rank's samples from pinned host memory (inputs are resident in HBM in the timed "
-                      "region); e2e from FASTA: scripts/cli_e2e.py (DESIGN.md section 8)"}
+                      "region); e2e_from_fasta: the `simka` driver on FASTA files of a bounded sample of the workload (files on disk -> CSVs)"}
     out = {
         "metric": "distinct k-mers/s end-to-end (count + merge + N x N matrices)", "value": value, "unit": "distinct k-mers/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
@@ -413,9 +459,15 @@ def main():
         except Exception as e:       # the baseline is a report, never a reason to lose the GPU number
             out["cpu_baseline"] = {"value": None, "unit": "distinct k-mers/s", "cores": os.cpu_count(), "kind": "port",
                                    "sample": "failed: %r" % (e,)}
+    ctx.close()
+    if rank == 0 and world == 1 and not args.no_e2e and not args.no_cpu_baseline:
+        try:
+            out["timing"]["e2e_from_fasta"] = e2e_from_fasta(wl, lib, torch, dev)
+            out["timing"]["e2e_from_fasta_ms"] = out["timing"]["e2e_from_fasta"]["ms"]
+        except Exception as e:
+            out["timing"]["e2e_from_fasta"] = {"ms": None, "sample": "failed: %r" % (e,)}
     if rank == 0:
         print(json.dumps(out))
-    ctx.close()
     if comm is not None:
         comm.close()
     if world > 1:

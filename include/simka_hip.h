@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define SIMKA_ABI_VERSION 3
+#define SIMKA_ABI_VERSION 4
 
 enum {
     SIMKA_OK = 0,
@@ -260,6 +260,14 @@ int simka_write_matrix_csv(const char *dir, const char *name, const char *const 
  * per produced fragment (reads are split at non-ACGT letters).  Returns the number of fragments
  * appended, or <0 on error.  Caller guarantees capacity for `len` more bases and len+1 offsets. */
 int64_t simka_pack_read(const char *seq, uint64_t len, uint64_t *packed, uint64_t *nb_bases, uint64_t *offsets_out);
+/* Page-locked host memory for the packed reads / offsets handed to simka_count_sample(on_device = 0): the copy to the GPU is
+ * then one DMA at PCIe speed into the staging buffer of the sample's lane (two buffers: the copy of sample i + 1 overlaps the
+ * kernels of sample i), where pageable memory goes through the runtime's bounce buffer.  Where the reference's count job reads
+ * its bank through gatb's buffered BankFasta iterator (ref: src/SimkaCount.cpp:283-299, src/core/SimkaCommons.hpp:159-314) the
+ * `simka` driver parses into these buffers.  *p = NULL and SIMKA_ERR_NOMEM when the allocation fails (callers may fall back to
+ * malloc: the ABI accepts any host pointer). */
+int simka_host_alloc(uint64_t nb_bytes, void **p);
+int simka_host_free(void *p);
 
 /* ---- profiling ----------------------------------------------------------------------------
  * HIP-event timing of the kernels launched by the ctx, on the stream they are launched on.  on = 0: off; 1: every kernel;

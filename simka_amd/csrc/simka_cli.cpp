@@ -252,8 +252,70 @@ uint64_t count_reads(const Sample &s) {
     return s.parts.empty() ? 0 : n / s.parts.size();
 }
 
+// Page-locked host buffers for what goes to the GPU (simka_host_alloc: the H2D copy is then one DMA into the staging buffer of
+// the sample's lane; plain malloc when pinning fails).  Blocks are recycled through a pool: pinning costs about as much as
+// first-touching the pages, and the loader keeps only a window of samples alive.
+class PinnedPool {
+public:
+    static PinnedPool &get() { static PinnedPool p; return p; }
+    void *take(size_t bytes, size_t &cap, bool &pinned) {
+        {
+            std::lock_guard<std::mutex> g(m_);
+            size_t best = free_.size();
+            for (size_t i = 0; i < free_.size(); i++) if (free_[i].cap >= bytes && (best == free_.size() || free_[i].cap < free_[best].cap)) best = i;
+            if (best != free_.size()) { Block b = free_[best]; free_.erase(free_.begin() + (long)best); cap = b.cap; pinned = b.pinned; return b.p; }
+        }
+        void *p = nullptr;
+        cap = (bytes + (1u << 20)) & ~(size_t)((1u << 20) - 1);
+        pinned = simka_host_alloc(cap, &p) == SIMKA_OK && p;
+        if (!pinned) p = malloc(cap);
+        return p;
+    }
+    void give(void *p, size_t cap, bool pinned) {
+        if (!p) return;
+        std::lock_guard<std::mutex> g(m_);
+        if (free_.size() >= 64) { if (pinned) simka_host_free(p); else free(p); return; }
+        free_.push_back(Block{p, cap, pinned});
+    }
+private:
+    struct Block { void *p; size_t cap; bool pinned; };
+    std::vector<Block> free_;
+    std::mutex m_;
+};
+
+class PinnedWords {
+public:
+    PinnedWords() {}
+    PinnedWords(const PinnedWords &) = delete;
+    PinnedWords &operator=(const PinnedWords &) = delete;
+    PinnedWords(PinnedWords &&o) noexcept { steal(o); }
+    PinnedWords &operator=(PinnedWords &&o) noexcept { if (this != &o) { release(); steal(o); } return *this; }
+    ~PinnedWords() { release(); }
+    uint64_t *data() { return p_; }
+    const uint64_t *data() const { return p_; }
+    size_t size() const { return n_; }
+    uint64_t &operator[](size_t i) { return p_[i]; }
+    // grows geometrically and keeps the content; the new words are NOT cleared (simka_pack_read clears a word when it starts it)
+    void resize(size_t n) {
+        if (n * 8 > cap_) {
+            size_t cap = 0; bool pinned = false;
+            uint64_t *q = (uint64_t *)PinnedPool::get().take(std::max(n * 8, cap_ * 2), cap, pinned);
+            if (!q) throw std::bad_alloc();
+            if (n_) memcpy(q, p_, n_ * 8);
+            PinnedPool::get().give(p_, cap_, pinned_);
+            p_ = q; cap_ = cap; pinned_ = pinned;
+        }
+        n_ = n;
+    }
+    void reserve(size_t n) { const size_t keep = n_; if (n > n_) { resize(n); n_ = keep; } }
+private:
+    void release() { PinnedPool::get().give(p_, cap_, pinned_); p_ = nullptr; n_ = 0; cap_ = 0; }
+    void steal(PinnedWords &o) { p_ = o.p_; n_ = o.n_; cap_ = o.cap_; pinned_ = o.pinned_; o.p_ = nullptr; o.n_ = 0; o.cap_ = 0; }
+    uint64_t *p_ = nullptr; size_t n_ = 0, cap_ = 0; bool pinned_ = false;
+};
+
 struct Packed {
-    std::vector<uint64_t> words, offsets;
+    PinnedWords words, offsets;
     uint64_t nb_bases = 0, nb_frag = 0, nb_reads = 0;
 };
 
@@ -326,6 +388,12 @@ bool load_sample(const Sample &s, const Options &o, uint64_t max_reads, Packed &
     out = Packed();
     InputIterator it(s, o, max_reads);
     if (it.comp.empty() || it.nb_banks == 0) return false;
+    if (max_reads == 0) {   // size the buffers once from the files (2-bit bases <= file bytes, x5 for gz): growing would copy pinned memory around
+        uint64_t bytes = 0;
+        for (auto &part : s.parts) for (auto &fn : part) { struct stat st; if (stat(fn.c_str(), &st) == 0) bytes += (uint64_t)st.st_size * (fn.size() > 3 && fn.substr(fn.size() - 3) == ".gz" ? 5 : 1); }
+        out.words.reserve((size_t)(bytes / 32 + 16));
+        out.offsets.reserve((size_t)(bytes / 64 + 16));
+    }
     for (it.first(); !it.is_done; it.next()) {
         const std::string &seq = *it.item;
         out.nb_reads++;

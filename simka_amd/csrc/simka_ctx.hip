@@ -51,9 +51,11 @@ struct simka_ctx {
     };
     Lane lanes[2];
     uint32_t nlanes = 2;
-    // staging for host-provided reads
-    uint64_t *d_reads = nullptr; uint64_t reads_cap = 0;      // (words)
-    uint64_t *d_offsets = nullptr; uint64_t offsets_cap = 0;
+    // staging for host-provided reads: one buffer per lane (double buffering), filled through a copy stream of its own, so the
+    // host -> device copy of sample i + 1 runs while the kernels of sample i (the other lane) are still busy
+    uint64_t *d_reads[2] = { nullptr, nullptr }; uint64_t reads_cap[2] = { 0, 0 };      // (words)
+    uint64_t *d_offsets[2] = { nullptr, nullptr }; uint64_t offsets_cap[2] = { 0, 0 };
+    hipStream_t copy_stream = nullptr;
     uint32_t *d_l1_ovf = nullptr;                             // [N] capacity-mode scatter overflow flag per sample
     uint64_t nb_exact_fallbacks = 0;
     uint32_t nb_counted_this_run = 0;
@@ -101,7 +103,7 @@ struct simka_ctx {
     }
 };
 
-static int resolve_pending(simka_ctx *ctx);
+static int resolve_pending(simka_ctx *ctx, int lane = -1);
 
 #define HIPCHK(call)                                                                             \
     do {                                                                                         \
@@ -418,7 +420,8 @@ SIMKA_EXPORT void simka_destroy(simka_ctx *ctx) {
     }
     for (auto &ev : ctx->events) { (void)hipEventDestroy(ev.a); (void)hipEventDestroy(ev.b); }
     for (hipEvent_t e : ctx->event_pool) (void)hipEventDestroy(e);
-    void *ptrs[] = { ctx->d_reads, ctx->d_offsets, ctx->d_l1_ovf, ctx->d_solid_keys, ctx->d_solid_counts, ctx->d_arena_cursor,
+    if (ctx->copy_stream) { (void)hipStreamSynchronize(ctx->copy_stream); (void)hipStreamDestroy(ctx->copy_stream); }
+    void *ptrs[] = { ctx->d_reads[0], ctx->d_reads[1], ctx->d_offsets[0], ctx->d_offsets[1], ctx->d_l1_ovf, ctx->d_solid_keys, ctx->d_solid_counts, ctx->d_arena_cursor,
                      ctx->d_sample_base, ctx->d_foff, ctx->d_fcnt, ctx->d_stats, ctx->d_err, ctx->d_part_total,
                      ctx->d_part_off, ctx->d_mkeys, ctx->d_mvals, ctx->d_entries, ctx->d_groups, ctx->d_fb_off,
                      ctx->d_spans, ctx->d_cursors, ctx->d_huge, ctx->d_xoff, ctx->d_hist, ctx->d_ovf_list, ctx->d_ovf_cursor,
@@ -615,25 +618,32 @@ static int run_count_kernels(simka_ctx *ctx, uint32_t sample, const SimkaScanArg
 }
 
 // read the overflow flags of the samples enqueued in capacity mode; redo the flagged ones exactly (their later kernels
-// skipped themselves, so no state was touched).  Synchronises.
-static int resolve_pending(simka_ctx *ctx) {
-    for (uint32_t li = 0; li < ctx->nlanes; li++) if (ctx->lanes[li].stream) HIPCHK(hipStreamSynchronize(ctx->lanes[li].stream));
+// skipped themselves, so no state was touched).  Synchronises every lane -- or, with lane >= 0, that lane only: its pending
+// samples are settled (their reads sit in the lane's staging buffer, which the caller is about to overwrite), the other lane
+// keeps running.
+static int resolve_pending(simka_ctx *ctx, int lane) {
+    for (uint32_t li = 0; li < ctx->nlanes; li++)
+        if (ctx->lanes[li].stream && (lane < 0 || (uint32_t)lane == li)) HIPCHK(hipStreamSynchronize(ctx->lanes[li].stream));
     if (ctx->pending.empty()) return SIMKA_OK;
     const uint32_t N = ctx->cfg.nb_samples;
+    std::vector<simka_ctx::Pending> todo, keep;
+    for (auto &p : ctx->pending) ((lane < 0 || p.sample % ctx->nlanes == (uint32_t)lane) ? todo : keep).push_back(p);
+    if (todo.empty()) return SIMKA_OK;
     std::vector<uint32_t> flags(N);
-    HIPCHK(hipMemcpyAsync(flags.data(), ctx->d_l1_ovf, (size_t)N * 4, hipMemcpyDeviceToHost, ctx->stream));
-    HIPCHK(hipStreamSynchronize(ctx->stream));
-    std::vector<simka_ctx::Pending> todo;
-    todo.swap(ctx->pending);
+    hipStream_t cs = lane < 0 ? ctx->stream : ctx->lanes[lane].stream;
+    HIPCHK(hipMemcpyAsync(flags.data(), ctx->d_l1_ovf, (size_t)N * 4, hipMemcpyDeviceToHost, cs));
+    HIPCHK(hipStreamSynchronize(cs));
+    ctx->pending.swap(keep);
     for (auto &p : todo) {
         if (!flags[p.sample]) continue;
         ctx->nb_exact_fallbacks++;
-        HIPCHK(hipMemsetAsync(ctx->d_l1_ovf + p.sample, 0, 4, ctx->stream));
-        HIPCHK(hipStreamSynchronize(ctx->stream));
+        HIPCHK(hipMemsetAsync(ctx->d_l1_ovf + p.sample, 0, 4, cs));
+        HIPCHK(hipStreamSynchronize(cs));
         int rc = run_count_kernels(ctx, p.sample, p.a, true, p.pass, p.npass);
         if (rc) return rc;
     }
-    for (uint32_t li = 0; li < ctx->nlanes; li++) HIPCHK(hipStreamSynchronize(ctx->lanes[li].stream));
+    for (uint32_t li = 0; li < ctx->nlanes; li++)
+        if (lane < 0 || (uint32_t)lane == li) HIPCHK(hipStreamSynchronize(ctx->lanes[li].stream));
     return SIMKA_OK;
 }
 
@@ -652,13 +662,13 @@ static int wide_count_sample(simka_ctx *ctx, uint32_t sample, const simka_reads 
     const void *d_packed = r->packed, *d_offsets = r->offsets;
     int rc;
     if (!r->on_device) {
-        rc = ensure_cap(ctx, &ctx->d_reads, &ctx->reads_cap, nb_words + 2); if (rc) return rc;
-        HIPCHK(hipMemcpyAsync(ctx->d_reads, r->packed, nb_words * 8, hipMemcpyHostToDevice, ctx->stream));
-        d_packed = ctx->d_reads; d_offsets = nullptr;
+        rc = ensure_cap(ctx, &ctx->d_reads[0], &ctx->reads_cap[0], nb_words + 2); if (rc) return rc;
+        HIPCHK(hipMemcpyAsync(ctx->d_reads[0], r->packed, nb_words * 8, hipMemcpyHostToDevice, ctx->stream));
+        d_packed = ctx->d_reads[0]; d_offsets = nullptr;
         if (!r->fixed_len) {
-            rc = ensure_cap(ctx, &ctx->d_offsets, &ctx->offsets_cap, r->nb_reads + 1); if (rc) return rc;
-            HIPCHK(hipMemcpyAsync(ctx->d_offsets, r->offsets, (r->nb_reads + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
-            d_offsets = ctx->d_offsets;
+            rc = ensure_cap(ctx, &ctx->d_offsets[0], &ctx->offsets_cap[0], r->nb_reads + 1); if (rc) return rc;
+            HIPCHK(hipMemcpyAsync(ctx->d_offsets[0], r->offsets, (r->nb_reads + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
+            d_offsets = ctx->d_offsets[0];
         }
     }
     unsigned long long tot[SIMKA_NB_TOTALS];
@@ -697,18 +707,22 @@ SIMKA_EXPORT int simka_count_sample(simka_ctx *ctx, uint32_t sample, const simka
     a.nb_bases = r->nb_bases; a.nb_words = nb_words; a.nb_reads = r->nb_reads; a.fixed_len = r->fixed_len;
     if (r->on_device) { a.packed = r->packed; a.offsets = r->offsets; }
     else {
-        // the staging buffers still hold the previous host-provided sample: settle it (overflow flags, exact redo)
-        // before they are overwritten.  Until this point its kernels ran concurrently with the caller's file parsing.
-        rc = resolve_pending(ctx); if (rc) return rc;
-        rc = ensure_cap(ctx, &ctx->d_reads, &ctx->reads_cap, nb_words + 2); if (rc) return rc;
-        HIPCHK(hipMemcpyAsync(ctx->d_reads, r->packed, nb_words * 8, hipMemcpyHostToDevice, ctx->stream));
-        a.packed = ctx->d_reads; a.offsets = nullptr;
+        // The lane's staging buffer still holds the host-provided sample counted two calls ago: settle THAT sample (overflow flag,
+        // exact redo) before it is overwritten.  The other lane -- the previous sample -- keeps running: its kernels overlap this
+        // copy (pinned host memory, simka_host_alloc(): a DMA at PCIe speed; pageable memory works, through the runtime's bounce
+        // buffer) and the caller's parsing of the sample after this one.
+        const uint32_t li = sample % ctx->nlanes;
+        rc = resolve_pending(ctx, (int)li); if (rc) return rc;
+        if (!ctx->copy_stream) HIPCHK(hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking));
+        rc = ensure_cap(ctx, &ctx->d_reads[li], &ctx->reads_cap[li], nb_words + 2); if (rc) return rc;
+        HIPCHK(hipMemcpyAsync(ctx->d_reads[li], r->packed, nb_words * 8, hipMemcpyHostToDevice, ctx->copy_stream));
+        a.packed = ctx->d_reads[li]; a.offsets = nullptr;
         if (!r->fixed_len) {
-            rc = ensure_cap(ctx, &ctx->d_offsets, &ctx->offsets_cap, r->nb_reads + 1); if (rc) return rc;
-            HIPCHK(hipMemcpyAsync(ctx->d_offsets, r->offsets, (r->nb_reads + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
-            a.offsets = ctx->d_offsets;
+            rc = ensure_cap(ctx, &ctx->d_offsets[li], &ctx->offsets_cap[li], r->nb_reads + 1); if (rc) return rc;
+            HIPCHK(hipMemcpyAsync(ctx->d_offsets[li], r->offsets, (r->nb_reads + 1) * 8, hipMemcpyHostToDevice, ctx->copy_stream));
+            a.offsets = ctx->d_offsets[li];
         }
-        HIPCHK(hipStreamSynchronize(ctx->stream));   // the host buffers may be reused by the caller right away
+        HIPCHK(hipStreamSynchronize(ctx->copy_stream));   // the host buffers may be reused by the caller right away; the kernels below are ordered behind the copy
     }
     // scratch per k-mer occurrence: two buffers of 16-byte super-k-mer records, ~2 B per occurrence each at the expected run
     // length (+ 30 % head room): say 6 B.  A sample whose share does not fit
@@ -1673,6 +1687,19 @@ SIMKA_EXPORT int simka_profile_get(simka_ctx *ctx, int which, const char **name,
     if (ms) *ms = ctx->prof_ms[which];
     return SIMKA_OK;
 }
+SIMKA_EXPORT int simka_host_alloc(uint64_t nb_bytes, void **p) {
+    if (!p) return SIMKA_ERR_INVALID;
+    *p = nullptr;
+    if (nb_bytes == 0) return SIMKA_OK;
+    if (hipHostMalloc(p, (size_t)nb_bytes, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); *p = nullptr; return SIMKA_ERR_NOMEM; }
+    return SIMKA_OK;
+}
+
+SIMKA_EXPORT int simka_host_free(void *p) {
+    if (!p) return SIMKA_OK;
+    return hipHostFree(p) == hipSuccess ? SIMKA_OK : SIMKA_ERR_HIP;
+}
+
 SIMKA_EXPORT int simka_device_memory(int device, uint64_t *free_bytes, uint64_t *total_bytes) {
     size_t fr = 0, tot = 0;
     if (hipSetDevice(device) != hipSuccess || hipMemGetInfo(&fr, &tot) != hipSuccess) return SIMKA_ERR_HIP;

@@ -127,6 +127,31 @@ def test_synthetic_vs_oracle(gpu_required, oracle_mod, k, amin, n, R, L, kw):
             np.testing.assert_allclose(st.matrices()[name], orc.matrix(w), rtol=1e-6, atol=0)
 
 
+@pytest.mark.parametrize("name,k,amin,n,R,L,simple,complex_", [
+    # BASELINE configs[2] / configs[3] shape: 100 samples, k = 31, full -simple-dist set, abundance-min 2 -- at a depth the oracle finishes in seconds
+    ("c3_shape", 31, 2, 100, 5000, 150, True, False),
+    # BASELINE configs[4] shape: 500 samples (tiled pair accumulator: N beyond one LDS tile), k = 31, -simple-dist -complex-dist
+    ("c5_shape", 31, 2, 500, 400, 150, True, True),
+])
+def test_baseline_config_shapes_vs_oracle(gpu_required, oracle_mod, name, k, amin, n, R, L, simple, complex_):
+    """The headline configurations' SHAPES (sample count, k, read length, distance families, abundance filter) against the oracle:
+    every per-sample total and every integer accumulator bit for bit, KL to 1e-9, every matrix to 1e-6 relative."""
+    from simka_amd import synth
+    packed = _synthetic(n, R, L)
+    offs = np.arange(R + 1, dtype=np.uint64) * L
+    inputs = [(np.concatenate([pk, np.zeros(2, dtype=np.uint64)]), offs, R * L, R) for pk in packed]
+    totals, st = _run_gpu(inputs, k, amin, simple=simple, complex_=complex_)
+    orc = oracle_mod.Oracle()
+    for s, pk in enumerate(packed):
+        orc.add_sample_ascii("S%d" % s, synth.unpack_ascii(pk, R * L), offs)
+    orc.run(k, amin, simple=simple, complex_=complex_, nparts=64, threads=min(32, os.cpu_count() or 1))
+    _check_vs_oracle(totals, st, orc, simple=simple, complex_=complex_)
+    mats = st.matrices()
+    for w, mname in enumerate(orc.matrix_names()):
+        if mname in mats:
+            np.testing.assert_allclose(mats[mname], orc.matrix(w), rtol=1e-6, atol=0, err_msg=mname)
+
+
 def test_complex_dist_list_of_large_counts_is_rebuilt_when_it_overflows(gpu_required, oracle_mod, monkeypatch):
     """-complex-dist keeps counts >= 1024 on a fixed-size device list (Whittaker's one-sided terms); when it overflows the list
     is rebuilt at its exact size from the resident spectra instead of failing after the merge (the reference has no such
@@ -302,8 +327,9 @@ def test_cli_fastq_gz_inputs(gpu_required, golden_dir, tmp_path):
     assert n == 20
 
 
-@pytest.mark.parametrize("shards,k,sort_path", [(2, 21, False), (3, 21, False), (3, 33, False), (2, 47, False), (3, 21, True)])
-def test_sharded_contexts_sum_to_unsharded(gpu_required, oracle_mod, monkeypatch, shards, k, sort_path):
+@pytest.mark.parametrize("shards,k,sort_path,shape", [(2, 21, False, "small"), (3, 21, False, "small"), (3, 33, False, "small"), (2, 47, False, "small"),
+                                                      (3, 21, True, "small"), (8, 31, False, "c4")])
+def test_sharded_contexts_sum_to_unsharded(gpu_required, oracle_mod, monkeypatch, shards, k, sort_path, shape):
     """Partition shards (power-of-two and not) on one GPU: per-sample totals and every pair accumulator add up to the
     single-context result, which equals the oracle.  Hash pipeline (a shard keeps level-1 buckets) and sort-based pipeline
     (k >= 32, or forced: a shard keeps the canonical k-mers that hash to it)."""
@@ -311,7 +337,8 @@ def test_sharded_contexts_sum_to_unsharded(gpu_required, oracle_mod, monkeypatch
     from simka_amd import synth
     if sort_path:
         monkeypatch.setenv("SIMKA_SORT_PATH", "1")
-    n, R, L = 4, 5000, 100
+    # "c4": north_star's decomposition at BASELINE configs[3]'s shape (100 samples, k = 31, 8 partition shards + one sum of the heads)
+    n, R, L = (100, 1500, 150) if shape == "c4" else (4, 5000, 100)
     packed = _synthetic(n, R, L, seed_shift=50)
     offs = np.arange(R + 1, dtype=np.uint64) * L
     inputs = [(np.concatenate([pk, np.zeros(2, dtype=np.uint64)]), offs, R * L, R) for pk in packed]
@@ -339,7 +366,7 @@ def test_sharded_contexts_sum_to_unsharded(gpu_required, oracle_mod, monkeypatch
     orc = oracle_mod.Oracle()
     for s, pk in enumerate(packed):
         orc.add_sample_ascii("S%d" % s, synth.unpack_ascii(pk, R * L), offs)
-    orc.run(k, 2, simple=True, complex_=True)
+    orc.run(k, 2, simple=True, complex_=True, nparts=64, threads=min(32, os.cpu_count() or 1))
     iu = np.triu_indices(n, 1)
     assert np.array_equal(ref.pairs()["a"], orc.acc("a")[iu]) and np.array_equal(ref.pairs()["whit"], orc.acc("whit")[iu])
 
@@ -680,8 +707,8 @@ def test_cli_keep_tmp_adds_samples_without_recounting(gpu_required, golden_dir, 
         assert f.read() == g.read()
 
 
-@pytest.mark.parametrize("world,complex_", [(2, True), (3, False), (8, False)])
-def test_sample_shards_then_partition_range_merge(gpu_required, world, complex_):
+@pytest.mark.parametrize("world,complex_,shape", [(2, True, "small"), (3, False, "small"), (8, False, "small"), (8, False, "c4")])
+def test_sample_shards_then_partition_range_merge(gpu_required, world, complex_, shape):
     """The N-GPU job of simka_amd/dist.py::count_exchange_merge, emulated on one GPU: `world` contexts each count the samples
     s % world == r and export them on the device; the pack / unpack phases route every sample's slice of partition range g to
     context g (the all-to-all is done by hand here, by torch.distributed on gloo in tests/test_dist_gloo.py); each context
@@ -690,7 +717,8 @@ def test_sample_shards_then_partition_range_merge(gpu_required, world, complex_)
     import simka_amd
     from simka_amd import dist as sdist
     dev = torch.device("cuda:0")
-    n, R, L, k = 7, 3000, 100, 21
+    # "c4": BASELINE configs[3]'s shape -- 100 samples, k = 31, -simple-dist, abundance-min 2, 8 ranks -- at a depth of 2000 reads
+    n, R, L, k = (100, 2000, 150, 31) if shape == "c4" else (7, 3000, 100, 21)
     packed = _synthetic(n, R, L, seed_shift=11)
     offs = np.arange(R + 1, dtype=np.uint64) * L
     kw = dict(kmer_size=k, abundance_min=2, simple_dist=True, complex_dist=complex_, max_kmers_per_sample=R * (L - k + 1))
@@ -986,11 +1014,12 @@ def test_hash_and_sort_pipelines_agree_at_scale(gpu_required):
     assert r.returncode == 0 and "cross-check ok" in r.stdout, r.stdout[-3000:]
 
 
-@pytest.mark.parametrize("workload,alt_pb", [("c2", 13), ("c3_10", 14)])
+@pytest.mark.parametrize("workload,alt_pb", [("c2", 13), ("c3_10", 14), ("c3", 20)])
 def test_full_size_size_independent_properties(gpu_required, workload, alt_pb):
     """BASELINE configs[1] at FULL size (c2: 10 samples x 1M x 100 bp, k = 21, 8e8 k-mer occurrences -- far beyond what the
     oracle finishes in seconds) and configs[2]'s shape at a tenth of its depth (c3_10: 100 samples x 1M x 150 bp, k = 31,
     -simple-dist, 1.2e10 occurrences; the full 37 GB of reads are bench.py --workload c3), checked through properties that hold
+    and configs[2] ITSELF (c3: 100 samples x 10M x 150 bp, k = 31, 1.2e11 occurrences, ~190 GB of HBM)
     for any input:
       * the partition geometry is result-neutral (SURVEY F4): another number of partitions gives bit-identical statistics;
       * the path is equivariant under a permutation of the samples (S_ij <-> S_ji where the order of a pair flips);
