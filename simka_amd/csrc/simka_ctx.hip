@@ -298,7 +298,7 @@ static int setup_geometry(simka_ctx *ctx, uint64_t max_kmers) {
         HIPCHK(dev_alloc(&L.d_b1_count, ctx->B1 + 1));
         HIPCHK(dev_alloc(&L.d_b1_start, ctx->B1 + 1));
         HIPCHK(dev_alloc(&L.d_b1_end, ctx->B1 + 1));
-        HIPCHK(dev_alloc(&L.d_b1_cursor, ctx->B1 + 1));
+        HIPCHK(dev_alloc(&L.d_b1_cursor, (uint64_t)(ctx->B1 + 1) * SKM_CSTRIDE));
         HIPCHK(dev_alloc(&L.d_redo_list, ctx->nparts + 1));
         HIPCHK(dev_alloc(&L.d_redo_count, 2));
         HIPCHK(dev_alloc(&L.d_pstart, ctx->nparts + 1)); HIPCHK(dev_alloc(&L.d_pcnt, ctx->nparts + 1));

@@ -38,6 +38,7 @@ typedef unsigned long long ull;
 #define SKM_STRIDE (SKM_OWN_HI - SKM_OWN_LO)
 #define SKM_BLOCK 512
 #define SKM_MAXB1 256            // level-1 buckets at most
+#define SKM_CSTRIDE 16            // the global fill cursor of a bucket has a 128-byte line of its own (every tile of the scan bumps every cursor)
 #define SKM_NT (SKM_BLOCK + 4)    // thread columns of the chunk-major hash array (4 pad columns)
 #define SKM_SEG 16               // entries per thread
 #define SKM_MAXW 20
@@ -90,9 +91,11 @@ __device__ __forceinline__ uint64_t skm_revcomp64(uint64_t x) {
 //   phase 1: every thread hashes the canonical m-mers at its 16 entries -> LDS
 //   phase 2: sliding-window minimum over W entries (van Herk / Gil-Werman on the thread's 40 loaded values) -> the minimizer
 //            value of the k-mers at its 16 entries (+ the one before)
-//   phase 3: run starts / breaks as bit masks -> LDS; run length = distance to the next break (own mask + two neighbours);
-//            one record per <= nmax k-mers, bases cut out of the LDS-staged tile; per-bucket LDS histogram
-//   phase 4: one global atomic per bucket reserves the tile's run, records are stored at reserved base + LDS rank
+//   phase 3: run starts / breaks as bit masks -> LDS; the starts of the tile as one list; one lane per start: run length =
+//            distance to the next break (own mask + three neighbours), records (one per <= nmax k-mers) per level-1 bucket
+//   phase 4: exclusive scan of the bucket histogram = the tile's records in BUCKET order; one global atomic per bucket reserves
+//            the tile's run; the records are cut out of the LDS-staged tile into that order (LDS cursor per bucket) and leave
+//            as contiguous runs: consecutive lanes store consecutive records
 // HIST: only count the records per level-1 bucket (the exact-sizing fallback when a capacity-sized bucket overflowed).
 // --------------------------------------------------------------------------------------------
 template <int W, bool FIXED, bool HIST>
@@ -101,6 +104,7 @@ k_skm_scan(SimkaScanArgs a, SimkaSkmCfg cfg, ull *b1_count, ull *b1_cursor, uint
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     uint32_t &s_nrec = *(uint32_t *)(smem + 0);        // extra records of long runs (beyond the first of a start)
     uint32_t &s_nstart = *(uint32_t *)(smem + 4);
+    uint32_t *stmp = (uint32_t *)(smem + 16);          // [4] wave totals of the bucket scan
     // m-mer hashes, chunk-major: entry e = 16 t + 4 c + r lives at dword ((c * SKM_NT + t) * 4 + r), so the 16-byte accesses of
     // consecutive lanes are consecutive in LDS (the thread-major layout made every wide access a 4-way bank conflict);
     // after phase 2: partition ids of the k-mers
@@ -283,66 +287,106 @@ k_skm_scan(SimkaScanArgs a, SimkaSkmCfg cfg, ull *b1_count, ull *b1_cursor, uint
     }
     __syncthreads();
     const uint32_t nstart = s_nstart;
-    for (uint32_t si = tid; si < nstart; si += SKM_BLOCK) {
-        uint32_t e = slist[si];
+    // run of start si: entry, length (distance to the next break: own mask + three neighbours), partition
+    auto run_of = [&](uint32_t si, uint32_t &e, uint32_t &len, uint32_t &pid) {
+        e = slist[si];
         const uint32_t t_ = e >> 4, jb = e & 15u;
         const uint32_t own_ = smask[t_] >> 16;
         const ull n1 = smask[t_ + 1] >> 16, n2 = smask[t_ + 2] >> 16, n3 = (smask[t_ + 3] >> 16) & 1u;
         const ull look = ((ull)(own_ >> (jb + 1u))) | (n1 << (15u - jb)) | (n2 << (31u - jb)) | (n3 << (47u - jb));
-        uint32_t len = (uint32_t)__ffsll((long long)look);       // look != 0: a break within 48 positions is guaranteed
-        const uint32_t pid = hm[((((e & 15u) >> 2) * SKM_NT + (e >> 4)) << 2) | (e & 3u)];
-        if (!skm_owns(pid, cfg)) { if (!HIST && si < caprec) stage[si] = make_uint4(~0u, ~0u, ~0u, ~0u); continue; }
-        const uint32_t b1 = cfg.pb ? pid >> (cfg.pb - cfg.l1) : 0u;
-        bool first = true;
-        while (len) {
-            const uint32_t n = len < cfg.nmax ? len : cfg.nmax;
-            if (HIST) atomicAdd(&hist[b1], 1u);
-            else {
-                const uint32_t wi = e >> 4, sh = (e & 15u) * 2u;
-                const uint32_t c0 = tb[wi], c1 = tb[wi + 1], c2 = tb[wi + 2], c3 = tb[wi + 3], c4 = tb[wi + 4];
-                uint4 rec;
-                rec.x = __builtin_amdgcn_alignbit(c1, c0, sh); rec.y = __builtin_amdgcn_alignbit(c2, c1, sh);
-                rec.z = __builtin_amdgcn_alignbit(c3, c2, sh);
-                rec.w = (__builtin_amdgcn_alignbit(c4, c3, sh) & 63u) | ((n - 1u) << 6) | (pid << 11);
-                // the first record of start si takes staging slot si; the (rare) further ones of a long run take slots from the top
-                const uint32_t slot = first ? si : caprec - 1u - atomicAdd(&s_nrec, 1u);
-                if (slot < caprec && (first || slot >= nstart)) { stage[slot] = rec; atomicAdd(&hist[b1], 1u); }
-                else {      // staging full (pathological tile): one global atomic per record
-                    const ull g = atomicAdd(&b1_cursor[b1], 1ull);
-                    if (b1_limit && g + 1 > b1_limit[b1]) *ovf_flag = 1u; else l1_recs[g] = rec;
-                }
-            }
-            first = false;
-            e += n; len -= n;
-        }
+        len = (uint32_t)__ffsll((long long)look);       // look != 0: a break within 48 positions is guaranteed
+        pid = hm[((((e & 15u) >> 2) * SKM_NT + (e >> 4)) << 2) | (e & 3u)];
+    };
+    // ---- phase 3c: records per level-1 bucket (one LANE PER START: a thread with five starts no longer holds its wave back)
+    for (uint32_t si = tid; si < nstart; si += SKM_BLOCK) {
+        uint32_t e, len, pid;
+        run_of(si, e, len, pid);
+        if (!skm_owns(pid, cfg)) continue;
+        atomicAdd(&hist[cfg.pb ? pid >> (cfg.pb - cfg.l1) : 0u], (len + cfg.nmax - 1u) / cfg.nmax);
     }
     __syncthreads();               // (C)
     if (HIST) {
         if (tid < B1 && hist[tid]) atomicAdd(&b1_count[tid], (ull)hist[tid]);
         return;
     }
-    // ---- phase 4: reserve the tile's run in every bucket, store the records
-    if (tid < B1) {
-        const uint32_t h = hist[tid];
-        ull g = 0;
-        if (h) {
-            g = atomicAdd(&b1_cursor[tid], (ull)h);
-            if (b1_limit && g + h > b1_limit[tid]) { *ovf_flag = 1u; g = ~0ull; }
+    // ---- phase 4a: the tile's records are laid out BY BUCKET in the staging area (exclusive scan of the histogram), and every
+    // bucket's run is reserved with one global atomic -- issued here, looked at after the records have been cut (phase 4b needs
+    // only the LDS cursors), so its round trip is hidden.  hist[] becomes the start of the bucket inside the staging order, lcur[]
+    // the bucket's fill cursor.
+    ull g_res = 0; uint32_t h_res = 0;
+    {
+        const uint32_t h = tid < B1 ? hist[tid] : 0u;
+        uint32_t excl = 0;
+        if (tid < SKM_MAXB1) {
+            const uint32_t inc = wave_incl_scan(h);
+            if ((tid & 63u) == 63u) stmp[tid >> 6] = inc;
+            excl = inc - h;
+            h_res = h;
+            if (h) g_res = atomicAdd(&b1_cursor[tid * SKM_CSTRIDE], (ull)h);
         }
-        gbase[tid] = g;
+        __syncthreads();
+        if (tid < SKM_MAXB1) {
+            for (uint32_t w = 0; w < (tid >> 6); w++) excl += stmp[w];
+            hist[tid] = excl; lcur[tid] = excl;
+            if (tid == SKM_MAXB1 - 1u) { s_nrec = excl + h; s_nstart = 0; }          // records of the tile; s_nstart: now the "tile too large" flag
+        }
     }
     __syncthreads();
-    // staged: slots [0, min(nstart, caprec)) (a start of a foreign shard left its slot empty: w == ~0) and the extra records at the top
-    const uint32_t nlow = nstart < caprec ? nstart : caprec;
-    const uint32_t nextra = s_nrec, room = caprec - nlow;
-    const uint32_t nhigh = nextra < room ? nextra : room;
-    for (uint32_t i = tid; i < nlow + nhigh; i += SKM_BLOCK) {
-        const uint4 rec = stage[i < nlow ? i : caprec - 1u - (i - nlow)];
-        if (rec.w == ~0u && rec.x == ~0u) continue;
-        const uint32_t b1 = cfg.pb ? skm_rec_pid(rec) >> (cfg.pb - cfg.l1) : 0u;
-        const ull g = gbase[b1];
-        const uint32_t rk = atomicAdd(&lcur[b1], 1u);
-        if (g != ~0ull) l1_recs[g + rk] = rec;
+    // cut one record out of the LDS-staged tile
+    auto cut = [&](uint32_t e, uint32_t n, uint32_t pid) {
+        const uint32_t wi = e >> 4, sh = (e & 15u) * 2u;
+        const uint32_t c0 = tb[wi], c1 = tb[wi + 1], c2 = tb[wi + 2], c3 = tb[wi + 3], c4 = tb[wi + 4];
+        uint4 rec;
+        rec.x = __builtin_amdgcn_alignbit(c1, c0, sh); rec.y = __builtin_amdgcn_alignbit(c2, c1, sh);
+        rec.z = __builtin_amdgcn_alignbit(c3, c2, sh);
+        rec.w = (__builtin_amdgcn_alignbit(c4, c3, sh) & 63u) | ((n - 1u) << 6) | (pid << 11);
+        return rec;
+    };
+    // ---- phase 4b: the records, straight to their place in the bucket order
+    const bool big = s_nrec > caprec;              // more records than the staging area takes (pathological tile): phase 4d
+    if (!big) {
+        for (uint32_t si = tid; si < nstart; si += SKM_BLOCK) {
+            uint32_t e, len, pid;
+            run_of(si, e, len, pid);
+            if (!skm_owns(pid, cfg)) continue;
+            const uint32_t b1 = cfg.pb ? pid >> (cfg.pb - cfg.l1) : 0u;
+            while (len) {
+                const uint32_t n = len < cfg.nmax ? len : cfg.nmax;
+                stage[atomicAdd(&lcur[b1], 1u)] = cut(e, n, pid);
+                e += n; len -= n;
+            }
+        }
+    }
+    if (tid < SKM_MAXB1) {
+        if (h_res && b1_limit && g_res + h_res > b1_limit[tid]) { *ovf_flag = 1u; g_res = ~0ull; }
+        gbase[tid] = g_res;
+    }
+    __syncthreads();
+    if (!big) {
+        // ---- phase 4c: the staged records leave in bucket order: consecutive lanes store consecutive 16-byte records of one
+        // bucket's run
+        const uint32_t ntot = s_nrec;
+        for (uint32_t i = tid; i < ntot; i += SKM_BLOCK) {
+            const uint4 rec = stage[i];
+            const uint32_t b1 = cfg.pb ? skm_rec_pid(rec) >> (cfg.pb - cfg.l1) : 0u;
+            const ull g = gbase[b1];
+            if (g != ~0ull) l1_recs[g + (i - hist[b1])] = rec;
+        }
+    } else {
+        // ---- phase 4d: every record directly to its reserved global slot
+        for (uint32_t si = tid; si < nstart; si += SKM_BLOCK) {
+            uint32_t e, len, pid;
+            run_of(si, e, len, pid);
+            if (!skm_owns(pid, cfg)) continue;
+            const uint32_t b1 = cfg.pb ? pid >> (cfg.pb - cfg.l1) : 0u;
+            const ull g = gbase[b1];
+            while (len) {
+                const uint32_t n = len < cfg.nmax ? len : cfg.nmax;
+                const uint32_t pos = atomicAdd(&lcur[b1], 1u);
+                if (g != ~0ull) l1_recs[g + (pos - hist[b1])] = cut(e, n, pid);
+                e += n; len -= n;
+            }
+        }
     }
 }
 
@@ -359,20 +403,20 @@ k_skm_layout(ull *b1_count, ull *b1_start, ull *b1_limit, ull *b1_cursor, uint32
     const uint32_t tid = threadIdx.x;
     if (mode != 2u && tid == 0) *redo_count = 0ull;
     if (mode == 1u) {
-        if (tid < B1) { b1_start[tid] = (ull)tid * cap; b1_cursor[tid] = (ull)tid * cap; b1_limit[tid] = (ull)(tid + 1) * cap; }
+        if (tid < B1) { b1_start[tid] = (ull)tid * cap; b1_cursor[tid * SKM_CSTRIDE] = (ull)tid * cap; b1_limit[tid] = (ull)(tid + 1) * cap; }
         if (tid == 0 && first_pass) *sample_base = *arena_cursor;
         return;
     }
     if (mode == 2u) {
         if (skip_flag && *skip_flag) return;
-        if (tid < B1) b1_count[tid] = b1_cursor[tid] - b1_start[tid];
+        if (tid < B1) b1_count[tid] = b1_cursor[tid * SKM_CSTRIDE] - b1_start[tid];
         return;
     }
     if (tid < B1) s_cnt[tid] = b1_count[tid];
     __syncthreads();
     if (tid == 0) {
         ull run = 0;
-        for (uint32_t b = 0; b < B1; b++) { const ull c = s_cnt[b]; b1_start[b] = run; b1_cursor[b] = run; b1_limit[b] = run + c; run += c; }
+        for (uint32_t b = 0; b < B1; b++) { const ull c = s_cnt[b]; b1_start[b] = run; b1_cursor[b * SKM_CSTRIDE] = run; b1_limit[b] = run + c; run += c; }
         if (first_pass) *sample_base = *arena_cursor;
     }
 }
