@@ -228,7 +228,7 @@ SIMKA_EXPORT int simka_abi_version(void) { return SIMKA_ABI_VERSION; }
 SIMKA_EXPORT const char *simka_last_error(const simka_ctx *ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
 
 // k_scan<SCATTER, FIXED, SHARDED>
-using SkmScanFn = void (*)(SimkaScanArgs, SimkaSkmCfg, ull *, ull *, uint4 *, const ull *, uint32_t *, uint32_t);
+using SkmScanFn = void (*)(SimkaScanArgs, SimkaSkmCfg, ull *, ull *, uint4 *, const ull *, uint32_t *, uint32_t, uint32_t, uint32_t);
 static int skm_w_index(uint32_t W) { switch (W) { case 1: return 0; case 4: return 1; case 8: return 2; case 12: return 3; case 16: return 4; default: return 5; } }
 static SkmScanFn skm_scan_kernel(int wi, bool fixed, bool hist) {
 #define SKM_ROW(W) { k_skm_scan<W, false, false>, k_skm_scan<W, false, true>, k_skm_scan<W, true, false>, k_skm_scan<W, true, true> }
@@ -517,8 +517,12 @@ static int run_count_kernels(simka_ctx *ctx, uint32_t sample, const SimkaScanArg
     const uint32_t caprec = (uint32_t)std::min<uint64_t>(4096, std::max<uint64_t>(1280, (uint64_t)(SKM_STRIDE / ((sk.W + 1) / 2.0) * 1.35) / 128 * 128 + 128));
     const int wi = skm_w_index(sk.W);
     const bool fixed = a.fixed_len != 0;
-    auto scan_lds = [&](bool hist) {
-        return (size_t)SIMKA_LDS_HEAD + (size_t)16 * SKM_NT * 4 + (SKM_TILE / 16 + 8) * 4 + (SKM_BLOCK + 4) * 4 + SKM_MAXB1 * 4 * 2 + SKM_MAXB1 * 8 + (fixed ? 0 : SKM_RTAB * 4) + (size_t)SKM_TILE * 2 + (hist ? 0 : (size_t)caprec * 16);
+    // LDS region R of the scan kernel: the m-mer hashes first, then staged records + the list of run starts (6 bytes each, as many
+    // as records fit)
+    const uint32_t rbytes = (uint32_t)std::max<size_t>((size_t)16 * SKM_NT * 4, (size_t)caprec * 22 + 16);
+    auto scan_lcap = [&](bool hist) { return (uint32_t)((rbytes - (hist ? 0 : (size_t)caprec * 16) - 16) / 6); };
+    auto scan_lds = [&](bool) {
+        return (size_t)SIMKA_LDS_HEAD + rbytes + (SKM_TILE / 16 + 8) * 4 + (SKM_BLOCK + 4) * 4 + SKM_MAXB1 * 4 * 2 + SKM_MAXB1 * 8 + (fixed ? 0 : SKM_RTAB * 4);
     };
     auto layout = [&](uint32_t mode, ull capb) {
         launch_timed(ctx, KID_LAYOUT, [&] {
@@ -531,7 +535,7 @@ static int run_count_kernels(simka_ctx *ctx, uint32_t sample, const SimkaScanArg
             SimkaSkmCfg skc = sk;
             skc.nmax = sk.nmax; skc.pb = sk.pb;
             hipLaunchKernelGGL(skm_scan_kernel(wi, fixed, hist), dim3(ntiles), dim3(SKM_BLOCK), scan_lds(hist), st, a, skc, L.d_b1_count, L.d_b1_cursor, L.d_skm_a, limit,
-                               hist ? (uint32_t *)nullptr : flag, caprec);
+                               hist ? (uint32_t *)nullptr : flag, caprec, rbytes, scan_lcap(hist));
         }, st);
     };
     uint64_t rec_cap;

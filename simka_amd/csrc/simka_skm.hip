@@ -100,23 +100,27 @@ __device__ __forceinline__ uint64_t skm_revcomp64(uint64_t x) {
 // --------------------------------------------------------------------------------------------
 template <int W, bool FIXED, bool HIST>
 __global__ void __launch_bounds__(SKM_BLOCK)
-k_skm_scan(SimkaScanArgs a, SimkaSkmCfg cfg, ull *b1_count, ull *b1_cursor, uint4 *l1_recs, const ull *b1_limit, uint32_t *ovf_flag, uint32_t caprec) {
+k_skm_scan(SimkaScanArgs a, SimkaSkmCfg cfg, ull *b1_count, ull *b1_cursor, uint4 *l1_recs, const ull *b1_limit, uint32_t *ovf_flag, uint32_t caprec,
+           uint32_t rbytes, uint32_t lcap) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     uint32_t &s_nrec = *(uint32_t *)(smem + 0);        // extra records of long runs (beyond the first of a start)
     uint32_t &s_nstart = *(uint32_t *)(smem + 4);
     uint32_t *stmp = (uint32_t *)(smem + 16);          // [4] wave totals of the bucket scan
-    // m-mer hashes, chunk-major: entry e = 16 t + 4 c + r lives at dword ((c * SKM_NT + t) * 4 + r), so the 16-byte accesses of
-    // consecutive lanes are consecutive in LDS (the thread-major layout made every wide access a 4-way bank conflict);
-    // after phase 2: partition ids of the k-mers
+    // Region R (rbytes >= 16 * SKM_NT * 4) is used three times:
+    //   phases 1-2: m-mer hashes, chunk-major: entry e = 16 t + 4 c + r lives at dword ((c * SKM_NT + t) * 4 + r), so the 16-byte
+    //               accesses of consecutive lanes are consecutive in LDS (thread-major: every wide access a 4-way bank conflict);
+    //   phases 3-4: [caprec] staged records | [lcap] run starts (entry index) | [lcap] their partition ids;
+    //   a tile with more starts than the list takes (rare): partition ids of all entries, in the layout of the hashes.
     uint32_t *hm = (uint32_t *)(smem + SIMKA_LDS_HEAD);             // [4][SKM_NT][4]
-    uint32_t *tb = hm + 16 * SKM_NT;                              // [TILE/16 + 8] the tile's bases, 16 per word
+    uint4 *stage = (uint4 *)hm;                                     // [caprec] (!HIST)
+    uint16_t *slist = (uint16_t *)(stage + (HIST ? 0u : caprec));   // [lcap] entry indices of the run starts
+    uint32_t *spid = (uint32_t *)(slist + ((lcap + 1u) & ~1u));     // [lcap]
+    uint32_t *tb = (uint32_t *)(smem + SIMKA_LDS_HEAD + rbytes);    // [TILE/16 + 8] the tile's bases, 16 per word
     uint32_t *smask = tb + SKM_TILE / 16 + 8;                       // [BLOCK] start | brk << 16
     uint32_t *hist = smask + SKM_BLOCK + 4;                         // [B1]   (smask has 4 pad words: all-break)
     uint32_t *lcur = hist + SKM_MAXB1;                              // [B1]
     ull *gbase = (ull *)(lcur + SKM_MAXB1);                         // [B1]
     uint32_t *rtab = (uint32_t *)(gbase + SKM_MAXB1);               // [SKM_RTAB] (!FIXED)
-    uint16_t *slist = (uint16_t *)(rtab + (FIXED ? 0 : SKM_RTAB));  // [TILE] entry indices of the run starts
-    uint4 *stage = (uint4 *)(slist + SKM_TILE);                     // [caprec] (!HIST)
 
     const uint32_t tid = threadIdx.x;
     const uint32_t B1 = 1u << cfg.l1;
@@ -265,45 +269,66 @@ k_skm_scan(SimkaScanArgs a, SimkaSkmCfg cfg, ull *b1_count, ull *b1_cursor, uint
         // a run without a break for 32 positions restarts at a thread's first entry, so the look-ahead below stays within 64 bits
         const uint32_t p1 = tid >= 1 ? smask[tid - 1] >> 16 : 0xffffu, p2 = tid >= 2 ? smask[tid - 2] >> 16 : 0xffffu;
         const bool forced = owner && ((valid >> 1) & 1u) && !(brk & 1u) && p1 == 0u && p2 == 0u;
-        // the partition ids of my k-mers go where my hashes were
-        if (owner) {
-#pragma unroll
-            for (int j = 1; j <= SKM_SEG; j++) hm[(((j - 1) >> 2) * SKM_NT + tid) * 4 + ((j - 1) & 3)] = skm_pid(mh[j], cfg.pb);
-        }
         __syncthreads();           // every thread has read the masks of its predecessors
         if (forced) { start |= 1u; brk |= 1u; smask[tid] = start | (brk << 16); }
     }
     __syncthreads();               // (B)
-    // ---- phase 3b: the run starts of the tile as one list (entry indices), then ONE LANE PER START: a thread with five starts no
-    // longer holds its wave back
+    // ---- phase 3b: the run starts of the tile as one list (entry index, partition id), then ONE LANE PER START: a thread with
+    // five starts no longer holds its wave back.  The list lives where the hashes were (dead since (A)).
     {
         const uint32_t ns = owner ? (uint32_t)__popc(start) : 0u;
         const uint32_t inc = wave_incl_scan(ns);
         uint32_t wb = 0;
         if ((tid & 63u) == 63u && inc) wb = atomicAdd(&s_nstart, inc);
         wb = __builtin_amdgcn_readlane(wb, 63);
-        uint32_t p = wb + inc - ns, todo = owner ? start : 0u;
-        while (todo) { slist[p++] = (uint16_t)(SKM_SEG * tid + __ffs(todo) - 1u); todo &= todo - 1u; }
+        uint32_t p = wb + inc - ns;
+        if (ns && p + ns <= lcap) {
+#pragma unroll
+            for (int j = 1; j <= SKM_SEG; j++)
+                if ((start >> (j - 1)) & 1u) { slist[p] = (uint16_t)(SKM_SEG * tid + (uint32_t)(j - 1)); spid[p] = skm_pid(mh[j], cfg.pb); p++; }
+        }
     }
     __syncthreads();
     const uint32_t nstart = s_nstart;
-    // run of start si: entry, length (distance to the next break: own mask + three neighbours), partition
-    auto run_of = [&](uint32_t si, uint32_t &e, uint32_t &len, uint32_t &pid) {
-        e = slist[si];
+    const bool listed = nstart <= lcap;
+    if (!listed) {
+        // more starts than the list takes: the partition ids of ALL entries go where the hashes were, every thread walks its own starts
+        if (owner) {
+            uint4 *dst = (uint4 *)hm;
+            dst[0 * SKM_NT + tid] = make_uint4(skm_pid(mh[1], cfg.pb), skm_pid(mh[2], cfg.pb), skm_pid(mh[3], cfg.pb), skm_pid(mh[4], cfg.pb));
+            dst[1 * SKM_NT + tid] = make_uint4(skm_pid(mh[5], cfg.pb), skm_pid(mh[6], cfg.pb), skm_pid(mh[7], cfg.pb), skm_pid(mh[8], cfg.pb));
+            dst[2 * SKM_NT + tid] = make_uint4(skm_pid(mh[9], cfg.pb), skm_pid(mh[10], cfg.pb), skm_pid(mh[11], cfg.pb), skm_pid(mh[12], cfg.pb));
+            dst[3 * SKM_NT + tid] = make_uint4(skm_pid(mh[13], cfg.pb), skm_pid(mh[14], cfg.pb), skm_pid(mh[15], cfg.pb), skm_pid(mh[16], cfg.pb));
+        }
+        __syncthreads();
+    }
+    // length of the run that starts at entry e: distance to the next break (own mask + three neighbours)
+    auto len_of = [&](uint32_t e) {
         const uint32_t t_ = e >> 4, jb = e & 15u;
         const uint32_t own_ = smask[t_] >> 16;
         const ull n1 = smask[t_ + 1] >> 16, n2 = smask[t_ + 2] >> 16, n3 = (smask[t_ + 3] >> 16) & 1u;
         const ull look = ((ull)(own_ >> (jb + 1u))) | (n1 << (15u - jb)) | (n2 << (31u - jb)) | (n3 << (47u - jb));
-        len = (uint32_t)__ffsll((long long)look);       // look != 0: a break within 48 positions is guaranteed
-        pid = hm[((((e & 15u) >> 2) * SKM_NT + (e >> 4)) << 2) | (e & 3u)];
+        return (uint32_t)__ffsll((long long)look);       // look != 0: a break within 48 positions is guaranteed
     };
-    // ---- phase 3c: records per level-1 bucket (one LANE PER START: a thread with five starts no longer holds its wave back)
-    for (uint32_t si = tid; si < nstart; si += SKM_BLOCK) {
-        uint32_t e, len, pid;
-        run_of(si, e, len, pid);
-        if (!skm_owns(pid, cfg)) continue;
-        atomicAdd(&hist[cfg.pb ? pid >> (cfg.pb - cfg.l1) : 0u], (len + cfg.nmax - 1u) / cfg.nmax);
-    }
+    // f(entry, run length, partition id) for every run of the tile that this shard owns
+    auto for_runs = [&](auto &&f) {
+        if (listed) {
+            for (uint32_t si = tid; si < nstart; si += SKM_BLOCK) {
+                const uint32_t e = slist[si], pid = spid[si];
+                if (skm_owns(pid, cfg)) f(e, len_of(e), pid);
+            }
+        } else if (owner) {
+            uint32_t todo = start;
+            while (todo) {
+                const uint32_t e = SKM_SEG * tid + (uint32_t)__ffs(todo) - 1u;
+                todo &= todo - 1u;
+                const uint32_t pid = hm[((((e & 15u) >> 2) * SKM_NT + (e >> 4)) << 2) | (e & 3u)];
+                if (skm_owns(pid, cfg)) f(e, len_of(e), pid);
+            }
+        }
+    };
+    // ---- phase 3c: records per level-1 bucket
+    for_runs([&](uint32_t, uint32_t len, uint32_t pid) { atomicAdd(&hist[cfg.pb ? pid >> (cfg.pb - cfg.l1) : 0u], (len + cfg.nmax - 1u) / cfg.nmax); });
     __syncthreads();               // (C)
     if (HIST) {
         if (tid < B1 && hist[tid]) atomicAdd(&b1_count[tid], (ull)hist[tid]);
@@ -342,27 +367,25 @@ k_skm_scan(SimkaScanArgs a, SimkaSkmCfg cfg, ull *b1_count, ull *b1_cursor, uint
         rec.w = (__builtin_amdgcn_alignbit(c4, c3, sh) & 63u) | ((n - 1u) << 6) | (pid << 11);
         return rec;
     };
-    // ---- phase 4b: the records, straight to their place in the bucket order
-    const bool big = s_nrec > caprec;              // more records than the staging area takes (pathological tile): phase 4d
-    if (!big) {
-        for (uint32_t si = tid; si < nstart; si += SKM_BLOCK) {
-            uint32_t e, len, pid;
-            run_of(si, e, len, pid);
-            if (!skm_owns(pid, cfg)) continue;
+    // ---- phase 4b: the records, straight to their place in the bucket order.  direct: more records than the staging area takes,
+    // or no list (the staging area holds the partition ids): every record goes to its reserved global slot instead (phase 4d)
+    const bool direct = !listed || s_nrec > caprec;
+    if (!direct) {
+        for_runs([&](uint32_t e, uint32_t len, uint32_t pid) {
             const uint32_t b1 = cfg.pb ? pid >> (cfg.pb - cfg.l1) : 0u;
             while (len) {
                 const uint32_t n = len < cfg.nmax ? len : cfg.nmax;
                 stage[atomicAdd(&lcur[b1], 1u)] = cut(e, n, pid);
                 e += n; len -= n;
             }
-        }
+        });
     }
     if (tid < SKM_MAXB1) {
         if (h_res && b1_limit && g_res + h_res > b1_limit[tid]) { *ovf_flag = 1u; g_res = ~0ull; }
         gbase[tid] = g_res;
     }
     __syncthreads();
-    if (!big) {
+    if (!direct) {
         // ---- phase 4c: the staged records leave in bucket order: consecutive lanes store consecutive 16-byte records of one
         // bucket's run
         const uint32_t ntot = s_nrec;
@@ -373,11 +396,8 @@ k_skm_scan(SimkaScanArgs a, SimkaSkmCfg cfg, ull *b1_count, ull *b1_cursor, uint
             if (g != ~0ull) l1_recs[g + (i - hist[b1])] = rec;
         }
     } else {
-        // ---- phase 4d: every record directly to its reserved global slot
-        for (uint32_t si = tid; si < nstart; si += SKM_BLOCK) {
-            uint32_t e, len, pid;
-            run_of(si, e, len, pid);
-            if (!skm_owns(pid, cfg)) continue;
+        // ---- phase 4d
+        for_runs([&](uint32_t e, uint32_t len, uint32_t pid) {
             const uint32_t b1 = cfg.pb ? pid >> (cfg.pb - cfg.l1) : 0u;
             const ull g = gbase[b1];
             while (len) {
@@ -386,7 +406,7 @@ k_skm_scan(SimkaScanArgs a, SimkaSkmCfg cfg, ull *b1_count, ull *b1_cursor, uint
                 if (g != ~0ull) l1_recs[g + (pos - hist[b1])] = cut(e, n, pid);
                 e += n; len -= n;
             }
-        }
+        });
     }
 }
 
