@@ -25,8 +25,10 @@ def per_kernel(path, counter):
 
 def main():
     d, wl, out = sys.argv[1], sys.argv[2], sys.argv[3]
-    ft, fc = per_kernel("%s/fetch_%s_counter_collection.csv" % (d, wl), "FETCH_SIZE")
-    wt, wc = per_kernel("%s/write_%s_counter_collection.csv" % (d, wl), "WRITE_SIZE")
+    import glob
+    find = lambda tag: sorted(glob.glob("%s/**/%s_%s_counter_collection.csv" % (d, tag, wl), recursive=True))[0]
+    ft, fc = per_kernel(find("fetch"), "FETCH_SIZE")
+    wt, wc = per_kernel(find("write"), "WRITE_SIZE")
     kernels = {}
     for k in sorted(ft):
         if not k.startswith("k_") or k.startswith("k_synth"):

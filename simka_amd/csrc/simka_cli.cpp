@@ -283,25 +283,27 @@ private:
     std::mutex m_;
 };
 
-class PinnedWords {
+template <class T>
+class PinnedBuf {
 public:
-    PinnedWords() {}
-    PinnedWords(const PinnedWords &) = delete;
-    PinnedWords &operator=(const PinnedWords &) = delete;
-    PinnedWords(PinnedWords &&o) noexcept { steal(o); }
-    PinnedWords &operator=(PinnedWords &&o) noexcept { if (this != &o) { release(); steal(o); } return *this; }
-    ~PinnedWords() { release(); }
-    uint64_t *data() { return p_; }
-    const uint64_t *data() const { return p_; }
+    PinnedBuf() {}
+    PinnedBuf(const PinnedBuf &) = delete;
+    PinnedBuf &operator=(const PinnedBuf &) = delete;
+    PinnedBuf(PinnedBuf &&o) noexcept { steal(o); }
+    PinnedBuf &operator=(PinnedBuf &&o) noexcept { if (this != &o) { release(); steal(o); } return *this; }
+    ~PinnedBuf() { release(); }
+    T *data() { return p_; }
+    const T *data() const { return p_; }
     size_t size() const { return n_; }
-    uint64_t &operator[](size_t i) { return p_[i]; }
+    T &operator[](size_t i) { return p_[i]; }
+    const T &operator[](size_t i) const { return p_[i]; }
     // grows geometrically and keeps the content; the new words are NOT cleared (simka_pack_read clears a word when it starts it)
     void resize(size_t n) {
-        if (n * 8 > cap_) {
+        if (n * sizeof(T) > cap_) {
             size_t cap = 0; bool pinned = false;
-            uint64_t *q = (uint64_t *)PinnedPool::get().take(std::max(n * 8, cap_ * 2), cap, pinned);
+            T *q = (T *)PinnedPool::get().take(std::max(n * sizeof(T), cap_ * 2), cap, pinned);
             if (!q) throw std::bad_alloc();
-            if (n_) memcpy(q, p_, n_ * 8);
+            if (n_) memcpy(q, p_, n_ * sizeof(T));
             PinnedPool::get().give(p_, cap_, pinned_);
             p_ = q; cap_ = cap; pinned_ = pinned;
         }
@@ -310,9 +312,11 @@ public:
     void reserve(size_t n) { const size_t keep = n_; if (n > n_) { resize(n); n_ = keep; } }
 private:
     void release() { PinnedPool::get().give(p_, cap_, pinned_); p_ = nullptr; n_ = 0; cap_ = 0; }
-    void steal(PinnedWords &o) { p_ = o.p_; n_ = o.n_; cap_ = o.cap_; pinned_ = o.pinned_; o.p_ = nullptr; o.n_ = 0; o.cap_ = 0; }
-    uint64_t *p_ = nullptr; size_t n_ = 0, cap_ = 0; bool pinned_ = false;
+    void steal(PinnedBuf &o) { p_ = o.p_; n_ = o.n_; cap_ = o.cap_; pinned_ = o.pinned_; o.p_ = nullptr; o.n_ = 0; o.cap_ = 0; }
+    T *p_ = nullptr; size_t n_ = 0, cap_ = 0; bool pinned_ = false;
 };
+
+typedef PinnedBuf<uint64_t> PinnedWords;
 
 struct Packed {
     PinnedWords words, offsets;
@@ -526,7 +530,8 @@ bool spec_matches(const SpecHeader &h, const Options &o, uint32_t g, uint32_t G,
            h.nb_partitions && !(h.nb_partitions & (h.nb_partitions - 1));
 }
 
-struct Spectrum { SpecHeader h; std::vector<uint32_t> part_counts, counts; std::vector<uint64_t> keys; };
+// (keys / counts are page-locked: they travel host <-> GPU whole with -nb-gpus, -merge-ranges and -keep-tmp)
+struct Spectrum { SpecHeader h; std::vector<uint32_t> part_counts; PinnedBuf<uint32_t> counts; PinnedBuf<uint64_t> keys; };
 
 bool read_spec(const std::string &path, Spectrum &sp) {
     FILE *f = fopen(path.c_str(), "rb");
@@ -814,8 +819,8 @@ int main(int argc, char **argv) {
                     const uint64_t *kp = n ? sp.keys.data() + before : nullptr;
                     if (n && sp.h.key_words == 2) {        // [hi x records][lo x records]: the slice of both halves, back to back
                         kslice.resize(2 * n);
-                        std::copy(sp.keys.begin() + before, sp.keys.begin() + before + n, kslice.begin());
-                        std::copy(sp.keys.begin() + sp.h.nb_records + before, sp.keys.begin() + sp.h.nb_records + before + n, kslice.begin() + n);
+                        std::copy(sp.keys.data() + before, sp.keys.data() + before + n, kslice.begin());
+                        std::copy(sp.keys.data() + sp.h.nb_records + before, sp.keys.data() + sp.h.nb_records + before + n, kslice.begin() + n);
                         kp = kslice.data();
                     }
                     if (simka_import_sample(c, i, &sp.h.totals, pc.data(), P, kp, n ? sp.counts.data() + before : nullptr, n) != SIMKA_OK)

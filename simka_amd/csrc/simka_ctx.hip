@@ -47,14 +47,16 @@ struct simka_ctx {
         uint32_t *d_redo_list = nullptr; ull *d_redo_count = nullptr;   // partitions k_skm_count_fast hands to k_skm_count
         // super-k-mer pipeline: two record buffers (level 1 / level 3 share one), level-2 counters, partition table
         uint4 *d_skm_a = nullptr, *d_skm_b = nullptr; uint64_t skm_a_cap = 0, skm_b_cap = 0;
+        uint32_t *d_skm_p = nullptr; uint64_t skm_p_cap = 0;      // partition id of every level-1 record (4-byte side array)
         uint32_t *d_pstart = nullptr, *d_pcnt = nullptr;
     };
-    Lane lanes[2];
+    static constexpr uint32_t MAX_LANES = 4;
+    Lane lanes[MAX_LANES];
     uint32_t nlanes = 2;
     // staging for host-provided reads: one buffer per lane (double buffering), filled through a copy stream of its own, so the
     // host -> device copy of sample i + 1 runs while the kernels of sample i (the other lane) are still busy
-    uint64_t *d_reads[2] = { nullptr, nullptr }; uint64_t reads_cap[2] = { 0, 0 };      // (words)
-    uint64_t *d_offsets[2] = { nullptr, nullptr }; uint64_t offsets_cap[2] = { 0, 0 };
+    uint64_t *d_reads[MAX_LANES] = {}; uint64_t reads_cap[MAX_LANES] = {};      // (words)
+    uint64_t *d_offsets[MAX_LANES] = {}; uint64_t offsets_cap[MAX_LANES] = {};
     hipStream_t copy_stream = nullptr;
     uint32_t *d_l1_ovf = nullptr;                             // [N] capacity-mode scatter overflow flag per sample
     uint64_t nb_exact_fallbacks = 0;
@@ -228,7 +230,7 @@ SIMKA_EXPORT int simka_abi_version(void) { return SIMKA_ABI_VERSION; }
 SIMKA_EXPORT const char *simka_last_error(const simka_ctx *ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
 
 // k_scan<SCATTER, FIXED, SHARDED>
-using SkmScanFn = void (*)(SimkaScanArgs, SimkaSkmCfg, ull *, ull *, uint4 *, const ull *, uint32_t *, uint32_t, uint32_t, uint32_t);
+using SkmScanFn = void (*)(SimkaScanArgs, SimkaSkmCfg, ull *, ull *, uint4 *, const ull *, uint32_t *, uint32_t, uint32_t, uint32_t, uint32_t *);
 static int skm_w_index(uint32_t W) { switch (W) { case 1: return 0; case 4: return 1; case 8: return 2; case 12: return 3; case 16: return 4; default: return 5; } }
 static SkmScanFn skm_scan_kernel(int wi, bool fixed, bool hist) {
 #define SKM_ROW(W) { k_skm_scan<W, false, false>, k_skm_scan<W, false, true>, k_skm_scan<W, true, false>, k_skm_scan<W, true, true> }
@@ -290,8 +292,8 @@ static int setup_geometry(simka_ctx *ctx, uint64_t max_kmers) {
     // of neighbouring samples overlap); the default single lane keeps per-kernel timings free of overlap.
     // samples alternate between two streams with private scratch: the scan of one sample overlaps the count of another (the
     // kernels are bound by different things: c3_10 212.7 -> 181.9 ms/step); SIMKA_LANES=1 keeps per-kernel timings free of overlap
-    const bool two_lanes = !(getenv("SIMKA_LANES") && atoi(getenv("SIMKA_LANES")) < 2);      // (read per context: bench.py profiles with one lane)
-    ctx->nlanes = (two_lanes && c.nb_samples >= 2) ? 2u : 1u;
+    const uint32_t want_lanes = getenv("SIMKA_LANES") ? (uint32_t)std::max(1, atoi(getenv("SIMKA_LANES"))) : 2u;      // (read per context: bench.py profiles with one lane)
+    ctx->nlanes = std::min<uint32_t>(std::min<uint32_t>(want_lanes, simka_ctx::MAX_LANES), std::max<uint32_t>(1u, c.nb_samples));
     for (uint32_t li = 0; li < ctx->nlanes; li++) {
         simka_ctx::Lane &L = ctx->lanes[li];
         if (!L.stream) HIPCHK(hipStreamCreateWithFlags(&L.stream, hipStreamNonBlocking));
@@ -414,14 +416,15 @@ SIMKA_EXPORT void simka_destroy(simka_ctx *ctx) {
     for (auto &L : ctx->lanes) {
         if (L.stream) (void)hipStreamSynchronize(L.stream);
         void *lp[] = { L.d_b1_count, L.d_b1_start, L.d_b1_end, L.d_b1_cursor, L.d_tile_r0, L.d_redo_list, L.d_redo_count,
-                       L.d_skm_a, L.d_skm_b, L.d_pstart, L.d_pcnt };
+                       L.d_skm_a, L.d_skm_b, L.d_skm_p, L.d_pstart, L.d_pcnt };
         for (void *q : lp) if (q) (void)hipFree(q);
         if (L.stream) (void)hipStreamDestroy(L.stream);
     }
     for (auto &ev : ctx->events) { (void)hipEventDestroy(ev.a); (void)hipEventDestroy(ev.b); }
     for (hipEvent_t e : ctx->event_pool) (void)hipEventDestroy(e);
     if (ctx->copy_stream) { (void)hipStreamSynchronize(ctx->copy_stream); (void)hipStreamDestroy(ctx->copy_stream); }
-    void *ptrs[] = { ctx->d_reads[0], ctx->d_reads[1], ctx->d_offsets[0], ctx->d_offsets[1], ctx->d_l1_ovf, ctx->d_solid_keys, ctx->d_solid_counts, ctx->d_arena_cursor,
+    for (uint32_t li = 0; li < simka_ctx::MAX_LANES; li++) { if (ctx->d_reads[li]) (void)hipFree(ctx->d_reads[li]); if (ctx->d_offsets[li]) (void)hipFree(ctx->d_offsets[li]); }
+    void *ptrs[] = { ctx->d_l1_ovf, ctx->d_solid_keys, ctx->d_solid_counts, ctx->d_arena_cursor,
                      ctx->d_sample_base, ctx->d_foff, ctx->d_fcnt, ctx->d_stats, ctx->d_err, ctx->d_part_total,
                      ctx->d_part_off, ctx->d_mkeys, ctx->d_mvals, ctx->d_entries, ctx->d_groups, ctx->d_fb_off,
                      ctx->d_spans, ctx->d_cursors, ctx->d_huge, ctx->d_xoff, ctx->d_hist, ctx->d_ovf_list, ctx->d_ovf_cursor,
@@ -535,7 +538,7 @@ static int run_count_kernels(simka_ctx *ctx, uint32_t sample, const SimkaScanArg
             SimkaSkmCfg skc = sk;
             skc.nmax = sk.nmax; skc.pb = sk.pb;
             hipLaunchKernelGGL(skm_scan_kernel(wi, fixed, hist), dim3(ntiles), dim3(SKM_BLOCK), scan_lds(hist), st, a, skc, L.d_b1_count, L.d_b1_cursor, L.d_skm_a, limit,
-                               hist ? (uint32_t *)nullptr : flag, caprec, rbytes, scan_lcap(hist));
+                               hist ? (uint32_t *)nullptr : flag, caprec, rbytes, scan_lcap(hist), L.d_skm_p);
         }, st);
     };
     uint64_t rec_cap;
@@ -546,6 +549,7 @@ static int run_count_kernels(simka_ctx *ctx, uint32_t sample, const SimkaScanArg
         rec_cap = capb * B1;
         rc = ensure_cap(ctx, &L.d_skm_a, &L.skm_a_cap, rec_cap); if (rc) return rc;
         rc = ensure_cap(ctx, &L.d_skm_b, &L.skm_b_cap, rec_cap); if (rc) return rc;
+        rc = ensure_cap(ctx, &L.d_skm_p, &L.skm_p_cap, rec_cap); if (rc) return rc;
         layout(1, capb);
         scan(false, (const ull *)L.d_b1_end);
         layout(2, capb);
@@ -562,13 +566,14 @@ static int run_count_kernels(simka_ctx *ctx, uint32_t sample, const SimkaScanArg
         if (rec_cap >= 0xffffffffull) return ctx->fail(SIMKA_ERR_OVERFLOW, "a sample yields more than 2^32 super-k-mer records in one pass");
         rc = ensure_cap(ctx, &L.d_skm_a, &L.skm_a_cap, rec_cap); if (rc) return rc;
         rc = ensure_cap(ctx, &L.d_skm_b, &L.skm_b_cap, rec_cap); if (rc) return rc;
+        rc = ensure_cap(ctx, &L.d_skm_p, &L.skm_p_cap, rec_cap); if (rc) return rc;
         layout(0, 0);
         scan(false, (const ull *)L.d_b1_end);
     }
     if (rec_cap >= 0xffffffffull) return ctx->fail(SIMKA_ERR_OVERFLOW, "a sample needs more than 2^32 super-k-mer record slots in one pass");
     launch_timed(ctx, KID_SKM_SPLIT, [&] {
         const size_t lds_split = ((size_t)1 << sk.l2) * 4 + 64 + ((size_t)1 << sk.l2) * 2 + 16 + (size_t)SKM_SPLIT_BLOCK * SKM_SPLIT_UNROLL * 16;
-        hipLaunchKernelGGL(k_skm_split, dim3(B1), dim3(SKM_SPLIT_BLOCK), lds_split, st, (const uint4 *)L.d_skm_a, (const ull *)L.d_b1_start, (const ull *)L.d_b1_count, sk,
+        hipLaunchKernelGGL(k_skm_split, dim3(B1), dim3(SKM_SPLIT_BLOCK), lds_split, st, (const uint4 *)L.d_skm_a, (const uint32_t *)L.d_skm_p, (const ull *)L.d_b1_start, (const ull *)L.d_b1_count, sk,
                            L.d_skm_b, L.d_pstart, L.d_pcnt, (const uint32_t *)flag);
     }, st);
     SimkaCountOut o;

@@ -37,7 +37,7 @@ typedef unsigned long long ull;
 #define SKM_OWN_HI (SKM_TILE - 32)
 #define SKM_STRIDE (SKM_OWN_HI - SKM_OWN_LO)
 #define SKM_BLOCK 512
-#define SKM_MAXB1 256            // level-1 buckets at most
+#define SKM_MAXB1 256            // level-1 buckets at most (512: the scan's runs per bucket halve to ~30 bytes and the kernel doubles, the split gains 10 %)
 #define SKM_CSTRIDE 16            // the global fill cursor of a bucket has a 128-byte line of its own (every tile of the scan bumps every cursor)
 #define SKM_NT (SKM_BLOCK + 4)    // thread columns of the chunk-major hash array (4 pad columns)
 #define SKM_SEG 16               // entries per thread
@@ -101,7 +101,7 @@ __device__ __forceinline__ uint64_t skm_revcomp64(uint64_t x) {
 template <int W, bool FIXED, bool HIST>
 __global__ void __launch_bounds__(SKM_BLOCK)
 k_skm_scan(SimkaScanArgs a, SimkaSkmCfg cfg, ull *b1_count, ull *b1_cursor, uint4 *l1_recs, const ull *b1_limit, uint32_t *ovf_flag, uint32_t caprec,
-           uint32_t rbytes, uint32_t lcap) {
+           uint32_t rbytes, uint32_t lcap, uint32_t *l1_pid) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     uint32_t &s_nrec = *(uint32_t *)(smem + 0);        // extra records of long runs (beyond the first of a start)
     uint32_t &s_nstart = *(uint32_t *)(smem + 4);
@@ -393,7 +393,7 @@ k_skm_scan(SimkaScanArgs a, SimkaSkmCfg cfg, ull *b1_count, ull *b1_cursor, uint
             const uint4 rec = stage[i];
             const uint32_t b1 = cfg.pb ? skm_rec_pid(rec) >> (cfg.pb - cfg.l1) : 0u;
             const ull g = gbase[b1];
-            if (g != ~0ull) l1_recs[g + (i - hist[b1])] = rec;
+            if (g != ~0ull) { l1_recs[g + (i - hist[b1])] = rec; l1_pid[g + (i - hist[b1])] = skm_rec_pid(rec); }       // (the split's first pass reads 4 bytes per record)
         }
     } else {
         // ---- phase 4d
@@ -403,7 +403,7 @@ k_skm_scan(SimkaScanArgs a, SimkaSkmCfg cfg, ull *b1_count, ull *b1_cursor, uint
             while (len) {
                 const uint32_t n = len < cfg.nmax ? len : cfg.nmax;
                 const uint32_t pos = atomicAdd(&lcur[b1], 1u);
-                if (g != ~0ull) l1_recs[g + (pos - hist[b1])] = cut(e, n, pid);
+                if (g != ~0ull) { l1_recs[g + (pos - hist[b1])] = cut(e, n, pid); l1_pid[g + (pos - hist[b1])] = pid; }
                 e += n; len -= n;
             }
         });
@@ -443,7 +443,8 @@ k_skm_layout(ull *b1_count, ull *b1_start, ull *b1_limit, ull *b1_cursor, uint32
 
 // --------------------------------------------------------------------------------------------
 // k_skm_split: level-1 bucket -> its 2^l2 partitions, exactly sized, ONE block per bucket.
-//   pass 1: stream the bucket, LDS histogram of the partitions (non-returning atomics) -> exclusive scan -> partition table;
+//   pass 1: stream the partition ids of the bucket (a 4-byte side array the scan writes next to the 16-byte records), LDS
+//           histogram of the partitions (non-returning atomics) -> exclusive scan -> partition table;
 //   pass 2: stream it again, LDS cursor per partition (returning atomic = final position), 16-byte stores into the bucket's
 //           range of the output buffer.
 // 256 buckets x one 1024-thread block each: every CU streams its own bucket (8.8 MB on C3) twice and writes it once --
@@ -452,7 +453,7 @@ k_skm_layout(ull *b1_count, ull *b1_start, ull *b1_limit, ull *b1_cursor, uint32
 #define SKM_SPLIT_BLOCK 1024
 #define SKM_SPLIT_UNROLL 8
 __global__ void __launch_bounds__(SKM_SPLIT_BLOCK)
-k_skm_split(const uint4 *l1_recs, const ull *b1_start, const ull *b1_count, SimkaSkmCfg cfg, uint4 *out_recs, uint32_t *pstart, uint32_t *pcnt, const uint32_t *flag) {
+k_skm_split(const uint4 *l1_recs, const uint32_t *l1_pid, const ull *b1_start, const ull *b1_count, SimkaSkmCfg cfg, uint4 *out_recs, uint32_t *pstart, uint32_t *pcnt, const uint32_t *flag) {
     if (*flag) return;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     uint32_t *lh = (uint32_t *)smem;                   // [F2] counts, then cursors
@@ -468,12 +469,12 @@ k_skm_split(const uint4 *l1_recs, const ull *b1_start, const ull *b1_count, Simk
     {
         uint32_t w[SKM_SPLIT_UNROLL], wn[SKM_SPLIT_UNROLL];
 #pragma unroll
-        for (int u = 0; u < SKM_SPLIT_UNROLL; u++) { const ull i = (ull)u * SKM_SPLIT_BLOCK + tid; w[u] = i < n ? l1_recs[st + i].w : 0u; }
+        for (int u = 0; u < SKM_SPLIT_UNROLL; u++) { const ull i = (ull)u * SKM_SPLIT_BLOCK + tid; w[u] = i < n ? l1_pid[st + i] : 0u; }
         for (ull i0 = 0; i0 < n; i0 += STEP) {
 #pragma unroll
-            for (int u = 0; u < SKM_SPLIT_UNROLL; u++) { const ull i = i0 + STEP + (ull)u * SKM_SPLIT_BLOCK + tid; wn[u] = i < n ? l1_recs[st + i].w : 0u; }
+            for (int u = 0; u < SKM_SPLIT_UNROLL; u++) { const ull i = i0 + STEP + (ull)u * SKM_SPLIT_BLOCK + tid; wn[u] = i < n ? l1_pid[st + i] : 0u; }
 #pragma unroll
-            for (int u = 0; u < SKM_SPLIT_UNROLL; u++) { const ull i = i0 + (ull)u * SKM_SPLIT_BLOCK + tid; if (i < n) atomicAdd(&lh[(w[u] >> 11) & m2], 1u); }
+            for (int u = 0; u < SKM_SPLIT_UNROLL; u++) { const ull i = i0 + (ull)u * SKM_SPLIT_BLOCK + tid; if (i < n) atomicAdd(&lh[w[u] & m2], 1u); }
 #pragma unroll
             for (int u = 0; u < SKM_SPLIT_UNROLL; u++) w[u] = wn[u];
         }
