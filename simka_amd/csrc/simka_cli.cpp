@@ -801,8 +801,17 @@ int main(int argc, char **argv) {
         if (o.verbose) std::cout << std::endl << "Merging k-mer counts and computing distances..." << std::endl;
         std::mutex acc_lock;
         bool have_tail = false;
+        // One range per GPU on distinct devices: the heads of the G merges are combined by ONE RCCL all-reduce over xGMI
+        // (simka_stats_allreduce_head: SimkaStatistics::operator+= across GPUs, ref: src/core/SimkaDistance.cpp:156-213); the
+        // imported per-sample totals are global on every GPU already.  Several ranges per GPU (or -gpu-shared): summed on the host.
+        const bool use_rccl = G > 1 && V == G && !o.same_gpu;
+        uint8_t comm_id[SIMKA_COMM_ID_BYTES];
+        if (use_rccl && simka_comm_unique_id(comm_id) != SIMKA_OK) die(std::string("EXCEPTION: simka_comm_unique_id: ") + simka_comm_last_error(nullptr));
         auto merger = [&](uint32_t g) {
             simka_ctx *c = make_ctx(N, device_of(g));
+            simka_comm *comm = nullptr;
+            if (use_rccl && simka_comm_create(comm_id, (int)G, (int)g, device_of(g), &comm) != SIMKA_OK)
+                die(std::string("EXCEPTION: simka_comm_create: ") + simka_comm_last_error(nullptr));
             std::vector<uint64_t> shard(nw), off(P + 1), kslice;
             std::vector<uint32_t> pc(P);
             bool first = true;
@@ -827,11 +836,18 @@ int main(int argc, char **argv) {
                         fatal(c, "simka_import_sample");
                 }
                 if (simka_merge(c) != SIMKA_OK) fatal(c, "simka_merge");
+                if (use_rccl) {
+                    if (simka_stats_allreduce_head(c, comm) != SIMKA_OK) fatal(c, "simka_stats_allreduce_head");
+                    if (g == 0 && simka_stats_download(c, flat.data(), nw, nullptr) != SIMKA_OK) fatal(c, "simka_stats_download");
+                    else if (g != 0 && simka_sync(c) != SIMKA_OK) fatal(c, "simka_sync");
+                    continue;
+                }
                 if (simka_stats_download(c, shard.data(), nw, nullptr) != SIMKA_OK) fatal(c, "simka_stats_download");
                 std::lock_guard<std::mutex> lk(acc_lock);          // SimkaStatistics::operator+= over the ranges (imported totals are global)
                 for (uint64_t w = 0; w < lay[5]; w++) flat[w] += shard[w];
                 if (!have_tail) { for (uint64_t w = lay[5]; w < nw; w++) flat[w] = shard[w]; have_tail = true; }
             }
+            if (comm) simka_comm_destroy(comm);
             simka_destroy(c);
         };
         std::vector<std::thread> th;

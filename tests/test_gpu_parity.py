@@ -1098,3 +1098,25 @@ def test_tile_major_pair_kernels_agree_with_the_scan_and_compact_kernel(gpu_requ
     r = subprocess.run([sys.executable, os.path.join(ROOT_DIR, "scripts", "cross_check_tiled.py"), "5", "21"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
                        text=True, timeout=900)
     assert r.returncode == 0 and "tiled cross-check ok" in r.stdout, r.stdout[-3000:]
+
+
+def test_bench_on_two_gpus_over_rccl(gpu_required):
+    """`bench.py --gpus 2` as the driver launches it (no launcher: it spawns its own ranks, one per GPU, RCCL through the C ABI):
+    both decompositions run, report n_gpus = 2 and the distance matrices of the 1-GPU run.  Needs two devices."""
+    import json
+    import subprocess
+    import sys
+    torch = gpu_required
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs >= 2 GPUs")
+    def run(n):
+        r = subprocess.run([sys.executable, os.path.join(ROOT_DIR, "bench.py"), "--gpus", str(n), "--workload", "c2", "--reads", "200000", "--steps", "1",
+                            "--warmup", "1", "--no-cpu-baseline"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
+        assert r.returncode == 0, r.stderr[-2000:]
+        return json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    one, two = run(1), run(2)
+    assert two["n_gpus"] == 2 and one["n_gpus"] == 1
+    assert two["config"]["matrix_checksum"] == one["config"]["matrix_checksum"]
+    assert set(two["decompositions"]) == {"sample", "partition"}
+    assert all(d["matrix_checksum"] == one["config"]["matrix_checksum"] for d in two["decompositions"].values())
+    assert "RCCL" in two["config"]["collectives"]
