@@ -1418,7 +1418,7 @@ SIMKA_EXPORT int simka_merge(simka_ctx *ctx) {
     if (maxpart > cap) return ctx->fail(SIMKA_ERR_NOMEM, "simka_merge: one partition holds %llu records, more than the merge buffer", maxpart);
     const uint64_t max_parts_batch = std::min<uint64_t>(nparts, (uint64_t)1 << 16);
     const uint64_t fb_cap = max_parts_batch * nsub;
-    const uint32_t grid_group = (uint32_t)ctx->num_cus * 3;
+    const uint32_t grid_group = (uint32_t)ctx->num_cus * 4;
     const uint64_t span_cap = fb_cap * 2 + 4096 + (uint64_t)grid_group * K3_SLAB_SPAN;
     const uint64_t csr_cap = cap + (uint64_t)grid_group * K3_SLAB_ENT;     // slab reservation leaves unused tails
     if (ctx->merge_cap < cap) {
@@ -1448,7 +1448,7 @@ SIMKA_EXPORT int simka_merge(simka_ctx *ctx) {
     co.entries = ctx->d_entries; co.groups = ctx->d_groups; co.spans = ctx->d_spans; co.cursors = ctx->d_cursors;
     co.cap_entries = csr_cap; co.cap_groups = csr_cap; co.cap_spans = span_cap; co.span_cap = pc.span_cap; co.huge = ctx->d_huge; co.cap_huge = huge_cap; co.glob = (ull *)ctx->d_stats; co.err = ctx->d_err;
     const uint32_t min_share = 2;   // -complex-dist would need 1 (ref: src/SimkaMerge.cpp:1317)
-    const size_t lds_group = SIMKA_LDS_HEAD + (size_t)K3_TABLE * 8 + (size_t)K3_CAP * 8 + (size_t)K3_TABLE * 8 + (size_t)K3_CAP * 2 + (size_t)K3_STACK * 16;
+    const size_t lds_group = SIMKA_LDS_HEAD + (size_t)K3_TABLE * 8 + (size_t)K3_CAP * 8 + (size_t)K3_TABLE * 6 + (size_t)K3_CAP * 2 + (size_t)K3_STACK * 16;
     ull *acc = (ull *)ctx->d_stats + stats_off_acc(N, 0);
 
     uint64_t pb = 0;
@@ -1468,6 +1468,13 @@ SIMKA_EXPORT int simka_merge(simka_ctx *ctx) {
                 hipLaunchKernelGGL(k_group, dim3(std::min<uint32_t>(nfb, grid_group)), dim3(K3_BLOCK), lds_group, ctx->stream, ctx->d_mkeys, ctx->d_mvals,
                                    ctx->d_fb_off, nfb, (uint32_t)recs, key, min_share, co);
             });
+            if (getenv("SIMKA_DEBUG_MERGE")) {
+                ull cur[4]; HIPCHK(hipMemcpyAsync(cur, ctx->d_cursors, 32, hipMemcpyDeviceToHost, ctx->stream)); HIPCHK(hipStreamSynchronize(ctx->stream));
+                std::vector<SimkaSpan> hs(cur[2]); HIPCHK(hipMemcpy(hs.data(), ctx->d_spans, cur[2] * sizeof(SimkaSpan), hipMemcpyDeviceToHost));
+                ull empty = 0, ent = 0, grp = 0, full = 0; for (auto &sp : hs) { if (!sp.ngrp) empty++; ent += sp.nent; grp += sp.ngrp; if (sp.nent > 3500) full++; }
+                fprintf(stderr, "merge batch: %llu records, span slots %llu (empty %llu, > 3500 entries %llu), entries %llu (slab cursor %llu), groups %llu, entries per real span %.0f\n",
+                        (unsigned long long)recs, cur[2], empty, full, ent, cur[0], grp, (double)ent / std::max<ull>(1, cur[2] - empty));
+            }
             pair_launch(ctx, pl, ctx->d_spans, ctx->d_cursors, ctx->d_entries, ctx->d_groups, N > K3_CAP ? ctx->d_huge : nullptr, acc);
         }
         pb = pe;

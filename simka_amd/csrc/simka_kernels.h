@@ -23,7 +23,7 @@
 #define K3_UNROLL 4           // K3_BLOCK*K3_UNROLL = K3_CAP: a whole sub-range in one batch of independent loads
 #define K3_SLAB_ENT 32768     // CSR entries / groups / span slots reserved per global atomic by a k_group block
 #define K3_SLAB_GRP 16384
-#define K3_SLAB_SPAN 32
+#define K3_SLAB_SPAN 8
 // K4  k_pairs
 #define K4_BLOCK_BIG 1024
 #define K4_BLOCK_SMALL 256

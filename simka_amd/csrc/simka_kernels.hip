@@ -200,8 +200,8 @@ k_group(const ull *mkeys, const ull *mvals, const uint32_t *fb_off, uint32_t nfb
     uint32_t &s_soff = *(uint32_t *)(smem + 356);          // entry offset of this round inside its span
     ull *tkeys = (ull *)(smem + SIMKA_LDS_HEAD);           // [K3_TABLE]
     ull *rval = tkeys + K3_TABLE;                          // [K3_CAP]
-    uint32_t *scnt = (uint32_t *)(rval + K3_CAP);          // [K3_TABLE] group size
-    uint32_t *gpk = scnt + K3_TABLE;                       // [K3_TABLE] packed prefix: entries | groups << 20; later the fill cursor
+    uint16_t *scnt = (uint16_t *)(rval + K3_CAP);          // [K3_TABLE] group size (<= K3_CAP records per round: 16 bits, added through the 32-bit word)
+    uint32_t *gpk = (uint32_t *)(scnt + K3_TABLE);                       // [K3_TABLE] packed prefix: entries | groups << 20; later the fill cursor
     uint16_t *rslot = (uint16_t *)(gpk + K3_TABLE);        // [K3_CAP]
     ull *s_stack = (ull *)(rslot + K3_CAP);                // [2*K3_STACK] (selector bits, value) of the refinement DFS: one level per key bit
 
@@ -234,7 +234,7 @@ k_group(const ull *mkeys, const ull *mvals, const uint32_t *fb_off, uint32_t nfb
                     const ulonglong2 ek = make_ulonglong2(SIMKA_EMPTY_KEY, SIMKA_EMPTY_KEY);
                     const uint4 z = make_uint4(0, 0, 0, 0);
                     for (uint32_t i = tid; i < K3_TABLE / 2; i += K3_BLOCK) k2[i] = ek;
-                    for (uint32_t i = tid; i < K3_TABLE / 4; i += K3_BLOCK) c4[i] = z;
+                    for (uint32_t i = tid; i < K3_TABLE / 8; i += K3_BLOCK) c4[i] = z;
                 }
                 __syncthreads();
                 // ---- hash the records of this (sub-)range; K3_UNROLL independent loads per thread
@@ -261,7 +261,7 @@ k_group(const ull *mkeys, const ull *mvals, const uint32_t *fb_off, uint32_t nfb
                             if (prev == SIMKA_EMPTY_KEY || prev == key) break;
                             slot = (slot + 1u) & (K3_TABLE - 1u);
                         }
-                        atomicAdd(&scnt[slot], 1u);
+                        atomicAdd((uint32_t *)scnt + (slot >> 1), 1u << ((slot & 1u) * 16u));
                         rslot[idx] = (uint16_t)slot;
                         rval[idx] = vv[u];
                         if ((uint32_t)vv[u] > mymax) mymax = (uint32_t)vv[u];
@@ -519,9 +519,15 @@ k_pairs(const SimkaSpan *spans, const ull *cursors, const ull *entries, const ui
     constexpr int EPT = (SIMKA_SPAN_MAX + K4_BLOCK - 1) / K4_BLOCK;     // entries (and group descriptors) per thread
     SimkaSpan span, nspan;
     span.ngrp = 0; span.nent = 0; nspan.ngrp = 0; nspan.nent = 0;
-    ull sp = blockIdx.x;
-    if (sp < nspans) span = spans[sp];
-    if (sp + gridDim.x < nspans) nspan = spans[sp + gridDim.x];
+    // Span slots come in slabs of K3_SLAB_SPAN (one k_group block each; the unused tail of a block's last slab is empty), and the grid
+    // is a multiple of the slab: with slot = row * grid + block every block would always see the SAME position inside the slabs --
+    // the blocks that land on slab heads would get up to twice the real spans of the others.  Row r is rotated by 13 r instead.
+    const ull nrows = (nspans + gridDim.x - 1) / gridDim.x;
+    auto slot_of = [&](ull row) -> ull { return row * gridDim.x + (blockIdx.x + row * 13ull) % gridDim.x; };
+    auto load_span = [&](ull row, SimkaSpan &out) { out.ngrp = 0; out.nent = 0; if (row < nrows) { const ull s_ = slot_of(row); if (s_ < nspans) out = spans[s_]; } };
+    ull row = 0;
+    load_span(0, span);
+    load_span(1, nspan);
     ull pre_e[EPT]; uint32_t pre_g[EPT];
 #pragma unroll
     for (int q = 0; q < EPT; q++) {
@@ -530,7 +536,7 @@ k_pairs(const SimkaSpan *spans, const ull *cursors, const ull *entries, const ui
         pre_g[q] = (i < span.ngrp) ? groups[span.gbase + i] : 0u;
     }
     PP_DECL
-    for (; sp < nspans; sp += gridDim.x) {
+    for (; row < nrows; row++) {
         // ---- current span: registers -> LDS
         PP(0)
         __syncthreads();
@@ -558,8 +564,7 @@ k_pairs(const SimkaSpan *spans, const ull *cursors, const ull *entries, const ui
         }
         // ---- issue the loads of the next span, fetch the descriptor after it
         span = nspan;
-        nspan.ngrp = 0; nspan.nent = 0;
-        if (sp + 2 * (ull)gridDim.x < nspans) nspan = spans[sp + 2 * (ull)gridDim.x];
+        load_span(row + 2, nspan);
 #pragma unroll
         for (int q = 0; q < EPT; q++) {
             const uint32_t i = tid + (uint32_t)q * K4_BLOCK;
