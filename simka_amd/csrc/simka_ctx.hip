@@ -597,6 +597,7 @@ static int run_count_kernels(simka_ctx *ctx, uint32_t sample, const SimkaScanArg
             ull h[16]; HIPCHK(hipMemcpy(h, d_phase, 128, hipMemcpyDeviceToHost)); HIPCHK(hipMemset(d_phase, 0, 128));
             if (h[12]) fprintf(stderr, "k_skm_count_fast counters: per wave and partition %.1f k-mers, %.1f queue entries left after the last batch, %.2f final drain passes\n",
                                (double)h[8] / h[12], (double)h[14] / h[12], (double)h[13] / h[12]);
+            if (h[11]) fprintf(stderr, "k_skm_count_fast blocks: busy time of the slowest block %.0f ticks, mean %.0f (%.1f %% above the mean)\n", (double)h[9], (double)h[10] / h[11], 100.0 * ((double)h[9] * h[11] / h[10] - 1.0));
             ull t_ = 0; for (int i_ = 0; i_ < 8; i_++) t_ += h[i_];
             if (t_) fprintf(stderr, "k_skm_count_fast phases %%: top %.1f map %.1f insert %.1f sync %.1f summary %.1f scan %.1f slab %.1f stores %.1f  (ticks/block %.0f)\n",
                     100.0 * h[0] / t_, 100.0 * h[1] / t_, 100.0 * h[2] / t_, 100.0 * h[3] / t_, 100.0 * h[4] / t_, 100.0 * h[5] / t_, 100.0 * h[6] / t_, 100.0 * h[7] / t_, (double)t_ / (ctx->num_cus * 2));

@@ -50,6 +50,7 @@ typedef unsigned long long ull;
 #define SKM_CNT_BATCH 256        // records expanded per batch
 #define SKM_FAST_BLOCK 256       // k_skm_count_fast: 4 waves, 2048 slots, four blocks per CU
 #define SKM_FAST_TS 2048
+#define SKM_FAST_WCHUNK 8         // partitions a block takes per grab of the work counter
 #ifndef SKM_FAST_U
 #define SKM_FAST_U 2             // k-mers per lane in flight in the insert loop (4: the queue grows and only three blocks fit a CU -- slower)
 #endif
@@ -421,7 +422,7 @@ k_skm_layout(ull *b1_count, ull *b1_start, ull *b1_limit, ull *b1_cursor, uint32
              ull *arena_cursor, ull *sample_base, uint32_t first_pass, const uint32_t *skip_flag, ull *redo_count) {
     __shared__ ull s_cnt[SKM_MAXB1];
     const uint32_t tid = threadIdx.x;
-    if (mode != 2u && tid == 0) *redo_count = 0ull;
+    if (mode != 2u && tid == 0) { redo_count[0] = 0ull; redo_count[1] = 0ull; }      // [1]: the work counter of k_skm_count_fast
     if (mode == 1u) {
         if (tid < B1) { b1_start[tid] = (ull)tid * cap; b1_cursor[tid * SKM_CSTRIDE] = (ull)tid * cap; b1_limit[tid] = (ull)(tid + 1) * cap; }
         if (tid == 0 && first_pass) *sample_base = *arena_cursor;
@@ -798,6 +799,7 @@ k_skm_count_fast(const uint4 *recs, const uint32_t *pstart, const uint32_t *pcnt
     ull bt_dall = 0, bt_D = 0, bt_N = 0, bt_Q = 0, bt_kocc = 0;
     PH_DECL
 #ifdef SIMKA_PHASE_PROF
+    const ull blk_t0 = wall_clock64();
     ull dbg[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #define DBG_ADD(i, v) { if (lane == 0) dbg[(i) - 8] += (ull)(v); }
 #else
@@ -851,7 +853,19 @@ k_skm_count_fast(const uint4 *recs, const uint32_t *pstart, const uint32_t *pcnt
         }
     };
 
-    uint32_t part = blockIdx.x, iter = 0;
+    // Work items = the partitions this shard (or pass) owns, handed out DYNAMICALLY in chunks of SKM_FAST_WCHUNK: chunk blockIdx.x
+    // first, then whatever the global counter says (one word serves ~90 grabs per microsecond: one grab per partition would cap
+    // the kernel at 6 ms per C3 sample, one per 8 partitions costs nothing).  Thread 0 grabs the chunk after next at the first item
+    // of a chunk (a returning global atomic, long back when it is needed) and publishes it in LDS before the summary barrier.
+    const uint32_t sh_c = cfg.shard_count, sh_i = cfg.shard_index;
+    const uint32_t nwork = nparts > sh_i ? (nparts - sh_i + sh_c - 1u) / sh_c : 0u;
+    auto part_of = [&](uint32_t j_) -> uint32_t { return j_ < nwork ? j_ * sh_c + sh_i : 0xffffffffu; };
+    uint32_t *s_next = (uint32_t *)(smem + 96);       // [2] the chunk after next, double-buffered
+    ull *work_counter = redo_count + 1;
+    if (tid == 0) s_next[0] = gridDim.x + (uint32_t)atomicAdd(work_counter, 1ull);
+    uint32_t tog = 0, wpos = 0;                        // wpos: position inside the chunk
+    uint32_t item = blockIdx.x * SKM_FAST_WCHUNK, iter = 0;
+    uint32_t part = part_of(item);
     uint32_t nrec = 0, rbase = 0;
     uint4 pre = make_uint4(0, 0, 0, 0);
     auto prefetch = [&](uint32_t n_, uint32_t rb_) {
@@ -868,10 +882,23 @@ k_skm_count_fast(const uint4 *recs, const uint32_t *pstart, const uint32_t *pcnt
         if (p_ < nparts && lane < 2u) { const uint32_t *src = lane == 0u ? pcnt : pstart; v = src[p_]; }
         return v;
     };
+    uint32_t chunk_n = s_next[0], chunk_n2 = 0;    // (published before the barrier above)
     while (part < nparts) {
-        const uint32_t next = part + gridDim.x;
+        const bool first = wpos == 0u, last = wpos + 1u == SKM_FAST_WCHUNK;
+        const uint32_t item_n = last ? chunk_n * SKM_FAST_WCHUNK : item + 1u;
+        const uint32_t next = part_of(item_n);
         const uint32_t desc_n = load_desc(next);
-        if (nrec == 0) {
+        ull grab = 0;
+        if (first && tid == 0) grab = atomicAdd(work_counter, 1ull);
+        if (nrec == 0) {       // an empty partition (rare among the owned ones)
+            if (first) {       // agree on the chunk after next through LDS right away
+                if (tid == 0) s_next[tog ^ 1u] = gridDim.x + (uint32_t)grab;
+                __syncthreads();
+                tog ^= 1u;
+                chunk_n2 = s_next[tog];
+            }
+            if (last) { chunk_n = chunk_n2; wpos = 0; } else wpos++;
+            item = item_n;
             part = next; nrec = __builtin_amdgcn_readlane(desc_n, 0); rbase = __builtin_amdgcn_readlane(desc_n, 1);
             prefetch(nrec, rbase);
             continue;
@@ -1008,7 +1035,9 @@ k_skm_count_fast(const uint4 *recs, const uint32_t *pstart, const uint32_t *pcnt
         iter++;
         // block-level offsets of the waves (one barrier)
         if (lane == 63u) tmp[par * 16u + wave] = winc;
+        if (first && tid == 0) s_next[tog ^ 1u] = gridDim.x + (uint32_t)grab;
         __syncthreads();
+        if (first) { tog ^= 1u; chunk_n2 = s_next[tog]; }
         uint32_t wpre = 0, total = 0;
 #pragma unroll
         for (uint32_t w = 0; w < NW; w++) { const uint32_t t = tmp[par * 16u + w]; if (w < wave) wpre += t; total += t; }
@@ -1062,11 +1091,14 @@ k_skm_count_fast(const uint4 *recs, const uint32_t *pstart, const uint32_t *pcnt
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // the staging region becomes the wave's retry queue again
         PH(7)
+        if (last) { chunk_n = chunk_n2; wpos = 0; } else wpos++;
+        item = item_n;
         part = next; nrec = nrec_n; rbase = rbase_n;
     }
     PH_FLUSH
 #ifdef SIMKA_PHASE_PROF
-    if (lane == 0 && o.phase) for (int i_ = 0; i_ < 8; i_++) atomicAdd(&o.phase[8 + i_], dbg[i_]);
+    if (lane == 0 && o.phase) for (int i_ = 0; i_ < 8; i_++) if (i_ < 1 || i_ > 3) atomicAdd(&o.phase[8 + i_], dbg[i_]);
+    if (tid == 0 && o.phase) { const ull el = wall_clock64() - blk_t0; atomicMax(&o.phase[9], el); atomicAdd(&o.phase[10], el); atomicAdd(&o.phase[11], 1ull); }
 #endif
     if (o.hist) {
         __syncthreads();
