@@ -72,6 +72,7 @@ struct simka_ctx {
     uint32_t *d_err = nullptr;
     // merge buffers
     ull *d_part_total = nullptr, *d_part_off = nullptr;
+    ull *d_work = nullptr;                                    // [2] work counters of the persistent merge-side kernels (zeroed before a launch)
     ull *d_mkeys = nullptr, *d_mvals = nullptr, *d_entries = nullptr; uint32_t *d_groups = nullptr;
     uint32_t *d_fb_off = nullptr; SimkaSpan *d_spans = nullptr; ull *d_cursors = nullptr; SimkaSpan *d_huge = nullptr;
     uint64_t merge_cap = 0, fb_cap = 0, span_cap = 0, huge_cap = 0;
@@ -391,6 +392,7 @@ SIMKA_EXPORT int simka_create(const simka_config *cfg, simka_ctx **out) {
     if (!chk(hipMemsetAsync(ctx->d_arena_cursor, 0, 16, ctx->stream), "memset(cursor)")) return bail(SIMKA_ERR_HIP);
     if (!chk(dev_alloc(&ctx->d_sample_base, N + 1), "hipMalloc(sample_base)")) return bail(SIMKA_ERR_NOMEM);
     if (!chk(dev_alloc(&ctx->d_cursors, 4), "hipMalloc(cursors)")) return bail(SIMKA_ERR_NOMEM);
+    if (!chk(dev_alloc(&ctx->d_work, 2), "hipMalloc(work)")) return bail(SIMKA_ERR_NOMEM);
     if (cfg->dist_flags & SIMKA_DIST_COMPLEX) {
         ctx->ovf_cap = getenv("SIMKA_OVF_CAP") ? (uint64_t)atoll(getenv("SIMKA_OVF_CAP")) : (uint64_t)1 << 22;      // (tests shrink it)
         if (!chk(dev_alloc(&ctx->d_hist, (uint64_t)N * SIMKA_HIST_MAX), "hipMalloc(hist)")) return bail(SIMKA_ERR_NOMEM);
@@ -426,7 +428,7 @@ SIMKA_EXPORT void simka_destroy(simka_ctx *ctx) {
     for (uint32_t li = 0; li < simka_ctx::MAX_LANES; li++) { if (ctx->d_reads[li]) (void)hipFree(ctx->d_reads[li]); if (ctx->d_offsets[li]) (void)hipFree(ctx->d_offsets[li]); }
     void *ptrs[] = { ctx->d_l1_ovf, ctx->d_solid_keys, ctx->d_solid_counts, ctx->d_arena_cursor,
                      ctx->d_sample_base, ctx->d_foff, ctx->d_fcnt, ctx->d_stats, ctx->d_err, ctx->d_part_total,
-                     ctx->d_part_off, ctx->d_mkeys, ctx->d_mvals, ctx->d_entries, ctx->d_groups, ctx->d_fb_off,
+                     ctx->d_part_off, ctx->d_work, ctx->d_mkeys, ctx->d_mvals, ctx->d_entries, ctx->d_groups, ctx->d_fb_off,
                      ctx->d_spans, ctx->d_cursors, ctx->d_huge, ctx->d_xoff, ctx->d_hist, ctx->d_ovf_list, ctx->d_ovf_cursor,
                      ctx->d_tm_ent, ctx->d_tm_p, ctx->d_tm_off };
     for (void *p : ptrs) if (p) (void)hipFree(p);
@@ -1261,11 +1263,13 @@ static void pair_launch(simka_ctx *ctx, const PairLaunch &pl, const SimkaSpan *s
                          (!cplx || tm_reserve(ctx, &ctx->d_tm_p, &ctx->tm_p_cap, nb_entries + 16)) &&
                          tm_reserve(ctx, &ctx->d_tm_off, &ctx->tm_off_cap, nb_spans * (uint64_t)(pc.ntiles + 1) + 16);
     }
+    ull *work = (have_spans && pl.ntp == 1 && (pl.small_block || pc.ntiles == 1)) ? ctx->d_work : nullptr;      // one tile: spans handed out dynamically
+    if (work && hipMemsetAsync(work, 0, 8, ctx->stream) != hipSuccess) work = nullptr;
     if (have_spans) launch_timed(ctx, KID_PAIRS, [&] {
         if (pl.small_block)
-            hipLaunchKernelGGL((k_pairs<false, K4_BLOCK_SMALL>), dim3(pl.nblk, pl.ntp), dim3(K4_BLOCK_SMALL), pl.lds_pairs, ctx->stream, spans, cursors, entries, groups, pc, acc);
+            hipLaunchKernelGGL((k_pairs<false, K4_BLOCK_SMALL>), dim3(pl.nblk, pl.ntp), dim3(K4_BLOCK_SMALL), pl.lds_pairs, ctx->stream, spans, cursors, entries, groups, pc, acc, work);
         else if (pc.ntiles == 1)
-            hipLaunchKernelGGL((k_pairs<false, K4_BLOCK_BIG>), dim3(pl.nblk, pl.ntp), dim3(K4_BLOCK_BIG), pl.lds_pairs, ctx->stream, spans, cursors, entries, groups, pc, acc);
+            hipLaunchKernelGGL((k_pairs<false, K4_BLOCK_BIG>), dim3(pl.nblk, pl.ntp), dim3(K4_BLOCK_BIG), pl.lds_pairs, ctx->stream, spans, cursors, entries, groups, pc, acc, work);
         else if (tile_major) {
             const uint32_t grid_tm = (uint32_t)std::min<uint64_t>((nb_spans + KTM_WAVES - 1) / KTM_WAVES, (uint64_t)ctx->num_cus * 4);
             hipLaunchKernelGGL(k_tile_major, dim3(grid_tm), dim3(64 * KTM_WAVES), 0, ctx->stream, spans, cursors, entries, groups, pc, ctx->d_tm_ent, ctx->d_tm_p, ctx->d_tm_off);
@@ -1276,7 +1280,7 @@ static void pair_launch(simka_ctx *ctx, const PairLaunch &pl, const SimkaSpan *s
             // the spans were built for pc.span_cap entries, which its tile geometry keeps)
             PairLaunch lg = pl;
             if (tile_major_enabled()) pair_setup(ctx, lg, true, pl.pc.span_cap);
-            hipLaunchKernelGGL((k_pairs<true, K4_BLOCK_BIG>), dim3(lg.nblk, lg.ntp), dim3(K4_BLOCK_BIG), lg.lds_pairs, ctx->stream, spans, cursors, entries, groups, lg.pc, acc);
+            hipLaunchKernelGGL((k_pairs<true, K4_BLOCK_BIG>), dim3(lg.nblk, lg.ntp), dim3(K4_BLOCK_BIG), lg.lds_pairs, ctx->stream, spans, cursors, entries, groups, lg.pc, acc, (ull *)nullptr);
         }
     });
 #ifdef SIMKA_PHASE_PROF

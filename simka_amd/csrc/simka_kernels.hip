@@ -470,7 +470,7 @@ __device__ ull g_pairs_phase[8];
 template <bool TILED, int K4_BLOCK>
 __global__ void __launch_bounds__(K4_BLOCK)
 k_pairs(const SimkaSpan *spans, const ull *cursors, const ull *entries, const uint32_t *groups, SimkaPairCfg pc,
-        ull *acc) {
+        ull *acc, ull *work) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const uint32_t CP = pc.ncell_pad, npk = pc.nacc32 >> 1;
     const bool cplx = pc.nacc64 != 0;
@@ -519,13 +519,34 @@ k_pairs(const SimkaSpan *spans, const ull *cursors, const ull *entries, const ui
     constexpr int EPT = (SIMKA_SPAN_MAX + K4_BLOCK - 1) / K4_BLOCK;     // entries (and group descriptors) per thread
     SimkaSpan span, nspan;
     span.ngrp = 0; span.nent = 0; nspan.ngrp = 0; nspan.nent = 0;
-    // Span slots come in slabs of K3_SLAB_SPAN (one k_group block each; the unused tail of a block's last slab is empty), and the grid
-    // is a multiple of the slab: with slot = row * grid + block every block would always see the SAME position inside the slabs --
-    // the blocks that land on slab heads would get up to twice the real spans of the others.  Row r is rotated by 13 r instead.
+    // Which span slots a block takes.  work != NULL (one tile: grid.y == 1): DYNAMIC -- chunks of KP_WCHUNK consecutive slots, chunk
+    // blockIdx.x first, then whatever the global counter says (thread 0 grabs the chunk after next at the first slot of a chunk and
+    // publishes it in LDS at the next loop-top barrier), so a block that drew expensive spans does not hold the launch back.
+    // work == NULL (tile pairs: every block row walks all spans): static rows.  Span slots come in slabs of K3_SLAB_SPAN (one
+    // k_group block each; the unused tail of a block's last slab is empty) and the grid is a multiple of the slab: with
+    // slot = row * grid + block every block would always see the SAME position inside the slabs -- the blocks that land on slab
+    // heads would get up to twice the real spans of the others.  Row r is rotated by 13 r instead.
+    constexpr uint32_t KP_WCHUNK = 4;
+    const bool dyn = work != nullptr;
+    uint32_t *s_nextc = (uint32_t *)smem;            // [2] (dyn) the chunk after next, double-buffered
     const ull nrows = (nspans + gridDim.x - 1) / gridDim.x;
-    auto slot_of = [&](ull row) -> ull { return row * gridDim.x + (blockIdx.x + row * 13ull) % gridDim.x; };
-    auto load_span = [&](ull row, SimkaSpan &out) { out.ngrp = 0; out.nent = 0; if (row < nrows) { const ull s_ = slot_of(row); if (s_ < nspans) out = spans[s_]; } };
-    ull row = 0;
+    ull row = 0;                                     // static: the row; dynamic: unused
+    ull chunk = blockIdx.x, chunk_n = 0, chunk_n2 = 0, grab = 0;
+    uint32_t kpos = 0, tog = 0;
+    if (dyn) {
+        if (tid == 0) s_nextc[0] = gridDim.x + (uint32_t)atomicAdd(work, 1ull);
+        __syncthreads();
+        chunk_n = s_nextc[0];
+    }
+    // slot of the span d iterations ahead (d <= 2 < KP_WCHUNK), ~0: none
+    auto slot_ahead = [&](uint32_t d) -> ull {
+        ull s_;
+        if (dyn) { const uint32_t pos = kpos + d; s_ = (pos < KP_WCHUNK ? chunk : chunk_n) * KP_WCHUNK + (pos % KP_WCHUNK); }
+        else { if (row + d >= nrows) return ~0ull; s_ = (row + d) * gridDim.x + (blockIdx.x + (row + d) * 13ull) % gridDim.x; }
+        return s_ < nspans ? s_ : ~0ull;
+    };
+    auto load_span = [&](uint32_t d, SimkaSpan &out) { out.ngrp = 0; out.nent = 0; const ull s_ = slot_ahead(d); if (s_ != ~0ull) out = spans[s_]; };
+    auto more = [&]() -> bool { return dyn ? chunk * KP_WCHUNK < nspans : row < nrows; };
     load_span(0, span);
     load_span(1, nspan);
     ull pre_e[EPT]; uint32_t pre_g[EPT];
@@ -536,10 +557,13 @@ k_pairs(const SimkaSpan *spans, const ull *cursors, const ull *entries, const ui
         pre_g[q] = (i < span.ngrp) ? groups[span.gbase + i] : 0u;
     }
     PP_DECL
-    for (; row < nrows; row++) {
+    for (; more(); ) {
         // ---- current span: registers -> LDS
         PP(0)
+        if (dyn && kpos == 1u && tid == 0) s_nextc[tog ^ 1u] = gridDim.x + (uint32_t)grab;
         __syncthreads();
+        if (dyn && kpos == 1u) { tog ^= 1u; chunk_n2 = s_nextc[tog]; }
+        if (dyn && kpos == 0u && tid == 0) grab = atomicAdd(work, 1ull);
         const SimkaSpan cur = span;
 #pragma unroll
         for (int q = 0; q < EPT; q++) {
@@ -564,7 +588,9 @@ k_pairs(const SimkaSpan *spans, const ull *cursors, const ull *entries, const ui
         }
         // ---- issue the loads of the next span, fetch the descriptor after it
         span = nspan;
-        load_span(row + 2, nspan);
+        load_span(2, nspan);
+        // (the position moves on here: every `continue` below goes straight to the next span)
+        if (dyn) { if (++kpos == KP_WCHUNK) { chunk = chunk_n; chunk_n = chunk_n2; kpos = 0; } } else row++;
 #pragma unroll
         for (int q = 0; q < EPT; q++) {
             const uint32_t i = tid + (uint32_t)q * K4_BLOCK;
