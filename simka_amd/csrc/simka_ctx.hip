@@ -573,6 +573,12 @@ static int run_count_kernels(simka_ctx *ctx, uint32_t sample, const SimkaScanArg
         scan(false, (const ull *)L.d_b1_end);
     }
     if (rec_cap >= 0xffffffffull) return ctx->fail(SIMKA_ERR_OVERFLOW, "a sample needs more than 2^32 super-k-mer record slots in one pass");
+    if (getenv("SIMKA_DEBUG_MERGE")) {
+        std::vector<ull> cnt(B1);
+        HIPCHK(hipMemcpyAsync(cnt.data(), L.d_b1_count, (size_t)B1 * 8, hipMemcpyDeviceToHost, st)); HIPCHK(hipStreamSynchronize(st));
+        ull mx = 0, sum = 0; for (ull c : cnt) { mx = std::max(mx, c); sum += c; }
+        fprintf(stderr, "level-1 buckets: %u, records %llu, largest bucket %.1f %% above the mean\n", B1, sum, 100.0 * ((double)mx * B1 / std::max<ull>(1, sum) - 1.0));
+    }
     launch_timed(ctx, KID_SKM_SPLIT, [&] {
         const size_t lds_split = ((size_t)1 << sk.l2) * 4 + 64 + ((size_t)1 << sk.l2) * 2 + 16 + (size_t)SKM_SPLIT_BLOCK * SKM_SPLIT_UNROLL * 16;
         hipLaunchKernelGGL(k_skm_split, dim3(B1), dim3(SKM_SPLIT_BLOCK), lds_split, st, (const uint4 *)L.d_skm_a, (const uint32_t *)L.d_skm_p, (const ull *)L.d_b1_start, (const ull *)L.d_b1_count, sk,
