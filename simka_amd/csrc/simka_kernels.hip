@@ -404,11 +404,13 @@ __device__ __forceinline__ void tri_unrank(uint32_t idx, uint32_t s, uint32_t &x
 // floor(sqrt(x)) for the Hellinger term: 32-bit fast path, exact
 __device__ __forceinline__ uint32_t pair_isqrt(ull x) {
     if (x >> 32) return (uint32_t)simka_isqrt(x);
+    // float sqrt of a 32-bit value is within 1 of the floor: two branch-free corrections (r <= 65535, so r * r fits 32 bits;
+    // (r + 1)^2 is compared in 64 bits only through its carry-free form r * r + 2 r + 1 <= v  <=>  2 r < v - r * r)
     const uint32_t v = (uint32_t)x;
     uint32_t r = (uint32_t)__fsqrt_rn((float)v);
-    if (r > 65535u) r = 65535u;
-    if (r * r > v) r--;
-    else if (r < 65535u && (r + 1u) * (r + 1u) <= v) r++;
+    r = r > 65535u ? 65535u : r;
+    r -= (r * r > v) ? 1u : 0u;
+    r += (2u * r < v - r * r) ? 1u : 0u;
     return r;
 }
 
