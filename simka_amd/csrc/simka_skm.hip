@@ -69,6 +69,7 @@ struct SimkaSkmCfg {
 };
 
 SIMKA_HD uint32_t skm_mm_hash(uint32_t c, uint32_t mmask, uint32_t m) {
+    // (two multiplies: with one -- 6 % off the VALU-bound scan -- the partitions get uneven enough to cost the count kernel 4 %)
     uint32_t h = (c * 0x9E3779B1u) & mmask;
     h ^= h >> m;
     return (h * 0x85EBCA6Bu) & mmask;
@@ -115,7 +116,7 @@ k_skm_scan(SimkaScanArgs a, SimkaSkmCfg cfg, ull *b1_count, ull *b1_cursor, uint
     uint32_t *hm = (uint32_t *)(smem + SIMKA_LDS_HEAD);             // [4][SKM_NT][4]
     uint4 *stage = (uint4 *)hm;                                     // [caprec] (!HIST)
     uint16_t *slist = (uint16_t *)(stage + (HIST ? 0u : caprec));   // [lcap] entry indices of the run starts
-    uint32_t *spid = (uint32_t *)(slist + ((lcap + 1u) & ~1u));     // [lcap]
+    uint32_t *spid = (uint32_t *)(slist + ((lcap + 1u) & ~1u));     // [lcap] their minimizer values
     uint32_t *tb = (uint32_t *)(smem + SIMKA_LDS_HEAD + rbytes);    // [TILE/16 + 8] the tile's bases, 16 per word
     uint32_t *smask = tb + SKM_TILE / 16 + 8;                       // [BLOCK] start | brk << 16
     uint32_t *hist = smask + SKM_BLOCK + 4;                         // [B1]   (smask has 4 pad words: all-break)
@@ -286,7 +287,7 @@ k_skm_scan(SimkaScanArgs a, SimkaSkmCfg cfg, ull *b1_count, ull *b1_cursor, uint
         if (ns && p + ns <= lcap) {
 #pragma unroll
             for (int j = 1; j <= SKM_SEG; j++)
-                if ((start >> (j - 1)) & 1u) { slist[p] = (uint16_t)(SKM_SEG * tid + (uint32_t)(j - 1)); spid[p] = skm_pid(mh[j], cfg.pb); p++; }
+                if ((start >> (j - 1)) & 1u) { slist[p] = (uint16_t)(SKM_SEG * tid + (uint32_t)(j - 1)); spid[p] = mh[j]; p++; }      // (the minimizer value: its partition id is one multiply per START, not per entry)
         }
     }
     __syncthreads();
@@ -315,7 +316,7 @@ k_skm_scan(SimkaScanArgs a, SimkaSkmCfg cfg, ull *b1_count, ull *b1_cursor, uint
     auto for_runs = [&](auto &&f) {
         if (listed) {
             for (uint32_t si = tid; si < nstart; si += SKM_BLOCK) {
-                const uint32_t e = slist[si], pid = spid[si];
+                const uint32_t e = slist[si], pid = skm_pid(spid[si], cfg.pb);
                 if (skm_owns(pid, cfg)) f(e, len_of(e), pid);
             }
         } else if (owner) {
