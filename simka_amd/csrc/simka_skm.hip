@@ -214,7 +214,19 @@ k_skm_scan(SimkaScanArgs a, SimkaSkmCfg cfg, ull *b1_count, ull *b1_cursor, uint
         const uint32_t k = cfg.k;
         if (FIXED) {
             const uint32_t L = a.fixed_len;
-            uint32_t rel = P0 >= 0 ? (uint32_t)((uint64_t)P0 % L) : (L - (uint32_t)((uint64_t)(-P0) % L)) % L;     // offset of e_0 inside its read
+            // offset of e_0 inside its read: the tile's first position modulo L is wave-uniform (one 64-bit modulo on the scalar unit),
+            // the thread's share 16 tid - 1 + L (< 2^14 + 2 L) is reduced with a float reciprocal and 24-bit multiplies -- a 64-bit modulo
+            // per thread cost a dozen quarter-rate multiplies in a VALU-bound kernel
+            const uint32_t relb = (uint32_t)__builtin_amdgcn_readfirstlane((int)(Q0 >= 0 ? (uint32_t)((uint64_t)Q0 % L) : (L - (uint32_t)((uint64_t)(-Q0) % L)) % L));
+            uint32_t rel;
+            if (L < (1u << 23)) {
+                const uint32_t x = relb + SKM_SEG * tid + (L - 1u);                 // Q0 % L + 16 tid - 1 + L  >= 0, < 2 L + 2^13
+                uint32_t q_ = (uint32_t)((float)x * (1.0f / (float)L));
+                uint32_t r_ = x - __umul24(q_, L);
+                if ((int32_t)r_ < 0) r_ += L;                                       // the quotient estimate is off by at most one
+                if (r_ >= L) r_ -= L;
+                rel = r_;
+            } else rel = (uint32_t)(((uint64_t)relb + SKM_SEG * tid + (L - 1u)) % L);
 #pragma unroll
             for (int j = 0; j <= SKM_SEG; j++) {
                 const long long P = P0 + j;
@@ -330,7 +342,7 @@ k_skm_scan(SimkaScanArgs a, SimkaSkmCfg cfg, ull *b1_count, ull *b1_cursor, uint
         }
     };
     // ---- phase 3c: records per level-1 bucket
-    for_runs([&](uint32_t, uint32_t len, uint32_t pid) { atomicAdd(&hist[cfg.pb ? pid >> (cfg.pb - cfg.l1) : 0u], (len + cfg.nmax - 1u) / cfg.nmax); });
+    for_runs([&](uint32_t, uint32_t len, uint32_t pid) { atomicAdd(&hist[cfg.pb ? pid >> (cfg.pb - cfg.l1) : 0u], 1u + (len > cfg.nmax ? 1u : 0u) + (len > 2u * cfg.nmax ? 1u : 0u) + (len > 3u * cfg.nmax ? (len - 1u) / cfg.nmax - 2u : 0u)); });       // = ceil(len / nmax), len <= 48: no division on the common path
     __syncthreads();               // (C)
     if (HIST) {
         if (tid < B1 && hist[tid]) atomicAdd(&b1_count[tid], (ull)hist[tid]);
