@@ -10,12 +10,11 @@
 //           groups of >= 2 samples (the gate, ref: :1307-1326)  ->  the same CSR (entries / groups / spans) the hash
 //           merge builds, consumed by the same k_pairs kernel.
 //
-// The radix sorts and prefix sums are rocPRIM/hipCUB library calls (plain primitives); everything else is hand-written.
+// The radix sorts and prefix sums are hand-written too (simka_sort.hip: LSD radix sort, 8 bits per pass, wave-match ranking).
 // Much slower than the hash pipeline (C2: ~100 ms against 12 ms per step; every base position goes through two 64-bit radix
 // sorts), exact, and an independent cross-check of it: with SIMKA_SORT_PATH=1 the k <= 31 tests run through this path and
 // must give bit-identical statistics (they do: goldens included).
 #include <hip/hip_runtime.h>
-#include <hipcub/hipcub.hpp>
 #include <stdint.h>
 #include <algorithm>
 #include <string>
@@ -23,6 +22,7 @@
 
 #include "simka_kernels.h"
 #include "simka_wide.h"
+#include "simka_sort.hip"
 
 typedef unsigned long long ull;
 
@@ -301,21 +301,24 @@ k_wgdesc(uint32_t nkept, const uint32_t *ge, const uint32_t *gs, const uint32_t 
 // --------------------------------------------------------------------------------------------
 static inline dim3 grid_for(uint64_t n) { return dim3((uint32_t)((n + 255) / 256)); }
 
+
+// exclusive prefix sum of n 32-bit values (in -> out, may alias) with scratch slot 11
+static int wide_scan(SimkaWide *w, const uint32_t *in, uint32_t *out, uint64_t n) {
+    if (n == 0) return 0;
+    uint32_t *tmp; int rc = wide_buf(w, 11, wscan_tmp_u32(n), &tmp); if (rc) return rc;
+    WCHK(wscan_u32(in, out, n, tmp, w->stream));
+    return 0;
+}
+
 // stable sort of n (hi, lo) keys (+ optional 32-bit payload) by (hi, lo): LSD, lo first.  In: hi0/lo0(/p0); out: hi1/lo1(/p1).
 static int wide_sort(SimkaWide *w, uint64_t n, uint32_t hi_bits, ull *hi0, ull *lo0, ull *hi1, ull *lo1, ull *tmp_key, uint32_t *idx0, uint32_t *idx1) {
     if (n == 0) return 0;
     if (n >= ((uint64_t)1 << 31)) { w->err = "wide-k path: more than 2^31 k-mers in one sort (sample too deep for k >= 32)"; return SIMKA_WIDE_ERR_LIMIT; }
-    size_t tb = 0, tb2 = 0;
-    WCHK(hipcub::DeviceRadixSort::SortPairs(nullptr, tb, lo0, tmp_key, idx0, idx1, (int)n, 0, 64, w->stream));
-    WCHK(hipcub::DeviceRadixSort::SortPairs(nullptr, tb2, hi0, hi1, idx0, idx1, (int)n, 0, (int)hi_bits, w->stream));
-    char *tmp; int rc = wide_buf(w, 11, std::max(tb, tb2), &tmp); if (rc) return rc;
+    char *tmp; int rc = wide_buf(w, 11, wsort_tmp_bytes<uint32_t>(n), &tmp); if (rc) return rc;
     hipLaunchKernelGGL(k_wiota, grid_for(n), dim3(256), 0, w->stream, idx0, n);
-    tb = std::max(tb, tb2);
-    size_t t1 = tb;
-    WCHK(hipcub::DeviceRadixSort::SortPairs(tmp, t1, lo0, tmp_key, idx0, idx1, (int)n, 0, 64, w->stream));          // by lo; idx1 = permutation
+    WCHK(wsort_pairs<uint32_t>(lo0, tmp_key, idx0, idx1, n, 64u, tmp, w->stream));                                   // by lo; idx1 = permutation
     hipLaunchKernelGGL(k_wgather, grid_for(n), dim3(256), 0, w->stream, hi0, idx1, lo1, n);                          // lo1 := hi in lo-order (scratch use)
-    t1 = tb;
-    WCHK(hipcub::DeviceRadixSort::SortPairs(tmp, t1, lo1, hi1, idx1, idx0, (int)n, 0, (int)hi_bits, w->stream));    // by hi (stable); idx0 = final permutation
+    WCHK(wsort_pairs<uint32_t>(lo1, hi1, idx1, idx0, n, hi_bits, tmp, w->stream));                                   // by hi (stable); idx0 = final permutation
     hipLaunchKernelGGL(k_wgather, grid_for(n), dim3(256), 0, w->stream, lo0, idx0, lo1, n);
     WCHK(hipGetLastError());
     return 0;
@@ -327,16 +330,10 @@ static int wide_sort_words(SimkaWide *w, uint64_t n, uint32_t hi_bits, ull *hi0,
     if (n == 0) return 0;
     if (n >= ((uint64_t)1 << 31)) { w->err = "wide-k path: more than 2^31 k-mers in one sort (sample too deep for k >= 32)"; return SIMKA_WIDE_ERR_LIMIT; }
     const int lo_bits = (int)std::min<uint32_t>(64u, w->W);
-    size_t tb = 0, tb2 = 0;
-    WCHK(hipcub::DeviceRadixSort::SortPairs(nullptr, tb, lo0, lo1, hi0, hi1, (int)n, 0, lo_bits, w->stream));
-    if (hi_bits) WCHK(hipcub::DeviceRadixSort::SortPairs(nullptr, tb2, hi1, hi0, lo1, lo0, (int)n, 0, (int)hi_bits, w->stream));
-    tb = std::max(tb, tb2);
-    char *tmp; int rc = wide_buf(w, 11, tb, &tmp); if (rc) return rc;
-    size_t t1 = tb;
-    WCHK(hipcub::DeviceRadixSort::SortPairs(tmp, t1, lo0, lo1, hi0, hi1, (int)n, 0, lo_bits, w->stream));         // by lo: (lo1, hi1)
-    if (!hi_bits) return 0;                                                                                       // k <= 32: done, result in hi1 / lo1
-    t1 = tb;
-    WCHK(hipcub::DeviceRadixSort::SortPairs(tmp, t1, hi1, hi0, lo1, lo0, (int)n, 0, (int)hi_bits, w->stream));    // by hi, stable: (hi0, lo0)
+    char *tmp; int rc = wide_buf(w, 11, wsort_tmp_bytes<ull>(n), &tmp); if (rc) return rc;
+    WCHK(wsort_pairs<ull>(lo0, lo1, hi0, hi1, n, (uint32_t)lo_bits, tmp, w->stream));         // by lo: (lo1, hi1)
+    if (!hi_bits) return 0;                                                                       // k <= 32: done, result in hi1 / lo1
+    WCHK(wsort_pairs<ull>(hi1, hi0, lo1, lo0, n, hi_bits, tmp, w->stream));                   // by hi, stable: (hi0, lo0)
     return 0;
 }
 
@@ -414,10 +411,7 @@ int simka_wide_count_sample(SimkaWide *w, uint32_t sample, const void *packed, u
     uint32_t *flag = idx0, *rank = idx1, *start, *sflag, *srank;
     if ((rc = wide_buf(w, 8, nvalid + 2, &start)) || (rc = wide_buf(w, 9, nvalid + 2, &sflag)) || (rc = wide_buf(w, 10, nvalid + 2, &srank))) return rc;
     hipLaunchKernelGGL(k_wheads, grid_for(nvalid), dim3(256), 0, w->stream, hi1, lo1, nvalid, flag);
-    size_t tb = 0;
-    WCHK(hipcub::DeviceScan::ExclusiveSum(nullptr, tb, flag, rank, (int)nvalid, w->stream));
-    char *tmp; if ((rc = wide_buf(w, 11, tb, &tmp))) return rc;
-    WCHK(hipcub::DeviceScan::ExclusiveSum(tmp, tb, flag, rank, (int)nvalid, w->stream));
+    if ((rc = wide_scan(w, flag, rank, nvalid))) return rc;
     hipLaunchKernelGGL(k_wstarts, grid_for(nvalid), dim3(256), 0, w->stream, flag, rank, nvalid, start, (const uint32_t *)nullptr);
     uint32_t last_rank = 0, last_flag = 0;
     WCHK(hipMemcpyAsync(&last_rank, rank + (nvalid - 1), 4, hipMemcpyDeviceToHost, w->stream));
@@ -427,10 +421,7 @@ int simka_wide_count_sample(SimkaWide *w, uint32_t sample, const void *packed, u
     totals5[SIMKA_TOT_DALL] = nruns;
     hipLaunchKernelGGL(k_wfilter, dim3((uint32_t)std::min<uint64_t>((nruns + 255) / 256, 2048)), dim3(256), 0, w->stream, start, nruns, amin, amax, sflag, d_small + 1, (ull *)d_hist_row, (uint32_t *)d_ovf_list,
                        (ull *)d_ovf_cursor, (ull)ovf_cap, sample);
-    tb = 0;
-    WCHK(hipcub::DeviceScan::ExclusiveSum(nullptr, tb, sflag, srank, (int)nruns, w->stream));
-    if ((rc = wide_buf(w, 11, tb, &tmp))) return rc;
-    WCHK(hipcub::DeviceScan::ExclusiveSum(tmp, tb, sflag, srank, (int)nruns, w->stream));
+    if ((rc = wide_scan(w, sflag, srank, nruns))) return rc;
     ull dnq[3]; uint32_t lr = 0, lf = 0;
     WCHK(hipMemcpyAsync(dnq, d_small + 1, 24, hipMemcpyDeviceToHost, w->stream));
     WCHK(hipMemcpyAsync(&lr, srank + (nruns - 1), 4, hipMemcpyDeviceToHost, w->stream));
@@ -466,10 +457,7 @@ int simka_wide_merge(SimkaWide *w, uint32_t span_cap, SimkaWideCsr *out) {
     uint32_t *flag = idx0, *rank = idx1, *gstart, *kflag, *ksize, *krank, *eoff;
     if ((rc = wide_buf(w, 7, M + 2, &gstart)) || (rc = wide_buf(w, 8, M + 2, &kflag)) || (rc = wide_buf(w, 9, M + 2, &ksize))) return rc;
     hipLaunchKernelGGL(k_wheads, grid_for(M), dim3(256), 0, w->stream, hi1, lo1, M, flag);
-    size_t tb = 0;
-    WCHK(hipcub::DeviceScan::ExclusiveSum(nullptr, tb, flag, rank, (int)M, w->stream));
-    char *tmp; if ((rc = wide_buf(w, 11, tb, &tmp))) return rc;
-    WCHK(hipcub::DeviceScan::ExclusiveSum(tmp, tb, flag, rank, (int)M, w->stream));
+    if ((rc = wide_scan(w, flag, rank, M))) return rc;
     hipLaunchKernelGGL(k_wstarts, grid_for(M), dim3(256), 0, w->stream, flag, rank, M, gstart, (const uint32_t *)nullptr);
     uint32_t lr = 0, lf = 0;
     WCHK(hipMemcpyAsync(&lr, rank + (M - 1), 4, hipMemcpyDeviceToHost, w->stream));
@@ -481,11 +469,8 @@ int simka_wide_merge(SimkaWide *w, uint32_t span_cap, SimkaWideCsr *out) {
     krank = idx0; eoff = idx1;
     auto scan_class = [&](uint32_t huge, uint32_t &count, uint64_t &nentries) -> int {
         hipLaunchKernelGGL(k_wgsizes, grid_for(ngroups), dim3(256), 0, w->stream, gstart, ngroups, maxg, huge, kflag, ksize);
-        size_t tb2 = 0;
-        WCHK(hipcub::DeviceScan::ExclusiveSum(nullptr, tb2, kflag, krank, (int)ngroups, w->stream));
-        char *tmp2; int r2 = wide_buf(w, 11, tb2, &tmp2); if (r2) return r2;
-        WCHK(hipcub::DeviceScan::ExclusiveSum(tmp2, tb2, kflag, krank, (int)ngroups, w->stream));
-        WCHK(hipcub::DeviceScan::ExclusiveSum(tmp2, tb2, ksize, eoff, (int)ngroups, w->stream));
+        int r2;
+        if ((r2 = wide_scan(w, kflag, krank, ngroups)) || (r2 = wide_scan(w, ksize, eoff, ngroups))) return r2;
         uint32_t a4[4] = { 0, 0, 0, 0 };
         WCHK(hipMemcpyAsync(&a4[0], krank + (ngroups - 1), 4, hipMemcpyDeviceToHost, w->stream));
         WCHK(hipMemcpyAsync(&a4[1], kflag + (ngroups - 1), 4, hipMemcpyDeviceToHost, w->stream));
