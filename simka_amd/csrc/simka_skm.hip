@@ -875,9 +875,13 @@ k_skm_count_fast(const uint4 *recs, const uint32_t *pstart, const uint32_t *pcnt
     auto part_of = [&](uint32_t j_) -> uint32_t { return j_ < nwork ? j_ * sh_c + sh_i : 0xffffffffu; };
     uint32_t *s_next = (uint32_t *)(smem + 96);       // [2] the chunk after next, double-buffered
     ull *work_counter = redo_count + 1;
-    if (tid == 0) s_next[0] = gridDim.x + (uint32_t)atomicAdd(work_counter, 1ull);
+    // (a handful of partitions per block -- small samples: nothing to balance, static stride without any atomic)
+    const bool dyn = nwork >= gridDim.x * 16u;
+    if (dyn && tid == 0) s_next[0] = gridDim.x + (uint32_t)atomicAdd(work_counter, 1ull);
     uint32_t tog = 0, wpos = 0;                        // wpos: position inside the chunk
-    uint32_t item = blockIdx.x * SKM_FAST_WCHUNK, iter = 0;
+    // (few partitions per block -- small samples: smaller chunks, down to one partition per grab)
+    const uint32_t wchunk = dyn ? min((uint32_t)SKM_FAST_WCHUNK, max(1u, nwork / (gridDim.x * 4u))) : 1u;
+    uint32_t item = blockIdx.x * wchunk, iter = 0;
     uint32_t part = part_of(item);
     uint32_t nrec = 0, rbase = 0;
     uint4 pre = make_uint4(0, 0, 0, 0);
@@ -895,16 +899,17 @@ k_skm_count_fast(const uint4 *recs, const uint32_t *pstart, const uint32_t *pcnt
         if (p_ < nparts && lane < 2u) { const uint32_t *src = lane == 0u ? pcnt : pstart; v = src[p_]; }
         return v;
     };
-    uint32_t chunk_n = s_next[0], chunk_n2 = 0;    // (published before the barrier above)
+    uint32_t chunk_n = dyn ? s_next[0] : blockIdx.x + gridDim.x, chunk_n2 = 0;    // (published before the barrier above)
     while (part < nparts) {
-        const bool first = wpos == 0u, last = wpos + 1u == SKM_FAST_WCHUNK;
-        const uint32_t item_n = last ? chunk_n * SKM_FAST_WCHUNK : item + 1u;
+        const bool first = wpos == 0u, last = wpos + 1u == wchunk;
+        const uint32_t item_n = last ? chunk_n * wchunk : item + 1u;
         const uint32_t next = part_of(item_n);
         const uint32_t desc_n = load_desc(next);
         ull grab = 0;
-        if (first && tid == 0) grab = atomicAdd(work_counter, 1ull);
+        if (dyn && first && tid == 0) grab = atomicAdd(work_counter, 1ull);
+        if (!dyn) chunk_n2 = chunk_n + gridDim.x;
         if (nrec == 0) {       // an empty partition (rare among the owned ones)
-            if (first) {       // agree on the chunk after next through LDS right away
+            if (dyn && first) {       // agree on the chunk after next through LDS right away
                 if (tid == 0) s_next[tog ^ 1u] = gridDim.x + (uint32_t)grab;
                 __syncthreads();
                 tog ^= 1u;
@@ -1048,9 +1053,9 @@ k_skm_count_fast(const uint4 *recs, const uint32_t *pstart, const uint32_t *pcnt
         iter++;
         // block-level offsets of the waves (one barrier)
         if (lane == 63u) tmp[par * 16u + wave] = winc;
-        if (first && tid == 0) s_next[tog ^ 1u] = gridDim.x + (uint32_t)grab;
+        if (dyn && first && tid == 0) s_next[tog ^ 1u] = gridDim.x + (uint32_t)grab;
         __syncthreads();
-        if (first) { tog ^= 1u; chunk_n2 = s_next[tog]; }
+        if (dyn && first) { tog ^= 1u; chunk_n2 = s_next[tog]; }
         uint32_t wpre = 0, total = 0;
 #pragma unroll
         for (uint32_t w = 0; w < NW; w++) { const uint32_t t = tmp[par * 16u + w]; if (w < wave) wpre += t; total += t; }
