@@ -230,7 +230,7 @@ SIMKA_EXPORT int simka_abi_version(void) { return SIMKA_ABI_VERSION; }
 
 SIMKA_EXPORT const char *simka_last_error(const simka_ctx *ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
 
-// k_scan<SCATTER, FIXED, SHARDED>
+// k_skm_scan<W, FIXED, HIST>
 using SkmScanFn = void (*)(SimkaScanArgs, SimkaSkmCfg, ull *, ull *, uint4 *, const ull *, uint32_t *, uint32_t, uint32_t, uint32_t, uint32_t *);
 static int skm_w_index(uint32_t W) { switch (W) { case 1: return 0; case 4: return 1; case 8: return 2; case 12: return 3; case 16: return 4; default: return 5; } }
 static SkmScanFn skm_scan_kernel(int wi, bool fixed, bool hist) {
@@ -254,7 +254,7 @@ static int set_lds_attr(simka_ctx *ctx) {
     return SIMKA_OK;
 }
 
-// ~SIMKA_TARGET_PER_PART k-mer occurrences of the largest sample per partition (one LDS table of k_count_fast)
+// ~SIMKA_TARGET_PER_PART k-mer occurrences of the largest sample per partition (one LDS table of k_skm_count_fast)
 static uint32_t default_log2_partitions(uint64_t max_kmers, uint32_t shard_count) {
     const uint64_t per_shard = std::max<uint64_t>(1, max_kmers / std::max(1u, shard_count));
     static const uint64_t target = getenv("SIMKA_TARGET_PER_PART") ? (uint64_t)atoll(getenv("SIMKA_TARGET_PER_PART")) : (uint64_t)SIMKA_TARGET_PER_PART;   // experiments

@@ -37,7 +37,7 @@ struct SimkaKeyCfg {
 // Only the TOP bits of the key route it (partition, sub-range), and the top bits of a product depend on every input bit
 // (multiplicative hashing); the xor-shift folds the high half into the low bits, which the LDS tables hash again
 // (simka_slot_hash / the 32-bit table hash).  One 64-bit multiply: the scan kernel is instruction-bound, a second
-// multiply round costs 7 % of k_scan and buys no measurable balance (measured on C2 / C3).
+// multiply round buys no measurable balance (measured on C2 / C3 in round 1).
 SIMKA_HD uint64_t simka_mix(uint64_t x, uint64_t mask, uint32_t xs) {
     x = (x * SIMKA_MIX_M1) & mask;
     x ^= x >> xs;

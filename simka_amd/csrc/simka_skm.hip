@@ -6,13 +6,15 @@
 // the partition of a k-mer is a function of its minimizer, ref: src/minikc/MiniKC.hpp:237-253).  This file is the same
 // flow on the GPU, with HBM where the reference has its temp disk:
 //
-//   packed reads --k_skm_scan----> 16-byte super-k-mer records in level-1 buckets (by the top bits of the partition id)
-//                --k_skm_hist2 / k_skm_scatter2--> level-2 buckets, exactly sized (two passes over the small records)
-//                --k_skm_split3--> every partition contiguous, exact (start,count) table
-//                --k_skm_count---> per partition: records -> k-mers -> canonical -> LDS hash table -> abundance filter ->
+//   packed reads --k_skm_scan----> 16-byte super-k-mer records in 2^8 level-1 buckets (by the top bits of the partition id)
+//                                  + a 4-byte array of their partition ids
+//                --k_skm_split---> every partition contiguous, exact (start, count) table: one block per bucket, a histogram
+//                                  pass over the ids, then 8192-record chunks ordered by partition in LDS
+//                --k_skm_count_fast (k_skm_count for the partitions it gives up on)-->
+//                                  per partition: records -> k-mers -> canonical -> LDS hash table -> abundance filter ->
 //                                  solid (k-mer,count) records in the HBM arena + D/N/Q totals (MiniKC.hpp:54-79)
 //
-// A k-mer occurrence costs ~1.6 bytes per level instead of 8, and the per-k-mer work of the partitioning levels (rank atomics,
+// A k-mer occurrence costs ~1.9 bytes per level instead of 8, and the per-k-mer work of the partitioning levels (rank atomics,
 // staging) becomes per-record work (one record per ~10 k-mers).  Results do not depend on the minimizer scheme:
 // the order on m-mers, m itself and the minimizer -> partition map are free choices; ours:
 //   * m-mer order: a bijective multiply / xor-shift / multiply hash of the CANONICAL m-mer (min of the m-mer and its reverse
@@ -140,7 +142,7 @@ k_skm_scan(SimkaScanArgs a, SimkaSkmCfg cfg, ull *b1_count, ull *b1_cursor, uint
             tb[2 * i] = (uint32_t)v; tb[2 * i + 1] = (uint32_t)(v >> 32);
         }
     }
-    // ---- variable-length reads: the read starts inside this tile (relative to max(Q0,0)), as k_scan does
+    // ---- variable-length reads: the read starts inside this tile (relative to max(Q0,0)), (one binary search per tile, k_tile_reads)
     const uint64_t T0 = Q0 < 0 ? 0ull : (uint64_t)Q0;
     uint32_t ntab = 0;
     if (!FIXED) {
