@@ -804,7 +804,7 @@ int main(int argc, char **argv) {
         // One range per GPU on distinct devices: the heads of the G merges are combined by ONE RCCL all-reduce over xGMI
         // (simka_stats_allreduce_head: SimkaStatistics::operator+= across GPUs, ref: src/core/SimkaDistance.cpp:156-213); the
         // imported per-sample totals are global on every GPU already.  Several ranges per GPU (or -gpu-shared): summed on the host.
-        const bool use_rccl = G > 1 && V == G && !o.same_gpu;
+        const bool use_rccl = G > 1 && V == G && !o.same_gpu && !getenv("SIMKA_NO_RCCL");      // (SIMKA_NO_RCCL=1: sum on the host)
         uint8_t comm_id[SIMKA_COMM_ID_BYTES];
         if (use_rccl && simka_comm_unique_id(comm_id) != SIMKA_OK) die(std::string("EXCEPTION: simka_comm_unique_id: ") + simka_comm_last_error(nullptr));
         auto merger = [&](uint32_t g) {
