@@ -54,7 +54,7 @@ typedef unsigned long long ull;
 #define SKM_FAST_TS 2048
 #define SKM_FAST_WCHUNK 8         // partitions a block takes per grab of the work counter
 #ifndef SKM_FAST_U
-#define SKM_FAST_U 2             // k-mers per lane in flight in the insert loop (4: the queue grows and only three blocks fit a CU -- slower)
+#define SKM_FAST_U 1             // k-mers per lane in flight in the insert loop (2: 1..5 % slower once the partitions are handed out dynamically; 4: three blocks per CU)
 #endif
 #define SKM_FAST_QCAP (64 + 64 * SKM_FAST_U)      // retry queue of a wave: what one iteration can add on top of an undrained rest
 #define SKM_FAST_BMW 32          // u64 words of a wave's record-start bitmap (64 records x nmax <= 32 k-mers)
