@@ -19,9 +19,9 @@
 #define SIMKA_EXPORT extern "C" __attribute__((visibility("default")))
 
 // kernel ids for the profiler
-enum { KID_SCAN_HIST = 0, KID_LAYOUT, KID_SKM_SCAN, KID_SKM_SPLIT, KID_SKM_COUNT, KID_COUNT, KID_PART_TOTALS, KID_REGROUP, KID_GROUP,
+enum { KID_SCAN_HIST = 0, KID_LAYOUT, KID_SKM_SCAN, KID_SKM_SPLIT, KID_SKM_DEDUP, KID_SKM_COUNT, KID_COUNT, KID_PART_TOTALS, KID_REGROUP, KID_GROUP,
        KID_PAIRS, KID_PAIRS_GLOBAL, KID_NB };
-static const char *const KID_NAMES[KID_NB] = { "k_skm_scan<hist>", "k_skm_layout", "k_skm_scan", "k_skm_split", "k_skm_count_fast", "k_skm_count",
+static const char *const KID_NAMES[KID_NB] = { "k_skm_scan<hist>", "k_skm_layout", "k_skm_scan", "k_skm_split", "k_skm_dedup", "k_skm_count_fast", "k_skm_count",
                                                "k_part_totals", "k_regroup", "k_group", "k_pairs", "k_pairs_global" };
 
 static thread_local std::string g_create_error;
@@ -48,7 +48,7 @@ struct simka_ctx {
         // super-k-mer pipeline: two record buffers (level 1 / level 3 share one), level-2 counters, partition table
         uint4 *d_skm_a = nullptr, *d_skm_b = nullptr; uint64_t skm_a_cap = 0, skm_b_cap = 0;
         uint32_t *d_skm_p = nullptr; uint64_t skm_p_cap = 0;      // partition id of every level-1 record (4-byte side array)
-        uint32_t *d_pstart = nullptr, *d_pcnt = nullptr;
+        uint32_t *d_pstart = nullptr, *d_pcnt = nullptr, *d_pcnt_dd = nullptr;      // partition table of the split; record counts after k_skm_dedup
     };
     static constexpr uint32_t MAX_LANES = 4;
     Lane lanes[MAX_LANES];
@@ -304,7 +304,7 @@ static int setup_geometry(simka_ctx *ctx, uint64_t max_kmers) {
         HIPCHK(dev_alloc(&L.d_b1_cursor, (uint64_t)(ctx->B1 + 1) * SKM_CSTRIDE));
         HIPCHK(dev_alloc(&L.d_redo_list, ctx->nparts + 1));
         HIPCHK(dev_alloc(&L.d_redo_count, 2));
-        HIPCHK(dev_alloc(&L.d_pstart, ctx->nparts + 1)); HIPCHK(dev_alloc(&L.d_pcnt, ctx->nparts + 1));
+        HIPCHK(dev_alloc(&L.d_pstart, ctx->nparts + 1)); HIPCHK(dev_alloc(&L.d_pcnt, ctx->nparts + 1)); HIPCHK(dev_alloc(&L.d_pcnt_dd, ctx->nparts + 1));
     }
     HIPCHK(dev_alloc(&ctx->d_l1_ovf, c.nb_samples + 1));
     HIPCHK(hipMemsetAsync(ctx->d_l1_ovf, 0, (size_t)(c.nb_samples + 1) * 4, ctx->stream));
@@ -418,7 +418,7 @@ SIMKA_EXPORT void simka_destroy(simka_ctx *ctx) {
     for (auto &L : ctx->lanes) {
         if (L.stream) (void)hipStreamSynchronize(L.stream);
         void *lp[] = { L.d_b1_count, L.d_b1_start, L.d_b1_end, L.d_b1_cursor, L.d_tile_r0, L.d_redo_list, L.d_redo_count,
-                       L.d_skm_a, L.d_skm_b, L.d_skm_p, L.d_pstart, L.d_pcnt };
+                       L.d_skm_a, L.d_skm_b, L.d_skm_p, L.d_pstart, L.d_pcnt, L.d_pcnt_dd };
         for (void *q : lp) if (q) (void)hipFree(q);
         if (L.stream) (void)hipStreamDestroy(L.stream);
     }
@@ -617,14 +617,20 @@ static int run_count_kernels(simka_ctx *ctx, uint32_t sample, const SimkaScanArg
     const size_t lds_fast = (size_t)SIMKA_LDS_HEAD + (size_t)SKM_FAST_TS * 12 + (size_t)SKM_FAST_BLOCK * 16 + hist_lds + (size_t)(SKM_FAST_BLOCK / 64) * SKM_FAST_WREG + 64;
     const size_t lds_count = (size_t)SIMKA_LDS_HEAD + (size_t)SKM_CNT_TS * 12 + (size_t)SKM_CNT_BATCH * 16 + (size_t)SKM_CNT_BLOCK * 4 + hist_lds + (size_t)SKM_CNT_BATCH * sk.nmax * 2 + 64;
     static const bool general_only = getenv("SIMKA_SKM_GENERAL") != nullptr;      // tests: every partition through the general kernel
-    if (!general_only)
+    if (!general_only) {
+        // identical records first (k_skm_dedup): the level-1 buffer is free again, the representatives go there, at their partition's start
+        launch_timed(ctx, KID_SKM_DEDUP, [&] {
+            hipLaunchKernelGGL(k_skm_dedup, dim3((uint32_t)std::min<uint64_t>((ctx->nparts + 3) / 4, (uint64_t)ctx->num_cus * 6)), dim3(SKM_DD_BLOCK), 0, st, (const uint4 *)L.d_skm_b,
+                               (const uint32_t *)L.d_pstart, (const uint32_t *)L.d_pcnt, sk, L.d_skm_a, L.d_pcnt_dd, (const uint32_t *)flag);
+        }, st);
         launch_timed(ctx, KID_SKM_COUNT, [&] {
             static const uint32_t bpc_env = getenv("SIMKA_SKM_BPC") ? (uint32_t)atoi(getenv("SIMKA_SKM_BPC")) : 0u;     // experiments
             const uint32_t bpc = bpc_env ? bpc_env : (uint32_t)std::max<size_t>(1, std::min<size_t>(4, (160 * 1024) / lds_fast));
-            hipLaunchKernelGGL(k_skm_count_fast, dim3((uint32_t)std::min<uint64_t>(ctx->nparts, (uint64_t)ctx->num_cus * bpc)), dim3(SKM_FAST_BLOCK), lds_fast, st, (const uint4 *)L.d_skm_b,
-                               (const uint32_t *)L.d_pstart, (const uint32_t *)L.d_pcnt, sk, ctx->key, ctx->cfg.abundance_min, ctx->cfg.abundance_max, o, (const uint32_t *)flag, kocc,
+            hipLaunchKernelGGL(k_skm_count_fast, dim3((uint32_t)std::min<uint64_t>(ctx->nparts, (uint64_t)ctx->num_cus * bpc)), dim3(SKM_FAST_BLOCK), lds_fast, st, (const uint4 *)L.d_skm_a,
+                               (const uint32_t *)L.d_pstart, (const uint32_t *)L.d_pcnt_dd, sk, ctx->key, ctx->cfg.abundance_min, ctx->cfg.abundance_max, o, (const uint32_t *)flag, kocc,
                                L.d_redo_list, L.d_redo_count);
         }, st);
+    }
     launch_timed(ctx, KID_COUNT, [&] {
         const uint32_t grid = general_only ? (uint32_t)std::min<uint64_t>(ctx->nparts, (uint64_t)ctx->num_cus * 2) : (uint32_t)ctx->num_cus;
         hipLaunchKernelGGL(k_skm_count, dim3(grid), dim3(SKM_CNT_BLOCK), lds_count, st, (const uint4 *)L.d_skm_b,

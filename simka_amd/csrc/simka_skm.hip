@@ -58,7 +58,10 @@ typedef unsigned long long ull;
 #endif
 #define SKM_FAST_QCAP (64 + 64 * SKM_FAST_U)      // retry queue of a wave: what one iteration can add on top of an undrained rest
 #define SKM_FAST_BMW 32          // u64 words of a wave's record-start bitmap (64 records x nmax <= 32 k-mers)
-#define SKM_FAST_WREG ((SKM_FAST_BMW * 8 + SKM_FAST_QCAP * 10 + 15) / 16 * 16)     // bytes of a wave's private LDS region
+#define SKM_FAST_WREG ((SKM_FAST_BMW * 8 + SKM_FAST_QCAP * 12 + 15) / 16 * 16)     // bytes of a wave's private LDS region (bitmap; queue: key 8 + slot 2 + multiplicity 2)
+#define SKM_DD_BLOCK 256         // k_skm_dedup: four independent waves, one partition at a time each
+#define SKM_DD_TS 1024           // slots of a wave's record table
+#define SKM_DD_MAXREC 1024       // records of a partition at most (beyond: passed through unchanged)
 #define SKM_SORT_BITS 3          // solid records leave the count kernel ordered by the top 3 bits of the slot hash
 #define SKM_NSORT (1 << SKM_SORT_BITS)
 
@@ -88,6 +91,26 @@ __device__ __forceinline__ uint64_t skm_revcomp64(uint64_t x) {
     const uint64_t M5 = 0x5555555555555555ull;
     uint64_t r = __brevll(x);
     return (((r >> 1) & M5) | ((r & M5) << 1)) ^ 0xAAAAAAAAAAAAAAAAull;
+}
+
+// canonical orientation of a record: min(bases, reverse complement of the bases) as 2(n + k - 1)-bit integers -- both strands of a
+// genomic super-k-mer give the same record (its k-mers are the same canonical k-mers either way).  n and the partition id stay.
+__device__ __forceinline__ uint4 skm_rec_canon(const uint4 &r, uint32_t k) {
+    const uint32_t n1 = (r.w >> 6) & 31u, w6 = r.w & 63u;
+    const uint32_t s = 128u - 2u * (n1 + k);                      // the reverse complement of the 64-base word pair, moved down by 64 - T bases
+    const uint64_t vlo = ((uint64_t)r.y << 32) | r.x, vhi = ((uint64_t)w6 << 32) | r.z;
+    uint64_t rlo = skm_revcomp64(vhi), rhi = skm_revcomp64(vlo);
+    if (s >= 64u) { rlo = rhi >> ((s - 64u) & 63u); rhi = 0; }
+    else { rlo = (rlo >> (s & 63u)) | (rhi << ((64u - s) & 63u)); rhi >>= (s & 63u); }    // (s >= 26: T <= 51 bases)
+    const bool rev = rhi < vhi || (rhi == vhi && rlo < vlo);
+    const uint64_t lo = rev ? rlo : vlo, hi = rev ? rhi : vhi;
+    return make_uint4((uint32_t)lo, (uint32_t)(lo >> 32), (uint32_t)hi, (uint32_t)(hi >> 32) | (r.w & ~63u));
+}
+// 32-bit hash of (bases, n)
+__device__ __forceinline__ uint32_t skm_rec_hash(uint32_t x, uint32_t y, uint32_t z, uint32_t w) {
+    uint32_t h = x * 0x9E3779B1u + y * 0x85EBCA6Bu + z * 0xC2B2AE35u + w * 0x27D4EB2Fu;
+    h ^= h >> 15;
+    return h * 0x2C1B3C6Du;
 }
 
 // --------------------------------------------------------------------------------------------
@@ -527,7 +550,7 @@ k_skm_split(const uint4 *l1_recs, const uint32_t *l1_pid, const ull *b1_start, c
         for (uint32_t i = tid; i < (F2 + 1) / 2; i += SKM_SPLIT_BLOCK) ((uint32_t *)ch)[i] = 0;
         uint4 rec[SKM_SPLIT_UNROLL]; uint32_t lr[SKM_SPLIT_UNROLL];
 #pragma unroll
-        for (int u = 0; u < SKM_SPLIT_UNROLL; u++) { const ull i = i0 + (ull)u * SKM_SPLIT_BLOCK + tid; if (i < n) rec[u] = l1_recs[st + i]; }
+        for (int u = 0; u < SKM_SPLIT_UNROLL; u++) { const ull i = i0 + (ull)u * SKM_SPLIT_BLOCK + tid; if (i < n) rec[u] = skm_rec_canon(l1_recs[st + i], cfg.k); }       // (canonical orientation: k_skm_dedup compares records)
         __syncthreads();
         // rank inside the chunk's run of the partition: 16-bit counters, two per word (the returning atomic works on the word)
 #pragma unroll
@@ -570,6 +593,91 @@ k_skm_split(const uint4 *l1_recs, const uint32_t *l1_pid, const ull *b1_start, c
         // the partitions' cursors move past this chunk: count of partition i = start of i + 1 (or the chunk's end) - start of i
         for (uint32_t i = tid; i < F2; i += SKM_SPLIT_BLOCK) lh[i] += (i + 1 < F2 ? (uint32_t)ch[i + 1] : nc) - (uint32_t)ch[i];
         __syncthreads();
+    }
+}
+
+// --------------------------------------------------------------------------------------------
+// k_skm_dedup: identical records of a partition are counted FIRST.  At sequencing depth a genomic super-k-mer comes back once per
+// read that covers it (C3: 100 % of the records -> 44 % distinct, their k-mers -> 46 %), and a record repeated c times only has to
+// be expanded once, its k-mers adding c.  One WAVE per partition, no block-level synchronisation: the (canonical, see k_skm_split)
+// records are hashed into a wave-private LDS table with a 32-bit CAS (record index | 22-bit fingerprint); a record that finds its
+// fingerprint there compares itself with the claimant (read back from global memory: the partition's few KB are cache-resident) and,
+// if equal, bumps the claimant's 16-bit counter and dies.  Two probes, then a record just stays its own representative
+// (deduplication is an optimisation, never a requirement).  Second pass: the representatives leave densely, their multiplicity
+// where the partition id was (w = base bits | (n - 1) << 6 | multiplicity << 11).  A partition of more than SKM_DD_MAXREC records
+// is passed through with multiplicity 1.
+// --------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(SKM_DD_BLOCK)
+k_skm_dedup(const uint4 *recs, const uint32_t *pstart, const uint32_t *pcnt, SimkaSkmCfg cfg, uint4 *out, uint32_t *pcnt_out, const uint32_t *flag) {
+    if (*flag) return;
+    __shared__ __attribute__((aligned(16))) uint32_t s_tab[SKM_DD_BLOCK / 64][SKM_DD_TS];
+    __shared__ __attribute__((aligned(16))) uint32_t s_mult[SKM_DD_BLOCK / 64][SKM_DD_MAXREC / 2];
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    uint32_t *tab = s_tab[wave], *mult = s_mult[wave];
+    const uint32_t nparts = 1u << cfg.pb;
+    const uint32_t nwaves = gridDim.x * (SKM_DD_BLOCK / 64);
+    for (uint32_t p = blockIdx.x * (SKM_DD_BLOCK / 64) + wave; p < nparts; p += nwaves) {
+        const uint32_t n = pcnt[p];
+        const uint32_t base = pstart[p];
+        if (n == 0) { if (lane == 0) pcnt_out[p] = 0; continue; }
+        if (n > SKM_DD_MAXREC) {
+            for (uint32_t i = lane; i < n; i += 64u) { const uint4 r = recs[base + i]; out[base + i] = make_uint4(r.x, r.y, r.z, (r.w & 0x7ffu) | (1u << 11)); }
+            if (lane == 0) pcnt_out[p] = n;
+            continue;
+        }
+        {
+            const uint4 e4 = make_uint4(~0u, ~0u, ~0u, ~0u), z4 = make_uint4(0, 0, 0, 0);
+#pragma unroll
+            for (uint32_t i = 0; i < SKM_DD_TS / 256; i++) ((uint4 *)tab)[i * 64u + lane] = e4;
+            for (uint32_t i = lane; i < (n + 7u) / 8u; i += 64u) ((uint4 *)mult)[i] = z4;
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        const uint32_t R = (n + 63u) >> 6;
+        uint32_t livemask = 0;
+        uint4 nx = make_uint4(0, 0, 0, 0);
+        if (lane < n) nx = recs[base + lane];
+        for (uint32_t r = 0; r < R; r++) {
+            const uint32_t i = (r << 6) + lane;
+            const bool valid = i < n;
+            const uint4 rc = nx;
+            if (i + 64u < n) nx = recs[base + i + 64u];
+            const uint32_t w = rc.w & 0x7ffu;
+            const uint32_t h = skm_rec_hash(rc.x, rc.y, rc.z, w);
+            const uint32_t fp = h & 0x3fffffu, entry = (i << 22) | fp;
+            uint32_t slot = h >> 22;
+            bool live = valid, searching = valid;
+#pragma unroll
+            for (int probe = 0; probe < 2; probe++) {
+                if (searching) {
+                    const uint32_t prev = atomicCAS(&tab[slot], ~0u, entry);
+                    if (prev == ~0u) searching = false;
+                    else if ((prev & 0x3fffffu) == fp) {
+                        const uint32_t j = prev >> 22;
+                        const uint4 ot = recs[base + j];
+                        if (ot.x == rc.x && ot.y == rc.y && ot.z == rc.z && (ot.w & 0x7ffu) == w) { atomicAdd(&mult[j >> 1], 1u << ((j & 1u) * 16u)); live = false; searching = false; }
+                    }
+                    slot = (slot + 1u) & (SKM_DD_TS - 1u);
+                }
+            }
+            livemask |= (live ? 1u : 0u) << r;
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        uint32_t outpos = 0;
+        for (uint32_t r = 0; r < R; r++) {
+            const bool live = (livemask >> r) & 1u;
+            const ull lm = __ballot(live);
+            if (lm == 0ull) continue;
+            if (live) {
+                const uint32_t i = (r << 6) + lane;
+                const uint4 rc = recs[base + i];
+                const uint32_t m = 1u + ((mult[i >> 1] >> ((i & 1u) * 16u)) & 0xffffu);
+                const uint32_t pos = outpos + __builtin_amdgcn_mbcnt_hi((uint32_t)(lm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)lm, 0u));
+                out[base + pos] = make_uint4(rc.x, rc.y, rc.z, (rc.w & 0x7ffu) | (m << 11));
+            }
+            outpos += (uint32_t)__popcll(lm);
+        }
+        if (lane == 0) pcnt_out[p] = outpos;
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // the table and the counters are rewritten for the next partition
     }
 }
 
@@ -774,6 +882,8 @@ k_skm_count(const uint4 *recs, const uint32_t *pstart, const uint32_t *pcnt, Sim
 
 // --------------------------------------------------------------------------------------------
 // k_skm_count_fast: the common case of k_skm_count -- the partition's distinct k-mers fit the table in ONE round.
+//   * its input are the DEDUPLICATED records of k_skm_dedup: w = base bits | (n - 1) << 6 | multiplicity << 11; a k-mer of a record
+//     adds the record's multiplicity;
 //   * every wave expands its own 64 records: the records go to a wave-private LDS copy together with the index of their first
 //     k-mer among the wave's k-mers, and ONE bit per record marks that index in a bitmap.  K-mer f of the wave then finds its
 //     record with two mbcnt (records before f = set bits below f; the 64 bits of a chunk of k-mers are wave-uniform), cuts
@@ -823,7 +933,8 @@ k_skm_count_fast(const uint4 *recs, const uint32_t *pstart, const uint32_t *pcnt
     uint4 *wrec = lrec + wave * 64u;
     ull *bm64 = (ull *)(wreg0 + wave * SKM_FAST_WREG);              // [SKM_FAST_BMW] bit f set: a record starts at k-mer f
     ull *qk = bm64 + SKM_FAST_BMW;                                  // [QCAP] retry queue: canonical k-mers ...
-    uint16_t *qm = (uint16_t *)(qk + SKM_FAST_QCAP);                // [QCAP] ... and the slot to try next
+    uint16_t *qm = (uint16_t *)(qk + SKM_FAST_QCAP);                // [QCAP] ... the slot to try next ...
+    uint16_t *qx = qm + SKM_FAST_QCAP;                              // [QCAP] ... and what to add (the record's multiplicity)
     constexpr uint32_t bmask = (TS >> SKM_SORT_BITS) - 1u;        // probing stays inside the sort block (TS / 8 slots)
     constexpr uint32_t U = SKM_FAST_U;
     uint32_t qn = 0;                                                // entries in the queue (wave-uniform)
@@ -836,8 +947,8 @@ k_skm_count_fast(const uint4 *recs, const uint32_t *pstart, const uint32_t *pcnt
         const uint32_t n = qn < 64u ? qn : 64u;
         const uint32_t e = qn - n + lane;
         const bool a = lane < n;
-        ull key = 0; uint32_t meta = 0;
-        if (a) { key = qk[e]; meta = qm[e]; }
+        ull key = 0; uint32_t meta = 0, mult = 0;
+        if (a) { key = qk[e]; meta = qm[e]; mult = qx[e]; }
         qn -= n;
         bool again = false;
         uint32_t slot = meta & (TS - 1u);
@@ -849,10 +960,10 @@ k_skm_count_fast(const uint4 *recs, const uint32_t *pstart, const uint32_t *pcnt
             const uint32_t st = h0 ? slot : h1 ? s1 : h2 ? s2 : s3;
             const ull ws = h0 ? w0 : h1 ? w1 : h2 ? w2 : w3;
             if (!(h0 || h1 || h2 || h3)) { again = true; slot = bb | ((slot + 4u) & bmask); }
-            else if (ws == key) atomicAdd(&tcnt[st], 1u);
+            else if (ws == key) atomicAdd(&tcnt[st], mult);
             else {
                 const ull prev = atomicCAS(&tkeys[st], SIMKA_EMPTY_KEY, key);
-                if (prev == SIMKA_EMPTY_KEY || prev == key) atomicAdd(&tcnt[st], 1u);
+                if (prev == SIMKA_EMPTY_KEY || prev == key) atomicAdd(&tcnt[st], mult);
                 else { again = true; slot = bb | ((st + 1u) & bmask); }
             }
             if (again) {
@@ -863,7 +974,7 @@ k_skm_count_fast(const uint4 *recs, const uint32_t *pstart, const uint32_t *pcnt
         }
         const ull am = __ballot(again);
         if (am) {
-            if (again) { const uint32_t pos = qn + __builtin_amdgcn_mbcnt_hi((uint32_t)(am >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)am, 0u)); qk[pos] = key; qm[pos] = (uint16_t)meta; }
+            if (again) { const uint32_t pos = qn + __builtin_amdgcn_mbcnt_hi((uint32_t)(am >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)am, 0u)); qk[pos] = key; qm[pos] = (uint16_t)meta; qx[pos] = (uint16_t)mult; }
             qn += (uint32_t)__popcll(am);
         }
     };
@@ -937,12 +1048,12 @@ k_skm_count_fast(const uint4 *recs, const uint32_t *pstart, const uint32_t *pcnt
             const uint32_t x = wave_incl_scan(len);
             const uint32_t kt = __builtin_amdgcn_readlane(x, 63);
             const uint32_t off = x - len;
-            // the wave's copy of the record carries the index of its first k-mer where the partition id was
-            wrec[lane] = make_uint4(rc.x, rc.y, rc.z, (rc.w & 63u) | (off << 6));
+            // the wave's copy of the record carries the index of its first k-mer where its length was: w = base bits | off << 6 | multiplicity << 17
+            wrec[lane] = make_uint4(rc.x, rc.y, rc.z, (rc.w & 63u) | (off << 6) | ((rc.w >> 11) << 17));
             if (lane < SKM_FAST_BMW) bm64[lane] = 0ull;
             if (len) atomicOr((uint32_t *)bm64 + (off >> 5), 1u << (off & 31u));
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            if (lane == 0) my_k += kt;
+            my_k += (ull)len * (ull)(rc.w >> 11);
             PH(1)
             // the whole bitmap in registers (word c in lane c): a chunk's 64 bits are then two readlanes away, no LDS round trip
             ull bmreg = 0;
@@ -967,12 +1078,13 @@ k_skm_count_fast(const uint4 *recs, const uint32_t *pstart, const uint32_t *pcnt
             };
             fetch(0);
             for (uint32_t f0 = 0; f0 < kt; f0 += 64u * U) {
-                ull cu[U]; uint32_t su[U]; bool actc[U];
+                ull cu[U]; uint32_t su[U], mu[U]; bool actc[U];
                 // cut, reverse complement, canonical, slot
 #pragma unroll
                 for (uint32_t u = 0; u < U; u++) {
                     actc[u] = act[u];
-                    const uint64_t fw = skm_kmer_at(rx[u], (f0 + 64u * u + lane - (rx[u].w >> 6)) & 31u, cfg);
+                    mu[u] = rx[u].w >> 17;
+                    const uint64_t fw = skm_kmer_at(rx[u], (f0 + 64u * u + lane - ((rx[u].w >> 6) & 2047u)) & 31u, cfg);
                     const uint64_t rv = skm_revcomp64(fw) >> (64u - 2u * cfg.k);
                     cu[u] = fw < rv ? fw : rv;
                     su[u] = skm_kmer_hash(cu[u]) >> (32u - TSL);
@@ -987,13 +1099,13 @@ k_skm_count_fast(const uint4 *recs, const uint32_t *pstart, const uint32_t *pcnt
 #pragma unroll
                 for (uint32_t u = 0; u < U; u++) {
                     const bool ok = pu[u] == SIMKA_EMPTY_KEY || pu[u] == cu[u];
-                    atomicAdd(&tcnt[su[u]], (actc[u] && ok) ? 1u : 0u);
+                    atomicAdd(&tcnt[su[u]], (actc[u] && ok) ? mu[u] : 0u);
                     const bool lost = actc[u] && !ok;
                     const ull lm = __ballot(lost);
                     if (lm) {       // (bmask >= 1: the next slot is never the home slot)
                         if (lost) {
                             const uint32_t pos = qn + __builtin_amdgcn_mbcnt_hi((uint32_t)(lm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)lm, 0u));
-                            qk[pos] = cu[u]; qm[pos] = (uint16_t)((su[u] & ~bmask) | ((su[u] + 1u) & bmask));
+                            qk[pos] = cu[u]; qm[pos] = (uint16_t)((su[u] & ~bmask) | ((su[u] + 1u) & bmask)); qx[pos] = (uint16_t)mu[u];
                         }
                         qn += (uint32_t)__popcll(lm);
                     }
@@ -1040,7 +1152,7 @@ k_skm_count_fast(const uint4 *recs, const uint32_t *pstart, const uint32_t *pcnt
         }
         const bool failed = s_fail != 0u;
         // the wave's solid records, in slot order, go to its (now empty) retry queue: keys [0, cap), counts behind them
-        constexpr uint32_t wcap = (SKM_FAST_QCAP * 10u) / 12u;                    // records the region takes
+        constexpr uint32_t wcap = SKM_FAST_QCAP;                                  // records the region takes (12 bytes each)
         ull *wk = qk; uint32_t *wc = (uint32_t *)(wk + wcap);
         const uint32_t winc = wave_incl_scan(nsol);
         const uint32_t wtot = __builtin_amdgcn_readlane(winc, 63);
