@@ -19,9 +19,9 @@
 #define SIMKA_EXPORT extern "C" __attribute__((visibility("default")))
 
 // kernel ids for the profiler
-enum { KID_SCAN_HIST = 0, KID_LAYOUT, KID_SKM_SCAN, KID_SKM_SPLIT, KID_SKM_DEDUP, KID_SKM_COUNT, KID_COUNT, KID_PART_TOTALS, KID_REGROUP, KID_GROUP,
+enum { KID_SCAN_HIST = 0, KID_LAYOUT, KID_SKM_SCAN, KID_SKM_SPLIT, KID_SKM_COUNT, KID_COUNT, KID_PART_TOTALS, KID_REGROUP, KID_GROUP,
        KID_PAIRS, KID_PAIRS_GLOBAL, KID_NB };
-static const char *const KID_NAMES[KID_NB] = { "k_skm_scan<hist>", "k_skm_layout", "k_skm_scan", "k_skm_split", "k_skm_dedup", "k_skm_count_fast", "k_skm_count",
+static const char *const KID_NAMES[KID_NB] = { "k_skm_scan<hist>", "k_skm_layout", "k_skm_scan", "k_skm_split", "k_skm_count_fast", "k_skm_count",
                                                "k_part_totals", "k_regroup", "k_group", "k_pairs", "k_pairs_global" };
 
 static thread_local std::string g_create_error;
@@ -48,8 +48,7 @@ struct simka_ctx {
         // super-k-mer pipeline: two record buffers (level 1 / level 3 share one), level-2 counters, partition table
         uint4 *d_skm_a = nullptr, *d_skm_b = nullptr; uint64_t skm_a_cap = 0, skm_b_cap = 0;
         uint32_t *d_skm_p = nullptr; uint64_t skm_p_cap = 0;      // partition id of every level-1 record (4-byte side array)
-        uint32_t *d_pstart = nullptr, *d_pcnt = nullptr;                            // partition table of the split
-        uint32_t *d_pstart_dd = nullptr, *d_pcnt_dd = nullptr;                      // sub-partition table of k_skm_dedup
+        uint32_t *d_pstart = nullptr, *d_pcnt = nullptr;
     };
     static constexpr uint32_t MAX_LANES = 4;
     Lane lanes[MAX_LANES];
@@ -255,15 +254,16 @@ static int set_lds_attr(simka_ctx *ctx) {
     return SIMKA_OK;
 }
 
-// ~target k-mer occurrences of the largest sample per (sub-)partition (one LDS table of k_skm_count_fast)
-static uint32_t default_log2_partitions(uint64_t max_kmers, uint32_t shard_count, uint64_t target = SIMKA_TARGET_PER_PART) {
+// ~SIMKA_TARGET_PER_PART k-mer occurrences of the largest sample per partition (one LDS table of k_skm_count_fast)
+static uint32_t default_log2_partitions(uint64_t max_kmers, uint32_t shard_count) {
     const uint64_t per_shard = std::max<uint64_t>(1, max_kmers / std::max(1u, shard_count));
+    static const uint64_t target = getenv("SIMKA_TARGET_PER_PART") ? (uint64_t)atoll(getenv("SIMKA_TARGET_PER_PART")) : (uint64_t)SIMKA_TARGET_PER_PART;   // experiments
     uint32_t pb = ceil_log2_u64((per_shard + target - 1) / target) + ceil_log2_u64(std::max(1u, shard_count));
-    return std::min(pb, 21u);
+    return std::min(pb, 20u);
 }
 
 SIMKA_EXPORT uint32_t simka_default_log2_partitions(uint64_t max_kmers_per_sample, uint32_t kmer_size) {
-    if (kmer_size > 31) return std::min(std::max(8u, default_log2_partitions(max_kmers_per_sample, 1, 3072)), 16u);      // sort path: key-prefix ranges
+    if (kmer_size > 31) return std::min(std::max(8u, default_log2_partitions(max_kmers_per_sample, 1)), 16u);      // sort path: key-prefix ranges
     return std::max(1u, std::min(default_log2_partitions(max_kmers_per_sample, 1), 2u * kmer_size));
 }
 
@@ -274,7 +274,7 @@ static int setup_geometry(simka_ctx *ctx, uint64_t max_kmers) {
     SimkaKeyCfg &k = ctx->key;
     uint32_t pb = c.log2_partitions;
     if (pb == 0) pb = default_log2_partitions(max_kmers, c.shard_count);
-    if (pb > 21) pb = 21;
+    if (pb > 20) pb = 20;
     if (pb > k.W) pb = k.W;
     k.l1 = 0; k.l2 = 0; k.pb = pb; k.t = 0;
     ctx->nparts = (uint64_t)1 << k.pb;
@@ -283,10 +283,7 @@ static int setup_geometry(simka_ctx *ctx, uint64_t max_kmers) {
         sk.pb = k.pb;
         static const uint32_t l1_env = getenv("SIMKA_SKM_L1") ? (uint32_t)atoi(getenv("SIMKA_SKM_L1")) : 8u;      // experiments
         sk.l1 = std::min<uint32_t>(sk.pb, std::min<uint32_t>(l1_env, 8u));
-        // the last two bits of a record's id are its sub-partition: the split stops above them, k_skm_dedup cuts a partition into its subs
-        sk.sb = std::min<uint32_t>(2u, sk.pb);
-        sk.l1 = std::min<uint32_t>(sk.pb - sk.sb, sk.l1);
-        sk.l2 = sk.pb - sk.sb - sk.l1;
+        sk.l2 = sk.pb - sk.l1; sk.l3 = 0;
         if (sk.l2 > 12) return ctx->fail(SIMKA_ERR_INVALID, "log2_partitions %u is beyond the two partitioning levels", sk.pb);
         ctx->B1 = 1u << sk.l1;
     }
@@ -307,7 +304,7 @@ static int setup_geometry(simka_ctx *ctx, uint64_t max_kmers) {
         HIPCHK(dev_alloc(&L.d_b1_cursor, (uint64_t)(ctx->B1 + 1) * SKM_CSTRIDE));
         HIPCHK(dev_alloc(&L.d_redo_list, ctx->nparts + 1));
         HIPCHK(dev_alloc(&L.d_redo_count, 2));
-        HIPCHK(dev_alloc(&L.d_pstart, ctx->nparts + 1)); HIPCHK(dev_alloc(&L.d_pcnt, ctx->nparts + 1)); HIPCHK(dev_alloc(&L.d_pstart_dd, ctx->nparts + 1)); HIPCHK(dev_alloc(&L.d_pcnt_dd, ctx->nparts + 1));
+        HIPCHK(dev_alloc(&L.d_pstart, ctx->nparts + 1)); HIPCHK(dev_alloc(&L.d_pcnt, ctx->nparts + 1));
     }
     HIPCHK(dev_alloc(&ctx->d_l1_ovf, c.nb_samples + 1));
     HIPCHK(hipMemsetAsync(ctx->d_l1_ovf, 0, (size_t)(c.nb_samples + 1) * 4, ctx->stream));
@@ -421,7 +418,7 @@ SIMKA_EXPORT void simka_destroy(simka_ctx *ctx) {
     for (auto &L : ctx->lanes) {
         if (L.stream) (void)hipStreamSynchronize(L.stream);
         void *lp[] = { L.d_b1_count, L.d_b1_start, L.d_b1_end, L.d_b1_cursor, L.d_tile_r0, L.d_redo_list, L.d_redo_count,
-                       L.d_skm_a, L.d_skm_b, L.d_skm_p, L.d_pstart, L.d_pcnt, L.d_pstart_dd, L.d_pcnt_dd };
+                       L.d_skm_a, L.d_skm_b, L.d_skm_p, L.d_pstart, L.d_pcnt };
         for (void *q : lp) if (q) (void)hipFree(q);
         if (L.stream) (void)hipStreamDestroy(L.stream);
     }
@@ -583,7 +580,7 @@ static int run_count_kernels(simka_ctx *ctx, uint32_t sample, const SimkaScanArg
         fprintf(stderr, "level-1 buckets: %u, records %llu, largest bucket %.1f %% above the mean\n", B1, sum, 100.0 * ((double)mx * B1 / std::max<ull>(1, sum) - 1.0));
     }
     launch_timed(ctx, KID_SKM_SPLIT, [&] {
-        const size_t lds_split = ((size_t)1 << sk.l2) * 4 + 64 + ((size_t)1 << sk.l2) * 2 + 48 + (size_t)SKM_SPLIT_BLOCK * SKM_SPLIT_UNROLL * 16;      // (the staging area starts 16-byte aligned behind F2 + 8 shorts)
+        const size_t lds_split = ((size_t)1 << sk.l2) * 4 + 64 + ((size_t)1 << sk.l2) * 2 + 16 + (size_t)SKM_SPLIT_BLOCK * SKM_SPLIT_UNROLL * 16;
         hipLaunchKernelGGL(k_skm_split, dim3(B1), dim3(SKM_SPLIT_BLOCK), lds_split, st, (const uint4 *)L.d_skm_a, (const uint32_t *)L.d_skm_p, (const ull *)L.d_b1_start, (const ull *)L.d_b1_count, sk,
                            L.d_skm_b, L.d_pstart, L.d_pcnt, (const uint32_t *)flag);
     }, st);
@@ -599,24 +596,35 @@ static int run_count_kernels(simka_ctx *ctx, uint32_t sample, const SimkaScanArg
                                           std::max<uint64_t>(64, ctx->arena_cap / ((uint64_t)ctx->num_cus * 4 * 8)));
     o.hist = ctx->d_hist; o.ovf_list = ctx->d_ovf_list; o.ovf_cursor = ctx->d_ovf_cursor; o.ovf_cap = ctx->ovf_cap;
     ull *kocc = (ull *)ctx->d_stats + stats_off_tot(N, ctx->cfg.dist_flags, SIMKA_TOT_KOCC) + sample;
+#ifdef SIMKA_PHASE_PROF
+    {   // debug build: per-phase wall_clock64 ticks of thread 0 of every k_skm_count_fast block, printed per sample
+        static ull *d_phase = nullptr;
+        if (!d_phase) { HIPCHK(hipMalloc(&d_phase, 128)); HIPCHK(hipMemset(d_phase, 0, 128)); }
+        else {
+            HIPCHK(hipDeviceSynchronize());
+            ull h[16]; HIPCHK(hipMemcpy(h, d_phase, 128, hipMemcpyDeviceToHost)); HIPCHK(hipMemset(d_phase, 0, 128));
+            if (h[12]) fprintf(stderr, "k_skm_count_fast counters: per wave and partition %.1f k-mers, %.1f queue entries left after the last batch, %.2f final drain passes\n",
+                               (double)h[8] / h[12], (double)h[14] / h[12], (double)h[13] / h[12]);
+            if (h[11]) fprintf(stderr, "k_skm_count_fast blocks: busy time of the slowest block %.0f ticks, mean %.0f (%.1f %% above the mean)\n", (double)h[9], (double)h[10] / h[11], 100.0 * ((double)h[9] * h[11] / h[10] - 1.0));
+            ull t_ = 0; for (int i_ = 0; i_ < 8; i_++) t_ += h[i_];
+            if (t_) fprintf(stderr, "k_skm_count_fast phases %%: top %.1f map %.1f insert %.1f sync %.1f summary %.1f scan %.1f slab %.1f stores %.1f  (ticks/block %.0f)\n",
+                    100.0 * h[0] / t_, 100.0 * h[1] / t_, 100.0 * h[2] / t_, 100.0 * h[3] / t_, 100.0 * h[4] / t_, 100.0 * h[5] / t_, 100.0 * h[6] / t_, 100.0 * h[7] / t_, (double)t_ / (ctx->num_cus * 2));
+        }
+        o.phase = d_phase;
+    }
+#endif
     const size_t hist_lds = ctx->d_hist ? (size_t)SIMKA_HIST_MAX * 4 : 0;
-    const size_t lds_fast = (size_t)SIMKA_LDS_HEAD + hist_lds + (size_t)(SKM_FAST_BLOCK / 64) * SKM_FAST_WREG + 64;
+    const size_t lds_fast = (size_t)SIMKA_LDS_HEAD + (size_t)SKM_FAST_TS * 12 + (size_t)SKM_FAST_BLOCK * 16 + hist_lds + (size_t)(SKM_FAST_BLOCK / 64) * SKM_FAST_WREG + 64;
     const size_t lds_count = (size_t)SIMKA_LDS_HEAD + (size_t)SKM_CNT_TS * 12 + (size_t)SKM_CNT_BATCH * 16 + (size_t)SKM_CNT_BLOCK * 4 + hist_lds + (size_t)SKM_CNT_BATCH * sk.nmax * 2 + 64;
     static const bool general_only = getenv("SIMKA_SKM_GENERAL") != nullptr;      // tests: every partition through the general kernel
-    if (!general_only) {
-        // identical records first (k_skm_dedup): the level-1 buffer is free again, the representatives go there, at their partition's start
-        launch_timed(ctx, KID_SKM_DEDUP, [&] {
-            hipLaunchKernelGGL(k_skm_dedup, dim3((uint32_t)std::min<uint64_t>(((ctx->nparts >> sk.sb) + 3) / 4, (uint64_t)ctx->num_cus * 6)), dim3(SKM_DD_BLOCK), 0, st, (const uint4 *)L.d_skm_b,
-                               (const uint32_t *)L.d_pstart, (const uint32_t *)L.d_pcnt, sk, L.d_skm_a, L.d_pstart_dd, L.d_pcnt_dd, (const uint32_t *)flag);
-        }, st);
+    if (!general_only)
         launch_timed(ctx, KID_SKM_COUNT, [&] {
             static const uint32_t bpc_env = getenv("SIMKA_SKM_BPC") ? (uint32_t)atoi(getenv("SIMKA_SKM_BPC")) : 0u;     // experiments
             const uint32_t bpc = bpc_env ? bpc_env : (uint32_t)std::max<size_t>(1, std::min<size_t>(4, (160 * 1024) / lds_fast));
-            hipLaunchKernelGGL(k_skm_count_fast, dim3((uint32_t)std::min<uint64_t>((ctx->nparts + 3) / 4, (uint64_t)ctx->num_cus * bpc)), dim3(SKM_FAST_BLOCK), lds_fast, st, (const uint4 *)L.d_skm_a,
-                               (const uint32_t *)L.d_pstart_dd, (const uint32_t *)L.d_pcnt_dd, sk, ctx->key, ctx->cfg.abundance_min, ctx->cfg.abundance_max, o, (const uint32_t *)flag, kocc,
+            hipLaunchKernelGGL(k_skm_count_fast, dim3((uint32_t)std::min<uint64_t>(ctx->nparts, (uint64_t)ctx->num_cus * bpc)), dim3(SKM_FAST_BLOCK), lds_fast, st, (const uint4 *)L.d_skm_b,
+                               (const uint32_t *)L.d_pstart, (const uint32_t *)L.d_pcnt, sk, ctx->key, ctx->cfg.abundance_min, ctx->cfg.abundance_max, o, (const uint32_t *)flag, kocc,
                                L.d_redo_list, L.d_redo_count);
         }, st);
-    }
     launch_timed(ctx, KID_COUNT, [&] {
         const uint32_t grid = general_only ? (uint32_t)std::min<uint64_t>(ctx->nparts, (uint64_t)ctx->num_cus * 2) : (uint32_t)ctx->num_cus;
         hipLaunchKernelGGL(k_skm_count, dim3(grid), dim3(SKM_CNT_BLOCK), lds_count, st, (const uint4 *)L.d_skm_b,
@@ -1733,7 +1741,7 @@ SIMKA_EXPORT int simka_device_memory(int device, uint64_t *free_bytes, uint64_t 
 
 SIMKA_EXPORT int simka_get_geometry(simka_ctx *ctx, uint32_t *l1, uint32_t *l2, uint32_t *t, uint64_t *arena, uint64_t *csr) {
     if (!ctx) return SIMKA_ERR_INVALID;
-    if (l1) *l1 = ctx->wide ? ctx->key.l1 : ctx->skm.l1; if (l2) *l2 = ctx->wide ? ctx->key.l2 : ctx->skm.l2 + ctx->skm.sb;      // (the sub-partition bits count as the second level) if (t) *t = ctx->key.t;
+    if (l1) *l1 = ctx->wide ? ctx->key.l1 : ctx->skm.l1; if (l2) *l2 = ctx->wide ? ctx->key.l2 : ctx->skm.l2; if (t) *t = ctx->key.t;
     if (arena) *arena = ctx->arena_cap; if (csr) *csr = ctx->merge_cap;
     return SIMKA_OK;
 }

@@ -7,10 +7,12 @@
 #define SIMKA_LDS_HEAD 512
 
 // count side: see simka_skm.hip (SKM_* geometry)
-#define K2_SLAB 1024          // arena records reserved per global atomic by a count wave (a sub-partition's solid records stay contiguous:
-                              // what is left of a slab when the next one does not fit is lost, so slabs are many sub-partitions long)
-#define SIMKA_TARGET_PER_PART 768    // sizing: k-mer occurrences per sub-partition (C3: 572, ~190 distinct; the fast count kernel's 512-slot
-                                     // table takes ~400 distinct k-mers, larger sub-partitions go through k_skm_count)
+#define K2_SLAB 4096          // arena records reserved per global atomic by a count block (a partition's solid records stay contiguous:
+                              // what is left of a slab when the next partition does not fit is lost, so slabs are several partitions long)
+#ifndef SIMKA_TARGET_PER_PART
+#define SIMKA_TARGET_PER_PART 3072   // sizing: k-mer occurrences per partition (minimizer partitions vary ~3x around it; the fast count
+                                     // kernel's 2048-slot table takes ~1500 distinct k-mers, larger partitions go through k_skm_count)
+#endif
 // K3  k_regroup / k_group
 #define K3_BLOCK 256
 #define K3_CAP 1024           // records hashed per round = entries per span

@@ -50,27 +50,22 @@ typedef unsigned long long ull;
 #define SKM_CNT_BLOCK 512
 #define SKM_CNT_TS 4096          // slots of the count kernel's LDS table
 #define SKM_CNT_BATCH 256        // records expanded per batch
-#define SKM_FAST_BLOCK 256       // k_skm_count_fast: 4 independent waves, a 512-slot table each, four blocks per CU
-#define SKM_FAST_TS 512
-#define SKM_FAST_TSL 9
-#define SKM_FAST_WCHUNK 32        // sub-partitions a wave takes per grab of the work counter
+#define SKM_FAST_BLOCK 256       // k_skm_count_fast: 4 waves, 2048 slots, four blocks per CU
+#define SKM_FAST_TS 2048
+#define SKM_FAST_WCHUNK 8         // partitions a block takes per grab of the work counter
 #ifndef SKM_FAST_U
 #define SKM_FAST_U 1             // k-mers per lane in flight in the insert loop (2: 1..5 % slower once the partitions are handed out dynamically; 4: three blocks per CU)
 #endif
 #define SKM_FAST_QCAP (64 + 64 * SKM_FAST_U)      // retry queue of a wave: what one iteration can add on top of an undrained rest
 #define SKM_FAST_BMW 32          // u64 words of a wave's record-start bitmap (64 records x nmax <= 32 k-mers)
-#define SKM_FAST_WREG ((SKM_FAST_TS * 12 + 64 * 16 + SKM_FAST_BMW * 8 + SKM_FAST_QCAP * 12 + 15) / 16 * 16)     // bytes of a wave's private LDS region (table, records, bitmap; queue: key 8 + slot 2 + multiplicity 2)
-#define SKM_DD_BLOCK 256         // k_skm_dedup: four independent waves, one partition at a time each
-#define SKM_DD_TS 1024           // slots of a wave's record table
-#define SKM_DD_MAXREC 1024       // records of a partition at most (beyond: passed through unchanged)
-#define SKM_DD_FASTR 8           // rounds of 64 records that the register-resident path takes
+#define SKM_FAST_WREG ((SKM_FAST_BMW * 8 + SKM_FAST_QCAP * 10 + 15) / 16 * 16)     // bytes of a wave's private LDS region
 #define SKM_SORT_BITS 3          // solid records leave the count kernel ordered by the top 3 bits of the slot hash
 #define SKM_NSORT (1 << SKM_SORT_BITS)
 
 struct SimkaSkmCfg {
     uint32_t k, W, m, nmax;          // k-mer size, m-mers per k-mer (k - m + 1), minimizer size, k-mers per record at most
     uint32_t mmask;                  // 2^(2m) - 1
-    uint32_t pb, l1, l2, sb;         // log2 #partitions = l1 + l2 + sb: level-1 buckets (scan), partitions of a bucket (split), sub-partitions (dedup)
+    uint32_t pb, l1, l2, l3;         // log2 #partitions = l1 + l2 + l3
     uint32_t shard_index, shard_count;   // this context keeps the partitions p with p % shard_count == shard_index
     uint64_t kmask;                  // 2^(2k) - 1
 };
@@ -93,26 +88,6 @@ __device__ __forceinline__ uint64_t skm_revcomp64(uint64_t x) {
     const uint64_t M5 = 0x5555555555555555ull;
     uint64_t r = __brevll(x);
     return (((r >> 1) & M5) | ((r & M5) << 1)) ^ 0xAAAAAAAAAAAAAAAAull;
-}
-
-// canonical orientation of a record: min(bases, reverse complement of the bases) as 2(n + k - 1)-bit integers -- both strands of a
-// genomic super-k-mer give the same record (its k-mers are the same canonical k-mers either way).  n and the partition id stay.
-__device__ __forceinline__ uint4 skm_rec_canon(const uint4 &r, uint32_t k) {
-    const uint32_t n1 = (r.w >> 6) & 31u, w6 = r.w & 63u;
-    const uint32_t s = 128u - 2u * (n1 + k);                      // the reverse complement of the 64-base word pair, moved down by 64 - T bases
-    const uint64_t vlo = ((uint64_t)r.y << 32) | r.x, vhi = ((uint64_t)w6 << 32) | r.z;
-    uint64_t rlo = skm_revcomp64(vhi), rhi = skm_revcomp64(vlo);
-    if (s >= 64u) { rlo = rhi >> ((s - 64u) & 63u); rhi = 0; }
-    else { rlo = (rlo >> (s & 63u)) | (rhi << ((64u - s) & 63u)); rhi >>= (s & 63u); }    // (s >= 26: T <= 51 bases)
-    const bool rev = rhi < vhi || (rhi == vhi && rlo < vlo);
-    const uint64_t lo = rev ? rlo : vlo, hi = rev ? rhi : vhi;
-    return make_uint4((uint32_t)lo, (uint32_t)(lo >> 32), (uint32_t)hi, (uint32_t)(hi >> 32) | (r.w & ~63u));
-}
-// 32-bit hash of (bases, n)
-__device__ __forceinline__ uint32_t skm_rec_hash(uint32_t x, uint32_t y, uint32_t z, uint32_t w) {
-    uint32_t h = x * 0x9E3779B1u + y * 0x85EBCA6Bu + z * 0xC2B2AE35u + w * 0x27D4EB2Fu;
-    h ^= h >> 15;
-    return h * 0x2C1B3C6Du;
 }
 
 // --------------------------------------------------------------------------------------------
@@ -498,9 +473,9 @@ k_skm_split(const uint4 *l1_recs, const uint32_t *l1_pid, const ull *b1_start, c
     if (*flag) return;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     uint32_t *lh = (uint32_t *)smem;                   // [F2] counts, then cursors
-    uint32_t *wsum = lh + (1u << cfg.l2);              // [16]
+    uint32_t *wsum = lh + (1u << (cfg.pb - cfg.l1));   // [16]
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
-    const uint32_t l2 = cfg.l2, F2 = 1u << l2, m2 = F2 - 1u, sb = cfg.sb;       // (a record's id: bucket | partition of the bucket | sub-partition)
+    const uint32_t l2 = cfg.pb - cfg.l1, F2 = 1u << l2, m2 = F2 - 1u;
     const uint32_t b1 = blockIdx.x;
     const ull st = b1_start[b1];
     const ull n = b1_count[b1];
@@ -515,7 +490,7 @@ k_skm_split(const uint4 *l1_recs, const uint32_t *l1_pid, const ull *b1_start, c
 #pragma unroll
             for (int u = 0; u < SKM_SPLIT_UNROLL; u++) { const ull i = i0 + STEP + (ull)u * SKM_SPLIT_BLOCK + tid; wn[u] = i < n ? l1_pid[st + i] : 0u; }
 #pragma unroll
-            for (int u = 0; u < SKM_SPLIT_UNROLL; u++) { const ull i = i0 + (ull)u * SKM_SPLIT_BLOCK + tid; if (i < n) atomicAdd(&lh[(w[u] >> sb) & m2], 1u); }
+            for (int u = 0; u < SKM_SPLIT_UNROLL; u++) { const ull i = i0 + (ull)u * SKM_SPLIT_BLOCK + tid; if (i < n) atomicAdd(&lh[w[u] & m2], 1u); }
 #pragma unroll
             for (int u = 0; u < SKM_SPLIT_UNROLL; u++) w[u] = wn[u];
         }
@@ -552,7 +527,7 @@ k_skm_split(const uint4 *l1_recs, const uint32_t *l1_pid, const ull *b1_start, c
         for (uint32_t i = tid; i < (F2 + 1) / 2; i += SKM_SPLIT_BLOCK) ((uint32_t *)ch)[i] = 0;
         uint4 rec[SKM_SPLIT_UNROLL]; uint32_t lr[SKM_SPLIT_UNROLL];
 #pragma unroll
-        for (int u = 0; u < SKM_SPLIT_UNROLL; u++) { const ull i = i0 + (ull)u * SKM_SPLIT_BLOCK + tid; if (i < n) rec[u] = skm_rec_canon(l1_recs[st + i], cfg.k); }       // (canonical orientation: k_skm_dedup compares records)
+        for (int u = 0; u < SKM_SPLIT_UNROLL; u++) { const ull i = i0 + (ull)u * SKM_SPLIT_BLOCK + tid; if (i < n) rec[u] = l1_recs[st + i]; }
         __syncthreads();
         // rank inside the chunk's run of the partition: 16-bit counters, two per word (the returning atomic works on the word)
 #pragma unroll
@@ -560,7 +535,7 @@ k_skm_split(const uint4 *l1_recs, const uint32_t *l1_pid, const ull *b1_start, c
             const ull i = i0 + (ull)u * SKM_SPLIT_BLOCK + tid;
             lr[u] = 0;
             if (i < n) {
-                const uint32_t b2 = (skm_rec_pid(rec[u]) >> sb) & m2, sh = (b2 & 1u) * 16u;
+                const uint32_t b2 = skm_rec_pid(rec[u]) & m2, sh = (b2 & 1u) * 16u;
                 lr[u] = (atomicAdd((uint32_t *)ch + (b2 >> 1), 1u << sh) >> sh) & 0xffffu;
             }
         }
@@ -582,202 +557,19 @@ k_skm_split(const uint4 *l1_recs, const uint32_t *l1_pid, const ull *b1_start, c
 #pragma unroll
         for (int u = 0; u < SKM_SPLIT_UNROLL; u++) {
             const ull i = i0 + (ull)u * SKM_SPLIT_BLOCK + tid;
-            if (i < n) stage[ch[(skm_rec_pid(rec[u]) >> sb) & m2] + lr[u]] = rec[u];
+            if (i < n) stage[ch[skm_rec_pid(rec[u]) & m2] + lr[u]] = rec[u];
         }
         __syncthreads();
         const uint32_t nc = (uint32_t)(n - i0 < (ull)STEP ? n - i0 : (ull)STEP);
         for (uint32_t sidx = tid; sidx < nc; sidx += SKM_SPLIT_BLOCK) {
             const uint4 r = stage[sidx];
-            const uint32_t b2 = (skm_rec_pid(r) >> sb) & m2;
+            const uint32_t b2 = skm_rec_pid(r) & m2;
             out_recs[st + lh[b2] + (sidx - ch[b2])] = r;
         }
         __syncthreads();
         // the partitions' cursors move past this chunk: count of partition i = start of i + 1 (or the chunk's end) - start of i
         for (uint32_t i = tid; i < F2; i += SKM_SPLIT_BLOCK) lh[i] += (i + 1 < F2 ? (uint32_t)ch[i + 1] : nc) - (uint32_t)ch[i];
         __syncthreads();
-    }
-}
-
-// --------------------------------------------------------------------------------------------
-// k_skm_dedup: identical records of a partition are counted FIRST, and the partition is cut into its 2^sb sub-partitions.
-// At sequencing depth a genomic super-k-mer comes back once per read that covers it (C3: 100 % of the records -> 44 % distinct,
-// their k-mers -> 46 %), and a record repeated c times only has to be expanded once, its k-mers adding c.  One WAVE per partition,
-// no block-level synchronisation: the (canonical, see k_skm_split) records are hashed into a wave-private LDS table with a 32-bit
-// CAS (record index | 22-bit fingerprint); a record that finds its fingerprint there compares itself with the claimant (read back
-// from global memory: the partition's few KB are cache-resident) and, if equal, bumps the claimant's 16-bit counter and dies.  Two
-// probes, then a record just stays its own representative (deduplication is an optimisation, never a requirement).  Second pass:
-// the representatives leave ordered by sub-partition (the low sb bits of their id: a function of the minimizer, like the partition),
-// each sub-partition dense, their multiplicity where the id was (w = base bits | (n - 1) << 6 | multiplicity << 11).  A partition
-// of more than SKM_DD_MAXREC records is only cut, every record with multiplicity 1.
-// --------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(SKM_DD_BLOCK)
-k_skm_dedup(const uint4 *recs, const uint32_t *pstart, const uint32_t *pcnt, SimkaSkmCfg cfg, uint4 *out, uint32_t *pstart_out, uint32_t *pcnt_out, const uint32_t *flag) {
-    if (*flag) return;
-    __shared__ __attribute__((aligned(16))) uint32_t s_tab[SKM_DD_BLOCK / 64][SKM_DD_TS];
-    __shared__ __attribute__((aligned(16))) uint32_t s_mult[SKM_DD_BLOCK / 64][SKM_DD_MAXREC / 2];
-    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-    uint32_t *tab = s_tab[wave], *mult = s_mult[wave];
-    const uint32_t sb = cfg.sb, nsub = 1u << sb, smask = nsub - 1u;       // (sb <= 2)
-    const uint32_t ncoarse = 1u << (cfg.pb - sb);
-    const uint32_t nwaves = gridDim.x * (SKM_DD_BLOCK / 64);
-    for (uint32_t p = blockIdx.x * (SKM_DD_BLOCK / 64) + wave; p < ncoarse; p += nwaves) {
-        const uint32_t n = pcnt[p];
-        const uint32_t base = pstart[p];
-        if (n == 0) { if (lane < nsub) { pcnt_out[(p << sb) | lane] = 0; pstart_out[(p << sb) | lane] = base; } continue; }
-        const uint32_t R = (n + 63u) >> 6;
-        uint32_t cnt0 = 0, cnt1 = 0, cnt2 = 0, cnt3 = 0;          // representatives per sub-partition (wave-uniform)
-        if (R <= SKM_DD_FASTR) {
-            // ---- the common case: the whole partition in registers, every phase issued for all rounds before its results are
-            // looked at (a wave is a chain of memory round trips; per round they would add up)
-            uint4 rc[SKM_DD_FASTR];
-#pragma unroll
-            for (uint32_t r = 0; r < SKM_DD_FASTR; r++) { rc[r] = make_uint4(0, 0, 0, 0); if ((r << 6) + lane < n) rc[r] = recs[base + (r << 6) + lane]; }
-            {
-                const uint4 e4 = make_uint4(~0u, ~0u, ~0u, ~0u), z4 = make_uint4(0, 0, 0, 0);
-#pragma unroll
-                for (uint32_t i = 0; i < SKM_DD_TS / 256; i++) ((uint4 *)tab)[i * 64u + lane] = e4;
-                if (lane < (n + 7u) / 8u) ((uint4 *)mult)[lane] = z4;        // (n <= 512: 64 x 8 counters)
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            }
-            uint32_t hh[SKM_DD_FASTR], prev[SKM_DD_FASTR];
-            uint4 ot[SKM_DD_FASTR];
-            bool live[SKM_DD_FASTR], again[SKM_DD_FASTR];
-            // first probe: CAS of every round (LDS serves them in order: a later round sees the claims of the earlier ones)
-#pragma unroll
-            for (uint32_t r = 0; r < SKM_DD_FASTR; r++) {
-                const uint32_t i = (r << 6) + lane;
-                live[r] = i < n; again[r] = false; prev[r] = ~0u;
-                hh[r] = skm_rec_hash(rc[r].x, rc[r].y, rc[r].z, rc[r].w & 0x7ffu);
-                if (r < R && live[r]) prev[r] = atomicCAS(&tab[hh[r] >> 22], ~0u, (i << 22) | (hh[r] & 0x3fffffu));
-            }
-            // the claimants whose fingerprint matches: all loads in flight together
-#pragma unroll
-            for (uint32_t r = 0; r < SKM_DD_FASTR; r++) {
-                ot[r] = make_uint4(0, 0, 0, 0);
-                if (r < R && prev[r] != ~0u) { if (((prev[r] ^ hh[r]) & 0x3fffffu) == 0u) ot[r] = recs[base + (prev[r] >> 22)]; else again[r] = true; }
-            }
-#pragma unroll
-            for (uint32_t r = 0; r < SKM_DD_FASTR; r++) {
-                if (r < R && prev[r] != ~0u && !again[r]) {
-                    if (ot[r].x == rc[r].x && ot[r].y == rc[r].y && ot[r].z == rc[r].z && ((ot[r].w ^ rc[r].w) & 0x7ffu) == 0u) { const uint32_t j = prev[r] >> 22; atomicAdd(&mult[j >> 1], 1u << ((j & 1u) * 16u)); live[r] = false; }
-                    else again[r] = true;
-                }
-            }
-            // second probe of the records whose slot holds another record
-#pragma unroll
-            for (uint32_t r = 0; r < SKM_DD_FASTR; r++) {
-                prev[r] = ~0u;
-                if (r < R && again[r]) prev[r] = atomicCAS(&tab[((hh[r] >> 22) + 1u) & (SKM_DD_TS - 1u)], ~0u, ((((r << 6) + lane) << 22)) | (hh[r] & 0x3fffffu));
-            }
-#pragma unroll
-            for (uint32_t r = 0; r < SKM_DD_FASTR; r++) {
-                again[r] = r < R && prev[r] != ~0u && ((prev[r] ^ hh[r]) & 0x3fffffu) == 0u;
-                if (again[r]) ot[r] = recs[base + (prev[r] >> 22)];
-            }
-#pragma unroll
-            for (uint32_t r = 0; r < SKM_DD_FASTR; r++) {
-                if (again[r] && ot[r].x == rc[r].x && ot[r].y == rc[r].y && ot[r].z == rc[r].z && ((ot[r].w ^ rc[r].w) & 0x7ffu) == 0u) { const uint32_t j = prev[r] >> 22; atomicAdd(&mult[j >> 1], 1u << ((j & 1u) * 16u)); live[r] = false; }
-            }
-            uint32_t sub[SKM_DD_FASTR];
-#pragma unroll
-            for (uint32_t r = 0; r < SKM_DD_FASTR; r++) {
-                sub[r] = (rc[r].w >> 11) & smask;
-                if (r < R) {
-                    cnt0 += (uint32_t)__popcll(__ballot(live[r] && sub[r] == 0u));
-                    if (sb) cnt1 += (uint32_t)__popcll(__ballot(live[r] && sub[r] == 1u));
-                    if (sb > 1u) { cnt2 += (uint32_t)__popcll(__ballot(live[r] && sub[r] == 2u)); cnt3 += (uint32_t)__popcll(__ballot(live[r] && sub[r] == 3u)); }
-                }
-            }
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            uint32_t run0 = 0, run1 = cnt0, run2 = cnt0 + cnt1, run3 = cnt0 + cnt1 + cnt2;
-            if (lane < nsub) {
-                const uint32_t st_ = lane == 0u ? run0 : lane == 1u ? run1 : lane == 2u ? run2 : run3, c_ = lane == 0u ? cnt0 : lane == 1u ? cnt1 : lane == 2u ? cnt2 : cnt3;
-                pstart_out[(p << sb) | lane] = base + st_; pcnt_out[(p << sb) | lane] = c_;
-            }
-#pragma unroll
-            for (uint32_t r = 0; r < SKM_DD_FASTR; r++) {
-                if (r < R) {
-                    const uint32_t i = (r << 6) + lane;
-                    uint32_t m = 1u;
-                    if (live[r]) m += (mult[i >> 1] >> ((i & 1u) * 16u)) & 0xffffu;
-                    const ull m0 = __ballot(live[r] && sub[r] == 0u), m1 = __ballot(live[r] && sub[r] == 1u), m2 = __ballot(live[r] && sub[r] == 2u), m3 = __ballot(live[r] && sub[r] == 3u);
-                    const ull mine = sub[r] == 0u ? m0 : sub[r] == 1u ? m1 : sub[r] == 2u ? m2 : m3;
-                    const uint32_t runs = sub[r] == 0u ? run0 : sub[r] == 1u ? run1 : sub[r] == 2u ? run2 : run3;
-                    if (live[r]) out[base + runs + __builtin_amdgcn_mbcnt_hi((uint32_t)(mine >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mine, 0u))] = make_uint4(rc[r].x, rc[r].y, rc[r].z, (rc[r].w & 0x7ffu) | (m << 11));
-                    run0 += (uint32_t)__popcll(m0); run1 += (uint32_t)__popcll(m1); run2 += (uint32_t)__popcll(m2); run3 += (uint32_t)__popcll(m3);
-                }
-            }
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // the table and the counters are rewritten for the next partition
-            continue;
-        }
-        // ---- a large partition: round by round, the records read again in the second pass
-        const bool dedup = n <= SKM_DD_MAXREC;
-        uint32_t livemask = 0;
-        if (dedup) {
-            const uint4 e4 = make_uint4(~0u, ~0u, ~0u, ~0u), z4 = make_uint4(0, 0, 0, 0);
-#pragma unroll
-            for (uint32_t i = 0; i < SKM_DD_TS / 256; i++) ((uint4 *)tab)[i * 64u + lane] = e4;
-            for (uint32_t i = lane; i < (n + 7u) / 8u; i += 64u) ((uint4 *)mult)[i] = z4;
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        }
-        {
-            uint4 nx = make_uint4(0, 0, 0, 0);
-            if (lane < n) nx = recs[base + lane];
-            for (uint32_t r = 0; r < R; r++) {
-                const uint32_t i = (r << 6) + lane;
-                const bool valid = i < n;
-                const uint4 rc = nx;
-                if (i + 64u < n) nx = recs[base + i + 64u];
-                bool live = valid;
-                if (dedup) {
-                    const uint32_t w = rc.w & 0x7ffu;
-                    const uint32_t h = skm_rec_hash(rc.x, rc.y, rc.z, w);
-                    const uint32_t fp = h & 0x3fffffu, entry = (i << 22) | fp;
-                    uint32_t slot = h >> 22;
-                    bool searching = valid;
-#pragma unroll
-                    for (int probe = 0; probe < 2; probe++) {
-                        if (searching) {
-                            const uint32_t prev = atomicCAS(&tab[slot], ~0u, entry);
-                            if (prev == ~0u) searching = false;
-                            else if ((prev & 0x3fffffu) == fp) {
-                                const uint32_t j = prev >> 22;
-                                const uint4 ot = recs[base + j];
-                                if (ot.x == rc.x && ot.y == rc.y && ot.z == rc.z && (ot.w & 0x7ffu) == w) { atomicAdd(&mult[j >> 1], 1u << ((j & 1u) * 16u)); live = false; searching = false; }
-                            }
-                            slot = (slot + 1u) & (SKM_DD_TS - 1u);
-                        }
-                    }
-                    livemask |= (live ? 1u : 0u) << (r & 31u);
-                }
-                const uint32_t sub = (rc.w >> 11) & smask;
-                cnt0 += (uint32_t)__popcll(__ballot(live && sub == 0u));
-                if (sb) cnt1 += (uint32_t)__popcll(__ballot(live && sub == 1u));
-                if (sb > 1u) { cnt2 += (uint32_t)__popcll(__ballot(live && sub == 2u)); cnt3 += (uint32_t)__popcll(__ballot(live && sub == 3u)); }
-            }
-        }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        // sub-partition s starts at base + (representatives of the subs before it)
-        uint32_t run0 = 0, run1 = cnt0, run2 = cnt0 + cnt1, run3 = cnt0 + cnt1 + cnt2;
-        if (lane < nsub) {
-            const uint32_t st_ = lane == 0u ? run0 : lane == 1u ? run1 : lane == 2u ? run2 : run3, c_ = lane == 0u ? cnt0 : lane == 1u ? cnt1 : lane == 2u ? cnt2 : cnt3;
-            pstart_out[(p << sb) | lane] = base + st_; pcnt_out[(p << sb) | lane] = c_;
-        }
-        for (uint32_t r = 0; r < R; r++) {
-            const uint32_t i = (r << 6) + lane;
-            const bool live = dedup ? ((livemask >> (r & 31u)) & 1u) != 0u : i < n;
-            if (__ballot(live) == 0ull) continue;
-            uint4 rc = make_uint4(0, 0, 0, 0);
-            uint32_t m = 1u;
-            if (live) { rc = recs[base + i]; if (dedup) m += (mult[i >> 1] >> ((i & 1u) * 16u)) & 0xffffu; }
-            const uint32_t sub = (rc.w >> 11) & smask;
-            const ull m0 = __ballot(live && sub == 0u), m1 = __ballot(live && sub == 1u), m2 = __ballot(live && sub == 2u), m3 = __ballot(live && sub == 3u);
-            const ull mine = sub == 0u ? m0 : sub == 1u ? m1 : sub == 2u ? m2 : m3;
-            const uint32_t runs = sub == 0u ? run0 : sub == 1u ? run1 : sub == 2u ? run2 : run3;
-            if (live) out[base + runs + __builtin_amdgcn_mbcnt_hi((uint32_t)(mine >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mine, 0u))] = make_uint4(rc.x, rc.y, rc.z, (rc.w & 0x7ffu) | (m << 11));
-            run0 += (uint32_t)__popcll(m0); run1 += (uint32_t)__popcll(m1); run2 += (uint32_t)__popcll(m2); run3 += (uint32_t)__popcll(m3);
-        }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // the table and the counters are rewritten for the next partition
     }
 }
 
@@ -833,10 +625,10 @@ k_skm_count(const uint4 *recs, const uint32_t *pstart, const uint32_t *pcnt, Sim
 
     const uint32_t nwork = part_list ? (uint32_t)(*part_count < (ull)nparts ? *part_count : (ull)nparts) : nparts;
     for (uint32_t wi_ = blockIdx.x; wi_ < nwork; wi_ += gridDim.x) {
-        const uint32_t part = part_list ? part_list[wi_] : wi_;       // a sub-partition: the records of its partition with its id
-        const uint32_t nrec = pcnt[part >> cfg.sb];
+        const uint32_t part = part_list ? part_list[wi_] : wi_;
+        const uint32_t nrec = pcnt[part];
         if (nrec == 0) continue;                       // (foff / fcnt of the sample were zeroed by the host)
-        const uint32_t rbase = pstart[part >> cfg.sb];
+        const uint32_t rbase = pstart[part];
         uint32_t rho = 0;                              // log2 #rounds
         bool done = false;
         while (!done) {
@@ -867,7 +659,7 @@ k_skm_count(const uint4 *recs, const uint32_t *pstart, const uint32_t *pcnt, Sim
                         __syncthreads();
                         const uint32_t nb = nrec - b0 < (uint32_t)SKM_CNT_BATCH ? nrec - b0 : (uint32_t)SKM_CNT_BATCH;
                         uint32_t len = 0;
-                        if (tid < nb) { const uint4 rc = recs[rbase + b0 + tid]; lrec[tid] = rc; len = skm_rec_pid(rc) == part ? skm_rec_n(rc) : 0u; }
+                        if (tid < nb) { const uint4 rc = recs[rbase + b0 + tid]; lrec[tid] = rc; len = skm_rec_n(rc); }
                         uint32_t x = len;
 #pragma unroll
                         for (int o_ = 1; o_ < 64; o_ <<= 1) { const uint32_t t = __shfl_up(x, o_, 64); if (lane >= (uint32_t)o_) x += t; }
@@ -981,277 +773,355 @@ k_skm_count(const uint4 *recs, const uint32_t *pstart, const uint32_t *pcnt, Sim
 
 
 // --------------------------------------------------------------------------------------------
-// k_skm_count_fast: the common case of k_skm_count -- a sub-partition whose distinct k-mers fit a 512-slot table in one round.
-// ONE WAVE PER SUB-PARTITION, no block-level synchronisation at all: a block is four independent waves, each with a private LDS
-// region (table 6 KB, record copies, bitmap, retry queue).  With the records deduplicated (k_skm_dedup) a sub-partition is ~32 records
-// / ~260 k-mers / ~190 distinct k-mers: what bounds the kernel is the chain of LDS round trips per work item, so what counts is how
-// many independent chains a CU runs (16 waves) and that no wave ever waits for another.
-//   * input: the records of k_skm_dedup: w = base bits | (n - 1) << 6 | multiplicity << 11; a k-mer of a record adds the multiplicity;
-//   * the wave expands its records 64 at a time: the records go to an LDS copy together with the index of their first k-mer among the
-//     round's k-mers, and ONE bit per record marks that index in a bitmap.  K-mer f then finds its record with two mbcnt (records
-//     before f = set bits below f; the 64 bits of a chunk of k-mers are wave-uniform), cuts itself out of the record (funnel shift),
-//     reverse complement, canonical, slot hash;
-//   * ONE straight-line insert (64-bit CAS + counter add).  A k-mer that finds its slot taken by another k-mer does not loop: ballot +
-//     mbcnt compact the losers into a retry queue (key, next slot, multiplicity), drained 64 dense lanes at a time;
-//   * the records and the descriptor of the NEXT sub-partition are loaded (registers) before this one is expanded;
-//   * summary: every lane owns 8 slots: abundance filter + D / N / Q (SimkaCompressedProcessor::process, ref: src/minikc/MiniKC.hpp:54-79),
-//     the solid records leave in slot order through an LDS staging area (coalesced stores) into the wave's arena slab.
-// Work items (sub-partitions this shard owns) are handed out dynamically, 32 at a time per grab of a global counter.
-// A sub-partition whose inserts fail (table full) goes to the redo list (k_skm_count takes it in rounds).
+// k_skm_count_fast: the common case of k_skm_count -- the partition's distinct k-mers fit the table in ONE round.
+//   * every wave expands its own 64 records: the records go to a wave-private LDS copy together with the index of their first
+//     k-mer among the wave's k-mers, and ONE bit per record marks that index in a bitmap.  K-mer f of the wave then finds its
+//     record with two mbcnt (records before f = set bits below f; the 64 bits of a chunk of k-mers are wave-uniform), cuts
+//     itself out of the record (funnel shift), reverse complement, canonical, slot hash;
+//   * SKM_FAST_U k-mers per lane are in flight through ONE straight-line insert (64-bit CAS + counter add).  A k-mer that finds
+//     its slot taken by another k-mer does not loop: ballot + mbcnt compact the losers into a wave-private retry queue (key, next
+//     slot), and the queue is drained 64 dense lanes at a time -- so a wave never idles 60 lanes while 4 keep probing;
+//   * the records of the NEXT partition are loaded (registers) before the summary of this one;
+//   * arena slab state double-buffered in LDS, so the emit needs no barrier of its own.
+// A partition whose inserts overflow a sort block of the table goes to the redo list (k_skm_count takes it in rounds).
 // --------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(SKM_FAST_BLOCK, 4)
+__global__ void __launch_bounds__(SKM_FAST_BLOCK)
 k_skm_count_fast(const uint4 *recs, const uint32_t *pstart, const uint32_t *pcnt, SimkaSkmCfg cfg, SimkaKeyCfg kcfg, uint32_t amin, uint32_t amax, SimkaCountOut o,
                  const uint32_t *flag, ull *kocc_owned, uint32_t *redo_list, ull *redo_count) {
     if (*flag) return;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    ull *s_tot = (ull *)smem;                          // [5] block totals (end of the kernel)
-    constexpr uint32_t TS = SKM_FAST_TS, SPT = TS / 64u, TSL = SKM_FAST_TSL, NW = SKM_FAST_BLOCK / 64;
-    uint32_t *lhist = (uint32_t *)(smem + SIMKA_LDS_HEAD);          // [SIMKA_HIST_MAX] (complex only), shared by the block's waves
-    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
-    unsigned char *wreg = smem + SIMKA_LDS_HEAD + (o.hist ? SIMKA_HIST_MAX * 4 : 0) + wave * SKM_FAST_WREG;      // the wave's private region
-    ull *tkeys = (ull *)wreg;                          // [TS]
+    ull *s_tot = (ull *)smem;                          // [5]
+    ull &s_base = *(ull *)(smem + 48);
+    uint32_t &s_fail = *(uint32_t *)(smem + 56);
+    uint32_t &s_ok = *(uint32_t *)(smem + 60);
+    ull *s_slab = (ull *)(smem + 64);                  // [2][2] (pos, end), double-buffered by iteration parity
+    uint32_t *tmp = (uint32_t *)(smem + 128);          // [BLOCK/64]
+    constexpr uint32_t TS = SKM_FAST_TS, SPT = TS / SKM_FAST_BLOCK, TSL = 11, NW = SKM_FAST_BLOCK / 64;
+    ull *tkeys = (ull *)(smem + SIMKA_LDS_HEAD);       // [TS]
     uint32_t *tcnt = (uint32_t *)(tkeys + TS);         // [TS]
-    uint4 *wrec = (uint4 *)(tcnt + TS);                // [64] the round's records
-    ull *bm64 = (ull *)(wrec + 64);                    // [SKM_FAST_BMW] bit f set: a record starts at k-mer f
-    ull *qk = bm64 + SKM_FAST_BMW;                     // [QCAP] retry queue: canonical k-mers ...
-    uint16_t *qm = (uint16_t *)(qk + SKM_FAST_QCAP);   // [QCAP] ... the slot to try next | passes << TSL ...
-    uint16_t *qx = qm + SKM_FAST_QCAP;                 // [QCAP] ... and what to add (the record's multiplicity)
+    uint4 *lrec = (uint4 *)(tcnt + TS);                // [BLOCK]: 64 per wave
+    uint32_t *lhist = (uint32_t *)(lrec + SKM_FAST_BLOCK);     // [SIMKA_HIST_MAX] (complex only)
+    unsigned char *wreg0 = (unsigned char *)(lhist + (o.hist ? SIMKA_HIST_MAX : 0));     // [NW][SKM_FAST_WREG] wave-private regions
 
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     const uint32_t nparts = 1u << cfg.pb;
     const ull sample_base = *o.sample_base;
-    for (uint32_t i = lane; i < TS; i += 64u) { tkeys[i] = SIMKA_EMPTY_KEY; tcnt[i] = 0; }
+    for (uint32_t i = tid; i < TS; i += SKM_FAST_BLOCK) { tkeys[i] = SIMKA_EMPTY_KEY; tcnt[i] = 0; }
     if (o.hist) for (uint32_t i = tid; i < SIMKA_HIST_MAX; i += SKM_FAST_BLOCK) lhist[i] = 0;
     if (tid < 5) s_tot[tid] = 0;
-    __syncthreads();                                   // (the only barrier before the end of the kernel)
+    if (tid < 4) s_slab[tid] = 0;
+    if (tid == 0) s_fail = 0;
     ull bt_dall = 0, bt_D = 0, bt_N = 0, bt_Q = 0, bt_kocc = 0;
-    ull slab_pos = 0, slab_end = 0;                    // the wave's arena slab (wave-uniform)
-    uint32_t qn = 0;                                   // entries in the queue (wave-uniform)
-    bool gave_up = false;                              // a k-mer of this lane found no slot: the sub-partition goes to the redo list
-    // one dense pass over the tail of the retry queue.  An entry = (k-mer, next slot to try | passes << TSL, multiplicity).  The lane
-    // LOOKS at four slots ahead (plain reads, one LDS round trip): a slot that holds another k-mer keeps it for the rest of the
-    // sub-partition, so it can be skipped without an atomic; the first slot that holds this k-mer takes a plain counter add, the first
-    // empty one a CAS.  Only a CAS lost to another k-mer, or four occupied slots, send the entry back.  After 127 passes the k-mer
-    // gives up (the table is full).
+    PH_DECL
+#ifdef SIMKA_PHASE_PROF
+    const ull blk_t0 = wall_clock64();
+    ull dbg[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#define DBG_ADD(i, v) { if (lane == 0) dbg[(i) - 8] += (ull)(v); }
+#else
+#define DBG_ADD(i, v)
+#endif
+    uint4 *wrec = lrec + wave * 64u;
+    ull *bm64 = (ull *)(wreg0 + wave * SKM_FAST_WREG);              // [SKM_FAST_BMW] bit f set: a record starts at k-mer f
+    ull *qk = bm64 + SKM_FAST_BMW;                                  // [QCAP] retry queue: canonical k-mers ...
+    uint16_t *qm = (uint16_t *)(qk + SKM_FAST_QCAP);                // [QCAP] ... and the slot to try next
+    constexpr uint32_t bmask = (TS >> SKM_SORT_BITS) - 1u;        // probing stays inside the sort block (TS / 8 slots)
+    constexpr uint32_t U = SKM_FAST_U;
+    uint32_t qn = 0;                                                // entries in the queue (wave-uniform)
+    // one dense pass over the tail of the retry queue.  An entry = (k-mer, next slot to try | passes << 11).  The lane LOOKS at four
+    // slots ahead (plain reads, one LDS round trip): a slot that holds another k-mer keeps it for the rest of the partition, so
+    // it can be skipped without an atomic; the first slot that holds this k-mer takes a plain counter add, the first empty one a
+    // CAS.  Only a CAS lost to another k-mer, or four occupied slots, send the entry back -- the tail of a wave's queue empties in
+    // one or two passes instead of one pass per probe.  After 31 passes (124 slots) the k-mer gives up: redo list.
     auto drain = [&]() {
         const uint32_t n = qn < 64u ? qn : 64u;
         const uint32_t e = qn - n + lane;
         const bool a = lane < n;
-        ull key = 0; uint32_t meta = 0, mult = 0;
-        if (a) { key = qk[e]; meta = qm[e]; mult = qx[e]; }
+        ull key = 0; uint32_t meta = 0;
+        if (a) { key = qk[e]; meta = qm[e]; }
         qn -= n;
         bool again = false;
         uint32_t slot = meta & (TS - 1u);
         if (a) {
-            const uint32_t s1 = (slot + 1u) & (TS - 1u), s2 = (slot + 2u) & (TS - 1u), s3 = (slot + 3u) & (TS - 1u);
+            const uint32_t bb = slot & ~bmask;
+            const uint32_t s1 = bb | ((slot + 1u) & bmask), s2 = bb | ((slot + 2u) & bmask), s3 = bb | ((slot + 3u) & bmask);
             const ull w0 = tkeys[slot], w1 = tkeys[s1], w2 = tkeys[s2], w3 = tkeys[s3];
             const bool h0 = w0 == SIMKA_EMPTY_KEY || w0 == key, h1 = w1 == SIMKA_EMPTY_KEY || w1 == key, h2 = w2 == SIMKA_EMPTY_KEY || w2 == key, h3 = w3 == SIMKA_EMPTY_KEY || w3 == key;
             const uint32_t st = h0 ? slot : h1 ? s1 : h2 ? s2 : s3;
             const ull ws = h0 ? w0 : h1 ? w1 : h2 ? w2 : w3;
-            if (!(h0 || h1 || h2 || h3)) { again = true; slot = (slot + 4u) & (TS - 1u); }
-            else if (ws == key) atomicAdd(&tcnt[st], mult);
+            if (!(h0 || h1 || h2 || h3)) { again = true; slot = bb | ((slot + 4u) & bmask); }
+            else if (ws == key) atomicAdd(&tcnt[st], 1u);
             else {
                 const ull prev = atomicCAS(&tkeys[st], SIMKA_EMPTY_KEY, key);
-                if (prev == SIMKA_EMPTY_KEY || prev == key) atomicAdd(&tcnt[st], mult);
-                else { again = true; slot = (st + 1u) & (TS - 1u); }
+                if (prev == SIMKA_EMPTY_KEY || prev == key) atomicAdd(&tcnt[st], 1u);
+                else { again = true; slot = bb | ((st + 1u) & bmask); }
             }
             if (again) {
-                const uint32_t passes = (meta >> TSL) + 1u;
-                if (passes >= (1u << (16u - TSL))) { gave_up = true; again = false; }
-                meta = slot | (passes << TSL);
+                const uint32_t passes = (meta >> 11) + 1u;
+                if (passes >= 32u) { s_fail = 1u; again = false; }
+                meta = slot | (passes << 11);
             }
         }
         const ull am = __ballot(again);
         if (am) {
-            if (again) { const uint32_t pos = qn + __builtin_amdgcn_mbcnt_hi((uint32_t)(am >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)am, 0u)); qk[pos] = key; qm[pos] = (uint16_t)meta; qx[pos] = (uint16_t)mult; }
+            if (again) { const uint32_t pos = qn + __builtin_amdgcn_mbcnt_hi((uint32_t)(am >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)am, 0u)); qk[pos] = key; qm[pos] = (uint16_t)meta; }
             qn += (uint32_t)__popcll(am);
         }
     };
 
-    // Work items = the sub-partitions this shard (or pass) owns, handed out DYNAMICALLY in chunks of SKM_FAST_WCHUNK: chunk `wave id`
-    // first, then whatever the global counter says.  Lane 0 grabs the chunk after next at the first item of a chunk (a returning
-    // global atomic, long back when its value is looked at, at the end of that item).
+    // Work items = the partitions this shard (or pass) owns, handed out DYNAMICALLY in chunks of SKM_FAST_WCHUNK: chunk blockIdx.x
+    // first, then whatever the global counter says (one word serves ~90 grabs per microsecond: one grab per partition would cap
+    // the kernel at 6 ms per C3 sample, one per 8 partitions costs nothing).  Thread 0 grabs the chunk after next at the first item
+    // of a chunk (a returning global atomic, long back when it is needed) and publishes it in LDS before the summary barrier.
     const uint32_t sh_c = cfg.shard_count, sh_i = cfg.shard_index;
     const uint32_t nwork = nparts > sh_i ? (nparts - sh_i + sh_c - 1u) / sh_c : 0u;
     auto part_of = [&](uint32_t j_) -> uint32_t { return j_ < nwork ? j_ * sh_c + sh_i : 0xffffffffu; };
+    uint32_t *s_next = (uint32_t *)(smem + 96);       // [2] the chunk after next, double-buffered
     ull *work_counter = redo_count + 1;
-    const uint32_t nwv = gridDim.x * NW, wid = blockIdx.x * NW + wave;
-    // (a handful of sub-partitions per wave -- small samples: nothing to balance, static stride without any atomic)
-    const bool dyn = nwork >= nwv * 16u;
-    const uint32_t wchunk = dyn ? min((uint32_t)SKM_FAST_WCHUNK, max(1u, nwork / (nwv * 4u))) : 1u;
-    uint32_t chunk_n = wid + nwv, chunk_n2 = 0;       // the next chunk, the one after it
-    if (dyn) { uint32_t g = 0; if (lane == 0) g = (uint32_t)atomicAdd(work_counter, 1ull); chunk_n = nwv + (uint32_t)__builtin_amdgcn_readfirstlane((int)g); }
-    uint32_t wpos = 0, item = wid * wchunk;
+    // (a handful of partitions per block -- small samples: nothing to balance, static stride without any atomic)
+    const bool dyn = nwork >= gridDim.x * 16u;
+    if (dyn && tid == 0) s_next[0] = gridDim.x + (uint32_t)atomicAdd(work_counter, 1ull);
+    uint32_t tog = 0, wpos = 0;                        // wpos: position inside the chunk
+    // (few partitions per block -- small samples: smaller chunks, down to one partition per grab)
+    const uint32_t wchunk = dyn ? min((uint32_t)SKM_FAST_WCHUNK, max(1u, nwork / (gridDim.x * 4u))) : 1u;
+    uint32_t item = blockIdx.x * wchunk, iter = 0;
     uint32_t part = part_of(item);
     uint32_t nrec = 0, rbase = 0;
     uint4 pre = make_uint4(0, 0, 0, 0);
-    if (part < nparts) { nrec = pcnt[part]; rbase = pstart[part]; if (lane < nrec) pre = recs[rbase + lane]; }
-    // (count, start) of the next sub-partition travel as a VECTOR load of lanes 0 / 1: a scalar load of these wave-uniform words would
+    auto prefetch = [&](uint32_t n_, uint32_t rb_) {
+        const uint32_t nb = n_ < (uint32_t)SKM_FAST_BLOCK ? n_ : (uint32_t)SKM_FAST_BLOCK;
+        const uint32_t per = (nb + NW - 1u) / NW;
+        if (lane < per && wave * per + lane < nb) pre = recs[rb_ + wave * per + lane];
+    };
+    if (part < nparts) { nrec = pcnt[part]; rbase = pstart[part]; prefetch(nrec, rbase); }
+    __syncthreads();
+    // (count, start) of the next partition travel as a VECTOR load of lanes 0 / 1: a scalar load of these wave-uniform words would
     // share the LDS counter (lgkmcnt), and the first LDS wait of the insert phase would sit out its HBM latency
     auto load_desc = [&](uint32_t p_) -> uint32_t {
         uint32_t v = 0;
         if (p_ < nparts && lane < 2u) { const uint32_t *src = lane == 0u ? pcnt : pstart; v = src[p_]; }
         return v;
     };
+    uint32_t chunk_n = dyn ? s_next[0] : blockIdx.x + gridDim.x, chunk_n2 = 0;    // (published before the barrier above)
     while (part < nparts) {
         const bool first = wpos == 0u, last = wpos + 1u == wchunk;
         const uint32_t item_n = last ? chunk_n * wchunk : item + 1u;
         const uint32_t next = part_of(item_n);
         const uint32_t desc_n = load_desc(next);
-        uint32_t grab = 0;
-        if (dyn && first && lane == 0) grab = (uint32_t)atomicAdd(work_counter, 1ull);
+        ull grab = 0;
+        if (dyn && first && tid == 0) grab = atomicAdd(work_counter, 1ull);
+        if (!dyn) chunk_n2 = chunk_n + gridDim.x;
+        if (nrec == 0) {       // an empty partition (rare among the owned ones)
+            if (dyn && first) {       // agree on the chunk after next through LDS right away
+                if (tid == 0) s_next[tog ^ 1u] = gridDim.x + (uint32_t)grab;
+                __syncthreads();
+                tog ^= 1u;
+                chunk_n2 = s_next[tog];
+            }
+            if (last) { chunk_n = chunk_n2; wpos = 0; } else wpos++;
+            item = item_n;
+            part = next; nrec = __builtin_amdgcn_readlane(desc_n, 0); rbase = __builtin_amdgcn_readlane(desc_n, 1);
+            prefetch(nrec, rbase);
+            continue;
+        }
+        // ---- expand + insert: every wave takes an equal share of the records (at most 64 per batch)
+        PH(0)
         ull my_k = 0;
-        // ---- expand + insert, 64 records at a time
-        for (uint32_t b0 = 0; b0 < nrec; b0 += 64u) {
-            const bool mine = b0 + lane < nrec;
+        for (uint32_t b0 = 0; b0 < nrec; b0 += SKM_FAST_BLOCK) {
+            const uint32_t nb = nrec - b0 < (uint32_t)SKM_FAST_BLOCK ? nrec - b0 : (uint32_t)SKM_FAST_BLOCK;
+            const uint32_t per = (nb + NW - 1u) / NW;                       // records of this wave: [b0 + wave*per, +per)
+            const uint32_t i = b0 + wave * per + lane;
+            const bool mine = lane < per && wave * per + lane < nb;
             uint4 rc = pre;
-            if (b0) { if (mine) rc = recs[rbase + b0 + lane]; }
-            const uint32_t len = mine ? skm_rec_n(rc) : 0u;
+            if (b0) { if (mine) rc = recs[rbase + i]; }
+            uint32_t len = mine ? skm_rec_n(rc) : 0u;
             const uint32_t x = wave_incl_scan(len);
             const uint32_t kt = __builtin_amdgcn_readlane(x, 63);
             const uint32_t off = x - len;
-            // the copy of the record carries the index of its first k-mer where its length was: w = base bits | off << 6 | multiplicity << 17
-            wrec[lane] = make_uint4(rc.x, rc.y, rc.z, (rc.w & 63u) | (off << 6) | ((rc.w >> 11) << 17));
+            // the wave's copy of the record carries the index of its first k-mer where the partition id was
+            wrec[lane] = make_uint4(rc.x, rc.y, rc.z, (rc.w & 63u) | (off << 6));
             if (lane < SKM_FAST_BMW) bm64[lane] = 0ull;
             if (len) atomicOr((uint32_t *)bm64 + (off >> 5), 1u << (off & 31u));
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            my_k += (ull)len * (ull)(rc.w >> 11);
+            if (lane == 0) my_k += kt;
+            PH(1)
             // the whole bitmap in registers (word c in lane c): a chunk's 64 bits are then two readlanes away, no LDS round trip
             ull bmreg = 0;
             if (lane < SKM_FAST_BMW) bmreg = bm64[lane];
             const uint32_t bmlo = (uint32_t)bmreg, bmhi = (uint32_t)(bmreg >> 32);
             uint32_t rbefore = 0;                                      // records that start before the current chunk of 64 k-mers
-            // record of k-mer f0 + lane; software pipeline: the read of iteration i + 1 is issued behind the CAS of iteration i (LDS
-            // returns in order), so an iteration exposes ONE round trip
-            uint4 rx; bool act;
+            // record of k-mer f0 + 64 u + lane, for the U chunks of one iteration; software pipeline: the reads of iteration i + 1
+            // are issued behind the CASes of iteration i (LDS returns in order), so an iteration exposes ONE round trip
+            uint4 rx[U]; bool act[U];
             auto fetch = [&](uint32_t f0_) {
-                const uint32_t c = f0_ >> 6;                        // (wave-uniform; c < SKM_FAST_BMW while f0_ < kt)
-                act = f0_ + lane < kt;
-                const uint32_t mlo = __builtin_amdgcn_readlane(bmlo, c & (SKM_FAST_BMW - 1u)), mhi = __builtin_amdgcn_readlane(bmhi, c & (SKM_FAST_BMW - 1u));
-                const uint32_t below = __builtin_amdgcn_mbcnt_hi(mhi, __builtin_amdgcn_mbcnt_lo(mlo, 0u));
-                const uint32_t own = ((lane < 32u ? mlo : mhi) >> (lane & 31u)) & 1u;
-                const uint32_t r = (rbefore + below + own - 1u) & 63u;      // (a lane beyond the last k-mer: any record)
-                rbefore += (uint32_t)__popc(mlo) + (uint32_t)__popc(mhi);
-                rx = wrec[r];
+#pragma unroll
+                for (uint32_t u = 0; u < U; u++) {
+                    const uint32_t c = (f0_ >> 6) + u;                  // (wave-uniform; c < SKM_FAST_BMW while f0_ < kt)
+                    act[u] = f0_ + 64u * u + lane < kt;
+                    const uint32_t mlo = __builtin_amdgcn_readlane(bmlo, c & (SKM_FAST_BMW - 1u)), mhi = __builtin_amdgcn_readlane(bmhi, c & (SKM_FAST_BMW - 1u));
+                    const uint32_t below = __builtin_amdgcn_mbcnt_hi(mhi, __builtin_amdgcn_mbcnt_lo(mlo, 0u));
+                    const uint32_t own = ((lane < 32u ? mlo : mhi) >> (lane & 31u)) & 1u;
+                    const uint32_t r = (rbefore + below + own - 1u) & 63u;      // (a lane beyond the last k-mer: any record)
+                    rbefore += (uint32_t)__popc(mlo) + (uint32_t)__popc(mhi);
+                    rx[u] = wrec[r];
+                }
             };
             fetch(0);
-            for (uint32_t f0 = 0; f0 < kt; f0 += 64u) {
+            for (uint32_t f0 = 0; f0 < kt; f0 += 64u * U) {
+                ull cu[U]; uint32_t su[U]; bool actc[U];
                 // cut, reverse complement, canonical, slot
-                const bool actc = act;
-                const uint32_t mu = rx.w >> 17;
-                const uint64_t fw = skm_kmer_at(rx, (f0 + lane - ((rx.w >> 6) & 2047u)) & 31u, cfg);
-                const uint64_t rv = skm_revcomp64(fw) >> (64u - 2u * cfg.k);
-                ull cu = fw < rv ? fw : rv;
-                const uint32_t su = skm_kmer_hash(cu) >> (32u - TSL);
-                // no lane is masked off: a lane beyond the last k-mer swaps EMPTY for EMPTY and adds 0, so the step is straight-line code
-                if (!actc) cu = SIMKA_EMPTY_KEY;
-                const ull pu = atomicCAS(&tkeys[su], SIMKA_EMPTY_KEY, cu);
-                fetch(f0 + 64u);                     // (beyond the last k-mer: no lane is active, every lane reads some record)
-                const bool ok = pu == SIMKA_EMPTY_KEY || pu == cu;
-                atomicAdd(&tcnt[su], (actc && ok) ? mu : 0u);
-                const bool lost = actc && !ok;
-                const ull lm = __ballot(lost);
-                if (lm) {
-                    if (lost) {
-                        const uint32_t pos = qn + __builtin_amdgcn_mbcnt_hi((uint32_t)(lm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)lm, 0u));
-                        qk[pos] = cu; qm[pos] = (uint16_t)((su + 1u) & (TS - 1u)); qx[pos] = (uint16_t)mu;
+#pragma unroll
+                for (uint32_t u = 0; u < U; u++) {
+                    actc[u] = act[u];
+                    const uint64_t fw = skm_kmer_at(rx[u], (f0 + 64u * u + lane - (rx[u].w >> 6)) & 31u, cfg);
+                    const uint64_t rv = skm_revcomp64(fw) >> (64u - 2u * cfg.k);
+                    cu[u] = fw < rv ? fw : rv;
+                    su[u] = skm_kmer_hash(cu[u]) >> (32u - TSL);
+                }
+                // all U inserts in flight together, the next iteration's records behind them.  No lane is masked off: a lane
+                // beyond the wave's last k-mer swaps EMPTY for EMPTY and adds 0, so the whole step is straight-line code and every wait
+                // counts exactly the LDS operations it needs
+                ull pu[U];
+#pragma unroll
+                for (uint32_t u = 0; u < U; u++) { if (!actc[u]) cu[u] = SIMKA_EMPTY_KEY; pu[u] = atomicCAS(&tkeys[su[u]], SIMKA_EMPTY_KEY, cu[u]); }
+                fetch(f0 + 64u * U);                 // (beyond the last k-mer: no lane is active, every lane reads some record)
+#pragma unroll
+                for (uint32_t u = 0; u < U; u++) {
+                    const bool ok = pu[u] == SIMKA_EMPTY_KEY || pu[u] == cu[u];
+                    atomicAdd(&tcnt[su[u]], (actc[u] && ok) ? 1u : 0u);
+                    const bool lost = actc[u] && !ok;
+                    const ull lm = __ballot(lost);
+                    if (lm) {       // (bmask >= 1: the next slot is never the home slot)
+                        if (lost) {
+                            const uint32_t pos = qn + __builtin_amdgcn_mbcnt_hi((uint32_t)(lm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)lm, 0u));
+                            qk[pos] = cu[u]; qm[pos] = (uint16_t)((su[u] & ~bmask) | ((su[u] + 1u) & bmask));
+                        }
+                        qn += (uint32_t)__popcll(lm);
                     }
-                    qn += (uint32_t)__popcll(lm);
                 }
                 while (qn >= 64u) drain();
             }
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // the bitmap / the records are rewritten by the next round
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // the wave's bitmap / records are rewritten by the next batch
+            PH(2)
         }
-        while (qn) drain();
+        DBG_ADD(8, my_k) DBG_ADD(12, 1) DBG_ADD(14, qn)
+        while (qn) { drain(); DBG_ADD(13, 1) }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        // ---- the next sub-partition's records travel while this one is summarised
+        __syncthreads();
+        PH(3)
+        // ---- the next partition's records travel while this one is summarised
         const uint32_t nrec_n = __builtin_amdgcn_readlane(desc_n, 0), rbase_n = __builtin_amdgcn_readlane(desc_n, 1);
-        if (lane < nrec_n) pre = recs[rbase_n + lane];
-        if (nrec) {
-            // ---- summary in slot order (SimkaCompressedProcessor::process, ref: src/minikc/MiniKC.hpp:54-79)
-            uint32_t cs[SPT]; ull ks[SPT];
-            uint32_t nsol = 0, ndall = 0;
-            ull D = 0, N = 0, Q = 0;
-            {   // the lane's 8 slots: vector loads, then the slots are reset unconditionally (vector stores, no branches)
-                static_assert(SPT == 8, "8 slots per lane");
-                uint4 *c4 = (uint4 *)(tcnt + lane * SPT); ulonglong2 *k2 = (ulonglong2 *)(tkeys + lane * SPT);
-                const uint4 ca = c4[0], cb = c4[1];
-                const ulonglong2 ka = k2[0], kb = k2[1], kc = k2[2], kd = k2[3];
-                const uint4 z = make_uint4(0, 0, 0, 0); const ulonglong2 ek = make_ulonglong2(SIMKA_EMPTY_KEY, SIMKA_EMPTY_KEY);
-                c4[0] = z; c4[1] = z; k2[0] = ek; k2[1] = ek; k2[2] = ek; k2[3] = ek;
-                cs[0] = ca.x; cs[1] = ca.y; cs[2] = ca.z; cs[3] = ca.w; cs[4] = cb.x; cs[5] = cb.y; cs[6] = cb.z; cs[7] = cb.w;
-                ks[0] = ka.x; ks[1] = ka.y; ks[2] = kb.x; ks[3] = kb.y; ks[4] = kc.x; ks[5] = kc.y; ks[6] = kd.x; ks[7] = kd.y;
-            }
-#pragma unroll
-            for (uint32_t q = 0; q < SPT; q++) {
-                const uint32_t c = cs[q];
-                const bool any = c != 0u, sol = any && !(c < amin || c > amax);
-                ndall += any ? 1u : 0u;
-                nsol += sol ? 1u : 0u;
-                D += sol ? 1ull : 0ull; N += sol ? (ull)c : 0ull; Q += sol ? (ull)c * (ull)c : 0ull;
-                cs[q] = sol ? c : 0u;
-            }
-            const bool failed = __ballot(gave_up) != 0ull;
-            gave_up = false;
-            // the solid records, in slot order, go to the (now empty) retry queue: keys [0, cap), counts behind them
-            constexpr uint32_t wcap = SKM_FAST_QCAP;                   // records the region takes (12 bytes each)
-            ull *wk = qk; uint32_t *wc = (uint32_t *)(wk + wcap);
-            const uint32_t winc = wave_incl_scan(nsol);
-            const uint32_t wtot = __builtin_amdgcn_readlane(winc, 63);
-            const bool staged = wtot <= wcap;
-            if (staged && !failed) {
-                uint32_t p = winc - nsol;
-#pragma unroll
-                for (uint32_t q = 0; q < SPT; q++) if (cs[q]) { wk[p] = ks[q]; wc[p] = cs[q]; p++; }
-            }
-            // arena space out of the wave's slab (one global atomic per slab)
-            bool ok_ = !failed;
-            ull base_ = sample_base;
-            if (failed) { if (lane == 0) { const ull w = atomicAdd(redo_count, 1ull); redo_list[w] = part; } }
-            else if (wtot) {
-                if (slab_pos + wtot > slab_end) {
-                    const ull want = wtot > o.slab ? (ull)wtot : (ull)o.slab;
-                    ull np = 0;
-                    if (lane == 0) np = atomicAdd(o.arena_cursor, want);
-                    np = ((ull)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(np >> 32)) << 32) | (ull)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)np);
-                    if (np + want > o.arena_cap) { if (lane == 0) atomicOr(o.err, SIMKA_DEVERR_ARENA_FULL); ok_ = false; }
-                    else { slab_pos = np; slab_end = np + want; }
-                }
-                if (ok_) {
-                    base_ = slab_pos; slab_pos += wtot;
-                    if (base_ - sample_base + wtot > 0xffffffffull) { if (lane == 0) atomicOr(o.err, SIMKA_DEVERR_SAMPLE_TOO_BIG); ok_ = false; }
-                }
-                if (ok_) { if (lane == 0) o.foff[part] = (uint32_t)(base_ - sample_base); if (lane == 1) o.fcnt[part] = wtot; }
-            }
-            if (ok_) {
-                bt_dall += ndall; bt_D += D; bt_N += N; bt_Q += Q; bt_kocc += my_k;
-                if (staged) {      // one record per lane: coalesced stores, one key mix per record
-                    for (uint32_t r = lane; r < wtot; r += 64u) {
-                        const ull key = wk[r]; const uint32_t c = wc[r];
-                        const ull pos = base_ + r;
-                        o.solid_keys[pos] = simka_mix(key, kcfg.mask, kcfg.xs); o.solid_counts[pos] = c;
-                        if (o.hist) count_hist(o, lhist, c);
-                    }
-                } else {
-                    ull pos = base_ + winc - nsol;
-#pragma unroll
-                    for (uint32_t q = 0; q < SPT; q++) {
-                        if (cs[q]) {
-                            o.solid_keys[pos] = simka_mix(ks[q], kcfg.mask, kcfg.xs); o.solid_counts[pos] = cs[q]; pos++;
-                            if (o.hist) count_hist(o, lhist, cs[q]);
-                        }
-                    }
-                }
-            }
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // the staging region becomes the retry queue again
+        {
+            const uint32_t nb = nrec_n < (uint32_t)SKM_FAST_BLOCK ? nrec_n : (uint32_t)SKM_FAST_BLOCK;
+            const uint32_t per = (nb + NW - 1u) / NW;
+            if (lane < per && wave * per + lane < nb) pre = recs[rbase_n + wave * per + lane];
         }
-        if (dyn && first) chunk_n2 = nwv + (uint32_t)__builtin_amdgcn_readfirstlane((int)grab);
-        if (!dyn) chunk_n2 = chunk_n + nwv;
+        // ---- summary in slot order (SimkaCompressedProcessor::process, ref: src/minikc/MiniKC.hpp:54-79)
+        uint32_t cs[SPT]; ull ks[SPT];
+        uint32_t nsol = 0, ndall = 0;
+        ull D = 0, N = 0, Q = 0;
+        {   // the thread's 8 slots: vector loads, then the slots are reset unconditionally (vector stores, no branches)
+            static_assert(SPT == 8, "8 slots per thread");
+            uint4 *c4 = (uint4 *)(tcnt + tid * SPT); ulonglong2 *k2 = (ulonglong2 *)(tkeys + tid * SPT);
+            const uint4 ca = c4[0], cb = c4[1];
+            const ulonglong2 ka = k2[0], kb = k2[1], kc = k2[2], kd = k2[3];
+            const uint4 z = make_uint4(0, 0, 0, 0); const ulonglong2 ek = make_ulonglong2(SIMKA_EMPTY_KEY, SIMKA_EMPTY_KEY);
+            c4[0] = z; c4[1] = z; k2[0] = ek; k2[1] = ek; k2[2] = ek; k2[3] = ek;
+            cs[0] = ca.x; cs[1] = ca.y; cs[2] = ca.z; cs[3] = ca.w; cs[4] = cb.x; cs[5] = cb.y; cs[6] = cb.z; cs[7] = cb.w;
+            ks[0] = ka.x; ks[1] = ka.y; ks[2] = kb.x; ks[3] = kb.y; ks[4] = kc.x; ks[5] = kc.y; ks[6] = kd.x; ks[7] = kd.y;
+        }
+#pragma unroll
+        for (uint32_t q = 0; q < SPT; q++) {
+            const uint32_t c = cs[q];
+            const bool any = c != 0u, sol = any && !(c < amin || c > amax);
+            ndall += any ? 1u : 0u;
+            nsol += sol ? 1u : 0u;
+            D += sol ? 1ull : 0ull; N += sol ? (ull)c : 0ull; Q += sol ? (ull)c * (ull)c : 0ull;
+            cs[q] = sol ? c : 0u;
+        }
+        const bool failed = s_fail != 0u;
+        // the wave's solid records, in slot order, go to its (now empty) retry queue: keys [0, cap), counts behind them
+        constexpr uint32_t wcap = (SKM_FAST_QCAP * 10u) / 12u;                    // records the region takes
+        ull *wk = qk; uint32_t *wc = (uint32_t *)(wk + wcap);
+        const uint32_t winc = wave_incl_scan(nsol);
+        const uint32_t wtot = __builtin_amdgcn_readlane(winc, 63);
+        const bool staged = wtot <= wcap;
+        if (staged) {
+            uint32_t p = winc - nsol;
+#pragma unroll
+            for (uint32_t q = 0; q < SPT; q++) if (cs[q]) { wk[p] = ks[q]; wc[p] = cs[q]; p++; }
+        }
+        PH(4)
+        const uint32_t par = iter & 1u;
+        iter++;
+        // block-level offsets of the waves (one barrier)
+        if (lane == 63u) tmp[par * 16u + wave] = winc;
+        if (dyn && first && tid == 0) s_next[tog ^ 1u] = gridDim.x + (uint32_t)grab;
+        __syncthreads();
+        if (dyn && first) { tog ^= 1u; chunk_n2 = s_next[tog]; }
+        uint32_t wpre = 0, total = 0;
+#pragma unroll
+        for (uint32_t w = 0; w < NW; w++) { const uint32_t t = tmp[par * 16u + w]; if (w < wave) wpre += t; total += t; }
+        PH(5)
+        const ull sp_ = s_slab[par * 2u], se_ = s_slab[par * 2u + 1u];
+        const bool fits = !failed && (total == 0 || (sp_ + total <= se_ && sp_ - sample_base + total <= 0xffffffffull));
+        ull base_ = sample_base;
+        bool ok_ = !failed;
+        if (fits) {
+            if (total) base_ = sp_;
+            if (tid == 0) { s_slab[(par ^ 1u) * 2u] = sp_ + total; s_slab[(par ^ 1u) * 2u + 1u] = se_; }
+            if (tid == 64) o.foff[part] = (uint32_t)(base_ - sample_base);
+            if (tid == 128) o.fcnt[part] = total;
+        } else {
+            if (tid == 0) {
+                uint32_t ok = 1;
+                ull slab_pos = sp_, slab_end = se_;
+                if (failed) { const ull w = atomicAdd(redo_count, 1ull); redo_list[w] = part; ok = 0; s_fail = 0u; }
+                else {
+                    const ull bb = slab_take(slab_pos, slab_end, total, o, sample_base, ok);
+                    o.foff[part] = ok ? (uint32_t)(bb - sample_base) : 0u;
+                    o.fcnt[part] = ok ? total : 0u;
+                    s_base = bb;
+                }
+                s_slab[(par ^ 1u) * 2u] = slab_pos; s_slab[(par ^ 1u) * 2u + 1u] = slab_end;
+                s_ok = ok;
+            }
+            __syncthreads();
+            base_ = s_base; ok_ = s_ok != 0;
+        }
+        PH(6)
+        if (ok_) {
+            bt_dall += ndall; bt_D += D; bt_N += N; bt_Q += Q; bt_kocc += my_k;
+            if (staged) {      // one record per lane: coalesced stores, one key mix per record
+                for (uint32_t r = lane; r < wtot; r += 64u) {
+                    const ull key = wk[r]; const uint32_t c = wc[r];
+                    const ull pos = base_ + wpre + r;
+                    o.solid_keys[pos] = simka_mix(key, kcfg.mask, kcfg.xs); o.solid_counts[pos] = c;
+                    if (o.hist) count_hist(o, lhist, c);
+                }
+            } else {
+                ull pos = base_ + wpre + winc - nsol;
+#pragma unroll
+                for (uint32_t q = 0; q < SPT; q++) {
+                    if (cs[q]) {
+                        o.solid_keys[pos] = simka_mix(ks[q], kcfg.mask, kcfg.xs); o.solid_counts[pos] = cs[q]; pos++;
+                        if (o.hist) count_hist(o, lhist, cs[q]);
+                    }
+                }
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // the staging region becomes the wave's retry queue again
+        PH(7)
         if (last) { chunk_n = chunk_n2; wpos = 0; } else wpos++;
         item = item_n;
         part = next; nrec = nrec_n; rbase = rbase_n;
     }
-    __syncthreads();
+    PH_FLUSH
+#ifdef SIMKA_PHASE_PROF
+    if (lane == 0 && o.phase) for (int i_ = 0; i_ < 8; i_++) if (i_ < 1 || i_ > 3) atomicAdd(&o.phase[8 + i_], dbg[i_]);
+    if (tid == 0 && o.phase) { const ull el = wall_clock64() - blk_t0; atomicMax(&o.phase[9], el); atomicAdd(&o.phase[10], el); atomicAdd(&o.phase[11], 1ull); }
+#endif
     if (o.hist) {
+        __syncthreads();
         for (uint32_t i = tid; i < SIMKA_HIST_MAX; i += SKM_FAST_BLOCK)
             if (lhist[i]) atomicAdd(&o.hist[(size_t)o.sample * SIMKA_HIST_MAX + i], (ull)lhist[i]);
     }
