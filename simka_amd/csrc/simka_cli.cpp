@@ -479,7 +479,7 @@ private:
 // (ref: src/SimkaPotara.hpp:837-842).  Here: the sample's solid spectrum as simka_export_sample() returns it, behind a
 // header that pins everything the spectrum depends on (k, abundance filter, read policies, the input files, the shard).
 struct SpecHeader {
-    char magic[8];                       // "SIMKSPC2"
+    char magic[8];                       // "SIMKSPC3" (3: segments ordered by key prefix)
     uint64_t abi, kmer_size, abundance_min, abundance_max, shard_index, shard_count, nb_partitions, nb_records, signature;
     uint64_t key_words;                  // 64-bit words per key: 1, or 2 for -kmer-size >= 32 (high words, then low words)
     simka_sample_totals totals;
@@ -519,7 +519,7 @@ std::string spec_path(const std::string &tmp, const Sample &s, uint32_t g, uint3
 bool read_spec_header(const std::string &path, SpecHeader &h) {
     FILE *f = fopen(path.c_str(), "rb");
     if (!f) return false;
-    const bool ok = fread(&h, sizeof h, 1, f) == 1 && memcmp(h.magic, "SIMKSPC2", 8) == 0;
+    const bool ok = fread(&h, sizeof h, 1, f) == 1 && memcmp(h.magic, "SIMKSPC3", 8) == 0;
     fclose(f);
     return ok;
 }
@@ -536,7 +536,7 @@ struct Spectrum { SpecHeader h; std::vector<uint32_t> part_counts; PinnedBuf<uin
 bool read_spec(const std::string &path, Spectrum &sp) {
     FILE *f = fopen(path.c_str(), "rb");
     if (!f) return false;
-    bool ok = fread(&sp.h, sizeof sp.h, 1, f) == 1 && memcmp(sp.h.magic, "SIMKSPC2", 8) == 0;
+    bool ok = fread(&sp.h, sizeof sp.h, 1, f) == 1 && memcmp(sp.h.magic, "SIMKSPC3", 8) == 0;
     if (ok) {
         if (sp.h.key_words < 1 || sp.h.key_words > 2) { fclose(f); return false; }
         sp.part_counts.resize(sp.h.nb_partitions); sp.keys.resize(sp.h.nb_records * sp.h.key_words); sp.counts.resize(sp.h.nb_records);
@@ -695,7 +695,7 @@ int main(int argc, char **argv) {
         rc = simka_export_sample(c, index, sp.part_counts.data(), sp.keys.data(), sp.counts.data());
         if (rc != SIMKA_OK) return rc;
         memset(&sp.h, 0, sizeof sp.h);
-        memcpy(sp.h.magic, "SIMKSPC2", 8);
+        memcpy(sp.h.magic, "SIMKSPC3", 8);
         sp.h.abi = (uint64_t)simka_abi_version(); sp.h.kmer_size = (uint64_t)o.kmer_size;
         sp.h.abundance_min = (uint64_t)o.abundance_min; sp.h.abundance_max = (uint64_t)o.abundance_max;
         sp.h.shard_index = 0; sp.h.shard_count = 1; sp.h.nb_partitions = info.nb_partitions; sp.h.nb_records = info.nb_records;

@@ -2,7 +2,7 @@
 // This is the only translation unit that launches kernels; simka_host.cpp holds the pure-host
 // pieces (finalisation, CSV, packing).
 #include <hip/hip_runtime.h>
-#include <rccl/rccl.h>
+#include <dlfcn.h>
 #include <stdarg.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -10,6 +10,7 @@
 #include <string>
 #include <vector>
 #include <algorithm>
+#include <mutex>
 
 #include "../../include/simka_hip.h"
 #include "simka_kernels.hip"
@@ -19,10 +20,10 @@
 #define SIMKA_EXPORT extern "C" __attribute__((visibility("default")))
 
 // kernel ids for the profiler
-enum { KID_SCAN_HIST = 0, KID_LAYOUT, KID_SKM_SCAN, KID_SKM_SPLIT, KID_SKM_COUNT, KID_COUNT, KID_PART_TOTALS, KID_REGROUP, KID_GROUP,
+enum { KID_SCAN_HIST = 0, KID_LAYOUT, KID_SKM_SCAN, KID_SKM_SPLIT, KID_SKM_COUNT, KID_COUNT, KID_PART_TOTALS, KID_SEG_ROWS, KID_GROUP,
        KID_PAIRS, KID_PAIRS_GLOBAL, KID_NB };
 static const char *const KID_NAMES[KID_NB] = { "k_skm_scan<hist>", "k_skm_layout", "k_skm_scan", "k_skm_split", "k_skm_count_fast", "k_skm_count",
-                                               "k_part_totals", "k_regroup", "k_group", "k_pairs", "k_pairs_global" };
+                                               "k_part_totals", "k_segment_rows", "k_group", "k_pairs", "k_pairs_global" };
 
 static thread_local std::string g_create_error;
 
@@ -73,9 +74,10 @@ struct simka_ctx {
     // merge buffers
     ull *d_part_total = nullptr, *d_part_off = nullptr;
     ull *d_work = nullptr;                                    // [2] work counters of the persistent merge-side kernels (zeroed before a launch)
-    ull *d_mkeys = nullptr, *d_mvals = nullptr, *d_entries = nullptr; uint32_t *d_groups = nullptr;
-    uint32_t *d_fb_off = nullptr; SimkaSpan *d_spans = nullptr; ull *d_cursors = nullptr; SimkaSpan *d_huge = nullptr;
-    uint64_t merge_cap = 0, fb_cap = 0, span_cap = 0, huge_cap = 0;
+    ull *d_seg_abs = nullptr; uint4 *d_seg_rows = nullptr;    // merge batch: [partitions][N] first record of a segment, ends of its 16 key-prefix blocks (k_segment_rows)
+    ull *d_entries = nullptr; uint32_t *d_groups = nullptr;
+    SimkaSpan *d_spans = nullptr; ull *d_cursors = nullptr; SimkaSpan *d_huge = nullptr;
+    uint64_t merge_cap = 0, seg_cap = 0, span_cap = 0, huge_cap = 0;
     // tile-major copy of the CSR for the tiled pair kernel (N too large for one LDS tile): entries, (p, p ln p), segment offsets
     ull *d_tm_ent = nullptr; double2 *d_tm_p = nullptr; uint32_t *d_tm_off = nullptr;
     uint64_t tm_ent_cap = 0, tm_p_cap = 0, tm_off_cap = 0;
@@ -428,7 +430,7 @@ SIMKA_EXPORT void simka_destroy(simka_ctx *ctx) {
     for (uint32_t li = 0; li < simka_ctx::MAX_LANES; li++) { if (ctx->d_reads[li]) (void)hipFree(ctx->d_reads[li]); if (ctx->d_offsets[li]) (void)hipFree(ctx->d_offsets[li]); }
     void *ptrs[] = { ctx->d_l1_ovf, ctx->d_solid_keys, ctx->d_solid_counts, ctx->d_arena_cursor,
                      ctx->d_sample_base, ctx->d_foff, ctx->d_fcnt, ctx->d_stats, ctx->d_err, ctx->d_part_total,
-                     ctx->d_part_off, ctx->d_work, ctx->d_mkeys, ctx->d_mvals, ctx->d_entries, ctx->d_groups, ctx->d_fb_off,
+                     ctx->d_part_off, ctx->d_work, ctx->d_seg_abs, ctx->d_seg_rows, ctx->d_entries, ctx->d_groups,
                      ctx->d_spans, ctx->d_cursors, ctx->d_huge, ctx->d_xoff, ctx->d_hist, ctx->d_ovf_list, ctx->d_ovf_cursor,
                      ctx->d_tm_ent, ctx->d_tm_p, ctx->d_tm_off };
     for (void *p : ptrs) if (p) (void)hipFree(p);
@@ -479,6 +481,7 @@ static int check_device_error(simka_ctx *ctx) {
     if (e & SIMKA_DEVERR_SAMPLE_TOO_BIG) return ctx->fail(SIMKA_ERR_OVERFLOW, "a sample holds more than 2^32 solid k-mers");
     if (e & SIMKA_DEVERR_GROUP_OVERFLOW) return ctx->fail(SIMKA_ERR_OVERFLOW, "merge: a sub-range could not be split below the LDS capacity");
     if (e & SIMKA_DEVERR_CSR_FULL) return ctx->fail(SIMKA_ERR_NOMEM, "merge: group buffer exhausted");
+    if (e & SIMKA_DEVERR_UNORDERED) return ctx->fail(SIMKA_ERR_INVALID, "merge: a spectrum is not ordered by key prefix inside its partitions (imported from another version?)");
     return SIMKA_OK;
 }
 
@@ -1261,6 +1264,7 @@ static void pair_launch(simka_ctx *ctx, const PairLaunch &pl, const SimkaSpan *s
             ull cur[4] = { 0, 0, 0, 0 };
             if (hipMemcpyAsync(cur, cursors, 32, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess || hipStreamSynchronize(ctx->stream) != hipSuccess) tile_major = false;
             nb_entries = cur[0]; nb_spans = cur[2];
+            if (spans == ctx->d_spans && nb_spans > ctx->span_cap) { have_spans = false; tile_major = false; }      // (k_group ran out of span slots and flagged it: nothing to pair up)
         }
         if (tile_major && nb_spans == 0) have_spans = false;
         const bool cplx = pc.nacc64 != 0;
@@ -1417,13 +1421,13 @@ SIMKA_EXPORT int simka_merge(simka_ctx *ctx) {
     SimkaKeyCfg key = ctx->key;
     uint32_t t = ctx->cfg.log2_subranges;
     if (t == 0) t = ceil_log2_u64((total / std::max<ull>(nonempty, 1) + K3_TARGET - 1) / K3_TARGET);
-    t = std::min<uint32_t>(t, 8);
-    t = std::min<uint32_t>(t, key.W - key.pb);
+    t = std::min<uint32_t>(t, SIMKA_SEG_BITS);            // (the segments are ordered by that many key bits; k_group splits larger sub-ranges on further bits)
+    t = std::min<uint32_t>(t, key.W);
     key.t = t; ctx->key.t = t;
     const uint32_t nsub = 1u << t;
 
-    // bounded merge buffers, processed in batches of consecutive partitions
-    // batch size: up to 2^29 records (15 GB of merge buffers; larger batches = fewer launches and shorter tails: C3 merge side 420 ->
+    // bounded CSR buffers, processed in batches of consecutive partitions
+    // batch size: up to 2^29 records (6 GB of CSR buffers; larger batches = fewer launches and shorter tails: C3 merge side 420 ->
     // 398 ms against 2^27), never more than half of what is free now (on top of the buffers a previous merge left)
     uint64_t cap_mem = (uint64_t)1 << 27;
     if (total > cap_mem && !ctx->cfg.csr_capacity) { size_t fr = 0, tot_ = 0; if (hipMemGetInfo(&fr, &tot_) == hipSuccess) cap_mem = std::max<uint64_t>((uint64_t)1 << 24, ctx->merge_cap + (uint64_t)(fr / 2) / 32); }
@@ -1431,21 +1435,27 @@ SIMKA_EXPORT int simka_merge(simka_ctx *ctx) {
     cap = std::max<uint64_t>(cap, maxpart);
     if (cap >= ((uint64_t)1 << 32)) cap = ((uint64_t)1 << 32) - 1;
     if (maxpart > cap) return ctx->fail(SIMKA_ERR_NOMEM, "simka_merge: one partition holds %llu records, more than the merge buffer", maxpart);
-    const uint64_t max_parts_batch = std::min<uint64_t>(nparts, (uint64_t)1 << 16);
+    const uint64_t max_parts_batch = std::min<uint64_t>(nparts, std::min<uint64_t>((uint64_t)1 << 16, std::max<uint64_t>(1, ((uint64_t)1 << 26) / N)));
     const uint64_t fb_cap = max_parts_batch * nsub;
     const uint32_t grid_group = (uint32_t)ctx->num_cus * 4;
-    const uint64_t span_cap = fb_cap * 2 + 4096 + (uint64_t)grid_group * K3_SLAB_SPAN;
+    // spans: one per work item and open-span break, plus the rounds of the sub-ranges that k_group has to split further (a round holds
+    // K3_PRESPLIT / 2 .. K3_PRESPLIT records unless the key bits are skewed; beyond the capacity the merge fails cleanly)
+    const uint64_t span_cap = fb_cap * 2 + 4096 + (uint64_t)grid_group * K3_SLAB_SPAN + cap / (K3_PRESPLIT / 4);
     const uint64_t csr_cap = cap + (uint64_t)grid_group * K3_SLAB_ENT;     // slab reservation leaves unused tails
     if (ctx->merge_cap < cap) {
-        void *old[] = { ctx->d_mkeys, ctx->d_mvals, ctx->d_entries, ctx->d_groups };
+        void *old[] = { ctx->d_entries, ctx->d_groups };
         for (void *p : old) if (p) HIPCHK(hipFree(p));
-        ctx->d_mkeys = ctx->d_mvals = ctx->d_entries = nullptr; ctx->d_groups = nullptr;
-        if (dev_alloc(&ctx->d_mkeys, cap) != hipSuccess || dev_alloc(&ctx->d_mvals, cap) != hipSuccess ||
-            dev_alloc(&ctx->d_entries, csr_cap) != hipSuccess || dev_alloc(&ctx->d_groups, csr_cap) != hipSuccess)
+        ctx->d_entries = nullptr; ctx->d_groups = nullptr;
+        if (dev_alloc(&ctx->d_entries, csr_cap) != hipSuccess || dev_alloc(&ctx->d_groups, csr_cap) != hipSuccess)
             return ctx->fail(SIMKA_ERR_NOMEM, "simka_merge: cannot allocate merge buffers for %llu records", (unsigned long long)cap);
         ctx->merge_cap = cap;
     }
-    if (ctx->fb_cap < fb_cap) { if (ctx->d_fb_off) HIPCHK(hipFree(ctx->d_fb_off)); ctx->d_fb_off = nullptr; HIPCHK(dev_alloc(&ctx->d_fb_off, fb_cap + 1)); ctx->fb_cap = fb_cap; }
+    const uint64_t seg_cap = max_parts_batch * N;
+    if (ctx->seg_cap < seg_cap) {
+        if (ctx->d_seg_abs) HIPCHK(hipFree(ctx->d_seg_abs)); if (ctx->d_seg_rows) HIPCHK(hipFree(ctx->d_seg_rows));
+        ctx->d_seg_abs = nullptr; ctx->d_seg_rows = nullptr;
+        HIPCHK(dev_alloc(&ctx->d_seg_abs, seg_cap)); HIPCHK(dev_alloc(&ctx->d_seg_rows, seg_cap * 2)); ctx->seg_cap = seg_cap;
+    }
     if (ctx->span_cap < span_cap) { if (ctx->d_spans) HIPCHK(hipFree(ctx->d_spans)); ctx->d_spans = nullptr; HIPCHK(dev_alloc(&ctx->d_spans, span_cap)); ctx->span_cap = span_cap; }
 
     PairLaunch pl;
@@ -1475,13 +1485,13 @@ SIMKA_EXPORT int simka_merge(simka_ctx *ctx) {
             const uint32_t np = (uint32_t)(pe - pb);
             const uint32_t nfb = np * nsub;
             HIPCHK(hipMemsetAsync(ctx->d_cursors, 0, 32, ctx->stream));
-            launch_timed(ctx, KID_REGROUP, [&] {
-                hipLaunchKernelGGL(k_regroup, dim3(np), dim3(K3_BLOCK), 0, ctx->stream, in, key, pb, ctx->d_part_off, poff[pb],
-                                   ctx->d_fb_off, ctx->d_mkeys, ctx->d_mvals);
+            launch_timed(ctx, KID_SEG_ROWS, [&] {
+                hipLaunchKernelGGL(k_segment_rows, dim3((uint32_t)std::min<uint64_t>(((uint64_t)np * N + 3) / 4, (uint64_t)ctx->num_cus * 8)), dim3(256), 0, ctx->stream, in, key, pb, np,
+                                   ctx->d_seg_abs, ctx->d_seg_rows, ctx->d_err);
             });
             launch_timed(ctx, KID_GROUP, [&] {
-                hipLaunchKernelGGL(k_group, dim3(std::min<uint32_t>(nfb, grid_group)), dim3(K3_BLOCK), lds_group, ctx->stream, ctx->d_mkeys, ctx->d_mvals,
-                                   ctx->d_fb_off, nfb, (uint32_t)recs, key, min_share, co);
+                hipLaunchKernelGGL(k_group, dim3(std::min<uint32_t>(np, grid_group)), dim3(K3_BLOCK), lds_group, ctx->stream, in, (const ull *)ctx->d_seg_abs,
+                                   (const uint16_t *)ctx->d_seg_rows, np, key, min_share, co);
             });
             if (getenv("SIMKA_DEBUG_MERGE")) {
                 ull cur[4]; HIPCHK(hipMemcpyAsync(cur, ctx->d_cursors, 32, hipMemcpyDeviceToHost, ctx->stream)); HIPCHK(hipStreamSynchronize(ctx->stream));
@@ -1595,6 +1605,45 @@ SIMKA_EXPORT int simka_stats_download(simka_ctx *ctx, uint64_t *h, uint64_t n, s
 // ---- RCCL: the cross-GPU reduction of SimkaStatistics (operator+=, ref: src/core/SimkaDistance.cpp:156-213) ------------
 // One communicator per GPU (one process per GPU, or one host thread per GPU inside `simka -nb-gpus`).  The accumulators of a
 // context are ONE flat u64 buffer, so the reduction is a single ncclAllReduce(sum, uint64) on the context's stream.
+// RCCL is loaded at the first simka_comm_* call (dlopen): a single-GPU installation needs neither the library nor its header, and
+// a context never touches it.  The handful of ABI constants below are those of RCCL's nccl.h.
+typedef void *ncclComm_t;
+typedef struct { char internal[SIMKA_COMM_ID_BYTES]; } ncclUniqueId;
+typedef int ncclResult_t;
+enum { ncclSuccess = 0 };
+enum { ncclUint8 = 1, ncclUint64 = 5 };       // ncclDataType_t
+enum { ncclSum = 0 };                         // ncclRedOp_t
+struct RcclApi {
+    void *lib = nullptr;
+    std::string err;
+    ncclResult_t (*GetUniqueId)(ncclUniqueId *) = nullptr;
+    ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*AllReduce)(const void *, void *, size_t, int, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*Send)(const void *, size_t, int, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*Recv)(void *, size_t, int, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*GroupStart)() = nullptr;
+    ncclResult_t (*GroupEnd)() = nullptr;
+    const char *(*GetErrorString)(ncclResult_t) = nullptr;
+};
+static const RcclApi *rccl() {
+    static RcclApi api;
+    static std::once_flag once;
+    std::call_once(once, [] {
+        for (const char *name : { "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1", "/opt/rocm/lib/librccl.so" }) { api.lib = dlopen(name, RTLD_NOW | RTLD_LOCAL); if (api.lib) break; }
+        if (!api.lib) { api.err = "RCCL is not installed (librccl.so not found): multi-GPU collectives are unavailable"; return; }
+        bool ok = true;
+        auto sym = [&](const char *n) { void *p = dlsym(api.lib, n); if (!p) { ok = false; api.err = std::string("librccl.so lacks ") + n; } return p; };
+        api.GetUniqueId = (decltype(api.GetUniqueId))sym("ncclGetUniqueId"); api.CommInitRank = (decltype(api.CommInitRank))sym("ncclCommInitRank");
+        api.CommDestroy = (decltype(api.CommDestroy))sym("ncclCommDestroy"); api.AllReduce = (decltype(api.AllReduce))sym("ncclAllReduce");
+        api.Send = (decltype(api.Send))sym("ncclSend"); api.Recv = (decltype(api.Recv))sym("ncclRecv");
+        api.GroupStart = (decltype(api.GroupStart))sym("ncclGroupStart"); api.GroupEnd = (decltype(api.GroupEnd))sym("ncclGroupEnd");
+        api.GetErrorString = (decltype(api.GetErrorString))sym("ncclGetErrorString");
+        if (!ok) { dlclose(api.lib); api.lib = nullptr; }
+    });
+    return &api;
+}
+
 struct simka_comm {
     ncclComm_t comm = nullptr;
     int rank = 0, nb_ranks = 1, device = 0;
@@ -1605,35 +1654,38 @@ static thread_local std::string g_comm_error;
 #define NCCLCHK(c, call)                                                                                   \
     do {                                                                                                   \
         ncclResult_t r_ = (call);                                                                          \
-        if (r_ != ncclSuccess) { (c)->err = std::string(#call) + " failed: " + ncclGetErrorString(r_); return SIMKA_ERR_HIP; } \
+        if (r_ != ncclSuccess) { (c)->err = std::string(#call) + " failed: " + rccl()->GetErrorString(r_); return SIMKA_ERR_HIP; } \
     } while (0)
 
 SIMKA_EXPORT int simka_comm_unique_id(uint8_t *id) {
     if (!id) return SIMKA_ERR_INVALID;
-    static_assert(sizeof(ncclUniqueId) == SIMKA_COMM_ID_BYTES, "SIMKA_COMM_ID_BYTES must be sizeof(ncclUniqueId)");
+    const RcclApi *R = rccl();
+    if (!R->lib) { g_comm_error = R->err; return SIMKA_ERR_UNSUPPORTED; }
     ncclUniqueId u;
-    const ncclResult_t r = ncclGetUniqueId(&u);
-    if (r != ncclSuccess) { g_comm_error = std::string("ncclGetUniqueId failed: ") + ncclGetErrorString(r); return SIMKA_ERR_HIP; }
+    const ncclResult_t r = R->GetUniqueId(&u);
+    if (r != ncclSuccess) { g_comm_error = std::string("ncclGetUniqueId failed: ") + R->GetErrorString(r); return SIMKA_ERR_HIP; }
     memcpy(id, &u, sizeof u);
     return SIMKA_OK;
 }
 
 SIMKA_EXPORT int simka_comm_create(const uint8_t *id, int nb_ranks, int rank, int device, simka_comm **out) {
     if (!id || !out || nb_ranks < 1 || rank < 0 || rank >= nb_ranks) { g_comm_error = "simka_comm_create: bad argument"; return SIMKA_ERR_INVALID; }
+    const RcclApi *R = rccl();
+    if (!R->lib) { g_comm_error = R->err; return SIMKA_ERR_UNSUPPORTED; }
     if (hipSetDevice(device) != hipSuccess) { g_comm_error = "simka_comm_create: hipSetDevice failed"; return SIMKA_ERR_HIP; }
     simka_comm *c = new simka_comm();
     c->rank = rank; c->nb_ranks = nb_ranks; c->device = device;
     ncclUniqueId u;
     memcpy(&u, id, sizeof u);
-    const ncclResult_t r = ncclCommInitRank(&c->comm, nb_ranks, u, rank);
-    if (r != ncclSuccess) { g_comm_error = std::string("ncclCommInitRank failed: ") + ncclGetErrorString(r); delete c; return SIMKA_ERR_HIP; }
+    const ncclResult_t r = R->CommInitRank(&c->comm, nb_ranks, u, rank);
+    if (r != ncclSuccess) { g_comm_error = std::string("ncclCommInitRank failed: ") + R->GetErrorString(r); delete c; return SIMKA_ERR_HIP; }
     *out = c;
     return SIMKA_OK;
 }
 
 SIMKA_EXPORT void simka_comm_destroy(simka_comm *c) {
     if (!c) return;
-    if (c->comm) (void)ncclCommDestroy(c->comm);
+    if (c->comm) (void)rccl()->CommDestroy(c->comm);
     delete c;
 }
 
@@ -1650,7 +1702,7 @@ SIMKA_EXPORT int simka_comm_info(const simka_comm *c, int *rank, int *nb_ranks) 
 SIMKA_EXPORT int simka_comm_allreduce_u64(simka_comm *c, void *d_buf, uint64_t n, void *stream) {
     if (!c || (!d_buf && n)) return SIMKA_ERR_INVALID;
     if (n == 0 || c->nb_ranks == 1) return SIMKA_OK;
-    NCCLCHK(c, ncclAllReduce(d_buf, d_buf, (size_t)n, ncclUint64, ncclSum, c->comm, (hipStream_t)stream));
+    NCCLCHK(c, rccl()->AllReduce(d_buf, d_buf, (size_t)n, ncclUint64, ncclSum, c->comm, (hipStream_t)stream));
     return SIMKA_OK;
 }
 
@@ -1661,16 +1713,19 @@ SIMKA_EXPORT int simka_comm_alltoallv(simka_comm *c, const void *d_send, const u
     if (!c || !send_counts || !send_displs || !recv_counts || !recv_displs || !elem_bytes) return SIMKA_ERR_INVALID;
     const hipStream_t st = (hipStream_t)stream;
     const char *sb = (const char *)d_send; char *rb = (char *)d_recv;
-    NCCLCHK(c, ncclGroupStart());
-    for (int p = 0; p < c->nb_ranks; p++) {
-        // the local block moves with a device copy; RCCL handles the others
-        if (p == c->rank) continue;
-        if (send_counts[p]) NCCLCHK(c, ncclSend(sb + send_displs[p] * elem_bytes, (size_t)(send_counts[p] * elem_bytes), ncclUint8, p, c->comm, st));
-        if (recv_counts[p]) NCCLCHK(c, ncclRecv(rb + recv_displs[p] * elem_bytes, (size_t)(recv_counts[p] * elem_bytes), ncclUint8, p, c->comm, st));
-    }
-    NCCLCHK(c, ncclGroupEnd());
     const int me = c->rank;
     if (send_counts[me] != recv_counts[me]) { c->err = "simka_comm_alltoallv: local send and receive counts differ"; return SIMKA_ERR_INVALID; }
+    const RcclApi *R = rccl();
+    NCCLCHK(c, R->GroupStart());
+    ncclResult_t bad = ncclSuccess;       // (a failure inside the group must not leave it open: close it first, report then)
+    for (int p = 0; p < c->nb_ranks && bad == ncclSuccess; p++) {
+        // the local block moves with a device copy; RCCL handles the others
+        if (p == me) continue;
+        if (send_counts[p]) bad = R->Send(sb + send_displs[p] * elem_bytes, (size_t)(send_counts[p] * elem_bytes), ncclUint8, p, c->comm, st);
+        if (recv_counts[p] && bad == ncclSuccess) bad = R->Recv(rb + recv_displs[p] * elem_bytes, (size_t)(recv_counts[p] * elem_bytes), ncclUint8, p, c->comm, st);
+    }
+    const ncclResult_t ended = R->GroupEnd();
+    if (bad != ncclSuccess || ended != ncclSuccess) { c->err = std::string("simka_comm_alltoallv: ncclSend / ncclRecv group failed: ") + R->GetErrorString(bad != ncclSuccess ? bad : ended); return SIMKA_ERR_HIP; }
     if (send_counts[me]) {
         const hipError_t e = hipMemcpyAsync(rb + recv_displs[me] * elem_bytes, sb + send_displs[me] * elem_bytes, (size_t)(send_counts[me] * elem_bytes), hipMemcpyDeviceToDevice, st);
         if (e != hipSuccess) { c->err = std::string("simka_comm_alltoallv: local copy failed: ") + hipGetErrorString(e); return SIMKA_ERR_HIP; }

@@ -44,9 +44,9 @@ SIMKA_HD uint64_t simka_mix(uint64_t x, uint64_t mask, uint32_t xs) {
     return x;
 }
 
-SIMKA_HD uint32_t simka_key_sub(uint64_t key, const SimkaKeyCfg &c) {
-    return (uint32_t)(key >> (c.W - c.pb - c.t)) & ((1u << c.t) - 1u);
-}
+// 32-bit hash of a key (= canonical k-mer): slot in the count kernels' LDS tables, and -- its top SIMKA_SEG_BITS bits -- the order of a
+// (sample, partition) segment of the arena, hence the merge's sub-range of the key
+SIMKA_HD uint32_t simka_key_hash32(uint64_t key) { return (uint32_t)key * 0x9E3779B1u + (uint32_t)(key >> 32) * 0x85EBCA6Bu; }
 // slot hash for the LDS tables: top bits of a 64-bit multiply see every key bit
 SIMKA_HD uint32_t simka_slot_hash(uint64_t key) { return (uint32_t)((key * 0xd6e8feb86659fd93ULL) >> 40); }
 

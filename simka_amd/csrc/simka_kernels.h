@@ -13,7 +13,9 @@
 #define SIMKA_TARGET_PER_PART 3072   // sizing: k-mer occurrences per partition (minimizer partitions vary ~3x around it; the fast count
                                      // kernel's 2048-slot table takes ~1500 distinct k-mers, larger partitions go through k_skm_count)
 #endif
-// K3  k_regroup / k_group
+// K3  k_segment_rows / k_group
+#define SIMKA_SEG_BITS 4       // a (sample, partition) segment of the arena is ordered by the top 4 bits of the key (SKM_SORT_BITS of the count kernels)
+#define SIMKA_SEG_BLOCKS (1 << SIMKA_SEG_BITS)
 #define K3_BLOCK 256
 #define K3_CAP 1024           // records hashed per round = entries per span
 #define K3_TARGET 940         // mean records per sub-range the merge aims for (sub-range bits t)
@@ -55,6 +57,7 @@
 #define SIMKA_DEVERR_SAMPLE_TOO_BIG 4u
 #define SIMKA_DEVERR_GROUP_OVERFLOW 8u
 #define SIMKA_DEVERR_CSR_FULL 16u
+#define SIMKA_DEVERR_UNORDERED 32u
 
 struct SimkaScanArgs {
     const uint64_t *packed;

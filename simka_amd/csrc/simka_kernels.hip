@@ -135,38 +135,45 @@ k_part_totals(const uint32_t *fcnt, uint32_t nb_samples, uint64_t nparts, ull *p
 }
 
 // --------------------------------------------------------------------------------------------
-// K3  k_regroup: bring partition p's records of all N samples together, ordered by sub-range.
-// (the reference opens the N files solid/part_p/__p__*.gz, ref: src/SimkaMerge.cpp:1082-1103)
+// K3  k_segment_rows: the merge's view of the arena.  The count kernels leave every (sample, partition) segment ordered by the top
+// SIMKA_SEG_BITS bits of the key (their tables are walked in slot order), so a sub-range of a segment is a SLICE of it and the
+// N-way merge can read its inputs in place (the reference opens the N sorted files solid/part_p/__p__*.gz side by side,
+// ref: src/SimkaMerge.cpp:1082-1103).  One wave per segment: row[p][s] = the 16 exclusive ends of the key-prefix blocks inside the
+// segment (u16: a segment has < 65536 records ... else the last entries saturate and the partition is flagged), seg_abs[p][s] = its
+// first record in the arena.  Partition-major, so that a merge block reads the N rows of its partition as one run.
+// A segment that is not ordered (a spectrum imported from a foreign source) flags SIMKA_DEVERR_UNORDERED.
 // --------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(K3_BLOCK)
-k_regroup(SimkaMergeIn in, SimkaKeyCfg cfg, uint64_t part_begin, const ull *part_off, ull batch_base,
-          uint32_t *fb_off, ull *mkeys, ull *mvals) {
-    __shared__ uint32_t hist[256];
-    __shared__ uint32_t tmp[K3_BLOCK];
-    const uint32_t nsub = 1u << cfg.t;
-    const uint64_t p = part_begin + blockIdx.x;
-    const uint32_t tid = threadIdx.x;
-    for (uint32_t i = tid; i < nsub; i += K3_BLOCK) hist[i] = 0;
-    __syncthreads();
-    const uint32_t GS = 16, g = tid / GS, lane = tid % GS, ngroups = K3_BLOCK / GS;
-    for (uint32_t s = g; s < in.nb_samples; s += ngroups) {
+__global__ void __launch_bounds__(256)
+k_segment_rows(SimkaMergeIn in, SimkaKeyCfg cfg, uint64_t part_begin, uint32_t np, ull *seg_abs, uint4 *rows, uint32_t *err) {
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint64_t nseg = (uint64_t)np * in.nb_samples;
+    const uint64_t nw = (uint64_t)gridDim.x * 4u;
+    for (uint64_t g = (uint64_t)blockIdx.x * 4u + (threadIdx.x >> 6); g < nseg; g += nw) {
+        const uint64_t pi = g / in.nb_samples;
+        const uint32_t s = (uint32_t)(g - pi * in.nb_samples);
+        const uint64_t p = part_begin + pi;
         const uint32_t n = in.fcnt[(size_t)s * in.nparts + p];
         const ull b = in.sample_base[s] + in.foff[(size_t)s * in.nparts + p];
-        for (uint32_t i = lane; i < n; i += GS) atomicAdd(&hist[simka_key_sub(in.solid_keys[b + i], cfg)], 1u);
-    }
-    __syncthreads();
-    block_excl_scan<K3_BLOCK>(hist, nsub, tmp);
-    const uint32_t rel = (uint32_t)(part_off[p] - batch_base);
-    for (uint32_t i = tid; i < nsub; i += K3_BLOCK) fb_off[(size_t)blockIdx.x * nsub + i] = rel + hist[i];
-    __syncthreads();
-    for (uint32_t s = g; s < in.nb_samples; s += ngroups) {
-        const uint32_t n = in.fcnt[(size_t)s * in.nparts + p];
-        const ull b = in.sample_base[s] + in.foff[(size_t)s * in.nparts + p];
-        for (uint32_t i = lane; i < n; i += GS) {
-            const ull key = in.solid_keys[b + i];
-            const uint32_t pos = rel + atomicAdd(&hist[simka_key_sub(key, cfg)], 1u);
-            mkeys[pos] = key;
-            mvals[pos] = ((ull)s << 32) | (ull)in.solid_counts[b + i];
+        uint32_t e[SIMKA_SEG_BLOCKS];
+#pragma unroll
+        for (uint32_t q = 0; q < SIMKA_SEG_BLOCKS; q++) e[q] = 0;
+        uint32_t last = 0; bool bad = n > 0xffffu;
+        for (uint32_t i0 = 0; i0 < n; i0 += 64u) {
+            const bool v = i0 + lane < n;
+            const uint32_t blk = v ? simka_key_hash32(in.solid_keys[b + i0 + lane]) >> (32u - SIMKA_SEG_BITS) : SIMKA_SEG_BLOCKS;     // (beyond the end: above every block)
+            const uint32_t prev = lane ? (uint32_t)__shfl_up((int)blk, 1, 64) : last;
+            if (v && prev > blk) bad = true;
+            last = (uint32_t)__builtin_amdgcn_readlane((int)blk, 63);
+#pragma unroll
+            for (uint32_t q = 0; q < SIMKA_SEG_BLOCKS; q++) e[q] += (uint32_t)__popcll(__ballot(blk <= q));
+        }
+        if (__ballot(bad)) { if (lane == 0) atomicOr(err, SIMKA_DEVERR_UNORDERED); }
+        if (lane == 0) {
+            seg_abs[g] = b;
+            uint4 r0, r1;
+            r0.x = e[0] | (e[1] << 16); r0.y = e[2] | (e[3] << 16); r0.z = e[4] | (e[5] << 16); r0.w = e[6] | (e[7] << 16);
+            r1.x = e[8] | (e[9] << 16); r1.y = e[10] | (e[11] << 16); r1.z = e[12] | (e[13] << 16); r1.w = e[14] | (e[15] << 16);
+            rows[2 * g] = r0; rows[2 * g + 1] = r1;
         }
     }
 }
@@ -180,7 +187,7 @@ k_regroup(SimkaMergeIn in, SimkaKeyCfg cfg, uint64_t part_begin, const ull *part
 // reserved in slabs, one global atomic per slab instead of three per sub-range.
 // --------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(K3_BLOCK)
-k_group(const ull *mkeys, const ull *mvals, const uint32_t *fb_off, uint32_t nfb, uint32_t batch_total,
+k_group(SimkaMergeIn in, const ull *seg_abs, const uint16_t *rows, uint32_t np,
         SimkaKeyCfg cfg, uint32_t min_share, SimkaCsrOut o) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     ull *s_slab = (ull *)smem;                              // [6] ent pos/end, grp pos/end, span pos/end
@@ -204,17 +211,98 @@ k_group(const ull *mkeys, const ull *mvals, const uint32_t *fb_off, uint32_t nfb
     uint32_t *gpk = (uint32_t *)(scnt + K3_TABLE);                       // [K3_TABLE] packed prefix: entries | groups << 20; later the fill cursor
     uint16_t *rslot = (uint16_t *)(gpk + K3_TABLE);        // [K3_CAP]
     ull *s_stack = (ull *)(rslot + K3_CAP);                // [2*K3_STACK] (selector bits, value) of the refinement DFS: one level per key bit
+    // a tile of samples while the records are gathered (gpk is written after that): first record of the sample's slice in the arena, the
+    // slices' exclusive prefix
+    ull *sbeg = (ull *)gpk;                                // [K3_BLOCK]
+    uint32_t *spre = (uint32_t *)(sbeg + K3_BLOCK);        // [K3_BLOCK + 1]
+    static_assert(K3_BLOCK * 12 + 4 <= K3_TABLE * 4, "the sample tile fits the prefix array it overlays");
 
     const uint32_t tid = threadIdx.x;
-    const uint32_t free_bits = cfg.W - cfg.pb - cfg.t;     // bits left to split an over-full sub-range
+    const uint32_t free_bits = cfg.W;                      // an over-full sub-range is split on the bits of simka_mix(key), a bijection on W bits: every bit fixed = one k-mer
     if (tid < 6) s_slab[tid] = 0;
     if (tid == 0) { s_ndist = 0; s_nshared = 0; s_open = ~0ull; s_open_nent = 0; s_open_ngrp = 0; s_open_maxc = 0; }
     __syncthreads();
 
-    for (uint32_t fb = blockIdx.x; fb < nfb; fb += gridDim.x) {
-        const uint32_t rb = fb_off[fb];
-        const uint32_t re = (fb + 1 < nfb) ? fb_off[fb + 1] : batch_total;
-        const uint32_t R = re - rb;
+    // Work item = a partition of the batch: its sub-ranges one after the other, so the lines of the N segments that two neighbouring
+    // slices share are touched by ONE block back to back.  The rows of the first K3_BLOCK samples live in registers for the whole
+    // partition (thread s: sample s), the rows of the NEXT partition are loaded while this one is grouped.
+    const uint32_t nsub = 1u << cfg.t, N = in.nb_samples;
+    const uint32_t bw = SIMKA_SEG_BLOCKS >> cfg.t;         // key-prefix blocks per sub-range (t <= SIMKA_SEG_BITS)
+    const uint4 *rows4 = (const uint4 *)rows;
+    // end of key-prefix block i (0 .. 15) of a row held as two uint4; i == ~0u: 0
+    auto row_end = [](const uint4 &r0, const uint4 &r1, uint32_t i) -> uint32_t {
+        if (i == ~0u) return 0u;
+        const uint32_t w = i >> 1;
+        const uint32_t a0 = (w & 2u) ? ((w & 1u) ? r0.w : r0.z) : ((w & 1u) ? r0.y : r0.x), a1 = (w & 2u) ? ((w & 1u) ? r1.w : r1.z) : ((w & 1u) ? r1.y : r1.x);
+        const uint32_t a = (w & 4u) ? a1 : a0;
+        return (i & 1u) ? a >> 16 : a & 0xffffu;
+    };
+    uint4 rr0 = make_uint4(0, 0, 0, 0), rr1 = rr0, nr0 = rr0, nr1 = rr0; ull rab = 0, nab = 0;       // this partition's row / the next one's (sample tid)
+    uint32_t cur_pi = blockIdx.x, cur_j = 0;
+    if (cur_pi < np && tid < N) { const size_t g = (size_t)cur_pi * N + tid; nr0 = rows4[2 * g]; nr1 = rows4[2 * g + 1]; nab = seg_abs[g]; }
+    // f(key, sample << 32 | count) for every record of the sub-range: a tile of K3_BLOCK samples at a time -- their slices from the
+    // rows, an exclusive scan, then one record per thread (the thread finds its sample in the prefix table)
+    auto for_records = [&](auto &&f) {
+        for (uint32_t s0 = 0; s0 < N; s0 += K3_BLOCK) {
+            const uint32_t s = s0 + tid;
+            uint32_t c = 0; ull b = 0;
+            if (s0 == 0) {
+                const uint32_t lo = row_end(rr0, rr1, cur_j * bw - 1u), hi = row_end(rr0, rr1, (cur_j + 1u) * bw - 1u);      // (cur_j == 0: ~0u)
+                c = hi - lo; b = rab + lo;
+            } else if (s < N) {
+                const size_t g = (size_t)cur_pi * N + s;
+                const uint16_t *row = rows + g * SIMKA_SEG_BLOCKS;
+                const uint32_t lo = cur_j ? row[cur_j * bw - 1u] : 0u, hi = row[(cur_j + 1u) * bw - 1u];
+                c = hi - lo; b = seg_abs[g] + lo;
+            }
+            __syncthreads();           // (the tables of the tile before are done with)
+            sbeg[tid] = b;
+            uint32_t excl;
+            const uint32_t tot = block_excl_scan1<K3_BLOCK>(c, excl, tmp + 8);
+            spre[tid] = excl;
+            if (tid == 0) spre[K3_BLOCK] = tot;
+            __syncthreads();
+            const uint32_t ns = N - s0 < (uint32_t)K3_BLOCK ? N - s0 : (uint32_t)K3_BLOCK;
+            for (uint32_t i0 = tid; i0 < tot; i0 += K3_BLOCK * K3_UNROLL) {
+                ull kk[K3_UNROLL], vv[K3_UNROLL];
+#pragma unroll
+                for (int u = 0; u < K3_UNROLL; u++) {
+                    const uint32_t i = i0 + (uint32_t)u * K3_BLOCK;
+                    kk[u] = SIMKA_EMPTY_KEY; vv[u] = 0;
+                    if (i < tot) {
+                        uint32_t lo = 0, hi = ns;          // largest x with spre[x] <= i
+                        while (hi - lo > 1u) { const uint32_t mid = (lo + hi) >> 1; if (spre[mid] <= i) lo = mid; else hi = mid; }
+                        const ull at = sbeg[lo] + (i - spre[lo]);
+                        kk[u] = in.solid_keys[at]; vv[u] = ((ull)(s0 + lo) << 32) | (ull)in.solid_counts[at];
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < K3_UNROLL; u++) if (kk[u] != SIMKA_EMPTY_KEY) f(kk[u], vv[u]);
+            }
+            __syncthreads();           // (gpk, which the tile overlays, is written next)
+        }
+    };
+    for (; cur_pi < np; cur_pi += gridDim.x) {
+        {      // a new partition: its rows arrived while the one before was grouped; the next one's set off
+            rr0 = nr0; rr1 = nr1; rab = nab;
+            const uint32_t npi = cur_pi + gridDim.x;
+            nr0 = make_uint4(0, 0, 0, 0); nr1 = nr0; nab = 0;
+            if (npi < np && tid < N) { const size_t g = (size_t)npi * N + tid; nr0 = rows4[2 * g]; nr1 = rows4[2 * g + 1]; nab = seg_abs[g]; }
+        }
+      for (cur_j = 0; cur_j < nsub; cur_j++) {
+        const uint32_t this_j = cur_j;
+        // records of the sub-range over all samples
+        uint32_t R = 0;
+        {
+            uint32_t c = row_end(rr0, rr1, (this_j + 1u) * bw - 1u) - row_end(rr0, rr1, this_j * bw - 1u);
+            for (uint32_t s = tid + K3_BLOCK; s < N; s += K3_BLOCK) {
+                const uint16_t *row = rows + ((size_t)cur_pi * N + s) * SIMKA_SEG_BLOCKS;
+                c += (uint32_t)row[(this_j + 1u) * bw - 1u] - (this_j ? (uint32_t)row[this_j * bw - 1u] : 0u);
+            }
+            __syncthreads();
+            uint32_t excl;
+            R = block_excl_scan1<K3_BLOCK>(c, excl, tmp + 8);
+        }
         if (R == 0) continue;
         uint32_t e0 = 0;
         while (((R >> e0) > K3_PRESPLIT) && e0 < free_bits) e0++;
@@ -226,7 +314,7 @@ k_group(const ull *mkeys, const ull *mvals, const uint32_t *fb_off, uint32_t nfb
                 __syncthreads();
                 if (s_sp == 0) break;
                 const uint32_t e = (uint32_t)s_stack[2 * (s_sp - 1)];
-                const ull val = s_stack[2 * (s_sp - 1) + 1];          // up to free_bits (> 32) selector bits
+                const ull val_ = s_stack[2 * (s_sp - 1) + 1];         // up to free_bits (> 32) selector bits
                 __syncthreads();
                 if (tid == 0) { s_sp--; s_nrec = 0; s_ovf = 0; s_maxc = 0; }
                 {
@@ -240,33 +328,21 @@ k_group(const ull *mkeys, const ull *mvals, const uint32_t *fb_off, uint32_t nfb
                 // ---- hash the records of this (sub-)range; K3_UNROLL independent loads per thread
                 const uint32_t selshift = free_bits - e;
                 uint32_t mymax = 0;
-                for (uint32_t i0 = rb + tid; i0 < re; i0 += K3_BLOCK * K3_UNROLL) {
-                    ull kk[K3_UNROLL], vv[K3_UNROLL];
-#pragma unroll
-                    for (int u = 0; u < K3_UNROLL; u++) {
-                        const uint32_t i = i0 + (uint32_t)u * K3_BLOCK;
-                        kk[u] = SIMKA_EMPTY_KEY; vv[u] = 0;
-                        if (i < re) { kk[u] = mkeys[i]; vv[u] = mvals[i]; }
+                for_records([&](ull key, ull val) {
+                    if (e && ((simka_mix(key, cfg.mask, cfg.xs) >> selshift) & ((1ull << e) - 1ull)) != val_) return;
+                    const uint32_t idx = atomicAdd(&s_nrec, 1u);
+                    if (idx >= K3_CAP) { s_ovf = 1; return; }
+                    uint32_t slot = simka_slot_hash(key) & (K3_TABLE - 1u);
+                    for (;;) {   // 2*K3_CAP slots, at most K3_CAP records: always terminates
+                        const ull prev = atomicCAS(&tkeys[slot], SIMKA_EMPTY_KEY, key);
+                        if (prev == SIMKA_EMPTY_KEY || prev == key) break;
+                        slot = (slot + 1u) & (K3_TABLE - 1u);
                     }
-#pragma unroll
-                    for (int u = 0; u < K3_UNROLL; u++) {
-                        const ull key = kk[u];
-                        if (key == SIMKA_EMPTY_KEY) continue;
-                        if (e && ((key >> selshift) & ((1ull << e) - 1ull)) != val) continue;
-                        const uint32_t idx = atomicAdd(&s_nrec, 1u);
-                        if (idx >= K3_CAP) { s_ovf = 1; continue; }
-                        uint32_t slot = simka_slot_hash(key) & (K3_TABLE - 1u);
-                        for (;;) {   // 2*K3_CAP slots, at most K3_CAP records: always terminates
-                            const ull prev = atomicCAS(&tkeys[slot], SIMKA_EMPTY_KEY, key);
-                            if (prev == SIMKA_EMPTY_KEY || prev == key) break;
-                            slot = (slot + 1u) & (K3_TABLE - 1u);
-                        }
-                        atomicAdd((uint32_t *)scnt + (slot >> 1), 1u << ((slot & 1u) * 16u));
-                        rslot[idx] = (uint16_t)slot;
-                        rval[idx] = vv[u];
-                        if ((uint32_t)vv[u] > mymax) mymax = (uint32_t)vv[u];
-                    }
-                }
+                    atomicAdd((uint32_t *)scnt + (slot >> 1), 1u << ((slot & 1u) * 16u));
+                    rslot[idx] = (uint16_t)slot;
+                    rval[idx] = val;
+                    if ((uint32_t)val > mymax) mymax = (uint32_t)val;
+                });
 #pragma unroll
                 for (int o_ = 32; o_ > 0; o_ >>= 1) { const uint32_t t_ = __shfl_xor(mymax, o_, 64); mymax = t_ > mymax ? t_ : mymax; }
                 if ((tid & 63u) == 0 && mymax) atomicMax(&s_maxc, mymax);
@@ -290,20 +366,18 @@ k_group(const ull *mkeys, const ull *mvals, const uint32_t *fb_off, uint32_t nfb
                         __syncthreads();
                         if (s_ovf != 2) {
                             const ull eb_ = s_ebase;
-                            for (uint32_t i = rb + tid; i < re; i += K3_BLOCK) {
-                                const ull key = mkeys[i];
-                                if (key == SIMKA_EMPTY_KEY) continue;
-                                if (e && ((key >> selshift) & ((1ull << e) - 1ull)) != val) continue;
-                                o.entries[eb_ + atomicAdd(&s_nrec, 1u)] = mvals[i];
-                            }
+                            for_records([&](ull key, ull val) {
+                                if (e && ((simka_mix(key, cfg.mask, cfg.xs) >> selshift) & ((1ull << e) - 1ull)) != val_) return;
+                                o.entries[eb_ + atomicAdd(&s_nrec, 1u)] = val;
+                            });
                         }
                         continue;
                     }
                     if (tid == 0) {   // refine: two children with one more selector bit
                         if (s_sp + 2 > K3_STACK) { atomicOr(o.err, SIMKA_DEVERR_GROUP_OVERFLOW); s_sp = 0; }
                         else {
-                            s_stack[2 * s_sp] = e + 1; s_stack[2 * s_sp + 1] = val * 2ull + 1ull; s_sp++;
-                            s_stack[2 * s_sp] = e + 1; s_stack[2 * s_sp + 1] = val * 2ull; s_sp++;
+                            s_stack[2 * s_sp] = e + 1; s_stack[2 * s_sp + 1] = val_ * 2ull + 1ull; s_sp++;
+                            s_stack[2 * s_sp] = e + 1; s_stack[2 * s_sp + 1] = val_ * 2ull; s_sp++;
                         }
                     }
                     continue;
@@ -360,6 +434,7 @@ k_group(const ull *mkeys, const ull *mvals, const uint32_t *fb_off, uint32_t nfb
                 }
             }
         }
+      }
     }
     __syncthreads();
     if (tid == 0) {

@@ -59,7 +59,7 @@ typedef unsigned long long ull;
 #define SKM_FAST_QCAP (64 + 64 * SKM_FAST_U)      // retry queue of a wave: what one iteration can add on top of an undrained rest
 #define SKM_FAST_BMW 32          // u64 words of a wave's record-start bitmap (64 records x nmax <= 32 k-mers)
 #define SKM_FAST_WREG ((SKM_FAST_BMW * 8 + SKM_FAST_QCAP * 10 + 15) / 16 * 16)     // bytes of a wave's private LDS region
-#define SKM_SORT_BITS 3          // solid records leave the count kernel ordered by the top 3 bits of the slot hash
+#define SKM_SORT_BITS 4          // solid records leave the count kernels ordered by the top 4 bits of their key (SIMKA_SEG_BITS): the merge reads sub-ranges of a segment in place
 #define SKM_NSORT (1 << SKM_SORT_BITS)
 
 struct SimkaSkmCfg {
@@ -80,8 +80,8 @@ SIMKA_HD uint32_t skm_pid(uint32_t minhash, uint32_t pb) { return pb ? (uint32_t
 SIMKA_HD bool skm_owns(uint32_t pid, const SimkaSkmCfg &c) { return c.shard_count == 1u || (pid % c.shard_count) == c.shard_index; }
 SIMKA_HD uint32_t skm_rec_n(const uint4 &r) { return ((r.w >> 6) & 31u) + 1u; }
 SIMKA_HD uint32_t skm_rec_pid(const uint4 &r) { return r.w >> 11; }
-// 32-bit hash of a canonical k-mer: slot and sort order of the count kernel's table
-SIMKA_HD uint32_t skm_kmer_hash(uint64_t canon) { return (uint32_t)canon * 0x9E3779B1u + (uint32_t)(canon >> 32) * 0x85EBCA6Bu; }
+// (slot and sort order of the count kernels' tables: simka_key_hash32 of the canonical k-mer, simka_device.h -- what leaves a table in
+// slot order is ordered by the top bits of that hash)
 
 // reverse complement of the 32 bases of a word (code ^ 2 = complement)
 __device__ __forceinline__ uint64_t skm_revcomp64(uint64_t x) {
@@ -677,7 +677,8 @@ k_skm_count(const uint4 *recs, const uint32_t *pstart, const uint32_t *pcnt, Sim
                             const uint64_t fwd = skm_kmer_at(rc, e & 31u, cfg);
                             const uint64_t rev = skm_revcomp64(fwd) >> (64u - 2u * cfg.k);
                             const uint64_t canon = fwd < rev ? fwd : rev;
-                            const uint32_t h = skm_kmer_hash(canon);
+                            const uint64_t mkey = canon;
+                            const uint32_t h = simka_key_hash32(canon);
                             if (rho && (h >> (32u - rho)) != r) continue;
                             const uint32_t hs = rho ? (h << rho) : h;
                             uint32_t slot = hs >> (32u - TSL);
@@ -686,8 +687,8 @@ k_skm_count(const uint4 *recs, const uint32_t *pstart, const uint32_t *pcnt, Sim
                             const uint32_t bbase = slot & ~bmask;
                             bool placed = false;
                             for (uint32_t probe = 0; probe <= bmask; probe++) {
-                                const ull prev = atomicCAS(&tkeys[slot], SIMKA_EMPTY_KEY, (ull)canon);
-                                if (prev == SIMKA_EMPTY_KEY || prev == (ull)canon) { atomicAdd(&tcnt[slot], 1u); placed = true; break; }
+                                const ull prev = atomicCAS(&tkeys[slot], SIMKA_EMPTY_KEY, (ull)mkey);
+                                if (prev == SIMKA_EMPTY_KEY || prev == (ull)mkey) { atomicAdd(&tcnt[slot], 1u); placed = true; break; }
                                 slot = bbase | ((slot + 1u) & bmask);
                             }
                             if (!placed) s_fail = 1u;
@@ -727,7 +728,7 @@ k_skm_count(const uint4 *recs, const uint32_t *pstart, const uint32_t *pcnt, Sim
 #pragma unroll
                         for (uint32_t q = 0; q < SPT; q++) {
                             if (cs[q]) {
-                                o.solid_keys[pos] = simka_mix(ks[q], kcfg.mask, kcfg.xs); o.solid_counts[pos] = cs[q]; pos++;
+                                o.solid_keys[pos] = ks[q]; o.solid_counts[pos] = cs[q]; pos++;
                                 if (o.hist) count_hist(o, lhist, cs[q]);
                             }
                         }
@@ -975,7 +976,7 @@ k_skm_count_fast(const uint4 *recs, const uint32_t *pstart, const uint32_t *pcnt
                     const uint64_t fw = skm_kmer_at(rx[u], (f0 + 64u * u + lane - (rx[u].w >> 6)) & 31u, cfg);
                     const uint64_t rv = skm_revcomp64(fw) >> (64u - 2u * cfg.k);
                     cu[u] = fw < rv ? fw : rv;
-                    su[u] = skm_kmer_hash(cu[u]) >> (32u - TSL);
+                    su[u] = simka_key_hash32(cu[u]) >> (32u - TSL);
                 }
                 // all U inserts in flight together, the next iteration's records behind them.  No lane is masked off: a lane
                 // beyond the wave's last k-mer swaps EMPTY for EMPTY and adds 0, so the whole step is straight-line code and every wait
@@ -1095,7 +1096,7 @@ k_skm_count_fast(const uint4 *recs, const uint32_t *pstart, const uint32_t *pcnt
                 for (uint32_t r = lane; r < wtot; r += 64u) {
                     const ull key = wk[r]; const uint32_t c = wc[r];
                     const ull pos = base_ + wpre + r;
-                    o.solid_keys[pos] = simka_mix(key, kcfg.mask, kcfg.xs); o.solid_counts[pos] = c;
+                    o.solid_keys[pos] = key; o.solid_counts[pos] = c;
                     if (o.hist) count_hist(o, lhist, c);
                 }
             } else {
@@ -1103,7 +1104,7 @@ k_skm_count_fast(const uint4 *recs, const uint32_t *pstart, const uint32_t *pcnt
 #pragma unroll
                 for (uint32_t q = 0; q < SPT; q++) {
                     if (cs[q]) {
-                        o.solid_keys[pos] = simka_mix(ks[q], kcfg.mask, kcfg.xs); o.solid_counts[pos] = cs[q]; pos++;
+                        o.solid_keys[pos] = ks[q]; o.solid_counts[pos] = cs[q]; pos++;
                         if (o.hist) count_hist(o, lhist, cs[q]);
                     }
                 }
