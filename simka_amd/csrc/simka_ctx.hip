@@ -74,7 +74,9 @@ struct simka_ctx {
     // merge buffers
     ull *d_part_total = nullptr, *d_part_off = nullptr;
     ull *d_work = nullptr;                                    // [2] work counters of the persistent merge-side kernels (zeroed before a launch)
-    ull *d_seg_abs = nullptr; uint4 *d_seg_rows = nullptr;    // merge batch: [partitions][N] first record of a segment, ends of its 16 key-prefix blocks (k_segment_rows)
+    ull *d_seg_abs = nullptr; uint4 *d_seg_rows = nullptr;    // [partitions][N] first record of a segment, ends of its 16 key-hash blocks: all partitions, written by the count kernels
+                                                               // (seg_all), or -- too many segments, or imported spectra (seg_dirty) -- one merge batch at a time by k_segment_rows
+    bool seg_all = false, seg_dirty = false;
     ull *d_entries = nullptr; uint32_t *d_groups = nullptr;
     SimkaSpan *d_spans = nullptr; ull *d_cursors = nullptr; SimkaSpan *d_huge = nullptr;
     uint64_t merge_cap = 0, seg_cap = 0, span_cap = 0, huge_cap = 0;
@@ -314,6 +316,17 @@ static int setup_geometry(simka_ctx *ctx, uint64_t max_kmers) {
     HIPCHK(dev_alloc(&ctx->d_fcnt, (uint64_t)N * ctx->nparts));
     HIPCHK(hipMemsetAsync(ctx->d_foff, 0, (uint64_t)N * ctx->nparts * 4, ctx->stream));
     HIPCHK(hipMemsetAsync(ctx->d_fcnt, 0, (uint64_t)N * ctx->nparts * 4, ctx->stream));
+    // the merge's index of the arena for ALL partitions (40 bytes per segment) if that stays below 1/32 of the device memory
+    {
+        size_t fr = 0, tot_ = 0;
+        const uint64_t nseg = (uint64_t)N * ctx->nparts;
+        if (N >= 2 && hipMemGetInfo(&fr, &tot_) == hipSuccess && nseg * 40 <= tot_ / 32 && dev_alloc(&ctx->d_seg_abs, nseg) == hipSuccess) {
+            if (dev_alloc(&ctx->d_seg_rows, nseg * 2) == hipSuccess) {
+                ctx->seg_all = true; ctx->seg_cap = nseg;
+                HIPCHK(hipMemsetAsync(ctx->d_seg_rows, 0, nseg * 32, ctx->stream));
+            } else { (void)hipFree(ctx->d_seg_abs); ctx->d_seg_abs = nullptr; (void)hipGetLastError(); }
+        } else (void)hipGetLastError();
+    }
     HIPCHK(dev_alloc(&ctx->d_part_total, ctx->nparts + 1));
     HIPCHK(dev_alloc(&ctx->d_part_off, ctx->nparts + 1));
 
@@ -457,7 +470,9 @@ SIMKA_EXPORT int simka_reset(simka_ctx *ctx) {
     if (ctx->geometry_ready) {
         HIPCHK(hipMemsetAsync(ctx->d_foff, 0, (uint64_t)N * ctx->nparts * 4, ctx->stream));
         HIPCHK(hipMemsetAsync(ctx->d_fcnt, 0, (uint64_t)N * ctx->nparts * 4, ctx->stream));
+        if (ctx->seg_all) HIPCHK(hipMemsetAsync(ctx->d_seg_rows, 0, (uint64_t)N * ctx->nparts * 32, ctx->stream));
     }
+    ctx->seg_dirty = false;
     if (ctx->d_hist) {
         HIPCHK(hipMemsetAsync(ctx->d_hist, 0, (uint64_t)N * SIMKA_HIST_MAX * 8, ctx->stream));
         HIPCHK(hipMemsetAsync(ctx->d_ovf_cursor, 0, 16, ctx->stream));
@@ -593,6 +608,7 @@ static int run_count_kernels(simka_ctx *ctx, uint32_t sample, const SimkaScanArg
     o.foff = ctx->d_foff + (uint64_t)sample * ctx->nparts; o.fcnt = ctx->d_fcnt + (uint64_t)sample * ctx->nparts;
     o.totals = (ull *)ctx->d_stats + stats_off_tot(N, ctx->cfg.dist_flags, 0); o.sample = sample; o.nb_samples = N; o.err = ctx->d_err;
     o.phase = nullptr; o.pad_ = 0;
+    o.seg_rows = ctx->seg_all ? (uint16_t *)ctx->d_seg_rows + (size_t)sample * SIMKA_SEG_BLOCKS : nullptr; o.seg_abs = ctx->seg_all ? ctx->d_seg_abs + sample : nullptr;
     // slabs several partitions long (what is left of a slab when the next partition does not fit is lost), but never more than a
     // small share of the arena per block
     o.slab = (uint32_t)std::min<uint64_t>(std::min<uint64_t>(K2_SLAB, std::max<uint64_t>(256, kocc_up / 10 / ((uint64_t)ctx->num_cus * 4 * 8))),
@@ -928,6 +944,7 @@ static int import_sample(simka_ctx *ctx, uint32_t sample, const simka_sample_tot
         HIPCHK(hipStreamSynchronize(ctx->stream));
         ctx->nb_reads[sample] = totals->nb_reads;
         ctx->counted[sample] = 1;
+        ctx->seg_dirty = true;      // (its segments carry no index of key-hash blocks: k_segment_rows builds it at the merge)
         return SIMKA_OK;
     }
     if (!ctx->geometry_ready) {
@@ -991,6 +1008,7 @@ static int import_sample(simka_ctx *ctx, uint32_t sample, const simka_sample_tot
     HIPCHK(hipStreamSynchronize(ctx->stream));       // host buffers (caller's and ours) may go away
     ctx->nb_reads[sample] = totals->nb_reads;
     ctx->counted[sample] = 1;
+    ctx->seg_dirty = true;      // (its segments carry no index of key-hash blocks: k_segment_rows builds it at the merge)
     return SIMKA_OK;
 }
 
@@ -1177,6 +1195,7 @@ SIMKA_EXPORT int simka_import_samples_device(simka_ctx *ctx, const uint32_t *sam
     }
     HIPCHK(hipStreamSynchronize(ctx->stream));
     for (uint32_t j = 0; j < nb; j++) { ctx->nb_reads[samples[j]] = totals[j].nb_reads; ctx->counted[samples[j]] = 1; }
+    ctx->seg_dirty = true;      // (its segments carry no index of key-hash blocks: k_segment_rows builds it at the merge)
     return SIMKA_OK;
 }
 
@@ -1451,7 +1470,7 @@ SIMKA_EXPORT int simka_merge(simka_ctx *ctx) {
         ctx->merge_cap = cap;
     }
     const uint64_t seg_cap = max_parts_batch * N;
-    if (ctx->seg_cap < seg_cap) {
+    if (!ctx->seg_all && ctx->seg_cap < seg_cap) {
         if (ctx->d_seg_abs) HIPCHK(hipFree(ctx->d_seg_abs)); if (ctx->d_seg_rows) HIPCHK(hipFree(ctx->d_seg_rows));
         ctx->d_seg_abs = nullptr; ctx->d_seg_rows = nullptr;
         HIPCHK(dev_alloc(&ctx->d_seg_abs, seg_cap)); HIPCHK(dev_alloc(&ctx->d_seg_rows, seg_cap * 2)); ctx->seg_cap = seg_cap;
@@ -1485,13 +1504,17 @@ SIMKA_EXPORT int simka_merge(simka_ctx *ctx) {
             const uint32_t np = (uint32_t)(pe - pb);
             const uint32_t nfb = np * nsub;
             HIPCHK(hipMemsetAsync(ctx->d_cursors, 0, 32, ctx->stream));
-            launch_timed(ctx, KID_SEG_ROWS, [&] {
-                hipLaunchKernelGGL(k_segment_rows, dim3((uint32_t)std::min<uint64_t>(((uint64_t)np * N + 3) / 4, (uint64_t)ctx->num_cus * 8)), dim3(256), 0, ctx->stream, in, key, pb, np,
-                                   ctx->d_seg_abs, ctx->d_seg_rows, ctx->d_err);
-            });
+            // the index of the batch's segments: written by the count kernels, or built here (imported spectra; too many segments to keep all)
+            ull *b_abs = ctx->d_seg_abs + (ctx->seg_all ? pb * N : 0);
+            uint4 *b_rows = ctx->d_seg_rows + (ctx->seg_all ? pb * N * 2 : 0);
+            if (!ctx->seg_all || ctx->seg_dirty)
+                launch_timed(ctx, KID_SEG_ROWS, [&] {
+                    hipLaunchKernelGGL(k_segment_rows, dim3((uint32_t)std::min<uint64_t>(((uint64_t)np * N + 3) / 4, (uint64_t)ctx->num_cus * 8)), dim3(256), 0, ctx->stream, in, key, pb, np,
+                                       b_abs, b_rows, ctx->d_err);
+                });
             launch_timed(ctx, KID_GROUP, [&] {
-                hipLaunchKernelGGL(k_group, dim3(std::min<uint32_t>(np, grid_group)), dim3(K3_BLOCK), lds_group, ctx->stream, in, (const ull *)ctx->d_seg_abs,
-                                   (const uint16_t *)ctx->d_seg_rows, np, key, min_share, co);
+                hipLaunchKernelGGL(k_group, dim3(std::min<uint32_t>(np, grid_group)), dim3(K3_BLOCK), lds_group, ctx->stream, in, (const ull *)b_abs,
+                                   (const uint16_t *)b_rows, np, key, min_share, co);
             });
             if (getenv("SIMKA_DEBUG_MERGE")) {
                 ull cur[4]; HIPCHK(hipMemcpyAsync(cur, ctx->d_cursors, 32, hipMemcpyDeviceToHost, ctx->stream)); HIPCHK(hipStreamSynchronize(ctx->stream));

@@ -75,6 +75,8 @@ struct SimkaCountOut {
     unsigned long long *solid_keys;
     uint32_t *solid_counts;
     uint32_t *foff, *fcnt;                   // this sample's rows [nparts]
+    uint16_t *seg_rows;                      // the merge's index of the arena, [nparts][N][SIMKA_SEG_BLOCKS] (see k_segment_rows), at this sample; NULL: built at merge time
+    unsigned long long *seg_abs;             // [nparts][N], at this sample
     unsigned long long *totals;              // [SIMKA_NB_TOTALS][N]
     uint32_t sample, nb_samples;
     uint32_t slab, pad_;                     // arena records a block reserves at a time

@@ -242,10 +242,14 @@ k_group(SimkaMergeIn in, const ull *seg_abs, const uint16_t *rows, uint32_t np,
     if (cur_pi < np && tid < N) { const size_t g = (size_t)cur_pi * N + tid; nr0 = rows4[2 * g]; nr1 = rows4[2 * g + 1]; nab = seg_abs[g]; }
     // f(key, sample << 32 | count) for every record of the sub-range: a tile of K3_BLOCK samples at a time -- their slices from the
     // rows, an exclusive scan, then one record per thread (the thread finds its sample in the prefix table)
+    bool tile_ready = false;       // (uniform) the tables of sample tile 0 are already in LDS (the scan that gave R): the first gather reuses them
     auto for_records = [&](auto &&f) {
         for (uint32_t s0 = 0; s0 < N; s0 += K3_BLOCK) {
             const uint32_t s = s0 + tid;
             uint32_t c = 0; ull b = 0;
+            uint32_t tot;
+            if (s0 == 0 && tile_ready) { tile_ready = false; tot = spre[K3_BLOCK]; }
+            else {
             if (s0 == 0) {
                 const uint32_t lo = row_end(rr0, rr1, cur_j * bw - 1u), hi = row_end(rr0, rr1, (cur_j + 1u) * bw - 1u);      // (cur_j == 0: ~0u)
                 c = hi - lo; b = rab + lo;
@@ -258,10 +262,11 @@ k_group(SimkaMergeIn in, const ull *seg_abs, const uint16_t *rows, uint32_t np,
             __syncthreads();           // (the tables of the tile before are done with)
             sbeg[tid] = b;
             uint32_t excl;
-            const uint32_t tot = block_excl_scan1<K3_BLOCK>(c, excl, tmp + 8);
+            tot = block_excl_scan1<K3_BLOCK>(c, excl, tmp + 8);
             spre[tid] = excl;
             if (tid == 0) spre[K3_BLOCK] = tot;
             __syncthreads();
+            }
             const uint32_t ns = N - s0 < (uint32_t)K3_BLOCK ? N - s0 : (uint32_t)K3_BLOCK;
             for (uint32_t i0 = tid; i0 < tot; i0 += K3_BLOCK * K3_UNROLL) {
                 ull kk[K3_UNROLL], vv[K3_UNROLL];
@@ -293,7 +298,17 @@ k_group(SimkaMergeIn in, const ull *seg_abs, const uint16_t *rows, uint32_t np,
         const uint32_t this_j = cur_j;
         // records of the sub-range over all samples
         uint32_t R = 0;
-        {
+        if (N <= (uint32_t)K3_BLOCK) {      // one tile of samples: its scan is the gather's scan too
+            const uint32_t lo = row_end(rr0, rr1, this_j * bw - 1u), c = row_end(rr0, rr1, (this_j + 1u) * bw - 1u) - lo;
+            __syncthreads();
+            sbeg[tid] = rab + lo;
+            uint32_t excl;
+            R = block_excl_scan1<K3_BLOCK>(c, excl, tmp + 8);
+            spre[tid] = excl;
+            if (tid == 0) spre[K3_BLOCK] = R;
+            __syncthreads();
+            tile_ready = true;
+        } else {
             uint32_t c = row_end(rr0, rr1, (this_j + 1u) * bw - 1u) - row_end(rr0, rr1, this_j * bw - 1u);
             for (uint32_t s = tid + K3_BLOCK; s < N; s += K3_BLOCK) {
                 const uint16_t *row = rows + ((size_t)cur_pi * N + s) * SIMKA_SEG_BLOCKS;

@@ -605,6 +605,7 @@ k_skm_count(const uint4 *recs, const uint32_t *pstart, const uint32_t *pcnt, Sim
     uint32_t &s_fail = *(uint32_t *)(smem + 76);
     uint32_t &s_ok = *(uint32_t *)(smem + 80);
     uint32_t *tmp = (uint32_t *)(smem + 128);          // [BLOCK/64]
+    uint32_t *s_row = (uint32_t *)(smem + 192);        // [SIMKA_SEG_BLOCKS] solid records of the partition per key-hash block
     ull *tkeys = (ull *)(smem + SIMKA_LDS_HEAD);       // [TS]
     uint32_t *tcnt = (uint32_t *)(tkeys + SKM_CNT_TS); // [TS]
     uint4 *lrec = (uint4 *)(tcnt + SKM_CNT_TS);        // [BATCH]
@@ -620,6 +621,7 @@ k_skm_count(const uint4 *recs, const uint32_t *pstart, const uint32_t *pcnt, Sim
     if (o.hist) for (uint32_t i = tid; i < SIMKA_HIST_MAX; i += SKM_CNT_BLOCK) lhist[i] = 0;
     if (tid < 5) s_tot[tid] = 0;
     if (tid == 0) { s_slab_pos = 0; s_slab_end = 0; s_fail = 0; }
+    if (tid < SIMKA_SEG_BLOCKS) s_row[tid] = 0;
     ull bt_dall = 0, bt_D = 0, bt_N = 0, bt_Q = 0, bt_kocc = 0;
     __syncthreads();
 
@@ -729,6 +731,7 @@ k_skm_count(const uint4 *recs, const uint32_t *pstart, const uint32_t *pcnt, Sim
                         for (uint32_t q = 0; q < SPT; q++) {
                             if (cs[q]) {
                                 o.solid_keys[pos] = ks[q]; o.solid_counts[pos] = cs[q]; pos++;
+                                if (o.seg_rows) atomicAdd(&s_row[simka_key_hash32(ks[q]) >> (32u - SIMKA_SEG_BITS)], 1u);
                                 if (o.hist) count_hist(o, lhist, cs[q]);
                             }
                         }
@@ -748,6 +751,12 @@ k_skm_count(const uint4 *recs, const uint32_t *pstart, const uint32_t *pcnt, Sim
                 const ull seg = (R == 1) ? s_base : s_base;
                 o.foff[part] = (ok && total_solid) ? (uint32_t)(seg - sample_base) : 0u;
                 o.fcnt[part] = ok ? total_solid : 0u;
+                if (o.seg_rows) {      // (the emit loops of this partition are behind the barrier above)
+                    uint32_t run = 0;
+                    for (uint32_t b_ = 0; b_ < SIMKA_SEG_BLOCKS; b_++) { run += s_row[b_]; s_row[b_] = 0; o.seg_rows[((size_t)part * o.nb_samples) * SIMKA_SEG_BLOCKS + b_] = (uint16_t)(ok ? (run > 0xffffu ? 0xffffu : run) : 0u); }
+                    o.seg_abs[(size_t)part * o.nb_samples] = seg;
+                    if (run > 0xffffu) atomicOr(o.err, SIMKA_DEVERR_UNORDERED);
+                }
             }
             bt_dall += pD_all; bt_D += pD; bt_N += pN; bt_Q += pQ; bt_kocc += pK;
             done = true;
@@ -1088,6 +1097,10 @@ k_skm_count_fast(const uint4 *recs, const uint32_t *pstart, const uint32_t *pcnt
             }
             __syncthreads();
             base_ = s_base; ok_ = s_ok != 0;
+        }
+        if (ok_ && o.seg_rows) {      // the merge's index of this segment: thread 16 b + 15 owns the last slots of key-hash block b, its inclusive prefix is the block's end
+            if ((tid & 15u) == 15u) o.seg_rows[((size_t)part * o.nb_samples) * SIMKA_SEG_BLOCKS + (tid >> 4)] = (uint16_t)(wpre + winc);
+            if (tid == 192) o.seg_abs[(size_t)part * o.nb_samples] = base_;
         }
         PH(6)
         if (ok_) {
