@@ -7,8 +7,10 @@ download, host finalisation into the float32 distance matrices.
 
     python bench.py --gpus N --steps K --warmup W [--workload c2|c3|c3_10 ...]
 
-For N>1 run under torch.distributed.run (one rank per GPU, backend nccl = RCCL): the partition space is
-sharded over ranks (strong scaling: the job is fixed, `value` is the whole-job rate).
+N>1: `python bench.py --gpus N` spawns its own N ranks (one per GPU); it also runs under
+`python -m torch.distributed.run --nproc-per-node N ...` as the driver launches it.  Both decompositions of the fixed job are
+timed (partition shards + one all-reduce; sample shards + spectrum all-to-all + one all-reduce): strong scaling, `value` is the
+whole-job rate of the faster one.  The collectives are RCCL calls made by the C ABI.
 Prints ONE JSON line on rank 0.
 """
 import argparse
@@ -23,6 +25,18 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0     # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s is the measured copy ceiling
+# what limits each kernel (SQ / TCC counters, profiles/r03_c3_sq_counters.txt) -- the path-level roofline is HBM
+# bytes, but only k_skm_split is bound by HBM itself
+KERNEL_BOUND = {
+    "k_skm_scan": "VALU + barriers (canonical m-mer hashes, sliding minimum; 24 waves per CU)",
+    "k_skm_split": "HBM (64-byte runs: partial-line writes amplify the traffic)",
+    "k_skm_count_fast": "LDS atomics + VALU, latency (random-slot 64-bit CAS + counter add per k-mer; 16 waves per CU)",
+    "k_skm_count": "LDS atomics (redo list only)",
+    "k_segment_rows": "HBM (imported spectra only)",
+    "k_group": "LDS atomics + gather latency (hash grouping of the N slices of a sub-range)",
+    "k_pairs": "LDS atomics (three 64-bit adds per pair) + VALU",
+    "k_pairs_global": "L2 atomics",
+}
 
 WORKLOADS = {
     # BASELINE.json configs[1]
@@ -382,7 +396,7 @@ def main():
     alg_bytes_per_step = {
         "k_skm_scan": scan_reads + 8.0 * K_occ * share,
         "k_skm_count_fast": 8.0 * K_occ * share + 12.0 * K_dist * share,
-        "k_regroup": 12.0 * K_solid * share,
+        "k_group": 12.0 * K_solid * share,
     }
     kern_ms = {kname: ms for kname, (cnt, ms) in prof.items()}
     total_kernel_ms = sum(kern_ms.values())
@@ -413,8 +427,8 @@ def main():
                 tot += v["traffic_bytes_per_launch"] * v["launches"]; n += v["launches"]
         return tot / n if n else None
     try:
-        tf = os.path.join(ROOT, "profiles", "r02_%s_hbm_traffic.json" % args.workload)
-        if world == 1 and not args.reads and not args.samples and os.path.exists(tf):
+        tf = next((f for f in (os.path.join(ROOT, "profiles", "r%02d_%s_hbm_traffic.json" % (rd, args.workload)) for rd in (3, 2)) if os.path.exists(f)), "")
+        if world == 1 and not args.reads and not args.samples and tf:
             tk = json.load(open(tf))["kernels"]
             traffic = measured_traffic(dom)
             traffic_src = os.path.relpath(tf, ROOT)
@@ -425,11 +439,18 @@ def main():
         if cnt == 0:
             continue
         ab = alg_bytes_per_step.get(kname, 0.0)
+        mt = measured_traffic(kname)
         per_kernel[kname] = {"launches_per_step": cnt / prof_steps, "ms_per_step": ms / prof_steps,
                              "alg_bytes_per_step": ab, "alg_GBps": (ab * prof_steps / (ms * 1e-3) / 1e9) if ms > 0 else 0.0,
-                             "hbm_traffic_bytes_per_launch": measured_traffic(kname)}
+                             "hbm_traffic_bytes_per_launch": mt,
+                             # what the kernel really moves over HBM (PMC counters) against the 8 TB/s peak -- NOT the attributed bytes above
+                             "hbm_frac_measured": (mt * cnt / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if (mt and ms > 0) else None,
+                             "bound": KERNEL_BOUND.get(kname)}
     roofline = {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
+                # `frac` prices the kernel in SURVEY 8(d)'s design-independent bytes (8-byte k-mers); its real HBM traffic is `traffic`:
+                "hbm_frac_measured": (traffic / (dom_avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if (traffic and dom_avg_ms > 0) else None,
+                "kernel_bound": KERNEL_BOUND.get(dom),
                 "avg_launch_ms": dom_avg_ms, "launches": dom_launches, "alg_bytes_per_launch": dom_bytes_per_launch,
                 "path_achieved": path_gbs, "path_frac": path_gbs / HBM_PEAK_GBS, "path_alg_bytes_per_step": b_alg,
                 "kernel_ms_per_step": {kk: v / prof_steps for kk, v in kern_ms.items()}, "kernels": per_kernel,

@@ -10,8 +10,10 @@
  * (ref: src/SimkaPotara.cpp:149-160, src/SimkaCount.cpp:382-390, src/SimkaMerge.cpp:1582-1590).
  *
  * Threading: a simka_ctx is single-owner (one host thread, one GPU), like one simkaCount /
- * simkaMerge process in the reference.  All device work of a ctx is issued on ONE HIP
- * stream (the caller's, or a private one); calls are asynchronous unless stated.
+ * simkaMerge process in the reference.  The device work of a ctx runs on streams the ctx owns:
+ * consecutive samples alternate between two "lanes" (a stream and scratch buffers each, so the
+ * scan of one sample overlaps the count of another), host-provided reads arrive through a copy
+ * stream, merge / statistics on the ctx stream; calls are asynchronous unless stated.
  */
 #ifndef SIMKA_HIP_H
 #define SIMKA_HIP_H
@@ -33,7 +35,7 @@ enum {
     SIMKA_ERR_OVERFLOW = 4,    /* a partition exceeded its LDS table: re-create with more partitions */
     SIMKA_ERR_STATE = 5,       /* call order violated (e.g. merge before every sample was counted) */
     SIMKA_ERR_IO = 6,          /* file could not be read / written */
-    SIMKA_ERR_UNSUPPORTED = 7  /* feature not available on the device path (e.g. k >= 32) */
+    SIMKA_ERR_UNSUPPORTED = 7  /* feature not available here (e.g. a collective without RCCL installed) */
 };
 
 /* -simple-dist / -complex-dist   ref: src/core/Simka.cpp:25-117, src/core/SimkaAlgorithm.cpp:178-179 */
@@ -193,7 +195,8 @@ int simka_merge(simka_ctx *ctx);
 /* ---- statistics ---------------------------------------------------------------------------
  * The accumulators live in ONE flat device buffer of nb_u64 64-bit words so that the
  * cross-shard reduction (SimkaStatistics::operator+=, ref: src/core/SimkaDistance.cpp:156-213)
- * is a single all-reduce(sum, uint64) issued by the caller (RCCL / torch.distributed). */
+ * is a single all-reduce(sum, uint64): simka_stats_allreduce() below (RCCL), or the caller's own
+ * collective on this buffer. */
 int simka_stats_device_buffer(simka_ctx *ctx, void **device_ptr, uint64_t *nb_u64);
 /* download (synchronises) into a host buffer of nb_u64 words and describe it */
 int simka_stats_download(simka_ctx *ctx, uint64_t *host_buf, uint64_t nb_u64, simka_stats_view *view);

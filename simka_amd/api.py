@@ -73,7 +73,10 @@ def load_library(build_if_missing=True):
         import torch  # noqa: F401
     except Exception:
         pass
-    path = os.environ.get("SIMKA_LIB_OVERRIDE") or _build.LIB_PATH      # (experiments: an instrumented build of the same sources)
+    path = _build.LIB_PATH
+    ov = os.environ.get("SIMKA_LIB_OVERRIDE")      # A/B runs: another build of the same sources, accepted only from the package's own lib directory
+    if ov and os.path.dirname(os.path.realpath(ov)) == os.path.realpath(_build.LIB_DIR):
+        path = ov
     if build_if_missing and not os.path.exists(path):
         _build.build()
     if not os.path.exists(path):

@@ -48,7 +48,7 @@ def build(force=False, verbose=False):
     hipcc = _hipcc()
     if force or _stale(LIB_PATH, LIB_DEPS):
         cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-fvisibility=hidden",
-               "-Wno-unused-result", "-o", LIB_PATH] + os.environ.get("SIMKA_EXTRA_CFLAGS", "").split() + LIB_SOURCES + ["-lz", "-ldl"]
+               "-Wno-unused-result", "-o", LIB_PATH] + LIB_SOURCES + ["-lz", "-ldl"]
         out = _run(cmd)
         if verbose:
             print(out)

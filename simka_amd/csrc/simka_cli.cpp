@@ -46,6 +46,7 @@ struct Options {
     int verbose = 1;
     int nb_gpus = 1, first_gpu = 0;     // new: GPUs to spread the samples (count) and the partition ranges (merge) over
     bool same_gpu = false;              // new (tests): all -nb-gpus contexts on GPU -gpu
+    bool gpu_allreduce = false;         // new: -nb-gpus combines the merges' accumulators with one RCCL all-reduce instead of summing them on the host
     long long solid_capacity = 0;       // new (tests): records of the solid-spectrum arena of every context (0: from the free memory)
     int merge_ranges = 0;               // new: >0 keeps the spectra in host memory and merges in that many partition ranges per GPU
     bool parse_only = false;            // new: stop after reading + packing the inputs (ingest benchmark, no GPU needed)
@@ -130,6 +131,7 @@ Options parse_args(int argc, char **argv) {
         else if (a == "-nb-gpus") o.nb_gpus = atoi(need(i).c_str());
         else if (a == "-gpu") o.first_gpu = atoi(need(i).c_str());
         else if (a == "-gpu-shared") o.same_gpu = true;
+        else if (a == "-gpu-allreduce") o.gpu_allreduce = true;
         else if (a == "-merge-ranges") o.merge_ranges = atoi(need(i).c_str());
         else if (a == "-solid-capacity") o.solid_capacity = atoll(need(i).c_str());
         else if (a == "-parse-only") o.parse_only = true;
@@ -254,7 +256,8 @@ uint64_t count_reads(const Sample &s) {
 
 // Page-locked host buffers for what goes to the GPU (simka_host_alloc: the H2D copy is then one DMA into the staging buffer of
 // the sample's lane; plain malloc when pinning fails).  Blocks are recycled through a pool: pinning costs about as much as
-// first-touching the pages, and the loader keeps only a window of samples alive.
+// first-touching the pages, and the loader keeps only a window of samples alive.  The pool holds at most kMaxIdleBytes of idle blocks,
+// and a request is never served by a block more than four times its size (a deep sample's buffer is not pinned forever behind small ones).
 class PinnedPool {
 public:
     static PinnedPool &get() { static PinnedPool p; return p; }
@@ -262,8 +265,8 @@ public:
         {
             std::lock_guard<std::mutex> g(m_);
             size_t best = free_.size();
-            for (size_t i = 0; i < free_.size(); i++) if (free_[i].cap >= bytes && (best == free_.size() || free_[i].cap < free_[best].cap)) best = i;
-            if (best != free_.size()) { Block b = free_[best]; free_.erase(free_.begin() + (long)best); cap = b.cap; pinned = b.pinned; return b.p; }
+            for (size_t i = 0; i < free_.size(); i++) if (free_[i].cap >= bytes && free_[i].cap / 4 <= bytes + (1u << 20) && (best == free_.size() || free_[i].cap < free_[best].cap)) best = i;
+            if (best != free_.size()) { Block b = free_[best]; free_.erase(free_.begin() + (long)best); idle_ -= b.cap; cap = b.cap; pinned = b.pinned; return b.p; }
         }
         void *p = nullptr;
         cap = (bytes + (1u << 20)) & ~(size_t)((1u << 20) - 1);
@@ -274,12 +277,15 @@ public:
     void give(void *p, size_t cap, bool pinned) {
         if (!p) return;
         std::lock_guard<std::mutex> g(m_);
-        if (free_.size() >= 64) { if (pinned) simka_host_free(p); else free(p); return; }
+        if (free_.size() >= 64 || idle_ + cap > kMaxIdleBytes) { if (pinned) simka_host_free(p); else free(p); return; }
         free_.push_back(Block{p, cap, pinned});
+        idle_ += cap;
     }
 private:
     struct Block { void *p; size_t cap; bool pinned; };
+    static constexpr size_t kMaxIdleBytes = (size_t)8 << 30;
     std::vector<Block> free_;
+    size_t idle_ = 0;
     std::mutex m_;
 };
 
@@ -803,10 +809,14 @@ int main(int argc, char **argv) {
         bool have_tail = false;
         // One range per GPU on distinct devices: the heads of the G merges are combined by ONE RCCL all-reduce over xGMI
         // (simka_stats_allreduce_head: SimkaStatistics::operator+= across GPUs, ref: src/core/SimkaDistance.cpp:156-213); the
-        // imported per-sample totals are global on every GPU already.  Several ranges per GPU (or -gpu-shared): summed on the host.
-        const bool use_rccl = G > 1 && V == G && !o.same_gpu && !getenv("SIMKA_NO_RCCL");      // (SIMKA_NO_RCCL=1: sum on the host)
+        // imported per-sample totals are global on every GPU already.  Opt-in (-gpu-allreduce: no multi-GPU node has run it yet); the
+        // default, several ranges per GPU, -gpu-shared, or no RCCL on the machine: summed on the host (0.7 MB per GPU at N = 100).
+        bool use_rccl = o.gpu_allreduce && G > 1 && V == G && !o.same_gpu;
         uint8_t comm_id[SIMKA_COMM_ID_BYTES];
-        if (use_rccl && simka_comm_unique_id(comm_id) != SIMKA_OK) die(std::string("EXCEPTION: simka_comm_unique_id: ") + simka_comm_last_error(nullptr));
+        if (use_rccl && simka_comm_unique_id(comm_id) != SIMKA_OK) {
+            std::cerr << "-gpu-allreduce: " << simka_comm_last_error(nullptr) << "; summing on the host" << std::endl;
+            use_rccl = false;
+        }
         auto merger = [&](uint32_t g) {
             simka_ctx *c = make_ctx(N, device_of(g));
             simka_comm *comm = nullptr;

@@ -261,7 +261,7 @@ static int set_lds_attr(simka_ctx *ctx) {
 // ~SIMKA_TARGET_PER_PART k-mer occurrences of the largest sample per partition (one LDS table of k_skm_count_fast)
 static uint32_t default_log2_partitions(uint64_t max_kmers, uint32_t shard_count) {
     const uint64_t per_shard = std::max<uint64_t>(1, max_kmers / std::max(1u, shard_count));
-    static const uint64_t target = getenv("SIMKA_TARGET_PER_PART") ? (uint64_t)atoll(getenv("SIMKA_TARGET_PER_PART")) : (uint64_t)SIMKA_TARGET_PER_PART;   // experiments
+    const uint64_t target = SIMKA_TARGET_PER_PART;
     uint32_t pb = ceil_log2_u64((per_shard + target - 1) / target) + ceil_log2_u64(std::max(1u, shard_count));
     return std::min(pb, 20u);
 }
@@ -598,7 +598,7 @@ static int run_count_kernels(simka_ctx *ctx, uint32_t sample, const SimkaScanArg
         fprintf(stderr, "level-1 buckets: %u, records %llu, largest bucket %.1f %% above the mean\n", B1, sum, 100.0 * ((double)mx * B1 / std::max<ull>(1, sum) - 1.0));
     }
     launch_timed(ctx, KID_SKM_SPLIT, [&] {
-        const size_t lds_split = ((size_t)1 << sk.l2) * 4 + 64 + ((size_t)1 << sk.l2) * 2 + 16 + (size_t)SKM_SPLIT_BLOCK * SKM_SPLIT_UNROLL * 16;
+        const size_t lds_split = ((size_t)1 << sk.l2) * 4 + 64 + ((size_t)1 << sk.l2) * 2 + 48 + (size_t)SKM_SPLIT_BLOCK * SKM_SPLIT_UNROLL * 16;      // (the staging area starts 16-byte aligned behind F2 + 8 shorts)
         hipLaunchKernelGGL(k_skm_split, dim3(B1), dim3(SKM_SPLIT_BLOCK), lds_split, st, (const uint4 *)L.d_skm_a, (const uint32_t *)L.d_skm_p, (const ull *)L.d_b1_start, (const ull *)L.d_b1_count, sk,
                            L.d_skm_b, L.d_pstart, L.d_pcnt, (const uint32_t *)flag);
     }, st);

@@ -331,7 +331,7 @@ def test_cli_fastq_gz_inputs(gpu_required, golden_dir, tmp_path):
                                                       (3, 21, True, "small"), (8, 31, False, "c4")])
 def test_sharded_contexts_sum_to_unsharded(gpu_required, oracle_mod, monkeypatch, shards, k, sort_path, shape):
     """Partition shards (power-of-two and not) on one GPU: per-sample totals and every pair accumulator add up to the
-    single-context result, which equals the oracle.  Hash pipeline (a shard keeps level-1 buckets) and sort-based pipeline
+    single-context result, which equals the oracle.  Hash pipeline (a shard keeps the partitions p % shard_count == shard_index) and sort-based pipeline
     (k >= 32, or forced: a shard keeps the canonical k-mers that hash to it)."""
     import simka_amd
     from simka_amd import synth
@@ -1120,3 +1120,29 @@ def test_bench_on_two_gpus_over_rccl(gpu_required):
     assert set(two["decompositions"]) == {"sample", "partition"}
     assert all(d["matrix_checksum"] == one["config"]["matrix_checksum"] for d in two["decompositions"].values())
     assert "RCCL" in two["config"]["collectives"]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("ranks", [2, 3])
+def test_bench_n_ranks_on_one_gpu_over_gloo(gpu_required, ranks):
+    """The N > 1 path of bench.py end to end on a ONE-GPU box (what scripts/mgpu_on_one_gpu.sh does by hand): `bench.py --gpus N`
+    spawns its own N ranks, they share GPU 0, torch.distributed runs on gloo instead of RCCL (SIMKA_BENCH_BACKEND).  Both
+    decompositions (partition shards + one all-reduce; sample shards + spectrum exchange + one all-reduce) must report the job
+    totals and the distance-matrix checksum of the 1-rank run."""
+    import json
+    import subprocess
+    import sys
+
+    def run(n):
+        env = dict(os.environ, SIMKA_BENCH_BACKEND="gloo")
+        r = subprocess.run([sys.executable, os.path.join(ROOT_DIR, "bench.py"), "--gpus", str(n), "--workload", "c2", "--reads", "200000", "--steps", "1",
+                            "--warmup", "1", "--no-cpu-baseline", "--no-e2e", "--no-two-streams"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900, env=env)
+        assert r.returncode == 0, r.stderr[-2000:]
+        return json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    one, many = run(1), run(ranks)
+    assert one["n_gpus"] == 1 and many["n_gpus"] == ranks
+    assert set(many["decompositions"]) == {"sample", "partition"}
+    for d in many["decompositions"].values():
+        assert d["matrix_checksum"] == one["config"]["matrix_checksum"]
+    for key in ("distinct_kmers", "solid_kmers", "kmer_occurrences"):
+        assert many["config"][key] == one["config"][key]
