@@ -329,83 +329,55 @@ struct Packed {
     uint64_t nb_bases = 0, nb_frag = 0, nb_reads = 0;
 };
 
-// SimkaInputIterator (ref: src/core/SimkaCommons.hpp:159-314), member for member, over the sample's files as gatb's bank
-// composition: with -max-reads m a paired part (";") delivers m filter-passing reads (read m+1 is fetched and then
-// overwritten by the first read of the next part, :277-287); the counter runs across the files (",") of a part, the first read
-// a file delivers does not advance it (:224-236); files-per-part is composition / nbPaired (:174), i.e. every part is
-// ASSUMED to list as many files -- with unequal parts the reference reads the wrong files, and so does this drop-in (with
-// a warning); an empty first file ends the sample (:224-236).
-struct InputIterator {
-    struct Bank {
-        std::string path; std::unique_ptr<SeqReader> r; std::string cur; bool done = true; bool failed = false;
-        void first() { r.reset(new SeqReader(path)); if (!r->ok()) { failed = true; done = true; return; } done = !r->next(cur); }
-        void next() { if (!done) done = !r->next(cur); }
-    };
-    std::vector<Bank> comp;
-    const Options &o;
-    Bank *ref = nullptr;
-    bool is_done = false, failed = false;
-    size_t current_bank = 0, nb_banks = 0, current_internal_bank = 0, current_dataset = 0, nb_datasets = 0;
-    uint64_t max_reads = 0, nb_read_processed = 0;
-    const std::string *item = nullptr;
-
-    InputIterator(const Sample &s, const Options &opt, uint64_t m) : o(opt) {
-        for (auto &part : s.parts) for (auto &fn : part) { Bank b; b.path = fn; comp.push_back(std::move(b)); }
-        nb_datasets = std::max<size_t>(1, s.parts.size());
-        nb_banks = comp.size() / nb_datasets;
-        max_reads = m;
-        ref = comp.empty() ? nullptr : &comp[0];
+// Which reads of a sample are counted (-max-reads m, paired parts, read filters).  The reference walks the sample's files with
+// SimkaInputIterator (ref: src/core/SimkaCommons.hpp:159-314); what that iterator DOES, stated as loops (the oracle keeps the
+// literal member-for-member restatement, tests/ compare the two):
+//   * the files of all parts form one flat list; part d owns files [d F, (d + 1) F) with F = #files / #parts (:174) -- every part
+//     is ASSUMED to list as many files; with unequal parts the reference reads the wrong files, and so does this drop-in (the
+//     driver warns); files beyond #parts * F are never read; F = 0 (more parts than files): no reads at all;
+//   * only reads that pass the filters (-min-read-size, -min-shannon-index) exist for what follows;
+//   * inside a part a counter runs across the files; the FIRST read a file delivers does not advance it (:224-236), every other
+//     read does; the read that brings the counter to m is fetched and dropped, and the part ends (:277-287): a part delivers
+//     its files' first reads plus at most m - 1 others;
+//   * a file that delivers no read at all (empty, or every read filtered) ends the SAMPLE: the iterator reports "done" when the
+//     bank it just opened is done (:192-208);
+//   * m = 0: no limit.
+template <class Consume>
+static bool for_counted_reads(const Sample &s, const Options &o, uint64_t max_reads, Consume &&consume) {
+    std::vector<const std::string *> files;
+    for (auto &part : s.parts) for (auto &fn : part) files.push_back(&fn);
+    const size_t nparts = std::max<size_t>(1, s.parts.size());
+    const size_t per_part = files.size() / nparts;
+    if (files.empty() || per_part == 0) return false;
+    std::string seq;
+    for (size_t d = 0; d < nparts; d++) {
+        uint64_t counted = 0;
+        bool part_full = false;
+        for (size_t f = 0; f < per_part && !part_full; f++) {
+            SeqReader r(*files[d * per_part + f]);
+            if (!r.ok()) return false;
+            bool delivered = false;
+            while (r.next(seq)) {
+                if (!read_passes(seq, o)) continue;
+                if (!delivered) { delivered = true; if (!consume(seq)) return false; continue; }      // a file's first read is free
+                if (max_reads && ++counted >= max_reads) { part_full = true; break; }                 // read m + 1: fetched, never seen
+                if (!consume(seq)) return false;
+            }
+            if (!delivered) return true;          // nothing came out of this file: the sample ends here
+        }
     }
-    bool is_finished() { if (current_dataset == nb_datasets) { is_done = true; return true; } return false; }
-    void first() {
-        ref->first();
-        if (ref->failed) failed = true;
-        while (!ref->done && !read_passes(ref->cur, o)) ref->next();
-        is_done = ref->done;
-        if (!is_done) item = &ref->cur;
-    }
-    void next_dataset() {
-        current_dataset += 1;
-        if (is_finished()) return;
-        current_bank = current_dataset * nb_banks;
-        current_internal_bank = 0;
-        nb_read_processed = 0;
-        if (is_finished()) return;
-        ref = &comp[current_bank];
-        is_done = false;
-        first();
-    }
-    void next_bank() {
-        current_internal_bank += 1;
-        if (current_internal_bank == nb_banks) next_dataset();
-        else { is_done = false; current_bank += 1; ref = &comp[current_bank]; first(); }
-    }
-    void next() {
-        if (is_finished()) { is_done = true; return; }
-        ref->next();
-        while (!ref->done && !read_passes(ref->cur, o)) ref->next();
-        is_done = ref->done;
-        if (is_done) {
-            if (is_finished()) return;
-            next_bank();
-            if (is_finished()) return;
-        } else { item = &ref->cur; nb_read_processed += 1; }
-        if (max_reads && nb_read_processed >= max_reads) { if (is_finished()) return; next_dataset(); }
-    }
-};
+    return true;
+}
 
 bool load_sample(const Sample &s, const Options &o, uint64_t max_reads, Packed &out) {
     out = Packed();
-    InputIterator it(s, o, max_reads);
-    if (it.comp.empty() || it.nb_banks == 0) return false;
     if (max_reads == 0) {   // size the buffers once from the files (2-bit bases <= file bytes, x5 for gz): growing would copy pinned memory around
         uint64_t bytes = 0;
         for (auto &part : s.parts) for (auto &fn : part) { struct stat st; if (stat(fn.c_str(), &st) == 0) bytes += (uint64_t)st.st_size * (fn.size() > 3 && fn.substr(fn.size() - 3) == ".gz" ? 5 : 1); }
         out.words.reserve((size_t)(bytes / 32 + 16));
         out.offsets.reserve((size_t)(bytes / 64 + 16));
     }
-    for (it.first(); !it.is_done; it.next()) {
-        const std::string &seq = *it.item;
+    const bool ok = for_counted_reads(s, o, max_reads, [&](const std::string &seq) {
         out.nb_reads++;
         const uint64_t need_words = (out.nb_bases + seq.size()) / 32 + 3;
         if (out.words.size() < need_words) out.words.resize(need_words * 2);
@@ -413,8 +385,9 @@ bool load_sample(const Sample &s, const Options &o, uint64_t max_reads, Packed &
         const int64_t nf = simka_pack_read(seq.data(), seq.size(), out.words.data(), &out.nb_bases, out.offsets.data() + out.nb_frag);
         if (nf < 0) return false;
         out.nb_frag += (uint64_t)nf;
-    }
-    if (it.failed) return false;
+        return true;
+    });
+    if (!ok) return false;
     if (out.offsets.size() < out.nb_frag + 1) out.offsets.resize(out.nb_frag + 1);
     out.offsets[out.nb_frag] = out.nb_bases;
     if (out.words.size() < out.nb_bases / 32 + 3) out.words.resize(out.nb_bases / 32 + 3);
@@ -636,6 +609,7 @@ int main(int argc, char **argv) {
             Packed *pk0;
             if (!loader.get(i, pk0)) die("ERROR: Can't open dataset: " + samples[i].id);
             bases += pk0->nb_bases; reads += pk0->nb_reads;
+            if (o.verbose) std::cout << "sample " << samples[i].id << ": " << pk0->nb_reads << " reads, " << pk0->nb_bases << " bases" << std::endl;
             loader.release(i);
         }
         std::cout << "parsed " << reads << " reads, " << bases << " bases with " << std::min<unsigned>(nthreads, N) << " threads" << std::endl;

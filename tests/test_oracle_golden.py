@@ -186,3 +186,64 @@ def test_shannon_filter_known_answers(oracle_mod, tmp_path):
     assert nreads(1.0) == 3          # index 1.0 >= 1.0 passes
     assert nreads(1.5) == 2
     assert nreads(2.0) == 2
+
+
+def test_driver_read_policy_vs_literal_iterator(oracle_mod, tmp_path):
+    """Row f2 as a real cross-check, on CPU: the `simka` driver states the read policies as derived loops (for_counted_reads in
+    simka_cli.cpp: first read of a file free, counter across the files of a part, read m + 1 dropped, a file that delivers nothing
+    ends the sample, files-per-part = files / parts), the oracle keeps the literal restatement of SimkaInputIterator
+    (ref: src/core/SimkaCommons.hpp:159-314).  `simka -parse-only` (no GPU needed) reports the reads / bases it would count per
+    sample; the oracle counts them at k = 1 (K_occ = ACGT bases).  Edge cases: empty first file, a file whose every read is filtered,
+    -max-reads reached exactly at a file boundary, more paired parts than files, unequal parts, FASTQ."""
+    import subprocess
+    from simka_amd import build as b
+    b.build()
+    a1 = _write_reads(str(tmp_path / "a1.fa"), [60 + i for i in range(20)], seed=1)
+    a2 = _write_reads(str(tmp_path / "a2.fa"), [90 + i for i in range(12)], seed=2)
+    _write_reads(str(tmp_path / "short.fa"), [20, 21, 22, 23], seed=3)          # every read below -min-read-size 50
+    _write_reads(str(tmp_path / "c1.fa"), [70, 25, 71, 26, 72, 73, 27, 74], seed=4)    # passing and filtered reads interleaved
+    open(str(tmp_path / "empty.fa"), "wb").close()
+    with open(str(tmp_path / "q1.fq"), "wb") as f:
+        rq = np.random.default_rng(9)
+        for i, ln in enumerate(a2[:7]):
+            sq = bytes(rq.choice(list(b"ACGT"), size=ln).tolist())
+            f.write(b"@r%d\n%s\n+\n%s\n" % (i, sq, b"I" * ln))
+    (tmp_path / "in.txt").write_text(
+        "E1: empty.fa , a1.fa\n"                # an empty first file ends the sample
+        "E2: a1.fa , short.fa , a2.fa\n"        # with -min-read-size 50 the middle file delivers nothing: the sample ends after a1
+        "E3: a1.fa , a2.fa\n"                   # -max-reads 19 / 20 / 21: the limit falls on the boundary between the files
+        "E4: a1.fa ; a2.fa ; c1.fa\n"           # three parts of one file
+        "E5: a1.fa , a2.fa ; c1.fa\n"           # unequal parts: 3 / 2 = 1 file per part -> a1 | a2
+        "E6: c1.fa , q1.fq ; a2.fa , a1.fa\n"   # two files per part, FASTQ inside
+        "E7: c1.fa\n")
+    exe = b.CLI_PATH
+
+    def driver(m, mrs):
+        r = subprocess.run([exe, "-parse-only", "-in", str(tmp_path / "in.txt"), "-out-tmp", str(tmp_path / "tmp"), "-max-reads", str(m if m else -1),
+                            "-min-read-size", str(mrs), "-verbose", "1"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=120)
+        assert r.returncode == 0, r.stdout[-1500:]
+        out = {}
+        for line in r.stdout.splitlines():
+            if line.startswith("sample "):
+                sid, rest = line[len("sample "):].split(": ")
+                out[sid] = (int(rest.split()[0]), int(rest.split()[2]))
+        return out
+
+    def literal(m, mrs):
+        o = oracle_mod.Oracle()
+        o.load_input(str(tmp_path / "in.txt"))
+        o.set_read_policy(max_reads=m, min_read_size=mrs)
+        o.run(1, 1)
+        t = o.totals()
+        return {sid: (int(t["nb_reads"][i]), int(t["K_occ"][i])) for i, sid in enumerate(o.ids())}
+
+    seen = set()
+    for m in (0, 1, 2, 5, 19, 20, 21, 31, 32, 33, 1000):
+        for mrs in (0, 50):
+            got, ref = driver(m, mrs), literal(m, mrs)
+            assert got == ref, (m, mrs, got, ref)
+            seen.add((m, mrs, tuple(sorted(got.items()))))
+    ref = literal(0, 50)
+    assert ref["E1"] == (0, 0) and ref["E2"][0] == 20 and ref["E7"][0] == 5       # the edge cases are exercised, not vacuous
+    assert literal(20, 0)["E3"][0] == 21 and literal(19, 0)["E3"][0] == 19
+    assert len(seen) > 12
