@@ -62,9 +62,33 @@ static void u64vec_push(u64vec *a, kmer_t x) {
     a->v[a->n++] = x;
 }
 
+/* k <= 32: the keys fit 64 bits (Kmer<span=32> of the reference) -- sort 8-byte words, as a CPU implementation would */
+static void radix_sort_words(uint64_t *a, size_t n, int bits) {
+    uint64_t *tmp = (uint64_t *)malloc(n * sizeof(uint64_t));
+    uint64_t *src = a, *dst = tmp;
+    for (int shift = 0; shift < bits; shift += 8) {
+        size_t hist[257];
+        memset(hist, 0, sizeof(hist));
+        for (size_t i = 0; i < n; i++) hist[(size_t)((src[i] >> shift) & 0xff) + 1]++;
+        for (int d = 0; d < 256; d++) hist[d + 1] += hist[d];
+        for (size_t i = 0; i < n; i++) dst[hist[(size_t)((src[i] >> shift) & 0xff)]++] = src[i];
+        uint64_t *t = src; src = dst; dst = t;
+    }
+    if (src != a) memcpy(a, src, n * sizeof(uint64_t));
+    free(tmp);
+}
+
 /* LSD radix sort of k-mers, `bits` significant bits. */
 static void radix_sort_u64(kmer_t *a, size_t n, int bits) {
     if (n < 2) return;
+    if (bits <= 64) {
+        uint64_t *w = (uint64_t *)malloc(n * sizeof(uint64_t));
+        for (size_t i = 0; i < n; i++) w[i] = (uint64_t)a[i];
+        radix_sort_words(w, n, bits);
+        for (size_t i = 0; i < n; i++) a[i] = (kmer_t)w[i];
+        free(w);
+        return;
+    }
     kmer_t *tmp = (kmer_t *)malloc(n * sizeof(kmer_t));
     kmer_t *src = a, *dst = tmp;
     for (int shift = 0; shift < bits; shift += 8) {
@@ -97,6 +121,19 @@ static inline int or_code(unsigned char c) {
 
 /* Append the canonical k-mers of one read to `out`; returns #k-mers appended. */
 static size_t or_kmers_of_read(const char *seq, size_t len, int k, u64vec *out) {
+    if (k <= 31) {      /* 64-bit rolling words (the reference's Kmer<span=32>) */
+        const uint64_t mask = (1ull << (2 * k)) - 1ull;
+        uint64_t fwd = 0, rev = 0;
+        size_t valid = 0, emitted = 0;
+        for (size_t i = 0; i < len; i++) {
+            int c = or_code((unsigned char)seq[i]);
+            if (c < 0) { valid = 0; fwd = rev = 0; continue; }
+            fwd = ((fwd << 2) | (uint64_t)c) & mask;
+            rev = (rev >> 2) | ((uint64_t)(c ^ 2) << (2 * (k - 1)));
+            if (++valid >= (size_t)k) { u64vec_push(out, (kmer_t)(fwd < rev ? fwd : rev)); emitted++; }
+        }
+        return emitted;
+    }
     const kmer_t mask = (((kmer_t)1) << (2 * k)) - 1;       /* k <= 63 */
     kmer_t fwd = 0, rev = 0;
     size_t valid = 0, emitted = 0;
