@@ -81,13 +81,17 @@ static void radix_sort_words(uint64_t *a, size_t n, int bits) {
 /* LSD radix sort of k-mers, `bits` significant bits. */
 static void radix_sort_u64(kmer_t *a, size_t n, int bits) {
     if (n < 2) return;
-    if (bits <= 64) {
+    if (bits <= 64) {      /* (a range of wide k-mers is sorted on its low bits only: the words must hold the whole k-mer) */
         uint64_t *w = (uint64_t *)malloc(n * sizeof(uint64_t));
-        for (size_t i = 0; i < n; i++) w[i] = (uint64_t)a[i];
-        radix_sort_words(w, n, bits);
-        for (size_t i = 0; i < n; i++) a[i] = (kmer_t)w[i];
+        uint64_t high = 0;
+        for (size_t i = 0; i < n; i++) { w[i] = (uint64_t)a[i]; high |= (uint64_t)(a[i] >> 64); }
+        if (high == 0) {
+            radix_sort_words(w, n, bits);
+            for (size_t i = 0; i < n; i++) a[i] = (kmer_t)w[i];
+            free(w);
+            return;
+        }
         free(w);
-        return;
     }
     kmer_t *tmp = (kmer_t *)malloc(n * sizeof(kmer_t));
     kmer_t *src = a, *dst = tmp;

@@ -1513,7 +1513,7 @@ SIMKA_EXPORT int simka_merge(simka_ctx *ctx) {
                                        b_abs, b_rows, ctx->d_err);
                 });
             launch_timed(ctx, KID_GROUP, [&] {
-                hipLaunchKernelGGL(k_group, dim3(std::min<uint32_t>(np, grid_group)), dim3(K3_BLOCK), lds_group, ctx->stream, in, (const ull *)b_abs,
+                hipLaunchKernelGGL(k_group, dim3(std::max<uint32_t>(32u, std::min<uint32_t>((np * 4u + 31u) / 32u * 32u, grid_group / 32u * 32u))), dim3(K3_BLOCK), lds_group, ctx->stream, in, (const ull *)b_abs,
                                    (const uint16_t *)b_rows, np, key, min_share, co);
             });
             if (getenv("SIMKA_DEBUG_MERGE")) {

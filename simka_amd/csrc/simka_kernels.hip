@@ -238,7 +238,14 @@ k_group(SimkaMergeIn in, const ull *seg_abs, const uint16_t *rows, uint32_t np,
         return (i & 1u) ? a >> 16 : a & 0xffffu;
     };
     uint4 rr0 = make_uint4(0, 0, 0, 0), rr1 = rr0, nr0 = rr0, nr1 = rr0; ull rab = 0, nab = 0;       // this partition's row / the next one's (sample tid)
-    uint32_t cur_pi = blockIdx.x, cur_j = 0;
+    // Which partitions a block takes: Q = min(4, #sub-ranges) neighbouring blocks of ONE XCD (blockIdx % 8: its own L2) share a partition,
+    // a quarter of its sub-ranges each -- the lines of the N segments that neighbouring slices share are then fetched into that L2 once
+    // (with a partition per block, 128 partitions are open per XCD: 23 MB of segments against 4 MB of L2, every line fetched 2-3 times).
+    const uint32_t Q = nsub < 4u ? nsub : 4u, jq = nsub / Q;
+    const uint32_t xcd = blockIdx.x & 7u, bx = blockIdx.x >> 3, gx = (gridDim.x + 7u - xcd) >> 3;       // this block's rank among the blocks of its XCD
+    const uint32_t quarter = bx % Q, nsets = gx / Q, pstep = 8u * nsets;      // (the host launches a multiple of 32 blocks: nsets >= 1, no block left over)
+    uint32_t cur_pi = (bx / Q) * 8u + xcd, cur_j = 0;
+    if (bx / Q >= nsets) cur_pi = np;
     if (cur_pi < np && tid < N) { const size_t g = (size_t)cur_pi * N + tid; nr0 = rows4[2 * g]; nr1 = rows4[2 * g + 1]; nab = seg_abs[g]; }
     // f(key, sample << 32 | count) for every record of the sub-range: a tile of K3_BLOCK samples at a time -- their slices from the
     // rows, an exclusive scan, then one record per thread (the thread finds its sample in the prefix table)
@@ -287,14 +294,14 @@ k_group(SimkaMergeIn in, const ull *seg_abs, const uint16_t *rows, uint32_t np,
             __syncthreads();           // (gpk, which the tile overlays, is written next)
         }
     };
-    for (; cur_pi < np; cur_pi += gridDim.x) {
+    for (; cur_pi < np; cur_pi += pstep) {
         {      // a new partition: its rows arrived while the one before was grouped; the next one's set off
             rr0 = nr0; rr1 = nr1; rab = nab;
-            const uint32_t npi = cur_pi + gridDim.x;
+            const uint32_t npi = cur_pi + pstep;
             nr0 = make_uint4(0, 0, 0, 0); nr1 = nr0; nab = 0;
             if (npi < np && tid < N) { const size_t g = (size_t)npi * N + tid; nr0 = rows4[2 * g]; nr1 = rows4[2 * g + 1]; nab = seg_abs[g]; }
         }
-      for (cur_j = 0; cur_j < nsub; cur_j++) {
+      for (cur_j = quarter * jq; cur_j < (quarter + 1u) * jq; cur_j++) {
         const uint32_t this_j = cur_j;
         // records of the sub-range over all samples
         uint32_t R = 0;

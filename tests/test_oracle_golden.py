@@ -247,3 +247,14 @@ def test_driver_read_policy_vs_literal_iterator(oracle_mod, tmp_path):
     assert ref["E1"] == (0, 0) and ref["E2"][0] == 20 and ref["E7"][0] == 5       # the edge cases are exercised, not vacuous
     assert literal(20, 0)["E3"][0] == 21 and literal(19, 0)["E3"][0] == 19
     assert len(seen) > 12
+
+
+@pytest.mark.parametrize("k", [32, 33, 47])
+def test_oracle_wide_kmers_partition_invariance(oracle_mod, golden_dir, k):
+    """k >= 32 (no golden vectors exist): at least the oracle's own partitioning / threading must not change its answer (its ranges are
+    sorted on the low bits of 128-bit k-mers; the 64-bit sort path of k <= 31 must not be taken for them)."""
+    a = oracle_mod.Oracle(); a.load_input(os.path.join(golden_dir, "example", "simka_input.txt")); a.run(k, 2, simple=True, complex_=True)
+    b = oracle_mod.Oracle(); b.load_input(os.path.join(golden_dir, "example", "simka_input.txt")); b.run(k, 2, simple=True, complex_=True, nparts=64, threads=4)
+    for name in ("S", "a", "bc", "chord", "hell", "whit"):
+        assert np.array_equal(a.acc(name), b.acc(name)), name
+    assert int(a.acc("a").sum()) > 0
