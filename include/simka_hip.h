@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define SIMKA_ABI_VERSION 4
+#define SIMKA_ABI_VERSION 5
 
 enum {
     SIMKA_OK = 0,
@@ -81,6 +81,21 @@ typedef struct simka_reads {
     uint32_t on_device;          /* 1: pointers are device memory, 0: host memory (copied) */
     uint64_t nb_input_reads;     /* reads before splitting (the .ok file's nbReads line) */
 } simka_reads;
+
+/* ---- device-side ingest ---------------------------------------------------------
+ * Replaces gatb's Bank layer + the 2-bit packing for plain-text inputs (ref: formats README.md:165; the reference's
+ * IBank / Sequence iteration is in the absent gatb-core): the bytes of a FASTA / FASTQ file are copied to the GPU as they are
+ * and parsed there (line table, sequence lines, ACGT runs -> packed bases + fragment offsets; simka_ingest.hip).
+ *   simka_ingest_begin(ctx, sample)
+ *   simka_ingest_text(ctx, sample, text, nb_bytes, format, &nb_reads, &irregular)   once per file, in order
+ *   simka_ingest_count(ctx, sample, &nb_bases, &nb_reads)                           = simka_count_sample on what was appended
+ * `text` is host memory (pinned: simka_host_alloc, or pageable); format 0 = FASTA (multi-line sequences allowed), 1 = FASTQ
+ * (4-line records).  Anything the kernels do not parse exactly as the host path does (blank lines inside a file, other FASTQ
+ * layouts, >= 4 GB of text) sets *irregular = 1 and appends NOTHING: parse that sample on the host (simka_pack_read +
+ * simka_count_sample).  Read-level policies (-max-reads, read filters) are host-side: use this path only without them. */
+int simka_ingest_begin(simka_ctx *ctx, uint32_t sample);
+int simka_ingest_text(simka_ctx *ctx, uint32_t sample, const char *text, uint64_t nb_bytes, int format, uint64_t *nb_reads, int *irregular);
+int simka_ingest_count(simka_ctx *ctx, uint32_t sample, uint64_t *nb_bases, uint64_t *nb_reads);
 
 /* The 4 lines of count_synchro/<ID>.ok (ref: src/SimkaCount.cpp:303-317,355-368) + pre-filter counts. */
 typedef struct simka_sample_totals {

@@ -92,6 +92,9 @@ def load_library(build_if_missing=True):
         "simka_reset": (i32, [vp]),
         "simka_count_sample": (i32, [vp, u32, C.POINTER(Reads)]),
         "simka_get_sample_totals": (i32, [vp, u32, C.POINTER(SampleTotals)]),
+        "simka_ingest_begin": (i32, [vp, u32]),
+        "simka_ingest_text": (i32, [vp, u32, vp, u64, i32, C.POINTER(u64), C.POINTER(i32)]),
+        "simka_ingest_count": (i32, [vp, u32, C.POINTER(u64), C.POINTER(u64)]),
         "simka_sample_spectrum_info": (i32, [vp, u32, C.POINTER(SpectrumInfo)]),
         "simka_export_sample": (i32, [vp, u32, vp, vp, vp]),
         "simka_import_sample": (i32, [vp, u32, C.POINTER(SampleTotals), vp, u64, vp, vp, u64]),
@@ -349,6 +352,23 @@ class SimkaContext:
         self.close()
 
     # -- count side -------------------------------------------------------------------------
+    def ingest_text(self, index, texts):
+        """Device-side ingest (simka_ingest_*): `texts` = the raw bytes of the sample's FASTA / FASTQ files, in order.  Returns
+        (nb_bases, nb_reads), or None when a file is irregular (nothing was counted: parse the sample on the host)."""
+        self._check(self.lib.simka_ingest_begin(self.h, index))
+        for t in texts:
+            buf = np.frombuffer(t, dtype=np.uint8)
+            fmt = 1 if len(t) and t.lstrip(b"\r\n")[:1] == b"@" else 0
+            nr, irr = C.c_uint64(), C.c_int()
+            self._check(self.lib.simka_ingest_text(self.h, index, buf.ctypes.data if len(t) else None, len(t), fmt, C.byref(nr), C.byref(irr)))
+            if irr.value:
+                return None
+            if nr.value == 0:
+                break          # a file that delivers no read ends the sample (SimkaInputIterator)
+        nb, nr = C.c_uint64(), C.c_uint64()
+        self._check(self.lib.simka_ingest_count(self.h, index, C.byref(nb), C.byref(nr)))
+        return nb.value, nr.value
+
     def count_sample(self, index, packed, nb_bases, nb_reads, fixed_len=0, offsets=None, on_device=False, nb_input_reads=0):
         """`packed`/`offsets`: numpy uint64 arrays (host) or integer device pointers (on_device=True)."""
         r = Reads()

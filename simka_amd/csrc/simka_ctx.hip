@@ -15,6 +15,8 @@
 #include "../../include/simka_hip.h"
 #include "simka_kernels.hip"
 #include "simka_skm.hip"
+#include "simka_sort.hip"
+#include "simka_ingest.hip"
 #include "simka_wide.h"
 
 #define SIMKA_EXPORT extern "C" __attribute__((visibility("default")))
@@ -59,6 +61,13 @@ struct simka_ctx {
     uint64_t *d_reads[MAX_LANES] = {}; uint64_t reads_cap[MAX_LANES] = {};      // (words)
     uint64_t *d_offsets[MAX_LANES] = {}; uint64_t offsets_cap[MAX_LANES] = {};
     hipStream_t copy_stream = nullptr;
+    // device-side ingest (simka_ingest_*): per lane the file's text, its line table and the per-line counts; what has been appended so far
+    struct Ingest {
+        unsigned char *d_text = nullptr; uint64_t text_cap = 0;
+        uint32_t *d_lines = nullptr, *d_lb = nullptr, *d_lf = nullptr, *d_tmp = nullptr; uint64_t lines_cap = 0, tmp_cap = 0;      // (d_lb, d_lf: inside d_lines' block)
+        ull *d_tot = nullptr;
+        uint32_t sample = ~0u; uint64_t nb_bases = 0, nb_frags = 0, nb_reads = 0; bool open = false;
+    } ing[MAX_LANES];
     uint32_t *d_l1_ovf = nullptr;                             // [N] capacity-mode scatter overflow flag per sample
     uint64_t nb_exact_fallbacks = 0;
     uint32_t nb_counted_this_run = 0;
@@ -441,6 +450,7 @@ SIMKA_EXPORT void simka_destroy(simka_ctx *ctx) {
     for (hipEvent_t e : ctx->event_pool) (void)hipEventDestroy(e);
     if (ctx->copy_stream) { (void)hipStreamSynchronize(ctx->copy_stream); (void)hipStreamDestroy(ctx->copy_stream); }
     for (uint32_t li = 0; li < simka_ctx::MAX_LANES; li++) { if (ctx->d_reads[li]) (void)hipFree(ctx->d_reads[li]); if (ctx->d_offsets[li]) (void)hipFree(ctx->d_offsets[li]); }
+    for (auto &g : ctx->ing) { void *q[] = { g.d_text, g.d_lines, g.d_tmp, g.d_tot }; for (void *p_ : q) if (p_) (void)hipFree(p_); }
     void *ptrs[] = { ctx->d_l1_ovf, ctx->d_solid_keys, ctx->d_solid_counts, ctx->d_arena_cursor,
                      ctx->d_sample_base, ctx->d_foff, ctx->d_fcnt, ctx->d_stats, ctx->d_err, ctx->d_part_total,
                      ctx->d_part_off, ctx->d_work, ctx->d_seg_abs, ctx->d_seg_rows, ctx->d_entries, ctx->d_groups,
@@ -785,6 +795,129 @@ SIMKA_EXPORT int simka_count_sample(simka_ctx *ctx, uint32_t sample, const simka
     }
     ctx->nb_counted_this_run++;
     return SIMKA_OK;
+}
+
+// ---- device-side ingest (kernels: simka_ingest.hip) -------------------------------------------------------
+// grow a device buffer and KEEP its first `keep` elements
+template <typename T>
+static int grow_keep(simka_ctx *ctx, T **p, uint64_t *cap, uint64_t need, uint64_t keep, hipStream_t st) {
+    if (*cap >= need && *p) return SIMKA_OK;
+    T *q = nullptr;
+    const uint64_t n = need + need / 8 + 16;
+    hipError_t e = dev_alloc(&q, n);
+    if (e != hipSuccess) return ctx->fail(SIMKA_ERR_NOMEM, "hipMalloc of %llu bytes failed: %s", (unsigned long long)(n * sizeof(T)), hipGetErrorString(e));
+    if (*p && keep) HIPCHK(hipMemcpyAsync(q, *p, keep * sizeof(T), hipMemcpyDeviceToDevice, st));
+    HIPCHK(hipStreamSynchronize(st));
+    if (*p) HIPCHK(hipFree(*p));
+    *p = q; *cap = n;
+    return SIMKA_OK;
+}
+
+SIMKA_EXPORT int simka_ingest_begin(simka_ctx *ctx, uint32_t sample) {
+    if (!ctx) return SIMKA_ERR_INVALID;
+    if (sample >= ctx->cfg.nb_samples) return ctx->fail(SIMKA_ERR_INVALID, "simka_ingest_begin: sample index %u out of range", sample);
+    if (ctx->counted[sample]) return ctx->fail(SIMKA_ERR_STATE, "simka_ingest_begin: sample %u was already counted", sample);
+    if (ctx->wide) return ctx->fail(SIMKA_ERR_UNSUPPORTED, "simka_ingest_*: kmer_size >= 32 takes host-packed reads");
+    HIPCHK(hipSetDevice(ctx->cfg.device));
+    // (the lane count is fixed with the geometry, at the first count: until then, what setup_geometry will decide)
+    const uint32_t want_lanes = getenv("SIMKA_LANES") ? (uint32_t)std::max(1, atoi(getenv("SIMKA_LANES"))) : 2u;
+    const uint32_t li = sample % (ctx->nlanes ? ctx->nlanes : std::min<uint32_t>(std::min<uint32_t>(want_lanes, simka_ctx::MAX_LANES), std::max<uint32_t>(1u, ctx->cfg.nb_samples)));
+    if (ctx->nlanes) { int rc = resolve_pending(ctx, (int)li); if (rc) return rc; }      // the lane's staging buffers still feed the sample counted two calls ago
+    if (!ctx->copy_stream) HIPCHK(hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking));
+    simka_ctx::Ingest &g = ctx->ing[li];
+    g.sample = sample; g.nb_bases = 0; g.nb_frags = 0; g.nb_reads = 0; g.open = true;
+    if (!g.d_tot) HIPCHK(dev_alloc(&g.d_tot, 4));
+    return SIMKA_OK;
+}
+
+SIMKA_EXPORT int simka_ingest_text(simka_ctx *ctx, uint32_t sample, const char *text, uint64_t nb_bytes, int format, uint64_t *nb_reads, int *irregular) {
+    if (!ctx || (!text && nb_bytes) || !irregular) return SIMKA_ERR_INVALID;
+    simka_ctx::Ingest *gp = nullptr; uint32_t li = 0;
+    for (uint32_t l = 0; l < simka_ctx::MAX_LANES; l++) if (ctx->ing[l].open && ctx->ing[l].sample == sample) { gp = &ctx->ing[l]; li = l; }
+    if (!gp) return ctx->fail(SIMKA_ERR_STATE, "simka_ingest_text: simka_ingest_begin was not called for sample %u", sample);
+    simka_ctx::Ingest &g = *gp;
+    *irregular = 0;
+    if (nb_reads) *nb_reads = 0;
+    if (nb_bytes == 0) return SIMKA_OK;
+    if (format != ING_FASTA && format != ING_FASTQ) return ctx->fail(SIMKA_ERR_INVALID, "simka_ingest_text: format must be 0 (FASTA) or 1 (FASTQ)");
+    if (nb_bytes >= 0xfffffff0ull) { *irregular = 1; return SIMKA_OK; }        // 32-bit line offsets
+    HIPCHK(hipSetDevice(ctx->cfg.device));
+    const hipStream_t st = ctx->copy_stream;
+    int rc = ensure_cap(ctx, &g.d_text, &g.text_cap, nb_bytes + 64); if (rc) return rc;
+    HIPCHK(hipMemcpyAsync(g.d_text, text, nb_bytes, hipMemcpyHostToDevice, st));
+    // ---- the line table
+    const uint64_t ntiles = (nb_bytes + ING_TILE - 1) / ING_TILE;
+    rc = ensure_cap(ctx, &g.d_tmp, &g.tmp_cap, ntiles + 16 + wscan_tmp_u32(ntiles) + 16); if (rc) return rc;
+    uint32_t *d_cnt = g.d_tmp;
+    HIPCHK(hipMemsetAsync(g.d_tot, 0, 32, st));
+    hipLaunchKernelGGL(k_ing_nl_count, dim3((uint32_t)ntiles), dim3(ING_BLOCK), 0, st, (const unsigned char *)g.d_text, nb_bytes, d_cnt);
+    uint32_t last_cnt = 0, last_off = 0;
+    HIPCHK(hipMemcpyAsync(&last_cnt, d_cnt + ntiles - 1, 4, hipMemcpyDeviceToHost, st));
+    HIPCHK(wscan_u32(d_cnt, d_cnt, ntiles, g.d_tmp + ntiles + 16, st));
+    HIPCHK(hipMemcpyAsync(&last_off, d_cnt + ntiles - 1, 4, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    const uint64_t nlines = (uint64_t)last_off + last_cnt + 1;
+    // one block for the per-line arrays: line starts [nlines + 1], bases, fragments, prefix of the bases, scan scratch
+    const uint64_t la = (nlines + 2 + 15) & ~(uint64_t)15, block_need = 4 * la + wscan_tmp_u32(nlines) + 32;
+    rc = ensure_cap(ctx, &g.d_lines, &g.lines_cap, block_need); if (rc) return rc;
+    g.d_lb = g.d_lines + la; g.d_lf = g.d_lb + la;
+    uint32_t *d_lbo = g.d_lf + la, *d_scan = d_lbo + la;
+    hipLaunchKernelGGL(k_ing_nl_fill, dim3((uint32_t)ntiles), dim3(ING_BLOCK), 0, st, (const unsigned char *)g.d_text, nb_bytes, (const uint32_t *)d_cnt, g.d_lines);
+    const uint32_t sentinel = (uint32_t)nb_bytes + 1u;
+    HIPCHK(hipMemcpyAsync(g.d_lines + nlines, &sentinel, 4, hipMemcpyHostToDevice, st));
+    // ---- per line: bases, fragments that start in it, reads; prefix sums (the counts of the last line are read before the in-place scan)
+    const uint32_t lgrid = (uint32_t)((nlines + ING_BLOCK - 1) / ING_BLOCK);
+    hipLaunchKernelGGL(k_ing_lines, dim3(lgrid), dim3(ING_BLOCK), 0, st, (const unsigned char *)g.d_text, (const uint32_t *)g.d_lines, (uint32_t)nlines, format, g.d_lb, g.d_lf, g.d_tot);
+    uint32_t lastb = 0, lastf = 0, sumb = 0, sumf = 0;
+    HIPCHK(hipMemcpyAsync(&lastf, g.d_lf + nlines - 1, 4, hipMemcpyDeviceToHost, st));
+    HIPCHK(wscan_u32(g.d_lf, g.d_lf, nlines, d_scan, st));
+    HIPCHK(hipMemcpyAsync(&sumf, g.d_lf + nlines - 1, 4, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync(&lastb, g.d_lb + nlines - 1, 4, hipMemcpyDeviceToHost, st));
+    HIPCHK(wscan_u32(g.d_lb, d_lbo, nlines, d_scan, st));            // (the bases per line stay: k_ing_pack skips the lines without any)
+    HIPCHK(hipMemcpyAsync(&sumb, d_lbo + nlines - 1, 4, hipMemcpyDeviceToHost, st));
+    ull tot[2] = { 0, 0 };
+    HIPCHK(hipMemcpyAsync(tot, g.d_tot, 16, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    if (tot[1]) { *irregular = 1; return SIMKA_OK; }
+    const uint64_t fbases = (uint64_t)sumb + lastb, ffrags = (uint64_t)sumf + lastf;
+    if (nb_reads) *nb_reads = tot[0];
+    // ---- append to the lane's staging buffers
+    const uint64_t words_now = (g.nb_bases + 31) / 32, words_need = (g.nb_bases + fbases + 31) / 32 + 2;
+    rc = grow_keep(ctx, &ctx->d_reads[li], &ctx->reads_cap[li], words_need, words_now, st); if (rc) return rc;
+    rc = grow_keep(ctx, &ctx->d_offsets[li], &ctx->offsets_cap[li], g.nb_frags + ffrags + 2, g.nb_frags, st); if (rc) return rc;
+    if (g.nb_bases == 0) HIPCHK(hipMemsetAsync(ctx->d_reads[li], 0, words_need * 8, st));
+    else HIPCHK(hipMemsetAsync(ctx->d_reads[li] + words_now, 0, (words_need - words_now) * 8, st));      // (the last word so far keeps its bases: its upper bits are zero)
+    if (fbases)
+        hipLaunchKernelGGL(k_ing_pack, dim3(lgrid), dim3(ING_BLOCK), 0, st, (const unsigned char *)g.d_text, (const uint32_t *)g.d_lines, (uint32_t)nlines, format, (const uint32_t *)g.d_lb,
+                           (const uint32_t *)d_lbo, (const uint32_t *)g.d_lf, (ull)g.nb_bases, (ull)g.nb_frags, (ull *)ctx->d_reads[li], (ull *)ctx->d_offsets[li]);
+    HIPCHK(hipGetLastError());
+    g.nb_bases += fbases; g.nb_frags += ffrags; g.nb_reads += tot[0];
+    HIPCHK(hipStreamSynchronize(st));          // the caller's text buffer is free again
+    return SIMKA_OK;
+}
+
+SIMKA_EXPORT int simka_ingest_count(simka_ctx *ctx, uint32_t sample, uint64_t *nb_bases, uint64_t *nb_reads) {
+    if (!ctx) return SIMKA_ERR_INVALID;
+    simka_ctx::Ingest *gp = nullptr; uint32_t li = 0;
+    for (uint32_t l = 0; l < simka_ctx::MAX_LANES; l++) if (ctx->ing[l].open && ctx->ing[l].sample == sample) { gp = &ctx->ing[l]; li = l; }
+    if (!gp) return ctx->fail(SIMKA_ERR_STATE, "simka_ingest_count: simka_ingest_begin was not called for sample %u", sample);
+    simka_ctx::Ingest &g = *gp;
+    g.open = false;
+    if (nb_bases) *nb_bases = g.nb_bases;
+    if (nb_reads) *nb_reads = g.nb_reads;
+    simka_reads r;
+    memset(&r, 0, sizeof r);
+    r.nb_bases = g.nb_bases; r.nb_reads = g.nb_frags; r.nb_input_reads = g.nb_reads; r.on_device = 1; r.fixed_len = 0;
+    if (g.nb_bases) {
+        const ull end = g.nb_bases;
+        HIPCHK(hipMemcpyAsync(ctx->d_offsets[li] + g.nb_frags, &end, 8, hipMemcpyHostToDevice, ctx->copy_stream));
+        HIPCHK(hipStreamSynchronize(ctx->copy_stream));
+        r.packed = ctx->d_reads[li]; r.offsets = ctx->d_offsets[li];
+    }
+    // (the geometry may have to be set up first: it fixes the number of lanes; a context whose lane count differs from the guess of
+    // simka_ingest_begin -- only the first sample can see that -- still finds its buffers: the lane index is kept with the state)
+    const int rc = simka_count_sample(ctx, sample, &r);
+    return rc;
 }
 
 SIMKA_EXPORT int simka_get_sample_totals(simka_ctx *ctx, uint32_t sample, simka_sample_totals *out) {

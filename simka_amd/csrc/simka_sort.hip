@@ -32,7 +32,7 @@ __device__ __forceinline__ uint32_t ws_wave_incl(uint32_t v) {
 }
 
 // sums[b] = sum of tile b
-__global__ void __launch_bounds__(WS_BLOCK)
+static __global__ void __launch_bounds__(WS_BLOCK)
 k_ws_reduce(const uint32_t *in, uint64_t n, uint32_t *sums) {
     __shared__ uint32_t s_w[WS_BLOCK / 64];
     const uint64_t base = (uint64_t)blockIdx.x * WS_TILE;
@@ -46,7 +46,7 @@ k_ws_reduce(const uint32_t *in, uint64_t n, uint32_t *sums) {
 }
 
 // out[i] = offs[tile] + exclusive prefix inside the tile (offs == NULL: 0); thread t owns WS_ITEMS CONSECUTIVE items
-__global__ void __launch_bounds__(WS_BLOCK)
+static __global__ void __launch_bounds__(WS_BLOCK)
 k_ws_scan(const uint32_t *in, uint32_t *out, uint64_t n, const uint32_t *offs) {
     __shared__ uint32_t s_w[WS_BLOCK / 64];
     const uint64_t base = (uint64_t)blockIdx.x * WS_TILE + (uint64_t)threadIdx.x * WS_ITEMS;
@@ -84,7 +84,7 @@ static hipError_t wscan_u32(const uint32_t *in, uint32_t *out, uint64_t n, uint3
 
 // ---- radix sort ------------------------------------------------------------------------------------------------------------
 // hist[d * ntiles + tile] = items of the tile whose digit is d
-__global__ void __launch_bounds__(RS_BLOCK)
+static __global__ void __launch_bounds__(RS_BLOCK)
 k_rs_hist(const ull *keys, uint64_t n, uint32_t shift, uint32_t ntiles, uint32_t *hist) {
     __shared__ uint32_t s_h[RS_DIGITS];
     s_h[threadIdx.x] = 0;
@@ -110,7 +110,7 @@ __device__ __forceinline__ ull rs_match(uint32_t d, bool valid) {
 // bases[d * ntiles + tile] = global position of the first item of (digit d, tile).  Stable: wave w of the block owns the items
 // [w * 1024, (w + 1) * 1024) of the tile and walks them in order.
 template <typename V>
-__global__ void __launch_bounds__(RS_BLOCK)
+static __global__ void __launch_bounds__(RS_BLOCK)
 k_rs_scatter(const ull *kin, const V *vin, ull *kout, V *vout, uint64_t n, uint32_t shift, uint32_t ntiles, const uint32_t *bases) {
     __shared__ uint32_t s_cnt[RS_BLOCK / 64][RS_DIGITS];       // per wave: items of each digit, then the wave's running output cursor
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;

@@ -1146,3 +1146,124 @@ def test_bench_n_ranks_on_one_gpu_over_gloo(gpu_required, ranks):
         assert d["matrix_checksum"] == one["config"]["matrix_checksum"]
     for key in ("distinct_kmers", "solid_kmers", "kmer_occurrences"):
         assert many["config"][key] == one["config"][key]
+
+
+def _stats_via_host_and_device(files_per_sample, k, amin=1):
+    """the same samples once through the host parser (read_sequences + simka_pack_read) and once through simka_ingest_*"""
+    import simka_amd
+    from simka_amd import api
+    n = len(files_per_sample)
+    out = []
+    for mode in ("host", "device"):
+        with simka_amd.SimkaContext(n, kmer_size=k, abundance_min=amin, simple_dist=True) as ctx:
+            for s, texts in enumerate(files_per_sample):
+                if mode == "device":
+                    r = ctx.ingest_text(s, texts)
+                    assert r is not None, "sample %d was flagged irregular" % s
+                else:
+                    seqs = []
+                    for t in texts:
+                        import tempfile
+                        with tempfile.NamedTemporaryFile(suffix=".txt") as f:
+                            f.write(t); f.flush()
+                            got = list(api.read_sequences(f.name))
+                        if not got:
+                            break
+                        seqs += got
+                    packed, offsets, nb, nin = api.pack_reads(seqs)
+                    ctx.count_sample(s, packed, nb, len(offsets) - 1, offsets=offsets, nb_input_reads=nin)
+            totals = [ctx.sample_totals(s) for s in range(n)]
+            ctx.merge()
+            out.append((totals, ctx.stats().flat.copy()))
+    return out
+
+
+@pytest.mark.gpu
+def test_device_ingest_equals_host_parse(gpu_required):
+    """simka_ingest_* (FASTA / FASTQ text parsed on the GPU, simka_ingest.hip) against the host parser, bit for bit: multi-line FASTA
+    sequences (a fragment continues over the line break), N and other letters (end a fragment), lower case, CR LF, a header without
+    a sequence, no newline at the end of the file, several files per sample (the second one appended at an odd base offset), FASTQ."""
+    rng = np.random.default_rng(5)
+
+    def seq(n, with_n=False):
+        s = bytearray(rng.choice(list(b"ACGT"), size=n).tolist())
+        if with_n:
+            for p in rng.integers(0, n, size=max(1, n // 40)):
+                s[int(p)] = rng.choice(list(b"NnRYx-"))
+        return bytes(s)
+
+    genome = seq(4000)
+
+    def read(ln, with_n=False):
+        st = int(rng.integers(0, len(genome) - ln))
+        s = bytearray(genome[st:st + ln])
+        if with_n:
+            for p in rng.integers(0, ln, size=2):
+                s[int(p)] = ord("N")
+        return bytes(s)
+
+    def fasta(reads, width=0, eol=b"\n", final_eol=True):
+        out = bytearray()
+        for i, r in enumerate(reads):
+            out += b">read%d some text ACGT" % i + eol
+            if width:
+                for p in range(0, len(r), width):
+                    out += r[p:p + width] + eol
+            elif r:
+                out += r + eol
+        if not final_eol and out.endswith(eol):
+            out = out[:-len(eol)]
+        return bytes(out)
+
+    def fastq(reads, eol=b"\n"):
+        return b"".join(b"@r%d\n" % i + r + eol + b"+" + eol + b"@" * len(r) + eol for i, r in enumerate(reads))       # ('@' in the qualities)
+
+    a = [read(int(rng.integers(60, 160)), with_n=(i % 5 == 0)) for i in range(400)]
+    b = [read(int(rng.integers(30, 200)), with_n=(i % 7 == 0)) for i in range(300)]
+    files = [
+        [fasta(a)],                                                     # two-line FASTA
+        [fasta(a, width=37), fasta(b, width=61)],                       # multi-line, two files: the second starts at an odd base offset
+        [fasta([x.lower() for x in b], eol=b"\r\n")],                   # lower case, CR LF
+        [fasta(a[:50] + [b""] + a[50:120], final_eol=False)],           # a header without sequence; no newline at the end
+        [fastq(b), fastq(a[:77], eol=b"\r\n")],                         # FASTQ, two files
+        [fasta(a, width=1000) + b"\n\n"],                               # blank lines at the end only
+    ]
+    (th, fh), (td, fd) = _stats_via_host_and_device(files, 21)
+    assert th == td
+    assert np.array_equal(fh, fd)
+    assert all(t["K_occ"] > 0 and t["nb_reads"] > 0 for t in th)
+
+
+@pytest.mark.gpu
+def test_device_ingest_flags_what_it_does_not_parse(gpu_required):
+    import simka_amd
+    with simka_amd.SimkaContext(4, kmer_size=15, abundance_min=1) as ctx:
+        assert ctx.ingest_text(0, [b">a\nACGTACGTACGTACGTACGT\n\n>b\nACGTTTGACCAGTAGCAT\n"]) is None          # a blank line inside the file
+        assert ctx.ingest_text(0, [b"@r\nACGTACGTACGTACGTACGT\nACGT\n+\nIIIIIIIIIIIIIIIIIIIIIIII\n"]) is None     # multi-line FASTQ
+        assert ctx.ingest_text(0, [b"ACGTACGTAGCTAGCATGCAT\n>x\nACGT\n"]) is None                               # sequence before any header
+        assert ctx.ingest_text(0, [b">ok\nACGTACGTACGTACGTACGTAAA\n"]) == (23, 1)                              # ... and the sample can still be counted
+
+
+@pytest.mark.gpu
+def test_device_ingest_reproduces_the_goldens(gpu_required, golden_dir, tmp_path):
+    """C1 through the device-side parser: the example's FASTA files as raw text -> simka_ingest_* -> the reference's golden CSVs."""
+    import simka_amd
+    from simka_amd import api
+    samples = api.parse_input_file(os.path.join(golden_dir, "example", "simka_input.txt"))
+    k, amin = 21, 2
+    with simka_amd.SimkaContext(len(samples), kmer_size=k, abundance_min=amin, simple_dist=True, complex_dist=True) as ctx:
+        for s, smp in enumerate(samples):
+            assert ctx.ingest_text(s, [open(f, "rb").read() for f in smp["files"]]) is not None
+        ctx.merge()
+        st = ctx.stats()
+    out = str(tmp_path / "res")
+    st.write_matrices(out, [s["id"] for s in samples], gz=True)
+    truth = os.path.join(golden_dir, "truth", "results_k%d_t%d" % (k, amin))
+    compared = 0
+    for gzf in glob.glob(os.path.join(out, "*.csv.gz")):
+        ref = os.path.join(truth, os.path.basename(gzf)[:-3])
+        if os.path.exists(ref):
+            with gzip.open(gzf, "rb") as f, open(ref, "rb") as g:
+                assert f.read() == g.read(), ref
+            compared += 1
+    assert compared == 20
