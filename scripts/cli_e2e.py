@@ -28,7 +28,7 @@ size = sum(os.path.getsize(os.path.join(d, "s%d.fasta" % s)) for s in range(n))
 print("generated %d FASTA files, %.2f GB in %.1f s" % (n, size / 1e9, time.time() - t0))
 base = [b.CLI_PATH, "-in", os.path.join(d, "in.txt"), "-out", os.path.join(d, "out"), "-out-tmp", os.path.join(d, "tmp"), "-kmer-size", "21",
         "-abundance-min", "2", "-max-reads", "-1", "-verbose", "0"]
-for extra, name in ((["-parse-only"], "ingest only"), ([], "end to end"), ([], "end to end (warm)")):
+for extra, name in ((["-parse-only"], "host ingest only"), (["-host-parse"], "end to end, host parse"), ([], "end to end, device parse"), ([], "end to end, device parse (warm)")):
     t = time.time()
     r = subprocess.run(base + extra, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
     dt = time.time() - t

@@ -21,6 +21,7 @@
 #include <condition_variable>
 #include <fstream>
 #include <mutex>
+#include <chrono>
 #include <thread>
 #include <iostream>
 #include <sstream>
@@ -46,6 +47,7 @@ struct Options {
     int verbose = 1;
     int nb_gpus = 1, first_gpu = 0;     // new: GPUs to spread the samples (count) and the partition ranges (merge) over
     bool same_gpu = false;              // new (tests): all -nb-gpus contexts on GPU -gpu
+    bool host_parse = false;            // new: parse + pack every input on the host (default: plain-text inputs without read policies are parsed on the GPU)
     bool gpu_allreduce = false;         // new: -nb-gpus combines the merges' accumulators with one RCCL all-reduce instead of summing them on the host
     long long solid_capacity = 0;       // new (tests): records of the solid-spectrum arena of every context (0: from the free memory)
     int merge_ranges = 0;               // new: >0 keeps the spectra in host memory and merges in that many partition ranges per GPU
@@ -132,6 +134,7 @@ Options parse_args(int argc, char **argv) {
         else if (a == "-gpu") o.first_gpu = atoi(need(i).c_str());
         else if (a == "-gpu-shared") o.same_gpu = true;
         else if (a == "-gpu-allreduce") o.gpu_allreduce = true;
+        else if (a == "-host-parse") o.host_parse = true;
         else if (a == "-merge-ranges") o.merge_ranges = atoi(need(i).c_str());
         else if (a == "-solid-capacity") o.solid_capacity = atoll(need(i).c_str());
         else if (a == "-parse-only") o.parse_only = true;
@@ -327,6 +330,10 @@ typedef PinnedBuf<uint64_t> PinnedWords;
 struct Packed {
     PinnedWords words, offsets;
     uint64_t nb_bases = 0, nb_frag = 0, nb_reads = 0;
+    // device-side ingest (simka_ingest_*): the files' bytes as they are, parsed on the GPU
+    bool raw = false;
+    std::vector<PinnedBuf<char>> texts;
+    std::vector<int> formats;             // 0 FASTA, 1 FASTQ
 };
 
 // Which reads of a sample are counted (-max-reads m, paired parts, read filters).  The reference walks the sample's files with
@@ -369,6 +376,43 @@ static bool for_counted_reads(const Sample &s, const Options &o, uint64_t max_re
     return true;
 }
 
+// The files of a sample as raw text for the device-side parser -- only where it parses exactly what the host path would deliver: every
+// read of every listed file (no -max-reads limit, no read filter), plain text (not gzip), below 4 GB per file.  false: use load_sample.
+bool load_sample_raw(const Sample &s, const Options &o, uint64_t max_reads, Packed &out) {
+    if (max_reads || o.min_read_size || o.min_shannon != 0 || o.kmer_size > 31) return false;
+    std::vector<const std::string *> files;
+    for (auto &part : s.parts) for (auto &fn : part) files.push_back(&fn);
+    const size_t nparts = std::max<size_t>(1, s.parts.size());
+    const size_t per_part = files.size() / nparts;
+    if (files.empty() || per_part == 0) return false;
+    out = Packed();
+    out.raw = true;
+    for (size_t f = 0; f < nparts * per_part; f++) {       // (files beyond #parts * files-per-part are never read: for_counted_reads)
+        FILE *fp = fopen(files[f]->c_str(), "rb");
+        if (!fp) return false;
+        struct stat st;
+        if (fstat(fileno(fp), &st) != 0 || !S_ISREG(st.st_mode) || (uint64_t)st.st_size >= 0xfffffff0ull) { fclose(fp); return false; }
+        PinnedBuf<char> buf;
+        buf.resize((size_t)st.st_size + 1);
+        size_t got = 0;
+        while (got < (size_t)st.st_size) { const size_t r = fread(buf.data() + got, 1, (size_t)st.st_size - got, fp); if (r == 0) break; got += r; }
+        fclose(fp);
+        if (got != (size_t)st.st_size) return false;
+        buf.resize(got);
+        if (got >= 2 && (unsigned char)buf[0] == 0x1f && (unsigned char)buf[1] == 0x8b) return false;       // gzip: the host inflates
+        size_t p = 0;
+        while (p < got && (buf[p] == '\n' || buf[p] == '\r')) p++;
+        int fmt = -1;
+        if (p == got) fmt = 0;                     // an empty file: delivers no read (which ends the sample)
+        else if (p == 0 && buf[0] == '>') fmt = 0;
+        else if (p == 0 && buf[0] == '@') fmt = 1;
+        if (fmt < 0) return false;
+        out.texts.push_back(std::move(buf));
+        out.formats.push_back(fmt);
+    }
+    return true;
+}
+
 bool load_sample(const Sample &s, const Options &o, uint64_t max_reads, Packed &out) {
     out = Packed();
     if (max_reads == 0) {   // size the buffers once from the files (2-bit bases <= file bytes, x5 for gz): growing would copy pinned memory around
@@ -400,10 +444,14 @@ bool load_sample(const Sample &s, const Options &o, uint64_t max_reads, Packed &
 class SampleLoader {
 public:
     // skip[i] != 0: sample i is not read at all (-keep-tmp found its spectrum); get() returns immediately with an empty slot
+    // raw: hand over the files' text where the device-side parser can take it (load_sample_raw), else parse + pack here
     SampleLoader(const std::vector<Sample> &samples, const Options &o, uint64_t max_reads, unsigned threads, unsigned window,
-                 const std::vector<char> &skip = std::vector<char>())
-        : samples_(samples), o_(o), max_reads_(max_reads), window_(std::max(1u, window)), slots_(samples.size()), state_(samples.size(), 0), skip_(skip) {
-        threads = std::max(1u, std::min<unsigned>(threads, (unsigned)samples.size()));
+                 const std::vector<char> &skip = std::vector<char>(), bool raw = false)
+        : samples_(samples), o_(o), max_reads_(max_reads), window_(std::max(1u, window)), slots_(samples.size()), state_(samples.size(), 0), skip_(skip), raw_(raw) {
+        // raw text: a file is only READ here (page cache -> pinned memory, ~3 GB/s per thread) -- eight samples in flight keep the GPU
+        // fed, and their pinned buffers are recycled (pinning a buffer costs as much as filling it: 66 fresh 150-MB buffers cost seconds)
+        if (raw_) window_ = std::min<size_t>(window_, 8);
+        threads = std::max(1u, std::min<unsigned>(threads, (unsigned)std::min<size_t>(samples.size(), window_)));
         for (unsigned t = 0; t < threads; t++) workers_.emplace_back([this] { run(); });
     }
     ~SampleLoader() {
@@ -434,7 +482,7 @@ private:
                 i = next_++;
             }
             Packed pk;
-            const bool ok = (i < skip_.size() && skip_[i]) ? true : load_sample(samples_[i], o_, max_reads_, pk);
+            const bool ok = (i < skip_.size() && skip_[i]) ? true : ((raw_ && load_sample_raw(samples_[i], o_, max_reads_, pk)) || load_sample(samples_[i], o_, max_reads_, pk));
             { std::lock_guard<std::mutex> g(m_); slots_[i] = std::move(pk); state_[i] = ok ? 1 : -1; }
             cv_.notify_all();
         }
@@ -446,6 +494,7 @@ private:
     std::vector<Packed> slots_;
     std::vector<int> state_;
     std::vector<char> skip_;
+    bool raw_ = false;
     std::vector<std::thread> workers_;
     std::mutex m_;
     std::condition_variable cv_;
@@ -547,6 +596,8 @@ void check(simka_ctx *ctx, int rc, const char *what) {
 }  // namespace
 
 int main(int argc, char **argv) {
+    const auto t_main = std::chrono::steady_clock::now();
+    auto since_main = [&] { return std::chrono::duration<double>(std::chrono::steady_clock::now() - t_main).count(); };
     Options o = parse_args(argc, argv);
     // ref: src/SimkaPotara.hpp:376-387
     if (o.max_memory < 2000) std::cout << "WARNING: running Simka with low memory is risky. Simka may hang because of that. Consider running with -max-memory X where X > 2000" << std::endl;
@@ -698,12 +749,18 @@ int main(int argc, char **argv) {
     // Returns SIMKA_ERR_NOMEM when the spectra do not fit the arena: the caller then takes the host-spectra path below.
     auto direct_run = [&]() -> int {
         simka_ctx *c = make_ctx(N, device_of(0));
-        SampleLoader loader(samples, o, max_reads, nthreads, nthreads + 2, reuse);
+        SampleLoader loader(samples, o, max_reads, nthreads, nthreads + 2, reuse, !o.host_parse);
         int rc = SIMKA_OK;
         auto soft = [&](int r, const char *what) { if (r == SIMKA_OK) return true; if (r != SIMKA_ERR_NOMEM) fatal(c, what); rc = r; return false; };
+        double t_wait = 0, t_count = 0;        // -verbose 2: where the main thread spends its time
+        auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+        const double t_begin = now();
         for (uint32_t i = 0; i < N && rc == SIMKA_OK; i++) {
             Packed *pkp;
+            const double t0 = now();
             if (!loader.get(i, pkp)) die("ERROR: Can't open dataset: " + samples[i].id);
+            const double t1 = now();
+            t_wait += t1 - t0;
             if (reuse[i]) {     // ref: src/SimkaPotara.hpp:837-842 (count_synchro/<ID>.ok exists -> the sample is not recounted)
                 Spectrum sp;
                 const std::string path = spec_path(tmp, samples[i], 0, 1);
@@ -713,19 +770,46 @@ int main(int argc, char **argv) {
                 loader.release(i);
                 continue;
             }
-            simka_reads r;
-            fill_reads(*pkp, r);
-            const bool ok = soft(simka_count_sample(c, i, &r), "simka_count_sample");
-            loader.release(i);     // host buffers may be reused as soon as simka_count_sample returns
+            bool ok = true, counted = false;
+            if (pkp->raw) {       // the files' text goes to the GPU as it is and is parsed there (simka_ingest.hip)
+                ok = soft(simka_ingest_begin(c, i), "simka_ingest_begin");
+                bool irregular = false;
+                for (size_t f = 0; ok && !irregular && f < pkp->texts.size(); f++) {
+                    uint64_t nr = 0; int irr = 0;
+                    ok = soft(simka_ingest_text(c, i, pkp->texts[f].data(), pkp->texts[f].size(), pkp->formats[f], &nr, &irr), "simka_ingest_text");
+                    irregular = irr != 0;
+                    if (ok && !irregular && nr == 0) break;       // a file that delivers no read ends the sample
+                }
+                if (ok && !irregular) { ok = soft(simka_ingest_count(c, i, nullptr, nullptr), "simka_ingest_count"); counted = true; }
+                else if (ok) {        // something the device parser does not take (blank lines inside a file, multi-line FASTQ, ...): the host parser decides
+                    Packed hp;
+                    if (!load_sample(samples[i], o, max_reads, hp)) die("ERROR: Can't open dataset: " + samples[i].id);
+                    simka_reads r;
+                    fill_reads(hp, r);
+                    ok = soft(simka_count_sample(c, i, &r), "simka_count_sample");
+                    counted = true;
+                }
+            }
+            if (!counted && ok) {
+                simka_reads r;
+                fill_reads(*pkp, r);
+                ok = soft(simka_count_sample(c, i, &r), "simka_count_sample");
+            }
+            loader.release(i);     // host buffers may be reused as soon as the count call returns
+            t_count += now() - t1;
             if (ok && o.keep_tmp) {      // persist the spectrum so that a later run with more samples skips this one
                 Spectrum sp;
                 if (soft(export_from(c, i, i, sp), "simka_export_sample") && !write_spec(spec_path(tmp, samples[i], 0, 1), sp))
                     die("ERROR: cannot write " + spec_path(tmp, samples[i], 0, 1));
             }
         }
+        const double t2 = now();
         for (uint32_t i = 0; i < N && rc == SIMKA_OK; i++) soft(simka_get_sample_totals(c, i, &totals[i]), "simka_get_sample_totals");
+        const double t3 = now();
         if (rc == SIMKA_OK) soft(simka_merge(c), "simka_merge");
         if (rc == SIMKA_OK) soft(simka_stats_download(c, flat.data(), nw, nullptr), "simka_stats_download");
+        if (o.verbose >= 2) std::cout << "main thread: waiting for the loader " << t_wait << " s, ingest / count calls " << t_count << " s, draining the count kernels " << t3 - t2
+                                      << " s, merge + download " << now() - t3 << " s (since the context: " << now() - t_begin << " s)" << std::endl;
         simka_destroy(c);
         return rc;
     };
@@ -841,7 +925,9 @@ int main(int argc, char **argv) {
 
     bool host_mode = G > 1 || o.merge_ranges > 0;
     if (!host_mode) {
+        if (o.verbose >= 2) std::cout << "process: " << since_main() << " s before the first context" << std::endl;
         const int rc = direct_run();
+        if (o.verbose >= 2) std::cout << "process: " << since_main() << " s after count + merge (context destroyed)" << std::endl;
         if (rc == SIMKA_ERR_NOMEM) {
             if (o.verbose) std::cout << "The solid k-mer spectra do not fit the GPU memory at once: recounting with the spectra in host memory and merging by partition ranges" << std::endl;
             std::fill(flat.begin(), flat.end(), 0);
@@ -885,5 +971,6 @@ int main(int argc, char **argv) {
         unlink((tmp + "/datasetIds").c_str());
         rmdir(tmp.c_str());
     }
+    if (o.verbose >= 2) std::cout << "process: " << since_main() << " s at the end of main" << std::endl;
     return EXIT_SUCCESS;
 }

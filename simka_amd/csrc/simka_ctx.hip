@@ -7,6 +7,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <time.h>
 #include <string>
 #include <vector>
 #include <algorithm>
@@ -75,6 +76,14 @@ struct simka_ctx {
     std::vector<Pending> pending;
     // solid spectra of all samples
     ull *d_solid_keys = nullptr; uint32_t *d_solid_counts = nullptr; uint64_t arena_cap = 0;
+    // The arena is a RESERVED virtual range of arena_cap records whose physical memory is mapped chunk by chunk as the samples arrive
+    // (hipMemAddressReserve / hipMemCreate / hipMemMap): a 138-GB hipMalloc costs 4..6 s, the 10 GB a run at a tenth of C3's depth
+    // really needs a fraction of a second.  arena_mapped: records backed by memory (what the kernels may use); arena_hi: upper bound
+    // of the arena cursor once everything enqueued has finished; lane_bound: what the sample in flight on a lane may still add.
+    bool arena_vmm = false; uint64_t arena_mapped = 0, arena_hi = 0, arena_reserved = 0;      // (arena_reserved: arena_cap rounded up to whole chunks)
+    uint64_t lane_bound[MAX_LANES] = {};
+    std::vector<char> arena_accounted;          // per sample: its bound is part of arena_hi (a redo or a further pass adds nothing)
+    std::vector<hipMemGenericAllocationHandle_t> arena_hk, arena_hc;
     ull *d_arena_cursor = nullptr, *d_sample_base = nullptr;
     uint32_t *d_foff = nullptr, *d_fcnt = nullptr;            // [N][nparts]
     // statistics
@@ -120,6 +129,8 @@ struct simka_ctx {
 };
 
 static int resolve_pending(simka_ctx *ctx, int lane = -1);
+#define ARENA_CHUNK ((uint64_t)1 << 27)        // records per physical chunk of the arena: 1 GiB of keys + 512 MiB of counts
+static double wall_now() { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec; }
 
 #define HIPCHK(call)                                                                             \
     do {                                                                                         \
@@ -283,6 +294,7 @@ SIMKA_EXPORT uint32_t simka_default_log2_partitions(uint64_t max_kmers_per_sampl
 // partition geometry from the largest sample's k-mer count (all samples must share it: the merge
 // joins partition p of every sample, as simkaMerge joins solid/part_p/ of every sample)
 static int setup_geometry(simka_ctx *ctx, uint64_t max_kmers) {
+    const double tgeo = wall_now();
     const simka_config &c = ctx->cfg;
     SimkaKeyCfg &k = ctx->key;
     uint32_t pb = c.log2_partitions;
@@ -350,9 +362,25 @@ static int setup_geometry(simka_ctx *ctx, uint64_t max_kmers) {
         cap = std::min(want, budget);
     }
     ctx->arena_cap = cap;
-    HIPCHK(dev_alloc(&ctx->d_solid_keys, cap));
-    HIPCHK(dev_alloc(&ctx->d_solid_counts, cap));
+    const double tdbg0 = getenv("SIMKA_DEBUG_SYNC") ? wall_now() : 0;
+    {   // reserve the range; memory comes with arena_ensure().  Without the virtual-memory API: one allocation, as before.
+        void *vk = nullptr, *vc = nullptr;
+        const uint64_t capr = (cap + ARENA_CHUNK - 1) / ARENA_CHUNK * ARENA_CHUNK;
+        if (!getenv("SIMKA_ARENA_MALLOC") && hipMemAddressReserve(&vk, capr * 8, 0, nullptr, 0) == hipSuccess) {
+            if (hipMemAddressReserve(&vc, capr * 4, 0, nullptr, 0) == hipSuccess) {
+                ctx->arena_vmm = true; ctx->d_solid_keys = (ull *)vk; ctx->d_solid_counts = (uint32_t *)vc; ctx->arena_reserved = capr; ctx->arena_mapped = 0;
+            } else { (void)hipMemAddressFree(vk, capr * 8); (void)hipGetLastError(); }
+        } else (void)hipGetLastError();
+        if (!ctx->arena_vmm) {
+            HIPCHK(dev_alloc(&ctx->d_solid_keys, cap));
+            HIPCHK(dev_alloc(&ctx->d_solid_counts, cap));
+            ctx->arena_mapped = cap;
+        }
+        ctx->arena_hi = 0;
+    }
+    if (getenv("SIMKA_DEBUG_SYNC")) fprintf(stderr, "[simka] arena of %llu records allocated (%.3f s)\n", (unsigned long long)cap, wall_now() - tdbg0);
     HIPCHK(hipStreamSynchronize(ctx->stream));       // the lanes' streams do not order against the main stream
+    if (getenv("SIMKA_DEBUG_SYNC")) fprintf(stderr, "[simka] geometry ready (%.3f s since the arena, %.3f s in all)\n", wall_now() - tdbg0, wall_now() - tgeo);
     ctx->geometry_ready = true;
     return SIMKA_OK;
 }
@@ -403,8 +431,10 @@ SIMKA_EXPORT int simka_create(const simka_config *cfg, simka_ctx **out) {
         sk.shard_index = cfg->shard_index; sk.shard_count = cfg->shard_count;
     }
 
+    const double tlds = wall_now();
     int rc = set_lds_attr(ctx);
     if (rc) return bail(rc);
+    if (getenv("SIMKA_DEBUG_SYNC")) fprintf(stderr, "[simka] kernel attributes set (%.3f s)\n", wall_now() - tlds);
     const uint32_t N = cfg->nb_samples;
     ctx->stats_n = simka_stats_nb_u64(N, cfg->dist_flags);
     auto chk = [&](hipError_t e, const char *what) { if (e != hipSuccess) { ctx->err = std::string(what) + ": " + hipGetErrorString(e); return false; } return true; };
@@ -451,6 +481,14 @@ SIMKA_EXPORT void simka_destroy(simka_ctx *ctx) {
     if (ctx->copy_stream) { (void)hipStreamSynchronize(ctx->copy_stream); (void)hipStreamDestroy(ctx->copy_stream); }
     for (uint32_t li = 0; li < simka_ctx::MAX_LANES; li++) { if (ctx->d_reads[li]) (void)hipFree(ctx->d_reads[li]); if (ctx->d_offsets[li]) (void)hipFree(ctx->d_offsets[li]); }
     for (auto &g : ctx->ing) { void *q[] = { g.d_text, g.d_lines, g.d_tmp, g.d_tot }; for (void *p_ : q) if (p_) (void)hipFree(p_); }
+    if (ctx->arena_vmm) {      // unmap and release the chunks, give the ranges back
+        (void)hipDeviceSynchronize();
+        if (ctx->arena_mapped) { (void)hipMemUnmap(ctx->d_solid_keys, ctx->arena_mapped * 8); (void)hipMemUnmap(ctx->d_solid_counts, ctx->arena_mapped * 4); }
+        for (auto h : ctx->arena_hk) (void)hipMemRelease(h);
+        for (auto h : ctx->arena_hc) (void)hipMemRelease(h);
+        (void)hipMemAddressFree(ctx->d_solid_keys, ctx->arena_reserved * 8); (void)hipMemAddressFree(ctx->d_solid_counts, ctx->arena_reserved * 4);
+        ctx->d_solid_keys = nullptr; ctx->d_solid_counts = nullptr;
+    }
     void *ptrs[] = { ctx->d_l1_ovf, ctx->d_solid_keys, ctx->d_solid_counts, ctx->d_arena_cursor,
                      ctx->d_sample_base, ctx->d_foff, ctx->d_fcnt, ctx->d_stats, ctx->d_err, ctx->d_part_total,
                      ctx->d_part_off, ctx->d_work, ctx->d_seg_abs, ctx->d_seg_rows, ctx->d_entries, ctx->d_groups,
@@ -483,6 +521,9 @@ SIMKA_EXPORT int simka_reset(simka_ctx *ctx) {
         if (ctx->seg_all) HIPCHK(hipMemsetAsync(ctx->d_seg_rows, 0, (uint64_t)N * ctx->nparts * 32, ctx->stream));
     }
     ctx->seg_dirty = false;
+    ctx->arena_hi = 0;
+    for (auto &b_ : ctx->lane_bound) b_ = 0;
+    std::fill(ctx->arena_accounted.begin(), ctx->arena_accounted.end(), 0);
     if (ctx->d_hist) {
         HIPCHK(hipMemsetAsync(ctx->d_hist, 0, (uint64_t)N * SIMKA_HIST_MAX * 8, ctx->stream));
         HIPCHK(hipMemsetAsync(ctx->d_ovf_cursor, 0, 16, ctx->stream));
@@ -518,6 +559,35 @@ static int ensure_cap(simka_ctx *ctx, T **p, uint64_t *cap, uint64_t need) {
     hipError_t e = dev_alloc(p, n);
     if (e != hipSuccess) return ctx->fail(SIMKA_ERR_NOMEM, "hipMalloc of %llu bytes failed: %s", (unsigned long long)(n * sizeof(T)), hipGetErrorString(e));
     *cap = n;
+    return SIMKA_OK;
+}
+
+// back the first `need` records of the arena with memory (no-op when they already are)
+static int arena_ensure(simka_ctx *ctx, uint64_t need) {
+    need = std::min(need, ctx->arena_cap);                                 // (beyond the capacity: the kernels flag SIMKA_DEVERR_ARENA_FULL)
+    if (!ctx->arena_vmm || need <= ctx->arena_mapped) return SIMKA_OK;
+    hipMemAllocationProp prop = {};
+    prop.type = hipMemAllocationTypePinned; prop.location.type = hipMemLocationTypeDevice; prop.location.id = ctx->cfg.device;
+    hipMemAccessDesc acc = {};
+    acc.location = prop.location; acc.flags = hipMemAccessFlagsProtReadWrite;
+    while (ctx->arena_mapped < need) {
+        hipMemGenericAllocationHandle_t hk, hc;
+        const uint64_t at = ctx->arena_mapped;
+        if (hipMemCreate(&hk, ARENA_CHUNK * 8, &prop, 0) != hipSuccess) { (void)hipGetLastError(); return ctx->fail(SIMKA_ERR_NOMEM, "the solid-spectrum arena cannot grow beyond %llu records (device memory exhausted)", (unsigned long long)at); }
+        if (hipMemCreate(&hc, ARENA_CHUNK * 4, &prop, 0) != hipSuccess) { (void)hipMemRelease(hk); (void)hipGetLastError(); return ctx->fail(SIMKA_ERR_NOMEM, "the solid-spectrum arena cannot grow beyond %llu records (device memory exhausted)", (unsigned long long)at); }
+        HIPCHK(hipMemMap((char *)ctx->d_solid_keys + at * 8, ARENA_CHUNK * 8, 0, hk, 0));
+        HIPCHK(hipMemMap((char *)ctx->d_solid_counts + at * 4, ARENA_CHUNK * 4, 0, hc, 0));
+        HIPCHK(hipMemSetAccess((char *)ctx->d_solid_keys + at * 8, ARENA_CHUNK * 8, &acc, 1));
+        HIPCHK(hipMemSetAccess((char *)ctx->d_solid_counts + at * 4, ARENA_CHUNK * 4, &acc, 1));
+        ctx->arena_hk.push_back(hk); ctx->arena_hc.push_back(hc);
+        ctx->arena_mapped = at + ARENA_CHUNK;
+    }
+    return SIMKA_OK;
+}
+// the arena cursor as of now (every stream that was synchronised by the caller is accounted for)
+static int arena_cursor_now(simka_ctx *ctx, ull *cur, hipStream_t st) {
+    HIPCHK(hipMemcpyAsync(cur, ctx->d_arena_cursor, 8, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
     return SIMKA_OK;
 }
 
@@ -612,8 +682,19 @@ static int run_count_kernels(simka_ctx *ctx, uint32_t sample, const SimkaScanArg
         hipLaunchKernelGGL(k_skm_split, dim3(B1), dim3(SKM_SPLIT_BLOCK), lds_split, st, (const uint4 *)L.d_skm_a, (const uint32_t *)L.d_skm_p, (const ull *)L.d_b1_start, (const ull *)L.d_b1_count, sk,
                            L.d_skm_b, L.d_pstart, L.d_pcnt, (const uint32_t *)flag);
     }, st);
+    if (ctx->arena_accounted.size() != N) ctx->arena_accounted.assign(N, 0);
+    if (ctx->arena_vmm && !ctx->arena_accounted[sample]) {
+        ctx->arena_accounted[sample] = 1;
+        // what this sample can add to the arena at most: every solid k-mer has >= abundance_min occurrences, plus the tails of the
+        // blocks' slab reservations
+        const uint64_t kocc_b = a.fixed_len ? (a.fixed_len >= sk.k ? a.nb_reads * (uint64_t)(a.fixed_len - sk.k + 1) : 0) : a.nb_bases;
+        const uint64_t bound = kocc_b / std::max<uint32_t>(1u, ctx->cfg.abundance_min) + (uint64_t)ctx->num_cus * 4 * K2_SLAB;
+        ctx->arena_hi = std::min<uint64_t>(ctx->arena_cap, ctx->arena_hi + bound);
+        ctx->lane_bound[sample % ctx->nlanes] = bound;
+        rc = arena_ensure(ctx, ctx->arena_hi); if (rc) return rc;
+    }
     SimkaCountOut o;
-    o.arena_cursor = ctx->d_arena_cursor; o.sample_base = ctx->d_sample_base + sample; o.arena_cap = ctx->arena_cap;
+    o.arena_cursor = ctx->d_arena_cursor; o.sample_base = ctx->d_sample_base + sample; o.arena_cap = ctx->arena_vmm ? std::min(ctx->arena_mapped, ctx->arena_cap) : ctx->arena_cap;
     o.solid_keys = ctx->d_solid_keys; o.solid_counts = ctx->d_solid_counts;
     o.foff = ctx->d_foff + (uint64_t)sample * ctx->nparts; o.fcnt = ctx->d_fcnt + (uint64_t)sample * ctx->nparts;
     o.totals = (ull *)ctx->d_stats + stats_off_tot(N, ctx->cfg.dist_flags, 0); o.sample = sample; o.nb_samples = N; o.err = ctx->d_err;
@@ -671,6 +752,13 @@ static int run_count_kernels(simka_ctx *ctx, uint32_t sample, const SimkaScanArg
 static int resolve_pending(simka_ctx *ctx, int lane) {
     for (uint32_t li = 0; li < ctx->nlanes; li++)
         if (ctx->lanes[li].stream && (lane < 0 || (uint32_t)lane == li)) HIPCHK(hipStreamSynchronize(ctx->lanes[li].stream));
+    if (ctx->arena_vmm && ctx->geometry_ready) {      // what the finished samples really took replaces their worst-case bounds
+        ull cur = 0;
+        HIPCHK(hipMemcpy(&cur, ctx->d_arena_cursor, 8, hipMemcpyDeviceToHost));
+        uint64_t hi = cur;
+        for (uint32_t li = 0; li < ctx->nlanes; li++) { if (lane < 0 || (uint32_t)lane == li) ctx->lane_bound[li] = 0; hi += ctx->lane_bound[li]; }
+        ctx->arena_hi = std::min(ctx->arena_hi, hi);
+    }
     if (ctx->pending.empty()) return SIMKA_OK;
     const uint32_t N = ctx->cfg.nb_samples;
     std::vector<simka_ctx::Pending> todo, keep;
@@ -1100,6 +1188,8 @@ static int import_sample(simka_ctx *ctx, uint32_t sample, const simka_sample_tot
     if (cursor + nb_records > ctx->arena_cap)
         return ctx->fail(SIMKA_ERR_NOMEM, "solid-spectrum arena exhausted (%llu records): raise solid_capacity", (unsigned long long)ctx->arena_cap);
     const ull next = cursor + nb_records;
+    rc = arena_ensure(ctx, next); if (rc) return rc;
+    ctx->arena_hi = std::max<uint64_t>(ctx->arena_hi, next);
     const hipMemcpyKind kind = on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
     if (nb_records) {
         HIPCHK(hipMemcpyAsync(ctx->d_solid_keys + cursor, keys, nb_records * 8, kind, ctx->stream));
@@ -1253,6 +1343,8 @@ SIMKA_EXPORT int simka_import_samples_device(simka_ctx *ctx, const uint32_t *sam
     if (cursor + nb_records > ctx->arena_cap)
         return ctx->fail(SIMKA_ERR_NOMEM, "solid-spectrum arena exhausted (%llu records): raise solid_capacity", (unsigned long long)ctx->arena_cap);
     const ull next = cursor + nb_records;
+    rc = arena_ensure(ctx, next); if (rc) return rc;
+    ctx->arena_hi = std::max<uint64_t>(ctx->arena_hi, next);
     if (nb_records) {
         HIPCHK(hipMemcpyAsync(ctx->d_solid_keys + cursor, d_keys, nb_records * 8, hipMemcpyDeviceToDevice, ctx->stream));
         HIPCHK(hipMemcpyAsync(ctx->d_solid_counts + cursor, d_counts, nb_records * 4, hipMemcpyDeviceToDevice, ctx->stream));

@@ -1267,3 +1267,45 @@ def test_device_ingest_reproduces_the_goldens(gpu_required, golden_dir, tmp_path
                 assert f.read() == g.read(), ref
             compared += 1
     assert compared == 20
+
+
+@pytest.mark.gpu
+def test_cli_device_parse_equals_host_parse(gpu_required, tmp_path):
+    """The `simka` driver parses plain-text inputs on the GPU by default (simka_ingest_*) and on the host with -host-parse; an input
+    the device parser flags (a blank line inside a file) silently takes the host parser.  Same CSV bytes either way."""
+    rng = np.random.default_rng(3)
+    genome = bytes(rng.choice(list(b"ACGT"), size=5000).tolist())
+
+    def reads(n, seed):
+        r = np.random.default_rng(seed)
+        out = []
+        for i in range(n):
+            ln = int(r.integers(50, 150)); st = int(r.integers(0, len(genome) - ln))
+            s = bytearray(genome[st:st + ln])
+            if i % 6 == 0:
+                s[int(r.integers(0, ln))] = ord("N")
+            out.append(bytes(s))
+        return out
+
+    def fasta(name, rs, width=0, blank_at=None):
+        with open(str(tmp_path / name), "wb") as f:
+            for i, s in enumerate(rs):
+                f.write(b">r%d\n" % i)
+                if width:
+                    for p in range(0, len(s), width):
+                        f.write(s[p:p + width] + b"\n")
+                else:
+                    f.write(s + b"\n")
+                if blank_at == i:
+                    f.write(b"\n")
+    fasta("a.fa", reads(300, 1)); fasta("b.fa", reads(200, 2), width=40); fasta("c.fa", reads(250, 3), blank_at=17)
+    with open(str(tmp_path / "d.fq"), "wb") as f:
+        for i, s in enumerate(reads(220, 4)):
+            f.write(b"@q%d\n%s\n+\n%s\n" % (i, s, b"I" * len(s)))
+    (tmp_path / "in.txt").write_text("A: a.fa\nB: a.fa , b.fa\nC: c.fa\nD: d.fq ; b.fa\n")
+    args = ["-in", str(tmp_path / "in.txt"), "-out-tmp", str(tmp_path / "tmp"), "-simple-dist", "-kmer-size", "19", "-abundance-min", "1"]
+    dev = _run_cli(args, str(tmp_path / "o1"))
+    host = _run_cli(args + ["-host-parse"], str(tmp_path / "o2"))
+    assert sorted(dev) == sorted(host) and len(dev) >= 15
+    for name in host:
+        assert dev[name] == host[name], name
