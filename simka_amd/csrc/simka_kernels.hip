@@ -499,6 +499,14 @@ __device__ __forceinline__ void tri_unrank(uint32_t idx, uint32_t s, uint32_t &x
 }
 
 // floor(sqrt(x)) for the Hellinger term: 32-bit fast path, exact
+// x < 2^32 (every count of the span below 65536, known per span): no 64-bit product, no normalisation, no branch
+__device__ __forceinline__ uint32_t pair_isqrt32(uint32_t v) {
+    uint32_t r = (uint32_t)__fsqrt_rn((float)v);
+    r = r > 65535u ? 65535u : r;
+    r -= (r * r > v) ? 1u : 0u;
+    r += (2u * r < v - r * r) ? 1u : 0u;
+    return r;
+}
 __device__ __forceinline__ uint32_t pair_isqrt(ull x) {
     if (x >> 32) return (uint32_t)simka_isqrt(x);
     // float sqrt of a 32-bit value is within 1 of the floor: two branch-free corrections (r <= 65535, so r * r fits 32 bits;
@@ -705,6 +713,7 @@ k_pairs(const SimkaSpan *spans, const ull *cursors, const ull *entries, const ui
         if (bound + add >= 0xffffffffull || (chord_fast && bound_q + addq >= 0xffffffffull)) { pairs_flush<TILED, K4_BLOCK>(pk, c64, acc, pc, rect, baseI, baseJ); bound = 0; bound_q = 0; }
         bound += add;
         if (chord_fast) bound_q += addq;
+        const bool smallc = chord_fast && cur.maxc < 32768u;       // every product of the span is a 32-bit value: the cheap chord / Hellinger update
         __syncthreads();
         PP(2)
         if (TILED) {
@@ -771,12 +780,17 @@ k_pairs(const SimkaSpan *spans, const ull *cursors, const ull *entries, const ui
                 atomicAdd(&pk[0 * CP + cell], (ull)ci | ((ull)cj << 32));                       // S_ij | S_ji
                 atomicAdd(&pk[1 * CP + cell], 1ull | ((ull)(ci < cj ? ci : cj) << 32));         // a | bc
                 if (pc.simple) {
-                    const ull prod = (ull)ci * (ull)cj;
-                    const ull hell = (ull)pair_isqrt(prod) << 32;
-                    if (chord_fast) atomicAdd(&pk[2 * CP + cell], (ull)(uint32_t)prod | hell);  // chord | hell
-                    else {   // huge counts: the product goes straight to the global u64 cell
-                        atomicAdd(&pk[2 * CP + cell], hell);
-                        atomicAdd(&acc[SIMKA_ACC_CHORD * pc.nb_pairs + simka_pair_index(si, sj, N)], prod);
+                    if (smallc) {       // (uniform per span) counts below 2^15: the product is a 32-bit value below 2^30
+                        const uint32_t prod32 = ci * cj;
+                        atomicAdd(&pk[2 * CP + cell], (ull)prod32 | ((ull)pair_isqrt32(prod32) << 32));  // chord | hell
+                    } else {
+                        const ull prod = (ull)ci * (ull)cj;
+                        const ull hell = (ull)pair_isqrt(prod) << 32;
+                        if (chord_fast) atomicAdd(&pk[2 * CP + cell], (ull)(uint32_t)prod | hell);  // chord | hell
+                        else {   // huge counts: the product goes straight to the global u64 cell
+                            atomicAdd(&pk[2 * CP + cell], hell);
+                            atomicAdd(&acc[SIMKA_ACC_CHORD * pc.nb_pairs + simka_pair_index(si, sj, N)], prod);
+                        }
                     }
                 }
                 if (cplx) {
@@ -1074,6 +1088,7 @@ k_pairs_tm(const SimkaSpan *spans, const ull *cursors, const ull *tm_ent, const 
         if (bound + add >= 0xffffffffull || (chord_fast && bound_q + addq >= 0xffffffffull)) { pairs_flush<true, K4_BLOCK>(pk, c64, acc, pc, rect, baseI, baseJ); bound = 0; bound_q = 0; }
         bound += add;
         if (chord_fast) bound_q += addq;
+        const bool smallc = chord_fast && cur.maxc < 32768u;       // every product of the span is a 32-bit value: the cheap chord / Hellinger update
         // group runs: the first entry of a run stores its index, the last one the index behind it.  Neighbouring segments of
         // different spans never share a group id; the I and J segments of one span may, hence the explicit boundary.
 #pragma unroll
@@ -1137,12 +1152,17 @@ k_pairs_tm(const SimkaSpan *spans, const ull *cursors, const ull *tm_ent, const 
                 atomicAdd(&pk[0 * CP + cell], (ull)ci | ((ull)cj << 32));                       // S_ij | S_ji
                 atomicAdd(&pk[1 * CP + cell], 1ull | ((ull)(ci < cj ? ci : cj) << 32));         // a | bc
                 if (pc.simple) {
-                    const ull prod = (ull)ci * (ull)cj;
-                    const ull hell = (ull)pair_isqrt(prod) << 32;
-                    if (chord_fast) atomicAdd(&pk[2 * CP + cell], (ull)(uint32_t)prod | hell);  // chord | hell
-                    else {
-                        atomicAdd(&pk[2 * CP + cell], hell);
-                        atomicAdd(&acc[SIMKA_ACC_CHORD * pc.nb_pairs + simka_pair_index(si, sj, N)], prod);
+                    if (smallc) {       // (uniform per span) counts below 2^15: the product is a 32-bit value below 2^30
+                        const uint32_t prod32 = ci * cj;
+                        atomicAdd(&pk[2 * CP + cell], (ull)prod32 | ((ull)pair_isqrt32(prod32) << 32));  // chord | hell
+                    } else {
+                        const ull prod = (ull)ci * (ull)cj;
+                        const ull hell = (ull)pair_isqrt(prod) << 32;
+                        if (chord_fast) atomicAdd(&pk[2 * CP + cell], (ull)(uint32_t)prod | hell);  // chord | hell
+                        else {   // huge counts: the product goes straight to the global u64 cell
+                            atomicAdd(&pk[2 * CP + cell], hell);
+                            atomicAdd(&acc[SIMKA_ACC_CHORD * pc.nb_pairs + simka_pair_index(si, sj, N)], prod);
+                        }
                     }
                 }
                 if (cplx) {
