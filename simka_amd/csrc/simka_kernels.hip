@@ -677,8 +677,11 @@ k_pairs(const SimkaSpan *spans, const ull *cursors, const ull *entries, const ui
             const uint32_t i = tid + (uint32_t)q * K4_BLOCK;
             if (i < cur.nent) {
                 const ull e = pre_e[q];
-                ent[i] = e;
                 const uint32_t si = (uint32_t)(e >> 32);
+                // one tile: the entry carries the start of its sample's row of pair cells, li N - li (li + 1) / 2 - li (< 2^16: the
+                // cells of all pairs fit LDS), so that a pair's cell is one add instead of two multiplies
+                if (!TILED) ent[i] = e | ((ull)(si * TD - ((si * (si + 1u)) >> 1) - si) << 48);
+                else ent[i] = e;
                 uint32_t fl = 0, loc = si;                       // membership flags (A | B<<16), index into tn
                 if (TILED) {
                     const uint32_t li = si - baseI, lj = si - baseJ;
@@ -773,10 +776,20 @@ k_pairs(const SimkaSpan *spans, const ull *cursors, const ull *entries, const ui
                 const ull ey = ent[iy];
                 uint32_t si = (uint32_t)(ex >> 32), sj = (uint32_t)(ey >> 32);
                 uint32_t ci = (uint32_t)ex, cj = (uint32_t)ey;
+                uint32_t li, lj, cell;
+                if (!TILED) {      // branch-free: order the pair with selects, the cell from the smaller sample's row start
+                    const uint32_t rx_ = si >> 16, ry_ = sj >> 16;
+                    si &= 0xffffu; sj &= 0xffffu;
+                    const bool lo = si < sj;
+                    const uint32_t a_ = lo ? ci : cj, b_ = lo ? cj : ci, smin = lo ? si : sj, smax = lo ? sj : si;
+                    cell = (lo ? rx_ : ry_) + smax - 1u;
+                    ci = a_; cj = b_; si = smin; sj = smax; li = si; lj = sj;
+                } else {
                 // off-diagonal tiles: every member of A precedes every member of B.  Elsewhere order the pair.
                 if (!rect && si > sj) { uint32_t t_ = si; si = sj; sj = t_; t_ = ci; ci = cj; cj = t_; }
-                const uint32_t li = si - baseI, lj = sj - baseJ;
-                const uint32_t cell = rect ? li * T + lj : li * TD - ((li * (li + 1u)) >> 1) + (lj - li - 1u);   // TD <= 65535: fits 32 bits
+                li = si - baseI; lj = sj - baseJ;
+                cell = rect ? li * T + lj : li * TD - ((li * (li + 1u)) >> 1) + (lj - li - 1u);   // TD <= 65535: fits 32 bits
+                }
                 atomicAdd(&pk[0 * CP + cell], (ull)ci | ((ull)cj << 32));                       // S_ij | S_ji
                 atomicAdd(&pk[1 * CP + cell], 1ull | ((ull)(ci < cj ? ci : cj) << 32));         // a | bc
                 if (pc.simple) {
