@@ -47,6 +47,7 @@ struct Options {
     int verbose = 1;
     int nb_gpus = 1, first_gpu = 0;     // new: GPUs to spread the samples (count) and the partition ranges (merge) over
     bool same_gpu = false;              // new (tests): all -nb-gpus contexts on GPU -gpu
+    long long ingest_chunk = 1ll << 30; // new: bytes of a file handed to the device-side parser at a time (cut at record boundaries)
     bool host_parse = false;            // new: parse + pack every input on the host (default: plain-text inputs without read policies are parsed on the GPU)
     bool gpu_allreduce = false;         // new: -nb-gpus combines the merges' accumulators with one RCCL all-reduce instead of summing them on the host
     long long solid_capacity = 0;       // new (tests): records of the solid-spectrum arena of every context (0: from the free memory)
@@ -135,6 +136,7 @@ Options parse_args(int argc, char **argv) {
         else if (a == "-gpu-shared") o.same_gpu = true;
         else if (a == "-gpu-allreduce") o.gpu_allreduce = true;
         else if (a == "-host-parse") o.host_parse = true;
+        else if (a == "-ingest-chunk") o.ingest_chunk = std::min<long long>(std::max<long long>(64, atoll(need(i).c_str())), 0xf0000000ll);
         else if (a == "-merge-ranges") o.merge_ranges = atoi(need(i).c_str());
         else if (a == "-solid-capacity") o.solid_capacity = atoll(need(i).c_str());
         else if (a == "-parse-only") o.parse_only = true;
@@ -334,6 +336,7 @@ struct Packed {
     bool raw = false;
     std::vector<PinnedBuf<char>> texts;
     std::vector<int> formats;             // 0 FASTA, 1 FASTQ
+    std::vector<uint32_t> file_of;        // which file a piece belongs to (a FILE that delivers no read ends the sample)
 };
 
 // Which reads of a sample are counted (-max-reads m, paired parts, read filters).  The reference walks the sample's files with
@@ -391,24 +394,58 @@ bool load_sample_raw(const Sample &s, const Options &o, uint64_t max_reads, Pack
         FILE *fp = fopen(files[f]->c_str(), "rb");
         if (!fp) return false;
         struct stat st;
-        if (fstat(fileno(fp), &st) != 0 || !S_ISREG(st.st_mode) || (uint64_t)st.st_size >= 0xfffffff0ull) { fclose(fp); return false; }
-        PinnedBuf<char> buf;
-        buf.resize((size_t)st.st_size + 1);
-        size_t got = 0;
-        while (got < (size_t)st.st_size) { const size_t r = fread(buf.data() + got, 1, (size_t)st.st_size - got, fp); if (r == 0) break; got += r; }
-        fclose(fp);
-        if (got != (size_t)st.st_size) return false;
-        buf.resize(got);
-        if (got >= 2 && (unsigned char)buf[0] == 0x1f && (unsigned char)buf[1] == 0x8b) return false;       // gzip: the host inflates
-        size_t p = 0;
-        while (p < got && (buf[p] == '\n' || buf[p] == '\r')) p++;
+        if (fstat(fileno(fp), &st) != 0 || !S_ISREG(st.st_mode)) { fclose(fp); return false; }
+        // The file goes over in pieces of at most -ingest-chunk bytes (1 GiB), each ending at a record boundary: the parser takes one piece
+        // as one text (32-bit offsets), and a pinned buffer of the whole file would be as large as the file.  FASTA: a piece ends before
+        // the last line that starts with '>'; FASTQ (4-line records, which the device parser verifies): before the last line whose
+        // number in the piece is a multiple of 4.  A record longer than a piece: the host parser takes the sample.
+        const size_t fsize = (size_t)st.st_size, chunk = (size_t)o.ingest_chunk;
+        size_t done = 0, carry = 0;
         int fmt = -1;
-        if (p == got) fmt = 0;                     // an empty file: delivers no read (which ends the sample)
-        else if (p == 0 && buf[0] == '>') fmt = 0;
-        else if (p == 0 && buf[0] == '@') fmt = 1;
-        if (fmt < 0) return false;
-        out.texts.push_back(std::move(buf));
-        out.formats.push_back(fmt);
+        PinnedBuf<char> cur;
+        bool first = true;
+        while (first || done < fsize) {
+            const size_t want = std::min(chunk > carry ? chunk - carry : (size_t)1, fsize - done);
+            PinnedBuf<char> buf;
+            buf.resize(carry + want + 1);
+            if (carry) memcpy(buf.data(), cur.data() + (cur.size() - carry), carry);
+            size_t got = 0;
+            while (got < want) { const size_t r = fread(buf.data() + carry + got, 1, want - got, fp); if (r == 0) break; got += r; }
+            if (got != want) { fclose(fp); return false; }
+            done += got;
+            size_t len = carry + got;
+            if (first) {
+                first = false;
+                if (len >= 2 && (unsigned char)buf[0] == 0x1f && (unsigned char)buf[1] == 0x8b) { fclose(fp); return false; }       // gzip: the host inflates
+                size_t p = 0;
+                while (p < len && (buf[p] == '\n' || buf[p] == '\r')) p++;
+                if (p == len && done == fsize) fmt = 0;     // an empty file: delivers no read (which ends the sample)
+                else if (p == 0 && buf[0] == '>') fmt = 0;
+                else if (p == 0 && buf[0] == '@') fmt = 1;
+                if (fmt < 0) { fclose(fp); return false; }
+            }
+            size_t cut = len;                               // the last piece takes everything
+            if (done < fsize) {
+                cut = 0;
+                if (fmt == 0) { for (size_t p = len; p-- > 1; ) if (buf[p] == '>' && buf[p - 1] == '\n') { cut = p; break; } }
+                else {
+                    size_t nl = 0;
+                    for (const char *q = buf.data(), *e = q + len; (q = (const char *)memchr(q, '\n', (size_t)(e - q))) != nullptr; q++) nl++;
+                    size_t skip = nl % 4 + 1;               // the (nl mod 4 + 1)-th newline from the end closes the last whole record
+                    if (nl >= 4) for (size_t p = len; p-- > 0; ) if (buf[p] == '\n' && --skip == 0) { cut = p + 1; break; }
+                }
+                if (cut == 0) { fclose(fp); return false; }      // no whole record in the piece
+            }
+            carry = len - cut;
+            cur = std::move(buf);
+            PinnedBuf<char> piece;
+            if (carry == 0) { cur.resize(cut); piece = std::move(cur); cur = PinnedBuf<char>(); }
+            else { piece.resize(cut); memcpy(piece.data(), cur.data(), cut); cur.resize(len); }
+            out.texts.push_back(std::move(piece));
+            out.formats.push_back(fmt);
+            out.file_of.push_back((uint32_t)f);
+        }
+        fclose(fp);
     }
     return true;
 }
@@ -753,6 +790,7 @@ int main(int argc, char **argv) {
         int rc = SIMKA_OK;
         auto soft = [&](int r, const char *what) { if (r == SIMKA_OK) return true; if (r != SIMKA_ERR_NOMEM) fatal(c, what); rc = r; return false; };
         double t_wait = 0, t_count = 0;        // -verbose 2: where the main thread spends its time
+        uint64_t n_dev_parsed = 0, n_pieces = 0;
         auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
         const double t_begin = now();
         for (uint32_t i = 0; i < N && rc == SIMKA_OK; i++) {
@@ -778,9 +816,10 @@ int main(int argc, char **argv) {
                     uint64_t nr = 0; int irr = 0;
                     ok = soft(simka_ingest_text(c, i, pkp->texts[f].data(), pkp->texts[f].size(), pkp->formats[f], &nr, &irr), "simka_ingest_text");
                     irregular = irr != 0;
-                    if (ok && !irregular && nr == 0) break;       // a file that delivers no read ends the sample
+                    if (ok && !irregular && nr == 0 && (f + 1 == pkp->texts.size() || pkp->file_of[f + 1] != pkp->file_of[f]) && (f == 0 || pkp->file_of[f - 1] != pkp->file_of[f]))
+                        break;       // a FILE that delivers no read ends the sample (a file in several pieces has reads in every piece)
                 }
-                if (ok && !irregular) { ok = soft(simka_ingest_count(c, i, nullptr, nullptr), "simka_ingest_count"); counted = true; }
+                if (ok && !irregular) { ok = soft(simka_ingest_count(c, i, nullptr, nullptr), "simka_ingest_count"); counted = true; n_dev_parsed++; n_pieces += pkp->texts.size(); }
                 else if (ok) {        // something the device parser does not take (blank lines inside a file, multi-line FASTQ, ...): the host parser decides
                     Packed hp;
                     if (!load_sample(samples[i], o, max_reads, hp)) die("ERROR: Can't open dataset: " + samples[i].id);
@@ -808,6 +847,7 @@ int main(int argc, char **argv) {
         const double t3 = now();
         if (rc == SIMKA_OK) soft(simka_merge(c), "simka_merge");
         if (rc == SIMKA_OK) soft(simka_stats_download(c, flat.data(), nw, nullptr), "simka_stats_download");
+        if (o.verbose >= 2) std::cout << "ingest: " << n_dev_parsed << " samples parsed on the GPU (" << n_pieces << " pieces of text), " << N - n_dev_parsed << " on the host" << std::endl;
         if (o.verbose >= 2) std::cout << "main thread: waiting for the loader " << t_wait << " s, ingest / count calls " << t_count << " s, draining the count kernels " << t3 - t2
                                       << " s, merge + download " << now() - t3 << " s (since the context: " << now() - t_begin << " s)" << std::endl;
         simka_destroy(c);

@@ -466,11 +466,13 @@ def test_kmer_shared_by_more_samples_than_a_span(gpu_required, oracle_mod):
     _check_vs_oracle(totals, st, orc, simple=True, complex_=True)
 
 
-def _run_cli(args, out):
+def _run_cli(args, out, log=None):
     import subprocess
     from simka_amd import build as b
-    r = subprocess.run([b.CLI_PATH] + args + ["-out", out, "-verbose", "0"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    r = subprocess.run([b.CLI_PATH] + args + ["-out", out, "-verbose", "0" if log is None else "2"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
     assert r.returncode == 0, r.stdout
+    if log is not None:
+        log.append(r.stdout)
     res = {}
     for gzf in sorted(glob.glob(os.path.join(out, "*.csv.gz"))):
         with gzip.open(gzf, "rb") as f:
@@ -1306,6 +1308,40 @@ def test_cli_device_parse_equals_host_parse(gpu_required, tmp_path):
     args = ["-in", str(tmp_path / "in.txt"), "-out-tmp", str(tmp_path / "tmp"), "-simple-dist", "-kmer-size", "19", "-abundance-min", "1"]
     dev = _run_cli(args, str(tmp_path / "o1"))
     host = _run_cli(args + ["-host-parse"], str(tmp_path / "o2"))
+    assert sorted(dev) == sorted(host) and len(dev) >= 15
+    for name in host:
+        assert dev[name] == host[name], name
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("chunk", [700, 5000])
+def test_cli_device_parse_in_pieces(gpu_required, tmp_path, chunk):
+    """Large inputs reach the device-side parser in pieces cut at record boundaries (-ingest-chunk, 1 GiB by default): with pieces of a
+    few hundred bytes every cut rule is exercised -- multi-line FASTA (cut before a header), FASTQ (cut on a line count that is a
+    multiple of four, '@' in the qualities), several files per sample.  Same CSV bytes as the host parser."""
+    rng = np.random.default_rng(8)
+    genome = bytes(rng.choice(list(b"ACGT"), size=4000).tolist())
+
+    def reads(n, seed):
+        r = np.random.default_rng(seed)
+        return [genome[st:st + ln] for st, ln in ((int(r.integers(0, 3700)), int(r.integers(40, 260))) for _ in range(n))]
+    with open(str(tmp_path / "a.fa"), "wb") as f:
+        for i, s in enumerate(reads(120, 1)):
+            f.write(b">r%d\n" % i + b"".join(s[p:p + 60] + b"\n" for p in range(0, len(s), 60)))
+    with open(str(tmp_path / "b.fq"), "wb") as f:
+        for i, s in enumerate(reads(150, 2)):
+            f.write(b"@q%d\n%s\n+\n%s\n" % (i, s, b"@>" * (len(s) // 2) + b"I" * (len(s) % 2)))
+    with open(str(tmp_path / "c.fa"), "wb") as f:
+        for i, s in enumerate(reads(90, 3)):
+            f.write(b">c%d\n%s\n" % (i, s))
+    (tmp_path / "in.txt").write_text("A: a.fa\nB: b.fq\nC: c.fa , a.fa\nD: b.fq ; c.fa\n")
+    args = ["-in", str(tmp_path / "in.txt"), "-out-tmp", str(tmp_path / "tmp"), "-simple-dist", "-kmer-size", "17", "-abundance-min", "1"]
+    log = []
+    dev = _run_cli(args + ["-ingest-chunk", str(chunk)], str(tmp_path / "o1"), log)
+    host = _run_cli(args + ["-host-parse"], str(tmp_path / "o2"))
+    import re
+    m = re.search(r"ingest: (\d+) samples parsed on the GPU \((\d+) pieces of text\), (\d+) on the host", log[0])
+    assert m and int(m.group(1)) == 4 and int(m.group(3)) == 0 and int(m.group(2)) > 12, log[0][-600:]      # really in pieces, really on the GPU
     assert sorted(dev) == sorted(host) and len(dev) >= 15
     for name in host:
         assert dev[name] == host[name], name
