@@ -229,12 +229,27 @@ k_skm_scan(SimkaScanArgs a, SimkaSkmCfg cfg, ull *b1_count, ull *b1_cursor, uint
                 if (r_ >= L) r_ -= L;
                 rel = r_;
             } else rel = (uint32_t)(((uint64_t)relb + SKM_SEG * tid + (L - 1u)) % L);
+            if (L >= k + (uint32_t)SKM_SEG) {
+                // A read holds at least 17 k-mers, so the 17 positions see at most ONE run of starts whose k-mer would cross the end
+                // of its read: positions j with L - k < rel + j < L, i.e. j in [L - k - rel + 1, L - rel) -- a mask, not 17 compares.
+                const int lo_ = (int)(L - k) - (int)rel + 1, hi_ = (int)(L - rel);
+                const uint32_t lo = lo_ < 0 ? 0u : (uint32_t)lo_, hi = hi_ > SKM_SEG + 1 ? (uint32_t)(SKM_SEG + 1) : (uint32_t)hi_;
+                const uint32_t bad = lo < hi ? (((1u << hi) - 1u) & ~((1u << lo) - 1u)) : 0u;
+                valid = ((1u << (SKM_SEG + 1)) - 1u) & ~bad;
+                // the ends of the data (first and last tile only: wave-uniform test)
+                if (Q0 < 0 || (uint64_t)(Q0 + SKM_TILE + 64) > a.nb_bases) {
+                    const long long l2 = P0 < 0 ? -P0 : 0ll, h2 = (long long)a.nb_bases - P0;
+                    const uint32_t lo2 = l2 > SKM_SEG + 1 ? (uint32_t)(SKM_SEG + 1) : (uint32_t)l2, hi2 = h2 < 0 ? 0u : (h2 > SKM_SEG + 1 ? (uint32_t)(SKM_SEG + 1) : (uint32_t)h2);
+                    valid &= lo2 < hi2 ? (((1u << hi2) - 1u) & ~((1u << lo2) - 1u)) : 0u;
+                }
+            } else {
 #pragma unroll
-            for (int j = 0; j <= SKM_SEG; j++) {
-                const long long P = P0 + j;
-                const bool ok = P >= 0 && (uint64_t)P < a.nb_bases && rel + k <= L;
-                valid |= (ok ? 1u : 0u) << j;
-                rel++; if (rel >= L) rel = 0;
+                for (int j = 0; j <= SKM_SEG; j++) {
+                    const long long P = P0 + j;
+                    const bool ok = P >= 0 && (uint64_t)P < a.nb_bases && rel + k <= L;
+                    valid |= (ok ? 1u : 0u) << j;
+                    rel++; if (rel >= L) rel = 0;
+                }
             }
         } else if (owner && (uint64_t)(P0 < 0 ? 0 : P0) < a.nb_bases) {
             // `next` = first read start beyond the current position: from the staged table (relative to T0) or the offsets array
@@ -270,14 +285,14 @@ k_skm_scan(SimkaScanArgs a, SimkaSkmCfg cfg, ull *b1_count, ull *b1_cursor, uint
     // ---- phase 3a: run starts and breaks among e_1 .. e_16 (bit j-1)
     uint32_t start = 0, brk = 0xffffu;
     if (owner) {
-        brk = 0;
+        // bit j - 1: the minimizer changes between e_{j-1} and e_j; then start = valid & (previous invalid | change), as masks
+        uint32_t neq = 0;
 #pragma unroll
-        for (int j = 1; j <= SKM_SEG; j++) {
-            const bool v = (valid >> j) & 1u, pv = (valid >> (j - 1)) & 1u;
-            const bool st = v && (!pv || mh[j] != mh[j - 1] || (j == 1 && tid == SKM_OWN_LO / SKM_SEG));   // a tile never continues a run
-            start |= (st ? 1u : 0u) << (j - 1);
-            brk |= ((st || !v) ? 1u : 0u) << (j - 1);
-        }
+        for (int j = 1; j <= SKM_SEG; j++) neq |= (mh[j] != mh[j - 1] ? 1u : 0u) << (j - 1);
+        if (tid == SKM_OWN_LO / SKM_SEG) neq |= 1u;                                  // a tile never continues a run
+        const uint32_t V = (valid >> 1) & 0xffffu, PV = valid & 0xffffu;
+        start = V & (~PV | neq);
+        brk = (start | ~V) & 0xffffu;
     }
     smask[tid] = start | (brk << 16);
     __syncthreads();               // (A) hm is dead from here on
