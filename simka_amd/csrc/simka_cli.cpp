@@ -1012,5 +1012,8 @@ int main(int argc, char **argv) {
         rmdir(tmp.c_str());
     }
     if (o.verbose >= 2) std::cout << "process: " << since_main() << " s at the end of main" << std::endl;
-    return EXIT_SUCCESS;
+    // Everything is on disk.  Unpinning the recycled host buffers and tearing the HIP runtime down in static destructors costs 0.3 s
+    // (a fifth of a 15-GB run): the process ends here, the operating system and the driver reclaim what is left.
+    std::cout.flush(); std::cerr.flush(); fflush(nullptr);
+    _Exit(EXIT_SUCCESS);
 }
