@@ -304,6 +304,10 @@ int simka_device_memory(int device, uint64_t *free_bytes, uint64_t *total_bytes)
 /* sizes chosen by the ctx (partition bits etc.), for DESIGN/bench reporting */
 int simka_get_geometry(simka_ctx *ctx, uint32_t *log2_level1, uint32_t *log2_level2, uint32_t *log2_subranges,
                        uint64_t *arena_capacity, uint64_t *csr_capacity);
+/* how the samples counted so far were counted: on the minimizer-partitioned pipeline (every sample for kmer_size <= 31, and for
+ * 32 <= kmer_size <= 51 unless a partition outgrew its table) or by sorting all k-mer occurrences (kmer_size >= 52, the fallback,
+ * SIMKA_SORT_PATH); and how many had their level-1 buckets sized exactly after a capacity-sized attempt overflowed */
+int simka_count_paths(simka_ctx *ctx, uint64_t *nb_partitioned, uint64_t *nb_sorted, uint64_t *nb_exact_redone);
 
 /* ---- synthetic reads (bench / test utility, not part of the reference path) ---------------
  * Seeded generator of SURVEY.md section 8(d): a pool of random genomes and reads sampled from

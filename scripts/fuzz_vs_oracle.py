@@ -1,6 +1,6 @@
 """Randomised parity check: GPU path (hash pipeline, or the sort path for k >= 32) against the oracle on random small inputs --
 random k, abundance window, sample count, variable read lengths, N letters, lowercase, empty reads, partition geometry.
-usage: fuzz_vs_oracle.py [seconds] [seed]"""
+usage: fuzz_vs_oracle.py [seconds] [seed]      (FUZZ_KS=33,36,51 restricts the k-mer sizes)"""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -12,9 +12,10 @@ seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 np.set_printoptions(threshold=100000, linewidth=220)
 rng = np.random.default_rng(seed)
 t_end = time.time() + budget
+KS = [int(x) for x in os.environ.get("FUZZ_KS", "").split(",") if x] or [1, 2, 3, 5, 8, 11, 15, 16, 17, 21, 25, 31, 32, 33, 34, 35, 36, 37, 40, 45, 50, 51, 52, 63]
 ncase = 0
 while time.time() < t_end:
-    k = int(rng.choice([1, 2, 3, 5, 8, 11, 15, 16, 17, 21, 25, 31, 32, 33, 40, 63]))
+    k = int(rng.choice(KS))
     n = int(rng.integers(1, 9))
     amin = int(rng.choice([0, 1, 2, 3])); amax = int(rng.choice([999999999, 999999999, 50, 5]))
     simple = bool(rng.integers(0, 2)); cplx = bool(rng.integers(0, 2))
@@ -38,7 +39,7 @@ while time.time() < t_end:
     kw = {}
     if pb and k <= 31:
         kw["log2_partitions"] = min(pb, 2 * k)
-    shards = int(rng.choice([1, 1, 2, 3])) if (k <= 31 and n >= 2) else 1
+    shards = int(rng.choice([1, 1, 2, 3])) if n >= 2 else 1
     if shards > 1:
         # partition shards: every shard sees every read and keeps its level-1 buckets; integer accumulators and totals add up
         cplx = False

@@ -139,6 +139,7 @@ def load_library(build_if_missing=True):
         "simka_profile_nb_kernels": (i32, [vp]),
         "simka_profile_get": (i32, [vp, i32, C.POINTER(C.c_char_p), C.POINTER(u64), C.POINTER(C.c_double)]),
         "simka_get_geometry": (i32, [vp, C.POINTER(u32), C.POINTER(u32), C.POINTER(u32), C.POINTER(u64), C.POINTER(u64)]),
+        "simka_count_paths": (i32, [vp, C.POINTER(u64), C.POINTER(u64), C.POINTER(u64)]),
         "simka_synth_genomes": (i32, [vp, vp, u32, u64, u64]),
         "simka_synth_reads": (i32, [vp, vp, u64, u32, vp, u64, u64, vp, vp, u32, u64, u32]),
     }
@@ -571,6 +572,12 @@ class SimkaContext:
         self._check(self.lib.simka_get_geometry(self.h, C.byref(l1), C.byref(l2), C.byref(t), C.byref(a), C.byref(c)))
         return {"log2_level1": l1.value, "log2_level2": l2.value, "log2_subranges": t.value, "arena_capacity": a.value,
                 "csr_capacity": c.value}
+
+    def count_paths(self):
+        """How the samples counted so far were counted (simka_count_paths)."""
+        a, b, c = C.c_uint64(), C.c_uint64(), C.c_uint64()
+        self._check(self.lib.simka_count_paths(self.h, C.byref(a), C.byref(b), C.byref(c)))
+        return {"partitioned": a.value, "sorted": b.value, "exact_redone": c.value}
 
 
 # ---- host-side ingest (FASTA/FASTQ, plain or gz) for the Python entry points -------------------

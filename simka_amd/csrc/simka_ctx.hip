@@ -102,6 +102,11 @@ struct simka_ctx {
     ull *d_tm_ent = nullptr; double2 *d_tm_p = nullptr; uint32_t *d_tm_off = nullptr;
     uint64_t tm_ent_cap = 0, tm_p_cap = 0, tm_off_cap = 0;
     // -complex-dist: per-sample histogram of solid counts + list of the counts above the histogram
+    // 32 <= k <= 51: the samples are counted on the super-k-mer pipeline (k_skm_count_wide), their solid records sorted into the wide arena
+    bool wide_hash = false;
+    ull *d_wh_hi = nullptr, *d_wh_lo = nullptr, *d_wh_cursor = nullptr; uint32_t *d_wh_cnt = nullptr;
+    uint64_t wh_hi_cap = 0, wh_lo_cap = 0, wh_cnt_cap = 0;
+    uint64_t nb_wide_hash = 0, nb_wide_sort = 0;                // samples counted on either path (tests / -verbose)
     SimkaWide *wide = nullptr;                                  // 32 <= k <= 63 (or SIMKA_SORT_PATH): the sort-based path of simka_wide.hip
     ull *d_xoff = nullptr; uint64_t xoff_cap = 0;               // simka_gather_samples_device: destination offsets
     ull *d_hist = nullptr; uint32_t *d_ovf_list = nullptr; ull *d_ovf_cursor = nullptr; uint64_t ovf_cap = 0;
@@ -275,6 +280,8 @@ static int set_lds_attr(simka_ctx *ctx) {
     HIPCHK(hipFuncSetAttribute((const void *)k_skm_count, hipFuncAttributeMaxDynamicSharedMemorySize, big));
     HIPCHK(hipFuncSetAttribute((const void *)k_skm_split, hipFuncAttributeMaxDynamicSharedMemorySize, big));
     HIPCHK(hipFuncSetAttribute((const void *)k_skm_count_fast, hipFuncAttributeMaxDynamicSharedMemorySize, big));
+    HIPCHK(hipFuncSetAttribute((const void *)k_skm_count_wide, hipFuncAttributeMaxDynamicSharedMemorySize, big));
+    HIPCHK(hipFuncSetAttribute((const void *)k_skm_count_wide_fast, hipFuncAttributeMaxDynamicSharedMemorySize, big));
     return SIMKA_OK;
 }
 
@@ -308,7 +315,7 @@ static int setup_geometry(simka_ctx *ctx, uint64_t max_kmers) {
         sk.pb = k.pb;
         static const uint32_t l1_env = getenv("SIMKA_SKM_L1") ? (uint32_t)atoi(getenv("SIMKA_SKM_L1")) : 8u;      // experiments
         sk.l1 = std::min<uint32_t>(sk.pb, std::min<uint32_t>(l1_env, 8u));
-        sk.l2 = sk.pb - sk.l1; sk.l3 = 0;
+        sk.l2 = sk.pb - sk.l1;
         if (sk.l2 > 12) return ctx->fail(SIMKA_ERR_INVALID, "log2_partitions %u is beyond the two partitioning levels", sk.pb);
         ctx->B1 = 1u << sk.l1;
     }
@@ -429,6 +436,22 @@ SIMKA_EXPORT int simka_create(const simka_config *cfg, simka_ctx **out) {
         sk.mmask = (uint32_t)((1ull << (2 * sk.m)) - 1ull);
         sk.kmask = k.mask;
         sk.shard_index = cfg->shard_index; sk.shard_count = cfg->shard_count;
+    } else if (cfg->kmer_size >= 32 && cfg->kmer_size <= 51 && !getenv("SIMKA_SORT_PATH") && !getenv("SIMKA_WIDE_SORT")) {
+        // 32 <= k <= 51: a record (<= 51 bases) still holds a k-mer.  The minimizer is the smallest of W = 20 m-mers in the MIDDLE of
+        // the k-mer: m-mers d .. d + W - 1 with 2 d = k - (W + m - 1), so that a k-mer and its reverse complement look at the same
+        // m-mers (m is lowered by one where the parity demands it).
+        SimkaSkmCfg &sk = ctx->skm;
+        memset(&sk, 0, sizeof sk);
+        sk.k = cfg->kmer_size;
+        sk.W = 20;
+        sk.m = std::min<uint32_t>(16u, sk.k - 19u);
+        if ((sk.k - (sk.W + sk.m - 1u)) & 1u) sk.m--;
+        sk.d = (sk.k - (sk.W + sk.m - 1u)) / 2u;
+        sk.nmax = 52u - sk.k;
+        sk.mmask = (uint32_t)((1ull << (2 * sk.m)) - 1ull);
+        sk.kmask = ~0ull;
+        sk.shard_index = 0; sk.shard_count = 1;          // (shards keep k-mers, not partitions: k_skm_count_wide)
+        ctx->wide_hash = true;
     }
 
     const double tlds = wall_now();
@@ -474,7 +497,7 @@ SIMKA_EXPORT void simka_destroy(simka_ctx *ctx) {
         void *lp[] = { L.d_b1_count, L.d_b1_start, L.d_b1_end, L.d_b1_cursor, L.d_tile_r0, L.d_redo_list, L.d_redo_count,
                        L.d_skm_a, L.d_skm_b, L.d_skm_p, L.d_pstart, L.d_pcnt };
         for (void *q : lp) if (q) (void)hipFree(q);
-        if (L.stream) (void)hipStreamDestroy(L.stream);
+        if (L.stream && L.stream != ctx->stream) (void)hipStreamDestroy(L.stream);
     }
     for (auto &ev : ctx->events) { (void)hipEventDestroy(ev.a); (void)hipEventDestroy(ev.b); }
     for (hipEvent_t e : ctx->event_pool) (void)hipEventDestroy(e);
@@ -489,7 +512,7 @@ SIMKA_EXPORT void simka_destroy(simka_ctx *ctx) {
         (void)hipMemAddressFree(ctx->d_solid_keys, ctx->arena_reserved * 8); (void)hipMemAddressFree(ctx->d_solid_counts, ctx->arena_reserved * 4);
         ctx->d_solid_keys = nullptr; ctx->d_solid_counts = nullptr;
     }
-    void *ptrs[] = { ctx->d_l1_ovf, ctx->d_solid_keys, ctx->d_solid_counts, ctx->d_arena_cursor,
+    void *ptrs[] = { ctx->d_wh_hi, ctx->d_wh_lo, ctx->d_wh_cnt, ctx->d_wh_cursor, ctx->d_l1_ovf, ctx->d_solid_keys, ctx->d_solid_counts, ctx->d_arena_cursor,
                      ctx->d_sample_base, ctx->d_foff, ctx->d_fcnt, ctx->d_stats, ctx->d_err, ctx->d_part_total,
                      ctx->d_part_off, ctx->d_work, ctx->d_seg_abs, ctx->d_seg_rows, ctx->d_entries, ctx->d_groups,
                      ctx->d_spans, ctx->d_cursors, ctx->d_huge, ctx->d_xoff, ctx->d_hist, ctx->d_ovf_list, ctx->d_ovf_cursor,
@@ -596,28 +619,26 @@ static int arena_cursor_now(simka_ctx *ctx, ull *cur, hipStream_t st) {
 // ---- super-k-mer pipeline: enqueue the count-side kernels of one sample (see simka_skm.hip) ----------------------------------
 // exact=false: capacity-sized level-1 buckets; if one overflows the later kernels skip themselves and resolve_pending() redoes
 // the sample with exact=true (a histogram-only scan first).
-static int run_count_kernels(simka_ctx *ctx, uint32_t sample, const SimkaScanArgs &a_in, bool exact, uint32_t pass = 0, uint32_t npass = 1) {
-    const uint32_t N = ctx->cfg.nb_samples;
-    simka_ctx::Lane &L = ctx->lanes[sample % ctx->nlanes];
+// scan + split of one sample (or one pass over it) on lane L: the partitioned records end up in L.d_skm_b, described by L.d_pstart /
+// L.d_pcnt.  `sk` carries the partition geometry (and the pass's shard).  Returns the sample's k-mer bound in *kocc_up_out.
+static int skm_scan_split(simka_ctx *ctx, simka_ctx::Lane &L, uint32_t sample, const SimkaScanArgs &a_in, const SimkaSkmCfg &sk, bool exact, uint32_t pass,
+                          uint64_t *kocc_up_out) {
     const hipStream_t st = L.stream;
     int rc;
     SimkaScanArgs a = a_in;
     a.tile_r0 = nullptr;
-    SimkaSkmCfg sk = ctx->skm;
-    if (npass > 1) { sk.shard_index = ctx->skm.shard_index + ctx->skm.shard_count * pass; sk.shard_count = ctx->skm.shard_count * npass; }
     const uint32_t B1 = 1u << sk.l1;
     const uint32_t ntiles = (uint32_t)((a.nb_bases + SKM_STRIDE - 1) / SKM_STRIDE);
     if (!a.fixed_len && a.nb_reads && ntiles) {
         rc = ensure_cap(ctx, &L.d_tile_r0, &L.tile_r0_cap, (uint64_t)ntiles + 2); if (rc) return rc;
-        hipLaunchKernelGGL(k_tile_reads, dim3((ntiles + 1 + 255) / 256), dim3(256), 0, st, a.offsets, a.nb_reads, a.nb_bases, ntiles, (uint64_t)SKM_STRIDE, L.d_tile_r0);
+        hipLaunchKernelGGL(k_tile_reads, dim3((ntiles + 1 + 255) / 256), dim3(256), 0, st, a.offsets, a.nb_reads, a.nb_bases, ntiles, (uint64_t)SKM_STRIDE, (uint64_t)(sk.d ? sk.d + 1u : 0u), L.d_tile_r0);
         a.tile_r0 = L.d_tile_r0;
     }
     uint32_t *flag = ctx->d_l1_ovf + sample;
-    static const bool force_exact = getenv("SIMKA_EXACT_SIZING") != nullptr;
-    if (force_exact) exact = true;
     const uint64_t kocc_up = a.fixed_len ? (a.fixed_len >= sk.k ? a.nb_reads * (uint64_t)(a.fixed_len - sk.k + 1) : 0) : a.nb_bases;
+    *kocc_up_out = kocc_up;
     // records staged per tile: what a tile yields at the expected run length (W + 1) / 2, + 35 %
-    const uint32_t caprec = (uint32_t)std::min<uint64_t>(4096, std::max<uint64_t>(1280, (uint64_t)(SKM_STRIDE / ((sk.W + 1) / 2.0) * 1.35) / 128 * 128 + 128));
+    const uint32_t caprec = (uint32_t)std::min<uint64_t>(4096, std::max<uint64_t>(1280, (uint64_t)(SKM_STRIDE / (std::min<double>((sk.W + 1) / 2.0, sk.nmax)) * 1.35) / 128 * 128 + 128));
     const int wi = skm_w_index(sk.W);
     const bool fixed = a.fixed_len != 0;
     // LDS region R of the scan kernel: the m-mer hashes first, then staged records + the list of run starts (6 bytes each, as many
@@ -635,16 +656,15 @@ static int run_count_kernels(simka_ctx *ctx, uint32_t sample, const SimkaScanArg
     };
     auto scan = [&](bool hist, const ull *limit) {
         launch_timed(ctx, hist ? KID_SCAN_HIST : KID_SKM_SCAN, [&] {
-            SimkaSkmCfg skc = sk;
-            skc.nmax = sk.nmax; skc.pb = sk.pb;
-            hipLaunchKernelGGL(skm_scan_kernel(wi, fixed, hist), dim3(ntiles), dim3(SKM_BLOCK), scan_lds(hist), st, a, skc, L.d_b1_count, L.d_b1_cursor, L.d_skm_a, limit,
+            hipLaunchKernelGGL(skm_scan_kernel(wi, fixed, hist), dim3(ntiles), dim3(SKM_BLOCK), scan_lds(hist), st, a, sk, L.d_b1_count, L.d_b1_cursor, L.d_skm_a, limit,
                                hist ? (uint32_t *)nullptr : flag, caprec, rbytes, scan_lcap(hist), L.d_skm_p);
         }, st);
     };
     uint64_t rec_cap;
     if (!exact) {
-        // expected records: one per (W + 1) / 2 k-mers; a bucket gets its share + 12 % + slack.  An overflow flags the sample.
-        const uint64_t est = (uint64_t)((double)kocc_up / std::max(1.0, (sk.W + 1) / 2.0) * 1.30 / sk.shard_count);
+        // expected records: one per (W + 1) / 2 k-mers (or per nmax, if a record takes fewer); a bucket gets its share + 12 % + slack.
+        // An overflow flags the sample.
+        const uint64_t est = (uint64_t)((double)kocc_up / std::max(1.0, std::min<double>((sk.W + 1) / 2.0, sk.nmax)) * 1.30 / sk.shard_count);
         const uint64_t capb = est / B1 + est / B1 / 8 + 4096;
         rec_cap = capb * B1;
         rc = ensure_cap(ctx, &L.d_skm_a, &L.skm_a_cap, rec_cap); if (rc) return rc;
@@ -653,8 +673,6 @@ static int run_count_kernels(simka_ctx *ctx, uint32_t sample, const SimkaScanArg
         layout(1, capb);
         scan(false, (const ull *)L.d_b1_end);
         layout(2, capb);
-        simka_ctx::Pending p; p.sample = sample; p.a = a_in; p.pass = pass; p.npass = npass;
-        ctx->pending.push_back(p);
     } else {
         HIPCHK(hipMemsetAsync(L.d_b1_count, 0, (size_t)(B1 + 1) * 8, st));
         scan(true, nullptr);
@@ -682,6 +700,27 @@ static int run_count_kernels(simka_ctx *ctx, uint32_t sample, const SimkaScanArg
         hipLaunchKernelGGL(k_skm_split, dim3(B1), dim3(SKM_SPLIT_BLOCK), lds_split, st, (const uint4 *)L.d_skm_a, (const uint32_t *)L.d_skm_p, (const ull *)L.d_b1_start, (const ull *)L.d_b1_count, sk,
                            L.d_skm_b, L.d_pstart, L.d_pcnt, (const uint32_t *)flag);
     }, st);
+    HIPCHK(hipGetLastError());
+    return SIMKA_OK;
+}
+
+static int run_count_kernels(simka_ctx *ctx, uint32_t sample, const SimkaScanArgs &a_in, bool exact, uint32_t pass = 0, uint32_t npass = 1) {
+    const uint32_t N = ctx->cfg.nb_samples;
+    simka_ctx::Lane &L = ctx->lanes[sample % ctx->nlanes];
+    const hipStream_t st = L.stream;
+    int rc;
+    const SimkaScanArgs &a = a_in;
+    SimkaSkmCfg sk = ctx->skm;
+    if (npass > 1) { sk.shard_index = ctx->skm.shard_index + ctx->skm.shard_count * pass; sk.shard_count = ctx->skm.shard_count * npass; }
+    uint32_t *flag = ctx->d_l1_ovf + sample;
+    static const bool force_exact = getenv("SIMKA_EXACT_SIZING") != nullptr;
+    if (force_exact) exact = true;
+    uint64_t kocc_up = 0;
+    rc = skm_scan_split(ctx, L, sample, a_in, sk, exact, pass, &kocc_up); if (rc) return rc;
+    if (!exact) {
+        simka_ctx::Pending p; p.sample = sample; p.a = a_in; p.pass = pass; p.npass = npass;
+        ctx->pending.push_back(p);
+    }
     if (ctx->arena_accounted.size() != N) ctx->arena_accounted.assign(N, 0);
     if (ctx->arena_vmm && !ctx->arena_accounted[sample]) {
         ctx->arena_accounted[sample] = 1;
@@ -788,6 +827,99 @@ static int wide_fail(simka_ctx *ctx, int wrc) {
     return ctx->fail(rc, "%s", simka_wide_error(ctx->wide));
 }
 
+// 32 <= k <= 51: scan + split + k_skm_count_wide on lane 0, the solid records sorted into the wide arena.  *done = false: the sample
+// does not fit this path (a partition beyond the LDS table, output arrays too small) -- nothing was kept, the caller sorts instead.
+static int wide_hash_count(simka_ctx *ctx, uint32_t sample, const void *d_packed, const void *d_offsets, const simka_reads *r, unsigned long long tot[SIMKA_NB_TOTALS], bool *done) {
+    *done = false;
+    const uint32_t N = ctx->cfg.nb_samples;
+    simka_ctx::Lane &L = ctx->lanes[0];
+    if (!L.stream) L.stream = ctx->stream;            // (the wide path is synchronous: everything on the context's stream)
+    const hipStream_t st = L.stream;
+    int rc;
+    SimkaScanArgs a;
+    a.nb_bases = r->nb_bases; a.nb_words = (r->nb_bases + 31) / 32; a.nb_reads = r->nb_reads; a.fixed_len = r->fixed_len;
+    a.packed = (const uint64_t *)d_packed; a.offsets = (const uint64_t *)d_offsets; a.tile_r0 = nullptr;
+    SimkaSkmCfg sk = ctx->skm;
+    const uint64_t kocc_b = a.fixed_len ? (a.fixed_len >= sk.k ? a.nb_reads * (uint64_t)(a.fixed_len - sk.k + 1) : 0) : a.nb_bases;
+    if (kocc_b == 0) { *done = true; for (int i = 0; i < SIMKA_NB_TOTALS; i++) tot[i] = 0; return simka_wide_adopt(ctx->wide, sample, nullptr, nullptr, nullptr, 0, 0) ? wide_fail(ctx, 1) : SIMKA_OK; }
+    // the partition count is the sample's own (the arena holds spectra, not partitions): ~100-190 k-mer occurrences per
+    // partition, three eighths of a wave's table (k_skm_count_wide_fast) even if all of them are distinct
+    const uint32_t per_part = getenv("SIMKA_WIDE_PER_PART") ? (uint32_t)std::max(1, atoi(getenv("SIMKA_WIDE_PER_PART"))) : 192u;      // (tests: partitions beyond the tables)
+    sk.pb = std::min<uint32_t>(20u, ceil_log2_u64((kocc_b + per_part - 1) / per_part));
+    sk.l1 = std::min<uint32_t>(sk.pb, 8u); sk.l2 = sk.pb - sk.l1;
+    const uint32_t B1 = 1u << sk.l1;
+    const uint64_t nparts = (uint64_t)1 << sk.pb;
+    if (!L.d_b1_count) {
+        HIPCHK(dev_alloc(&L.d_b1_count, SKM_MAXB1 + 1)); HIPCHK(dev_alloc(&L.d_b1_start, SKM_MAXB1 + 1)); HIPCHK(dev_alloc(&L.d_b1_end, SKM_MAXB1 + 1));
+        HIPCHK(dev_alloc(&L.d_b1_cursor, (uint64_t)(SKM_MAXB1 + 1) * SKM_CSTRIDE));
+        HIPCHK(dev_alloc(&L.d_redo_count, 2)); HIPCHK(dev_alloc(&L.d_redo_list, ((uint64_t)1 << 20) + 1));
+        HIPCHK(dev_alloc(&L.d_pstart, ((uint64_t)1 << 20) + 1)); HIPCHK(dev_alloc(&L.d_pcnt, ((uint64_t)1 << 20) + 1));
+        HIPCHK(dev_alloc(&ctx->d_l1_ovf, N + 1));
+        HIPCHK(hipMemsetAsync(ctx->d_l1_ovf, 0, (size_t)(N + 1) * 4, st));
+        HIPCHK(dev_alloc(&ctx->d_wh_cursor, 8));
+    }
+    (void)B1;
+    // capacity-sized buckets first; an overflow (the later kernels skipped themselves) is redone with exact sizes
+    uint64_t kocc_up = 0;
+    // (every solid k-mer has >= abundance_min occurrences; + the unused ends of the waves' slabs)
+    const uint64_t solid_up = kocc_b / std::max<uint32_t>(1u, ctx->cfg.abundance_min);
+    const uint64_t out_cap = solid_up + solid_up / 8 + (uint64_t)ctx->num_cus * 16 * SKM_WF_SLAB + 16;
+    rc = ensure_cap(ctx, &ctx->d_wh_hi, &ctx->wh_hi_cap, out_cap); if (rc) return rc;
+    rc = ensure_cap(ctx, &ctx->d_wh_lo, &ctx->wh_lo_cap, out_cap); if (rc) return rc;
+    rc = ensure_cap(ctx, &ctx->d_wh_cnt, &ctx->wh_cnt_cap, out_cap); if (rc) return rc;
+    static const bool force_exact = getenv("SIMKA_EXACT_SIZING") != nullptr;
+    ull ovf_before[2] = { 0, 0 };
+    if (ctx->d_ovf_cursor) { HIPCHK(hipMemcpyAsync(ovf_before, ctx->d_ovf_cursor, 16, hipMemcpyDeviceToHost, st)); HIPCHK(hipStreamSynchronize(st)); }
+    for (int attempt = force_exact ? 1 : 0; attempt < 2; attempt++) {
+        HIPCHK(hipMemsetAsync(ctx->d_wh_cursor, 0, 64, st));
+        rc = skm_scan_split(ctx, L, sample, a, sk, attempt == 1, 0, &kocc_up); if (rc) return rc;
+        SimkaWideOut wo;
+        wo.hi = ctx->d_wh_hi; wo.lo = ctx->d_wh_lo; wo.cnt = ctx->d_wh_cnt; wo.cursor = ctx->d_wh_cursor; wo.cap = out_cap;
+        wo.shard_index = ctx->cfg.shard_index; wo.shard_count = ctx->cfg.shard_count;
+        SimkaCountOut o;
+        memset(&o, 0, sizeof o);
+        o.sample = sample; o.nb_samples = N; o.err = ctx->d_err;
+        o.hist = ctx->d_hist; o.ovf_list = ctx->d_ovf_list; o.ovf_cursor = ctx->d_ovf_cursor; o.ovf_cap = ctx->ovf_cap;
+        const size_t hist_lds = ctx->d_hist ? (size_t)SIMKA_HIST_MAX * 4 : 0;
+        const size_t lds_wide = (size_t)SIMKA_LDS_HEAD + (size_t)SKM_WIDE_TS * 20 + (size_t)SKM_CNT_BATCH * 16 + (size_t)SKM_CNT_BLOCK * 4 + hist_lds + (size_t)SKM_CNT_BATCH * sk.nmax * 2 + 64;
+        const bool general_only = getenv("SIMKA_SKM_GENERAL") != nullptr;      // tests: every partition through the block kernel
+        if (!general_only)
+            launch_timed(ctx, KID_SKM_COUNT, [&] {
+                const size_t lds_wf = (size_t)SIMKA_LDS_HEAD + hist_lds + (size_t)(SKM_WF_BLOCK / 64) * skm_wf_wave_bytes(sk.nmax);
+                const uint32_t bpc = (uint32_t)std::max<size_t>(1, std::min<size_t>(4, (160 * 1024) / lds_wf));
+                hipLaunchKernelGGL(k_skm_count_wide_fast, dim3((uint32_t)std::min<uint64_t>((nparts + 3) / 4, (uint64_t)ctx->num_cus * bpc)), dim3(SKM_WF_BLOCK), lds_wf, st, (const uint4 *)L.d_skm_b,
+                                   (const uint32_t *)L.d_pstart, (const uint32_t *)L.d_pcnt, sk, ctx->cfg.abundance_min, ctx->cfg.abundance_max, wo, o, (const uint32_t *)(ctx->d_l1_ovf + sample),
+                                   L.d_redo_list, L.d_redo_count);
+            }, st);
+        launch_timed(ctx, KID_COUNT, [&] {
+            hipLaunchKernelGGL(k_skm_count_wide, dim3((uint32_t)std::min<uint64_t>(nparts, (uint64_t)ctx->num_cus)), dim3(SKM_CNT_BLOCK), lds_wide, st, (const uint4 *)L.d_skm_b,
+                               (const uint32_t *)L.d_pstart, (const uint32_t *)L.d_pcnt, sk, ctx->cfg.abundance_min, ctx->cfg.abundance_max, wo, o, (const uint32_t *)(ctx->d_l1_ovf + sample),
+                               general_only ? (const uint32_t *)nullptr : (const uint32_t *)L.d_redo_list, general_only ? (const ull *)nullptr : (const ull *)L.d_redo_count);
+        }, st);
+        uint32_t flag = 0;
+        HIPCHK(hipMemcpyAsync(&flag, ctx->d_l1_ovf + sample, 4, hipMemcpyDeviceToHost, st));
+        HIPCHK(hipStreamSynchronize(st));
+        if (!flag) break;
+        if (attempt == 1) return ctx->fail(SIMKA_ERR_OVERFLOW, "the exactly sized level-1 buckets of sample %u overflowed", sample);
+        ctx->nb_exact_fallbacks++;
+        HIPCHK(hipMemsetAsync(ctx->d_l1_ovf + sample, 0, 4, st));
+    }
+    ull cur[8];
+    HIPCHK(hipMemcpyAsync(cur, ctx->d_wh_cursor, 64, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    if (cur[6]) {      // nothing was kept; the abundance histogram of -complex-dist was touched: as before, for the sort path
+        if (ctx->d_hist) HIPCHK(hipMemsetAsync(ctx->d_hist + (uint64_t)sample * SIMKA_HIST_MAX, 0, (size_t)SIMKA_HIST_MAX * 8, st));
+        if (ctx->d_ovf_cursor) HIPCHK(hipMemcpyAsync(ctx->d_ovf_cursor, ovf_before, 16, hipMemcpyHostToDevice, st));
+        HIPCHK(hipStreamSynchronize(st));
+        return SIMKA_OK;
+    }
+    tot[SIMKA_TOT_DALL] = cur[1]; tot[SIMKA_TOT_D] = cur[2]; tot[SIMKA_TOT_N] = cur[3]; tot[SIMKA_TOT_Q] = cur[4]; tot[SIMKA_TOT_KOCC] = cur[5];
+    const int wrc = simka_wide_adopt(ctx->wide, sample, ctx->d_wh_hi, ctx->d_wh_lo, ctx->d_wh_cnt, cur[0], cur[2]);
+    if (wrc) return wide_fail(ctx, wrc);
+    *done = true;
+    return SIMKA_OK;
+}
+
 static int wide_count_sample(simka_ctx *ctx, uint32_t sample, const simka_reads *r) {
     const uint32_t N = ctx->cfg.nb_samples, fl = ctx->cfg.dist_flags;
     ctx->nb_reads[sample] = r->nb_input_reads ? r->nb_input_reads : r->nb_reads;
@@ -807,7 +939,10 @@ static int wide_count_sample(simka_ctx *ctx, uint32_t sample, const simka_reads 
         }
     }
     unsigned long long tot[SIMKA_NB_TOTALS];
-    const int wrc = simka_wide_count_sample(ctx->wide, sample, d_packed, r->nb_bases, nb_words, d_offsets, r->nb_reads, r->fixed_len, ctx->cfg.abundance_min,
+    bool hashed = false;
+    if (ctx->wide_hash) { rc = wide_hash_count(ctx, sample, d_packed, d_offsets, r, tot, &hashed); if (rc) return rc; }
+    (hashed ? ctx->nb_wide_hash : ctx->nb_wide_sort)++;
+    const int wrc = hashed ? 0 : simka_wide_count_sample(ctx->wide, sample, d_packed, r->nb_bases, nb_words, d_offsets, r->nb_reads, r->fixed_len, ctx->cfg.abundance_min,
                                             ctx->cfg.abundance_max, tot, ctx->d_hist ? (void *)(ctx->d_hist + (uint64_t)sample * SIMKA_HIST_MAX) : nullptr,
                                             ctx->d_ovf_list, ctx->d_ovf_cursor, ctx->ovf_cap);
     if (wrc) return wide_fail(ctx, wrc);
@@ -2046,6 +2181,14 @@ SIMKA_EXPORT int simka_get_geometry(simka_ctx *ctx, uint32_t *l1, uint32_t *l2, 
     if (!ctx) return SIMKA_ERR_INVALID;
     if (l1) *l1 = ctx->wide ? ctx->key.l1 : ctx->skm.l1; if (l2) *l2 = ctx->wide ? ctx->key.l2 : ctx->skm.l2; if (t) *t = ctx->key.t;
     if (arena) *arena = ctx->arena_cap; if (csr) *csr = ctx->merge_cap;
+    return SIMKA_OK;
+}
+
+SIMKA_EXPORT int simka_count_paths(simka_ctx *ctx, uint64_t *nb_partitioned, uint64_t *nb_sorted, uint64_t *nb_exact_redone) {
+    if (!ctx) return SIMKA_ERR_INVALID;
+    if (nb_partitioned) *nb_partitioned = ctx->wide ? ctx->nb_wide_hash : ctx->nb_counted_this_run;
+    if (nb_sorted) *nb_sorted = ctx->nb_wide_sort;
+    if (nb_exact_redone) *nb_exact_redone = ctx->nb_exact_fallbacks;
     return SIMKA_OK;
 }
 

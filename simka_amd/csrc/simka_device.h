@@ -70,3 +70,11 @@ SIMKA_HD uint64_t simka_rng(uint64_t key, uint64_t ctr) {
     z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
     return z ^ (z >> 31);
 }
+
+// partition shards for 32 <= k <= 63: a canonical k-mer (hi, lo) belongs to shard  mix(hi, lo) * G >> 32  (every context of a sharded
+// run scans all reads and keeps its own k-mers)
+SIMKA_HD bool simka_wide_owns(unsigned long long hi, unsigned long long lo, uint32_t shard_index, uint32_t shard_count) {
+    unsigned long long x = lo ^ (hi * 0x9E3779B97F4A7C15ull);
+    x ^= x >> 29; x *= 0xBF58476D1CE4E5B9ull; x ^= x >> 32;
+    return (uint32_t)(((x >> 32) * (unsigned long long)shard_count) >> 32) == shard_index;
+}

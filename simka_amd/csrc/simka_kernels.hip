@@ -80,13 +80,14 @@ __device__ __forceinline__ uint32_t block_excl_scan(uint32_t *a, uint32_t n, uin
     return total;
 }
 
-// k_tile_reads: variable-length reads.  tile_r0[b] = index of the read that holds base b * tile (largest r with
-// offsets[r] <= b * tile), one thread per tile; k_skm_scan stages the read starts of its tile in LDS from it.
+// k_tile_reads: variable-length reads.  tile_r0[b] = index of the read that holds base b * tile - back (largest r with
+// offsets[r] <= that), one thread per tile; k_skm_scan stages the read starts of its tile in LDS from it.  back: how far before
+// its first window a tile's first k-mer starts (k >= 36: the minimizer window sits in the middle of the k-mer).
 __global__ void __launch_bounds__(256)
-k_tile_reads(const uint64_t *offsets, uint64_t nb_reads, uint64_t nb_bases, uint32_t ntiles, uint64_t tile, uint32_t *tile_r0) {
+k_tile_reads(const uint64_t *offsets, uint64_t nb_reads, uint64_t nb_bases, uint32_t ntiles, uint64_t tile, uint64_t back, uint32_t *tile_r0) {
     const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b > ntiles) return;
-    const uint64_t pos = (uint64_t)b * tile;
+    const uint64_t pos = (uint64_t)b * tile > back ? (uint64_t)b * tile - back : 0ull;
     uint64_t lo = 0, hi = nb_reads;
     if (pos >= nb_bases) { tile_r0[b] = (uint32_t)(nb_reads ? nb_reads - 1 : 0); return; }
     while (hi - lo > 1) { const uint64_t mid = (lo + hi) >> 1; if (offsets[mid] <= pos) lo = mid; else hi = mid; }

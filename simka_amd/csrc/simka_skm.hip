@@ -65,7 +65,9 @@ typedef unsigned long long ull;
 struct SimkaSkmCfg {
     uint32_t k, W, m, nmax;          // k-mer size, m-mers per k-mer (k - m + 1), minimizer size, k-mers per record at most
     uint32_t mmask;                  // 2^(2m) - 1
-    uint32_t pb, l1, l2, l3;         // log2 #partitions = l1 + l2 + l3
+    uint32_t pb, l1, l2, d;          // log2 #partitions = l1 + l2;  d: the minimizer window of the k-mer that starts at base p covers the
+                                     // m-mers at p + d .. p + d + W - 1 (k <= 31: d = 0; k >= 36: the window is CENTRED in the k-mer, so that a
+                                     // k-mer and its reverse complement see the same m-mers)
     uint32_t shard_index, shard_count;   // this context keeps the partitions p with p % shard_count == shard_index
     uint64_t kmask;                  // 2^(2k) - 1
 };
@@ -212,14 +214,15 @@ k_skm_scan(SimkaScanArgs a, SimkaSkmCfg cfg, ull *b1_count, ull *b1_cursor, uint
     // ---- validity of the k-mers at e_0 .. e_16: start inside the data, end inside their read
     uint32_t valid = 0;
     {
-        const long long P0 = Q0 + (long long)(SKM_SEG * tid) - 1;           // position of e_0
+        const long long Qk = Q0 - (long long)cfg.d;                          // where the k-mer of entry 0 starts (its window starts d bases in)
+        const long long P0 = Qk + (long long)(SKM_SEG * tid) - 1;           // start of the k-mer of e_0
         const uint32_t k = cfg.k;
         if (FIXED) {
             const uint32_t L = a.fixed_len;
             // offset of e_0 inside its read: the tile's first position modulo L is wave-uniform (one 64-bit modulo on the scalar unit),
             // the thread's share 16 tid - 1 + L (< 2^14 + 2 L) is reduced with a float reciprocal and 24-bit multiplies -- a 64-bit modulo
             // per thread cost a dozen quarter-rate multiplies in a VALU-bound kernel
-            const uint32_t relb = (uint32_t)__builtin_amdgcn_readfirstlane((int)(Q0 >= 0 ? (uint32_t)((uint64_t)Q0 % L) : (L - (uint32_t)((uint64_t)(-Q0) % L)) % L));
+            const uint32_t relb = (uint32_t)__builtin_amdgcn_readfirstlane((int)(Qk >= 0 ? (uint32_t)((uint64_t)Qk % L) : (L - (uint32_t)((uint64_t)(-Qk) % L)) % L));
             uint32_t rel;
             if (L < (1u << 23)) {
                 const uint32_t x = relb + SKM_SEG * tid + (L - 1u);                 // Q0 % L + 16 tid - 1 + L  >= 0, < 2 L + 2^13
@@ -237,7 +240,7 @@ k_skm_scan(SimkaScanArgs a, SimkaSkmCfg cfg, ull *b1_count, ull *b1_cursor, uint
                 const uint32_t bad = lo < hi ? (((1u << hi) - 1u) & ~((1u << lo) - 1u)) : 0u;
                 valid = ((1u << (SKM_SEG + 1)) - 1u) & ~bad;
                 // the ends of the data (first and last tile only: wave-uniform test)
-                if (Q0 < 0 || (uint64_t)(Q0 + SKM_TILE + 64) > a.nb_bases) {
+                if (Qk < 0 || (uint64_t)(Qk + SKM_TILE + 64) > a.nb_bases) {
                     const long long l2 = P0 < 0 ? -P0 : 0ll, h2 = (long long)a.nb_bases - P0;
                     const uint32_t lo2 = l2 > SKM_SEG + 1 ? (uint32_t)(SKM_SEG + 1) : (uint32_t)l2, hi2 = h2 < 0 ? 0u : (h2 > SKM_SEG + 1 ? (uint32_t)(SKM_SEG + 1) : (uint32_t)h2);
                     valid &= lo2 < hi2 ? (((1u << hi2) - 1u) & ~((1u << lo2) - 1u)) : 0u;
@@ -256,7 +259,8 @@ k_skm_scan(SimkaScanArgs a, SimkaSkmCfg cfg, ull *b1_count, ull *b1_cursor, uint
             const uint64_t w0 = P0 < 0 ? 0ull : (uint64_t)P0;
             uint64_t rd = 0, next;
             uint32_t ti = 0;
-            if (ntab) {
+            const bool tab = ntab && w0 >= T0;          // (d > 0: a k-mer may start before the tile's first base)
+            if (tab) {
                 const uint32_t w0rel = (uint32_t)(w0 - T0);
                 uint32_t lo = 0, hi = ntab;          // smallest i with rtab[i] > w0rel
                 while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (rtab[mid] > w0rel) hi = mid; else lo = mid + 1; }
@@ -273,7 +277,7 @@ k_skm_scan(SimkaScanArgs a, SimkaSkmCfg cfg, ull *b1_count, ull *b1_cursor, uint
                 const long long P = P0 + j;
                 if (P >= 0 && (uint64_t)P < a.nb_bases) {
                     while (next <= (uint64_t)P) {            // e_j starts a later read (empty reads: several steps)
-                        if (ntab) { ti++; next = ti < ntab ? T0 + rtab[ti] : a.nb_bases; }
+                        if (tab) { ti++; next = ti < ntab ? T0 + rtab[ti] : a.nb_bases; }
                         else { rd++; next = rd + 1 <= a.nb_reads ? a.offsets[rd + 1] : a.nb_bases; }
                         if (next >= a.nb_bases) break;
                     }
@@ -389,7 +393,8 @@ k_skm_scan(SimkaScanArgs a, SimkaSkmCfg cfg, ull *b1_count, ull *b1_cursor, uint
     }
     __syncthreads();
     // cut one record out of the LDS-staged tile
-    auto cut = [&](uint32_t e, uint32_t n, uint32_t pid) {
+    auto cut = [&](uint32_t e_, uint32_t n, uint32_t pid) {
+        const uint32_t e = e_ - cfg.d;               // the run's first k-mer starts d bases before its window
         const uint32_t wi = e >> 4, sh = (e & 15u) * 2u;
         const uint32_t c0 = tb[wi], c1 = tb[wi + 1], c2 = tb[wi + 2], c3 = tb[wi + 3], c4 = tb[wi + 4];
         uint4 rec;
@@ -796,6 +801,351 @@ k_skm_count(const uint4 *recs, const uint32_t *pstart, const uint32_t *pcnt, Sim
     }
 }
 
+
+// --------------------------------------------------------------------------------------------
+// k_skm_count_wide: 32 <= k <= 51 -- the canonical k-mer is a pair of 64-bit words (hi, lo), counted per minimizer partition in an
+// LDS hash table like k_skm_count, instead of sorting every k-mer occurrence of the sample (simka_wide.hip, which stays for k > 51
+// and as the cross-check).  There is no 128-bit LDS atomic: a slot is CLAIMED with a 64-bit CAS on the high word (never all ones:
+// it has at most 38 bits), the claimant then stores the low word and bumps the counter; a k-mer that finds its high word in a slot
+// compares the low word once the counter says it is there (the LDS serves a wave's operations in order: counter > 0 implies the low
+// word is written).  Within a wave the claimants' stores are issued before any lane looks, so no lane waits for a lane of its own wave.
+// The solid records of the sample leave unordered, (hi, lo, count) into three arrays behind a global cursor; the host sorts them
+// by k-mer into the sorted spectrum the wide merge works on.  A partition that fills the table flags the sample (the caller then
+// counts it on the sort path).
+// --------------------------------------------------------------------------------------------
+struct SimkaWideOut {
+    ull *hi, *lo; uint32_t *cnt;     // the sample's solid records
+    ull *cursor;                     // [0] records written, [1] D_all, [2] D, [3] N, [4] Q, [5] K_occ, [6] flags: 1 = a table overflowed, 2 = the arrays are full
+    ull cap;
+    uint32_t shard_index, shard_count;   // the k-mers this context keeps (simka_wide_owns; the scan keeps every partition)
+};
+#define SKM_WIDE_TS 4096
+#define SKM_WIDE_TSL 12
+
+__device__ __forceinline__ void skm_wkmer_at(const uint4 &r, uint32_t j, uint32_t k, ull &hi, ull &lo) {
+    const uint32_t s = 2u * j, wd = s >> 5, sh = s & 31u;         // j <= 19: wd is 0 or 1
+    const uint32_t w3 = r.w & 63u;
+    const uint32_t a0 = wd ? r.y : r.x, a1 = wd ? r.z : r.y, a2 = wd ? w3 : r.z, a3 = wd ? 0u : w3;
+    const uint32_t o0 = __builtin_amdgcn_alignbit(a1, a0, sh), o1 = __builtin_amdgcn_alignbit(a2, a1, sh), o2 = __builtin_amdgcn_alignbit(a3, a2, sh), o3 = a3 >> sh;
+    lo = ((ull)o1 << 32) | o0;
+    hi = (((ull)o3 << 32) | o2) & ((2u * k > 64u) ? ((1ull << (2u * k - 64u)) - 1ull) : 0ull);
+}
+
+__global__ void __launch_bounds__(SKM_CNT_BLOCK)
+k_skm_count_wide(const uint4 *recs, const uint32_t *pstart, const uint32_t *pcnt, SimkaSkmCfg cfg, uint32_t amin, uint32_t amax, SimkaWideOut wo, SimkaCountOut o,
+                 const uint32_t *flag, const uint32_t *redo_list, const ull *redo_count) {
+    if (*flag) return;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    ull *s_tot = (ull *)smem;                          // [5] D_all, D, N, Q, K_occ of the whole block
+    ull &s_base = *(ull *)(smem + 48);
+    uint32_t &s_kt = *(uint32_t *)(smem + 72);
+    uint32_t &s_fail = *(uint32_t *)(smem + 76);
+    uint32_t *tmp = (uint32_t *)(smem + 128);          // [BLOCK/64]
+    constexpr uint32_t TS = SKM_WIDE_TS, SPT = TS / SKM_CNT_BLOCK, TSL = SKM_WIDE_TSL;
+    ull *thi = (ull *)(smem + SIMKA_LDS_HEAD);         // [TS] high words: the claim (SIMKA_EMPTY_KEY: free)
+    ull *tlo = thi + TS;                               // [TS] low words
+    uint32_t *tcnt = (uint32_t *)(tlo + TS);           // [TS]
+    uint4 *lrec = (uint4 *)(tcnt + TS);                // [BATCH]
+    uint32_t *spos = (uint32_t *)(lrec + SKM_CNT_BATCH);     // [BLOCK]
+    uint32_t *lhist = spos + SKM_CNT_BLOCK;            // [SIMKA_HIST_MAX] (complex only)
+    uint16_t *map = (uint16_t *)(lhist + (o.hist ? SIMKA_HIST_MAX : 0));     // [BATCH * nmax]
+
+    const uint32_t tid = threadIdx.x, lane = tid & 63u;
+    const uint32_t nparts = redo_list ? (uint32_t)*redo_count : 1u << cfg.pb;      // with a list: the partitions k_skm_count_wide_fast gave up on
+    const uint32_t k = cfg.k, s2 = 128u - 2u * k;      // 26 .. 64
+    for (uint32_t i = tid; i < TS; i += SKM_CNT_BLOCK) { thi[i] = SIMKA_EMPTY_KEY; tcnt[i] = 0; }
+    if (o.hist) for (uint32_t i = tid; i < SIMKA_HIST_MAX; i += SKM_CNT_BLOCK) lhist[i] = 0;
+    if (tid < 5) s_tot[tid] = 0;
+    if (tid == 0) s_fail = 0;
+    ull bt_dall = 0, bt_D = 0, bt_N = 0, bt_Q = 0, bt_kocc = 0;
+    __syncthreads();
+    for (uint32_t pi = blockIdx.x; pi < nparts; pi += gridDim.x) {
+        const uint32_t part = redo_list ? redo_list[pi] : pi;
+        const uint32_t nrec = pcnt[part];
+        if (nrec == 0) continue;
+        const uint32_t rbase = pstart[part];
+        for (uint32_t b0 = 0; b0 < nrec; b0 += SKM_CNT_BATCH) {
+            __syncthreads();
+            if (tid == 0) s_kt = 0;
+            __syncthreads();
+            const uint32_t nb = nrec - b0 < (uint32_t)SKM_CNT_BATCH ? nrec - b0 : (uint32_t)SKM_CNT_BATCH;
+            uint32_t len = 0;
+            if (tid < nb) { const uint4 rc = recs[rbase + b0 + tid]; lrec[tid] = rc; len = skm_rec_n(rc); }
+            uint32_t x = len;
+#pragma unroll
+            for (int o_ = 1; o_ < 64; o_ <<= 1) { const uint32_t t = __shfl_up(x, o_, 64); if (lane >= (uint32_t)o_) x += t; }
+            uint32_t wbase_ = 0;
+            if (lane == 63u) wbase_ = atomicAdd(&s_kt, x);
+            wbase_ = __shfl(wbase_, 63, 64);
+            const uint32_t off = wbase_ + x - len;
+            for (uint32_t j = 0; j < len; j++) map[off + j] = (uint16_t)((tid << 5) | j);
+            __syncthreads();
+            const uint32_t kt = s_kt;
+            for (uint32_t f0 = 0; f0 < kt; f0 += SKM_CNT_BLOCK) {
+                const uint32_t f = f0 + tid;
+                bool pending = f < kt;
+                ull hi = 0, lo = 0;
+                uint32_t slot = 0;
+                if (pending) {
+                    const uint32_t e = map[f];
+                    ull fh, fl;
+                    skm_wkmer_at(lrec[e >> 5], e & 31u, k, fh, fl);
+                    // reverse complement of the 2k-bit value: the 128-bit reversal, moved down by 128 - 2k bits
+                    const ull rh_ = skm_revcomp64(fl), rl_ = skm_revcomp64(fh);
+                    ull rl, rh;
+                    if (s2 >= 64u) { rl = rh_; rh = 0; } else { rl = (rl_ >> s2) | (rh_ << (64u - s2)); rh = rh_ >> s2; }
+                    const bool fsm = fh < rh || (fh == rh && fl < rl);
+                    hi = fsm ? fh : rh; lo = fsm ? fl : rl;
+                    if (wo.shard_count > 1u && !simka_wide_owns(hi, lo, wo.shard_index, wo.shard_count)) pending = false;
+                    else bt_kocc++;
+                    uint32_t h = (uint32_t)lo * 0x9E3779B1u + (uint32_t)(lo >> 32) * 0x85EBCA6Bu + (uint32_t)hi * 0xC2B2AE35u + (uint32_t)(hi >> 32) * 0x27D4EB2Fu;
+                    h ^= h >> 15; h *= 0x2C1B3C6Du;
+                    slot = h >> (32u - TSL);
+                }
+                // every lane of the wave runs the SAME straight-line probe step; a lane is done when its k-mer is counted
+                for (uint32_t step = 0; step < 4u * TS; step++) {
+                    if (!__any(pending)) break;
+                    ull prev = 0;
+                    if (pending) prev = atomicCAS(&thi[slot], SIMKA_EMPTY_KEY, hi);
+                    const bool won = pending && prev == SIMKA_EMPTY_KEY;
+                    if (won) tlo[slot] = lo;
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");          // the claimants of this wave have stored their low words
+                    bool hit = won, wait = false;
+                    if (pending && !won && prev == hi) {
+                        const uint32_t c = ((volatile uint32_t *)tcnt)[slot];
+                        if (c == 0u) wait = true;                              // claimed by another wave, its low word not counted in yet: look again
+                        else hit = ((volatile ull *)tlo)[slot] == lo;
+                    }
+                    if (hit) { atomicAdd(&tcnt[slot], 1u); pending = false; }
+                    else if (pending && !wait) slot = (slot + 1u) & (TS - 1u);
+                }
+                if (pending) s_fail = 1u;
+            }
+        }
+        __syncthreads();
+        // ---- summary (SimkaCompressedProcessor::process, ref: src/minikc/MiniKC.hpp:54-79): the solid records leave unordered
+        uint32_t cs[SPT]; ull kh[SPT], kl[SPT];
+        uint32_t nsol = 0, ndall = 0;
+        ull D = 0, N = 0, Q = 0;
+#pragma unroll
+        for (uint32_t q = 0; q < SPT; q++) {
+            const uint32_t sl = tid * SPT + q;
+            const uint32_t c = tcnt[sl];
+            cs[q] = 0; kh[q] = 0; kl[q] = 0;
+            if (c) {
+                kh[q] = thi[sl]; kl[q] = tlo[sl];
+                tcnt[sl] = 0; thi[sl] = SIMKA_EMPTY_KEY;
+                ndall++;
+                if (!(c < amin || c > amax)) { cs[q] = c; D++; N += c; Q += (ull)c * (ull)c; nsol++; }
+            } else if (thi[sl] != SIMKA_EMPTY_KEY) thi[sl] = SIMKA_EMPTY_KEY;      // (claimed, never counted: only after a failure)
+        }
+        spos[tid] = nsol;
+        __syncthreads();
+        const uint32_t tot = block_excl_scan<SKM_CNT_BLOCK>(spos, SKM_CNT_BLOCK, tmp);
+        if (tid == 0) { s_base = tot ? atomicAdd(wo.cursor, (ull)tot) : 0ull; if (s_fail) { atomicOr(&wo.cursor[6], 1ull); s_fail = 0; } }
+        __syncthreads();
+        const ull base = s_base;
+        if (base + tot > wo.cap) { if (tid == 0) atomicOr(&wo.cursor[6], 2ull); }
+        else {
+            ull pos = base + spos[tid];
+#pragma unroll
+            for (uint32_t q = 0; q < SPT; q++) if (cs[q]) { wo.hi[pos] = kh[q]; wo.lo[pos] = kl[q]; wo.cnt[pos] = cs[q]; pos++; if (o.hist) count_hist(o, lhist, cs[q]); }
+        }
+        bt_dall += ndall; bt_D += D; bt_N += N; bt_Q += Q;
+        __syncthreads();
+    }
+    if (o.hist) {
+        __syncthreads();
+        for (uint32_t i = tid; i < SIMKA_HIST_MAX; i += SKM_CNT_BLOCK)
+            if (lhist[i]) atomicAdd(&o.hist[(size_t)o.sample * SIMKA_HIST_MAX + i], (ull)lhist[i]);
+    }
+    if (bt_dall) atomicAdd(&s_tot[0], bt_dall);
+    if (bt_D) { atomicAdd(&s_tot[1], bt_D); atomicAdd(&s_tot[2], bt_N); atomicAdd(&s_tot[3], bt_Q); }
+    if (bt_kocc) atomicAdd(&s_tot[4], bt_kocc);
+    __syncthreads();
+    if (tid < 5 && s_tot[tid]) atomicAdd(&wo.cursor[1 + tid], s_tot[tid]);
+}
+
+// --------------------------------------------------------------------------------------------
+// k_skm_count_wide_fast: the common case of k_skm_count_wide -- EVERY WAVE counts partitions of its own in a private table of 512
+// two-word slots, so nothing in the kernel waits for another wave (no barrier, no "claimed but not yet written" state: the LDS
+// serves a wave's operations in order, so the low word a lane stores after winning a slot is there for every later read of the
+// wave).  Twelve waves per CU instead of four.  The partitions are sized for it (~130 k-mer occurrences); one that fills more than
+// three quarters of the table is cleared and handed to k_skm_count_wide through the redo list.
+// A wave is bound by latency, not by throughput, so the dependent chains are kept short: the records of the NEXT partition (and
+// the table entry of the one after) are loaded before the current one is counted; two k-mers per lane are in flight in the probe
+// loop; the solid records leave into a slab the wave reserves 512 at a time (one global atomic per ~12 partitions; what is left
+// of a slab when a partition does not fit gets count 0 -- simka_wide_adopt drops those slots), one ballot per 64 slots gives
+// every record its place, so consecutive lanes store consecutive records.
+// --------------------------------------------------------------------------------------------
+#define SKM_WF_BLOCK 256
+#define SKM_WF_TS 512
+#define SKM_WF_TSL 9
+#define SKM_WF_CHUNK 32
+#define SKM_WF_SLAB 512
+SIMKA_HD uint32_t skm_wf_wave_bytes(uint32_t nmax) { return SKM_WF_TS * 20u + SKM_WF_CHUNK * 16u + ((SKM_WF_CHUNK * nmax * 2u + 15u) & ~15u); }
+
+__device__ __forceinline__ void skm_wcanon(const uint4 &r, uint32_t j, uint32_t k, uint32_t s2, ull &hi, ull &lo, uint32_t &slot) {
+    ull fh, fl;
+    skm_wkmer_at(r, j, k, fh, fl);
+    // reverse complement of the 2k-bit value: the 128-bit reversal, moved down by 128 - 2k bits
+    const ull rh_ = skm_revcomp64(fl), rl_ = skm_revcomp64(fh);
+    ull rl, rh;
+    if (s2 >= 64u) { rl = rh_; rh = 0; } else { rl = (rl_ >> s2) | (rh_ << (64u - s2)); rh = rh_ >> s2; }
+    const bool fsm = fh < rh || (fh == rh && fl < rl);
+    hi = fsm ? fh : rh; lo = fsm ? fl : rl;
+    uint32_t h = (uint32_t)lo * 0x9E3779B1u + (uint32_t)(lo >> 32) * 0x85EBCA6Bu + (uint32_t)hi * 0xC2B2AE35u + (uint32_t)(hi >> 32) * 0x27D4EB2Fu;
+    h ^= h >> 15; h *= 0x2C1B3C6Du;
+    slot = h;
+}
+
+__global__ void __launch_bounds__(SKM_WF_BLOCK)
+k_skm_count_wide_fast(const uint4 *recs, const uint32_t *pstart, const uint32_t *pcnt, SimkaSkmCfg cfg, uint32_t amin, uint32_t amax, SimkaWideOut wo, SimkaCountOut o,
+                      const uint32_t *flag, uint32_t *redo_list, ull *redo_count) {
+    if (*flag) return;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    ull *s_tot = (ull *)smem;                          // [5] D_all, D, N, Q, K_occ of the whole block
+    uint32_t *lhist = (uint32_t *)(smem + SIMKA_LDS_HEAD);      // [SIMKA_HIST_MAX] (complex only)
+    constexpr uint32_t TS = SKM_WF_TS, SPT = TS / 64u;
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    unsigned char *wreg = smem + SIMKA_LDS_HEAD + (o.hist ? SIMKA_HIST_MAX * 4u : 0u) + wave * skm_wf_wave_bytes(cfg.nmax);
+    ull *thi = (ull *)wreg;                            // [TS] high words (SIMKA_EMPTY_KEY: free)
+    ull *tlo = thi + TS;                               // [TS] low words
+    uint32_t *tcnt = (uint32_t *)(tlo + TS);           // [TS]
+    uint4 *lrec = (uint4 *)(tcnt + TS);                // [CHUNK]
+    uint16_t *map = (uint16_t *)(lrec + SKM_WF_CHUNK); // [CHUNK * nmax] k-mer f of the chunk -> (record << 5) | index
+
+    const uint32_t nparts = 1u << cfg.pb;
+    const uint32_t k = cfg.k, s2 = 128u - 2u * k;      // 26 .. 64
+    for (uint32_t i = lane; i < TS; i += 64u) { thi[i] = SIMKA_EMPTY_KEY; tcnt[i] = 0; }
+    if (o.hist) for (uint32_t i = tid; i < SIMKA_HIST_MAX; i += SKM_WF_BLOCK) lhist[i] = 0;
+    if (tid < 5) s_tot[tid] = 0;
+    ull bt_dall = 0, bt_D = 0, bt_N = 0, bt_Q = 0, bt_kocc = 0;
+    ull slab_pos = 0, slab_end = 0;                    // the wave's slab of output slots (wave-uniform)
+    __syncthreads();
+    const uint32_t nwaves = gridDim.x * (SKM_WF_BLOCK / 64u);
+    auto meta = [&](uint32_t p, uint32_t &nrec_, uint32_t &rbase_) {
+        nrec_ = 0; rbase_ = 0;
+        if (p < nparts) { nrec_ = (uint32_t)__builtin_amdgcn_readfirstlane((int)pcnt[p]); rbase_ = (uint32_t)__builtin_amdgcn_readfirstlane((int)pstart[p]); }
+    };
+    auto first_chunk = [&](uint32_t nrec_, uint32_t rbase_) {
+        uint4 r = make_uint4(0, 0, 0, 0);
+        if (lane < nrec_ && lane < (uint32_t)SKM_WF_CHUNK) r = recs[rbase_ + lane];
+        return r;
+    };
+    uint32_t part = blockIdx.x * (SKM_WF_BLOCK / 64u) + wave;
+    uint32_t nrec, rbase, nrec_n, rbase_n;
+    meta(part, nrec, rbase);
+    uint4 rc0 = first_chunk(nrec, rbase);
+    meta(part + nwaves, nrec_n, rbase_n);
+    for (; part < nparts; part += nwaves) {
+        // what the next two partitions need is under way while this one is counted
+        const uint4 rc0_n = first_chunk(nrec_n, rbase_n);
+        uint32_t nrec_nn, rbase_nn;
+        meta(part + 2u * nwaves, nrec_nn, rbase_nn);
+        bool fail = false;
+        uint32_t ndist = 0, my_k = 0;
+        for (uint32_t b0 = 0; b0 < nrec && !fail; b0 += SKM_WF_CHUNK) {
+            const uint32_t nb = nrec - b0 < (uint32_t)SKM_WF_CHUNK ? nrec - b0 : (uint32_t)SKM_WF_CHUNK;
+            uint32_t len = 0;
+            if (lane < nb) { const uint4 rc = b0 ? recs[rbase + b0 + lane] : rc0; lrec[lane] = rc; len = skm_rec_n(rc); }
+            const uint32_t x = wave_incl_scan(len);
+            const uint32_t kt = (uint32_t)__builtin_amdgcn_readlane((int)x, 63);
+            const uint32_t off = x - len;
+            for (uint32_t j = 0; j < len; j++) map[off + j] = (uint16_t)((lane << 5) | j);
+            for (uint32_t f0 = 0; f0 < kt && !fail; f0 += 128u) {
+                const uint32_t fa = f0 + lane, fb = f0 + 64u + lane;
+                bool pa = fa < kt, pb_ = fb < kt;
+                ull hia = 0, loa = 0, hib = 0, lob = 0;
+                uint32_t sa = 0, sb = 0;
+                if (pa) { const uint32_t e = map[fa]; skm_wcanon(lrec[e >> 5], e & 31u, k, s2, hia, loa, sa); sa >>= 32u - SKM_WF_TSL; }
+                if (pb_) { const uint32_t e = map[fb]; skm_wcanon(lrec[e >> 5], e & 31u, k, s2, hib, lob, sb); sb >>= 32u - SKM_WF_TSL; }
+                if (wo.shard_count > 1u) {
+                    if (pa && !simka_wide_owns(hia, loa, wo.shard_index, wo.shard_count)) pa = false;
+                    if (pb_ && !simka_wide_owns(hib, lob, wo.shard_index, wo.shard_count)) pb_ = false;
+                }
+                my_k += (pa ? 1u : 0u) + (pb_ ? 1u : 0u);
+                while (__any(pa || pb_)) {
+                    ull pva = 0, pvb = 0;
+                    if (pa) pva = atomicCAS(&thi[sa], SIMKA_EMPTY_KEY, hia);
+                    if (pb_) pvb = atomicCAS(&thi[sb], SIMKA_EMPTY_KEY, hib);
+                    const bool wa = pa && pva == SIMKA_EMPTY_KEY, wb = pb_ && pvb == SIMKA_EMPTY_KEY;
+                    if (wa) { tlo[sa] = loa; atomicAdd(&tcnt[sa], 1u); }
+                    if (wb) { tlo[sb] = lob; atomicAdd(&tcnt[sb], 1u); }
+                    asm volatile("" ::: "memory");          // the low words are stored (in program order: that is enough inside one wave) before any is compared
+                    ndist += (uint32_t)__popcll(__ballot(wa)) + (uint32_t)__popcll(__ballot(wb));
+                    if (ndist > TS * 3u / 4u) { fail = true; break; }
+                    const bool ca = pa && !wa && pva == hia, cb = pb_ && !wb && pvb == hib;
+                    ull la = 0, lb = 0;
+                    if (ca) la = ((volatile ull *)tlo)[sa];
+                    if (cb) lb = ((volatile ull *)tlo)[sb];
+                    const bool ha = ca && la == loa, hb = cb && lb == lob;
+                    if (ha) atomicAdd(&tcnt[sa], 1u);
+                    if (hb) atomicAdd(&tcnt[sb], 1u);
+                    if (wa || ha) pa = false; else if (pa) sa = (sa + 1u) & (TS - 1u);
+                    if (wb || hb) pb_ = false; else if (pb_) sb = (sb + 1u) & (TS - 1u);
+                }
+            }
+        }
+        if (nrec) {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            if (fail) {      // too many distinct k-mers for this table: the block kernel's (eight times the slots)
+                for (uint32_t i = lane; i < TS; i += 64u) { thi[i] = SIMKA_EMPTY_KEY; tcnt[i] = 0; }
+                if (lane == 0) redo_list[atomicAdd(redo_count, 1ull)] = part;
+            } else {
+                // ---- summary (SimkaCompressedProcessor::process, ref: src/minikc/MiniKC.hpp:54-79): the solid records leave unordered
+                uint32_t tot = 0, ndall = 0;
+                ull D = 0, N = 0, Q = 0;
+#pragma unroll
+                for (uint32_t q = 0; q < SPT; q++) {
+                    const uint32_t c = tcnt[q * 64u + lane];
+                    const bool solid = c && !(c < amin || c > amax);
+                    if (c) ndall++;
+                    if (solid) { D++; N += c; Q += (ull)c * (ull)c; }
+                    tot += (uint32_t)__popcll(__ballot(solid));
+                }
+                bool room = true;
+                if (slab_pos + tot > slab_end) {      // (wave-uniform) the rest of the slab stays empty: count 0
+                    for (ull i = slab_pos + lane; i < slab_end; i += 64u) wo.cnt[i] = 0;
+                    const ull want = tot > (uint32_t)SKM_WF_SLAB ? (ull)tot : (ull)SKM_WF_SLAB;
+                    ull b_ = 0;
+                    if (lane == 0) b_ = atomicAdd(wo.cursor, want);
+                    slab_pos = ((ull)(uint32_t)__builtin_amdgcn_readfirstlane((int)(b_ >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)b_);
+                    slab_end = slab_pos + want;
+                    if (slab_end > wo.cap) { room = false; slab_end = slab_pos; if (lane == 0) atomicOr(&wo.cursor[6], 2ull); }
+                }
+                ull pos = slab_pos;
+#pragma unroll
+                for (uint32_t q = 0; q < SPT; q++) {
+                    const uint32_t sl = q * 64u + lane;
+                    const uint32_t c = tcnt[sl];
+                    const bool solid = room && c && !(c < amin || c > amax);
+                    const ull m = __ballot(solid);
+                    if (solid) {
+                        const ull at = pos + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+                        wo.hi[at] = thi[sl]; wo.lo[at] = tlo[sl]; wo.cnt[at] = c;
+                        if (o.hist) count_hist(o, lhist, c);
+                    }
+                    if (c) { tcnt[sl] = 0; thi[sl] = SIMKA_EMPTY_KEY; }
+                    pos += (ull)__popcll(m);
+                }
+                if (room) slab_pos = pos;
+                bt_dall += ndall; bt_D += D; bt_N += N; bt_Q += Q; bt_kocc += my_k;
+            }
+        }
+        nrec = nrec_n; rbase = rbase_n; rc0 = rc0_n;
+        nrec_n = nrec_nn; rbase_n = rbase_nn;
+    }
+    for (ull i = slab_pos + lane; i < slab_end; i += 64u) wo.cnt[i] = 0;
+    if (bt_dall) atomicAdd(&s_tot[0], bt_dall);
+    if (bt_D) { atomicAdd(&s_tot[1], bt_D); atomicAdd(&s_tot[2], bt_N); atomicAdd(&s_tot[3], bt_Q); }
+    if (bt_kocc) atomicAdd(&s_tot[4], bt_kocc);
+    __syncthreads();
+    if (o.hist)
+        for (uint32_t i = tid; i < SIMKA_HIST_MAX; i += SKM_WF_BLOCK)
+            if (lhist[i]) atomicAdd(&o.hist[(size_t)o.sample * SIMKA_HIST_MAX + i], (ull)lhist[i]);
+    if (tid < 5 && s_tot[tid]) atomicAdd(&wo.cursor[1 + tid], s_tot[tid]);
+}
 
 // --------------------------------------------------------------------------------------------
 // k_skm_count_fast: the common case of k_skm_count -- the partition's distinct k-mers fit the table in ONE round.

@@ -26,6 +26,9 @@ const char *simka_wide_error(SimkaWide *w);
 int simka_wide_count_sample(SimkaWide *w, uint32_t sample, const void *packed, uint64_t nb_bases, uint64_t nb_words, const void *offsets, uint64_t nb_reads,
                             uint32_t fixed_len, uint32_t amin, uint32_t amax, unsigned long long totals5[5], void *d_hist_row, void *d_ovf_list,
                             void *d_ovf_cursor, uint64_t ovf_cap);
+// solid records counted by the partitioned pipeline (k <= 51): unordered device triples, n of them in nb_slots slots (count 0: unused) ->
+// the sample's run of the arena (sorted on demand)
+int simka_wide_adopt(SimkaWide *w, uint32_t sample, const void *d_hi, const void *d_lo, const void *d_cnt, uint64_t nb_slots, uint64_t n);
 int simka_wide_merge(SimkaWide *w, uint32_t span_cap, SimkaWideCsr *out);
 
 // spectra out of / into the wide arena: partition p of a (sorted) sample = the records whose top log2_parts key bits equal p

@@ -20,6 +20,7 @@
 #include <string>
 #include <vector>
 
+#include "simka_device.h"
 #include "simka_kernels.h"
 #include "simka_wide.h"
 #include "simka_sort.hip"
@@ -38,10 +39,12 @@ struct SimkaWide {
     uint32_t shard_index = 0, shard_count = 1;   // partition shard: the k-mers this context keeps (wide_owns)
     hipStream_t stream = nullptr;
     std::string err;
-    // wide arena: the solid spectra of all samples, each sorted by (hi, lo)
+    // wide arena: the solid spectra of all samples, each sorted by (hi, lo) -- or, for a sample adopted from the partitioned count
+    // (simka_wide_adopt), in any order until someone asks for its order (export, partition runs): the merge sorts all records anyway
     ull *a_hi = nullptr, *a_lo = nullptr; uint32_t *a_cnt = nullptr;
     uint64_t a_cap = 0, a_used = 0;
     std::vector<uint64_t> s_off, s_n;            // per sample: offset and number of solid records
+    std::vector<uint8_t> s_sorted;
     // scratch (grown on demand)
     void *scratch[12] = { nullptr }; uint64_t scratch_bytes[12] = { 0 };
     // CSR handed to k_pairs (owned here, valid until the next reset / merge)
@@ -70,13 +73,7 @@ static int wide_buf(SimkaWide *w, int slot, uint64_t n, T **out) {
 struct WideScanArgs { const uint64_t *packed; uint64_t nb_bases, nb_words; const uint64_t *offsets; uint64_t nb_reads; uint32_t fixed_len, k;
                       uint32_t shard_index, shard_count; };
 
-// partition shards of the sort-based path: a canonical k-mer belongs to shard  mix(hi, lo) * G >> 32  (every context of a sharded run
-// scans all reads and keeps its own k-mers, as a shard of the hash pipeline keeps its level-1 buckets)
-__device__ __forceinline__ bool wide_owns(ull hi, ull lo, uint32_t shard_index, uint32_t shard_count) {
-    ull x = lo ^ (hi * 0x9E3779B97F4A7C15ull);
-    x ^= x >> 29; x *= 0xBF58476D1CE4E5B9ull; x ^= x >> 32;
-    return (uint32_t)(((x >> 32) * (ull)shard_count) >> 32) == shard_index;
-}
+#define wide_owns simka_wide_owns      // (simka_device.h: the hash path for k <= 51 applies the same rule)
 
 __device__ __forceinline__ uint32_t wbase(const uint64_t *packed, uint64_t p) { return (uint32_t)(packed[p >> 5] >> ((p & 31u) * 2u)) & 3u; }
 
@@ -340,7 +337,7 @@ static int wide_sort_words(SimkaWide *w, uint64_t n, uint32_t hi_bits, ull *hi0,
 int simka_wide_create(SimkaWide **out, int device, uint32_t nb_samples, uint32_t k, void *stream) {
     SimkaWide *w = new SimkaWide();
     w->device = device; w->nb_samples = nb_samples; w->k = k; w->W = 2 * k; w->stream = (hipStream_t)stream;
-    w->s_off.assign(nb_samples, 0); w->s_n.assign(nb_samples, 0);
+    w->s_off.assign(nb_samples, 0); w->s_n.assign(nb_samples, 0); w->s_sorted.assign(nb_samples, 1);
     *out = w;
     return 0;
 }
@@ -360,7 +357,7 @@ void simka_wide_destroy(SimkaWide *w) {
 
 int simka_wide_reset(SimkaWide *w) {
     w->a_used = 0;
-    std::fill(w->s_off.begin(), w->s_off.end(), 0); std::fill(w->s_n.begin(), w->s_n.end(), 0);
+    std::fill(w->s_off.begin(), w->s_off.end(), 0); std::fill(w->s_n.begin(), w->s_n.end(), 0); std::fill(w->s_sorted.begin(), w->s_sorted.end(), 1);
     return 0;
 }
 
@@ -387,7 +384,7 @@ int simka_wide_count_sample(SimkaWide *w, uint32_t sample, const void *packed, u
                             uint32_t fixed_len, uint32_t amin, uint32_t amax, unsigned long long totals5[5], void *d_hist_row, void *d_ovf_list,
                             void *d_ovf_cursor, uint64_t ovf_cap) {
     for (int i = 0; i < 5; i++) totals5[i] = 0;
-    w->s_off[sample] = w->a_used; w->s_n[sample] = 0;
+    w->s_off[sample] = w->a_used; w->s_n[sample] = 0; w->s_sorted[sample] = 1;
     if (nb_bases == 0) return 0;
     const uint64_t n = nb_bases;
     ull *hi0, *lo0, *hi1, *lo1; uint32_t *idx0, *idx1; ull *d_small;
@@ -435,6 +432,68 @@ int simka_wide_count_sample(SimkaWide *w, uint32_t sample, const void *packed, u
     WCHK(hipGetLastError());
     w->s_n[sample] = nsolid;
     w->a_used += nsolid;
+    return 0;
+}
+
+// a sample's solid records counted by k_skm_count_wide (simka_skm.hip): unordered (hi, lo, count) triples on the device.  They
+// enter the arena as they are; wide_ensure_sorted() orders them when a caller needs the sample's own order.
+__global__ void __launch_bounds__(256)
+k_wgather32(const uint32_t *src, const uint32_t *idx, uint32_t *dst, uint64_t n) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) dst[i] = src[idx[i]];
+}
+
+__global__ void __launch_bounds__(256)
+k_wused(const uint32_t *cnt, uint64_t n, uint32_t *flag) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) flag[i] = cnt[i] ? 1u : 0u;
+}
+__global__ void __launch_bounds__(256)
+k_wcompact(const ull *hi, const ull *lo, const uint32_t *cnt, const uint32_t *rank, uint64_t n, ull *o_hi, ull *o_lo, uint32_t *o_cnt) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t c = cnt[i];
+    if (c) { const uint32_t r = rank[i]; o_hi[r] = hi[i]; o_lo[r] = lo[i]; o_cnt[r] = c; }
+}
+
+// nb_slots slots hold n records: the slots with count 0 are the unused ends of the count kernel's slabs
+int simka_wide_adopt(SimkaWide *w, uint32_t sample, const void *d_hi, const void *d_lo, const void *d_cnt, uint64_t nb_slots, uint64_t n) {
+    int rc = arena_reserve(w, n); if (rc) return rc;
+    w->s_off[sample] = w->a_used; w->s_n[sample] = n; w->s_sorted[sample] = n <= 1;
+    if (n == 0) return 0;
+    if (nb_slots >= ((uint64_t)1 << 32)) { w->err = "wide-k path: more than 2^32 output slots of one sample"; return SIMKA_WIDE_ERR_LIMIT; }
+    if (nb_slots == n) {
+        WCHK(hipMemcpyAsync(w->a_hi + w->a_used, d_hi, n * 8, hipMemcpyDeviceToDevice, w->stream));
+        WCHK(hipMemcpyAsync(w->a_lo + w->a_used, d_lo, n * 8, hipMemcpyDeviceToDevice, w->stream));
+        WCHK(hipMemcpyAsync(w->a_cnt + w->a_used, d_cnt, n * 4, hipMemcpyDeviceToDevice, w->stream));
+    } else {
+        uint32_t *flag, *rank;
+        if ((rc = wide_buf(w, 5, nb_slots + 2, &flag)) || (rc = wide_buf(w, 6, nb_slots + 2, &rank))) return rc;
+        hipLaunchKernelGGL(k_wused, grid_for(nb_slots), dim3(256), 0, w->stream, (const uint32_t *)d_cnt, nb_slots, flag);
+        if ((rc = wide_scan(w, flag, rank, nb_slots))) return rc;
+        hipLaunchKernelGGL(k_wcompact, grid_for(nb_slots), dim3(256), 0, w->stream, (const ull *)d_hi, (const ull *)d_lo, (const uint32_t *)d_cnt, (const uint32_t *)rank, nb_slots,
+                           w->a_hi + w->a_used, w->a_lo + w->a_used, w->a_cnt + w->a_used);
+        WCHK(hipGetLastError());
+    }
+    w->a_used += n;
+    return 0;
+}
+
+static int wide_ensure_sorted(SimkaWide *w, uint32_t sample) {
+    if (w->s_sorted[sample]) return 0;
+    const uint64_t n = w->s_n[sample], off = w->s_off[sample];
+    int rc;
+    ull *h0, *l0, *tkey; uint32_t *c0, *idx0, *idx1;
+    if ((rc = wide_buf(w, 0, n, &h0)) || (rc = wide_buf(w, 1, n, &l0)) || (rc = wide_buf(w, 2, n, &c0)) || (rc = wide_buf(w, 3, n, &tkey)) ||
+        (rc = wide_buf(w, 5, n + 2, &idx0)) || (rc = wide_buf(w, 6, n + 2, &idx1))) return rc;
+    WCHK(hipMemcpyAsync(h0, w->a_hi + off, n * 8, hipMemcpyDeviceToDevice, w->stream));
+    WCHK(hipMemcpyAsync(l0, w->a_lo + off, n * 8, hipMemcpyDeviceToDevice, w->stream));
+    WCHK(hipMemcpyAsync(c0, w->a_cnt + off, n * 4, hipMemcpyDeviceToDevice, w->stream));
+    const uint32_t hi_bits = std::max<uint32_t>(1u, w->W > 64 ? w->W - 64 : 0);
+    if ((rc = wide_sort(w, n, hi_bits, h0, l0, w->a_hi + off, w->a_lo + off, tkey, idx0, idx1))) return rc;
+    hipLaunchKernelGGL(k_wgather32, grid_for(n), dim3(256), 0, w->stream, (const uint32_t *)c0, (const uint32_t *)idx0, w->a_cnt + off, n);
+    WCHK(hipGetLastError());
+    w->s_sorted[sample] = 1;
     return 0;
 }
 
@@ -555,7 +614,8 @@ int simka_wide_part_counts(SimkaWide *w, uint32_t sample, uint32_t log2_parts, u
     const uint32_t P = 1u << log2_parts;
     const uint64_t n = w->s_n[sample], off = w->s_off[sample];
     if (n == 0) { std::fill(host_counts, host_counts + P, 0u); return 0; }
-    uint32_t *d_b; int rc = wide_buf(w, 7, (uint64_t)P + 2, &d_b); if (rc) return rc;
+    int rc = wide_ensure_sorted(w, sample); if (rc) return rc;
+    uint32_t *d_b; rc = wide_buf(w, 7, (uint64_t)P + 2, &d_b); if (rc) return rc;
     hipLaunchKernelGGL(k_wpartbounds, grid_for((uint64_t)P + 1), dim3(256), 0, w->stream, w->a_hi + off, w->a_lo + off, n, w->W, log2_parts, d_b);
     std::vector<uint32_t> b((size_t)P + 1);
     WCHK(hipMemcpyAsync(b.data(), d_b, ((size_t)P + 1) * 4, hipMemcpyDeviceToHost, w->stream));
@@ -570,6 +630,7 @@ uint64_t simka_wide_sample_records(SimkaWide *w, uint32_t sample) { return w->s_
 int simka_wide_export(SimkaWide *w, uint32_t sample, void *keys, void *counts, int on_device) {
     const uint64_t n = w->s_n[sample], off = w->s_off[sample];
     if (n == 0) return 0;
+    { const int rc = wide_ensure_sorted(w, sample); if (rc) return rc; }
     const hipMemcpyKind kind = on_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost;
     WCHK(hipMemcpyAsync(keys, w->a_hi + off, n * 8, kind, w->stream));
     WCHK(hipMemcpyAsync((ull *)keys + n, w->a_lo + off, n * 8, kind, w->stream));
@@ -580,7 +641,7 @@ int simka_wide_export(SimkaWide *w, uint32_t sample, void *keys, void *counts, i
 
 int simka_wide_import(SimkaWide *w, uint32_t sample, const void *keys, const void *counts, uint64_t n, int on_device) {
     int rc = arena_reserve(w, n); if (rc) return rc;
-    w->s_off[sample] = w->a_used; w->s_n[sample] = n;
+    w->s_off[sample] = w->a_used; w->s_n[sample] = n; w->s_sorted[sample] = 1;
     if (n == 0) return 0;
     const hipMemcpyKind kind = on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
     WCHK(hipMemcpyAsync(w->a_hi + w->a_used, keys, n * 8, kind, w->stream));
@@ -612,6 +673,7 @@ int simka_wide_gather(SimkaWide *w, const uint32_t *samples, uint32_t nb, uint32
         const uint32_t s = samples[j];
         const uint64_t n = w->s_n[s], off = w->s_off[s];
         if (n == 0) continue;
+        if ((rc = wide_ensure_sorted(w, s))) return rc;
         hipLaunchKernelGGL(k_wpartbounds, grid_for((uint64_t)P + 1), dim3(256), 0, w->stream, w->a_hi + off, w->a_lo + off, n, w->W, log2_parts, d_b);
         WCHK(hipMemcpyAsync(d_off, out_offsets + (size_t)j * P, (size_t)P * 8, hipMemcpyHostToDevice, w->stream));
         hipLaunchKernelGGL(k_wgather_runs, dim3(std::min<uint32_t>(P, 1024u)), dim3(256), 0, w->stream, w->a_hi, w->a_lo, w->a_cnt, (ull)off, d_b, d_off, P,
@@ -625,7 +687,7 @@ int simka_wide_gather(SimkaWide *w, const uint32_t *samples, uint32_t nb, uint32
 // one sample's (sorted) slice out of a received block: separate word arrays
 int simka_wide_import_words(SimkaWide *w, uint32_t sample, const void *d_hi, const void *d_lo, const void *d_counts, uint64_t n) {
     int rc = arena_reserve(w, n); if (rc) return rc;
-    w->s_off[sample] = w->a_used; w->s_n[sample] = n;
+    w->s_off[sample] = w->a_used; w->s_n[sample] = n; w->s_sorted[sample] = 1;
     if (n == 0) return 0;
     WCHK(hipMemcpyAsync(w->a_hi + w->a_used, d_hi, n * 8, hipMemcpyDeviceToDevice, w->stream));
     WCHK(hipMemcpyAsync(w->a_lo + w->a_used, d_lo, n * 8, hipMemcpyDeviceToDevice, w->stream));

@@ -915,16 +915,29 @@ def test_cli_spectra_larger_than_the_arena_merge_by_partition_ranges(gpu_require
                                           (33, 1, 4, 2500, 120), (47, 2, 5, 2500, 150), (63, 1, 3, 2000, 150),
                                           (33, 1, 150, 120, 100)])     # more samples than one LDS tile: the tile-major pair kernel on the sorted CSR
 def test_sort_based_path_for_wide_kmers(gpu_required, oracle_mod, monkeypatch, k, amin, n, R, L):
-    """k >= 32 (k-mers of up to 126 bits, the reference's span-64 build) takes the sort-based path of simka_wide.hip; the same
-    path is forced for k <= 31 (SIMKA_SORT_PATH) as a cross-check of the hash pipeline.  Totals and every accumulator vs the
+    """k >= 52 (k-mers of up to 126 bits, the reference's span-64 build) takes the sort-based path of simka_wide.hip; the same
+    path is forced for smaller k (SIMKA_SORT_PATH) as a cross-check of the partitioned pipeline.  Totals and every accumulator vs the
     oracle (128-bit k-mers), -simple-dist and -complex-dist; variable-length layout for one case.  k >= 32 has no golden
     vectors in the reference (parity unpinned): the oracle is the same code that reproduces the k = 21 / 31 goldens."""
-    from simka_amd import synth
     monkeypatch.setenv("SIMKA_SORT_PATH", "1")
+    _wide_case(oracle_mod, k, amin, n, R, L, expect="sorted")
+
+
+def _wide_case(oracle_mod, k, amin, n, R, L, expect, fixed=True, **ctx_kw):
+    from simka_amd import synth
     packed = _synthetic(n, R, L, seed_shift=70)
     offs = np.arange(R + 1, dtype=np.uint64) * L
     inputs = [(np.concatenate([pk, np.zeros(2, dtype=np.uint64)]), offs, R * L, R) for pk in packed]
-    totals, st = _run_gpu(inputs, k, amin, simple=True)
+    import simka_amd
+    ctx = simka_amd.SimkaContext(n, kmer_size=k, abundance_min=amin, simple_dist=True, complex_dist=True, **ctx_kw)
+    for s, (pk, of, nb, nr) in enumerate(inputs):
+        ctx.count_sample(s, pk, nb, nr, fixed_len=L if fixed else 0, offsets=None if fixed else of, nb_input_reads=nr)
+    totals = [ctx.sample_totals(i) for i in range(n)]
+    ctx.merge()
+    st = ctx.stats()
+    paths = ctx.count_paths()
+    ctx.close()
+    assert paths[expect] == n and paths["partitioned"] + paths["sorted"] == n, paths
     orc = oracle_mod.Oracle()
     for s, pk in enumerate(packed):
         orc.add_sample_ascii("S%d" % s, synth.unpack_ascii(pk, R * L), offs)
@@ -933,6 +946,27 @@ def test_sort_based_path_for_wide_kmers(gpu_required, oracle_mod, monkeypatch, k
     for w, name in enumerate(orc.matrix_names()):
         if name in st.matrices():
             np.testing.assert_allclose(st.matrices()[name], orc.matrix(w), rtol=1e-6, atol=0)
+
+
+@pytest.mark.parametrize("k,amin,n,R,L,fixed", [(32, 2, 4, 2500, 120, True), (33, 1, 4, 2500, 120, True), (34, 1, 3, 2000, 100, False), (35, 2, 3, 2000, 100, True),
+                                                (36, 1, 3, 2000, 100, True), (41, 2, 4, 2500, 150, False), (47, 2, 5, 2500, 150, True), (50, 1, 3, 2000, 150, True),
+                                                (51, 1, 3, 2000, 150, False), (51, 2, 3, 3000, 51, True), (33, 1, 150, 120, 100, True)])
+def test_wide_kmers_on_the_partitioned_pipeline(gpu_required, oracle_mod, k, amin, n, R, L, fixed):
+    """32 <= k <= 51: a super-k-mer record still holds a k-mer, so the samples are counted per minimizer partition in LDS tables of
+    two-word keys (k_skm_count_wide; the minimizer window sits in the middle of the k-mer, every parity of k - m) and only their
+    solid records are sorted; the merge is the sorted one.  Same oracle, same checks as the sort-based path."""
+    _wide_case(oracle_mod, k, amin, n, R, L, expect="partitioned", fixed=fixed)
+
+
+@pytest.mark.parametrize("per_part,general,expect", [(3000, False, "partitioned"), (192, True, "partitioned"), (200000, False, "sorted")])
+def test_wide_kmers_partitions_beyond_the_tables(gpu_required, oracle_mod, monkeypatch, per_part, general, expect):
+    """The three ways a partition of two-word k-mers gets counted: in a wave's table (the other tests), in the block's table when it
+    outgrows that (here: partitions made 16 times too large, or every partition sent there), and -- when even that one fills --
+    the whole sample on the sort-based path.  Same results."""
+    monkeypatch.setenv("SIMKA_WIDE_PER_PART", str(per_part))
+    if general:
+        monkeypatch.setenv("SIMKA_SKM_GENERAL", "1")
+    _wide_case(oracle_mod, 37, 2, 3, 4000, 120, expect=expect)
 
 
 def test_example_goldens_through_the_sort_path(gpu_required, golden_dir, tmp_path, monkeypatch):
