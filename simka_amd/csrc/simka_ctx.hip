@@ -882,6 +882,20 @@ static int wide_hash_count(simka_ctx *ctx, uint32_t sample, const void *d_packed
         o.hist = ctx->d_hist; o.ovf_list = ctx->d_ovf_list; o.ovf_cursor = ctx->d_ovf_cursor; o.ovf_cap = ctx->ovf_cap;
         const size_t hist_lds = ctx->d_hist ? (size_t)SIMKA_HIST_MAX * 4 : 0;
         const size_t lds_wide = (size_t)SIMKA_LDS_HEAD + (size_t)SKM_WIDE_TS * 20 + (size_t)SKM_CNT_BATCH * 16 + (size_t)SKM_CNT_BLOCK * 4 + hist_lds + (size_t)SKM_CNT_BATCH * sk.nmax * 2 + 64;
+#ifdef SIMKA_PHASE_PROF
+        {   // debug build: per-phase wall_clock64 ticks of thread 0 of every k_skm_count_wide_fast block, printed per sample
+            static ull *d_phase = nullptr;
+            if (!d_phase) { HIPCHK(hipMalloc(&d_phase, 128)); HIPCHK(hipMemset(d_phase, 0, 128)); }
+            else {
+                HIPCHK(hipDeviceSynchronize());
+                ull h[16]; HIPCHK(hipMemcpy(h, d_phase, 128, hipMemcpyDeviceToHost)); HIPCHK(hipMemset(d_phase, 0, 128));
+                ull t_ = 0; for (int i_ = 0; i_ < 8; i_++) t_ += h[i_];
+                if (t_) fprintf(stderr, "k_skm_count_wide_fast phases %%: prefetch+summary-tail %.1f load+scan %.1f map %.1f canonical %.1f probe %.1f - %.1f rows %.1f records %.1f\n",
+                        100.0 * h[0] / t_, 100.0 * h[1] / t_, 100.0 * h[2] / t_, 100.0 * h[3] / t_, 100.0 * h[4] / t_, 100.0 * h[5] / t_, 100.0 * h[6] / t_, 100.0 * h[7] / t_);
+            }
+            o.phase = d_phase;
+        }
+#endif
         const bool general_only = getenv("SIMKA_SKM_GENERAL") != nullptr;      // tests: every partition through the block kernel
         if (!general_only)
             launch_timed(ctx, KID_SKM_COUNT, [&] {

@@ -970,8 +970,9 @@ k_skm_count_wide(const uint4 *recs, const uint32_t *pstart, const uint32_t *pcnt
 // k_skm_count_wide_fast: the common case of k_skm_count_wide -- EVERY WAVE counts partitions of its own in a private table of 512
 // two-word slots, so nothing in the kernel waits for another wave (no barrier, no "claimed but not yet written" state: the LDS
 // serves a wave's operations in order, so the low word a lane stores after winning a slot is there for every later read of the
-// wave).  Twelve waves per CU instead of four.  The partitions are sized for it (~130 k-mer occurrences); one that fills more than
-// three quarters of the table is cleared and handed to k_skm_count_wide through the redo list.
+// wave).  A slot is two 64-bit words: (high word << 26 | count) -- claimed, with count 1, by one compare-and-swap -- and the low word:
+// 8 KB per table, sixteen waves per CU instead of four.  The partitions are sized for it (~130 k-mer occurrences); one that fills
+// more than three quarters of the table (or could count beyond 2^26) is cleared and handed to k_skm_count_wide through the redo list.
 // A wave is bound by latency, not by throughput, so the dependent chains are kept short: the records of the NEXT partition (and
 // the table entry of the one after) are loaded before the current one is counted; two k-mers per lane are in flight in the probe
 // loop; the solid records leave into a slab the wave reserves 512 at a time (one global atomic per ~12 partitions; what is left
@@ -983,7 +984,12 @@ k_skm_count_wide(const uint4 *recs, const uint32_t *pstart, const uint32_t *pcnt
 #define SKM_WF_TSL 9
 #define SKM_WF_CHUNK 32
 #define SKM_WF_SLAB 512
-SIMKA_HD uint32_t skm_wf_wave_bytes(uint32_t nmax) { return SKM_WF_TS * 20u + SKM_WF_CHUNK * 16u + ((SKM_WF_CHUNK * nmax * 2u + 15u) & ~15u); }
+#define SKM_WF_CBITS 26
+#ifndef SKM_WF_LOADX
+#define SKM_WF_LOADX 4u            // half-slots per k-mer occurrence of a one-chunk partition
+#endif
+// (records + map: at least the 768 bytes the summary's list of solid slots takes)
+SIMKA_HD uint32_t skm_wf_wave_bytes(uint32_t nmax) { const uint32_t rm = SKM_WF_CHUNK * 16u + ((SKM_WF_CHUNK * nmax * 2u + 15u) & ~15u); return SKM_WF_TS * 16u + (rm < 768u ? 768u : rm); }
 
 __device__ __forceinline__ void skm_wcanon(const uint4 &r, uint32_t j, uint32_t k, uint32_t s2, ull &hi, ull &lo, uint32_t &slot) {
     ull fh, fl;
@@ -1009,24 +1015,25 @@ k_skm_count_wide_fast(const uint4 *recs, const uint32_t *pstart, const uint32_t 
     constexpr uint32_t TS = SKM_WF_TS, SPT = TS / 64u;
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     unsigned char *wreg = smem + SIMKA_LDS_HEAD + (o.hist ? SIMKA_HIST_MAX * 4u : 0u) + wave * skm_wf_wave_bytes(cfg.nmax);
-    ull *thi = (ull *)wreg;                            // [TS] high words (SIMKA_EMPTY_KEY: free)
-    ull *tlo = thi + TS;                               // [TS] low words
-    uint32_t *tcnt = (uint32_t *)(tlo + TS);           // [TS]
-    uint4 *lrec = (uint4 *)(tcnt + TS);                // [CHUNK]
+    ulonglong2 *tab = (ulonglong2 *)wreg;              // [TS] x: high word << 26 | count (SIMKA_EMPTY_KEY: free), y: low word
+    uint4 *lrec = (uint4 *)(tab + TS);                 // [CHUNK]
     uint16_t *map = (uint16_t *)(lrec + SKM_WF_CHUNK); // [CHUNK * nmax] k-mer f of the chunk -> (record << 5) | index
 
     const uint32_t nparts = 1u << cfg.pb;
     const uint32_t k = cfg.k, s2 = 128u - 2u * k;      // 26 .. 64
-    for (uint32_t i = lane; i < TS; i += 64u) { thi[i] = SIMKA_EMPTY_KEY; tcnt[i] = 0; }
+    for (uint32_t i = lane; i < TS; i += 64u) tab[i].x = SIMKA_EMPTY_KEY;
     if (o.hist) for (uint32_t i = tid; i < SIMKA_HIST_MAX; i += SKM_WF_BLOCK) lhist[i] = 0;
     if (tid < 5) s_tot[tid] = 0;
     ull bt_dall = 0, bt_D = 0, bt_N = 0, bt_Q = 0, bt_kocc = 0;
     ull slab_pos = 0, slab_end = 0;                    // the wave's slab of output slots (wave-uniform)
     __syncthreads();
+    PH_DECL
     const uint32_t nwaves = gridDim.x * (SKM_WF_BLOCK / 64u);
+    // (the table entries of the partition after the next stay in vector registers until they are needed: a readfirstlane here would
+    // wait for the load it was just issued)
     auto meta = [&](uint32_t p, uint32_t &nrec_, uint32_t &rbase_) {
         nrec_ = 0; rbase_ = 0;
-        if (p < nparts) { nrec_ = (uint32_t)__builtin_amdgcn_readfirstlane((int)pcnt[p]); rbase_ = (uint32_t)__builtin_amdgcn_readfirstlane((int)pstart[p]); }
+        if (p < nparts) { nrec_ = pcnt[p]; rbase_ = pstart[p]; }
     };
     auto first_chunk = [&](uint32_t nrec_, uint32_t rbase_) {
         uint4 r = make_uint4(0, 0, 0, 0);
@@ -1034,17 +1041,21 @@ k_skm_count_wide_fast(const uint4 *recs, const uint32_t *pstart, const uint32_t 
         return r;
     };
     uint32_t part = blockIdx.x * (SKM_WF_BLOCK / 64u) + wave;
-    uint32_t nrec, rbase, nrec_n, rbase_n;
-    meta(part, nrec, rbase);
+    uint32_t nrec_v, rbase_v, nrec_nv, rbase_nv;
+    meta(part, nrec_v, rbase_v);
+    uint32_t nrec = (uint32_t)__builtin_amdgcn_readfirstlane((int)nrec_v), rbase = (uint32_t)__builtin_amdgcn_readfirstlane((int)rbase_v);
     uint4 rc0 = first_chunk(nrec, rbase);
-    meta(part + nwaves, nrec_n, rbase_n);
+    meta(part + nwaves, nrec_nv, rbase_nv);
+    constexpr int NF = 2;                              // k-mers a lane has in flight in the probe loop
     for (; part < nparts; part += nwaves) {
         // what the next two partitions need is under way while this one is counted
+        const uint32_t nrec_n = (uint32_t)__builtin_amdgcn_readfirstlane((int)nrec_nv), rbase_n = (uint32_t)__builtin_amdgcn_readfirstlane((int)rbase_nv);
         const uint4 rc0_n = first_chunk(nrec_n, rbase_n);
-        uint32_t nrec_nn, rbase_nn;
-        meta(part + 2u * nwaves, nrec_nn, rbase_nn);
-        bool fail = false;
+        meta(part + 2u * nwaves, nrec_nv, rbase_nv);
+        PH(0)
+        bool fail = nrec >= (1u << (SKM_WF_CBITS - 6));          // (a count could leave its 26 bits)
         uint32_t ndist = 0, my_k = 0;
+        uint32_t tsl = SKM_WF_TSL;                                 // log2 of the slots this partition uses
         for (uint32_t b0 = 0; b0 < nrec && !fail; b0 += SKM_WF_CHUNK) {
             const uint32_t nb = nrec - b0 < (uint32_t)SKM_WF_CHUNK ? nrec - b0 : (uint32_t)SKM_WF_CHUNK;
             uint32_t len = 0;
@@ -1052,91 +1063,114 @@ k_skm_count_wide_fast(const uint4 *recs, const uint32_t *pstart, const uint32_t 
             const uint32_t x = wave_incl_scan(len);
             const uint32_t kt = (uint32_t)__builtin_amdgcn_readlane((int)x, 63);
             const uint32_t off = x - len;
+            // a partition of one chunk knows its k-mers now: a table of >= 2 slots per occurrence (>= 64) is enough, and the
+            // summary reads only that many
+            if (nrec <= (uint32_t)SKM_WF_CHUNK) { tsl = 6u; while (tsl < (uint32_t)SKM_WF_TSL && (2u << tsl) < SKM_WF_LOADX * kt) tsl++; }
+            PH_WAITVM
+            PH(1)
             for (uint32_t j = 0; j < len; j++) map[off + j] = (uint16_t)((lane << 5) | j);
-            for (uint32_t f0 = 0; f0 < kt && !fail; f0 += 128u) {
-                const uint32_t fa = f0 + lane, fb = f0 + 64u + lane;
-                bool pa = fa < kt, pb_ = fb < kt;
-                ull hia = 0, loa = 0, hib = 0, lob = 0;
-                uint32_t sa = 0, sb = 0;
-                if (pa) { const uint32_t e = map[fa]; skm_wcanon(lrec[e >> 5], e & 31u, k, s2, hia, loa, sa); sa >>= 32u - SKM_WF_TSL; }
-                if (pb_) { const uint32_t e = map[fb]; skm_wcanon(lrec[e >> 5], e & 31u, k, s2, hib, lob, sb); sb >>= 32u - SKM_WF_TSL; }
-                if (wo.shard_count > 1u) {
-                    if (pa && !simka_wide_owns(hia, loa, wo.shard_index, wo.shard_count)) pa = false;
-                    if (pb_ && !simka_wide_owns(hib, lob, wo.shard_index, wo.shard_count)) pb_ = false;
+            PH(2)
+            const uint32_t tmask = (1u << tsl) - 1u, tfull = (3u << tsl) >> 2;
+            for (uint32_t f0 = 0; f0 < kt && !fail; f0 += 64u * NF) {
+                bool pd[NF]; ull hi[NF], lo[NF]; uint32_t sl[NF];
+#pragma unroll
+                for (int i = 0; i < NF; i++) {
+                    const uint32_t f = f0 + 64u * i + lane;
+                    pd[i] = f < kt; hi[i] = 0; lo[i] = 0; sl[i] = 0;
+                    if (pd[i]) {
+                        const uint32_t e = map[f];
+                        skm_wcanon(lrec[e >> 5], e & 31u, k, s2, hi[i], lo[i], sl[i]);
+                        sl[i] >>= 32u - tsl;
+                        if (wo.shard_count > 1u && !simka_wide_owns(hi[i], lo[i], wo.shard_index, wo.shard_count)) pd[i] = false;
+                    }
+                    my_k += pd[i] ? 1u : 0u;
                 }
-                my_k += (pa ? 1u : 0u) + (pb_ ? 1u : 0u);
-                while (__any(pa || pb_)) {
-                    ull pva = 0, pvb = 0;
-                    if (pa) pva = atomicCAS(&thi[sa], SIMKA_EMPTY_KEY, hia);
-                    if (pb_) pvb = atomicCAS(&thi[sb], SIMKA_EMPTY_KEY, hib);
-                    const bool wa = pa && pva == SIMKA_EMPTY_KEY, wb = pb_ && pvb == SIMKA_EMPTY_KEY;
-                    if (wa) { tlo[sa] = loa; atomicAdd(&tcnt[sa], 1u); }
-                    if (wb) { tlo[sb] = lob; atomicAdd(&tcnt[sb], 1u); }
+                PH(3)
+                // claim the slot (compare-and-swap of high word | count 1 into a free one: the winner stores the low word) or find it
+                // taken: by the same high word -> compare the low word -> count; else the next slot
+                while (__any(pd[0] || pd[1])) {
+                    ull pv[NF]; bool wn[NF];
+#pragma unroll
+                    for (int i = 0; i < NF; i++) { pv[i] = 0; if (pd[i]) pv[i] = atomicCAS(&tab[sl[i]].x, SIMKA_EMPTY_KEY, (hi[i] << SKM_WF_CBITS) | 1ull); }
+#pragma unroll
+                    for (int i = 0; i < NF; i++) { wn[i] = pd[i] && pv[i] == SIMKA_EMPTY_KEY; if (wn[i]) tab[sl[i]].y = lo[i]; ndist += (uint32_t)__popcll(__ballot(wn[i])); }
                     asm volatile("" ::: "memory");          // the low words are stored (in program order: that is enough inside one wave) before any is compared
-                    ndist += (uint32_t)__popcll(__ballot(wa)) + (uint32_t)__popcll(__ballot(wb));
-                    if (ndist > TS * 3u / 4u) { fail = true; break; }
-                    const bool ca = pa && !wa && pva == hia, cb = pb_ && !wb && pvb == hib;
-                    ull la = 0, lb = 0;
-                    if (ca) la = ((volatile ull *)tlo)[sa];
-                    if (cb) lb = ((volatile ull *)tlo)[sb];
-                    const bool ha = ca && la == loa, hb = cb && lb == lob;
-                    if (ha) atomicAdd(&tcnt[sa], 1u);
-                    if (hb) atomicAdd(&tcnt[sb], 1u);
-                    if (wa || ha) pa = false; else if (pa) sa = (sa + 1u) & (TS - 1u);
-                    if (wb || hb) pb_ = false; else if (pb_) sb = (sb + 1u) & (TS - 1u);
+                    if (ndist > tfull) { fail = true; break; }
+                    ull lw[NF]; bool cm[NF];
+#pragma unroll
+                    for (int i = 0; i < NF; i++) { cm[i] = pd[i] && !wn[i] && (pv[i] >> SKM_WF_CBITS) == hi[i]; lw[i] = 0; if (cm[i]) lw[i] = ((volatile ull *)&tab[sl[i]].y)[0]; }
+#pragma unroll
+                    for (int i = 0; i < NF; i++) {
+                        const bool hit = cm[i] && lw[i] == lo[i];
+                        if (hit) atomicAdd(&tab[sl[i]].x, 1ull);
+                        if (wn[i] || hit) pd[i] = false; else if (pd[i]) sl[i] = (sl[i] + 1u) & tmask;
+                    }
                 }
+                PH(4)
             }
+            PH(5)
         }
         if (nrec) {
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             if (fail) {      // too many distinct k-mers for this table: the block kernel's (eight times the slots)
-                for (uint32_t i = lane; i < TS; i += 64u) { thi[i] = SIMKA_EMPTY_KEY; tcnt[i] = 0; }
+                for (uint32_t i = lane; i < TS; i += 64u) tab[i].x = SIMKA_EMPTY_KEY;
                 if (lane == 0) redo_list[atomicAdd(redo_count, 1ull)] = part;
             } else {
-                // ---- summary (SimkaCompressedProcessor::process, ref: src/minikc/MiniKC.hpp:54-79): the solid records leave unordered
-                uint32_t tot = 0, ndall = 0;
-                ull D = 0, N = 0, Q = 0;
-#pragma unroll
-                for (uint32_t q = 0; q < SPT; q++) {
-                    const uint32_t c = tcnt[q * 64u + lane];
-                    const bool solid = c && !(c < amin || c > amax);
-                    if (c) ndall++;
-                    if (solid) { D++; N += c; Q += (ull)c * (ull)c; }
-                    tot += (uint32_t)__popcll(__ballot(solid));
-                }
+                // ---- summary (SimkaCompressedProcessor::process, ref: src/minikc/MiniKC.hpp:54-79): the solid records leave unordered,
+                // one pass over the table (the slab has room for every distinct k-mer of it, solid or not)
                 bool room = true;
-                if (slab_pos + tot > slab_end) {      // (wave-uniform) the rest of the slab stays empty: count 0
+                if (slab_pos + ndist > slab_end) {      // (wave-uniform) the rest of the slab stays empty: count 0
                     for (ull i = slab_pos + lane; i < slab_end; i += 64u) wo.cnt[i] = 0;
-                    const ull want = tot > (uint32_t)SKM_WF_SLAB ? (ull)tot : (ull)SKM_WF_SLAB;
+                    const ull want = ndist > (uint32_t)SKM_WF_SLAB ? (ull)ndist : (ull)SKM_WF_SLAB;
                     ull b_ = 0;
                     if (lane == 0) b_ = atomicAdd(wo.cursor, want);
                     slab_pos = ((ull)(uint32_t)__builtin_amdgcn_readfirstlane((int)(b_ >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)b_);
                     slab_end = slab_pos + want;
                     if (slab_end > wo.cap) { room = false; slab_end = slab_pos; if (lane == 0) atomicOr(&wo.cursor[6], 2ull); }
                 }
-                ull pos = slab_pos;
-#pragma unroll
-                for (uint32_t q = 0; q < SPT; q++) {
+                // rows of 64 slots: the solid ones into a list (over the records and the map, which are done with), the others cleared;
+                // then one lane per solid record: every lane of the (usually single) pass has work
+                uint16_t *list = (uint16_t *)lrec;                 // [<= 3 TS / 4]
+                uint32_t nl = 0;
+                const uint32_t nrows = 1u << (tsl - 6u);
+                for (uint32_t q = 0; q < nrows; q++) {
                     const uint32_t sl = q * 64u + lane;
-                    const uint32_t c = tcnt[sl];
-                    const bool solid = room && c && !(c < amin || c > amax);
+                    const ull w = tab[sl].x;
+                    const bool used = w != SIMKA_EMPTY_KEY;
+                    const uint32_t c = (uint32_t)w & ((1u << SKM_WF_CBITS) - 1u);
+                    const bool solid = used && !(c < amin || c > amax);
                     const ull m = __ballot(solid);
-                    if (solid) {
-                        const ull at = pos + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
-                        wo.hi[at] = thi[sl]; wo.lo[at] = tlo[sl]; wo.cnt[at] = c;
+                    if (solid) list[nl + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u))] = (uint16_t)sl;
+                    else if (used) tab[sl].x = SIMKA_EMPTY_KEY;
+                    nl += (uint32_t)__popcll(m);
+                }
+                asm volatile("" ::: "memory");
+                PH(6)
+                ull D = 0, N = 0, Q = 0;
+                for (uint32_t i = lane; i < nl; i += 64u) {
+                    const uint32_t sl = ((volatile uint16_t *)list)[i];
+                    const ulonglong2 e_ = tab[sl];
+                    const ull w = e_.x, lo_ = e_.y;
+                    tab[sl].x = SIMKA_EMPTY_KEY;
+                    const uint32_t c = (uint32_t)w & ((1u << SKM_WF_CBITS) - 1u);
+                    D++; N += c; Q += (ull)c * (ull)c;
+                    if (room) {
+                        const ull at = slab_pos + i;
+                        wo.hi[at] = w >> SKM_WF_CBITS; wo.lo[at] = lo_; wo.cnt[at] = c;
                         if (o.hist) count_hist(o, lhist, c);
                     }
-                    if (c) { tcnt[sl] = 0; thi[sl] = SIMKA_EMPTY_KEY; }
-                    pos += (ull)__popcll(m);
                 }
-                if (room) slab_pos = pos;
-                bt_dall += ndall; bt_D += D; bt_N += N; bt_Q += Q; bt_kocc += my_k;
+                if (room) slab_pos += nl;
+                asm volatile("" ::: "memory");          // (the list is read before the next partition's records overwrite it)
+                PH(7)
+                if (lane == 0) bt_dall += ndist;
+                bt_D += D; bt_N += N; bt_Q += Q; bt_kocc += my_k;
             }
         }
         nrec = nrec_n; rbase = rbase_n; rc0 = rc0_n;
-        nrec_n = nrec_nn; rbase_n = rbase_nn;
     }
     for (ull i = slab_pos + lane; i < slab_end; i += 64u) wo.cnt[i] = 0;
+    PH_FLUSH
     if (bt_dall) atomicAdd(&s_tot[0], bt_dall);
     if (bt_D) { atomicAdd(&s_tot[1], bt_D); atomicAdd(&s_tot[2], bt_N); atomicAdd(&s_tot[3], bt_Q); }
     if (bt_kocc) atomicAdd(&s_tot[4], bt_kocc);

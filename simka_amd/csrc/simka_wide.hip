@@ -260,20 +260,38 @@ k_whuge(const uint32_t *gstart, uint32_t ngroups, const uint32_t *hflag, const u
     huge[hrank[g]] = sp;
 }
 
-// kept group r: entries copied, span bookkeeping (span = the groups whose first entry falls into [sp*C, (sp+1)*C))
+// kept group r: entries copied, span bookkeeping (span = the groups whose first entry falls into [sp*C, (sp+1)*C)).  The groups of
+// a wave are neighbours, so nearly always they all belong to ONE span: its four counters then take one atomic each from the wave
+// instead of one from every lane (thousands of groups per span: the per-lane atomics on four hot words were most of the merge).
 __global__ void __launch_bounds__(256)
 k_wgroups(const uint32_t *gstart, uint32_t ngroups, const uint32_t *kflag, const uint32_t *krank, const uint32_t *eoff, const ull *val,
           uint32_t C, ull *entries, uint32_t *ge, uint32_t *gs, uint32_t *sp_first, uint32_t *sp_ngrp, uint32_t *sp_nent, uint32_t *sp_maxc) {
     const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
-    if (g >= ngroups || !kflag[g]) return;
-    const uint32_t b = gstart[g], s = gstart[g + 1] - b, r = krank[g], e = eoff[g], sp = e / C;
-    uint32_t maxc = 0;
-    for (uint32_t t = 0; t < s; t++) { const ull v = val[b + t]; entries[e + t] = v; const uint32_t c = (uint32_t)v; maxc = c > maxc ? c : maxc; }
-    ge[r] = e; gs[r] = s;
-    atomicMin(&sp_first[sp], r);
-    atomicAdd(&sp_ngrp[sp], 1u);
-    atomicAdd(&sp_nent[sp], s);
-    atomicMax(&sp_maxc[sp], maxc);
+    const bool act = g < ngroups && kflag[g];
+    uint32_t s = 0, r = 0xffffffffu, sp = 0, maxc = 0;
+    if (act) {
+        const uint32_t b = gstart[g], e = eoff[g];
+        s = gstart[g + 1] - b; r = krank[g]; sp = e / C;
+        for (uint32_t t = 0; t < s; t++) { const ull v = val[b + t]; entries[e + t] = v; const uint32_t c = (uint32_t)v; maxc = c > maxc ? c : maxc; }
+        ge[r] = e; gs[r] = s;
+    }
+    const ull am = __ballot(act);
+    if (am == 0ull) return;
+    const uint32_t sp0 = (uint32_t)__builtin_amdgcn_readlane((int)sp, __ffsll((long long)am) - 1);
+    if (__all(!act || sp == sp0)) {
+        uint32_t rmin = r, cnt = act ? 1u : 0u, ssum = s, cmax = maxc;
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) {
+            const uint32_t a_ = __shfl_xor(rmin, o, 64), b_ = __shfl_xor(cnt, o, 64), c_ = __shfl_xor(ssum, o, 64), d_ = __shfl_xor(cmax, o, 64);
+            rmin = a_ < rmin ? a_ : rmin; cnt += b_; ssum += c_; cmax = d_ > cmax ? d_ : cmax;
+        }
+        if ((threadIdx.x & 63u) == 0u) { atomicMin(&sp_first[sp0], rmin); atomicAdd(&sp_ngrp[sp0], cnt); atomicAdd(&sp_nent[sp0], ssum); atomicMax(&sp_maxc[sp0], cmax); }
+    } else if (act) {
+        atomicMin(&sp_first[sp], r);
+        atomicAdd(&sp_ngrp[sp], 1u);
+        atomicAdd(&sp_nent[sp], s);
+        atomicMax(&sp_maxc[sp], maxc);
+    }
 }
 
 __global__ void __launch_bounds__(256)
