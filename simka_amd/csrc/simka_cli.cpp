@@ -382,7 +382,7 @@ static bool for_counted_reads(const Sample &s, const Options &o, uint64_t max_re
 // The files of a sample as raw text for the device-side parser -- only where it parses exactly what the host path would deliver: every
 // read of every listed file (no -max-reads limit, no read filter), plain text (not gzip), below 4 GB per file.  false: use load_sample.
 bool load_sample_raw(const Sample &s, const Options &o, uint64_t max_reads, Packed &out) {
-    if (max_reads || o.min_read_size || o.min_shannon != 0 || o.kmer_size > 31) return false;
+    if (max_reads || o.min_read_size || o.min_shannon != 0) return false;
     std::vector<const std::string *> files;
     for (auto &part : s.parts) for (auto &fn : part) files.push_back(&fn);
     const size_t nparts = std::max<size_t>(1, s.parts.size());

@@ -1054,7 +1054,6 @@ SIMKA_EXPORT int simka_ingest_begin(simka_ctx *ctx, uint32_t sample) {
     if (!ctx) return SIMKA_ERR_INVALID;
     if (sample >= ctx->cfg.nb_samples) return ctx->fail(SIMKA_ERR_INVALID, "simka_ingest_begin: sample index %u out of range", sample);
     if (ctx->counted[sample]) return ctx->fail(SIMKA_ERR_STATE, "simka_ingest_begin: sample %u was already counted", sample);
-    if (ctx->wide) return ctx->fail(SIMKA_ERR_UNSUPPORTED, "simka_ingest_*: kmer_size >= 32 takes host-packed reads");
     HIPCHK(hipSetDevice(ctx->cfg.device));
     // (the lane count is fixed with the geometry, at the first count: until then, what setup_geometry will decide)
     const uint32_t want_lanes = getenv("SIMKA_LANES") ? (uint32_t)std::max(1, atoi(getenv("SIMKA_LANES"))) : 2u;

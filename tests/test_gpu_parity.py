@@ -1215,10 +1215,12 @@ def _stats_via_host_and_device(files_per_sample, k, amin=1):
 
 
 @pytest.mark.gpu
-def test_device_ingest_equals_host_parse(gpu_required):
+@pytest.mark.parametrize("k", [21, 33, 51, 55])
+def test_device_ingest_equals_host_parse(gpu_required, k):
     """simka_ingest_* (FASTA / FASTQ text parsed on the GPU, simka_ingest.hip) against the host parser, bit for bit: multi-line FASTA
     sequences (a fragment continues over the line break), N and other letters (end a fragment), lower case, CR LF, a header without
-    a sequence, no newline at the end of the file, several files per sample (the second one appended at an odd base offset), FASTQ."""
+    a sequence, no newline at the end of the file, several files per sample (the second one appended at an odd base offset), FASTQ.
+    k = 21: one-word k-mers; 33 / 51: two words on the partitioned pipeline; 55: the sort-based path."""
     rng = np.random.default_rng(5)
 
     def seq(n, with_n=False):
@@ -1264,7 +1266,7 @@ def test_device_ingest_equals_host_parse(gpu_required):
         [fastq(b), fastq(a[:77], eol=b"\r\n")],                         # FASTQ, two files
         [fasta(a, width=1000) + b"\n\n"],                               # blank lines at the end only
     ]
-    (th, fh), (td, fd) = _stats_via_host_and_device(files, 21)
+    (th, fh), (td, fd) = _stats_via_host_and_device(files, k)
     assert th == td
     assert np.array_equal(fh, fd)
     assert all(t["K_occ"] > 0 and t["nb_reads"] > 0 for t in th)
