@@ -302,6 +302,13 @@ int simka_profile_get(simka_ctx *ctx, int which, const char **name, uint64_t *nb
 uint32_t simka_default_log2_partitions(uint64_t max_kmers_per_sample, uint32_t kmer_size);
 /* free / total memory of a device in bytes (hipMemGetInfo), for callers that plan how many partition ranges to merge at once */
 int simka_device_memory(int device, uint64_t *free_bytes, uint64_t *total_bytes);
+/* Device buffers for a caller that moves spectra between the GPUs of one process itself -- simka_gather_samples_device on the GPU
+ * that counted the samples, simka_device_copy (a peer copy over xGMI when the devices differ, synchronous), simka_import_samples_device
+ * on the GPU that merges the partition range -- the `simka -nb-gpus` driver: what the reference moves through solid/part_<p>/ files
+ * on a shared disk (ref: src/SimkaPotara.hpp:813-1124) never leaves device memory.  SIMKA_ERR_NOMEM when the allocation fails. */
+int simka_device_alloc(int device, uint64_t nb_bytes, void **p);
+int simka_device_free(int device, void *p);
+int simka_device_copy(int dst_device, void *dst, int src_device, const void *src, uint64_t nb_bytes);
 /* sizes chosen by the ctx (partition bits etc.), for DESIGN/bench reporting */
 int simka_get_geometry(simka_ctx *ctx, uint32_t *log2_level1, uint32_t *log2_level2, uint32_t *log2_subranges,
                        uint64_t *arena_capacity, uint64_t *csr_capacity);

@@ -36,8 +36,12 @@ try:
     base = [b.CLI_PATH, "-in", os.path.join(d, "in.txt"), "-out", os.path.join(d, "out"), "-out-tmp", os.path.join(d, "tmp"), "-kmer-size", str(k),
             "-abundance-min", "2", "-simple-dist", "-max-reads", "-1", "-verbose", "2"]
     occ = float(n) * R * (L - k + 1)
-    for extra, name in ((["-parse-only"], "host ingest only (-parse-only)"), (["-host-parse"], "end to end, host parse"), ([], "end to end, device parse"),
-                        ([], "end to end, device parse (again)")):
+    runs = [(["-parse-only"], "host ingest only (-parse-only)"), (["-host-parse"], "end to end, host parse"), ([], "end to end, device parse"),
+            ([], "end to end, device parse (again)")]
+    if os.environ.get("MGPU"):      # the -nb-gpus routes with every context on this one GPU: spectra device-to-device against the host bounce
+        runs = [([], "one context"), (["-nb-gpus", "2", "-gpu-shared"], "-nb-gpus 2, spectra on the device"), (["-nb-gpus", "2", "-gpu-shared", "-host-spectra"], "-nb-gpus 2, spectra through the host")]
+    sums = []
+    for extra, name in runs:
         t = time.time()
         r = subprocess.run(base + extra, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
         dt = time.time() - t
@@ -46,6 +50,14 @@ try:
             if ln.startswith("main thread") or ln.startswith("process:"):
                 print("   ", ln)
         print("%-34s %7.2f s  %6.2f GB/s of FASTA  %.3g k-mer occurrences/s" % (name, dt, size / dt / 1e9, occ / dt), flush=True)
+        if "-parse-only" not in extra:
+            import hashlib, glob
+            h = hashlib.sha1()
+            for f in sorted(glob.glob(os.path.join(d, "out", "*.csv.gz"))):
+                h.update(open(f, "rb").read())
+            sums.append(h.hexdigest())
+    assert len(set(sums)) <= 1, sums
+    print("matrices identical across the runs:", sums[0][:16] if sums else None)
 finally:
     if os.environ.get("KEEP"):
         print("kept", d)

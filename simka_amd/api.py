@@ -104,6 +104,9 @@ def load_library(build_if_missing=True):
         "simka_gather_samples_device": (i32, [vp, vp, u32, vp, vp, vp]),
         "simka_import_samples_device": (i32, [vp, vp, u32, vp, u64, u64, vp, vp, u64, vp, vp, u64]),
         "simka_device_memory": (i32, [i32, C.POINTER(u64), C.POINTER(u64)]),
+        "simka_device_alloc": (i32, [i32, u64, C.POINTER(vp)]),
+        "simka_device_free": (i32, [i32, vp]),
+        "simka_device_copy": (i32, [i32, vp, i32, vp, u64]),
         "simka_host_alloc": (i32, [u64, C.POINTER(vp)]),
         "simka_host_free": (i32, [vp]),
         "simka_default_log2_partitions": (u32, [u64, u32]),

@@ -49,6 +49,7 @@ struct Options {
     bool same_gpu = false;              // new (tests): all -nb-gpus contexts on GPU -gpu
     long long ingest_chunk = 1ll << 30; // new: bytes of a file handed to the device-side parser at a time (cut at record boundaries)
     bool host_parse = false;            // new: parse + pack every input on the host (default: plain-text inputs without read policies are parsed on the GPU)
+    bool host_spectra = false;          // new: -nb-gpus keeps the spectra in host memory between count and merge (the round-2 route)
     bool gpu_allreduce = false;         // new: -nb-gpus combines the merges' accumulators with one RCCL all-reduce instead of summing them on the host
     long long solid_capacity = 0;       // new (tests): records of the solid-spectrum arena of every context (0: from the free memory)
     int merge_ranges = 0;               // new: >0 keeps the spectra in host memory and merges in that many partition ranges per GPU
@@ -100,7 +101,8 @@ void usage() {
         "       -max-count        (1 arg) :    accepted for compatibility (no job processes here)\n"
         "       -max-merge        (1 arg) :    accepted for compatibility\n"
         "   [gpu options]\n"
-        "       -nb-gpus          (1 arg) :    MI355X devices: samples are counted on GPU i % n, partition ranges merged per GPU  [default '1']\n"
+        "       -nb-gpus          (1 arg) :    MI355X devices: samples are counted on GPU i % n, partition ranges merged per GPU, spectra moved between the GPUs  [default '1']\n"
+        "       -host-spectra     (0 arg) :    with -nb-gpus: keep the k-mer spectra in host memory between count and merge\n"
         "       -merge-ranges     (1 arg) :    keep the k-mer spectra in host memory and merge in this many partition ranges per GPU (0: only when GPU memory requires it)  [default '0']\n"
         "       -gpu              (1 arg) :    first device ordinal  [default '0']\n"
         "       -verbose          (1 arg) :    verbosity level  [default '1']\n";
@@ -134,6 +136,7 @@ Options parse_args(int argc, char **argv) {
         else if (a == "-nb-gpus") o.nb_gpus = atoi(need(i).c_str());
         else if (a == "-gpu") o.first_gpu = atoi(need(i).c_str());
         else if (a == "-gpu-shared") o.same_gpu = true;
+        else if (a == "-host-spectra") o.host_spectra = true;
         else if (a == "-gpu-allreduce") o.gpu_allreduce = true;
         else if (a == "-host-parse") o.host_parse = true;
         else if (a == "-ingest-chunk") o.ingest_chunk = std::min<long long>(std::max<long long>(64, atoll(need(i).c_str())), 0xf0000000ll);
@@ -782,6 +785,38 @@ int main(int argc, char **argv) {
     };
     if (o.verbose) std::cout << "Counting k-mers... (log files are " << tmp << "/log/count_*)" << std::endl;
 
+    // one sample into slot `index` of context c: its files' text parsed on the GPU (simka_ingest.hip), or the host-packed reads.
+    // Returns the library's code (SIMKA_ERR_NOMEM: the caller may take another route); anything else than that and OK is fatal.
+    auto count_into = [&](simka_ctx *c, uint32_t index, uint32_t i, Packed *pkp, uint64_t &n_dev_parsed, uint64_t &n_pieces) -> int {
+        auto chk = [&](int r, const char *what) { if (r != SIMKA_OK && r != SIMKA_ERR_NOMEM) fatal(c, what); return r; };
+        int rc;
+        if (pkp->raw) {
+            if ((rc = chk(simka_ingest_begin(c, index), "simka_ingest_begin")) != SIMKA_OK) return rc;
+            bool irregular = false;
+            for (size_t f = 0; !irregular && f < pkp->texts.size(); f++) {
+                uint64_t nr = 0; int irr = 0;
+                if ((rc = chk(simka_ingest_text(c, index, pkp->texts[f].data(), pkp->texts[f].size(), pkp->formats[f], &nr, &irr), "simka_ingest_text")) != SIMKA_OK) return rc;
+                irregular = irr != 0;
+                if (!irregular && nr == 0 && (f + 1 == pkp->texts.size() || pkp->file_of[f + 1] != pkp->file_of[f]) && (f == 0 || pkp->file_of[f - 1] != pkp->file_of[f]))
+                    break;       // a FILE that delivers no read ends the sample (a file in several pieces has reads in every piece)
+            }
+            if (!irregular) {
+                rc = chk(simka_ingest_count(c, index, nullptr, nullptr), "simka_ingest_count");
+                if (rc == SIMKA_OK) { n_dev_parsed++; n_pieces += pkp->texts.size(); }
+                return rc;
+            }
+            // something the device parser does not take (blank lines inside a file, multi-line FASTQ, ...): the host parser decides
+            Packed hp;
+            if (!load_sample(samples[i], o, max_reads, hp)) die("ERROR: Can't open dataset: " + samples[i].id);
+            simka_reads r;
+            fill_reads(hp, r);
+            return chk(simka_count_sample(c, index, &r), "simka_count_sample");
+        }
+        simka_reads r;
+        fill_reads(*pkp, r);
+        return chk(simka_count_sample(c, index, &r), "simka_count_sample");
+    };
+
     // ---- DIRECT: one GPU, every solid spectrum stays in its HBM arena; count, merge, download.
     // Returns SIMKA_ERR_NOMEM when the spectra do not fit the arena: the caller then takes the host-spectra path below.
     auto direct_run = [&]() -> int {
@@ -808,32 +843,7 @@ int main(int argc, char **argv) {
                 loader.release(i);
                 continue;
             }
-            bool ok = true, counted = false;
-            if (pkp->raw) {       // the files' text goes to the GPU as it is and is parsed there (simka_ingest.hip)
-                ok = soft(simka_ingest_begin(c, i), "simka_ingest_begin");
-                bool irregular = false;
-                for (size_t f = 0; ok && !irregular && f < pkp->texts.size(); f++) {
-                    uint64_t nr = 0; int irr = 0;
-                    ok = soft(simka_ingest_text(c, i, pkp->texts[f].data(), pkp->texts[f].size(), pkp->formats[f], &nr, &irr), "simka_ingest_text");
-                    irregular = irr != 0;
-                    if (ok && !irregular && nr == 0 && (f + 1 == pkp->texts.size() || pkp->file_of[f + 1] != pkp->file_of[f]) && (f == 0 || pkp->file_of[f - 1] != pkp->file_of[f]))
-                        break;       // a FILE that delivers no read ends the sample (a file in several pieces has reads in every piece)
-                }
-                if (ok && !irregular) { ok = soft(simka_ingest_count(c, i, nullptr, nullptr), "simka_ingest_count"); counted = true; n_dev_parsed++; n_pieces += pkp->texts.size(); }
-                else if (ok) {        // something the device parser does not take (blank lines inside a file, multi-line FASTQ, ...): the host parser decides
-                    Packed hp;
-                    if (!load_sample(samples[i], o, max_reads, hp)) die("ERROR: Can't open dataset: " + samples[i].id);
-                    simka_reads r;
-                    fill_reads(hp, r);
-                    ok = soft(simka_count_sample(c, i, &r), "simka_count_sample");
-                    counted = true;
-                }
-            }
-            if (!counted && ok) {
-                simka_reads r;
-                fill_reads(*pkp, r);
-                ok = soft(simka_count_sample(c, i, &r), "simka_count_sample");
-            }
+            const bool ok = soft(count_into(c, i, i, pkp, n_dev_parsed, n_pieces), "counting a sample");
             loader.release(i);     // host buffers may be reused as soon as the count call returns
             t_count += now() - t1;
             if (ok && o.keep_tmp) {      // persist the spectrum so that a later run with more samples skips this one
@@ -854,7 +864,137 @@ int main(int argc, char **argv) {
         return rc;
     };
 
-    // ---- HOST SPECTRA: G GPUs and/or spectra larger than one arena.  Phase 1: sample i is counted over the whole key space by
+    // ---- DEVICE SPECTRA: G GPUs, nothing leaves device memory.  Phase 1: GPU g counts the samples i = g, g + G, ... in ONE context
+    // (text parsed on the GPU like the direct path).  Phase 2: every GPU gathers its samples' records destination-major (the runs of
+    // partition range h of all its samples back to back) into a send buffer and lets its count context go; GPU h copies its
+    // block from every GPU (simka_device_copy: xGMI peer copies), imports the blocks into a merge context, merges its range, and the
+    // heads are added (host, or one RCCL all-reduce with -gpu-allreduce).  The reference moves the same data through the
+    // solid/part_<p>/ files of a shared disk (ref: src/SimkaPotara.hpp:813-1124, src/SimkaMerge.cpp:1164-1264).
+    // Returns SIMKA_ERR_NOMEM when a GPU cannot hold its share: the caller then takes the host-spectra path.
+    auto device_run = [&]() -> int {
+        std::vector<std::vector<uint32_t>> mine(G);
+        for (uint32_t i = 0; i < N; i++) mine[i % G].push_back(i);
+        std::vector<simka_ctx *> cctx(G, nullptr);
+        std::vector<std::vector<uint32_t>> pc(G);                   // [n_g][P] records per (local sample, partition)
+        std::vector<std::vector<simka_sample_totals>> tot(G);
+        std::vector<void *> send_k(G, nullptr), send_c(G, nullptr);
+        std::vector<std::vector<uint64_t>> blk(G, std::vector<uint64_t>(G + 1, 0));      // blk[g][h]: where the block for GPU h starts in g's send buffers
+        std::atomic<int> worst(SIMKA_OK);
+        auto note = [&](int r) { if (r != SIMKA_OK) worst.store(r); return r == SIMKA_OK; };
+        auto lo_of = [&](uint32_t h) { return P * h / G; };
+        uint64_t n_dev_parsed = 0, n_pieces = 0;
+        std::mutex cnt_lock;
+        {
+            SampleLoader loader(samples, o, max_reads, nthreads, nthreads + 2 * G, reuse, !o.host_parse);
+            auto counter = [&](uint32_t g) {
+                const uint32_t n = (uint32_t)mine[g].size();
+                if (n == 0) return;
+                simka_ctx *c = cctx[g] = make_ctx(n, device_of(g));
+                uint64_t ndp = 0, npc = 0;
+                bool ok = true;
+                for (uint32_t j = 0; j < n; j++) {
+                    Packed *pkp;
+                    if (!loader.get(mine[g][j], pkp)) die("ERROR: Can't open dataset: " + samples[mine[g][j]].id);
+                    if (ok) ok = note(count_into(c, j, mine[g][j], pkp, ndp, npc));        // (after a failure: keep the loader's window moving)
+                    loader.release(mine[g][j]);
+                }
+                { std::lock_guard<std::mutex> lk(cnt_lock); n_dev_parsed += ndp; n_pieces += npc; }
+                if (!ok) return;
+                std::vector<uint32_t> idx(n);
+                for (uint32_t j = 0; j < n; j++) idx[j] = j;
+                pc[g].assign((size_t)n * P, 0); tot[g].resize(n);
+                int rc = simka_samples_spectrum_info(c, idx.data(), n, pc[g].data(), tot[g].data());
+                if (rc != SIMKA_OK && rc != SIMKA_ERR_NOMEM) fatal(c, "simka_samples_spectrum_info");
+                if (!note(rc)) return;
+                // destination-major layout of the send buffers
+                std::vector<uint64_t> off((size_t)n * P);
+                uint64_t run = 0;
+                for (uint32_t h = 0; h < G; h++) {
+                    blk[g][h] = run;
+                    for (uint32_t j = 0; j < n; j++)
+                        for (uint64_t p = lo_of(h); p < lo_of(h + 1); p++) { off[(size_t)j * P + p] = run; run += pc[g][(size_t)j * P + p]; }
+                }
+                blk[g][G] = run;
+                if (!note(simka_device_alloc(device_of(g), run * 8 + 8, &send_k[g])) || !note(simka_device_alloc(device_of(g), run * 4 + 8, &send_c[g]))) return;
+                rc = simka_gather_samples_device(c, idx.data(), n, off.data(), send_k[g], send_c[g]);
+                if (rc != SIMKA_OK) fatal(c, "simka_gather_samples_device");
+            };
+            std::vector<std::thread> th;
+            for (uint32_t g = 0; g < G; g++) th.emplace_back(counter, g);
+            for (auto &t : th) t.join();
+        }
+        for (uint32_t g = 0; g < G; g++) if (cctx[g]) simka_destroy(cctx[g]);         // the arenas make room for the merge contexts
+        auto drop_send = [&] { for (uint32_t g = 0; g < G; g++) { simka_device_free(device_of(g), send_k[g]); simka_device_free(device_of(g), send_c[g]); send_k[g] = send_c[g] = nullptr; } };
+        if (worst.load() != SIMKA_OK) { drop_send(); return worst.load(); }
+        for (uint32_t g = 0; g < G; g++) for (size_t j = 0; j < mine[g].size(); j++) totals[mine[g][j]] = tot[g][j];
+        if (o.verbose >= 2) std::cout << "ingest: " << n_dev_parsed << " samples parsed on the GPUs (" << n_pieces << " pieces of text), " << N - n_dev_parsed << " on the host" << std::endl;
+        if (o.verbose) std::cout << std::endl << "Merging k-mer counts and computing distances... (spectra exchanged between the GPUs: "
+                                 << [&] { uint64_t t = 0; for (uint32_t g = 0; g < G; g++) t += blk[g][G]; return t; }() << " solid k-mers)" << std::endl;
+        std::mutex acc_lock;
+        bool have_tail = false;
+        bool use_rccl = o.gpu_allreduce && !o.same_gpu;
+        uint8_t comm_id[SIMKA_COMM_ID_BYTES];
+        if (use_rccl && simka_comm_unique_id(comm_id) != SIMKA_OK) {
+            std::cerr << "-gpu-allreduce: " << simka_comm_last_error(nullptr) << "; summing on the host" << std::endl;
+            use_rccl = false;
+        }
+        auto merger = [&](uint32_t h) {
+            simka_ctx *c = make_ctx(N, device_of(h));
+            simka_comm *comm = nullptr;
+            if (use_rccl && simka_comm_create(comm_id, (int)G, (int)h, device_of(h), &comm) != SIMKA_OK)
+                die(std::string("EXCEPTION: simka_comm_create: ") + simka_comm_last_error(nullptr));
+            const uint64_t lo = lo_of(h), width = lo_of(h + 1) - lo;
+            uint64_t nrec = 0;
+            for (uint32_t g = 0; g < G; g++) nrec += blk[g][h + 1] - blk[g][h];
+            void *rk = nullptr, *rc_ = nullptr;
+            bool ok = note(simka_device_alloc(device_of(h), nrec * 8 + 8, &rk)) && note(simka_device_alloc(device_of(h), nrec * 4 + 8, &rc_));
+            uint64_t at = 0;
+            for (uint32_t g = 0; ok && g < G; g++) {
+                const uint32_t n = (uint32_t)mine[g].size();
+                const uint64_t cnt = blk[g][h + 1] - blk[g][h];
+                if (n == 0) continue;
+                if (simka_device_copy(device_of(h), (char *)rk + at * 8, device_of(g), (const char *)send_k[g] + blk[g][h] * 8, cnt * 8) != SIMKA_OK ||
+                    simka_device_copy(device_of(h), (char *)rc_ + at * 4, device_of(g), (const char *)send_c[g] + blk[g][h] * 4, cnt * 4) != SIMKA_OK)
+                    die("EXCEPTION: simka_device_copy between GPUs failed");
+                std::vector<uint32_t> pcs((size_t)n * width);
+                std::vector<uint64_t> ino((size_t)n * width);
+                uint64_t run = 0;
+                for (uint32_t j = 0; j < n; j++)
+                    for (uint64_t p = 0; p < width; p++) { pcs[(size_t)j * width + p] = pc[g][(size_t)j * P + lo + p]; ino[(size_t)j * width + p] = run; run += pcs[(size_t)j * width + p]; }
+                const int rc = simka_import_samples_device(c, mine[g].data(), n, tot[g].data(), lo, width, pcs.data(), ino.data(), P, (const char *)rk + at * 8, (const char *)rc_ + at * 4, cnt);
+                if (rc != SIMKA_OK && rc != SIMKA_ERR_NOMEM) fatal(c, "simka_import_samples_device");
+                ok = note(rc);
+                at += cnt;
+            }
+            simka_device_free(device_of(h), rk); simka_device_free(device_of(h), rc_);
+            if (ok) {
+                const int rc = simka_merge(c);
+                if (rc != SIMKA_OK && rc != SIMKA_ERR_NOMEM) fatal(c, "simka_merge");
+                ok = note(rc);
+            }
+            if (use_rccl) {        // (every rank must reach the collective: a failed rank contributes zeros... it cannot: all or nothing)
+                if (!ok) die("EXCEPTION: a GPU ran out of memory under -gpu-allreduce; run without it");
+                if (simka_stats_allreduce_head(c, comm) != SIMKA_OK) fatal(c, "simka_stats_allreduce_head");
+                if (h == 0 && simka_stats_download(c, flat.data(), nw, nullptr) != SIMKA_OK) fatal(c, "simka_stats_download");
+                else if (h != 0 && simka_sync(c) != SIMKA_OK) fatal(c, "simka_sync");
+            } else if (ok) {
+                std::vector<uint64_t> shard(nw);
+                if (simka_stats_download(c, shard.data(), nw, nullptr) != SIMKA_OK) fatal(c, "simka_stats_download");
+                std::lock_guard<std::mutex> lk(acc_lock);          // SimkaStatistics::operator+= over the ranges (imported totals are global)
+                for (uint64_t w = 0; w < lay[5]; w++) flat[w] += shard[w];
+                if (!have_tail) { for (uint64_t w = lay[5]; w < nw; w++) flat[w] = shard[w]; have_tail = true; }
+            }
+            if (comm) simka_comm_destroy(comm);
+            simka_destroy(c);
+        };
+        std::vector<std::thread> th;
+        for (uint32_t h = 0; h < G; h++) th.emplace_back(merger, h);
+        for (auto &t : th) t.join();
+        drop_send();
+        return worst.load();
+    };
+
+    // ---- HOST SPECTRA: spectra larger than the GPUs' memory, -keep-tmp or two-word k-mers with several GPUs.  Phase 1: sample i is counted over the whole key space by
     // a one-sample context on GPU i % G and its spectrum is taken to host memory.  Phase 2: the partition space is cut into
     // V = G * R ranges; GPU g imports the slice of range v = g, g + G, ... of every sample, merges it and adds its pair
     // accumulators to the total (the reference: one simkaMerge job per partition, summed by SimkaStatistics::operator+=).
@@ -964,7 +1104,14 @@ int main(int argc, char **argv) {
     };
 
     bool host_mode = G > 1 || o.merge_ranges > 0;
-    if (!host_mode) {
+    if (G > 1 && o.merge_ranges <= 0 && !o.keep_tmp && !o.host_spectra && o.kmer_size <= 31 && N >= G) {
+        const int rc = device_run();
+        if (rc == SIMKA_OK) host_mode = false;
+        else {
+            if (o.verbose) std::cout << "The solid k-mer spectra do not fit the GPUs' memory at once: recounting with the spectra in host memory and merging by partition ranges" << std::endl;
+            std::fill(flat.begin(), flat.end(), 0);
+        }
+    } else if (!host_mode) {
         if (o.verbose >= 2) std::cout << "process: " << since_main() << " s before the first context" << std::endl;
         const int rc = direct_run();
         if (o.verbose >= 2) std::cout << "process: " << since_main() << " s after count + merge (context destroyed)" << std::endl;

@@ -2190,6 +2190,29 @@ SIMKA_EXPORT int simka_device_memory(int device, uint64_t *free_bytes, uint64_t 
     return SIMKA_OK;
 }
 
+// device buffers of a caller that moves spectra between GPUs itself (simka_gather_samples_device on one, simka_import_samples_device
+// on another): no host bounce, no HIP in the caller
+SIMKA_EXPORT int simka_device_alloc(int device, uint64_t nb_bytes, void **p) {
+    if (!p) return SIMKA_ERR_INVALID;
+    *p = nullptr;
+    if (hipSetDevice(device) != hipSuccess) return SIMKA_ERR_HIP;
+    if (hipMalloc(p, nb_bytes ? nb_bytes : 1) != hipSuccess) { (void)hipGetLastError(); *p = nullptr; return SIMKA_ERR_NOMEM; }
+    return SIMKA_OK;
+}
+SIMKA_EXPORT int simka_device_free(int device, void *p) {
+    if (!p) return SIMKA_OK;
+    if (hipSetDevice(device) != hipSuccess) return SIMKA_ERR_HIP;
+    return hipFree(p) == hipSuccess ? SIMKA_OK : SIMKA_ERR_HIP;
+}
+SIMKA_EXPORT int simka_device_copy(int dst_device, void *dst, int src_device, const void *src, uint64_t nb_bytes) {
+    if (nb_bytes == 0) return SIMKA_OK;
+    if (!dst || !src) return SIMKA_ERR_INVALID;
+    if (hipSetDevice(dst_device) != hipSuccess) return SIMKA_ERR_HIP;
+    // (distinct devices: a peer copy over xGMI; the same device: an ordinary device-to-device copy).  Synchronous.
+    const hipError_t e = dst_device == src_device ? hipMemcpy(dst, src, nb_bytes, hipMemcpyDeviceToDevice) : hipMemcpyPeer(dst, dst_device, src, src_device, nb_bytes);
+    return e == hipSuccess ? SIMKA_OK : SIMKA_ERR_HIP;
+}
+
 SIMKA_EXPORT int simka_get_geometry(simka_ctx *ctx, uint32_t *l1, uint32_t *l2, uint32_t *t, uint64_t *arena, uint64_t *csr) {
     if (!ctx) return SIMKA_ERR_INVALID;
     if (l1) *l1 = ctx->wide ? ctx->key.l1 : ctx->skm.l1; if (l2) *l2 = ctx->wide ? ctx->key.l2 : ctx->skm.l2; if (t) *t = ctx->key.t;

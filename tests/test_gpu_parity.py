@@ -800,6 +800,41 @@ def test_cli_multi_gpu_sample_shards_on_one_device(gpu_required, golden_dir, tmp
     assert run(str(tmp_path / "o2"), 5 - gpus).count("k-mer spectrum reused") == 5        # other GPU count, same spectra
 
 
+@pytest.mark.parametrize("gpus,extra", [(2, []), (3, []), (5, []), (2, ["-host-spectra"]), (3, ["-host-parse"]), (2, ["-max-reads", "300"])])
+def test_cli_multi_gpu_spectra_stay_on_the_devices(gpu_required, golden_dir, tmp_path, gpus, extra):
+    """`simka -nb-gpus G` without -keep-tmp: GPU g counts the samples i = g, g + G, ... in one context (text parsed on the GPU), the
+    spectra go from the send buffer of the GPU that counted them to the GPU that merges their partition range (simka_device_copy:
+    a peer copy between distinct devices, here -gpu-shared) and never touch the host.  The goldens byte for byte, -complex-dist
+    included; -host-spectra takes the older route; a read policy (host parser) goes through the same exchange."""
+    import subprocess
+    from simka_amd import build as b
+    out = str(tmp_path / "o")
+    base = [b.CLI_PATH, "-in", os.path.join(golden_dir, "example", "simka_input.txt"), "-out-tmp", str(tmp_path / "tmp"), "-simple-dist", "-complex-dist",
+            "-kmer-size", "31", "-abundance-min", "2", "-verbose", "2"] + extra
+    r = subprocess.run(base + ["-out", out, "-gpu-shared", "-nb-gpus", str(gpus)], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    assert r.returncode == 0, r.stdout
+    assert ("spectra exchanged between the GPUs" in r.stdout) == ("-host-spectra" not in extra), r.stdout
+    if "-max-reads" in extra:          # no goldens for the policy: against the one-GPU run
+        ref = str(tmp_path / "ref")
+        r1 = subprocess.run(base + ["-out", ref], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+        assert r1.returncode == 0, r1.stdout
+        names = sorted(os.path.basename(f) for f in glob.glob(os.path.join(ref, "*.csv.gz")))
+        assert len(names) >= 20
+        for nme in names:
+            with gzip.open(os.path.join(ref, nme), "rb") as f, gzip.open(os.path.join(out, nme), "rb") as h:
+                assert f.read() == h.read(), nme
+        return
+    truth = os.path.join(golden_dir, "truth", "results_k31_t2")
+    n = 0
+    for gzf in glob.glob(os.path.join(out, "*.csv.gz")):
+        ref = os.path.join(truth, os.path.basename(gzf)[:-3])
+        if os.path.exists(ref):
+            with gzip.open(gzf, "rb") as f, open(ref, "rb") as h:
+                assert f.read() == h.read(), os.path.basename(gzf)
+            n += 1
+    assert n == 20
+
+
 def test_rccl_single_rank_runs_both_multi_gpu_protocols(gpu_required):
     """scripts/dist_smoke.py: torch.distributed on the real "nccl" (= RCCL) backend with one rank -- the partition-shard protocol
     and the whole sample-shard exchange (all_to_all_single with uneven splits, all_gather, head all-reduce; rank 0 sends to
