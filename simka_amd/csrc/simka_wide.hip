@@ -228,6 +228,99 @@ k_wemit(const ull *khi, const ull *klo, const uint32_t *start, const uint32_t *s
     ohi[o] = khi[s]; olo[o] = klo[s]; ocnt[o] = start[j + 1] - s;
 }
 
+// ---- merge: grouping without a full sort ------------------------------------------------------------------------------------
+// What the CSR needs is every k-mer's records side by side, not an order.  So the records are scattered into buckets of ~750 by a
+// hash of the k-mer (two 8-bit passes of the radix sort on the bucket number, not nine on the k-mer), and one block per bucket
+// finishes in LDS: the bucket's keys are staged, a table of first-record indices groups them (claim a slot with the record's
+// index, or find a record with the same two words there), a scan of the group sizes gives every group its place.
+#define WL_BLOCK 256
+#define WL_CAP 2048
+#define WL_TS 4096
+__device__ __forceinline__ uint32_t wide_hash32(ull hi, ull lo) {
+    ull x = lo ^ (hi * 0x9E3779B97F4A7C15ull);
+    x ^= x >> 31; x *= 0xD6E8FEB86659FD93ull; x ^= x >> 29;
+    return (uint32_t)(x >> 32);
+}
+// one sample's records: bucket number + index for the sort, and (hi, lo, sample << 32 | count) packed into 32 bytes -- k_wlocal_group
+// fetches a record with one sector instead of three
+__global__ void __launch_bounds__(256)
+k_wbucket_key(const ull *hi, const ull *lo, const uint32_t *cnt, uint64_t off, uint64_t n, uint32_t sample, uint32_t bits, ull *key, uint32_t *idx, ulonglong4 *pack) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const ull h_ = hi[off + i], l_ = lo[off + i];
+    key[off + i] = (ull)(wide_hash32(h_, l_) >> (32u - bits)); idx[off + i] = (uint32_t)(off + i);
+    pack[off + i] = make_ulonglong4(h_, l_, ((ull)sample << 32) | cnt[off + i], 0ull);
+}
+// bstart[b] = first position of the sorted bucket numbers that is >= b (b = 0 .. nb); the largest bucket
+__global__ void __launch_bounds__(256)
+k_wbucket_bounds(const ull *key, uint64_t n, uint32_t nb, uint32_t *bstart, uint32_t *maxsize) {
+    const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b > nb) return;
+    auto lower = [&](ull v) { uint64_t a = 0, e = n; while (a < e) { const uint64_t m = (a + e) >> 1; if (key[m] < v) a = m + 1; else e = m; } return (uint32_t)a; };
+    const uint32_t lo_ = lower((ull)b);
+    bstart[b] = lo_;
+    if (b < nb) atomicMax(maxsize, lower((ull)b + 1ull) - lo_);
+}
+__global__ void __launch_bounds__(WL_BLOCK)
+k_wlocal_group(const uint32_t *bstart, const uint32_t *idx, const ulonglong4 *pack, ull *o_hi, ull *o_lo, ull *o_val) {
+    __shared__ ull khi[WL_CAP], klo[WL_CAP];
+    __shared__ uint32_t first[WL_TS], cnt[WL_TS];
+    __shared__ uint32_t wsum[WL_BLOCK / 64];
+    const uint32_t tid = threadIdx.x;
+    const uint32_t base = bstart[blockIdx.x], n = bstart[blockIdx.x + 1] - base;
+    if (n == 0) return;
+    constexpr uint32_t RPT = WL_CAP / WL_BLOCK, SPT = WL_TS / WL_BLOCK;
+    for (uint32_t i = tid; i < WL_TS; i += WL_BLOCK) { first[i] = 0xffffffffu; cnt[i] = 0; }
+    uint32_t my_slot[RPT]; ull my_val[RPT];
+#pragma unroll
+    for (uint32_t q = 0; q < RPT; q++) {
+        const uint32_t r = q * WL_BLOCK + tid;
+        my_val[q] = 0; my_slot[q] = 0;
+        if (r < n) { const ulonglong4 e = pack[idx[base + r]]; khi[r] = e.x; klo[r] = e.y; my_val[q] = e.z; }
+    }
+    __syncthreads();
+#pragma unroll
+    for (uint32_t q = 0; q < RPT; q++) {
+        const uint32_t r = q * WL_BLOCK + tid;
+        if (r < n) {
+            const ull h_ = khi[r], l_ = klo[r];
+            uint32_t slot = (wide_hash32(l_, h_) * 0x9E3779B1u) >> (32u - 12u);          // (other bits than the bucket number's)
+            for (;;) {
+                const uint32_t prev = atomicCAS(&first[slot], 0xffffffffu, r);
+                if (prev == 0xffffffffu || (khi[prev] == h_ && klo[prev] == l_)) break;
+                slot = (slot + 1u) & (WL_TS - 1u);
+            }
+            my_slot[q] = slot;
+            atomicAdd(&cnt[slot], 1u);
+        }
+    }
+    __syncthreads();
+    // exclusive scan of the group sizes over the slots: cnt[] becomes every group's cursor
+    {
+        uint32_t c[SPT], sum = 0;
+#pragma unroll
+        for (uint32_t j = 0; j < SPT; j++) { c[j] = cnt[tid * SPT + j]; sum += c[j]; }
+        uint32_t inc = sum;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { const uint32_t t = __shfl_up(inc, o, 64); if ((tid & 63u) >= (uint32_t)o) inc += t; }
+        if ((tid & 63u) == 63u) wsum[tid >> 6] = inc;
+        __syncthreads();
+        uint32_t run = inc - sum;
+        for (uint32_t w_ = 0; w_ < (tid >> 6); w_++) run += wsum[w_];
+#pragma unroll
+        for (uint32_t j = 0; j < SPT; j++) { cnt[tid * SPT + j] = run; run += c[j]; }
+    }
+    __syncthreads();
+#pragma unroll
+    for (uint32_t q = 0; q < RPT; q++) {
+        const uint32_t r = q * WL_BLOCK + tid;
+        if (r < n) {
+            const uint32_t pos = base + atomicAdd(&cnt[my_slot[q]], 1u);
+            o_hi[pos] = khi[r]; o_lo[pos] = klo[r]; o_val[pos] = my_val[q];
+        }
+    }
+}
+
 // ---- merge ----
 __global__ void __launch_bounds__(256)
 k_wvals(const uint32_t *cnt, uint64_t off, uint64_t n, uint32_t sample, ull *val) {
@@ -525,11 +618,39 @@ int simka_wide_merge(SimkaWide *w, uint32_t span_cap, SimkaWideCsr *out) {
     ull *val, *hi1, *lo1, *tkey, *val2; uint32_t *idx0, *idx1;
     if ((rc = wide_buf(w, 0, M, &val)) || (rc = wide_buf(w, 1, M, &hi1)) || (rc = wide_buf(w, 2, M, &lo1)) || (rc = wide_buf(w, 3, M, &tkey)) ||
         (rc = wide_buf(w, 4, M, &val2)) || (rc = wide_buf(w, 5, M + 2, &idx0)) || (rc = wide_buf(w, 6, M + 2, &idx1))) return rc;
-    for (uint32_t s = 0; s < N; s++)
-        if (w->s_n[s]) hipLaunchKernelGGL(k_wvals, grid_for(w->s_n[s]), dim3(256), 0, w->stream, w->a_cnt, w->s_off[s], w->s_n[s], s, val);
-    const uint32_t hi_bits = (w->W > 64 ? w->W - 64 : 0) + 1;
-    if ((rc = wide_sort(w, M, hi_bits, w->a_hi, w->a_lo, hi1, lo1, tkey, idx0, idx1))) return rc;     // idx0 = final permutation
-    hipLaunchKernelGGL(k_wgather, grid_for(M), dim3(256), 0, w->stream, val, idx0, val2, M);
+    // the records of every k-mer side by side in hi1 / lo1 / val2: buckets by hash + grouping in LDS; a bucket beyond the LDS staging
+    // (a k-mer in thousands of samples) or SIMKA_WIDE_MERGE_SORT: the full sort by k-mer
+    bool grouped = false;
+    if (!getenv("SIMKA_WIDE_MERGE_SORT") && M < ((uint64_t)1 << 31)) {
+        uint32_t bits = 1;
+        while ((M >> bits) > 1024u && bits < 24u) bits++;
+        const uint32_t nb = 1u << bits;
+        uint32_t *bstart, *d_max;
+        char *tmp;
+        ulonglong4 *pack;
+        if ((rc = wide_buf(w, 7, (uint64_t)nb + 8, &bstart)) || (rc = wide_buf(w, 11, wsort_tmp_bytes<uint32_t>(M), &tmp)) || (rc = wide_buf(w, 9, M, &pack))) return rc;
+        d_max = bstart + nb + 2;
+        WCHK(hipMemsetAsync(d_max, 0, 4, w->stream));
+        for (uint32_t s = 0; s < N; s++)
+            if (w->s_n[s]) hipLaunchKernelGGL(k_wbucket_key, grid_for(w->s_n[s]), dim3(256), 0, w->stream, w->a_hi, w->a_lo, w->a_cnt, w->s_off[s], w->s_n[s], s, bits, tkey, idx0, pack);
+        WCHK(wsort_pairs<uint32_t>(tkey, hi1, idx0, idx1, M, bits, tmp, w->stream));          // (hi1: the sorted bucket numbers, until k_wlocal_group overwrites it)
+        hipLaunchKernelGGL(k_wbucket_bounds, grid_for((uint64_t)nb + 1), dim3(256), 0, w->stream, hi1, M, nb, bstart, d_max);
+        uint32_t mx = 0;
+        WCHK(hipMemcpyAsync(&mx, d_max, 4, hipMemcpyDeviceToHost, w->stream));
+        WCHK(hipStreamSynchronize(w->stream));
+        if (mx <= (uint32_t)WL_CAP) {
+            hipLaunchKernelGGL(k_wlocal_group, dim3(nb), dim3(WL_BLOCK), 0, w->stream, bstart, idx1, pack, hi1, lo1, val2);
+            WCHK(hipGetLastError());
+            grouped = true;
+        }
+    }
+    if (!grouped) {
+        for (uint32_t s = 0; s < N; s++)
+            if (w->s_n[s]) hipLaunchKernelGGL(k_wvals, grid_for(w->s_n[s]), dim3(256), 0, w->stream, w->a_cnt, w->s_off[s], w->s_n[s], s, val);
+        const uint32_t hi_bits = (w->W > 64 ? w->W - 64 : 0) + 1;
+        if ((rc = wide_sort(w, M, hi_bits, w->a_hi, w->a_lo, hi1, lo1, tkey, idx0, idx1))) return rc;     // idx0 = final permutation
+        hipLaunchKernelGGL(k_wgather, grid_for(M), dim3(256), 0, w->stream, val, idx0, val2, M);
+    }
     // groups = runs of equal k-mers
     uint32_t *flag = idx0, *rank = idx1, *gstart, *kflag, *ksize, *krank, *eoff;
     if ((rc = wide_buf(w, 7, M + 2, &gstart)) || (rc = wide_buf(w, 8, M + 2, &kflag)) || (rc = wide_buf(w, 9, M + 2, &ksize))) return rc;

@@ -1004,6 +1004,14 @@ def test_wide_kmers_partitions_beyond_the_tables(gpu_required, oracle_mod, monke
     _wide_case(oracle_mod, 37, 2, 3, 4000, 120, expect=expect)
 
 
+@pytest.mark.parametrize("k,n", [(33, 6), (47, 4), (63, 3)])
+def test_wide_merge_by_full_sort_equals_the_grouped_merge(gpu_required, oracle_mod, monkeypatch, k, n):
+    """The merge of two-word k-mers groups the records by hash bucket + an LDS table (k_wlocal_group); the full sort by k-mer stays as
+    the route for buckets beyond the LDS staging and is forced here: same oracle, same checks."""
+    monkeypatch.setenv("SIMKA_WIDE_MERGE_SORT", "1")
+    _wide_case(oracle_mod, k, 1, n, 3000, 130, expect="partitioned" if k <= 51 else "sorted")
+
+
 def test_example_goldens_through_the_sort_path(gpu_required, golden_dir, tmp_path, monkeypatch):
     """The reference's own example (k = 31, abundance-min 2, all 20 matrices) through the sort-based path: the CSV bytes of
     tests/truth must come out of BOTH pipelines."""
