@@ -48,9 +48,9 @@ WORKLOADS = {
     # 1/10-scale C3 (same shape, 1M reads per sample)
     "c3_10": dict(n=100, reads=1_000_000, L=150, k=31, amin=2, simple=True,
                   desc="100 samples x 1M 150 bp reads (C3 at 1/10 read depth), k=31, -simple-dist"),
-    # C2's reads at k = 33: two-word k-mers -- counted per minimizer partition (k_skm_count_wide_fast), merged by sorting (simka_wide.hip)
+    # C2's reads at k = 33: two-word k-mers -- counted per minimizer partition (k_skm_count_wide_fast), merged by hash buckets + LDS grouping (simka_wide.hip)
     "c2_k33": dict(n=10, reads=1_000_000, L=100, k=33, amin=2, simple=False,
-                   desc="10 synthetic samples x 1M 100 bp reads, k=33 (two-word k-mers: partitioned count, sorted merge), Bray-Curtis + Jaccard"),
+                   desc="10 synthetic samples x 1M 100 bp reads, k=33 (two-word k-mers: partitioned count, bucketed merge), Bray-Curtis + Jaccard"),
     # BASELINE.json configs[4] shape at 1/50 read depth: the tiled (N > LDS tile) pair accumulator + -complex-dist
     "c5_50": dict(n=500, reads=100_000, L=150, k=31, amin=2, simple=True, complex=True,
                   desc="500 samples x 100k 150 bp reads (C5 at 1/50 read depth), k=31, -simple-dist -complex-dist"),

@@ -50,7 +50,7 @@ typedef struct simka_config {
     uint32_t nb_samples;         /* N, SimkaStatistics::_nbBanks (1..65535) */
     uint32_t kmer_size;          /* -kmer-size, 1..63.  k <= 31 (one 64-bit word, Kmer<span=32>): the hash pipeline.  32..63 (two words,
                                   * Kmer<span=64>): counted on the same minimizer-partitioned pipeline up to k = 51, by sorting all
-                                  * occurrences from 52 on (~5x slower); merged by sorting; a partition shard keeps the k-mers that hash to it */
+                                  * occurrences from 52 on (~5x slower); merged by hash buckets + LDS grouping; a partition shard keeps the k-mers that hash to it */
     uint32_t abundance_min;      /* -abundance-min (ref: src/minikc/MiniKC.hpp:56) */
     uint32_t abundance_max;      /* -abundance-max, clamped to 999999999 (ref: src/core/SimkaAlgorithm.cpp:188) */
     uint32_t dist_flags;         /* SIMKA_DIST_* */

@@ -748,10 +748,25 @@ static int run_count_kernels(simka_ctx *ctx, uint32_t sample, const SimkaScanArg
 #ifdef SIMKA_PHASE_PROF
     {   // debug build: per-phase wall_clock64 ticks of thread 0 of every k_skm_count_fast block, printed per sample
         static ull *d_phase = nullptr;
-        if (!d_phase) { HIPCHK(hipMalloc(&d_phase, 128)); HIPCHK(hipMemset(d_phase, 0, 128)); }
+        const size_t phase_bytes = (16 + 2 * 2048) * 8;
+        if (!d_phase) { HIPCHK(hipMalloc(&d_phase, phase_bytes)); HIPCHK(hipMemset(d_phase, 0, phase_bytes)); }
         else {
             HIPCHK(hipDeviceSynchronize());
-            ull h[16]; HIPCHK(hipMemcpy(h, d_phase, 128, hipMemcpyDeviceToHost)); HIPCHK(hipMemset(d_phase, 0, 128));
+            ull h[16]; HIPCHK(hipMemcpy(h, d_phase, 128, hipMemcpyDeviceToHost));
+            {   // when the blocks started and ended, relative to the first start, as deciles
+                std::vector<ull> se(2 * 2048);
+                HIPCHK(hipMemcpy(se.data(), d_phase + 16, se.size() * 8, hipMemcpyDeviceToHost));
+                std::vector<ull> st_, en_;
+                for (size_t b_ = 0; b_ < 2048; b_++) if (se[2 * b_ + 1]) { st_.push_back(se[2 * b_]); en_.push_back(se[2 * b_ + 1]); }
+                if (!st_.empty()) {
+                    const ull t0_ = *std::min_element(st_.begin(), st_.end());
+                    std::sort(st_.begin(), st_.end()); std::sort(en_.begin(), en_.end());
+                    fprintf(stderr, "k_skm_count_fast blocks: %zu; starts (ticks after the first) p50 %llu p90 %llu max %llu; ends p10 %llu p25 %llu p50 %llu p75 %llu p90 %llu max %llu\n", st_.size(),
+                            st_[st_.size() / 2] - t0_, st_[st_.size() * 9 / 10] - t0_, st_.back() - t0_, en_[en_.size() / 10] - t0_, en_[en_.size() / 4] - t0_, en_[en_.size() / 2] - t0_,
+                            en_[en_.size() * 3 / 4] - t0_, en_[en_.size() * 9 / 10] - t0_, en_.back() - t0_);
+                }
+            }
+            HIPCHK(hipMemset(d_phase, 0, phase_bytes));
             if (h[12]) fprintf(stderr, "k_skm_count_fast counters: per wave and partition %.1f k-mers, %.1f queue entries left after the last batch, %.2f final drain passes\n",
                                (double)h[8] / h[12], (double)h[14] / h[12], (double)h[13] / h[12]);
             if (h[11]) fprintf(stderr, "k_skm_count_fast blocks: busy time of the slowest block %.0f ticks, mean %.0f (%.1f %% above the mean)\n", (double)h[9], (double)h[10] / h[11], 100.0 * ((double)h[9] * h[11] / h[10] - 1.0));

@@ -1531,7 +1531,8 @@ k_skm_count_fast(const uint4 *recs, const uint32_t *pstart, const uint32_t *pcnt
     PH_FLUSH
 #ifdef SIMKA_PHASE_PROF
     if (lane == 0 && o.phase) for (int i_ = 0; i_ < 8; i_++) if (i_ < 1 || i_ > 3) atomicAdd(&o.phase[8 + i_], dbg[i_]);
-    if (tid == 0 && o.phase) { const ull el = wall_clock64() - blk_t0; atomicMax(&o.phase[9], el); atomicAdd(&o.phase[10], el); atomicAdd(&o.phase[11], 1ull); }
+    if (tid == 0 && o.phase) { const ull t1_ = wall_clock64(), el = t1_ - blk_t0; atomicMax(&o.phase[9], el); atomicAdd(&o.phase[10], el); atomicAdd(&o.phase[11], 1ull);
+                               if (blockIdx.x < 2048u) { o.phase[16 + 2 * blockIdx.x] = blk_t0; o.phase[17 + 2 * blockIdx.x] = t1_; } }
 #endif
     if (o.hist) {
         __syncthreads();
