@@ -229,13 +229,13 @@ k_wemit(const ull *khi, const ull *klo, const uint32_t *start, const uint32_t *s
 }
 
 // ---- merge: grouping without a full sort ------------------------------------------------------------------------------------
-// What the CSR needs is every k-mer's records side by side, not an order.  So the records are scattered into buckets of ~750 by a
-// hash of the k-mer (two 8-bit passes of the radix sort on the bucket number, not nine on the k-mer), and one block per bucket
-// finishes in LDS: the bucket's keys are staged, a table of first-record indices groups them (claim a slot with the record's
-// index, or find a record with the same two words there), a scan of the group sizes gives every group its place.
+// What the CSR needs is every k-mer's records side by side, not an order.  So the records are scattered into buckets of 450..900 by a
+// hash of the k-mer (two or three 8-bit passes of the radix sort on the bucket number, not nine on the k-mer), and one block per bucket
+// finishes in LDS: a table of the bucket's k-mers counts the records of each, a scan of the counts gives every group its place.
 #define WL_BLOCK 256
-#define WL_CAP 2048
-#define WL_TS 4096
+#define WL_RPT 4              // records a thread keeps in registers between the two passes (buckets of up to 1024 records: all of them)
+#define WL_TS 2048
+#define WL_TSL 11
 __device__ __forceinline__ uint32_t wide_hash32(ull hi, ull lo) {
     ull x = lo ^ (hi * 0x9E3779B97F4A7C15ull);
     x ^= x >> 31; x *= 0xD6E8FEB86659FD93ull; x ^= x >> 29;
@@ -261,45 +261,74 @@ k_wbucket_bounds(const ull *key, uint64_t n, uint32_t nb, uint32_t *bstart, uint
     bstart[b] = lo_;
     if (b < nb) atomicMax(maxsize, lower((ull)b + 1ull) - lo_);
 }
+// the table of a bucket: claim a slot with a compare-and-swap on the high word (never all ones: <= 62 bits), store the low word, then
+// count -- a lane that finds its high word in a slot compares the low word once the counter says it is there (the LDS serves a wave's
+// operations in order: counter > 0 implies the low word is written).  Returns the slot (its counter one up), or ~0 when the table is
+// (nearly) full.
+template <bool LOOKUP>
+__device__ __forceinline__ uint32_t wl_slot(ull *thi, ull *tlo, uint32_t *tcnt, ull h_, ull l_, uint32_t *ndist) {
+    uint32_t slot = (wide_hash32(l_, h_) * 0x9E3779B1u) >> (32u - WL_TSL);          // (other bits than the bucket number's)
+    for (uint32_t step = 0; step < 8u * WL_TS; step++) {
+        if (LOOKUP) {      // every key is in the table and ready
+            if (thi[slot] == h_ && tlo[slot] == l_) return slot;
+        } else {
+            const ull prev = atomicCAS(&thi[slot], ~0ull, h_);
+            if (prev == ~0ull) {      // (the count is added HERE, inside the loop: a lane of the same wave may be waiting for it below)
+                tlo[slot] = l_;
+                atomicAdd(&tcnt[slot], 1u);
+                if (atomicAdd(ndist, 1u) >= (uint32_t)(WL_TS * 3 / 4)) return ~0u;
+                return slot;
+            }
+            if (prev == h_) {
+                if (((volatile uint32_t *)tcnt)[slot] == 0u) continue;          // claimed, its low word not counted in yet: look again
+                if (((volatile ull *)tlo)[slot] == l_) { atomicAdd(&tcnt[slot], 1u); return slot; }
+            }
+        }
+        slot = (slot + 1u) & (WL_TS - 1u);
+    }
+    return ~0u;
+}
+
+// one block per bucket, any number of records: pass A counts the records of every k-mer (the first WL_RPT rounds keep their record
+// and slot in registers), a scan of the counts gives every group its place, pass B writes the records there (later rounds fetch
+// their record again and look the slot up).  A bucket with more distinct k-mers than 3/4 of the table raises *fail.
 __global__ void __launch_bounds__(WL_BLOCK)
-k_wlocal_group(const uint32_t *bstart, const uint32_t *idx, const ulonglong4 *pack, ull *o_hi, ull *o_lo, ull *o_val) {
-    __shared__ ull khi[WL_CAP], klo[WL_CAP];
-    __shared__ uint32_t first[WL_TS], cnt[WL_TS];
+k_wlocal_group(const uint32_t *bstart, const uint32_t *idx, const ulonglong4 *pack, ull *o_hi, ull *o_lo, ull *o_val, uint32_t *fail) {
+    __shared__ ull thi[WL_TS], tlo[WL_TS];
+    __shared__ uint32_t tcnt[WL_TS];
     __shared__ uint32_t wsum[WL_BLOCK / 64];
+    __shared__ uint32_t s_ndist, s_fail;
     const uint32_t tid = threadIdx.x;
     const uint32_t base = bstart[blockIdx.x], n = bstart[blockIdx.x + 1] - base;
     if (n == 0) return;
-    constexpr uint32_t RPT = WL_CAP / WL_BLOCK, SPT = WL_TS / WL_BLOCK;
-    for (uint32_t i = tid; i < WL_TS; i += WL_BLOCK) { first[i] = 0xffffffffu; cnt[i] = 0; }
-    uint32_t my_slot[RPT]; ull my_val[RPT];
-#pragma unroll
-    for (uint32_t q = 0; q < RPT; q++) {
-        const uint32_t r = q * WL_BLOCK + tid;
-        my_val[q] = 0; my_slot[q] = 0;
-        if (r < n) { const ulonglong4 e = pack[idx[base + r]]; khi[r] = e.x; klo[r] = e.y; my_val[q] = e.z; }
-    }
+    constexpr uint32_t SPT = WL_TS / WL_BLOCK;
+    for (uint32_t i = tid; i < WL_TS; i += WL_BLOCK) { thi[i] = ~0ull; tcnt[i] = 0; }
+    if (tid == 0) { s_ndist = 0; s_fail = 0; }
     __syncthreads();
+    ull my_hi[WL_RPT], my_lo[WL_RPT], my_val[WL_RPT]; uint32_t my_slot[WL_RPT];
 #pragma unroll
-    for (uint32_t q = 0; q < RPT; q++) {
+    for (uint32_t q = 0; q < WL_RPT; q++) {
         const uint32_t r = q * WL_BLOCK + tid;
+        my_slot[q] = ~0u; my_hi[q] = 0; my_lo[q] = 0; my_val[q] = 0;
         if (r < n) {
-            const ull h_ = khi[r], l_ = klo[r];
-            uint32_t slot = (wide_hash32(l_, h_) * 0x9E3779B1u) >> (32u - 12u);          // (other bits than the bucket number's)
-            for (;;) {
-                const uint32_t prev = atomicCAS(&first[slot], 0xffffffffu, r);
-                if (prev == 0xffffffffu || (khi[prev] == h_ && klo[prev] == l_)) break;
-                slot = (slot + 1u) & (WL_TS - 1u);
-            }
-            my_slot[q] = slot;
-            atomicAdd(&cnt[slot], 1u);
+            const ulonglong4 e = pack[idx[base + r]];
+            my_hi[q] = e.x; my_lo[q] = e.y; my_val[q] = e.z;
+            const uint32_t sl = wl_slot<false>(thi, tlo, tcnt, e.x, e.y, &s_ndist);
+            my_slot[q] = sl;
+            if (sl == ~0u) s_fail = 1u;
         }
     }
+    for (uint32_t r = WL_RPT * WL_BLOCK + tid; r < n; r += WL_BLOCK) {
+        const ulonglong4 e = pack[idx[base + r]];
+        if (wl_slot<false>(thi, tlo, tcnt, e.x, e.y, &s_ndist) == ~0u) s_fail = 1u;
+    }
     __syncthreads();
-    // exclusive scan of the group sizes over the slots: cnt[] becomes every group's cursor
+    if (s_fail) { if (tid == 0) *fail = 1u; return; }
+    // exclusive scan of the group sizes over the slots: tcnt[] becomes every group's cursor
     {
         uint32_t c[SPT], sum = 0;
 #pragma unroll
-        for (uint32_t j = 0; j < SPT; j++) { c[j] = cnt[tid * SPT + j]; sum += c[j]; }
+        for (uint32_t j = 0; j < SPT; j++) { c[j] = tcnt[tid * SPT + j]; sum += c[j]; }
         uint32_t inc = sum;
 #pragma unroll
         for (int o = 1; o < 64; o <<= 1) { const uint32_t t = __shfl_up(inc, o, 64); if ((tid & 63u) >= (uint32_t)o) inc += t; }
@@ -308,16 +337,21 @@ k_wlocal_group(const uint32_t *bstart, const uint32_t *idx, const ulonglong4 *pa
         uint32_t run = inc - sum;
         for (uint32_t w_ = 0; w_ < (tid >> 6); w_++) run += wsum[w_];
 #pragma unroll
-        for (uint32_t j = 0; j < SPT; j++) { cnt[tid * SPT + j] = run; run += c[j]; }
+        for (uint32_t j = 0; j < SPT; j++) { tcnt[tid * SPT + j] = run; run += c[j]; }
     }
     __syncthreads();
 #pragma unroll
-    for (uint32_t q = 0; q < RPT; q++) {
-        const uint32_t r = q * WL_BLOCK + tid;
-        if (r < n) {
-            const uint32_t pos = base + atomicAdd(&cnt[my_slot[q]], 1u);
-            o_hi[pos] = khi[r]; o_lo[pos] = klo[r]; o_val[pos] = my_val[q];
+    for (uint32_t q = 0; q < WL_RPT; q++) {
+        if (my_slot[q] != ~0u) {
+            const uint32_t pos = base + atomicAdd(&tcnt[my_slot[q]], 1u);
+            o_hi[pos] = my_hi[q]; o_lo[pos] = my_lo[q]; o_val[pos] = my_val[q];
         }
+    }
+    for (uint32_t r = WL_RPT * WL_BLOCK + tid; r < n; r += WL_BLOCK) {
+        const ulonglong4 e = pack[idx[base + r]];
+        const uint32_t sl = wl_slot<true>(thi, tlo, tcnt, e.x, e.y, nullptr);
+        const uint32_t pos = base + atomicAdd(&tcnt[sl], 1u);
+        o_hi[pos] = e.x; o_lo[pos] = e.y; o_val[pos] = e.z;
     }
 }
 
@@ -623,7 +657,7 @@ int simka_wide_merge(SimkaWide *w, uint32_t span_cap, SimkaWideCsr *out) {
     bool grouped = false;
     if (!getenv("SIMKA_WIDE_MERGE_SORT") && M < ((uint64_t)1 << 31)) {
         uint32_t bits = 1;
-        while ((M >> bits) > 1024u && bits < 24u) bits++;
+        while ((M >> bits) > 900u && bits < 24u) bits++;          // (<= 900 records per bucket: at most 900 of the table's 1536 usable slots)
         const uint32_t nb = 1u << bits;
         uint32_t *bstart, *d_max;
         char *tmp;
@@ -635,14 +669,12 @@ int simka_wide_merge(SimkaWide *w, uint32_t span_cap, SimkaWideCsr *out) {
             if (w->s_n[s]) hipLaunchKernelGGL(k_wbucket_key, grid_for(w->s_n[s]), dim3(256), 0, w->stream, w->a_hi, w->a_lo, w->a_cnt, w->s_off[s], w->s_n[s], s, bits, tkey, idx0, pack);
         WCHK(wsort_pairs<uint32_t>(tkey, hi1, idx0, idx1, M, bits, tmp, w->stream));          // (hi1: the sorted bucket numbers, until k_wlocal_group overwrites it)
         hipLaunchKernelGGL(k_wbucket_bounds, grid_for((uint64_t)nb + 1), dim3(256), 0, w->stream, hi1, M, nb, bstart, d_max);
-        uint32_t mx = 0;
-        WCHK(hipMemcpyAsync(&mx, d_max, 4, hipMemcpyDeviceToHost, w->stream));
+        WCHK(hipMemsetAsync(d_max, 0, 4, w->stream));           // (from here on: the "a bucket's table filled" flag)
+        hipLaunchKernelGGL(k_wlocal_group, dim3(nb), dim3(WL_BLOCK), 0, w->stream, bstart, idx1, pack, hi1, lo1, val2, d_max);
+        uint32_t failed = 0;
+        WCHK(hipMemcpyAsync(&failed, d_max, 4, hipMemcpyDeviceToHost, w->stream));
         WCHK(hipStreamSynchronize(w->stream));
-        if (mx <= (uint32_t)WL_CAP) {
-            hipLaunchKernelGGL(k_wlocal_group, dim3(nb), dim3(WL_BLOCK), 0, w->stream, bstart, idx1, pack, hi1, lo1, val2);
-            WCHK(hipGetLastError());
-            grouped = true;
-        }
+        grouped = !failed && !getenv("SIMKA_WIDE_MERGE_FAIL");          // (tests: the fallback after a failed grouping)
     }
     if (!grouped) {
         for (uint32_t s = 0; s < N; s++)

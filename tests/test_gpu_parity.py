@@ -1004,12 +1004,33 @@ def test_wide_kmers_partitions_beyond_the_tables(gpu_required, oracle_mod, monke
     _wide_case(oracle_mod, 37, 2, 3, 4000, 120, expect=expect)
 
 
-@pytest.mark.parametrize("k,n", [(33, 6), (47, 4), (63, 3)])
-def test_wide_merge_by_full_sort_equals_the_grouped_merge(gpu_required, oracle_mod, monkeypatch, k, n):
+@pytest.mark.parametrize("k,n,env", [(33, 6, "SIMKA_WIDE_MERGE_SORT"), (47, 4, "SIMKA_WIDE_MERGE_SORT"), (63, 3, "SIMKA_WIDE_MERGE_SORT"), (33, 5, "SIMKA_WIDE_MERGE_FAIL")])
+def test_wide_merge_by_full_sort_equals_the_grouped_merge(gpu_required, oracle_mod, monkeypatch, k, n, env):
     """The merge of two-word k-mers groups the records by hash bucket + an LDS table (k_wlocal_group); the full sort by k-mer stays as
-    the route for buckets beyond the LDS staging and is forced here: same oracle, same checks."""
-    monkeypatch.setenv("SIMKA_WIDE_MERGE_SORT", "1")
+    the route for a bucket whose table fills and is forced here (directly, and after a grouping declared failed): same oracle, same checks."""
+    monkeypatch.setenv(env, "1")
     _wide_case(oracle_mod, k, 1, n, 3000, 130, expect="partitioned" if k <= 51 else "sorted")
+
+
+def test_wide_merge_groups_kmers_shared_by_thousands_of_samples(gpu_required):
+    """2500 samples with the same few reads: every k-mer's group holds 2500 records -- far beyond what a thread block keeps in
+    registers between the two passes of k_wlocal_group, and more than a bucket's mean -- and the merge still groups them (no fallback
+    to the sort): all pairs at distance zero, the shared k-mers = one sample's distinct k-mers."""
+    import simka_amd
+    n, R, L, k = 2500, 12, 90, 35
+    pk = _synthetic(1, R, L, seed_shift=91)[0]
+    packed = np.concatenate([pk, np.zeros(2, dtype=np.uint64)])
+    with simka_amd.SimkaContext(n, kmer_size=k, abundance_min=1, simple_dist=False, complex_dist=False) as ctx:
+        for s in range(n):
+            ctx.count_sample(s, packed, R * L, R, fixed_len=L)
+        t0 = ctx.sample_totals(0)
+        ctx.merge()
+        st = ctx.stats()
+    m = st.matrices()
+    assert t0["D"] > 500
+    for name in ("mat_abundance_braycurtis", "mat_presenceAbsence_jaccard"):
+        assert name in m and np.all(m[name] == 0.0), name
+    assert int(st.view.nb_shared_kmers) == int(t0["D"]) == int(st.view.nb_distinct_kmers)
 
 
 def test_example_goldens_through_the_sort_path(gpu_required, golden_dir, tmp_path, monkeypatch):
