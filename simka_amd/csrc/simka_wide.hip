@@ -525,6 +525,73 @@ static int arena_reserve(SimkaWide *w, uint64_t extra) {
     return 0;
 }
 
+// ---- counting by buckets (k >= 52, and the last resort of the partitioned count): the occurrences of a sample are scattered into
+// buckets by a hash of the k-mer like the records of the merge, and a block counts its bucket in the same LDS table: what leaves is
+// the bucket's solid (hi, lo, count) records, unordered, behind a global cursor.
+__global__ void __launch_bounds__(256)
+k_wocc_key(const ull *hi, const ull *lo, uint64_t n, uint32_t bits, ull *key, uint32_t *idx, ulonglong2 *pack) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const ull h_ = hi[i], l_ = lo[i];
+    key[i] = (ull)(wide_hash32(h_, l_) >> (32u - bits)); idx[i] = (uint32_t)i;
+    pack[i] = make_ulonglong2(h_, l_);
+}
+__global__ void __launch_bounds__(WL_BLOCK)
+k_wlocal_count(const uint32_t *bstart, const uint32_t *idx, const ulonglong2 *pack, uint32_t amin, uint32_t amax, ull *o_hi, ull *o_lo, uint32_t *o_cnt, ull o_cap,
+               ull *small /* [1] D [2] N [3] Q [4] D_all [5] records written [6] flags: 1 a table filled, 2 the arrays are full */,
+               ull *hist, uint32_t *ovf_list, ull *ovf_cursor, ull ovf_cap, uint32_t sample) {
+    __shared__ ull thi[WL_TS], tlo[WL_TS];
+    __shared__ uint32_t tcnt[WL_TS];
+    __shared__ uint32_t wsum[WL_BLOCK / 64];
+    __shared__ uint32_t s_ndist, s_fail;
+    __shared__ ull s_base;
+    __shared__ uint32_t lhist[SIMKA_HIST_MAX];      // -complex-dist: the block's histogram of solid counts
+    const uint32_t tid = threadIdx.x;
+    const uint32_t base = bstart[blockIdx.x], n = bstart[blockIdx.x + 1] - base;
+    if (n == 0) return;
+    constexpr uint32_t SPT = WL_TS / WL_BLOCK;
+    for (uint32_t i = tid; i < WL_TS; i += WL_BLOCK) { thi[i] = ~0ull; tcnt[i] = 0; }
+    if (hist) for (uint32_t i = tid; i < SIMKA_HIST_MAX; i += WL_BLOCK) lhist[i] = 0;
+    if (tid == 0) { s_ndist = 0; s_fail = 0; }
+    __syncthreads();
+    for (uint32_t r = tid; r < n; r += WL_BLOCK) {
+        const ulonglong2 e = pack[idx[base + r]];
+        if (wl_slot<false>(thi, tlo, tcnt, e.x, e.y, &s_ndist) == ~0u) s_fail = 1u;
+    }
+    __syncthreads();
+    if (s_fail) { if (tid == 0) atomicOr(&small[6], 1ull); return; }
+    uint32_t c[SPT], nsol = 0, ndall = 0;
+    ull D = 0, N = 0, Q = 0;
+#pragma unroll
+    for (uint32_t j = 0; j < SPT; j++) {
+        c[j] = tcnt[tid * SPT + j];
+        if (c[j]) { ndall++; if (c[j] < amin || c[j] > amax) c[j] = 0; else { nsol++; D++; N += c[j]; Q += (ull)c[j] * (ull)c[j]; } }
+    }
+    uint32_t inc = nsol;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const uint32_t t = __shfl_up(inc, o, 64); if ((tid & 63u) >= (uint32_t)o) inc += t; }
+    if ((tid & 63u) == 63u) wsum[tid >> 6] = inc;
+    __syncthreads();
+    uint32_t run = inc - nsol, tot = 0;
+    for (uint32_t w_ = 0; w_ < WL_BLOCK / 64; w_++) { if (w_ < (tid >> 6)) run += wsum[w_]; tot += wsum[w_]; }
+    if (tid == 0) s_base = tot ? atomicAdd(&small[5], (ull)tot) : 0ull;
+    __syncthreads();
+    if (s_base + tot > o_cap) { if (tid == 0) atomicOr(&small[6], 2ull); return; }
+    ull pos = s_base + run;
+#pragma unroll
+    for (uint32_t j = 0; j < SPT; j++)
+        if (c[j]) {
+            o_hi[pos] = thi[tid * SPT + j]; o_lo[pos] = tlo[tid * SPT + j]; o_cnt[pos] = c[j]; pos++;
+            if (hist) {
+                if (c[j] < SIMKA_HIST_MAX) atomicAdd(&lhist[c[j]], 1u);
+                else { const ull wq = atomicAdd(ovf_cursor, 1ull); if (wq < ovf_cap) { ovf_list[2 * wq] = sample; ovf_list[2 * wq + 1] = c[j]; } }
+            }
+        }
+    for (int o = 32; o > 0; o >>= 1) { D += __shfl_down(D, o, 64); N += __shfl_down(N, o, 64); Q += __shfl_down(Q, o, 64); ndall += __shfl_down(ndall, o, 64); }
+    if ((tid & 63u) == 0) { if (D) { atomicAdd(&small[1], D); atomicAdd(&small[2], N); atomicAdd(&small[3], Q); } if (ndall) atomicAdd(&small[4], (ull)ndall); }
+    if (hist) { __syncthreads(); for (uint32_t i = tid; i < SIMKA_HIST_MAX; i += WL_BLOCK) if (lhist[i]) atomicAdd(&hist[i], (ull)lhist[i]); }
+}
+
 int simka_wide_count_sample(SimkaWide *w, uint32_t sample, const void *packed, uint64_t nb_bases, uint64_t nb_words, const void *offsets, uint64_t nb_reads,
                             uint32_t fixed_len, uint32_t amin, uint32_t amax, unsigned long long totals5[5], void *d_hist_row, void *d_ovf_list,
                             void *d_ovf_cursor, uint64_t ovf_cap) {
@@ -535,7 +602,12 @@ int simka_wide_count_sample(SimkaWide *w, uint32_t sample, const void *packed, u
     ull *hi0, *lo0, *hi1, *lo1; uint32_t *idx0, *idx1; ull *d_small;
     int rc;
     if ((rc = wide_buf(w, 0, n, &hi0)) || (rc = wide_buf(w, 1, n, &lo0)) || (rc = wide_buf(w, 2, n, &hi1)) || (rc = wide_buf(w, 3, n, &lo1)) ||
-        (rc = wide_buf(w, 5, n + 2, &idx0)) || (rc = wide_buf(w, 6, n + 2, &idx1)) || (rc = wide_buf(w, 7, 16, &d_small))) return rc;
+        (rc = wide_buf(w, 5, n + 2, &idx0)) || (rc = wide_buf(w, 6, n + 2, &idx1))) return rc;
+    {   // 16 small words + the bucket table of the bucket route (u32, at most 2^bits + 8 with n >> bits <= 1100)
+        uint32_t bmax = 1;
+        while ((n >> bmax) > 1100u && bmax < 24u) bmax++;
+        if ((rc = wide_buf(w, 7, 16 + (((uint64_t)1 << bmax) + 8) / 2 + 1, &d_small))) return rc;
+    }
     WCHK(hipMemsetAsync(d_small, 0, 16 * 8, w->stream));
     WideScanArgs a; a.packed = (const uint64_t *)packed; a.nb_bases = nb_bases; a.nb_words = nb_words; a.offsets = (const uint64_t *)offsets;
     a.nb_reads = nb_reads; a.fixed_len = fixed_len; a.k = w->k; a.shard_index = w->shard_index; a.shard_count = w->shard_count;
@@ -544,6 +616,37 @@ int simka_wide_count_sample(SimkaWide *w, uint32_t sample, const void *packed, u
     ull nvalid = 0;
     WCHK(hipMemcpyAsync(&nvalid, d_small, 8, hipMemcpyDeviceToHost, w->stream));
     WCHK(hipStreamSynchronize(w->stream));
+    // ---- by buckets: hash -> bucket number, two or three radix passes on it, one LDS table per bucket (k_wlocal_count)
+    if (nvalid && nvalid < ((uint64_t)1 << 31) && !getenv("SIMKA_WIDE_COUNT_SORT")) {
+        uint32_t bits = 1;
+        while ((nvalid >> bits) > 1100u && bits < 24u) bits++;
+        const uint32_t nb = 1u << bits;
+        const uint64_t ocap = nvalid / std::max<uint32_t>(1u, amin) + 16;
+        ulonglong2 *pack; char *tmp; ull *ohi, *olo; uint32_t *ocnt;
+        if ((rc = wide_buf(w, 4, nvalid, &pack)) || (rc = wide_buf(w, 11, wsort_tmp_bytes<uint32_t>(nvalid), &tmp)) || (rc = wide_buf(w, 8, ocap, &ohi)) ||
+            (rc = wide_buf(w, 9, ocap, &olo)) || (rc = wide_buf(w, 10, ocap, &ocnt))) return rc;
+        uint32_t *bstart = (uint32_t *)(d_small + 16);
+        hipLaunchKernelGGL(k_wocc_key, grid_for(nvalid), dim3(256), 0, w->stream, hi0, lo0, nvalid, bits, hi1, idx0, pack);
+        WCHK(wsort_pairs<uint32_t>(hi1, lo1, idx0, idx1, nvalid, bits, tmp, w->stream));          // lo1: the sorted bucket numbers
+        hipLaunchKernelGGL(k_wbucket_bounds, grid_for((uint64_t)nb + 1), dim3(256), 0, w->stream, lo1, nvalid, nb, bstart, (uint32_t *)(d_small + 15));
+        ull before[2] = { 0, 0 };
+        if (d_ovf_cursor) WCHK(hipMemcpyAsync(before, d_ovf_cursor, 16, hipMemcpyDeviceToHost, w->stream));
+        hipLaunchKernelGGL(k_wlocal_count, dim3(nb), dim3(WL_BLOCK), 0, w->stream, bstart, idx1, pack, amin, amax, ohi, olo, ocnt, (ull)ocap, d_small,
+                           (ull *)d_hist_row, (uint32_t *)d_ovf_list, (ull *)d_ovf_cursor, (ull)ovf_cap, sample);
+        ull sm[8];
+        WCHK(hipMemcpyAsync(sm, d_small, 64, hipMemcpyDeviceToHost, w->stream));
+        WCHK(hipStreamSynchronize(w->stream));
+        if (sm[6] == 0 && !getenv("SIMKA_WIDE_COUNT_FAIL")) {
+            totals5[SIMKA_TOT_KOCC] = nvalid; totals5[SIMKA_TOT_DALL] = sm[4];
+            totals5[SIMKA_TOT_D] = sm[1]; totals5[SIMKA_TOT_N] = sm[2]; totals5[SIMKA_TOT_Q] = sm[3];
+            return simka_wide_adopt(w, sample, ohi, olo, ocnt, sm[5], sm[5]);
+        }
+        // a bucket's table filled: by sorting, below -- with the totals and the abundance histogram as they were
+        WCHK(hipMemsetAsync(d_small + 1, 0, 15 * 8, w->stream));
+        if (d_hist_row) WCHK(hipMemsetAsync(d_hist_row, 0, (size_t)SIMKA_HIST_MAX * 8, w->stream));
+        if (d_ovf_cursor) WCHK(hipMemcpyAsync(d_ovf_cursor, before, 16, hipMemcpyHostToDevice, w->stream));
+        WCHK(hipStreamSynchronize(w->stream));
+    }
     const uint32_t hi_bits = w->W > 64 ? w->W - 64 : 0;
     if ((rc = wide_sort_words(w, nvalid, hi_bits, hi0, lo0, hi1, lo1))) return rc;
     if (hi_bits) { hi1 = hi0; lo1 = lo0; }          // the sorted words (one sort only: they are in hi1 / lo1)

@@ -946,15 +946,23 @@ def test_cli_spectra_larger_than_the_arena_merge_by_partition_ranges(gpu_require
     assert "do not fit the GPU memory" in log and "partition ranges" in log
 
 
-@pytest.mark.parametrize("k,amin,n,R,L", [(21, 2, 5, 3000, 100), (31, 1, 4, 2000, 150), (9, 2, 3, 1500, 80), (32, 2, 4, 2500, 120),
-                                          (33, 1, 4, 2500, 120), (47, 2, 5, 2500, 150), (63, 1, 3, 2000, 150),
-                                          (33, 1, 150, 120, 100)])     # more samples than one LDS tile: the tile-major pair kernel on the sorted CSR
-def test_sort_based_path_for_wide_kmers(gpu_required, oracle_mod, monkeypatch, k, amin, n, R, L):
-    """k >= 52 (k-mers of up to 126 bits, the reference's span-64 build) takes the sort-based path of simka_wide.hip; the same
-    path is forced for smaller k (SIMKA_SORT_PATH) as a cross-check of the partitioned pipeline.  Totals and every accumulator vs the
-    oracle (128-bit k-mers), -simple-dist and -complex-dist; variable-length layout for one case.  k >= 32 has no golden
-    vectors in the reference (parity unpinned): the oracle is the same code that reproduces the k = 21 / 31 goldens."""
+@pytest.mark.parametrize("k,amin,n,R,L,how", [(21, 2, 5, 3000, 100, "buckets"), (31, 1, 4, 2000, 150, "buckets"), (9, 2, 3, 1500, 80, "buckets"), (32, 2, 4, 2500, 120, "buckets"),
+                                              (33, 1, 4, 2500, 120, "buckets"), (47, 2, 5, 2500, 150, "buckets"), (63, 1, 3, 2000, 150, "buckets"), (55, 2, 4, 2500, 150, "buckets"),
+                                              (33, 1, 150, 120, 100, "buckets"),     # more samples than one LDS tile: the tile-major pair kernel on the sorted CSR
+                                              (31, 2, 4, 2000, 150, "sort"), (47, 2, 4, 2500, 150, "sort"), (63, 1, 3, 2000, 150, "sort"), (63, 2, 3, 2000, 150, "failed")])
+def test_sort_based_path_for_wide_kmers(gpu_required, oracle_mod, monkeypatch, k, amin, n, R, L, how):
+    """k >= 52 (k-mers of up to 126 bits, the reference's span-64 build) takes the path of simka_wide.hip that looks at every k-mer
+    occurrence on its own -- scattered into buckets by a hash of the k-mer and counted per bucket in an LDS table ("buckets"), or sorted
+    by k-mer ("sort": what a bucket with too many distinct k-mers falls back to; "failed": that fallback after a bucket count declared
+    failed, with the abundance histogram of -complex-dist restored); the same path is forced for smaller k (SIMKA_SORT_PATH) as a
+    cross-check of the partitioned pipeline.  Totals and every accumulator vs the oracle (128-bit k-mers), -simple-dist and
+    -complex-dist.  k >= 32 has no golden vectors in the reference (parity unpinned): the oracle is the same code that
+    reproduces the k = 21 / 31 goldens."""
     monkeypatch.setenv("SIMKA_SORT_PATH", "1")
+    if how == "sort":
+        monkeypatch.setenv("SIMKA_WIDE_COUNT_SORT", "1")
+    if how == "failed":
+        monkeypatch.setenv("SIMKA_WIDE_COUNT_FAIL", "1")
     _wide_case(oracle_mod, k, amin, n, R, L, expect="sorted")
 
 
