@@ -185,6 +185,7 @@ def main():
     ap.add_argument("--workload", default=os.environ.get("SIMKA_BENCH_WORKLOAD", "c3"), choices=sorted(WORKLOADS),
                     help="default c3 = BASELINE.json configs[2], the configuration the metric and the targets are quoted on (fits one GPU)")
     ap.add_argument("--reads", type=int, default=0, help="override reads per sample")
+    ap.add_argument("--kmer-size", type=int, default=0, help="override the workload's k (experiments: the bench line then names a workload of its own)")
     ap.add_argument("--samples", type=int, default=0, help="override number of samples")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--lanes", type=int, default=1, help="streams the samples alternate between in the timed region (library default: 2, "
@@ -250,6 +251,9 @@ def main():
     wl = dict(WORKLOADS[args.workload])
     if args.reads:
         wl["reads"] = args.reads
+    if args.kmer_size:
+        wl["k"] = args.kmer_size
+        wl["desc"] = wl.get("desc", "") + " [k overridden: %d]" % args.kmer_size
     if args.samples:
         wl["n"] = args.samples
     n, R, L, k = wl["n"], wl["reads"], wl["L"], wl["k"]
@@ -440,7 +444,7 @@ def main():
         return tot / n if n else None
     try:
         tf = next((f for f in (os.path.join(ROOT, "profiles", "r%02d_%s_hbm_traffic.json" % (rd, args.workload)) for rd in (3, 2)) if os.path.exists(f)), "")
-        if world == 1 and not args.reads and not args.samples and tf:
+        if world == 1 and not args.reads and not args.samples and not args.kmer_size and tf:
             tk = json.load(open(tf))["kernels"]
             traffic = measured_traffic(dom)
             traffic_src = os.path.relpath(tf, ROOT)

@@ -49,8 +49,8 @@ typedef struct simka_config {
     uint32_t struct_size;        /* = sizeof(simka_config) */
     uint32_t nb_samples;         /* N, SimkaStatistics::_nbBanks (1..65535) */
     uint32_t kmer_size;          /* -kmer-size, 1..63.  k <= 31 (one 64-bit word, Kmer<span=32>): the hash pipeline.  32..63 (two words,
-                                  * Kmer<span=64>): counted on the same minimizer-partitioned pipeline up to k = 51, by sorting all
-                                  * occurrences from 52 on (~5x slower); merged by hash buckets + LDS grouping; a partition shard keeps the k-mers that hash to it */
+                                  * Kmer<span=64>): counted on the same minimizer-partitioned pipeline up to k = 51, occurrence by
+                                  * occurrence in hash buckets from 52 on (~2x slower); merged by hash buckets + LDS grouping; a partition shard keeps the k-mers that hash to it */
     uint32_t abundance_min;      /* -abundance-min (ref: src/minikc/MiniKC.hpp:56) */
     uint32_t abundance_max;      /* -abundance-max, clamped to 999999999 (ref: src/core/SimkaAlgorithm.cpp:188) */
     uint32_t dist_flags;         /* SIMKA_DIST_* */
@@ -313,9 +313,10 @@ int simka_device_copy(int dst_device, void *dst, int src_device, const void *src
 int simka_get_geometry(simka_ctx *ctx, uint32_t *log2_level1, uint32_t *log2_level2, uint32_t *log2_subranges,
                        uint64_t *arena_capacity, uint64_t *csr_capacity);
 /* how the samples counted so far were counted: on the minimizer-partitioned pipeline (every sample for kmer_size <= 31, and for
- * 32 <= kmer_size <= 51 unless a partition outgrew its table) or by sorting all k-mer occurrences (kmer_size >= 52, the fallback,
- * SIMKA_SORT_PATH); and how many had their level-1 buckets sized exactly after a capacity-sized attempt overflowed */
-int simka_count_paths(simka_ctx *ctx, uint64_t *nb_partitioned, uint64_t *nb_sorted, uint64_t *nb_exact_redone);
+ * 32 <= kmer_size <= 51 unless a partition outgrew its table) or k-mer occurrence by occurrence (kmer_size >= 52, the fallback,
+ * SIMKA_SORT_PATH); how many had their level-1 buckets sized exactly after a capacity-sized attempt overflowed; and how many counts /
+ * merges of two-word k-mers sorted every record by k-mer because a hash bucket held too many distinct k-mers (0 in normal runs) */
+int simka_count_paths(simka_ctx *ctx, uint64_t *nb_partitioned, uint64_t *nb_sorted, uint64_t *nb_exact_redone, uint64_t *nb_full_sorts);
 
 /* ---- synthetic reads (bench / test utility, not part of the reference path) ---------------
  * Seeded generator of SURVEY.md section 8(d): a pool of random genomes and reads sampled from

@@ -142,7 +142,7 @@ def load_library(build_if_missing=True):
         "simka_profile_nb_kernels": (i32, [vp]),
         "simka_profile_get": (i32, [vp, i32, C.POINTER(C.c_char_p), C.POINTER(u64), C.POINTER(C.c_double)]),
         "simka_get_geometry": (i32, [vp, C.POINTER(u32), C.POINTER(u32), C.POINTER(u32), C.POINTER(u64), C.POINTER(u64)]),
-        "simka_count_paths": (i32, [vp, C.POINTER(u64), C.POINTER(u64), C.POINTER(u64)]),
+        "simka_count_paths": (i32, [vp, C.POINTER(u64), C.POINTER(u64), C.POINTER(u64), C.POINTER(u64)]),
         "simka_synth_genomes": (i32, [vp, vp, u32, u64, u64]),
         "simka_synth_reads": (i32, [vp, vp, u64, u32, vp, u64, u64, vp, vp, u32, u64, u32]),
     }
@@ -578,9 +578,9 @@ class SimkaContext:
 
     def count_paths(self):
         """How the samples counted so far were counted (simka_count_paths)."""
-        a, b, c = C.c_uint64(), C.c_uint64(), C.c_uint64()
-        self._check(self.lib.simka_count_paths(self.h, C.byref(a), C.byref(b), C.byref(c)))
-        return {"partitioned": a.value, "sorted": b.value, "exact_redone": c.value}
+        a, b, c, d = C.c_uint64(), C.c_uint64(), C.c_uint64(), C.c_uint64()
+        self._check(self.lib.simka_count_paths(self.h, C.byref(a), C.byref(b), C.byref(c), C.byref(d)))
+        return {"partitioned": a.value, "sorted": b.value, "exact_redone": c.value, "full_sorts": d.value}
 
 
 # ---- host-side ingest (FASTA/FASTQ, plain or gz) for the Python entry points -------------------

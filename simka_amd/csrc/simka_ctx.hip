@@ -2235,8 +2235,9 @@ SIMKA_EXPORT int simka_get_geometry(simka_ctx *ctx, uint32_t *l1, uint32_t *l2, 
     return SIMKA_OK;
 }
 
-SIMKA_EXPORT int simka_count_paths(simka_ctx *ctx, uint64_t *nb_partitioned, uint64_t *nb_sorted, uint64_t *nb_exact_redone) {
+SIMKA_EXPORT int simka_count_paths(simka_ctx *ctx, uint64_t *nb_partitioned, uint64_t *nb_sorted, uint64_t *nb_exact_redone, uint64_t *nb_full_sorts) {
     if (!ctx) return SIMKA_ERR_INVALID;
+    if (nb_full_sorts) *nb_full_sorts = ctx->wide ? simka_wide_full_sorts(ctx->wide) : 0;
     if (nb_partitioned) *nb_partitioned = ctx->wide ? ctx->nb_wide_hash : ctx->nb_counted_this_run;
     if (nb_sorted) *nb_sorted = ctx->nb_wide_sort;
     if (nb_exact_redone) *nb_exact_redone = ctx->nb_exact_fallbacks;

@@ -34,6 +34,7 @@ int simka_wide_merge(SimkaWide *w, uint32_t span_cap, SimkaWideCsr *out);
 // spectra out of / into the wide arena: partition p of a (sorted) sample = the records whose top log2_parts key bits equal p
 int simka_wide_part_counts(SimkaWide *w, uint32_t sample, uint32_t log2_parts, uint32_t *host_counts);
 uint64_t simka_wide_sample_records(SimkaWide *w, uint32_t sample);
+uint64_t simka_wide_full_sorts(SimkaWide *w);      // counts / merges that sorted by k-mer (fallback of the bucket routes)
 int simka_wide_export(SimkaWide *w, uint32_t sample, void *keys_hi_then_lo, void *counts, int on_device);
 int simka_wide_import(SimkaWide *w, uint32_t sample, const void *keys_hi_then_lo, const void *counts, uint64_t n, int on_device);
 int simka_wide_gather(SimkaWide *w, const uint32_t *samples, uint32_t nb, uint32_t log2_parts, const uint64_t *out_offsets, void *d_hi, void *d_lo, void *d_counts);

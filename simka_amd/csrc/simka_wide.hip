@@ -45,6 +45,7 @@ struct SimkaWide {
     uint64_t a_cap = 0, a_used = 0;
     std::vector<uint64_t> s_off, s_n;            // per sample: offset and number of solid records
     std::vector<uint8_t> s_sorted;
+    uint64_t nb_full_sorts = 0;                  // counts and merges that sorted by k-mer instead of bucketing (fallbacks, forced)
     // scratch (grown on demand)
     void *scratch[12] = { nullptr }; uint64_t scratch_bytes[12] = { 0 };
     // CSR handed to k_pairs (owned here, valid until the next reset / merge)
@@ -266,27 +267,36 @@ k_wbucket_bounds(const ull *key, uint64_t n, uint32_t nb, uint32_t *bstart, uint
 // operations in order: counter > 0 implies the low word is written).  Returns the slot (its counter one up), or ~0 when the table is
 // (nearly) full.
 template <bool LOOKUP>
-__device__ __forceinline__ uint32_t wl_slot(ull *thi, ull *tlo, uint32_t *tcnt, ull h_, ull l_, uint32_t *ndist) {
+__device__ __forceinline__ uint32_t wl_slot(ull *thi, ull *tlo, uint32_t *tcnt, ull h_, ull l_, uint32_t *ndist, bool active = true) {
     uint32_t slot = (wide_hash32(l_, h_) * 0x9E3779B1u) >> (32u - WL_TSL);          // (other bits than the bucket number's)
-    for (uint32_t step = 0; step < 8u * WL_TS; step++) {
-        if (LOOKUP) {      // every key is in the table and ready
+    if (LOOKUP) {      // every key is in the table and ready
+        if (!active) return ~0u;
+        for (uint32_t step = 0; step < WL_TS; step++) {
             if (thi[slot] == h_ && tlo[slot] == l_) return slot;
-        } else {
-            const ull prev = atomicCAS(&thi[slot], ~0ull, h_);
-            if (prev == ~0ull) {      // (the count is added HERE, inside the loop: a lane of the same wave may be waiting for it below)
-                tlo[slot] = l_;
-                atomicAdd(&tcnt[slot], 1u);
-                if (atomicAdd(ndist, 1u) >= (uint32_t)(WL_TS * 3 / 4)) return ~0u;
-                return slot;
-            }
-            if (prev == h_) {
-                if (((volatile uint32_t *)tcnt)[slot] == 0u) continue;          // claimed, its low word not counted in yet: look again
-                if (((volatile ull *)tlo)[slot] == l_) { atomicAdd(&tcnt[slot], 1u); return slot; }
-            }
+            slot = (slot + 1u) & (WL_TS - 1u);
         }
-        slot = (slot + 1u) & (WL_TS - 1u);
+        return ~0u;
     }
-    return ~0u;
+    // Every lane of the wave runs the SAME straight-line step until none is pending: a lane that waits for a claimed slot to become
+    // ready may be waiting for a lane of its own wave, whose store and count therefore must not sit behind the loop's exit.
+    bool pending = active;
+    uint32_t res = ~0u;
+    for (uint32_t step = 0; step < 8u * WL_TS; step++) {
+        if (!__any(pending)) break;
+        ull prev = 0;
+        if (pending) prev = atomicCAS(&thi[slot], ~0ull, h_);
+        const bool won = pending && prev == ~0ull;
+        if (won) { tlo[slot] = l_; atomicAdd(&tcnt[slot], 1u); }
+        bool done = won, wait = false, full = false;
+        if (won) full = atomicAdd(ndist, 1u) >= (uint32_t)(WL_TS * 3 / 4);
+        if (pending && !won && prev == h_) {
+            if (((volatile uint32_t *)tcnt)[slot] == 0u) wait = true;          // claimed, its low word not counted in yet: look again
+            else if (((volatile ull *)tlo)[slot] == l_) { atomicAdd(&tcnt[slot], 1u); done = true; }
+        }
+        if (done) { pending = false; res = full ? ~0u : slot; }
+        else if (pending && !wait) slot = (slot + 1u) & (WL_TS - 1u);
+    }
+    return res;
 }
 
 // one block per bucket, any number of records: pass A counts the records of every k-mer (the first WL_RPT rounds keep their record
@@ -310,17 +320,18 @@ k_wlocal_group(const uint32_t *bstart, const uint32_t *idx, const ulonglong4 *pa
     for (uint32_t q = 0; q < WL_RPT; q++) {
         const uint32_t r = q * WL_BLOCK + tid;
         my_slot[q] = ~0u; my_hi[q] = 0; my_lo[q] = 0; my_val[q] = 0;
-        if (r < n) {
-            const ulonglong4 e = pack[idx[base + r]];
-            my_hi[q] = e.x; my_lo[q] = e.y; my_val[q] = e.z;
-            const uint32_t sl = wl_slot<false>(thi, tlo, tcnt, e.x, e.y, &s_ndist);
+        if (q * WL_BLOCK < n) {          // (block-uniform: whole waves enter wl_slot)
+            if (r < n) { const ulonglong4 e = pack[idx[base + r]]; my_hi[q] = e.x; my_lo[q] = e.y; my_val[q] = e.z; }
+            const uint32_t sl = wl_slot<false>(thi, tlo, tcnt, my_hi[q], my_lo[q], &s_ndist, r < n);
             my_slot[q] = sl;
-            if (sl == ~0u) s_fail = 1u;
+            if (r < n && sl == ~0u) s_fail = 1u;
         }
     }
-    for (uint32_t r = WL_RPT * WL_BLOCK + tid; r < n; r += WL_BLOCK) {
-        const ulonglong4 e = pack[idx[base + r]];
-        if (wl_slot<false>(thi, tlo, tcnt, e.x, e.y, &s_ndist) == ~0u) s_fail = 1u;
+    for (uint32_t r0 = WL_RPT * WL_BLOCK; r0 < n; r0 += WL_BLOCK) {
+        const uint32_t r = r0 + tid;
+        ulonglong4 e = make_ulonglong4(0, 0, 0, 0);
+        if (r < n) e = pack[idx[base + r]];
+        if (wl_slot<false>(thi, tlo, tcnt, e.x, e.y, &s_ndist, r < n) == ~0u && r < n) s_fail = 1u;
     }
     __syncthreads();
     if (s_fail) { if (tid == 0) *fail = 1u; return; }
@@ -536,30 +547,36 @@ k_wocc_key(const ull *hi, const ull *lo, uint64_t n, uint32_t bits, ull *key, ui
     key[i] = (ull)(wide_hash32(h_, l_) >> (32u - bits)); idx[i] = (uint32_t)i;
     pack[i] = make_ulonglong2(h_, l_);
 }
+// part: [WL_NPART][8] partial totals -- [1] D [2] N [3] Q [4] D_all [6] flag "a table filled" -- spread over WL_NPART rows: tens of
+// thousands of blocks adding to ONE set of words queue up behind each other in the L2 (13 ms of a 14-ms kernel).  The solid records
+// of bucket b go to the slots [bstart[b], ...) of the output, the rest of the bucket's range gets count 0 (simka_wide_adopt drops
+// those): no cursor to reserve from either.
+#define WL_NPART 256
 __global__ void __launch_bounds__(WL_BLOCK)
-k_wlocal_count(const uint32_t *bstart, const uint32_t *idx, const ulonglong2 *pack, uint32_t amin, uint32_t amax, ull *o_hi, ull *o_lo, uint32_t *o_cnt, ull o_cap,
-               ull *small /* [1] D [2] N [3] Q [4] D_all [5] records written [6] flags: 1 a table filled, 2 the arrays are full */,
+k_wlocal_count(const uint32_t *bstart, const uint32_t *idx, const ulonglong2 *pack, uint32_t amin, uint32_t amax, ull *o_hi, ull *o_lo, uint32_t *o_cnt, ull *part,
                ull *hist, uint32_t *ovf_list, ull *ovf_cursor, ull ovf_cap, uint32_t sample) {
     __shared__ ull thi[WL_TS], tlo[WL_TS];
     __shared__ uint32_t tcnt[WL_TS];
     __shared__ uint32_t wsum[WL_BLOCK / 64];
     __shared__ uint32_t s_ndist, s_fail;
-    __shared__ ull s_base;
     __shared__ uint32_t lhist[SIMKA_HIST_MAX];      // -complex-dist: the block's histogram of solid counts
     const uint32_t tid = threadIdx.x;
     const uint32_t base = bstart[blockIdx.x], n = bstart[blockIdx.x + 1] - base;
     if (n == 0) return;
+    ull *mine = part + (size_t)(blockIdx.x % WL_NPART) * 8;
     constexpr uint32_t SPT = WL_TS / WL_BLOCK;
     for (uint32_t i = tid; i < WL_TS; i += WL_BLOCK) { thi[i] = ~0ull; tcnt[i] = 0; }
     if (hist) for (uint32_t i = tid; i < SIMKA_HIST_MAX; i += WL_BLOCK) lhist[i] = 0;
     if (tid == 0) { s_ndist = 0; s_fail = 0; }
     __syncthreads();
-    for (uint32_t r = tid; r < n; r += WL_BLOCK) {
-        const ulonglong2 e = pack[idx[base + r]];
-        if (wl_slot<false>(thi, tlo, tcnt, e.x, e.y, &s_ndist) == ~0u) s_fail = 1u;
+    for (uint32_t r0 = 0; r0 < n; r0 += WL_BLOCK) {          // (block-uniform trip count: whole waves enter wl_slot)
+        const uint32_t r = r0 + tid;
+        ulonglong2 e = make_ulonglong2(0, 0);
+        if (r < n) e = pack[idx[base + r]];
+        if (wl_slot<false>(thi, tlo, tcnt, e.x, e.y, &s_ndist, r < n) == ~0u && r < n) s_fail = 1u;
     }
     __syncthreads();
-    if (s_fail) { if (tid == 0) atomicOr(&small[6], 1ull); return; }
+    if (s_fail) { if (tid == 0) atomicOr(&mine[6], 1ull); return; }
     uint32_t c[SPT], nsol = 0, ndall = 0;
     ull D = 0, N = 0, Q = 0;
 #pragma unroll
@@ -574,10 +591,7 @@ k_wlocal_count(const uint32_t *bstart, const uint32_t *idx, const ulonglong2 *pa
     __syncthreads();
     uint32_t run = inc - nsol, tot = 0;
     for (uint32_t w_ = 0; w_ < WL_BLOCK / 64; w_++) { if (w_ < (tid >> 6)) run += wsum[w_]; tot += wsum[w_]; }
-    if (tid == 0) s_base = tot ? atomicAdd(&small[5], (ull)tot) : 0ull;
-    __syncthreads();
-    if (s_base + tot > o_cap) { if (tid == 0) atomicOr(&small[6], 2ull); return; }
-    ull pos = s_base + run;
+    ull pos = (ull)base + run;          // tot <= the bucket's distinct k-mers <= n
 #pragma unroll
     for (uint32_t j = 0; j < SPT; j++)
         if (c[j]) {
@@ -587,8 +601,9 @@ k_wlocal_count(const uint32_t *bstart, const uint32_t *idx, const ulonglong2 *pa
                 else { const ull wq = atomicAdd(ovf_cursor, 1ull); if (wq < ovf_cap) { ovf_list[2 * wq] = sample; ovf_list[2 * wq + 1] = c[j]; } }
             }
         }
+    for (uint32_t i = tot + tid; i < n; i += WL_BLOCK) o_cnt[base + i] = 0;
     for (int o = 32; o > 0; o >>= 1) { D += __shfl_down(D, o, 64); N += __shfl_down(N, o, 64); Q += __shfl_down(Q, o, 64); ndall += __shfl_down(ndall, o, 64); }
-    if ((tid & 63u) == 0) { if (D) { atomicAdd(&small[1], D); atomicAdd(&small[2], N); atomicAdd(&small[3], Q); } if (ndall) atomicAdd(&small[4], (ull)ndall); }
+    if ((tid & 63u) == 0) { if (D) { atomicAdd(&mine[1], D); atomicAdd(&mine[2], N); atomicAdd(&mine[3], Q); } if (ndall) atomicAdd(&mine[4], (ull)ndall); }
     if (hist) { __syncthreads(); for (uint32_t i = tid; i < SIMKA_HIST_MAX; i += WL_BLOCK) if (lhist[i]) atomicAdd(&hist[i], (ull)lhist[i]); }
 }
 
@@ -603,10 +618,10 @@ int simka_wide_count_sample(SimkaWide *w, uint32_t sample, const void *packed, u
     int rc;
     if ((rc = wide_buf(w, 0, n, &hi0)) || (rc = wide_buf(w, 1, n, &lo0)) || (rc = wide_buf(w, 2, n, &hi1)) || (rc = wide_buf(w, 3, n, &lo1)) ||
         (rc = wide_buf(w, 5, n + 2, &idx0)) || (rc = wide_buf(w, 6, n + 2, &idx1))) return rc;
-    {   // 16 small words + the bucket table of the bucket route (u32, at most 2^bits + 8 with n >> bits <= 1100)
+    {   // 16 small words + the partial totals + the bucket table of the bucket route (u32, at most 2^bits + 8 with n >> bits <= 1100)
         uint32_t bmax = 1;
         while ((n >> bmax) > 1100u && bmax < 24u) bmax++;
-        if ((rc = wide_buf(w, 7, 16 + (((uint64_t)1 << bmax) + 8) / 2 + 1, &d_small))) return rc;
+        if ((rc = wide_buf(w, 7, 16 + 2048 + (((uint64_t)1 << bmax) + 8) / 2 + 1, &d_small))) return rc;          // (2048 = WL_NPART * 8 partial totals)
     }
     WCHK(hipMemsetAsync(d_small, 0, 16 * 8, w->stream));
     WideScanArgs a; a.packed = (const uint64_t *)packed; a.nb_bases = nb_bases; a.nb_words = nb_words; a.offsets = (const uint64_t *)offsets;
@@ -621,25 +636,29 @@ int simka_wide_count_sample(SimkaWide *w, uint32_t sample, const void *packed, u
         uint32_t bits = 1;
         while ((nvalid >> bits) > 1100u && bits < 24u) bits++;
         const uint32_t nb = 1u << bits;
-        const uint64_t ocap = nvalid / std::max<uint32_t>(1u, amin) + 16;
+        const uint64_t ocap = nvalid + 16;          // (bucket b's solid records sit at the start of its range of the occurrences)
         ulonglong2 *pack; char *tmp; ull *ohi, *olo; uint32_t *ocnt;
         if ((rc = wide_buf(w, 4, nvalid, &pack)) || (rc = wide_buf(w, 11, wsort_tmp_bytes<uint32_t>(nvalid), &tmp)) || (rc = wide_buf(w, 8, ocap, &ohi)) ||
             (rc = wide_buf(w, 9, ocap, &olo)) || (rc = wide_buf(w, 10, ocap, &ocnt))) return rc;
-        uint32_t *bstart = (uint32_t *)(d_small + 16);
+        ull *part = d_small + 16;
+        uint32_t *bstart = (uint32_t *)(part + WL_NPART * 8);
+        WCHK(hipMemsetAsync(part, 0, (size_t)WL_NPART * 64, w->stream));
         hipLaunchKernelGGL(k_wocc_key, grid_for(nvalid), dim3(256), 0, w->stream, hi0, lo0, nvalid, bits, hi1, idx0, pack);
         WCHK(wsort_pairs<uint32_t>(hi1, lo1, idx0, idx1, nvalid, bits, tmp, w->stream));          // lo1: the sorted bucket numbers
         hipLaunchKernelGGL(k_wbucket_bounds, grid_for((uint64_t)nb + 1), dim3(256), 0, w->stream, lo1, nvalid, nb, bstart, (uint32_t *)(d_small + 15));
         ull before[2] = { 0, 0 };
         if (d_ovf_cursor) WCHK(hipMemcpyAsync(before, d_ovf_cursor, 16, hipMemcpyDeviceToHost, w->stream));
-        hipLaunchKernelGGL(k_wlocal_count, dim3(nb), dim3(WL_BLOCK), 0, w->stream, bstart, idx1, pack, amin, amax, ohi, olo, ocnt, (ull)ocap, d_small,
+        hipLaunchKernelGGL(k_wlocal_count, dim3(nb), dim3(WL_BLOCK), 0, w->stream, bstart, idx1, pack, amin, amax, ohi, olo, ocnt, part,
                            (ull *)d_hist_row, (uint32_t *)d_ovf_list, (ull *)d_ovf_cursor, (ull)ovf_cap, sample);
-        ull sm[8];
-        WCHK(hipMemcpyAsync(sm, d_small, 64, hipMemcpyDeviceToHost, w->stream));
+        std::vector<ull> ph((size_t)WL_NPART * 8);
+        WCHK(hipMemcpyAsync(ph.data(), part, ph.size() * 8, hipMemcpyDeviceToHost, w->stream));
         WCHK(hipStreamSynchronize(w->stream));
+        ull sm[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
+        for (size_t i = 0; i < ph.size(); i++) sm[i & 7] += ph[i];
         if (sm[6] == 0 && !getenv("SIMKA_WIDE_COUNT_FAIL")) {
             totals5[SIMKA_TOT_KOCC] = nvalid; totals5[SIMKA_TOT_DALL] = sm[4];
             totals5[SIMKA_TOT_D] = sm[1]; totals5[SIMKA_TOT_N] = sm[2]; totals5[SIMKA_TOT_Q] = sm[3];
-            return simka_wide_adopt(w, sample, ohi, olo, ocnt, sm[5], sm[5]);
+            return simka_wide_adopt(w, sample, ohi, olo, ocnt, nvalid, sm[1]);
         }
         // a bucket's table filled: by sorting, below -- with the totals and the abundance histogram as they were
         WCHK(hipMemsetAsync(d_small + 1, 0, 15 * 8, w->stream));
@@ -648,6 +667,7 @@ int simka_wide_count_sample(SimkaWide *w, uint32_t sample, const void *packed, u
         WCHK(hipStreamSynchronize(w->stream));
     }
     const uint32_t hi_bits = w->W > 64 ? w->W - 64 : 0;
+    if (nvalid) w->nb_full_sorts++;
     if ((rc = wide_sort_words(w, nvalid, hi_bits, hi0, lo0, hi1, lo1))) return rc;
     if (hi_bits) { hi1 = hi0; lo1 = lo0; }          // the sorted words (one sort only: they are in hi1 / lo1)
     totals5[SIMKA_TOT_KOCC] = nvalid;
@@ -780,6 +800,7 @@ int simka_wide_merge(SimkaWide *w, uint32_t span_cap, SimkaWideCsr *out) {
         grouped = !failed && !getenv("SIMKA_WIDE_MERGE_FAIL");          // (tests: the fallback after a failed grouping)
     }
     if (!grouped) {
+        w->nb_full_sorts++;
         for (uint32_t s = 0; s < N; s++)
             if (w->s_n[s]) hipLaunchKernelGGL(k_wvals, grid_for(w->s_n[s]), dim3(256), 0, w->stream, w->a_cnt, w->s_off[s], w->s_n[s], s, val);
         const uint32_t hi_bits = (w->W > 64 ? w->W - 64 : 0) + 1;
@@ -899,6 +920,7 @@ int simka_wide_part_counts(SimkaWide *w, uint32_t sample, uint32_t log2_parts, u
 }
 
 uint64_t simka_wide_sample_records(SimkaWide *w, uint32_t sample) { return w->s_n[sample]; }
+uint64_t simka_wide_full_sorts(SimkaWide *w) { return w->nb_full_sorts; }
 
 // keys: [hi x n][lo x n]
 int simka_wide_export(SimkaWide *w, uint32_t sample, void *keys, void *counts, int on_device) {

@@ -963,10 +963,10 @@ def test_sort_based_path_for_wide_kmers(gpu_required, oracle_mod, monkeypatch, k
         monkeypatch.setenv("SIMKA_WIDE_COUNT_SORT", "1")
     if how == "failed":
         monkeypatch.setenv("SIMKA_WIDE_COUNT_FAIL", "1")
-    _wide_case(oracle_mod, k, amin, n, R, L, expect="sorted")
+    _wide_case(oracle_mod, k, amin, n, R, L, expect="sorted", full_sorts=0 if how == "buckets" else n)
 
 
-def _wide_case(oracle_mod, k, amin, n, R, L, expect, fixed=True, **ctx_kw):
+def _wide_case(oracle_mod, k, amin, n, R, L, expect, fixed=True, full_sorts=0, **ctx_kw):
     from simka_amd import synth
     packed = _synthetic(n, R, L, seed_shift=70)
     offs = np.arange(R + 1, dtype=np.uint64) * L
@@ -980,7 +980,7 @@ def _wide_case(oracle_mod, k, amin, n, R, L, expect, fixed=True, **ctx_kw):
     st = ctx.stats()
     paths = ctx.count_paths()
     ctx.close()
-    assert paths[expect] == n and paths["partitioned"] + paths["sorted"] == n, paths
+    assert paths[expect] == n and paths["partitioned"] + paths["sorted"] == n and paths["full_sorts"] == full_sorts, paths
     orc = oracle_mod.Oracle()
     for s, pk in enumerate(packed):
         orc.add_sample_ascii("S%d" % s, synth.unpack_ascii(pk, R * L), offs)
@@ -1009,7 +1009,7 @@ def test_wide_kmers_partitions_beyond_the_tables(gpu_required, oracle_mod, monke
     monkeypatch.setenv("SIMKA_WIDE_PER_PART", str(per_part))
     if general:
         monkeypatch.setenv("SIMKA_SKM_GENERAL", "1")
-    _wide_case(oracle_mod, 37, 2, 3, 4000, 120, expect=expect)
+    _wide_case(oracle_mod, 37, 2, 3, 4000, 120, expect=expect)       # ("sorted": occurrence by occurrence, in hash buckets)
 
 
 @pytest.mark.parametrize("k,n,env", [(33, 6, "SIMKA_WIDE_MERGE_SORT"), (47, 4, "SIMKA_WIDE_MERGE_SORT"), (63, 3, "SIMKA_WIDE_MERGE_SORT"), (33, 5, "SIMKA_WIDE_MERGE_FAIL")])
@@ -1017,7 +1017,7 @@ def test_wide_merge_by_full_sort_equals_the_grouped_merge(gpu_required, oracle_m
     """The merge of two-word k-mers groups the records by hash bucket + an LDS table (k_wlocal_group); the full sort by k-mer stays as
     the route for a bucket whose table fills and is forced here (directly, and after a grouping declared failed): same oracle, same checks."""
     monkeypatch.setenv(env, "1")
-    _wide_case(oracle_mod, k, 1, n, 3000, 130, expect="partitioned" if k <= 51 else "sorted")
+    _wide_case(oracle_mod, k, 1, n, 3000, 130, expect="partitioned" if k <= 51 else "sorted", full_sorts=1)
 
 
 def test_wide_merge_groups_kmers_shared_by_thousands_of_samples(gpu_required):
@@ -1034,6 +1034,7 @@ def test_wide_merge_groups_kmers_shared_by_thousands_of_samples(gpu_required):
         t0 = ctx.sample_totals(0)
         ctx.merge()
         st = ctx.stats()
+        assert ctx.count_paths()["full_sorts"] == 0
     m = st.matrices()
     assert t0["D"] > 500
     for name in ("mat_abundance_braycurtis", "mat_presenceAbsence_jaccard"):
