@@ -32,6 +32,8 @@ KERNEL_BOUND = {
     "k_skm_split": "HBM (64-byte runs: partial-line writes amplify the traffic)",
     "k_skm_count_fast": "LDS atomics + VALU, latency (random-slot 64-bit CAS + counter add per k-mer; 16 waves per CU)",
     "k_skm_count": "LDS atomics (redo list only)",
+    "k_skm_count_wide_fast": "LDS latency + VALU issue (two-word k-mers: claim by 64-bit CAS, compare, count; a table per wave, 16 waves per CU)",
+    "k_skm_count_wide": "LDS atomics (redo list only)",
     "k_segment_rows": "HBM (imported spectra only)",
     "k_group": "LDS atomics + gather latency (hash grouping of the N slices of a sub-range)",
     "k_pairs": "LDS atomics (three 64-bit adds per pair) + VALU",
@@ -409,10 +411,12 @@ def main():
     # k-mer once and writes the counted records, the merge reads the solid records once; k_skm_split is an extra level (0).
     share = 1.0 / world                    # each rank owns 1/world of the key space (or counts 1/world of the samples)
     scan_reads = n * nb_bases / 4.0 * (share if by_sample else 1.0)       # partition shards: every rank reads every base
+    kb = 16.0 if k > 31 else 8.0           # bytes of a k-mer (SURVEY 8d prices 8-byte k-mers; two words from k = 32 on)
     alg_bytes_per_step = {
-        "k_skm_scan": scan_reads + 8.0 * K_occ * share,
-        "k_skm_count_fast": 8.0 * K_occ * share + 12.0 * K_dist * share,
-        "k_group": 12.0 * K_solid * share,
+        "k_skm_scan": scan_reads + kb * K_occ * share,
+        "k_skm_count_fast": kb * K_occ * share + (kb + 4.0) * K_dist * share,
+        "k_skm_count_wide_fast": kb * K_occ * share + (kb + 4.0) * K_dist * share,
+        "k_group": (kb + 4.0) * K_solid * share,
     }
     kern_ms = {kname: ms for kname, (cnt, ms) in prof.items()}
     total_kernel_ms = sum(kern_ms.values())
@@ -420,7 +424,7 @@ def main():
     dom_bytes_per_launch = alg_bytes_per_step.get(dom, 0.0) * args.steps / max(dom_launches, 1)
     dom_avg_ms = dom_ms / max(dom_launches, 1)
     achieved = dom_bytes_per_launch / (dom_avg_ms * 1e-3) / 1e9 if dom_avg_ms > 0 else 0.0
-    b_alg = scan_reads + (16.0 * K_occ + 12.0 * K_dist + 12.0 * K_solid) * share
+    b_alg = scan_reads + (2.0 * kb * K_occ + (kb + 4.0) * K_dist + (kb + 4.0) * K_solid) * share
     # the whole path: B_alg over the step's wall time (kernels of neighbouring samples overlap on two streams, so the sum of the
     # one-lane kernel times is an upper bound of the device time; it is reported as timing.device_kernels_ms)
     path_gbs = b_alg / (dt / args.steps) / 1e9

@@ -2179,7 +2179,7 @@ SIMKA_EXPORT int simka_profile_nb_kernels(simka_ctx *) { return KID_NB; }
 SIMKA_EXPORT int simka_profile_get(simka_ctx *ctx, int which, const char **name, uint64_t *n, double *ms) {
     if (!ctx || which < 0 || which >= KID_NB) return SIMKA_ERR_INVALID;
     profile_collect(ctx);
-    if (name) *name = KID_NAMES[which];
+    if (name) *name = (ctx->wide_hash && which == KID_SKM_COUNT) ? "k_skm_count_wide_fast" : (ctx->wide_hash && which == KID_COUNT) ? "k_skm_count_wide" : KID_NAMES[which];
     if (n) *n = ctx->prof_n[which];
     if (ms) *ms = ctx->prof_ms[which];
     return SIMKA_OK;
