@@ -1,6 +1,7 @@
 """Cost of hot k-mers (adapter-like repeated reads): one C2-size sample where a share of the reads are copies of a few reads.
 Their k-mers overflow the capacity-sized level-2 regions -> spill buffer -> general kernel (or, past the spill capacity, the
-exact redo of the sample).  usage: hot_kmers.py"""
+exact redo of the sample).  usage: hot_kmers.py [k]      (k = 33..51: two-word k-mers, where hot k-mers only repeat inside a
+wave's table; k >= 52: the bucket count)"""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -9,7 +10,7 @@ import simka_amd, bench
 wl = dict(bench.WORKLOADS["c2"]); wl["n"] = 2
 lib = simka_amd.load_library(); dev = torch.device("cuda:0")
 pool, reads = bench.gen_device_samples(lib, torch, wl, dev)
-R, L, k = wl["reads"], wl["L"], wl["k"]
+R, L, k = wl["reads"], wl["L"], (int(sys.argv[1]) if len(sys.argv) > 1 else wl["k"])
 wpr = None
 base = reads[0].clone()
 def with_hot(nhot, copies):
@@ -28,5 +29,5 @@ for nhot, copies in ((0, 0), (1, 20000), (10, 20000), (40, 5000), (200, 1000), (
         ctx.reset(); torch.cuda.synchronize(); t0 = time.perf_counter()
         ctx.count_sample(0, t.data_ptr(), R * L, R, fixed_len=L, on_device=True)
         tot = ctx.sample_totals(0); torch.cuda.synchronize(); dt = time.perf_counter() - t0
-    print("%4d hot reads x %5d copies (%4.1f %% of the reads): count_sample %.2f ms, D_all %d" % (nhot, copies, 100.0 * nhot * copies / R, dt * 1e3, tot["D_all"]))
+    print("%4d hot reads x %5d copies (%4.1f %% of the reads): count_sample %.2f ms, D_all %d, paths %s" % (nhot, copies, 100.0 * nhot * copies / R, dt * 1e3, tot["D_all"], ctx.count_paths()))
     ctx.close()

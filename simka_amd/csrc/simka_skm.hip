@@ -1053,7 +1053,7 @@ k_skm_count_wide_fast(const uint4 *recs, const uint32_t *pstart, const uint32_t 
         const uint4 rc0_n = first_chunk(nrec_n, rbase_n);
         meta(part + 2u * nwaves, nrec_nv, rbase_nv);
         PH(0)
-        bool fail = nrec >= (1u << (SKM_WF_CBITS - 6));          // (a count could leave its 26 bits)
+        bool fail = nrec > 512u;          // a partition of many records (a few hot k-mers: one wave would walk them alone; and a count must stay below 2^26): the block kernel's
         uint32_t ndist = 0, my_k = 0;
         uint32_t tsl = SKM_WF_TSL;                                 // log2 of the slots this partition uses
         for (uint32_t b0 = 0; b0 < nrec && !fail; b0 += SKM_WF_CHUNK) {
