@@ -245,7 +245,17 @@ def main():
             assert dist.get_world_size() == args.gpus and dist.get_backend() == "nccl"
             # the data-path collectives run inside the C ABI on RCCL (simka_comm_*, simka_stats_allreduce); torch.distributed
             # bootstraps the communicator (unique id broadcast) and provides the timing barrier
-            comm = sdist.create_comm(rank, world, local)
+            # (if the C ABI cannot get its communicator -- no librccl.so to dlopen, an init error -- every rank falls back to the same
+            # collectives through torch.distributed, which is RCCL as well: the line says which under config.collectives)
+            try:
+                comm = sdist.create_comm(rank, world, local)
+            except Exception as e:
+                sys.stderr.write("bench.py rank %d: simka_comm_* unavailable (%r): collectives through torch.distributed\n" % (rank, e))
+                comm = None
+            ok = torch.tensor([1 if comm is not None else 0], dtype=torch.int64, device=dev)
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+            if int(ok.item()) == 0 and comm is not None:
+                comm.close(); comm = None
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
     modes = ["single"] if world == 1 else (["partition", "sample"] if args.mgpu == "both" else [args.mgpu])
