@@ -877,7 +877,8 @@ int main(int argc, char **argv) {
         std::vector<simka_ctx *> cctx(G, nullptr);
         std::vector<std::vector<uint32_t>> pc(G);                   // [n_g][P] records per (local sample, partition)
         std::vector<std::vector<simka_sample_totals>> tot(G);
-        std::vector<void *> send_k(G, nullptr), send_c(G, nullptr);
+        const bool two = o.kmer_size > 31;          // two-word k-mers: high and low words in separate buffers (simka_*_samples_device_wide)
+        std::vector<void *> send_k(G, nullptr), send_k2(G, nullptr), send_c(G, nullptr);
         std::vector<std::vector<uint64_t>> blk(G, std::vector<uint64_t>(G + 1, 0));      // blk[g][h]: where the block for GPU h starts in g's send buffers
         std::atomic<int> worst(SIMKA_OK);
         auto note = [&](int r) { if (r != SIMKA_OK) worst.store(r); return r == SIMKA_OK; };
@@ -915,8 +916,10 @@ int main(int argc, char **argv) {
                         for (uint64_t p = lo_of(h); p < lo_of(h + 1); p++) { off[(size_t)j * P + p] = run; run += pc[g][(size_t)j * P + p]; }
                 }
                 blk[g][G] = run;
-                if (!note(simka_device_alloc(device_of(g), run * 8 + 8, &send_k[g])) || !note(simka_device_alloc(device_of(g), run * 4 + 8, &send_c[g]))) return;
-                rc = simka_gather_samples_device(c, idx.data(), n, off.data(), send_k[g], send_c[g]);
+                if (!note(simka_device_alloc(device_of(g), run * 8 + 8, &send_k[g])) || !note(simka_device_alloc(device_of(g), run * 4 + 8, &send_c[g])) ||
+                    (two && !note(simka_device_alloc(device_of(g), run * 8 + 8, &send_k2[g])))) return;
+                rc = two ? simka_gather_samples_device_wide(c, idx.data(), n, off.data(), send_k[g], send_k2[g], send_c[g])
+                         : simka_gather_samples_device(c, idx.data(), n, off.data(), send_k[g], send_c[g]);
                 if (rc != SIMKA_OK) fatal(c, "simka_gather_samples_device");
             };
             std::vector<std::thread> th;
@@ -924,7 +927,7 @@ int main(int argc, char **argv) {
             for (auto &t : th) t.join();
         }
         for (uint32_t g = 0; g < G; g++) if (cctx[g]) simka_destroy(cctx[g]);         // the arenas make room for the merge contexts
-        auto drop_send = [&] { for (uint32_t g = 0; g < G; g++) { simka_device_free(device_of(g), send_k[g]); simka_device_free(device_of(g), send_c[g]); send_k[g] = send_c[g] = nullptr; } };
+        auto drop_send = [&] { for (uint32_t g = 0; g < G; g++) { simka_device_free(device_of(g), send_k[g]); simka_device_free(device_of(g), send_k2[g]); simka_device_free(device_of(g), send_c[g]); send_k[g] = send_k2[g] = send_c[g] = nullptr; } };
         if (worst.load() != SIMKA_OK) { drop_send(); return worst.load(); }
         for (uint32_t g = 0; g < G; g++) for (size_t j = 0; j < mine[g].size(); j++) totals[mine[g][j]] = tot[g][j];
         if (o.verbose >= 2) std::cout << "ingest: " << n_dev_parsed << " samples parsed on the GPUs (" << n_pieces << " pieces of text), " << N - n_dev_parsed << " on the host" << std::endl;
@@ -946,27 +949,36 @@ int main(int argc, char **argv) {
             const uint64_t lo = lo_of(h), width = lo_of(h + 1) - lo;
             uint64_t nrec = 0;
             for (uint32_t g = 0; g < G; g++) nrec += blk[g][h + 1] - blk[g][h];
-            void *rk = nullptr, *rc_ = nullptr;
-            bool ok = note(simka_device_alloc(device_of(h), nrec * 8 + 8, &rk)) && note(simka_device_alloc(device_of(h), nrec * 4 + 8, &rc_));
+            void *rk = nullptr, *rk2 = nullptr, *rc_ = nullptr;
+            bool ok = note(simka_device_alloc(device_of(h), nrec * 8 + 8, &rk)) && note(simka_device_alloc(device_of(h), nrec * 4 + 8, &rc_)) &&
+                      (!two || note(simka_device_alloc(device_of(h), nrec * 8 + 8, &rk2)));
             uint64_t at = 0;
             for (uint32_t g = 0; ok && g < G; g++) {
                 const uint32_t n = (uint32_t)mine[g].size();
                 const uint64_t cnt = blk[g][h + 1] - blk[g][h];
                 if (n == 0) continue;
                 if (simka_device_copy(device_of(h), (char *)rk + at * 8, device_of(g), (const char *)send_k[g] + blk[g][h] * 8, cnt * 8) != SIMKA_OK ||
-                    simka_device_copy(device_of(h), (char *)rc_ + at * 4, device_of(g), (const char *)send_c[g] + blk[g][h] * 4, cnt * 4) != SIMKA_OK)
+                    simka_device_copy(device_of(h), (char *)rc_ + at * 4, device_of(g), (const char *)send_c[g] + blk[g][h] * 4, cnt * 4) != SIMKA_OK ||
+                    (two && simka_device_copy(device_of(h), (char *)rk2 + at * 8, device_of(g), (const char *)send_k2[g] + blk[g][h] * 8, cnt * 8) != SIMKA_OK))
                     die("EXCEPTION: simka_device_copy between GPUs failed");
                 std::vector<uint32_t> pcs((size_t)n * width);
                 std::vector<uint64_t> ino((size_t)n * width);
                 uint64_t run = 0;
                 for (uint32_t j = 0; j < n; j++)
                     for (uint64_t p = 0; p < width; p++) { pcs[(size_t)j * width + p] = pc[g][(size_t)j * P + lo + p]; ino[(size_t)j * width + p] = run; run += pcs[(size_t)j * width + p]; }
-                const int rc = simka_import_samples_device(c, mine[g].data(), n, tot[g].data(), lo, width, pcs.data(), ino.data(), P, (const char *)rk + at * 8, (const char *)rc_ + at * 4, cnt);
+                int rc;
+                if (two) {      // every sample's run of the block is contiguous and sorted (partitions = key-prefix ranges, ascending)
+                    std::vector<uint64_t> soff(n), srec(n);
+                    uint64_t at_ = 0;
+                    for (uint32_t j = 0; j < n; j++) { soff[j] = at_; for (uint64_t p = 0; p < width; p++) at_ += pcs[(size_t)j * width + p]; srec[j] = at_ - soff[j]; }
+                    rc = simka_import_samples_device_wide(c, mine[g].data(), n, tot[g].data(), soff.data(), srec.data(), (const char *)rk + at * 8, (const char *)rk2 + at * 8, (const char *)rc_ + at * 4);
+                } else
+                    rc = simka_import_samples_device(c, mine[g].data(), n, tot[g].data(), lo, width, pcs.data(), ino.data(), P, (const char *)rk + at * 8, (const char *)rc_ + at * 4, cnt);
                 if (rc != SIMKA_OK && rc != SIMKA_ERR_NOMEM) fatal(c, "simka_import_samples_device");
                 ok = note(rc);
                 at += cnt;
             }
-            simka_device_free(device_of(h), rk); simka_device_free(device_of(h), rc_);
+            simka_device_free(device_of(h), rk); simka_device_free(device_of(h), rk2); simka_device_free(device_of(h), rc_);
             if (ok) {
                 const int rc = simka_merge(c);
                 if (rc != SIMKA_OK && rc != SIMKA_ERR_NOMEM) fatal(c, "simka_merge");
@@ -1104,7 +1116,7 @@ int main(int argc, char **argv) {
     };
 
     bool host_mode = G > 1 || o.merge_ranges > 0;
-    if (G > 1 && o.merge_ranges <= 0 && !o.keep_tmp && !o.host_spectra && o.kmer_size <= 31 && N >= G) {
+    if (G > 1 && o.merge_ranges <= 0 && !o.keep_tmp && !o.host_spectra && N >= G) {
         const int rc = device_run();
         if (rc == SIMKA_OK) host_mode = false;
         else {

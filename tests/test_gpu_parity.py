@@ -1091,8 +1091,10 @@ def test_wide_kmers_through_spectrum_export_paths(gpu_required, golden_dir, tmp_
         return res, r.stdout
 
     ref, _ = run("plain", [])
-    assert run("g2", ["-nb-gpus", "2", "-gpu-shared"])[0] == ref
+    res2, log_g2 = run("g2", ["-nb-gpus", "2", "-gpu-shared"])            # spectra from GPU to GPU (high and low words in separate buffers)
+    assert res2 == ref and "spectra exchanged between the GPUs" in log_g2
     assert run("g3", ["-nb-gpus", "3", "-gpu-shared"])[0] == ref
+    assert run("g2h", ["-nb-gpus", "2", "-gpu-shared", "-host-spectra"])[0] == ref      # ... and through host memory
     assert run("ranges", ["-merge-ranges", "4"])[0] == ref
     first, log1 = run("keep_a", ["-keep-tmp"])
     again, log2 = run("keep_b", ["-keep-tmp"])
