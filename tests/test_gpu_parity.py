@@ -835,6 +835,40 @@ def test_cli_multi_gpu_spectra_stay_on_the_devices(gpu_required, golden_dir, tmp
     assert n == 20
 
 
+def test_rccl_communicator_of_the_c_abi_with_one_rank(gpu_required, golden_dir):
+    """simka_comm_* on the GPU box: librccl.so is dlopen'ed, a one-rank communicator is created from its own unique id, and the three
+    collectives of the C ABI run on it -- all-reduce of u64 words, the uneven all-to-all (rank 0 sends to itself), the all-reduce of a
+    context's statistics (a sum over one rank: unchanged).  What a second rank would add is only the peer."""
+    import torch
+    import simka_amd
+    from simka_amd import api
+    try:
+        uid = api.Comm.unique_id()
+    except api.SimkaError as e:
+        pytest.skip("no RCCL on this machine: %s" % e)
+    comm = api.Comm(uid, 1, 0, 0)
+    dev = torch.device("cuda", 0)
+    t = torch.arange(1000, dtype=torch.int64, device=dev)
+    comm.allreduce_u64(t.data_ptr(), t.numel(), torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    assert torch.equal(t.cpu(), torch.arange(1000, dtype=torch.int64))
+    src = torch.arange(5000, dtype=torch.int64, device=dev) * 3 + 1
+    dst = torch.zeros(5000, dtype=torch.int64, device=dev)
+    comm.alltoallv(src.data_ptr(), [5000], dst.data_ptr(), [5000], 8, torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    assert torch.equal(src, dst)
+    samples, packed = _load_example(golden_dir)
+    with simka_amd.SimkaContext(len(packed), kmer_size=21, abundance_min=2, simple_dist=True) as ctx:
+        for i, (pk, off, nb, nin) in enumerate(packed):
+            ctx.count_sample(i, pk, nb, len(off) - 1, offsets=off, nb_input_reads=nin)
+        ctx.merge()
+        before = ctx.stats().flat.copy()
+        ctx.allreduce_stats(comm, "all")
+        ctx.sync()
+        assert np.array_equal(ctx.stats().flat, before)
+    comm.close()
+
+
 def test_rccl_single_rank_runs_both_multi_gpu_protocols(gpu_required):
     """scripts/dist_smoke.py: torch.distributed on the real "nccl" (= RCCL) backend with one rank -- the partition-shard protocol
     and the whole sample-shard exchange (all_to_all_single with uneven splits, all_gather, head all-reduce; rank 0 sends to
