@@ -711,6 +711,11 @@ int main(int argc, char **argv) {
     // the slice of partition range [P*g/G, P*(g+1)/G) is imported into the merge context of GPU g (the reference: every
     // simkaMerge job reads partition p of every sample's solid/ directory, ref: src/SimkaMerge.cpp:1164-1264).
     const uint32_t G = (uint32_t)o.nb_gpus;
+    // Several contexts of this process on ONE device (-gpu-shared: the tests of the -nb-gpus routes on a one-GPU box): their arenas are
+    // plain allocations.  With lazily mapped ranges (hipMemMap / hipMemSetAccess by one worker thread while another context's kernels
+    // run on the same device) about one run in a hundred ended in a GPU memory access fault at an arena's base on ROCm 7.0; 300 runs
+    // with plain allocations: none.  Contexts on distinct devices keep the mapped ranges (page tables are per device).
+    if (o.same_gpu && G > 1) setenv("SIMKA_ARENA_MALLOC", "1", 1);
     const uint32_t flags = (o.simple ? SIMKA_DIST_SIMPLE : 0u) | (o.complex_ ? SIMKA_DIST_COMPLEX : 0u);
     // -keep-tmp: samples whose spectrum is in the temp dir and still valid are not read again
     std::vector<char> reuse(N, 0);
@@ -887,10 +892,11 @@ int main(int argc, char **argv) {
         std::mutex cnt_lock;
         {
             SampleLoader loader(samples, o, max_reads, nthreads, nthreads + 2 * G, reuse, !o.host_parse);
+            for (uint32_t g = 0; g < G; g++) if (!mine[g].empty()) cctx[g] = make_ctx((uint32_t)mine[g].size(), device_of(g));
             auto counter = [&](uint32_t g) {
                 const uint32_t n = (uint32_t)mine[g].size();
                 if (n == 0) return;
-                simka_ctx *c = cctx[g] = make_ctx(n, device_of(g));
+                simka_ctx *c = cctx[g];
                 uint64_t ndp = 0, npc = 0;
                 bool ok = true;
                 for (uint32_t j = 0; j < n; j++) {
@@ -941,8 +947,13 @@ int main(int argc, char **argv) {
             std::cerr << "-gpu-allreduce: " << simka_comm_last_error(nullptr) << "; summing on the host" << std::endl;
             use_rccl = false;
         }
+        // (the merge contexts are created before and destroyed after the worker threads: with several contexts on ONE device -- -gpu-shared,
+        // the tests -- a context's virtual ranges being reserved or given back while another context's kernels run ended in a memory
+        // access fault once in some dozen runs)
+        std::vector<simka_ctx *> mctx(G, nullptr);
+        for (uint32_t h = 0; h < G; h++) mctx[h] = make_ctx(N, device_of(h));
         auto merger = [&](uint32_t h) {
-            simka_ctx *c = make_ctx(N, device_of(h));
+            simka_ctx *c = mctx[h];
             simka_comm *comm = nullptr;
             if (use_rccl && simka_comm_create(comm_id, (int)G, (int)h, device_of(h), &comm) != SIMKA_OK)
                 die(std::string("EXCEPTION: simka_comm_create: ") + simka_comm_last_error(nullptr));
@@ -997,11 +1008,11 @@ int main(int argc, char **argv) {
                 if (!have_tail) { for (uint64_t w = lay[5]; w < nw; w++) flat[w] = shard[w]; have_tail = true; }
             }
             if (comm) simka_comm_destroy(comm);
-            simka_destroy(c);
         };
         std::vector<std::thread> th;
         for (uint32_t h = 0; h < G; h++) th.emplace_back(merger, h);
         for (auto &t : th) t.join();
+        for (uint32_t h = 0; h < G; h++) simka_destroy(mctx[h]);
         drop_send();
         return worst.load();
     };
@@ -1067,8 +1078,10 @@ int main(int argc, char **argv) {
             std::cerr << "-gpu-allreduce: " << simka_comm_last_error(nullptr) << "; summing on the host" << std::endl;
             use_rccl = false;
         }
+        std::vector<simka_ctx *> mctx(G, nullptr);          // (created before, destroyed after the worker threads: see device_run)
+        for (uint32_t g = 0; g < G; g++) mctx[g] = make_ctx(N, device_of(g));
         auto merger = [&](uint32_t g) {
-            simka_ctx *c = make_ctx(N, device_of(g));
+            simka_ctx *c = mctx[g];
             simka_comm *comm = nullptr;
             if (use_rccl && simka_comm_create(comm_id, (int)G, (int)g, device_of(g), &comm) != SIMKA_OK)
                 die(std::string("EXCEPTION: simka_comm_create: ") + simka_comm_last_error(nullptr));
@@ -1108,11 +1121,11 @@ int main(int argc, char **argv) {
                 if (!have_tail) { for (uint64_t w = lay[5]; w < nw; w++) flat[w] = shard[w]; have_tail = true; }
             }
             if (comm) simka_comm_destroy(comm);
-            simka_destroy(c);
         };
         std::vector<std::thread> th;
         for (uint32_t g = 0; g < G; g++) th.emplace_back(merger, g);
         for (auto &t : th) t.join();
+        for (uint32_t g = 0; g < G; g++) simka_destroy(mctx[g]);
     };
 
     bool host_mode = G > 1 || o.merge_ranges > 0;

@@ -257,6 +257,11 @@ SIMKA_EXPORT int simka_stats_describe(uint32_t N, uint32_t flags, uint64_t *h, u
 // ---- lifecycle ----------------------------------------------------------------------------
 SIMKA_EXPORT int simka_abi_version(void) { return SIMKA_ABI_VERSION; }
 
+// Reserving, mapping and unmapping virtual ranges from several threads at once (contexts of one process on one device: `simka -nb-gpus
+// -gpu-shared`, one worker thread per context) ended, once in ten runs, in a memory access fault at the base of a freshly mapped arena:
+// the virtual-memory calls of a process go one at a time.
+static std::mutex g_vmm_lock;
+
 SIMKA_EXPORT const char *simka_last_error(const simka_ctx *ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
 
 // k_skm_scan<W, FIXED, HIST>
@@ -371,6 +376,7 @@ static int setup_geometry(simka_ctx *ctx, uint64_t max_kmers) {
     ctx->arena_cap = cap;
     const double tdbg0 = getenv("SIMKA_DEBUG_SYNC") ? wall_now() : 0;
     {   // reserve the range; memory comes with arena_ensure().  Without the virtual-memory API: one allocation, as before.
+        std::lock_guard<std::mutex> vmm_guard(g_vmm_lock);
         void *vk = nullptr, *vc = nullptr;
         const uint64_t capr = (cap + ARENA_CHUNK - 1) / ARENA_CHUNK * ARENA_CHUNK;
         if (!getenv("SIMKA_ARENA_MALLOC") && hipMemAddressReserve(&vk, capr * 8, 0, nullptr, 0) == hipSuccess) {
@@ -505,6 +511,7 @@ SIMKA_EXPORT void simka_destroy(simka_ctx *ctx) {
     for (uint32_t li = 0; li < simka_ctx::MAX_LANES; li++) { if (ctx->d_reads[li]) (void)hipFree(ctx->d_reads[li]); if (ctx->d_offsets[li]) (void)hipFree(ctx->d_offsets[li]); }
     for (auto &g : ctx->ing) { void *q[] = { g.d_text, g.d_lines, g.d_tmp, g.d_tot }; for (void *p_ : q) if (p_) (void)hipFree(p_); }
     if (ctx->arena_vmm) {      // unmap and release the chunks, give the ranges back
+        std::lock_guard<std::mutex> vmm_guard(g_vmm_lock);
         (void)hipDeviceSynchronize();
         if (ctx->arena_mapped) { (void)hipMemUnmap(ctx->d_solid_keys, ctx->arena_mapped * 8); (void)hipMemUnmap(ctx->d_solid_counts, ctx->arena_mapped * 4); }
         for (auto h : ctx->arena_hk) (void)hipMemRelease(h);
@@ -589,6 +596,7 @@ static int ensure_cap(simka_ctx *ctx, T **p, uint64_t *cap, uint64_t need) {
 static int arena_ensure(simka_ctx *ctx, uint64_t need) {
     need = std::min(need, ctx->arena_cap);                                 // (beyond the capacity: the kernels flag SIMKA_DEVERR_ARENA_FULL)
     if (!ctx->arena_vmm || need <= ctx->arena_mapped) return SIMKA_OK;
+    std::lock_guard<std::mutex> vmm_guard(g_vmm_lock);
     hipMemAllocationProp prop = {};
     prop.type = hipMemAllocationTypePinned; prop.location.type = hipMemLocationTypeDevice; prop.location.id = ctx->cfg.device;
     hipMemAccessDesc acc = {};
