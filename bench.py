@@ -234,6 +234,10 @@ def main():
     backend = os.environ.get("SIMKA_BENCH_BACKEND", "nccl")      # "nccl" IS RCCL on ROCm; gloo only for single-GPU tests of the N>1 path
     if world > 1 and backend == "nccl" and torch.cuda.device_count() < world:
         raise SystemExit("bench.py: %d ranks but %d visible GPUs (RCCL needs one GPU per rank)" % (world, torch.cuda.device_count()))
+    if world > torch.cuda.device_count():
+        # several ranks on one device (the gloo tests of the N > 1 path): plain arena allocations -- chunks of a lazily mapped arena
+        # being mapped while another context's kernels run on the same device faulted once in ~100 runs of `simka -nb-gpus -gpu-shared`
+        os.environ["SIMKA_ARENA_MALLOC"] = "1"
     local = local % torch.cuda.device_count()        # tests run two ranks on one GPU (gloo)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
