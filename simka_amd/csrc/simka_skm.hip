@@ -980,16 +980,18 @@ k_skm_count_wide(const uint4 *recs, const uint32_t *pstart, const uint32_t *pcnt
 // every record its place, so consecutive lanes store consecutive records.
 // --------------------------------------------------------------------------------------------
 #define SKM_WF_BLOCK 256
-#define SKM_WF_TS 512
+#ifndef SKM_WF_TSL
 #define SKM_WF_TSL 9
+#endif
+#define SKM_WF_TS (1 << SKM_WF_TSL)
 #define SKM_WF_CHUNK 32
 #define SKM_WF_SLAB 512
 #define SKM_WF_CBITS 26
 #ifndef SKM_WF_LOADX
 #define SKM_WF_LOADX 4u            // half-slots per k-mer occurrence of a one-chunk partition
 #endif
-// (records + map: at least the 768 bytes the summary's list of solid slots takes)
-SIMKA_HD uint32_t skm_wf_wave_bytes(uint32_t nmax) { const uint32_t rm = SKM_WF_CHUNK * 16u + ((SKM_WF_CHUNK * nmax * 2u + 15u) & ~15u); return SKM_WF_TS * 16u + (rm < 768u ? 768u : rm); }
+// (records + map: at least the 3 TS / 4 two-byte entries the summary's list of solid slots takes)
+SIMKA_HD uint32_t skm_wf_wave_bytes(uint32_t nmax) { const uint32_t rm = SKM_WF_CHUNK * 16u + ((SKM_WF_CHUNK * nmax * 2u + 15u) & ~15u); const uint32_t lst = SKM_WF_TS * 3u / 2u; return SKM_WF_TS * 16u + (rm < lst ? lst : rm); }
 
 __device__ __forceinline__ void skm_wcanon(const uint4 &r, uint32_t j, uint32_t k, uint32_t s2, ull &hi, ull &lo, uint32_t &slot) {
     ull fh, fl;
