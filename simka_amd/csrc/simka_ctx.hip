@@ -577,6 +577,7 @@ static int check_device_error(simka_ctx *ctx) {
     if (e & SIMKA_DEVERR_SAMPLE_TOO_BIG) return ctx->fail(SIMKA_ERR_OVERFLOW, "a sample holds more than 2^32 solid k-mers");
     if (e & SIMKA_DEVERR_GROUP_OVERFLOW) return ctx->fail(SIMKA_ERR_OVERFLOW, "merge: a sub-range could not be split below the LDS capacity");
     if (e & SIMKA_DEVERR_CSR_FULL) return ctx->fail(SIMKA_ERR_NOMEM, "merge: group buffer exhausted");
+    if (e & SIMKA_DEVERR_SEGMENT_TOO_BIG) return ctx->fail(SIMKA_ERR_OVERFLOW, "a partition of one sample holds more than 65535 solid k-mers (the merge index has 16-bit rows): raise log2_partitions (now %u; 0 = sized from max_kmers_per_sample)", ctx->key.pb);
     if (e & SIMKA_DEVERR_UNORDERED) return ctx->fail(SIMKA_ERR_INVALID, "merge: a spectrum is not ordered by key prefix inside its partitions (imported from another version?)");
     return SIMKA_OK;
 }
@@ -735,7 +736,9 @@ static int run_count_kernels(simka_ctx *ctx, uint32_t sample, const SimkaScanArg
         // what this sample can add to the arena at most: every solid k-mer has >= abundance_min occurrences, plus the tails of the
         // blocks' slab reservations
         const uint64_t kocc_b = a.fixed_len ? (a.fixed_len >= sk.k ? a.nb_reads * (uint64_t)(a.fixed_len - sk.k + 1) : 0) : a.nb_bases;
-        const uint64_t bound = kocc_b / std::max<uint32_t>(1u, ctx->cfg.abundance_min) + (uint64_t)ctx->num_cus * 4 * K2_SLAB;
+        // (slab_take loses at most a third on top of the records it places; every block of the two count kernels leaves one open slab)
+        const uint64_t solid_up = kocc_b / std::max<uint32_t>(1u, ctx->cfg.abundance_min);
+        const uint64_t bound = solid_up + solid_up / 3 + (uint64_t)ctx->num_cus * 6 * K2_SLAB;
         ctx->arena_hi = std::min<uint64_t>(ctx->arena_cap, ctx->arena_hi + bound);
         ctx->lane_bound[sample % ctx->nlanes] = bound;
         rc = arena_ensure(ctx, ctx->arena_hi); if (rc) return rc;
@@ -834,6 +837,7 @@ static int resolve_pending(simka_ctx *ctx, int lane) {
     for (auto &p : todo) {
         if (!flags[p.sample]) continue;
         ctx->nb_exact_fallbacks++;
+        if (ctx->arena_accounted.size() == N) ctx->arena_accounted[p.sample] = 0;      // its bound left arena_hi above: the redo adds it again
         HIPCHK(hipMemsetAsync(ctx->d_l1_ovf + p.sample, 0, 4, cs));
         HIPCHK(hipStreamSynchronize(cs));
         int rc = run_count_kernels(ctx, p.sample, p.a, true, p.pass, p.npass);
@@ -1049,6 +1053,7 @@ SIMKA_EXPORT int simka_count_sample(simka_ctx *ctx, uint32_t sample, const simka
         npass = std::max<uint32_t>(1, std::min(npass, max_pass));
     }
     for (uint32_t j = 0; j < npass; j++) {
+        if (j && ctx->arena_accounted.size() == N) ctx->arena_accounted[sample] = 0;      // resolve_pending() dropped the bound of the pass before
         rc = run_count_kernels(ctx, sample, a, false, j, npass);
         if (rc) return rc;
         if (npass > 1) { rc = resolve_pending(ctx); if (rc) return rc; }       // the passes share the scratch buffers

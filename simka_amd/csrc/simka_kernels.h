@@ -58,6 +58,7 @@
 #define SIMKA_DEVERR_GROUP_OVERFLOW 8u
 #define SIMKA_DEVERR_CSR_FULL 16u
 #define SIMKA_DEVERR_UNORDERED 32u
+#define SIMKA_DEVERR_SEGMENT_TOO_BIG 64u   // a (sample, partition) segment holds more than 65535 solid k-mers: the merge index has 16-bit rows
 
 struct SimkaScanArgs {
     const uint64_t *packed;

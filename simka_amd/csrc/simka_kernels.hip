@@ -95,15 +95,27 @@ k_tile_reads(const uint64_t *offsets, uint64_t nb_reads, uint64_t nb_bases, uint
 }
 
 // reserve `ns` arena records for one partition out of the block's private slab (thread 0 only)
+// A block reserves arena space in slabs of o.slab records.  What is left of a slab when a partition does not fit is lost, so the
+// loss must be bounded for the host's upper bound of the arena cursor (run_count_kernels, SIMKA_SLAB_WASTE_NUM/DEN): a partition of
+// at least a quarter of a slab that does not fit takes EXACTLY its records from the global cursor and leaves the open slab alone;
+// only a smaller one opens a new slab, losing less than a quarter of the old one -- at most 1/3 on top of the records placed.
 __device__ __forceinline__ ull slab_take(ull &slab_pos, ull &slab_end, uint32_t ns, const SimkaCountOut &o, ull sample_base, uint32_t &ok) {
+    ull b;
     if (slab_pos + ns > slab_end) {
-        const ull want = ns > o.slab ? (ull)ns : (ull)o.slab;
-        slab_pos = atomicAdd(o.arena_cursor, want);
-        slab_end = slab_pos + want;
-        if (slab_end > o.arena_cap) { atomicOr(o.err, SIMKA_DEVERR_ARENA_FULL); ok = 0; slab_end = slab_pos; return 0; }
+        if ((ull)ns * 4ull >= (ull)o.slab) {
+            b = atomicAdd(o.arena_cursor, (ull)ns);
+            if (b + ns > o.arena_cap) { atomicOr(o.err, SIMKA_DEVERR_ARENA_FULL); ok = 0; return 0; }
+        } else {
+            slab_pos = atomicAdd(o.arena_cursor, (ull)o.slab);
+            slab_end = slab_pos + o.slab;
+            if (slab_end > o.arena_cap) { atomicOr(o.err, SIMKA_DEVERR_ARENA_FULL); ok = 0; slab_end = slab_pos; return 0; }
+            b = slab_pos;
+            slab_pos += ns;
+        }
+    } else {
+        b = slab_pos;
+        slab_pos += ns;
     }
-    const ull b = slab_pos;
-    slab_pos += ns;
     if (b - sample_base + ns > 0xffffffffull) { atomicOr(o.err, SIMKA_DEVERR_SAMPLE_TOO_BIG); ok = 0; }
     return b;
 }
@@ -158,7 +170,8 @@ k_segment_rows(SimkaMergeIn in, SimkaKeyCfg cfg, uint64_t part_begin, uint32_t n
         uint32_t e[SIMKA_SEG_BLOCKS];
 #pragma unroll
         for (uint32_t q = 0; q < SIMKA_SEG_BLOCKS; q++) e[q] = 0;
-        uint32_t last = 0; bool bad = n > 0xffffu;
+        uint32_t last = 0; bool bad = false;
+        if (n > 0xffffu && lane == 0) atomicOr(err, SIMKA_DEVERR_SEGMENT_TOO_BIG);
         for (uint32_t i0 = 0; i0 < n; i0 += 64u) {
             const bool v = i0 + lane < n;
             const uint32_t blk = v ? simka_key_hash32(in.solid_keys[b + i0 + lane]) >> (32u - SIMKA_SEG_BITS) : SIMKA_SEG_BLOCKS;     // (beyond the end: above every block)

@@ -34,6 +34,12 @@
 
 typedef unsigned long long ull;
 
+#ifdef SKM_SCAN_STOP       // experiments: the scan returns after phase n (timing only, the results are garbage)
+#define SKM_STOP_AT(n) if (SKM_SCAN_STOP == (n)) return;
+#else
+#define SKM_STOP_AT(n)
+#endif
+
 #define SKM_TILE 8192            // m-mer positions hashed per block (entry i <-> base position Q0 + i)
 #define SKM_OWN_LO 32            // a tile emits the k-mers starting at entries [32, 8160): 254 words of 32 bases
 #define SKM_OWN_HI (SKM_TILE - 32)
@@ -182,6 +188,7 @@ k_skm_scan(SimkaScanArgs a, SimkaSkmCfg cfg, ull *b1_count, ull *b1_cursor, uint
         if (tid < 16) dst[(tid >> 2) * SKM_NT + SKM_BLOCK + (tid & 3u)] = make_uint4(~0u, ~0u, ~0u, ~0u);       // pad columns read by the last threads
     }
     __syncthreads();
+    SKM_STOP_AT(1)
 
     // ---- phase 2: minimizer value of the k-mers at entries e_j = 16t - 1 + j, j = 0..16 (window of W entries)
     const bool owner = tid >= SKM_OWN_LO / SKM_SEG && tid < SKM_OWN_HI / SKM_SEG;
@@ -299,6 +306,7 @@ k_skm_scan(SimkaScanArgs a, SimkaSkmCfg cfg, ull *b1_count, ull *b1_cursor, uint
         brk = (start | ~V) & 0xffffu;
     }
     smask[tid] = start | (brk << 16);
+    SKM_STOP_AT(2)
     __syncthreads();               // (A) hm is dead from here on
     {
         // a run without a break for 32 positions restarts at a thread's first entry, so the look-ahead below stays within 64 bits
@@ -324,6 +332,7 @@ k_skm_scan(SimkaScanArgs a, SimkaSkmCfg cfg, ull *b1_count, ull *b1_cursor, uint
         }
     }
     __syncthreads();
+    SKM_STOP_AT(3)
     const uint32_t nstart = s_nstart;
     const bool listed = nstart <= lcap;
     if (!listed) {
@@ -365,6 +374,7 @@ k_skm_scan(SimkaScanArgs a, SimkaSkmCfg cfg, ull *b1_count, ull *b1_cursor, uint
     // ---- phase 3c: records per level-1 bucket
     for_runs([&](uint32_t, uint32_t len, uint32_t pid) { atomicAdd(&hist[cfg.pb ? pid >> (cfg.pb - cfg.l1) : 0u], 1u + (len > cfg.nmax ? 1u : 0u) + (len > 2u * cfg.nmax ? 1u : 0u) + (len > 3u * cfg.nmax ? (len - 1u) / cfg.nmax - 2u : 0u)); });       // = ceil(len / nmax), len <= 48: no division on the common path
     __syncthreads();               // (C)
+    SKM_STOP_AT(4)
     if (HIST) {
         if (tid < B1 && hist[tid]) atomicAdd(&b1_count[tid], (ull)hist[tid]);
         return;
@@ -416,6 +426,7 @@ k_skm_scan(SimkaScanArgs a, SimkaSkmCfg cfg, ull *b1_count, ull *b1_cursor, uint
             }
         });
     }
+    SKM_STOP_AT(5)
     if (tid < SKM_MAXB1) {
         if (h_res && b1_limit && g_res + h_res > b1_limit[tid]) { *ovf_flag = 1u; g_res = ~0ull; }
         gbase[tid] = g_res;
@@ -775,7 +786,7 @@ k_skm_count(const uint4 *recs, const uint32_t *pstart, const uint32_t *pcnt, Sim
                     uint32_t run = 0;
                     for (uint32_t b_ = 0; b_ < SIMKA_SEG_BLOCKS; b_++) { run += s_row[b_]; s_row[b_] = 0; o.seg_rows[((size_t)part * o.nb_samples) * SIMKA_SEG_BLOCKS + b_] = (uint16_t)(ok ? (run > 0xffffu ? 0xffffu : run) : 0u); }
                     o.seg_abs[(size_t)part * o.nb_samples] = seg;
-                    if (run > 0xffffu) atomicOr(o.err, SIMKA_DEVERR_UNORDERED);
+                    if (run > 0xffffu) atomicOr(o.err, SIMKA_DEVERR_SEGMENT_TOO_BIG);
                 }
             }
             bt_dall += pD_all; bt_D += pD; bt_N += pN; bt_Q += pQ; bt_kocc += pK;

@@ -123,3 +123,75 @@ def test_shard_additivity_and_geometry_invariance(device_reads):
     other.close()
     assert np.array_equal(st2.flat[:klo], ref.flat[:klo])
     assert np.array_equal(st2.flat[klo + P: lay["derived"]], ref.flat[klo + P: lay["derived"]])
+
+
+def _oracle_of(oracle_mod, reads, n, R_, L_):
+    """the CPU oracle over the same reads, downloaded from the device generator (all host cores: sort-count per sample is
+    parallel over the oracle's partitions)"""
+    from simka_amd import synth
+    import os
+    orc = oracle_mod.Oracle()
+    offs = np.arange(R_ + 1, dtype=np.uint64) * L_
+    for s in range(n):
+        pk = reads[s].cpu().numpy().view(np.uint64)
+        orc.add_sample_ascii("S%d" % s, synth.unpack_ascii(pk[: (R_ * L_ + 31) // 32], R_ * L_), offs)
+    return orc, min(os.cpu_count() or 1, 64)
+
+
+def _flat_equal_to_oracle(st, orc, n, simple, complex_):
+    """every per-sample total and every integer accumulator bit for bit, KL to 1e-9, the matrices to 1e-6 relative"""
+    ot, ps, pr = orc.totals(), st.per_sample(), st.pairs()
+    for key in ("K_occ", "D_all", "D", "N", "Q"):
+        assert np.array_equal(ps[key].astype(np.uint64), ot[key]), key
+    iu = np.triu_indices(n, 1)
+    S = orc.acc("S")
+    assert np.array_equal(pr["S_ij"], S[iu]) and np.array_equal(pr["S_ji"], S.T[iu])
+    assert np.array_equal(pr["a"], orc.acc("a")[iu]) and np.array_equal(pr["bc"], orc.acc("bc")[iu])
+    if simple:
+        assert np.array_equal(pr["chord"], orc.acc("chord")[iu]) and np.array_equal(pr["hell"], orc.acc("hell")[iu])
+    if complex_:
+        assert np.array_equal(pr["whit"], orc.acc("whit")[iu]) and np.array_equal(pr["canb"], orc.acc("canb")[iu])
+        np.testing.assert_allclose(pr["kl"], orc.kl()[iu], rtol=1e-9, atol=1e-15)
+    assert (int(st.view.nb_distinct_kmers), int(st.view.nb_shared_kmers)) == orc.global_counts()
+    m = st.matrices()
+    for w, name in enumerate(orc.matrix_names()):
+        if name in m:
+            np.testing.assert_allclose(m[name], orc.matrix(w), rtol=1e-6, atol=0, err_msg=name)
+
+
+def test_c2_full_size_bit_exact_vs_oracle(device_reads, oracle_mod):
+    """BASELINE configs[1] AT FULL SIZE (10 x 1M x 100 bp, k = 21, abundance-min 2; all three distance families, which contain the
+    configuration's Bray-Curtis + Jaccard): 8e8 k-mer occurrences through the HIP path against the CPU oracle -- whole-path equality
+    in the spirit of the reference's own test (ref: tests/simple_test.py:29-68)."""
+    ctx = _run(device_reads, 2)
+    ctx.merge()
+    st = ctx.stats()
+    ctx.close()
+    orc, threads = _oracle_of(oracle_mod, device_reads, N, R, L)
+    orc.run(K, 2, simple=True, complex_=True, nparts=4 * threads, threads=threads)
+    _flat_equal_to_oracle(st, orc, N, True, True)
+    orc.close()
+
+
+def test_c3_shape_at_100k_reads_bit_exact_vs_oracle(gpu_required, oracle_mod):
+    """BASELINE configs[2]'s shape (100 samples, 150 bp, k = 31, -simple-dist, abundance-min 2) at 100 000 reads per sample -- 1.2e9
+    k-mer occurrences, a hundredth of the full depth and 20x the depth of test_baseline_config_shapes_vs_oracle -- bit-exact vs the
+    oracle.  The partition geometry is the one the full-depth run uses per k-mer occurrence (sized from the sample)."""
+    torch = gpu_required
+    import simka_amd
+    import bench
+    n, R3, L3, k3 = 100, 100_000, 150, 31
+    wl = dict(bench.WORKLOADS["c3"], n=n, reads=R3)
+    lib = simka_amd.load_library()
+    _, reads = bench.gen_device_samples(lib, torch, wl, torch.device("cuda", 0))
+    ctx = simka_amd.SimkaContext(n, kmer_size=k3, abundance_min=2, simple_dist=True, complex_dist=False, max_kmers_per_sample=R3 * (L3 - k3 + 1))
+    for s in range(n):
+        ctx.count_sample(s, reads[s].data_ptr(), R3 * L3, R3, fixed_len=L3, on_device=True)
+    ctx.merge()
+    st = ctx.stats()
+    ctx.close()
+    orc, threads = _oracle_of(oracle_mod, reads, n, R3, L3)
+    del reads
+    orc.run(k3, 2, simple=True, complex_=False, nparts=4 * threads, threads=threads)
+    _flat_equal_to_oracle(st, orc, n, True, False)
+    orc.close()
