@@ -1,8 +1,8 @@
-# build a variant of the library for A/B runs: bash scripts/build_variant.sh NAME [-DFLAG=..]...  ->  simka_amd/lib/variants/NAME.so
-# (then: LIBS="NAME=simka_amd/lib/variants/NAME.so ..." bash scripts/ab.sh on the GPU box)
+# build a variant of the library for A/B runs: bash scripts/build_variant.sh NAME [-DFLAG=..]...  ->  simka_amd/lib/libsimka_NAME.so
+# (then: LIBS="NAME=simka_amd/lib/libsimka_NAME.so ..." bash scripts/ab.sh on the GPU box)
 set -e
 name=$1; shift
 cd "$(dirname "$0")/../simka_amd/csrc"
-mkdir -p ../lib/variants
-hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -fvisibility=hidden -Wno-unused-result "$@" -o ../lib/variants/$name.so simka_ctx.hip simka_wide.hip simka_host.cpp -lz -ldl 2>&1 | grep -E "error|Error" || true
-ls -la ../lib/variants/$name.so
+
+hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -fvisibility=hidden -Wno-unused-result "$@" -o ../lib/libsimka_$name.so simka_ctx.hip simka_wide.hip simka_host.cpp -lz -ldl 2>&1 | grep -E "error|Error" || true
+ls -la ../lib/libsimka_$name.so

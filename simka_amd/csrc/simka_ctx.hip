@@ -53,6 +53,8 @@ struct simka_ctx {
         uint4 *d_skm_a = nullptr, *d_skm_b = nullptr; uint64_t skm_a_cap = 0, skm_b_cap = 0;
         uint32_t *d_skm_p = nullptr; uint64_t skm_p_cap = 0;      // partition id of every level-1 record (4-byte side array)
         uint32_t *d_pstart = nullptr, *d_pcnt = nullptr;
+        // gather mode (k_skm_chunksort): chunk numbering of the level-1 buckets, chunk table
+        uint32_t *d_cbase = nullptr; uint16_t *d_ctab = nullptr; uint64_t ctab_cap = 0;
     };
     static constexpr uint32_t MAX_LANES = 4;
     Lane lanes[MAX_LANES];
@@ -282,9 +284,12 @@ static int set_lds_attr(simka_ctx *ctx) {
     HIPCHK(hipFuncSetAttribute((const void *)k_pairs<true, K4_BLOCK_BIG>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
     HIPCHK(hipFuncSetAttribute((const void *)k_pairs_tm, hipFuncAttributeMaxDynamicSharedMemorySize, big));
     for (int wi = 0; wi < 6; wi++) for (int v = 0; v < 4; v++) HIPCHK(hipFuncSetAttribute((const void *)skm_scan_kernel(wi, v & 2, v & 1), hipFuncAttributeMaxDynamicSharedMemorySize, big));
-    HIPCHK(hipFuncSetAttribute((const void *)k_skm_count, hipFuncAttributeMaxDynamicSharedMemorySize, big));
+    HIPCHK(hipFuncSetAttribute((const void *)k_skm_count<false>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
+    HIPCHK(hipFuncSetAttribute((const void *)k_skm_count<true>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
     HIPCHK(hipFuncSetAttribute((const void *)k_skm_split, hipFuncAttributeMaxDynamicSharedMemorySize, big));
-    HIPCHK(hipFuncSetAttribute((const void *)k_skm_count_fast, hipFuncAttributeMaxDynamicSharedMemorySize, big));
+    HIPCHK(hipFuncSetAttribute((const void *)k_skm_chunksort, hipFuncAttributeMaxDynamicSharedMemorySize, big));
+    HIPCHK(hipFuncSetAttribute((const void *)k_skm_count_fast<false>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
+    HIPCHK(hipFuncSetAttribute((const void *)k_skm_count_fast<true>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
     HIPCHK(hipFuncSetAttribute((const void *)k_skm_count_wide, hipFuncAttributeMaxDynamicSharedMemorySize, big));
     HIPCHK(hipFuncSetAttribute((const void *)k_skm_count_wide_fast, hipFuncAttributeMaxDynamicSharedMemorySize, big));
     return SIMKA_OK;
@@ -342,6 +347,7 @@ static int setup_geometry(simka_ctx *ctx, uint64_t max_kmers) {
         HIPCHK(dev_alloc(&L.d_redo_list, ctx->nparts + 1));
         HIPCHK(dev_alloc(&L.d_redo_count, 2));
         HIPCHK(dev_alloc(&L.d_pstart, ctx->nparts + 1)); HIPCHK(dev_alloc(&L.d_pcnt, ctx->nparts + 1));
+        HIPCHK(dev_alloc(&L.d_cbase, SKM_MAXB1 + 2));
     }
     HIPCHK(dev_alloc(&ctx->d_l1_ovf, c.nb_samples + 1));
     HIPCHK(hipMemsetAsync(ctx->d_l1_ovf, 0, (size_t)(c.nb_samples + 1) * 4, ctx->stream));
@@ -501,7 +507,7 @@ SIMKA_EXPORT void simka_destroy(simka_ctx *ctx) {
     for (auto &L : ctx->lanes) {
         if (L.stream) (void)hipStreamSynchronize(L.stream);
         void *lp[] = { L.d_b1_count, L.d_b1_start, L.d_b1_end, L.d_b1_cursor, L.d_tile_r0, L.d_redo_list, L.d_redo_count,
-                       L.d_skm_a, L.d_skm_b, L.d_skm_p, L.d_pstart, L.d_pcnt };
+                       L.d_skm_a, L.d_skm_b, L.d_skm_p, L.d_pstart, L.d_pcnt, L.d_cbase, L.d_ctab };
         for (void *q : lp) if (q) (void)hipFree(q);
         if (L.stream && L.stream != ctx->stream) (void)hipStreamDestroy(L.stream);
     }
@@ -630,8 +636,11 @@ static int arena_cursor_now(simka_ctx *ctx, ull *cur, hipStream_t st) {
 // the sample with exact=true (a histogram-only scan first).
 // scan + split of one sample (or one pass over it) on lane L: the partitioned records end up in L.d_skm_b, described by L.d_pstart /
 // L.d_pcnt.  `sk` carries the partition geometry (and the pass's shard).  Returns the sample's k-mer bound in *kocc_up_out.
+// *gather (in: allowed, out: used): the records stay in L.d_skm_a, every chunk of a level-1 bucket ordered by partition in place
+// (k_skm_chunksort, table L.d_ctab / L.d_cbase) and the count kernels gather a partition's pieces -- unless a bucket could hold more
+// chunks than their piece tables take, then the exact split as before.
 static int skm_scan_split(simka_ctx *ctx, simka_ctx::Lane &L, uint32_t sample, const SimkaScanArgs &a_in, const SimkaSkmCfg &sk, bool exact, uint32_t pass,
-                          uint64_t *kocc_up_out) {
+                          uint64_t *kocc_up_out, bool *gather) {
     const hipStream_t st = L.stream;
     int rc;
     SimkaScanArgs a = a_in;
@@ -657,18 +666,22 @@ static int skm_scan_split(simka_ctx *ctx, simka_ctx::Lane &L, uint32_t sample, c
     auto scan_lds = [&](bool) {
         return (size_t)SIMKA_LDS_HEAD + rbytes + (SKM_TILE / 16 + 8) * 4 + (SKM_BLOCK + 4) * 4 + SKM_MAXB1 * 4 * 2 + SKM_MAXB1 * 8 + (fixed ? 0 : SKM_RTAB * 4);
     };
+    static const bool no_gather = getenv("SIMKA_SKM_SPLIT") != nullptr;      // tests: the exact split instead of chunk sort + gather
+    bool use_gather = *gather && !no_gather && L.d_cbase;
     auto layout = [&](uint32_t mode, ull capb) {
         launch_timed(ctx, KID_LAYOUT, [&] {
             hipLaunchKernelGGL(k_skm_layout, dim3(1), dim3(SKM_MAXB1), 0, st, L.d_b1_count, L.d_b1_start, L.d_b1_end, L.d_b1_cursor, B1, mode, capb,
-                               ctx->d_arena_cursor, ctx->d_sample_base + sample, pass == 0 ? 1u : 0u, (const uint32_t *)flag, L.d_redo_count);
+                               ctx->d_arena_cursor, ctx->d_sample_base + sample, pass == 0 ? 1u : 0u, (const uint32_t *)flag, L.d_redo_count,
+                               use_gather ? L.d_cbase : (uint32_t *)nullptr, (uint32_t)SKM_CS_CHUNK);
         }, st);
     };
     auto scan = [&](bool hist, const ull *limit) {
         launch_timed(ctx, hist ? KID_SCAN_HIST : KID_SKM_SCAN, [&] {
             hipLaunchKernelGGL(skm_scan_kernel(wi, fixed, hist), dim3(ntiles), dim3(SKM_BLOCK), scan_lds(hist), st, a, sk, L.d_b1_count, L.d_b1_cursor, L.d_skm_a, limit,
-                               hist ? (uint32_t *)nullptr : flag, caprec, rbytes, scan_lcap(hist), L.d_skm_p);
+                               hist ? (uint32_t *)nullptr : flag, caprec, rbytes, scan_lcap(hist), use_gather ? (uint32_t *)nullptr : L.d_skm_p);
         }, st);
     };
+    const uint32_t cstride = ((1u << sk.l2) + 2u + 1u) & ~1u;      // u16 entries per row of the chunk table (even: rows are 4-byte aligned)
     uint64_t rec_cap;
     if (!exact) {
         // expected records: one per (W + 1) / 2 k-mers (or per nmax, if a record takes fewer); a bucket gets its share + 12 % + slack.
@@ -676,9 +689,12 @@ static int skm_scan_split(simka_ctx *ctx, simka_ctx::Lane &L, uint32_t sample, c
         const uint64_t est = (uint64_t)((double)kocc_up / std::max(1.0, std::min<double>((sk.W + 1) / 2.0, sk.nmax)) * 1.30 / sk.shard_count);
         const uint64_t capb = est / B1 + est / B1 / 8 + 4096;
         rec_cap = capb * B1;
+        if ((capb + SKM_CS_CHUNK - 1) / SKM_CS_CHUNK > SKM_G_MAXCH) use_gather = false;
         rc = ensure_cap(ctx, &L.d_skm_a, &L.skm_a_cap, rec_cap); if (rc) return rc;
-        rc = ensure_cap(ctx, &L.d_skm_b, &L.skm_b_cap, rec_cap); if (rc) return rc;
-        rc = ensure_cap(ctx, &L.d_skm_p, &L.skm_p_cap, rec_cap); if (rc) return rc;
+        if (!use_gather) {
+            rc = ensure_cap(ctx, &L.d_skm_b, &L.skm_b_cap, rec_cap); if (rc) return rc;
+            rc = ensure_cap(ctx, &L.d_skm_p, &L.skm_p_cap, rec_cap); if (rc) return rc;
+        }
         layout(1, capb);
         scan(false, (const ull *)L.d_b1_end);
         layout(2, capb);
@@ -689,11 +705,13 @@ static int skm_scan_split(simka_ctx *ctx, simka_ctx::Lane &L, uint32_t sample, c
         HIPCHK(hipMemcpyAsync(cnt.data(), L.d_b1_count, (size_t)B1 * 8, hipMemcpyDeviceToHost, st));
         HIPCHK(hipStreamSynchronize(st));
         rec_cap = 16;
-        for (ull c : cnt) rec_cap += c;
+        for (ull c : cnt) { rec_cap += c; if ((c + SKM_CS_CHUNK - 1) / SKM_CS_CHUNK > SKM_G_MAXCH) use_gather = false; }
         if (rec_cap >= 0xffffffffull) return ctx->fail(SIMKA_ERR_OVERFLOW, "a sample yields more than 2^32 super-k-mer records in one pass");
         rc = ensure_cap(ctx, &L.d_skm_a, &L.skm_a_cap, rec_cap); if (rc) return rc;
-        rc = ensure_cap(ctx, &L.d_skm_b, &L.skm_b_cap, rec_cap); if (rc) return rc;
-        rc = ensure_cap(ctx, &L.d_skm_p, &L.skm_p_cap, rec_cap); if (rc) return rc;
+        if (!use_gather) {
+            rc = ensure_cap(ctx, &L.d_skm_b, &L.skm_b_cap, rec_cap); if (rc) return rc;
+            rc = ensure_cap(ctx, &L.d_skm_p, &L.skm_p_cap, rec_cap); if (rc) return rc;
+        }
         layout(0, 0);
         scan(false, (const ull *)L.d_b1_end);
     }
@@ -703,6 +721,19 @@ static int skm_scan_split(simka_ctx *ctx, simka_ctx::Lane &L, uint32_t sample, c
         HIPCHK(hipMemcpyAsync(cnt.data(), L.d_b1_count, (size_t)B1 * 8, hipMemcpyDeviceToHost, st)); HIPCHK(hipStreamSynchronize(st));
         ull mx = 0, sum = 0; for (ull c : cnt) { mx = std::max(mx, c); sum += c; }
         fprintf(stderr, "level-1 buckets: %u, records %llu, largest bucket %.1f %% above the mean\n", B1, sum, 100.0 * ((double)mx * B1 / std::max<ull>(1, sum) - 1.0));
+    }
+    *gather = use_gather;
+    if (use_gather) {
+        // every bucket's records in chunks of SKM_CS_CHUNK: at most rec_cap / chunk + one partial chunk per bucket
+        const uint64_t nch_max = rec_cap / SKM_CS_CHUNK + B1 + 1;
+        rc = ensure_cap(ctx, &L.d_ctab, &L.ctab_cap, nch_max * cstride); if (rc) return rc;
+        launch_timed(ctx, KID_SKM_SPLIT, [&] {
+            const size_t lds_cs = (((size_t)cstride * 2 + 15) & ~(size_t)15) + 64 + (size_t)SKM_CS_CHUNK * 16;
+            hipLaunchKernelGGL(k_skm_chunksort, dim3((uint32_t)nch_max), dim3(SKM_CS_BLOCK), lds_cs, st, L.d_skm_a, (const ull *)L.d_b1_start, (const ull *)L.d_b1_count,
+                               (const uint32_t *)L.d_cbase, sk, L.d_ctab, cstride, (const uint32_t *)flag);
+        }, st);
+        HIPCHK(hipGetLastError());
+        return SIMKA_OK;
     }
     launch_timed(ctx, KID_SKM_SPLIT, [&] {
         const size_t lds_split = ((size_t)1 << sk.l2) * 4 + 64 + ((size_t)1 << sk.l2) * 2 + 48 + (size_t)SKM_SPLIT_BLOCK * SKM_SPLIT_UNROLL * 16;      // (the staging area starts 16-byte aligned behind F2 + 8 shorts)
@@ -725,7 +756,12 @@ static int run_count_kernels(simka_ctx *ctx, uint32_t sample, const SimkaScanArg
     static const bool force_exact = getenv("SIMKA_EXACT_SIZING") != nullptr;
     if (force_exact) exact = true;
     uint64_t kocc_up = 0;
-    rc = skm_scan_split(ctx, L, sample, a_in, sk, exact, pass, &kocc_up); if (rc) return rc;
+    bool gather = true;
+    rc = skm_scan_split(ctx, L, sample, a_in, sk, exact, pass, &kocc_up, &gather); if (rc) return rc;
+    SimkaSkmSrc src;
+    memset(&src, 0, sizeof src);
+    if (gather) { src.recs = L.d_skm_a; src.cbase = L.d_cbase; src.b1_start = L.d_b1_start; src.ctab = L.d_ctab; src.cstride = ((1u << sk.l2) + 2u + 1u) & ~1u; }
+    else { src.recs = L.d_skm_b; src.pstart = L.d_pstart; src.pcnt = L.d_pcnt; }
     if (!exact) {
         simka_ctx::Pending p; p.sample = sample; p.a = a_in; p.pass = pass; p.npass = npass;
         ctx->pending.push_back(p);
@@ -789,21 +825,23 @@ static int run_count_kernels(simka_ctx *ctx, uint32_t sample, const SimkaScanArg
     }
 #endif
     const size_t hist_lds = ctx->d_hist ? (size_t)SIMKA_HIST_MAX * 4 : 0;
-    const size_t lds_fast = (size_t)SIMKA_LDS_HEAD + (size_t)SKM_FAST_TS * 12 + (size_t)SKM_FAST_BLOCK * 16 + hist_lds + (size_t)(SKM_FAST_BLOCK / 64) * SKM_FAST_WREG + 64;
-    const size_t lds_count = (size_t)SIMKA_LDS_HEAD + (size_t)SKM_CNT_TS * 12 + (size_t)SKM_CNT_BATCH * 16 + (size_t)SKM_CNT_BLOCK * 4 + hist_lds + (size_t)SKM_CNT_BATCH * sk.nmax * 2 + 64;
+    const size_t lds_fast = (size_t)SIMKA_LDS_HEAD + (size_t)SKM_FAST_TS * 12 + (size_t)SKM_FAST_BLOCK * 16 + hist_lds + (size_t)(SKM_FAST_BLOCK / 64) * SKM_FAST_WREG +
+                            (gather ? (size_t)SKM_G_BYTES(SKM_FAST_BLOCK / 64) : 64);
+    const size_t lds_count = (size_t)SIMKA_LDS_HEAD + (size_t)SKM_CNT_TS * 12 + (size_t)SKM_CNT_BATCH * 16 + (size_t)SKM_CNT_BLOCK * 4 + hist_lds + (size_t)SKM_CNT_BATCH * sk.nmax * 2 + 64 +
+                             (gather ? (size_t)(SKM_G_MAXCH * 10 + 32) : 0);
     static const bool general_only = getenv("SIMKA_SKM_GENERAL") != nullptr;      // tests: every partition through the general kernel
     if (!general_only)
         launch_timed(ctx, KID_SKM_COUNT, [&] {
             static const uint32_t bpc_env = getenv("SIMKA_SKM_BPC") ? (uint32_t)atoi(getenv("SIMKA_SKM_BPC")) : 0u;     // experiments
             const uint32_t bpc = bpc_env ? bpc_env : (uint32_t)std::max<size_t>(1, std::min<size_t>(4, (160 * 1024) / lds_fast));
-            hipLaunchKernelGGL(k_skm_count_fast, dim3((uint32_t)std::min<uint64_t>(ctx->nparts, (uint64_t)ctx->num_cus * bpc)), dim3(SKM_FAST_BLOCK), lds_fast, st, (const uint4 *)L.d_skm_b,
-                               (const uint32_t *)L.d_pstart, (const uint32_t *)L.d_pcnt, sk, ctx->key, ctx->cfg.abundance_min, ctx->cfg.abundance_max, o, (const uint32_t *)flag, kocc,
+            hipLaunchKernelGGL(gather ? k_skm_count_fast<true> : k_skm_count_fast<false>, dim3((uint32_t)std::min<uint64_t>(ctx->nparts, (uint64_t)ctx->num_cus * bpc)), dim3(SKM_FAST_BLOCK), lds_fast, st,
+                               src, sk, ctx->key, ctx->cfg.abundance_min, ctx->cfg.abundance_max, o, (const uint32_t *)flag, kocc,
                                L.d_redo_list, L.d_redo_count);
         }, st);
     launch_timed(ctx, KID_COUNT, [&] {
         const uint32_t grid = general_only ? (uint32_t)std::min<uint64_t>(ctx->nparts, (uint64_t)ctx->num_cus * 2) : (uint32_t)ctx->num_cus;
-        hipLaunchKernelGGL(k_skm_count, dim3(grid), dim3(SKM_CNT_BLOCK), lds_count, st, (const uint4 *)L.d_skm_b,
-                           (const uint32_t *)L.d_pstart, (const uint32_t *)L.d_pcnt, sk, ctx->key, ctx->cfg.abundance_min, ctx->cfg.abundance_max, o, (const uint32_t *)flag, kocc,
+        hipLaunchKernelGGL(gather ? k_skm_count<true> : k_skm_count<false>, dim3(grid), dim3(SKM_CNT_BLOCK), lds_count, st,
+                           src, sk, ctx->key, ctx->cfg.abundance_min, ctx->cfg.abundance_max, o, (const uint32_t *)flag, kocc,
                            general_only ? (const uint32_t *)nullptr : (const uint32_t *)L.d_redo_list, general_only ? (const ull *)nullptr : (const ull *)L.d_redo_count);
     }, st);
     HIPCHK(hipGetLastError());
@@ -899,7 +937,8 @@ static int wide_hash_count(simka_ctx *ctx, uint32_t sample, const void *d_packed
     if (ctx->d_ovf_cursor) { HIPCHK(hipMemcpyAsync(ovf_before, ctx->d_ovf_cursor, 16, hipMemcpyDeviceToHost, st)); HIPCHK(hipStreamSynchronize(st)); }
     for (int attempt = force_exact ? 1 : 0; attempt < 2; attempt++) {
         HIPCHK(hipMemsetAsync(ctx->d_wh_cursor, 0, 64, st));
-        rc = skm_scan_split(ctx, L, sample, a, sk, attempt == 1, 0, &kocc_up); if (rc) return rc;
+        bool gather_ = false;          // (the two-word count kernels read contiguous partitions)
+        rc = skm_scan_split(ctx, L, sample, a, sk, attempt == 1, 0, &kocc_up, &gather_); if (rc) return rc;
         SimkaWideOut wo;
         wo.hi = ctx->d_wh_hi; wo.lo = ctx->d_wh_lo; wo.cnt = ctx->d_wh_cnt; wo.cursor = ctx->d_wh_cursor; wo.cap = out_cap;
         wo.shard_index = ctx->cfg.shard_index; wo.shard_count = ctx->cfg.shard_count;

@@ -440,7 +440,7 @@ k_skm_scan(SimkaScanArgs a, SimkaSkmCfg cfg, ull *b1_count, ull *b1_cursor, uint
             const uint4 rec = stage[i];
             const uint32_t b1 = cfg.pb ? skm_rec_pid(rec) >> (cfg.pb - cfg.l1) : 0u;
             const ull g = gbase[b1];
-            if (g != ~0ull) { l1_recs[g + (i - hist[b1])] = rec; l1_pid[g + (i - hist[b1])] = skm_rec_pid(rec); }       // (the split's first pass reads 4 bytes per record)
+            if (g != ~0ull) { l1_recs[g + (i - hist[b1])] = rec; if (l1_pid) l1_pid[g + (i - hist[b1])] = skm_rec_pid(rec); }       // (the exact split's first pass reads 4 bytes per record; the chunk sort needs no ids)
         }
     } else {
         // ---- phase 4d
@@ -450,7 +450,7 @@ k_skm_scan(SimkaScanArgs a, SimkaSkmCfg cfg, ull *b1_count, ull *b1_cursor, uint
             while (len) {
                 const uint32_t n = len < cfg.nmax ? len : cfg.nmax;
                 const uint32_t pos = atomicAdd(&lcur[b1], 1u);
-                if (g != ~0ull) { l1_recs[g + (pos - hist[b1])] = cut(e, n, pid); l1_pid[g + (pos - hist[b1])] = pid; }
+                if (g != ~0ull) { l1_recs[g + (pos - hist[b1])] = cut(e, n, pid); if (l1_pid) l1_pid[g + (pos - hist[b1])] = pid; }
                 e += n; len -= n;
             }
         });
@@ -465,7 +465,7 @@ k_skm_scan(SimkaScanArgs a, SimkaSkmCfg cfg, ull *b1_count, ull *b1_cursor, uint
 // --------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(SKM_MAXB1)
 k_skm_layout(ull *b1_count, ull *b1_start, ull *b1_limit, ull *b1_cursor, uint32_t B1, uint32_t mode, ull cap,
-             ull *arena_cursor, ull *sample_base, uint32_t first_pass, const uint32_t *skip_flag, ull *redo_count) {
+             ull *arena_cursor, ull *sample_base, uint32_t first_pass, const uint32_t *skip_flag, ull *redo_count, uint32_t *cbase, uint32_t cs_chunk) {
     __shared__ ull s_cnt[SKM_MAXB1];
     const uint32_t tid = threadIdx.x;
     if (mode != 2u && tid == 0) { redo_count[0] = 0ull; redo_count[1] = 0ull; }      // [1]: the work counter of k_skm_count_fast
@@ -476,14 +476,23 @@ k_skm_layout(ull *b1_count, ull *b1_start, ull *b1_limit, ull *b1_cursor, uint32
     }
     if (mode == 2u) {
         if (skip_flag && *skip_flag) return;
-        if (tid < B1) b1_count[tid] = b1_cursor[tid * SKM_CSTRIDE] - b1_start[tid];
+        if (tid < B1) { const ull c = b1_cursor[tid * SKM_CSTRIDE] - b1_start[tid]; b1_count[tid] = c; s_cnt[tid] = c; }
+        if (cbase) {       // chunk numbering of k_skm_chunksort: bucket b owns the chunks [cbase[b], cbase[b + 1])
+            __syncthreads();
+            if (tid == 0) { uint32_t run = 0; for (uint32_t b = 0; b < B1; b++) { cbase[b] = run; run += (uint32_t)((s_cnt[b] + cs_chunk - 1) / cs_chunk); } cbase[B1] = run; }
+        }
         return;
     }
     if (tid < B1) s_cnt[tid] = b1_count[tid];
     __syncthreads();
     if (tid == 0) {
         ull run = 0;
-        for (uint32_t b = 0; b < B1; b++) { const ull c = s_cnt[b]; b1_start[b] = run; b1_cursor[b * SKM_CSTRIDE] = run; b1_limit[b] = run + c; run += c; }
+        uint32_t crun = 0;
+        for (uint32_t b = 0; b < B1; b++) {
+            const ull c = s_cnt[b]; b1_start[b] = run; b1_cursor[b * SKM_CSTRIDE] = run; b1_limit[b] = run + c; run += c;
+            if (cbase) { cbase[b] = crun; crun += (uint32_t)((c + cs_chunk - 1) / cs_chunk); }
+        }
+        if (cbase) cbase[B1] = crun;
         if (first_pass) *sample_base = *arena_cursor;
     }
 }
@@ -553,12 +562,12 @@ k_skm_split(const uint4 *l1_recs, const uint32_t *l1_pid, const ull *b1_start, c
     // pass 2, chunk by chunk (STEP records): the chunk is ordered by partition in LDS first, so that what goes to one partition
     // leaves as ONE run (direct 16-byte stores into 2048 open partitions were written back line by line: 3.7x the bytes)
     uint16_t *ch = (uint16_t *)(wsum + 16);            // [F2] records of the chunk per partition, then their start in the staging area
-    uint4 *stage = (uint4 *)(((uintptr_t)(ch + F2 + 8) + 15u) & ~(uintptr_t)15u);             // [STEP]
+    uint4 *stage = (uint4 *)(smem + ((F2 * 4u + 64u + (F2 + 8u) * 2u + 15u) & ~15u));         // [STEP] (behind lh [F2], wsum [16], ch [F2 + 8]; 16-byte aligned)
     for (ull i0 = 0; i0 < n; i0 += STEP) {
         for (uint32_t i = tid; i < (F2 + 1) / 2; i += SKM_SPLIT_BLOCK) ((uint32_t *)ch)[i] = 0;
         uint4 rec[SKM_SPLIT_UNROLL]; uint32_t lr[SKM_SPLIT_UNROLL];
 #pragma unroll
-        for (int u = 0; u < SKM_SPLIT_UNROLL; u++) { const ull i = i0 + (ull)u * SKM_SPLIT_BLOCK + tid; if (i < n) rec[u] = l1_recs[st + i]; }
+        for (int u = 0; u < SKM_SPLIT_UNROLL; u++) { const ull i = i0 + (ull)u * SKM_SPLIT_BLOCK + tid; rec[u] = make_uint4(0u, 0u, 0u, 0u); if (i < n) rec[u] = l1_recs[st + i]; }
         __syncthreads();
         // rank inside the chunk's run of the partition: 16-bit counters, two per word (the returning atomic works on the word)
 #pragma unroll
@@ -605,6 +614,94 @@ k_skm_split(const uint4 *l1_recs, const uint32_t *l1_pid, const ull *b1_start, c
 }
 
 // --------------------------------------------------------------------------------------------
+// k_skm_chunksort: level-1 bucket -> its 2^l2 partitions WITHOUT moving the records to a second buffer: one block per chunk of
+// SKM_CS_CHUNK records of a bucket orders the chunk by partition in LDS and writes it back IN PLACE, fully coalesced, together with
+// one row of the chunk table: ctab[chunk][i] = first record of partition i inside the sorted chunk (i = 0 .. 2^l2, the last entry =
+// records of the chunk).  The count kernels then GATHER a partition: piece c of partition i = records [ctab[c][i], ctab[c][i+1]) of
+// chunk c of its bucket (C3: 67 pieces of ~4 records).  Against k_skm_split this reads the records once and writes them once in whole
+// lines (the exact split read a 4-byte id array first and wrote 64-byte runs into 2048 open partitions: 1.9x its algorithmic bytes),
+// needs no second record buffer and no id array -- the price is the gather in the count kernels (two 2-byte table entries per piece).
+//   cbase[b] = first chunk of bucket b in the chunk numbering of the sample (k_skm_layout), cbase[B1] = chunks of the sample.
+// --------------------------------------------------------------------------------------------
+#define SKM_CS_CHUNK 8192
+#define SKM_CS_BLOCK 1024
+#define SKM_CS_UNROLL (SKM_CS_CHUNK / SKM_CS_BLOCK)
+__global__ void __launch_bounds__(SKM_CS_BLOCK)
+k_skm_chunksort(uint4 *recs, const ull *b1_start, const ull *b1_count, const uint32_t *cbase, SimkaSkmCfg cfg, uint16_t *ctab, uint32_t cstride, const uint32_t *flag) {
+    if (*flag) return;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const uint32_t l2 = cfg.pb - cfg.l1, F2 = 1u << l2, m2 = F2 - 1u, B1 = 1u << cfg.l1;
+    uint16_t *ch = (uint16_t *)smem;                     // [F2 + 2] records of the chunk per partition, then their start in the sorted chunk
+    const uint32_t ch_bytes = (((F2 + 2u) * 2u) + 15u) & ~15u;
+    uint32_t *wsum = (uint32_t *)(smem + ch_bytes);      // [16]
+    uint4 *stage = (uint4 *)(smem + ch_bytes + 64);      // [CHUNK]
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    const uint32_t gc = blockIdx.x;
+    if (gc >= cbase[B1]) return;
+    // bucket of this chunk: the last b with cbase[b] <= gc (wave-uniform search)
+    uint32_t lo = 0, hi = B1;
+    while (hi - lo > 1u) { const uint32_t mid = (lo + hi) >> 1; if (cbase[mid] <= gc) lo = mid; else hi = mid; }
+    const uint32_t b1 = lo;
+    const ull i0 = (ull)(gc - cbase[b1]) * SKM_CS_CHUNK, n = b1_count[b1];
+    const ull st = b1_start[b1] + i0;
+    const uint32_t nc = (uint32_t)(n - i0 < (ull)SKM_CS_CHUNK ? n - i0 : (ull)SKM_CS_CHUNK);
+    for (uint32_t i = tid; i < (F2 + 2u) / 2u; i += SKM_CS_BLOCK) ((uint32_t *)ch)[i] = 0;
+    uint4 rec[SKM_CS_UNROLL]; uint32_t lr[SKM_CS_UNROLL];
+#pragma unroll
+    for (int u = 0; u < SKM_CS_UNROLL; u++) { const uint32_t i = (uint32_t)u * SKM_CS_BLOCK + tid; rec[u] = make_uint4(0u, 0u, 0u, 0u); if (i < nc) rec[u] = recs[st + i]; }
+    __syncthreads();
+    // rank inside the chunk's run of the partition: 16-bit counters, two per word (the returning atomic works on the word)
+#pragma unroll
+    for (int u = 0; u < SKM_CS_UNROLL; u++) {
+        const uint32_t i = (uint32_t)u * SKM_CS_BLOCK + tid;
+        lr[u] = 0;
+        if (i < nc) {
+            const uint32_t b2 = skm_rec_pid(rec[u]) & m2, sh = (b2 & 1u) * 16u;
+            lr[u] = (atomicAdd((uint32_t *)ch + (b2 >> 1), 1u << sh) >> sh) & 0xffffu;
+        }
+    }
+    __syncthreads();
+    {   // exclusive scan of the chunk histogram (F2 <= 4096 counters, <= 4 per thread); the starts are the chunk's table row
+        const uint32_t per = (F2 + SKM_CS_BLOCK - 1) / SKM_CS_BLOCK;
+        uint32_t v[4] = { 0, 0, 0, 0 }, sum = 0;
+        for (uint32_t q = 0; q < per; q++) { const uint32_t i = tid * per + q; v[q] = i < F2 ? ch[i] : 0u; sum += v[q]; }
+        const uint32_t inc = wave_incl_scan(sum);
+        if (lane == 63u) wsum[wave] = inc;
+        __syncthreads();
+        uint32_t wpre = 0;
+#pragma unroll
+        for (uint32_t w_ = 0; w_ < SKM_CS_BLOCK / 64; w_++) { const uint32_t t = wsum[w_]; if (w_ < wave) wpre += t; }
+        uint32_t run = wpre + inc - sum;
+        for (uint32_t q = 0; q < per; q++) { const uint32_t i = tid * per + q; if (i < F2) { ch[i] = (uint16_t)run; run += v[q]; } }
+        if (tid == 0) { ch[F2] = (uint16_t)nc; ch[F2 + 1u] = (uint16_t)nc; }
+    }
+    __syncthreads();
+    {
+        uint32_t *row = (uint32_t *)(ctab + (size_t)gc * cstride);       // (cstride is even: rows are 4-byte aligned)
+        for (uint32_t i = tid; i < (F2 + 2u) / 2u; i += SKM_CS_BLOCK) row[i] = ((const uint32_t *)ch)[i];
+    }
+#pragma unroll
+    for (int u = 0; u < SKM_CS_UNROLL; u++) {
+        const uint32_t i = (uint32_t)u * SKM_CS_BLOCK + tid;
+        if (i < nc) stage[ch[skm_rec_pid(rec[u]) & m2] + lr[u]] = rec[u];
+    }
+    __syncthreads();
+    for (uint32_t sidx = tid; sidx < nc; sidx += SKM_CS_BLOCK) recs[st + sidx] = stage[sidx];
+}
+
+// Where the count kernels find the records of a partition.  Legacy (ctab == nullptr): ONE contiguous run of `recs` (k_skm_split:
+// pstart / pcnt).  Gather: the pieces of the partition in the sorted chunks of its level-1 bucket (k_skm_chunksort): piece c =
+// records [ctab[c][p2], ctab[c][p2 + 1]) of chunk c, c < cbase[b + 1] - cbase[b] <= SKM_G_MAXCH.
+struct SimkaSkmSrc {
+    const uint4 *recs;
+    const uint32_t *pstart, *pcnt;
+    const uint32_t *cbase; const ull *b1_start; const uint16_t *ctab; uint32_t cstride, pad_;
+};
+#define SKM_G_MAXCH 128          // chunks per level-1 bucket the gather takes (two per lane of a wave); beyond: the exact split
+#define SKM_G_WBYTES (SKM_G_MAXCH / 4 * 6)      // per wave of k_skm_count_fast (it owns the chunks c = 4 l + wave): u32 prefix + u16 start of its pieces
+#define SKM_G_BYTES(nw) ((SKM_MAXB1 + 1) * 4 + SKM_MAXB1 * 4 + (nw) * SKM_G_WBYTES)      // cbase + bucket starts + the waves' piece tables
+
+// --------------------------------------------------------------------------------------------
 // k_skm_count: one partition at a time per (persistent) block.
 //   records -> LDS; a wave scan of the record lengths + one LDS atomic per wave gives every record a range of k-mer slots,
 //   map[slot] = (record, offset); then one LANE PER K-MER: cut the k-mer out of its record (funnel shift, no rolling state),
@@ -623,10 +720,12 @@ __device__ __forceinline__ uint64_t skm_kmer_at(const uint4 &r, uint32_t j, cons
     return (((uint64_t)hi << 32) | lo) & cfg.kmask;
 }
 
+template <bool GATHER>
 __global__ void __launch_bounds__(SKM_CNT_BLOCK)
-k_skm_count(const uint4 *recs, const uint32_t *pstart, const uint32_t *pcnt, SimkaSkmCfg cfg, SimkaKeyCfg kcfg, uint32_t amin, uint32_t amax, SimkaCountOut o,
+k_skm_count(SimkaSkmSrc src, SimkaSkmCfg cfg, SimkaKeyCfg kcfg, uint32_t amin, uint32_t amax, SimkaCountOut o,
             const uint32_t *flag, ull *kocc_owned, const uint32_t *part_list, const ull *part_count) {
     if (*flag) return;
+    const uint4 *recs = src.recs; const uint32_t *pstart = src.pstart, *pcnt = src.pcnt;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     ull *s_tot = (ull *)smem;                          // [5] D_all, D, N, Q, K_occ of the whole block
     ull &s_base = *(ull *)(smem + 48);
@@ -643,9 +742,14 @@ k_skm_count(const uint4 *recs, const uint32_t *pstart, const uint32_t *pcnt, Sim
     uint32_t *spos = (uint32_t *)(lrec + SKM_CNT_BATCH);     // [BLOCK]
     uint32_t *lhist = spos + SKM_CNT_BLOCK;            // [SIMKA_HIST_MAX] (complex only)
     uint16_t *map = (uint16_t *)(lhist + (o.hist ? SIMKA_HIST_MAX : 0));     // [BATCH * nmax]
+    // GATHER: the piece table of the current partition (SimkaSkmSrc), one for the block
+    uint32_t *gpre = (uint32_t *)(((uintptr_t)(map + SKM_CNT_BATCH * cfg.nmax) + 15u) & ~(uintptr_t)15u);      // [SKM_G_MAXCH + 1] records before piece c, [MAXCH]: all
+    uint32_t *gcnt = gpre + SKM_G_MAXCH + 1;                                                                  // [SKM_G_MAXCH]
+    uint16_t *gst = (uint16_t *)(gcnt + SKM_G_MAXCH);                                                         // [SKM_G_MAXCH]
 
     const uint32_t tid = threadIdx.x, lane = tid & 63u;
     const uint32_t nparts = 1u << cfg.pb;
+    const uint32_t gl2 = cfg.pb - cfg.l1, gm2 = (1u << gl2) - 1u;
     constexpr uint32_t TS = SKM_CNT_TS, SPT = TS / SKM_CNT_BLOCK, TSL = 12;          // log2 TS
     const ull sample_base = *o.sample_base;
     for (uint32_t i = tid; i < TS; i += SKM_CNT_BLOCK) { tkeys[i] = SIMKA_EMPTY_KEY; tcnt[i] = 0; }
@@ -659,9 +763,31 @@ k_skm_count(const uint4 *recs, const uint32_t *pstart, const uint32_t *pcnt, Sim
     const uint32_t nwork = part_list ? (uint32_t)(*part_count < (ull)nparts ? *part_count : (ull)nparts) : nparts;
     for (uint32_t wi_ = blockIdx.x; wi_ < nwork; wi_ += gridDim.x) {
         const uint32_t part = part_list ? part_list[wi_] : wi_;
-        const uint32_t nrec = pcnt[part];
+        uint32_t nrec, rbase;
+        if (GATHER) {
+            const uint32_t b = part >> gl2, p2 = part & gm2, gc0 = src.cbase[b], nch = src.cbase[b + 1u] - gc0;
+            __syncthreads();       // (the table of the partition before is done with)
+            if (tid < SKM_G_MAXCH) {
+                uint32_t t0 = 0, t1 = 0;
+                if (tid < nch) { const uint16_t *row = src.ctab + (size_t)(gc0 + tid) * src.cstride + p2; t0 = row[0]; t1 = row[1]; }
+                gcnt[tid] = t1 - t0; gst[tid] = (uint16_t)t0;
+            }
+            __syncthreads();
+            if (tid == 0) { uint32_t run = 0; for (uint32_t c = 0; c < SKM_G_MAXCH; c++) { gpre[c] = run; run += gcnt[c]; } gpre[SKM_G_MAXCH] = run; }
+            __syncthreads();
+            nrec = gpre[SKM_G_MAXCH];
+            rbase = (uint32_t)src.b1_start[b];
+        } else { nrec = pcnt[part]; rbase = pstart[part]; }
         if (nrec == 0) continue;                       // (foff / fcnt of the sample were zeroed by the host)
-        const uint32_t rbase = pstart[part];
+        auto rec_at = [&](uint32_t i) -> uint4 {
+            if (GATHER) {
+                uint32_t c = 0;
+#pragma unroll
+                for (uint32_t stp = SKM_G_MAXCH / 2; stp; stp >>= 1) c += gpre[c + stp] <= i ? stp : 0u;
+                return recs[(size_t)rbase + (size_t)c * SKM_CS_CHUNK + gst[c] + (i - gpre[c])];
+            }
+            return recs[rbase + i];
+        };
         uint32_t rho = 0;                              // log2 #rounds
         bool done = false;
         while (!done) {
@@ -692,7 +818,7 @@ k_skm_count(const uint4 *recs, const uint32_t *pstart, const uint32_t *pcnt, Sim
                         __syncthreads();
                         const uint32_t nb = nrec - b0 < (uint32_t)SKM_CNT_BATCH ? nrec - b0 : (uint32_t)SKM_CNT_BATCH;
                         uint32_t len = 0;
-                        if (tid < nb) { const uint4 rc = recs[rbase + b0 + tid]; lrec[tid] = rc; len = skm_rec_n(rc); }
+                        if (tid < nb) { const uint4 rc = rec_at(b0 + tid); lrec[tid] = rc; len = skm_rec_n(rc); }
                         uint32_t x = len;
 #pragma unroll
                         for (int o_ = 1; o_ < 64; o_ <<= 1) { const uint32_t t = __shfl_up(x, o_, 64); if (lane >= (uint32_t)o_) x += t; }
@@ -1207,10 +1333,12 @@ k_skm_count_wide_fast(const uint4 *recs, const uint32_t *pstart, const uint32_t 
 //   * arena slab state double-buffered in LDS, so the emit needs no barrier of its own.
 // A partition whose inserts overflow a sort block of the table goes to the redo list (k_skm_count takes it in rounds).
 // --------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(SKM_FAST_BLOCK)
-k_skm_count_fast(const uint4 *recs, const uint32_t *pstart, const uint32_t *pcnt, SimkaSkmCfg cfg, SimkaKeyCfg kcfg, uint32_t amin, uint32_t amax, SimkaCountOut o,
+template <bool GATHER>
+__global__ void __launch_bounds__(SKM_FAST_BLOCK, 4)       // (four blocks per CU = four waves per SIMD: at most 128 VGPRs)
+k_skm_count_fast(SimkaSkmSrc src, SimkaSkmCfg cfg, SimkaKeyCfg kcfg, uint32_t amin, uint32_t amax, SimkaCountOut o,
                  const uint32_t *flag, ull *kocc_owned, uint32_t *redo_list, ull *redo_count) {
     if (*flag) return;
+    const uint4 *recs = src.recs; const uint32_t *pstart = src.pstart, *pcnt = src.pcnt;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     ull *s_tot = (ull *)smem;                          // [5]
     ull &s_base = *(ull *)(smem + 48);
@@ -1224,9 +1352,21 @@ k_skm_count_fast(const uint4 *recs, const uint32_t *pstart, const uint32_t *pcnt
     uint4 *lrec = (uint4 *)(tcnt + TS);                // [BLOCK]: 64 per wave
     uint32_t *lhist = (uint32_t *)(lrec + SKM_FAST_BLOCK);     // [SIMKA_HIST_MAX] (complex only)
     unsigned char *wreg0 = (unsigned char *)(lhist + (o.hist ? SIMKA_HIST_MAX : 0));     // [NW][SKM_FAST_WREG] wave-private regions
+    // GATHER: chunk numbering and start of every level-1 bucket, then per wave the piece table of the partition it loads next
+    uint32_t *s_cb = (uint32_t *)(wreg0 + NW * SKM_FAST_WREG);     // [SKM_MAXB1 + 1]
+    uint32_t *s_bs = s_cb + SKM_MAXB1 + 1;                         // [SKM_MAXB1] (a lane's record buffer holds < 2^32 records)
 
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    // (wave w gathers the pieces in the chunks c = NW l + w, l < GNL, of the partition's bucket: its share of the records)
+    constexpr uint32_t GNL = SKM_G_MAXCH / NW;
+    uint32_t *gpre = (uint32_t *)((unsigned char *)(s_bs + SKM_MAXB1) + wave * SKM_G_WBYTES);      // [GNL] records of the wave before its piece l
+    uint16_t *gst = (uint16_t *)(gpre + GNL);                                                     // [GNL] first record of piece l inside its chunk
     const uint32_t nparts = 1u << cfg.pb;
+    const uint32_t gl2 = cfg.pb - cfg.l1, gm2 = (1u << gl2) - 1u;
+    if (GATHER) {
+        const uint32_t B1 = 1u << cfg.l1;
+        for (uint32_t i = tid; i <= B1; i += SKM_FAST_BLOCK) { s_cb[i] = src.cbase[i]; if (i < B1) s_bs[i] = (uint32_t)src.b1_start[i]; }
+    }
     const ull sample_base = *o.sample_base;
     for (uint32_t i = tid; i < TS; i += SKM_FAST_BLOCK) { tkeys[i] = SIMKA_EMPTY_KEY; tcnt[i] = 0; }
     if (o.hist) for (uint32_t i = tid; i < SIMKA_HIST_MAX; i += SKM_FAST_BLOCK) lhist[i] = 0;
@@ -1309,20 +1449,52 @@ k_skm_count_fast(const uint4 *recs, const uint32_t *pstart, const uint32_t *pcnt
     uint32_t part = part_of(item);
     uint32_t nrec = 0, rbase = 0;
     uint4 pre = make_uint4(0, 0, 0, 0);
+    // record i of the partition the wave's piece table describes (GATHER) / of the run that starts at rb_
+    auto rec_at = [&](uint32_t rb_, uint32_t i) -> uint4 {
+        if (GATHER) {
+            uint32_t l = 0;           // the wave's last piece that starts at or before its record i (empty pieces share their successor's prefix)
+#pragma unroll
+            for (uint32_t stp = GNL / 2; stp; stp >>= 1) l += gpre[l + stp] <= i ? stp : 0u;
+            return recs[(size_t)rb_ + (size_t)(l * NW + wave) * SKM_CS_CHUNK + gst[l] + (i - gpre[l])];
+        }
+        return recs[rb_ + i];
+    };
+    // (GATHER: n_ = records of THIS WAVE, taken 64 at a time; else of the partition, 256 at a time in equal shares)
     auto prefetch = [&](uint32_t n_, uint32_t rb_) {
+        if (GATHER) { if (lane < n_) pre = rec_at(rb_, lane); return; }
         const uint32_t nb = n_ < (uint32_t)SKM_FAST_BLOCK ? n_ : (uint32_t)SKM_FAST_BLOCK;
         const uint32_t per = (nb + NW - 1u) / NW;
-        if (lane < per && wave * per + lane < nb) pre = recs[rb_ + wave * per + lane];
+        if (lane < per && wave * per + lane < nb) pre = rec_at(rb_, wave * per + lane);
     };
-    if (part < nparts) { nrec = pcnt[part]; rbase = pstart[part]; prefetch(nrec, rbase); }
-    __syncthreads();
     // (count, start) of the next partition travel as a VECTOR load of lanes 0 / 1: a scalar load of these wave-uniform words would
-    // share the LDS counter (lgkmcnt), and the first LDS wait of the insert phase would sit out its HBM latency
+    // share the LDS counter (lgkmcnt), and the first LDS wait of the insert phase would sit out its HBM latency.
+    // GATHER: the table entries (start | end << 16) of the wave's piece in chunk NW lane + wave of the partition's bucket instead;
+    // take_desc() turns them into the wave's piece table.
     auto load_desc = [&](uint32_t p_) -> uint32_t {
         uint32_t v = 0;
-        if (p_ < nparts && lane < 2u) { const uint32_t *src = lane == 0u ? pcnt : pstart; v = src[p_]; }
+        if (GATHER) {
+            if (p_ < nparts) {
+                const uint32_t b = p_ >> gl2, p2 = p_ & gm2, gc0 = s_cb[b], nch = s_cb[b + 1u] - gc0, c = lane * NW + wave;
+                if (lane < GNL && c < nch) { const uint16_t *row = src.ctab + (size_t)(gc0 + c) * src.cstride + p2; v = (uint32_t)row[0] | ((uint32_t)row[1] << 16); }
+            }
+        } else if (p_ < nparts && lane < 2u) { const uint32_t *q = lane == 0u ? pcnt : pstart; v = q[p_]; }
         return v;
     };
+    // descriptor -> (records, start) of partition p_; GATHER: also the wave's piece table (the table of the partition before is dead:
+    // its last batch has been loaded)
+    auto take_desc = [&](uint32_t p_, uint32_t d, uint32_t &n_, uint32_t &rb_) {
+        if (GATHER) {
+            const uint32_t cA = (d >> 16) - (d & 0xffffu);          // (0 beyond the wave's pieces)
+            const uint32_t iA = wave_incl_scan(cA);
+            if (lane < GNL) { gpre[lane] = iA - cA; gst[lane] = (uint16_t)(d & 0xffffu); }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            n_ = (uint32_t)__builtin_amdgcn_readlane((int)iA, 63);
+            rb_ = p_ < nparts ? s_bs[p_ >> gl2] : 0u;
+        } else { n_ = (uint32_t)__builtin_amdgcn_readlane((int)d, 0); rb_ = (uint32_t)__builtin_amdgcn_readlane((int)d, 1); }
+    };
+    __syncthreads();           // (the tables and s_cb / s_bs are in place)
+    if (part < nparts) { const uint32_t d0 = load_desc(part); take_desc(part, d0, nrec, rbase); prefetch(nrec, rbase); }
+    __syncthreads();
     uint32_t chunk_n = dyn ? s_next[0] : blockIdx.x + gridDim.x, chunk_n2 = 0;    // (published before the barrier above)
     while (part < nparts) {
         const bool first = wpos == 0u, last = wpos + 1u == wchunk;
@@ -1332,7 +1504,7 @@ k_skm_count_fast(const uint4 *recs, const uint32_t *pstart, const uint32_t *pcnt
         ull grab = 0;
         if (dyn && first && tid == 0) grab = atomicAdd(work_counter, 1ull);
         if (!dyn) chunk_n2 = chunk_n + gridDim.x;
-        if (nrec == 0) {       // an empty partition (rare among the owned ones)
+        if (!GATHER && nrec == 0) {       // an empty partition (rare among the owned ones; GATHER: nrec is the wave's share, an empty partition takes the common path)
             if (dyn && first) {       // agree on the chunk after next through LDS right away
                 if (tid == 0) s_next[tog ^ 1u] = gridDim.x + (uint32_t)grab;
                 __syncthreads();
@@ -1341,20 +1513,20 @@ k_skm_count_fast(const uint4 *recs, const uint32_t *pstart, const uint32_t *pcnt
             }
             if (last) { chunk_n = chunk_n2; wpos = 0; } else wpos++;
             item = item_n;
-            part = next; nrec = __builtin_amdgcn_readlane(desc_n, 0); rbase = __builtin_amdgcn_readlane(desc_n, 1);
+            part = next; take_desc(next, desc_n, nrec, rbase);
             prefetch(nrec, rbase);
             continue;
         }
         // ---- expand + insert: every wave takes an equal share of the records (at most 64 per batch)
         PH(0)
         ull my_k = 0;
-        for (uint32_t b0 = 0; b0 < nrec; b0 += SKM_FAST_BLOCK) {
+        for (uint32_t b0 = 0; b0 < nrec; b0 += (GATHER ? 64u : (uint32_t)SKM_FAST_BLOCK)) {
             const uint32_t nb = nrec - b0 < (uint32_t)SKM_FAST_BLOCK ? nrec - b0 : (uint32_t)SKM_FAST_BLOCK;
             const uint32_t per = (nb + NW - 1u) / NW;                       // records of this wave: [b0 + wave*per, +per)
-            const uint32_t i = b0 + wave * per + lane;
-            const bool mine = lane < per && wave * per + lane < nb;
+            const uint32_t i = GATHER ? b0 + lane : b0 + wave * per + lane;
+            const bool mine = GATHER ? i < nrec : (lane < per && wave * per + lane < nb);
             uint4 rc = pre;
-            if (b0) { if (mine) rc = recs[rbase + i]; }
+            if (b0) { if (mine) rc = rec_at(rbase, i); }
             uint32_t len = mine ? skm_rec_n(rc) : 0u;
             const uint32_t x = wave_incl_scan(len);
             const uint32_t kt = __builtin_amdgcn_readlane(x, 63);
@@ -1431,12 +1603,9 @@ k_skm_count_fast(const uint4 *recs, const uint32_t *pstart, const uint32_t *pcnt
         __syncthreads();
         PH(3)
         // ---- the next partition's records travel while this one is summarised
-        const uint32_t nrec_n = __builtin_amdgcn_readlane(desc_n, 0), rbase_n = __builtin_amdgcn_readlane(desc_n, 1);
-        {
-            const uint32_t nb = nrec_n < (uint32_t)SKM_FAST_BLOCK ? nrec_n : (uint32_t)SKM_FAST_BLOCK;
-            const uint32_t per = (nb + NW - 1u) / NW;
-            if (lane < per && wave * per + lane < nb) pre = recs[rbase_n + wave * per + lane];
-        }
+        uint32_t nrec_n, rbase_n;
+        take_desc(next, desc_n, nrec_n, rbase_n);
+        prefetch(nrec_n, rbase_n);
         // ---- summary in slot order (SimkaCompressedProcessor::process, ref: src/minikc/MiniKC.hpp:54-79)
         uint32_t cs[SPT]; ull ks[SPT];
         uint32_t nsol = 0, ndall = 0;
