@@ -92,10 +92,20 @@ SIMKA_HD uint32_t skm_rec_pid(const uint4 &r) { return r.w >> 11; }
 // slot order is ordered by the top bits of that hash)
 
 // reverse complement of the 32 bases of a word (code ^ 2 = complement)
+// (32-bit halves: the bit pairs never cross the word boundary, so the pair swap needs no 64-bit shifts -- quarter-rate on the VALU;
+//  swap + complement of one word = one shift each way and a 3-input bit operation: a ? b : ~c with a = 0x5555..)
+__device__ __forceinline__ uint32_t skm_swapcomp32(uint32_t r) {
+    return ((0x55555555u & (r >> 1)) | (0xAAAAAAAAu & (r << 1))) ^ 0xAAAAAAAAu;
+}
 __device__ __forceinline__ uint64_t skm_revcomp64(uint64_t x) {
-    const uint64_t M5 = 0x5555555555555555ull;
-    uint64_t r = __brevll(x);
-    return (((r >> 1) & M5) | ((r & M5) << 1)) ^ 0xAAAAAAAAAAAAAAAAull;
+    const uint32_t rl = skm_swapcomp32(__brev((uint32_t)(x >> 32))), rh = skm_swapcomp32(__brev((uint32_t)x));
+    return ((uint64_t)rh << 32) | rl;
+}
+// reverse complement of the k-mer in the low 2k bits of x: skm_revcomp64(x) >> (64 - 2k), with 32-bit funnel shifts (sh = 64 - 2k, wave-uniform)
+__device__ __forceinline__ uint64_t skm_revcomp_k(uint64_t x, uint32_t sh) {
+    const uint32_t rl = skm_swapcomp32(__brev((uint32_t)(x >> 32))), rh = skm_swapcomp32(__brev((uint32_t)x));
+    if (sh < 32u) return ((uint64_t)(rh >> sh) << 32) | __builtin_amdgcn_alignbit(rh, rl, sh);
+    return (uint64_t)(rh >> (sh - 32u));
 }
 
 // --------------------------------------------------------------------------------------------
@@ -176,11 +186,21 @@ k_skm_scan(SimkaScanArgs a, SimkaSkmCfg cfg, ull *b1_count, ull *b1_cursor, uint
         const uint64_t R = skm_revcomp64(F) >> (2u * (17u - cfg.m));        // m-mer at entry q of the window: (R >> 2(15-q)) & mmask
         const uint32_t f0 = (uint32_t)F, f1 = (uint32_t)(F >> 32), r0_ = (uint32_t)R, r1_ = (uint32_t)(R >> 32);
         uint32_t hv[SKM_SEG];
+        if (cfg.mmask == 0xffffffffu) {       // (wave-uniform) m = 16, the headline geometry: a 32-bit m-mer needs none of the four masks
 #pragma unroll
-        for (int q = 0; q < SKM_SEG; q++) {
-            const uint32_t fw = __builtin_amdgcn_alignbit(f1, f0, 2 * q) & cfg.mmask;
-            const uint32_t rv = __builtin_amdgcn_alignbit(r1_, r0_, 2 * (15 - q)) & cfg.mmask;
-            hv[q] = skm_mm_hash(fw < rv ? fw : rv, cfg.mmask, cfg.m);
+            for (int q = 0; q < SKM_SEG; q++) {
+                const uint32_t fw = __builtin_amdgcn_alignbit(f1, f0, 2 * q), rv = __builtin_amdgcn_alignbit(r1_, r0_, 2 * (15 - q));
+                uint32_t h = (fw < rv ? fw : rv) * 0x9E3779B1u;
+                h ^= h >> 16;
+                hv[q] = h * 0x85EBCA6Bu;
+            }
+        } else {
+#pragma unroll
+            for (int q = 0; q < SKM_SEG; q++) {
+                const uint32_t fw = __builtin_amdgcn_alignbit(f1, f0, 2 * q) & cfg.mmask;
+                const uint32_t rv = __builtin_amdgcn_alignbit(r1_, r0_, 2 * (15 - q)) & cfg.mmask;
+                hv[q] = skm_mm_hash(fw < rv ? fw : rv, cfg.mmask, cfg.m);
+            }
         }
         uint4 *dst = (uint4 *)hm;
         dst[0 * SKM_NT + tid] = make_uint4(hv[0], hv[1], hv[2], hv[3]); dst[1 * SKM_NT + tid] = make_uint4(hv[4], hv[5], hv[6], hv[7]);
@@ -698,8 +718,8 @@ struct SimkaSkmSrc {
     const uint32_t *cbase; const ull *b1_start; const uint16_t *ctab; uint32_t cstride, pad_;
 };
 #define SKM_G_MAXCH 128          // chunks per level-1 bucket the gather takes (two per lane of a wave); beyond: the exact split
-#define SKM_G_WBYTES (SKM_G_MAXCH / 4 * 6)      // per wave of k_skm_count_fast (it owns the chunks c = 4 l + wave): u32 prefix + u16 start of its pieces
-#define SKM_G_BYTES(nw) ((SKM_MAXB1 + 1) * 4 + SKM_MAXB1 * 4 + (nw) * SKM_G_WBYTES)      // cbase + bucket starts + the waves' piece tables
+#define SKM_G_WBYTES (SKM_G_MAXCH / 4 * 6)      // per wave of k_skm_count_fast (it tabulates the chunks c = 4 l + wave): u32 prefix + u16 start of its pieces
+#define SKM_G_BYTES(nw) ((SKM_MAXB1 + 1) * 4 + SKM_MAXB1 * 4 + 2 * (nw) * (SKM_G_WBYTES + 4))      // cbase + bucket starts + the waves' piece tables and totals, double-buffered
 
 // --------------------------------------------------------------------------------------------
 // k_skm_count: one partition at a time per (persistent) block.
@@ -834,7 +854,7 @@ k_skm_count(SimkaSkmSrc src, SimkaSkmCfg cfg, SimkaKeyCfg kcfg, uint32_t amin, u
                             const uint32_t e = map[f];
                             const uint4 rc = lrec[e >> 5];
                             const uint64_t fwd = skm_kmer_at(rc, e & 31u, cfg);
-                            const uint64_t rev = skm_revcomp64(fwd) >> (64u - 2u * cfg.k);
+                            const uint64_t rev = skm_revcomp_k(fwd, 64u - 2u * cfg.k);
                             const uint64_t canon = fwd < rev ? fwd : rev;
                             const uint64_t mkey = canon;
                             const uint32_t h = simka_key_hash32(canon);
@@ -1357,10 +1377,16 @@ k_skm_count_fast(SimkaSkmSrc src, SimkaSkmCfg cfg, SimkaKeyCfg kcfg, uint32_t am
     uint32_t *s_bs = s_cb + SKM_MAXB1 + 1;                         // [SKM_MAXB1] (a lane's record buffer holds < 2^32 records)
 
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
-    // (wave w gathers the pieces in the chunks c = NW l + w, l < GNL, of the partition's bucket: its share of the records)
+    // (wave w TABULATES the pieces in the chunks c = NW l + w, l < GNL, of the next partition's bucket -- a quarter of the table each,
+    //  no redundant loads; the records are then split evenly over the waves, whichever wave tabulated their piece: the tables are
+    //  double-buffered by partition parity, written before the barrier that ends a partition's inserts and read by every wave after it)
     constexpr uint32_t GNL = SKM_G_MAXCH / NW;
-    uint32_t *gpre = (uint32_t *)((unsigned char *)(s_bs + SKM_MAXB1) + wave * SKM_G_WBYTES);      // [GNL] records of the wave before its piece l
-    uint16_t *gst = (uint16_t *)(gpre + GNL);                                                     // [GNL] first record of piece l inside its chunk
+    unsigned char *gtab0 = (unsigned char *)(s_bs + SKM_MAXB1);                                   // [2][NW] { u32 gpre[GNL]; u16 gst[GNL]; }
+    uint32_t *s_gt = (uint32_t *)(gtab0 + 2 * NW * SKM_G_WBYTES);                                 // [2][NW] records each wave tabulated
+    auto gpre_of = [&](uint32_t buf, uint32_t w) -> uint32_t * { return (uint32_t *)(gtab0 + (buf * NW + w) * SKM_G_WBYTES); };
+    auto gst_of = [&](uint32_t buf, uint32_t w) -> uint16_t * { return (uint16_t *)(gtab0 + (buf * NW + w) * SKM_G_WBYTES + GNL * 4); };
+    uint32_t gbuf = 0;                  // table buffer of the current partition
+    uint32_t gT0 = 0, gT1 = 0, gT2 = 0; // records tabulated by the waves before wave 1 / 2 / 3 (current partition)
     const uint32_t nparts = 1u << cfg.pb;
     const uint32_t gl2 = cfg.pb - cfg.l1, gm2 = (1u << gl2) - 1u;
     if (GATHER) {
@@ -1452,16 +1478,19 @@ k_skm_count_fast(SimkaSkmSrc src, SimkaSkmCfg cfg, SimkaKeyCfg kcfg, uint32_t am
     // record i of the partition the wave's piece table describes (GATHER) / of the run that starts at rb_
     auto rec_at = [&](uint32_t rb_, uint32_t i) -> uint4 {
         if (GATHER) {
-            uint32_t l = 0;           // the wave's last piece that starts at or before its record i (empty pieces share their successor's prefix)
+            // the wave that tabulated record i (the waves' records follow each other), then the last piece of its table that starts at
+            // or before the record (empty pieces share their successor's prefix)
+            const uint32_t w = (i >= gT0 ? 1u : 0u) + (i >= gT1 ? 1u : 0u) + (i >= gT2 ? 1u : 0u);
+            const uint32_t li = i - (w == 0u ? 0u : w == 1u ? gT0 : w == 2u ? gT1 : gT2);
+            const uint32_t *gp = gpre_of(gbuf, w); const uint16_t *gs = gst_of(gbuf, w);
+            uint32_t l = 0;
 #pragma unroll
-            for (uint32_t stp = GNL / 2; stp; stp >>= 1) l += gpre[l + stp] <= i ? stp : 0u;
-            return recs[(size_t)rb_ + (size_t)(l * NW + wave) * SKM_CS_CHUNK + gst[l] + (i - gpre[l])];
+            for (uint32_t stp = GNL / 2; stp; stp >>= 1) l += gp[l + stp] <= li ? stp : 0u;
+            return recs[(size_t)rb_ + (size_t)(l * NW + w) * SKM_CS_CHUNK + gs[l] + (li - gp[l])];
         }
         return recs[rb_ + i];
     };
-    // (GATHER: n_ = records of THIS WAVE, taken 64 at a time; else of the partition, 256 at a time in equal shares)
     auto prefetch = [&](uint32_t n_, uint32_t rb_) {
-        if (GATHER) { if (lane < n_) pre = rec_at(rb_, lane); return; }
         const uint32_t nb = n_ < (uint32_t)SKM_FAST_BLOCK ? n_ : (uint32_t)SKM_FAST_BLOCK;
         const uint32_t per = (nb + NW - 1u) / NW;
         if (lane < per && wave * per + lane < nb) pre = rec_at(rb_, wave * per + lane);
@@ -1482,18 +1511,27 @@ k_skm_count_fast(SimkaSkmSrc src, SimkaSkmCfg cfg, SimkaKeyCfg kcfg, uint32_t am
     };
     // descriptor -> (records, start) of partition p_; GATHER: also the wave's piece table (the table of the partition before is dead:
     // its last batch has been loaded)
+    // GATHER, before the barrier: the wave's quarter of the piece table of the partition that comes next, into the other buffer
+    auto tabulate = [&](uint32_t d) {
+        const uint32_t cA = (d >> 16) - (d & 0xffffu);          // (0 beyond the wave's pieces)
+        const uint32_t iA = wave_incl_scan(cA);
+        if (lane < GNL) { gpre_of(gbuf ^ 1u, wave)[lane] = iA - cA; gst_of(gbuf ^ 1u, wave)[lane] = (uint16_t)(d & 0xffffu); }
+        if (lane == 63u) s_gt[(gbuf ^ 1u) * NW + wave] = iA;
+    };
+    // descriptor -> (records, start) of partition p_; GATHER (after the barrier): the other buffer becomes the current one
     auto take_desc = [&](uint32_t p_, uint32_t d, uint32_t &n_, uint32_t &rb_) {
         if (GATHER) {
-            const uint32_t cA = (d >> 16) - (d & 0xffffu);          // (0 beyond the wave's pieces)
-            const uint32_t iA = wave_incl_scan(cA);
-            if (lane < GNL) { gpre[lane] = iA - cA; gst[lane] = (uint16_t)(d & 0xffffu); }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            n_ = (uint32_t)__builtin_amdgcn_readlane((int)iA, 63);
+            gbuf ^= 1u;
+            const uint32_t t0 = s_gt[gbuf * NW], t1 = s_gt[gbuf * NW + 1u], t2 = s_gt[gbuf * NW + 2u], t3 = s_gt[gbuf * NW + 3u];
+            static_assert(NW == 4, "four waves tabulate");
+            gT0 = t0; gT1 = t0 + t1; gT2 = gT1 + t2;
+            n_ = gT2 + t3;
             rb_ = p_ < nparts ? s_bs[p_ >> gl2] : 0u;
         } else { n_ = (uint32_t)__builtin_amdgcn_readlane((int)d, 0); rb_ = (uint32_t)__builtin_amdgcn_readlane((int)d, 1); }
     };
     __syncthreads();           // (the tables and s_cb / s_bs are in place)
-    if (part < nparts) { const uint32_t d0 = load_desc(part); take_desc(part, d0, nrec, rbase); prefetch(nrec, rbase); }
+    if (GATHER) { tabulate(load_desc(part)); __syncthreads(); }
+    if (part < nparts) { const uint32_t d0 = GATHER ? 0u : load_desc(part); take_desc(part, d0, nrec, rbase); prefetch(nrec, rbase); }
     __syncthreads();
     uint32_t chunk_n = dyn ? s_next[0] : blockIdx.x + gridDim.x, chunk_n2 = 0;    // (published before the barrier above)
     while (part < nparts) {
@@ -1504,7 +1542,7 @@ k_skm_count_fast(SimkaSkmSrc src, SimkaSkmCfg cfg, SimkaKeyCfg kcfg, uint32_t am
         ull grab = 0;
         if (dyn && first && tid == 0) grab = atomicAdd(work_counter, 1ull);
         if (!dyn) chunk_n2 = chunk_n + gridDim.x;
-        if (!GATHER && nrec == 0) {       // an empty partition (rare among the owned ones; GATHER: nrec is the wave's share, an empty partition takes the common path)
+        if (!GATHER && nrec == 0) {       // an empty partition (rare among the owned ones; GATHER: it takes the common path -- the next table is built before a barrier)
             if (dyn && first) {       // agree on the chunk after next through LDS right away
                 if (tid == 0) s_next[tog ^ 1u] = gridDim.x + (uint32_t)grab;
                 __syncthreads();
@@ -1520,11 +1558,11 @@ k_skm_count_fast(SimkaSkmSrc src, SimkaSkmCfg cfg, SimkaKeyCfg kcfg, uint32_t am
         // ---- expand + insert: every wave takes an equal share of the records (at most 64 per batch)
         PH(0)
         ull my_k = 0;
-        for (uint32_t b0 = 0; b0 < nrec; b0 += (GATHER ? 64u : (uint32_t)SKM_FAST_BLOCK)) {
+        for (uint32_t b0 = 0; b0 < nrec; b0 += SKM_FAST_BLOCK) {
             const uint32_t nb = nrec - b0 < (uint32_t)SKM_FAST_BLOCK ? nrec - b0 : (uint32_t)SKM_FAST_BLOCK;
             const uint32_t per = (nb + NW - 1u) / NW;                       // records of this wave: [b0 + wave*per, +per)
-            const uint32_t i = GATHER ? b0 + lane : b0 + wave * per + lane;
-            const bool mine = GATHER ? i < nrec : (lane < per && wave * per + lane < nb);
+            const uint32_t i = b0 + wave * per + lane;
+            const bool mine = lane < per && wave * per + lane < nb;
             uint4 rc = pre;
             if (b0) { if (mine) rc = rec_at(rbase, i); }
             uint32_t len = mine ? skm_rec_n(rc) : 0u;
@@ -1567,7 +1605,7 @@ k_skm_count_fast(SimkaSkmSrc src, SimkaSkmCfg cfg, SimkaKeyCfg kcfg, uint32_t am
                 for (uint32_t u = 0; u < U; u++) {
                     actc[u] = act[u];
                     const uint64_t fw = skm_kmer_at(rx[u], (f0 + 64u * u + lane - (rx[u].w >> 6)) & 31u, cfg);
-                    const uint64_t rv = skm_revcomp64(fw) >> (64u - 2u * cfg.k);
+                    const uint64_t rv = skm_revcomp_k(fw, 64u - 2u * cfg.k);
                     cu[u] = fw < rv ? fw : rv;
                     su[u] = simka_key_hash32(cu[u]) >> (32u - TSL);
                 }
@@ -1599,6 +1637,7 @@ k_skm_count_fast(SimkaSkmSrc src, SimkaSkmCfg cfg, SimkaKeyCfg kcfg, uint32_t am
         }
         DBG_ADD(8, my_k) DBG_ADD(12, 1) DBG_ADD(14, qn)
         while (qn) { drain(); DBG_ADD(13, 1) }
+        if (GATHER) tabulate(desc_n);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __syncthreads();
         PH(3)
