@@ -379,169 +379,224 @@ def main():
         # sha1 of every distance matrix (float32 bytes, by name): equal across --gpus N and decompositions for the same workload
         return __import__("hashlib").sha1(b"".join(np.ascontiguousarray(mats[m]).tobytes() for m in sorted(mats))).hexdigest()[:16]
 
-    results = []
+    def finish(results, failures, hard, note):
+        """the bench line from the decompositions that ran (hard: called after a failure or from the watchdog -- host data only, no device
+        call that could queue behind a hung collective, no further measurements)"""
+        best = results[0]
+        ctx, dt, st, mats, prof_all, prof_dom, dom, geo, by_sample = (best[x] for x in ("ctx", "dt", "st", "mats", "prof_all", "prof_dom", "dom", "geo", "by_sample"))
+        prof = prof_all
+        prof_steps = best["prof_steps"]
+
+        # ---- timing boundaries of SURVEY 8(d), measured outside the timed region (per step, this rank)
+        def timed(f, reps=3):
+            torch.cuda.synchronize(); t = time.perf_counter()
+            for _ in range(reps):
+                f()
+            torch.cuda.synchronize()
+            return (time.perf_counter() - t) / reps * 1e3
+        t_finalise = t_h2d = t_allreduce = None
+        if not hard:
+            t_finalise = timed(lambda: ctx.stats().matrices())                       # download + 15..21 matrices on the host
+            one = next(r for r in reads if r is not None)
+            pinned = torch.empty(one.numel(), dtype=torch.int64).pin_memory()
+            scratch = torch.empty_like(one)
+            nmine = sum(1 for r in reads if r is not None) if by_sample else n
+            t_h2d = timed(lambda: scratch.copy_(pinned, non_blocking=True)) * nmine      # packed reads host -> HBM (pinned), not part of `value`
+            if world > 1:
+                t_allreduce = timed(lambda: sdist.allreduce_stats_device(ctx, comm=comm))      # (sums the buffer into itself: timing only, after the results were taken)
+            del pinned, scratch
+
+        ps = st.per_sample()
+        K_dist = float(ps["D_all"].sum())     # distinct canonical k-mers before the filter, summed over samples (whole job)
+        K_occ = float(ps["K_occ"].sum())
+        K_solid = float(ps["D"].sum())
+        ms_per_step = dt / args.steps * 1e3
+        value = K_dist / (dt / args.steps)
+
+        # ---- roofline (DESIGN.md section 4 "Algorithmic bytes").  SURVEY 8(d): B_alg = R*L/4 + 16*K_occ + 12*K_dist + 12*K_solid, where
+        # 16*K_occ = "write + read each 8-byte k-mer once for partitioning".  The super-k-mer pipeline partitions 16-byte records of
+        # ~8.5 k-mers instead (real traffic ~2 B per k-mer and level), so the kernels' MEASURED traffic is far below these
+        # design-independent bytes; the attribution follows the roles: the scan writes every k-mer once, the count kernel reads every
+        # k-mer once and writes the counted records, the merge reads the solid records once; k_skm_split is an extra level (0).
+        share = 1.0 / world                    # each rank owns 1/world of the key space (or counts 1/world of the samples)
+        scan_reads = n * nb_bases / 4.0 * (share if by_sample else 1.0)       # partition shards: every rank reads every base
+        kb = 16.0 if k > 31 else 8.0           # bytes of a k-mer (SURVEY 8d prices 8-byte k-mers; two words from k = 32 on)
+        alg_bytes_per_step = {
+            "k_skm_scan": scan_reads + kb * K_occ * share,
+            "k_skm_count_fast": kb * K_occ * share + (kb + 4.0) * K_dist * share,
+            "k_skm_count_wide_fast": kb * K_occ * share + (kb + 4.0) * K_dist * share,
+            "k_group": (kb + 4.0) * K_solid * share,
+        }
+        kern_ms = {kname: ms for kname, (cnt, ms) in prof.items()}
+        total_kernel_ms = sum(kern_ms.values())
+        dom_launches, dom_ms = prof_dom[dom]
+        dom_bytes_per_launch = alg_bytes_per_step.get(dom, 0.0) * args.steps / max(dom_launches, 1)
+        dom_avg_ms = dom_ms / max(dom_launches, 1)
+        achieved = dom_bytes_per_launch / (dom_avg_ms * 1e-3) / 1e9 if dom_avg_ms > 0 else 0.0
+        b_alg = scan_reads + (2.0 * kb * K_occ + (kb + 4.0) * K_dist + (kb + 4.0) * K_solid) * share
+        # the whole path: B_alg over the step's wall time (kernels of neighbouring samples overlap on two streams, so the sum of the
+        # one-lane kernel times is an upper bound of the device time; it is reported as timing.device_kernels_ms)
+        path_gbs = b_alg / (dt / args.steps) / 1e9
+        # HBM bytes per launch of the dominant kernel from the PMC passes committed under profiles/ (scripts/pmc_traffic.sh:
+        # FETCH_SIZE and WRITE_SIZE in separate rocprofv3 runs, FETCH_SIZE x2 on gfx950); only when it is the same workload
+        traffic = None
+        traffic_src = None
+        tk = {}
+        # rocprofv3 reports template instances; the library's profiler reports one name per kernel family
+        def family(name):
+            if name.startswith("k_skm_scan<"):
+                return "k_skm_scan<hist>" if name.rstrip(">").endswith("true") else "k_skm_scan"
+            return name.split("<")[0]
+
+        def measured_traffic(kname):
+            """launch-weighted mean HBM bytes per launch over the template instances of the family"""
+            tot, n = 0.0, 0
+            for cand, v in tk.items():
+                if family(cand) == kname:
+                    tot += v["traffic_bytes_per_launch"] * v["launches"]; n += v["launches"]
+            return tot / n if n else None
+        try:
+            tf = next((f for f in (os.path.join(ROOT, "profiles", "r%02d_%s_hbm_traffic.json" % (rd, args.workload)) for rd in (3, 2)) if os.path.exists(f)), "")
+            if world == 1 and not args.reads and not args.samples and not args.kmer_size and tf:
+                tk = json.load(open(tf))["kernels"]
+                traffic = measured_traffic(dom)
+                traffic_src = os.path.relpath(tf, ROOT)
+        except Exception:
+            traffic = None
+        per_kernel = {}
+        for kname, (cnt, ms) in prof.items():
+            if cnt == 0:
+                continue
+            ab = alg_bytes_per_step.get(kname, 0.0)
+            mt = measured_traffic(kname)
+            per_kernel[kname] = {"launches_per_step": cnt / prof_steps, "ms_per_step": ms / prof_steps,
+                                 "alg_bytes_per_step": ab, "alg_GBps": (ab * prof_steps / (ms * 1e-3) / 1e9) if ms > 0 else 0.0,
+                                 "hbm_traffic_bytes_per_launch": mt,
+                                 # what the kernel really moves over HBM (PMC counters) against the 8 TB/s peak -- NOT the attributed bytes above
+                                 "hbm_frac_measured": (mt * cnt / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if (mt and ms > 0) else None,
+                                 "bound": KERNEL_BOUND.get(kname)}
+        roofline = {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
+                    # `frac` prices the kernel in SURVEY 8(d)'s design-independent bytes (8-byte k-mers); its real HBM traffic is `traffic`:
+                    "hbm_frac_measured": (traffic / (dom_avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if (traffic and dom_avg_ms > 0) else None,
+                    "kernel_bound": KERNEL_BOUND.get(dom),
+                    "avg_launch_ms": dom_avg_ms, "launches": dom_launches, "alg_bytes_per_launch": dom_bytes_per_launch,
+                    "path_achieved": path_gbs, "path_frac": path_gbs / HBM_PEAK_GBS, "path_alg_bytes_per_step": b_alg,
+                    "kernel_ms_per_step": {kk: v / prof_steps for kk, v in kern_ms.items()}, "kernels": per_kernel,
+                    "events": "timed region (%d stream%s): HIP events around the %s launches only (avg_launch_ms, achieved); path_*: B_alg over the timed "
+                              "step; kernel_ms_per_step, kernels and timing.device_kernels_ms: an untimed pass of %d steps on a one-stream context with "
+                              "every kernel timed" % (max(1, args.lanes), "" if args.lanes <= 1 else "s: a launch may share the GPU with the other stream's kernels", dom, prof_steps)}
+
+        pair_updates = float(st.pairs()["a"].sum())            # sum over k-mers of s(s-1)/2 = sum over pairs of the shared distinct k-mers
+        if "k_pairs" in per_kernel and per_kernel["k_pairs"]["ms_per_step"] > 0:
+            per_kernel["k_pairs"]["pair_updates_per_step"] = pair_updates
+            per_kernel["k_pairs"]["pair_updates_per_s"] = pair_updates / world / (per_kernel["k_pairs"]["ms_per_step"] * 1e-3)
+        timing = {"step_ms_two_streams": best.get("two_ms"), "device_kernels_ms": total_kernel_ms / prof_steps, "finalise_ms": t_finalise, "h2d_packed_reads_ms": t_h2d,
+                  "allreduce_ms": t_allreduce, "step_ms": ms_per_step,
+                  "note": "per step on rank 0; h2d = the packed reads of this rank's samples from pinned host memory (inputs are resident in HBM in the timed "
+                          "region); e2e_from_fasta: the `simka` driver on FASTA files of a bounded sample of the workload (files on disk -> CSVs)"}
+        out = {
+            "metric": "distinct k-mers/s end-to-end (count + merge + N x N matrices)", "value": value, "unit": "distinct k-mers/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "u64", "data": "synthetic",
+            "config": {"workload": "%s: %s" % (args.workload, wl["desc"]), "samples": n, "reads_per_sample": R, "read_len": L,
+                       "kmer_size": k, "abundance_min": wl["amin"], "simple_dist": wl["simple"],
+                       "parallelism": ("1 GPU" if world == 1 else "samples x%d -> all-to-all of solid spectra by partition range -> 1 all-reduce" % world
+                                       if by_sample else "partition shards x%d + 1 all-reduce" % world),
+                       "kmer_occurrences": K_occ, "distinct_kmers": K_dist, "solid_kmers": K_solid,
+                       "kmer_occurrences_per_s": K_occ / (dt / args.steps), "geometry": geo,
+                       # sha1 of every distance matrix (float32 bytes, by name): equal across --gpus N for the same workload
+                       "matrix_checksum": checksum(mats)},
+            "roofline": roofline,
+            "timing": timing,
+        }
+        if world > 1:
+            # every decomposition that ran: the reported one first (`value` is the faster); checksums must agree
+            out["decompositions"] = {r["mode"]: {"ms_per_step": r["dt"] / args.steps * 1e3, "value": K_dist / (r["dt"] / args.steps),
+                                                 "matrix_checksum": checksum(r["mats"])} for r in results}
+            if failures or note:
+                out["decomposition_failures"] = dict(failures, **({"note": note} if note else {}))
+            out["config"]["collectives"] = ("RCCL through the C ABI (simka_stats_allreduce / simka_exchange_*)" if comm is not None
+                                            else "torch.distributed %s" % backend)
+        if hard:
+            if rank == 0:
+                print(json.dumps(out), flush=True)
+            return
+        if rank == 0 and world == 1 and not args.no_cpu_baseline:
+            try:
+                out["cpu_baseline"] = cpu_baseline(wl, lib, torch, dev)
+            except Exception as e:       # the baseline is a report, never a reason to lose the GPU number
+                out["cpu_baseline"] = {"value": None, "unit": "distinct k-mers/s", "cores": os.cpu_count(), "kind": "port",
+                                       "sample": "failed: %r" % (e,)}
+        ctx.close()
+        if rank == 0 and world == 1 and not args.no_e2e and not args.no_cpu_baseline:
+            try:
+                out["timing"]["e2e_from_fasta"] = e2e_from_fasta(wl, lib, torch, dev)
+                out["timing"]["e2e_from_fasta_ms"] = out["timing"]["e2e_from_fasta"]["ms"]
+            except Exception as e:
+                out["timing"]["e2e_from_fasta"] = {"ms": None, "sample": "failed: %r" % (e,)}
+        if rank == 0:
+            print(json.dumps(out))
+
+    # Every decomposition runs under its own try / except, and -- once one of them has a result -- under a watchdog: an RCCL error or
+    # a hang in the second one (no multi-GPU box has run these collectives yet) must not lose the line of the first.  On such a
+    # failure rank 0 prints the line of what did run (`decomposition_failures` says what did not) and every rank leaves with
+    # os._exit: the process group may be wedged, so no further collective, no destructor.
+    import threading
+    results, failures = [], {}
+    state = {"done": False}
+
+    def bail(reason):
+        if state["done"]:
+            return
+        state["done"] = True
+        try:
+            if rank == 0 and results:
+                finish(results, failures, hard=True, note=reason)
+        finally:
+            sys.stdout.flush(); sys.stderr.flush()
+            os._exit(0 if results else 3)
+
     for mode in modes:
-        r = run_mode(mode)
+        wd = None
+        t_mode = time.perf_counter()
+        if world > 1 and results:
+            limit = float(os.environ.get("SIMKA_BENCH_MODE_TIMEOUT", "0")) or max(240.0, 8.0 * results[0]["wall"])
+            wd = threading.Timer(limit, bail, args=("decomposition '%s' did not finish within %.0f s" % (mode, limit),))
+            wd.daemon = True
+            wd.start()
+        try:
+            if os.environ.get("SIMKA_BENCH_FAIL_MODE") == mode:          # tests: this decomposition fails / hangs
+                if os.environ.get("SIMKA_BENCH_FAIL_HOW") == "hang":
+                    time.sleep(1e6)
+                raise RuntimeError("SIMKA_BENCH_FAIL_MODE=%s" % mode)
+            r = run_mode(mode)
+            r["wall"] = time.perf_counter() - t_mode
+        except Exception as e:
+            if wd is not None:
+                wd.cancel()
+            failures[mode] = repr(e)
+            sys.stderr.write("bench.py rank %d: decomposition '%s' failed: %r\n" % (rank, mode, e))
+            if world > 1 and results:
+                bail("decomposition '%s' failed: %r" % (mode, e))
+            continue
+        if wd is not None:
+            wd.cancel()
         if results:                       # keep one context alive: the faster decomposition is the reported one
             keep, drop = (r, results[0]) if r["dt"] < results[0]["dt"] else (results[0], r)
             drop["ctx"].close(); drop["ctx"] = None
             results = [keep, drop]
         else:
             results = [r]
-    best = results[0]
-    ctx, dt, st, mats, prof_all, prof_dom, dom, geo, by_sample = (best[x] for x in ("ctx", "dt", "st", "mats", "prof_all", "prof_dom", "dom", "geo", "by_sample"))
-    prof = prof_all
-    prof_steps = best["prof_steps"]
-
-    # ---- timing boundaries of SURVEY 8(d), measured outside the timed region (per step, this rank)
-    def timed(f, reps=3):
-        torch.cuda.synchronize(); t = time.perf_counter()
-        for _ in range(reps):
-            f()
-        torch.cuda.synchronize()
-        return (time.perf_counter() - t) / reps * 1e3
-    t_finalise = timed(lambda: ctx.stats().matrices())                       # download + 15..21 matrices on the host
-    one = next(r for r in reads if r is not None)
-    pinned = torch.empty(one.numel(), dtype=torch.int64).pin_memory()
-    scratch = torch.empty_like(one)
-    nmine = sum(1 for r in reads if r is not None) if by_sample else n
-    t_h2d = timed(lambda: scratch.copy_(pinned, non_blocking=True)) * nmine      # packed reads host -> HBM (pinned), not part of `value`
-    t_allreduce = None
-    if world > 1:
-        t_allreduce = timed(lambda: sdist.allreduce_stats_device(ctx, comm=comm))      # (sums the buffer into itself: timing only, after the results were taken)
-    del pinned, scratch
-
-    ps = st.per_sample()
-    K_dist = float(ps["D_all"].sum())     # distinct canonical k-mers before the filter, summed over samples (whole job)
-    K_occ = float(ps["K_occ"].sum())
-    K_solid = float(ps["D"].sum())
-    ms_per_step = dt / args.steps * 1e3
-    value = K_dist / (dt / args.steps)
-
-    # ---- roofline (DESIGN.md section 4 "Algorithmic bytes").  SURVEY 8(d): B_alg = R*L/4 + 16*K_occ + 12*K_dist + 12*K_solid, where
-    # 16*K_occ = "write + read each 8-byte k-mer once for partitioning".  The super-k-mer pipeline partitions 16-byte records of
-    # ~8.5 k-mers instead (real traffic ~2 B per k-mer and level), so the kernels' MEASURED traffic is far below these
-    # design-independent bytes; the attribution follows the roles: the scan writes every k-mer once, the count kernel reads every
-    # k-mer once and writes the counted records, the merge reads the solid records once; k_skm_split is an extra level (0).
-    share = 1.0 / world                    # each rank owns 1/world of the key space (or counts 1/world of the samples)
-    scan_reads = n * nb_bases / 4.0 * (share if by_sample else 1.0)       # partition shards: every rank reads every base
-    kb = 16.0 if k > 31 else 8.0           # bytes of a k-mer (SURVEY 8d prices 8-byte k-mers; two words from k = 32 on)
-    alg_bytes_per_step = {
-        "k_skm_scan": scan_reads + kb * K_occ * share,
-        "k_skm_count_fast": kb * K_occ * share + (kb + 4.0) * K_dist * share,
-        "k_skm_count_wide_fast": kb * K_occ * share + (kb + 4.0) * K_dist * share,
-        "k_group": (kb + 4.0) * K_solid * share,
-    }
-    kern_ms = {kname: ms for kname, (cnt, ms) in prof.items()}
-    total_kernel_ms = sum(kern_ms.values())
-    dom_launches, dom_ms = prof_dom[dom]
-    dom_bytes_per_launch = alg_bytes_per_step.get(dom, 0.0) * args.steps / max(dom_launches, 1)
-    dom_avg_ms = dom_ms / max(dom_launches, 1)
-    achieved = dom_bytes_per_launch / (dom_avg_ms * 1e-3) / 1e9 if dom_avg_ms > 0 else 0.0
-    b_alg = scan_reads + (2.0 * kb * K_occ + (kb + 4.0) * K_dist + (kb + 4.0) * K_solid) * share
-    # the whole path: B_alg over the step's wall time (kernels of neighbouring samples overlap on two streams, so the sum of the
-    # one-lane kernel times is an upper bound of the device time; it is reported as timing.device_kernels_ms)
-    path_gbs = b_alg / (dt / args.steps) / 1e9
-    # HBM bytes per launch of the dominant kernel from the PMC passes committed under profiles/ (scripts/pmc_traffic.sh:
-    # FETCH_SIZE and WRITE_SIZE in separate rocprofv3 runs, FETCH_SIZE x2 on gfx950); only when it is the same workload
-    traffic = None
-    traffic_src = None
-    tk = {}
-    # rocprofv3 reports template instances; the library's profiler reports one name per kernel family
-    def family(name):
-        if name.startswith("k_skm_scan<"):
-            return "k_skm_scan<hist>" if name.rstrip(">").endswith("true") else "k_skm_scan"
-        return name.split("<")[0]
-
-    def measured_traffic(kname):
-        """launch-weighted mean HBM bytes per launch over the template instances of the family"""
-        tot, n = 0.0, 0
-        for cand, v in tk.items():
-            if family(cand) == kname:
-                tot += v["traffic_bytes_per_launch"] * v["launches"]; n += v["launches"]
-        return tot / n if n else None
-    try:
-        tf = next((f for f in (os.path.join(ROOT, "profiles", "r%02d_%s_hbm_traffic.json" % (rd, args.workload)) for rd in (3, 2)) if os.path.exists(f)), "")
-        if world == 1 and not args.reads and not args.samples and not args.kmer_size and tf:
-            tk = json.load(open(tf))["kernels"]
-            traffic = measured_traffic(dom)
-            traffic_src = os.path.relpath(tf, ROOT)
-    except Exception:
-        traffic = None
-    per_kernel = {}
-    for kname, (cnt, ms) in prof.items():
-        if cnt == 0:
-            continue
-        ab = alg_bytes_per_step.get(kname, 0.0)
-        mt = measured_traffic(kname)
-        per_kernel[kname] = {"launches_per_step": cnt / prof_steps, "ms_per_step": ms / prof_steps,
-                             "alg_bytes_per_step": ab, "alg_GBps": (ab * prof_steps / (ms * 1e-3) / 1e9) if ms > 0 else 0.0,
-                             "hbm_traffic_bytes_per_launch": mt,
-                             # what the kernel really moves over HBM (PMC counters) against the 8 TB/s peak -- NOT the attributed bytes above
-                             "hbm_frac_measured": (mt * cnt / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if (mt and ms > 0) else None,
-                             "bound": KERNEL_BOUND.get(kname)}
-    roofline = {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
-                # `frac` prices the kernel in SURVEY 8(d)'s design-independent bytes (8-byte k-mers); its real HBM traffic is `traffic`:
-                "hbm_frac_measured": (traffic / (dom_avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if (traffic and dom_avg_ms > 0) else None,
-                "kernel_bound": KERNEL_BOUND.get(dom),
-                "avg_launch_ms": dom_avg_ms, "launches": dom_launches, "alg_bytes_per_launch": dom_bytes_per_launch,
-                "path_achieved": path_gbs, "path_frac": path_gbs / HBM_PEAK_GBS, "path_alg_bytes_per_step": b_alg,
-                "kernel_ms_per_step": {kk: v / prof_steps for kk, v in kern_ms.items()}, "kernels": per_kernel,
-                "events": "timed region (%d stream%s): HIP events around the %s launches only (avg_launch_ms, achieved); path_*: B_alg over the timed "
-                          "step; kernel_ms_per_step, kernels and timing.device_kernels_ms: an untimed pass of %d steps on a one-stream context with "
-                          "every kernel timed" % (max(1, args.lanes), "" if args.lanes <= 1 else "s: a launch may share the GPU with the other stream's kernels", dom, prof_steps)}
-
-    pair_updates = float(st.pairs()["a"].sum())            # sum over k-mers of s(s-1)/2 = sum over pairs of the shared distinct k-mers
-    if "k_pairs" in per_kernel and per_kernel["k_pairs"]["ms_per_step"] > 0:
-        per_kernel["k_pairs"]["pair_updates_per_step"] = pair_updates
-        per_kernel["k_pairs"]["pair_updates_per_s"] = pair_updates / world / (per_kernel["k_pairs"]["ms_per_step"] * 1e-3)
-    timing = {"step_ms_two_streams": best.get("two_ms"), "device_kernels_ms": total_kernel_ms / prof_steps, "finalise_ms": t_finalise, "h2d_packed_reads_ms": t_h2d,
-              "allreduce_ms": t_allreduce, "step_ms": ms_per_step,
-              "note": "per step on rank 0; h2d = the packed reads of this rank's samples from pinned host memory (inputs are resident in HBM in the timed "
-                      "region); e2e_from_fasta: the `simka` driver on FASTA files of a bounded sample of the workload (files on disk -> CSVs)"}
-    out = {
-        "metric": "distinct k-mers/s end-to-end (count + merge + N x N matrices)", "value": value, "unit": "distinct k-mers/s",
-        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
-        "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "u64", "data": "synthetic",
-        "config": {"workload": "%s: %s" % (args.workload, wl["desc"]), "samples": n, "reads_per_sample": R, "read_len": L,
-                   "kmer_size": k, "abundance_min": wl["amin"], "simple_dist": wl["simple"],
-                   "parallelism": ("1 GPU" if world == 1 else "samples x%d -> all-to-all of solid spectra by partition range -> 1 all-reduce" % world
-                                   if by_sample else "partition shards x%d + 1 all-reduce" % world),
-                   "kmer_occurrences": K_occ, "distinct_kmers": K_dist, "solid_kmers": K_solid,
-                   "kmer_occurrences_per_s": K_occ / (dt / args.steps), "geometry": geo,
-                   # sha1 of every distance matrix (float32 bytes, by name): equal across --gpus N for the same workload
-                   "matrix_checksum": checksum(mats)},
-        "roofline": roofline,
-        "timing": timing,
-    }
-    if world > 1:
-        # every decomposition that ran: the reported one first (`value` is the faster); checksums must agree
-        out["decompositions"] = {r["mode"]: {"ms_per_step": r["dt"] / args.steps * 1e3, "value": K_dist / (r["dt"] / args.steps),
-                                             "matrix_checksum": checksum(r["mats"])} for r in results}
-        out["config"]["collectives"] = ("RCCL through the C ABI (simka_stats_allreduce / simka_exchange_*)" if comm is not None
-                                        else "torch.distributed %s" % backend)
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        try:
-            out["cpu_baseline"] = cpu_baseline(wl, lib, torch, dev)
-        except Exception as e:       # the baseline is a report, never a reason to lose the GPU number
-            out["cpu_baseline"] = {"value": None, "unit": "distinct k-mers/s", "cores": os.cpu_count(), "kind": "port",
-                                   "sample": "failed: %r" % (e,)}
-    ctx.close()
-    if rank == 0 and world == 1 and not args.no_e2e and not args.no_cpu_baseline:
-        try:
-            out["timing"]["e2e_from_fasta"] = e2e_from_fasta(wl, lib, torch, dev)
-            out["timing"]["e2e_from_fasta_ms"] = out["timing"]["e2e_from_fasta"]["ms"]
-        except Exception as e:
-            out["timing"]["e2e_from_fasta"] = {"ms": None, "sample": "failed: %r" % (e,)}
-    if rank == 0:
-        print(json.dumps(out))
+    if not results:
+        raise SystemExit("bench.py: no decomposition ran: %r" % (failures,))
+    state["done"] = True
+    finish(results, failures, hard=False, note=None)
     if comm is not None:
         comm.close()
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
-
 
 if __name__ == "__main__":
     main()

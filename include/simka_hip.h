@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define SIMKA_ABI_VERSION 5
+#define SIMKA_ABI_VERSION 6
 
 enum {
     SIMKA_OK = 0,
@@ -40,6 +40,14 @@ enum {
 
 /* -simple-dist / -complex-dist   ref: src/core/Simka.cpp:25-117, src/core/SimkaAlgorithm.cpp:178-179 */
 enum { SIMKA_DIST_SIMPLE = 1u, SIMKA_DIST_COMPLEX = 2u };
+
+/* simka_config.flags */
+enum {
+    SIMKA_CFG_ARENA_PLAIN = 1u   /* allocate the solid-spectrum arena with one plain device allocation instead of a reserved virtual range
+                                  * that is mapped as the samples arrive.  The library also does so by itself when another context is alive
+                                  * on the same device (several contexts of one process mapping and launching concurrently is the pattern
+                                  * that ended in a GPU memory fault about once in a hundred runs, scripts/ubench/vmm_two_contexts.hip). */
+};
 
 typedef struct simka_ctx simka_ctx;
 
@@ -59,7 +67,7 @@ typedef struct simka_config {
     uint32_t shard_count;        /* ... of shard_count (1 = everything); partitions p with p % count == index */
     uint32_t log2_partitions;    /* 0 = derive from max_kmers_per_sample */
     uint32_t log2_subranges;     /* 0 = derive from nb_samples */
-    uint32_t reserved0;
+    uint32_t flags;              /* SIMKA_CFG_* (0 = defaults; was reserved0 up to ABI 5) */
     uint64_t max_kmers_per_sample; /* upper bound of k-mer occurrences of the largest sample (sizing) */
     uint64_t solid_capacity;     /* capacity (records) of the solid-spectrum arena, 0 = from free memory */
     uint64_t csr_capacity;       /* capacity (records) of the merged-group buffer, 0 = auto */

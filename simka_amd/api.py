@@ -29,7 +29,7 @@ class Config(C.Structure):
     _fields_ = [("struct_size", C.c_uint32), ("nb_samples", C.c_uint32), ("kmer_size", C.c_uint32),
                 ("abundance_min", C.c_uint32), ("abundance_max", C.c_uint32), ("dist_flags", C.c_uint32),
                 ("device", C.c_int32), ("shard_index", C.c_uint32), ("shard_count", C.c_uint32),
-                ("log2_partitions", C.c_uint32), ("log2_subranges", C.c_uint32), ("reserved0", C.c_uint32),
+                ("log2_partitions", C.c_uint32), ("log2_subranges", C.c_uint32), ("flags", C.c_uint32),
                 ("max_kmers_per_sample", C.c_uint64), ("solid_capacity", C.c_uint64), ("csr_capacity", C.c_uint64),
                 ("stream", C.c_void_p)]
 

@@ -47,6 +47,7 @@ struct Options {
     int verbose = 1;
     int nb_gpus = 1, first_gpu = 0;     // new: GPUs to spread the samples (count) and the partition ranges (merge) over
     bool same_gpu = false;              // new (tests): all -nb-gpus contexts on GPU -gpu
+    bool mapped_arenas = false;         // new: -nb-gpus on distinct devices with lazily mapped arenas (default: plain allocations until a multi-GPU box has run the mapped path)
     long long ingest_chunk = 1ll << 30; // new: bytes of a file handed to the device-side parser at a time (cut at record boundaries)
     bool host_parse = false;            // new: parse + pack every input on the host (default: plain-text inputs without read policies are parsed on the GPU)
     bool host_spectra = false;          // new: -nb-gpus keeps the spectra in host memory between count and merge (the round-2 route)
@@ -136,6 +137,7 @@ Options parse_args(int argc, char **argv) {
         else if (a == "-nb-gpus") o.nb_gpus = atoi(need(i).c_str());
         else if (a == "-gpu") o.first_gpu = atoi(need(i).c_str());
         else if (a == "-gpu-shared") o.same_gpu = true;
+        else if (a == "-gpu-mapped-arenas") o.mapped_arenas = true;
         else if (a == "-host-spectra") o.host_spectra = true;
         else if (a == "-gpu-allreduce") o.gpu_allreduce = true;
         else if (a == "-host-parse") o.host_parse = true;
@@ -714,8 +716,10 @@ int main(int argc, char **argv) {
     // Several contexts of this process on ONE device (-gpu-shared: the tests of the -nb-gpus routes on a one-GPU box): their arenas are
     // plain allocations.  With lazily mapped ranges (hipMemMap / hipMemSetAccess by one worker thread while another context's kernels
     // run on the same device) about one run in a hundred ended in a GPU memory access fault at an arena's base on ROCm 7.0; 300 runs
-    // with plain allocations: none.  Contexts on distinct devices keep the mapped ranges (page tables are per device).
-    if (o.same_gpu && G > 1) setenv("SIMKA_ARENA_MALLOC", "1", 1);
+    // with plain allocations: none.  Page tables are per device, so contexts on DISTINCT devices should be safe with mapped ranges --
+    // but the worker threads of -nb-gpus map from several threads of one process all the same, and no multi-GPU box has run that
+    // path yet: every -nb-gpus run takes plain arenas until one has (-gpu-mapped-arenas restores the lazily mapped ranges).
+    if (G > 1 && !(o.mapped_arenas && !o.same_gpu)) setenv("SIMKA_ARENA_MALLOC", "1", 1);
     const uint32_t flags = (o.simple ? SIMKA_DIST_SIMPLE : 0u) | (o.complex_ ? SIMKA_DIST_COMPLEX : 0u);
     // -keep-tmp: samples whose spectrum is in the temp dir and still valid are not read again
     std::vector<char> reuse(N, 0);

@@ -84,6 +84,7 @@ struct simka_ctx {
     // of the arena cursor once everything enqueued has finished; lane_bound: what the sample in flight on a lane may still add.
     bool arena_vmm = false; uint64_t arena_mapped = 0, arena_hi = 0, arena_reserved = 0;      // (arena_reserved: arena_cap rounded up to whole chunks)
     uint64_t lane_bound[MAX_LANES] = {};
+    bool live_counted = false;                  // this context is part of g_live_ctx[device]
     std::vector<char> arena_accounted;          // per sample: its bound is part of arena_hi (a redo or a further pass adds nothing)
     std::vector<hipMemGenericAllocationHandle_t> arena_hk, arena_hc;
     ull *d_arena_cursor = nullptr, *d_sample_base = nullptr;
@@ -263,6 +264,14 @@ SIMKA_EXPORT int simka_abi_version(void) { return SIMKA_ABI_VERSION; }
 // -gpu-shared`, one worker thread per context) ended, once in ten runs, in a memory access fault at the base of a freshly mapped arena:
 // the virtual-memory calls of a process go one at a time.
 static std::mutex g_vmm_lock;
+static int g_live_ctx[64] = {0};        // contexts alive per device (under g_vmm_lock): a second one on a device gets a plain arena
+// Virtual ranges of destroyed contexts are RETIRED, never given back: on ROCm 7.0 / gfx950 a range that was unmapped and is mapped
+// again (hipMemAddressFree -> a later hipMemAddressReserve returns the same addresses -> hipMemMap) is read and written through stale
+// translations now and then -- whole 256-MiB chunks read back wrong, or a GPU memory access fault (scripts/ubench/vmm_two_contexts.hip:
+// the same range remapped every round fails within 10 rounds with one thread or two, with or without draining the device around the
+// mapping calls; a fresh range every round passes).  A retired range costs address space only; past 2^45 bytes of it the arenas
+// of new contexts are plain allocations.
+static uint64_t g_vmm_retired_bytes = 0;
 
 SIMKA_EXPORT const char *simka_last_error(const simka_ctx *ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
 
@@ -385,7 +394,11 @@ static int setup_geometry(simka_ctx *ctx, uint64_t max_kmers) {
         std::lock_guard<std::mutex> vmm_guard(g_vmm_lock);
         void *vk = nullptr, *vc = nullptr;
         const uint64_t capr = (cap + ARENA_CHUNK - 1) / ARENA_CHUNK * ARENA_CHUNK;
-        if (!getenv("SIMKA_ARENA_MALLOC") && hipMemAddressReserve(&vk, capr * 8, 0, nullptr, 0) == hipSuccess) {
+        // plain allocation on request, and whenever another context is alive on this device: chunks being mapped while another
+        // context's kernels run is the pattern that faulted (root cause unknown; scripts/ubench/vmm_two_contexts.hip)
+        const int dv = c.device >= 0 && c.device < 64 ? c.device : 0;
+        const bool plain = (c.flags & SIMKA_CFG_ARENA_PLAIN) || getenv("SIMKA_ARENA_MALLOC") || g_live_ctx[dv] > 1 || g_vmm_retired_bytes > ((uint64_t)1 << 45);
+        if (!plain && hipMemAddressReserve(&vk, capr * 8, 0, nullptr, 0) == hipSuccess) {
             if (hipMemAddressReserve(&vc, capr * 4, 0, nullptr, 0) == hipSuccess) {
                 ctx->arena_vmm = true; ctx->d_solid_keys = (ull *)vk; ctx->d_solid_counts = (uint32_t *)vc; ctx->arena_reserved = capr; ctx->arena_mapped = 0;
             } else { (void)hipMemAddressFree(vk, capr * 8); (void)hipGetLastError(); }
@@ -420,6 +433,7 @@ SIMKA_EXPORT int simka_create(const simka_config *cfg, simka_ctx **out) {
     if (cfg->device < 0 || cfg->device >= ndev) { g_create_error = "simka_create: bad device ordinal"; return SIMKA_ERR_INVALID; }
     simka_ctx *ctx = new simka_ctx();
     ctx->cfg = *cfg;
+    { std::lock_guard<std::mutex> g_(g_vmm_lock); if (cfg->device < 64) g_live_ctx[cfg->device]++; ctx->live_counted = true; }
     if (ctx->cfg.abundance_max > 999999999u) ctx->cfg.abundance_max = 999999999u;   // ref: src/core/SimkaAlgorithm.cpp:188
     auto bail = [&](int rc) { g_create_error = ctx->err; simka_destroy(ctx); return rc; };
     if (hipSetDevice(cfg->device) != hipSuccess) { ctx->err = "hipSetDevice failed"; return bail(SIMKA_ERR_HIP); }
@@ -502,6 +516,7 @@ SIMKA_EXPORT int simka_create(const simka_config *cfg, simka_ctx **out) {
 
 SIMKA_EXPORT void simka_destroy(simka_ctx *ctx) {
     if (!ctx) return;
+    if (ctx->live_counted) { std::lock_guard<std::mutex> g_(g_vmm_lock); if (ctx->cfg.device >= 0 && ctx->cfg.device < 64) g_live_ctx[ctx->cfg.device]--; ctx->live_counted = false; }
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     if (ctx->wide) { simka_wide_destroy(ctx->wide); ctx->wide = nullptr; }
     for (auto &L : ctx->lanes) {
@@ -519,10 +534,15 @@ SIMKA_EXPORT void simka_destroy(simka_ctx *ctx) {
     if (ctx->arena_vmm) {      // unmap and release the chunks, give the ranges back
         std::lock_guard<std::mutex> vmm_guard(g_vmm_lock);
         (void)hipDeviceSynchronize();
-        if (ctx->arena_mapped) { (void)hipMemUnmap(ctx->d_solid_keys, ctx->arena_mapped * 8); (void)hipMemUnmap(ctx->d_solid_counts, ctx->arena_mapped * 4); }
+        // chunk by chunk, mirroring the hipMemMap calls (one unmap over several mappings is not guaranteed to release them all)
+        for (uint64_t at = 0; at < ctx->arena_mapped; at += ARENA_CHUNK) {
+            const hipError_t e1 = hipMemUnmap((char *)ctx->d_solid_keys + at * 8, ARENA_CHUNK * 8), e2 = hipMemUnmap((char *)ctx->d_solid_counts + at * 4, ARENA_CHUNK * 4);
+            if ((e1 != hipSuccess || e2 != hipSuccess) && getenv("SIMKA_DEBUG_SYNC")) fprintf(stderr, "[simka] hipMemUnmap of arena chunk %llu failed: %s\n", (unsigned long long)(at / ARENA_CHUNK), hipGetErrorString(e1 != hipSuccess ? e1 : e2));
+            (void)hipGetLastError();
+        }
         for (auto h : ctx->arena_hk) (void)hipMemRelease(h);
         for (auto h : ctx->arena_hc) (void)hipMemRelease(h);
-        (void)hipMemAddressFree(ctx->d_solid_keys, ctx->arena_reserved * 8); (void)hipMemAddressFree(ctx->d_solid_counts, ctx->arena_reserved * 4);
+        g_vmm_retired_bytes += ctx->arena_reserved * 12;      // (no hipMemAddressFree: see g_vmm_retired_bytes)
         ctx->d_solid_keys = nullptr; ctx->d_solid_counts = nullptr;
     }
     void *ptrs[] = { ctx->d_wh_hi, ctx->d_wh_lo, ctx->d_wh_cnt, ctx->d_wh_cursor, ctx->d_l1_ovf, ctx->d_solid_keys, ctx->d_solid_counts, ctx->d_arena_cursor,
@@ -613,10 +633,18 @@ static int arena_ensure(simka_ctx *ctx, uint64_t need) {
         const uint64_t at = ctx->arena_mapped;
         if (hipMemCreate(&hk, ARENA_CHUNK * 8, &prop, 0) != hipSuccess) { (void)hipGetLastError(); return ctx->fail(SIMKA_ERR_NOMEM, "the solid-spectrum arena cannot grow beyond %llu records (device memory exhausted)", (unsigned long long)at); }
         if (hipMemCreate(&hc, ARENA_CHUNK * 4, &prop, 0) != hipSuccess) { (void)hipMemRelease(hk); (void)hipGetLastError(); return ctx->fail(SIMKA_ERR_NOMEM, "the solid-spectrum arena cannot grow beyond %llu records (device memory exhausted)", (unsigned long long)at); }
-        HIPCHK(hipMemMap((char *)ctx->d_solid_keys + at * 8, ARENA_CHUNK * 8, 0, hk, 0));
-        HIPCHK(hipMemMap((char *)ctx->d_solid_counts + at * 4, ARENA_CHUNK * 4, 0, hc, 0));
-        HIPCHK(hipMemSetAccess((char *)ctx->d_solid_keys + at * 8, ARENA_CHUNK * 8, &acc, 1));
-        HIPCHK(hipMemSetAccess((char *)ctx->d_solid_counts + at * 4, ARENA_CHUNK * 4, &acc, 1));
+        // (a failure after hipMemCreate must not leak the handles: undo this chunk, keep the chunks before it)
+        hipError_t me = hipMemMap((char *)ctx->d_solid_keys + at * 8, ARENA_CHUNK * 8, 0, hk, 0);
+        bool mk = me == hipSuccess, mc = false;
+        if (mk) { me = hipMemMap((char *)ctx->d_solid_counts + at * 4, ARENA_CHUNK * 4, 0, hc, 0); mc = me == hipSuccess; }
+        if (mc) me = hipMemSetAccess((char *)ctx->d_solid_keys + at * 8, ARENA_CHUNK * 8, &acc, 1);
+        if (mc && me == hipSuccess) me = hipMemSetAccess((char *)ctx->d_solid_counts + at * 4, ARENA_CHUNK * 4, &acc, 1);
+        if (me != hipSuccess) {
+            if (mk) (void)hipMemUnmap((char *)ctx->d_solid_keys + at * 8, ARENA_CHUNK * 8);
+            if (mc) (void)hipMemUnmap((char *)ctx->d_solid_counts + at * 4, ARENA_CHUNK * 4);
+            (void)hipMemRelease(hk); (void)hipMemRelease(hc); (void)hipGetLastError();
+            return ctx->fail(SIMKA_ERR_HIP, "mapping chunk %llu of the solid-spectrum arena failed: %s", (unsigned long long)(at / ARENA_CHUNK), hipGetErrorString(me));
+        }
         ctx->arena_hk.push_back(hk); ctx->arena_hc.push_back(hc);
         ctx->arena_mapped = at + ARENA_CHUNK;
     }

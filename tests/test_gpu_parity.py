@@ -1293,6 +1293,23 @@ def test_bench_n_ranks_on_one_gpu_over_gloo(gpu_required, ranks):
         assert many["config"][key] == one["config"][key]
 
 
+@pytest.mark.parametrize("how", ["raise", "hang"])
+def test_bench_keeps_the_line_of_one_decomposition_when_the_other_fails(gpu_required, how):
+    """First-contact safety of `bench.py --gpus N` (no multi-GPU box has run the exchange yet): the second decomposition failing --
+    an exception, or a hang cut by the watchdog -- still leaves ONE bench line, from the decomposition that ran, with the failure named."""
+    import json
+    import subprocess
+    import sys
+    env = dict(os.environ, SIMKA_BENCH_BACKEND="gloo", SIMKA_BENCH_FAIL_MODE="sample", SIMKA_BENCH_FAIL_HOW=how, SIMKA_BENCH_MODE_TIMEOUT="20")
+    r = subprocess.run([sys.executable, os.path.join(ROOT_DIR, "bench.py"), "--gpus", "2", "--workload", "c2", "--reads", "100000", "--steps", "1",
+                        "--warmup", "1", "--no-cpu-baseline", "--no-e2e", "--no-two-streams"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600, env=env)
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, (r.returncode, r.stdout[-500:], r.stderr[-1500:])
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and set(d["decompositions"]) == {"partition"} and d["value"] > 0
+    assert "sample" in json.dumps(d["decomposition_failures"])
+
+
 def _stats_via_host_and_device(files_per_sample, k, amin=1):
     """the same samples once through the host parser (read_sequences + simka_pack_read) and once through simka_ingest_*"""
     import simka_amd
