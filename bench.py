@@ -122,59 +122,137 @@ def cpu_baseline(wl, lib, torch, dev, seconds_budget=15.0):
             "seconds": dt}
 
 
+def _gz_member(b):
+    import zlib
+    c = zlib.compressobj(1, zlib.DEFLATED, 31)
+    return c.compress(b) + c.flush()
+
+
 def e2e_from_fasta(wl, lib, torch, dev, max_samples=100, max_reads=1_000_000):
-    """t_e2e of SURVEY 8(d): FASTA files on disk -> distance-matrix CSVs through the C++ `simka` driver (files read into pinned memory,
-    text parsed on the GPU -- simka_ingest_* --, count, merge, matrices, gz CSVs), on a BOUNDED sample of the workload: the same
-    generator at a tenth of the read depth (c3: 100 samples x 1M x 150 bp = 15.4 GB of FASTA).  Every sample gets its own file when
-    the temp directory has room for them (else 10 distinct files, each listed by several samples: the driver reads, parses and counts
-    every listed file either way).  Run twice (the second run has the files in the page cache), and once with -host-parse."""
+    """t_e2e of SURVEY 8(d): sequence files on disk -> distance-matrix CSVs through the C++ `simka` driver (process start, files read into
+    pinned memory, text parsed on the GPU -- simka_ingest_* --, count, merge, matrices, gz CSVs written), three legs:
+      * `tenth`: the workload at a tenth of its read depth (c3: 100 samples x 1M x 150 bp = 15.4 GB of FASTA, one file per sample when the
+        temp directory has room); run twice (the second run has the files in the page cache) and once with -host-parse;
+      * `full_depth`: the workload's own depth -- 10 distinct files, each listed by a tenth of the samples (the driver reads, parses and
+        counts every listed file; the box's temp space holds 15 GB, not the 154 GB of c3) -- the largest depth this box allows;
+      * `fastq_gz`: the tenth-depth reads as .fastq.gz (what real metagenomes look like): gzip goes through the host parser
+        (inflate + parse + 2-bit pack on the driver's worker threads).
+    The top-level keys (ms, fasta_GBps ...) are the `tenth` leg's, as in round 3."""
+    import multiprocessing
     import shutil
     import subprocess
     import tempfile
     from simka_amd import build as b
-    n, R, L, k = min(wl["n"], max_samples), min(wl["reads"], max_reads), wl["L"], wl["k"]
+    n, L, k = min(wl["n"], max_samples), wl["L"], wl["k"]
     d = tempfile.mkdtemp(prefix="simka_e2e_")
-    try:
-        per_file = R * (L + 4)
-        free = shutil.disk_usage(d).free
-        D = n if free > 2.5 * n * per_file else min(n, 10)
+    lut = torch.tensor([ord(c) for c in "ACTG"], dtype=torch.uint8, device=dev)
+    sh = torch.arange(32, device=dev, dtype=torch.int64) * 2
+
+    def ascii_reads(t, R):
+        w = t[: (R * L + 31) // 32]
+        out = torch.empty((R, L), dtype=torch.uint8, device=dev)
+        step = 1 << 20                                        # reads per slice: the 8-byte codes of a slice stay below 2 GB
+        for r0 in range(0, R, step):
+            r1 = min(R, r0 + step)
+            ws = w[(r0 * L) // 32: (r1 * L + 31) // 32 + 1]
+            codes = ((ws[:, None] >> sh[None, :]) & 3).reshape(-1)
+            o0 = r0 * L - ((r0 * L) // 32) * 32
+            out[r0:r1] = lut[codes[o0: o0 + (r1 - r0) * L]].reshape(r1 - r0, L)
+            del codes
+        return out
+
+    def write_files(R, D, kind, tag):
+        """D distinct files of R reads each; kind: fasta | fastq_gz.  Returns their paths."""
         sub = dict(wl, n=D, reads=R)
         _, reads = gen_device_samples(lib, torch, sub, dev)
-        lut = torch.tensor([ord(c) for c in "ACTG"], dtype=torch.uint8, device=dev)
-        sh = torch.arange(32, device=dev, dtype=torch.int64) * 2
+        paths = []
+        pool = multiprocessing.Pool(min(64, os.cpu_count() or 1)) if kind == "fastq_gz" else None
         for s in range(D):
-            w = reads[s][: (R * L + 31) // 32]
-            codes = ((w[:, None] >> sh[None, :]) & 3).reshape(-1)[: R * L]
-            rec = torch.empty((R, L + 4), dtype=torch.uint8, device=dev)          # ">r\n" + read + "\n"
-            rec[:, 0] = ord(">"); rec[:, 1] = ord("r"); rec[:, 2] = ord("\n"); rec[:, 3:3 + L] = lut[codes].reshape(R, L); rec[:, 3 + L] = ord("\n")
-            rec.cpu().numpy().tofile(os.path.join(d, "s%d.fasta" % s))
+            asc = ascii_reads(reads[s], R)
             reads[s] = None
-            del codes, rec, w
+            if kind == "fasta":
+                rec = torch.empty((R, L + 4), dtype=torch.uint8, device=dev)          # ">r\n" + read + "\n"
+                rec[:, 0] = ord(">"); rec[:, 1] = ord("r"); rec[:, 2] = ord("\n"); rec[:, 3:3 + L] = asc; rec[:, 3 + L] = ord("\n")
+                path = os.path.join(d, "%s%d.fasta" % (tag, s))
+                rec.cpu().numpy().tofile(path)
+            else:
+                rec = torch.empty((R, 2 * L + 7), dtype=torch.uint8, device=dev)      # "@r\n" + read + "\n+\n" + qualities + "\n"
+                rec[:, 0] = ord("@"); rec[:, 1] = ord("r"); rec[:, 2] = ord("\n"); rec[:, 3:3 + L] = asc
+                rec[:, 3 + L] = ord("\n"); rec[:, 4 + L] = ord("+"); rec[:, 5 + L] = ord("\n"); rec[:, 6 + L: 6 + 2 * L] = ord("I"); rec[:, 6 + 2 * L] = ord("\n")
+                raw = rec.cpu().numpy()
+                rows = max(1, R // 64)
+                parts = pool.map(_gz_member, [raw[r0: r0 + rows].tobytes() for r0 in range(0, R, rows)])      # concatenated gzip members
+                path = os.path.join(d, "%s%d.fastq.gz" % (tag, s))
+                with open(path, "wb") as f:
+                    for m in parts:
+                        f.write(m)
+            paths.append(path)
+            del asc, rec
+        if pool is not None:
+            pool.close()
         del reads
         torch.cuda.empty_cache()
-        open(os.path.join(d, "in.txt"), "w").write("".join("S%d: %s\n" % (s, os.path.join(d, "s%d.fasta" % (s % D))) for s in range(n)))
-        size = sum(os.path.getsize(os.path.join(d, "s%d.fasta" % (s % D))) for s in range(n))
-        cmd = [b.CLI_PATH, "-in", os.path.join(d, "in.txt"), "-out", os.path.join(d, "out"), "-out-tmp", os.path.join(d, "tmp"),
+        return paths
+
+    def driver(paths, tag, extra=()):
+        inp = os.path.join(d, "in_%s.txt" % tag)
+        open(inp, "w").write("".join("S%d: %s\n" % (s, paths[s % len(paths)]) for s in range(n)))
+        size = sum(os.path.getsize(paths[s % len(paths)]) for s in range(n))
+        cmd = [b.CLI_PATH, "-in", inp, "-out", os.path.join(d, "out_" + tag), "-out-tmp", os.path.join(d, "tmp_" + tag),
                "-kmer-size", str(k), "-abundance-min", str(wl["amin"]), "-max-reads", "-1", "-verbose", "0"]
         if wl["simple"]:
             cmd.append("-simple-dist")
         if wl.get("complex"):
             cmd.append("-complex-dist")
+        t = time.perf_counter()
+        r = subprocess.run(cmd + list(extra), stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+        dt = (time.perf_counter() - t) * 1e3
+        if r.returncode != 0:
+            raise RuntimeError(r.stdout[-400:])
+        shutil.rmtree(os.path.join(d, "out_" + tag), ignore_errors=True)
+        return dt, size
 
-        def run(extra):
-            t = time.perf_counter()
-            r = subprocess.run(cmd + extra, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
-            dt = (time.perf_counter() - t) * 1e3
-            if r.returncode != 0:
-                raise RuntimeError(r.stdout[-400:])
-            return dt
-        ts = [run([]), run([])]
-        t_host = run(["-host-parse"])
+    try:
+        R = min(wl["reads"], max_reads)
+        per_file = R * (L + 4)
+        free = shutil.disk_usage(d).free
+        D = n if free > 2.5 * n * per_file else min(n, 10)
+        paths = write_files(R, D, "fasta", "s")
+        ts = [driver(paths, "tenth")[0], driver(paths, "tenth")[0]]
+        t_host, size = driver(paths, "tenth", ["-host-parse"])
         occ = float(n) * R * (L - k + 1)
-        return {"ms": min(ts), "ms_first_run": ts[0], "ms_host_parse": t_host, "fasta_bytes": size, "fasta_GBps": size / (min(ts) * 1e-3) / 1e9,
-                "kmer_occurrences_per_s": occ / (min(ts) * 1e-3),
-                "sample": "%d samples x %d reads x %d bp as FASTA files (%d distinct files, %.1f GB listed), k=%d, `simka` driver process start to CSVs "
-                          "written; text parsed on the GPU (ms_host_parse: the same run with -host-parse)" % (n, R, L, D, size / 1e9, k)}
+        out = {"ms": min(ts), "ms_first_run": ts[0], "ms_host_parse": t_host, "fasta_bytes": size, "fasta_GBps": size / (min(ts) * 1e-3) / 1e9,
+               "kmer_occurrences_per_s": occ / (min(ts) * 1e-3),
+               "sample": "%d samples x %d reads x %d bp as FASTA files (%d distinct files, %.1f GB listed), k=%d, `simka` driver process start to CSVs "
+                         "written; text parsed on the GPU (ms_host_parse: the same run with -host-parse)" % (n, R, L, D, size / 1e9, k)}
+        for p_ in paths:
+            os.remove(p_)
+        try:        # the tenth-depth reads as .fastq.gz, 10 distinct files
+            gz = write_files(R, min(n, 10), "fastq_gz", "q")
+            tg = [driver(gz, "gz")[0], driver(gz, "gz")[0]]
+            gsize = sum(os.path.getsize(gz[s % len(gz)]) for s in range(n))
+            out["fastq_gz"] = {"ms": min(tg), "gz_bytes": gsize, "text_bytes": float(n) * R * (2 * L + 7), "text_GBps": float(n) * R * (2 * L + 7) / (min(tg) * 1e-3) / 1e9,
+                               "kmer_occurrences_per_s": occ / (min(tg) * 1e-3),
+                               "sample": "%d samples x %d reads x %d bp as .fastq.gz (%d distinct files, %.2f GB of gzip listed): inflated, parsed and packed by the driver's worker threads" % (n, R, L, len(gz), gsize / 1e9)}
+            for p_ in gz:
+                os.remove(p_)
+        except Exception as e:
+            out["fastq_gz"] = {"ms": None, "sample": "failed: %r" % (e,)}
+        try:        # the workload's own depth, 10 distinct files
+            Rf, Df = wl["reads"], min(n, 10)
+            if Rf > R and shutil.disk_usage(d).free > 1.3 * Df * Rf * (L + 4):
+                full = write_files(Rf, Df, "fasta", "f")
+                tf = [driver(full, "full")[0], driver(full, "full")[0]]
+                fsize = sum(os.path.getsize(full[s % len(full)]) for s in range(n))
+                out["full_depth"] = {"ms": min(tf), "ms_first_run": tf[0], "fasta_bytes": fsize, "fasta_GBps": fsize / (min(tf) * 1e-3) / 1e9,
+                                     "kmer_occurrences_per_s": float(n) * Rf * (L - k + 1) / (min(tf) * 1e-3),
+                                     "sample": "%d samples x %d reads x %d bp (the workload's own depth): %d distinct FASTA files, each listed by %d samples -- %.0f GB listed, "
+                                               "read from the page cache; the largest depth the temp space of this box allows" % (n, Rf, L, Df, n // Df, fsize / 1e9)}
+            else:
+                out["full_depth"] = {"ms": None, "sample": "skipped: not enough temp space (or the workload is already at this depth)"}
+        except Exception as e:
+            out["full_depth"] = {"ms": None, "sample": "failed: %r" % (e,)}
+        return out
     finally:
         shutil.rmtree(d, ignore_errors=True)
 
@@ -195,6 +273,7 @@ def main():
                     "a rocprofv3 trace of the same command; the two-stream step is reported as timing.step_ms_two_streams")
     ap.add_argument("--no-two-streams", action="store_true", help="skip the untimed two-stream pass (timing.step_ms_two_streams)")
     ap.add_argument("--no-e2e", action="store_true", help="skip the FASTA -> CSV leg (timing.e2e_from_fasta)")
+    ap.add_argument("--no-from-host", action="store_true", help="skip the step that starts from pinned HOST memory (timing.step_ms_from_host)")
     ap.add_argument("--prof-steps", type=int, default=3, help="steps of the untimed pass that times every kernel (0 = as many as --steps)")
     ap.add_argument("--log2-partitions", type=int, default=0)
     ap.add_argument("--offsets", action="store_true", help="hand the reads over with an offsets array (variable-length layout, what the "
@@ -522,13 +601,57 @@ def main():
             if rank == 0:
                 print(json.dumps(out), flush=True)
             return
+        if world == 1 and not args.no_from_host and not args.offsets:
+            # the same step with the packed reads in PINNED HOST memory: simka_count_sample(on_device = 0) copies sample i + 1 through the
+            # copy stream into its lane's staging buffer while the kernels of sample i run on the other lane (library default: two lanes).
+            # Never `value` (inputs resident in HBM there); done = within 5 % of step_ms
+            try:
+                ctx.close(); best["ctx"] = None
+                os.environ["SIMKA_LANES"] = "2"
+                nw_ = (nb_bases + 31) // 32 + 2
+                t_pin = time.perf_counter()
+                host = []
+                for s_ in range(n):
+                    hbuf = torch.empty(nw_, dtype=torch.int64).pin_memory()
+                    hbuf.copy_(reads[s_][:nw_])
+                    host.append(hbuf)
+                torch.cuda.synchronize()
+                t_pin = time.perf_counter() - t_pin
+                hctx = simka_amd.SimkaContext(n, kmer_size=k, abundance_min=wl["amin"], simple_dist=wl["simple"], complex_dist=wl.get("complex", False),
+                                              device=local, max_kmers_per_sample=kocc_per_sample, log2_partitions=args.log2_partitions)
+
+                def host_step():
+                    hctx.reset()
+                    for s_ in range(n):
+                        hctx.count_sample(s_, host[s_].data_ptr(), nb_bases, R, fixed_len=L, on_device=False, host_pointer=True)
+                    hctx.merge()
+                    return hctx.stats().matrices()
+                host_step()
+                torch.cuda.synchronize(); t0_ = time.perf_counter()
+                reps_ = 2
+                for _ in range(reps_):
+                    hm_ = host_step()
+                torch.cuda.synchronize()
+                t_host = (time.perf_counter() - t0_) / reps_ * 1e3
+                out["timing"]["step_ms_from_host"] = t_host
+                out["timing"]["step_from_host_over_step"] = t_host / ms_per_step
+                out["timing"]["step_from_host_note"] = ("packed reads in pinned host memory (%.1f GB, pinned + filled in %.1f s, untimed), H2D on the copy stream under the "
+                                                        "other lane's kernels; matrices %s the device-resident step's" % (n * nw_ * 8 / 1e9, t_pin, "equal" if checksum(hm_) == out["config"]["matrix_checksum"] else "DIFFER FROM"))
+                hctx.close()
+                del host
+                ctx = None
+            except Exception as e:
+                out["timing"]["step_ms_from_host"] = None
+                out["timing"]["step_from_host_note"] = "failed: %r" % (e,)
+                ctx = None
         if rank == 0 and world == 1 and not args.no_cpu_baseline:
             try:
                 out["cpu_baseline"] = cpu_baseline(wl, lib, torch, dev)
             except Exception as e:       # the baseline is a report, never a reason to lose the GPU number
                 out["cpu_baseline"] = {"value": None, "unit": "distinct k-mers/s", "cores": os.cpu_count(), "kind": "port",
                                        "sample": "failed: %r" % (e,)}
-        ctx.close()
+        if ctx is not None:
+            ctx.close()
         if rank == 0 and world == 1 and not args.no_e2e and not args.no_cpu_baseline:
             try:
                 out["timing"]["e2e_from_fasta"] = e2e_from_fasta(wl, lib, torch, dev)

@@ -373,10 +373,11 @@ class SimkaContext:
         self._check(self.lib.simka_ingest_count(self.h, index, C.byref(nb), C.byref(nr)))
         return nb.value, nr.value
 
-    def count_sample(self, index, packed, nb_bases, nb_reads, fixed_len=0, offsets=None, on_device=False, nb_input_reads=0):
-        """`packed`/`offsets`: numpy uint64 arrays (host) or integer device pointers (on_device=True)."""
+    def count_sample(self, index, packed, nb_bases, nb_reads, fixed_len=0, offsets=None, on_device=False, nb_input_reads=0, host_pointer=False):
+        """`packed`/`offsets`: numpy uint64 arrays (host), integer device pointers (on_device=True) or integer HOST pointers
+        (host_pointer=True: e.g. pinned buffers of simka_host_alloc / torch pin_memory)."""
         r = Reads()
-        if on_device:
+        if on_device or host_pointer:
             r.packed = int(packed)
             r.offsets = int(offsets) if offsets is not None else None
         else:
