@@ -56,6 +56,9 @@ WORKLOADS = {
     # BASELINE.json configs[4] shape at 1/50 read depth: the tiled (N > LDS tile) pair accumulator + -complex-dist
     "c5_50": dict(n=500, reads=100_000, L=150, k=31, amin=2, simple=True, complex=True,
                   desc="500 samples x 100k 150 bp reads (C5 at 1/50 read depth), k=31, -simple-dist -complex-dist"),
+    # BASELINE.json configs[4] shape at 1/5 read depth (500 x 1M reads: 19 GB of packed reads + 47 GB of solid spectra fit one GPU)
+    "c5_5": dict(n=500, reads=1_000_000, L=150, k=31, amin=2, simple=True, complex=True,
+                 desc="500 samples x 1M 150 bp reads (C5 at 1/5 read depth), k=31, -simple-dist -complex-dist"),
 }
 
 

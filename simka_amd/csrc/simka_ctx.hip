@@ -1696,7 +1696,7 @@ static void pair_setup(simka_ctx *ctx, PairLaunch &pl, bool legacy_layout = fals
     // LDS of k_pairs: head | packed cells | ent | (complex: p, p ln p, tile N table) | gdesc | gpref | tmp | (tiled: gdescB, epre, idxA, idxB)
     // The span capacity EC (entries staged per iteration) takes what the cells leave: longer spans amortise the per-span cost.
     const bool cplx = pc.nacc64 != 0;
-    auto lds_single = [&](size_t ec) { return SIMKA_LDS_HEAD + ec * 8 + (cplx ? ec * 16 + SIMKA_PAIR_TN * 8 : 0) + (ec / 2) * 4 + (ec / 2 + 2) * 4 + 32 * 4 + 64; };
+    auto lds_single = [&](size_t ec) { return SIMKA_LDS_HEAD + ec * 8 + (cplx ? ec * 16 + SIMKA_PAIR_TN * 16 + SIMKA_LNTAB * 16 : 0) + (ec / 2) * 4 + (ec / 2 + 2) * 4 + 32 * 4 + 64; };
     // tiled: + gdescB + (scan-and-compact kernel: flag scan, two index lists | tile-major kernel: the two run tables)
     const bool tm_layout = !legacy_layout && tile_major_enabled();
     auto lds_tiled = [&](size_t ec) { return lds_single(ec) + (ec / 2) * 4 + (tm_layout ? (ec / 2) * 8 + 2 * sizeof(KtmRange) + 64 /* range tables */ : (ec + 2) * 4 + ec * 4); };

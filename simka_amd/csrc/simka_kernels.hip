@@ -533,6 +533,97 @@ __device__ __forceinline__ uint32_t pair_isqrt(ull x) {
     return r;
 }
 
+// ---- -complex-dist, both-present pairs: the two terms that cost the pair loop most, priced down (C5's shape, 500 samples: the
+// pair kernel is 72 percent of the step and the complex terms were 54 percent of it)
+// natural logarithm of a positive normal double from a 64-entry table of (1 / c, ln c), c = 1 + (i + 1/2) / 64, and a degree-6
+// polynomial in r = m / c - 1, |r| < 2^-7: absolute error below 1e-15 (the remainder r^7 / 7 is 2.5e-16) -- the library log is
+// correctly rounded with three times the instructions; the KL sums are kept in 2^-60 fixed point and compared to 1e-9 relative.
+#define SIMKA_LNTAB 64
+__device__ const double2 g_simka_lntab[SIMKA_LNTAB] = {
+    { 0x1.fc07f01fc07f0p-1, 0x1.fe02a6b106789p-8 },
+    { 0x1.f44659e4a4271p-1, 0x1.7b91b07d5b11bp-6 },
+    { 0x1.ecc07b301ecc0p-1, 0x1.39e87b9febd60p-5 },
+    { 0x1.e573ac901e574p-1, 0x1.b42dd711971bfp-5 },
+    { 0x1.de5d6e3f8868ap-1, 0x1.16536eea37ae1p-4 },
+    { 0x1.d77b654b82c34p-1, 0x1.51b073f06183fp-4 },
+    { 0x1.d0cb58f6ec074p-1, 0x1.8c345d6319b21p-4 },
+    { 0x1.ca4b3055ee191p-1, 0x1.c5e548f5bc743p-4 },
+    { 0x1.c3f8f01c3f8f0p-1, 0x1.fec9131dbeabbp-4 },
+    { 0x1.bdd2b899406f7p-1, 0x1.1b72ad52f67a0p-3 },
+    { 0x1.b7d6c3dda338bp-1, 0x1.371fc201e8f74p-3 },
+    { 0x1.b2036406c80d9p-1, 0x1.526e5e3a1b438p-3 },
+    { 0x1.ac5701ac5701bp-1, 0x1.6d60fe719d21dp-3 },
+    { 0x1.a6d01a6d01a6dp-1, 0x1.87fa06520c911p-3 },
+    { 0x1.a16d3f97a4b02p-1, 0x1.a23bc1fe2b563p-3 },
+    { 0x1.9c2d14ee4a102p-1, 0x1.bc286742d8cd6p-3 },
+    { 0x1.970e4f80cb872p-1, 0x1.d5c216b4fbb91p-3 },
+    { 0x1.920fb49d0e229p-1, 0x1.ef0adcbdc5936p-3 },
+    { 0x1.8d3018d3018d3p-1, 0x1.0402594b4d041p-2 },
+    { 0x1.886e5f0abb04ap-1, 0x1.1058bf9ae4ad5p-2 },
+    { 0x1.83c977ab2beddp-1, 0x1.1c898c16999fbp-2 },
+    { 0x1.7f405fd017f40p-1, 0x1.2895a13de86a3p-2 },
+    { 0x1.7ad2208e0ecc3p-1, 0x1.347dd9a987d55p-2 },
+    { 0x1.767dce434a9b1p-1, 0x1.404308686a7e4p-2 },
+    { 0x1.724287f46debcp-1, 0x1.4be5f957778a1p-2 },
+    { 0x1.6e1f76b4337c7p-1, 0x1.5767717455a6cp-2 },
+    { 0x1.6a13cd1537290p-1, 0x1.62c82f2b9c795p-2 },
+    { 0x1.661ec6a5122f9p-1, 0x1.6e08eaa2ba1e4p-2 },
+    { 0x1.623fa77016240p-1, 0x1.792a55fdd47a2p-2 },
+    { 0x1.5e75bb8d015e7p-1, 0x1.842d1da1e8b17p-2 },
+    { 0x1.5ac056b015ac0p-1, 0x1.8f11e873662c7p-2 },
+    { 0x1.571ed3c506b3ap-1, 0x1.99d958117e08bp-2 },
+    { 0x1.5390948f40febp-1, 0x1.a484090e5bb0ap-2 },
+    { 0x1.5015015015015p-1, 0x1.af1293247786bp-2 },
+    { 0x1.4cab88725af6ep-1, 0x1.b9858969310fbp-2 },
+    { 0x1.49539e3b2d067p-1, 0x1.c3dd7a7cdad4dp-2 },
+    { 0x1.460cbc7f5cf9ap-1, 0x1.ce1af0b85f3ebp-2 },
+    { 0x1.42d6625d51f87p-1, 0x1.d83e7258a2f3ep-2 },
+    { 0x1.3fb013fb013fbp-1, 0x1.e24881a7c6c26p-2 },
+    { 0x1.3c995a47babe7p-1, 0x1.ec399d2468cc0p-2 },
+    { 0x1.3991c2c187f63p-1, 0x1.f6123fa7028acp-2 },
+    { 0x1.3698df3de0748p-1, 0x1.ffd2e0857f498p-2 },
+    { 0x1.33ae45b57bcb2p-1, 0x1.04bdf9da926d2p-1 },
+    { 0x1.30d190130d190p-1, 0x1.0986f4f573521p-1 },
+    { 0x1.2e025c04b8097p-1, 0x1.0e44985d1cc8cp-1 },
+    { 0x1.2b404ad012b40p-1, 0x1.12f719593efbcp-1 },
+    { 0x1.288b01288b013p-1, 0x1.179eabbd899a1p-1 },
+    { 0x1.25e22708092f1p-1, 0x1.1c3b81f713c25p-1 },
+    { 0x1.23456789abcdfp-1, 0x1.20cdcd192ab6ep-1 },
+    { 0x1.20b470c67c0d9p-1, 0x1.2555bce98f7cbp-1 },
+    { 0x1.1e2ef3b3fb874p-1, 0x1.29d37fec2b08bp-1 },
+    { 0x1.1bb4a4046ed29p-1, 0x1.2e47436e40268p-1 },
+    { 0x1.19453808ca29cp-1, 0x1.32b1339121d71p-1 },
+    { 0x1.16e0689427379p-1, 0x1.37117b54747b6p-1 },
+    { 0x1.1485f0e0acd3bp-1, 0x1.3b68449fffc23p-1 },
+    { 0x1.12358e75d3033p-1, 0x1.3fb5b84d16f42p-1 },
+    { 0x1.0fef010fef011p-1, 0x1.43f9fe2f9ce67p-1 },
+    { 0x1.0db20a88f4696p-1, 0x1.48353d1ea88dfp-1 },
+    { 0x1.0b7e6ec259dc8p-1, 0x1.4c679afccee3ap-1 },
+    { 0x1.0953f39010954p-1, 0x1.50913cc01686bp-1 },
+    { 0x1.073260a47f7c6p-1, 0x1.54b2467999498p-1 },
+    { 0x1.05197f7d73404p-1, 0x1.58cadb5cd7989p-1 },
+    { 0x1.03091b51f5e1ap-1, 0x1.5cdb1dc6c1765p-1 },
+    { 0x1.0101010101010p-1, 0x1.60e32f44788d9p-1 }
+};
+__device__ __forceinline__ double simka_fast_ln(double h, const double2 *tab) {
+    const long long b = __double_as_longlong(h);
+    const int e = (int)((b >> 52) & 0x7ff) - 1023;
+    const double m = __longlong_as_double((b & 0x000fffffffffffffll) | 0x3ff0000000000000ll);
+    const double2 t = tab[(uint32_t)(b >> 46) & (SIMKA_LNTAB - 1u)];
+    const double r = fma(m, t.x, -1.0);
+    double q = -1.0 / 6.0;
+    q = fma(q, r, 0.2); q = fma(q, r, -0.25); q = fma(q, r, 1.0 / 3.0); q = fma(q, r, -0.5); q = fma(q, r, 1.0);
+    return fma((double)e, 0.69314718055994530942, fma(q, r, t.y));
+}
+// Whittaker, both-present part: |(int)(u64)(ci Nj) - (u64)(cj Ni)| - |..(ci Nj)| - |..(cj Ni)| with the reference's products in double
+// (ref: src/core/SimkaAlgorithm.hpp:477-481).  A product below 2^53 is exact in double, so it IS the integer product (two 32 x 32
+// multiplies instead of two conversions, a double multiply and the emulated double -> u64 conversion); beyond, the double path.
+__device__ __forceinline__ ull simka_whit_term(uint32_t ci, uint32_t cj, ull ni, ull nj, double dni, double dnj) {
+    ull uX = (ull)ci * nj, uY = (ull)cj * ni;
+    if (((ni | nj) >> 32) || ((uX | uY) >> 53)) { uX = (ull)((double)ci * dnj); uY = (ull)((double)cj * dni); }
+    return simka_whit_abs(uX - uY) - simka_whit_abs(uX) - simka_whit_abs(uY);
+}
+
 // LDS cells of the 32-bit accumulators are PACKED two per u64 -- (S_ij | S_ji<<32), (a | bc<<32), (chord | hell<<32) --
 // so one non-returning ds_add_u64 feeds two accumulators.  Every half stays < 2^32 between flushes (`bound`), so the
 // low half never carries into the high one.
@@ -600,10 +691,12 @@ k_pairs(const SimkaSpan *spans, const ull *cursors, const ull *entries, const ui
     // a span holds <= EC = pc.span_cap entries in <= GC = EC/2 groups (every group has >= 2 entries)
     const uint32_t EC = pc.span_cap, GC = EC / 2u;
     ull *ent = c64 + (size_t)pc.nacc64 * CP;                     // [EC]          (sample<<32 | count)
-    double *ep = (double *)(ent + EC);                           // [EC]          complex: p = c / N_sample
-    double *eplp = ep + (cplx ? EC : 0);                         // [EC]          complex: p * ln p
+    double2 *epp = (double2 *)(ent + EC);                        // [EC]          complex: (p = c / N_sample, p ln p): one 16-byte read per entry
+    double *eplp = (double *)epp + (cplx ? EC : 0);              //               (second half of that array: the layout below counts 2 x EC doubles)
     double *tn = eplp + (cplx ? EC : 0);                         // [SIMKA_PAIR_TN] complex: N of the samples of tile I, then tile J
-    uint32_t *gdesc = (uint32_t *)(tn + (cplx ? SIMKA_PAIR_TN : 0));   // [GC]      list A of the group: (start<<16 | size)
+    ull *tnu = (ull *)(tn + (cplx ? SIMKA_PAIR_TN : 0));         // [SIMKA_PAIR_TN] complex: the same N as integers
+    double2 *lntab = (double2 *)(tnu + (cplx ? SIMKA_PAIR_TN : 0));    // [SIMKA_LNTAB] complex: simka_fast_ln
+    uint32_t *gdesc = (uint32_t *)(lntab + (cplx ? SIMKA_LNTAB : 0));   // [GC]      list A of the group: (start<<16 | size)
     uint32_t *gpref = gdesc + GC;                                // [GC+2]        pair prefix
     uint32_t *tmp = gpref + GC + 2;                              // [32]
     uint32_t *gdescB = tmp + 32;                                 // tiled: [GC]   list B of the group
@@ -624,9 +717,11 @@ k_pairs(const SimkaSpan *spans, const ull *cursors, const ull *entries, const ui
     for (uint32_t i = tid; i < npk * CP; i += K4_BLOCK) pk[i] = 0;
     for (uint32_t i = tid; i < pc.nacc64 * CP; i += K4_BLOCK) c64[i] = 0;
     if (cplx) {
+        for (uint32_t i = tid; i < SIMKA_LNTAB; i += K4_BLOCK) lntab[i] = g_simka_lntab[i];
         for (uint32_t i = tid; i < TD; i += K4_BLOCK) {
-            tn[i] = (baseI + i < N) ? (double)pc.tot_n[baseI + i] : 1.0;
-            if (rect) tn[T + i] = (baseJ + i < N) ? (double)pc.tot_n[baseJ + i] : 1.0;
+            const ull ni_ = (baseI + i < N) ? pc.tot_n[baseI + i] : 1ull;
+            tn[i] = (double)ni_; tnu[i] = ni_;
+            if (rect) { const ull nj_ = (baseJ + i < N) ? pc.tot_n[baseJ + i] : 1ull; tn[T + i] = (double)nj_; tnu[T + i] = nj_; }
         }
     }
     // every packed half is fed by NON-returning atomics and receives at most one add per group, so
@@ -705,7 +800,7 @@ k_pairs(const SimkaSpan *spans, const ull *cursors, const ull *entries, const ui
                 }
                 if (cplx && (!TILED || fl)) {
                     const double p = (double)(uint32_t)e / tn[loc];
-                    ep[i] = p; eplp[i] = p * log(p);
+                    epp[i] = make_double2(p, p * log(p));
                 }
             }
             if (i < cur.ngrp) { gdesc[i] = pre_g[q]; if (!TILED) { const uint32_t s_ = pre_g[q] & 0xffffu; gpref[i] = s_ * (s_ - 1u) / 2u; } }
@@ -825,12 +920,13 @@ k_pairs(const SimkaSpan *spans, const ull *cursors, const ull *entries, const ui
                     // the one-sided terms are closed forms of S / totals / count histograms, added on the host.
                     // KL: with p = ci/Ni, q = cj/Nj the reference's  p ln(2p/(p+q)) + q ln(2q/(p+q))  equals
                     // p ln p + q ln q - (p+q) ln((p+q)/2): one logarithm per pair, the p ln p terms are per entry.
-                    const double h = ep[ix] + ep[iy];
-                    double dd = eplp[ix] + eplp[iy] - h * log(h * 0.5);
+                    const double2 px = epp[ix], py = epp[iy];
+                    const double h = px.x + py.x;
+                    double dd = px.y + py.y - h * simka_fast_ln(h * 0.5, lntab);
                     dd = dd < 0.0 ? 0.0 : dd;            // >= 0 mathematically (Jensen); rounding noise must not drive a sum of near-identical samples negative
                     atomicAdd(&c64[1 * CP + cell], (ull)(long long)llrint(dd * SIMKA_KL_SCALE));
-                    const ull uX = (ull)((double)ci * tn[(rect ? T : 0u) + lj]), uY = (ull)((double)cj * tn[li]);
-                    atomicAdd(&c64[0 * CP + cell], simka_whit_abs(uX - uY) - simka_whit_abs(uX) - simka_whit_abs(uY));
+                    const uint32_t jn = (rect ? T : 0u) + lj;
+                    atomicAdd(&c64[0 * CP + cell], simka_whit_term(ci, cj, tnu[li], tnu[jn], tn[li], tn[jn]));
                 }
                 // next pair of the span
                 y++;
@@ -962,10 +1058,12 @@ k_pairs_tm(const SimkaSpan *spans, const ull *cursors, const ull *tm_ent, const 
     ull *c64 = pk + (size_t)npk * CP;                            // [nacc64][CP]  (whit, klfix)
     const uint32_t EC = pc.span_cap, GC = EC / 2u;
     ull *ent = c64 + (size_t)pc.nacc64 * CP;                     // [EC]          per staged span: segment I, then segment J: (g<<48 | sample<<32 | count)
-    double *ep = (double *)(ent + EC);                           // [EC]          complex: p = c / N_sample
-    double *eplp = ep + (cplx ? EC : 0);                         // [EC]          complex: p * ln p
+    double2 *epp = (double2 *)(ent + EC);                        // [EC]          complex: (p = c / N_sample, p ln p): one 16-byte read per entry
+    double *eplp = (double *)epp + (cplx ? EC : 0);              //               (second half of that array: the layout below counts 2 x EC doubles)
     double *tn = eplp + (cplx ? EC : 0);                         // [SIMKA_PAIR_TN] complex: N of the samples of tile I, then tile J
-    uint32_t *gdesc = (uint32_t *)(tn + (cplx ? SIMKA_PAIR_TN : 0));   // [GC]      run of the group in segment I: (start<<16 | size)
+    ull *tnu = (ull *)(tn + (cplx ? SIMKA_PAIR_TN : 0));         // [SIMKA_PAIR_TN] complex: the same N as integers
+    double2 *lntab = (double2 *)(tnu + (cplx ? SIMKA_PAIR_TN : 0));    // [SIMKA_LNTAB] complex: simka_fast_ln
+    uint32_t *gdesc = (uint32_t *)(lntab + (cplx ? SIMKA_LNTAB : 0));   // [GC]      run of the group in segment I: (start<<16 | size)
     uint32_t *gpref = gdesc + GC;                                // [GC+2]        pair prefix
     uint32_t *tmp = gpref + GC + 2;                              // [32]
     uint32_t *gdescB = tmp + 32;                                 // [GC]          run of the group in segment J
@@ -986,9 +1084,11 @@ k_pairs_tm(const SimkaSpan *spans, const ull *cursors, const ull *tm_ent, const 
     for (uint32_t i = tid; i < npk * CP; i += K4_BLOCK) pk[i] = 0;
     for (uint32_t i = tid; i < pc.nacc64 * CP; i += K4_BLOCK) c64[i] = 0;
     if (cplx) {
+        for (uint32_t i = tid; i < SIMKA_LNTAB; i += K4_BLOCK) lntab[i] = g_simka_lntab[i];
         for (uint32_t i = tid; i < T; i += K4_BLOCK) {
-            tn[i] = (baseI + i < N) ? (double)pc.tot_n[baseI + i] : 1.0;
-            if (rect) tn[T + i] = (baseJ + i < N) ? (double)pc.tot_n[baseJ + i] : 1.0;
+            const ull ni_ = (baseI + i < N) ? pc.tot_n[baseI + i] : 1ull;
+            tn[i] = (double)ni_; tnu[i] = ni_;
+            if (rect) { const ull nj_ = (baseJ + i < N) ? pc.tot_n[baseJ + i] : 1ull; tn[T + i] = (double)nj_; tnu[T + i] = nj_; }
         }
     }
     ull bound = 0, bound_q = 0;
@@ -1101,7 +1201,7 @@ k_pairs_tm(const SimkaSpan *spans, const ull *cursors, const ull *tm_ent, const 
         for (int q = 0; q < EPT; q++) {
             const uint32_t i = tid + (uint32_t)q * K4_BLOCK;
             cur_j[q] = pre_j[q];
-            if (i < cur.nm) { ent[i] = pre_e[q] + ((ull)CR->sl[pre_j[q]].gbase << 48); if (cplx) { ep[i] = pre_p[q].x; eplp[i] = pre_p[q].y; } }
+            if (i < cur.nm) { ent[i] = pre_e[q] + ((ull)CR->sl[pre_j[q]].gbase << 48); if (cplx) epp[i] = pre_p[q]; }
             if (i < cur.ng) { runA[i] = 0u; runB[i] = 0u; }
         }
         // the batch after this one (may lay out the next range into the other table: barriers), then issue its loads
@@ -1194,12 +1294,13 @@ k_pairs_tm(const SimkaSpan *spans, const ull *cursors, const ull *tm_ent, const 
                 }
                 if (cplx) {
                     // same arithmetic as k_pairs (ref: src/core/SimkaAlgorithm.hpp:437-446,477-481)
-                    const double h = ep[ix] + ep[iy];
-                    double dd = eplp[ix] + eplp[iy] - h * log(h * 0.5);
+                    const double2 px = epp[ix], py = epp[iy];
+                    const double h = px.x + py.x;
+                    double dd = px.y + py.y - h * simka_fast_ln(h * 0.5, lntab);
                     dd = dd < 0.0 ? 0.0 : dd;
                     atomicAdd(&c64[1 * CP + cell], (ull)(long long)llrint(dd * SIMKA_KL_SCALE));
-                    const ull uX = (ull)((double)ci * tn[(rect ? T : 0u) + lj]), uY = (ull)((double)cj * tn[li]);
-                    atomicAdd(&c64[0 * CP + cell], simka_whit_abs(uX - uY) - simka_whit_abs(uX) - simka_whit_abs(uY));
+                    const uint32_t jn = (rect ? T : 0u) + lj;
+                    atomicAdd(&c64[0 * CP + cell], simka_whit_term(ci, cj, tnu[li], tnu[jn], tn[li], tn[jn]));
                 }
                 y++;
                 if (rect ? (y == nB) : (y == nA)) {
