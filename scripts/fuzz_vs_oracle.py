@@ -13,6 +13,41 @@ np.set_printoptions(threshold=100000, linewidth=220)
 rng = np.random.default_rng(seed)
 t_end = time.time() + budget
 KS = [int(x) for x in os.environ.get("FUZZ_KS", "").split(",") if x] or [1, 2, 3, 5, 8, 11, 15, 16, 17, 21, 25, 31, 32, 33, 34, 35, 36, 37, 40, 45, 50, 51, 52, 63]
+
+
+def kl_edge_cases():
+    """The both-present KL sum of (near-)identical samples.  Reference (ref: src/core/SimkaAlgorithm.hpp:437-446,
+    src/core/SimkaDistance.cpp:1001-1007): every term p ln(2p/(p+q)) + q ln(2q/(p+q)) is computed in double and added to a long double;
+    IDENTICAL samples give terms that are exactly 0, the sum is exactly 0, and the Jensen-Shannon cell is then 1 (`if kl == 0 return 1`,
+    a quirk); NEAR-identical samples give terms of either sign around 1e-17, and a negative sum makes sqrt(kl / 2) NaN.
+    Here: every term is clamped at 0 and accumulated in 2^-60 fixed point -- identical samples cancel exactly as well (the pair loop and
+    the per-entry p ln p use the same logarithm), so that cell is 1 as in the reference; a near-identical pair can never go negative:
+    where the reference prints NaN or a value below 1e-8 out of rounding noise, this path prints a value in [0, 1e-8]."""
+    rs = np.random.default_rng(7)
+    genome = rs.integers(0, 4, size=3000)
+    base = [np.frombuffer(b"ACTG", dtype=np.uint8)[genome[st:st + 100]].tobytes() for st in rs.integers(0, 2900, size=600)]
+    extra = np.frombuffer(b"ACTG", dtype=np.uint8)[rs.integers(0, 4, size=100)].tobytes()
+    for k in (21, 31):
+        samples = [base, list(base), base + [base[0]], base + [extra]]       # 1 = 0; 2: one read twice; 3: one foreign read
+        ctx = simka_amd.SimkaContext(len(samples), kmer_size=k, abundance_min=1, simple_dist=True, complex_dist=True)
+        orc = oracle_lib.Oracle()
+        for s_, reads in enumerate(samples):
+            packed, off, nb, nfrag = simka_amd.pack_reads(reads)
+            ctx.count_sample(s_, packed, nb, len(off) - 1, offsets=off, nb_input_reads=len(reads))
+            orc.add_sample_ascii("S%d" % s_, np.frombuffer(b"".join(reads), dtype=np.uint8), np.concatenate([[0], np.cumsum([len(r) for r in reads])]).astype(np.uint64))
+        ctx.merge(); st = ctx.stats(); ctx.close()
+        orc.run(k, 1, simple=True, complex_=True)
+        iu = np.triu_indices(len(samples), 1)
+        js_ref = orc.matrix(orc.matrix_names().index("mat_abundance_jensenshannon")); js = st.matrices()["mat_abundance_jensenshannon"]
+        kl_ref, kl = orc.kl()[iu], st.pairs()["kl"]
+        for c, (i, j) in enumerate(zip(*iu)):
+            print("k=%d pair (%d,%d): kl reference % .3e  here % .3e | jensen-shannon reference %s  here %s" % (k, i, j, kl_ref[c], kl[c], js_ref[i, j], js[i, j]))
+        assert kl[0] == 0.0 and kl_ref[0] == 0.0 and js[0, 1] == 1.0 and js_ref[0, 1] == 1.0, "identical samples: KL exactly 0, Jensen-Shannon 1 (the reference's quirk)"
+        assert np.all(kl >= 0.0) and np.all(np.abs(kl - kl_ref) <= 1e-9 * np.abs(kl_ref) + 1e-13)
+        assert np.all(np.isfinite(js))
+
+
+kl_edge_cases()
 ncase = 0
 while time.time() < t_end:
     k = int(rng.choice(KS))

@@ -149,7 +149,7 @@ static double wall_now() { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &t
 template <typename F>
 static inline void launch_timed(simka_ctx *ctx, int kid, F &&f, hipStream_t st = nullptr) {
     if (!st) st = ctx->stream;
-    static const bool dbg = getenv("SIMKA_DEBUG_SYNC") != nullptr;     // synchronise after every launch, name the kernel
+    static const bool dbg = simka_test_knob("SIMKA_DEBUG_SYNC") != nullptr;     // synchronise after every launch, name the kernel
     if (dbg) {
         fprintf(stderr, "[simka] launch %s\n", KID_NAMES[kid]); fflush(stderr);
         f();
@@ -332,7 +332,7 @@ static int setup_geometry(simka_ctx *ctx, uint64_t max_kmers) {
     {   // super-k-mer pipeline: the same partition count over two levels (<= 256 level-1 buckets x <= 4096 partitions each)
         SimkaSkmCfg &sk = ctx->skm;
         sk.pb = k.pb;
-        static const uint32_t l1_env = getenv("SIMKA_SKM_L1") ? (uint32_t)atoi(getenv("SIMKA_SKM_L1")) : 8u;      // experiments
+        static const uint32_t l1_env = simka_exp_knob("SIMKA_SKM_L1") ? (uint32_t)atoi(simka_exp_knob("SIMKA_SKM_L1")) : 8u;      // experiments
         sk.l1 = std::min<uint32_t>(sk.pb, std::min<uint32_t>(l1_env, 8u));
         sk.l2 = sk.pb - sk.l1;
         if (sk.l2 > 12) return ctx->fail(SIMKA_ERR_INVALID, "log2_partitions %u is beyond the two partitioning levels", sk.pb);
@@ -344,7 +344,7 @@ static int setup_geometry(simka_ctx *ctx, uint64_t max_kmers) {
     // of neighbouring samples overlap); the default single lane keeps per-kernel timings free of overlap.
     // samples alternate between two streams with private scratch: the scan of one sample overlaps the count of another (the
     // kernels are bound by different things: c3_10 212.7 -> 181.9 ms/step); SIMKA_LANES=1 keeps per-kernel timings free of overlap
-    const uint32_t want_lanes = getenv("SIMKA_LANES") ? (uint32_t)std::max(1, atoi(getenv("SIMKA_LANES"))) : 2u;      // (read per context: bench.py profiles with one lane)
+    const uint32_t want_lanes = simka_test_knob("SIMKA_LANES") ? (uint32_t)std::max(1, atoi(simka_test_knob("SIMKA_LANES"))) : 2u;      // (read per context: bench.py profiles with one lane)
     ctx->nlanes = std::min<uint32_t>(std::min<uint32_t>(want_lanes, simka_ctx::MAX_LANES), std::max<uint32_t>(1u, c.nb_samples));
     for (uint32_t li = 0; li < ctx->nlanes; li++) {
         simka_ctx::Lane &L = ctx->lanes[li];
@@ -389,7 +389,7 @@ static int setup_geometry(simka_ctx *ctx, uint64_t max_kmers) {
         cap = std::min(want, budget);
     }
     ctx->arena_cap = cap;
-    const double tdbg0 = getenv("SIMKA_DEBUG_SYNC") ? wall_now() : 0;
+    const double tdbg0 = simka_test_knob("SIMKA_DEBUG_SYNC") ? wall_now() : 0;
     {   // reserve the range; memory comes with arena_ensure().  Without the virtual-memory API: one allocation, as before.
         std::lock_guard<std::mutex> vmm_guard(g_vmm_lock);
         void *vk = nullptr, *vc = nullptr;
@@ -397,7 +397,7 @@ static int setup_geometry(simka_ctx *ctx, uint64_t max_kmers) {
         // plain allocation on request, and whenever another context is alive on this device: chunks being mapped while another
         // context's kernels run is the pattern that faulted (root cause unknown; scripts/ubench/vmm_two_contexts.hip)
         const int dv = c.device >= 0 && c.device < 64 ? c.device : 0;
-        const bool plain = (c.flags & SIMKA_CFG_ARENA_PLAIN) || getenv("SIMKA_ARENA_MALLOC") || g_live_ctx[dv] > 1 || g_vmm_retired_bytes > ((uint64_t)1 << 45);
+        const bool plain = (c.flags & SIMKA_CFG_ARENA_PLAIN) || simka_test_knob("SIMKA_ARENA_MALLOC") || g_live_ctx[dv] > 1 || g_vmm_retired_bytes > ((uint64_t)1 << 45);
         if (!plain && hipMemAddressReserve(&vk, capr * 8, 0, nullptr, 0) == hipSuccess) {
             if (hipMemAddressReserve(&vc, capr * 4, 0, nullptr, 0) == hipSuccess) {
                 ctx->arena_vmm = true; ctx->d_solid_keys = (ull *)vk; ctx->d_solid_counts = (uint32_t *)vc; ctx->arena_reserved = capr; ctx->arena_mapped = 0;
@@ -410,9 +410,9 @@ static int setup_geometry(simka_ctx *ctx, uint64_t max_kmers) {
         }
         ctx->arena_hi = 0;
     }
-    if (getenv("SIMKA_DEBUG_SYNC")) fprintf(stderr, "[simka] arena of %llu records allocated (%.3f s)\n", (unsigned long long)cap, wall_now() - tdbg0);
+    if (simka_test_knob("SIMKA_DEBUG_SYNC")) fprintf(stderr, "[simka] arena of %llu records allocated (%.3f s)\n", (unsigned long long)cap, wall_now() - tdbg0);
     HIPCHK(hipStreamSynchronize(ctx->stream));       // the lanes' streams do not order against the main stream
-    if (getenv("SIMKA_DEBUG_SYNC")) fprintf(stderr, "[simka] geometry ready (%.3f s since the arena, %.3f s in all)\n", wall_now() - tdbg0, wall_now() - tgeo);
+    if (simka_test_knob("SIMKA_DEBUG_SYNC")) fprintf(stderr, "[simka] geometry ready (%.3f s since the arena, %.3f s in all)\n", wall_now() - tdbg0, wall_now() - tgeo);
     ctx->geometry_ready = true;
     return SIMKA_OK;
 }
@@ -422,7 +422,7 @@ SIMKA_EXPORT int simka_create(const simka_config *cfg, simka_ctx **out) {
     if (cfg->struct_size != sizeof(simka_config)) { g_create_error = "simka_create: struct_size mismatch (ABI)"; return SIMKA_ERR_INVALID; }
     if (cfg->nb_samples == 0 || cfg->nb_samples > 65535) { g_create_error = "simka_create: nb_samples must be in [1,65535]"; return SIMKA_ERR_INVALID; }
     if (cfg->kmer_size < 1 || cfg->kmer_size > 63) { g_create_error = "simka_create: kmer_size must be in [1,63]"; return SIMKA_ERR_INVALID; }
-    const bool want_wide = cfg->kmer_size > 31 || getenv("SIMKA_SORT_PATH") != nullptr;
+    const bool want_wide = cfg->kmer_size > 31 || simka_test_knob("SIMKA_SORT_PATH") != nullptr;
     if (cfg->shard_count == 0 || cfg->shard_index >= cfg->shard_count) { g_create_error = "simka_create: bad shard_index/shard_count"; return SIMKA_ERR_INVALID; }
     if (cfg->log2_subranges > 8) { g_create_error = "simka_create: log2_subranges must be <= 8"; return SIMKA_ERR_INVALID; }
     int ndev = 0;
@@ -462,7 +462,7 @@ SIMKA_EXPORT int simka_create(const simka_config *cfg, simka_ctx **out) {
         sk.mmask = (uint32_t)((1ull << (2 * sk.m)) - 1ull);
         sk.kmask = k.mask;
         sk.shard_index = cfg->shard_index; sk.shard_count = cfg->shard_count;
-    } else if (cfg->kmer_size >= 32 && cfg->kmer_size <= 51 && !getenv("SIMKA_SORT_PATH") && !getenv("SIMKA_WIDE_SORT")) {
+    } else if (cfg->kmer_size >= 32 && cfg->kmer_size <= 51 && !simka_test_knob("SIMKA_SORT_PATH") && !simka_test_knob("SIMKA_WIDE_SORT")) {
         // 32 <= k <= 51: a record (<= 51 bases) still holds a k-mer.  The minimizer is the smallest of W = 20 m-mers in the MIDDLE of
         // the k-mer: m-mers d .. d + W - 1 with 2 d = k - (W + m - 1), so that a k-mer and its reverse complement look at the same
         // m-mers (m is lowered by one where the parity demands it).
@@ -483,7 +483,7 @@ SIMKA_EXPORT int simka_create(const simka_config *cfg, simka_ctx **out) {
     const double tlds = wall_now();
     int rc = set_lds_attr(ctx);
     if (rc) return bail(rc);
-    if (getenv("SIMKA_DEBUG_SYNC")) fprintf(stderr, "[simka] kernel attributes set (%.3f s)\n", wall_now() - tlds);
+    if (simka_test_knob("SIMKA_DEBUG_SYNC")) fprintf(stderr, "[simka] kernel attributes set (%.3f s)\n", wall_now() - tlds);
     const uint32_t N = cfg->nb_samples;
     ctx->stats_n = simka_stats_nb_u64(N, cfg->dist_flags);
     auto chk = [&](hipError_t e, const char *what) { if (e != hipSuccess) { ctx->err = std::string(what) + ": " + hipGetErrorString(e); return false; } return true; };
@@ -497,7 +497,7 @@ SIMKA_EXPORT int simka_create(const simka_config *cfg, simka_ctx **out) {
     if (!chk(dev_alloc(&ctx->d_cursors, 4), "hipMalloc(cursors)")) return bail(SIMKA_ERR_NOMEM);
     if (!chk(dev_alloc(&ctx->d_work, 2), "hipMalloc(work)")) return bail(SIMKA_ERR_NOMEM);
     if (cfg->dist_flags & SIMKA_DIST_COMPLEX) {
-        ctx->ovf_cap = getenv("SIMKA_OVF_CAP") ? (uint64_t)atoll(getenv("SIMKA_OVF_CAP")) : (uint64_t)1 << 22;      // (tests shrink it)
+        ctx->ovf_cap = simka_test_knob("SIMKA_OVF_CAP") ? (uint64_t)atoll(simka_test_knob("SIMKA_OVF_CAP")) : (uint64_t)1 << 22;      // (tests shrink it)
         if (!chk(dev_alloc(&ctx->d_hist, (uint64_t)N * SIMKA_HIST_MAX), "hipMalloc(hist)")) return bail(SIMKA_ERR_NOMEM);
         if (!chk(dev_alloc(&ctx->d_ovf_list, 2 * ctx->ovf_cap), "hipMalloc(ovf)")) return bail(SIMKA_ERR_NOMEM);
         if (!chk(dev_alloc(&ctx->d_ovf_cursor, 2), "hipMalloc(ovf cursor)")) return bail(SIMKA_ERR_NOMEM);
@@ -537,7 +537,7 @@ SIMKA_EXPORT void simka_destroy(simka_ctx *ctx) {
         // chunk by chunk, mirroring the hipMemMap calls (one unmap over several mappings is not guaranteed to release them all)
         for (uint64_t at = 0; at < ctx->arena_mapped; at += ARENA_CHUNK) {
             const hipError_t e1 = hipMemUnmap((char *)ctx->d_solid_keys + at * 8, ARENA_CHUNK * 8), e2 = hipMemUnmap((char *)ctx->d_solid_counts + at * 4, ARENA_CHUNK * 4);
-            if ((e1 != hipSuccess || e2 != hipSuccess) && getenv("SIMKA_DEBUG_SYNC")) fprintf(stderr, "[simka] hipMemUnmap of arena chunk %llu failed: %s\n", (unsigned long long)(at / ARENA_CHUNK), hipGetErrorString(e1 != hipSuccess ? e1 : e2));
+            if ((e1 != hipSuccess || e2 != hipSuccess) && simka_test_knob("SIMKA_DEBUG_SYNC")) fprintf(stderr, "[simka] hipMemUnmap of arena chunk %llu failed: %s\n", (unsigned long long)(at / ARENA_CHUNK), hipGetErrorString(e1 != hipSuccess ? e1 : e2));
             (void)hipGetLastError();
         }
         for (auto h : ctx->arena_hk) (void)hipMemRelease(h);
@@ -694,7 +694,7 @@ static int skm_scan_split(simka_ctx *ctx, simka_ctx::Lane &L, uint32_t sample, c
     auto scan_lds = [&](bool) {
         return (size_t)SIMKA_LDS_HEAD + rbytes + (SKM_TILE / 16 + 8) * 4 + (SKM_BLOCK + 4) * 4 + SKM_MAXB1 * 4 * 2 + SKM_MAXB1 * 8 + (fixed ? 0 : SKM_RTAB * 4);
     };
-    static const bool no_gather = getenv("SIMKA_SKM_SPLIT") != nullptr;      // tests: the exact split instead of chunk sort + gather
+    static const bool no_gather = simka_test_knob("SIMKA_SKM_SPLIT") != nullptr;      // tests: the exact split instead of chunk sort + gather
     bool use_gather = *gather && !no_gather && L.d_cbase;
     auto layout = [&](uint32_t mode, ull capb) {
         launch_timed(ctx, KID_LAYOUT, [&] {
@@ -744,7 +744,7 @@ static int skm_scan_split(simka_ctx *ctx, simka_ctx::Lane &L, uint32_t sample, c
         scan(false, (const ull *)L.d_b1_end);
     }
     if (rec_cap >= 0xffffffffull) return ctx->fail(SIMKA_ERR_OVERFLOW, "a sample needs more than 2^32 super-k-mer record slots in one pass");
-    if (getenv("SIMKA_DEBUG_MERGE")) {
+    if (simka_exp_knob("SIMKA_DEBUG_MERGE")) {
         std::vector<ull> cnt(B1);
         HIPCHK(hipMemcpyAsync(cnt.data(), L.d_b1_count, (size_t)B1 * 8, hipMemcpyDeviceToHost, st)); HIPCHK(hipStreamSynchronize(st));
         ull mx = 0, sum = 0; for (ull c : cnt) { mx = std::max(mx, c); sum += c; }
@@ -781,7 +781,7 @@ static int run_count_kernels(simka_ctx *ctx, uint32_t sample, const SimkaScanArg
     SimkaSkmCfg sk = ctx->skm;
     if (npass > 1) { sk.shard_index = ctx->skm.shard_index + ctx->skm.shard_count * pass; sk.shard_count = ctx->skm.shard_count * npass; }
     uint32_t *flag = ctx->d_l1_ovf + sample;
-    static const bool force_exact = getenv("SIMKA_EXACT_SIZING") != nullptr;
+    static const bool force_exact = simka_test_knob("SIMKA_EXACT_SIZING") != nullptr;
     if (force_exact) exact = true;
     uint64_t kocc_up = 0;
     bool gather = true;
@@ -857,10 +857,10 @@ static int run_count_kernels(simka_ctx *ctx, uint32_t sample, const SimkaScanArg
                             (gather ? (size_t)SKM_G_BYTES(SKM_FAST_BLOCK / 64) : 64);
     const size_t lds_count = (size_t)SIMKA_LDS_HEAD + (size_t)SKM_CNT_TS * 12 + (size_t)SKM_CNT_BATCH * 16 + (size_t)SKM_CNT_BLOCK * 4 + hist_lds + (size_t)SKM_CNT_BATCH * sk.nmax * 2 + 64 +
                              (gather ? (size_t)(SKM_G_MAXCH * 10 + 32) : 0);
-    static const bool general_only = getenv("SIMKA_SKM_GENERAL") != nullptr;      // tests: every partition through the general kernel
+    static const bool general_only = simka_test_knob("SIMKA_SKM_GENERAL") != nullptr;      // tests: every partition through the general kernel
     if (!general_only)
         launch_timed(ctx, KID_SKM_COUNT, [&] {
-            static const uint32_t bpc_env = getenv("SIMKA_SKM_BPC") ? (uint32_t)atoi(getenv("SIMKA_SKM_BPC")) : 0u;     // experiments
+            static const uint32_t bpc_env = simka_exp_knob("SIMKA_SKM_BPC") ? (uint32_t)atoi(simka_exp_knob("SIMKA_SKM_BPC")) : 0u;     // experiments
             const uint32_t bpc = bpc_env ? bpc_env : (uint32_t)std::max<size_t>(1, std::min<size_t>(4, (160 * 1024) / lds_fast));
             hipLaunchKernelGGL(gather ? k_skm_count_fast<true> : k_skm_count_fast<false>, dim3((uint32_t)std::min<uint64_t>(ctx->nparts, (uint64_t)ctx->num_cus * bpc)), dim3(SKM_FAST_BLOCK), lds_fast, st,
                                src, sk, ctx->key, ctx->cfg.abundance_min, ctx->cfg.abundance_max, o, (const uint32_t *)flag, kocc,
@@ -937,7 +937,7 @@ static int wide_hash_count(simka_ctx *ctx, uint32_t sample, const void *d_packed
     if (kocc_b == 0) { *done = true; for (int i = 0; i < SIMKA_NB_TOTALS; i++) tot[i] = 0; return simka_wide_adopt(ctx->wide, sample, nullptr, nullptr, nullptr, 0, 0) ? wide_fail(ctx, 1) : SIMKA_OK; }
     // the partition count is the sample's own (the arena holds spectra, not partitions): ~100-190 k-mer occurrences per
     // partition, three eighths of a wave's table (k_skm_count_wide_fast) even if all of them are distinct
-    const uint32_t per_part = getenv("SIMKA_WIDE_PER_PART") ? (uint32_t)std::max(1, atoi(getenv("SIMKA_WIDE_PER_PART"))) : 192u;      // (tests: partitions beyond the tables)
+    const uint32_t per_part = simka_test_knob("SIMKA_WIDE_PER_PART") ? (uint32_t)std::max(1, atoi(simka_test_knob("SIMKA_WIDE_PER_PART"))) : 192u;      // (tests: partitions beyond the tables)
     sk.pb = std::min<uint32_t>(20u, ceil_log2_u64((kocc_b + per_part - 1) / per_part));
     sk.l1 = std::min<uint32_t>(sk.pb, 8u); sk.l2 = sk.pb - sk.l1;
     const uint32_t B1 = 1u << sk.l1;
@@ -960,7 +960,7 @@ static int wide_hash_count(simka_ctx *ctx, uint32_t sample, const void *d_packed
     rc = ensure_cap(ctx, &ctx->d_wh_hi, &ctx->wh_hi_cap, out_cap); if (rc) return rc;
     rc = ensure_cap(ctx, &ctx->d_wh_lo, &ctx->wh_lo_cap, out_cap); if (rc) return rc;
     rc = ensure_cap(ctx, &ctx->d_wh_cnt, &ctx->wh_cnt_cap, out_cap); if (rc) return rc;
-    static const bool force_exact = getenv("SIMKA_EXACT_SIZING") != nullptr;
+    static const bool force_exact = simka_test_knob("SIMKA_EXACT_SIZING") != nullptr;
     ull ovf_before[2] = { 0, 0 };
     if (ctx->d_ovf_cursor) { HIPCHK(hipMemcpyAsync(ovf_before, ctx->d_ovf_cursor, 16, hipMemcpyDeviceToHost, st)); HIPCHK(hipStreamSynchronize(st)); }
     for (int attempt = force_exact ? 1 : 0; attempt < 2; attempt++) {
@@ -990,7 +990,7 @@ static int wide_hash_count(simka_ctx *ctx, uint32_t sample, const void *d_packed
             o.phase = d_phase;
         }
 #endif
-        const bool general_only = getenv("SIMKA_SKM_GENERAL") != nullptr;      // tests: every partition through the block kernel
+        const bool general_only = simka_test_knob("SIMKA_SKM_GENERAL") != nullptr;      // tests: every partition through the block kernel
         if (!general_only)
             launch_timed(ctx, KID_SKM_COUNT, [&] {
                 const size_t lds_wf = (size_t)SIMKA_LDS_HEAD + hist_lds + (size_t)(SKM_WF_BLOCK / 64) * skm_wf_wave_bytes(sk.nmax);
@@ -1107,7 +1107,7 @@ SIMKA_EXPORT int simka_count_sample(simka_ctx *ctx, uint32_t sample, const simka
     // a third of the device is counted in several passes over its reads, each keeping a subset of the level-1 buckets.
     uint32_t npass = 1;
     {
-        static const char *force = getenv("SIMKA_FORCE_PASSES");          // tests
+        static const char *force = simka_test_knob("SIMKA_FORCE_PASSES");          // tests
         const uint32_t max_pass = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(64, ctx->nparts / std::max<uint32_t>(1, ctx->cfg.shard_count)));
         if (force) npass = (uint32_t)atoi(force);
         else {
@@ -1151,7 +1151,7 @@ SIMKA_EXPORT int simka_ingest_begin(simka_ctx *ctx, uint32_t sample) {
     if (ctx->counted[sample]) return ctx->fail(SIMKA_ERR_STATE, "simka_ingest_begin: sample %u was already counted", sample);
     HIPCHK(hipSetDevice(ctx->cfg.device));
     // (the lane count is fixed with the geometry, at the first count: until then, what setup_geometry will decide)
-    const uint32_t want_lanes = getenv("SIMKA_LANES") ? (uint32_t)std::max(1, atoi(getenv("SIMKA_LANES"))) : 2u;
+    const uint32_t want_lanes = simka_test_knob("SIMKA_LANES") ? (uint32_t)std::max(1, atoi(simka_test_knob("SIMKA_LANES"))) : 2u;
     const uint32_t li = sample % (ctx->nlanes ? ctx->nlanes : std::min<uint32_t>(std::min<uint32_t>(want_lanes, simka_ctx::MAX_LANES), std::max<uint32_t>(1u, ctx->cfg.nb_samples)));
     if (ctx->nlanes) { int rc = resolve_pending(ctx, (int)li); if (rc) return rc; }      // the lane's staging buffers still feed the sample counted two calls ago
     if (!ctx->copy_stream) HIPCHK(hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking));
@@ -1682,7 +1682,7 @@ static void pairs_phase_report() {
 struct PairLaunch { SimkaPairCfg pc; size_t lds_pairs = 0; uint32_t ntp = 1, nblk = 1; bool small_block = false; };
 
 // is the tile-major pair kernel usable (SIMKA_PAIRS_LEGACY=1 keeps the scan-and-compact kernel: tests / A-B; read at every merge)
-static bool tile_major_enabled() { return getenv("SIMKA_PAIRS_LEGACY") == nullptr; }
+static bool tile_major_enabled() { return simka_test_knob("SIMKA_PAIRS_LEGACY") == nullptr; }
 
 static void pair_setup(simka_ctx *ctx, PairLaunch &pl, bool legacy_layout = false, uint32_t force_span_cap = 0) {
     // pair-accumulator tiling: all N(N-1)/2 cells in LDS when they fit, else T x T sample tiles
@@ -1711,7 +1711,7 @@ static void pair_setup(simka_ctx *ctx, PairLaunch &pl, bool legacy_layout = fals
         lds_fixed = lds_single(pc.span_cap);
     } else {
         pc.span_cap = 2 * K3_CAP;       // tiled: larger spans cost tile edge (more tile pairs replaying the spans)
-        if (tm_layout && getenv("SIMKA_TM_SPAN")) pc.span_cap = std::min<uint32_t>(SIMKA_SPAN_MAX, std::max<uint32_t>(K3_CAP, (uint32_t)atoi(getenv("SIMKA_TM_SPAN")) / K3_CAP * K3_CAP));   // experiments
+        if (tm_layout && simka_exp_knob("SIMKA_TM_SPAN")) pc.span_cap = std::min<uint32_t>(SIMKA_SPAN_MAX, std::max<uint32_t>(K3_CAP, (uint32_t)atoi(simka_exp_knob("SIMKA_TM_SPAN")) / K3_CAP * K3_CAP));   // experiments
         if (force_span_cap) pc.span_cap = force_span_cap;                // the spans already exist
         lds_fixed = lds_tiled(pc.span_cap);
         const uint64_t max_cells = (lds_max - lds_fixed) / cell_bytes - 4;     // ncell_pad rounds up to a multiple of 4
@@ -1743,7 +1743,7 @@ static void pair_launch(simka_ctx *ctx, const PairLaunch &pl, const SimkaSpan *s
                         const SimkaSpan *huge, ull *acc, bool have_spans = true, uint64_t nb_entries = 0, uint64_t nb_spans = 0) {
     const SimkaPairCfg &pc = pl.pc;
     // N beyond one LDS tile: reorder the spans tile-major once (k_tile_major), then every tile pair stages only its two segments
-    const char *nt_env = getenv("SIMKA_TM_MAX_TILES");          // tests: force the fallback below a smaller tile count
+    const char *nt_env = simka_test_knob("SIMKA_TM_MAX_TILES");          // tests: force the fallback below a smaller tile count
     const uint32_t nt_max = nt_env ? std::min<uint32_t>(KTM_NT_MAX, (uint32_t)atoi(nt_env)) : (uint32_t)KTM_NT_MAX;
     bool tile_major = have_spans && pc.ntiles > 1 && pc.ntiles <= nt_max && tile_major_enabled();
     if (tile_major) {
@@ -1984,7 +1984,7 @@ SIMKA_EXPORT int simka_merge(simka_ctx *ctx) {
                 hipLaunchKernelGGL(k_group, dim3(std::max<uint32_t>(32u, std::min<uint32_t>((np * 4u + 31u) / 32u * 32u, grid_group / 32u * 32u))), dim3(K3_BLOCK), lds_group, ctx->stream, in, (const ull *)b_abs,
                                    (const uint16_t *)b_rows, np, key, min_share, co);
             });
-            if (getenv("SIMKA_DEBUG_MERGE")) {
+            if (simka_exp_knob("SIMKA_DEBUG_MERGE")) {
                 ull cur[4]; HIPCHK(hipMemcpyAsync(cur, ctx->d_cursors, 32, hipMemcpyDeviceToHost, ctx->stream)); HIPCHK(hipStreamSynchronize(ctx->stream));
                 std::vector<SimkaSpan> hs(cur[2]); HIPCHK(hipMemcpy(hs.data(), ctx->d_spans, cur[2] * sizeof(SimkaSpan), hipMemcpyDeviceToHost));
                 ull empty = 0, ent = 0, grp = 0, full = 0; for (auto &sp : hs) { if (!sp.ngrp) empty++; ent += sp.nent; grp += sp.ngrp; if (sp.nent > 3500) full++; }

@@ -50,6 +50,21 @@ SIMKA_HD uint32_t simka_key_hash32(uint64_t key) { return (uint32_t)key * 0x9E37
 // slot hash for the LDS tables: top bits of a 64-bit multiply see every key bit
 SIMKA_HD uint32_t simka_slot_hash(uint64_t key) { return (uint32_t)((key * 0xd6e8feb86659fd93ULL) >> 40); }
 
+// ---- environment knobs -----------------------------------------------------------------------------------------------------
+// Two classes.  simka_test_knob(): switches the TEST SUITE needs to force the rarely taken routes of the
+// shipped library (fallback kernels, sort paths, passes, table overflows) plus SIMKA_LANES / SIMKA_ARENA_MALLOC / SIMKA_DEBUG_SYNC --
+// always compiled in.  simka_exp_knob(): tuning experiments (block counts, fan-outs, span sizes, debug statistics) -- compiled in
+// only with -DSIMKA_DEBUG_KNOBS (scripts/build_variant.sh NAME -DSIMKA_DEBUG_KNOBS); the shipped library ignores them.
+#include <stdlib.h>
+static inline const char *simka_test_knob(const char *name) { return getenv(name); }
+static inline const char *simka_exp_knob(const char *name) {
+#ifdef SIMKA_DEBUG_KNOBS
+    return getenv(name);
+#else
+    (void)name; return (const char *)0;
+#endif
+}
+
 // floor(sqrt(x)) exactly, x < 2^64.  The reference adds sqrt((double)(ci*cj)) to a u64, i.e.
 // floor of the correctly-rounded double sqrt (ref: src/core/SimkaAlgorithm.hpp:397), which equals
 // this for x < 2^52.

@@ -605,6 +605,9 @@ __device__ const double2 g_simka_lntab[SIMKA_LNTAB] = {
     { 0x1.03091b51f5e1ap-1, 0x1.5cdb1dc6c1765p-1 },
     { 0x1.0101010101010p-1, 0x1.60e32f44788d9p-1 }
 };
+// a product / sum rounded on its own (HIP's __dmul_rn is a plain `*`, which the compiler may still fuse into a later add)
+__device__ __forceinline__ double simka_mul_rn(double a, double b) { double r = a * b; asm volatile("" : "+v"(r)); return r; }
+__device__ __forceinline__ double simka_add_rn(double a, double b) { double r = a + b; asm volatile("" : "+v"(r)); return r; }
 __device__ __forceinline__ double simka_fast_ln(double h, const double2 *tab) {
     const long long b = __double_as_longlong(h);
     const int e = (int)((b >> 52) & 0x7ff) - 1023;
@@ -800,7 +803,7 @@ k_pairs(const SimkaSpan *spans, const ull *cursors, const ull *entries, const ui
                 }
                 if (cplx && (!TILED || fl)) {
                     const double p = (double)(uint32_t)e / tn[loc];
-                    epp[i] = make_double2(p, p * log(p));
+                    epp[i] = make_double2(p, simka_mul_rn(p, simka_fast_ln(p, lntab)));      // (the SAME logarithm as in the pair loop: two identical samples cancel to exactly 0, as in the reference)
                 }
             }
             if (i < cur.ngrp) { gdesc[i] = pre_g[q]; if (!TILED) { const uint32_t s_ = pre_g[q] & 0xffffu; gpref[i] = s_ * (s_ - 1u) / 2u; } }
@@ -922,7 +925,7 @@ k_pairs(const SimkaSpan *spans, const ull *cursors, const ull *entries, const ui
                     // p ln p + q ln q - (p+q) ln((p+q)/2): one logarithm per pair, the p ln p terms are per entry.
                     const double2 px = epp[ix], py = epp[iy];
                     const double h = px.x + py.x;
-                    double dd = px.y + py.y - h * simka_fast_ln(h * 0.5, lntab);
+                    double dd = simka_add_rn(px.y, py.y) - simka_mul_rn(h, simka_fast_ln(h * 0.5, lntab));      // (products rounded on their own, never fused into the subtraction: identical samples give 2 a - 2 a = 0 exactly)
                     dd = dd < 0.0 ? 0.0 : dd;            // >= 0 mathematically (Jensen); rounding noise must not drive a sum of near-identical samples negative
                     atomicAdd(&c64[1 * CP + cell], (ull)(long long)llrint(dd * SIMKA_KL_SCALE));
                     const uint32_t jn = (rect ? T : 0u) + lj;
@@ -1025,7 +1028,7 @@ k_tile_major(const SimkaSpan *spans, const ull *cursors, const ull *entries, con
                 tm_ent[span.ebase + pos] = ((ull)gid[i] << 48) | ((ull)(smp & 0xffffu) << 32) | (ull)(uint32_t)e;
                 if (cplx) {
                     const double p = (double)(uint32_t)e / (double)pc.tot_n[smp];
-                    tm_p[span.ebase + pos] = make_double2(p, p * log(p));
+                    tm_p[span.ebase + pos] = make_double2(p, simka_mul_rn(p, simka_fast_ln(p, g_simka_lntab)));      // (the logarithm of the pair loop: identical samples cancel exactly)
                 }
             }
         }
@@ -1296,7 +1299,7 @@ k_pairs_tm(const SimkaSpan *spans, const ull *cursors, const ull *tm_ent, const 
                     // same arithmetic as k_pairs (ref: src/core/SimkaAlgorithm.hpp:437-446,477-481)
                     const double2 px = epp[ix], py = epp[iy];
                     const double h = px.x + py.x;
-                    double dd = px.y + py.y - h * simka_fast_ln(h * 0.5, lntab);
+                    double dd = simka_add_rn(px.y, py.y) - simka_mul_rn(h, simka_fast_ln(h * 0.5, lntab));      // (products rounded on their own, never fused into the subtraction: identical samples give 2 a - 2 a = 0 exactly)
                     dd = dd < 0.0 ? 0.0 : dd;
                     atomicAdd(&c64[1 * CP + cell], (ull)(long long)llrint(dd * SIMKA_KL_SCALE));
                     const uint32_t jn = (rect ? T : 0u) + lj;
@@ -1364,7 +1367,7 @@ k_pairs_global(const SimkaSpan *huge, const ull *cursors, const ull *entries, Si
             if (pc.nacc64) {
                 const double Ni = (double)pc.tot_n[si], Nj = (double)pc.tot_n[sj];
                 const double pi_ = (double)ci / Ni, pj_ = (double)cj / Nj, hh = pi_ + pj_;
-                double dd = pi_ * log(pi_) + pj_ * log(pj_) - hh * log(hh * 0.5);       // same form as k_pairs
+                double dd = simka_add_rn(simka_mul_rn(pi_, simka_fast_ln(pi_, g_simka_lntab)), simka_mul_rn(pj_, simka_fast_ln(pj_, g_simka_lntab))) - simka_mul_rn(hh, simka_fast_ln(hh * 0.5, g_simka_lntab));       // same form, logarithm and roundings as k_pairs
                 dd = dd < 0.0 ? 0.0 : dd;
                 atomicAdd(&acc[((ull)pc.nacc32 + 1) * NP + pg], (ull)(long long)llrint(dd * SIMKA_KL_SCALE));
                 const ull uX = (ull)((double)ci * Nj), uY = (ull)((double)cj * Ni);

@@ -632,7 +632,7 @@ int simka_wide_count_sample(SimkaWide *w, uint32_t sample, const void *packed, u
     WCHK(hipMemcpyAsync(&nvalid, d_small, 8, hipMemcpyDeviceToHost, w->stream));
     WCHK(hipStreamSynchronize(w->stream));
     // ---- by buckets: hash -> bucket number, two or three radix passes on it, one LDS table per bucket (k_wlocal_count)
-    if (nvalid && nvalid < ((uint64_t)1 << 31) && !getenv("SIMKA_WIDE_COUNT_SORT")) {
+    if (nvalid && nvalid < ((uint64_t)1 << 31) && !simka_test_knob("SIMKA_WIDE_COUNT_SORT")) {
         uint32_t bits = 1;
         while ((nvalid >> bits) > 1100u && bits < 24u) bits++;
         const uint32_t nb = 1u << bits;
@@ -655,7 +655,7 @@ int simka_wide_count_sample(SimkaWide *w, uint32_t sample, const void *packed, u
         WCHK(hipStreamSynchronize(w->stream));
         ull sm[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
         for (size_t i = 0; i < ph.size(); i++) sm[i & 7] += ph[i];
-        if (sm[6] == 0 && !getenv("SIMKA_WIDE_COUNT_FAIL")) {
+        if (sm[6] == 0 && !simka_test_knob("SIMKA_WIDE_COUNT_FAIL")) {
             totals5[SIMKA_TOT_KOCC] = nvalid; totals5[SIMKA_TOT_DALL] = sm[4];
             totals5[SIMKA_TOT_D] = sm[1]; totals5[SIMKA_TOT_N] = sm[2]; totals5[SIMKA_TOT_Q] = sm[3];
             return simka_wide_adopt(w, sample, ohi, olo, ocnt, nvalid, sm[1]);
@@ -778,7 +778,7 @@ int simka_wide_merge(SimkaWide *w, uint32_t span_cap, SimkaWideCsr *out) {
     // the records of every k-mer side by side in hi1 / lo1 / val2: buckets by hash + grouping in LDS; a bucket beyond the LDS staging
     // (a k-mer in thousands of samples) or SIMKA_WIDE_MERGE_SORT: the full sort by k-mer
     bool grouped = false;
-    if (!getenv("SIMKA_WIDE_MERGE_SORT") && M < ((uint64_t)1 << 31)) {
+    if (!simka_test_knob("SIMKA_WIDE_MERGE_SORT") && M < ((uint64_t)1 << 31)) {
         uint32_t bits = 1;
         while ((M >> bits) > 900u && bits < 24u) bits++;          // (<= 900 records per bucket: at most 900 of the table's 1536 usable slots)
         const uint32_t nb = 1u << bits;
@@ -797,7 +797,7 @@ int simka_wide_merge(SimkaWide *w, uint32_t span_cap, SimkaWideCsr *out) {
         uint32_t failed = 0;
         WCHK(hipMemcpyAsync(&failed, d_max, 4, hipMemcpyDeviceToHost, w->stream));
         WCHK(hipStreamSynchronize(w->stream));
-        grouped = !failed && !getenv("SIMKA_WIDE_MERGE_FAIL");          // (tests: the fallback after a failed grouping)
+        grouped = !failed && !simka_test_knob("SIMKA_WIDE_MERGE_FAIL");          // (tests: the fallback after a failed grouping)
     }
     if (!grouped) {
         w->nb_full_sorts++;
