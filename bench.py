@@ -30,6 +30,7 @@ HBM_PEAK_GBS = 8000.0     # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 
 KERNEL_BOUND = {
     "k_skm_scan": "VALU + barriers (canonical m-mer hashes, sliding minimum; 24 waves per CU)",
     "k_skm_split": "HBM (64-byte runs: partial-line writes amplify the traffic)",
+    "k_skm_chunksort": "HBM (every record read once and written once in whole lines: a streaming sort of 8192-record chunks in LDS)",
     "k_skm_count_fast": "LDS atomics + VALU, latency (random-slot 64-bit CAS + counter add per k-mer; 16 waves per CU)",
     "k_skm_count": "LDS atomics (redo list only)",
     "k_skm_count_wide_fast": "LDS latency + VALU issue (two-word k-mers: claim by 64-bit CAS, compare, count; a table per wave, 16 waves per CU)",
@@ -499,7 +500,7 @@ def main():
         # 16*K_occ = "write + read each 8-byte k-mer once for partitioning".  The super-k-mer pipeline partitions 16-byte records of
         # ~8.5 k-mers instead (real traffic ~2 B per k-mer and level), so the kernels' MEASURED traffic is far below these
         # design-independent bytes; the attribution follows the roles: the scan writes every k-mer once, the count kernel reads every
-        # k-mer once and writes the counted records, the merge reads the solid records once; k_skm_split is an extra level (0).
+        # k-mer once and writes the counted records, the merge reads the solid records once; k_skm_chunksort (the partitioning level) is an extra level (0).
         share = 1.0 / world                    # each rank owns 1/world of the key space (or counts 1/world of the samples)
         scan_reads = n * nb_bases / 4.0 * (share if by_sample else 1.0)       # partition shards: every rank reads every base
         kb = 16.0 if k > 31 else 8.0           # bytes of a k-mer (SURVEY 8d prices 8-byte k-mers; two words from k = 32 on)
@@ -538,7 +539,7 @@ def main():
                     tot += v["traffic_bytes_per_launch"] * v["launches"]; n += v["launches"]
             return tot / n if n else None
         try:
-            tf = next((f for f in (os.path.join(ROOT, "profiles", "r%02d_%s_hbm_traffic.json" % (rd, args.workload)) for rd in (3, 2)) if os.path.exists(f)), "")
+            tf = next((f for f in (os.path.join(ROOT, "profiles", "r%02d_%s_hbm_traffic.json" % (rd, args.workload)) for rd in (4, 3, 2)) if os.path.exists(f)), "")
             if world == 1 and not args.reads and not args.samples and not args.kmer_size and tf:
                 tk = json.load(open(tf))["kernels"]
                 traffic = measured_traffic(dom)

@@ -289,13 +289,18 @@ public:
     void give(void *p, size_t cap, bool pinned) {
         if (!p) return;
         std::lock_guard<std::mutex> g(m_);
-        if (free_.size() >= 64 || idle_ + cap > kMaxIdleBytes) { if (pinned) simka_host_free(p); else free(p); return; }
+        if (free_.size() >= 256 || idle_ + cap > max_idle_) { if (pinned) simka_host_free(p); else free(p); return; }
         free_.push_back(Block{p, cap, pinned});
         idle_ += cap;
     }
 private:
     struct Block { void *p; size_t cap; bool pinned; };
-    static constexpr size_t kMaxIdleBytes = (size_t)8 << 30;
+    // idle blocks kept for reuse: pinning a fresh buffer costs as much as filling it, so the pool should hold what the reader window
+    // cycles through (window x file size); set_max_idle() is called by the driver once it knows both
+    size_t max_idle_ = (size_t)8 << 30;
+public:
+    void set_max_idle(size_t b) { std::lock_guard<std::mutex> g(m_); max_idle_ = std::max(max_idle_, b); }
+private:
     std::vector<Block> free_;
     size_t idle_ = 0;
     std::mutex m_;
@@ -412,7 +417,8 @@ bool load_sample_raw(const Sample &s, const Options &o, uint64_t max_reads, Pack
         PinnedBuf<char> cur;
         bool first = true;
         while (first || done < fsize) {
-            const size_t want = std::min(chunk > carry ? chunk - carry : (size_t)1, fsize - done);
+            if (carry * 2 > chunk) { fclose(fp); return false; }       // a record about as long as a piece: the host parser takes the sample (reading on in ever smaller steps would copy the carry every time)
+            const size_t want = std::min(chunk - carry, fsize - done);
             PinnedBuf<char> buf;
             buf.resize(carry + want + 1);
             if (carry) memcpy(buf.data(), cur.data() + (cur.size() - carry), carry);
@@ -496,7 +502,13 @@ public:
         // fed, and their pinned buffers are recycled (pinning a buffer costs as much as filling it: 66 fresh 150-MB buffers cost seconds)
         // (-ingest-window: measured on C3 at full depth, 154 GB listed: 8 samples in flight 10.3 s, 16: 14.0 s, 24: 17.6 s -- more readers
         //  and more fresh pinned buffers slow the main thread's copies down more than they feed it)
-        if (raw_) window_ = std::min<size_t>(window_, o.ingest_window > 0 ? (size_t)o.ingest_window : 8);
+        if (raw_) {
+            window_ = std::min<size_t>(window_, o.ingest_window > 0 ? (size_t)o.ingest_window : 8);
+            uint64_t bytes = 0;
+            for (auto &sm : samples) for (auto &part : sm.parts) for (auto &fn : part) { struct stat st_; if (stat(fn.c_str(), &st_) == 0) bytes += (uint64_t)st_.st_size; }
+            // the pinned buffers of the window (+ 2 being handed over) stay in the pool between samples, up to 64 GB
+            PinnedPool::get().set_max_idle((size_t)std::min<uint64_t>((uint64_t)64 << 30, bytes / std::max<size_t>(1, samples.size()) * (window_ + 2) + ((uint64_t)2 << 30)));
+        }
         threads = std::max(1u, std::min<unsigned>(threads, (unsigned)std::min<size_t>(samples.size(), window_)));
         for (unsigned t = 0; t < threads; t++) workers_.emplace_back([this] { run(); });
     }

@@ -84,6 +84,7 @@ struct simka_ctx {
     // of the arena cursor once everything enqueued has finished; lane_bound: what the sample in flight on a lane may still add.
     bool arena_vmm = false; uint64_t arena_mapped = 0, arena_hi = 0, arena_reserved = 0;      // (arena_reserved: arena_cap rounded up to whole chunks)
     uint64_t lane_bound[MAX_LANES] = {};
+    bool used_gather = false;                   // the partitioning kernel of this context is k_skm_chunksort (profile name)
     bool live_counted = false;                  // this context is part of g_live_ctx[device]
     std::vector<char> arena_accounted;          // per sample: its bound is part of arena_hi (a redo or a further pass adds nothing)
     std::vector<hipMemGenericAllocationHandle_t> arena_hk, arena_hc;
@@ -751,6 +752,7 @@ static int skm_scan_split(simka_ctx *ctx, simka_ctx::Lane &L, uint32_t sample, c
         fprintf(stderr, "level-1 buckets: %u, records %llu, largest bucket %.1f %% above the mean\n", B1, sum, 100.0 * ((double)mx * B1 / std::max<ull>(1, sum) - 1.0));
     }
     *gather = use_gather;
+    if (use_gather) ctx->used_gather = true;
     if (use_gather) {
         // every bucket's records in chunks of SKM_CS_CHUNK: at most rec_cap / chunk + one partial chunk per bucket
         const uint64_t nch_max = rec_cap / SKM_CS_CHUNK + B1 + 1;
@@ -2259,7 +2261,8 @@ SIMKA_EXPORT int simka_profile_nb_kernels(simka_ctx *) { return KID_NB; }
 SIMKA_EXPORT int simka_profile_get(simka_ctx *ctx, int which, const char **name, uint64_t *n, double *ms) {
     if (!ctx || which < 0 || which >= KID_NB) return SIMKA_ERR_INVALID;
     profile_collect(ctx);
-    if (name) *name = (ctx->wide_hash && which == KID_SKM_COUNT) ? "k_skm_count_wide_fast" : (ctx->wide_hash && which == KID_COUNT) ? "k_skm_count_wide" : KID_NAMES[which];
+    if (name) *name = (ctx->wide_hash && which == KID_SKM_COUNT) ? "k_skm_count_wide_fast" : (ctx->wide_hash && which == KID_COUNT) ? "k_skm_count_wide" :
+                      (ctx->used_gather && which == KID_SKM_SPLIT) ? "k_skm_chunksort" : KID_NAMES[which];
     if (n) *n = ctx->prof_n[which];
     if (ms) *ms = ctx->prof_ms[which];
     return SIMKA_OK;

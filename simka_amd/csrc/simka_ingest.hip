@@ -79,7 +79,7 @@ k_ing_nl_fill(const unsigned char *text, uint64_t n, const uint32_t *tile_off, u
 __device__ __forceinline__ uint32_t ing_line_end(const unsigned char *text, const uint32_t *lines, uint32_t i) {
     const uint32_t st = lines[i];
     uint32_t en = lines[i + 1u] - 1u;                   // position of the '\n' (or n for the last line)
-    if (en > st && text[en - 1u] == '\r') en--;
+    while (en > st && text[en - 1u] == '\r') en--;     // every trailing CR, as the host's SeqReader::getline does (one left behind would end a FASTA fragment that continues on the next line)
     return en;
 }
 

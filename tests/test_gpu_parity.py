@@ -1391,6 +1391,7 @@ def test_device_ingest_equals_host_parse(gpu_required, k):
         [fasta(a[:50] + [b""] + a[50:120], final_eol=False)],           # a header without sequence; no newline at the end
         [fastq(b), fastq(a[:77], eol=b"\r\n")],                         # FASTQ, two files
         [fasta(a, width=1000) + b"\n\n"],                               # blank lines at the end only
+        [fasta(b, width=53, eol=b"\r\r\n")],                             # two CRs before the LF, multi-line: every trailing CR goes, the fragment continues
     ]
     (th, fh), (td, fd) = _stats_via_host_and_device(files, k)
     assert th == td
