@@ -56,7 +56,9 @@ typedef struct simka_ctx simka_ctx;
 typedef struct simka_config {
     uint32_t struct_size;        /* = sizeof(simka_config) */
     uint32_t nb_samples;         /* N, SimkaStatistics::_nbBanks (1..65535) */
-    uint32_t kmer_size;          /* -kmer-size, 1..63.  k <= 31 (one 64-bit word, Kmer<span=32>): the hash pipeline.  32..63 (two words,
+    uint32_t kmer_size;          /* -kmer-size, 1..127 (the reference's spans 32 / 64 / 96 / 128, ref: CMakeLists.txt:66-71).  64..127: the k-mer is rolled
+                                  * in four words and counted / merged as a 126-bit fingerprint on the two-word path (simka_wide.hip: wfinger).
+                                  * k <= 31 (one 64-bit word, Kmer<span=32>): the hash pipeline.  32..63 (two words,
                                   * Kmer<span=64>): counted on the same minimizer-partitioned pipeline up to k = 51, occurrence by
                                   * occurrence in hash buckets from 52 on (~2x slower); merged by hash buckets + LDS grouping; a partition shard keeps the k-mers that hash to it */
     uint32_t abundance_min;      /* -abundance-min (ref: src/minikc/MiniKC.hpp:56) */

@@ -123,8 +123,64 @@ static inline int or_code(unsigned char c) {
     }
 }
 
+/* ---- 64 <= k <= 127 (the reference's Kmer<span=96/128>, ref: CMakeLists.txt:66-71, src/SimkaPotara.cpp:132-141): the canonical k-mer
+ * is kept WHOLE, four 64-bit words (w[3] most significant), and every distinct one gets its RANK in the sorted dictionary of the run --
+ * distances depend only on which k-mers are equal, so everything behind the extraction works on the ranks with the
+ * machinery of k <= 63.  Two passes over the reads: collect (mode 1), then map (mode 2). */
+typedef struct { uint64_t w[4]; } k256;
+static int g_k256_mode = 0;
+static k256 *g_k256_v = NULL; static size_t g_k256_n = 0, g_k256_cap = 0;
+static int k256_cmp(const void *a, const void *b) {
+    const k256 *x = (const k256 *)a, *y = (const k256 *)b;
+    for (int q = 3; q >= 0; q--) if (x->w[q] != y->w[q]) return x->w[q] < y->w[q] ? -1 : 1;
+    return 0;
+}
+static void k256_collect(const k256 *x) {
+#ifdef _OPENMP
+#pragma omp critical(k256_collect)
+#endif
+    {
+        if (g_k256_n == g_k256_cap) { g_k256_cap = g_k256_cap ? g_k256_cap * 2 : 4096; g_k256_v = (k256 *)realloc(g_k256_v, g_k256_cap * sizeof(k256)); }
+        g_k256_v[g_k256_n++] = *x;
+    }
+}
+static void k256_build_dictionary(void) {
+    qsort(g_k256_v, g_k256_n, sizeof(k256), k256_cmp);
+    size_t w = 0;
+    for (size_t i = 0; i < g_k256_n; i++) if (w == 0 || k256_cmp(&g_k256_v[w - 1], &g_k256_v[i]) != 0) g_k256_v[w++] = g_k256_v[i];
+    g_k256_n = w;
+}
+static uint64_t k256_rank(const k256 *x) {
+    const k256 *f = (const k256 *)bsearch(x, g_k256_v, g_k256_n, sizeof(k256), k256_cmp);
+    return f ? (uint64_t)(f - g_k256_v) : ~0ull;       /* (every k-mer of the map pass was collected) */
+}
+static size_t or_kmers_of_read_256(const char *seq, size_t len, int k, u64vec *out) {
+    const int W = 2 * k, tw = (W - 1) / 64, top = 2 * (k - 1);
+    const uint64_t mtop = (W % 64) ? ((1ull << (W % 64)) - 1ull) : ~0ull;
+    k256 f, r; memset(&f, 0, sizeof f); memset(&r, 0, sizeof r);
+    size_t valid = 0, emitted = 0;
+    for (size_t i = 0; i < len; i++) {
+        int c = or_code((unsigned char)seq[i]);
+        if (c < 0) { valid = 0; memset(&f, 0, sizeof f); memset(&r, 0, sizeof r); continue; }
+        for (int q = 3; q > 0; q--) f.w[q] = (f.w[q] << 2) | (f.w[q - 1] >> 62);
+        f.w[0] = (f.w[0] << 2) | (uint64_t)c;
+        f.w[tw] &= mtop; for (int q = tw + 1; q < 4; q++) f.w[q] = 0;
+        for (int q = 0; q < 3; q++) r.w[q] = (r.w[q] >> 2) | (r.w[q + 1] << 62);
+        r.w[3] >>= 2;
+        r.w[top / 64] |= (uint64_t)(c ^ 2) << (top % 64);
+        if (++valid >= (size_t)k) {
+            const k256 *canon = k256_cmp(&f, &r) < 0 ? &f : &r;
+            if (g_k256_mode == 1) { k256_collect(canon); u64vec_push(out, (kmer_t)0); }
+            else u64vec_push(out, (kmer_t)k256_rank(canon));
+            emitted++;
+        }
+    }
+    return emitted;
+}
+
 /* Append the canonical k-mers of one read to `out`; returns #k-mers appended. */
 static size_t or_kmers_of_read(const char *seq, size_t len, int k, u64vec *out) {
+    if (k >= 64) return or_kmers_of_read_256(seq, len, k, out);
     if (k <= 31) {      /* 64-bit rolling words (the reference's Kmer<span=32>) */
         const uint64_t mask = (1ull << (2 * k)) - 1ull;
         uint64_t fwd = 0, rev = 0;
@@ -453,8 +509,8 @@ static void or_count_range(const oracle *o, kmer_t *v, size_t n, int sort_bits, 
 static int or_count_sample(oracle *o, or_sample *s, int threads) {
     s->nb_reads = 0; s->k_occ = 0;
     if (threads < 1) threads = 1;
-    const int W = 2 * o->k;
-    const int rb = W >= 12 ? 12 : 0;                       /* range = top 12 bits of the k-mer (one range for tiny k) */
+    const int W = o->k >= 64 ? 64 : 2 * o->k;              /* (k >= 64: the "k-mers" are dictionary ranks, or_kmers_of_read_256) */
+    const int rb = (W >= 12 && o->k < 64) ? 12 : 0;        /* range = top 12 bits of the k-mer (one range for tiny k and for ranks) */
     const size_t NR = (size_t)1 << rb;
     const int T = (s->bases && s->nreads_mem >= 64) ? threads : 1;        /* extraction threads (files are read by one iterator) */
     u64vec *loc = (u64vec *)calloc((size_t)T, sizeof(u64vec));
@@ -959,12 +1015,22 @@ OR_API int oracle_add_sample_mem(oracle *o, const char *id, const char *bases, c
  * (shard_count=1: everything.)  threads<=1 -> serial. */
 OR_API int oracle_run_shard(oracle *o, int k, uint32_t amin, uint32_t amax, int simple, int complex_, unsigned nparts, int threads,
                             unsigned shard_index, unsigned shard_count) {
-    if (k < 1 || k > 63) { snprintf(o->err, sizeof o->err, "oracle: k must be in [1,63]"); return -1; }
+    if (k < 1 || k > 127) { snprintf(o->err, sizeof o->err, "oracle: k must be in [1,127]"); return -1; }
     o->k = k; o->amin = amin; o->amax = amax > 999999999u ? 999999999u : amax;  /* ref: src/core/SimkaAlgorithm.cpp:188 */
     if (nparts < 1) nparts = 1;
     int rc = 0;
     for (int i = 0; i < o->n; i++) { free(o->s[i].kmer); free(o->s[i].count); o->s[i].kmer = NULL; o->s[i].count = NULL; }
     if (threads < 1) threads = 1;
+    g_k256_mode = 0;
+    if (k >= 64) {      /* pass 1: the dictionary of the run's canonical k-mers (the counts of this pass are thrown away) */
+        g_k256_n = 0; g_k256_mode = 1;
+        for (int i = 0; i < o->n; i++) {
+            if (or_count_sample(o, &o->s[i], threads) != 0) { g_k256_mode = 0; return -1; }
+            free(o->s[i].kmer); free(o->s[i].count); o->s[i].kmer = NULL; o->s[i].count = NULL;
+        }
+        k256_build_dictionary();
+        g_k256_mode = 2;
+    }
     /* at least as many samples as threads: one sample per thread (as the reference runs one simkaCount job per sample);
      * fewer: the samples one after the other, each on all threads */
     if (o->n >= threads || threads == 1) {

@@ -661,7 +661,7 @@ int main(int argc, char **argv) {
     if (o.max_memory < 2000) std::cout << "WARNING: running Simka with low memory is risky. Simka may hang because of that. Consider running with -max-memory X where X > 2000" << std::endl;
     if (o.max_memory < 500) { std::cout << "Please run Simka with higher memory usage than 500 MB" << std::endl; return 1; }
     if (!exists(o.in)) die("ERROR: Input filename does not exist");
-    if (o.kmer_size < 1 || o.kmer_size > 63) die("ERROR: -kmer-size must be in [1,63]");
+    if (o.kmer_size < 1 || o.kmer_size > 127) die("ERROR: -kmer-size must be in [1,127]");       // (the reference's largest span, ref: CMakeLists.txt:66-71)
     if (o.nb_gpus < 1) die("ERROR: -nb-gpus must be >= 1");
     if (o.abundance_min < 0) o.abundance_min = 0;
     o.abundance_max = std::min<long long>(std::max<long long>(o.abundance_max, 0), 999999999LL);

@@ -422,7 +422,7 @@ SIMKA_EXPORT int simka_create(const simka_config *cfg, simka_ctx **out) {
     if (!cfg || !out) { g_create_error = "simka_create: null argument"; return SIMKA_ERR_INVALID; }
     if (cfg->struct_size != sizeof(simka_config)) { g_create_error = "simka_create: struct_size mismatch (ABI)"; return SIMKA_ERR_INVALID; }
     if (cfg->nb_samples == 0 || cfg->nb_samples > 65535) { g_create_error = "simka_create: nb_samples must be in [1,65535]"; return SIMKA_ERR_INVALID; }
-    if (cfg->kmer_size < 1 || cfg->kmer_size > 63) { g_create_error = "simka_create: kmer_size must be in [1,63]"; return SIMKA_ERR_INVALID; }
+    if (cfg->kmer_size < 1 || cfg->kmer_size > 127) { g_create_error = "simka_create: kmer_size must be in [1,127]"; return SIMKA_ERR_INVALID; }
     const bool want_wide = cfg->kmer_size > 31 || simka_test_knob("SIMKA_SORT_PATH") != nullptr;
     if (cfg->shard_count == 0 || cfg->shard_index >= cfg->shard_count) { g_create_error = "simka_create: bad shard_index/shard_count"; return SIMKA_ERR_INVALID; }
     if (cfg->log2_subranges > 8) { g_create_error = "simka_create: log2_subranges must be <= 8"; return SIMKA_ERR_INVALID; }

@@ -121,6 +121,58 @@ __device__ __forceinline__ uint32_t wroll(const WideScanArgs &a, uint64_t p0, ui
     return n;
 }
 
+// ---- 64 <= k <= 127 (the reference's Kmer<span=96/128>, ref: CMakeLists.txt:66-71, src/SimkaPotara.cpp:132-141): the canonical k-mer is
+// rolled in FOUR words and leaves the scan as a 126-bit FINGERPRINT (hi: 62 bits, lo: 64 bits -- the key geometry of k = 63), so that
+// everything behind the scan (bucket count, sort fallback, bucket merge, export / import, shards) is the two-word machinery unchanged.
+// Two independently keyed 64-bit mixes of the four words; two DISTINCT k-mers of a run share a fingerprint with probability
+// < (number of distinct k-mers)^2 / 2^127 (1e-16 for 1e11 of them) -- not a proof of exactness like the word-exact paths of k <= 63,
+// stated as such in DESIGN.md; the oracle keeps the whole k-mers and the tests compare bit for bit.
+__device__ __forceinline__ ull wfmix(ull x) { x ^= x >> 33; x *= 0xff51afd7ed558ccdULL; x ^= x >> 33; x *= 0xc4ceb9fe1a85ec53ULL; x ^= x >> 33; return x; }
+__device__ __forceinline__ void wfinger(const ull c[4], ull &hi, ull &lo) {
+    const ull a = wfmix(c[0] ^ wfmix(c[1] ^ wfmix(c[2] ^ wfmix(c[3] ^ 0x9E3779B97F4A7C15ULL))));
+    const ull b = wfmix(c[3] + 0xD6E8FEB86659FD93ULL * (wfmix(c[2] + 0xD6E8FEB86659FD93ULL * (wfmix(c[1] + 0xD6E8FEB86659FD93ULL * wfmix(c[0] ^ 0xBF58476D1CE4E5B9ULL))))));
+    hi = a & 0x3fffffffffffffffULL; lo = b;
+}
+template <bool EMIT, bool SHARDED>
+__device__ __forceinline__ uint32_t wroll4(const WideScanArgs &a, uint64_t p0, uint64_t pend, uint64_t rd, uint64_t rstart, uint64_t rend, ull *khi, ull *klo, ull wr) {
+    const uint32_t k = a.k, W = 2u * k;                      // 128 <= W <= 254
+    const uint32_t tw = (W - 1u) >> 6;                       // top word (2 or 3)
+    const ull mtop = (W & 63u) ? ((1ull << (W & 63u)) - 1ull) : ~0ull;
+    const uint32_t top = 2u * (k - 1u);                      // bit position of the first base in the reverse complement
+    ull f[4] = { 0, 0, 0, 0 }, r[4] = { 0, 0, 0, 0 };
+    uint32_t have = 0, n = 0;
+    uint64_t p = p0 > rstart + (k - 1u) ? p0 - (k - 1u) : rstart;
+    ull word = a.packed[p >> 5] >> ((p & 31u) * 2u);
+    for (; p < pend; p++) {
+        while (p >= rend) {
+            rd++; rstart = rend;
+            rend = a.fixed_len ? rstart + a.fixed_len : a.offsets[rd + 1];
+            have = 0; f[0] = f[1] = f[2] = f[3] = 0; r[0] = r[1] = r[2] = r[3] = 0;
+        }
+        if ((p & 31u) == 0u) word = a.packed[p >> 5];
+        const ull c = word & 3ull;
+        word >>= 2;
+        f[3] = (f[3] << 2) | (f[2] >> 62); f[2] = (f[2] << 2) | (f[1] >> 62); f[1] = (f[1] << 2) | (f[0] >> 62); f[0] = (f[0] << 2) | c;
+        if (tw == 2u) { f[2] &= mtop; f[3] = 0; } else f[3] &= mtop;
+        r[0] = (r[0] >> 2) | (r[1] << 62); r[1] = (r[1] >> 2) | (r[2] << 62); r[2] = (r[2] >> 2) | (r[3] << 62); r[3] >>= 2;
+        r[top >> 6] |= (c ^ 2ull) << (top & 63u);
+        if (have < k) have++;
+        if (p >= p0 && have >= k) {
+            bool fsm = false, decided = false;
+#pragma unroll
+            for (int q = 3; q >= 0; q--) if (!decided && f[q] != r[q]) { fsm = f[q] < r[q]; decided = true; }
+            ull ch, cl;
+            const ull cw[4] = { fsm ? f[0] : r[0], fsm ? f[1] : r[1], fsm ? f[2] : r[2], fsm ? f[3] : r[3] };
+            wfinger(cw, ch, cl);
+            if (!SHARDED || wide_owns(ch, cl, a.shard_index, a.shard_count)) {
+                if (EMIT) { khi[wr] = ch; klo[wr] = cl; wr++; }
+                n++;
+            }
+        }
+    }
+    return n;
+}
+
 template <bool SHARDED>
 __global__ void __launch_bounds__(256)
 k_wscan(WideScanArgs a, ull *khi, ull *klo, ull *nvalid) {
@@ -140,7 +192,7 @@ k_wscan(WideScanArgs a, ull *khi, ull *klo, ull *nvalid) {
             while (hi - lo > 1) { const uint64_t mid = (lo + hi) >> 1; if (a.offsets[mid] <= p0) lo = mid; else hi = mid; }
             rd = lo; rstart = a.offsets[rd]; rend = a.offsets[rd + 1];
         }
-        if (SHARDED) cnt = wroll<false, true>(a, p0, pend, rd, rstart, rend, khi, klo, 0ull);      // ownership needs the k-mer itself
+        if (SHARDED) cnt = k >= 64u ? wroll4<false, true>(a, p0, pend, rd, rstart, rend, khi, klo, 0ull) : wroll<false, true>(a, p0, pend, rd, rstart, rend, khi, klo, 0ull);      // ownership needs the k-mer itself
         else {
             // pass 1 (no bases touched): how many of my end positions close a whole k-mer inside one read
             uint64_t rr = rd, rs = rstart, re = rend;
@@ -162,7 +214,8 @@ k_wscan(WideScanArgs a, ull *khi, ull *klo, ull *nvalid) {
     __syncthreads();
     if (!active || cnt == 0) return;
     // pass 2: write the k-mers
-    (void)wroll<true, SHARDED>(a, p0, pend, rd, rstart, rend, khi, klo, s_base + wpre + incl - cnt);
+    if (k >= 64u) (void)wroll4<true, SHARDED>(a, p0, pend, rd, rstart, rend, khi, klo, s_base + wpre + incl - cnt);
+    else (void)wroll<true, SHARDED>(a, p0, pend, rd, rstart, rend, khi, klo, s_base + wpre + incl - cnt);
 }
 
 __global__ void __launch_bounds__(256)
@@ -492,7 +545,7 @@ static int wide_sort_words(SimkaWide *w, uint64_t n, uint32_t hi_bits, ull *hi0,
 
 int simka_wide_create(SimkaWide **out, int device, uint32_t nb_samples, uint32_t k, void *stream) {
     SimkaWide *w = new SimkaWide();
-    w->device = device; w->nb_samples = nb_samples; w->k = k; w->W = 2 * k; w->stream = (hipStream_t)stream;
+    w->device = device; w->nb_samples = nb_samples; w->k = k; w->W = k >= 64 ? 126 : 2 * k;      // (k >= 64: the keys are 126-bit fingerprints, wfinger) w->stream = (hipStream_t)stream;
     w->s_off.assign(nb_samples, 0); w->s_n.assign(nb_samples, 0); w->s_sorted.assign(nb_samples, 1);
     *out = w;
     return 0;

@@ -1000,6 +1000,18 @@ def test_sort_based_path_for_wide_kmers(gpu_required, oracle_mod, monkeypatch, k
     _wide_case(oracle_mod, k, amin, n, R, L, expect="sorted", full_sorts=0 if how == "buckets" else n)
 
 
+@pytest.mark.parametrize("k,amin,n,R,L,how,fixed", [(64, 2, 4, 2500, 150, "buckets", True), (65, 1, 3, 2000, 150, "buckets", False), (96, 2, 4, 2500, 200, "buckets", True),
+                                                    (127, 2, 4, 2500, 250, "buckets", True), (127, 1, 3, 1500, 150, "sort", False), (100, 2, 3, 1500, 90, "buckets", True)])
+def test_kmers_of_64_to_127_bases(gpu_required, oracle_mod, monkeypatch, k, amin, n, R, L, how, fixed):
+    """k = 64..127 (the reference's Kmer<span=96/128> builds, ref: CMakeLists.txt:66-71, src/SimkaPotara.cpp:132-141): the scan rolls
+    four-word k-mers and hands their 126-bit fingerprints to the two-word path (bucket count or sort, bucket merge).  Totals and every
+    accumulator, -simple-dist and -complex-dist, against the oracle, which keeps the k-mers whole (dictionary ranks, pinned against a
+    pure-Python restatement on strings: tests/test_oracle_golden.py).  (100, ..., L = 90): reads shorter than k -- nothing to count."""
+    if how == "sort":
+        monkeypatch.setenv("SIMKA_WIDE_COUNT_SORT", "1")
+    _wide_case(oracle_mod, k, amin, n, R, L, expect="sorted", fixed=fixed, full_sorts=0 if how == "buckets" else n)
+
+
 def _wide_case(oracle_mod, k, amin, n, R, L, expect, fixed=True, full_sorts=0, **ctx_kw):
     from simka_amd import synth
     packed = _synthetic(n, R, L, seed_shift=70)

@@ -258,3 +258,60 @@ def test_oracle_wide_kmers_partition_invariance(oracle_mod, golden_dir, k):
     for name in ("S", "a", "bc", "chord", "hell", "whit"):
         assert np.array_equal(a.acc(name), b.acc(name)), name
     assert int(a.acc("a").sum()) > 0
+
+
+@pytest.mark.parametrize("k", [31, 63, 64, 65, 96, 127])
+def test_oracle_kmers_of_any_width_vs_python_strings(oracle_mod, k):
+    """The oracle's k-mer extraction and counting at every word width (one word, __int128, and -- k >= 64 -- whole four-word k-mers
+    ranked in a dictionary) against a pure-Python restatement on STRINGS: canonical = min(s, reverse complement) as text, counts in a
+    dict.  Three small samples, reads of varying length with N letters, abundance-min 2: per-sample totals and the default
+    accumulators (shared abundance, shared distinct k-mers, Bray-Curtis numerator) must agree exactly.
+    (k = 64..127 is the reference's Kmer<span=96/128>, ref: CMakeLists.txt:66-71.)"""
+    from collections import Counter
+    rng = np.random.default_rng(100 + k)
+    genome = "".join(rng.choice(list("ACGT"), size=1500))
+    comp = str.maketrans("ACGT", "TGCA")
+    samples = []
+    for s in range(3):
+        reads = []
+        for _ in range(int(rng.integers(25, 40))):
+            ln = int(rng.integers(k - 5, 3 * k))
+            st = int(rng.integers(0, len(genome) - ln))
+            r = list(genome[st:st + ln])
+            if rng.random() < 0.3 and ln:
+                r[int(rng.integers(0, ln))] = "N"
+            r = "".join(r)
+            if rng.random() < 0.5:
+                r = r.translate(comp)[::-1]
+            reads.append(r)
+        samples.append(reads)
+    amin = 2
+    spectra, occ, dall = [], [], []
+    for reads in samples:
+        c = Counter()
+        for r in reads:
+            for i in range(len(r) - k + 1):
+                w = r[i:i + k]
+                if "N" in w:
+                    continue
+                rc = w.translate(comp)[::-1]
+                c[min(w, rc)] += 1
+        occ.append(sum(c.values())); dall.append(len(c))
+        spectra.append({km: n for km, n in c.items() if n >= amin})
+    o = oracle_mod.Oracle()
+    for s, reads in enumerate(samples):
+        o.add_sample_ascii("S%d" % s, np.frombuffer("".join(reads).encode(), dtype=np.uint8), np.concatenate([[0], np.cumsum([len(r) for r in reads])]).astype(np.uint64))
+    o.run(k, amin, simple=True, complex_=False, nparts=3, threads=2)
+    t = o.totals()
+    assert [int(x) for x in t["K_occ"]] == occ and [int(x) for x in t["D_all"]] == dall
+    assert [int(x) for x in t["D"]] == [len(sp) for sp in spectra]
+    assert [int(x) for x in t["N"]] == [sum(sp.values()) for sp in spectra]
+    assert [int(x) for x in t["Q"]] == [sum(v * v for v in sp.values()) for sp in spectra]
+    S, a, bc = o.acc("S"), o.acc("a"), o.acc("bc")
+    for i in range(3):
+        for j in range(i + 1, 3):
+            both = set(spectra[i]) & set(spectra[j])
+            assert int(a[i, j]) == len(both)
+            assert int(S[i, j]) == sum(spectra[i][x] for x in both) and int(S[j, i]) == sum(spectra[j][x] for x in both)
+            assert int(bc[i, j]) == sum(min(spectra[i][x], spectra[j][x]) for x in both)
+    assert sum(occ) > 0 and any(len(sp) for sp in spectra)
