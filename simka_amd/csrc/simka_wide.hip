@@ -136,7 +136,7 @@ __device__ __forceinline__ void wfinger(const ull c[4], ull &hi, ull &lo) {
 template <bool EMIT, bool SHARDED>
 __device__ __forceinline__ uint32_t wroll4(const WideScanArgs &a, uint64_t p0, uint64_t pend, uint64_t rd, uint64_t rstart, uint64_t rend, ull *khi, ull *klo, ull wr) {
     const uint32_t k = a.k, W = 2u * k;                      // 128 <= W <= 254
-    const uint32_t tw = (W - 1u) >> 6;                       // top word (2 or 3)
+    const uint32_t tw = (W - 1u) >> 6;                       // top word (1 for k = 64, else 2 or 3)
     const ull mtop = (W & 63u) ? ((1ull << (W & 63u)) - 1ull) : ~0ull;
     const uint32_t top = 2u * (k - 1u);                      // bit position of the first base in the reverse complement
     ull f[4] = { 0, 0, 0, 0 }, r[4] = { 0, 0, 0, 0 };
@@ -153,7 +153,7 @@ __device__ __forceinline__ uint32_t wroll4(const WideScanArgs &a, uint64_t p0, u
         const ull c = word & 3ull;
         word >>= 2;
         f[3] = (f[3] << 2) | (f[2] >> 62); f[2] = (f[2] << 2) | (f[1] >> 62); f[1] = (f[1] << 2) | (f[0] >> 62); f[0] = (f[0] << 2) | c;
-        if (tw == 2u) { f[2] &= mtop; f[3] = 0; } else f[3] &= mtop;
+        if (tw == 1u) { f[1] &= mtop; f[2] = 0; f[3] = 0; } else if (tw == 2u) { f[2] &= mtop; f[3] = 0; } else f[3] &= mtop;
         r[0] = (r[0] >> 2) | (r[1] << 62); r[1] = (r[1] >> 2) | (r[2] << 62); r[2] = (r[2] >> 2) | (r[3] << 62); r[3] >>= 2;
         r[top >> 6] |= (c ^ 2ull) << (top & 63u);
         if (have < k) have++;

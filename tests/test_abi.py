@@ -51,7 +51,7 @@ def test_create_validates_arguments(simka_lib):
     cfg.struct_size = 4          # wrong ABI size
     assert simka_lib.simka_create(C.byref(cfg), C.byref(h)) == 1
     cfg.struct_size = C.sizeof(api.Config)
-    cfg.nb_samples, cfg.kmer_size, cfg.shard_count = 2, 64, 1      # k >= 64 is not supported (32..63: the sort-based path)
+    cfg.nb_samples, cfg.kmer_size, cfg.shard_count = 2, 128, 1     # k >= 128 is beyond the reference's largest span (64..127: four-word scan, fingerprints)
     assert simka_lib.simka_create(C.byref(cfg), C.byref(h)) == 1
     cfg.kmer_size, cfg.shard_index = 21, 3                          # shard_index >= shard_count
     assert simka_lib.simka_create(C.byref(cfg), C.byref(h)) == 1

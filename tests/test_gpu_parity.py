@@ -466,7 +466,7 @@ def test_kmer_shared_by_more_samples_than_a_span(gpu_required, oracle_mod):
     _check_vs_oracle(totals, st, orc, simple=True, complex_=True)
 
 
-def _run_cli(args, out, log=None):
+def _run_cli(args, out, log=None, nb_matrices=18):
     import subprocess
     from simka_amd import build as b
     r = subprocess.run([b.CLI_PATH] + args + ["-out", out, "-verbose", "0" if log is None else "2"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
@@ -477,7 +477,7 @@ def _run_cli(args, out, log=None):
     for gzf in sorted(glob.glob(os.path.join(out, "*.csv.gz"))):
         with gzip.open(gzf, "rb") as f:
             res[os.path.basename(gzf)] = f.read()
-    assert len(res) == 18
+    assert len(res) == nb_matrices
     return res
 
 
@@ -550,6 +550,24 @@ def test_cli_read_policies_vs_oracle(gpu_required, oracle_mod, tmp_path, policy)
     assert sorted(got) == sorted(ref)
     for name in ref:
         assert got[name] == ref[name], name
+
+
+@pytest.mark.parametrize("k", [33, 63, 64, 90, 100, 127])
+def test_cli_every_kmer_span_of_the_reference_vs_oracle(gpu_required, oracle_mod, golden_dir, tmp_path, k):
+    """`simka -kmer-size k` for the spans the reference builds (32 / 64 / 96 / 128, ref: CMakeLists.txt:66-71, src/SimkaPotara.cpp:132-141)
+    on the example data set (reads of 100 bp and more): the driver's CSV bytes equal the oracle's, -simple-dist and -complex-dist."""
+    inp = os.path.join(golden_dir, "example", "simka_input.txt")
+    got = _run_cli(["-in", inp, "-out-tmp", str(tmp_path / "tmp"), "-simple-dist", "-complex-dist", "-kmer-size", str(k), "-abundance-min", "1", "-max-reads", "-1"], str(tmp_path / "o1"), nb_matrices=21)
+    orc = oracle_mod.Oracle()
+    orc.load_input(inp)
+    orc.run(k, 1, simple=True, complex_=True)
+    orc.write_matrices(str(tmp_path / "o2"), gz=False)
+    assert (int(orc.totals()["K_occ"].sum()) > 0) == (k <= 100)       # (the example's reads hold 100 bases: k = 127 counts nothing, in both)
+    ref = sorted(glob.glob(os.path.join(str(tmp_path / "o2"), "*.csv")))
+    assert len(ref) >= 20
+    for f in ref:
+        with open(f, "rb") as h:
+            assert got[os.path.basename(f) + ".gz"] == h.read(), (k, os.path.basename(f))
 
 
 def test_cli_auto_max_reads_vs_oracle(gpu_required, oracle_mod, golden_dir, tmp_path):
