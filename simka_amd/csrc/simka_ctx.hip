@@ -288,7 +288,8 @@ static SkmScanFn skm_scan_kernel(int wi, bool fixed, bool hist) {
 
 static int set_lds_attr(simka_ctx *ctx) {
     const int big = 160 * 1024;
-    HIPCHK(hipFuncSetAttribute((const void *)k_group, hipFuncAttributeMaxDynamicSharedMemorySize, big));
+    HIPCHK(hipFuncSetAttribute((const void *)k_group<K3_BLOCK>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
+    HIPCHK(hipFuncSetAttribute((const void *)k_group<2 * K3_BLOCK>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
     HIPCHK(hipFuncSetAttribute((const void *)k_pairs<false, K4_BLOCK_BIG>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
     HIPCHK(hipFuncSetAttribute((const void *)k_pairs<false, K4_BLOCK_SMALL>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
     HIPCHK(hipFuncSetAttribute((const void *)k_pairs<true, K4_BLOCK_BIG>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
@@ -1909,7 +1910,10 @@ SIMKA_EXPORT int simka_merge(simka_ctx *ctx) {
     // sub-range bits: at most K3_TARGET records per k_group round on average (a round hashes up to K3_CAP)
     SimkaKeyCfg key = ctx->key;
     uint32_t t = ctx->cfg.log2_subranges;
-    if (t == 0) t = ceil_log2_u64((total / std::max<ull>(nonempty, 1) + K3_TARGET - 1) / K3_TARGET);
+    // (more than K3_BLOCK samples: k_group<512> -- twice the records per round, every sample in one tile)
+    const bool group_big = N > (uint32_t)K3_BLOCK;
+    const uint32_t g_mul = group_big ? 2u : 1u;
+    if (t == 0) t = ceil_log2_u64((total / std::max<ull>(nonempty, 1) + K3_TARGET * g_mul - 1) / (K3_TARGET * g_mul));
     t = std::min<uint32_t>(t, SIMKA_SEG_BITS);            // (the segments are ordered by that many key bits; k_group splits larger sub-ranges on further bits)
     t = std::min<uint32_t>(t, key.W);
     key.t = t; ctx->key.t = t;
@@ -1926,7 +1930,7 @@ SIMKA_EXPORT int simka_merge(simka_ctx *ctx) {
     if (maxpart > cap) return ctx->fail(SIMKA_ERR_NOMEM, "simka_merge: one partition holds %llu records, more than the merge buffer", maxpart);
     const uint64_t max_parts_batch = std::min<uint64_t>(nparts, std::min<uint64_t>((uint64_t)1 << 16, std::max<uint64_t>(1, ((uint64_t)1 << 26) / N)));
     const uint64_t fb_cap = max_parts_batch * nsub;
-    const uint32_t grid_group = (uint32_t)ctx->num_cus * 4;
+    const uint32_t grid_group = (uint32_t)ctx->num_cus * (group_big ? 2 : 4);
     // spans: one per work item and open-span break, plus the rounds of the sub-ranges that k_group has to split further (a round holds
     // K3_PRESPLIT / 2 .. K3_PRESPLIT records unless the key bits are skewed; beyond the capacity the merge fails cleanly)
     const uint64_t span_cap = fb_cap * 2 + 4096 + (uint64_t)grid_group * K3_SLAB_SPAN + cap / (K3_PRESPLIT / 4);
@@ -1962,7 +1966,7 @@ SIMKA_EXPORT int simka_merge(simka_ctx *ctx) {
     co.entries = ctx->d_entries; co.groups = ctx->d_groups; co.spans = ctx->d_spans; co.cursors = ctx->d_cursors;
     co.cap_entries = csr_cap; co.cap_groups = csr_cap; co.cap_spans = span_cap; co.span_cap = pc.span_cap; co.huge = ctx->d_huge; co.cap_huge = huge_cap; co.glob = (ull *)ctx->d_stats; co.err = ctx->d_err;
     const uint32_t min_share = 2;   // -complex-dist would need 1 (ref: src/SimkaMerge.cpp:1317)
-    const size_t lds_group = SIMKA_LDS_HEAD + (size_t)K3_TABLE * 8 + (size_t)K3_CAP * 8 + (size_t)K3_TABLE * 6 + (size_t)K3_CAP * 2 + (size_t)K3_STACK * 16;
+    const size_t lds_group = SIMKA_LDS_HEAD + ((size_t)K3_TABLE * 8 + (size_t)K3_CAP * 8 + (size_t)K3_TABLE * 6 + (size_t)K3_CAP * 2) * g_mul + (size_t)K3_STACK * 16;
     ull *acc = (ull *)ctx->d_stats + stats_off_acc(N, 0);
 
     uint64_t pb = 0;
@@ -1983,8 +1987,8 @@ SIMKA_EXPORT int simka_merge(simka_ctx *ctx) {
                                        b_abs, b_rows, ctx->d_err);
                 });
             launch_timed(ctx, KID_GROUP, [&] {
-                hipLaunchKernelGGL(k_group, dim3(std::max<uint32_t>(32u, std::min<uint32_t>((np * 4u + 31u) / 32u * 32u, grid_group / 32u * 32u))), dim3(K3_BLOCK), lds_group, ctx->stream, in, (const ull *)b_abs,
-                                   (const uint16_t *)b_rows, np, key, min_share, co);
+                hipLaunchKernelGGL(group_big ? k_group<2 * K3_BLOCK> : k_group<K3_BLOCK>, dim3(std::max<uint32_t>(32u, std::min<uint32_t>((np * 4u + 31u) / 32u * 32u, grid_group / 32u * 32u))),
+                                   dim3(group_big ? 2 * K3_BLOCK : K3_BLOCK), lds_group, ctx->stream, in, (const ull *)b_abs, (const uint16_t *)b_rows, np, key, min_share, co);
             });
             if (simka_exp_knob("SIMKA_DEBUG_MERGE")) {
                 ull cur[4]; HIPCHK(hipMemcpyAsync(cur, ctx->d_cursors, 32, hipMemcpyDeviceToHost, ctx->stream)); HIPCHK(hipStreamSynchronize(ctx->stream));

@@ -16,10 +16,10 @@
 // K3  k_segment_rows / k_group
 #define SIMKA_SEG_BITS 4       // a (sample, partition) segment of the arena is ordered by the top 4 bits of the key (SKM_SORT_BITS of the count kernels)
 #define SIMKA_SEG_BLOCKS (1 << SIMKA_SEG_BITS)
-#define K3_BLOCK 256
-#define K3_CAP 1024           // records hashed per round = entries per span
-#define K3_TARGET 940         // mean records per sub-range the merge aims for (sub-range bits t)
-#define K3_PRESPLIT 1024      // a sub-range above this is split on one more key bit before hashing
+#define K3_BLOCK 256          // k_group<256>; k_group<512> (twice the records per round, twice the table) for more than 256 samples
+#define K3_CAP 1024           // records hashed per round = entries per span (x2 with 512 threads)
+#define K3_TARGET 940         // mean records per sub-range the merge aims for (sub-range bits t; x2 with 512 threads)
+#define K3_PRESPLIT 1024      // a sub-range above this is split on one more key bit before hashing (x2 with 512 threads)
 #define K3_STACK 72           // refinement stack of k_group: deeper than the 62 key bits
 #define K3_TABLE 2048         // = 2*K3_CAP slots
 #define K3_UNROLL 4           // K3_BLOCK*K3_UNROLL = K3_CAP: a whole sub-range in one batch of independent loads

@@ -200,9 +200,14 @@ k_segment_rows(SimkaMergeIn in, SimkaKeyCfg cfg, uint64_t part_begin, uint32_t n
 // Persistent blocks (3 per CU) walk the sub-ranges; output space (entries / groups / span slots) is
 // reserved in slabs, one global atomic per slab instead of three per sub-range.
 // --------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(K3_BLOCK)
+// GB: threads per block.  256 (records per round GCAP = 1024, table 2048 slots, four blocks per CU) up to 256 samples; 512 (2048 / 4096, two
+// blocks per CU) beyond: all samples of C5's 500 are then ONE tile -- the rows stay in registers, a sub-range is gathered once instead
+// of once per sample tile and is not split again on key bits (k_group on c5_50: 28.6 -> 15.5 ms)
+template <int GB>
+__global__ void __launch_bounds__(GB)
 k_group(SimkaMergeIn in, const ull *seg_abs, const uint16_t *rows, uint32_t np,
         SimkaKeyCfg cfg, uint32_t min_share, SimkaCsrOut o) {
+    constexpr int GCAP = GB * K3_UNROLL, GTAB = 2 * GCAP;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     ull *s_slab = (ull *)smem;                              // [6] ent pos/end, grp pos/end, span pos/end
     ull &s_ebase = *(ull *)(smem + 48);
@@ -213,23 +218,23 @@ k_group(SimkaMergeIn in, const ull *seg_abs, const uint16_t *rows, uint32_t np,
     uint32_t &s_nshared = *(uint32_t *)(smem + 76);
     int &s_sp = *(int *)(smem + 80);
     uint32_t &s_maxc = *(uint32_t *)(smem + 84);
-    uint32_t *tmp = (uint32_t *)(smem + 96);               // [K3_BLOCK/64]
+    uint32_t *tmp = (uint32_t *)(smem + 96);               // [GB/64]
     ull &s_open = *(ull *)(smem + 336);                    // slot of the block's open span (~0: none)
     uint32_t &s_open_nent = *(uint32_t *)(smem + 344);     // its entries / groups / largest count so far
     uint32_t &s_open_ngrp = *(uint32_t *)(smem + 348);
     uint32_t &s_open_maxc = *(uint32_t *)(smem + 352);
     uint32_t &s_soff = *(uint32_t *)(smem + 356);          // entry offset of this round inside its span
-    ull *tkeys = (ull *)(smem + SIMKA_LDS_HEAD);           // [K3_TABLE]
-    ull *rval = tkeys + K3_TABLE;                          // [K3_CAP]
-    uint16_t *scnt = (uint16_t *)(rval + K3_CAP);          // [K3_TABLE] group size (<= K3_CAP records per round: 16 bits, added through the 32-bit word)
-    uint32_t *gpk = (uint32_t *)(scnt + K3_TABLE);                       // [K3_TABLE] packed prefix: entries | groups << 20; later the fill cursor
-    uint16_t *rslot = (uint16_t *)(gpk + K3_TABLE);        // [K3_CAP]
-    ull *s_stack = (ull *)(rslot + K3_CAP);                // [2*K3_STACK] (selector bits, value) of the refinement DFS: one level per key bit
+    ull *tkeys = (ull *)(smem + SIMKA_LDS_HEAD);           // [GTAB]
+    ull *rval = tkeys + GTAB;                          // [GCAP]
+    uint16_t *scnt = (uint16_t *)(rval + GCAP);          // [GTAB] group size (<= GCAP records per round: 16 bits, added through the 32-bit word)
+    uint32_t *gpk = (uint32_t *)(scnt + GTAB);                       // [GTAB] packed prefix: entries | groups << 20; later the fill cursor
+    uint16_t *rslot = (uint16_t *)(gpk + GTAB);        // [GCAP]
+    ull *s_stack = (ull *)(rslot + GCAP);                // [2*K3_STACK] (selector bits, value) of the refinement DFS: one level per key bit
     // a tile of samples while the records are gathered (gpk is written after that): first record of the sample's slice in the arena, the
     // slices' exclusive prefix
-    ull *sbeg = (ull *)gpk;                                // [K3_BLOCK]
-    uint32_t *spre = (uint32_t *)(sbeg + K3_BLOCK);        // [K3_BLOCK + 1]
-    static_assert(K3_BLOCK * 12 + 4 <= K3_TABLE * 4, "the sample tile fits the prefix array it overlays");
+    ull *sbeg = (ull *)gpk;                                // [GB]
+    uint32_t *spre = (uint32_t *)(sbeg + GB);        // [GB + 1]
+    static_assert(GB * 12 + 4 <= GTAB * 4, "the sample tile fits the prefix array it overlays");
 
     const uint32_t tid = threadIdx.x;
     const uint32_t free_bits = cfg.W;                      // an over-full sub-range is split on the bits of simka_mix(key), a bijection on W bits: every bit fixed = one k-mer
@@ -238,7 +243,7 @@ k_group(SimkaMergeIn in, const ull *seg_abs, const uint16_t *rows, uint32_t np,
     __syncthreads();
 
     // Work item = a partition of the batch: its sub-ranges one after the other, so the lines of the N segments that two neighbouring
-    // slices share are touched by ONE block back to back.  The rows of the first K3_BLOCK samples live in registers for the whole
+    // slices share are touched by ONE block back to back.  The rows of the first GB samples live in registers for the whole
     // partition (thread s: sample s), the rows of the NEXT partition are loaded while this one is grouped.
     const uint32_t nsub = 1u << cfg.t, N = in.nb_samples;
     const uint32_t bw = SIMKA_SEG_BLOCKS >> cfg.t;         // key-prefix blocks per sub-range (t <= SIMKA_SEG_BITS)
@@ -261,15 +266,15 @@ k_group(SimkaMergeIn in, const ull *seg_abs, const uint16_t *rows, uint32_t np,
     uint32_t cur_pi = (bx / Q) * 8u + xcd, cur_j = 0;
     if (bx / Q >= nsets) cur_pi = np;
     if (cur_pi < np && tid < N) { const size_t g = (size_t)cur_pi * N + tid; nr0 = rows4[2 * g]; nr1 = rows4[2 * g + 1]; nab = seg_abs[g]; }
-    // f(key, sample << 32 | count) for every record of the sub-range: a tile of K3_BLOCK samples at a time -- their slices from the
+    // f(key, sample << 32 | count) for every record of the sub-range: a tile of GB samples at a time -- their slices from the
     // rows, an exclusive scan, then one record per thread (the thread finds its sample in the prefix table)
     bool tile_ready = false;       // (uniform) the tables of sample tile 0 are already in LDS (the scan that gave R): the first gather reuses them
     auto for_records = [&](auto &&f) {
-        for (uint32_t s0 = 0; s0 < N; s0 += K3_BLOCK) {
+        for (uint32_t s0 = 0; s0 < N; s0 += GB) {
             const uint32_t s = s0 + tid;
             uint32_t c = 0; ull b = 0;
             uint32_t tot;
-            if (s0 == 0 && tile_ready) { tile_ready = false; tot = spre[K3_BLOCK]; }
+            if (s0 == 0 && tile_ready) { tile_ready = false; tot = spre[GB]; }
             else {
             if (s0 == 0) {
                 const uint32_t lo = row_end(rr0, rr1, cur_j * bw - 1u), hi = row_end(rr0, rr1, (cur_j + 1u) * bw - 1u);      // (cur_j == 0: ~0u)
@@ -283,17 +288,17 @@ k_group(SimkaMergeIn in, const ull *seg_abs, const uint16_t *rows, uint32_t np,
             __syncthreads();           // (the tables of the tile before are done with)
             sbeg[tid] = b;
             uint32_t excl;
-            tot = block_excl_scan1<K3_BLOCK>(c, excl, tmp + 8);
+            tot = block_excl_scan1<GB>(c, excl, tmp + 8);
             spre[tid] = excl;
-            if (tid == 0) spre[K3_BLOCK] = tot;
+            if (tid == 0) spre[GB] = tot;
             __syncthreads();
             }
-            const uint32_t ns = N - s0 < (uint32_t)K3_BLOCK ? N - s0 : (uint32_t)K3_BLOCK;
-            for (uint32_t i0 = tid; i0 < tot; i0 += K3_BLOCK * K3_UNROLL) {
+            const uint32_t ns = N - s0 < (uint32_t)GB ? N - s0 : (uint32_t)GB;
+            for (uint32_t i0 = tid; i0 < tot; i0 += GB * K3_UNROLL) {
                 ull kk[K3_UNROLL], vv[K3_UNROLL];
 #pragma unroll
                 for (int u = 0; u < K3_UNROLL; u++) {
-                    const uint32_t i = i0 + (uint32_t)u * K3_BLOCK;
+                    const uint32_t i = i0 + (uint32_t)u * GB;
                     kk[u] = SIMKA_EMPTY_KEY; vv[u] = 0;
                     if (i < tot) {
                         uint32_t lo = 0, hi = ns;          // largest x with spre[x] <= i
@@ -319,29 +324,29 @@ k_group(SimkaMergeIn in, const ull *seg_abs, const uint16_t *rows, uint32_t np,
         const uint32_t this_j = cur_j;
         // records of the sub-range over all samples
         uint32_t R = 0;
-        if (N <= (uint32_t)K3_BLOCK) {      // one tile of samples: its scan is the gather's scan too
+        if (N <= (uint32_t)GB) {      // one tile of samples: its scan is the gather's scan too
             const uint32_t lo = row_end(rr0, rr1, this_j * bw - 1u), c = row_end(rr0, rr1, (this_j + 1u) * bw - 1u) - lo;
             __syncthreads();
             sbeg[tid] = rab + lo;
             uint32_t excl;
-            R = block_excl_scan1<K3_BLOCK>(c, excl, tmp + 8);
+            R = block_excl_scan1<GB>(c, excl, tmp + 8);
             spre[tid] = excl;
-            if (tid == 0) spre[K3_BLOCK] = R;
+            if (tid == 0) spre[GB] = R;
             __syncthreads();
             tile_ready = true;
         } else {
             uint32_t c = row_end(rr0, rr1, (this_j + 1u) * bw - 1u) - row_end(rr0, rr1, this_j * bw - 1u);
-            for (uint32_t s = tid + K3_BLOCK; s < N; s += K3_BLOCK) {
+            for (uint32_t s = tid + GB; s < N; s += GB) {
                 const uint16_t *row = rows + ((size_t)cur_pi * N + s) * SIMKA_SEG_BLOCKS;
                 c += (uint32_t)row[(this_j + 1u) * bw - 1u] - (this_j ? (uint32_t)row[this_j * bw - 1u] : 0u);
             }
             __syncthreads();
             uint32_t excl;
-            R = block_excl_scan1<K3_BLOCK>(c, excl, tmp + 8);
+            R = block_excl_scan1<GB>(c, excl, tmp + 8);
         }
         if (R == 0) continue;
         uint32_t e0 = 0;
-        while (((R >> e0) > K3_PRESPLIT) && e0 < free_bits) e0++;
+        while (((R >> e0) > GCAP) && e0 < free_bits) e0++;
         const uint32_t nvals0 = 1u << e0;
         for (uint32_t v0 = 0; v0 < nvals0; v0++) {
             __syncthreads();
@@ -357,8 +362,8 @@ k_group(SimkaMergeIn in, const ull *seg_abs, const uint16_t *rows, uint32_t np,
                     ulonglong2 *k2 = (ulonglong2 *)tkeys; uint4 *c4 = (uint4 *)scnt;
                     const ulonglong2 ek = make_ulonglong2(SIMKA_EMPTY_KEY, SIMKA_EMPTY_KEY);
                     const uint4 z = make_uint4(0, 0, 0, 0);
-                    for (uint32_t i = tid; i < K3_TABLE / 2; i += K3_BLOCK) k2[i] = ek;
-                    for (uint32_t i = tid; i < K3_TABLE / 8; i += K3_BLOCK) c4[i] = z;
+                    for (uint32_t i = tid; i < GTAB / 2; i += GB) k2[i] = ek;
+                    for (uint32_t i = tid; i < GTAB / 8; i += GB) c4[i] = z;
                 }
                 __syncthreads();
                 // ---- hash the records of this (sub-)range; K3_UNROLL independent loads per thread
@@ -367,12 +372,12 @@ k_group(SimkaMergeIn in, const ull *seg_abs, const uint16_t *rows, uint32_t np,
                 for_records([&](ull key, ull val) {
                     if (e && ((simka_mix(key, cfg.mask, cfg.xs) >> selshift) & ((1ull << e) - 1ull)) != val_) return;
                     const uint32_t idx = atomicAdd(&s_nrec, 1u);
-                    if (idx >= K3_CAP) { s_ovf = 1; return; }
-                    uint32_t slot = simka_slot_hash(key) & (K3_TABLE - 1u);
-                    for (;;) {   // 2*K3_CAP slots, at most K3_CAP records: always terminates
+                    if (idx >= GCAP) { s_ovf = 1; return; }
+                    uint32_t slot = simka_slot_hash(key) & (GTAB - 1u);
+                    for (;;) {   // 2*GCAP slots, at most GCAP records: always terminates
                         const ull prev = atomicCAS(&tkeys[slot], SIMKA_EMPTY_KEY, key);
                         if (prev == SIMKA_EMPTY_KEY || prev == key) break;
-                        slot = (slot + 1u) & (K3_TABLE - 1u);
+                        slot = (slot + 1u) & (GTAB - 1u);
                     }
                     atomicAdd((uint32_t *)scnt + (slot >> 1), 1u << ((slot & 1u) * 16u));
                     rslot[idx] = (uint16_t)slot;
@@ -385,7 +390,7 @@ k_group(SimkaMergeIn in, const ull *seg_abs, const uint16_t *rows, uint32_t np,
                 __syncthreads();
                 if (s_ovf) {
                     if (e >= free_bits) {
-                        // Every key bit is fixed: the selected records are ONE k-mer shared by more than K3_CAP samples.  Such a
+                        // Every key bit is fixed: the selected records are ONE k-mer shared by more than GCAP samples.  Such a
                         // group cannot be staged in LDS; it becomes a span of its own on the huge list (k_pairs_global).
                         const uint32_t s_ = s_nrec;
                         __syncthreads();
@@ -422,7 +427,7 @@ k_group(SimkaMergeIn in, const ull *seg_abs, const uint16_t *rows, uint32_t np,
                 if (nrec == 0) continue;
                 // ---- group geometry: one packed prefix over the table slots (entries | groups << 20)
                 uint32_t ndist = 0, nshared = 0;
-                for (uint32_t i = tid; i < K3_TABLE; i += K3_BLOCK) {
+                for (uint32_t i = tid; i < GTAB; i += GB) {
                     const uint32_t c = scnt[i];
                     if (c) ndist++;
                     if (c > 1) nshared++;
@@ -431,7 +436,7 @@ k_group(SimkaMergeIn in, const ull *seg_abs, const uint16_t *rows, uint32_t np,
                 if (ndist) atomicAdd(&s_ndist, ndist);
                 if (nshared) atomicAdd(&s_nshared, nshared);
                 __syncthreads();
-                const uint32_t tot = block_excl_scan<K3_BLOCK>(gpk, K3_TABLE, tmp);
+                const uint32_t tot = block_excl_scan<GB>(gpk, GTAB, tmp);
                 const uint32_t nent = tot & 0xfffffu, ngrp = tot >> 20;
                 if (ngrp == 0) continue;
                 if (tid == 0) {
@@ -458,13 +463,13 @@ k_group(SimkaMergeIn in, const ull *seg_abs, const uint16_t *rows, uint32_t np,
                 if (s_ovf == 2) continue;
                 const ull eb = s_ebase, gb = s_gbase;
                 const uint32_t soff = s_soff;
-                for (uint32_t i = tid; i < K3_TABLE; i += K3_BLOCK) {
+                for (uint32_t i = tid; i < GTAB; i += GB) {
                     const uint32_t c = scnt[i], g_ = gpk[i];
                     if (c >= min_share) o.groups[gb + (g_ >> 20)] = (((g_ & 0xfffffu) + soff) << 16) | c;    // start is relative to the span
                     gpk[i] = g_ & 0xfffffu;               // now: entry offset, advanced as fill cursor
                 }
                 __syncthreads();
-                for (uint32_t i = tid; i < nrec; i += K3_BLOCK) {
+                for (uint32_t i = tid; i < nrec; i += GB) {
                     const uint32_t slot = rslot[i];
                     if (scnt[slot] >= min_share) o.entries[eb + atomicAdd(&gpk[slot], 1u)] = rval[i];
                 }
@@ -478,7 +483,7 @@ k_group(SimkaMergeIn in, const ull *seg_abs, const uint16_t *rows, uint32_t np,
         if (s_nshared) atomicAdd(&o.glob[1], (ull)s_nshared);  // _nbSharedKmers    (:1319-1321)
     }
     // unused span slots of this block's last slab: mark empty
-    for (ull i = s_slab[4] + tid; i < s_slab[5]; i += K3_BLOCK) { SimkaSpan sp; sp.ebase = 0; sp.gbase = 0; sp.nent = 0; sp.ngrp = 0; sp.maxc = 0; sp.pad = 0; o.spans[i] = sp; }
+    for (ull i = s_slab[4] + tid; i < s_slab[5]; i += GB) { SimkaSpan sp; sp.ebase = 0; sp.gbase = 0; sp.nent = 0; sp.ngrp = 0; sp.maxc = 0; sp.pad = 0; o.spans[i] = sp; }
 }
 
 // --------------------------------------------------------------------------------------------
