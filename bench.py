@@ -134,7 +134,8 @@ def _gz_member(b):
 
 def e2e_from_fasta(wl, lib, torch, dev, max_samples=100, max_reads=1_000_000):
     """t_e2e of SURVEY 8(d): sequence files on disk -> distance-matrix CSVs through the C++ `simka` driver (process start, files read into
-    pinned memory, text parsed on the GPU -- simka_ingest_* --, count, merge, matrices, gz CSVs written), three legs:
+    small pinned staging buffers by the loader threads and uploaded by them, text parsed on the GPU -- simka_ingest_* --, count, merge,
+    matrices, gz CSVs written), three legs (runs 8 s apart: see driver()):
       * `tenth`: the workload at a tenth of its read depth (c3: 100 samples x 1M x 150 bp = 15.4 GB of FASTA, one file per sample when the
         temp directory has room); run twice (the second run has the files in the page cache) and once with -host-parse;
       * `full_depth`: the workload's own depth -- 10 distinct files, each listed by a tenth of the samples (the driver reads, parses and
@@ -208,6 +209,10 @@ def e2e_from_fasta(wl, lib, torch, dev, max_samples=100, max_reads=1_000_000):
             cmd.append("-simple-dist")
         if wl.get("complex"):
             cmd.append("-complex-dist")
+        # (untimed pause: the driver process of the run before left its device memory -- 100+ GB at C3's depth -- to the kernel driver, and a
+        # process that starts while that is still being reclaimed waits for it in its own allocations: back-to-back runs measured 7.5 s
+        # where runs ten seconds apart take 3.6 s)
+        time.sleep(float(os.environ.get("SIMKA_BENCH_E2E_PAUSE", "8")))
         t = time.perf_counter()
         r = subprocess.run(cmd + list(extra), stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
         dt = (time.perf_counter() - t) * 1e3

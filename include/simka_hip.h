@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define SIMKA_ABI_VERSION 6
+#define SIMKA_ABI_VERSION 7
 
 enum {
     SIMKA_OK = 0,
@@ -107,6 +107,11 @@ typedef struct simka_reads {
 int simka_ingest_begin(simka_ctx *ctx, uint32_t sample);
 int simka_ingest_text(simka_ctx *ctx, uint32_t sample, const char *text, uint64_t nb_bytes, int format, uint64_t *nb_reads, int *irregular);
 int simka_ingest_count(simka_ctx *ctx, uint32_t sample, uint64_t *nb_bases, uint64_t *nb_reads);
+/* The same with the text ALREADY in device memory (16-byte aligned, readable for nb_bytes; e.g. uploaded piecewise by loader threads with
+ * simka_device_upload while the kernels of other samples run -- the `simka` driver: the main thread then only launches kernels, the
+ * copies run on the DMA engines from small pinned staging buffers).  The buffer is read where it is and may be reused when the call
+ * returns.  (ABI 7) */
+int simka_ingest_text_device(simka_ctx *ctx, uint32_t sample, const void *d_text, uint64_t nb_bytes, int format, uint64_t *nb_reads, int *irregular);
 
 /* The 4 lines of count_synchro/<ID>.ok (ref: src/SimkaCount.cpp:303-317,355-368) + pre-filter counts. */
 typedef struct simka_sample_totals {
@@ -319,6 +324,11 @@ int simka_device_memory(int device, uint64_t *free_bytes, uint64_t *total_bytes)
 int simka_device_alloc(int device, uint64_t nb_bytes, void **p);
 int simka_device_free(int device, void *p);
 int simka_device_copy(int dst_device, void *dst, int src_device, const void *src, uint64_t nb_bytes);
+/* the CPUs on the device's NUMA node as the kernel lists them ("0-63,128-191"; "" if unknown): where a host should run the threads
+ * that feed the device and allocate their pinned staging memory (ABI 7) */
+int simka_device_cpulist(int device, char *buf, uint64_t buf_bytes);
+/* host -> device copy, synchronous, on a stream private to the calling thread: safe from several threads at once (ABI 7) */
+int simka_device_upload(int device, void *dst, const void *src_host, uint64_t nb_bytes);
 /* sizes chosen by the ctx (partition bits etc.), for DESIGN/bench reporting */
 int simka_get_geometry(simka_ctx *ctx, uint32_t *log2_level1, uint32_t *log2_level2, uint32_t *log2_subranges,
                        uint64_t *arena_capacity, uint64_t *csr_capacity);

@@ -30,7 +30,8 @@ try:
     size = n * R * (L + 4)
     base = [b.CLI_PATH, "-in", os.path.join(d, "in.txt"), "-out", os.path.join(d, "out"), "-out-tmp", os.path.join(d, "tmp"), "-kmer-size", str(k),
             "-abundance-min", "2", "-simple-dist", "-max-reads", "-1", "-verbose", "2"]
-    for extra in ([], ["-ingest-window", "8"], ["-ingest-window", "16"], ["-ingest-window", "24"], ["-ingest-window", "8"]) if len(sys.argv) <= 2 else [sys.argv[2:]]:
+    for extra in ([], [], ["-ingest-window", "8"], ["-ingest-host-upload"], ["-no-numa-bind"], []) if len(sys.argv) <= 2 else [sys.argv[2:]]:
+        time.sleep(float(os.environ.get('PAUSE', '10')))      # (the driver of the run before leaves 100+ GB of device memory to be reclaimed: back-to-back runs wait for it)
         t = time.time()
         r = subprocess.run(base + extra, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
         dt = time.time() - t
@@ -39,4 +40,7 @@ try:
             if ln.startswith("main thread") or ln.startswith("process:"):
                 print("   ", ln)
 finally:
-    shutil.rmtree(d, ignore_errors=True)
+    if os.environ.get("KEEP"):
+        print("kept", d)
+    else:
+        shutil.rmtree(d, ignore_errors=True)

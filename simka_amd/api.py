@@ -95,6 +95,9 @@ def load_library(build_if_missing=True):
         "simka_ingest_begin": (i32, [vp, u32]),
         "simka_ingest_text": (i32, [vp, u32, vp, u64, i32, C.POINTER(u64), C.POINTER(i32)]),
         "simka_ingest_count": (i32, [vp, u32, C.POINTER(u64), C.POINTER(u64)]),
+        "simka_ingest_text_device": (i32, [vp, u32, vp, u64, i32, C.POINTER(u64), C.POINTER(i32)]),
+        "simka_device_upload": (i32, [i32, vp, vp, u64]),
+        "simka_device_cpulist": (i32, [i32, C.c_char_p, u64]),
         "simka_sample_spectrum_info": (i32, [vp, u32, C.POINTER(SpectrumInfo)]),
         "simka_export_sample": (i32, [vp, u32, vp, vp, vp]),
         "simka_import_sample": (i32, [vp, u32, C.POINTER(SampleTotals), vp, u64, vp, vp, u64]),

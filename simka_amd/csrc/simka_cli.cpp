@@ -7,6 +7,8 @@
 // simka_merge() once; on G GPUs the samples are spread over the GPUs for counting, their spectra
 // exchanged by partition range, and the GPUs' pair accumulators summed.
 #include <errno.h>
+#include <fcntl.h>
+#include <sched.h>
 #include <math.h>
 #include <stdint.h>
 #include <stdio.h>
@@ -49,7 +51,10 @@ struct Options {
     bool same_gpu = false;              // new (tests): all -nb-gpus contexts on GPU -gpu
     bool mapped_arenas = false;         // new: -nb-gpus on distinct devices with lazily mapped arenas (default: plain allocations until a multi-GPU box has run the mapped path)
     int ingest_window = 0;              // new: samples whose text is in flight between the reader threads and the GPU (0 = auto)
-    long long ingest_chunk = 1ll << 30; // new: bytes of a file handed to the device-side parser at a time (cut at record boundaries)
+    long long ingest_chunk = 0;         // new: bytes of a file handed to the device-side parser at a time (cut at record boundaries); 0 = 3 GiB when the
+                                        // loader threads upload the text themselves (one GPU), 1 GiB of pinned memory per piece otherwise
+    bool numa_bind = true;              // new: run on the CPUs of the GPU's NUMA node (the loader threads' staging memory is then local to it)
+    bool host_upload = false;           // new: the text goes through whole-file pinned buffers and the MAIN thread copies it (the round-3 route; -nb-gpus uses it)
     bool host_parse = false;            // new: parse + pack every input on the host (default: plain-text inputs without read policies are parsed on the GPU)
     bool host_spectra = false;          // new: -nb-gpus keeps the spectra in host memory between count and merge (the round-2 route)
     bool gpu_allreduce = false;         // new: -nb-gpus combines the merges' accumulators with one RCCL all-reduce instead of summing them on the host
@@ -143,6 +148,8 @@ Options parse_args(int argc, char **argv) {
         else if (a == "-gpu-allreduce") o.gpu_allreduce = true;
         else if (a == "-host-parse") o.host_parse = true;
         else if (a == "-ingest-window") o.ingest_window = atoi(need(i).c_str());
+        else if (a == "-ingest-host-upload") o.host_upload = true;
+        else if (a == "-no-numa-bind") o.numa_bind = false;
         else if (a == "-ingest-chunk") o.ingest_chunk = std::min<long long>(std::max<long long>(64, atoll(need(i).c_str())), 0xf0000000ll);
         else if (a == "-merge-ranges") o.merge_ranges = atoi(need(i).c_str());
         else if (a == "-solid-capacity") o.solid_capacity = atoll(need(i).c_str());
@@ -341,12 +348,57 @@ private:
 
 typedef PinnedBuf<uint64_t> PinnedWords;
 
+// Device buffers for the text of the files (one GPU): recycled like the pinned host buffers -- a hipMalloc / hipFree per piece would
+// synchronise the device under the kernels of the samples before.
+class DevPool {
+public:
+    static DevPool &get() { static DevPool p; return p; }
+    void *take(int device, size_t bytes, size_t &cap) {
+        {
+            std::lock_guard<std::mutex> g(m_);
+            size_t best = free_.size();
+            for (size_t i = 0; i < free_.size(); i++)
+                if (free_[i].device == device && free_[i].cap >= bytes && free_[i].cap / 4 <= bytes + (1u << 20) && (best == free_.size() || free_[i].cap < free_[best].cap)) best = i;
+            if (best != free_.size()) { Block b = free_[best]; free_.erase(free_.begin() + (long)best); idle_ -= b.cap; cap = b.cap; return b.p; }
+        }
+        void *p = nullptr;
+        cap = (bytes + (1u << 20)) & ~(size_t)((1u << 20) - 1);
+        if (simka_device_alloc(device, cap, &p) != SIMKA_OK) { cap = 0; return nullptr; }
+        return p;
+    }
+    void give(int device, void *p, size_t cap) {
+        if (!p) return;
+        {
+            std::lock_guard<std::mutex> g(m_);
+            if (free_.size() < 256 && idle_ + cap <= max_idle_) { free_.push_back(Block{p, cap, device}); idle_ += cap; return; }
+        }
+        simka_device_free(device, p);
+    }
+    void set_max_idle(size_t b) { std::lock_guard<std::mutex> g(m_); max_idle_ = std::max(max_idle_, b); }
+private:
+    struct Block { void *p; size_t cap; int device; };
+    std::vector<Block> free_;
+    size_t idle_ = 0, max_idle_ = (size_t)2 << 30;
+    std::mutex m_;
+};
+struct DevText {
+    void *p = nullptr; size_t cap = 0, n = 0; int device = -1;
+    DevText() {}
+    DevText(const DevText &) = delete;
+    DevText &operator=(const DevText &) = delete;
+    DevText(DevText &&o) noexcept { p = o.p; cap = o.cap; n = o.n; device = o.device; o.p = nullptr; o.cap = 0; }
+    DevText &operator=(DevText &&o) noexcept { if (this != &o) { release(); p = o.p; cap = o.cap; n = o.n; device = o.device; o.p = nullptr; o.cap = 0; } return *this; }
+    ~DevText() { release(); }
+    void release() { if (p) DevPool::get().give(device, p, cap); p = nullptr; cap = 0; }
+};
+
 struct Packed {
     PinnedWords words, offsets;
     uint64_t nb_bases = 0, nb_frag = 0, nb_reads = 0;
     // device-side ingest (simka_ingest_*): the files' bytes as they are, parsed on the GPU
     bool raw = false;
     std::vector<PinnedBuf<char>> texts;
+    std::vector<DevText> dtexts;          // ... or already in DEVICE memory, uploaded by the loader thread (load_sample_raw_device)
     std::vector<int> formats;             // 0 FASTA, 1 FASTQ
     std::vector<uint32_t> file_of;        // which file a piece belongs to (a FILE that delivers no read ends the sample)
 };
@@ -411,13 +463,13 @@ bool load_sample_raw(const Sample &s, const Options &o, uint64_t max_reads, Pack
         // as one text (32-bit offsets), and a pinned buffer of the whole file would be as large as the file.  FASTA: a piece ends before
         // the last line that starts with '>'; FASTQ (4-line records, which the device parser verifies): before the last line whose
         // number in the piece is a multiple of 4.  A record longer than a piece: the host parser takes the sample.
-        const size_t fsize = (size_t)st.st_size, chunk = (size_t)o.ingest_chunk;
+        const size_t fsize = (size_t)st.st_size, chunk = (size_t)(o.ingest_chunk > 0 ? o.ingest_chunk : (1ll << 30));
         size_t done = 0, carry = 0;
         int fmt = -1;
         PinnedBuf<char> cur;
         bool first = true;
         while (first || done < fsize) {
-            if (carry * 2 > chunk) { fclose(fp); return false; }       // a record about as long as a piece: the host parser takes the sample (reading on in ever smaller steps would copy the carry every time)
+            if (carry + std::max<size_t>(64, chunk / 16) > chunk) { fclose(fp); return false; }       // a record about as long as a piece: the host parser takes the sample (reading on in ever smaller steps would copy the carry every time)
             const size_t want = std::min(chunk - carry, fsize - done);
             PinnedBuf<char> buf;
             buf.resize(carry + want + 1);
@@ -463,6 +515,95 @@ bool load_sample_raw(const Sample &s, const Options &o, uint64_t max_reads, Pack
     return true;
 }
 
+// The same for ONE GPU, without the whole-file pinned buffers: the loader thread reads the file 16 MiB at a time into a small pinned
+// staging buffer of its own and uploads every block straight into a device buffer (simka_device_upload: a stream per thread), so
+// the copies of all loader threads run on the DMA engines under the kernels of the samples before, the main thread only launches
+// kernels (simka_ingest_text_device), and the pinned memory of the process is a few staging buffers -- pinning runs at 4 - 6 GB/s for
+// the whole process and a piece in flight had to be pinned first (scripts/ubench/read_rate.hip).  Pieces of at most -ingest-chunk
+// bytes (3 GiB) end at a record boundary, looked for in the LAST staging block of the piece (a longer record: the host parser).
+bool load_sample_raw_device(const Sample &s, const Options &o, uint64_t max_reads, int device, Packed &out) {
+    if (max_reads || o.min_read_size || o.min_shannon != 0) return false;
+    std::vector<const std::string *> files;
+    for (auto &part : s.parts) for (auto &fn : part) files.push_back(&fn);
+    const size_t nparts = std::max<size_t>(1, s.parts.size());
+    const size_t per_part = files.size() / nparts;
+    if (files.empty() || per_part == 0) return false;
+    out = Packed();
+    out.raw = true;
+    const size_t chunk = (size_t)(o.ingest_chunk > 0 ? o.ingest_chunk : (3ll << 30));
+    const size_t S = std::min<size_t>((size_t)16 << 20, chunk);      // (small blocks: whatever else crosses the bus waits for at most one of them)
+    static thread_local PinnedBuf<char> stage;
+    if (stage.size() < S + 16) stage.resize(S + 16);
+    auto count_nl = [](const char *q, size_t n) { size_t c = 0; for (const char *e = q + n; (q = (const char *)memchr(q, '\n', (size_t)(e - q))) != nullptr; q++) c++; return c; };
+    for (size_t f = 0; f < nparts * per_part; f++) {
+        const int fd = open(files[f]->c_str(), O_RDONLY);
+        if (fd < 0) return false;
+        struct stat st;
+        if (fstat(fd, &st) != 0 || !S_ISREG(st.st_mode)) { close(fd); return false; }
+        const size_t fsize = (size_t)st.st_size;
+        size_t done = 0;
+        int fmt = -1;
+        bool first = true;
+        std::vector<char> carry;                 // what the piece before left behind its last whole record
+        for (;;) {
+            if (carry.size() + std::max<size_t>(64, chunk / 16) > chunk) { close(fd); return false; }       // a record about as long as a piece: the host parser
+            const size_t body = std::min(chunk - carry.size(), fsize - done), len = carry.size() + body;
+            const bool last_piece = done + body == fsize;
+            DevText dt;
+            dt.device = device;
+            dt.p = DevPool::get().take(device, len + 64, dt.cap);
+            if (!dt.p) { close(fd); return false; }
+            size_t at = 0, nl = 0, tail_off = 0, tail_len = 0;
+            if (!carry.empty()) {
+                memcpy(stage.data(), carry.data(), carry.size());
+                if (simka_device_upload(device, dt.p, stage.data(), carry.size()) != SIMKA_OK) { close(fd); return false; }
+                if (fmt == 1 && !last_piece) nl += count_nl(stage.data(), carry.size());
+                at = carry.size(); tail_off = 0; tail_len = carry.size();
+            }
+            for (size_t got_total = 0; got_total < body; ) {
+                const size_t want = std::min(S, body - got_total);
+                size_t got = 0;
+                while (got < want) { const ssize_t r = pread(fd, stage.data() + got, want - got, (off_t)(done + got_total + got)); if (r <= 0) break; got += (size_t)r; }
+                if (got != want) { close(fd); return false; }
+                if (first) {
+                    first = false;
+                    if (want >= 2 && (unsigned char)stage[0] == 0x1f && (unsigned char)stage[1] == 0x8b) { close(fd); return false; }       // gzip: the host inflates
+                    size_t p = 0;
+                    while (p < want && (stage[p] == '\n' || stage[p] == '\r')) p++;
+                    if (p == want && want == fsize) fmt = 0;      // only line ends: delivers no read (which ends the sample)
+                    else if (p == 0 && stage[0] == '>') fmt = 0;
+                    else if (p == 0 && stage[0] == '@') fmt = 1;
+                    if (fmt < 0) { close(fd); return false; }
+                }
+                if (fmt == 1 && !last_piece) nl += count_nl(stage.data(), want);
+                if (simka_device_upload(device, (char *)dt.p + at, stage.data(), want) != SIMKA_OK) { close(fd); return false; }
+                tail_off = at; tail_len = want; at += want; got_total += want;
+            }
+            if (first) { first = false; fmt = 0; }       // an empty file
+            done += body;
+            size_t cut = len;
+            carry.clear();
+            if (!last_piece) {
+                cut = 0;
+                if (fmt == 0) { for (size_t p = tail_len; p-- > 1; ) if (stage[p] == '>' && stage[p - 1] == '\n') { cut = tail_off + p; break; } }
+                else {
+                    size_t skip = nl % 4 + 1;           // the (nl mod 4 + 1)-th newline from the end closes the last whole record
+                    if (nl >= 4) for (size_t p = tail_len; p-- > 0; ) if (stage[p] == '\n' && --skip == 0) { cut = tail_off + p + 1; break; }
+                }
+                if (cut == 0) { close(fd); return false; }      // no record boundary in the last block of the piece
+                carry.assign(stage.data() + (cut - tail_off), stage.data() + tail_len);
+            }
+            dt.n = cut;
+            out.dtexts.push_back(std::move(dt));
+            out.formats.push_back(fmt);
+            out.file_of.push_back((uint32_t)f);
+            if (last_piece) break;
+        }
+        close(fd);
+    }
+    return true;
+}
+
 bool load_sample(const Sample &s, const Options &o, uint64_t max_reads, Packed &out) {
     out = Packed();
     if (max_reads == 0) {   // size the buffers once from the files (2-bit bases <= file bytes, x5 for gz): growing would copy pinned memory around
@@ -496,18 +637,23 @@ public:
     // skip[i] != 0: sample i is not read at all (-keep-tmp found its spectrum); get() returns immediately with an empty slot
     // raw: hand over the files' text where the device-side parser can take it (load_sample_raw), else parse + pack here
     SampleLoader(const std::vector<Sample> &samples, const Options &o, uint64_t max_reads, unsigned threads, unsigned window,
-                 const std::vector<char> &skip = std::vector<char>(), bool raw = false)
-        : samples_(samples), o_(o), max_reads_(max_reads), window_(std::max(1u, window)), slots_(samples.size()), state_(samples.size(), 0), skip_(skip), raw_(raw) {
+                 const std::vector<char> &skip = std::vector<char>(), bool raw = false, int raw_device = -1)
+        : samples_(samples), o_(o), max_reads_(max_reads), window_(std::max(1u, window)), slots_(samples.size()), state_(samples.size(), 0), skip_(skip), raw_(raw), raw_device_(raw_device) {
         // raw text: a file is only READ here (page cache -> pinned memory, ~3 GB/s per thread) -- eight samples in flight keep the GPU
         // fed, and their pinned buffers are recycled (pinning a buffer costs as much as filling it: 66 fresh 150-MB buffers cost seconds)
-        // (-ingest-window: measured on C3 at full depth, 154 GB listed: 8 samples in flight 10.3 s, 16: 14.0 s, 24: 17.6 s -- more readers
-        //  and more fresh pinned buffers slow the main thread's copies down more than they feed it)
+        // How many samples are in flight.  Measured on the MI355X box (scripts/ubench/read_rate.hip): threads read the page cache into
+        // WARM pinned buffers at 85 GB/s (8 threads) -- but pinning a fresh buffer runs at 4 - 6 GB/s for the whole process, and every
+        // byte in flight has to be pinned once (and unpinned when the process ends).  So the window is sized in BYTES: about 6 GB of text
+        // in flight, between 3 and 8 samples (C3 at full depth, 1.54-GB files: 4; a tenth of that depth: 8); -ingest-window overrides.
         if (raw_) {
-            window_ = std::min<size_t>(window_, o.ingest_window > 0 ? (size_t)o.ingest_window : 8);
             uint64_t bytes = 0;
             for (auto &sm : samples) for (auto &part : sm.parts) for (auto &fn : part) { struct stat st_; if (stat(fn.c_str(), &st_) == 0) bytes += (uint64_t)st_.st_size; }
-            // the pinned buffers of the window (+ 2 being handed over) stay in the pool between samples, up to 64 GB
-            PinnedPool::get().set_max_idle((size_t)std::min<uint64_t>((uint64_t)64 << 30, bytes / std::max<size_t>(1, samples.size()) * (window_ + 2) + ((uint64_t)2 << 30)));
+            const uint64_t per = std::max<uint64_t>(1, bytes / std::max<size_t>(1, samples.size()));
+            const size_t by_bytes = (size_t)std::min<uint64_t>(8, std::max<uint64_t>(3, ((uint64_t)6 << 30) / per));
+            window_ = std::min<size_t>(window_, o.ingest_window > 0 ? (size_t)o.ingest_window : by_bytes);
+            // the pinned buffers of the window (+ 2 being handed over) stay in the pool between samples
+            if (raw_device_ >= 0) DevPool::get().set_max_idle((size_t)std::min<uint64_t>((uint64_t)64 << 30, per * (window_ + 2) + ((uint64_t)1 << 30)));
+            else PinnedPool::get().set_max_idle((size_t)std::min<uint64_t>((uint64_t)64 << 30, per * (window_ + 2) + ((uint64_t)1 << 30)));
         }
         threads = std::max(1u, std::min<unsigned>(threads, (unsigned)std::min<size_t>(samples.size(), window_)));
         for (unsigned t = 0; t < threads; t++) workers_.emplace_back([this] { run(); });
@@ -540,7 +686,7 @@ private:
                 i = next_++;
             }
             Packed pk;
-            const bool ok = (i < skip_.size() && skip_[i]) ? true : ((raw_ && load_sample_raw(samples_[i], o_, max_reads_, pk)) || load_sample(samples_[i], o_, max_reads_, pk));
+            const bool ok = (i < skip_.size() && skip_[i]) ? true : ((raw_ && (raw_device_ >= 0 ? load_sample_raw_device(samples_[i], o_, max_reads_, raw_device_, pk) : load_sample_raw(samples_[i], o_, max_reads_, pk))) || load_sample(samples_[i], o_, max_reads_, pk));
             { std::lock_guard<std::mutex> g(m_); slots_[i] = std::move(pk); state_[i] = ok ? 1 : -1; }
             cv_.notify_all();
         }
@@ -553,6 +699,7 @@ private:
     std::vector<int> state_;
     std::vector<char> skip_;
     bool raw_ = false;
+    int raw_device_ = -1;               // >= 0: the loader threads upload the text to this device themselves
     std::vector<std::thread> workers_;
     std::mutex m_;
     std::condition_variable cv_;
@@ -818,16 +965,20 @@ int main(int argc, char **argv) {
         if (pkp->raw) {
             if ((rc = chk(simka_ingest_begin(c, index), "simka_ingest_begin")) != SIMKA_OK) return rc;
             bool irregular = false;
-            for (size_t f = 0; !irregular && f < pkp->texts.size(); f++) {
+            const bool on_dev = !pkp->dtexts.empty();
+            const size_t npieces = on_dev ? pkp->dtexts.size() : pkp->texts.size();
+            for (size_t f = 0; !irregular && f < npieces; f++) {
                 uint64_t nr = 0; int irr = 0;
-                if ((rc = chk(simka_ingest_text(c, index, pkp->texts[f].data(), pkp->texts[f].size(), pkp->formats[f], &nr, &irr), "simka_ingest_text")) != SIMKA_OK) return rc;
+                if (on_dev) rc = chk(simka_ingest_text_device(c, index, pkp->dtexts[f].p, pkp->dtexts[f].n, pkp->formats[f], &nr, &irr), "simka_ingest_text_device");
+                else rc = chk(simka_ingest_text(c, index, pkp->texts[f].data(), pkp->texts[f].size(), pkp->formats[f], &nr, &irr), "simka_ingest_text");
+                if (rc != SIMKA_OK) return rc;
                 irregular = irr != 0;
-                if (!irregular && nr == 0 && (f + 1 == pkp->texts.size() || pkp->file_of[f + 1] != pkp->file_of[f]) && (f == 0 || pkp->file_of[f - 1] != pkp->file_of[f]))
+                if (!irregular && nr == 0 && (f + 1 == npieces || pkp->file_of[f + 1] != pkp->file_of[f]) && (f == 0 || pkp->file_of[f - 1] != pkp->file_of[f]))
                     break;       // a FILE that delivers no read ends the sample (a file in several pieces has reads in every piece)
             }
             if (!irregular) {
                 rc = chk(simka_ingest_count(c, index, nullptr, nullptr), "simka_ingest_count");
-                if (rc == SIMKA_OK) { n_dev_parsed++; n_pieces += pkp->texts.size(); }
+                if (rc == SIMKA_OK) { n_dev_parsed++; n_pieces += npieces; }
                 return rc;
             }
             // something the device parser does not take (blank lines inside a file, multi-line FASTQ, ...): the host parser decides
@@ -845,8 +996,26 @@ int main(int argc, char **argv) {
     // ---- DIRECT: one GPU, every solid spectrum stays in its HBM arena; count, merge, download.
     // Returns SIMKA_ERR_NOMEM when the spectra do not fit the arena: the caller then takes the host-spectra path below.
     auto direct_run = [&]() -> int {
+        if (o.numa_bind) {
+            // The process moves to the CPUs next to the GPU before it starts its loader threads and pins their staging buffers: on the
+            // two-socket MI355X box a run whose threads happened to sit on the far socket took 7.6 s where a near one took 5 s.
+            char cl[4096];
+            cpu_set_t set; CPU_ZERO(&set);
+            int ncpu = 0;
+            if (simka_device_cpulist(device_of(0), cl, sizeof cl) == SIMKA_OK && cl[0]) {
+                for (const char *q = cl; *q; ) {
+                    char *e; const long a = strtol(q, &e, 10); long b = a;
+                    if (e == q) break;
+                    if (*e == '-') { q = e + 1; b = strtol(q, &e, 10); }
+                    for (long x = a; x <= b && x < CPU_SETSIZE; x++) { CPU_SET((int)x, &set); ncpu++; }
+                    q = *e == ',' ? e + 1 : e;
+                    if (*e != ',' ) break;
+                }
+                if (ncpu >= 4 && sched_setaffinity(0, sizeof set, &set) == 0 && o.verbose >= 2) std::cout << "process: bound to the " << ncpu << " CPUs next to GPU " << device_of(0) << " (" << cl << ")" << std::endl;
+            }
+        }
         simka_ctx *c = make_ctx(N, device_of(0));
-        SampleLoader loader(samples, o, max_reads, nthreads, nthreads + 2, reuse, !o.host_parse);
+        SampleLoader loader(samples, o, max_reads, nthreads, nthreads + 2, reuse, !o.host_parse, o.host_upload ? -1 : device_of(0));
         int rc = SIMKA_OK;
         auto soft = [&](int r, const char *what) { if (r == SIMKA_OK) return true; if (r != SIMKA_ERR_NOMEM) fatal(c, what); rc = r; return false; };
         double t_wait = 0, t_count = 0;        // -verbose 2: where the main thread spends its time

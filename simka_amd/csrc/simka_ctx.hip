@@ -1164,7 +1164,12 @@ SIMKA_EXPORT int simka_ingest_begin(simka_ctx *ctx, uint32_t sample) {
     return SIMKA_OK;
 }
 
-SIMKA_EXPORT int simka_ingest_text(simka_ctx *ctx, uint32_t sample, const char *text, uint64_t nb_bytes, int format, uint64_t *nb_reads, int *irregular) {
+// one word written by a kernel: a 4-byte hipMemcpy would queue on the host-to-device DMA engine behind the 64-MiB text blocks the
+// loader threads are uploading (the main thread then waits milliseconds for a few bytes: simka_ingest_text_device)
+__global__ void k_store_u32(uint32_t *p, uint32_t v) { *p = v; }
+__global__ void k_store_u64(ull *p, ull v) { *p = v; }
+
+static int ingest_text_impl(simka_ctx *ctx, uint32_t sample, const char *text, uint64_t nb_bytes, int format, uint64_t *nb_reads, int *irregular, bool on_device) {
     if (!ctx || (!text && nb_bytes) || !irregular) return SIMKA_ERR_INVALID;
     simka_ctx::Ingest *gp = nullptr; uint32_t li = 0;
     for (uint32_t l = 0; l < simka_ctx::MAX_LANES; l++) if (ctx->ing[l].open && ctx->ing[l].sample == sample) { gp = &ctx->ing[l]; li = l; }
@@ -1177,14 +1182,20 @@ SIMKA_EXPORT int simka_ingest_text(simka_ctx *ctx, uint32_t sample, const char *
     if (nb_bytes >= 0xfffffff0ull) { *irregular = 1; return SIMKA_OK; }        // 32-bit line offsets
     HIPCHK(hipSetDevice(ctx->cfg.device));
     const hipStream_t st = ctx->copy_stream;
-    int rc = ensure_cap(ctx, &g.d_text, &g.text_cap, nb_bytes + 64); if (rc) return rc;
-    HIPCHK(hipMemcpyAsync(g.d_text, text, nb_bytes, hipMemcpyHostToDevice, st));
+    int rc;
+    // the text: copied into the lane's buffer -- or, already on the device (simka_ingest_text_device), parsed where it is
+    unsigned char *const d_text = on_device ? (unsigned char *)const_cast<char *>(text) : nullptr;
+    if (!on_device) {
+        rc = ensure_cap(ctx, &g.d_text, &g.text_cap, nb_bytes + 64); if (rc) return rc;
+        HIPCHK(hipMemcpyAsync(g.d_text, text, nb_bytes, hipMemcpyHostToDevice, st));
+    }
+    const unsigned char *const txt = on_device ? d_text : g.d_text;
     // ---- the line table
     const uint64_t ntiles = (nb_bytes + ING_TILE - 1) / ING_TILE;
     rc = ensure_cap(ctx, &g.d_tmp, &g.tmp_cap, ntiles + 16 + wscan_tmp_u32(ntiles) + 16); if (rc) return rc;
     uint32_t *d_cnt = g.d_tmp;
     HIPCHK(hipMemsetAsync(g.d_tot, 0, 32, st));
-    hipLaunchKernelGGL(k_ing_nl_count, dim3((uint32_t)ntiles), dim3(ING_BLOCK), 0, st, (const unsigned char *)g.d_text, nb_bytes, d_cnt);
+    hipLaunchKernelGGL(k_ing_nl_count, dim3((uint32_t)ntiles), dim3(ING_BLOCK), 0, st, txt, nb_bytes, d_cnt);
     uint32_t last_cnt = 0, last_off = 0;
     HIPCHK(hipMemcpyAsync(&last_cnt, d_cnt + ntiles - 1, 4, hipMemcpyDeviceToHost, st));
     HIPCHK(wscan_u32(d_cnt, d_cnt, ntiles, g.d_tmp + ntiles + 16, st));
@@ -1196,12 +1207,12 @@ SIMKA_EXPORT int simka_ingest_text(simka_ctx *ctx, uint32_t sample, const char *
     rc = ensure_cap(ctx, &g.d_lines, &g.lines_cap, block_need); if (rc) return rc;
     g.d_lb = g.d_lines + la; g.d_lf = g.d_lb + la;
     uint32_t *d_lbo = g.d_lf + la, *d_scan = d_lbo + la;
-    hipLaunchKernelGGL(k_ing_nl_fill, dim3((uint32_t)ntiles), dim3(ING_BLOCK), 0, st, (const unsigned char *)g.d_text, nb_bytes, (const uint32_t *)d_cnt, g.d_lines);
+    hipLaunchKernelGGL(k_ing_nl_fill, dim3((uint32_t)ntiles), dim3(ING_BLOCK), 0, st, txt, nb_bytes, (const uint32_t *)d_cnt, g.d_lines);
     const uint32_t sentinel = (uint32_t)nb_bytes + 1u;
-    HIPCHK(hipMemcpyAsync(g.d_lines + nlines, &sentinel, 4, hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(k_store_u32, dim3(1), dim3(1), 0, st, g.d_lines + nlines, sentinel);
     // ---- per line: bases, fragments that start in it, reads; prefix sums (the counts of the last line are read before the in-place scan)
     const uint32_t lgrid = (uint32_t)((nlines + ING_BLOCK - 1) / ING_BLOCK);
-    hipLaunchKernelGGL(k_ing_lines, dim3(lgrid), dim3(ING_BLOCK), 0, st, (const unsigned char *)g.d_text, (const uint32_t *)g.d_lines, (uint32_t)nlines, format, g.d_lb, g.d_lf, g.d_tot);
+    hipLaunchKernelGGL(k_ing_lines, dim3(lgrid), dim3(ING_BLOCK), 0, st, txt, (const uint32_t *)g.d_lines, (uint32_t)nlines, format, g.d_lb, g.d_lf, g.d_tot);
     uint32_t lastb = 0, lastf = 0, sumb = 0, sumf = 0;
     HIPCHK(hipMemcpyAsync(&lastf, g.d_lf + nlines - 1, 4, hipMemcpyDeviceToHost, st));
     HIPCHK(wscan_u32(g.d_lf, g.d_lf, nlines, d_scan, st));
@@ -1222,12 +1233,20 @@ SIMKA_EXPORT int simka_ingest_text(simka_ctx *ctx, uint32_t sample, const char *
     if (g.nb_bases == 0) HIPCHK(hipMemsetAsync(ctx->d_reads[li], 0, words_need * 8, st));
     else HIPCHK(hipMemsetAsync(ctx->d_reads[li] + words_now, 0, (words_need - words_now) * 8, st));      // (the last word so far keeps its bases: its upper bits are zero)
     if (fbases)
-        hipLaunchKernelGGL(k_ing_pack, dim3(lgrid), dim3(ING_BLOCK), 0, st, (const unsigned char *)g.d_text, (const uint32_t *)g.d_lines, (uint32_t)nlines, format, (const uint32_t *)g.d_lb,
+        hipLaunchKernelGGL(k_ing_pack, dim3(lgrid), dim3(ING_BLOCK), 0, st, txt, (const uint32_t *)g.d_lines, (uint32_t)nlines, format, (const uint32_t *)g.d_lb,
                            (const uint32_t *)d_lbo, (const uint32_t *)g.d_lf, (ull)g.nb_bases, (ull)g.nb_frags, (ull *)ctx->d_reads[li], (ull *)ctx->d_offsets[li]);
     HIPCHK(hipGetLastError());
     g.nb_bases += fbases; g.nb_frags += ffrags; g.nb_reads += tot[0];
     HIPCHK(hipStreamSynchronize(st));          // the caller's text buffer is free again
     return SIMKA_OK;
+}
+
+SIMKA_EXPORT int simka_ingest_text(simka_ctx *ctx, uint32_t sample, const char *text, uint64_t nb_bytes, int format, uint64_t *nb_reads, int *irregular) {
+    return ingest_text_impl(ctx, sample, text, nb_bytes, format, nb_reads, irregular, false);
+}
+SIMKA_EXPORT int simka_ingest_text_device(simka_ctx *ctx, uint32_t sample, const void *d_text, uint64_t nb_bytes, int format, uint64_t *nb_reads, int *irregular) {
+    if (d_text && ((uintptr_t)d_text & 15u)) return ctx ? ctx->fail(SIMKA_ERR_INVALID, "simka_ingest_text_device: the text must be 16-byte aligned") : SIMKA_ERR_INVALID;
+    return ingest_text_impl(ctx, sample, (const char *)d_text, nb_bytes, format, nb_reads, irregular, true);
 }
 
 SIMKA_EXPORT int simka_ingest_count(simka_ctx *ctx, uint32_t sample, uint64_t *nb_bases, uint64_t *nb_reads) {
@@ -1244,7 +1263,7 @@ SIMKA_EXPORT int simka_ingest_count(simka_ctx *ctx, uint32_t sample, uint64_t *n
     r.nb_bases = g.nb_bases; r.nb_reads = g.nb_frags; r.nb_input_reads = g.nb_reads; r.on_device = 1; r.fixed_len = 0;
     if (g.nb_bases) {
         const ull end = g.nb_bases;
-        HIPCHK(hipMemcpyAsync(ctx->d_offsets[li] + g.nb_frags, &end, 8, hipMemcpyHostToDevice, ctx->copy_stream));
+        hipLaunchKernelGGL(k_store_u64, dim3(1), dim3(1), 0, ctx->copy_stream, (ull *)(ctx->d_offsets[li] + g.nb_frags), end);
         HIPCHK(hipStreamSynchronize(ctx->copy_stream));
         r.packed = ctx->d_reads[li]; r.offsets = ctx->d_offsets[li];
     }
@@ -2306,6 +2325,38 @@ SIMKA_EXPORT int simka_device_free(int device, void *p) {
     if (hipSetDevice(device) != hipSuccess) return SIMKA_ERR_HIP;
     return hipFree(p) == hipSuccess ? SIMKA_OK : SIMKA_ERR_HIP;
 }
+// the CPUs next to a device ("0-63,128-191": the kernel's local_cpulist of its PCI function), for a host that wants its loader threads and
+// its pinned staging memory on the GPU's NUMA node -- on a two-socket box the copies of threads on the far socket cross the
+// inter-socket link (the `simka` driver binds itself with this).  Empty string when the kernel does not say.
+SIMKA_EXPORT int simka_device_cpulist(int device, char *buf, uint64_t buf_bytes) {
+    if (!buf || buf_bytes < 2) return SIMKA_ERR_INVALID;
+    buf[0] = 0;
+    char bdf[64] = {0};
+    if (hipDeviceGetPCIBusId(bdf, (int)sizeof bdf, device) != hipSuccess) { (void)hipGetLastError(); return SIMKA_ERR_HIP; }
+    for (char *q = bdf; *q; q++) if (*q >= 'A' && *q <= 'Z') *q = (char)(*q - 'A' + 'a');
+    const std::string path = std::string("/sys/bus/pci/devices/") + bdf + "/local_cpulist";
+    FILE *f = fopen(path.c_str(), "r");
+    if (!f) return SIMKA_OK;
+    if (fgets(buf, (int)std::min<uint64_t>(buf_bytes, 1u << 20), f)) { size_t n = strlen(buf); while (n && (buf[n - 1] == '\n' || buf[n - 1] == ' ')) buf[--n] = 0; } else buf[0] = 0;
+    fclose(f);
+    return SIMKA_OK;
+}
+
+// host -> device, synchronous, on a stream private to the calling thread (several loader threads upload at once)
+SIMKA_EXPORT int simka_device_upload(int device, void *dst, const void *src_host, uint64_t nb_bytes) {
+    if (!nb_bytes) return SIMKA_OK;
+    if (!dst || !src_host) return SIMKA_ERR_INVALID;
+    static thread_local hipStream_t tl_stream = nullptr;
+    static thread_local int tl_device = -1;
+    if (hipSetDevice(device) != hipSuccess) return SIMKA_ERR_HIP;
+    if (!tl_stream || tl_device != device) {
+        if (hipStreamCreateWithFlags(&tl_stream, hipStreamNonBlocking) != hipSuccess) { tl_stream = nullptr; return SIMKA_ERR_HIP; }
+        tl_device = device;      // (a thread that changes device leaks one stream: the loader threads never do)
+    }
+    if (hipMemcpyAsync(dst, src_host, nb_bytes, hipMemcpyHostToDevice, tl_stream) != hipSuccess) return SIMKA_ERR_HIP;
+    return hipStreamSynchronize(tl_stream) == hipSuccess ? SIMKA_OK : SIMKA_ERR_HIP;
+}
+
 SIMKA_EXPORT int simka_device_copy(int dst_device, void *dst, int src_device, const void *src, uint64_t nb_bytes) {
     if (nb_bytes == 0) return SIMKA_OK;
     if (!dst || !src) return SIMKA_ERR_INVALID;
