@@ -645,7 +645,11 @@ public:
         // WARM pinned buffers at 85 GB/s (8 threads) -- but pinning a fresh buffer runs at 4 - 6 GB/s for the whole process, and every
         // byte in flight has to be pinned once (and unpinned when the process ends).  So the window is sized in BYTES: about 6 GB of text
         // in flight, between 3 and 8 samples (C3 at full depth, 1.54-GB files: 4; a tenth of that depth: 8); -ingest-window overrides.
-        if (raw_) {
+        // (.gz inputs are inflated and parsed by these threads, one sample each: there the window stays as wide as the thread pool)
+        size_t ngz = 0, nfiles_ = 0;
+        for (auto &sm : samples) for (auto &part : sm.parts) for (auto &fn : part) { nfiles_++; if (fn.size() > 3 && fn.compare(fn.size() - 3, 3, ".gz") == 0) ngz++; }
+        const bool text_inputs = raw_ && ngz * 2 <= nfiles_;
+        if (text_inputs) {
             uint64_t bytes = 0;
             for (auto &sm : samples) for (auto &part : sm.parts) for (auto &fn : part) { struct stat st_; if (stat(fn.c_str(), &st_) == 0) bytes += (uint64_t)st_.st_size; }
             const uint64_t per = std::max<uint64_t>(1, bytes / std::max<size_t>(1, samples.size()));
