@@ -128,6 +128,8 @@ def cpu_baseline(wl, lib, torch, dev, seconds_budget=15.0):
 
 def _gz_member(b):
     import zlib
+    if not isinstance(b, (bytes, bytearray)):
+        b = memoryview(np.ascontiguousarray(b)).cast("B")
     c = zlib.compressobj(1, zlib.DEFLATED, 31)
     return c.compress(b) + c.flush()
 
@@ -143,7 +145,6 @@ def e2e_from_fasta(wl, lib, torch, dev, max_samples=100, max_reads=1_000_000):
       * `fastq_gz`: the tenth-depth reads as .fastq.gz (what real metagenomes look like): gzip goes through the host parser
         (inflate + parse + 2-bit pack on the driver's worker threads).
     The top-level keys (ms, fasta_GBps ...) are the `tenth` leg's, as in round 3."""
-    import multiprocessing
     import shutil
     import subprocess
     import tempfile
@@ -171,7 +172,10 @@ def e2e_from_fasta(wl, lib, torch, dev, max_samples=100, max_reads=1_000_000):
         sub = dict(wl, n=D, reads=R)
         _, reads = gen_device_samples(lib, torch, sub, dev)
         paths = []
-        pool = multiprocessing.Pool(min(64, os.cpu_count() or 1)) if kind == "fastq_gz" else None
+        # (threads, not processes: zlib releases the GIL, and forking / pickling out of a process that holds 40 GB of device state took
+        # nine minutes for these 3 GB)
+        import concurrent.futures
+        pool = concurrent.futures.ThreadPoolExecutor(min(64, os.cpu_count() or 1)) if kind == "fastq_gz" else None
         for s in range(D):
             asc = ascii_reads(reads[s], R)
             reads[s] = None
@@ -186,7 +190,7 @@ def e2e_from_fasta(wl, lib, torch, dev, max_samples=100, max_reads=1_000_000):
                 rec[:, 3 + L] = ord("\n"); rec[:, 4 + L] = ord("+"); rec[:, 5 + L] = ord("\n"); rec[:, 6 + L: 6 + 2 * L] = ord("I"); rec[:, 6 + 2 * L] = ord("\n")
                 raw = rec.cpu().numpy()
                 rows = max(1, R // 64)
-                parts = pool.map(_gz_member, [raw[r0: r0 + rows].tobytes() for r0 in range(0, R, rows)])      # concatenated gzip members
+                parts = list(pool.map(_gz_member, [raw[r0: r0 + rows] for r0 in range(0, R, rows)]))      # concatenated gzip members
                 path = os.path.join(d, "%s%d.fastq.gz" % (tag, s))
                 with open(path, "wb") as f:
                     for m in parts:
@@ -194,7 +198,7 @@ def e2e_from_fasta(wl, lib, torch, dev, max_samples=100, max_reads=1_000_000):
             paths.append(path)
             del asc, rec
         if pool is not None:
-            pool.close()
+            pool.shutdown()
         del reads
         torch.cuda.empty_cache()
         return paths
@@ -226,7 +230,9 @@ def e2e_from_fasta(wl, lib, torch, dev, max_samples=100, max_reads=1_000_000):
         per_file = R * (L + 4)
         free = shutil.disk_usage(d).free
         D = n if free > 2.5 * n * per_file else min(n, 10)
+        mark("e2e: writing the tenth-depth FASTA files")
         paths = write_files(R, D, "fasta", "s")
+        mark("e2e: files written")
         ts = [driver(paths, "tenth")[0], driver(paths, "tenth")[0]]
         t_host, size = driver(paths, "tenth", ["-host-parse"])
         occ = float(n) * R * (L - k + 1)
@@ -237,7 +243,9 @@ def e2e_from_fasta(wl, lib, torch, dev, max_samples=100, max_reads=1_000_000):
         for p_ in paths:
             os.remove(p_)
         try:        # the tenth-depth reads as .fastq.gz, 10 distinct files
+            mark("e2e: tenth-depth leg done; writing .fastq.gz")
             gz = write_files(R, min(n, 10), "fastq_gz", "q")
+            mark("e2e: gz written")
             tg = [driver(gz, "gz")[0], driver(gz, "gz")[0]]
             gsize = sum(os.path.getsize(gz[s % len(gz)]) for s in range(n))
             out["fastq_gz"] = {"ms": min(tg), "gz_bytes": gsize, "text_bytes": float(n) * R * (2 * L + 7), "text_GBps": float(n) * R * (2 * L + 7) / (min(tg) * 1e-3) / 1e9,
@@ -250,7 +258,9 @@ def e2e_from_fasta(wl, lib, torch, dev, max_samples=100, max_reads=1_000_000):
         try:        # the workload's own depth, 10 distinct files
             Rf, Df = wl["reads"], min(n, 10)
             if Rf > R and shutil.disk_usage(d).free > 1.3 * Df * Rf * (L + 4):
+                mark("e2e: gz leg done; writing the full-depth files")
                 full = write_files(Rf, Df, "fasta", "f")
+                mark("e2e: full-depth files written")
                 tf = [driver(full, "full")[0], driver(full, "full")[0]]
                 fsize = sum(os.path.getsize(full[s % len(full)]) for s in range(n))
                 out["full_depth"] = {"ms": min(tf), "ms_first_run": tf[0], "fasta_bytes": fsize, "fasta_GBps": fsize / (min(tf) * 1e-3) / 1e9,
@@ -264,6 +274,16 @@ def e2e_from_fasta(wl, lib, torch, dev, max_samples=100, max_reads=1_000_000):
         return out
     finally:
         shutil.rmtree(d, ignore_errors=True)
+
+
+_T0 = time.perf_counter()
+
+
+def mark(what):
+    """coarse wall-clock marks on stderr: where a bench run spends its time"""
+    if os.environ.get("RANK", "0") == "0":
+        sys.stderr.write("[bench %7.1f s] %s\n" % (time.perf_counter() - _T0, what))
+        sys.stderr.flush()
 
 
 def main():
@@ -363,7 +383,9 @@ def main():
     n, R, L, k = wl["n"], wl["reads"], wl["L"], wl["k"]
     lib = simka_amd.load_library()
     need_all = any(m != "sample" for m in modes)
+    mark("generating the samples on the device")
     pool, reads = gen_device_samples(lib, torch, wl, dev, which=None if need_all else set(sdist.samples_of(rank, world, n)))
+    mark("samples ready")
     nb_bases = R * L
     kocc_per_sample = R * (L - k + 1)
     d_offsets = torch.arange(0, (R + 1) * L, L, dtype=torch.int64, device=dev) if args.offsets else None
@@ -425,6 +447,7 @@ def main():
             fence()
             two_ms = (time.perf_counter() - t0) * 1e3
             ctx.close()
+        mark("%s: two-stream pass done" % mode)
         # ---- (a) per-kernel times, one lane
         prof_steps = min(args.steps, args.prof_steps) if args.prof_steps else args.steps
         os.environ["SIMKA_LANES"] = "1"
@@ -442,6 +465,7 @@ def main():
         ctx.close()
         os.environ["SIMKA_LANES"] = str(max(1, args.lanes))
         dom = max(prof_all, key=lambda kk: prof_all[kk][1])
+        mark("%s: per-kernel pass done" % mode)
         # ---- (b) the timed region
         ctx = make_ctx()
         step = make_step(ctx)
@@ -456,6 +480,7 @@ def main():
         fence()
         dt = time.perf_counter() - t0
         ctx.profile_enable(False)
+        mark("%s: timed region done (%.1f ms per step)" % (mode, dt / args.steps * 1e3))
         if world > 1:
             tdt = torch.tensor([dt], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
             dist.all_reduce(tdt, op=dist.ReduceOp.MAX)
@@ -610,6 +635,7 @@ def main():
             if rank == 0:
                 print(json.dumps(out), flush=True)
             return
+        mark("line assembled")
         if world == 1 and not args.no_from_host and not args.offsets:
             # the same step with the packed reads in PINNED HOST memory: simka_count_sample(on_device = 0) copies sample i + 1 through the
             # copy stream into its lane's staging buffer while the kernels of sample i run on the other lane (library default: two lanes).
@@ -653,6 +679,7 @@ def main():
                 out["timing"]["step_ms_from_host"] = None
                 out["timing"]["step_from_host_note"] = "failed: %r" % (e,)
                 ctx = None
+        mark("from-host step done")
         if rank == 0 and world == 1 and not args.no_cpu_baseline:
             try:
                 out["cpu_baseline"] = cpu_baseline(wl, lib, torch, dev)
@@ -661,9 +688,11 @@ def main():
                                        "sample": "failed: %r" % (e,)}
         if ctx is not None:
             ctx.close()
+        mark("cpu baseline done")
         if rank == 0 and world == 1 and not args.no_e2e and not args.no_cpu_baseline:
             try:
                 out["timing"]["e2e_from_fasta"] = e2e_from_fasta(wl, lib, torch, dev)
+                mark("e2e legs done")
                 out["timing"]["e2e_from_fasta_ms"] = out["timing"]["e2e_from_fasta"]["ms"]
             except Exception as e:
                 out["timing"]["e2e_from_fasta"] = {"ms": None, "sample": "failed: %r" % (e,)}
