@@ -521,6 +521,10 @@ bool load_sample_raw(const Sample &s, const Options &o, uint64_t max_reads, Pack
 // kernels (simka_ingest_text_device), and the pinned memory of the process is a few staging buffers -- pinning runs at 4 - 6 GB/s for
 // the whole process and a piece in flight had to be pinned first (scripts/ubench/read_rate.hip).  Pieces of at most -ingest-chunk
 // bytes (3 GiB) end at a record boundary, looked for in the LAST staging block of the piece (a longer record: the host parser).
+// -verbose 2: where the loader threads of the upload route spend their time, summed over the threads (microseconds)
+static std::atomic<long long> g_ld_stage_us(0), g_ld_dev_us(0), g_ld_read_us(0), g_ld_up_us(0);
+static inline long long ld_now_us() { return std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+
 bool load_sample_raw_device(const Sample &s, const Options &o, uint64_t max_reads, int device, Packed &out) {
     if (max_reads || o.min_read_size || o.min_shannon != 0) return false;
     std::vector<const std::string *> files;
@@ -533,7 +537,7 @@ bool load_sample_raw_device(const Sample &s, const Options &o, uint64_t max_read
     const size_t chunk = (size_t)(o.ingest_chunk > 0 ? o.ingest_chunk : (3ll << 30));
     const size_t S = std::min<size_t>((size_t)16 << 20, chunk);      // (small blocks: whatever else crosses the bus waits for at most one of them)
     static thread_local PinnedBuf<char> stage;
-    if (stage.size() < S + 16) stage.resize(S + 16);
+    { const long long t0 = ld_now_us(); if (stage.size() < S + 16) stage.resize(S + 16); g_ld_stage_us += ld_now_us() - t0; }
     auto count_nl = [](const char *q, size_t n) { size_t c = 0; for (const char *e = q + n; (q = (const char *)memchr(q, '\n', (size_t)(e - q))) != nullptr; q++) c++; return c; };
     for (size_t f = 0; f < nparts * per_part; f++) {
         const int fd = open(files[f]->c_str(), O_RDONLY);
@@ -541,46 +545,71 @@ bool load_sample_raw_device(const Sample &s, const Options &o, uint64_t max_read
         struct stat st;
         if (fstat(fd, &st) != 0 || !S_ISREG(st.st_mode)) { close(fd); return false; }
         const size_t fsize = (size_t)st.st_size;
-        size_t done = 0;
+        // gzip: this thread inflates into its staging block and uploads the TEXT -- the GPU parses it like any other (the host parser
+        // behind load_sample saturates at ~16 threads and 4.8 GB/s of text; zlib scales with the threads)
+        unsigned char magic[2] = { 0, 0 };
+        const bool gz = fsize >= 2 && pread(fd, magic, 2, 0) == 2 && magic[0] == 0x1f && magic[1] == 0x8b;
+        gzFile gzf = nullptr;
+        if (gz) { gzf = gzopen(files[f]->c_str(), "rb"); if (!gzf) { close(fd); return false; } gzbuffer(gzf, 1 << 20); }
+        auto done_with = [&]() { if (gzf) gzclose(gzf); close(fd); };
+        size_t done = 0;                        // plain: bytes of the file read so far
+        bool eof = fsize == 0;
+        auto read_block = [&](char *dst, size_t want) -> long long {      // < 0: error
+            size_t got = 0;
+            if (gz) {
+                while (got < want) { const int r = gzread(gzf, dst + got, (unsigned)std::min<size_t>(want - got, (size_t)1 << 30)); if (r < 0) return -1; if (r == 0) { eof = true; break; } got += (size_t)r; }
+            } else {
+                const size_t lim = std::min(want, fsize - done);
+                while (got < lim) { const ssize_t r = pread(fd, dst + got, lim - got, (off_t)(done + got)); if (r <= 0) return -1; got += (size_t)r; }
+                done += got;
+                if (done == fsize) eof = true;
+            }
+            return (long long)got;
+        };
         int fmt = -1;
         bool first = true;
         std::vector<char> carry;                 // what the piece before left behind its last whole record
-        for (;;) {
-            if (carry.size() + std::max<size_t>(64, chunk / 16) > chunk) { close(fd); return false; }       // a record about as long as a piece: the host parser
-            const size_t body = std::min(chunk - carry.size(), fsize - done), len = carry.size() + body;
-            const bool last_piece = done + body == fsize;
+        for (size_t piece = 0;; piece++) {
+            if (carry.size() + std::max<size_t>(64, chunk / 16) > chunk) { done_with(); return false; }       // a record about as long as a piece: the host parser
+            // capacity of the piece: the rest of a plain file; for gzip an estimate of the text (6 x the compressed bytes) -- what does
+            // not fit goes to a further piece
+            const size_t cap = gz ? std::min(chunk, std::max<size_t>((size_t)64 << 20, 6 * fsize + ((size_t)16 << 20))) : std::min(chunk, carry.size() + (fsize - done));
+            const bool known_last = !gz && carry.size() + (fsize - done) <= chunk;
             DevText dt;
             dt.device = device;
-            dt.p = DevPool::get().take(device, len + 64, dt.cap);
-            if (!dt.p) { close(fd); return false; }
+            { const long long t0 = ld_now_us(); dt.p = DevPool::get().take(device, cap + 64, dt.cap); g_ld_dev_us += ld_now_us() - t0; }
+            if (!dt.p) { done_with(); return false; }
             size_t at = 0, nl = 0, tail_off = 0, tail_len = 0;
             if (!carry.empty()) {
                 memcpy(stage.data(), carry.data(), carry.size());
-                if (simka_device_upload(device, dt.p, stage.data(), carry.size()) != SIMKA_OK) { close(fd); return false; }
-                if (fmt == 1 && !last_piece) nl += count_nl(stage.data(), carry.size());
+                if (simka_device_upload(device, dt.p, stage.data(), carry.size()) != SIMKA_OK) { done_with(); return false; }
+                if (fmt == 1 && !known_last) nl += count_nl(stage.data(), carry.size());
                 at = carry.size(); tail_off = 0; tail_len = carry.size();
             }
-            for (size_t got_total = 0; got_total < body; ) {
-                const size_t want = std::min(S, body - got_total);
-                size_t got = 0;
-                while (got < want) { const ssize_t r = pread(fd, stage.data() + got, want - got, (off_t)(done + got_total + got)); if (r <= 0) break; got += (size_t)r; }
-                if (got != want) { close(fd); return false; }
+            while (at < cap && !eof) {
+                const long long tr0 = ld_now_us();
+                const long long got_ = read_block(stage.data(), std::min(S, cap - at));
+                g_ld_read_us += ld_now_us() - tr0;
+                if (got_ < 0) { done_with(); return false; }
+                const size_t got = (size_t)got_;
+                if (got == 0) break;
                 if (first) {
                     first = false;
-                    if (want >= 2 && (unsigned char)stage[0] == 0x1f && (unsigned char)stage[1] == 0x8b) { close(fd); return false; }       // gzip: the host inflates
                     size_t p = 0;
-                    while (p < want && (stage[p] == '\n' || stage[p] == '\r')) p++;
-                    if (p == want && want == fsize) fmt = 0;      // only line ends: delivers no read (which ends the sample)
+                    while (p < got && (stage[p] == '\n' || stage[p] == '\r')) p++;
+                    if (p == got && eof) fmt = 0;                 // only line ends: delivers no read (which ends the sample)
                     else if (p == 0 && stage[0] == '>') fmt = 0;
                     else if (p == 0 && stage[0] == '@') fmt = 1;
-                    if (fmt < 0) { close(fd); return false; }
+                    if (fmt < 0) { done_with(); return false; }
                 }
-                if (fmt == 1 && !last_piece) nl += count_nl(stage.data(), want);
-                if (simka_device_upload(device, (char *)dt.p + at, stage.data(), want) != SIMKA_OK) { close(fd); return false; }
-                tail_off = at; tail_len = want; at += want; got_total += want;
+                if (fmt == 1 && !known_last) nl += count_nl(stage.data(), got);
+                { const long long t0 = ld_now_us(); const int urc = simka_device_upload(device, (char *)dt.p + at, stage.data(), got); g_ld_up_us += ld_now_us() - t0; if (urc != SIMKA_OK) { done_with(); return false; } }
+                tail_off = at; tail_len = got; at += got;
             }
             if (first) { first = false; fmt = 0; }       // an empty file
-            done += body;
+            const bool last_piece = eof;
+            const size_t len = at;
+            if (len == 0 && piece > 0) break;            // (gzip: the text ended exactly where the piece before was full)
             size_t cut = len;
             carry.clear();
             if (!last_piece) {
@@ -590,7 +619,7 @@ bool load_sample_raw_device(const Sample &s, const Options &o, uint64_t max_read
                     size_t skip = nl % 4 + 1;           // the (nl mod 4 + 1)-th newline from the end closes the last whole record
                     if (nl >= 4) for (size_t p = tail_len; p-- > 0; ) if (stage[p] == '\n' && --skip == 0) { cut = tail_off + p + 1; break; }
                 }
-                if (cut == 0) { close(fd); return false; }      // no record boundary in the last block of the piece
+                if (cut == 0) { done_with(); return false; }      // no record boundary in the last block of the piece
                 carry.assign(stage.data() + (cut - tail_off), stage.data() + tail_len);
             }
             dt.n = cut;
@@ -599,7 +628,7 @@ bool load_sample_raw_device(const Sample &s, const Options &o, uint64_t max_read
             out.file_of.push_back((uint32_t)f);
             if (last_piece) break;
         }
-        close(fd);
+        done_with();
     }
     return true;
 }
@@ -645,19 +674,34 @@ public:
         // WARM pinned buffers at 85 GB/s (8 threads) -- but pinning a fresh buffer runs at 4 - 6 GB/s for the whole process, and every
         // byte in flight has to be pinned once (and unpinned when the process ends).  So the window is sized in BYTES: about 6 GB of text
         // in flight, between 3 and 8 samples (C3 at full depth, 1.54-GB files: 4; a tenth of that depth: 8); -ingest-window overrides.
-        // (.gz inputs are inflated and parsed by these threads, one sample each: there the window stays as wide as the thread pool)
+        // (.gz inputs: with one GPU the loader threads inflate them and upload the text -- zlib at ~0.3 GB/s of text per thread, so the
+        //  window stays wide, bounded by ~32 GB of device buffers; without that route they are inflated AND parsed here, one sample per
+        //  thread: the window stays as wide as the thread pool)
         size_t ngz = 0, nfiles_ = 0;
-        for (auto &sm : samples) for (auto &part : sm.parts) for (auto &fn : part) { nfiles_++; if (fn.size() > 3 && fn.compare(fn.size() - 3, 3, ".gz") == 0) ngz++; }
-        const bool text_inputs = raw_ && ngz * 2 <= nfiles_;
-        if (text_inputs) {
-            uint64_t bytes = 0;
-            for (auto &sm : samples) for (auto &part : sm.parts) for (auto &fn : part) { struct stat st_; if (stat(fn.c_str(), &st_) == 0) bytes += (uint64_t)st_.st_size; }
+        uint64_t bytes = 0, est_text = 0;
+        for (auto &sm : samples) for (auto &part : sm.parts) for (auto &fn : part) {
+            nfiles_++;
+            struct stat st_;
+            const uint64_t sz = stat(fn.c_str(), &st_) == 0 ? (uint64_t)st_.st_size : 0;
+            bytes += sz;
+            if (fn.size() > 3 && fn.compare(fn.size() - 3, 3, ".gz") == 0) { ngz++; est_text += 6 * sz + ((uint64_t)16 << 20); } else est_text += sz;
+        }
+        const bool mostly_gz = ngz * 2 > nfiles_;
+        if (raw_ && !mostly_gz) {
             const uint64_t per = std::max<uint64_t>(1, bytes / std::max<size_t>(1, samples.size()));
             const size_t by_bytes = (size_t)std::min<uint64_t>(8, std::max<uint64_t>(3, ((uint64_t)6 << 30) / per));
             window_ = std::min<size_t>(window_, o.ingest_window > 0 ? (size_t)o.ingest_window : by_bytes);
-            // the pinned buffers of the window (+ 2 being handed over) stay in the pool between samples
+            // the buffers of the window (+ 2 being handed over) stay in the pool between samples
             if (raw_device_ >= 0) DevPool::get().set_max_idle((size_t)std::min<uint64_t>((uint64_t)64 << 30, per * (window_ + 2) + ((uint64_t)1 << 30)));
             else PinnedPool::get().set_max_idle((size_t)std::min<uint64_t>((uint64_t)64 << 30, per * (window_ + 2) + ((uint64_t)1 << 30)));
+        } else if (raw_ && raw_device_ >= 0) {
+            const uint64_t per = std::max<uint64_t>(1, est_text / std::max<size_t>(1, samples.size()));
+            const size_t by_bytes = (size_t)std::max<uint64_t>(4, ((uint64_t)32 << 30) / per);
+            window_ = std::min<size_t>(window_, o.ingest_window > 0 ? (size_t)o.ingest_window : by_bytes);
+            DevPool::get().set_max_idle((size_t)std::min<uint64_t>((uint64_t)64 << 30, per * (window_ + 2) + ((uint64_t)1 << 30)));
+            // (measured on the 128-CPU node of the MI355X box, 100 x 57 MB of .fastq.gz: inflating takes 0.5 s per sample alone, 1.0 s with
+            //  32 threads, 2.4 s with 100 -- 4.3 s against 5.4 s end to end; -nb-cores overrides)
+            if (o.nb_cores <= 0) threads = std::min(threads, 32u);
         }
         threads = std::max(1u, std::min<unsigned>(threads, (unsigned)std::min<size_t>(samples.size(), window_)));
         for (unsigned t = 0; t < threads; t++) workers_.emplace_back([this] { run(); });
@@ -1056,6 +1100,8 @@ int main(int argc, char **argv) {
         if (rc == SIMKA_OK) soft(simka_merge(c), "simka_merge");
         if (rc == SIMKA_OK) soft(simka_stats_download(c, flat.data(), nw, nullptr), "simka_stats_download");
         if (o.verbose >= 2) std::cout << "ingest: " << n_dev_parsed << " samples parsed on the GPU (" << n_pieces << " pieces of text), " << N - n_dev_parsed << " on the host" << std::endl;
+        if (o.verbose >= 2 && g_ld_read_us.load()) std::cout << "loader threads (summed): staging buffers " << g_ld_stage_us.load() * 1e-6 << " s, device buffers " << g_ld_dev_us.load() * 1e-6
+                                                             << " s, reading / inflating " << g_ld_read_us.load() * 1e-6 << " s, uploading " << g_ld_up_us.load() * 1e-6 << " s" << std::endl;
         if (o.verbose >= 2) std::cout << "main thread: waiting for the loader " << t_wait << " s, ingest / count calls " << t_count << " s, draining the count kernels " << t3 - t2
                                       << " s, merge + download " << now() - t3 << " s (since the context: " << now() - t_begin << " s)" << std::endl;
         simka_destroy(c);

@@ -1507,8 +1507,8 @@ def test_cli_device_parse_equals_host_parse(gpu_required, tmp_path):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("chunk", [700, 5000])
-def test_cli_device_parse_in_pieces(gpu_required, tmp_path, chunk):
+@pytest.mark.parametrize("chunk,gz", [(700, False), (5000, False), (900, True), (100000, True)])
+def test_cli_device_parse_in_pieces(gpu_required, tmp_path, chunk, gz):
     """Large inputs reach the device-side parser in pieces cut at record boundaries (-ingest-chunk, 1 GiB by default): with pieces of a
     few hundred bytes every cut rule is exercised -- multi-line FASTA (cut before a header), FASTQ (cut on a line count that is a
     multiple of four, '@' in the qualities), several files per sample.  Same CSV bytes as the host parser."""
@@ -1527,14 +1527,25 @@ def test_cli_device_parse_in_pieces(gpu_required, tmp_path, chunk):
     with open(str(tmp_path / "c.fa"), "wb") as f:
         for i, s in enumerate(reads(90, 3)):
             f.write(b">c%d\n%s\n" % (i, s))
-    (tmp_path / "in.txt").write_text("A: a.fa\nB: b.fq\nC: c.fa , a.fa\nD: b.fq ; c.fa\n")
+    ext = ""
+    if gz:      # the same files gzipped (b.fq as two concatenated members): the loader threads inflate them, the GPU parses the text -- in pieces as well
+        ext = ".gz"
+        for name in ("a.fa", "b.fq", "c.fa"):
+            data = open(str(tmp_path / name), "rb").read()
+            with open(str(tmp_path / (name + ".gz")), "wb") as f:
+                if name == "b.fq":
+                    half = data.index(b"\n@q75\n") + 1
+                    f.write(gzip.compress(data[:half]) + gzip.compress(data[half:]))
+                else:
+                    f.write(gzip.compress(data))
+    (tmp_path / "in.txt").write_text("A: a.fa%s\nB: b.fq%s\nC: c.fa%s , a.fa%s\nD: b.fq%s ; c.fa%s\n" % ((ext,) * 6))
     args = ["-in", str(tmp_path / "in.txt"), "-out-tmp", str(tmp_path / "tmp"), "-simple-dist", "-kmer-size", "17", "-abundance-min", "1"]
     log = []
     dev = _run_cli(args + ["-ingest-chunk", str(chunk)], str(tmp_path / "o1"), log)
     host = _run_cli(args + ["-host-parse"], str(tmp_path / "o2"))
     import re
     m = re.search(r"ingest: (\d+) samples parsed on the GPU \((\d+) pieces of text\), (\d+) on the host", log[0])
-    assert m and int(m.group(1)) == 4 and int(m.group(3)) == 0 and int(m.group(2)) > 12, log[0][-600:]      # really in pieces, really on the GPU
+    assert m and int(m.group(1)) == 4 and int(m.group(3)) == 0 and int(m.group(2)) > (12 if chunk < 10000 else 5), log[0][-600:]      # really in pieces, really on the GPU
     assert sorted(dev) == sorted(host) and len(dev) >= 15
     for name in host:
         assert dev[name] == host[name], name
