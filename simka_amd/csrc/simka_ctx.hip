@@ -288,8 +288,10 @@ static SkmScanFn skm_scan_kernel(int wi, bool fixed, bool hist) {
 
 static int set_lds_attr(simka_ctx *ctx) {
     const int big = 160 * 1024;
-    HIPCHK(hipFuncSetAttribute((const void *)k_group<K3_BLOCK>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
-    HIPCHK(hipFuncSetAttribute((const void *)k_group<2 * K3_BLOCK>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
+    HIPCHK(hipFuncSetAttribute((const void *)k_group<K3_BLOCK, false>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
+    HIPCHK(hipFuncSetAttribute((const void *)k_group<2 * K3_BLOCK, false>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
+    HIPCHK(hipFuncSetAttribute((const void *)k_group<K3_BLOCK, true>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
+    HIPCHK(hipFuncSetAttribute((const void *)k_group<2 * K3_BLOCK, true>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
     HIPCHK(hipFuncSetAttribute((const void *)k_pairs<false, K4_BLOCK_BIG>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
     HIPCHK(hipFuncSetAttribute((const void *)k_pairs<false, K4_BLOCK_SMALL>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
     HIPCHK(hipFuncSetAttribute((const void *)k_pairs<true, K4_BLOCK_BIG>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
@@ -605,7 +607,7 @@ static int check_device_error(simka_ctx *ctx) {
     if (e & SIMKA_DEVERR_SAMPLE_TOO_BIG) return ctx->fail(SIMKA_ERR_OVERFLOW, "a sample holds more than 2^32 solid k-mers");
     if (e & SIMKA_DEVERR_GROUP_OVERFLOW) return ctx->fail(SIMKA_ERR_OVERFLOW, "merge: a sub-range could not be split below the LDS capacity");
     if (e & SIMKA_DEVERR_CSR_FULL) return ctx->fail(SIMKA_ERR_NOMEM, "merge: group buffer exhausted");
-    if (e & SIMKA_DEVERR_SEGMENT_TOO_BIG) return ctx->fail(SIMKA_ERR_OVERFLOW, "a partition of one sample holds more than 65535 solid k-mers (the merge index has 16-bit rows): raise log2_partitions (now %u; 0 = sized from max_kmers_per_sample)", ctx->key.pb);
+    // (SIMKA_DEVERR_SEGMENT_TOO_BIG is not an error: simka_merge finds the largest segment itself and takes 32-bit rows then)
     if (e & SIMKA_DEVERR_UNORDERED) return ctx->fail(SIMKA_ERR_INVALID, "merge: a spectrum is not ordered by key prefix inside its partitions (imported from another version?)");
     return SIMKA_OK;
 }
@@ -1913,13 +1915,17 @@ SIMKA_EXPORT int simka_merge(simka_ctx *ctx) {
     const uint64_t nparts = ctx->nparts;
 
     // records per partition over all samples -> host scan (also drives the batching)
+    HIPCHK(hipMemsetAsync(ctx->d_part_total + nparts, 0, 8, ctx->stream));
     launch_timed(ctx, KID_PART_TOTALS, [&] {
         hipLaunchKernelGGL(k_part_totals, dim3((uint32_t)((nparts + 255) / 256)), dim3(256), 0, ctx->stream, ctx->d_fcnt, N,
                            nparts, ctx->d_part_total);
     });
-    std::vector<ull> ptot(nparts), poff(nparts + 1);
-    HIPCHK(hipMemcpyAsync(ptot.data(), ctx->d_part_total, nparts * 8, hipMemcpyDeviceToHost, ctx->stream));
+    std::vector<ull> ptot(nparts + 1), poff(nparts + 1);
+    HIPCHK(hipMemcpyAsync(ptot.data(), ctx->d_part_total, (nparts + 1) * 8, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));
+    // A (sample, partition) segment beyond 65535 records (a small user-set log2_partitions; a hot partition): the 16-bit rows the count
+    // kernels left cannot index it -- every batch gets 32-bit rows from k_segment_rows<true> and k_group reads those (slower, rare).
+    const bool rows32 = ptot[nparts] > 0xffffull;
     ull total = 0, maxpart = 0, nonempty = 0;
     for (uint64_t p = 0; p < nparts; p++) { poff[p] = total; total += ptot[p]; maxpart = std::max(maxpart, ptot[p]); nonempty += ptot[p] ? 1 : 0; }
     poff[nparts] = total;
@@ -1947,7 +1953,7 @@ SIMKA_EXPORT int simka_merge(simka_ctx *ctx) {
     cap = std::max<uint64_t>(cap, maxpart);
     if (cap >= ((uint64_t)1 << 32)) cap = ((uint64_t)1 << 32) - 1;
     if (maxpart > cap) return ctx->fail(SIMKA_ERR_NOMEM, "simka_merge: one partition holds %llu records, more than the merge buffer", maxpart);
-    const uint64_t max_parts_batch = std::min<uint64_t>(nparts, std::min<uint64_t>((uint64_t)1 << 16, std::max<uint64_t>(1, ((uint64_t)1 << 26) / N)));
+    const uint64_t max_parts_batch = std::min<uint64_t>(nparts, std::min<uint64_t>((uint64_t)1 << 16, std::max<uint64_t>(1, ((uint64_t)1 << (rows32 ? 22 : 26)) / N)));
     const uint64_t fb_cap = max_parts_batch * nsub;
     const uint32_t grid_group = (uint32_t)ctx->num_cus * (group_big ? 2 : 4);
     // spans: one per work item and open-span break, plus the rounds of the sub-ranges that k_group has to split further (a round holds
@@ -1963,6 +1969,11 @@ SIMKA_EXPORT int simka_merge(simka_ctx *ctx) {
         ctx->merge_cap = cap;
     }
     const uint64_t seg_cap = max_parts_batch * N;
+    struct Rows32 { ull *abs = nullptr; uint4 *rows = nullptr; ~Rows32() { if (abs) (void)hipFree(abs); if (rows) (void)hipFree(rows); } } r32;
+    if (rows32) {
+        if (dev_alloc(&r32.abs, seg_cap) != hipSuccess || dev_alloc(&r32.rows, seg_cap * 4) != hipSuccess)
+            return ctx->fail(SIMKA_ERR_NOMEM, "simka_merge: cannot allocate the 32-bit segment rows (%llu segments)", (unsigned long long)seg_cap);
+    } else
     if (!ctx->seg_all && ctx->seg_cap < seg_cap) {
         if (ctx->d_seg_abs) HIPCHK(hipFree(ctx->d_seg_abs)); if (ctx->d_seg_rows) HIPCHK(hipFree(ctx->d_seg_rows));
         ctx->d_seg_abs = nullptr; ctx->d_seg_rows = nullptr;
@@ -1998,15 +2009,16 @@ SIMKA_EXPORT int simka_merge(simka_ctx *ctx) {
             const uint32_t nfb = np * nsub;
             HIPCHK(hipMemsetAsync(ctx->d_cursors, 0, 32, ctx->stream));
             // the index of the batch's segments: written by the count kernels, or built here (imported spectra; too many segments to keep all)
-            ull *b_abs = ctx->d_seg_abs + (ctx->seg_all ? pb * N : 0);
-            uint4 *b_rows = ctx->d_seg_rows + (ctx->seg_all ? pb * N * 2 : 0);
-            if (!ctx->seg_all || ctx->seg_dirty)
+            ull *b_abs = rows32 ? r32.abs : ctx->d_seg_abs + (ctx->seg_all ? pb * N : 0);
+            uint4 *b_rows = rows32 ? r32.rows : ctx->d_seg_rows + (ctx->seg_all ? pb * N * 2 : 0);
+            if (rows32 || !ctx->seg_all || ctx->seg_dirty)
                 launch_timed(ctx, KID_SEG_ROWS, [&] {
-                    hipLaunchKernelGGL(k_segment_rows, dim3((uint32_t)std::min<uint64_t>(((uint64_t)np * N + 3) / 4, (uint64_t)ctx->num_cus * 8)), dim3(256), 0, ctx->stream, in, key, pb, np,
+                    hipLaunchKernelGGL(rows32 ? k_segment_rows<true> : k_segment_rows<false>, dim3((uint32_t)std::min<uint64_t>(((uint64_t)np * N + 3) / 4, (uint64_t)ctx->num_cus * 8)), dim3(256), 0, ctx->stream, in, key, pb, np,
                                        b_abs, b_rows, ctx->d_err);
                 });
             launch_timed(ctx, KID_GROUP, [&] {
-                hipLaunchKernelGGL(group_big ? k_group<2 * K3_BLOCK> : k_group<K3_BLOCK>, dim3(std::max<uint32_t>(32u, std::min<uint32_t>((np * 4u + 31u) / 32u * 32u, grid_group / 32u * 32u))),
+                auto kg = group_big ? (rows32 ? k_group<2 * K3_BLOCK, true> : k_group<2 * K3_BLOCK, false>) : (rows32 ? k_group<K3_BLOCK, true> : k_group<K3_BLOCK, false>);
+                hipLaunchKernelGGL(kg, dim3(std::max<uint32_t>(32u, std::min<uint32_t>((np * 4u + 31u) / 32u * 32u, grid_group / 32u * 32u))),
                                    dim3(group_big ? 2 * K3_BLOCK : K3_BLOCK), lds_group, ctx->stream, in, (const ull *)b_abs, (const uint16_t *)b_rows, np, key, min_share, co);
             });
             if (simka_exp_knob("SIMKA_DEBUG_MERGE")) {

@@ -138,13 +138,18 @@ __device__ __forceinline__ void count_hist(const SimkaCountOut &o, uint32_t *lhi
 #endif
 
 // per-partition record totals over all samples (input of the host-side partition scan)
+// (part_total[nparts], zeroed by the caller: the largest (sample, partition) segment -- beyond 65535 records the merge index takes 32-bit rows)
 __global__ void __launch_bounds__(256)
 k_part_totals(const uint32_t *fcnt, uint32_t nb_samples, uint64_t nparts, ull *part_total) {
     const uint64_t p = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (p >= nparts) return;
-    ull s = 0;
-    for (uint32_t i = 0; i < nb_samples; i++) s += fcnt[(size_t)i * nparts + p];
-    part_total[p] = s;
+    ull s = 0; uint32_t mx = 0;
+    if (p < nparts) {
+        for (uint32_t i = 0; i < nb_samples; i++) { const uint32_t c = fcnt[(size_t)i * nparts + p]; s += c; mx = c > mx ? c : mx; }
+        part_total[p] = s;
+    }
+#pragma unroll
+    for (int o_ = 32; o_ > 0; o_ >>= 1) { const uint32_t t_ = __shfl_xor(mx, o_, 64); mx = t_ > mx ? t_ : mx; }
+    if ((threadIdx.x & 63u) == 0 && mx > 0xffffu) atomicMax(&part_total[nparts], (ull)mx);
 }
 
 // --------------------------------------------------------------------------------------------
@@ -156,6 +161,10 @@ k_part_totals(const uint32_t *fcnt, uint32_t nb_samples, uint64_t nparts, ull *p
 // first record in the arena.  Partition-major, so that a merge block reads the N rows of its partition as one run.
 // A segment that is not ordered (a spectrum imported from a foreign source) flags SIMKA_DEVERR_UNORDERED.
 // --------------------------------------------------------------------------------------------
+// ROW32: 32-bit block ends (four uint4 per row) for contexts in which a segment holds more than 65535 records -- a user-set small
+// log2_partitions, or a hot low-complexity partition counted by k_skm_count in rounds: the merge then rebuilds the rows of every batch
+// here and k_group reads the wide form.
+template <bool ROW32>
 __global__ void __launch_bounds__(256)
 k_segment_rows(SimkaMergeIn in, SimkaKeyCfg cfg, uint64_t part_begin, uint32_t np, ull *seg_abs, uint4 *rows, uint32_t *err) {
     const uint32_t lane = threadIdx.x & 63u;
@@ -171,7 +180,7 @@ k_segment_rows(SimkaMergeIn in, SimkaKeyCfg cfg, uint64_t part_begin, uint32_t n
 #pragma unroll
         for (uint32_t q = 0; q < SIMKA_SEG_BLOCKS; q++) e[q] = 0;
         uint32_t last = 0; bool bad = false;
-        if (n > 0xffffu && lane == 0) atomicOr(err, SIMKA_DEVERR_SEGMENT_TOO_BIG);
+        if (!ROW32 && n > 0xffffu && lane == 0) atomicOr(err, SIMKA_DEVERR_SEGMENT_TOO_BIG);
         for (uint32_t i0 = 0; i0 < n; i0 += 64u) {
             const bool v = i0 + lane < n;
             const uint32_t blk = v ? simka_key_hash32(in.solid_keys[b + i0 + lane]) >> (32u - SIMKA_SEG_BITS) : SIMKA_SEG_BLOCKS;     // (beyond the end: above every block)
@@ -184,10 +193,15 @@ k_segment_rows(SimkaMergeIn in, SimkaKeyCfg cfg, uint64_t part_begin, uint32_t n
         if (__ballot(bad)) { if (lane == 0) atomicOr(err, SIMKA_DEVERR_UNORDERED); }
         if (lane == 0) {
             seg_abs[g] = b;
-            uint4 r0, r1;
-            r0.x = e[0] | (e[1] << 16); r0.y = e[2] | (e[3] << 16); r0.z = e[4] | (e[5] << 16); r0.w = e[6] | (e[7] << 16);
-            r1.x = e[8] | (e[9] << 16); r1.y = e[10] | (e[11] << 16); r1.z = e[12] | (e[13] << 16); r1.w = e[14] | (e[15] << 16);
-            rows[2 * g] = r0; rows[2 * g + 1] = r1;
+            if (ROW32) {
+                rows[4 * g] = make_uint4(e[0], e[1], e[2], e[3]); rows[4 * g + 1] = make_uint4(e[4], e[5], e[6], e[7]);
+                rows[4 * g + 2] = make_uint4(e[8], e[9], e[10], e[11]); rows[4 * g + 3] = make_uint4(e[12], e[13], e[14], e[15]);
+            } else {
+                uint4 r0, r1;
+                r0.x = e[0] | (e[1] << 16); r0.y = e[2] | (e[3] << 16); r0.z = e[4] | (e[5] << 16); r0.w = e[6] | (e[7] << 16);
+                r1.x = e[8] | (e[9] << 16); r1.y = e[10] | (e[11] << 16); r1.z = e[12] | (e[13] << 16); r1.w = e[14] | (e[15] << 16);
+                rows[2 * g] = r0; rows[2 * g + 1] = r1;
+            }
         }
     }
 }
@@ -203,7 +217,9 @@ k_segment_rows(SimkaMergeIn in, SimkaKeyCfg cfg, uint64_t part_begin, uint32_t n
 // GB: threads per block.  256 (records per round GCAP = 1024, table 2048 slots, four blocks per CU) up to 256 samples; 512 (2048 / 4096, two
 // blocks per CU) beyond: all samples of C5's 500 are then ONE tile -- the rows stay in registers, a sub-range is gathered once instead
 // of once per sample tile and is not split again on key bits (k_group on c5_50: 28.6 -> 15.5 ms)
-template <int GB>
+// ROW32: the rows of the batch are 32-bit (k_segment_rows<true>: a segment beyond 65535 records somewhere): read from memory where they are
+// needed instead of living in registers -- the rare, slower form.
+template <int GB, bool ROW32>
 __global__ void __launch_bounds__(GB)
 k_group(SimkaMergeIn in, const ull *seg_abs, const uint16_t *rows, uint32_t np,
         SimkaKeyCfg cfg, uint32_t min_share, SimkaCsrOut o) {
@@ -257,6 +273,13 @@ k_group(SimkaMergeIn in, const ull *seg_abs, const uint16_t *rows, uint32_t np,
         return (i & 1u) ? a >> 16 : a & 0xffffu;
     };
     uint4 rr0 = make_uint4(0, 0, 0, 0), rr1 = rr0, nr0 = rr0, nr1 = rr0; ull rab = 0, nab = 0;       // this partition's row / the next one's (sample tid)
+    const uint32_t *rows32 = (const uint32_t *)rows;
+    // end of key-prefix block i of the segment (partition pi of the batch, sample s_), whatever the row width
+    auto seg_end = [&](uint32_t pi_, uint32_t s_, uint32_t i) -> uint32_t {
+        if (i == ~0u) return 0u;
+        const size_t g = (size_t)pi_ * in.nb_samples + s_;
+        return ROW32 ? rows32[g * SIMKA_SEG_BLOCKS + i] : (uint32_t)rows[g * SIMKA_SEG_BLOCKS + i];
+    };
     // Which partitions a block takes: Q = min(4, #sub-ranges) neighbouring blocks of ONE XCD (blockIdx % 8: its own L2) share a partition,
     // a quarter of its sub-ranges each -- the lines of the N segments that neighbouring slices share are then fetched into that L2 once
     // (with a partition per block, 128 partitions are open per XCD: 23 MB of segments against 4 MB of L2, every line fetched 2-3 times).
@@ -265,7 +288,7 @@ k_group(SimkaMergeIn in, const ull *seg_abs, const uint16_t *rows, uint32_t np,
     const uint32_t quarter = bx % Q, nsets = gx / Q, pstep = 8u * nsets;      // (the host launches a multiple of 32 blocks: nsets >= 1, no block left over)
     uint32_t cur_pi = (bx / Q) * 8u + xcd, cur_j = 0;
     if (bx / Q >= nsets) cur_pi = np;
-    if (cur_pi < np && tid < N) { const size_t g = (size_t)cur_pi * N + tid; nr0 = rows4[2 * g]; nr1 = rows4[2 * g + 1]; nab = seg_abs[g]; }
+    if (cur_pi < np && tid < N) { const size_t g = (size_t)cur_pi * N + tid; if (!ROW32) { nr0 = rows4[2 * g]; nr1 = rows4[2 * g + 1]; } nab = seg_abs[g]; }
     // f(key, sample << 32 | count) for every record of the sub-range: a tile of GB samples at a time -- their slices from the
     // rows, an exclusive scan, then one record per thread (the thread finds its sample in the prefix table)
     bool tile_ready = false;       // (uniform) the tables of sample tile 0 are already in LDS (the scan that gave R): the first gather reuses them
@@ -277,12 +300,12 @@ k_group(SimkaMergeIn in, const ull *seg_abs, const uint16_t *rows, uint32_t np,
             if (s0 == 0 && tile_ready) { tile_ready = false; tot = spre[GB]; }
             else {
             if (s0 == 0) {
-                const uint32_t lo = row_end(rr0, rr1, cur_j * bw - 1u), hi = row_end(rr0, rr1, (cur_j + 1u) * bw - 1u);      // (cur_j == 0: ~0u)
+                const uint32_t lo = ROW32 ? (tid < N ? seg_end(cur_pi, tid, cur_j * bw - 1u) : 0u) : row_end(rr0, rr1, cur_j * bw - 1u);      // (cur_j == 0: ~0u)
+                const uint32_t hi = ROW32 ? (tid < N ? seg_end(cur_pi, tid, (cur_j + 1u) * bw - 1u) : 0u) : row_end(rr0, rr1, (cur_j + 1u) * bw - 1u);
                 c = hi - lo; b = rab + lo;
             } else if (s < N) {
                 const size_t g = (size_t)cur_pi * N + s;
-                const uint16_t *row = rows + g * SIMKA_SEG_BLOCKS;
-                const uint32_t lo = cur_j ? row[cur_j * bw - 1u] : 0u, hi = row[(cur_j + 1u) * bw - 1u];
+                const uint32_t lo = seg_end(cur_pi, s, cur_j * bw - 1u), hi = seg_end(cur_pi, s, (cur_j + 1u) * bw - 1u);
                 c = hi - lo; b = seg_abs[g] + lo;
             }
             __syncthreads();           // (the tables of the tile before are done with)
@@ -318,14 +341,15 @@ k_group(SimkaMergeIn in, const ull *seg_abs, const uint16_t *rows, uint32_t np,
             rr0 = nr0; rr1 = nr1; rab = nab;
             const uint32_t npi = cur_pi + pstep;
             nr0 = make_uint4(0, 0, 0, 0); nr1 = nr0; nab = 0;
-            if (npi < np && tid < N) { const size_t g = (size_t)npi * N + tid; nr0 = rows4[2 * g]; nr1 = rows4[2 * g + 1]; nab = seg_abs[g]; }
+            if (npi < np && tid < N) { const size_t g = (size_t)npi * N + tid; if (!ROW32) { nr0 = rows4[2 * g]; nr1 = rows4[2 * g + 1]; } nab = seg_abs[g]; }
         }
       for (cur_j = quarter * jq; cur_j < (quarter + 1u) * jq; cur_j++) {
         const uint32_t this_j = cur_j;
         // records of the sub-range over all samples
         uint32_t R = 0;
         if (N <= (uint32_t)GB) {      // one tile of samples: its scan is the gather's scan too
-            const uint32_t lo = row_end(rr0, rr1, this_j * bw - 1u), c = row_end(rr0, rr1, (this_j + 1u) * bw - 1u) - lo;
+            const uint32_t lo = ROW32 ? (tid < N ? seg_end(cur_pi, tid, this_j * bw - 1u) : 0u) : row_end(rr0, rr1, this_j * bw - 1u);
+            const uint32_t c = (ROW32 ? (tid < N ? seg_end(cur_pi, tid, (this_j + 1u) * bw - 1u) : 0u) : row_end(rr0, rr1, (this_j + 1u) * bw - 1u)) - lo;
             __syncthreads();
             sbeg[tid] = rab + lo;
             uint32_t excl;
@@ -335,11 +359,9 @@ k_group(SimkaMergeIn in, const ull *seg_abs, const uint16_t *rows, uint32_t np,
             __syncthreads();
             tile_ready = true;
         } else {
-            uint32_t c = row_end(rr0, rr1, (this_j + 1u) * bw - 1u) - row_end(rr0, rr1, this_j * bw - 1u);
-            for (uint32_t s = tid + GB; s < N; s += GB) {
-                const uint16_t *row = rows + ((size_t)cur_pi * N + s) * SIMKA_SEG_BLOCKS;
-                c += (uint32_t)row[(this_j + 1u) * bw - 1u] - (this_j ? (uint32_t)row[this_j * bw - 1u] : 0u);
-            }
+            uint32_t c = ROW32 ? (tid < N ? seg_end(cur_pi, tid, (this_j + 1u) * bw - 1u) - seg_end(cur_pi, tid, this_j * bw - 1u) : 0u)
+                               : row_end(rr0, rr1, (this_j + 1u) * bw - 1u) - row_end(rr0, rr1, this_j * bw - 1u);
+            for (uint32_t s = tid + GB; s < N; s += GB) c += seg_end(cur_pi, s, (this_j + 1u) * bw - 1u) - seg_end(cur_pi, s, this_j * bw - 1u);
             __syncthreads();
             uint32_t excl;
             R = block_excl_scan1<GB>(c, excl, tmp + 8);

@@ -287,6 +287,27 @@ def test_low_coverage_all_distinct_partitions(gpu_required, oracle_mod, order):
     _check_vs_oracle(totals, st, orc)
 
 
+@pytest.mark.parametrize("pb,subranges", [(1, 0), (2, 2), (1, 4)])
+def test_segments_beyond_65535_records_take_32_bit_rows(gpu_required, oracle_mod, pb, subranges):
+    """A (sample, partition) segment with more than 65535 solid k-mers does not fit the 16-bit rows the count kernels leave for the
+    merge: simka_merge sees the largest segment and rebuilds every batch's rows in 32 bits (k_segment_rows<true>, k_group<.., true>).
+    Three samples of ~280k distinct k-mers in 2 / 4 partitions: 70k .. 140k records per segment; exact vs the oracle."""
+    from simka_amd import synth
+    R, L, k = 4000, 100, 31
+    packed = [_random_reads_packed(R, L, 21 + i) for i in range(3)]
+    packed[1][: len(packed[1]) // 2] = packed[0][: len(packed[0]) // 2]
+    packed[2][len(packed[2]) // 3:] = packed[0][len(packed[0]) // 3:]
+    offs = np.arange(R + 1, dtype=np.uint64) * L
+    inputs = [(np.concatenate([pk, np.zeros(2, dtype=np.uint64)]), offs, R * L, R) for pk in packed]
+    totals, st = _run_gpu(inputs, k, 1, log2_partitions=pb, log2_subranges=subranges)
+    assert max(int(t["D"]) for t in totals) >> pb > 65535
+    orc = oracle_mod.Oracle()
+    for s, pk in enumerate(packed):
+        orc.add_sample_ascii("S%d" % s, synth.unpack_ascii(pk, R * L), offs)
+    orc.run(k, 1, simple=True, complex_=True)
+    _check_vs_oracle(totals, st, orc)
+
+
 def test_cli_fastq_gz_inputs(gpu_required, golden_dir, tmp_path):
     """Same sequences as the example, delivered as FASTQ / FASTQ.gz / FASTA.gz: the matrices must not change."""
     import subprocess
