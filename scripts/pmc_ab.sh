@@ -1,24 +1,19 @@
-# SQ / LDS counters of k_skm_count_fast for several library builds: LIBS="name=path ..."
+# SQ counters of one kernel for several library builds: LIBS="name=path ..." KERNEL=k_skm_count_fast WL=c3 SAMPLES=4 bash scripts/pmc_ab.sh
 export TMPDIR=/tmp
-R=$PWD
-for spec in $LIBS; do
+R=$PWD; WL=${WL:-c3}; SAMPLES=${SAMPLES:-4}; KERNEL=${KERNEL:-k_skm_count_fast}
+T=$R/gpurun_out/pmc_ab; rm -rf $T; mkdir -p $T
+for spec in ${LIBS:-default=}; do
   name=${spec%%=*}; path=${spec#*=}
-  O=$R/gpurun_out/pmc_ab/$name; mkdir -p $O
-  export SIMKA_LIB_OVERRIDE=$R/$path
-  cd /tmp
-  SIMKA_LANES=1 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CU_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_LDS SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT --output-format csv -d $O -o a -- python $R/bench.py --workload c3 --samples 2 --steps 1 --warmup 0 --no-cpu-baseline > /dev/null 2> $O/err_a.txt
-  SIMKA_LANES=1 rocprofv3 --kernel-trace --pmc SQ_LDS_IDX_ACTIVE SQ_LDS_ADDR_CONFLICT SQ_WAIT_INST_LDS SQ_INSTS_VALU SQ_INSTS_SALU SQ_ACTIVE_INST_VALU SQ_LDS_ATOMIC_RETURN SQ_LDS_UNALIGNED_STALL --output-format csv -d $O -o b -- python $R/bench.py --workload c3 --samples 2 --steps 1 --warmup 0 --no-cpu-baseline > /dev/null 2> $O/err_b.txt
-  cd $R
-  python - $O $name <<'PY'
-import csv, glob, collections, sys, os
-O, name = sys.argv[1], sys.argv[2]
-for tag in "ab":
-    fs = glob.glob(O + "/**/%s_counter_collection.csv" % tag, recursive=True)
-    if not fs: print(name, "no csv", tag); continue
-    acc = collections.defaultdict(float); n = 0
-    for r in csv.DictReader(open(fs[0])):
-        if os.environ.get("KFILTER", "count_fast") not in r["Kernel_Name"]: continue
-        acc[r["Counter_Name"]] += float(r["Counter_Value"])
-    print(name, tag, {a: "%.3g" % b for a, b in sorted(acc.items())})
-PY
+  [ -n "$path" ] && export SIMKA_LIB_OVERRIDE=$R/$path || unset SIMKA_LIB_OVERRIDE
+  (cd /tmp && timeout 600 rocprofv3 --kernel-trace --pmc ${PMC:-SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_BUSY_CU_CYCLES SQ_INSTS_LDS SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_INSTS_SALU SQ_WAVE_CYCLES} --output-format csv -d $T -o pmc_$name -- python $R/bench.py --workload $WL --samples $SAMPLES --no-cpu-baseline --no-two-streams --no-from-host --no-e2e --steps 1 --warmup 0 --prof-steps 1 > /dev/null 2> $T/err_$name.txt)
+  python - "$T" "$name" "$KERNEL" <<'P'
+import csv, glob, sys, collections
+T, name, kern = sys.argv[1:4]
+acc = collections.Counter(); n = set()
+for f in glob.glob(T + "/**/*pmc_%s*counter_collection.csv" % name, recursive=True):
+    for r in csv.DictReader(open(f)):
+        if r["Kernel_Name"].startswith(kern + "<") or r["Kernel_Name"].split("(")[0] == kern or kern in r["Kernel_Name"].split("(")[0]:
+            acc[r["Counter_Name"]] += float(r["Counter_Value"]); n.add(r["Dispatch_Id"])
+print(name, kern, "launches", len(n), {k: "%.3g" % v for k, v in sorted(acc.items())})
+P
 done
