@@ -12,7 +12,7 @@ seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 np.set_printoptions(threshold=100000, linewidth=220)
 rng = np.random.default_rng(seed)
 t_end = time.time() + budget
-KS = [int(x) for x in os.environ.get("FUZZ_KS", "").split(",") if x] or [1, 2, 3, 5, 8, 11, 15, 16, 17, 21, 25, 31, 32, 33, 34, 35, 36, 37, 40, 45, 50, 51, 52, 63]
+KS = [int(x) for x in os.environ.get("FUZZ_KS", "").split(",") if x] or [1, 2, 3, 5, 8, 11, 15, 16, 17, 21, 25, 31, 32, 33, 34, 35, 36, 37, 40, 45, 50, 51, 52, 63, 64, 65, 80, 96, 127]
 
 
 def kl_edge_cases():
