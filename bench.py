@@ -408,6 +408,8 @@ def main():
                                           shard_index=0 if mode != "partition" else rank, shard_count=1 if mode != "partition" else world,
                                           max_kmers_per_sample=kocc_per_sample, log2_partitions=args.log2_partitions)
 
+        trace = os.environ.get("SIMKA_BENCH_TRACE")
+
         def make_step(ctx):
             def count(s):
                 if args.offsets:
@@ -421,16 +423,33 @@ def main():
                     # their partition range (all-to-all), the pair accumulators are all-reduced (simka_amd/dist.py)
                     sdist.count_exchange_merge(ctx, count, n, dev, comm=comm)
                 else:
+                    tr = [time.perf_counter()] if trace else None      # SIMKA_BENCH_TRACE: where the host spends a step
                     ctx.reset()
+                    if tr: tr.append(time.perf_counter())
                     for s in range(n):
                         count(s)
+                    if tr: tr.append(time.perf_counter())
                     if wl.get("complex") and world > 1:        # -complex-dist terms need the GLOBAL per-sample totals inside the merge
                         sdist.allreduce_totals_device(ctx, comm=comm)
                     ctx.merge()
+                    if tr:
+                        tr.append(time.perf_counter())
+                        if trace == "threads":
+                            import threading, traceback
+                            for th_id, fr in sys._current_frames().items():
+                                if th_id != threading.get_ident():
+                                    sys.stderr.write("other thread %s:\n%s\n" % ([t.name for t in threading.enumerate() if t.ident == th_id], "".join(traceback.format_stack(fr)[-4:])))
+                        if trace == "sleep": time.sleep(0.03)
+                        if trace == "sync": torch.cuda.synchronize()
+                        tr.append(time.perf_counter())
                     # ONE RCCL all-reduce of the flat u64 accumulators (no-op at N=1)
                     sdist.allreduce_stats_device(ctx, totals_already_reduced=bool(wl.get("complex")) and world > 1, comm=comm)
                 st = ctx.stats()
+                if trace and not by_sample: tr.append(time.perf_counter())
                 mats = st.matrices()
+                if trace and not by_sample:
+                    tr.append(time.perf_counter())
+                    sys.stderr.write("step trace (ms): reset %.2f  count calls %.2f  merge %.2f  (%s) %.2f  stats %.2f  matrices %.2f\n" % ((tuple((b_ - a_) * 1e3 for a_, b_ in zip(tr, tr[1:])))[:3] + (trace,) + (tuple((b_ - a_) * 1e3 for a_, b_ in zip(tr, tr[1:])))[3:]))
                 return st, mats
             return step
 

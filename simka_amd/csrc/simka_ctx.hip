@@ -95,6 +95,8 @@ struct simka_ctx {
     uint32_t *d_err = nullptr;
     // merge buffers
     ull *d_part_total = nullptr, *d_part_off = nullptr;
+    struct PinSlot { void *p = nullptr; size_t cap = 0; } pin[4];       // pinned staging for the large host <-> device copies of the spectrum exchange (see stage_h2d)
+    ull *h_part = nullptr; uint64_t h_part_n = 0;             // pinned: the merge's per-partition totals and offsets (a pageable copy of megabytes is pinned and unpinned by the runtime at every merge)
     ull *d_work = nullptr;                                    // [2] work counters of the persistent merge-side kernels (zeroed before a launch)
     ull *d_seg_abs = nullptr; uint4 *d_seg_rows = nullptr;    // [partitions][N] first record of a segment, ends of its 16 key-hash blocks: all partitions, written by the count kernels
                                                                // (seg_all), or -- too many segments, or imported spectra (seg_dirty) -- one merge batch at a time by k_segment_rows
@@ -185,6 +187,42 @@ static void profile_collect(simka_ctx *ctx) {
 
 template <typename T>
 static hipError_t dev_alloc(T **p, uint64_t n) { return hipMalloc((void **)p, std::max<uint64_t>(n, 1) * sizeof(T)); }
+
+// ---- large copies between PAGEABLE host memory and the device.  The runtime pins such a buffer for the copy and unpins it afterwards
+// (a few GB/s, and the deferred unpin holds the process' address-space lock: the next malloc or page fault of any thread waits --
+// measured as 10-25 ms of host stall after every merge in a process that runs after another GPU process).  Copies of 256 KB and more
+// therefore go through pinned staging slots of the context; callers that pass pinned memory (simka_host_alloc) are copied from directly.
+#define SIMKA_STAGE_MIN ((size_t)256 << 10)
+static size_t stage_min() { const char *e = simka_test_knob("SIMKA_STAGE_MIN"); return e ? (size_t)atoll(e) : SIMKA_STAGE_MIN; }      // (tests: stage small copies too)
+static bool host_is_pinned(const void *p) {
+    hipPointerAttribute_t a;
+    if (hipPointerGetAttributes(&a, p) != hipSuccess) { (void)hipGetLastError(); return false; }
+    return a.type == hipMemoryTypeHost;
+}
+static void *pin_slot(simka_ctx *ctx, int slot, size_t bytes) {
+    auto &ps = ctx->pin[slot];
+    if (ps.cap >= bytes && ps.p) return ps.p;
+    if (ps.p) { (void)hipHostFree(ps.p); ps.p = nullptr; ps.cap = 0; }
+    const size_t want = bytes + bytes / 4;
+    if (hipHostMalloc(&ps.p, want, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); ps.p = nullptr; return nullptr; }
+    ps.cap = want;
+    return ps.p;
+}
+// host source of an upload: src itself (small, or already pinned, or no staging memory), else its copy in the slot.  The slot is
+// free again after the next synchronisation of the stream the copy is queued on.
+static const void *stage_h2d(simka_ctx *ctx, int slot, const void *src, size_t bytes) {
+    if (bytes < stage_min() || host_is_pinned(src)) return src;
+    void *st = pin_slot(ctx, slot, bytes);
+    if (!st) return src;
+    memcpy(st, src, bytes);
+    return st;
+}
+// host destination of a download: dst itself or the slot (then the caller copies slot -> dst after synchronising)
+static void *stage_d2h(simka_ctx *ctx, int slot, void *dst, size_t bytes) {
+    if (bytes < stage_min() || host_is_pinned(dst)) return dst;
+    void *st = pin_slot(ctx, slot, bytes);
+    return st ? st : dst;
+}
 
 static uint32_t ceil_log2_u64(uint64_t x) { uint32_t l = 0; while (((uint64_t)1 << l) < x && l < 63) l++; return l; }
 
@@ -555,6 +593,8 @@ SIMKA_EXPORT void simka_destroy(simka_ctx *ctx) {
                      ctx->d_spans, ctx->d_cursors, ctx->d_huge, ctx->d_xoff, ctx->d_hist, ctx->d_ovf_list, ctx->d_ovf_cursor,
                      ctx->d_tm_ent, ctx->d_tm_p, ctx->d_tm_off };
     for (void *p : ptrs) if (p) (void)hipFree(p);
+    if (ctx->h_part) (void)hipHostFree(ctx->h_part);
+    for (auto &ps : ctx->pin) if (ps.p) (void)hipHostFree(ps.p);
     if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }
@@ -1525,14 +1565,17 @@ SIMKA_EXPORT int simka_samples_spectrum_info(simka_ctx *ctx, const uint32_t *sam
     if (rc) return rc;
     std::vector<ull> tot((size_t)SIMKA_NB_TOTALS * N, 0);
     HIPCHK(hipMemcpyAsync(tot.data(), ctx->d_stats + stats_off_tot(N, fl, 0), tot.size() * 8, hipMemcpyDeviceToHost, ctx->stream));
+    uint32_t *pc_host = part_counts;          // where the rows are downloaded to (a pinned slot when part_counts is pageable)
+    if (!ctx->wide && ctx->geometry_ready) pc_host = (uint32_t *)stage_d2h(ctx, 0, part_counts, (size_t)nb * ctx->nparts * 4);
     for (uint32_t j = 0; j < nb; j++) {
         if (ctx->wide) {      // sorted two-word spectra: partitions are key-prefix ranges
             const int wrc = simka_wide_part_counts(ctx->wide, samples[j], wide_log2_parts(ctx), part_counts + ((size_t)j << wide_log2_parts(ctx)));
             if (wrc) return wide_fail(ctx, wrc);
-        } else if (ctx->geometry_ready) HIPCHK(hipMemcpyAsync(part_counts + (size_t)j * ctx->nparts, ctx->d_fcnt + (uint64_t)samples[j] * ctx->nparts, ctx->nparts * 4, hipMemcpyDeviceToHost, ctx->stream));
+        } else if (ctx->geometry_ready) HIPCHK(hipMemcpyAsync(pc_host + (size_t)j * ctx->nparts, ctx->d_fcnt + (uint64_t)samples[j] * ctx->nparts, ctx->nparts * 4, hipMemcpyDeviceToHost, ctx->stream));
         else memset(part_counts + (size_t)j * ctx->nparts, 0, ctx->nparts * 4);
     }
     HIPCHK(hipStreamSynchronize(ctx->stream));
+    if (pc_host != part_counts) memcpy(part_counts, pc_host, (size_t)nb * ctx->nparts * 4);
     for (uint32_t j = 0; j < nb; j++) {
         const uint32_t s = samples[j];
         totals[j].nb_reads = ctx->nb_reads[s];
@@ -1558,7 +1601,7 @@ SIMKA_EXPORT int simka_gather_samples_device(simka_ctx *ctx, const uint32_t *sam
     if (rc) return rc;
     rc = ensure_cap(ctx, &ctx->d_xoff, &ctx->xoff_cap, (uint64_t)nb * ctx->nparts + (nb + 1) / 2 + 1); if (rc) return rc;
     uint32_t *d_samples = (uint32_t *)(ctx->d_xoff + (uint64_t)nb * ctx->nparts);
-    HIPCHK(hipMemcpyAsync(ctx->d_xoff, out_offsets, (uint64_t)nb * ctx->nparts * 8, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(hipMemcpyAsync(ctx->d_xoff, stage_h2d(ctx, 1, out_offsets, (size_t)nb * ctx->nparts * 8), (uint64_t)nb * ctx->nparts * 8, hipMemcpyHostToDevice, ctx->stream));
     HIPCHK(hipMemcpyAsync(d_samples, samples, (size_t)nb * 4, hipMemcpyHostToDevice, ctx->stream));
     hipLaunchKernelGGL(k_gather_samples, dim3((uint32_t)std::min<uint64_t>(ctx->nparts, (uint64_t)ctx->num_cus * 4), nb), dim3(256), 0, ctx->stream,
                        ctx->d_solid_keys, ctx->d_solid_counts, ctx->d_sample_base, ctx->d_foff, ctx->d_fcnt, d_samples, ctx->d_xoff,
@@ -1621,8 +1664,12 @@ SIMKA_EXPORT int simka_import_samples_device(simka_ctx *ctx, const uint32_t *sam
     // sample must lie within 2^32 records of each other -- the block itself may be larger (C3 on two ranks: 3.7e9 records)
     bool consecutive = true;
     for (uint32_t j = 1; j < nb; j++) if (samples[j] != samples[0] + j) consecutive = false;
-    std::vector<uint32_t> hfo((size_t)nb * std::max<uint64_t>(w, 1));
-    const uint32_t *hfc_p = part_counts;
+    // (both tables go up as nb x w words: from pinned memory -- the offsets are built in a slot, the caller's counts staged in another)
+    std::vector<uint32_t> hfo_v;
+    const size_t tab_bytes = (size_t)nb * std::max<uint64_t>(w, 1) * 4;
+    uint32_t *hfo = tab_bytes >= stage_min() ? (uint32_t *)pin_slot(ctx, 2, tab_bytes) : nullptr;
+    if (!hfo) { hfo_v.resize((size_t)nb * std::max<uint64_t>(w, 1)); hfo = hfo_v.data(); }
+    const uint32_t *hfc_p = (const uint32_t *)stage_h2d(ctx, 3, part_counts, (size_t)nb * w * 4);
     std::vector<ull> bases(nb, cursor);
     for (uint32_t j = 0; j < nb; j++) {
         uint64_t lo = ~0ull, hi = 0;
@@ -1636,14 +1683,14 @@ SIMKA_EXPORT int simka_import_samples_device(simka_ctx *ctx, const uint32_t *sam
     }
     if (consecutive) {
         if (w) {
-            HIPCHK(hipMemcpy2DAsync(ctx->d_foff + (uint64_t)samples[0] * P + pmin, P * 4, hfo.data(), w * 4, w * 4, nb, hipMemcpyHostToDevice, ctx->stream));
+            HIPCHK(hipMemcpy2DAsync(ctx->d_foff + (uint64_t)samples[0] * P + pmin, P * 4, hfo, w * 4, w * 4, nb, hipMemcpyHostToDevice, ctx->stream));
             HIPCHK(hipMemcpy2DAsync(ctx->d_fcnt + (uint64_t)samples[0] * P + pmin, P * 4, hfc_p, w * 4, w * 4, nb, hipMemcpyHostToDevice, ctx->stream));
         }
         HIPCHK(hipMemcpyAsync(ctx->d_sample_base + samples[0], bases.data(), (size_t)nb * 8, hipMemcpyHostToDevice, ctx->stream));
     } else {
         for (uint32_t j = 0; j < nb; j++) {
             if (w) {
-                HIPCHK(hipMemcpyAsync(ctx->d_foff + (uint64_t)samples[j] * P + pmin, hfo.data() + (size_t)j * w, w * 4, hipMemcpyHostToDevice, ctx->stream));
+                HIPCHK(hipMemcpyAsync(ctx->d_foff + (uint64_t)samples[j] * P + pmin, hfo + (size_t)j * w, w * 4, hipMemcpyHostToDevice, ctx->stream));
                 HIPCHK(hipMemcpyAsync(ctx->d_fcnt + (uint64_t)samples[j] * P + pmin, hfc_p + (size_t)j * w, w * 4, hipMemcpyHostToDevice, ctx->stream));
             }
             HIPCHK(hipMemcpyAsync(ctx->d_sample_base + samples[j], &bases[j], 8, hipMemcpyHostToDevice, ctx->stream));
@@ -1920,8 +1967,14 @@ SIMKA_EXPORT int simka_merge(simka_ctx *ctx) {
         hipLaunchKernelGGL(k_part_totals, dim3((uint32_t)((nparts + 255) / 256)), dim3(256), 0, ctx->stream, ctx->d_fcnt, N,
                            nparts, ctx->d_part_total);
     });
-    std::vector<ull> ptot(nparts + 1), poff(nparts + 1);
-    HIPCHK(hipMemcpyAsync(ptot.data(), ctx->d_part_total, (nparts + 1) * 8, hipMemcpyDeviceToHost, ctx->stream));
+    if (ctx->h_part_n < 2 * (nparts + 1)) {
+        if (ctx->h_part) (void)hipHostFree(ctx->h_part);
+        ctx->h_part = nullptr; ctx->h_part_n = 0;
+        if (hipHostMalloc((void **)&ctx->h_part, 2 * (nparts + 1) * 8, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); return ctx->fail(SIMKA_ERR_NOMEM, "simka_merge: cannot allocate %llu bytes of pinned host memory", (unsigned long long)(2 * (nparts + 1) * 8)); }
+        ctx->h_part_n = 2 * (nparts + 1);
+    }
+    ull *const ptot = ctx->h_part, *const poff = ctx->h_part + nparts + 1;
+    HIPCHK(hipMemcpyAsync(ptot, ctx->d_part_total, (nparts + 1) * 8, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));
     // A (sample, partition) segment beyond 65535 records (a small user-set log2_partitions; a hot partition): the 16-bit rows the count
     // kernels left cannot index it -- every batch gets 32-bit rows from k_segment_rows<true> and k_group reads those (slower, rare).
@@ -1930,7 +1983,7 @@ SIMKA_EXPORT int simka_merge(simka_ctx *ctx) {
     for (uint64_t p = 0; p < nparts; p++) { poff[p] = total; total += ptot[p]; maxpart = std::max(maxpart, ptot[p]); nonempty += ptot[p] ? 1 : 0; }
     poff[nparts] = total;
     if (total == 0) return SIMKA_OK;
-    HIPCHK(hipMemcpyAsync(ctx->d_part_off, poff.data(), (nparts + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(hipMemcpyAsync(ctx->d_part_off, poff, (nparts + 1) * 8, hipMemcpyHostToDevice, ctx->stream));      // (pinned: really asynchronous -- poff is not written again before the merge's last synchronize)
 
     // sub-range bits: at most K3_TARGET records per k_group round on average (a round hashes up to K3_CAP)
     SimkaKeyCfg key = ctx->key;

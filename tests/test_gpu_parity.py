@@ -748,8 +748,8 @@ def test_cli_keep_tmp_adds_samples_without_recounting(gpu_required, golden_dir, 
         assert f.read() == g.read()
 
 
-@pytest.mark.parametrize("world,complex_,shape", [(2, True, "small"), (3, False, "small"), (8, False, "small"), (8, False, "c4")])
-def test_sample_shards_then_partition_range_merge(gpu_required, world, complex_, shape):
+@pytest.mark.parametrize("world,complex_,shape", [(2, True, "small"), (3, False, "small"), (8, False, "small"), (8, False, "c4"), (3, False, "staged")])
+def test_sample_shards_then_partition_range_merge(gpu_required, monkeypatch, world, complex_, shape):
     """The N-GPU job of simka_amd/dist.py::count_exchange_merge, emulated on one GPU: `world` contexts each count the samples
     s % world == r and export them on the device; the pack / unpack phases route every sample's slice of partition range g to
     context g (the all-to-all is done by hand here, by torch.distributed on gloo in tests/test_dist_gloo.py); each context
@@ -758,6 +758,8 @@ def test_sample_shards_then_partition_range_merge(gpu_required, world, complex_,
     import simka_amd
     from simka_amd import dist as sdist
     dev = torch.device("cuda:0")
+    if shape == "staged":        # the partition tables of the exchange go through the context's pinned staging slots whatever their size (at scale: from 256 KB)
+        monkeypatch.setenv("SIMKA_STAGE_MIN", "1")
     # "c4": BASELINE configs[3]'s shape -- 100 samples, k = 31, -simple-dist, abundance-min 2, 8 ranks -- at a depth of 2000 reads
     n, R, L, k = (100, 2000, 150, 31) if shape == "c4" else (7, 3000, 100, 21)
     packed = _synthetic(n, R, L, seed_shift=11)
