@@ -20,10 +20,24 @@ packed = []
 for s in range(n):
     ids, cdf = synth.sample_profile(s)
     packed.append(np.concatenate([synth.reads_cpu(R, L, pool, gw, g, ids, cdf, synth.sample_seed(s)), np.zeros(2, dtype=np.uint64)]))
+# sample 1: one read 3000 times -- counts beyond the -complex-dist histogram (SIMKA_HIST_MAX = 1024) travel on the list of large counts,
+# filled by the count kernels in (a) and by k_import_hist from the imported spectra in (b)
+hot = synth.unpack_ascii(packed[1][:-2], R * L).reshape(R, L).copy()
+hot[100:3100] = hot[7]
+hot_packed, hot_off, hot_nb, _ = simka_amd.pack_reads([row.tobytes() for row in hot])
+
+
+def count_into(c, s):
+    if s == 1:
+        c.count_sample(s, hot_packed, hot_nb, R, offsets=hot_off, nb_input_reads=R)
+    else:
+        c.count_sample(s, packed[s], R * L, R, fixed_len=L)
+
+
 kw = dict(kmer_size=k, abundance_min=2, simple_dist=True, complex_dist=True, device=local)
 ctx = simka_amd.SimkaContext(n, shard_index=rank, shard_count=world, **kw)
 for s in range(n):
-    ctx.count_sample(s, packed[s], R * L, R, fixed_len=L)
+    count_into(ctx, s)
 sdist.allreduce_totals_device(ctx)
 ctx.merge()
 sdist.allreduce_stats_device(ctx, totals_already_reduced=True)
@@ -31,7 +45,7 @@ a = ctx.stats().flat.copy()
 ctx.close()
 os.environ["SIMKA_FORCE_EXCHANGE"] = "1"
 ctx = simka_amd.SimkaContext(n, max_kmers_per_sample=R * (L - k + 1), **kw)
-sdist.count_exchange_merge(ctx, lambda s: ctx.count_sample(s, packed[s], R * L, R, fixed_len=L), n, dev)
+sdist.count_exchange_merge(ctx, lambda s: count_into(ctx, s), n, dev)
 b = ctx.stats().flat.copy()
 ctx.close()
 # (c) the same exchange for k = 33 (two-word keys: high and low words in separate all-to-alls) against the plain wide-k run
@@ -39,13 +53,13 @@ kw33 = dict(kw, kmer_size=33)
 os.environ.pop("SIMKA_FORCE_EXCHANGE")
 ctx = simka_amd.SimkaContext(n, **kw33)
 for s in range(n):
-    ctx.count_sample(s, packed[s], R * L, R, fixed_len=L)
+    count_into(ctx, s)
 ctx.merge()
 c = ctx.stats().flat.copy()
 ctx.close()
 os.environ["SIMKA_FORCE_EXCHANGE"] = "1"
 ctx = simka_amd.SimkaContext(n, **kw33)
-sdist.count_exchange_merge(ctx, lambda s: ctx.count_sample(s, packed[s], R * L, R, fixed_len=L), n, dev)
+sdist.count_exchange_merge(ctx, lambda s: count_into(ctx, s), n, dev)
 d = ctx.stats().flat.copy()
 ctx.close()
 if rank == 0:

@@ -1428,6 +1428,32 @@ k_big_counts(const uint32_t *solid_counts, const ull *sample_base, const uint32_
 }
 
 // --------------------------------------------------------------------------------------------
+// k_import_hist: -complex-dist histogram of the solid counts of IMPORTED spectra (simka_import_samples_device): sample s0 + blockIdx.y,
+// partitions [p_lo, p_lo + p_w) of the arena.  What the count kernels do record by record (count_hist) for the samples they count.
+// --------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+k_import_hist(const uint32_t *solid_counts, const ull *sample_base, const uint32_t *foff, const uint32_t *fcnt, uint32_t nparts, uint32_t p_lo, uint32_t p_w,
+              uint32_t s0, ull *hist, uint32_t *ovf_list, ull *ovf_cursor, ull ovf_cap) {
+    __shared__ uint32_t lh[SIMKA_HIST_MAX];
+    const uint32_t s = s0 + blockIdx.y;
+    for (uint32_t i = threadIdx.x; i < SIMKA_HIST_MAX; i += 256) lh[i] = 0;
+    __syncthreads();
+    const ull base = sample_base[s];
+    const uint32_t *fo = foff + (size_t)s * nparts, *fc = fcnt + (size_t)s * nparts;
+    for (uint32_t p = p_lo + blockIdx.x; p < p_lo + p_w; p += gridDim.x) {
+        const uint32_t n = fc[p];
+        const ull src = base + fo[p];
+        for (uint32_t i = threadIdx.x; i < n; i += 256) {
+            const uint32_t c = solid_counts[src + i];
+            if (c < SIMKA_HIST_MAX) atomicAdd(&lh[c], 1u);
+            else { const ull w = atomicAdd(ovf_cursor, 1ull); if (w < ovf_cap) { ovf_list[2 * w] = s; ovf_list[2 * w + 1] = c; } }
+        }
+    }
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < SIMKA_HIST_MAX; i += 256) if (lh[i]) atomicAdd(&hist[(size_t)s * SIMKA_HIST_MAX + i], (ull)lh[i]);
+}
+
+// --------------------------------------------------------------------------------------------
 // k_gather_sample: the arena records of one sample, partition-major and gap-free (simka_export_sample)
 // --------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256)
