@@ -120,10 +120,17 @@ def cpu_baseline(wl, lib, torch, dev, seconds_budget=15.0):
             o.matrix(w)
     dt = time.perf_counter() - t0
     tot = o.totals()
+    # a container may be limited to fewer CPUs than it sees (cgroup v2 cpu.max = "quota period"): the threads then share that much CPU time
+    quota = None
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        quota = None if q == "max" else float(q) / float(per)
+    except Exception:
+        pass
     return {"value": float(tot["D_all"].sum()) / dt, "unit": "distinct k-mers/s", "cores": threads, "kind": "port",
-            "sample": "%d samples x %d reads x %d bp, k=%d, same generator/coverage (%.1f s CPU wall, %.3g k-mer occurrences/s)" %
-                      (n, R, L, k, dt, float(tot["K_occ"].sum()) / dt),
-            "seconds": dt}
+            "sample": "%d samples x %d reads x %d bp, k=%d, same generator/coverage (%.1f s CPU wall, %.3g k-mer occurrences/s; %d threads on %d visible CPUs%s)" %
+                      (n, R, L, k, dt, float(tot["K_occ"].sum()) / dt, threads, cores, ", cgroup CPU quota %.0f" % quota if quota else ""),
+            "cpu_quota": quota, "seconds": dt}
 
 
 def _gz_member(b):
