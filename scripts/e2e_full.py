@@ -32,10 +32,19 @@ try:
             "-abundance-min", "2", "-simple-dist", "-max-reads", "-1", "-verbose", "2"]
     for extra in ([], [], ["-ingest-window", "8"], ["-ingest-host-upload"], ["-no-numa-bind"], []) if len(sys.argv) <= 2 else [sys.argv[2:]]:
         time.sleep(float(os.environ.get('PAUSE', '10')))      # (the driver of the run before leaves 100+ GB of device memory to be reclaimed: back-to-back runs wait for it)
+        def cpu_stat():
+            try:
+                return {a: int(b_) for a, b_ in (ln.split() for ln in open("/sys/fs/cgroup/cpu.stat"))}
+            except Exception:
+                return {}
+        c0 = cpu_stat()
         t = time.time()
         r = subprocess.run(base + extra, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
         dt = time.time() - t
-        print(extra, "%.2f s  %.2f GB/s" % (dt, size / dt / 1e9), "rc", r.returncode, flush=True)
+        c1 = cpu_stat()
+        print(extra, "%.2f s  %.2f GB/s" % (dt, size / dt / 1e9), "rc", r.returncode,
+              "| CPU time %.1f s (%.1f CPUs busy), throttled periods %d, throttled %.1f s" % ((c1.get("usage_usec", 0) - c0.get("usage_usec", 0)) / 1e6, (c1.get("usage_usec", 0) - c0.get("usage_usec", 0)) / 1e6 / dt,
+                                                                                             c1.get("nr_throttled", 0) - c0.get("nr_throttled", 0), (c1.get("throttled_usec", 0) - c0.get("throttled_usec", 0)) / 1e6), flush=True)
         for ln in r.stdout.splitlines():
             if ln.startswith("main thread") or ln.startswith("process:"):
                 print("   ", ln)
