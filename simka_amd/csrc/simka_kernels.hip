@@ -1206,8 +1206,11 @@ k_pairs_tm(const SimkaSpan *spans, const ull *cursors, const ull *tm_ent, const 
         const uint32_t i = tid + (uint32_t)q * K4_BLOCK;                                      \
         pre_e[q] = 0ull; pre_p[q] = make_double2(0.0, 0.0); pre_j[q] = 0u;                    \
         if (i < (B).nm) {                                                                     \
-            uint32_t j = (B).bf;                                                              \
-            while (j + 1u < (B).bl && (R_->d[j].ngrp == 0u || i >= R_->sl[j].st + R_->d[j].na + R_->d[j].nb)) j++;   \
+            /* the span of staged entry i: the LAST span of the batch that starts at or before i (the staging starts are         \
+               non-decreasing; a span without members shares its start with its successor, never with its predecessor's members). \
+               Binary search: the linear walk over the spans of a batch cost the slowest thread 30 LDS round trips per entry. */     \
+            uint32_t j = (B).bf, hi_ = (B).bl;                                                \
+            while (hi_ - j > 1u) { const uint32_t mid_ = (j + hi_) >> 1; if (R_->sl[mid_].st <= i) j = mid_; else hi_ = mid_; }   \
             const KtmSlot sl = R_->sl[j];                                                     \
             const KtmSpan d = R_->d[j];                                                       \
             const ull src = d.ebase + (i < sl.mid ? d.a0 + (i - sl.st) : d.b0 + (i - sl.mid)); \
