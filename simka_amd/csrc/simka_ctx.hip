@@ -1728,6 +1728,14 @@ SIMKA_EXPORT int simka_import_samples_device(simka_ctx *ctx, const uint32_t *sam
 
 // ---- pair accumulation: shared by the hash merge (k_group's CSR) and the sort merge of the wide-k path -------------------
 #ifdef SIMKA_PHASE_PROF
+static void group_phase_report() {
+    ull h[8];
+    if (hipDeviceSynchronize() != hipSuccess || hipMemcpyFromSymbol(h, HIP_SYMBOL(g_group_phase), 64) != hipSuccess) return;
+    ull t_ = 0; for (int i_ = 0; i_ < 8; i_++) t_ += h[i_];
+    if (t_) fprintf(stderr, "k_group phases %%: sizing %.1f clear %.1f gather+hash %.1f geometry %.1f scan %.1f slab bookkeeping %.1f groups+entries %.1f\n", 100.0 * h[0] / t_, 100.0 * h[1] / t_, 100.0 * h[2] / t_,
+                    100.0 * h[3] / t_, 100.0 * h[4] / t_, 100.0 * h[5] / t_, 100.0 * h[6] / t_);
+    memset(h, 0, 64); (void)hipMemcpyToSymbol(HIP_SYMBOL(g_group_phase), h, 64);
+}
 static void pairs_phase_report() {
     ull h[8];
     if (hipDeviceSynchronize() != hipSuccess || hipMemcpyFromSymbol(h, HIP_SYMBOL(g_pairs_phase), 64) != hipSuccess) return;
@@ -1840,6 +1848,7 @@ static void pair_launch(simka_ctx *ctx, const PairLaunch &pl, const SimkaSpan *s
         }
     });
 #ifdef SIMKA_PHASE_PROF
+    group_phase_report();
     pairs_phase_report();
 #endif
     if (huge)

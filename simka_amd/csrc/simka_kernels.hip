@@ -217,6 +217,16 @@ k_segment_rows(SimkaMergeIn in, SimkaKeyCfg cfg, uint64_t part_begin, uint32_t n
 // GB: threads per block.  256 (records per round GCAP = 1024, table 2048 slots, four blocks per CU) up to 256 samples; 512 (2048 / 4096, two
 // blocks per CU) beyond: all samples of C5's 500 are then ONE tile -- the rows stay in registers, a sub-range is gathered once instead
 // of once per sample tile and is not split again on key bits (k_group on c5_50: 28.6 -> 15.5 ms)
+#ifdef SIMKA_PHASE_PROF
+__device__ ull g_group_phase[8];
+#define PG_DECL ull pg_t = wall_clock64(), pg_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#define PG(i) { const ull n_ = wall_clock64(); pg_acc[i] += n_ - pg_t; pg_t = n_; }
+#define PG_FLUSH if (threadIdx.x == 0) { for (int i_ = 0; i_ < 8; i_++) atomicAdd(&g_group_phase[i_], pg_acc[i_]); }
+#else
+#define PG_DECL
+#define PG(i)
+#define PG_FLUSH
+#endif
 // ROW32: the rows of the batch are 32-bit (k_segment_rows<true>: a segment beyond 65535 records somewhere): read from memory where they are
 // needed instead of living in registers -- the rare, slower form.
 template <int GB, bool ROW32>
@@ -336,6 +346,7 @@ k_group(SimkaMergeIn in, const ull *seg_abs, const uint16_t *rows, uint32_t np,
             __syncthreads();           // (gpk, which the tile overlays, is written next)
         }
     };
+    PG_DECL
     for (; cur_pi < np; cur_pi += pstep) {
         {      // a new partition: its rows arrived while the one before was grouped; the next one's set off
             rr0 = nr0; rr1 = nr1; rab = nab;
@@ -366,6 +377,7 @@ k_group(SimkaMergeIn in, const ull *seg_abs, const uint16_t *rows, uint32_t np,
             uint32_t excl;
             R = block_excl_scan1<GB>(c, excl, tmp + 8);
         }
+        PG(0)
         if (R == 0) continue;
         uint32_t e0 = 0;
         while (((R >> e0) > GCAP) && e0 < free_bits) e0++;
@@ -388,6 +400,7 @@ k_group(SimkaMergeIn in, const ull *seg_abs, const uint16_t *rows, uint32_t np,
                     for (uint32_t i = tid; i < GTAB / 8; i += GB) c4[i] = z;
                 }
                 __syncthreads();
+                PG(1)
                 // ---- hash the records of this (sub-)range; K3_UNROLL independent loads per thread
                 const uint32_t selshift = free_bits - e;
                 uint32_t mymax = 0;
@@ -410,6 +423,7 @@ k_group(SimkaMergeIn in, const ull *seg_abs, const uint16_t *rows, uint32_t np,
                 for (int o_ = 32; o_ > 0; o_ >>= 1) { const uint32_t t_ = __shfl_xor(mymax, o_, 64); mymax = t_ > mymax ? t_ : mymax; }
                 if ((tid & 63u) == 0 && mymax) atomicMax(&s_maxc, mymax);
                 __syncthreads();
+                PG(2)
                 if (s_ovf) {
                     if (e >= free_bits) {
                         // Every key bit is fixed: the selected records are ONE k-mer shared by more than GCAP samples.  Such a
@@ -448,17 +462,41 @@ k_group(SimkaMergeIn in, const ull *seg_abs, const uint16_t *rows, uint32_t np,
                 const uint32_t nrec = s_nrec;
                 if (nrec == 0) continue;
                 // ---- group geometry: one packed prefix over the table slots (entries | groups << 20)
+                // (a thread owns the GTAB / GB = 8 slots [8 tid, 8 tid + 8): one 16-byte read of their counts, the packed values and
+                //  their prefix in registers, ONE block scan of the threads' sums, two 16-byte stores -- the slot-strided loop + the
+                //  generic in-LDS scan behind it took a quarter of the kernel)
+                static_assert(GTAB == 8 * GB, "eight slots per thread");
                 uint32_t ndist = 0, nshared = 0;
-                for (uint32_t i = tid; i < GTAB; i += GB) {
-                    const uint32_t c = scnt[i];
-                    if (c) ndist++;
-                    if (c > 1) nshared++;
-                    gpk[i] = (c >= min_share) ? (c | (1u << 20)) : 0u;
+                uint32_t pv[8];
+                {
+                    const uint4 c4 = ((const uint4 *)scnt)[tid];
+                    const uint32_t cw[4] = { c4.x, c4.y, c4.z, c4.w };
+#pragma unroll
+                    for (int q = 0; q < 8; q++) {
+                        const uint32_t c = (cw[q >> 1] >> ((q & 1) * 16)) & 0xffffu;
+                        ndist += c ? 1u : 0u;
+                        nshared += c > 1u ? 1u : 0u;
+                        pv[q] = (c >= min_share) ? (c | (1u << 20)) : 0u;
+                    }
                 }
-                if (ndist) atomicAdd(&s_ndist, ndist);
-                if (nshared) atomicAdd(&s_nshared, nshared);
-                __syncthreads();
-                const uint32_t tot = block_excl_scan<GB>(gpk, GTAB, tmp);
+                {   // one LDS atomic per wave for the two statistics (packed: both stay below 2^16 per wave and round)
+                    const uint32_t both = wave_incl_scan(ndist | (nshared << 16));
+                    if ((tid & 63u) == 63u && both) { atomicAdd(&s_ndist, both & 0xffffu); atomicAdd(&s_nshared, both >> 16); }
+                }
+                PG(3)
+                uint32_t tsum = 0;
+#pragma unroll
+                for (int q = 0; q < 8; q++) tsum += pv[q];
+                uint32_t run;
+                const uint32_t tot = block_excl_scan1<GB>(tsum, run, tmp);
+                {
+                    uint32_t ex[8];
+#pragma unroll
+                    for (int q = 0; q < 8; q++) { ex[q] = run; run += pv[q]; }
+                    ((uint4 *)gpk)[2 * tid] = make_uint4(ex[0], ex[1], ex[2], ex[3]);
+                    ((uint4 *)gpk)[2 * tid + 1] = make_uint4(ex[4], ex[5], ex[6], ex[7]);
+                }
+                PG(4)
                 const uint32_t nent = tot & 0xfffffu, ngrp = tot >> 20;
                 if (ngrp == 0) continue;
                 if (tid == 0) {
@@ -482,23 +520,35 @@ k_group(SimkaMergeIn in, const ull *seg_abs, const uint16_t *rows, uint32_t np,
                     }
                 }
                 __syncthreads();
+                PG(5)
                 if (s_ovf == 2) continue;
                 const ull eb = s_ebase, gb = s_gbase;
                 const uint32_t soff = s_soff;
-                for (uint32_t i = tid; i < GTAB; i += GB) {
-                    const uint32_t c = scnt[i], g_ = gpk[i];
-                    if (c >= min_share) o.groups[gb + (g_ >> 20)] = (((g_ & 0xfffffu) + soff) << 16) | c;    // start is relative to the span
-                    gpk[i] = g_ & 0xfffffu;               // now: entry offset, advanced as fill cursor
+                {   // the thread's eight slots again: group descriptors out, gpk becomes the entry offset (advanced as fill cursor)
+                    const uint4 c4 = ((const uint4 *)scnt)[tid];
+                    const uint4 g0 = ((const uint4 *)gpk)[2 * tid], g1 = ((const uint4 *)gpk)[2 * tid + 1];
+                    const uint32_t cw[4] = { c4.x, c4.y, c4.z, c4.w };
+                    uint32_t gv[8] = { g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w };
+#pragma unroll
+                    for (int q = 0; q < 8; q++) {
+                        const uint32_t c = (cw[q >> 1] >> ((q & 1) * 16)) & 0xffffu, g_ = gv[q];
+                        if (c >= min_share) o.groups[gb + (g_ >> 20)] = (((g_ & 0xfffffu) + soff) << 16) | c;    // start is relative to the span
+                        gv[q] = g_ & 0xfffffu;
+                    }
+                    ((uint4 *)gpk)[2 * tid] = make_uint4(gv[0], gv[1], gv[2], gv[3]);
+                    ((uint4 *)gpk)[2 * tid + 1] = make_uint4(gv[4], gv[5], gv[6], gv[7]);
                 }
                 __syncthreads();
                 for (uint32_t i = tid; i < nrec; i += GB) {
                     const uint32_t slot = rslot[i];
                     if (scnt[slot] >= min_share) o.entries[eb + atomicAdd(&gpk[slot], 1u)] = rval[i];
                 }
+                PG(6)
             }
         }
       }
     }
+    PG_FLUSH
     __syncthreads();
     if (tid == 0) {
         if (s_ndist) atomicAdd(&o.glob[0], (ull)s_ndist);      // _nbDistinctKmers  (:1315)
