@@ -63,12 +63,7 @@ __device__ __forceinline__ uint32_t block_excl_scan(uint32_t *a, uint32_t n, uin
     const uint32_t e = (b + ipt < n) ? b + ipt : n;
     uint32_t s = 0;
     for (uint32_t i = b; i < e; i++) s += a[i];
-    uint32_t v = s;                                   // inclusive scan across the 64 lanes of the wave
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-        const uint32_t t = __shfl_up(v, o, 64);
-        if (lane >= (uint32_t)o) v += t;
-    }
+    const uint32_t v = wave_incl_scan(s);             // inclusive scan across the 64 lanes of the wave (DPP: no LDS permutes)
     if (lane == 63u) tmp[wave] = v;
     __syncthreads();
     uint32_t wpre = 0, total = 0;
@@ -576,6 +571,18 @@ __device__ __forceinline__ ull simka_whit_abs(ull d) {
 
 __device__ __forceinline__ void tri_unrank(uint32_t idx, uint32_t s, uint32_t &x, uint32_t &y) {
     // pairs (x<y) of s items, row-major; row x starts at x*s - x*(x+1)/2
+    if (s <= 2048u) {      // (2 s - 1)^2 < 2^24: single precision holds the discriminant exactly, 32-bit corrections by at most one row
+        const uint32_t fsu = 2u * s - 1u;
+        const uint32_t disc = fsu * fsu - 8u * idx;                  // >= 1 for idx < s (s - 1) / 2
+        int xi = (int)(((float)fsu - __fsqrt_rn((float)disc)) * 0.5f);
+        const int S = (int)s, id = (int)idx;
+        xi = xi < 0 ? 0 : (xi > S - 2 ? S - 2 : xi);
+        while (xi > 0 && (xi * S - xi * (xi + 1) / 2) > id) xi--;
+        while (xi + 1 <= S - 2 && ((xi + 1) * S - (xi + 1) * (xi + 2) / 2) <= id) xi++;
+        x = (uint32_t)xi;
+        y = (uint32_t)(id - (xi * S - xi * (xi + 1) / 2) + xi + 1);
+        return;
+    }
     const double fs = 2.0 * (double)s - 1.0;
     double disc = fs * fs - 8.0 * (double)idx;
     if (disc < 0) disc = 0;
