@@ -1649,14 +1649,21 @@ k_skm_count_fast(SimkaSkmSrc src, SimkaSkmCfg cfg, SimkaKeyCfg kcfg, uint32_t am
         uint32_t cs[SPT]; ull ks[SPT];
         uint32_t nsol = 0, ndall = 0;
         ull D = 0, N = 0, Q = 0;
-        {   // the thread's 8 slots: vector loads, then the slots are reset unconditionally (vector stores, no branches)
-            static_assert(SPT == 8, "8 slots per thread");
-            uint4 *c4 = (uint4 *)(tcnt + tid * SPT); ulonglong2 *k2 = (ulonglong2 *)(tkeys + tid * SPT);
-            const uint4 ca = c4[0], cb = c4[1];
-            const ulonglong2 ka = k2[0], kb = k2[1], kc = k2[2], kd = k2[3];
+        {   // the thread's 8 slots: vector loads, then the slots are reset unconditionally (vector stores, no branches).
+            // The 16 threads of a group own one sort block of 128 slots (only the order of the BLOCKS matters downstream): thread l of the
+            // group takes the slot pairs 2 l + 32 m, m = 0..3 -- the 16-byte key vectors l + 16 m, consecutive over the lanes of every
+            // access (eight consecutive slots per thread made every 16-byte access a 2- to 4-way bank conflict) -- and the halves of the
+            // count vectors (l >> 1) + 8 m that hold them (neighbouring lanes read the same vector).
+            static_assert(SPT == 8 && TS == 16u * 128u && SKM_FAST_BLOCK == 256, "16 groups of 16 threads, a sort block each");
+            const uint32_t grp = tid >> 4, l = tid & 15u;
+            uint4 *c4 = (uint4 *)(tcnt + grp * 128u) + (l >> 1); ulonglong2 *k2 = (ulonglong2 *)(tkeys + grp * 128u) + l;
+            const uint4 ca = c4[0], cb = c4[8], cc = c4[16], cd = c4[24];
+            const ulonglong2 ka = k2[0], kb = k2[16], kc = k2[32], kd = k2[48];
             const uint4 z = make_uint4(0, 0, 0, 0); const ulonglong2 ek = make_ulonglong2(SIMKA_EMPTY_KEY, SIMKA_EMPTY_KEY);
-            c4[0] = z; c4[1] = z; k2[0] = ek; k2[1] = ek; k2[2] = ek; k2[3] = ek;
-            cs[0] = ca.x; cs[1] = ca.y; cs[2] = ca.z; cs[3] = ca.w; cs[4] = cb.x; cs[5] = cb.y; cs[6] = cb.z; cs[7] = cb.w;
+            c4[0] = z; c4[8] = z; c4[16] = z; c4[24] = z; k2[0] = ek; k2[16] = ek; k2[32] = ek; k2[48] = ek;      // (both lanes of a pair zero the same count vector)
+            const bool hi_ = (l & 1u) != 0u;
+            cs[0] = hi_ ? ca.z : ca.x; cs[1] = hi_ ? ca.w : ca.y; cs[2] = hi_ ? cb.z : cb.x; cs[3] = hi_ ? cb.w : cb.y;
+            cs[4] = hi_ ? cc.z : cc.x; cs[5] = hi_ ? cc.w : cc.y; cs[6] = hi_ ? cd.z : cd.x; cs[7] = hi_ ? cd.w : cd.y;
             ks[0] = ka.x; ks[1] = ka.y; ks[2] = kb.x; ks[3] = kb.y; ks[4] = kc.x; ks[5] = kc.y; ks[6] = kd.x; ks[7] = kd.y;
         }
 #pragma unroll
