@@ -1558,13 +1558,21 @@ k_skm_count_fast(SimkaSkmSrc src, SimkaSkmCfg cfg, SimkaKeyCfg kcfg, uint32_t am
         // ---- expand + insert: every wave takes an equal share of the records (at most 64 per batch)
         PH(0)
         ull my_k = 0;
+        // (the records of the SECOND batch -- about every other C3 partition has a few beyond the first 256 -- are asked for now and
+        //  arrive behind the inserts of the first: loaded where they are needed, every wave sat out a trip to memory)
+        uint4 pre2 = make_uint4(0, 0, 0, 0);
+        if (nrec > (uint32_t)SKM_FAST_BLOCK) {
+            const uint32_t nb2 = nrec - SKM_FAST_BLOCK < (uint32_t)SKM_FAST_BLOCK ? nrec - SKM_FAST_BLOCK : (uint32_t)SKM_FAST_BLOCK;
+            const uint32_t per2 = (nb2 + NW - 1u) / NW;
+            if (lane < per2 && wave * per2 + lane < nb2) pre2 = rec_at(rbase, SKM_FAST_BLOCK + wave * per2 + lane);
+        }
         for (uint32_t b0 = 0; b0 < nrec; b0 += SKM_FAST_BLOCK) {
             const uint32_t nb = nrec - b0 < (uint32_t)SKM_FAST_BLOCK ? nrec - b0 : (uint32_t)SKM_FAST_BLOCK;
             const uint32_t per = (nb + NW - 1u) / NW;                       // records of this wave: [b0 + wave*per, +per)
             const uint32_t i = b0 + wave * per + lane;
             const bool mine = lane < per && wave * per + lane < nb;
-            uint4 rc = pre;
-            if (b0) { if (mine) rc = rec_at(rbase, i); }
+            uint4 rc = b0 == (uint32_t)SKM_FAST_BLOCK ? pre2 : pre;
+            if (b0 > (uint32_t)SKM_FAST_BLOCK) { if (mine) rc = rec_at(rbase, i); }
             uint32_t len = mine ? skm_rec_n(rc) : 0u;
             const uint32_t x = wave_incl_scan(len);
             const uint32_t kt = __builtin_amdgcn_readlane(x, 63);
