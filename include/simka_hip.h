@@ -44,9 +44,13 @@ enum { SIMKA_DIST_SIMPLE = 1u, SIMKA_DIST_COMPLEX = 2u };
 /* simka_config.flags */
 enum {
     SIMKA_CFG_ARENA_PLAIN = 1u   /* allocate the solid-spectrum arena with one plain device allocation instead of a reserved virtual range
-                                  * that is mapped as the samples arrive.  The library also does so by itself when another context is alive
-                                  * on the same device (several contexts of one process mapping and launching concurrently is the pattern
-                                  * that ended in a GPU memory fault about once in a hundred runs, scripts/ubench/vmm_two_contexts.hip). */
+                                  * that is mapped as the samples arrive.  The mode is fixed in simka_create: a context created while another
+                                  * one is alive on the same device takes a plain arena by itself; the EARLIER context keeps its mapped
+                                  * range, so a caller that creates several contexts on one device up front sets this flag on ALL of them.
+                                  * (Background: a virtual range that is unmapped and mapped again is accessed through stale translations on
+                                  * ROCm 7.0 / gfx950, scripts/ubench/vmm_two_contexts.hip; the library retires the ranges of destroyed
+                                  * contexts instead of reusing them, the plain mode is the second line of defence.)  Any other bit set in
+                                  * simka_config.flags is rejected with SIMKA_ERR_INVALID. */
 };
 
 typedef struct simka_ctx simka_ctx;

@@ -85,6 +85,7 @@ struct simka_ctx {
     bool arena_vmm = false; uint64_t arena_mapped = 0, arena_hi = 0, arena_reserved = 0;      // (arena_reserved: arena_cap rounded up to whole chunks)
     uint64_t lane_bound[MAX_LANES] = {};
     bool used_gather = false;                   // the partitioning kernel of this context is k_skm_chunksort (profile name)
+    bool arena_plain = false;                   // plain hipMalloc arena instead of a lazily mapped virtual range (decided in simka_create)
     bool live_counted = false;                  // this context is part of g_live_ctx[device]
     std::vector<char> arena_accounted;          // per sample: its bound is part of arena_hi (a redo or a further pass adds nothing)
     std::vector<hipMemGenericAllocationHandle_t> arena_hk, arena_hc;
@@ -439,7 +440,8 @@ static int setup_geometry(simka_ctx *ctx, uint64_t max_kmers) {
         // plain allocation on request, and whenever another context is alive on this device: chunks being mapped while another
         // context's kernels run is the pattern that faulted (root cause unknown; scripts/ubench/vmm_two_contexts.hip)
         const int dv = c.device >= 0 && c.device < 64 ? c.device : 0;
-        const bool plain = (c.flags & SIMKA_CFG_ARENA_PLAIN) || simka_test_knob("SIMKA_ARENA_MALLOC") || g_live_ctx[dv] > 1 || g_vmm_retired_bytes > ((uint64_t)1 << 45);
+        (void)dv;
+        const bool plain = ctx->arena_plain || g_vmm_retired_bytes > ((uint64_t)1 << 45);      // (decided in simka_create, not at the lazy geometry setup)
         if (!plain && hipMemAddressReserve(&vk, capr * 8, 0, nullptr, 0) == hipSuccess) {
             if (hipMemAddressReserve(&vc, capr * 4, 0, nullptr, 0) == hipSuccess) {
                 ctx->arena_vmm = true; ctx->d_solid_keys = (ull *)vk; ctx->d_solid_counts = (uint32_t *)vc; ctx->arena_reserved = capr; ctx->arena_mapped = 0;
@@ -466,6 +468,7 @@ SIMKA_EXPORT int simka_create(const simka_config *cfg, simka_ctx **out) {
     if (cfg->kmer_size < 1 || cfg->kmer_size > 127) { g_create_error = "simka_create: kmer_size must be in [1,127]"; return SIMKA_ERR_INVALID; }
     const bool want_wide = cfg->kmer_size > 31 || simka_test_knob("SIMKA_SORT_PATH") != nullptr;
     if (cfg->shard_count == 0 || cfg->shard_index >= cfg->shard_count) { g_create_error = "simka_create: bad shard_index/shard_count"; return SIMKA_ERR_INVALID; }
+    if (cfg->flags & ~(uint32_t)SIMKA_CFG_ARENA_PLAIN) { g_create_error = "simka_create: unknown bits in simka_config.flags (an ABI <= 5 caller must zero reserved0)"; return SIMKA_ERR_INVALID; }
     if (cfg->log2_subranges > 8) { g_create_error = "simka_create: log2_subranges must be <= 8"; return SIMKA_ERR_INVALID; }
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
@@ -475,7 +478,15 @@ SIMKA_EXPORT int simka_create(const simka_config *cfg, simka_ctx **out) {
     if (cfg->device < 0 || cfg->device >= ndev) { g_create_error = "simka_create: bad device ordinal"; return SIMKA_ERR_INVALID; }
     simka_ctx *ctx = new simka_ctx();
     ctx->cfg = *cfg;
-    { std::lock_guard<std::mutex> g_(g_vmm_lock); if (cfg->device < 64) g_live_ctx[cfg->device]++; ctx->live_counted = true; }
+    {   // the arena mode is fixed HERE, from what is alive at creation: a context that finds another one on its device takes a plain arena
+        // (the known fault needs a range that is unmapped and mapped again, which the library no longer does -- retired ranges --, so
+        // this is a second line of defence; callers that create several contexts on one device up front set SIMKA_CFG_ARENA_PLAIN
+        // on all of them, see include/simka_hip.h)
+        std::lock_guard<std::mutex> g_(g_vmm_lock);
+        if (cfg->device < 64) g_live_ctx[cfg->device]++;
+        ctx->live_counted = true;
+        ctx->arena_plain = (cfg->flags & SIMKA_CFG_ARENA_PLAIN) || simka_test_knob("SIMKA_ARENA_MALLOC") || (cfg->device < 64 && g_live_ctx[cfg->device] > 1);
+    }
     if (ctx->cfg.abundance_max > 999999999u) ctx->cfg.abundance_max = 999999999u;   // ref: src/core/SimkaAlgorithm.cpp:188
     auto bail = [&](int rc) { g_create_error = ctx->err; simka_destroy(ctx); return rc; };
     if (hipSetDevice(cfg->device) != hipSuccess) { ctx->err = "hipSetDevice failed"; return bail(SIMKA_ERR_HIP); }
@@ -1710,14 +1721,16 @@ SIMKA_EXPORT int simka_import_samples_device(simka_ctx *ctx, const uint32_t *sam
     if (ctx->d_hist && w) {   // -complex-dist: per-sample histogram of the imported solid counts (Whittaker's one-sided terms), on the device:
         // the imported runs are described by the tables just uploaded (C5 on eight ranks imports 2.4e9 records per rank -- not a host loop)
         const uint32_t gx = (uint32_t)std::min<uint64_t>(w, 1024);
+        bool hist_ok = true;
         auto launch = [&](uint32_t s0, uint32_t ns) {
-            (void)hipMemsetAsync(ctx->d_hist + (uint64_t)s0 * SIMKA_HIST_MAX, 0, (size_t)ns * SIMKA_HIST_MAX * 8, ctx->stream);
+            if (hipMemsetAsync(ctx->d_hist + (uint64_t)s0 * SIMKA_HIST_MAX, 0, (size_t)ns * SIMKA_HIST_MAX * 8, ctx->stream) != hipSuccess) { hist_ok = false; return; }
             hipLaunchKernelGGL(k_import_hist, dim3(gx, ns), dim3(256), 0, ctx->stream, (const uint32_t *)ctx->d_solid_counts, (const ull *)ctx->d_sample_base,
                                (const uint32_t *)ctx->d_foff, (const uint32_t *)ctx->d_fcnt, (uint32_t)P, (uint32_t)pmin, (uint32_t)w, s0, (ull *)ctx->d_hist,
                                ctx->d_ovf_list, (ull *)ctx->d_ovf_cursor, (ull)ctx->ovf_cap);
         };
         if (consecutive) launch(samples[0], nb);
         else for (uint32_t j = 0; j < nb; j++) launch(samples[j], 1);
+        if (!hist_ok) { ctx->err = "simka_import_samples_device: clearing the count histogram failed"; return SIMKA_ERR_HIP; }
         HIPCHK(hipGetLastError());
     }
     HIPCHK(hipStreamSynchronize(ctx->stream));

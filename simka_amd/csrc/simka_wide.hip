@@ -545,7 +545,9 @@ static int wide_sort_words(SimkaWide *w, uint64_t n, uint32_t hi_bits, ull *hi0,
 
 int simka_wide_create(SimkaWide **out, int device, uint32_t nb_samples, uint32_t k, void *stream) {
     SimkaWide *w = new SimkaWide();
-    w->device = device; w->nb_samples = nb_samples; w->k = k; w->W = k >= 64 ? 126 : 2 * k;      // (k >= 64: the keys are 126-bit fingerprints, wfinger) w->stream = (hipStream_t)stream;
+    // k >= 64: the keys are 126-bit fingerprints (wfinger)
+    w->device = device; w->nb_samples = nb_samples; w->k = k; w->W = k >= 64 ? 126 : 2 * k;
+    w->stream = (hipStream_t)stream;
     w->s_off.assign(nb_samples, 0); w->s_n.assign(nb_samples, 0); w->s_sorted.assign(nb_samples, 1);
     *out = w;
     return 0;

@@ -137,3 +137,19 @@ def test_cli_error_conventions(simka_lib):
         r = subprocess.run([b.CLI_PATH, "-in", inp, "-out", "/tmp/simka_cli_o", "-out-tmp", "/tmp/simka_cli_t", "-verbose", "0"],
                            stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
         assert r.returncode == 1 and "EXCEPTION" in r.stdout and "no CPU fallback" in r.stdout
+
+
+def test_create_rejects_unknown_config_flags(simka_lib):
+    """simka_config.flags (reserved0 up to ABI 5): a bit the library does not know is an error, not a silent mode switch -- checked before
+    any device is touched, so this runs without a GPU (advisor, round 4)."""
+    import ctypes as C
+    import simka_amd
+    from simka_amd import api
+    cfg = api.Config()
+    cfg.struct_size = C.sizeof(api.Config)
+    cfg.nb_samples, cfg.kmer_size, cfg.abundance_min, cfg.abundance_max = 2, 21, 2, 999999999
+    cfg.shard_index, cfg.shard_count = 0, 1
+    cfg.flags = 0x10
+    h = C.c_void_p()
+    assert simka_lib.simka_create(C.byref(cfg), C.byref(h)) == 1      # SIMKA_ERR_INVALID
+    assert b"flags" in simka_lib.simka_last_error(None)

@@ -173,25 +173,168 @@ def test_c2_full_size_bit_exact_vs_oracle(device_reads, oracle_mod):
     orc.close()
 
 
-def test_c3_shape_at_100k_reads_bit_exact_vs_oracle(gpu_required, oracle_mod):
-    """BASELINE configs[2]'s shape (100 samples, 150 bp, k = 31, -simple-dist, abundance-min 2) at 100 000 reads per sample -- 1.2e9
-    k-mer occurrences, a hundredth of the full depth and 20x the depth of test_baseline_config_shapes_vs_oracle -- bit-exact vs the
-    oracle.  The partition geometry is the one the full-depth run uses per k-mer occurrence (sized from the sample)."""
-    torch = gpu_required
-    import simka_amd
+class _OracleResult:
+    """What the parity checks need from an oracle run, kept after the oracle (and its copy of the reads) is gone."""
+
+    def __init__(self, orc, simple, complex_):
+        self.n = orc.n
+        self.simple, self.complex_ = simple, complex_
+        self.tot = {k: v.copy() for k, v in orc.totals().items()}
+        self.accs = {name: orc.acc(name) for name in (["S", "a", "bc"] + (["chord", "hell"] if simple else []) + (["whit", "canb"] if complex_ else []))}
+        self.kl_ = orc.kl() if complex_ else None
+        self.glob = orc.global_counts()
+        self.names = orc.matrix_names()
+        self.mats = [orc.matrix(w) for w in range(len(self.names))]
+
+    def totals(self):
+        return self.tot
+
+    def acc(self, name):
+        return self.accs[name]
+
+    def kl(self):
+        return self.kl_
+
+    def global_counts(self):
+        return self.glob
+
+    def matrix_names(self):
+        return self.names
+
+    def matrix(self, w):
+        return self.mats[w]
+
+
+def _device_workload(torch, name, **over):
+    import sys, os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if root not in sys.path:
+        sys.path.insert(0, root)
     import bench
-    n, R3, L3, k3 = 100, 100_000, 150, 31
-    wl = dict(bench.WORKLOADS["c3"], n=n, reads=R3)
-    lib = simka_amd.load_library()
-    _, reads = bench.gen_device_samples(lib, torch, wl, torch.device("cuda", 0))
-    ctx = simka_amd.SimkaContext(n, kmer_size=k3, abundance_min=2, simple_dist=True, complex_dist=False, max_kmers_per_sample=R3 * (L3 - k3 + 1))
-    for s in range(n):
-        ctx.count_sample(s, reads[s].data_ptr(), R3 * L3, R3, fixed_len=L3, on_device=True)
-    ctx.merge()
-    st = ctx.stats()
-    ctx.close()
-    orc, threads = _oracle_of(oracle_mod, reads, n, R3, L3)
-    del reads
-    orc.run(k3, 2, simple=True, complex_=False, nparts=4 * threads, threads=threads)
-    _flat_equal_to_oracle(st, orc, n, True, False)
+    import simka_amd
+    wl = dict(bench.WORKLOADS[name], **over)
+    _, reads = bench.gen_device_samples(simka_amd.load_library(), torch, wl, torch.device("cuda", 0))
+    return wl, reads
+
+
+def _hip_stats(reads, wl, order=None, **kw):
+    import simka_amd
+    n, R_, L_, k_ = wl["n"], wl["reads"], wl["L"], wl["k"]
+    order = list(range(n)) if order is None else order
+    with simka_amd.SimkaContext(len(order), kmer_size=k_, abundance_min=wl["amin"], simple_dist=wl["simple"], complex_dist=bool(wl.get("complex")),
+                                max_kmers_per_sample=R_ * (L_ - k_ + 1), **kw) as ctx:
+        for slot, s in enumerate(order):
+            ctx.count_sample(slot, reads[s].data_ptr(), R_ * L_, R_, fixed_len=L_, on_device=True)
+        ctx.merge()
+        return ctx.stats()
+
+
+def _oracle_result(oracle_mod, reads, wl):
+    orc, threads = _oracle_of(oracle_mod, reads, wl["n"], wl["reads"], wl["L"])
+    orc.run(wl["k"], wl["amin"], simple=wl["simple"], complex_=bool(wl.get("complex")), nparts=4 * threads, threads=threads)
+    res = _OracleResult(orc, wl["simple"], bool(wl.get("complex")))
     orc.close()
+    return res
+
+
+@pytest.fixture(scope="module")
+def c3_100k(gpu_required, oracle_mod):
+    """BASELINE configs[2] / configs[3]'s shape (100 samples, 150 bp, k = 31, -simple-dist, abundance-min 2) at 100 000 reads per sample:
+    the reads on the device + ONE oracle run that the single-context test and the two 8-rank decompositions of configs[3] share."""
+    wl, reads = _device_workload(gpu_required, "c3", reads=100_000)
+    return wl, reads, _oracle_result(oracle_mod, reads, wl)
+
+
+def test_c3_shape_at_100k_reads_bit_exact_vs_oracle(c3_100k):
+    """BASELINE configs[2]'s shape at 100 000 reads per sample -- 1.2e9 k-mer occurrences, a hundredth of the full depth and 20x the
+    depth of test_baseline_config_shapes_vs_oracle -- bit-exact vs the oracle.  The partition geometry is the one the full-depth run
+    uses per k-mer occurrence (sized from the sample)."""
+    wl, reads, ref = c3_100k
+    _flat_equal_to_oracle(_hip_stats(reads, wl), ref, wl["n"], True, False)
+
+
+def test_c4_eight_partition_shards_sum_to_the_oracle(c3_100k):
+    """BASELINE configs[3] (C3's job with the minimizer space sharded over 8 GPUs + ONE all-reduce of the N x N partials,
+    ref: src/SimkaPotara.hpp:974-1124 one merge job per partition, src/core/SimkaDistance.cpp:156-213 operator+=) emulated on one
+    GPU: eight contexts with shard_index g of 8 scan every read and keep the partitions p % 8 == g; the SUM of their flat statistics
+    -- what the all-reduce computes -- is compared with the ORACLE, not with the single-context run."""
+    import simka_amd
+    wl, reads, ref = c3_100k
+    n = wl["n"]
+    total = None
+    for g in range(8):
+        st = _hip_stats(reads, wl, shard_index=g, shard_count=8, solid_capacity=60_000_000)
+        f = st.flat.copy()
+        lay = st.layout
+        total = f if total is None else total + f          # accumulators AND the per-sample totals rows (partial per shard) add up
+    # D_all / K_occ rows: every shard counts its own share as well
+    summed = simka_amd.Stats(n, st.dist_flags, total[: lay["derived"]])
+    _flat_equal_to_oracle(summed, ref, n, True, False)
+
+
+def test_c4_eight_sample_shards_exchange_and_merge_to_the_oracle(c3_100k):
+    """BASELINE configs[3] the other way round (simka_amd/dist.py::count_exchange_merge: one count job per sample, one merge job per
+    partition RANGE -- the reference's own job structure, ref: src/SimkaPotara.hpp:813-1124): rank r of 8 counts the samples
+    s % 8 == r, the solid spectra are routed to the rank that owns their partition range (the all-to-all done by hand), every rank
+    imports + merges its range, and the summed heads are compared with the ORACLE."""
+    import torch
+    import simka_amd
+    from simka_amd import dist as sdist
+    wl, reads, ref = c3_100k
+    n, R_, L_, k_ = wl["n"], wl["reads"], wl["L"], wl["k"]
+    world = 8
+    dev = torch.device("cuda:0")
+    kw = dict(kmer_size=k_, abundance_min=wl["amin"], simple_dist=True, complex_dist=False, max_kmers_per_sample=R_ * (L_ - k_ + 1), solid_capacity=120_000_000)
+    sends, nparts = [], None
+    for r in range(world):
+        with simka_amd.SimkaContext(n, **kw) as c:
+            mine = sdist.samples_of(r, world, n)
+            for s in mine:
+                c.count_sample(s, reads[s].data_ptr(), R_ * L_, R_, fixed_len=L_, on_device=True)
+            local = {s: c.export_sample_device(s, dev) for s in mine}
+        nparts = len(next(iter(local.values()))[1])
+        sends.append(local)
+    packs = [sdist.pack_spectra(sends[r], nparts, world, n, r, dev) for r in range(world)]
+    tot_all = np.stack([p[1] for p in packs])
+    lay = simka_amd.api.stats_layout(n, 1)
+    head = lay["head"]
+    total = np.zeros(head, dtype=np.uint64)
+    last = None
+    for g in range(world):
+        meta_recv = np.stack([packs[r][0][g] for r in range(world)])
+        kr, cr = [], []
+        for r in range(world):
+            splits = packs[r][4]
+            lo = sum(splits[:g])
+            kr.append(packs[r][2][lo: lo + splits[g]]); cr.append(packs[r][3][lo: lo + splits[g]])
+        incoming = sdist.unpack_spectra(meta_recv, tot_all, torch.cat(kr), torch.cat(cr), nparts, world, n, g)
+        with simka_amd.SimkaContext(n, **kw) as c:
+            for s, t, pc, kk, cc in incoming:
+                c.import_sample_device(s, t, pc, kk, cc)
+            c.merge()
+            last = c.stats()
+        total += last.flat[:head]
+    flat = last.flat.copy()
+    flat[:head] = total
+    _flat_equal_to_oracle(simka_amd.Stats(n, last.dist_flags, flat[: lay["derived"]]), ref, n, True, False)
+
+
+def test_c3_at_a_tenth_of_its_depth_bit_exact_vs_oracle(gpu_required, oracle_mod):
+    """bench.py's `c3_10` (BASELINE configs[2] at 1M reads per sample: 1.2e10 k-mer occurrences, 2^16 x 8 partitions per sample as a
+    full-depth run has per occurrence) bit-exact vs the oracle -- the deepest oracle comparison of the suite (minutes of CPU)."""
+    wl, reads = _device_workload(gpu_required, "c3_10")
+    st = _hip_stats(reads, wl)
+    ref = _oracle_result(oracle_mod, reads, wl)
+    del reads
+    _flat_equal_to_oracle(st, ref, wl["n"], True, False)
+
+
+def test_c5_shape_at_10k_reads_bit_exact_vs_oracle(gpu_required, oracle_mod):
+    """BASELINE configs[4]'s shape (500 samples, 150 bp, k = 31, -simple-dist -complex-dist: the tiled pair accumulator and the
+    closed forms of updateDistanceComplex, ref: src/core/SimkaAlgorithm.hpp:404-516) at 10 000 reads per sample -- 25x the depth of
+    test_baseline_config_shapes_vs_oracle[c5_shape]; the oracle's literal O(N^2) complex update is what bounds the depth."""
+    wl, reads = _device_workload(gpu_required, "c5_5", reads=10_000)
+    st = _hip_stats(reads, wl)
+    ref = _oracle_result(oracle_mod, reads, wl)
+    del reads
+    _flat_equal_to_oracle(st, ref, wl["n"], True, True)

@@ -1088,6 +1088,17 @@ def test_wide_kmers_on_the_partitioned_pipeline(gpu_required, oracle_mod, k, ami
     _wide_case(oracle_mod, k, amin, n, R, L, expect="partitioned", fixed=fixed)
 
 
+@pytest.mark.parametrize("k", [33, 57, 70])
+def test_wide_kmers_on_a_non_blocking_caller_stream(gpu_required, oracle_mod, k):
+    """simka_config.stream: a caller-supplied NON-BLOCKING stream (torch's pool streams are created with hipStreamNonBlocking) does not
+    synchronise with the null stream, so every kernel and copy of the k >= 32 state must run on that very stream -- a round-4 slip had
+    them on the null stream, which only the blocking private stream of the other tests forgave (advisor, round 4)."""
+    torch = gpu_required
+    stream = torch.cuda.Stream()
+    for rep in range(3):
+        _wide_case(oracle_mod, k, 2, 4, 3000 + 500 * rep, 150, expect="partitioned" if k <= 51 else "sorted", stream=stream.cuda_stream)
+
+
 @pytest.mark.parametrize("per_part,general,expect", [(3000, False, "partitioned"), (192, True, "partitioned"), (200000, False, "sorted")])
 def test_wide_kmers_partitions_beyond_the_tables(gpu_required, oracle_mod, monkeypatch, per_part, general, expect):
     """The three ways a partition of two-word k-mers gets counted: in a wave's table (the other tests), in the block's table when it
@@ -1212,12 +1223,14 @@ def test_hash_and_sort_pipelines_agree_at_scale(gpu_required):
     assert r.returncode == 0 and "cross-check ok" in r.stdout, r.stdout[-3000:]
 
 
-@pytest.mark.parametrize("workload,alt_pb", [("c2", 13), ("c3_10", 14), ("c3", 20)])
+@pytest.mark.parametrize("workload,alt_pb", [("c2", 13), ("c3_10", 14), ("c3", 20), ("c5_5", 14)])
 def test_full_size_size_independent_properties(gpu_required, workload, alt_pb):
     """BASELINE configs[1] at FULL size (c2: 10 samples x 1M x 100 bp, k = 21, 8e8 k-mer occurrences -- far beyond what the
     oracle finishes in seconds) and configs[2]'s shape at a tenth of its depth (c3_10: 100 samples x 1M x 150 bp, k = 31,
     -simple-dist, 1.2e10 occurrences; the full 37 GB of reads are bench.py --workload c3), checked through properties that hold
     and configs[2] ITSELF (c3: 100 samples x 10M x 150 bp, k = 31, 1.2e11 occurrences, ~190 GB of HBM)
+    and configs[4]'s shape at the largest depth one GPU holds (c5_5: 500 samples x 1M x 150 bp, k = 31, -simple-dist -complex-dist,
+    6e10 occurrences, the tiled pair accumulator; Whittaker / Canberra / KL join the permutation check)
     for any input:
       * the partition geometry is result-neutral (SURVEY F4): another number of partitions gives bit-identical statistics;
       * the path is equivariant under a permutation of the samples (S_ij <-> S_ji where the order of a pair flips);
@@ -1233,10 +1246,11 @@ def test_full_size_size_independent_properties(gpu_required, workload, alt_pb):
     wl = dict(bench.WORKLOADS[workload])
     n, R, L, k = wl["n"], wl["reads"], wl["L"], wl["k"]
     dev = torch.device("cuda:0")
+    cplx = bool(wl.get("complex"))
     _, reads = bench.gen_device_samples(lib, torch, wl, dev)
 
     def run(order, **kw):
-        with simka_amd.SimkaContext(len(order), kmer_size=k, abundance_min=wl["amin"], simple_dist=True, max_kmers_per_sample=R * (L - k + 1), **kw) as c:
+        with simka_amd.SimkaContext(len(order), kmer_size=k, abundance_min=wl["amin"], simple_dist=True, complex_dist=cplx, max_kmers_per_sample=R * (L - k + 1), **kw) as c:
             for slot, s in enumerate(order):
                 c.count_sample(slot, reads[s].data_ptr(), R * L, R, fixed_len=L, on_device=True)
             c.merge()
@@ -1247,7 +1261,11 @@ def test_full_size_size_independent_properties(gpu_required, workload, alt_pb):
     assert int(base.per_sample()["K_occ"].sum()) == n * R * (L - k + 1)
     # geometry
     other = run(ident, log2_partitions=alt_pb)
-    assert np.array_equal(base.flat, other.flat)
+    if cplx:      # the both-present KL sums are 2^-60 fixed point: integer adds, so the geometry does not change them either
+        assert np.array_equal(base.flat[: base.layout["derived"]], other.flat[: other.layout["derived"]])
+        np.testing.assert_allclose(other.pairs()["kl"], base.pairs()["kl"], rtol=1e-12, atol=1e-15)
+    else:
+        assert np.array_equal(base.flat, other.flat)
     del other
     # permutation of the samples
     perm = [int(x) for x in np.random.default_rng(5).permutation(n)]
@@ -1258,8 +1276,13 @@ def test_full_size_size_independent_properties(gpu_required, workload, alt_pb):
     bS, pS = base.dense("S"), pst.dense("S")
     full = lambda m: m + m.T
     assert np.array_equal(pS, bS[np.ix_(perm, perm)])
-    for name in ("a", "bc", "chord", "hell"):
+    for name in ("a", "bc", "chord", "hell") + (("whit", "canb") if cplx else ()):
         assert np.array_equal(full(pst.dense(name)), full(base.dense(name))[np.ix_(perm, perm)]), name
+    if cplx:      # KL: the pair term is evaluated in the order of the pair, so a flipped pair may round differently
+        iu_ = np.triu_indices(n, 1)
+        kb, kp = np.zeros((n, n)), np.zeros((n, n))
+        kb[iu_], kp[iu_] = base.pairs()["kl"], pst.pairs()["kl"]
+        np.testing.assert_allclose(full(kp), full(kb)[np.ix_(perm, perm)], rtol=1e-9, atol=1e-15)
     # bounds
     pr = base.pairs()
     iu = np.triu_indices(n, 1)
@@ -1278,6 +1301,8 @@ def test_full_size_size_independent_properties(gpu_required, workload, alt_pb):
             # (the reference never writes _kulczynski_minNiNj[j][i], ref: src/core/SimkaDistance.cpp:1024-1038, so its abundance
             # Kulczynski distance of identical samples is 1 - (1 + 0) / 2; the goldens pin that quirk and the host mirrors it)
             want = 0.5 if name == "mat_abundance_kulczynski" else 0.0
+            if name == "mat_abundance_jensenshannon":       # KL == 0 -> 1 in the reference (ref: src/core/SimkaDistance.cpp:1001-1007)
+                want = 1.0
             v = float(mat[0, 1])
             # chord / Hellinger are sqrt(2 - 2 x / (sqrt(Q) sqrt(Q))) in the reference (ref: src/core/SimkaDistance.cpp:942-972):
             # for identical samples the denominator may round a hair below x and the reference's own formula yields NaN
