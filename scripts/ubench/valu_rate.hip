@@ -73,11 +73,41 @@ KERNEL(k_bitop3, "v_bitop3_b32 %0, %0, %12, %13 bitop3:0x34\nv_bitop3_b32 %1, %1
 KERNEL(k_dpp_mov, "v_mov_b32_dpp %0, %1 row_shr:1 row_mask:0xf bank_mask:0xf\nv_mov_b32_dpp %1, %2 row_shr:1 row_mask:0xf bank_mask:0xf\nv_mov_b32_dpp %2, %3 row_shr:1 row_mask:0xf bank_mask:0xf\nv_mov_b32_dpp %3, %4 row_shr:1 row_mask:0xf bank_mask:0xf\nv_mov_b32_dpp %4, %5 row_shr:1 row_mask:0xf bank_mask:0xf\nv_mov_b32_dpp %5, %6 row_shr:1 row_mask:0xf bank_mask:0xf\nv_mov_b32_dpp %6, %7 row_shr:1 row_mask:0xf bank_mask:0xf\nv_mov_b32_dpp %7, %0 row_shr:1 row_mask:0xf bank_mask:0xf\n")
 KERNEL(k_add_dpp, "v_add_u32_dpp %0, %1, %0 row_shr:1 row_mask:0xf bank_mask:0xf\nv_add_u32_dpp %1, %2, %1 row_shr:2 row_mask:0xf bank_mask:0xf\nv_add_u32_dpp %2, %3, %2 row_shr:4 row_mask:0xf bank_mask:0xf\nv_add_u32_dpp %3, %4, %3 row_shr:8 row_mask:0xf bank_mask:0xf\nv_add_u32_dpp %4, %5, %4 row_bcast:15 row_mask:0xa bank_mask:0xf\nv_add_u32_dpp %5, %6, %5 row_bcast:31 row_mask:0xc bank_mask:0xf\nv_add_u32_dpp %6, %7, %6 row_shr:1 row_mask:0xf bank_mask:0xf\nv_add_u32_dpp %7, %0, %7 row_shr:2 row_mask:0xf bank_mask:0xf\n")
 KERNEL(k_sdwa, "v_and_b32_sdwa %0, %0, %12 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_0 src1_sel:DWORD\nv_and_b32_sdwa %1, %1, %12 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_0 src1_sel:DWORD\nv_and_b32_sdwa %2, %2, %12 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_0 src1_sel:DWORD\nv_and_b32_sdwa %3, %3, %12 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_0 src1_sel:DWORD\nv_and_b32_sdwa %4, %4, %12 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_0 src1_sel:DWORD\nv_and_b32_sdwa %5, %5, %12 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_0 src1_sel:DWORD\nv_and_b32_sdwa %6, %6, %12 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_0 src1_sel:DWORD\nv_and_b32_sdwa %7, %7, %12 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_0 src1_sel:DWORD\n")
-KERNEL(k_salu, "s_add_u32 s20, s20, s21\ns_and_b32 s21, s21, s22\ns_lshl_b32 s22, s22, 1\ns_bcnt1_i32_b32 s23, s24\ns_add_u32 s24, s24, s25\ns_or_b32 s25, s25, s26\ns_xor_b32 s26, s26, s27\ns_add_u32 s27, s27, s20\n")
-KERNEL(k_salu64, "s_and_b64 s[20:21], s[20:21], s[22:23]\ns_or_b64 s[22:23], s[22:23], s[24:25]\ns_xor_b64 s[24:25], s[24:25], s[26:27]\ns_bcnt1_i32_b64 s26, s[20:21]\ns_and_b64 s[20:21], s[20:21], s[22:23]\ns_or_b64 s[22:23], s[22:23], s[24:25]\ns_xor_b64 s[24:25], s[24:25], s[20:21]\ns_bcnt1_i32_b64 s27, s[22:23]\n")
-// VALU and SALU interleaved: do they issue in parallel from different waves of a SIMD?
-KERNEL(k_valu_salu, "v_add_u32 %0, %0, %12\ns_add_u32 s20, s20, s21\nv_add_u32 %1, %1, %12\ns_and_b32 s21, s21, s22\nv_add_u32 %2, %2, %12\ns_lshl_b32 s22, s22, 1\nv_add_u32 %3, %3, %12\ns_add_u32 s24, s24, s25\n")
 
+
+KERNEL(k_or, I32_8("v_or_b32"))
+KERNEL(k_sub, I32_8("v_sub_u32"))
+KERNEL(k_max, I32_8("v_max_u32"))
+KERNEL(k_ashr, I32S_8("v_ashrrev_i32"))
+KERNEL(k_not, I32_1_8("v_not_b32"))
+KERNEL(k_lshl_c, "v_lshlrev_b32 %0, 3, %0\nv_lshlrev_b32 %1, 3, %1\nv_lshlrev_b32 %2, 3, %2\nv_lshlrev_b32 %3, 3, %3\nv_lshlrev_b32 %4, 3, %4\nv_lshlrev_b32 %5, 3, %5\nv_lshlrev_b32 %6, 3, %6\nv_lshlrev_b32 %7, 3, %7\n")
+KERNEL(k_lshr_c, "v_lshrrev_b32 %0, 3, %0\nv_lshrrev_b32 %1, 3, %1\nv_lshrrev_b32 %2, 3, %2\nv_lshrrev_b32 %3, 3, %3\nv_lshrrev_b32 %4, 3, %4\nv_lshrrev_b32 %5, 3, %5\nv_lshrrev_b32 %6, 3, %6\nv_lshrrev_b32 %7, 3, %7\n")
+KERNEL(k_alignbit_c, "v_alignbit_b32 %0, %0, %12, 6\nv_alignbit_b32 %1, %1, %12, 6\nv_alignbit_b32 %2, %2, %12, 6\nv_alignbit_b32 %3, %3, %12, 6\nv_alignbit_b32 %4, %4, %12, 6\nv_alignbit_b32 %5, %5, %12, 6\nv_alignbit_b32 %6, %6, %12, 6\nv_alignbit_b32 %7, %7, %12, 6\n")
+KERNEL(k_mov_b64, "v_mov_b64 %8, %9\nv_mov_b64 %9, %10\nv_mov_b64 %10, %11\nv_mov_b64 %11, %8\nv_mov_b64 %8, %9\nv_mov_b64 %9, %10\nv_mov_b64 %10, %11\nv_mov_b64 %11, %8\n")
+KERNEL(k_cnd_after_cmp, "v_cmp_lt_u32 vcc, %0, %12\nv_cndmask_b32 %1, %1, %12, vcc\nv_cndmask_b32 %2, %2, %12, vcc\nv_cndmask_b32 %3, %3, %12, vcc\nv_cmp_lt_u32 vcc, %4, %12\nv_cndmask_b32 %5, %5, %12, vcc\nv_cndmask_b32 %6, %6, %12, vcc\nv_cndmask_b32 %7, %7, %12, vcc\n")
+KERNEL(k_cnd_cmp_pair, "v_cmp_lt_u32 vcc, %0, %12\nv_cndmask_b32 %1, %1, %12, vcc\nv_cmp_lt_u32 vcc, %2, %12\nv_cndmask_b32 %3, %3, %12, vcc\nv_cmp_lt_u32 vcc, %4, %12\nv_cndmask_b32 %5, %5, %12, vcc\nv_cmp_lt_u32 vcc, %6, %12\nv_cndmask_b32 %7, %7, %12, vcc\n")
+KERNEL(k_cnd_sgpr, "v_cmp_lt_u32 s[20:21], %0, %12\nv_cndmask_b32_e64 %1, %1, %12, s[20:21]\nv_cndmask_b32_e64 %2, %2, %12, s[20:21]\nv_cndmask_b32_e64 %3, %3, %12, s[20:21]\nv_cmp_lt_u32 s[22:23], %4, %12\nv_cndmask_b32_e64 %5, %5, %12, s[22:23]\nv_cndmask_b32_e64 %6, %6, %12, s[22:23]\nv_cndmask_b32_e64 %7, %7, %12, s[22:23]\n")
+KERNEL(k_cnd_const, "v_cndmask_b32 %0, 0, %0, vcc\nv_cndmask_b32 %1, 0, %1, vcc\nv_cndmask_b32 %2, 0, %2, vcc\nv_cndmask_b32 %3, 0, %3, vcc\nv_cndmask_b32 %4, 0, %4, vcc\nv_cndmask_b32 %5, 0, %5, vcc\nv_cndmask_b32 %6, 0, %6, vcc\nv_cndmask_b32 %7, 0, %7, vcc\n")
+KERNEL(k_cmp_class, "v_cmp_eq_u32 vcc, 0, %0\nv_cmp_eq_u32 vcc, 0, %1\nv_cmp_eq_u32 vcc, 0, %2\nv_cmp_eq_u32 vcc, 0, %3\nv_cmp_eq_u32 vcc, 0, %4\nv_cmp_eq_u32 vcc, 0, %5\nv_cmp_eq_u32 vcc, 0, %6\nv_cmp_eq_u32 vcc, 0, %7\n")
+// 4 fast + 4 slow interleaved: do the classes overlap?
+KERNEL(k_mix_fs, "v_add_u32 %0, %0, %12\nv_alignbit_b32 %1, %1, %12, %13\nv_xor_b32 %2, %2, %12\nv_bfe_u32 %3, %3, %12, %13\nv_and_b32 %4, %4, %12\nv_add3_u32 %5, %5, %12, %13\nv_lshrrev_b32 %6, %13, %6\nv_mul_lo_u32 %7, %7, %12\n")
+
+// SALU: eight independent scalar instructions (operands chosen by the compiler)
+__global__ void __launch_bounds__(256, 4) k_salu(uint64_t *out, uint32_t seed) {
+    uint32_t s0 = seed, s1 = seed * 3u, s2 = seed * 5u, s3 = seed * 7u, s4 = seed * 11u, s5 = seed * 13u, s6 = seed * 17u, s7 = seed * 19u;
+    for (int i = 0; i < ITER; i++) {
+        REP8(asm volatile("s_add_u32 %0, %0, %1\ns_and_b32 %1, %1, %2\ns_lshl_b32 %2, %2, 1\ns_bcnt1_i32_b32 %3, %4\ns_add_u32 %4, %4, %5\ns_or_b32 %5, %5, %6\ns_xor_b32 %6, %6, %7\ns_add_u32 %7, %7, %0\n" : "+s"(s0), "+s"(s1), "+s"(s2), "+s"(s3), "+s"(s4), "+s"(s5), "+s"(s6), "+s"(s7) :: "scc");)
+    }
+    out[(size_t)blockIdx.x * 256 + threadIdx.x] = s0 + s1 + s2 + s3 + s4 + s5 + s6 + s7;
+}
+__global__ void __launch_bounds__(256, 4) k_valu_salu(uint64_t *out, uint32_t seed) {
+    uint32_t s0 = seed, s1 = seed * 3u, s2 = seed * 5u, s3 = seed * 7u;
+    uint32_t a0 = seed + threadIdx.x, a1 = a0 * 3u, a2 = a0 * 5u, a3 = a0 * 7u;
+    for (int i = 0; i < ITER; i++) {
+        REP8(asm volatile("v_add_u32 %4, %4, %5\ns_add_u32 %0, %0, %1\nv_add_u32 %5, %5, %6\ns_and_b32 %1, %1, %2\nv_add_u32 %6, %6, %7\ns_lshl_b32 %2, %2, 1\nv_add_u32 %7, %7, %4\ns_add_u32 %3, %3, %0\n" : "+s"(s0), "+s"(s1), "+s"(s2), "+s"(s3), "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) :: "scc");)
+    }
+    out[(size_t)blockIdx.x * 256 + threadIdx.x] = s0 + s1 + s2 + s3 + a0 + a1 + a2 + a3;
+}
 typedef void (*kfn)(uint64_t *, uint32_t);
 struct Row { const char *name; kfn f; int n_inst; };
 
@@ -92,7 +122,7 @@ int main(int argc, char **argv) {
         R(k_add), R(k_and), R(k_xor), R(k_lshl), R(k_lshr), R(k_alignbit), R(k_bfrev), R(k_mov), R(k_bfe), R(k_bfi), R(k_perm), R(k_add3), R(k_lshl_add), R(k_lshl_or),
         R(k_and_or), R(k_or3), R(k_xad), R(k_min), R(k_mul_lo), R(k_mul_hi), R(k_mul_u24), R(k_mad_u24), R(k_mul_f32), R(k_fma_f32), R(k_cndmask), R(k_cmp_u32), R(k_cmp_u32_sgpr),
         R(k_cmp_u64), R(k_cmp_eq_u64), R(k_lshl64), R(k_lshr64), R(k_lshl_add_u64), R(k_mad_u64_u32), R(k_add_co), R(k_mbcnt), R(k_readlane), R(k_readfirstlane), R(k_bitop3),
-        R(k_dpp_mov), R(k_add_dpp), R(k_sdwa), R(k_salu), R(k_salu64), R(k_valu_salu),
+        R(k_dpp_mov), R(k_add_dpp), R(k_sdwa), R(k_or), R(k_sub), R(k_max), R(k_ashr), R(k_not), R(k_lshl_c), R(k_lshr_c), R(k_alignbit_c), R(k_mov_b64), R(k_cnd_after_cmp), R(k_cnd_cmp_pair), R(k_cnd_sgpr), R(k_cnd_const), R(k_cmp_class), R(k_mix_fs), R(k_salu), R(k_valu_salu),
     };
     printf("# %s, %d CUs; blocks of 256 threads, W blocks per CU = W waves per SIMD; %d x 64 instructions per wave\n", p.name, cus, ITER);
     printf("%-18s %10s %10s %10s %10s\n", "kernel", "cyc/inst@1", "cyc/inst@2", "cyc/inst@4", "ns/inst@4");
@@ -117,7 +147,7 @@ int main(int argc, char **argv) {
             hipEventDestroy(e0); hipEventDestroy(e1);
         }
         const double ghz = argc > 1 ? atof(argv[1]) : 2.4;
-        printf("%-18s %10.2f %10.2f %10.2f %10.3f\n", r.name, res[0] * ghz, res[1] * ghz, res[2] * ghz, nsi);
+        printf("%-18s %10.2f %10.2f %10.2f %10.3f\n", r.name, res[0] * ghz, res[1] * ghz, res[2] * ghz, nsi); fflush(stdout);
     }
     return 0;
 }
