@@ -55,10 +55,12 @@ def klass(op):
 def parse(asm_path):
     """-> {kernel: [(label or None, op, text), ...]}, {kernel: resources}"""
     kernels, cur, res = {}, None, {}
-    meta_name = None
+    entries = []
     for line in open(asm_path, errors="replace"):
+        if line.startswith("amdhsa.kernels:") or line.startswith("\t.amdgpu_metadata") or line.startswith("\t.section\t.rodata") or line.startswith("\t.data"):
+            cur = None
         m = re.match(r"^(_Z\w+|k_\w+):\s*(;.*)?$", line)
-        if m:
+        if m and "@function" not in line and ("; @" in line):
             cur = m.group(1); kernels[cur] = []; continue
         if cur is not None:
             if line.startswith(".Lfunc_end"):
@@ -70,15 +72,18 @@ def parse(asm_path):
             if m and not line.lstrip().startswith(".") and not line.lstrip().startswith(";"):
                 kernels[cur].append((None, m.group(1), m.group(2).split(";")[0].strip()))
             continue
-        m = re.match(r"^\s+\.name:\s+(\S+)", line)
-        if m:
-            meta_name = m.group(1); res.setdefault(meta_name, {}); continue
-        m = re.match(r"^\s+-?\s*\.(agpr_count|vgpr_count|sgpr_count|vgpr_spill_count|sgpr_spill_count|private_segment_fixed_size|group_segment_fixed_size|max_flat_workgroup_size):\s+(\d+)", line)
-        if m and meta_name:
-            res[meta_name][m.group(1)] = int(m.group(2))
-        m = re.match(r"^\s+-\s+\.agpr_count:\s+(\d+)", line)
-        if m:
-            pending_agpr = int(m.group(1))
+        # code-object metadata: one "  - .agpr_count: ..." entry per kernel, fields in alphabetical order (.name in the middle)
+        if re.match(r"^  - \.agpr_count:", line):
+            entry = {}; entries.append(entry)
+        m = re.match(r"^\s+(?:- )?\.(agpr_count|vgpr_count|sgpr_count|vgpr_spill_count|sgpr_spill_count|private_segment_fixed_size|group_segment_fixed_size|max_flat_workgroup_size):\s+(\d+)", line)
+        if m and entries:
+            entries[-1][m.group(1)] = int(m.group(2))
+        m = re.match(r"^    \.name:\s+(\S+)", line)
+        if m and entries:
+            entries[-1]["name"] = m.group(1)
+    for e in entries:
+        if "name" in e:
+            res[e["name"]] = e
     return kernels, res
 
 

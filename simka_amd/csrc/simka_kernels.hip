@@ -272,9 +272,13 @@ k_group(SimkaMergeIn in, const ull *seg_abs, const uint16_t *rows, uint32_t np,
     // end of key-prefix block i (0 .. 15) of a row held as two uint4; i == ~0u: 0
     auto row_end = [](const uint4 &r0, const uint4 &r1, uint32_t i) -> uint32_t {
         if (i == ~0u) return 0u;
-        const uint32_t w = i >> 1;
-        const uint32_t a0 = (w & 2u) ? ((w & 1u) ? r0.w : r0.z) : ((w & 1u) ? r0.y : r0.x), a1 = (w & 2u) ? ((w & 1u) ? r1.w : r1.z) : ((w & 1u) ? r1.y : r1.x);
-        const uint32_t a = (w & 4u) ? a1 : a0;
+        // (i is wave-uniform: a switch, i.e. scalar branches -- as a select chain the compiler turned the row into a 32-byte scratch array
+        //  indexed through a scalar register: 48 bytes of private memory per lane and a scratch load per use)
+        uint32_t a;
+        switch (i >> 1) {
+            case 0: a = r0.x; break; case 1: a = r0.y; break; case 2: a = r0.z; break; case 3: a = r0.w; break;
+            case 4: a = r1.x; break; case 5: a = r1.y; break; case 6: a = r1.z; break; default: a = r1.w; break;
+        }
         return (i & 1u) ? a >> 16 : a & 0xffffu;
     };
     uint4 rr0 = make_uint4(0, 0, 0, 0), rr1 = rr0, nr0 = rr0, nr1 = rr0; ull rab = 0, nab = 0;       // this partition's row / the next one's (sample tid)
@@ -986,9 +990,19 @@ k_pairs(const SimkaSpan *spans, const ull *cursors, const ull *entries, const ui
                 li = si - baseI; lj = sj - baseJ;
                 cell = rect ? li * T + lj : li * TD - ((li * (li + 1u)) >> 1) + (lj - li - 1u);   // TD <= 65535: fits 32 bits
                 }
+#ifdef SIMKA_EXP_PAIRS_NO_BILINEAR     // experiment (garbage S / a / chord): what the pair loop costs when the bilinear accumulators are taken off it (upper bound of an MFMA offload)
+                if (pc.simple && smallc) { atomicAdd(&pk[1 * CP + cell], (ull)(ci < cj ? ci : cj) | ((ull)pair_isqrt32(ci * cj) << 32)); }
+                else
+#endif
+                {
                 atomicAdd(&pk[0 * CP + cell], (ull)ci | ((ull)cj << 32));                       // S_ij | S_ji
                 atomicAdd(&pk[1 * CP + cell], 1ull | ((ull)(ci < cj ? ci : cj) << 32));         // a | bc
+                }
+#ifdef SIMKA_EXP_PAIRS_NO_BILINEAR
+                if (pc.simple && !smallc) {
+#else
                 if (pc.simple) {
+#endif
                     if (smallc) {       // (uniform per span) counts below 2^15: the product is a 32-bit value below 2^30
                         const uint32_t prod32 = ci * cj;
                         atomicAdd(&pk[2 * CP + cell], (ull)prod32 | ((ull)pair_isqrt32(prod32) << 32));  // chord | hell
