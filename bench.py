@@ -664,6 +664,11 @@ def main():
                 out["decomposition_failures"] = dict(failures, **({"note": note} if note else {}))
             out["config"]["collectives"] = ("RCCL through the C ABI (simka_stats_allreduce / simka_exchange_*)" if comm is not None
                                             else "torch.distributed %s" % backend)
+            if comm is not None:       # which librccl the C ABI got (one RCCL per process: torch's already loaded copy is reused)
+                try:
+                    out["config"]["rccl_library"] = simka_amd.api.Comm.library()
+                except Exception as e:
+                    out["config"]["rccl_library"] = "unknown (%r)" % (e,)
         if hard:
             if rank == 0:
                 print(json.dumps(out), flush=True)

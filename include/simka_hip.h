@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define SIMKA_ABI_VERSION 7
+#define SIMKA_ABI_VERSION 8
 
 enum {
     SIMKA_OK = 0,
@@ -262,6 +262,10 @@ int simka_totals_upload(simka_ctx *ctx, const uint64_t *in_5n);
  * simka_comm_create.  One communicator per GPU; its calls must come from the thread that owns the context. */
 #define SIMKA_COMM_ID_BYTES 128
 typedef struct simka_comm simka_comm;
+/* Which RCCL serves the collectives: "<file> (<how it was found>)".  A copy that is already loaded in the process -- e.g. the one a Python
+ * caller's torch has bootstrapped its process group with -- is reused (one RCCL per process); SIMKA_RCCL_PATH names a file explicitly;
+ * otherwise librccl.so.1 from the loader's search path.  SIMKA_ERR_UNSUPPORTED without RCCL.  (ABI 8) */
+int  simka_comm_library(char *path, uint64_t capacity);
 int  simka_comm_unique_id(uint8_t id[SIMKA_COMM_ID_BYTES]);
 int  simka_comm_create(const uint8_t id[SIMKA_COMM_ID_BYTES], int nb_ranks, int rank, int device, simka_comm **out);
 void simka_comm_destroy(simka_comm *comm);
@@ -336,6 +340,11 @@ int simka_device_upload(int device, void *dst, const void *src_host, uint64_t nb
 /* sizes chosen by the ctx (partition bits etc.), for DESIGN/bench reporting */
 int simka_get_geometry(simka_ctx *ctx, uint32_t *log2_level1, uint32_t *log2_level2, uint32_t *log2_subranges,
                        uint64_t *arena_capacity, uint64_t *csr_capacity);
+/* the solid-spectrum arena of the context: 1 = a reserved virtual range mapped as the samples arrive, 0 = one plain allocation
+ * (SIMKA_CFG_ARENA_PLAIN, or another context alive on the device at creation); records reserved / backed by memory now; and the
+ * address space (bytes) of the ranges of DESTROYED contexts of this process, which are retired instead of reused (a remapped range is
+ * read through stale translations on ROCm 7.0 / gfx950) -- past 2^45 bytes new contexts take plain arenas.  (ABI 8) */
+int simka_arena_info(simka_ctx *ctx, uint64_t *mapped_mode, uint64_t *reserved_records, uint64_t *mapped_records, uint64_t *retired_va_bytes);
 /* how the samples counted so far were counted: on the minimizer-partitioned pipeline (every sample for kmer_size <= 31, and for
  * 32 <= kmer_size <= 51 unless a partition outgrew its table) or k-mer occurrence by occurrence (kmer_size >= 52, the fallback,
  * SIMKA_SORT_PATH); how many had their level-1 buckets sized exactly after a capacity-sized attempt overflowed; and how many counts /

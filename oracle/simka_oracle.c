@@ -128,33 +128,38 @@ static inline int or_code(unsigned char c) {
  * distances depend only on which k-mers are equal, so everything behind the extraction works on the ranks with the
  * machinery of k <= 63.  Two passes over the reads: collect (mode 1), then map (mode 2). */
 typedef struct { uint64_t w[4]; } k256;
-static int g_k256_mode = 0;
-static k256 *g_k256_v = NULL; static size_t g_k256_n = 0, g_k256_cap = 0;
+/* the dictionary belongs to ONE oracle instance (it lives in the oracle struct: two instances, or two threads running two oracles, do not
+ * share state); mode 0: unused, 1: collect, 2: map */
+typedef struct { int mode; k256 *v; size_t n, cap; int failed; } k256_dict;
 static int k256_cmp(const void *a, const void *b) {
     const k256 *x = (const k256 *)a, *y = (const k256 *)b;
     for (int q = 3; q >= 0; q--) if (x->w[q] != y->w[q]) return x->w[q] < y->w[q] ? -1 : 1;
     return 0;
 }
-static void k256_collect(const k256 *x) {
+static void k256_collect(k256_dict *d, const k256 *x) {
 #ifdef _OPENMP
 #pragma omp critical(k256_collect)
 #endif
     {
-        if (g_k256_n == g_k256_cap) { g_k256_cap = g_k256_cap ? g_k256_cap * 2 : 4096; g_k256_v = (k256 *)realloc(g_k256_v, g_k256_cap * sizeof(k256)); }
-        g_k256_v[g_k256_n++] = *x;
+        if (d->n == d->cap && !d->failed) {
+            const size_t cap = d->cap ? d->cap * 2 : 4096;
+            k256 *nv = (k256 *)realloc(d->v, cap * sizeof(k256));
+            if (nv) { d->v = nv; d->cap = cap; } else d->failed = 1;        /* (reported by oracle_run_shard) */
+        }
+        if (d->n < d->cap) d->v[d->n++] = *x;
     }
 }
-static void k256_build_dictionary(void) {
-    qsort(g_k256_v, g_k256_n, sizeof(k256), k256_cmp);
+static void k256_build_dictionary(k256_dict *d) {
+    qsort(d->v, d->n, sizeof(k256), k256_cmp);
     size_t w = 0;
-    for (size_t i = 0; i < g_k256_n; i++) if (w == 0 || k256_cmp(&g_k256_v[w - 1], &g_k256_v[i]) != 0) g_k256_v[w++] = g_k256_v[i];
-    g_k256_n = w;
+    for (size_t i = 0; i < d->n; i++) if (w == 0 || k256_cmp(&d->v[w - 1], &d->v[i]) != 0) d->v[w++] = d->v[i];
+    d->n = w;
 }
-static uint64_t k256_rank(const k256 *x) {
-    const k256 *f = (const k256 *)bsearch(x, g_k256_v, g_k256_n, sizeof(k256), k256_cmp);
-    return f ? (uint64_t)(f - g_k256_v) : ~0ull;       /* (every k-mer of the map pass was collected) */
+static uint64_t k256_rank(const k256_dict *d, const k256 *x) {
+    const k256 *f = (const k256 *)bsearch(x, d->v, d->n, sizeof(k256), k256_cmp);
+    return f ? (uint64_t)(f - d->v) : ~0ull;       /* (every k-mer of the map pass was collected) */
 }
-static size_t or_kmers_of_read_256(const char *seq, size_t len, int k, u64vec *out) {
+static size_t or_kmers_of_read_256(const char *seq, size_t len, int k, u64vec *out, k256_dict *dict) {
     const int W = 2 * k, tw = (W - 1) / 64, top = 2 * (k - 1);
     const uint64_t mtop = (W % 64) ? ((1ull << (W % 64)) - 1ull) : ~0ull;
     k256 f, r; memset(&f, 0, sizeof f); memset(&r, 0, sizeof r);
@@ -170,8 +175,8 @@ static size_t or_kmers_of_read_256(const char *seq, size_t len, int k, u64vec *o
         r.w[top / 64] |= (uint64_t)(c ^ 2) << (top % 64);
         if (++valid >= (size_t)k) {
             const k256 *canon = k256_cmp(&f, &r) < 0 ? &f : &r;
-            if (g_k256_mode == 1) { k256_collect(canon); u64vec_push(out, (kmer_t)0); }
-            else u64vec_push(out, (kmer_t)k256_rank(canon));
+            if (dict->mode == 1) { k256_collect(dict, canon); u64vec_push(out, (kmer_t)0); }
+            else u64vec_push(out, (kmer_t)k256_rank(dict, canon));
             emitted++;
         }
     }
@@ -179,8 +184,8 @@ static size_t or_kmers_of_read_256(const char *seq, size_t len, int k, u64vec *o
 }
 
 /* Append the canonical k-mers of one read to `out`; returns #k-mers appended. */
-static size_t or_kmers_of_read(const char *seq, size_t len, int k, u64vec *out) {
-    if (k >= 64) return or_kmers_of_read_256(seq, len, k, out);
+static size_t or_kmers_of_read(const char *seq, size_t len, int k, u64vec *out, k256_dict *dict) {
+    if (k >= 64) return or_kmers_of_read_256(seq, len, k, out, dict);
     if (k <= 31) {      /* 64-bit rolling words (the reference's Kmer<span=32>) */
         const uint64_t mask = (1ull << (2 * k)) - 1ull;
         uint64_t fwd = 0, rev = 0;
@@ -248,6 +253,7 @@ typedef struct {
     int k; uint32_t amin, amax;
     uint64_t max_reads; uint64_t min_read_size; double min_shannon;   /* [a2] read policies (0 = off) */
     or_stats *stats;
+    k256_dict dict;                   /* 64 <= k <= 127: the run's dictionary of whole k-mers */
     char err[512];
 } oracle;
 
@@ -469,7 +475,7 @@ static int or_read_sample_files(const oracle *o, or_sample *s, u64vec *out) {
     if (it.ncomp == 0 || it.nbBanks == 0) rc = -1;
     else
         for (or_iter_first(&it); !it.isDone; or_iter_next(&it)) {
-            s->k_occ += or_kmers_of_read(it.item->b ? it.item->b : "", it.item->n, o->k, out);
+            s->k_occ += or_kmers_of_read(it.item->b ? it.item->b : "", it.item->n, o->k, out, (k256_dict *)&o->dict);
             s->nb_reads++;
         }
     if (it.io_error) rc = -1;
@@ -522,7 +528,7 @@ static int or_count_sample(oracle *o, or_sample *s, int threads) {
         for (int t = 0; t < T; t++) {
             const uint64_t r0 = s->nreads_mem * (uint64_t)t / (uint64_t)T, r1 = s->nreads_mem * (uint64_t)(t + 1) / (uint64_t)T;
             for (uint64_t r = r0; r < r1; r++)
-                tk[t] += or_kmers_of_read(s->bases + s->offsets[r], (size_t)(s->offsets[r + 1] - s->offsets[r]), o->k, &loc[t]);
+                tk[t] += or_kmers_of_read(s->bases + s->offsets[r], (size_t)(s->offsets[r + 1] - s->offsets[r]), o->k, &loc[t], &o->dict);
         }
         s->nb_reads = s->nreads_mem;
         for (int t = 0; t < T; t++) s->k_occ += tk[t];
@@ -968,7 +974,7 @@ OR_API void oracle_free(oracle *o) {
         for (int f = 0; f < o->s[i].nfiles; f++) free(o->s[i].files[f]);
         free(o->s[i].files); free(o->s[i].kmer); free(o->s[i].count);
     }
-    free(o->s); or_stats_free(o->stats); free(o);
+    free(o->s); or_stats_free(o->stats); free(o->dict.v); free(o);
 }
 OR_API const char *oracle_error(const oracle *o) { return o->err; }
 OR_API int oracle_load_input(oracle *o, const char *input_txt) { return or_parse_input(o, input_txt); }
@@ -1021,15 +1027,16 @@ OR_API int oracle_run_shard(oracle *o, int k, uint32_t amin, uint32_t amax, int 
     int rc = 0;
     for (int i = 0; i < o->n; i++) { free(o->s[i].kmer); free(o->s[i].count); o->s[i].kmer = NULL; o->s[i].count = NULL; }
     if (threads < 1) threads = 1;
-    g_k256_mode = 0;
+    o->dict.mode = 0;
     if (k >= 64) {      /* pass 1: the dictionary of the run's canonical k-mers (the counts of this pass are thrown away) */
-        g_k256_n = 0; g_k256_mode = 1;
+        o->dict.n = 0; o->dict.failed = 0; o->dict.mode = 1;
         for (int i = 0; i < o->n; i++) {
-            if (or_count_sample(o, &o->s[i], threads) != 0) { g_k256_mode = 0; return -1; }
+            if (or_count_sample(o, &o->s[i], threads) != 0) { o->dict.mode = 0; return -1; }
             free(o->s[i].kmer); free(o->s[i].count); o->s[i].kmer = NULL; o->s[i].count = NULL;
         }
-        k256_build_dictionary();
-        g_k256_mode = 2;
+        if (o->dict.failed) { o->dict.mode = 0; snprintf(o->err, sizeof o->err, "oracle: out of memory for the dictionary of %d-base k-mers", k); return -1; }
+        k256_build_dictionary(&o->dict);
+        o->dict.mode = 2;
     }
     /* at least as many samples as threads: one sample per thread (as the reference runs one simkaCount job per sample);
      * fewer: the samples one after the other, each on all threads */

@@ -124,6 +124,7 @@ def load_library(build_if_missing=True):
         "simka_stats_device_ranges": (i32, [vp, C.POINTER(vp), C.POINTER(u64), C.POINTER(vp), C.POINTER(u64)]),
         "simka_totals_download": (i32, [vp, vp]),
         "simka_totals_upload": (i32, [vp, vp]),
+        "simka_comm_library": (i32, [C.c_char_p, u64]),
         "simka_comm_unique_id": (i32, [vp]),
         "simka_comm_create": (i32, [vp, i32, i32, i32, C.POINTER(vp)]),
         "simka_comm_destroy": (None, [vp]),
@@ -144,6 +145,7 @@ def load_library(build_if_missing=True):
         "simka_profile_reset": (i32, [vp]),
         "simka_profile_nb_kernels": (i32, [vp]),
         "simka_profile_get": (i32, [vp, i32, C.POINTER(C.c_char_p), C.POINTER(u64), C.POINTER(C.c_double)]),
+        "simka_arena_info": (i32, [vp, C.POINTER(u64), C.POINTER(u64), C.POINTER(u64), C.POINTER(u64)]),
         "simka_get_geometry": (i32, [vp, C.POINTER(u32), C.POINTER(u32), C.POINTER(u32), C.POINTER(u64), C.POINTER(u64)]),
         "simka_count_paths": (i32, [vp, C.POINTER(u64), C.POINTER(u64), C.POINTER(u64), C.POINTER(u64)]),
         "simka_synth_genomes": (i32, [vp, vp, u32, u64, u64]),
@@ -257,6 +259,16 @@ COMM_ID_BYTES = 128
 class Comm:
     """One RCCL communicator behind the C ABI (simka_comm_*): rank 0 makes the id (Comm.unique_id()), every rank creates.
     The cross-GPU reduction of the accumulators is then ctx.allreduce_stats(comm) -- SimkaStatistics::operator+= over xGMI."""
+
+    @staticmethod
+    def library():
+        """which librccl serves the collectives of the C ABI: "<file> (<how it was found>)" (simka_comm_library)"""
+        buf = C.create_string_buffer(1024)
+        lib = load_library()
+        rc = lib.simka_comm_library(buf, 1024)
+        if rc != SIMKA_OK:
+            raise SimkaError(rc, lib.simka_comm_last_error(None).decode())
+        return buf.value.decode()
 
     @staticmethod
     def unique_id():
@@ -579,6 +591,12 @@ class SimkaContext:
         self._check(self.lib.simka_get_geometry(self.h, C.byref(l1), C.byref(l2), C.byref(t), C.byref(a), C.byref(c)))
         return {"log2_level1": l1.value, "log2_level2": l2.value, "log2_subranges": t.value, "arena_capacity": a.value,
                 "csr_capacity": c.value}
+
+    def arena_info(self):
+        """simka_arena_info: mode (mapped range / plain allocation), records reserved and backed, retired address space of the process"""
+        a, b, c, d = C.c_uint64(), C.c_uint64(), C.c_uint64(), C.c_uint64()
+        self._check(self.lib.simka_arena_info(self.h, C.byref(a), C.byref(b), C.byref(c), C.byref(d)))
+        return {"mapped_range": bool(a.value), "reserved_records": b.value, "mapped_records": c.value, "retired_va_bytes": d.value}
 
     def count_paths(self):
         """How the samples counted so far were counted (simka_count_paths)."""

@@ -94,7 +94,8 @@ void usage() {
         "       -simple-dist      (0 arg) :    compute all simple distances (Chord, Hellinger...)\n"
         "       -complex-dist     (0 arg) :    compute all complex distances (Jensen-Shannon...)\n"
         "   [kmer options]\n"
-        "       -kmer-size        (1 arg) :    size of a kmer  [default '21']\n"
+        "       -kmer-size        (1 arg) :    size of a kmer  [default '21']  (1..127; up to 63 the k-mers are compared word for word, from 64 on by a\n"
+        "                                       126-bit fingerprint of the four-word k-mer: two distinct k-mers collide with probability < D^2 / 2^127)\n"
         "       -abundance-min    (1 arg) :    min abundance a kmer need to be considered  [default '2']\n"
         "       -abundance-max    (1 arg) :    max abundance a kmer can have to be considered  [default '999999999']\n"
         "       -kmer-shannon-index (1 arg) :    minimal Shannon index a kmer should have to be kept. Float in [0,2]  [default '0']\n"

@@ -2206,7 +2206,7 @@ enum { ncclUint8 = 1, ncclUint64 = 5 };       // ncclDataType_t
 enum { ncclSum = 0 };                         // ncclRedOp_t
 struct RcclApi {
     void *lib = nullptr;
-    std::string err;
+    std::string err, how, path;
     ncclResult_t (*GetUniqueId)(ncclUniqueId *) = nullptr;
     ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
     ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
@@ -2221,7 +2221,13 @@ static const RcclApi *rccl() {
     static RcclApi api;
     static std::once_flag once;
     std::call_once(once, [] {
-        for (const char *name : { "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1", "/opt/rocm/lib/librccl.so" }) { api.lib = dlopen(name, RTLD_NOW | RTLD_LOCAL); if (api.lib) break; }
+        // ONE RCCL per process: a copy that is already loaded (a Python caller's torch brings its own librccl.so and has bootstrapped the
+        // process group with it) serves the data path as well -- RTLD_NOLOAD finds it by its soname whatever directory it came from.
+        // SIMKA_RCCL_PATH names a file explicitly; otherwise the usual search.
+        for (const char *name : { "librccl.so.1", "librccl.so" }) { api.lib = dlopen(name, RTLD_NOW | RTLD_LOCAL | RTLD_NOLOAD); if (api.lib) { api.how = "already loaded in the process"; break; } }
+        if (!api.lib) { const char *pth = getenv("SIMKA_RCCL_PATH"); if (pth && *pth) { api.lib = dlopen(pth, RTLD_NOW | RTLD_LOCAL); if (api.lib) api.how = "SIMKA_RCCL_PATH"; } }
+        if (!api.lib)
+            for (const char *name : { "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1", "/opt/rocm/lib/librccl.so" }) { api.lib = dlopen(name, RTLD_NOW | RTLD_LOCAL); if (api.lib) { api.how = "loaded by the library"; break; } }
         if (!api.lib) { api.err = "RCCL is not installed (librccl.so not found): multi-GPU collectives are unavailable"; return; }
         bool ok = true;
         auto sym = [&](const char *n) { void *p = dlsym(api.lib, n); if (!p) { ok = false; api.err = std::string("librccl.so lacks ") + n; } return p; };
@@ -2230,7 +2236,9 @@ static const RcclApi *rccl() {
         api.Send = (decltype(api.Send))sym("ncclSend"); api.Recv = (decltype(api.Recv))sym("ncclRecv");
         api.GroupStart = (decltype(api.GroupStart))sym("ncclGroupStart"); api.GroupEnd = (decltype(api.GroupEnd))sym("ncclGroupEnd");
         api.GetErrorString = (decltype(api.GetErrorString))sym("ncclGetErrorString");
-        if (!ok) { dlclose(api.lib); api.lib = nullptr; }
+        if (!ok) { dlclose(api.lib); api.lib = nullptr; return; }
+        Dl_info di;
+        if (dladdr((void *)api.AllReduce, &di) && di.dli_fname) api.path = di.dli_fname;
     });
     return &api;
 }
@@ -2247,6 +2255,14 @@ static thread_local std::string g_comm_error;
         ncclResult_t r_ = (call);                                                                          \
         if (r_ != ncclSuccess) { (c)->err = std::string(#call) + " failed: " + rccl()->GetErrorString(r_); return SIMKA_ERR_HIP; } \
     } while (0)
+
+SIMKA_EXPORT int simka_comm_library(char *path, uint64_t cap) {
+    const RcclApi *R = rccl();
+    if (!R->lib) { g_comm_error = R->err; return SIMKA_ERR_UNSUPPORTED; }
+    if (!path || cap == 0) return SIMKA_ERR_INVALID;
+    snprintf(path, (size_t)cap, "%s (%s)", R->path.empty() ? "?" : R->path.c_str(), R->how.c_str());
+    return SIMKA_OK;
+}
 
 SIMKA_EXPORT int simka_comm_unique_id(uint8_t *id) {
     if (!id) return SIMKA_ERR_INVALID;
@@ -2445,6 +2461,16 @@ SIMKA_EXPORT int simka_get_geometry(simka_ctx *ctx, uint32_t *l1, uint32_t *l2, 
     if (!ctx) return SIMKA_ERR_INVALID;
     if (l1) *l1 = ctx->wide ? ctx->key.l1 : ctx->skm.l1; if (l2) *l2 = ctx->wide ? ctx->key.l2 : ctx->skm.l2; if (t) *t = ctx->key.t;
     if (arena) *arena = ctx->arena_cap; if (csr) *csr = ctx->merge_cap;
+    return SIMKA_OK;
+}
+
+SIMKA_EXPORT int simka_arena_info(simka_ctx *ctx, uint64_t *mapped_mode, uint64_t *reserved_records, uint64_t *mapped_records, uint64_t *retired_va_bytes) {
+    if (!ctx) return SIMKA_ERR_INVALID;
+    std::lock_guard<std::mutex> g_(g_vmm_lock);
+    if (mapped_mode) *mapped_mode = ctx->arena_vmm ? 1 : 0;
+    if (reserved_records) *reserved_records = ctx->arena_vmm ? ctx->arena_reserved : ctx->arena_cap;
+    if (mapped_records) *mapped_records = ctx->arena_mapped;
+    if (retired_va_bytes) *retired_va_bytes = g_vmm_retired_bytes;
     return SIMKA_OK;
 }
 

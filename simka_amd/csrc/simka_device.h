@@ -13,7 +13,7 @@
 #pragma once
 #include <stdint.h>
 
-#if defined(__HIPCC__) || defined(SIMKA_EMU)
+#if defined(__HIPCC__)
 #define SIMKA_HD __host__ __device__ __forceinline__
 #else
 #define SIMKA_HD inline

@@ -24,7 +24,7 @@ def test_library_exports_every_declared_symbol(simka_lib):
     assert len(names) >= 25
     for n in names:
         assert hasattr(simka_lib, n), "libsimka_hip.so does not export %s" % n
-    assert simka_lib.simka_abi_version() == 7
+    assert simka_lib.simka_abi_version() == 8
 
 
 def test_struct_sizes_match_header():

@@ -887,6 +887,11 @@ def test_rccl_communicator_of_the_c_abi_with_one_rank(gpu_required, golden_dir):
         uid = api.Comm.unique_id()
     except api.SimkaError as e:
         pytest.skip("no RCCL on this machine: %s" % e)
+    # ONE RCCL per process: torch has loaded its own librccl.so (it is linked against it), and that copy serves the C ABI
+    which = api.Comm.library()
+    loaded = [l.split()[-1] for l in open("/proc/self/maps") if "librccl" in l]
+    assert loaded and all(os.path.realpath(p_) == os.path.realpath(loaded[0]) for p_ in loaded), "more than one librccl in the process: %s" % sorted(set(loaded))
+    assert os.path.realpath(which.split(" (")[0]) == os.path.realpath(loaded[0]), (which, loaded[0])
     comm = api.Comm(uid, 1, 0, 0)
     dev = torch.device("cuda", 0)
     t = torch.arange(1000, dtype=torch.int64, device=dev)
@@ -920,6 +925,26 @@ def test_rccl_single_rank_runs_both_multi_gpu_protocols(gpu_required):
     r = subprocess.run([sys.executable, os.path.join(ROOT_DIR, "scripts", "dist_smoke.py")], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
                        text=True, timeout=300)
     assert r.returncode == 0 and "dist smoke ok" in r.stdout, r.stdout[-2000:]
+
+
+def test_arena_mode_is_fixed_at_creation_and_reported(gpu_required):
+    """simka_arena_info (advisor, round 4): a lone context maps its arena lazily; a context created while another one is alive on the
+    device takes a plain allocation (decided in simka_create, not at the lazy geometry setup); the address ranges of destroyed contexts
+    are retired and the total is visible."""
+    import simka_amd
+    kw = dict(kmer_size=21, abundance_min=2, max_kmers_per_sample=200_000)
+    with simka_amd.SimkaContext(2, **kw) as a:
+        ia = a.arena_info()
+        with simka_amd.SimkaContext(2, **kw) as b:
+            ib = b.arena_info()
+        assert ib["mapped_range"] is False and ib["mapped_records"] == ib["reserved_records"] > 0
+    retired0 = ia["retired_va_bytes"]
+    if os.environ.get("SIMKA_ARENA_MALLOC"):
+        return
+    assert ia["mapped_range"] is True and ia["reserved_records"] > 0
+    with simka_amd.SimkaContext(2, **kw) as c:
+        ic = c.arena_info()
+    assert ic["mapped_range"] is True and ic["retired_va_bytes"] >= retired0 + ia["reserved_records"] * 12
 
 
 def test_capacity_errors_are_reported_not_silent(gpu_required):
@@ -1369,6 +1394,17 @@ def test_bench_n_ranks_on_one_gpu_over_gloo(gpu_required, ranks):
         assert d["matrix_checksum"] == one["config"]["matrix_checksum"]
     for key in ("distinct_kmers", "solid_kmers", "kmer_occurrences"):
         assert many["config"][key] == one["config"][key]
+
+
+def test_first_contact_script_dry_run_over_gloo(gpu_required):
+    """scripts/first_contact.sh -- the staged first run on a multi-GPU node (2-rank all-reduce and all-to-all of the C ABI, then bench.py
+    --gpus 2 with either decomposition, each under a timeout, the first failing stage named) -- as a DRY RUN on this one-GPU box: the two
+    ranks share GPU 0 and gloo carries the collectives; launch, rendezvous, buffers and checks are those of the real run."""
+    import subprocess
+    env = dict(os.environ, SIMKA_BENCH_BACKEND="gloo", FIRST_CONTACT_TIMEOUT="400")
+    r = subprocess.run(["bash", os.path.join(ROOT_DIR, "scripts", "first_contact.sh"), "2"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=1500, env=env)
+    assert r.returncode == 0 and "all stages passed" in r.stdout, r.stdout[-3000:]
+    assert "allreduce ok on 2 ranks" in r.stdout and "alltoallv ok on 2 ranks" in r.stdout
 
 
 @pytest.mark.parametrize("how", ["raise", "hang"])
