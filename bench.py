@@ -25,19 +25,19 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0     # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s is the measured copy ceiling
-# what limits each kernel (SQ / TCC counters, profiles/r03_c3_sq_counters.txt) -- the path-level roofline is HBM
-# bytes, but only k_skm_split is bound by HBM itself
+# what limits each kernel (SQ / TCC counters, profiles/r05_c3_sq_counters.txt; DESIGN.md sections 4 and 6) -- the path-level roofline is HBM
+# bytes, but only k_skm_chunksort is bound by HBM itself
 KERNEL_BOUND = {
-    "k_skm_scan": "VALU + barriers (canonical m-mer hashes, sliding minimum; 24 waves per CU)",
+    "k_skm_scan": "instruction issue + barriers (canonical m-mer hashes, sliding minimum; 24 waves per CU, 11 barriers per tile)",
     "k_skm_split": "HBM (64-byte runs: partial-line writes amplify the traffic)",
     "k_skm_chunksort": "HBM (every record read once and written once in whole lines: a streaming sort of 8192-record chunks in LDS)",
-    "k_skm_count_fast": "LDS atomics + VALU, latency (random-slot 64-bit CAS + counter add per k-mer; 16 waves per CU)",
+    "k_skm_count_fast": "serial instruction streams of 4 waves per SIMD (1.0e6 instructions of every class per wave at ~4.7 cycles, 35 % parked at barriers / LDS returns; VALU pipe 89 % behind it)",
     "k_skm_count": "LDS atomics (redo list only)",
     "k_skm_count_wide_fast": "LDS latency + VALU issue (two-word k-mers: claim by 64-bit CAS, compare, count; a table per wave, 16 waves per CU)",
     "k_skm_count_wide": "LDS atomics (redo list only)",
     "k_segment_rows": "HBM (imported spectra only)",
     "k_group": "LDS atomics + gather latency (hash grouping of the N slices of a sub-range)",
-    "k_pairs": "LDS atomics (three 64-bit adds per pair) + VALU",
+    "k_pairs": "pair enumeration on a serial instruction stream (~50 instructions per pair; its three LDS atomics are NOT the bound: -3 % without two of them)",
     "k_pairs_global": "L2 atomics",
 }
 
@@ -602,7 +602,7 @@ def main():
                     tot += v["traffic_bytes_per_launch"] * v["launches"]; n += v["launches"]
             return tot / n if n else None
         try:
-            tf = next((f for f in (os.path.join(ROOT, "profiles", "r%02d_%s_hbm_traffic.json" % (rd, args.workload)) for rd in (4, 3, 2)) if os.path.exists(f)), "")
+            tf = next((f for f in (os.path.join(ROOT, "profiles", "r%02d_%s_hbm_traffic.json" % (rd, args.workload)) for rd in (5, 4, 3, 2)) if os.path.exists(f)), "")
             if world == 1 and not args.reads and not args.samples and not args.kmer_size and tf:
                 tk = json.load(open(tf))["kernels"]
                 traffic = measured_traffic(dom)

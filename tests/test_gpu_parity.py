@@ -1192,6 +1192,9 @@ def test_randomised_inputs_against_the_oracle(gpu_required, oracle_mod):
     r = subprocess.run([sys.executable, os.path.join(ROOT_DIR, "scripts", "fuzz_vs_oracle.py"), "20", "12345"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
                        text=True, timeout=600)
     assert r.returncode == 0 and "fuzz ok" in r.stdout, r.stdout[-3000:]
+    # the script opens with the KL edge block (identical and near-identical samples, k = 21 and 31: the both-present sum cancels to exactly 0
+    # and the Jensen-Shannon cell is 1 as in the reference, a near-identical pair never goes negative) -- part of this test, not a side script
+    assert r.stdout.count("jensen-shannon reference") == 12, r.stdout[:2000]
 
 
 def test_wide_kmers_through_spectrum_export_paths(gpu_required, golden_dir, tmp_path):
