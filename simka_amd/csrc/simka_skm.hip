@@ -1563,28 +1563,14 @@ k_skm_count_fast(SimkaSkmSrc src, SimkaSkmCfg cfg, SimkaKeyCfg kcfg, uint32_t am
         uint4 pre2 = make_uint4(0, 0, 0, 0);
         if (nrec > (uint32_t)SKM_FAST_BLOCK) {
             const uint32_t nb2 = nrec - SKM_FAST_BLOCK < (uint32_t)SKM_FAST_BLOCK ? nrec - SKM_FAST_BLOCK : (uint32_t)SKM_FAST_BLOCK;
-#ifdef SIMKA_EXP_TAIL_ONE_WAVE      // experiment: a tail of <= 64 records is ONE wave's (rotating), the other three go straight to the barrier
-            if (nb2 <= 64u) { if (wave == (part & (NW - 1u)) && lane < nb2) pre2 = rec_at(rbase, SKM_FAST_BLOCK + lane); }
-            else
-#endif
-            {
             const uint32_t per2 = (nb2 + NW - 1u) / NW;
             if (lane < per2 && wave * per2 + lane < nb2) pre2 = rec_at(rbase, SKM_FAST_BLOCK + wave * per2 + lane);
-            }
         }
         for (uint32_t b0 = 0; b0 < nrec; b0 += SKM_FAST_BLOCK) {
             const uint32_t nb = nrec - b0 < (uint32_t)SKM_FAST_BLOCK ? nrec - b0 : (uint32_t)SKM_FAST_BLOCK;
-#ifdef SIMKA_EXP_TAIL_ONE_WAVE
-            const bool tail1 = b0 == (uint32_t)SKM_FAST_BLOCK && nb <= 64u;
-            if (tail1 && wave != (part & (NW - 1u))) continue;
-            const uint32_t per = tail1 ? nb : (nb + NW - 1u) / NW;
-            const uint32_t i = tail1 ? b0 + lane : b0 + wave * per + lane;
-            const bool mine = tail1 ? lane < nb : (lane < per && wave * per + lane < nb);
-#else
             const uint32_t per = (nb + NW - 1u) / NW;                       // records of this wave: [b0 + wave*per, +per)
             const uint32_t i = b0 + wave * per + lane;
             const bool mine = lane < per && wave * per + lane < nb;
-#endif
             uint4 rc = b0 == (uint32_t)SKM_FAST_BLOCK ? pre2 : pre;
             if (b0 > (uint32_t)SKM_FAST_BLOCK) { if (mine) rc = rec_at(rbase, i); }
             uint32_t len = mine ? skm_rec_n(rc) : 0u;
