@@ -7,7 +7,7 @@
     of the N x N partials, ref: src/SimkaPotara.hpp:974-1124 one merge job per partition): the whole step of shard g of G, for EVERY g --
     the slowest rank bounds the step; its kernel table shows the replicated scan.
 (b) sample shards (one count job per sample, one merge job per partition range -- the reference's own job structure, ref:
-    src/SimkaPotara.hpp:813-1124): rank r counts the samples s % G == r (timed), exports their spectra to device buffers (timed; the bytes
+    src/SimkaPotara.hpp:813-1124): rank r counts the samples s % G == r (timed), gathers their spectra into ONE destination-major send buffer (timed: dist.pack_batch, the entry point bench.py uses; the bytes
     it would send to each peer are reported), and rank g imports the partition range [P g / G, P (g + 1) / G) of every sample's spectrum and
     merges it (timed, for g = 0, G / 2 and G - 1).  The all-to-all of the spectra and the all-reduce of the heads are NOT timed: a one-GPU box.
 """
@@ -66,8 +66,8 @@ for G in (1, 2, 4, 8):
     if G == 1:
         res["sample_shards"]["1"] = {"step_ms": per_rank[0]}
         continue
-    # ---- (b) sample shards
-    count_ms, gather_ms, sends, nparts = [], [], [], None
+    # ---- (b) sample shards, through the BATCH entry points bench.py uses (simka_amd/dist.py::pack_batch / import_batch)
+    count_ms, gather_ms, packs, P, kw_ = [], [], [], None, 1
     for r in range(G):
         mine = sdist.samples_of(r, G, n)
         with simka_amd.SimkaContext(n, **kw) as ctx:
@@ -78,48 +78,44 @@ for G in (1, 2, 4, 8):
                 ctx.sync()
             count(); sync()
             t0 = time.perf_counter(); count(); sync(); count_ms.append(round((time.perf_counter() - t0) * 1e3, 2))
-            local = {s: ctx.export_sample_device(s, dev) for s in mine}        # (first pass: the allocator's first touch of the send buffers)
-            sync(); del local
+            info = ctx.spectrum_info(mine[0])
+            P, kw_ = info[1], info[2]
+            pk = sdist.pack_batch(ctx, mine, P, kw_, G, n, dev); ctx.sync(); sync(); del pk       # (first pass: the allocator's first touch of the send buffers)
             t0 = time.perf_counter()
-            local = {s: ctx.export_sample_device(s, dev) for s in mine}
-            sync(); gather_ms.append(round((time.perf_counter() - t0) * 1e3, 2))
-        nparts = len(next(iter(local.values()))[1])
-        sends.append(local)
-    bounds = sdist.partition_bounds(nparts, G)
-    # bytes rank r sends to every peer (12 per solid record), and what rank g imports
-    send_bytes = []
-    for r in range(G):
-        row = []
-        for g in range(G):
-            row.append(int(sum(int(pc[bounds[g]:bounds[g + 1]].astype(np.int64).sum()) for (_, pc, _, _) in sends[r].values()) * 12))
-        send_bytes.append(row)
+            meta, tot_send, ks, ks2, cs, splits = sdist.pack_batch(ctx, mine, P, kw_, G, n, dev)
+            ctx.sync(); sync(); gather_ms.append(round((time.perf_counter() - t0) * 1e3, 2))
+            packs.append((meta.copy(), tot_send.copy(), ks, ks2, cs, list(splits)))
+    send_bytes = [[int(x) * (12 if kw_ == 1 else 20) for x in pk[5]] for pk in packs]
+    tot_all = np.stack([pk[1] for pk in packs])
     merge = {}
     for g in sorted({0, G // 2, G - 1}):
-        lo, hi = bounds[g], bounds[g + 1]
-        imports = []
+        # the all-to-all, by slicing: rank g receives block g of every rank's send buffer
+        meta_recv = np.stack([packs[r][0][g] for r in range(G)])
+        kr, cr, kr2 = [], [], []
         for r in range(G):
-            for s, (tot, pc, keys, counts) in sends[r].items():
-                pre = np.concatenate([[0], np.cumsum(pc.astype(np.int64))])
-                pcm = np.zeros_like(pc); pcm[lo:hi] = pc[lo:hi]
-                imports.append((s, tot, pcm, keys[int(pre[lo]): int(pre[hi])], counts[int(pre[lo]): int(pre[hi])]))
+            sp = packs[r][5]; lo_ = sum(sp[:g])
+            kr.append(packs[r][2][lo_: lo_ + sp[g]]); cr.append(packs[r][4][lo_: lo_ + sp[g]])
+            if kw_ == 2:
+                kr2.append(packs[r][3][lo_: lo_ + sp[g]])
+        kr, cr = torch.cat(kr), torch.cat(cr)
+        kr2 = torch.cat(kr2) if kw_ == 2 else None
         with simka_amd.SimkaContext(n, **kw) as ctx:
             def imp():
-                ctx.reset()
-                for s, tot, pcm, kk, cc in imports:
-                    ctx.import_sample_device(s, tot, pcm, kk, cc)
+                sdist.import_batch(ctx, g, G, n, P, kw_, meta_recv, tot_all, kr, kr2, cr, dev)
                 ctx.sync()
             imp(); ctx.merge(); ctx.stats(); sync()           # (first pass: arena chunks mapped, merge buffers allocated)
             t0 = time.perf_counter(); imp(); sync(); t_imp = (time.perf_counter() - t0) * 1e3
             t0 = time.perf_counter(); ctx.merge(); ctx.stats(); sync(); t_mrg = (time.perf_counter() - t0) * 1e3
             imp(); ctx.profile_enable(True); ctx.profile_reset(); ctx.merge(); ctx.stats(); sync()
             merge[str(g)] = {"import_ms": round(t_imp, 2), "merge_ms": round(t_mrg, 2), "kernels_ms": kernel_ms(ctx)}
-    del sends
+        del kr, cr, kr2
+    del packs
     torch.cuda.empty_cache()
     worst_merge = max(v["import_ms"] + v["merge_ms"] for v in merge.values())
-    res["sample_shards"][str(G)] = {"count_ms_per_rank": count_ms, "export_ms_per_rank": gather_ms, "merge_of_partition_range": merge,
+    res["sample_shards"][str(G)] = {"count_ms_per_rank": count_ms, "pack_ms_per_rank": gather_ms, "merge_of_partition_range": merge,
                                     "send_bytes_rank_to_rank": send_bytes, "bytes_sent_per_rank": [int(sum(row) - row[i]) for i, row in enumerate(send_bytes)],
                                     "step_ms_compute_only": round(max(c + e for c, e in zip(count_ms, gather_ms)) + worst_merge, 2)}
-    print("sample shards G=%d: count %s export %s merge %s" % (G, count_ms, gather_ms, {g: (v["import_ms"], v["merge_ms"]) for g, v in merge.items()}), flush=True)
+    print("sample shards G=%d: count %s pack %s merge %s" % (G, count_ms, gather_ms, {g: (v["import_ms"], v["merge_ms"]) for g, v in merge.items()}), flush=True)
 os.makedirs(os.path.dirname(out_path), exist_ok=True)
 json.dump(res, open(out_path, "w"), indent=1)
 print("written", out_path)

@@ -227,7 +227,9 @@ __device__ ull g_group_phase[8];
 template <int GB, bool ROW32>
 __global__ void __launch_bounds__(GB)
 k_group(SimkaMergeIn in, const ull *seg_abs, const uint16_t *rows, uint32_t np,
-        SimkaKeyCfg cfg, uint32_t min_share, SimkaCsrOut o) {
+        SimkaKeyCfg cfg, uint32_t min_share, SimkaCsrOut o, uint32_t pstride) {
+    // pstride: work item pi of the batch is partition pi * pstride of the index arrays (1: consecutive partitions; G: the partitions
+    // p = g + G i a partition shard owns -- the others are empty, and walking them cost as much as grouping the owned ones)
     constexpr int GCAP = GB * K3_UNROLL, GTAB = 2 * GCAP;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     ull *s_slab = (ull *)smem;                              // [6] ent pos/end, grp pos/end, span pos/end
@@ -286,7 +288,7 @@ k_group(SimkaMergeIn in, const ull *seg_abs, const uint16_t *rows, uint32_t np,
     // end of key-prefix block i of the segment (partition pi of the batch, sample s_), whatever the row width
     auto seg_end = [&](uint32_t pi_, uint32_t s_, uint32_t i) -> uint32_t {
         if (i == ~0u) return 0u;
-        const size_t g = (size_t)pi_ * in.nb_samples + s_;
+        const size_t g = (size_t)pi_ * pstride * in.nb_samples + s_;
         return ROW32 ? rows32[g * SIMKA_SEG_BLOCKS + i] : (uint32_t)rows[g * SIMKA_SEG_BLOCKS + i];
     };
     // Which partitions a block takes: Q = min(4, #sub-ranges) neighbouring blocks of ONE XCD (blockIdx % 8: its own L2) share a partition,
@@ -297,7 +299,7 @@ k_group(SimkaMergeIn in, const ull *seg_abs, const uint16_t *rows, uint32_t np,
     const uint32_t quarter = bx % Q, nsets = gx / Q, pstep = 8u * nsets;      // (the host launches a multiple of 32 blocks: nsets >= 1, no block left over)
     uint32_t cur_pi = (bx / Q) * 8u + xcd, cur_j = 0;
     if (bx / Q >= nsets) cur_pi = np;
-    if (cur_pi < np && tid < N) { const size_t g = (size_t)cur_pi * N + tid; if (!ROW32) { nr0 = rows4[2 * g]; nr1 = rows4[2 * g + 1]; } nab = seg_abs[g]; }
+    if (cur_pi < np && tid < N) { const size_t g = (size_t)cur_pi * pstride * N + tid; if (!ROW32) { nr0 = rows4[2 * g]; nr1 = rows4[2 * g + 1]; } nab = seg_abs[g]; }
     // f(key, sample << 32 | count) for every record of the sub-range: a tile of GB samples at a time -- their slices from the
     // rows, an exclusive scan, then one record per thread (the thread finds its sample in the prefix table)
     bool tile_ready = false;       // (uniform) the tables of sample tile 0 are already in LDS (the scan that gave R): the first gather reuses them
@@ -313,7 +315,7 @@ k_group(SimkaMergeIn in, const ull *seg_abs, const uint16_t *rows, uint32_t np,
                 const uint32_t hi = ROW32 ? (tid < N ? seg_end(cur_pi, tid, (cur_j + 1u) * bw - 1u) : 0u) : row_end(rr0, rr1, (cur_j + 1u) * bw - 1u);
                 c = hi - lo; b = rab + lo;
             } else if (s < N) {
-                const size_t g = (size_t)cur_pi * N + s;
+                const size_t g = (size_t)cur_pi * pstride * N + s;
                 const uint32_t lo = seg_end(cur_pi, s, cur_j * bw - 1u), hi = seg_end(cur_pi, s, (cur_j + 1u) * bw - 1u);
                 c = hi - lo; b = seg_abs[g] + lo;
             }
@@ -351,7 +353,7 @@ k_group(SimkaMergeIn in, const ull *seg_abs, const uint16_t *rows, uint32_t np,
             rr0 = nr0; rr1 = nr1; rab = nab;
             const uint32_t npi = cur_pi + pstep;
             nr0 = make_uint4(0, 0, 0, 0); nr1 = nr0; nab = 0;
-            if (npi < np && tid < N) { const size_t g = (size_t)npi * N + tid; if (!ROW32) { nr0 = rows4[2 * g]; nr1 = rows4[2 * g + 1]; } nab = seg_abs[g]; }
+            if (npi < np && tid < N) { const size_t g = (size_t)npi * pstride * N + tid; if (!ROW32) { nr0 = rows4[2 * g]; nr1 = rows4[2 * g + 1]; } nab = seg_abs[g]; }
         }
       for (cur_j = quarter * jq; cur_j < (quarter + 1u) * jq; cur_j++) {
         const uint32_t this_j = cur_j;

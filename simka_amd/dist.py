@@ -225,32 +225,13 @@ def _host_table(ctx, name, shape, np_dtype, device):
     return a
 
 
-def count_exchange_merge(ctx, count_fn, nb_samples, device, comm=None):
-    """One sample-sharded job on this rank: count my samples (count_fn(sample)), exchange, import every sample's slice of my
-    partition range, merge, all-reduce the pair accumulators.  `ctx` is created with shard_count=1.  Single process: plain path.
-    Batch ABI: one gather into a destination-major send buffer, three collectives (counts, keys, counts of k-mers) + the
-    totals all-gather, one import of the received block."""
-    from .api import SampleTotals
-    world = dist.get_world_size() if dist.is_initialized() else 1
-    rank = dist.get_rank() if dist.is_initialized() else 0
-    ctx.reset()
-    if world == 1 and not (dist.is_initialized() and os.environ.get("SIMKA_FORCE_EXCHANGE")):
-        for s in range(nb_samples):
-            count_fn(s)
-        ctx.merge()
-        return
-    cdev = _comm_device(device)
-    mine = samples_of(rank, world, nb_samples)
-    for s in mine:
-        count_fn(s)
-    info = ctx.spectrum_info(mine[0]) if mine else (0, 0, 0)
-    np_t = torch.tensor([info[1], info[2]], dtype=torch.int64, device=cdev)
-    dist.all_reduce(np_t, op=dist.ReduceOp.MAX)          # ranks without samples learn the partition count and the key width
-    P, kw = int(np_t[0].item()), int(np_t[1].item())      # kw = 2: kmer_size >= 32, high and low key words travel separately
+def pack_batch(ctx, mine, P, kw, world, nb_samples, device):
+    """Send side of the batch exchange on one rank: the counted samples `mine` of `ctx` gathered into ONE destination-major buffer
+    [g][my sample j][partitions of g] (simka_gather_samples_device).  -> (meta int32 [world, maxn, width], totals int64 [maxn, 6],
+    keys, keys2 (kmer_size >= 32: low words), counts, send_splits)."""
     bounds = partition_bounds(P, world)
     width = max(bounds[g + 1] - bounds[g] for g in range(world))
     maxn = (nb_samples + world - 1) // world
-    # ---- send side: destination-major layout [g][my sample j][partitions of g]
     meta = _host_table(ctx, "meta", (world, maxn, width), np.int32, device)
     tot_send = np.zeros((maxn, 6), dtype=np.int64)
     send_splits = [0] * world
@@ -281,6 +262,70 @@ def count_exchange_merge(ctx, count_fn, nb_samples, device, comm=None):
         ks = torch.empty(0, dtype=torch.int64, device=device)
         ks2 = torch.empty(0, dtype=torch.int64, device=device)
         cs = torch.empty(0, dtype=torch.int32, device=device)
+    return meta, tot_send, ks, ks2, cs, send_splits
+
+
+def import_batch(ctx, rank, world, nb_samples, P, kw, meta_recv, tot_all, kr, kr2, cr, device):
+    """Receive side on rank `rank`: the received block [source r][its sample j][my partitions] (record counts meta_recv int32
+    [world, maxn, width], per-sample totals tot_all int64 [world, maxn, 6]) imported into `ctx` in ONE call
+    (simka_import_samples_device).  The context is reset first; the caller merges."""
+    from .api import SampleTotals
+    bounds = partition_bounds(P, world)
+    lo, hi = bounds[rank], bounds[rank + 1]
+    w = hi - lo
+    pc_in = _host_table(ctx, "pc_in", (nb_samples, max(w, 1)), np.uint32, device)
+    off_in = _host_table(ctx, "off_in", (nb_samples, max(w, 1)), np.uint64, device)
+    tot_in = (SampleTotals * nb_samples)()
+    pos = 0
+    for r in range(world):
+        ss = samples_of(r, world, nb_samples)
+        if not ss:
+            continue
+        seg = meta_recv[r, : len(ss), :w]
+        rows = seg.astype(np.int64).sum(axis=1)
+        starts = pos + np.concatenate([[0], np.cumsum(rows)[:-1]])
+        pc_in[ss, :w] = seg.astype(np.uint32)
+        off_in[ss, :w] = (_excl_cumsum_rows(seg) + starts[:, None]).astype(np.uint64)
+        pos += int(rows.sum())
+        for j, s in enumerate(ss):
+            tt = tot_all[r, j]
+            tot_in[s] = SampleTotals(int(tt[0]), int(tt[1]), int(tt[2]), int(tt[3]), int(tt[4]), int(tt[5]))
+    assert pos == int(kr.numel())
+    ctx.reset()
+    if kw == 2:      # each sample's slice of my key-prefix range is one contiguous, sorted run of the received block
+        s_rec = pc_in.astype(np.int64).sum(axis=1)
+        s_off = off_in[:, 0].astype(np.int64) if w else np.zeros(nb_samples, dtype=np.int64)
+        ctx.import_samples_device_wide(np.arange(nb_samples), tot_in, s_off, s_rec, kr, kr2, cr)
+    else:
+        ctx.import_samples_device(np.arange(nb_samples), tot_in, lo, pc_in[:, :max(w, 0)] if w else pc_in[:, :0], off_in[:, :w] if w else off_in[:, :0], P, kr, cr)
+
+
+def count_exchange_merge(ctx, count_fn, nb_samples, device, comm=None):
+    """One sample-sharded job on this rank: count my samples (count_fn(sample)), exchange, import every sample's slice of my
+    partition range, merge, all-reduce the pair accumulators.  `ctx` is created with shard_count=1.  Single process: plain path.
+    Batch ABI: one gather into a destination-major send buffer, three collectives (counts, keys, counts of k-mers) + the
+    totals all-gather, one import of the received block."""
+    from .api import SampleTotals
+    world = dist.get_world_size() if dist.is_initialized() else 1
+    rank = dist.get_rank() if dist.is_initialized() else 0
+    ctx.reset()
+    if world == 1 and not (dist.is_initialized() and os.environ.get("SIMKA_FORCE_EXCHANGE")):
+        for s in range(nb_samples):
+            count_fn(s)
+        ctx.merge()
+        return
+    cdev = _comm_device(device)
+    mine = samples_of(rank, world, nb_samples)
+    for s in mine:
+        count_fn(s)
+    info = ctx.spectrum_info(mine[0]) if mine else (0, 0, 0)
+    np_t = torch.tensor([info[1], info[2]], dtype=torch.int64, device=cdev)
+    dist.all_reduce(np_t, op=dist.ReduceOp.MAX)          # ranks without samples learn the partition count and the key width
+    P, kw = int(np_t[0].item()), int(np_t[1].item())      # kw = 2: kmer_size >= 32, high and low key words travel separately
+    maxn = (nb_samples + world - 1) // world
+    width = max(b - a_ for a_, b in zip(partition_bounds(P, world)[:-1], partition_bounds(P, world)[1:]))
+    # ---- send side: destination-major layout [g][my sample j][partitions of g]
+    meta, tot_send, ks, ks2, cs, send_splits = pack_batch(ctx, mine, P, kw, world, nb_samples, device)
     # ---- the exchange
     meta_t = torch.from_numpy(meta).to(cdev)
     meta_r = torch.empty_like(meta_t)
@@ -316,35 +361,6 @@ def count_exchange_merge(ctx, count_fn, nb_samples, device, comm=None):
         kr, cr = kr.to(device), cr.to(device)
     ks = ks2 = cs = None
     # ---- receive side: block layout [r][j][my partitions]; samples in ascending order for the import
-    lo, hi = bounds[rank], bounds[rank + 1]
-    w = hi - lo
-    pc_in = _host_table(ctx, "pc_in", (nb_samples, max(w, 1)), np.uint32, device)
-    off_in = _host_table(ctx, "off_in", (nb_samples, max(w, 1)), np.uint64, device)
-    tot_in = (SampleTotals * nb_samples)()
-    tot_all = torch.stack(tot_list).cpu().numpy()
-    pos = 0
-    for r in range(world):
-        ss = samples_of(r, world, nb_samples)
-        if not ss:
-            continue
-        seg = meta_recv[r, : len(ss), :w]
-        rows = seg.astype(np.int64).sum(axis=1)
-        starts = pos + np.concatenate([[0], np.cumsum(rows)[:-1]])
-        pc_in[ss, :w] = seg.astype(np.uint32)
-        off_in[ss, :w] = (_excl_cumsum_rows(seg) + starts[:, None]).astype(np.uint64)
-        pos += int(rows.sum())
-        for j, s in enumerate(ss):
-            tt = tot_all[r, j]
-            tot_in[s] = SampleTotals(int(tt[0]), int(tt[1]), int(tt[2]), int(tt[3]), int(tt[4]), int(tt[5]))
-    assert pos == int(kr.numel())
-    ctx.reset()
-    if kw == 2:      # each sample's slice of my key-prefix range is one contiguous, sorted run of the received block
-        s_rec = pc_in.astype(np.int64).sum(axis=1)
-        s_off = off_in[:, 0].astype(np.int64) if w else np.zeros(nb_samples, dtype=np.int64)
-        ctx.import_samples_device_wide(np.arange(nb_samples), tot_in, s_off, s_rec, kr, kr2, cr)
-        ctx.merge()
-        allreduce_stats_device(ctx, totals_already_reduced=True, comm=comm)
-        return
-    ctx.import_samples_device(np.arange(nb_samples), tot_in, lo, pc_in[:, :max(w, 0)] if w else pc_in[:, :0], off_in[:, :w] if w else off_in[:, :0], P, kr, cr)
+    import_batch(ctx, rank, world, nb_samples, P, kw, meta_recv, torch.stack(tot_list).cpu().numpy(), kr, kr2, cr, device)
     ctx.merge()
     allreduce_stats_device(ctx, totals_already_reduced=True, comm=comm)      # imported totals are already global on every rank
