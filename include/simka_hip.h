@@ -212,6 +212,23 @@ int simka_import_samples_device(simka_ctx *ctx, const uint32_t *samples, uint32_
                                 uint64_t part_lo, uint64_t part_width, const uint32_t *part_counts, const uint64_t *in_offsets,
                                 uint64_t nb_partitions, const void *d_keys, const void *d_counts, uint64_t nb_records);
 
+/* The same exchange with its per-(sample, partition) tables computed ON THE DEVICE (ABI 8): with 2^19 partitions those tables are tens of
+ * megabytes per rank, and their prefix sums on the host cost ten times what the device needs to move the records.
+ *   simka_pack_plan(ctx, samples, nb, nb_ranges, send_records): the counted samples[nb] (slot j = samples[j]) are to be sent to nb_ranges
+ *     ranks, rank g receiving the partitions [P g / nb_ranges, P (g + 1) / nb_ranges); send_records[g] (host) = records bound for rank g.
+ *   simka_pack_run(ctx, d_keys, d_counts, d_meta, nb_slots, width): gathers the planned runs destination-major -- [g][slot j][partitions
+ *     of g] -- into d_keys (u64) / d_counts (u32) of sum(send_records) records, and writes the run lengths to d_meta, device int32
+ *     [nb_ranges][nb_slots][width] (nb_slots >= nb, width >= the widest range; cells it does not own are left as they are: clear it first).
+ *   simka_import_block_device: the receive side.  The block holds nb_slots_total slots one after the other (source rank major), slot q =
+ *     the runs of sample slot_samples[q] (0xffffffff: an empty slot) in the partitions [part_lo, part_lo + part_width), their lengths in
+ *     row q of d_meta (device int32 [nb_slots_total][width]); totals[q] as for simka_import_samples_device.
+ * (kmer_size >= 32 exchanges whole sorted runs: simka_gather_samples_device_wide / simka_import_samples_device_wide.) */
+int simka_pack_plan(simka_ctx *ctx, const uint32_t *samples, uint32_t nb, uint32_t nb_ranges, uint64_t *send_records);
+int simka_pack_run(simka_ctx *ctx, void *d_keys, void *d_counts, int32_t *d_meta, uint32_t nb_slots, uint32_t width);
+int simka_import_block_device(simka_ctx *ctx, const uint32_t *slot_samples, uint32_t nb_slots_total, const simka_sample_totals *totals,
+                              uint64_t part_lo, uint64_t part_width, uint32_t width, const int32_t *d_meta, uint64_t nb_partitions,
+                              const void *d_keys, const void *d_counts, uint64_t nb_records);
+
 /* kmer_size >= 32 (key_words == 2): the batch gather / import with the high and the low key words in separate device buffers.
  * A received block holds each sample's records contiguously and sorted (a sample comes from ONE rank): sample_offsets /
  * sample_records say where.  simka_samples_spectrum_info is shared (its partitions are key-prefix ranges). */

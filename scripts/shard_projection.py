@@ -84,13 +84,13 @@ for G in (1, 2, 4, 8):
             t0 = time.perf_counter()
             meta, tot_send, ks, ks2, cs, splits = sdist.pack_batch(ctx, mine, P, kw_, G, n, dev)
             ctx.sync(); sync(); gather_ms.append(round((time.perf_counter() - t0) * 1e3, 2))
-            packs.append((meta.copy(), tot_send.copy(), ks, ks2, cs, list(splits)))
+            packs.append((meta.clone() if isinstance(meta, torch.Tensor) else meta.copy(), tot_send.copy(), ks, ks2, cs, list(splits)))
     send_bytes = [[int(x) * (12 if kw_ == 1 else 20) for x in pk[5]] for pk in packs]
     tot_all = np.stack([pk[1] for pk in packs])
     merge = {}
     for g in sorted({0, G // 2, G - 1}):
         # the all-to-all, by slicing: rank g receives block g of every rank's send buffer
-        meta_recv = np.stack([packs[r][0][g] for r in range(G)])
+        meta_recv = torch.stack([packs[r][0][g] for r in range(G)]) if isinstance(packs[0][0], torch.Tensor) else np.stack([packs[r][0][g] for r in range(G)])
         kr, cr, kr2 = [], [], []
         for r in range(G):
             sp = packs[r][5]; lo_ = sum(sp[:g])

@@ -106,6 +106,9 @@ def load_library(build_if_missing=True):
         "simka_samples_spectrum_info": (i32, [vp, vp, u32, vp, vp]),
         "simka_gather_samples_device": (i32, [vp, vp, u32, vp, vp, vp]),
         "simka_import_samples_device": (i32, [vp, vp, u32, vp, u64, u64, vp, vp, u64, vp, vp, u64]),
+        "simka_pack_plan": (i32, [vp, vp, u32, u32, vp]),
+        "simka_pack_run": (i32, [vp, vp, vp, vp, u32, u32]),
+        "simka_import_block_device": (i32, [vp, vp, u32, vp, u64, u64, u32, vp, u64, vp, vp, u64]),
         "simka_device_memory": (i32, [i32, C.POINTER(u64), C.POINTER(u64)]),
         "simka_device_alloc": (i32, [i32, u64, C.POINTER(vp)]),
         "simka_device_free": (i32, [i32, vp]),
@@ -514,6 +517,28 @@ class SimkaContext:
                                                          counts.data_ptr() if n else None, n))
 
     # -- merge side -------------------------------------------------------------------------
+    # the exchange with its tables on the device (simka_pack_plan / _run, simka_import_block_device)
+    def pack_plan(self, samples, nb_ranges):
+        """-> records bound for each of nb_ranges ranks (rank g: partitions [P g / nb_ranges, P (g + 1) / nb_ranges))"""
+        idx = np.ascontiguousarray(samples, dtype=np.uint32)
+        out = np.zeros(nb_ranges, dtype=np.uint64)
+        self._keep_plan = idx
+        self._check(self.lib.simka_pack_plan(self.h, idx.ctypes.data if len(idx) else None, len(idx), nb_ranges, out.ctypes.data))
+        return [int(x) for x in out]
+
+    def pack_run(self, keys, counts, meta):
+        """keys (int64) / counts (int32): torch tensors of sum(pack_plan) records; meta: int32 tensor [nb_ranges, nb_slots, width] on this GPU (zeroed)"""
+        n = int(counts.numel())
+        self._check(self.lib.simka_pack_run(self.h, keys.data_ptr() if n else None, counts.data_ptr() if n else None, meta.data_ptr() if meta is not None else None,
+                                            int(meta.shape[1]) if meta is not None else 0, int(meta.shape[2]) if meta is not None else 0))
+
+    def import_block_device(self, slot_samples, totals, part_lo, part_width, meta, nb_partitions, keys, counts):
+        """slot_samples: uint32 [nb_slots_total] (0xffffffff: empty slot); totals: SampleTotals array per slot; meta: int32 device tensor [nb_slots_total, width]"""
+        ss = np.ascontiguousarray(slot_samples, dtype=np.uint32)
+        n = int(counts.numel())
+        self._check(self.lib.simka_import_block_device(self.h, ss.ctypes.data, len(ss), C.addressof(totals), int(part_lo), int(part_width), int(meta.shape[-1]),
+                                                       meta.data_ptr(), int(nb_partitions), keys.data_ptr() if n else None, counts.data_ptr() if n else None, n))
+
     def merge(self):
         self._check(self.lib.simka_merge(self.h))
 

@@ -116,6 +116,10 @@ struct simka_ctx {
     uint64_t nb_wide_hash = 0, nb_wide_sort = 0;                // samples counted on either path (tests / -verbose)
     SimkaWide *wide = nullptr;                                  // 32 <= k <= 63 (or SIMKA_SORT_PATH): the sort-based path of simka_wide.hip
     ull *d_xoff = nullptr; uint64_t xoff_cap = 0;               // simka_gather_samples_device: destination offsets
+    // simka_pack_plan / _run, simka_import_block_device: the exchange tables on the device
+    ull *d_xrows = nullptr; uint64_t xrows_cap = 0;             // [nb][nb_ranges] records of (sample slot, destination); then their starts
+    uint32_t *d_xsamples = nullptr; uint64_t xsamples_cap = 0;  // sample of every slot
+    std::vector<uint32_t> plan_samples; uint32_t plan_ranges = 0; uint64_t plan_total = 0;
     ull *d_hist = nullptr; uint32_t *d_ovf_list = nullptr; ull *d_ovf_cursor = nullptr; uint64_t ovf_cap = 0;
 
     std::vector<uint8_t> counted;
@@ -602,7 +606,7 @@ SIMKA_EXPORT void simka_destroy(simka_ctx *ctx) {
                      ctx->d_sample_base, ctx->d_foff, ctx->d_fcnt, ctx->d_stats, ctx->d_err, ctx->d_part_total,
                      ctx->d_part_off, ctx->d_work, ctx->d_seg_abs, ctx->d_seg_rows, ctx->d_entries, ctx->d_groups,
                      ctx->d_spans, ctx->d_cursors, ctx->d_huge, ctx->d_xoff, ctx->d_hist, ctx->d_ovf_list, ctx->d_ovf_cursor,
-                     ctx->d_tm_ent, ctx->d_tm_p, ctx->d_tm_off };
+                     ctx->d_tm_ent, ctx->d_tm_p, ctx->d_tm_off, ctx->d_xrows, ctx->d_xsamples };
     for (void *p : ptrs) if (p) (void)hipFree(p);
     if (ctx->h_part) (void)hipHostFree(ctx->h_part);
     for (auto &ps : ctx->pin) if (ps.p) (void)hipHostFree(ps.p);
@@ -1619,6 +1623,148 @@ SIMKA_EXPORT int simka_gather_samples_device(simka_ctx *ctx, const uint32_t *sam
                        (uint32_t)ctx->nparts, (ull *)d_keys, (uint32_t *)d_counts);
     HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(ctx->stream));       // the caller hands the buffers to RCCL on another stream
+    return SIMKA_OK;
+}
+
+// ---- the same exchange with its tables computed on the device (ABI 8) ---------------------------------------------------------------
+SIMKA_EXPORT int simka_pack_plan(simka_ctx *ctx, const uint32_t *samples, uint32_t nb, uint32_t nb_ranges, uint64_t *send_records) {
+    if (!ctx || !send_records || nb_ranges == 0 || (nb && !samples)) return SIMKA_ERR_INVALID;
+    if (ctx->wide) return ctx->fail(SIMKA_ERR_INVALID, "simka_pack_plan: kmer_size >= 32 exchanges whole sorted runs (simka_gather_samples_device_wide)");
+    const uint32_t N = ctx->cfg.nb_samples;
+    for (uint32_t j = 0; j < nb; j++)
+        if (samples[j] >= N || !ctx->counted[samples[j]]) return ctx->fail(SIMKA_ERR_STATE, "simka_pack_plan: sample %u not counted", samples[j]);
+    for (uint32_t g = 0; g < nb_ranges; g++) send_records[g] = 0;
+    ctx->plan_samples.assign(samples, samples + nb); ctx->plan_ranges = nb_ranges; ctx->plan_total = 0;
+    if (nb == 0 || !ctx->geometry_ready) return SIMKA_OK;
+    if (nb_ranges > ctx->nparts) return ctx->fail(SIMKA_ERR_INVALID, "simka_pack_plan: more ranges (%u) than partitions", nb_ranges);
+    HIPCHK(hipSetDevice(ctx->cfg.device));
+    int rc = resolve_pending(ctx); if (rc) return rc;
+    rc = check_device_error(ctx); if (rc) return rc;
+    rc = ensure_cap(ctx, &ctx->d_xrows, &ctx->xrows_cap, (uint64_t)nb * nb_ranges); if (rc) return rc;
+    rc = ensure_cap(ctx, &ctx->d_xsamples, &ctx->xsamples_cap, (uint64_t)nb); if (rc) return rc;
+    HIPCHK(hipMemcpyAsync(ctx->d_xsamples, samples, (size_t)nb * 4, hipMemcpyHostToDevice, ctx->stream));
+    hipLaunchKernelGGL(k_range_rowsum, dim3(nb_ranges, nb), dim3(256), 0, ctx->stream, (const uint32_t *)ctx->d_fcnt, (const uint32_t *)ctx->d_xsamples, (uint32_t)ctx->nparts, nb_ranges, ctx->d_xrows);
+    std::vector<ull> rows((size_t)nb * nb_ranges), starts((size_t)nb * nb_ranges);
+    HIPCHK(hipMemcpyAsync(rows.data(), ctx->d_xrows, rows.size() * 8, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    ull pos = 0;
+    for (uint32_t g = 0; g < nb_ranges; g++) {          // destination-major: [g][slot j][partitions of g]
+        for (uint32_t j = 0; j < nb; j++) { starts[(size_t)j * nb_ranges + g] = pos; pos += rows[(size_t)j * nb_ranges + g]; send_records[g] += rows[(size_t)j * nb_ranges + g]; }
+    }
+    ctx->plan_total = pos;
+    HIPCHK(hipMemcpyAsync(ctx->d_xrows, starts.data(), starts.size() * 8, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));          // (starts is a local)
+    return SIMKA_OK;
+}
+
+SIMKA_EXPORT int simka_pack_run(simka_ctx *ctx, void *d_keys, void *d_counts, int32_t *d_meta, uint32_t nb_slots, uint32_t width) {
+    if (!ctx) return SIMKA_ERR_INVALID;
+    const uint32_t nb = (uint32_t)ctx->plan_samples.size(), G = ctx->plan_ranges;
+    if (nb == 0 || !ctx->geometry_ready) return SIMKA_OK;
+    if (G == 0) return ctx->fail(SIMKA_ERR_STATE, "simka_pack_run: no plan (simka_pack_plan first)");
+    if (ctx->plan_total && (!d_keys || !d_counts)) return ctx->fail(SIMKA_ERR_INVALID, "simka_pack_run: NULL buffers");
+    const uint32_t maxw = (uint32_t)((ctx->nparts + G - 1) / G);
+    if (d_meta && (nb_slots < nb || width < maxw)) return ctx->fail(SIMKA_ERR_INVALID, "simka_pack_run: meta of %u slots x %u partitions, the plan needs %u x %u", nb_slots, width, nb, maxw);
+    HIPCHK(hipSetDevice(ctx->cfg.device));
+    int rc = ensure_cap(ctx, &ctx->d_xoff, &ctx->xoff_cap, (uint64_t)nb * ctx->nparts + 1); if (rc) return rc;
+    hipLaunchKernelGGL(k_range_offsets, dim3(nb), dim3(1024), 0, ctx->stream, (const uint32_t *)ctx->d_fcnt, (const uint32_t *)ctx->d_xsamples, (uint32_t)ctx->nparts, G,
+                       (const ull *)ctx->d_xrows, ctx->d_xoff, d_meta, nb_slots, width);
+    hipLaunchKernelGGL(k_gather_samples, dim3((uint32_t)std::min<uint64_t>(ctx->nparts, (uint64_t)ctx->num_cus * 4), nb), dim3(256), 0, ctx->stream,
+                       ctx->d_solid_keys, ctx->d_solid_counts, ctx->d_sample_base, ctx->d_foff, ctx->d_fcnt, ctx->d_xsamples, ctx->d_xoff,
+                       (uint32_t)ctx->nparts, (ull *)d_keys, (uint32_t *)d_counts);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(ctx->stream));       // the caller hands the buffers to RCCL on another stream
+    return SIMKA_OK;
+}
+
+SIMKA_EXPORT int simka_import_block_device(simka_ctx *ctx, const uint32_t *slot_samples, uint32_t nb_slots_total, const simka_sample_totals *totals,
+                                           uint64_t part_lo, uint64_t part_width, uint32_t width, const int32_t *d_meta, uint64_t nb_partitions,
+                                           const void *d_keys, const void *d_counts, uint64_t nb_records) {
+    if (ctx && ctx->wide) return ctx->fail(SIMKA_ERR_INVALID, "simka_import_block_device: use simka_import_samples_device_wide for kmer_size >= 32");
+    if (!ctx || (nb_slots_total && (!slot_samples || !totals || !d_meta))) return SIMKA_ERR_INVALID;
+    const uint32_t N = ctx->cfg.nb_samples, fl = ctx->cfg.dist_flags;
+    if (ctx->merged) return ctx->fail(SIMKA_ERR_STATE, "simka_import_block_device: merge already ran");
+    std::vector<uint8_t> seen(N, 0);
+    for (uint32_t q = 0; q < nb_slots_total; q++) {
+        const uint32_t s = slot_samples[q];
+        if (s == 0xffffffffu) continue;
+        if (s >= N) return ctx->fail(SIMKA_ERR_INVALID, "simka_import_block_device: sample index %u out of range", s);
+        if (ctx->counted[s] || seen[s]) return ctx->fail(SIMKA_ERR_STATE, "simka_import_block_device: sample %u was already counted", s);
+        seen[s] = 1;
+    }
+    if (nb_records && (!d_keys || !d_counts)) return ctx->fail(SIMKA_ERR_INVALID, "simka_import_block_device: keys / counts are NULL");
+    if (nb_partitions == 0 || (nb_partitions & (nb_partitions - 1))) return ctx->fail(SIMKA_ERR_INVALID, "simka_import_block_device: nb_partitions must be a power of two");
+    if (part_lo + part_width > nb_partitions || part_width > width) return ctx->fail(SIMKA_ERR_INVALID, "simka_import_block_device: partition range outside [0, nb_partitions) or wider than the meta rows");
+    if (nb_slots_total == 0) return SIMKA_OK;
+    HIPCHK(hipSetDevice(ctx->cfg.device));
+    int rc;
+    if (!ctx->geometry_ready) {
+        ctx->cfg.log2_partitions = ceil_log2_u64(nb_partitions);
+        uint64_t hint = std::max<uint64_t>(ctx->cfg.max_kmers_per_sample, 1);
+        for (uint32_t q = 0; q < nb_slots_total; q++) if (slot_samples[q] != 0xffffffffu) hint = std::max<uint64_t>(hint, totals[q].kmer_occurrences);
+        rc = setup_geometry(ctx, hint); if (rc) return rc;
+    }
+    if (ctx->nparts != nb_partitions)
+        return ctx->fail(SIMKA_ERR_INVALID, "simka_import_block_device: spectra have %llu partitions, this run %llu", (unsigned long long)nb_partitions, (unsigned long long)ctx->nparts);
+    rc = resolve_pending(ctx); if (rc) return rc;
+    const uint64_t P = ctx->nparts;
+    rc = ensure_cap(ctx, &ctx->d_xrows, &ctx->xrows_cap, (uint64_t)nb_slots_total); if (rc) return rc;
+    rc = ensure_cap(ctx, &ctx->d_xsamples, &ctx->xsamples_cap, (uint64_t)nb_slots_total); if (rc) return rc;
+    HIPCHK(hipMemcpyAsync(ctx->d_xsamples, slot_samples, (size_t)nb_slots_total * 4, hipMemcpyHostToDevice, ctx->stream));
+    hipLaunchKernelGGL(k_import_tables, dim3(nb_slots_total), dim3(1024), 0, ctx->stream, d_meta, (const uint32_t *)ctx->d_xsamples, width, (uint32_t)part_width, (uint32_t)P, (uint32_t)part_lo,
+                       ctx->d_foff, ctx->d_fcnt, ctx->d_xrows);
+    std::vector<ull> slot_tot(nb_slots_total);
+    ull cursor = 0;
+    HIPCHK(hipMemcpyAsync(slot_tot.data(), ctx->d_xrows, (size_t)nb_slots_total * 8, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipMemcpyAsync(&cursor, ctx->d_arena_cursor, 8, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    ull sum = 0;
+    for (uint32_t q = 0; q < nb_slots_total; q++) {
+        if (slot_tot[q] > 0xffffffffull) return ctx->fail(SIMKA_ERR_INVALID, "simka_import_block_device: slot %u holds more than 2^32 records", q);
+        sum += slot_tot[q];
+    }
+    if (sum != nb_records) return ctx->fail(SIMKA_ERR_INVALID, "simka_import_block_device: the meta rows sum to %llu records, nb_records is %llu", (unsigned long long)sum, (unsigned long long)nb_records);
+    if (cursor + nb_records > ctx->arena_cap)
+        return ctx->fail(SIMKA_ERR_NOMEM, "solid-spectrum arena exhausted (%llu records): raise solid_capacity", (unsigned long long)ctx->arena_cap);
+    const ull next = cursor + nb_records;
+    rc = arena_ensure(ctx, next); if (rc) return rc;
+    ctx->arena_hi = std::max<uint64_t>(ctx->arena_hi, next);
+    if (nb_records) {
+        HIPCHK(hipMemcpyAsync(ctx->d_solid_keys + cursor, d_keys, nb_records * 8, hipMemcpyDeviceToDevice, ctx->stream));
+        HIPCHK(hipMemcpyAsync(ctx->d_solid_counts + cursor, d_counts, nb_records * 4, hipMemcpyDeviceToDevice, ctx->stream));
+    }
+    HIPCHK(hipMemcpyAsync(ctx->d_arena_cursor, &next, 8, hipMemcpyHostToDevice, ctx->stream));
+    // sample bases and totals: read-modify-write of two small arrays
+    std::vector<ull> bases(N + 1), tot((size_t)SIMKA_NB_TOTALS * N);
+    HIPCHK(hipMemcpyAsync(bases.data(), ctx->d_sample_base, (size_t)(N + 1) * 8, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipMemcpyAsync(tot.data(), ctx->d_stats + stats_off_tot(N, fl, 0), tot.size() * 8, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    ull pos = cursor;
+    for (uint32_t q = 0; q < nb_slots_total; q++) {
+        const uint32_t s = slot_samples[q];
+        if (s == 0xffffffffu) continue;
+        bases[s] = pos; pos += slot_tot[q];
+        tot[(size_t)SIMKA_TOT_D * N + s] = totals[q].nb_distinct; tot[(size_t)SIMKA_TOT_N * N + s] = totals[q].nb_kmers;
+        tot[(size_t)SIMKA_TOT_Q * N + s] = totals[q].sum_sq; tot[(size_t)SIMKA_TOT_KOCC * N + s] = totals[q].kmer_occurrences;
+        tot[(size_t)SIMKA_TOT_DALL * N + s] = totals[q].distinct_all;
+    }
+    HIPCHK(hipMemcpyAsync(ctx->d_sample_base, bases.data(), (size_t)(N + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(hipMemcpyAsync(ctx->d_stats + stats_off_tot(N, fl, 0), tot.data(), tot.size() * 8, hipMemcpyHostToDevice, ctx->stream));
+    if (ctx->d_hist && part_width) {   // -complex-dist: per-sample histogram of the imported solid counts
+        const uint32_t gx = (uint32_t)std::min<uint64_t>(part_width, 1024);
+        for (uint32_t q = 0; q < nb_slots_total; q++) {
+            const uint32_t s = slot_samples[q];
+            if (s == 0xffffffffu) continue;
+            HIPCHK(hipMemsetAsync(ctx->d_hist + (uint64_t)s * SIMKA_HIST_MAX, 0, (size_t)SIMKA_HIST_MAX * 8, ctx->stream));
+            hipLaunchKernelGGL(k_import_hist, dim3(gx, 1), dim3(256), 0, ctx->stream, (const uint32_t *)ctx->d_solid_counts, (const ull *)ctx->d_sample_base,
+                               (const uint32_t *)ctx->d_foff, (const uint32_t *)ctx->d_fcnt, (uint32_t)P, (uint32_t)part_lo, (uint32_t)part_width, s, (ull *)ctx->d_hist,
+                               ctx->d_ovf_list, (ull *)ctx->d_ovf_cursor, (ull)ctx->ovf_cap);
+        }
+        HIPCHK(hipGetLastError());
+    }
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    for (uint32_t q = 0; q < nb_slots_total; q++) { const uint32_t s = slot_samples[q]; if (s != 0xffffffffu) { ctx->nb_reads[s] = totals[q].nb_reads; ctx->counted[s] = 1; } }
+    ctx->seg_dirty = true;      // (its segments carry no index of key-hash blocks: k_segment_rows builds it at the merge)
     return SIMKA_OK;
 }
 

@@ -1559,6 +1559,83 @@ k_gather_samples(const ull *solid_keys, const uint32_t *solid_counts, const ull 
 }
 
 // --------------------------------------------------------------------------------------------
+// The tables of the spectrum exchange (sample shards), computed on the device: with 2^19 partitions the per-(sample, partition) tables
+// are tens of megabytes per rank, and the prefix sums over them on the host (numpy / C++ loops) cost ten times what the device
+// needs to move the records themselves.
+//   k_range_rowsum   records of sample slot j bound for rank g (the partitions [bounds[g], bounds[g + 1]))
+//   k_range_offsets  destination offset of every run (slot j, partition p) in the destination-major send buffer
+//                    [g][slot j][partitions of g] from the starts of the (j, g) rows; the run lengths go to meta[g][j][p - lo_g]
+//   k_import_tables  receive side: slot (r, j) of the received block = sample slot_samples[r * nb_slots + j]: foff / fcnt of the
+//                    sample's runs in my partition range (the runs of a slot are contiguous), the slot's total
+// --------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+k_range_rowsum(const uint32_t *fcnt, const uint32_t *samples, uint32_t nparts, uint32_t nb_ranges, ull *rows) {
+    const uint32_t g = blockIdx.x, j = blockIdx.y;
+    const uint32_t lo = (uint32_t)(((ull)nparts * g) / nb_ranges), hi = (uint32_t)(((ull)nparts * (g + 1u)) / nb_ranges);
+    const uint32_t *fc = fcnt + (size_t)samples[j] * nparts;
+    ull acc = 0;
+    for (uint32_t p = lo + threadIdx.x; p < hi; p += 256) acc += fc[p];
+    __shared__ ull s_part[256];
+    s_part[threadIdx.x] = acc;
+    __syncthreads();
+    for (uint32_t st = 128; st; st >>= 1) { if (threadIdx.x < st) s_part[threadIdx.x] += s_part[threadIdx.x + st]; __syncthreads(); }
+    if (threadIdx.x == 0) rows[(size_t)j * nb_ranges + g] = s_part[0];
+}
+
+__global__ void __launch_bounds__(1024)
+k_range_offsets(const uint32_t *fcnt, const uint32_t *samples, uint32_t nparts, uint32_t nb_ranges, const ull *starts, ull *xoff,
+                int32_t *meta, uint32_t nb_slots, uint32_t width) {
+    const uint32_t j = blockIdx.x, tid = threadIdx.x;
+    const uint32_t *fc = fcnt + (size_t)samples[j] * nparts;
+    ull *xo = xoff + (size_t)j * nparts;
+    __shared__ uint32_t tmp[16];
+    __shared__ ull s_carry;
+    for (uint32_t g = 0; g < nb_ranges; g++) {
+        const uint32_t lo = (uint32_t)(((ull)nparts * g) / nb_ranges), hi = (uint32_t)(((ull)nparts * (g + 1u)) / nb_ranges);
+        if (tid == 0) s_carry = starts[(size_t)j * nb_ranges + g];
+        __syncthreads();
+        int32_t *mrow = meta ? meta + ((size_t)g * nb_slots + j) * width : nullptr;
+        for (uint32_t p0 = lo; p0 < hi; p0 += 1024) {
+            const uint32_t p = p0 + tid;
+            const uint32_t c = p < hi ? fc[p] : 0u;
+            uint32_t excl;
+            const uint32_t tot = block_excl_scan1<1024>(c, excl, tmp);
+            const ull carry = s_carry;
+            if (p < hi) { xo[p] = carry + excl; if (mrow) mrow[p - lo] = (int32_t)c; }
+            __syncthreads();
+            if (tid == 0) s_carry = carry + tot;
+            __syncthreads();
+        }
+    }
+}
+
+__global__ void __launch_bounds__(1024)
+k_import_tables(const int32_t *meta, const uint32_t *slot_samples, uint32_t width, uint32_t w, uint32_t nparts, uint32_t p_lo,
+                uint32_t *foff, uint32_t *fcnt, ull *slot_total) {
+    const uint32_t slot = blockIdx.x, tid = threadIdx.x;
+    const uint32_t s = slot_samples[slot];
+    if (s == 0xffffffffu) { if (tid == 0) slot_total[slot] = 0; return; }
+    const int32_t *mrow = meta + (size_t)slot * width;
+    uint32_t *fo = foff + (size_t)s * nparts + p_lo, *fc = fcnt + (size_t)s * nparts + p_lo;
+    __shared__ uint32_t tmp[16];
+    __shared__ ull s_carry;
+    if (tid == 0) s_carry = 0;
+    __syncthreads();
+    for (uint32_t p0 = 0; p0 < w; p0 += 1024) {
+        const uint32_t p = p0 + tid;
+        const uint32_t c = p < w ? (uint32_t)mrow[p] : 0u;
+        uint32_t excl;
+        const uint32_t tot = block_excl_scan1<1024>(c, excl, tmp);
+        const ull carry = s_carry;
+        if (p < w) { fo[p] = c ? (uint32_t)(carry + excl) : 0u; fc[p] = c; }      // (a slot holds < 2^32 records: checked on the host from its total)
+        __syncthreads();
+        if (tid == 0) s_carry = carry + tot;
+        __syncthreads();
+    }
+    if (tid == 0) slot_total[slot] = s_carry;
+}
+
+// --------------------------------------------------------------------------------------------
 // synthetic data (bench / test utility): genome pool and error-bearing reads, 2-bit packed
 // --------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256)

@@ -227,13 +227,26 @@ def _host_table(ctx, name, shape, np_dtype, device):
 
 def pack_batch(ctx, mine, P, kw, world, nb_samples, device):
     """Send side of the batch exchange on one rank: the counted samples `mine` of `ctx` gathered into ONE destination-major buffer
-    [g][my sample j][partitions of g] (simka_gather_samples_device).  -> (meta int32 [world, maxn, width], totals int64 [maxn, 6],
-    keys, keys2 (kmer_size >= 32: low words), counts, send_splits)."""
+    [g][my sample j][partitions of g].  One-word k-mers: the tables stay on the device (simka_pack_plan / simka_pack_run: with 2^19
+    partitions their prefix sums on the host cost ten times the gather itself) and `meta` is an int32 DEVICE tensor; two-word k-mers:
+    whole sorted runs, host tables (simka_gather_samples_device_wide), `meta` a numpy array.
+    -> (meta [world, maxn, width], totals int64 [maxn, 6], keys, keys2 (kmer_size >= 32: low words), counts, send_splits)."""
     bounds = partition_bounds(P, world)
     width = max(bounds[g + 1] - bounds[g] for g in range(world))
     maxn = (nb_samples + world - 1) // world
-    meta = _host_table(ctx, "meta", (world, maxn, width), np.int32, device)
     tot_send = np.zeros((maxn, 6), dtype=np.int64)
+    if kw == 1 and torch.device(device).type == "cuda":
+        for j, s_ in enumerate(mine):
+            t = ctx.sample_totals(s_)
+            tot_send[j] = [t["nb_reads"], t["D"], t["N"], t["Q"], t["K_occ"], t["D_all"]]
+        send_splits = ctx.pack_plan(mine, world) if mine else [0] * world
+        meta = torch.zeros((world, maxn, width), dtype=torch.int32, device=device)
+        ks = torch.empty(sum(send_splits), dtype=torch.int64, device=device)
+        cs = torch.empty(sum(send_splits), dtype=torch.int32, device=device)
+        if mine:
+            ctx.pack_run(ks, cs, meta)
+        return meta, tot_send, ks, torch.empty(0, dtype=torch.int64, device=device), cs, send_splits
+    meta = _host_table(ctx, "meta", (world, maxn, width), np.int32, device)
     send_splits = [0] * world
     if mine:
         pc, tot = ctx.samples_spectrum_info(mine)
@@ -266,13 +279,29 @@ def pack_batch(ctx, mine, P, kw, world, nb_samples, device):
 
 
 def import_batch(ctx, rank, world, nb_samples, P, kw, meta_recv, tot_all, kr, kr2, cr, device):
-    """Receive side on rank `rank`: the received block [source r][its sample j][my partitions] (record counts meta_recv int32
-    [world, maxn, width], per-sample totals tot_all int64 [world, maxn, 6]) imported into `ctx` in ONE call
-    (simka_import_samples_device).  The context is reset first; the caller merges."""
+    """Receive side on rank `rank`: the received block [source r][its sample j][my partitions] (run lengths meta_recv int32
+    [world, maxn, width] -- a device tensor or a numpy array --, per-sample totals tot_all int64 [world, maxn, 6]) imported into `ctx`
+    in ONE call (one-word k-mers: simka_import_block_device, tables on the device).  The context is reset first; the caller merges."""
     from .api import SampleTotals
     bounds = partition_bounds(P, world)
     lo, hi = bounds[rank], bounds[rank + 1]
     w = hi - lo
+    if kw == 1 and torch.device(device).type == "cuda":
+        meta_dev = meta_recv if isinstance(meta_recv, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(meta_recv))
+        meta_dev = meta_dev.to(device=device, dtype=torch.int32).contiguous()
+        maxn = int(meta_dev.shape[1])
+        slots = np.full(world * maxn, 0xffffffff, dtype=np.uint32)
+        tot_in = (SampleTotals * (world * maxn))()
+        for r in range(world):
+            for j, s_ in enumerate(samples_of(r, world, nb_samples)):
+                slots[r * maxn + j] = s_
+                tt = tot_all[r, j]
+                tot_in[r * maxn + j] = SampleTotals(int(tt[0]), int(tt[1]), int(tt[2]), int(tt[3]), int(tt[4]), int(tt[5]))
+        ctx.reset()
+        ctx.import_block_device(slots, tot_in, lo, w, meta_dev.view(world * maxn, -1), P, kr, cr)
+        return
+    if isinstance(meta_recv, torch.Tensor):
+        meta_recv = meta_recv.cpu().numpy()
     pc_in = _host_table(ctx, "pc_in", (nb_samples, max(w, 1)), np.uint32, device)
     off_in = _host_table(ctx, "off_in", (nb_samples, max(w, 1)), np.uint64, device)
     tot_in = (SampleTotals * nb_samples)()
@@ -326,16 +355,18 @@ def count_exchange_merge(ctx, count_fn, nb_samples, device, comm=None):
     width = max(b - a_ for a_, b in zip(partition_bounds(P, world)[:-1], partition_bounds(P, world)[1:]))
     # ---- send side: destination-major layout [g][my sample j][partitions of g]
     meta, tot_send, ks, ks2, cs, send_splits = pack_batch(ctx, mine, P, kw, world, nb_samples, device)
-    # ---- the exchange
-    meta_t = torch.from_numpy(meta).to(cdev)
+    # ---- the exchange: run lengths (device to device with RCCL; through the host with gloo), totals, who sends how much to whom
+    meta_t = (meta if isinstance(meta, torch.Tensor) else torch.from_numpy(meta)).to(cdev)
     meta_r = torch.empty_like(meta_t)
     dist.all_to_all_single(meta_r, meta_t)
     tot_t = torch.from_numpy(tot_send).to(cdev)
     tot_list = [torch.empty_like(tot_t) for _ in range(world)]
     dist.all_gather(tot_list, tot_t)
-    meta_recv = _host_table(ctx, "meta_recv", (world, maxn, width), np.int32, device)       # [source rank][its sample j][my partitions]
-    torch.from_numpy(meta_recv).copy_(meta_r)
-    recv_splits = recv_splits_of(meta_recv)
+    sp_t = torch.tensor(send_splits, dtype=torch.int64, device=cdev)
+    sp_list = [torch.empty_like(sp_t) for _ in range(world)]
+    dist.all_gather(sp_list, sp_t)
+    recv_splits = [int(sp_list[r][rank].item()) for r in range(world)]
+    meta_recv = meta_r              # [source rank][its sample j][my partitions]
     kr2 = None
     if comm is not None:
         # the data path on RCCL through the C ABI: grouped ncclSend / ncclRecv between device buffers, on torch's current stream

@@ -812,6 +812,78 @@ def test_sample_shards_then_partition_range_merge(gpu_required, monkeypatch, wor
     assert np.array_equal(total, ref.flat[:head])
 
 
+@pytest.mark.parametrize("world,k,complex_", [(2, 21, True), (3, 31, False), (8, 21, False), (3, 33, False)])
+def test_batch_exchange_with_its_tables_on_the_device(gpu_required, world, k, complex_):
+    """The batch form of the spectrum exchange that bench.py --gpus N runs (simka_amd/dist.py::pack_batch / import_batch): for one-word
+    k-mers the per-(sample, partition) tables never leave the device (simka_pack_plan / simka_pack_run / simka_import_block_device: range
+    sums, destination offsets, run lengths, foff / fcnt of the imported runs).  `world` emulated ranks on one GPU -- uneven partition
+    ranges for world = 3, empty sample slots for world = 8 --, the all-to-all by slicing; the summed heads equal the single-context run
+    bit for bit, and the device tables equal the host-side ones of the per-sample path (pack_spectra).  k = 33: the two-word route."""
+    import torch
+    import simka_amd
+    from simka_amd import dist as sdist
+    dev = torch.device("cuda:0")
+    n, R, L = 7, 3000, 100
+    packed = _synthetic(n, R, L, seed_shift=23)
+    kw = dict(kmer_size=k, abundance_min=2, simple_dist=True, complex_dist=complex_, max_kmers_per_sample=R * (L - k + 1))
+
+    def count(ctx, s):
+        ctx.count_sample(s, np.concatenate([packed[s], np.zeros(2, dtype=np.uint64)]), R * L, R, fixed_len=L)
+
+    with simka_amd.SimkaContext(n, **kw) as c:
+        for s in range(n):
+            count(c, s)
+        c.merge()
+        ref = c.stats()
+    lay = simka_amd.api.stats_layout(n, ref.dist_flags)
+    head = lay["head"]
+    packs, P, kw_ = [], None, 1
+    for r in range(world):
+        mine = sdist.samples_of(r, world, n)
+        with simka_amd.SimkaContext(n, **kw) as c:
+            for s in mine:
+                count(c, s)
+            if mine:
+                info = c.spectrum_info(mine[0]); P, kw_ = info[1], info[2]
+            P_r = P if P is not None else 1
+            meta, tot_send, ks, ks2, cs, splits = sdist.pack_batch(c, mine, P_r, kw_, world, n, dev)
+            if kw_ == 1 and mine:      # the device tables against the host-side ones of the per-sample path
+                local = {s: c.export_sample_device(s, dev) for s in mine}
+                m_host, _, k_host, c_host, sp_host = sdist.pack_spectra(local, P_r, world, n, r, dev)
+                assert list(sp_host) == list(splits) and torch.equal(k_host, ks) and torch.equal(c_host, cs)
+                assert np.array_equal(meta.cpu().numpy()[:, : len(mine), :], m_host[:, : len(mine), : meta.shape[2]])
+            packs.append((meta.clone() if isinstance(meta, torch.Tensor) else meta.copy(), tot_send.copy(), ks, ks2, cs, list(splits)))
+    assert P is not None
+    tot_all = np.stack([pk[1] for pk in packs])
+    total = np.zeros(head, dtype=np.uint64)
+    for g in range(world):
+        if isinstance(packs[0][0], torch.Tensor):
+            meta_recv = torch.stack([packs[r][0][g] for r in range(world)])
+        else:
+            meta_recv = np.stack([packs[r][0][g] for r in range(world)])
+        kr, cr, kr2 = [], [], []
+        for r in range(world):
+            sp = packs[r][5]; lo_ = sum(sp[:g])
+            kr.append(packs[r][2][lo_: lo_ + sp[g]]); cr.append(packs[r][4][lo_: lo_ + sp[g]])
+            if kw_ == 2:
+                kr2.append(packs[r][3][lo_: lo_ + sp[g]])
+        with simka_amd.SimkaContext(n, **kw) as c:
+            sdist.import_batch(c, g, world, n, P, kw_, meta_recv, tot_all, torch.cat(kr), torch.cat(kr2) if kw_ == 2 else None, torch.cat(cr), dev)
+            if complex_:      # the totals are global already (imported): nothing to all-reduce before the merge
+                pass
+            c.merge()
+            st = c.stats()
+        total += st.flat[:head]
+        tail = slice(head, lay["derived"])
+        assert np.array_equal(st.flat[tail], ref.flat[tail])
+    if complex_:
+        P_ = lay["nb_pairs"]; klo = lay["acc0"] + 7 * P_
+        assert np.array_equal(total[:klo], ref.flat[:klo]) and np.array_equal(total[klo + P_: head], ref.flat[klo + P_: head])
+        assert np.max(np.abs(total[klo:klo + P_].view(np.int64) - ref.flat[klo:klo + P_].view(np.int64))) <= 64 * world
+    else:
+        assert np.array_equal(total, ref.flat[:head])
+
+
 @pytest.mark.parametrize("gpus", [2, 3])
 def test_cli_multi_gpu_sample_shards_on_one_device(gpu_required, golden_dir, tmp_path, gpus):
     """`simka -nb-gpus G`: samples counted by one-sample contexts (GPU i % G), spectra exported and imported by partition range
