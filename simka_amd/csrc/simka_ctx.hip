@@ -518,7 +518,7 @@ SIMKA_EXPORT int simka_create(const simka_config *cfg, simka_ctx **out) {
         sk.nmax = std::min<uint32_t>(32u, 52u - sk.k);
         sk.mmask = (uint32_t)((1ull << (2 * sk.m)) - 1ull);
         sk.kmask = k.mask;
-        sk.shard_index = cfg->shard_index; sk.shard_count = cfg->shard_count;
+        skm_set_shard(sk, cfg->shard_index, cfg->shard_count);
     } else if (cfg->kmer_size >= 32 && cfg->kmer_size <= 51 && !simka_test_knob("SIMKA_SORT_PATH") && !simka_test_knob("SIMKA_WIDE_SORT")) {
         // 32 <= k <= 51: a record (<= 51 bases) still holds a k-mer.  The minimizer is the smallest of W = 20 m-mers in the MIDDLE of
         // the k-mer: m-mers d .. d + W - 1 with 2 d = k - (W + m - 1), so that a k-mer and its reverse complement look at the same
@@ -533,7 +533,7 @@ SIMKA_EXPORT int simka_create(const simka_config *cfg, simka_ctx **out) {
         sk.nmax = 52u - sk.k;
         sk.mmask = (uint32_t)((1ull << (2 * sk.m)) - 1ull);
         sk.kmask = ~0ull;
-        sk.shard_index = 0; sk.shard_count = 1;          // (shards keep k-mers, not partitions: k_skm_count_wide)
+        skm_set_shard(sk, 0, 1);          // (shards keep k-mers, not partitions: k_skm_count_wide)
         ctx->wide_hash = true;
     }
 
@@ -839,7 +839,7 @@ static int run_count_kernels(simka_ctx *ctx, uint32_t sample, const SimkaScanArg
     int rc;
     const SimkaScanArgs &a = a_in;
     SimkaSkmCfg sk = ctx->skm;
-    if (npass > 1) { sk.shard_index = ctx->skm.shard_index + ctx->skm.shard_count * pass; sk.shard_count = ctx->skm.shard_count * npass; }
+    if (npass > 1) skm_set_shard(sk, ctx->skm.shard_index + ctx->skm.shard_count * pass, ctx->skm.shard_count * npass);
     uint32_t *flag = ctx->d_l1_ovf + sample;
     static const bool force_exact = simka_test_knob("SIMKA_EXACT_SIZING") != nullptr;
     if (force_exact) exact = true;

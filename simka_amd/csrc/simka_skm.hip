@@ -75,6 +75,7 @@ struct SimkaSkmCfg {
                                      // m-mers at p + d .. p + d + W - 1 (k <= 31: d = 0; k >= 36: the window is CENTRED in the k-mer, so that a
                                      // k-mer and its reverse complement see the same m-mers)
     uint32_t shard_index, shard_count;   // this context keeps the partitions p with p % shard_count == shard_index
+    uint32_t shard_magic, pad1_;         // floor(2^32 / shard_count) + 1 (0: plain modulo): pid / shard_count by one multiply, exact for pid < 2^21, count < 2^11
     uint64_t kmask;                  // 2^(2k) - 1
 };
 
@@ -85,7 +86,17 @@ SIMKA_HD uint32_t skm_mm_hash(uint32_t c, uint32_t mmask, uint32_t m) {
     return (h * 0x85EBCA6Bu) & mmask;
 }
 SIMKA_HD uint32_t skm_pid(uint32_t minhash, uint32_t pb) { return pb ? (uint32_t)((minhash * 0xC2B2AE35u) >> (32u - pb)) : 0u; }
-SIMKA_HD bool skm_owns(uint32_t pid, const SimkaSkmCfg &c) { return c.shard_count == 1u || (pid % c.shard_count) == c.shard_index; }
+// (the run loops of the scan ask this four times per thread and tile: a modulo by a run-time divisor is ~30 instructions on the vector unit)
+SIMKA_HD bool skm_owns(uint32_t pid, const SimkaSkmCfg &c) {
+    if (c.shard_count == 1u) return true;
+    if (!c.shard_magic) return (pid % c.shard_count) == c.shard_index;
+    const uint32_t q = (uint32_t)(((uint64_t)pid * c.shard_magic) >> 32);
+    return pid - q * c.shard_count == c.shard_index;
+}
+SIMKA_HD void skm_set_shard(SimkaSkmCfg &c, uint32_t index, uint32_t count) {
+    c.shard_index = index; c.shard_count = count ? count : 1u;
+    c.shard_magic = (c.shard_count > 1u && c.shard_count < 2048u) ? (uint32_t)(0x100000000ull / c.shard_count) + 1u : 0u;
+}
 SIMKA_HD uint32_t skm_rec_n(const uint4 &r) { return ((r.w >> 6) & 31u) + 1u; }
 SIMKA_HD uint32_t skm_rec_pid(const uint4 &r) { return r.w >> 11; }
 // (slot and sort order of the count kernels' tables: simka_key_hash32 of the canonical k-mer, simka_device.h -- what leaves a table in
