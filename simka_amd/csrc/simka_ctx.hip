@@ -106,7 +106,7 @@ struct simka_ctx {
     SimkaSpan *d_spans = nullptr; ull *d_cursors = nullptr; SimkaSpan *d_huge = nullptr;
     uint64_t merge_cap = 0, seg_cap = 0, span_cap = 0, huge_cap = 0;
     // tile-major copy of the CSR for the tiled pair kernel (N too large for one LDS tile): entries, (p, p ln p), segment offsets
-    ull *d_tm_ent = nullptr; double2 *d_tm_p = nullptr; uint32_t *d_tm_off = nullptr;
+    ull *d_tm_ent = nullptr; ktm_p_t *d_tm_p = nullptr; uint32_t *d_tm_off = nullptr;
     uint64_t tm_ent_cap = 0, tm_p_cap = 0, tm_off_cap = 0;
     // -complex-dist: per-sample histogram of solid counts + list of the counts above the histogram
     // 32 <= k <= 51: the samples are counted on the super-k-mer pipeline (k_skm_count_wide), their solid records sorted into the wide arena
@@ -338,7 +338,8 @@ static int set_lds_attr(simka_ctx *ctx) {
     HIPCHK(hipFuncSetAttribute((const void *)k_pairs<false, K4_BLOCK_BIG>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
     HIPCHK(hipFuncSetAttribute((const void *)k_pairs<false, K4_BLOCK_SMALL>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
     HIPCHK(hipFuncSetAttribute((const void *)k_pairs<true, K4_BLOCK_BIG>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
-    HIPCHK(hipFuncSetAttribute((const void *)k_pairs_tm, hipFuncAttributeMaxDynamicSharedMemorySize, big));
+    HIPCHK(hipFuncSetAttribute((const void *)k_pairs_tm<false>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
+    HIPCHK(hipFuncSetAttribute((const void *)k_pairs_tm<true>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
     for (int wi = 0; wi < 6; wi++) for (int v = 0; v < 4; v++) HIPCHK(hipFuncSetAttribute((const void *)skm_scan_kernel(wi, v & 2, v & 1), hipFuncAttributeMaxDynamicSharedMemorySize, big));
     HIPCHK(hipFuncSetAttribute((const void *)k_skm_count<false>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
     HIPCHK(hipFuncSetAttribute((const void *)k_skm_count<true>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
@@ -1996,8 +1997,10 @@ static void pair_launch(simka_ctx *ctx, const PairLaunch &pl, const SimkaSpan *s
         else if (tile_major) {
             const uint32_t grid_tm = (uint32_t)std::min<uint64_t>((nb_spans + KTM_WAVES - 1) / KTM_WAVES, (uint64_t)ctx->num_cus * 4);
             hipLaunchKernelGGL(k_tile_major, dim3(grid_tm), dim3(64 * KTM_WAVES), 0, ctx->stream, spans, cursors, entries, groups, pc, ctx->d_tm_ent, ctx->d_tm_p, ctx->d_tm_off);
-            hipLaunchKernelGGL(k_pairs_tm, dim3(pl.nblk, pl.ntp), dim3(K4_BLOCK_BIG), pl.lds_pairs, ctx->stream, spans, cursors, (const ull *)ctx->d_tm_ent,
-                               (const double2 *)ctx->d_tm_p, (const uint32_t *)ctx->d_tm_off, pc, acc);
+            if (pc.nacc64) hipLaunchKernelGGL(k_pairs_tm<true>, dim3(pl.nblk, pl.ntp), dim3(K4_BLOCK_BIG), pl.lds_pairs, ctx->stream, spans, cursors, (const ull *)ctx->d_tm_ent,
+                                              (const ktm_p_t *)ctx->d_tm_p, (const uint32_t *)ctx->d_tm_off, pc, acc);
+            else hipLaunchKernelGGL(k_pairs_tm<false>, dim3(pl.nblk, pl.ntp), dim3(K4_BLOCK_BIG), pl.lds_pairs, ctx->stream, spans, cursors, (const ull *)ctx->d_tm_ent,
+                                    (const ktm_p_t *)ctx->d_tm_p, (const uint32_t *)ctx->d_tm_off, pc, acc);
         } else {
             // (the tile-major buffers could not be had, or too many tiles: the scan-and-compact kernel with its own LDS layout;
             // the spans were built for pc.span_cap entries, which its tile geometry keeps)

@@ -1060,16 +1060,28 @@ k_pairs(const SimkaSpan *spans, const ull *cursors, const ull *entries, const ui
 //   k_tile_major: one wave per span, a stable counting sort of the span's entries by sample tile.  Entries keep their group
 //   order inside a tile segment, so the members a group has in one tile are contiguous; each entry carries its span-local
 //   group index (g << 48 | sample << 32 | count).  tm_off[span][t] = start of tile t's segment; complex: (p, p ln p) per entry,
-//   computed once instead of once per tile pair.
+//   computed once instead of once per tile pair (recomputing p ln p when a tile pair stages the entry saves eight prefetch registers
+//   and costs the pair kernel 8 % on c5_5: measured in round 5).
 //   k_pairs_tm: block row (I, J) stages only the two segments it owns; group runs are found from heads and tails (two 16-bit
 //   LDS stores per run, no scan over the entries, no index lists) and pairs are enumerated exactly as in k_pairs.
 // --------------------------------------------------------------------------------------------
 #define KTM_WAVES 4                 // k_tile_major: waves (= spans in flight) per block
+// What k_tile_major leaves per entry for -complex-dist: (p, p ln p) -- 16 prefetch registers per thread in k_pairs_tm<true>, which then
+// keeps 8 VGPRs in scratch (stored / reloaded once per BATCH of spans, outside the pair loop) -- or, with -DKTM_PLNP_AT_STAGING=1, p alone and
+// p ln p recomputed by every tile pair that stages the entry: no spill, but k_pairs_tm 1654 -> 1718 ms on c5_5 (round 5): not the default.
+#ifndef KTM_PLNP_AT_STAGING
+#define KTM_PLNP_AT_STAGING 0
+#endif
+#if KTM_PLNP_AT_STAGING
+typedef double ktm_p_t;
+#else
+typedef double2 ktm_p_t;
+#endif
 #define KTM_NT_MAX 256              // largest number of sample tiles the tile-major path handles
 
 __global__ void __launch_bounds__(64 * KTM_WAVES)
 k_tile_major(const SimkaSpan *spans, const ull *cursors, const ull *entries, const uint32_t *groups, SimkaPairCfg pc,
-             ull *tm_ent, double2 *tm_p, uint32_t *tm_off) {
+             ull *tm_ent, ktm_p_t *tm_p, uint32_t *tm_off) {
     __shared__ uint16_t s_gid[KTM_WAVES][SIMKA_SPAN_MAX];
     __shared__ uint32_t s_tb[KTM_WAVES][KTM_NT_MAX + 4];
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
@@ -1128,7 +1140,11 @@ k_tile_major(const SimkaSpan *spans, const ull *cursors, const ull *entries, con
                 tm_ent[span.ebase + pos] = ((ull)gid[i] << 48) | ((ull)(smp & 0xffffu) << 32) | (ull)(uint32_t)e;
                 if (cplx) {
                     const double p = (double)(uint32_t)e / (double)pc.tot_n[smp];
+#if KTM_PLNP_AT_STAGING
+                    tm_p[span.ebase + pos] = p;
+#else
                     tm_p[span.ebase + pos] = make_double2(p, simka_mul_rn(p, simka_fast_ln(p, g_simka_lntab)));      // (the logarithm of the pair loop: identical samples cancel exactly)
+#endif
                 }
             }
         }
@@ -1150,13 +1166,20 @@ struct KtmRange {
     uint32_t nbatch, cnt;
 };
 
+// CPLX: the -complex-dist accumulators (whit, klfix) and the (p, p ln p) staging are compiled in -- the simple-only instance keeps no
+// prefetch registers for them.  The span a STAGED entry belongs to (index in the range table, < KTM_RANGE = 32) rides in the five top
+// bits of the entry (the batch-wide group id below it needs 11 of its 16 bits).
+template <bool CPLX>
 __global__ void __launch_bounds__(K4_BLOCK_BIG)
-k_pairs_tm(const SimkaSpan *spans, const ull *cursors, const ull *tm_ent, const double2 *tm_p, const uint32_t *tm_off, SimkaPairCfg pc,
+k_pairs_tm(const SimkaSpan *spans, const ull *cursors, const ull *tm_ent, const ktm_p_t *tm_p, const uint32_t *tm_off, SimkaPairCfg pc,
            ull *acc) {
     constexpr int K4_BLOCK = K4_BLOCK_BIG;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const uint32_t CP = pc.ncell_pad, npk = pc.nacc32 >> 1;
-    const bool cplx = pc.nacc64 != 0;
+    // (CPLX = true: the test stays a run-time one on purpose.  With a compile-time constant the complex part of the pair loop is
+    // scheduled into the simple part and every s_waitcnt of the loop becomes lgkmcnt(0): k_pairs_tm 166 -> 174 ms on c5_50, 1652 -> 1740 ms
+    // on c5_5; sched barriers between the parts, or all LDS reads of a pair ahead of its atomics, did not bring it back -- round 5)
+    const bool cplx = CPLX && pc.nacc64 != 0;
     ull *pk = (ull *)(smem + SIMKA_LDS_HEAD);                    // [npk][CP]     packed u32 pairs
     ull *c64 = pk + (size_t)npk * CP;                            // [nacc64][CP]  (whit, klfix)
     const uint32_t EC = pc.span_cap, GC = EC / 2u;
@@ -1271,13 +1294,16 @@ k_pairs_tm(const SimkaSpan *spans, const ull *cursors, const ull *tm_ent, const 
             return b;
         }
     };
-    ull pre_e[EPT]; double2 pre_p[EPT]; uint32_t pre_j[EPT];
-    // issue the loads of batch B; pre_j = the span (index in the range table) a staged entry belongs to
+    ull pre_e[EPT]; ktm_p_t pre_p[CPLX ? EPT : 1]; uint32_t pre_j = 0;       // pre_j: five bits per prefetched entry
+    static_assert(EPT * 5 <= 32, "span indices of the prefetched entries share one register");
+    static_assert(KTM_RANGE <= 32 && SIMKA_SPAN_MAX / 2 <= (1 << 11), "span index and group id share the top 16 bits of a prefetched entry");
+    // issue the loads of batch B; pre_j = the spans (index in the range table) the staged entries belong to
 #define KTM_FETCH(B) {                                                                        \
     const KtmRange *R_ = s_rng + (B).rt;                                                      \
+    pre_j = 0u;                                                                               \
     _Pragma("unroll") for (int q = 0; q < EPT; q++) {                                         \
         const uint32_t i = tid + (uint32_t)q * K4_BLOCK;                                      \
-        pre_e[q] = 0ull; pre_p[q] = make_double2(0.0, 0.0); pre_j[q] = 0u;                    \
+        pre_e[q] = 0ull; if (CPLX) pre_p[CPLX ? q : 0] = ktm_p_t();                           \
         if (i < (B).nm) {                                                                     \
             /* the span of staged entry i: the LAST span of the batch that starts at or before i (the staging starts are         \
                non-decreasing; a span without members shares its start with its successor, never with its predecessor's members). \
@@ -1287,9 +1313,8 @@ k_pairs_tm(const SimkaSpan *spans, const ull *cursors, const ull *tm_ent, const 
             const KtmSlot sl = R_->sl[j];                                                     \
             const KtmSpan d = R_->d[j];                                                       \
             const ull src = d.ebase + (i < sl.mid ? d.a0 + (i - sl.st) : d.b0 + (i - sl.mid)); \
-            pre_e[q] = tm_ent[src];                                                           \
-            if (cplx) pre_p[q] = tm_p[src];                                                   \
-            pre_j[q] = j;                                                                     \
+            pre_e[q] = tm_ent[src]; pre_j |= j << (5 * q);    /* (not OR-ed into the entry here: that would wait for the load) */ \
+            if (CPLX) pre_p[CPLX ? q : 0] = tm_p[src];                                        \
         }                                                                                     \
     } }
     uint32_t it = 0;
@@ -1302,12 +1327,17 @@ k_pairs_tm(const SimkaSpan *spans, const ull *cursors, const ull *tm_ent, const 
         PP(0)
         const Batch cur = nxt;
         const KtmRange *CR = s_rng + cur.rt;
-        uint32_t cur_j[EPT];              // which span of the range my staged entries belong to
 #pragma unroll
         for (int q = 0; q < EPT; q++) {
             const uint32_t i = tid + (uint32_t)q * K4_BLOCK;
-            cur_j[q] = pre_j[q];
-            if (i < cur.nm) { ent[i] = pre_e[q] + ((ull)CR->sl[pre_j[q]].gbase << 48); if (cplx) epp[i] = pre_p[q]; }
+            // (the span index stays in bits 59..63 of the staged entry: batch-wide group ids are below GC <= 2048)
+            const uint32_t j_ = (pre_j >> (5 * q)) & 31u;
+            if (i < cur.nm) { ent[i] = pre_e[q] + ((ull)(CR->sl[j_].gbase | (j_ << 11)) << 48); 
+#if KTM_PLNP_AT_STAGING
+                              if (CPLX) { const double p_ = pre_p[CPLX ? q : 0]; epp[i] = make_double2(p_, simka_mul_rn(p_, simka_fast_ln(p_, lntab))); } }
+#else
+                              if (CPLX) epp[i] = pre_p[CPLX ? q : 0]; }
+#endif
             if (i < cur.ng) { runA[i] = 0u; runB[i] = 0u; }
         }
         // the batch after this one (may lay out the next range into the other table: barriers), then issue its loads
@@ -1328,13 +1358,13 @@ k_pairs_tm(const SimkaSpan *spans, const ull *cursors, const ull *tm_ent, const 
         for (int q = 0; q < EPT; q++) {
             const uint32_t i = tid + (uint32_t)q * K4_BLOCK;
             if (i < cur.nm) {
-                const KtmSlot sl = CR->sl[cur_j[q]];
-                const uint32_t g = (uint32_t)(ent[i] >> 48);
+                const uint32_t gj = (uint32_t)(ent[i] >> 48), g = gj & 0x7ffu, j = gj >> 11;       // (neighbours are compared on group AND span)
+                const KtmSlot sl = CR->sl[j];
                 const bool inA = i < sl.mid;
                 uint16_t *run = (uint16_t *)(inA ? runA : runB) + 2u * g;
-                const uint32_t lo = inA ? sl.st : sl.mid, hi = inA ? sl.mid : sl.mid + CR->d[cur_j[q]].nb;
-                if (i == lo || (uint32_t)(ent[i - 1u] >> 48) != g) run[0] = (uint16_t)i;
-                if (i + 1u == hi || (uint32_t)(ent[i + 1u] >> 48) != g) run[1] = (uint16_t)(i + 1u);
+                const uint32_t lo = inA ? sl.st : sl.mid, hi = inA ? sl.mid : sl.mid + CR->d[j].nb;
+                if (i == lo || (uint32_t)(ent[i - 1u] >> 48) != gj) run[0] = (uint16_t)i;
+                if (i + 1u == hi || (uint32_t)(ent[i + 1u] >> 48) != gj) run[1] = (uint16_t)(i + 1u);
             }
         }
         __syncthreads();

@@ -1205,22 +1205,25 @@ k_skm_count_wide_fast(const uint4 *recs, const uint32_t *pstart, const uint32_t 
         nrec_ = 0; rbase_ = 0;
         if (p < nparts) { nrec_ = pcnt[p]; rbase_ = pstart[p]; }
     };
+    // (a native vector, not HIP's uint4: the struct went through a private-memory temporary -- a dead 16-byte scratch store behind an
+    // s_waitcnt vmcnt(0), i.e. the prefetch of the next partition's records was waited for where it was issued)
+    typedef uint32_t skm_v4u __attribute__((ext_vector_type(4)));
     auto first_chunk = [&](uint32_t nrec_, uint32_t rbase_) {
-        uint4 r = make_uint4(0, 0, 0, 0);
-        if (lane < nrec_ && lane < (uint32_t)SKM_WF_CHUNK) r = recs[rbase_ + lane];
+        skm_v4u r = {0u, 0u, 0u, 0u};
+        if (lane < nrec_ && lane < (uint32_t)SKM_WF_CHUNK) r = *(const skm_v4u *)(recs + rbase_ + lane);
         return r;
     };
     uint32_t part = blockIdx.x * (SKM_WF_BLOCK / 64u) + wave;
     uint32_t nrec_v, rbase_v, nrec_nv, rbase_nv;
     meta(part, nrec_v, rbase_v);
     uint32_t nrec = (uint32_t)__builtin_amdgcn_readfirstlane((int)nrec_v), rbase = (uint32_t)__builtin_amdgcn_readfirstlane((int)rbase_v);
-    uint4 rc0 = first_chunk(nrec, rbase);
+    skm_v4u rc0 = first_chunk(nrec, rbase);
     meta(part + nwaves, nrec_nv, rbase_nv);
     constexpr int NF = 2;                              // k-mers a lane has in flight in the probe loop
     for (; part < nparts; part += nwaves) {
         // what the next two partitions need is under way while this one is counted
         const uint32_t nrec_n = (uint32_t)__builtin_amdgcn_readfirstlane((int)nrec_nv), rbase_n = (uint32_t)__builtin_amdgcn_readfirstlane((int)rbase_nv);
-        const uint4 rc0_n = first_chunk(nrec_n, rbase_n);
+        const skm_v4u rc0_n = first_chunk(nrec_n, rbase_n);
         meta(part + 2u * nwaves, nrec_nv, rbase_nv);
         PH(0)
         bool fail = nrec > 512u;          // a partition of many records (a few hot k-mers: one wave would walk them alone; and a count must stay below 2^26): the block kernel's
@@ -1229,7 +1232,7 @@ k_skm_count_wide_fast(const uint4 *recs, const uint32_t *pstart, const uint32_t 
         for (uint32_t b0 = 0; b0 < nrec && !fail; b0 += SKM_WF_CHUNK) {
             const uint32_t nb = nrec - b0 < (uint32_t)SKM_WF_CHUNK ? nrec - b0 : (uint32_t)SKM_WF_CHUNK;
             uint32_t len = 0;
-            if (lane < nb) { const uint4 rc = b0 ? recs[rbase + b0 + lane] : rc0; lrec[lane] = rc; len = skm_rec_n(rc); }
+            if (lane < nb) { const uint4 rc = b0 ? recs[rbase + b0 + lane] : make_uint4(rc0.x, rc0.y, rc0.z, rc0.w); lrec[lane] = rc; len = skm_rec_n(rc); }
             const uint32_t x = wave_incl_scan(len);
             const uint32_t kt = (uint32_t)__builtin_amdgcn_readlane((int)x, 63);
             const uint32_t off = x - len;
