@@ -2148,7 +2148,7 @@ SIMKA_EXPORT int simka_merge(simka_ctx *ctx) {
     SimkaKeyCfg key = ctx->key;
     uint32_t t = ctx->cfg.log2_subranges;
     // (more than K3_BLOCK samples: k_group<512> -- twice the records per round, every sample in one tile)
-    const bool group_big = N > (uint32_t)K3_BLOCK;
+    const bool group_big = N > (uint32_t)K3_BLOCK || (simka_exp_knob("SIMKA_GROUP_BIG") && atoi(simka_exp_knob("SIMKA_GROUP_BIG")) > 0);
     const uint32_t g_mul = group_big ? 2u : 1u;
     if (t == 0) t = ceil_log2_u64((total / std::max<ull>(nonempty, 1) + K3_TARGET * g_mul - 1) / (K3_TARGET * g_mul));
     t = std::min<uint32_t>(t, SIMKA_SEG_BITS);            // (the segments are ordered by that many key bits; k_group splits larger sub-ranges on further bits)
@@ -2167,7 +2167,7 @@ SIMKA_EXPORT int simka_merge(simka_ctx *ctx) {
     if (maxpart > cap) return ctx->fail(SIMKA_ERR_NOMEM, "simka_merge: one partition holds %llu records, more than the merge buffer", maxpart);
     const uint64_t max_parts_batch = std::min<uint64_t>(nparts, std::min<uint64_t>((uint64_t)1 << 16, std::max<uint64_t>(1, ((uint64_t)1 << (rows32 ? 22 : 26)) / N)));
     const uint64_t fb_cap = max_parts_batch * nsub;
-    const uint32_t grid_group = (uint32_t)ctx->num_cus * (group_big ? 2 : 4);
+    const uint32_t grid_group = (uint32_t)ctx->num_cus * (simka_exp_knob("SIMKA_GROUP_BPC") ? (uint32_t)atoi(simka_exp_knob("SIMKA_GROUP_BPC")) : (group_big ? 2 : 4));
     // spans: one per work item and open-span break, plus the rounds of the sub-ranges that k_group has to split further (a round holds
     // K3_PRESPLIT / 2 .. K3_PRESPLIT records unless the key bits are skewed; beyond the capacity the merge fails cleanly)
     const uint64_t span_cap = fb_cap * 2 + 4096 + (uint64_t)grid_group * K3_SLAB_SPAN + cap / (K3_PRESPLIT / 4);

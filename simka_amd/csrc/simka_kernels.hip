@@ -224,10 +224,20 @@ __device__ ull g_group_phase[8];
 #endif
 // ROW32: the rows of the batch are 32-bit (k_segment_rows<true>: a segment beyond 65535 records somewhere): read from memory where they are
 // needed instead of living in registers -- the rare, slower form.
+// the kernel arguments as the kernel-argument segment holds them
+struct KGroupArgs { SimkaMergeIn in; const ull *seg_abs; const uint16_t *rows; uint32_t np; SimkaKeyCfg cfg; uint32_t min_share; SimkaCsrOut o; uint32_t pstride; };
 template <int GB, bool ROW32>
 __global__ void __launch_bounds__(GB)
 k_group(SimkaMergeIn in, const ull *seg_abs, const uint16_t *rows, uint32_t np,
-        SimkaKeyCfg cfg, uint32_t min_share, SimkaCsrOut o, uint32_t pstride) {
+        SimkaKeyCfg cfg, uint32_t min_share, SimkaCsrOut o_unused, uint32_t pstride) {
+    // The output descriptor (15 pointers and capacities) and the mix constants are used once per round or less.  As ordinary arguments
+    // they sit in scalar registers for the whole kernel, the compiler runs out of those (106) and parks values in vector lanes:
+    // ~200 v_readlane per wave and round in a kernel that is bound by instruction issue.  They are read from the kernel-argument
+    // segment where they are used instead (scalar loads through the constant cache); KG_FRESH keeps the loads inside the round.
+    typedef const __attribute__((address_space(4))) KGroupArgs *KGroupArgsP;
+    KGroupArgsP ka = (KGroupArgsP)__builtin_amdgcn_kernarg_segment_ptr();
+#define KG_FRESH() asm volatile("" : "+s"(ka))
+    (void)o_unused;
     // pstride: work item pi of the batch is partition pi * pstride of the index arrays (1: consecutive partitions; G: the partitions
     // p = g + G i a partition shard owns -- the others are empty, and walking them cost as much as grouping the owned ones)
     constexpr int GCAP = GB * K3_UNROLL, GTAB = 2 * GCAP;
@@ -357,6 +367,7 @@ k_group(SimkaMergeIn in, const ull *seg_abs, const uint16_t *rows, uint32_t np,
         }
       for (cur_j = quarter * jq; cur_j < (quarter + 1u) * jq; cur_j++) {
         const uint32_t this_j = cur_j;
+        KG_FRESH();
         // records of the sub-range over all samples
         uint32_t R = 0;
         if (N <= (uint32_t)GB) {      // one tile of samples: its scan is the gather's scan too
@@ -406,7 +417,7 @@ k_group(SimkaMergeIn in, const ull *seg_abs, const uint16_t *rows, uint32_t np,
                 const uint32_t selshift = free_bits - e;
                 uint32_t mymax = 0;
                 for_records([&](ull key, ull val) {
-                    if (e && ((simka_mix(key, cfg.mask, cfg.xs) >> selshift) & ((1ull << e) - 1ull)) != val_) return;
+                    if (e && ((simka_mix(key, ka->cfg.mask, ka->cfg.xs) >> selshift) & ((1ull << e) - 1ull)) != val_) return;
                     const uint32_t idx = atomicAdd(&s_nrec, 1u);
                     if (idx >= GCAP) { s_ovf = 1; return; }
                     uint32_t slot = simka_slot_hash(key) & (GTAB - 1u);
@@ -432,11 +443,11 @@ k_group(SimkaMergeIn in, const ull *seg_abs, const uint16_t *rows, uint32_t np,
                         const uint32_t s_ = s_nrec;
                         __syncthreads();
                         if (tid == 0) {
-                            const ull eb_ = atomicAdd(&o.cursors[0], (ull)s_), hs = atomicAdd(&o.cursors[3], 1ull);
-                            if (eb_ + s_ > o.cap_entries || hs >= o.cap_huge) { atomicOr(o.err, SIMKA_DEVERR_CSR_FULL); s_ovf = 2; }
+                            const ull eb_ = atomicAdd(&ka->o.cursors[0], (ull)s_), hs = atomicAdd(&ka->o.cursors[3], 1ull);
+                            if (eb_ + s_ > ka->o.cap_entries || hs >= ka->o.cap_huge) { atomicOr(ka->o.err, SIMKA_DEVERR_CSR_FULL); s_ovf = 2; }
                             else {
                                 SimkaSpan sp; sp.ebase = eb_; sp.gbase = 0; sp.nent = s_; sp.ngrp = 1; sp.maxc = 0; sp.pad = 0;
-                                o.huge[hs] = sp;
+                                ka->o.huge[hs] = sp;
                                 s_ebase = eb_; s_ndist++; s_nshared++;
                             }
                             s_nrec = 0;      // now the fill cursor
@@ -445,14 +456,14 @@ k_group(SimkaMergeIn in, const ull *seg_abs, const uint16_t *rows, uint32_t np,
                         if (s_ovf != 2) {
                             const ull eb_ = s_ebase;
                             for_records([&](ull key, ull val) {
-                                if (e && ((simka_mix(key, cfg.mask, cfg.xs) >> selshift) & ((1ull << e) - 1ull)) != val_) return;
-                                o.entries[eb_ + atomicAdd(&s_nrec, 1u)] = val;
+                                if (e && ((simka_mix(key, ka->cfg.mask, ka->cfg.xs) >> selshift) & ((1ull << e) - 1ull)) != val_) return;
+                                ka->o.entries[eb_ + atomicAdd(&s_nrec, 1u)] = val;
                             });
                         }
                         continue;
                     }
                     if (tid == 0) {   // refine: two children with one more selector bit
-                        if (s_sp + 2 > K3_STACK) { atomicOr(o.err, SIMKA_DEVERR_GROUP_OVERFLOW); s_sp = 0; }
+                        if (s_sp + 2 > K3_STACK) { atomicOr(ka->o.err, SIMKA_DEVERR_GROUP_OVERFLOW); s_sp = 0; }
                         else {
                             s_stack[2 * s_sp] = e + 1; s_stack[2 * s_sp + 1] = val_ * 2ull + 1ull; s_sp++;
                             s_stack[2 * s_sp] = e + 1; s_stack[2 * s_sp + 1] = val_ * 2ull; s_sp++;
@@ -502,21 +513,21 @@ k_group(SimkaMergeIn in, const ull *seg_abs, const uint16_t *rows, uint32_t np,
                 if (ngrp == 0) continue;
                 if (tid == 0) {
                     // slab reservations: one global atomic per K3_SLAB_* items.  A round whose output lands right behind the
-                    // block's open span (same slabs) EXTENDS that span up to o.span_cap entries: k_pairs pays its per-span
+                    // block's open span (same slabs) EXTENDS that span up to ka->o.span_cap entries: k_pairs pays its per-span
                     // overhead (scans, barriers, pair-range search) once per span, so longer spans are cheaper.
                     uint32_t ok = 1, fresh = 0;
-                    if (s_slab[0] + nent > s_slab[1]) { s_slab[0] = atomicAdd(&o.cursors[0], (ull)K3_SLAB_ENT); s_slab[1] = s_slab[0] + K3_SLAB_ENT; fresh = 1; if (s_slab[1] > o.cap_entries) ok = 0; }
-                    if (s_slab[2] + ngrp > s_slab[3]) { s_slab[2] = atomicAdd(&o.cursors[1], (ull)K3_SLAB_GRP); s_slab[3] = s_slab[2] + K3_SLAB_GRP; fresh = 1; if (s_slab[3] > o.cap_groups) ok = 0; }
-                    const bool extend = !fresh && s_open != ~0ull && s_open_nent + nent <= o.span_cap && s_open_ngrp + ngrp <= o.span_cap / 2u;
-                    if (!extend && s_slab[4] + 1 > s_slab[5]) { s_slab[4] = atomicAdd(&o.cursors[2], (ull)K3_SLAB_SPAN); s_slab[5] = s_slab[4] + K3_SLAB_SPAN; if (s_slab[5] > o.cap_spans) ok = 0; }
-                    if (!ok) { atomicOr(o.err, SIMKA_DEVERR_CSR_FULL); s_ovf = 2; }
+                    if (s_slab[0] + nent > s_slab[1]) { s_slab[0] = atomicAdd(&ka->o.cursors[0], (ull)K3_SLAB_ENT); s_slab[1] = s_slab[0] + K3_SLAB_ENT; fresh = 1; if (s_slab[1] > ka->o.cap_entries) ok = 0; }
+                    if (s_slab[2] + ngrp > s_slab[3]) { s_slab[2] = atomicAdd(&ka->o.cursors[1], (ull)K3_SLAB_GRP); s_slab[3] = s_slab[2] + K3_SLAB_GRP; fresh = 1; if (s_slab[3] > ka->o.cap_groups) ok = 0; }
+                    const bool extend = !fresh && s_open != ~0ull && s_open_nent + nent <= ka->o.span_cap && s_open_ngrp + ngrp <= ka->o.span_cap / 2u;
+                    if (!extend && s_slab[4] + 1 > s_slab[5]) { s_slab[4] = atomicAdd(&ka->o.cursors[2], (ull)K3_SLAB_SPAN); s_slab[5] = s_slab[4] + K3_SLAB_SPAN; if (s_slab[5] > ka->o.cap_spans) ok = 0; }
+                    if (!ok) { atomicOr(ka->o.err, SIMKA_DEVERR_CSR_FULL); s_ovf = 2; }
                     else {
                         if (!extend) { s_open = s_slab[4]; s_slab[4] += 1; s_open_nent = 0; s_open_ngrp = 0; s_open_maxc = 0; }
                         s_soff = s_open_nent;
                         s_ebase = s_slab[0]; s_gbase = s_slab[2];
                         s_open_nent += nent; s_open_ngrp += ngrp; s_open_maxc = s_maxc > s_open_maxc ? s_maxc : s_open_maxc;
                         SimkaSpan sp; sp.ebase = s_slab[0] - s_soff; sp.gbase = s_slab[2] - (s_open_ngrp - ngrp); sp.nent = s_open_nent; sp.ngrp = s_open_ngrp; sp.maxc = s_open_maxc; sp.pad = 0;
-                        o.spans[s_open] = sp;
+                        ka->o.spans[s_open] = sp;
                         s_slab[0] += nent; s_slab[2] += ngrp;
                     }
                 }
@@ -533,7 +544,7 @@ k_group(SimkaMergeIn in, const ull *seg_abs, const uint16_t *rows, uint32_t np,
 #pragma unroll
                     for (int q = 0; q < 8; q++) {
                         const uint32_t c = (cw[q >> 1] >> ((q & 1) * 16)) & 0xffffu, g_ = gv[q];
-                        if (c >= min_share) o.groups[gb + (g_ >> 20)] = (((g_ & 0xfffffu) + soff) << 16) | c;    // start is relative to the span
+                        if (c >= min_share) ka->o.groups[gb + (g_ >> 20)] = (((g_ & 0xfffffu) + soff) << 16) | c;    // start is relative to the span
                         gv[q] = g_ & 0xfffffu;
                     }
                     ((uint4 *)gpk)[2 * tid] = make_uint4(gv[0], gv[1], gv[2], gv[3]);
@@ -542,7 +553,7 @@ k_group(SimkaMergeIn in, const ull *seg_abs, const uint16_t *rows, uint32_t np,
                 __syncthreads();
                 for (uint32_t i = tid; i < nrec; i += GB) {
                     const uint32_t slot = rslot[i];
-                    if (scnt[slot] >= min_share) o.entries[eb + atomicAdd(&gpk[slot], 1u)] = rval[i];
+                    if (scnt[slot] >= min_share) ka->o.entries[eb + atomicAdd(&gpk[slot], 1u)] = rval[i];
                 }
                 PG(6)
             }
@@ -552,11 +563,12 @@ k_group(SimkaMergeIn in, const ull *seg_abs, const uint16_t *rows, uint32_t np,
     PG_FLUSH
     __syncthreads();
     if (tid == 0) {
-        if (s_ndist) atomicAdd(&o.glob[0], (ull)s_ndist);      // _nbDistinctKmers  (:1315)
-        if (s_nshared) atomicAdd(&o.glob[1], (ull)s_nshared);  // _nbSharedKmers    (:1319-1321)
+        if (s_ndist) atomicAdd(&ka->o.glob[0], (ull)s_ndist);      // _nbDistinctKmers  (:1315)
+        if (s_nshared) atomicAdd(&ka->o.glob[1], (ull)s_nshared);  // _nbSharedKmers    (:1319-1321)
     }
+#undef KG_FRESH
     // unused span slots of this block's last slab: mark empty
-    for (ull i = s_slab[4] + tid; i < s_slab[5]; i += GB) { SimkaSpan sp; sp.ebase = 0; sp.gbase = 0; sp.nent = 0; sp.ngrp = 0; sp.maxc = 0; sp.pad = 0; o.spans[i] = sp; }
+    for (ull i = s_slab[4] + tid; i < s_slab[5]; i += GB) { SimkaSpan sp; sp.ebase = 0; sp.gbase = 0; sp.nent = 0; sp.ngrp = 0; sp.maxc = 0; sp.pad = 0; ka->o.spans[i] = sp; }
 }
 
 // --------------------------------------------------------------------------------------------
@@ -826,8 +838,14 @@ k_pairs(const SimkaSpan *spans, const ull *cursors, const ull *entries, const ui
     // (registers), so the global-load latency of span i+1 hides behind the pair loop of span i.
     // A span has <= SIMKA_SPAN_MAX entries: up to 4 per thread for 1024-thread blocks, 16 for 256-thread ones.
     constexpr int EPT = (SIMKA_SPAN_MAX + K4_BLOCK - 1) / K4_BLOCK;     // entries (and group descriptors) per thread
-    SimkaSpan span, nspan;
-    span.ngrp = 0; span.nent = 0; nspan.ngrp = 0; nspan.nent = 0;
+    SimkaSpan span;
+    span.ngrp = 0; span.nent = 0;
+    // The descriptor of the span AFTER the next is loaded two iterations ahead -- and has to stay in VECTOR registers until it is needed: a
+    // value the compiler knows to be wave-uniform is moved to scalar registers (v_readfirstlane) right behind its load, i.e. every block
+    // sat out one trip to memory per span in the staging phase.  The address gets a lane-dependent zero the compiler cannot see through; the
+    // fields become scalars an iteration later (to_uniform).
+    uint32_t lane_zero; asm volatile("v_mov_b32 %0, 0" : "=v"(lane_zero));
+    struct SpanV { uint32_t eb_lo, eb_hi, gb_lo, gb_hi, nent, ngrp, maxc; } nspan_v;
     // Which span slots a block takes.  work != NULL (one tile: grid.y == 1): DYNAMIC -- chunks of KP_WCHUNK consecutive slots, chunk
     // blockIdx.x first, then whatever the global counter says (thread 0 grabs the chunk after next at the first slot of a chunk and
     // publishes it in LDS at the next loop-top barrier), so a block that drew expensive spans does not hold the launch back.
@@ -854,10 +872,24 @@ k_pairs(const SimkaSpan *spans, const ull *cursors, const ull *entries, const ui
         else { if (row + d >= nrows) return ~0ull; s_ = (row + d) * gridDim.x + (blockIdx.x + (row + d) * 13ull) % gridDim.x; }
         return s_ < nspans ? s_ : ~0ull;
     };
+    auto load_span_v = [&](ull s_, SpanV &out) {
+        out.eb_lo = 0; out.eb_hi = 0; out.gb_lo = 0; out.gb_hi = 0; out.nent = 0; out.ngrp = 0; out.maxc = 0;
+        if (s_ != ~0ull) {
+            const uint4 *q_ = (const uint4 *)(spans + s_) + lane_zero;
+            const uint4 a_ = q_[0], b_ = q_[1];
+            out.eb_lo = a_.x; out.eb_hi = a_.y; out.gb_lo = a_.z; out.gb_hi = a_.w; out.nent = b_.x; out.ngrp = b_.y; out.maxc = b_.z;
+        }
+    };
+    auto to_uniform = [&](const SpanV &v, SimkaSpan &out) {
+        out.ebase = ((ull)(uint32_t)__builtin_amdgcn_readfirstlane((int)v.eb_hi) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)v.eb_lo);
+        out.gbase = ((ull)(uint32_t)__builtin_amdgcn_readfirstlane((int)v.gb_hi) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)v.gb_lo);
+        out.nent = (uint32_t)__builtin_amdgcn_readfirstlane((int)v.nent); out.ngrp = (uint32_t)__builtin_amdgcn_readfirstlane((int)v.ngrp);
+        out.maxc = (uint32_t)__builtin_amdgcn_readfirstlane((int)v.maxc); out.pad = 0;
+    };
     auto load_span = [&](uint32_t d, SimkaSpan &out) { out.ngrp = 0; out.nent = 0; const ull s_ = slot_ahead(d); if (s_ != ~0ull) out = spans[s_]; };
     auto more = [&]() -> bool { return dyn ? chunk * KP_WCHUNK < nspans : row < nrows; };
     load_span(0, span);
-    load_span(1, nspan);
+    load_span_v(slot_ahead(1), nspan_v);
     ull pre_e[EPT]; uint32_t pre_g[EPT];
 #pragma unroll
     for (int q = 0; q < EPT; q++) {
@@ -899,8 +931,8 @@ k_pairs(const SimkaSpan *spans, const ull *cursors, const ull *entries, const ui
             if (i < cur.ngrp) { gdesc[i] = pre_g[q]; if (!TILED) { const uint32_t s_ = pre_g[q] & 0xffffu; gpref[i] = s_ * (s_ - 1u) / 2u; } }
         }
         // ---- issue the loads of the next span, fetch the descriptor after it
-        span = nspan;
-        load_span(2, nspan);
+        to_uniform(nspan_v, span);
+        const ull slot2 = slot_ahead(2);
         // (the position moves on here: every `continue` below goes straight to the next span)
         if (dyn) { if (++kpos == KP_WCHUNK) { chunk = chunk_n; chunk_n = chunk_n2; kpos = 0; } } else row++;
 #pragma unroll
@@ -909,6 +941,7 @@ k_pairs(const SimkaSpan *spans, const ull *cursors, const ull *entries, const ui
             pre_e[q] = (i < span.nent) ? entries[span.ebase + i] : 0ull;
             pre_g[q] = (i < span.ngrp) ? groups[span.gbase + i] : 0u;
         }
+        load_span_v(slot2, nspan_v);      // (behind the entry loads: the compiler waits for every older load before it overwrites the prefetch registers)
         PP(1)
         if (cur.ngrp == 0) continue;     // unused slot of a k_group span slab (uniform)
         const ull add = (ull)cur.ngrp * (ull)cur.maxc;
