@@ -2167,7 +2167,7 @@ SIMKA_EXPORT int simka_merge(simka_ctx *ctx) {
     if (maxpart > cap) return ctx->fail(SIMKA_ERR_NOMEM, "simka_merge: one partition holds %llu records, more than the merge buffer", maxpart);
     const uint64_t max_parts_batch = std::min<uint64_t>(nparts, std::min<uint64_t>((uint64_t)1 << 16, std::max<uint64_t>(1, ((uint64_t)1 << (rows32 ? 22 : 26)) / N)));
     const uint64_t fb_cap = max_parts_batch * nsub;
-    const uint32_t grid_group = (uint32_t)ctx->num_cus * (simka_exp_knob("SIMKA_GROUP_BPC") ? (uint32_t)atoi(simka_exp_knob("SIMKA_GROUP_BPC")) : (group_big ? 2 : 4));
+    const uint32_t grid_group = (uint32_t)ctx->num_cus * (simka_exp_knob("SIMKA_GROUP_BPC") ? (uint32_t)atoi(simka_exp_knob("SIMKA_GROUP_BPC")) : (group_big ? 2 : 5));
     // spans: one per work item and open-span break, plus the rounds of the sub-ranges that k_group has to split further (a round holds
     // K3_PRESPLIT / 2 .. K3_PRESPLIT records unless the key bits are skewed; beyond the capacity the merge fails cleanly)
     const uint64_t span_cap = fb_cap * 2 + 4096 + (uint64_t)grid_group * K3_SLAB_SPAN + cap / (K3_PRESPLIT / 4);
@@ -2208,7 +2208,7 @@ SIMKA_EXPORT int simka_merge(simka_ctx *ctx) {
     co.entries = ctx->d_entries; co.groups = ctx->d_groups; co.spans = ctx->d_spans; co.cursors = ctx->d_cursors;
     co.cap_entries = csr_cap; co.cap_groups = csr_cap; co.cap_spans = span_cap; co.span_cap = pc.span_cap; co.huge = ctx->d_huge; co.cap_huge = huge_cap; co.glob = (ull *)ctx->d_stats; co.err = ctx->d_err;
     const uint32_t min_share = 2;   // -complex-dist would need 1 (ref: src/SimkaMerge.cpp:1317)
-    const size_t lds_group = SIMKA_LDS_HEAD + ((size_t)K3_TABLE * 8 + (size_t)K3_CAP * 8 + (size_t)K3_TABLE * 6 + (size_t)K3_CAP * 2) * g_mul + (size_t)K3_STACK * 16;
+    const size_t lds_group = K3_LDS_BYTES(K3_BLOCK * g_mul);        // 31 688 bytes (five blocks per CU: the LDS granule is 1280 bytes) / 64 456
     ull *acc = (ull *)ctx->d_stats + stats_off_acc(N, 0);
 
     // A partition shard owns the partitions p = g + G i; the others are empty.  With the index of every partition in place the merge

@@ -21,6 +21,9 @@
 #define K3_TARGET 940         // mean records per sub-range the merge aims for (sub-range bits t; x2 with 512 threads)
 #define K3_PRESPLIT 1024      // a sub-range above this is split on one more key bit before hashing (x2 with 512 threads)
 #define K3_STACK 72           // refinement stack of k_group: deeper than the 62 key bits
+#define K3_HEAD 384           // bytes of block scalars in front of k_group's tables
+// dynamic LDS of k_group<GB>: table keys / packed prefix, record counts, group sizes, record samples, record slots, the sample tile, the stack
+#define K3_LDS_BYTES(GB_) ((size_t)K3_HEAD + (size_t)(GB_) * K3_UNROLL * 2 * 8 + (size_t)(GB_) * K3_UNROLL * 4 + (size_t)(GB_) * K3_UNROLL * 2 * 2 + (size_t)(GB_) * K3_UNROLL * 2 + (size_t)(GB_) * K3_UNROLL * ((GB_) == K3_BLOCK ? 1 : 2) + (size_t)(GB_) * 8 + ((size_t)(GB_) + 2) * 4 + (size_t)K3_STACK * 8)
 #define K3_TABLE 2048         // = 2*K3_CAP slots
 #define K3_UNROLL 4           // K3_BLOCK*K3_UNROLL = K3_CAP: a whole sub-range in one batch of independent loads
 #define K3_SLAB_ENT 32768     // CSR entries / groups / span slots reserved per global atomic by a k_group block

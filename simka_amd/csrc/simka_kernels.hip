@@ -257,17 +257,22 @@ k_group(SimkaMergeIn in, const ull *seg_abs, const uint16_t *rows, uint32_t np,
     uint32_t &s_open_ngrp = *(uint32_t *)(smem + 348);
     uint32_t &s_open_maxc = *(uint32_t *)(smem + 352);
     uint32_t &s_soff = *(uint32_t *)(smem + 356);          // entry offset of this round inside its span
-    ull *tkeys = (ull *)(smem + SIMKA_LDS_HEAD);           // [GTAB]
-    ull *rval = tkeys + GTAB;                          // [GCAP]
-    uint16_t *scnt = (uint16_t *)(rval + GCAP);          // [GTAB] group size (<= GCAP records per round: 16 bits, added through the 32-bit word)
-    uint32_t *gpk = (uint32_t *)(scnt + GTAB);                       // [GTAB] packed prefix: entries | groups << 20; later the fill cursor
-    uint16_t *rslot = (uint16_t *)(gpk + GTAB);        // [GCAP]
-    ull *s_stack = (ull *)(rslot + GCAP);                // [2*K3_STACK] (selector bits, value) of the refinement DFS: one level per key bit
-    // a tile of samples while the records are gathered (gpk is written after that): first record of the sample's slice in the arena, the
-    // slices' exclusive prefix
-    ull *sbeg = (ull *)gpk;                                // [GB]
-    uint32_t *spre = (uint32_t *)(sbeg + GB);        // [GB + 1]
-    static_assert(GB * 12 + 4 <= GTAB * 4, "the sample tile fits the prefix array it overlays");
+    // 31 688 bytes with GB = 256 (K3_LDS_BYTES): FIVE blocks per CU -- a round is a chain of dependent steps, the blocks of a CU are what
+    // overlaps it (1 / 2 / 3 / 4 blocks: 31.4 / 17.1 / 12.4 / 10.1 ms on c3_10).  The dispatcher hands out LDS in granules of 1280 bytes
+    // (scripts/ubench/lds_occupancy.hip: five blocks are co-resident up to 32 000 bytes each, not the 32 768 the occupancy API computes).
+    // What made room: the packed prefix lives where the table keys were (dead once the records are hashed), a record's value is 4 + 1
+    // bytes (GB = 256 serves at most 256 samples; 4 + 2 beyond), a stack entry 8 bytes.
+    typedef typename std::conditional<GB == K3_BLOCK, uint8_t, uint16_t>::type smp_t;
+    ull *tkeys = (ull *)(smem + K3_HEAD);                  // [GTAB] the keys of the round's hash table ...
+    uint32_t *gpk = (uint32_t *)tkeys;                     // [GTAB] ... then the packed prefix: entries | groups << 20; later the fill cursor
+    uint32_t *rcnt = (uint32_t *)(tkeys + GTAB);           // [GCAP] count of the record ...
+    uint16_t *scnt = (uint16_t *)(rcnt + GCAP);            // [GTAB] group size (<= GCAP records per round: 16 bits, added through the 32-bit word)
+    uint16_t *rslot = scnt + GTAB;                         // [GCAP]
+    smp_t *rsmp = (smp_t *)(rslot + GCAP);                 // [GCAP] ... and its sample (GB = 256: N <= 256; else nb_samples <= 65535)
+    // a tile of samples while the records are gathered: first record of the sample's slice in the arena, the slices' exclusive prefix
+    ull *sbeg = (ull *)(rsmp + GCAP);                      // [GB]
+    uint32_t *spre = (uint32_t *)(sbeg + GB);              // [GB + 2]
+    ull *s_stack = (ull *)(spre + GB + 2);                 // [K3_STACK] refinement DFS, one level per key bit: (1 << selector bits) | value
 
     const uint32_t tid = threadIdx.x;
     const uint32_t free_bits = cfg.W;                      // an over-full sub-range is split on the bits of simka_mix(key), a bijection on W bits: every bit fixed = one k-mer
@@ -396,12 +401,13 @@ k_group(SimkaMergeIn in, const ull *seg_abs, const uint16_t *rows, uint32_t np,
         const uint32_t nvals0 = 1u << e0;
         for (uint32_t v0 = 0; v0 < nvals0; v0++) {
             __syncthreads();
-            if (tid == 0) { s_sp = 1; s_stack[0] = e0; s_stack[1] = v0; }
+            if (tid == 0) { s_sp = 1; s_stack[0] = (1ull << e0) | (ull)v0; }
             while (true) {
                 __syncthreads();
                 if (s_sp == 0) break;
-                const uint32_t e = (uint32_t)s_stack[2 * (s_sp - 1)];
-                const ull val_ = s_stack[2 * (s_sp - 1) + 1];         // up to free_bits (> 32) selector bits
+                const ull top_ = s_stack[s_sp - 1];
+                const uint32_t e = 63u - (uint32_t)__clzll((long long)top_);
+                const ull val_ = top_ ^ (1ull << e);                  // up to free_bits (<= 62) selector bits
                 __syncthreads();
                 if (tid == 0) { s_sp--; s_nrec = 0; s_ovf = 0; s_maxc = 0; }
                 {
@@ -428,7 +434,7 @@ k_group(SimkaMergeIn in, const ull *seg_abs, const uint16_t *rows, uint32_t np,
                     }
                     atomicAdd((uint32_t *)scnt + (slot >> 1), 1u << ((slot & 1u) * 16u));
                     rslot[idx] = (uint16_t)slot;
-                    rval[idx] = val;
+                    rcnt[idx] = (uint32_t)val; rsmp[idx] = (smp_t)(val >> 32);
                     if ((uint32_t)val > mymax) mymax = (uint32_t)val;
                 });
 #pragma unroll
@@ -465,8 +471,8 @@ k_group(SimkaMergeIn in, const ull *seg_abs, const uint16_t *rows, uint32_t np,
                     if (tid == 0) {   // refine: two children with one more selector bit
                         if (s_sp + 2 > K3_STACK) { atomicOr(ka->o.err, SIMKA_DEVERR_GROUP_OVERFLOW); s_sp = 0; }
                         else {
-                            s_stack[2 * s_sp] = e + 1; s_stack[2 * s_sp + 1] = val_ * 2ull + 1ull; s_sp++;
-                            s_stack[2 * s_sp] = e + 1; s_stack[2 * s_sp + 1] = val_ * 2ull; s_sp++;
+                            s_stack[s_sp] = (2ull << e) | (val_ * 2ull + 1ull); s_sp++;
+                            s_stack[s_sp] = (2ull << e) | (val_ * 2ull); s_sp++;
                         }
                     }
                     continue;
@@ -553,7 +559,7 @@ k_group(SimkaMergeIn in, const ull *seg_abs, const uint16_t *rows, uint32_t np,
                 __syncthreads();
                 for (uint32_t i = tid; i < nrec; i += GB) {
                     const uint32_t slot = rslot[i];
-                    if (scnt[slot] >= min_share) ka->o.entries[eb + atomicAdd(&gpk[slot], 1u)] = rval[i];
+                    if (scnt[slot] >= min_share) ka->o.entries[eb + atomicAdd(&gpk[slot], 1u)] = ((ull)rsmp[i] << 32) | (ull)rcnt[i];
                 }
                 PG(6)
             }
