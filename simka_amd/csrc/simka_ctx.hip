@@ -752,7 +752,12 @@ static int skm_scan_split(simka_ctx *ctx, simka_ctx::Lane &L, uint32_t sample, c
     const uint32_t rbytes = (uint32_t)std::max<size_t>((size_t)16 * SKM_NT * 4, (size_t)caprec * 22 + 16);
     auto scan_lcap = [&](bool hist) { return (uint32_t)((rbytes - (hist ? 0 : (size_t)caprec * 16) - 16) / 6); };
     auto scan_lds = [&](bool) {
-        return (size_t)SIMKA_LDS_HEAD + rbytes + (SKM_TILE / 16 + 8) * 4 + (SKM_BLOCK + 4) * 4 + SKM_MAXB1 * 4 * 2 + SKM_MAXB1 * 8 + (fixed ? 0 : SKM_RTAB * 4);
+        // 40 304 bytes at W = 16, fixed-length reads: 32 LDS granules of 1280 bytes, FOUR blocks per CU -- which pays for a launch of a
+        // few waves of tiles (c5_50, 1845 tiles: 21.1 -> 18.8 ms per 500 samples) and costs a long one 5 % (C3, 184 000 tiles: 28.5 ->
+        // 30.0 ms per 12 samples): a long launch asks for a 33rd granule and runs three blocks per CU
+        size_t b = (size_t)SKM_SCAN_HEAD + rbytes + (SKM_TILE / 16 + 8) * 4 + (SKM_BLOCK + 4) * 4 + SKM_MAXB1 * 4 * 2 + SKM_MAXB1 * 4 + (fixed ? 0 : SKM_RTAB * 4);
+        if (ntiles > (uint32_t)ctx->num_cus * 32u && b <= 32 * 1280) b = 32 * 1280 + 16;
+        return b;
     };
     static const bool no_gather = simka_test_knob("SIMKA_SKM_SPLIT") != nullptr;      // tests: the exact split instead of chunk sort + gather
     bool use_gather = *gather && !no_gather && L.d_cbase;
@@ -914,7 +919,7 @@ static int run_count_kernels(simka_ctx *ctx, uint32_t sample, const SimkaScanArg
     }
 #endif
     const size_t hist_lds = ctx->d_hist ? (size_t)SIMKA_HIST_MAX * 4 : 0;
-    const size_t lds_fast = (size_t)SIMKA_LDS_HEAD + (size_t)SKM_FAST_TS * 12 + (size_t)SKM_FAST_BLOCK * 16 + hist_lds + (size_t)(SKM_FAST_BLOCK / 64) * SKM_FAST_WREG +
+    const size_t lds_fast = (size_t)SKM_FAST_HEAD + (size_t)SKM_FAST_TS * 12 + (size_t)SKM_FAST_BLOCK * 16 + (ctx->d_hist ? (size_t)SKM_FAST_HBINS * 4 : 0) + (size_t)(SKM_FAST_BLOCK / 64) * SKM_FAST_WREG +
                             (gather ? (size_t)SKM_G_BYTES(SKM_FAST_BLOCK / 64) : 64);
     const size_t lds_count = (size_t)SIMKA_LDS_HEAD + (size_t)SKM_CNT_TS * 12 + (size_t)SKM_CNT_BATCH * 16 + (size_t)SKM_CNT_BLOCK * 4 + hist_lds + (size_t)SKM_CNT_BATCH * sk.nmax * 2 + 64 +
                              (gather ? (size_t)(SKM_G_MAXCH * 10 + 32) : 0);
@@ -922,7 +927,8 @@ static int run_count_kernels(simka_ctx *ctx, uint32_t sample, const SimkaScanArg
     if (!general_only)
         launch_timed(ctx, KID_SKM_COUNT, [&] {
             static const uint32_t bpc_env = simka_exp_knob("SIMKA_SKM_BPC") ? (uint32_t)atoi(simka_exp_knob("SIMKA_SKM_BPC")) : 0u;     // experiments
-            const uint32_t bpc = bpc_env ? bpc_env : (uint32_t)std::max<size_t>(1, std::min<size_t>(4, (160 * 1024) / lds_fast));
+            // (the dispatcher hands out LDS in granules of 1280 bytes, 128 per CU: scripts/ubench/lds_occupancy.hip)
+            const uint32_t bpc = bpc_env ? bpc_env : (uint32_t)std::max<size_t>(1, std::min<size_t>(4, 128 / ((lds_fast + 1279) / 1280)));
             hipLaunchKernelGGL(gather ? k_skm_count_fast<true> : k_skm_count_fast<false>, dim3((uint32_t)std::min<uint64_t>(ctx->nparts, (uint64_t)ctx->num_cus * bpc)), dim3(SKM_FAST_BLOCK), lds_fast, st,
                                src, sk, ctx->key, ctx->cfg.abundance_min, ctx->cfg.abundance_max, o, (const uint32_t *)flag, kocc,
                                L.d_redo_list, L.d_redo_count);
@@ -1055,7 +1061,7 @@ static int wide_hash_count(simka_ctx *ctx, uint32_t sample, const void *d_packed
         if (!general_only)
             launch_timed(ctx, KID_SKM_COUNT, [&] {
                 const size_t lds_wf = (size_t)SIMKA_LDS_HEAD + hist_lds + (size_t)(SKM_WF_BLOCK / 64) * skm_wf_wave_bytes(sk.nmax);
-                const uint32_t bpc = (uint32_t)std::max<size_t>(1, std::min<size_t>(4, (160 * 1024) / lds_wf));
+                const uint32_t bpc = (uint32_t)std::max<size_t>(1, std::min<size_t>(4, 128 / ((lds_wf + 1279) / 1280)));      // (LDS granules of 1280 bytes, 128 per CU)
                 hipLaunchKernelGGL(k_skm_count_wide_fast, dim3((uint32_t)std::min<uint64_t>((nparts + 3) / 4, (uint64_t)ctx->num_cus * bpc)), dim3(SKM_WF_BLOCK), lds_wf, st, (const uint4 *)L.d_skm_b,
                                    (const uint32_t *)L.d_pstart, (const uint32_t *)L.d_pcnt, sk, ctx->cfg.abundance_min, ctx->cfg.abundance_max, wo, o, (const uint32_t *)(ctx->d_l1_ovf + sample),
                                    L.d_redo_list, L.d_redo_count);
@@ -1950,7 +1956,7 @@ static void pair_setup(simka_ctx *ctx, PairLaunch &pl, bool legacy_layout = fals
     pl.ntp = pc.ntiles * (pc.ntiles + 1) / 2;
     pl.lds_pairs = lds_fixed + (size_t)pc.ncell_pad * cell_bytes;
     pl.small_block = pc.ntiles == 1 && N <= 32;     // few pairs per span: more, smaller blocks
-    const uint32_t per_cu = (uint32_t)std::min<size_t>(pl.small_block ? 6 : 2, std::max<size_t>(1, (160 * 1024) / pl.lds_pairs));
+    const uint32_t per_cu = (uint32_t)std::min<size_t>(pl.small_block ? 6 : 2, std::max<size_t>(1, 128 / ((pl.lds_pairs + 1279) / 1280)));      // (LDS granules of 1280 bytes, 128 per CU)
     pl.nblk = (uint32_t)ctx->num_cus * per_cu;
 }
 

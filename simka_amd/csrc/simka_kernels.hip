@@ -115,8 +115,10 @@ __device__ __forceinline__ ull slab_take(ull &slab_pos, ull &slab_end, uint32_t 
     return b;
 }
 
-__device__ __forceinline__ void count_hist(const SimkaCountOut &o, uint32_t *lhist, uint32_t c) {
-    if (c < SIMKA_HIST_MAX) atomicAdd(&lhist[c], 1u);
+// (lbins: how many of the SIMKA_HIST_MAX exact bins the kernel keeps in LDS; the rarer counts above go straight to the global histogram)
+__device__ __forceinline__ void count_hist(const SimkaCountOut &o, uint32_t *lhist, uint32_t c, uint32_t lbins = SIMKA_HIST_MAX) {
+    if (c < lbins) atomicAdd(&lhist[c], 1u);
+    else if (c < SIMKA_HIST_MAX) atomicAdd(&o.hist[(size_t)o.sample * SIMKA_HIST_MAX + c], 1ull);
     else { const ull w = atomicAdd(o.ovf_cursor, 1ull); if (w < o.ovf_cap) { o.ovf_list[2 * w] = o.sample; o.ovf_list[2 * w + 1] = c; } }
 }
 

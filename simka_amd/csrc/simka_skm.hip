@@ -47,6 +47,8 @@ typedef unsigned long long ull;
 #define SKM_BLOCK 512
 #define SKM_MAXB1 256            // level-1 buckets at most (512: the scan's runs per bucket halve to ~30 bytes and the kernel doubles, the split gains 10 %)
 #define SKM_CSTRIDE 16            // the global fill cursor of a bucket has a 128-byte line of its own (every tile of the scan bumps every cursor)
+#define SKM_SCAN_HEAD 64          // bytes of block scalars in front of k_skm_scan's tables (with gbase as 32-bit record indices: 40 304 bytes of LDS at
+                                 // W = 16 = 32 granules of 1280 bytes -- FOUR blocks per CU; it was 41 776 = 33 granules = three)
 #define SKM_NT (SKM_BLOCK + 4)    // thread columns of the chunk-major hash array (4 pad columns)
 #define SKM_SEG 16               // entries per thread
 #define SKM_MAXW 20
@@ -65,6 +67,9 @@ typedef unsigned long long ull;
 #define SKM_FAST_QCAP (64 + 64 * SKM_FAST_U)      // retry queue of a wave: what one iteration can add on top of an undrained rest
 #define SKM_FAST_BMW 32          // u64 words of a wave's record-start bitmap (64 records x nmax <= 32 k-mers)
 #define SKM_FAST_WREG ((SKM_FAST_BMW * 8 + SKM_FAST_QCAP * 10 + 15) / 16 * 16)     // bytes of a wave's private LDS region
+#define SKM_FAST_HEAD 256        // bytes of block scalars in front of k_skm_count_fast's table
+#define SKM_FAST_HBINS 512       // bins of the -complex-dist count histogram k_skm_count_fast keeps in LDS: with all SIMKA_HIST_MAX = 1024 the block took
+                                 // 43 044 bytes = 34 LDS granules of 1280 bytes, i.e. THREE blocks per CU instead of four (40 740 bytes now: 32 granules)
 #define SKM_SORT_BITS 4          // solid records leave the count kernels ordered by the top 4 bits of their key (SIMKA_SEG_BITS): the merge reads sub-ranges of a segment in place
 #define SKM_NSORT (1 << SKM_SORT_BITS)
 
@@ -144,16 +149,16 @@ k_skm_scan(SimkaScanArgs a, SimkaSkmCfg cfg, ull *b1_count, ull *b1_cursor, uint
     //               accesses of consecutive lanes are consecutive in LDS (thread-major: every wide access a 4-way bank conflict);
     //   phases 3-4: [caprec] staged records | [lcap] run starts (entry index) | [lcap] their partition ids;
     //   a tile with more starts than the list takes (rare): partition ids of all entries, in the layout of the hashes.
-    uint32_t *hm = (uint32_t *)(smem + SIMKA_LDS_HEAD);             // [4][SKM_NT][4]
+    uint32_t *hm = (uint32_t *)(smem + SKM_SCAN_HEAD);              // [4][SKM_NT][4]
     uint4 *stage = (uint4 *)hm;                                     // [caprec] (!HIST)
     uint16_t *slist = (uint16_t *)(stage + (HIST ? 0u : caprec));   // [lcap] entry indices of the run starts
     uint32_t *spid = (uint32_t *)(slist + ((lcap + 1u) & ~1u));     // [lcap] their minimizer values
-    uint32_t *tb = (uint32_t *)(smem + SIMKA_LDS_HEAD + rbytes);    // [TILE/16 + 8] the tile's bases, 16 per word
+    uint32_t *tb = (uint32_t *)(smem + SKM_SCAN_HEAD + rbytes);     // [TILE/16 + 8] the tile's bases, 16 per word
     uint32_t *smask = tb + SKM_TILE / 16 + 8;                       // [BLOCK] start | brk << 16
     uint32_t *hist = smask + SKM_BLOCK + 4;                         // [B1]   (smask has 4 pad words: all-break)
     uint32_t *lcur = hist + SKM_MAXB1;                              // [B1]
-    ull *gbase = (ull *)(lcur + SKM_MAXB1);                         // [B1]
-    uint32_t *rtab = (uint32_t *)(gbase + SKM_MAXB1);               // [SKM_RTAB] (!FIXED)
+    uint32_t *gbase = lcur + SKM_MAXB1;                             // [B1] where the tile's run of the bucket starts (a lane's record buffer holds < 2^32 records); ~0u: overflow
+    uint32_t *rtab = gbase + SKM_MAXB1;                             // [SKM_RTAB] (!FIXED)
 
     const uint32_t tid = threadIdx.x;
     const uint32_t B1 = 1u << cfg.l1;
@@ -460,7 +465,7 @@ k_skm_scan(SimkaScanArgs a, SimkaSkmCfg cfg, ull *b1_count, ull *b1_cursor, uint
     SKM_STOP_AT(5)
     if (tid < SKM_MAXB1) {
         if (h_res && b1_limit && g_res + h_res > b1_limit[tid]) { *ovf_flag = 1u; g_res = ~0ull; }
-        gbase[tid] = g_res;
+        gbase[tid] = g_res == ~0ull ? 0xffffffffu : (uint32_t)g_res;
     }
     __syncthreads();
     if (!direct) {
@@ -470,18 +475,19 @@ k_skm_scan(SimkaScanArgs a, SimkaSkmCfg cfg, ull *b1_count, ull *b1_cursor, uint
         for (uint32_t i = tid; i < ntot; i += SKM_BLOCK) {
             const uint4 rec = stage[i];
             const uint32_t b1 = cfg.pb ? skm_rec_pid(rec) >> (cfg.pb - cfg.l1) : 0u;
-            const ull g = gbase[b1];
-            if (g != ~0ull) { l1_recs[g + (i - hist[b1])] = rec; if (l1_pid) l1_pid[g + (i - hist[b1])] = skm_rec_pid(rec); }       // (the exact split's first pass reads 4 bytes per record; the chunk sort needs no ids)
+            const uint32_t g = gbase[b1];
+            if (g != 0xffffffffu) { l1_recs[(ull)g + (i - hist[b1])] = rec; if (l1_pid) l1_pid[(ull)g + (i - hist[b1])] = skm_rec_pid(rec); }       // (the exact split's first pass reads 4 bytes per record; the chunk sort needs no ids)
         }
     } else {
         // ---- phase 4d
         for_runs([&](uint32_t e, uint32_t len, uint32_t pid) {
             const uint32_t b1 = cfg.pb ? pid >> (cfg.pb - cfg.l1) : 0u;
-            const ull g = gbase[b1];
+            const uint32_t g32 = gbase[b1];
+            const ull g = g32;
             while (len) {
                 const uint32_t n = len < cfg.nmax ? len : cfg.nmax;
                 const uint32_t pos = atomicAdd(&lcur[b1], 1u);
-                if (g != ~0ull) { l1_recs[g + (pos - hist[b1])] = cut(e, n, pid); if (l1_pid) l1_pid[g + (pos - hist[b1])] = pid; }
+                if (g32 != 0xffffffffu) { l1_recs[g + (pos - hist[b1])] = cut(e, n, pid); if (l1_pid) l1_pid[g + (pos - hist[b1])] = pid; }
                 e += n; len -= n;
             }
         });
@@ -1381,11 +1387,11 @@ k_skm_count_fast(SimkaSkmSrc src, SimkaSkmCfg cfg, SimkaKeyCfg kcfg, uint32_t am
     ull *s_slab = (ull *)(smem + 64);                  // [2][2] (pos, end), double-buffered by iteration parity
     uint32_t *tmp = (uint32_t *)(smem + 128);          // [BLOCK/64]
     constexpr uint32_t TS = SKM_FAST_TS, SPT = TS / SKM_FAST_BLOCK, TSL = 11, NW = SKM_FAST_BLOCK / 64;
-    ull *tkeys = (ull *)(smem + SIMKA_LDS_HEAD);       // [TS]
+    ull *tkeys = (ull *)(smem + SKM_FAST_HEAD);        // [TS]
     uint32_t *tcnt = (uint32_t *)(tkeys + TS);         // [TS]
     uint4 *lrec = (uint4 *)(tcnt + TS);                // [BLOCK]: 64 per wave
-    uint32_t *lhist = (uint32_t *)(lrec + SKM_FAST_BLOCK);     // [SIMKA_HIST_MAX] (complex only)
-    unsigned char *wreg0 = (unsigned char *)(lhist + (o.hist ? SIMKA_HIST_MAX : 0));     // [NW][SKM_FAST_WREG] wave-private regions
+    uint32_t *lhist = (uint32_t *)(lrec + SKM_FAST_BLOCK);     // [SKM_FAST_HBINS] (complex only)
+    unsigned char *wreg0 = (unsigned char *)(lhist + (o.hist ? SKM_FAST_HBINS : 0));     // [NW][SKM_FAST_WREG] wave-private regions
     // GATHER: chunk numbering and start of every level-1 bucket, then per wave the piece table of the partition it loads next
     uint32_t *s_cb = (uint32_t *)(wreg0 + NW * SKM_FAST_WREG);     // [SKM_MAXB1 + 1]
     uint32_t *s_bs = s_cb + SKM_MAXB1 + 1;                         // [SKM_MAXB1] (a lane's record buffer holds < 2^32 records)
@@ -1409,7 +1415,7 @@ k_skm_count_fast(SimkaSkmSrc src, SimkaSkmCfg cfg, SimkaKeyCfg kcfg, uint32_t am
     }
     const ull sample_base = *o.sample_base;
     for (uint32_t i = tid; i < TS; i += SKM_FAST_BLOCK) { tkeys[i] = SIMKA_EMPTY_KEY; tcnt[i] = 0; }
-    if (o.hist) for (uint32_t i = tid; i < SIMKA_HIST_MAX; i += SKM_FAST_BLOCK) lhist[i] = 0;
+    if (o.hist) for (uint32_t i = tid; i < SKM_FAST_HBINS; i += SKM_FAST_BLOCK) lhist[i] = 0;
     if (tid < 5) s_tot[tid] = 0;
     if (tid < 4) s_slab[tid] = 0;
     if (tid == 0) s_fail = 0;
@@ -1759,7 +1765,7 @@ k_skm_count_fast(SimkaSkmSrc src, SimkaSkmCfg cfg, SimkaKeyCfg kcfg, uint32_t am
                     const ull key = wk[r]; const uint32_t c = wc[r];
                     const ull pos = base_ + wpre + r;
                     o.solid_keys[pos] = key; o.solid_counts[pos] = c;
-                    if (o.hist) count_hist(o, lhist, c);
+                    if (o.hist) count_hist(o, lhist, c, SKM_FAST_HBINS);
                 }
             } else {
                 ull pos = base_ + wpre + winc - nsol;
@@ -1767,7 +1773,7 @@ k_skm_count_fast(SimkaSkmSrc src, SimkaSkmCfg cfg, SimkaKeyCfg kcfg, uint32_t am
                 for (uint32_t q = 0; q < SPT; q++) {
                     if (cs[q]) {
                         o.solid_keys[pos] = ks[q]; o.solid_counts[pos] = cs[q]; pos++;
-                        if (o.hist) count_hist(o, lhist, cs[q]);
+                        if (o.hist) count_hist(o, lhist, cs[q], SKM_FAST_HBINS);
                     }
                 }
             }
@@ -1786,7 +1792,7 @@ k_skm_count_fast(SimkaSkmSrc src, SimkaSkmCfg cfg, SimkaKeyCfg kcfg, uint32_t am
 #endif
     if (o.hist) {
         __syncthreads();
-        for (uint32_t i = tid; i < SIMKA_HIST_MAX; i += SKM_FAST_BLOCK)
+        for (uint32_t i = tid; i < SKM_FAST_HBINS; i += SKM_FAST_BLOCK)
             if (lhist[i]) atomicAdd(&o.hist[(size_t)o.sample * SIMKA_HIST_MAX + i], (ull)lhist[i]);
     }
     if (bt_dall) atomicAdd(&s_tot[0], bt_dall);
