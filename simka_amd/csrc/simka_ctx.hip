@@ -154,9 +154,20 @@ static double wall_now() { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &t
         if (e_ != hipSuccess) return ctx->fail(SIMKA_ERR_HIP, "%s failed: %s", #call, hipGetErrorString(e_)); \
     } while (0)
 
+// tests: see launch_timed (one 160 KB block per CU)
+__global__ void __launch_bounds__(1024) k_poison_lds(uint32_t mode) {
+    extern __shared__ uint32_t poison_smem[];
+    for (uint32_t i = threadIdx.x; i < 160u * 1024u / 4u; i += 1024u) poison_smem[i] = mode == 0u ? 0u : (mode == 1u ? 0xffffffffu : (i * 2654435761u) ^ (blockIdx.x * 40503u));
+    __syncthreads();
+    if (poison_smem[(threadIdx.x * 37u) % (160u * 1024u / 4u)] == 0x12345678u && mode == 77u) poison_smem[0] = 1u;      // (keeps the stores alive)
+}
 template <typename F>
 static inline void launch_timed(simka_ctx *ctx, int kid, F &&f, hipStream_t st = nullptr) {
     if (!st) st = ctx->stream;
+    // tests (SIMKA_POISON_LDS=0|1|2): every CU's LDS is overwritten before each kernel -- zeros, ones or an address hash -- so that a kernel
+    // which reads LDS it has not written (what an earlier kernel left there) fails every time instead of once in a while
+    static const char *poison = simka_test_knob("SIMKA_POISON_LDS");
+    if (poison) hipLaunchKernelGGL(k_poison_lds, dim3((uint32_t)ctx->num_cus), dim3(1024), 160 * 1024, st, (uint32_t)atoi(poison));
     static const bool dbg = simka_test_knob("SIMKA_DEBUG_SYNC") != nullptr;     // synchronise after every launch, name the kernel
     if (dbg) {
         fprintf(stderr, "[simka] launch %s\n", KID_NAMES[kid]); fflush(stderr);
@@ -308,6 +319,7 @@ SIMKA_EXPORT int simka_abi_version(void) { return SIMKA_ABI_VERSION; }
 // -gpu-shared`, one worker thread per context) ended, once in ten runs, in a memory access fault at the base of a freshly mapped arena:
 // the virtual-memory calls of a process go one at a time.
 static std::mutex g_vmm_lock;
+static int arena_ensure(simka_ctx *ctx, uint64_t need);
 static int g_live_ctx[64] = {0};        // contexts alive per device (under g_vmm_lock): a second one on a device gets a plain arena
 // Virtual ranges of destroyed contexts are RETIRED, never given back: on ROCm 7.0 / gfx950 a range that was unmapped and is mapped
 // again (hipMemAddressFree -> a later hipMemAddressReserve returns the same addresses -> hipMemMap) is read and written through stale
@@ -339,6 +351,7 @@ static int set_lds_attr(simka_ctx *ctx) {
     HIPCHK(hipFuncSetAttribute((const void *)k_pairs<false, K4_BLOCK_SMALL>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
     HIPCHK(hipFuncSetAttribute((const void *)k_pairs<true, K4_BLOCK_BIG>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
     HIPCHK(hipFuncSetAttribute((const void *)k_pairs_tm<false>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
+    HIPCHK(hipFuncSetAttribute((const void *)k_poison_lds, hipFuncAttributeMaxDynamicSharedMemorySize, big));
     HIPCHK(hipFuncSetAttribute((const void *)k_pairs_tm<true>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
     for (int wi = 0; wi < 6; wi++) for (int v = 0; v < 4; v++) HIPCHK(hipFuncSetAttribute((const void *)skm_scan_kernel(wi, v & 2, v & 1), hipFuncAttributeMaxDynamicSharedMemorySize, big));
     HIPCHK(hipFuncSetAttribute((const void *)k_skm_count<false>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
@@ -459,6 +472,11 @@ static int setup_geometry(simka_ctx *ctx, uint64_t max_kmers) {
         }
         ctx->arena_hi = 0;
     }
+    // A small arena (<= 4 chunks: 6 GB) is backed right here, before any kernel of this context runs.  Mapping chunks WHILE kernels run
+    // (the other lane's, with the default two lanes) is the pattern behind a rare GPU memory access fault at a chunk boundary -- twice in
+    // ~25 runs of the GPU suite in round 5, never reproduced on demand (docs/rounds/r05.md); larger arenas still grow on demand, behind a
+    // device synchronisation (arena_ensure).
+    if (ctx->arena_vmm && ctx->arena_reserved <= 4 * ARENA_CHUNK) { const int rca = arena_ensure(ctx, cap); if (rca) return rca; }
     if (simka_test_knob("SIMKA_DEBUG_SYNC")) fprintf(stderr, "[simka] arena of %llu records allocated (%.3f s)\n", (unsigned long long)cap, wall_now() - tdbg0);
     HIPCHK(hipStreamSynchronize(ctx->stream));       // the lanes' streams do not order against the main stream
     if (simka_test_knob("SIMKA_DEBUG_SYNC")) fprintf(stderr, "[simka] geometry ready (%.3f s since the arena, %.3f s in all)\n", wall_now() - tdbg0, wall_now() - tgeo);
@@ -684,6 +702,7 @@ static int arena_ensure(simka_ctx *ctx, uint64_t need) {
     need = std::min(need, ctx->arena_cap);                                 // (beyond the capacity: the kernels flag SIMKA_DEVERR_ARENA_FULL)
     if (!ctx->arena_vmm || need <= ctx->arena_mapped) return SIMKA_OK;
     std::lock_guard<std::mutex> vmm_guard(g_vmm_lock);
+    (void)hipDeviceSynchronize();      // no kernel in flight while the page tables change (see the geometry setup; a chunk is 1.3e8 records: rare)
     hipMemAllocationProp prop = {};
     prop.type = hipMemAllocationTypePinned; prop.location.type = hipMemLocationTypeDevice; prop.location.id = ctx->cfg.device;
     hipMemAccessDesc acc = {};

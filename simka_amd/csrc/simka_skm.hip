@@ -47,8 +47,10 @@ typedef unsigned long long ull;
 #define SKM_BLOCK 512
 #define SKM_MAXB1 256            // level-1 buckets at most (512: the scan's runs per bucket halve to ~30 bytes and the kernel doubles, the split gains 10 %)
 #define SKM_CSTRIDE 16            // the global fill cursor of a bucket has a 128-byte line of its own (every tile of the scan bumps every cursor)
+#ifndef SKM_SCAN_HEAD
 #define SKM_SCAN_HEAD 64          // bytes of block scalars in front of k_skm_scan's tables (with gbase as 32-bit record indices: 40 304 bytes of LDS at
                                  // W = 16 = 32 granules of 1280 bytes -- FOUR blocks per CU; it was 41 776 = 33 granules = three)
+#endif
 #define SKM_NT (SKM_BLOCK + 4)    // thread columns of the chunk-major hash array (4 pad columns)
 #define SKM_SEG 16               // entries per thread
 #define SKM_MAXW 20
