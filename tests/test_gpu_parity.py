@@ -1015,7 +1015,13 @@ def test_arena_mode_is_fixed_at_creation_and_reported(gpu_required):
         return
     assert ia["mapped_range"] is True and ia["reserved_records"] > 0
     with simka_amd.SimkaContext(2, **kw) as c:
+        # (round 5) an arena of at most four chunks is backed when the geometry is set up -- before the context has launched a kernel:
+        # chunks mapped while kernels run are the suspected pattern behind a rare GPU memory access fault (docs/rounds/r05.md)
+        pk, off, nb, nin = simka_amd.pack_reads([b"ACGTTGCAAGGCTTAACCGGTTAAGCGCGATATCGGCTAAGCTT", b"TTGCAAGGCTTAACCGGTTAAGCGCGATATCGGCTAAGCTTACG"])
+        c.count_sample(0, pk, nb, len(off) - 1, offsets=off, nb_input_reads=nin)
         ic = c.arena_info()
+        if ic["reserved_records"] <= 4 * (1 << 27):
+            assert ic["mapped_records"] >= min(ic["reserved_records"], 1 << 27), ic
     assert ic["mapped_range"] is True and ic["retired_va_bytes"] >= retired0 + ia["reserved_records"] * 12
 
 
