@@ -2,6 +2,7 @@
 // This is the only translation unit that launches kernels; simka_host.cpp holds the pure-host
 // pieces (finalisation, CSV, packing).
 #include <hip/hip_runtime.h>
+#include "simka_efence.h"      // (test builds: -DSIMKA_EFENCE)
 #include <dlfcn.h>
 #include <stdarg.h>
 #include <stdio.h>

@@ -15,6 +15,7 @@
 // sorts), exact, and an independent cross-check of it: with SIMKA_SORT_PATH=1 the k <= 31 tests run through this path and
 // must give bit-identical statistics (they do: goldens included).
 #include <hip/hip_runtime.h>
+#include "simka_efence.h"      // (test builds: -DSIMKA_EFENCE)
 #include <stdint.h>
 #include <algorithm>
 #include <string>
