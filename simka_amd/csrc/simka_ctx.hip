@@ -777,6 +777,7 @@ static int skm_scan_split(simka_ctx *ctx, simka_ctx::Lane &L, uint32_t sample, c
         // 30.0 ms per 12 samples): a long launch asks for a 33rd granule and runs three blocks per CU
         size_t b = (size_t)SKM_SCAN_HEAD + rbytes + (SKM_TILE / 16 + 8) * 4 + (SKM_BLOCK + 4) * 4 + SKM_MAXB1 * 4 * 2 + SKM_MAXB1 * 4 + (fixed ? 0 : SKM_RTAB * 4);
         if (ntiles > (uint32_t)ctx->num_cus * 32u && b <= 32 * 1280) b = 32 * 1280 + 16;
+        if (simka_exp_knob("SIMKA_SCAN_BPC")) { const size_t want = (size_t)(128 / std::max(1, atoi(simka_exp_knob("SIMKA_SCAN_BPC")))) * 1280; if (b < want - 1279) b = want - 1279; }      // experiments: blocks per CU by LDS padding
         return b;
     };
     static const bool no_gather = simka_test_knob("SIMKA_SKM_SPLIT") != nullptr;      // tests: the exact split instead of chunk sort + gather
