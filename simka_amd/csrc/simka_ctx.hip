@@ -319,6 +319,12 @@ SIMKA_EXPORT int simka_abi_version(void) { return SIMKA_ABI_VERSION; }
 // Reserving, mapping and unmapping virtual ranges from several threads at once (contexts of one process on one device: `simka -nb-gpus
 // -gpu-shared`, one worker thread per context) ended, once in ten runs, in a memory access fault at the base of a freshly mapped arena:
 // the virtual-memory calls of a process go one at a time.
+// LDS budgets that decide how many blocks a CU holds (granules of 1280 bytes, 128 per CU: scripts/ubench/lds_occupancy.hip) -- a few bytes
+// more and a persistent grid silently runs in two waves
+static_assert(K3_LDS_BYTES(K3_BLOCK) <= 25 * 1280, "k_group<256>: five blocks per CU");
+static_assert(K3_LDS_BYTES(2 * K3_BLOCK) <= 64 * 1280, "k_group<512>: two blocks per CU");
+static_assert((size_t)SKM_FAST_HEAD + (size_t)SKM_FAST_TS * 12 + (size_t)SKM_FAST_BLOCK * 16 + (size_t)SKM_FAST_HBINS * 4 + (size_t)(SKM_FAST_BLOCK / 64) * SKM_FAST_WREG +
+              (size_t)SKM_G_BYTES(SKM_FAST_BLOCK / 64) <= 32 * 1280, "k_skm_count_fast with the complex histogram: four blocks per CU");
 static std::mutex g_vmm_lock;
 static int arena_ensure(simka_ctx *ctx, uint64_t need);
 static int g_live_ctx[64] = {0};        // contexts alive per device (under g_vmm_lock): a second one on a device gets a plain arena
