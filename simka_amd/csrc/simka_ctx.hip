@@ -356,6 +356,9 @@ static int set_lds_attr(simka_ctx *ctx) {
     HIPCHK(hipFuncSetAttribute((const void *)k_group<2 * K3_BLOCK, true>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
     HIPCHK(hipFuncSetAttribute((const void *)k_pairs<false, K4_BLOCK_BIG>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
     HIPCHK(hipFuncSetAttribute((const void *)k_pairs<false, K4_BLOCK_SMALL>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
+#ifdef SIMKA_DEBUG_KNOBS
+    HIPCHK(hipFuncSetAttribute((const void *)k_pairs<false, 512>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
+#endif
     HIPCHK(hipFuncSetAttribute((const void *)k_pairs<true, K4_BLOCK_BIG>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
     HIPCHK(hipFuncSetAttribute((const void *)k_pairs_tm<false>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
     HIPCHK(hipFuncSetAttribute((const void *)k_poison_lds, hipFuncAttributeMaxDynamicSharedMemorySize, big));
@@ -2025,6 +2028,10 @@ static void pair_launch(simka_ctx *ctx, const PairLaunch &pl, const SimkaSpan *s
     if (have_spans) launch_timed(ctx, KID_PAIRS, [&] {
         if (pl.small_block)
             hipLaunchKernelGGL((k_pairs<false, K4_BLOCK_SMALL>), dim3(pl.nblk, pl.ntp), dim3(K4_BLOCK_SMALL), pl.lds_pairs, ctx->stream, spans, cursors, entries, groups, pc, acc, work);
+#ifdef SIMKA_DEBUG_KNOBS
+        else if (pc.ntiles == 1 && simka_exp_knob("SIMKA_PAIRS_BLOCK512"))      // experiments: eight waves per block instead of sixteen
+            hipLaunchKernelGGL((k_pairs<false, 512>), dim3(pl.nblk, pl.ntp), dim3(512), pl.lds_pairs, ctx->stream, spans, cursors, entries, groups, pc, acc, work);
+#endif
         else if (pc.ntiles == 1)
             hipLaunchKernelGGL((k_pairs<false, K4_BLOCK_BIG>), dim3(pl.nblk, pl.ntp), dim3(K4_BLOCK_BIG), pl.lds_pairs, ctx->stream, spans, cursors, entries, groups, pc, acc, work);
         else if (tile_major) {
