@@ -222,7 +222,13 @@ int simka_import_samples_device(simka_ctx *ctx, const uint32_t *samples, uint32_
  *   simka_import_block_device: the receive side.  The block holds nb_slots_total slots one after the other (source rank major), slot q =
  *     the runs of sample slot_samples[q] (0xffffffff: an empty slot) in the partitions [part_lo, part_lo + part_width), their lengths in
  *     row q of d_meta (device int32 [nb_slots_total][width]); totals[q] as for simka_import_samples_device.
- * (kmer_size >= 32 exchanges whole sorted runs: simka_gather_samples_device_wide / simka_import_samples_device_wide.) */
+ * (kmer_size >= 32 exchanges whole sorted runs: simka_gather_samples_device_wide / simka_import_samples_device_wide.)
+ * Stream ordering of caller buffers: every entry point that takes a DEVICE pointer reads / writes it on the context's stream
+ *   (simka_config.stream, or a stream of its own) and returns after that work has completed.  Work the caller has queued on ANOTHER stream for
+ *   the same buffer (the zero-fill of d_meta, an asynchronous copy or a collective that produces d_keys / d_counts / d_meta) must have
+ *   completed -- or be ordered by an event the context's stream waits on -- before the call; only the legacy null stream orders implicitly.
+ * State: a plan lives until the next simka_pack_plan, simka_reset or import on the context (those drop it: simka_pack_run then fails with
+ *   SIMKA_ERR_STATE); a simka_import_block_device that fails leaves the context as it was (the tables of the target samples are rolled back). */
 int simka_pack_plan(simka_ctx *ctx, const uint32_t *samples, uint32_t nb, uint32_t nb_ranges, uint64_t *send_records);
 int simka_pack_run(simka_ctx *ctx, void *d_keys, void *d_counts, int32_t *d_meta, uint32_t nb_slots, uint32_t width);
 int simka_import_block_device(simka_ctx *ctx, const uint32_t *slot_samples, uint32_t nb_slots_total, const simka_sample_totals *totals,

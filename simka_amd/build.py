@@ -18,7 +18,7 @@ CLI_PATH = os.path.join(BIN_DIR, "simka")
 LIB_SOURCES = ["simka_ctx.hip", "simka_wide.hip", "simka_host.cpp"]
 # every file a translation unit of the library #includes (simka_ctx.hip pulls the other .hip files in)
 LIB_DEPS = LIB_SOURCES + ["simka_kernels.hip", "simka_skm.hip", "simka_sort.hip", "simka_ingest.hip", "simka_kernels.h",
-                          "simka_device.h", "simka_wide.h", "simka_efence.h", "../../include/simka_hip.h"]
+                          "simka_device.h", "simka_wide.h", "simka_efence.h", "simka_trace.h", "../../include/simka_hip.h"]
 CLI_SOURCES = ["simka_cli.cpp"]
 
 

@@ -3,6 +3,7 @@
 // pieces (finalisation, CSV, packing).
 #include <hip/hip_runtime.h>
 #include "simka_efence.h"      // (test builds: -DSIMKA_EFENCE)
+#include "simka_trace.h"       // SIMKA_FAULT_TRACE=1: registry of device ranges + ring of launches, dumped when the process dies
 #include <dlfcn.h>
 #include <stdarg.h>
 #include <stdio.h>
@@ -121,6 +122,9 @@ struct simka_ctx {
     ull *d_xrows = nullptr; uint64_t xrows_cap = 0;             // [nb][nb_ranges] records of (sample slot, destination); then their starts
     uint32_t *d_xsamples = nullptr; uint64_t xsamples_cap = 0;  // sample of every slot
     std::vector<uint32_t> plan_samples; uint32_t plan_ranges = 0; uint64_t plan_total = 0;
+    uint32_t trace_id = 0;          // SIMKA_FAULT_TRACE: the context's number in the dump
+    bool plan_valid = false;        // simka_pack_plan succeeded and nothing has reused d_xrows / d_xsamples or reset the context since
+    void drop_plan() { plan_valid = false; plan_ranges = 0; plan_total = 0; plan_samples.clear(); }
     ull *d_hist = nullptr; uint32_t *d_ovf_list = nullptr; ull *d_ovf_cursor = nullptr; uint64_t ovf_cap = 0;
 
     std::vector<uint8_t> counted;
@@ -168,7 +172,7 @@ static inline void launch_timed(simka_ctx *ctx, int kid, F &&f, hipStream_t st =
     // tests (SIMKA_POISON_LDS=0|1|2): every CU's LDS is overwritten before each kernel -- zeros, ones or an address hash -- so that a kernel
     // which reads LDS it has not written (what an earlier kernel left there) fails every time instead of once in a while
     static const char *poison = simka_test_knob("SIMKA_POISON_LDS");
-    if (poison) hipLaunchKernelGGL(k_poison_lds, dim3((uint32_t)ctx->num_cus), dim3(1024), 160 * 1024, st, (uint32_t)atoi(poison));
+    if (poison) SIMKA_LAUNCH(k_poison_lds, dim3((uint32_t)ctx->num_cus), dim3(1024), 160 * 1024, st, (uint32_t)atoi(poison));
     static const bool dbg = simka_test_knob("SIMKA_DEBUG_SYNC") != nullptr;     // synchronise after every launch, name the kernel
     if (dbg) {
         fprintf(stderr, "[simka] launch %s\n", KID_NAMES[kid]); fflush(stderr);
@@ -203,7 +207,8 @@ static void profile_collect(simka_ctx *ctx) {
 }
 
 template <typename T>
-static hipError_t dev_alloc(T **p, uint64_t n) { return hipMalloc((void **)p, std::max<uint64_t>(n, 1) * sizeof(T)); }
+static hipError_t dev_alloc_(const char *name, const char *file, int line, T **p, uint64_t n) { return simka_trace::traced_malloc(name, file, line, (void **)p, std::max<uint64_t>(n, 1) * sizeof(T)); }
+#define dev_alloc(p, n) dev_alloc_(#p, __FILE__, __LINE__, (p), (n))      // (the fault trace names a range after the expression that holds it)
 
 // ---- large copies between PAGEABLE host memory and the device.  The runtime pins such a buffer for the copy and unpins it afterwards
 // (a few GB/s, and the deferred unpin holds the process' address-space lock: the next malloc or page fault of any thread waits --
@@ -473,6 +478,8 @@ static int setup_geometry(simka_ctx *ctx, uint64_t max_kmers) {
         if (!plain && hipMemAddressReserve(&vk, capr * 8, 0, nullptr, 0) == hipSuccess) {
             if (hipMemAddressReserve(&vc, capr * 4, 0, nullptr, 0) == hipSuccess) {
                 ctx->arena_vmm = true; ctx->d_solid_keys = (ull *)vk; ctx->d_solid_counts = (uint32_t *)vc; ctx->arena_reserved = capr; ctx->arena_mapped = 0;
+                simka_trace::add_range(1, "arena keys: virtual range", __FILE__, __LINE__, vk, capr * 8);
+                simka_trace::add_range(1, "arena counts: virtual range", __FILE__, __LINE__, vc, capr * 4);
             } else { (void)hipMemAddressFree(vk, capr * 8); (void)hipGetLastError(); }
         } else (void)hipGetLastError();
         if (!ctx->arena_vmm) {
@@ -486,7 +493,8 @@ static int setup_geometry(simka_ctx *ctx, uint64_t max_kmers) {
     // (the other lane's, with the default two lanes) is the pattern behind a rare GPU memory access fault at a chunk boundary -- twice in
     // ~25 runs of the GPU suite in round 5, never reproduced on demand (docs/rounds/r05.md); larger arenas still grow on demand, behind a
     // device synchronisation (arena_ensure).
-    if (ctx->arena_vmm && ctx->arena_reserved <= 4 * ARENA_CHUNK) { const int rca = arena_ensure(ctx, cap); if (rca) return rca; }
+    // (SIMKA_ARENA_LAZY: the policy of rounds 1-4 -- every chunk mapped on demand, no synchronisation -- for scripts/stress_fault_trace.sh)
+    if (ctx->arena_vmm && !simka_test_knob("SIMKA_ARENA_LAZY") && ctx->arena_reserved <= 4 * ARENA_CHUNK) { const int rca = arena_ensure(ctx, cap); if (rca) return rca; }
     if (simka_test_knob("SIMKA_DEBUG_SYNC")) fprintf(stderr, "[simka] arena of %llu records allocated (%.3f s)\n", (unsigned long long)cap, wall_now() - tdbg0);
     HIPCHK(hipStreamSynchronize(ctx->stream));       // the lanes' streams do not order against the main stream
     if (simka_test_knob("SIMKA_DEBUG_SYNC")) fprintf(stderr, "[simka] geometry ready (%.3f s since the arena, %.3f s in all)\n", wall_now() - tdbg0, wall_now() - tgeo);
@@ -511,6 +519,7 @@ SIMKA_EXPORT int simka_create(const simka_config *cfg, simka_ctx **out) {
     if (cfg->device < 0 || cfg->device >= ndev) { g_create_error = "simka_create: bad device ordinal"; return SIMKA_ERR_INVALID; }
     simka_ctx *ctx = new simka_ctx();
     ctx->cfg = *cfg;
+    ctx->trace_id = simka_trace::new_ctx();
     {   // the arena mode is fixed HERE, from what is alive at creation: a context that finds another one on its device takes a plain arena
         // (the known fault needs a range that is unmapped and mapped again, which the library no longer does -- retired ranges --, so
         // this is a second line of defence; callers that create several contexts on one device up front set SIMKA_CFG_ARENA_PLAIN
@@ -626,6 +635,7 @@ SIMKA_EXPORT void simka_destroy(simka_ctx *ctx) {
             if ((e1 != hipSuccess || e2 != hipSuccess) && simka_test_knob("SIMKA_DEBUG_SYNC")) fprintf(stderr, "[simka] hipMemUnmap of arena chunk %llu failed: %s\n", (unsigned long long)(at / ARENA_CHUNK), hipGetErrorString(e1 != hipSuccess ? e1 : e2));
             (void)hipGetLastError();
         }
+        simka_trace::del_chunks(ctx->d_solid_keys, ctx->arena_reserved * 8); simka_trace::del_chunks(ctx->d_solid_counts, ctx->arena_reserved * 4);
         for (auto h : ctx->arena_hk) (void)hipMemRelease(h);
         for (auto h : ctx->arena_hc) (void)hipMemRelease(h);
         g_vmm_retired_bytes += ctx->arena_reserved * 12;      // (no hipMemAddressFree: see g_vmm_retired_bytes)
@@ -673,6 +683,7 @@ SIMKA_EXPORT int simka_reset(simka_ctx *ctx) {
         HIPCHK(hipMemsetAsync(ctx->d_ovf_cursor, 0, 16, ctx->stream));
     }
     ctx->pending.clear();
+    ctx->drop_plan();
     ctx->nb_counted_this_run = 0;
     if (ctx->d_l1_ovf) HIPCHK(hipMemsetAsync(ctx->d_l1_ovf, 0, (size_t)(N + 1) * 4, ctx->stream));
     std::fill(ctx->counted.begin(), ctx->counted.end(), 0);
@@ -697,22 +708,26 @@ static int check_device_error(simka_ctx *ctx) {
 }
 
 template <typename T>
-static int ensure_cap(simka_ctx *ctx, T **p, uint64_t *cap, uint64_t need) {
+static int ensure_cap_(const char *name, int line, simka_ctx *ctx, T **p, uint64_t *cap, uint64_t need) {
     if (*cap >= need && *p) return SIMKA_OK;
     if (*p) { HIPCHK(hipDeviceSynchronize()); HIPCHK(hipFree(*p)); *p = nullptr; *cap = 0; }
     const uint64_t n = need + need / 8 + 16;
-    hipError_t e = dev_alloc(p, n);
+    hipError_t e = dev_alloc_(name, __FILE__, line, p, n);
     if (e != hipSuccess) return ctx->fail(SIMKA_ERR_NOMEM, "hipMalloc of %llu bytes failed: %s", (unsigned long long)(n * sizeof(T)), hipGetErrorString(e));
     *cap = n;
     return SIMKA_OK;
 }
+#define ensure_cap(ctx, p, cap, need) ensure_cap_(#p, __LINE__, (ctx), (p), (cap), (need))
 
 // back the first `need` records of the arena with memory (no-op when they already are)
 static int arena_ensure(simka_ctx *ctx, uint64_t need) {
     need = std::min(need, ctx->arena_cap);                                 // (beyond the capacity: the kernels flag SIMKA_DEVERR_ARENA_FULL)
     if (!ctx->arena_vmm || need <= ctx->arena_mapped) return SIMKA_OK;
+    // no kernel of THIS device in flight while its page tables change (see the geometry setup; a chunk is 1.3e8 records: rare).  The wait
+    // happens before the process-wide lock is taken -- other contexts and devices are not held up behind it -- and a sticky
+    // asynchronous error surfaces here instead of being swallowed.
+    if (!simka_test_knob("SIMKA_ARENA_LAZY")) HIPCHK(hipDeviceSynchronize());
     std::lock_guard<std::mutex> vmm_guard(g_vmm_lock);
-    (void)hipDeviceSynchronize();      // no kernel in flight while the page tables change (see the geometry setup; a chunk is 1.3e8 records: rare)
     hipMemAllocationProp prop = {};
     prop.type = hipMemAllocationTypePinned; prop.location.type = hipMemLocationTypeDevice; prop.location.id = ctx->cfg.device;
     hipMemAccessDesc acc = {};
@@ -736,6 +751,8 @@ static int arena_ensure(simka_ctx *ctx, uint64_t need) {
         }
         ctx->arena_hk.push_back(hk); ctx->arena_hc.push_back(hc);
         ctx->arena_mapped = at + ARENA_CHUNK;
+        simka_trace::add_range(2, "arena keys chunk", __FILE__, (int)(at / ARENA_CHUNK), (char *)ctx->d_solid_keys + at * 8, ARENA_CHUNK * 8);       // (line = chunk number)
+        simka_trace::add_range(2, "arena counts chunk", __FILE__, (int)(at / ARENA_CHUNK), (char *)ctx->d_solid_counts + at * 4, ARENA_CHUNK * 4);
     }
     return SIMKA_OK;
 }
@@ -766,7 +783,7 @@ static int skm_scan_split(simka_ctx *ctx, simka_ctx::Lane &L, uint32_t sample, c
     const uint32_t ntiles = (uint32_t)((a.nb_bases + SKM_STRIDE - 1) / SKM_STRIDE);
     if (!a.fixed_len && a.nb_reads && ntiles) {
         rc = ensure_cap(ctx, &L.d_tile_r0, &L.tile_r0_cap, (uint64_t)ntiles + 2); if (rc) return rc;
-        hipLaunchKernelGGL(k_tile_reads, dim3((ntiles + 1 + 255) / 256), dim3(256), 0, st, a.offsets, a.nb_reads, a.nb_bases, ntiles, (uint64_t)SKM_STRIDE, (uint64_t)(sk.d ? sk.d + 1u : 0u), L.d_tile_r0);
+        SIMKA_LAUNCH(k_tile_reads, dim3((ntiles + 1 + 255) / 256), dim3(256), 0, st, a.offsets, a.nb_reads, a.nb_bases, ntiles, (uint64_t)SKM_STRIDE, (uint64_t)(sk.d ? sk.d + 1u : 0u), L.d_tile_r0);
         a.tile_r0 = L.d_tile_r0;
     }
     uint32_t *flag = ctx->d_l1_ovf + sample;
@@ -793,14 +810,14 @@ static int skm_scan_split(simka_ctx *ctx, simka_ctx::Lane &L, uint32_t sample, c
     bool use_gather = *gather && !no_gather && L.d_cbase;
     auto layout = [&](uint32_t mode, ull capb) {
         launch_timed(ctx, KID_LAYOUT, [&] {
-            hipLaunchKernelGGL(k_skm_layout, dim3(1), dim3(SKM_MAXB1), 0, st, L.d_b1_count, L.d_b1_start, L.d_b1_end, L.d_b1_cursor, B1, mode, capb,
+            SIMKA_LAUNCH(k_skm_layout, dim3(1), dim3(SKM_MAXB1), 0, st, L.d_b1_count, L.d_b1_start, L.d_b1_end, L.d_b1_cursor, B1, mode, capb,
                                ctx->d_arena_cursor, ctx->d_sample_base + sample, pass == 0 ? 1u : 0u, (const uint32_t *)flag, L.d_redo_count,
                                use_gather ? L.d_cbase : (uint32_t *)nullptr, (uint32_t)SKM_CS_CHUNK);
         }, st);
     };
     auto scan = [&](bool hist, const ull *limit) {
         launch_timed(ctx, hist ? KID_SCAN_HIST : KID_SKM_SCAN, [&] {
-            hipLaunchKernelGGL(skm_scan_kernel(wi, fixed, hist), dim3(ntiles), dim3(SKM_BLOCK), scan_lds(hist), st, a, sk, L.d_b1_count, L.d_b1_cursor, L.d_skm_a, limit,
+            SIMKA_LAUNCH(skm_scan_kernel(wi, fixed, hist), dim3(ntiles), dim3(SKM_BLOCK), scan_lds(hist), st, a, sk, L.d_b1_count, L.d_b1_cursor, L.d_skm_a, limit,
                                hist ? (uint32_t *)nullptr : flag, caprec, rbytes, scan_lcap(hist), use_gather ? (uint32_t *)nullptr : L.d_skm_p);
         }, st);
     };
@@ -853,7 +870,7 @@ static int skm_scan_split(simka_ctx *ctx, simka_ctx::Lane &L, uint32_t sample, c
         rc = ensure_cap(ctx, &L.d_ctab, &L.ctab_cap, nch_max * cstride); if (rc) return rc;
         launch_timed(ctx, KID_SKM_SPLIT, [&] {
             const size_t lds_cs = (((size_t)cstride * 2 + 15) & ~(size_t)15) + 64 + (size_t)SKM_CS_CHUNK * 16;
-            hipLaunchKernelGGL(k_skm_chunksort, dim3((uint32_t)nch_max), dim3(SKM_CS_BLOCK), lds_cs, st, L.d_skm_a, (const ull *)L.d_b1_start, (const ull *)L.d_b1_count,
+            SIMKA_LAUNCH(k_skm_chunksort, dim3((uint32_t)nch_max), dim3(SKM_CS_BLOCK), lds_cs, st, L.d_skm_a, (const ull *)L.d_b1_start, (const ull *)L.d_b1_count,
                                (const uint32_t *)L.d_cbase, sk, L.d_ctab, cstride, (const uint32_t *)flag);
         }, st);
         HIPCHK(hipGetLastError());
@@ -861,7 +878,7 @@ static int skm_scan_split(simka_ctx *ctx, simka_ctx::Lane &L, uint32_t sample, c
     }
     launch_timed(ctx, KID_SKM_SPLIT, [&] {
         const size_t lds_split = ((size_t)1 << sk.l2) * 4 + 64 + ((size_t)1 << sk.l2) * 2 + 48 + (size_t)SKM_SPLIT_BLOCK * SKM_SPLIT_UNROLL * 16;      // (the staging area starts 16-byte aligned behind F2 + 8 shorts)
-        hipLaunchKernelGGL(k_skm_split, dim3(B1), dim3(SKM_SPLIT_BLOCK), lds_split, st, (const uint4 *)L.d_skm_a, (const uint32_t *)L.d_skm_p, (const ull *)L.d_b1_start, (const ull *)L.d_b1_count, sk,
+        SIMKA_LAUNCH(k_skm_split, dim3(B1), dim3(SKM_SPLIT_BLOCK), lds_split, st, (const uint4 *)L.d_skm_a, (const uint32_t *)L.d_skm_p, (const ull *)L.d_b1_start, (const ull *)L.d_b1_count, sk,
                            L.d_skm_b, L.d_pstart, L.d_pcnt, (const uint32_t *)flag);
     }, st);
     HIPCHK(hipGetLastError());
@@ -903,6 +920,7 @@ static int run_count_kernels(simka_ctx *ctx, uint32_t sample, const SimkaScanArg
         ctx->lane_bound[sample % ctx->nlanes] = bound;
         rc = arena_ensure(ctx, ctx->arena_hi); if (rc) return rc;
     }
+    simka_trace::set_arena(ctx->trace_id, sample, ctx->arena_mapped, ctx->arena_hi, ctx->arena_cap);
     SimkaCountOut o;
     o.arena_cursor = ctx->d_arena_cursor; o.sample_base = ctx->d_sample_base + sample; o.arena_cap = ctx->arena_vmm ? std::min(ctx->arena_mapped, ctx->arena_cap) : ctx->arena_cap;
     o.solid_keys = ctx->d_solid_keys; o.solid_counts = ctx->d_solid_counts;
@@ -959,13 +977,13 @@ static int run_count_kernels(simka_ctx *ctx, uint32_t sample, const SimkaScanArg
             static const uint32_t bpc_env = simka_exp_knob("SIMKA_SKM_BPC") ? (uint32_t)atoi(simka_exp_knob("SIMKA_SKM_BPC")) : 0u;     // experiments
             // (the dispatcher hands out LDS in granules of 1280 bytes, 128 per CU: scripts/ubench/lds_occupancy.hip)
             const uint32_t bpc = bpc_env ? bpc_env : (uint32_t)std::max<size_t>(1, std::min<size_t>(4, 128 / ((lds_fast + 1279) / 1280)));
-            hipLaunchKernelGGL(gather ? k_skm_count_fast<true> : k_skm_count_fast<false>, dim3((uint32_t)std::min<uint64_t>(ctx->nparts, (uint64_t)ctx->num_cus * bpc)), dim3(SKM_FAST_BLOCK), lds_fast, st,
+            SIMKA_LAUNCH(gather ? k_skm_count_fast<true> : k_skm_count_fast<false>, dim3((uint32_t)std::min<uint64_t>(ctx->nparts, (uint64_t)ctx->num_cus * bpc)), dim3(SKM_FAST_BLOCK), lds_fast, st,
                                src, sk, ctx->key, ctx->cfg.abundance_min, ctx->cfg.abundance_max, o, (const uint32_t *)flag, kocc,
                                L.d_redo_list, L.d_redo_count);
         }, st);
     launch_timed(ctx, KID_COUNT, [&] {
         const uint32_t grid = general_only ? (uint32_t)std::min<uint64_t>(ctx->nparts, (uint64_t)ctx->num_cus * 2) : (uint32_t)ctx->num_cus;
-        hipLaunchKernelGGL(gather ? k_skm_count<true> : k_skm_count<false>, dim3(grid), dim3(SKM_CNT_BLOCK), lds_count, st,
+        SIMKA_LAUNCH(gather ? k_skm_count<true> : k_skm_count<false>, dim3(grid), dim3(SKM_CNT_BLOCK), lds_count, st,
                            src, sk, ctx->key, ctx->cfg.abundance_min, ctx->cfg.abundance_max, o, (const uint32_t *)flag, kocc,
                            general_only ? (const uint32_t *)nullptr : (const uint32_t *)L.d_redo_list, general_only ? (const ull *)nullptr : (const ull *)L.d_redo_count);
     }, st);
@@ -1092,12 +1110,12 @@ static int wide_hash_count(simka_ctx *ctx, uint32_t sample, const void *d_packed
             launch_timed(ctx, KID_SKM_COUNT, [&] {
                 const size_t lds_wf = (size_t)SIMKA_LDS_HEAD + hist_lds + (size_t)(SKM_WF_BLOCK / 64) * skm_wf_wave_bytes(sk.nmax);
                 const uint32_t bpc = (uint32_t)std::max<size_t>(1, std::min<size_t>(4, 128 / ((lds_wf + 1279) / 1280)));      // (LDS granules of 1280 bytes, 128 per CU)
-                hipLaunchKernelGGL(k_skm_count_wide_fast, dim3((uint32_t)std::min<uint64_t>((nparts + 3) / 4, (uint64_t)ctx->num_cus * bpc)), dim3(SKM_WF_BLOCK), lds_wf, st, (const uint4 *)L.d_skm_b,
+                SIMKA_LAUNCH(k_skm_count_wide_fast, dim3((uint32_t)std::min<uint64_t>((nparts + 3) / 4, (uint64_t)ctx->num_cus * bpc)), dim3(SKM_WF_BLOCK), lds_wf, st, (const uint4 *)L.d_skm_b,
                                    (const uint32_t *)L.d_pstart, (const uint32_t *)L.d_pcnt, sk, ctx->cfg.abundance_min, ctx->cfg.abundance_max, wo, o, (const uint32_t *)(ctx->d_l1_ovf + sample),
                                    L.d_redo_list, L.d_redo_count);
             }, st);
         launch_timed(ctx, KID_COUNT, [&] {
-            hipLaunchKernelGGL(k_skm_count_wide, dim3((uint32_t)std::min<uint64_t>(nparts, (uint64_t)ctx->num_cus)), dim3(SKM_CNT_BLOCK), lds_wide, st, (const uint4 *)L.d_skm_b,
+            SIMKA_LAUNCH(k_skm_count_wide, dim3((uint32_t)std::min<uint64_t>(nparts, (uint64_t)ctx->num_cus)), dim3(SKM_CNT_BLOCK), lds_wide, st, (const uint4 *)L.d_skm_b,
                                (const uint32_t *)L.d_pstart, (const uint32_t *)L.d_pcnt, sk, ctx->cfg.abundance_min, ctx->cfg.abundance_max, wo, o, (const uint32_t *)(ctx->d_l1_ovf + sample),
                                general_only ? (const uint32_t *)nullptr : (const uint32_t *)L.d_redo_list, general_only ? (const ull *)nullptr : (const ull *)L.d_redo_count);
         }, st);
@@ -1289,7 +1307,7 @@ static int ingest_text_impl(simka_ctx *ctx, uint32_t sample, const char *text, u
     rc = ensure_cap(ctx, &g.d_tmp, &g.tmp_cap, ntiles + 16 + wscan_tmp_u32(ntiles) + 16); if (rc) return rc;
     uint32_t *d_cnt = g.d_tmp;
     HIPCHK(hipMemsetAsync(g.d_tot, 0, 32, st));
-    hipLaunchKernelGGL(k_ing_nl_count, dim3((uint32_t)ntiles), dim3(ING_BLOCK), 0, st, txt, nb_bytes, d_cnt);
+    SIMKA_LAUNCH(k_ing_nl_count, dim3((uint32_t)ntiles), dim3(ING_BLOCK), 0, st, txt, nb_bytes, d_cnt);
     uint32_t last_cnt = 0, last_off = 0;
     HIPCHK(hipMemcpyAsync(&last_cnt, d_cnt + ntiles - 1, 4, hipMemcpyDeviceToHost, st));
     HIPCHK(wscan_u32(d_cnt, d_cnt, ntiles, g.d_tmp + ntiles + 16, st));
@@ -1301,12 +1319,12 @@ static int ingest_text_impl(simka_ctx *ctx, uint32_t sample, const char *text, u
     rc = ensure_cap(ctx, &g.d_lines, &g.lines_cap, block_need); if (rc) return rc;
     g.d_lb = g.d_lines + la; g.d_lf = g.d_lb + la;
     uint32_t *d_lbo = g.d_lf + la, *d_scan = d_lbo + la;
-    hipLaunchKernelGGL(k_ing_nl_fill, dim3((uint32_t)ntiles), dim3(ING_BLOCK), 0, st, txt, nb_bytes, (const uint32_t *)d_cnt, g.d_lines);
+    SIMKA_LAUNCH(k_ing_nl_fill, dim3((uint32_t)ntiles), dim3(ING_BLOCK), 0, st, txt, nb_bytes, (const uint32_t *)d_cnt, g.d_lines);
     const uint32_t sentinel = (uint32_t)nb_bytes + 1u;
-    hipLaunchKernelGGL(k_store_u32, dim3(1), dim3(1), 0, st, g.d_lines + nlines, sentinel);
+    SIMKA_LAUNCH(k_store_u32, dim3(1), dim3(1), 0, st, g.d_lines + nlines, sentinel);
     // ---- per line: bases, fragments that start in it, reads; prefix sums (the counts of the last line are read before the in-place scan)
     const uint32_t lgrid = (uint32_t)((nlines + ING_BLOCK - 1) / ING_BLOCK);
-    hipLaunchKernelGGL(k_ing_lines, dim3(lgrid), dim3(ING_BLOCK), 0, st, txt, (const uint32_t *)g.d_lines, (uint32_t)nlines, format, g.d_lb, g.d_lf, g.d_tot);
+    SIMKA_LAUNCH(k_ing_lines, dim3(lgrid), dim3(ING_BLOCK), 0, st, txt, (const uint32_t *)g.d_lines, (uint32_t)nlines, format, g.d_lb, g.d_lf, g.d_tot);
     uint32_t lastb = 0, lastf = 0, sumb = 0, sumf = 0;
     HIPCHK(hipMemcpyAsync(&lastf, g.d_lf + nlines - 1, 4, hipMemcpyDeviceToHost, st));
     HIPCHK(wscan_u32(g.d_lf, g.d_lf, nlines, d_scan, st));
@@ -1327,7 +1345,7 @@ static int ingest_text_impl(simka_ctx *ctx, uint32_t sample, const char *text, u
     if (g.nb_bases == 0) HIPCHK(hipMemsetAsync(ctx->d_reads[li], 0, words_need * 8, st));
     else HIPCHK(hipMemsetAsync(ctx->d_reads[li] + words_now, 0, (words_need - words_now) * 8, st));      // (the last word so far keeps its bases: its upper bits are zero)
     if (fbases)
-        hipLaunchKernelGGL(k_ing_pack, dim3(lgrid), dim3(ING_BLOCK), 0, st, txt, (const uint32_t *)g.d_lines, (uint32_t)nlines, format, (const uint32_t *)g.d_lb,
+        SIMKA_LAUNCH(k_ing_pack, dim3(lgrid), dim3(ING_BLOCK), 0, st, txt, (const uint32_t *)g.d_lines, (uint32_t)nlines, format, (const uint32_t *)g.d_lb,
                            (const uint32_t *)d_lbo, (const uint32_t *)g.d_lf, (ull)g.nb_bases, (ull)g.nb_frags, (ull *)ctx->d_reads[li], (ull *)ctx->d_offsets[li]);
     HIPCHK(hipGetLastError());
     g.nb_bases += fbases; g.nb_frags += ffrags; g.nb_reads += tot[0];
@@ -1357,7 +1375,7 @@ SIMKA_EXPORT int simka_ingest_count(simka_ctx *ctx, uint32_t sample, uint64_t *n
     r.nb_bases = g.nb_bases; r.nb_reads = g.nb_frags; r.nb_input_reads = g.nb_reads; r.on_device = 1; r.fixed_len = 0;
     if (g.nb_bases) {
         const ull end = g.nb_bases;
-        hipLaunchKernelGGL(k_store_u64, dim3(1), dim3(1), 0, ctx->copy_stream, (ull *)(ctx->d_offsets[li] + g.nb_frags), end);
+        SIMKA_LAUNCH(k_store_u64, dim3(1), dim3(1), 0, ctx->copy_stream, (ull *)(ctx->d_offsets[li] + g.nb_frags), end);
         HIPCHK(hipStreamSynchronize(ctx->copy_stream));
         r.packed = ctx->d_reads[li]; r.offsets = ctx->d_offsets[li];
     }
@@ -1459,7 +1477,7 @@ static int export_sample(simka_ctx *ctx, uint32_t sample, uint32_t *part_counts,
     }
     hipError_t e = hipMemcpyAsync(d_off, off.data(), (ctx->nparts + 1) * 8, hipMemcpyHostToDevice, ctx->stream);
     if (e == hipSuccess) {
-        hipLaunchKernelGGL(k_gather_sample, dim3((uint32_t)std::min<uint64_t>(ctx->nparts, (uint64_t)ctx->num_cus * 8)), dim3(256), 0, ctx->stream,
+        SIMKA_LAUNCH(k_gather_sample, dim3((uint32_t)std::min<uint64_t>(ctx->nparts, (uint64_t)ctx->num_cus * 8)), dim3(256), 0, ctx->stream,
                            ctx->d_solid_keys, ctx->d_solid_counts, ctx->d_sample_base + sample, ctx->d_foff + (uint64_t)sample * ctx->nparts,
                            ctx->d_fcnt + (uint64_t)sample * ctx->nparts, d_off, (uint32_t)ctx->nparts, d_keys, d_counts);
         e = hipGetLastError();
@@ -1655,7 +1673,7 @@ SIMKA_EXPORT int simka_gather_samples_device(simka_ctx *ctx, const uint32_t *sam
     uint32_t *d_samples = (uint32_t *)(ctx->d_xoff + (uint64_t)nb * ctx->nparts);
     HIPCHK(hipMemcpyAsync(ctx->d_xoff, stage_h2d(ctx, 1, out_offsets, (size_t)nb * ctx->nparts * 8), (uint64_t)nb * ctx->nparts * 8, hipMemcpyHostToDevice, ctx->stream));
     HIPCHK(hipMemcpyAsync(d_samples, samples, (size_t)nb * 4, hipMemcpyHostToDevice, ctx->stream));
-    hipLaunchKernelGGL(k_gather_samples, dim3((uint32_t)std::min<uint64_t>(ctx->nparts, (uint64_t)ctx->num_cus * 4), nb), dim3(256), 0, ctx->stream,
+    SIMKA_LAUNCH(k_gather_samples, dim3((uint32_t)std::min<uint64_t>(ctx->nparts, (uint64_t)ctx->num_cus * 4), nb), dim3(256), 0, ctx->stream,
                        ctx->d_solid_keys, ctx->d_solid_counts, ctx->d_sample_base, ctx->d_foff, ctx->d_fcnt, d_samples, ctx->d_xoff,
                        (uint32_t)ctx->nparts, (ull *)d_keys, (uint32_t *)d_counts);
     HIPCHK(hipGetLastError());
@@ -1671,16 +1689,16 @@ SIMKA_EXPORT int simka_pack_plan(simka_ctx *ctx, const uint32_t *samples, uint32
     for (uint32_t j = 0; j < nb; j++)
         if (samples[j] >= N || !ctx->counted[samples[j]]) return ctx->fail(SIMKA_ERR_STATE, "simka_pack_plan: sample %u not counted", samples[j]);
     for (uint32_t g = 0; g < nb_ranges; g++) send_records[g] = 0;
-    ctx->plan_samples.assign(samples, samples + nb); ctx->plan_ranges = nb_ranges; ctx->plan_total = 0;
-    if (nb == 0 || !ctx->geometry_ready) return SIMKA_OK;
-    if (nb_ranges > ctx->nparts) return ctx->fail(SIMKA_ERR_INVALID, "simka_pack_plan: more ranges (%u) than partitions", nb_ranges);
+    ctx->drop_plan();            // (a plan exists only once every check below has passed)
+    if (ctx->geometry_ready && nb_ranges > ctx->nparts) return ctx->fail(SIMKA_ERR_INVALID, "simka_pack_plan: more ranges (%u) than partitions", nb_ranges);
+    if (nb == 0 || !ctx->geometry_ready) { ctx->plan_samples.assign(samples, samples + nb); ctx->plan_ranges = nb_ranges; ctx->plan_valid = true; return SIMKA_OK; }
     HIPCHK(hipSetDevice(ctx->cfg.device));
     int rc = resolve_pending(ctx); if (rc) return rc;
     rc = check_device_error(ctx); if (rc) return rc;
     rc = ensure_cap(ctx, &ctx->d_xrows, &ctx->xrows_cap, (uint64_t)nb * nb_ranges); if (rc) return rc;
     rc = ensure_cap(ctx, &ctx->d_xsamples, &ctx->xsamples_cap, (uint64_t)nb); if (rc) return rc;
     HIPCHK(hipMemcpyAsync(ctx->d_xsamples, samples, (size_t)nb * 4, hipMemcpyHostToDevice, ctx->stream));
-    hipLaunchKernelGGL(k_range_rowsum, dim3(nb_ranges, nb), dim3(256), 0, ctx->stream, (const uint32_t *)ctx->d_fcnt, (const uint32_t *)ctx->d_xsamples, (uint32_t)ctx->nparts, nb_ranges, ctx->d_xrows);
+    SIMKA_LAUNCH(k_range_rowsum, dim3(nb_ranges, nb), dim3(256), 0, ctx->stream, (const uint32_t *)ctx->d_fcnt, (const uint32_t *)ctx->d_xsamples, (uint32_t)ctx->nparts, nb_ranges, ctx->d_xrows);
     std::vector<ull> rows((size_t)nb * nb_ranges), starts((size_t)nb * nb_ranges);
     HIPCHK(hipMemcpyAsync(rows.data(), ctx->d_xrows, rows.size() * 8, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));
@@ -1688,25 +1706,27 @@ SIMKA_EXPORT int simka_pack_plan(simka_ctx *ctx, const uint32_t *samples, uint32
     for (uint32_t g = 0; g < nb_ranges; g++) {          // destination-major: [g][slot j][partitions of g]
         for (uint32_t j = 0; j < nb; j++) { starts[(size_t)j * nb_ranges + g] = pos; pos += rows[(size_t)j * nb_ranges + g]; send_records[g] += rows[(size_t)j * nb_ranges + g]; }
     }
-    ctx->plan_total = pos;
     HIPCHK(hipMemcpyAsync(ctx->d_xrows, starts.data(), starts.size() * 8, hipMemcpyHostToDevice, ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));          // (starts is a local)
+    ctx->plan_samples.assign(samples, samples + nb); ctx->plan_ranges = nb_ranges; ctx->plan_total = pos; ctx->plan_valid = true;
     return SIMKA_OK;
 }
 
 SIMKA_EXPORT int simka_pack_run(simka_ctx *ctx, void *d_keys, void *d_counts, int32_t *d_meta, uint32_t nb_slots, uint32_t width) {
     if (!ctx) return SIMKA_ERR_INVALID;
+    // the plan lives in d_xrows / d_xsamples: simka_reset, an import or a failed simka_pack_plan drop it (stale starts and sample ids would
+    // send the gather out of bounds)
+    if (!ctx->plan_valid || ctx->plan_ranges == 0) return ctx->fail(SIMKA_ERR_STATE, "simka_pack_run: no valid plan (simka_pack_plan first; simka_reset and the imports drop it)");
     const uint32_t nb = (uint32_t)ctx->plan_samples.size(), G = ctx->plan_ranges;
     if (nb == 0 || !ctx->geometry_ready) return SIMKA_OK;
-    if (G == 0) return ctx->fail(SIMKA_ERR_STATE, "simka_pack_run: no plan (simka_pack_plan first)");
     if (ctx->plan_total && (!d_keys || !d_counts)) return ctx->fail(SIMKA_ERR_INVALID, "simka_pack_run: NULL buffers");
     const uint32_t maxw = (uint32_t)((ctx->nparts + G - 1) / G);
     if (d_meta && (nb_slots < nb || width < maxw)) return ctx->fail(SIMKA_ERR_INVALID, "simka_pack_run: meta of %u slots x %u partitions, the plan needs %u x %u", nb_slots, width, nb, maxw);
     HIPCHK(hipSetDevice(ctx->cfg.device));
     int rc = ensure_cap(ctx, &ctx->d_xoff, &ctx->xoff_cap, (uint64_t)nb * ctx->nparts + 1); if (rc) return rc;
-    hipLaunchKernelGGL(k_range_offsets, dim3(nb), dim3(1024), 0, ctx->stream, (const uint32_t *)ctx->d_fcnt, (const uint32_t *)ctx->d_xsamples, (uint32_t)ctx->nparts, G,
+    SIMKA_LAUNCH(k_range_offsets, dim3(nb), dim3(1024), 0, ctx->stream, (const uint32_t *)ctx->d_fcnt, (const uint32_t *)ctx->d_xsamples, (uint32_t)ctx->nparts, G,
                        (const ull *)ctx->d_xrows, ctx->d_xoff, d_meta, nb_slots, width);
-    hipLaunchKernelGGL(k_gather_samples, dim3((uint32_t)std::min<uint64_t>(ctx->nparts, (uint64_t)ctx->num_cus * 4), nb), dim3(256), 0, ctx->stream,
+    SIMKA_LAUNCH(k_gather_samples, dim3((uint32_t)std::min<uint64_t>(ctx->nparts, (uint64_t)ctx->num_cus * 4), nb), dim3(256), 0, ctx->stream,
                        ctx->d_solid_keys, ctx->d_solid_counts, ctx->d_sample_base, ctx->d_foff, ctx->d_fcnt, ctx->d_xsamples, ctx->d_xoff,
                        (uint32_t)ctx->nparts, (ull *)d_keys, (uint32_t *)d_counts);
     HIPCHK(hipGetLastError());
@@ -1745,26 +1765,40 @@ SIMKA_EXPORT int simka_import_block_device(simka_ctx *ctx, const uint32_t *slot_
         return ctx->fail(SIMKA_ERR_INVALID, "simka_import_block_device: spectra have %llu partitions, this run %llu", (unsigned long long)nb_partitions, (unsigned long long)ctx->nparts);
     rc = resolve_pending(ctx); if (rc) return rc;
     const uint64_t P = ctx->nparts;
+    ctx->drop_plan();            // (d_xrows / d_xsamples hold a pack plan until here)
     rc = ensure_cap(ctx, &ctx->d_xrows, &ctx->xrows_cap, (uint64_t)nb_slots_total); if (rc) return rc;
     rc = ensure_cap(ctx, &ctx->d_xsamples, &ctx->xsamples_cap, (uint64_t)nb_slots_total); if (rc) return rc;
     HIPCHK(hipMemcpyAsync(ctx->d_xsamples, slot_samples, (size_t)nb_slots_total * 4, hipMemcpyHostToDevice, ctx->stream));
-    hipLaunchKernelGGL(k_import_tables, dim3(nb_slots_total), dim3(1024), 0, ctx->stream, d_meta, (const uint32_t *)ctx->d_xsamples, width, (uint32_t)part_width, (uint32_t)P, (uint32_t)part_lo,
+    SIMKA_LAUNCH(k_import_tables, dim3(nb_slots_total), dim3(1024), 0, ctx->stream, d_meta, (const uint32_t *)ctx->d_xsamples, width, (uint32_t)part_width, (uint32_t)P, (uint32_t)part_lo,
                        ctx->d_foff, ctx->d_fcnt, ctx->d_xrows);
     std::vector<ull> slot_tot(nb_slots_total);
     ull cursor = 0;
-    HIPCHK(hipMemcpyAsync(slot_tot.data(), ctx->d_xrows, (size_t)nb_slots_total * 8, hipMemcpyDeviceToHost, ctx->stream));
-    HIPCHK(hipMemcpyAsync(&cursor, ctx->d_arena_cursor, 8, hipMemcpyDeviceToHost, ctx->stream));
-    HIPCHK(hipStreamSynchronize(ctx->stream));
+    // k_import_tables has written the foff / fcnt rows of the target samples (the slot totals come out of the same scan): a block that
+    // is rejected below must not leave them behind -- the samples stay "not counted", and a later merge would walk rows that point
+    // anywhere.  The rows of a sample that is not counted are all zero, so clearing the partition range restores them.
+    auto rollback = [&](int code) {
+        for (uint32_t q = 0; q < nb_slots_total; q++) {
+            const uint32_t s = slot_samples[q];
+            if (s == 0xffffffffu || part_width == 0) continue;
+            (void)hipMemsetAsync(ctx->d_foff + (uint64_t)s * P + part_lo, 0, (size_t)part_width * 4, ctx->stream);
+            (void)hipMemsetAsync(ctx->d_fcnt + (uint64_t)s * P + part_lo, 0, (size_t)part_width * 4, ctx->stream);
+        }
+        (void)hipStreamSynchronize(ctx->stream);
+        return code;
+    };
+    if (hipMemcpyAsync(slot_tot.data(), ctx->d_xrows, (size_t)nb_slots_total * 8, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
+        hipMemcpyAsync(&cursor, ctx->d_arena_cursor, 8, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess || hipStreamSynchronize(ctx->stream) != hipSuccess)
+        return rollback(ctx->fail(SIMKA_ERR_HIP, "simka_import_block_device: reading the slot totals failed: %s", hipGetErrorString(hipGetLastError())));
     ull sum = 0;
     for (uint32_t q = 0; q < nb_slots_total; q++) {
-        if (slot_tot[q] > 0xffffffffull) return ctx->fail(SIMKA_ERR_INVALID, "simka_import_block_device: slot %u holds more than 2^32 records", q);
+        if (slot_tot[q] > 0xffffffffull) return rollback(ctx->fail(SIMKA_ERR_INVALID, "simka_import_block_device: slot %u holds more than 2^32 records", q));
         sum += slot_tot[q];
     }
-    if (sum != nb_records) return ctx->fail(SIMKA_ERR_INVALID, "simka_import_block_device: the meta rows sum to %llu records, nb_records is %llu", (unsigned long long)sum, (unsigned long long)nb_records);
+    if (sum != nb_records) return rollback(ctx->fail(SIMKA_ERR_INVALID, "simka_import_block_device: the meta rows sum to %llu records, nb_records is %llu", (unsigned long long)sum, (unsigned long long)nb_records));
     if (cursor + nb_records > ctx->arena_cap)
-        return ctx->fail(SIMKA_ERR_NOMEM, "solid-spectrum arena exhausted (%llu records): raise solid_capacity", (unsigned long long)ctx->arena_cap);
+        return rollback(ctx->fail(SIMKA_ERR_NOMEM, "solid-spectrum arena exhausted (%llu records): raise solid_capacity", (unsigned long long)ctx->arena_cap));
     const ull next = cursor + nb_records;
-    rc = arena_ensure(ctx, next); if (rc) return rc;
+    rc = arena_ensure(ctx, next); if (rc) return rollback(rc);
     ctx->arena_hi = std::max<uint64_t>(ctx->arena_hi, next);
     if (nb_records) {
         HIPCHK(hipMemcpyAsync(ctx->d_solid_keys + cursor, d_keys, nb_records * 8, hipMemcpyDeviceToDevice, ctx->stream));
@@ -1793,7 +1827,7 @@ SIMKA_EXPORT int simka_import_block_device(simka_ctx *ctx, const uint32_t *slot_
             const uint32_t s = slot_samples[q];
             if (s == 0xffffffffu) continue;
             HIPCHK(hipMemsetAsync(ctx->d_hist + (uint64_t)s * SIMKA_HIST_MAX, 0, (size_t)SIMKA_HIST_MAX * 8, ctx->stream));
-            hipLaunchKernelGGL(k_import_hist, dim3(gx, 1), dim3(256), 0, ctx->stream, (const uint32_t *)ctx->d_solid_counts, (const ull *)ctx->d_sample_base,
+            SIMKA_LAUNCH(k_import_hist, dim3(gx, 1), dim3(256), 0, ctx->stream, (const uint32_t *)ctx->d_solid_counts, (const ull *)ctx->d_sample_base,
                                (const uint32_t *)ctx->d_foff, (const uint32_t *)ctx->d_fcnt, (uint32_t)P, (uint32_t)part_lo, (uint32_t)part_width, s, (ull *)ctx->d_hist,
                                ctx->d_ovf_list, (ull *)ctx->d_ovf_cursor, (ull)ctx->ovf_cap);
         }
@@ -1907,7 +1941,7 @@ SIMKA_EXPORT int simka_import_samples_device(simka_ctx *ctx, const uint32_t *sam
         bool hist_ok = true;
         auto launch = [&](uint32_t s0, uint32_t ns) {
             if (hipMemsetAsync(ctx->d_hist + (uint64_t)s0 * SIMKA_HIST_MAX, 0, (size_t)ns * SIMKA_HIST_MAX * 8, ctx->stream) != hipSuccess) { hist_ok = false; return; }
-            hipLaunchKernelGGL(k_import_hist, dim3(gx, ns), dim3(256), 0, ctx->stream, (const uint32_t *)ctx->d_solid_counts, (const ull *)ctx->d_sample_base,
+            SIMKA_LAUNCH(k_import_hist, dim3(gx, ns), dim3(256), 0, ctx->stream, (const uint32_t *)ctx->d_solid_counts, (const ull *)ctx->d_sample_base,
                                (const uint32_t *)ctx->d_foff, (const uint32_t *)ctx->d_fcnt, (uint32_t)P, (uint32_t)pmin, (uint32_t)w, s0, (ull *)ctx->d_hist,
                                ctx->d_ovf_list, (ull *)ctx->d_ovf_cursor, (ull)ctx->ovf_cap);
         };
@@ -2027,26 +2061,26 @@ static void pair_launch(simka_ctx *ctx, const PairLaunch &pl, const SimkaSpan *s
     if (work && hipMemsetAsync(work, 0, 8, ctx->stream) != hipSuccess) work = nullptr;
     if (have_spans) launch_timed(ctx, KID_PAIRS, [&] {
         if (pl.small_block)
-            hipLaunchKernelGGL((k_pairs<false, K4_BLOCK_SMALL>), dim3(pl.nblk, pl.ntp), dim3(K4_BLOCK_SMALL), pl.lds_pairs, ctx->stream, spans, cursors, entries, groups, pc, acc, work);
+            SIMKA_LAUNCH((k_pairs<false, K4_BLOCK_SMALL>), dim3(pl.nblk, pl.ntp), dim3(K4_BLOCK_SMALL), pl.lds_pairs, ctx->stream, spans, cursors, entries, groups, pc, acc, work);
 #ifdef SIMKA_DEBUG_KNOBS
         else if (pc.ntiles == 1 && simka_exp_knob("SIMKA_PAIRS_BLOCK512"))      // experiments: eight waves per block instead of sixteen
-            hipLaunchKernelGGL((k_pairs<false, 512>), dim3(pl.nblk, pl.ntp), dim3(512), pl.lds_pairs, ctx->stream, spans, cursors, entries, groups, pc, acc, work);
+            SIMKA_LAUNCH((k_pairs<false, 512>), dim3(pl.nblk, pl.ntp), dim3(512), pl.lds_pairs, ctx->stream, spans, cursors, entries, groups, pc, acc, work);
 #endif
         else if (pc.ntiles == 1)
-            hipLaunchKernelGGL((k_pairs<false, K4_BLOCK_BIG>), dim3(pl.nblk, pl.ntp), dim3(K4_BLOCK_BIG), pl.lds_pairs, ctx->stream, spans, cursors, entries, groups, pc, acc, work);
+            SIMKA_LAUNCH((k_pairs<false, K4_BLOCK_BIG>), dim3(pl.nblk, pl.ntp), dim3(K4_BLOCK_BIG), pl.lds_pairs, ctx->stream, spans, cursors, entries, groups, pc, acc, work);
         else if (tile_major) {
             const uint32_t grid_tm = (uint32_t)std::min<uint64_t>((nb_spans + KTM_WAVES - 1) / KTM_WAVES, (uint64_t)ctx->num_cus * 4);
-            hipLaunchKernelGGL(k_tile_major, dim3(grid_tm), dim3(64 * KTM_WAVES), 0, ctx->stream, spans, cursors, entries, groups, pc, ctx->d_tm_ent, ctx->d_tm_p, ctx->d_tm_off);
-            if (pc.nacc64) hipLaunchKernelGGL(k_pairs_tm<true>, dim3(pl.nblk, pl.ntp), dim3(K4_BLOCK_BIG), pl.lds_pairs, ctx->stream, spans, cursors, (const ull *)ctx->d_tm_ent,
+            SIMKA_LAUNCH(k_tile_major, dim3(grid_tm), dim3(64 * KTM_WAVES), 0, ctx->stream, spans, cursors, entries, groups, pc, ctx->d_tm_ent, ctx->d_tm_p, ctx->d_tm_off);
+            if (pc.nacc64) SIMKA_LAUNCH(k_pairs_tm<true>, dim3(pl.nblk, pl.ntp), dim3(K4_BLOCK_BIG), pl.lds_pairs, ctx->stream, spans, cursors, (const ull *)ctx->d_tm_ent,
                                               (const ktm_p_t *)ctx->d_tm_p, (const uint32_t *)ctx->d_tm_off, pc, acc);
-            else hipLaunchKernelGGL(k_pairs_tm<false>, dim3(pl.nblk, pl.ntp), dim3(K4_BLOCK_BIG), pl.lds_pairs, ctx->stream, spans, cursors, (const ull *)ctx->d_tm_ent,
+            else SIMKA_LAUNCH(k_pairs_tm<false>, dim3(pl.nblk, pl.ntp), dim3(K4_BLOCK_BIG), pl.lds_pairs, ctx->stream, spans, cursors, (const ull *)ctx->d_tm_ent,
                                     (const ktm_p_t *)ctx->d_tm_p, (const uint32_t *)ctx->d_tm_off, pc, acc);
         } else {
             // (the tile-major buffers could not be had, or too many tiles: the scan-and-compact kernel with its own LDS layout;
             // the spans were built for pc.span_cap entries, which its tile geometry keeps)
             PairLaunch lg = pl;
             if (tile_major_enabled()) pair_setup(ctx, lg, true, pl.pc.span_cap);
-            hipLaunchKernelGGL((k_pairs<true, K4_BLOCK_BIG>), dim3(lg.nblk, lg.ntp), dim3(K4_BLOCK_BIG), lg.lds_pairs, ctx->stream, spans, cursors, entries, groups, lg.pc, acc, (ull *)nullptr);
+            SIMKA_LAUNCH((k_pairs<true, K4_BLOCK_BIG>), dim3(lg.nblk, lg.ntp), dim3(K4_BLOCK_BIG), lg.lds_pairs, ctx->stream, spans, cursors, entries, groups, lg.pc, acc, (ull *)nullptr);
         }
     });
 #ifdef SIMKA_PHASE_PROF
@@ -2055,7 +2089,7 @@ static void pair_launch(simka_ctx *ctx, const PairLaunch &pl, const SimkaSpan *s
 #endif
     if (huge)
         launch_timed(ctx, KID_PAIRS_GLOBAL, [&] {
-            hipLaunchKernelGGL(k_pairs_global, dim3(64, 64), dim3(256), 0, ctx->stream, huge, cursors, entries, pc, acc);
+            SIMKA_LAUNCH(k_pairs_global, dim3(64, 64), dim3(256), 0, ctx->stream, huge, cursors, entries, pc, acc);
         });
 }
 
@@ -2129,6 +2163,7 @@ SIMKA_EXPORT int simka_merge(simka_ctx *ctx) {
     for (uint32_t s = 0; s < N; s++) if (!ctx->counted[s]) return ctx->fail(SIMKA_ERR_STATE, "simka_merge: sample %u has not been counted", s);
     if (ctx->merged) return ctx->fail(SIMKA_ERR_STATE, "simka_merge: already merged");
     HIPCHK(hipSetDevice(ctx->cfg.device));
+    simka_trace::set_arena(ctx->trace_id, 0xffffffffu, ctx->arena_mapped, ctx->arena_hi, ctx->arena_cap);      // (sample ~0: the merge)
     int rc = resolve_pending(ctx);
     if (rc) return rc;
     rc = check_device_error(ctx);
@@ -2163,7 +2198,7 @@ SIMKA_EXPORT int simka_merge(simka_ctx *ctx) {
     // records per partition over all samples -> host scan (also drives the batching)
     HIPCHK(hipMemsetAsync(ctx->d_part_total + nparts, 0, 8, ctx->stream));
     launch_timed(ctx, KID_PART_TOTALS, [&] {
-        hipLaunchKernelGGL(k_part_totals, dim3((uint32_t)((nparts + 255) / 256)), dim3(256), 0, ctx->stream, ctx->d_fcnt, N,
+        SIMKA_LAUNCH(k_part_totals, dim3((uint32_t)((nparts + 255) / 256)), dim3(256), 0, ctx->stream, ctx->d_fcnt, N,
                            nparts, ctx->d_part_total);
     });
     if (ctx->h_part_n < 2 * (nparts + 1)) {
@@ -2272,12 +2307,12 @@ SIMKA_EXPORT int simka_merge(simka_ctx *ctx) {
             uint4 *b_rows = rows32 ? r32.rows : ctx->d_seg_rows + (ctx->seg_all ? pb * N * 2 : 0);
             if (rows32 || !ctx->seg_all || ctx->seg_dirty)
                 launch_timed(ctx, KID_SEG_ROWS, [&] {
-                    hipLaunchKernelGGL(rows32 ? k_segment_rows<true> : k_segment_rows<false>, dim3((uint32_t)std::min<uint64_t>(((uint64_t)np * N + 3) / 4, (uint64_t)ctx->num_cus * 8)), dim3(256), 0, ctx->stream, in, key, pb, np,
+                    SIMKA_LAUNCH(rows32 ? k_segment_rows<true> : k_segment_rows<false>, dim3((uint32_t)std::min<uint64_t>(((uint64_t)np * N + 3) / 4, (uint64_t)ctx->num_cus * 8)), dim3(256), 0, ctx->stream, in, key, pb, np,
                                        b_abs, b_rows, ctx->d_err);
                 });
             launch_timed(ctx, KID_GROUP, [&] {
                 auto kg = group_big ? (rows32 ? k_group<2 * K3_BLOCK, true> : k_group<2 * K3_BLOCK, false>) : (rows32 ? k_group<K3_BLOCK, true> : k_group<K3_BLOCK, false>);
-                hipLaunchKernelGGL(kg, dim3(std::max<uint32_t>(32u, std::min<uint32_t>((np * 4u + 31u) / 32u * 32u, grid_group / 32u * 32u))),
+                SIMKA_LAUNCH(kg, dim3(std::max<uint32_t>(32u, std::min<uint32_t>((np * 4u + 31u) / 32u * 32u, grid_group / 32u * 32u))),
                                    dim3(group_big ? 2 * K3_BLOCK : K3_BLOCK), lds_group, ctx->stream, in, (const ull *)b_abs, (const uint16_t *)b_rows, np, key, min_share, co, (uint32_t)stride);
             });
             if (simka_exp_knob("SIMKA_DEBUG_MERGE")) {
@@ -2318,7 +2353,7 @@ static int complex_finish(simka_ctx *ctx, const SimkaPairCfg &pc) {
             uint32_t *d_list = nullptr; ull *d_cur = nullptr;
             if (dev_alloc(&d_list, 2 * novf) != hipSuccess || dev_alloc(&d_cur, 1) != hipSuccess) { if (d_list) (void)hipFree(d_list); return ctx->fail(SIMKA_ERR_NOMEM, "cannot allocate the list of %llu large counts", (unsigned long long)novf); }
             HIPCHK(hipMemsetAsync(d_cur, 0, 8, ctx->stream));
-            hipLaunchKernelGGL(k_big_counts, dim3((uint32_t)std::min<uint64_t>(ctx->nparts, 1024), N), dim3(256), 0, ctx->stream, (const uint32_t *)ctx->d_solid_counts,
+            SIMKA_LAUNCH(k_big_counts, dim3((uint32_t)std::min<uint64_t>(ctx->nparts, 1024), N), dim3(256), 0, ctx->stream, (const uint32_t *)ctx->d_solid_counts,
                                (const ull *)ctx->d_sample_base, (const uint32_t *)ctx->d_foff, (const uint32_t *)ctx->d_fcnt, (uint32_t)ctx->nparts, d_list, d_cur, novf);
             ull got = 0;
             HIPCHK(hipMemcpyAsync(&got, d_cur, 8, hipMemcpyDeviceToHost, ctx->stream));
@@ -2683,7 +2718,7 @@ SIMKA_EXPORT int simka_count_paths(simka_ctx *ctx, uint64_t *nb_partitioned, uin
 SIMKA_EXPORT int simka_synth_genomes(void *stream, uint64_t *d_pool, uint32_t nb_genomes, uint64_t genome_words, uint64_t seed) {
     const uint64_t n = (uint64_t)nb_genomes * genome_words;
     if (!d_pool || n == 0) return SIMKA_ERR_INVALID;
-    hipLaunchKernelGGL(k_synth_genomes, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, d_pool, nb_genomes,
+    SIMKA_LAUNCH(k_synth_genomes, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, d_pool, nb_genomes,
                        genome_words, seed);
     return hipGetLastError() == hipSuccess ? SIMKA_OK : SIMKA_ERR_HIP;
 }
@@ -2693,7 +2728,7 @@ SIMKA_EXPORT int simka_synth_reads(void *stream, uint64_t *d_packed, uint64_t nb
     if (!d_packed || !d_pool || !d_ids || !d_cdf || nb_sel == 0 || read_len == 0 || genome_len < read_len) return SIMKA_ERR_INVALID;
     const uint64_t nw = (nb_reads * (uint64_t)read_len + 31) / 32;
     if (nw == 0) return SIMKA_OK;
-    hipLaunchKernelGGL(k_synth_reads, dim3((uint32_t)((nw + 255) / 256)), dim3(256), 0, (hipStream_t)stream, d_packed, nb_reads,
+    SIMKA_LAUNCH(k_synth_reads, dim3((uint32_t)((nw + 255) / 256)), dim3(256), 0, (hipStream_t)stream, d_packed, nb_reads,
                        read_len, d_pool, genome_words, genome_len, d_ids, d_cdf, nb_sel, seed, err_thr);
     return hipGetLastError() == hipSuccess ? SIMKA_OK : SIMKA_ERR_HIP;
 }

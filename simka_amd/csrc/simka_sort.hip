@@ -72,13 +72,13 @@ static hipError_t wscan_u32(const uint32_t *in, uint32_t *out, uint64_t n, uint3
     if (n == 0) return hipSuccess;
     const uint64_t nt = (n + WS_TILE - 1) / WS_TILE;
     if (nt == 1) {
-        hipLaunchKernelGGL(k_ws_scan, dim3(1), dim3(WS_BLOCK), 0, st, in, out, n, (const uint32_t *)nullptr);
+        SIMKA_LAUNCH(k_ws_scan, dim3(1), dim3(WS_BLOCK), 0, st, in, out, n, (const uint32_t *)nullptr);
         return hipGetLastError();
     }
-    hipLaunchKernelGGL(k_ws_reduce, dim3((uint32_t)nt), dim3(WS_BLOCK), 0, st, in, n, tmp);
+    SIMKA_LAUNCH(k_ws_reduce, dim3((uint32_t)nt), dim3(WS_BLOCK), 0, st, in, n, tmp);
     hipError_t e = wscan_u32(tmp, tmp, nt, tmp + nt + 16, st);          // tile sums -> tile offsets, in place
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(k_ws_scan, dim3((uint32_t)nt), dim3(WS_BLOCK), 0, st, in, out, n, (const uint32_t *)tmp);
+    SIMKA_LAUNCH(k_ws_scan, dim3((uint32_t)nt), dim3(WS_BLOCK), 0, st, in, out, n, (const uint32_t *)tmp);
     return hipGetLastError();
 }
 
@@ -174,10 +174,10 @@ static hipError_t wsort_pairs(const ull *kin, ull *kout, const V *vin, V *vout, 
         // the last pass writes the output arrays; the ones before alternate so that it does
         const bool to_out = ((passes - 1u - p) & 1u) == 0u;
         ull *kd = to_out ? kout : kt; V *vd = to_out ? vout : vt;
-        hipLaunchKernelGGL(k_rs_hist, dim3(nt), dim3(RS_BLOCK), 0, st, ks, n, 8u * p, nt, hist);
+        SIMKA_LAUNCH(k_rs_hist, dim3(nt), dim3(RS_BLOCK), 0, st, ks, n, 8u * p, nt, hist);
         hipError_t e = wscan_u32(hist, hist, (uint64_t)nt * RS_DIGITS, stmp, st);
         if (e != hipSuccess) return e;
-        hipLaunchKernelGGL((k_rs_scatter<V>), dim3(nt), dim3(RS_BLOCK), 0, st, ks, vs, kd, vd, n, 8u * p, nt, (const uint32_t *)hist);
+        SIMKA_LAUNCH((k_rs_scatter<V>), dim3(nt), dim3(RS_BLOCK), 0, st, ks, vs, kd, vd, n, 8u * p, nt, (const uint32_t *)hist);
         ks = kd; vs = vd;
     }
     return hipGetLastError();

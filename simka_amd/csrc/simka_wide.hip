@@ -16,6 +16,7 @@
 // must give bit-identical statistics (they do: goldens included).
 #include <hip/hip_runtime.h>
 #include "simka_efence.h"      // (test builds: -DSIMKA_EFENCE)
+#include "simka_trace.h"       // SIMKA_FAULT_TRACE=1: registry of device ranges + ring of launches, dumped when the process dies
 #include <stdint.h>
 #include <algorithm>
 #include <string>
@@ -522,11 +523,11 @@ static int wide_sort(SimkaWide *w, uint64_t n, uint32_t hi_bits, ull *hi0, ull *
     if (n == 0) return 0;
     if (n >= ((uint64_t)1 << 31)) { w->err = "wide-k path: more than 2^31 k-mers in one sort (sample too deep for k >= 32)"; return SIMKA_WIDE_ERR_LIMIT; }
     char *tmp; int rc = wide_buf(w, 11, wsort_tmp_bytes<uint32_t>(n), &tmp); if (rc) return rc;
-    hipLaunchKernelGGL(k_wiota, grid_for(n), dim3(256), 0, w->stream, idx0, n);
+    SIMKA_LAUNCH(k_wiota, grid_for(n), dim3(256), 0, w->stream, idx0, n);
     WCHK(wsort_pairs<uint32_t>(lo0, tmp_key, idx0, idx1, n, 64u, tmp, w->stream));                                   // by lo; idx1 = permutation
-    hipLaunchKernelGGL(k_wgather, grid_for(n), dim3(256), 0, w->stream, hi0, idx1, lo1, n);                          // lo1 := hi in lo-order (scratch use)
+    SIMKA_LAUNCH(k_wgather, grid_for(n), dim3(256), 0, w->stream, hi0, idx1, lo1, n);                          // lo1 := hi in lo-order (scratch use)
     WCHK(wsort_pairs<uint32_t>(lo1, hi1, idx1, idx0, n, hi_bits, tmp, w->stream));                                   // by hi (stable); idx0 = final permutation
-    hipLaunchKernelGGL(k_wgather, grid_for(n), dim3(256), 0, w->stream, lo0, idx0, lo1, n);
+    SIMKA_LAUNCH(k_wgather, grid_for(n), dim3(256), 0, w->stream, lo0, idx0, lo1, n);
     WCHK(hipGetLastError());
     return 0;
 }
@@ -682,8 +683,8 @@ int simka_wide_count_sample(SimkaWide *w, uint32_t sample, const void *packed, u
     WCHK(hipMemsetAsync(d_small, 0, 16 * 8, w->stream));
     WideScanArgs a; a.packed = (const uint64_t *)packed; a.nb_bases = nb_bases; a.nb_words = nb_words; a.offsets = (const uint64_t *)offsets;
     a.nb_reads = nb_reads; a.fixed_len = fixed_len; a.k = w->k; a.shard_index = w->shard_index; a.shard_count = w->shard_count;
-    if (w->shard_count > 1) hipLaunchKernelGGL(k_wscan<true>, grid_for((n + WSEG - 1) / WSEG), dim3(256), 0, w->stream, a, hi0, lo0, d_small /* [0] = nvalid */);
-    else hipLaunchKernelGGL(k_wscan<false>, grid_for((n + WSEG - 1) / WSEG), dim3(256), 0, w->stream, a, hi0, lo0, d_small /* [0] = nvalid */);
+    if (w->shard_count > 1) SIMKA_LAUNCH(k_wscan<true>, grid_for((n + WSEG - 1) / WSEG), dim3(256), 0, w->stream, a, hi0, lo0, d_small /* [0] = nvalid */);
+    else SIMKA_LAUNCH(k_wscan<false>, grid_for((n + WSEG - 1) / WSEG), dim3(256), 0, w->stream, a, hi0, lo0, d_small /* [0] = nvalid */);
     ull nvalid = 0;
     WCHK(hipMemcpyAsync(&nvalid, d_small, 8, hipMemcpyDeviceToHost, w->stream));
     WCHK(hipStreamSynchronize(w->stream));
@@ -699,12 +700,12 @@ int simka_wide_count_sample(SimkaWide *w, uint32_t sample, const void *packed, u
         ull *part = d_small + 16;
         uint32_t *bstart = (uint32_t *)(part + WL_NPART * 8);
         WCHK(hipMemsetAsync(part, 0, (size_t)WL_NPART * 64, w->stream));
-        hipLaunchKernelGGL(k_wocc_key, grid_for(nvalid), dim3(256), 0, w->stream, hi0, lo0, nvalid, bits, hi1, idx0, pack);
+        SIMKA_LAUNCH(k_wocc_key, grid_for(nvalid), dim3(256), 0, w->stream, hi0, lo0, nvalid, bits, hi1, idx0, pack);
         WCHK(wsort_pairs<uint32_t>(hi1, lo1, idx0, idx1, nvalid, bits, tmp, w->stream));          // lo1: the sorted bucket numbers
-        hipLaunchKernelGGL(k_wbucket_bounds, grid_for((uint64_t)nb + 1), dim3(256), 0, w->stream, lo1, nvalid, nb, bstart, (uint32_t *)(d_small + 15));
+        SIMKA_LAUNCH(k_wbucket_bounds, grid_for((uint64_t)nb + 1), dim3(256), 0, w->stream, lo1, nvalid, nb, bstart, (uint32_t *)(d_small + 15));
         ull before[2] = { 0, 0 };
         if (d_ovf_cursor) WCHK(hipMemcpyAsync(before, d_ovf_cursor, 16, hipMemcpyDeviceToHost, w->stream));
-        hipLaunchKernelGGL(k_wlocal_count, dim3(nb), dim3(WL_BLOCK), 0, w->stream, bstart, idx1, pack, amin, amax, ohi, olo, ocnt, part,
+        SIMKA_LAUNCH(k_wlocal_count, dim3(nb), dim3(WL_BLOCK), 0, w->stream, bstart, idx1, pack, amin, amax, ohi, olo, ocnt, part,
                            (ull *)d_hist_row, (uint32_t *)d_ovf_list, (ull *)d_ovf_cursor, (ull)ovf_cap, sample);
         std::vector<ull> ph((size_t)WL_NPART * 8);
         WCHK(hipMemcpyAsync(ph.data(), part, ph.size() * 8, hipMemcpyDeviceToHost, w->stream));
@@ -731,16 +732,16 @@ int simka_wide_count_sample(SimkaWide *w, uint32_t sample, const void *packed, u
     // runs of equal keys
     uint32_t *flag = idx0, *rank = idx1, *start, *sflag, *srank;
     if ((rc = wide_buf(w, 8, nvalid + 2, &start)) || (rc = wide_buf(w, 9, nvalid + 2, &sflag)) || (rc = wide_buf(w, 10, nvalid + 2, &srank))) return rc;
-    hipLaunchKernelGGL(k_wheads, grid_for(nvalid), dim3(256), 0, w->stream, hi1, lo1, nvalid, flag);
+    SIMKA_LAUNCH(k_wheads, grid_for(nvalid), dim3(256), 0, w->stream, hi1, lo1, nvalid, flag);
     if ((rc = wide_scan(w, flag, rank, nvalid))) return rc;
-    hipLaunchKernelGGL(k_wstarts, grid_for(nvalid), dim3(256), 0, w->stream, flag, rank, nvalid, start, (const uint32_t *)nullptr);
+    SIMKA_LAUNCH(k_wstarts, grid_for(nvalid), dim3(256), 0, w->stream, flag, rank, nvalid, start, (const uint32_t *)nullptr);
     uint32_t last_rank = 0, last_flag = 0;
     WCHK(hipMemcpyAsync(&last_rank, rank + (nvalid - 1), 4, hipMemcpyDeviceToHost, w->stream));
     WCHK(hipMemcpyAsync(&last_flag, flag + (nvalid - 1), 4, hipMemcpyDeviceToHost, w->stream));
     WCHK(hipStreamSynchronize(w->stream));
     const uint32_t nruns = last_rank + last_flag;
     totals5[SIMKA_TOT_DALL] = nruns;
-    hipLaunchKernelGGL(k_wfilter, dim3((uint32_t)std::min<uint64_t>((nruns + 255) / 256, 2048)), dim3(256), 0, w->stream, start, nruns, amin, amax, sflag, d_small + 1, (ull *)d_hist_row, (uint32_t *)d_ovf_list,
+    SIMKA_LAUNCH(k_wfilter, dim3((uint32_t)std::min<uint64_t>((nruns + 255) / 256, 2048)), dim3(256), 0, w->stream, start, nruns, amin, amax, sflag, d_small + 1, (ull *)d_hist_row, (uint32_t *)d_ovf_list,
                        (ull *)d_ovf_cursor, (ull)ovf_cap, sample);
     if ((rc = wide_scan(w, sflag, srank, nruns))) return rc;
     ull dnq[3]; uint32_t lr = 0, lf = 0;
@@ -751,7 +752,7 @@ int simka_wide_count_sample(SimkaWide *w, uint32_t sample, const void *packed, u
     const uint64_t nsolid = (uint64_t)lr + lf;
     totals5[SIMKA_TOT_D] = dnq[0]; totals5[SIMKA_TOT_N] = dnq[1]; totals5[SIMKA_TOT_Q] = dnq[2];
     if ((rc = arena_reserve(w, nsolid))) return rc;
-    if (nsolid) hipLaunchKernelGGL(k_wemit, grid_for(nruns), dim3(256), 0, w->stream, hi1, lo1, start, sflag, srank, nruns, w->a_hi + w->a_used, w->a_lo + w->a_used,
+    if (nsolid) SIMKA_LAUNCH(k_wemit, grid_for(nruns), dim3(256), 0, w->stream, hi1, lo1, start, sflag, srank, nruns, w->a_hi + w->a_used, w->a_lo + w->a_used,
                                    w->a_cnt + w->a_used);
     WCHK(hipGetLastError());
     w->s_n[sample] = nsolid;
@@ -793,9 +794,9 @@ int simka_wide_adopt(SimkaWide *w, uint32_t sample, const void *d_hi, const void
     } else {
         uint32_t *flag, *rank;
         if ((rc = wide_buf(w, 5, nb_slots + 2, &flag)) || (rc = wide_buf(w, 6, nb_slots + 2, &rank))) return rc;
-        hipLaunchKernelGGL(k_wused, grid_for(nb_slots), dim3(256), 0, w->stream, (const uint32_t *)d_cnt, nb_slots, flag);
+        SIMKA_LAUNCH(k_wused, grid_for(nb_slots), dim3(256), 0, w->stream, (const uint32_t *)d_cnt, nb_slots, flag);
         if ((rc = wide_scan(w, flag, rank, nb_slots))) return rc;
-        hipLaunchKernelGGL(k_wcompact, grid_for(nb_slots), dim3(256), 0, w->stream, (const ull *)d_hi, (const ull *)d_lo, (const uint32_t *)d_cnt, (const uint32_t *)rank, nb_slots,
+        SIMKA_LAUNCH(k_wcompact, grid_for(nb_slots), dim3(256), 0, w->stream, (const ull *)d_hi, (const ull *)d_lo, (const uint32_t *)d_cnt, (const uint32_t *)rank, nb_slots,
                            w->a_hi + w->a_used, w->a_lo + w->a_used, w->a_cnt + w->a_used);
         WCHK(hipGetLastError());
     }
@@ -815,7 +816,7 @@ static int wide_ensure_sorted(SimkaWide *w, uint32_t sample) {
     WCHK(hipMemcpyAsync(c0, w->a_cnt + off, n * 4, hipMemcpyDeviceToDevice, w->stream));
     const uint32_t hi_bits = std::max<uint32_t>(1u, w->W > 64 ? w->W - 64 : 0);
     if ((rc = wide_sort(w, n, hi_bits, h0, l0, w->a_hi + off, w->a_lo + off, tkey, idx0, idx1))) return rc;
-    hipLaunchKernelGGL(k_wgather32, grid_for(n), dim3(256), 0, w->stream, (const uint32_t *)c0, (const uint32_t *)idx0, w->a_cnt + off, n);
+    SIMKA_LAUNCH(k_wgather32, grid_for(n), dim3(256), 0, w->stream, (const uint32_t *)c0, (const uint32_t *)idx0, w->a_cnt + off, n);
     WCHK(hipGetLastError());
     w->s_sorted[sample] = 1;
     return 0;
@@ -845,11 +846,11 @@ int simka_wide_merge(SimkaWide *w, uint32_t span_cap, SimkaWideCsr *out) {
         d_max = bstart + nb + 2;
         WCHK(hipMemsetAsync(d_max, 0, 4, w->stream));
         for (uint32_t s = 0; s < N; s++)
-            if (w->s_n[s]) hipLaunchKernelGGL(k_wbucket_key, grid_for(w->s_n[s]), dim3(256), 0, w->stream, w->a_hi, w->a_lo, w->a_cnt, w->s_off[s], w->s_n[s], s, bits, tkey, idx0, pack);
+            if (w->s_n[s]) SIMKA_LAUNCH(k_wbucket_key, grid_for(w->s_n[s]), dim3(256), 0, w->stream, w->a_hi, w->a_lo, w->a_cnt, w->s_off[s], w->s_n[s], s, bits, tkey, idx0, pack);
         WCHK(wsort_pairs<uint32_t>(tkey, hi1, idx0, idx1, M, bits, tmp, w->stream));          // (hi1: the sorted bucket numbers, until k_wlocal_group overwrites it)
-        hipLaunchKernelGGL(k_wbucket_bounds, grid_for((uint64_t)nb + 1), dim3(256), 0, w->stream, hi1, M, nb, bstart, d_max);
+        SIMKA_LAUNCH(k_wbucket_bounds, grid_for((uint64_t)nb + 1), dim3(256), 0, w->stream, hi1, M, nb, bstart, d_max);
         WCHK(hipMemsetAsync(d_max, 0, 4, w->stream));           // (from here on: the "a bucket's table filled" flag)
-        hipLaunchKernelGGL(k_wlocal_group, dim3(nb), dim3(WL_BLOCK), 0, w->stream, bstart, idx1, pack, hi1, lo1, val2, d_max);
+        SIMKA_LAUNCH(k_wlocal_group, dim3(nb), dim3(WL_BLOCK), 0, w->stream, bstart, idx1, pack, hi1, lo1, val2, d_max);
         uint32_t failed = 0;
         WCHK(hipMemcpyAsync(&failed, d_max, 4, hipMemcpyDeviceToHost, w->stream));
         WCHK(hipStreamSynchronize(w->stream));
@@ -858,17 +859,17 @@ int simka_wide_merge(SimkaWide *w, uint32_t span_cap, SimkaWideCsr *out) {
     if (!grouped) {
         w->nb_full_sorts++;
         for (uint32_t s = 0; s < N; s++)
-            if (w->s_n[s]) hipLaunchKernelGGL(k_wvals, grid_for(w->s_n[s]), dim3(256), 0, w->stream, w->a_cnt, w->s_off[s], w->s_n[s], s, val);
+            if (w->s_n[s]) SIMKA_LAUNCH(k_wvals, grid_for(w->s_n[s]), dim3(256), 0, w->stream, w->a_cnt, w->s_off[s], w->s_n[s], s, val);
         const uint32_t hi_bits = (w->W > 64 ? w->W - 64 : 0) + 1;
         if ((rc = wide_sort(w, M, hi_bits, w->a_hi, w->a_lo, hi1, lo1, tkey, idx0, idx1))) return rc;     // idx0 = final permutation
-        hipLaunchKernelGGL(k_wgather, grid_for(M), dim3(256), 0, w->stream, val, idx0, val2, M);
+        SIMKA_LAUNCH(k_wgather, grid_for(M), dim3(256), 0, w->stream, val, idx0, val2, M);
     }
     // groups = runs of equal k-mers
     uint32_t *flag = idx0, *rank = idx1, *gstart, *kflag, *ksize, *krank, *eoff;
     if ((rc = wide_buf(w, 7, M + 2, &gstart)) || (rc = wide_buf(w, 8, M + 2, &kflag)) || (rc = wide_buf(w, 9, M + 2, &ksize))) return rc;
-    hipLaunchKernelGGL(k_wheads, grid_for(M), dim3(256), 0, w->stream, hi1, lo1, M, flag);
+    SIMKA_LAUNCH(k_wheads, grid_for(M), dim3(256), 0, w->stream, hi1, lo1, M, flag);
     if ((rc = wide_scan(w, flag, rank, M))) return rc;
-    hipLaunchKernelGGL(k_wstarts, grid_for(M), dim3(256), 0, w->stream, flag, rank, M, gstart, (const uint32_t *)nullptr);
+    SIMKA_LAUNCH(k_wstarts, grid_for(M), dim3(256), 0, w->stream, flag, rank, M, gstart, (const uint32_t *)nullptr);
     uint32_t lr = 0, lf = 0;
     WCHK(hipMemcpyAsync(&lr, rank + (M - 1), 4, hipMemcpyDeviceToHost, w->stream));
     WCHK(hipMemcpyAsync(&lf, flag + (M - 1), 4, hipMemcpyDeviceToHost, w->stream));
@@ -878,7 +879,7 @@ int simka_wide_merge(SimkaWide *w, uint32_t span_cap, SimkaWideCsr *out) {
     // kept groups (2..maxg samples): rank and entry offset.  flag / rank (idx0 / idx1) are free again: reuse them.
     krank = idx0; eoff = idx1;
     auto scan_class = [&](uint32_t huge, uint32_t &count, uint64_t &nentries) -> int {
-        hipLaunchKernelGGL(k_wgsizes, grid_for(ngroups), dim3(256), 0, w->stream, gstart, ngroups, maxg, huge, kflag, ksize);
+        SIMKA_LAUNCH(k_wgsizes, grid_for(ngroups), dim3(256), 0, w->stream, gstart, ngroups, maxg, huge, kflag, ksize);
         int r2;
         if ((r2 = wide_scan(w, kflag, krank, ngroups)) || (r2 = wide_scan(w, ksize, eoff, ngroups))) return r2;
         uint32_t a4[4] = { 0, 0, 0, 0 };
@@ -900,7 +901,7 @@ int simka_wide_merge(SimkaWide *w, uint32_t span_cap, SimkaWideCsr *out) {
     if (nhuge) {      // stage the huge groups now (the scan buffers are reused below)
         WCHK(hipMalloc(&h_entries, (hent + 16) * 8));
         WCHK(hipMalloc(&w->huge, ((uint64_t)nhuge + 4) * sizeof(SimkaSpan)));
-        hipLaunchKernelGGL(k_whuge, grid_for(ngroups), dim3(256), 0, w->stream, gstart, ngroups, kflag, krank, eoff, val2, 0ull, h_entries, w->huge);
+        SIMKA_LAUNCH(k_whuge, grid_for(ngroups), dim3(256), 0, w->stream, gstart, ngroups, kflag, krank, eoff, val2, 0ull, h_entries, w->huge);
     }
     if ((rc = scan_class(0, nkept, nent))) { if (h_entries) (void)hipFree(h_entries); return rc; }
     out->nb_shared = (uint64_t)nkept + nhuge;
@@ -928,10 +929,10 @@ int simka_wide_merge(SimkaWide *w, uint32_t span_cap, SimkaWideCsr *out) {
         uint32_t *sp_first = spb, *sp_ngrp = spb + nspans, *sp_nent = spb + 2 * (uint64_t)nspans, *sp_maxc = spb + 3 * (uint64_t)nspans;
         WCHK(hipMemsetAsync(sp_first, 0xff, (size_t)nspans * 4, w->stream));
         WCHK(hipMemsetAsync(sp_ngrp, 0, (size_t)nspans * 12, w->stream));
-        hipLaunchKernelGGL(k_wgroups, grid_for(ngroups), dim3(256), 0, w->stream, gstart, ngroups, kflag, krank, eoff, val2, C, w->entries, ge, gs, sp_first, sp_ngrp,
+        SIMKA_LAUNCH(k_wgroups, grid_for(ngroups), dim3(256), 0, w->stream, gstart, ngroups, kflag, krank, eoff, val2, C, w->entries, ge, gs, sp_first, sp_ngrp,
                            sp_nent, sp_maxc);
-        hipLaunchKernelGGL(k_wspans, grid_for(nspans), dim3(256), 0, w->stream, nspans, sp_first, sp_ngrp, sp_nent, sp_maxc, ge, w->spans, w->cursors);
-        hipLaunchKernelGGL(k_wgdesc, grid_for(nkept), dim3(256), 0, w->stream, nkept, ge, gs, sp_first, C, w->groups);
+        SIMKA_LAUNCH(k_wspans, grid_for(nspans), dim3(256), 0, w->stream, nspans, sp_first, sp_ngrp, sp_nent, sp_maxc, ge, w->spans, w->cursors);
+        SIMKA_LAUNCH(k_wgdesc, grid_for(nkept), dim3(256), 0, w->stream, nkept, ge, gs, sp_first, C, w->groups);
     }
     WCHK(hipGetLastError());
     WCHK(hipStreamSynchronize(w->stream));
@@ -967,7 +968,7 @@ int simka_wide_part_counts(SimkaWide *w, uint32_t sample, uint32_t log2_parts, u
     if (n == 0) { std::fill(host_counts, host_counts + P, 0u); return 0; }
     int rc = wide_ensure_sorted(w, sample); if (rc) return rc;
     uint32_t *d_b; rc = wide_buf(w, 7, (uint64_t)P + 2, &d_b); if (rc) return rc;
-    hipLaunchKernelGGL(k_wpartbounds, grid_for((uint64_t)P + 1), dim3(256), 0, w->stream, w->a_hi + off, w->a_lo + off, n, w->W, log2_parts, d_b);
+    SIMKA_LAUNCH(k_wpartbounds, grid_for((uint64_t)P + 1), dim3(256), 0, w->stream, w->a_hi + off, w->a_lo + off, n, w->W, log2_parts, d_b);
     std::vector<uint32_t> b((size_t)P + 1);
     WCHK(hipMemcpyAsync(b.data(), d_b, ((size_t)P + 1) * 4, hipMemcpyDeviceToHost, w->stream));
     WCHK(hipStreamSynchronize(w->stream));
@@ -1026,9 +1027,9 @@ int simka_wide_gather(SimkaWide *w, const uint32_t *samples, uint32_t nb, uint32
         const uint64_t n = w->s_n[s], off = w->s_off[s];
         if (n == 0) continue;
         if ((rc = wide_ensure_sorted(w, s))) return rc;
-        hipLaunchKernelGGL(k_wpartbounds, grid_for((uint64_t)P + 1), dim3(256), 0, w->stream, w->a_hi + off, w->a_lo + off, n, w->W, log2_parts, d_b);
+        SIMKA_LAUNCH(k_wpartbounds, grid_for((uint64_t)P + 1), dim3(256), 0, w->stream, w->a_hi + off, w->a_lo + off, n, w->W, log2_parts, d_b);
         WCHK(hipMemcpyAsync(d_off, out_offsets + (size_t)j * P, (size_t)P * 8, hipMemcpyHostToDevice, w->stream));
-        hipLaunchKernelGGL(k_wgather_runs, dim3(std::min<uint32_t>(P, 1024u)), dim3(256), 0, w->stream, w->a_hi, w->a_lo, w->a_cnt, (ull)off, d_b, d_off, P,
+        SIMKA_LAUNCH(k_wgather_runs, dim3(std::min<uint32_t>(P, 1024u)), dim3(256), 0, w->stream, w->a_hi, w->a_lo, w->a_cnt, (ull)off, d_b, d_off, P,
                            (ull *)d_hi, (ull *)d_lo, (uint32_t *)d_counts);
         WCHK(hipStreamSynchronize(w->stream));          // d_off is reused by the next sample
     }

@@ -244,6 +244,9 @@ def pack_batch(ctx, mine, P, kw, world, nb_samples, device):
         ks = torch.empty(sum(send_splits), dtype=torch.int64, device=device)
         cs = torch.empty(sum(send_splits), dtype=torch.int32, device=device)
         if mine:
+            # `meta` was zero-filled on torch's current stream, simka_pack_run writes it on the context's stream: nothing orders the two
+            # unless one of them is the legacy null stream (include/simka_hip.h, "stream ordering of caller buffers")
+            torch.cuda.current_stream(device).synchronize()
             ctx.pack_run(ks, cs, meta)
         return meta, tot_send, ks, torch.empty(0, dtype=torch.int64, device=device), cs, send_splits
     meta = _host_table(ctx, "meta", (world, maxn, width), np.int32, device)
@@ -298,6 +301,7 @@ def import_batch(ctx, rank, world, nb_samples, P, kw, meta_recv, tot_all, kr, kr
                 tt = tot_all[r, j]
                 tot_in[r * maxn + j] = SampleTotals(int(tt[0]), int(tt[1]), int(tt[2]), int(tt[3]), int(tt[4]), int(tt[5]))
         ctx.reset()
+        torch.cuda.current_stream(device).synchronize()      # meta_dev / kr / cr come from an asynchronous .to() / all_to_all on torch's stream
         ctx.import_block_device(slots, tot_in, lo, w, meta_dev.view(world * maxn, -1), P, kr, cr)
         return
     if isinstance(meta_recv, torch.Tensor):

@@ -9,6 +9,17 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 
+# Every test process (and the subprocesses it starts: the simka driver, the cross-check scripts) runs with the library's fault trace on
+# (simka_amd/csrc/simka_trace.h): should a GPU memory access fault end one of them, the registry of device ranges and the last launches
+# land in gpurun_out/fault_trace/ (merged back from the GPU box) and scripts/fault_resolve.py names the buffer and the kernels.
+os.environ.setdefault("SIMKA_FAULT_TRACE", "1")
+_TRACE_DIR = os.path.join(ROOT, "gpurun_out", "fault_trace")
+try:
+    os.makedirs(_TRACE_DIR, exist_ok=True)
+    os.environ.setdefault("SIMKA_FAULT_TRACE_DIR", _TRACE_DIR)
+except OSError:
+    pass
+
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")

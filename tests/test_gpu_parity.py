@@ -884,6 +884,51 @@ def test_batch_exchange_with_its_tables_on_the_device(gpu_required, world, k, co
         assert np.array_equal(total, ref.flat[:head])
 
 
+def test_rejected_block_and_stale_plan_leave_the_context_usable(gpu_required):
+    """Error behaviour of the device-table exchange: (1) a block that simka_import_block_device rejects AFTER its table kernel
+    ran (the meta rows do not sum to nb_records) must leave no foff / fcnt rows behind -- the same context then imports the correct block
+    and merges to the single-context result; (2) a pack plan dies with simka_reset / an import: simka_pack_run then fails with
+    SIMKA_ERR_STATE instead of gathering with stale starts."""
+    import torch
+    import simka_amd
+    from simka_amd import dist as sdist
+    dev = torch.device("cuda:0")
+    n, R, L, k = 4, 2000, 100, 21
+    packed = _synthetic(n, R, L, seed_shift=61)
+    kw = dict(kmer_size=k, abundance_min=2, simple_dist=True, complex_dist=False, max_kmers_per_sample=R * (L - k + 1))
+
+    def count(ctx, s):
+        ctx.count_sample(s, np.concatenate([packed[s], np.zeros(2, dtype=np.uint64)]), R * L, R, fixed_len=L)
+
+    with simka_amd.SimkaContext(n, **kw) as c:
+        for s in range(n):
+            count(c, s)
+        P = c.spectrum_info(0)[1]
+        mine = list(range(n))
+        meta, tot_send, ks, _, cs, splits = sdist.pack_batch(c, mine, P, 1, 1, n, dev)
+        c.merge()
+        ref = c.stats().flat.copy()
+        # (2) the plan is dropped by a reset
+        splits2 = c.pack_plan(mine, 1)
+        assert list(splits2) == list(splits)
+        c.reset()
+        with pytest.raises(simka_amd.SimkaError) as ei:
+            c.pack_run(ks, cs, meta)
+        assert "plan" in str(ei.value)
+    tot_all = tot_send[None]
+    with simka_amd.SimkaContext(n, **kw) as c:
+        bad = meta.clone()
+        bad[0, 0, 0] += 1                       # one record more than the block holds
+        with pytest.raises(simka_amd.SimkaError) as ei:
+            sdist.import_batch(c, 0, 1, n, P, 1, bad, tot_all, ks, None, cs, dev)
+        assert "sum to" in str(ei.value)
+        with pytest.raises(simka_amd.SimkaError):            # nothing was imported: no sample is counted
+            c.merge()
+        sdist.import_batch(c, 0, 1, n, P, 1, meta, tot_all, ks, None, cs, dev)
+        c.merge()
+        assert np.array_equal(c.stats().flat, ref)
+
+
 @pytest.mark.parametrize("gpus", [2, 3])
 def test_cli_multi_gpu_sample_shards_on_one_device(gpu_required, golden_dir, tmp_path, gpus):
     """`simka -nb-gpus G`: samples counted by one-sample contexts (GPU i % G), spectra exported and imported by partition range
