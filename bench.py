@@ -41,6 +41,9 @@ KERNEL_BOUND = {
     "k_pairs_global": "L2 atomics",
 }
 
+# resident waves per SIMD of the hot kernels (registers / LDS of the shipped build, profiles/r06_isa_mix.txt)
+WAVES_PER_SIMD = {"k_skm_count_fast": 4, "k_skm_scan": 6, "k_group": 5, "k_pairs": 4, "k_skm_chunksort": 4, "k_skm_count_wide_fast": 4}
+
 WORKLOADS = {
     # BASELINE.json configs[1]
     "c2": dict(n=10, reads=1_000_000, L=100, k=21, amin=2, simple=False,
@@ -602,7 +605,7 @@ def main():
                     tot += v["traffic_bytes_per_launch"] * v["launches"]; n += v["launches"]
             return tot / n if n else None
         try:
-            tf = next((f for f in (os.path.join(ROOT, "profiles", "r%02d_%s_hbm_traffic.json" % (rd, args.workload)) for rd in (5, 4, 3, 2)) if os.path.exists(f)), "")
+            tf = next((f for f in (os.path.join(ROOT, "profiles", "r%02d_%s_hbm_traffic.json" % (rd, args.workload)) for rd in (6, 5, 4, 3, 2)) if os.path.exists(f)), "")
             if world == 1 and not args.reads and not args.samples and not args.kmer_size and tf:
                 tk = json.load(open(tf))["kernels"]
                 traffic = measured_traffic(dom)
@@ -621,7 +624,25 @@ def main():
                                  # what the kernel really moves over HBM (PMC counters) against the 8 TB/s peak -- NOT the attributed bytes above
                                  "hbm_frac_measured": (mt * cnt / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if (mt and ms > 0) else None,
                                  "bound": KERNEL_BOUND.get(kname)}
-        roofline = {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+        # what bounds the dominant kernel when it is not its bytes: the SQ pass committed under profiles/ (scripts/sq_summary.py ... out.json), per
+        # k-mer occurrence of THIS run.  valu_busy next to hbm_frac_measured says at a glance which pipe is full.
+        issue = None
+        try:
+            sf = next((f for f in (os.path.join(ROOT, "profiles", "r%02d_%s_sq_counters.json" % (rd, args.workload)) for rd in (6, 5)) if os.path.exists(f)), "")
+            if world == 1 and not args.reads and not args.samples and not args.kmer_size and sf:
+                sq = json.load(open(sf))["kernels"].get(dom.split("<")[0])
+                if sq and sq["launches"]:
+                    kocc_per_launch = K_occ / max(dom_launches / max(args.steps, 1), 1)
+                    per_launch = lambda key: sq[key] / sq["launches"]
+                    issue = {"valu_busy": sq["valu_busy"], "active": sq["active"], "wait": sq["wait"], "issue_stall": sq["issue_stall"], "lds_busy": sq["lds_busy"],
+                             # lane-instructions per k-mer occurrence (wave instructions x 64 lanes / k-mer occurrences of a launch)
+                             "inst_per_kmer": {c: per_launch("wave_inst_" + c) * 64.0 / kocc_per_launch for c in ("valu", "salu", "lds", "vmem")},
+                             "cycles_per_inst": sq["cycles_per_inst"], "waves_per_simd": WAVES_PER_SIMD.get(dom.split("<")[0]),
+                             "source": os.path.relpath(sf, ROOT)}
+                    issue["inst_per_kmer"]["all"] = sum(issue["inst_per_kmer"].values())
+        except Exception:
+            issue = None
+        roofline = {"bound": "hbm", "kernel": dom, "achieved": achieved, "issue": issue, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                     # `frac` prices the kernel in SURVEY 8(d)'s design-independent bytes (8-byte k-mers); its real HBM traffic is `traffic`:
                     "hbm_frac_measured": (traffic / (dom_avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if (traffic and dom_avg_ms > 0) else None,
@@ -729,7 +750,11 @@ def main():
                 torch.cuda.synchronize()
                 t_host = (time.perf_counter() - t0_) / reps_ * 1e3
                 out["timing"]["step_ms_from_host"] = t_host
-                out["timing"]["step_from_host_over_step"] = t_host / ms_per_step
+                # like for like: the host-resident step runs on the library's two lanes, so it is compared with the two-lane device-resident step
+                # (timing.step_ms_two_streams) when that was measured, with the one-lane timed step otherwise -- the note says which
+                two_ = out["timing"].get("step_ms_two_streams")
+                out["timing"]["step_from_host_over_step"] = t_host / (two_ if two_ else ms_per_step)
+                out["timing"]["step_from_host_over_step_denominator"] = "step_ms_two_streams" if two_ else "ms_per_step (one lane)"
                 out["timing"]["step_from_host_note"] = ("packed reads in pinned host memory (%.1f GB, pinned + filled in %.1f s, untimed), H2D on the copy stream under the "
                                                         "other lane's kernels; matrices %s the device-resident step's" % (n * nw_ * 8 / 1e9, t_pin, "equal" if checksum(hm_) == out["config"]["matrix_checksum"] else "DIFFER FROM"))
                 hctx.close()

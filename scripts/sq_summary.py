@@ -1,8 +1,8 @@
 #!/usr/bin/env python3
 """Per-kernel SQ counter summary from two rocprofv3 --pmc passes (sqa_<wl>, sqb_<wl>): what bounds each kernel.
-usage: sq_summary.py <dir> <wl>.  Units: SQ_WAVE_CYCLES / SQ_WAIT_* / SQ_ACTIVE_INST_* are quad-cycles summed over waves
+usage: sq_summary.py <dir> <wl> [out.json].  Units: SQ_WAVE_CYCLES / SQ_WAIT_* / SQ_ACTIVE_INST_* are quad-cycles summed over waves
 (MI355X_MICROARCH.md); SQ_BUSY_CU_CYCLES, SQ_LDS_IDX_ACTIVE, SQ_LDS_BANK_CONFLICT are cycles summed over CUs."""
-import csv, glob, re, sys
+import csv, glob, json, re, sys
 from collections import defaultdict
 
 d, wl = sys.argv[1], sys.argv[2]
@@ -41,3 +41,21 @@ for k in sorted(acc, key=lambda x: -acc[x].get("SQ_WAVE_CYCLES", 0)):
         k, launches[k], 100 * a.get("SQ_WAIT_ANY", 0) / wc, 100 * a.get("SQ_WAIT_INST_ANY", 0) / wc, 100 * a.get("SQ_ACTIVE_INST_ANY", 0) / wc,
         100 * lds / busy, 100 * a.get("SQ_LDS_BANK_CONFLICT", 0) / (lds or 1), 100 * a.get("SQ_ACTIVE_INST_VALU", 0) * 4 / (busy * 4),
         a.get("SQ_INSTS_VALU", 0), a.get("SQ_INSTS_SALU", 0), a.get("SQ_INSTS_LDS", 0)))
+
+if len(sys.argv) > 3:
+    # machine-readable form: bench.py turns the dominant kernel's entry into roofline.issue.  SQ_WAVE_CYCLES and the SQ_WAIT / SQ_ACTIVE counters are
+    # quad-cycles summed over waves; cycles_per_inst = wave cycles (x4) over the wave-instructions of every class the wave executed
+    out = {"workload": wl, "source": "rocprofv3 --pmc, two passes of 8 SQ counters (scripts/r06_profiles.sh)", "kernels": {}}
+    for k, a in acc.items():
+        wc = a.get("SQ_WAVE_CYCLES", 0) or 1
+        busy = a.get("SQ_BUSY_CU_CYCLES", 0) or 1
+        ninst = a.get("SQ_INSTS_VALU", 0) + a.get("SQ_INSTS_SALU", 0) + a.get("SQ_INSTS_LDS", 0) + a.get("SQ_INSTS_VMEM_RD", 0) + a.get("SQ_INSTS_VMEM_WR", 0)
+        out["kernels"][k] = {
+            "launches": launches[k], "valu_busy": a.get("SQ_ACTIVE_INST_VALU", 0) * 4 / (busy * 4), "wait": a.get("SQ_WAIT_ANY", 0) / wc,
+            "issue_stall": a.get("SQ_WAIT_INST_ANY", 0) / wc, "active": a.get("SQ_ACTIVE_INST_ANY", 0) / wc,
+            "lds_busy": a.get("SQ_LDS_IDX_ACTIVE", 0) / busy, "lds_conflict": a.get("SQ_LDS_BANK_CONFLICT", 0) / (a.get("SQ_LDS_IDX_ACTIVE", 0) or 1),
+            "wave_inst_valu": a.get("SQ_INSTS_VALU", 0), "wave_inst_salu": a.get("SQ_INSTS_SALU", 0), "wave_inst_lds": a.get("SQ_INSTS_LDS", 0),
+            "wave_inst_vmem": a.get("SQ_INSTS_VMEM_RD", 0) + a.get("SQ_INSTS_VMEM_WR", 0), "waves": a.get("SQ_WAVES", 0),
+            "cycles_per_inst": 4.0 * wc / ninst if ninst else None,
+        }
+    json.dump(out, open(sys.argv[3], "w"), indent=1, sort_keys=True)

@@ -63,9 +63,6 @@ typedef unsigned long long ull;
 #define SKM_FAST_BLOCK 256       // k_skm_count_fast: 4 waves, 2048 slots, four blocks per CU
 #define SKM_FAST_TS 2048
 #define SKM_FAST_WCHUNK 8         // partitions a block takes per grab of the work counter
-#ifndef SKM_FAST_ROLL
-#define SKM_FAST_ROLL 1           // 1: a lane rolls through a run of consecutive k-mers (round 6); 0: k-mer f of the wave finds its record by itself (rounds 3-5)
-#endif
 #ifndef SKM_FAST_U
 #define SKM_FAST_U 1             // k-mers per lane in flight in the insert loop (2: 1..5 % slower once the partitions are handed out dynamically; 4: three blocks per CU)
 #endif
@@ -1602,90 +1599,6 @@ k_skm_count_fast(SimkaSkmSrc src, SimkaSkmCfg cfg, SimkaKeyCfg kcfg, uint32_t am
             const uint32_t x = wave_incl_scan(len);
             const uint32_t kt = __builtin_amdgcn_readlane(x, 63);
             const uint32_t off = x - len;
-#if SKM_FAST_ROLL
-            // ---- round 6: every lane takes a RUN of c = ceil(kt / 64) consecutive k-mers of the wave and ROLLS through it: the record
-            // window moves down by one base per k-mer (four funnel shifts), the reverse complement rolls the other way (one 64-bit
-            // shift + the complement of the base that enters), and only where a lane crosses into its next record does it take that
-            // record (LDS, read behind the CAS of the k-mer before) and the reverse complement of ITS first k-mer -- computed once per
-            // record by the lane that loaded it and fetched with two ds_bpermute.  Against "k-mer f finds its record with two mbcnt, cuts
-            // itself out with a variable funnel shift and reverse-complements itself" this is 19 VALU and 11 SALU instructions less per 64
-            // k-mers (65 + 19 -> 46 + 8; profiles/r06_isa_mix.txt).  The canonical k-mers, hence the tables and everything downstream, are
-            // the same.
-            // the wave's copy of the record: bases | n - 1 (bits 6..10 of w, as loaded) | index of its first k-mer among the wave's (from bit 11)
-            wrec[lane] = make_uint4(rc.x, rc.y, rc.z, (rc.w & 0x7ffu) | (off << 11));
-            const uint64_t rv0 = skm_revcomp_k((((uint64_t)rc.y << 32) | rc.x) & cfg.kmask, 64u - 2u * cfg.k);      // of the record's first k-mer
-            const uint32_t rv0lo = (uint32_t)rv0, rv0hi = (uint32_t)(rv0 >> 32);
-            if (lane < SKM_FAST_BMW) bm64[lane] = 0ull;
-            if (len) atomicOr((uint32_t *)bm64 + (off >> 5), 1u << (off & 31u));
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            if (lane == 0) my_k += kt;
-            PH(1)
-            const uint32_t cpl = (kt + 63u) >> 6;                       // k-mers per lane (wave-uniform, <= 32)
-            const uint32_t g = lane * cpl;                              // the lane's first k-mer
-            const uint32_t my_n = g < kt ? (kt - g < cpl ? kt - g : cpl) : 0u;
-            // the record that holds k-mer g = (record starts at or below g) - 1: prefix popcounts of the bitmap words (word w in lane w)
-            uint32_t idx;
-            {
-                ull bmreg = 0;
-                if (lane < SKM_FAST_BMW) bmreg = bm64[lane];
-                const uint32_t pc = (uint32_t)__popcll(bmreg);
-                const uint32_t pex = wave_incl_scan(pc) - pc;
-                const uint32_t gq = my_n ? g : 0u, wi = gq >> 6, b = gq & 63u;
-                const ull word = bm64[wi];
-                const uint32_t before = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(wi << 2), (int)pex);
-                const ull msk = b == 63u ? ~0ull : ((2ull << b) - 1ull);
-                idx = (before + (uint32_t)__popcll(word & msk) - 1u) & 63u;
-            }
-            uint32_t R0, R1, R2, R3, remm1;                             // the record from the current k-mer on; k-mers of the record after this one
-            {
-                const uint4 r = wrec[idx];
-                const uint32_t j = (g - (r.w >> 11)) & 31u, s2 = 2u * j, sh = s2 & 31u;      // (inactive lanes: anything)
-                remm1 = ((r.w >> 6) & 31u) - j;
-                const bool wd = s2 >= 32u;
-                const uint32_t a0 = wd ? r.y : r.x, a1 = wd ? r.z : r.y, a2 = wd ? r.w : r.z, a3 = wd ? 0u : r.w;
-                R0 = __builtin_amdgcn_alignbit(a1, a0, sh); R1 = __builtin_amdgcn_alignbit(a2, a1, sh); R2 = __builtin_amdgcn_alignbit(a3, a2, sh); R3 = a3 >> sh;
-            }
-            const uint32_t khi = (uint32_t)(cfg.kmask >> 32), klo = (uint32_t)cfg.kmask;
-            uint64_t rv = skm_revcomp_k((((uint64_t)R1 << 32) | R0) & cfg.kmask, 64u - 2u * cfg.k);
-            const uint32_t topsh = 2u * (cfg.k - 1u);                    // where the last base of a k-mer sits
-            for (uint32_t i = 0; i < cpl; i++) {
-                const bool act = i < my_n;
-                const uint64_t fw = ((uint64_t)(R1 & khi) << 32) | (R0 & klo);
-                ull cu = fw < rv ? fw : rv;
-                if (!act) cu = SIMKA_EMPTY_KEY;
-                const uint32_t su = simka_key_hash32(cu) >> (32u - TSL);
-                // No lane is masked off: a lane beyond its last k-mer swaps EMPTY for EMPTY and adds 0 -- straight-line code, every wait
-                // counts exactly the LDS operations it needs
-                const ull pu = atomicCAS(&tkeys[su], SIMKA_EMPTY_KEY, cu);
-                // the next record of the lane and the reverse complement of its first k-mer travel behind the CAS (LDS returns in order)
-                const uint32_t nidx = (idx + 1u) & 63u;
-                const uint4 nx = wrec[nidx];
-                const uint32_t nrlo = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(nidx << 2), (int)rv0lo), nrhi = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(nidx << 2), (int)rv0hi);
-                const bool cross = remm1 == 0u;
-                // roll: the window one base down, the reverse complement one base up with the complement of the base that enters
-                R0 = __builtin_amdgcn_alignbit(R1, R0, 2); R1 = __builtin_amdgcn_alignbit(R2, R1, 2); R2 = __builtin_amdgcn_alignbit(R3, R2, 2); R3 >>= 2;
-                const uint32_t nb_ = (uint32_t)(((((uint64_t)R1 << 32) | R0) >> topsh)) & 3u;
-                rv = ((rv << 2) & cfg.kmask) | (uint64_t)(nb_ ^ 2u);
-                remm1 -= 1u;
-                const bool ok = pu == SIMKA_EMPTY_KEY || pu == cu;
-                atomicAdd(&tcnt[su], (act && ok) ? 1u : 0u);
-                const bool lost = act && !ok;
-                const ull lm = __ballot(lost);
-                if (lm) {       // (bmask >= 1: the next slot is never the home slot)
-                    if (lost) {
-                        const uint32_t pos = qn + __builtin_amdgcn_mbcnt_hi((uint32_t)(lm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)lm, 0u));
-                        qk[pos] = cu; qm[pos] = (uint16_t)((su & ~bmask) | ((su + 1u) & bmask));
-                    }
-                    qn += (uint32_t)__popcll(lm);
-                }
-                // (bits above the 102 of the bases ride along in R3: a k-mer of the record never reaches them)
-                R0 = cross ? nx.x : R0; R1 = cross ? nx.y : R1; R2 = cross ? nx.z : R2; R3 = cross ? nx.w : R3;
-                remm1 = cross ? ((nx.w >> 6) & 31u) : remm1;
-                rv = cross ? (((uint64_t)nrhi << 32) | nrlo) : rv;
-                idx = cross ? nidx : idx;
-                while (qn >= 64u) drain();
-            }
-#else
             // the wave's copy of the record carries the index of its first k-mer where the partition id was
             wrec[lane] = make_uint4(rc.x, rc.y, rc.z, (rc.w & 63u) | (off << 6));
             if (lane < SKM_FAST_BMW) bm64[lane] = 0ull;
@@ -1749,7 +1662,6 @@ k_skm_count_fast(SimkaSkmSrc src, SimkaSkmCfg cfg, SimkaKeyCfg kcfg, uint32_t am
                 }
                 while (qn >= 64u) drain();
             }
-#endif
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // the wave's bitmap / records are rewritten by the next batch
             PH(2)
         }
