@@ -5,6 +5,9 @@
 #   2  uneven all-to-all through simka_comm_alltoallv
 #   3  bench.py --gpus N --mgpu partition on c2 (partition shards + ONE all-reduce, north_star's split)
 #   4  bench.py --gpus N --mgpu sample on c2 (sample shards + spectrum all-to-all + one all-reduce)
+#   5  the C++ driver: simka -nb-gpus N -gpu-shards partition on the reference's example (N contexts in ONE process, RCCL communicators created by
+#      its worker threads from one unique id, simka_totals_allreduce + simka_stats_allreduce_head); the 20 CSVs must equal tests/golden/truth.
+#      SIMKA_BENCH_BACKEND=gloo: -gpu-shared (one device, the host sums)
 # The matrix checksums of 3 and 4 must equal the one-rank run's.  SIMKA_BENCH_BACKEND=gloo: dry run on a one-GPU box (the ranks share
 # GPU 0, gloo instead of RCCL) -- what the GPU test suite runs.
 N=${1:-2}
@@ -26,4 +29,16 @@ for MODE in partition sample; do
   [ "$1" = "$ref" ] || fail "bench.py --gpus $N --mgpu $MODE (matrix checksum $1, one rank: $ref)"
   echo "[first-contact] bench.py --gpus $2 --mgpu $MODE ok: checksum $1, $3 ms per step"
 done
+O=$(mktemp -d)
+SHARED=""; [ "${SIMKA_BENCH_BACKEND:-nccl}" = gloo ] && SHARED="-gpu-shared"
+timeout $T simka_amd/bin/simka -in tests/golden/example/simka_input.txt -out $O/out -out-tmp $O/tmp -kmer-size 31 -abundance-min 2 -simple-dist -complex-dist \
+    -nb-gpus $N -gpu-shards partition $SHARED > $O/log.txt 2>&1 || { tail -5 $O/log.txt; fail "5 simka -nb-gpus $N -gpu-shards partition"; }
+grep -q "partition shards, one all-reduce" $O/log.txt || fail "5 simka -gpu-shards partition (the driver took another route)"
+for f in $O/out/*.csv.gz; do
+  b=$(basename $f .gz)
+  [ -f tests/golden/truth/results_k31_t2/$b ] || continue
+  zcat $f | cmp -s - tests/golden/truth/results_k31_t2/$b || fail "5 simka -gpu-shards partition ($b differs from the golden)"
+done
+echo "[first-contact] simka -nb-gpus $N -gpu-shards partition ok ($(grep -o 'one all-reduce [a-zA-Z ]*' $O/log.txt | head -1)): goldens byte for byte"
+rm -rf $O
 echo "[first-contact] all stages passed"

@@ -57,6 +57,8 @@ struct Options {
     bool host_upload = false;           // new: the text goes through whole-file pinned buffers and the MAIN thread copies it (the round-3 route; -nb-gpus uses it)
     bool host_parse = false;            // new: parse + pack every input on the host (default: plain-text inputs without read policies are parsed on the GPU)
     bool host_spectra = false;          // new: -nb-gpus keeps the spectra in host memory between count and merge (the round-2 route)
+    bool gpu_partition = false;         // new: -gpu-shards partition -- BASELINE north_star's split: every GPU scans all reads and keeps the minimizer partitions p % G == g
+    bool gpu_host_sum = false;          // new: -gpu-host-sum -- partition shards: add the heads on the host even where RCCL could
     bool gpu_allreduce = false;         // new: -nb-gpus combines the merges' accumulators with one RCCL all-reduce instead of summing them on the host
     long long solid_capacity = 0;       // new (tests): records of the solid-spectrum arena of every context (0: from the free memory)
     int merge_ranges = 0;               // new: >0 keeps the spectra in host memory and merges in that many partition ranges per GPU
@@ -110,6 +112,8 @@ void usage() {
         "       -max-merge        (1 arg) :    accepted for compatibility\n"
         "   [gpu options]\n"
         "       -nb-gpus          (1 arg) :    MI355X devices: samples are counted on GPU i % n, partition ranges merged per GPU, spectra moved between the GPUs  [default '1']\n"
+        "       -gpu-shards       (1 arg) :    with -nb-gpus: 'sample' (a GPU counts the samples i % n, the spectra are exchanged by partition range) or 'partition' (every GPU scans all reads and keeps the minimizer partitions p % n; nothing is exchanged but ONE all-reduce of the N x N accumulators: RCCL over xGMI on distinct devices, the host with -gpu-shared / -gpu-host-sum)  [default 'sample']\n"
+        "       -gpu-host-sum     (0 arg) :    with -gpu-shards partition: add the GPUs' accumulators on the host instead of the RCCL all-reduce\n"
         "       -host-spectra     (0 arg) :    with -nb-gpus: keep the k-mer spectra in host memory between count and merge\n"
         "       -merge-ranges     (1 arg) :    keep the k-mer spectra in host memory and merge in this many partition ranges per GPU (0: only when GPU memory requires it)  [default '0']\n"
         "       -gpu              (1 arg) :    first device ordinal  [default '0']\n"
@@ -147,6 +151,8 @@ Options parse_args(int argc, char **argv) {
         else if (a == "-gpu-mapped-arenas") o.mapped_arenas = true;
         else if (a == "-host-spectra") o.host_spectra = true;
         else if (a == "-gpu-allreduce") o.gpu_allreduce = true;
+        else if (a == "-gpu-host-sum") o.gpu_host_sum = true;
+        else if (a == "-gpu-shards") { const std::string v = need(i); if (v == "partition") o.gpu_partition = true; else if (v == "sample") o.gpu_partition = false; else die("ERROR: -gpu-shards takes sample or partition"); }
         else if (a == "-host-parse") o.host_parse = true;
         else if (a == "-ingest-window") o.ingest_window = atoi(need(i).c_str());
         else if (a == "-ingest-host-upload") o.host_upload = true;
@@ -953,14 +959,14 @@ int main(int argc, char **argv) {
     uint32_t log2_parts = simka_default_log2_partitions(biggest, (uint32_t)o.kmer_size);
     if (kept_partitions) { log2_parts = 0; while (((uint64_t)1 << log2_parts) < kept_partitions) log2_parts++; }      // new samples join the kept partitioning
     const uint64_t P = (uint64_t)1 << log2_parts;
-    auto make_ctx = [&](uint32_t nb_samples, int device) {
+    auto make_ctx = [&](uint32_t nb_samples, int device, uint32_t shard_index = 0, uint32_t shard_count = 1) {
         simka_config cfg;
         memset(&cfg, 0, sizeof cfg);
         cfg.struct_size = sizeof cfg;
         cfg.nb_samples = nb_samples; cfg.kmer_size = (uint32_t)o.kmer_size;
         cfg.abundance_min = (uint32_t)std::min<long long>(o.abundance_min, 0xffffffffLL);
         cfg.abundance_max = (uint32_t)o.abundance_max;
-        cfg.dist_flags = flags; cfg.device = device; cfg.shard_index = 0; cfg.shard_count = 1;
+        cfg.dist_flags = flags; cfg.device = device; cfg.shard_index = shard_index; cfg.shard_count = shard_count;
         cfg.max_kmers_per_sample = biggest; cfg.log2_partitions = log2_parts;
         cfg.solid_capacity = (uint64_t)std::max<long long>(0, o.solid_capacity);
         simka_ctx *c = nullptr;
@@ -1107,6 +1113,103 @@ int main(int argc, char **argv) {
                                       << " s, merge + download " << now() - t3 << " s (since the context: " << now() - t_begin << " s)" << std::endl;
         simka_destroy(c);
         return rc;
+    };
+
+    // ---- PARTITION SHARDS (-gpu-shards partition): BASELINE.json north_star's decomposition.  GPU g holds ONE context over all N samples
+    // with shard (g, G): it scans every sample's reads and keeps the minimizer partitions p with p % G == g, so no k-mer ever moves
+    // between GPUs.  With -complex-dist the per-sample totals N_i are made global first (the per-k-mer terms need them; the
+    // reference reads them from every count_synchro/<ID>.ok, ref: src/core/SimkaDistance.cpp:116-151), every GPU merges its partitions
+    // (the reference: one simkaMerge job per partition, ref: src/SimkaPotara.hpp:974-1124), and ONE all-reduce(sum, u64) of the
+    // N x N numerators / denominators combines them (SimkaStatistics::operator+=, ref: src/core/SimkaDistance.cpp:156-213): RCCL over
+    // xGMI when the G contexts sit on G distinct devices and the library finds RCCL, the host otherwise (-gpu-shared, -gpu-host-sum).
+    // Returns SIMKA_ERR_NOMEM when a GPU cannot hold its share of the spectra.
+    auto partition_run = [&]() -> int {
+        std::vector<simka_ctx *> pctx(G, nullptr);
+        for (uint32_t g = 0; g < G; g++) pctx[g] = make_ctx(N, device_of(g), g, G);
+        std::atomic<int> worst(SIMKA_OK);
+        auto note = [&](int r) { if (r != SIMKA_OK) worst.store(r); return r == SIMKA_OK; };
+        uint64_t n_dev_parsed = 0, n_pieces = 0;
+        std::mutex cnt_lock;
+        {
+            // the text of a sample goes to every GPU: the loader leaves it in pinned host memory and each context uploads its copy
+            SampleLoader loader(samples, o, max_reads, nthreads, nthreads + 2, std::vector<char>(), !o.host_parse, -1);
+            for (uint32_t i = 0; i < N; i++) {
+                Packed *pkp;
+                if (!loader.get(i, pkp)) die("ERROR: Can't open dataset: " + samples[i].id);
+                std::vector<std::thread> th;
+                for (uint32_t g = 0; g < G; g++)
+                    th.emplace_back([&, g] {
+                        if (worst.load() != SIMKA_OK) return;
+                        uint64_t ndp = 0, npc = 0;
+                        note(count_into(pctx[g], i, i, pkp, ndp, npc));
+                        if (g == 0) { std::lock_guard<std::mutex> lk(cnt_lock); n_dev_parsed += ndp; n_pieces += npc; }
+                    });
+                for (auto &t : th) t.join();
+                loader.release(i);
+            }
+        }
+        auto destroy_all = [&] { for (uint32_t g = 0; g < G; g++) if (pctx[g]) { simka_destroy(pctx[g]); pctx[g] = nullptr; } };
+        if (worst.load() != SIMKA_OK) { destroy_all(); return worst.load(); }
+        if (o.verbose >= 2) std::cout << "ingest: " << n_dev_parsed << " samples parsed on the GPUs (" << n_pieces << " pieces of text per GPU), " << N - n_dev_parsed << " on the host" << std::endl;
+        // the shards' per-sample totals (5 rows of N) add up to the samples' totals
+        std::vector<uint64_t> tsum((size_t)5 * N, 0), tpart((size_t)5 * N);
+        for (uint32_t g = 0; g < G; g++) {
+            const int rc = simka_totals_download(pctx[g], tpart.data());
+            if (rc != SIMKA_OK && rc != SIMKA_ERR_NOMEM) fatal(pctx[g], "simka_totals_download");
+            if (!note(rc)) { destroy_all(); return rc; }
+            for (size_t w = 0; w < tsum.size(); w++) tsum[w] += tpart[w];
+        }
+        for (uint32_t i = 0; i < N; i++) {
+            simka_sample_totals t0;
+            if (simka_get_sample_totals(pctx[0], i, &t0) != SIMKA_OK) fatal(pctx[0], "simka_get_sample_totals");
+            totals[i].nb_reads = t0.nb_reads;           // (every shard saw every read)
+            totals[i].nb_distinct = tsum[0 * (size_t)N + i]; totals[i].nb_kmers = tsum[1 * (size_t)N + i]; totals[i].sum_sq = tsum[2 * (size_t)N + i];
+            totals[i].distinct_all = tsum[3 * (size_t)N + i]; totals[i].kmer_occurrences = tsum[4 * (size_t)N + i];
+        }
+        bool use_rccl = G > 1 && !o.same_gpu && !o.gpu_host_sum;
+        uint8_t comm_id[SIMKA_COMM_ID_BYTES];
+        if (use_rccl && simka_comm_unique_id(comm_id) != SIMKA_OK) {
+            if (o.verbose) std::cout << "partition shards: " << simka_comm_last_error(nullptr) << "; the accumulators are added on the host" << std::endl;
+            use_rccl = false;
+        }
+        if (o.verbose) std::cout << std::endl << "Merging k-mer counts and computing distances... (" << G << " partition shards, one all-reduce "
+                                 << (use_rccl ? "over RCCL" : "on the host") << ")" << std::endl;
+        std::mutex acc_lock;
+        auto merger = [&](uint32_t g) {
+            simka_ctx *c = pctx[g];
+            simka_comm *comm = nullptr;
+            if (use_rccl && simka_comm_create(comm_id, (int)G, (int)g, device_of(g), &comm) != SIMKA_OK)
+                die(std::string("EXCEPTION: simka_comm_create: ") + simka_comm_last_error(nullptr));
+            if (o.complex_) {       // N_i global BEFORE the merge
+                if (use_rccl) { if (simka_totals_allreduce(c, comm) != SIMKA_OK) fatal(c, "simka_totals_allreduce"); }
+                else if (simka_totals_upload(c, tsum.data()) != SIMKA_OK) fatal(c, "simka_totals_upload");
+            }
+            const int rc = simka_merge(c);
+            if (rc != SIMKA_OK && rc != SIMKA_ERR_NOMEM) fatal(c, "simka_merge");
+            const bool ok = note(rc);
+            if (use_rccl) {        // (every rank must reach the collective)
+                if (!ok) die("EXCEPTION: a GPU ran out of memory in a partition-shard merge; run with -gpu-host-sum or fewer samples per GPU");
+                if (o.complex_) { if (simka_stats_allreduce_head(c, comm) != SIMKA_OK) fatal(c, "simka_stats_allreduce_head"); }
+                else if (simka_stats_allreduce(c, comm) != SIMKA_OK) fatal(c, "simka_stats_allreduce");
+                if (g == 0) { if (simka_stats_download(c, flat.data(), nw, nullptr) != SIMKA_OK) fatal(c, "simka_stats_download"); }
+                else if (simka_sync(c) != SIMKA_OK) fatal(c, "simka_sync");
+            } else if (ok) {
+                std::vector<uint64_t> shard(nw);
+                if (simka_stats_download(c, shard.data(), nw, nullptr) != SIMKA_OK) fatal(c, "simka_stats_download");
+                std::lock_guard<std::mutex> lk(acc_lock);          // SimkaStatistics::operator+= over the shards
+                for (uint64_t w = 0; w < lay[5]; w++) flat[w] += shard[w];
+            }
+            if (comm) simka_comm_destroy(comm);
+        };
+        std::vector<std::thread> th;
+        for (uint32_t g = 0; g < G; g++) th.emplace_back(merger, g);
+        for (auto &t : th) t.join();
+        if (!use_rccl && worst.load() == SIMKA_OK) {      // the rows of the totals behind the head: global by construction
+            for (uint32_t i = 0; i < N; i++)
+                for (uint32_t r = 0; r < 5; r++) flat[lay[2] + (size_t)r * N + i] = tsum[(size_t)r * N + i];
+        }
+        destroy_all();
+        return worst.load();
     };
 
     // ---- DEVICE SPECTRA: G GPUs, nothing leaves device memory.  Phase 1: GPU g counts the samples i = g, g + G, ... in ONE context
@@ -1369,7 +1472,21 @@ int main(int argc, char **argv) {
     };
 
     bool host_mode = G > 1 || o.merge_ranges > 0;
-    if (G > 1 && o.merge_ranges <= 0 && !o.keep_tmp && !o.host_spectra && N >= G) {
+    bool partition_done = false;
+    if (G > 1 && o.gpu_partition) {
+        if (o.keep_tmp || o.merge_ranges > 0 || o.host_spectra || o.kmer_size > 31)
+            std::cout << "-gpu-shards partition: not combined with -keep-tmp / -merge-ranges / -gpu-host-spectra / -kmer-size >= 32; sample shards instead" << std::endl;
+        else {
+            const int rc = partition_run();
+            if (rc == SIMKA_OK) { partition_done = true; host_mode = false; }
+            else {
+                if (o.verbose) std::cout << "The partition shards do not fit the GPUs' memory: recounting with the spectra in host memory and merging by partition ranges" << std::endl;
+                std::fill(flat.begin(), flat.end(), 0);
+            }
+        }
+    }
+    if (partition_done) {
+    } else if (G > 1 && o.merge_ranges <= 0 && !o.keep_tmp && !o.host_spectra && N >= G && !o.gpu_partition) {
         const int rc = device_run();
         if (rc == SIMKA_OK) host_mode = false;
         else {

@@ -1822,14 +1822,22 @@ SIMKA_EXPORT int simka_import_block_device(simka_ctx *ctx, const uint32_t *slot_
     HIPCHK(hipMemcpyAsync(ctx->d_sample_base, bases.data(), (size_t)(N + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
     HIPCHK(hipMemcpyAsync(ctx->d_stats + stats_off_tot(N, fl, 0), tot.data(), tot.size() * 8, hipMemcpyHostToDevice, ctx->stream));
     if (ctx->d_hist && part_width) {   // -complex-dist: per-sample histogram of the imported solid counts
+        // one clear + one launch per RUN of consecutive sample indices among the slots (blockIdx.y = sample of the run), as
+        // simka_import_samples_device does: rank r's slots hold the samples r, r + world, ... -- runs of one -- but a caller with contiguous
+        // sample blocks gets one launch per block instead of one per slot
         const uint32_t gx = (uint32_t)std::min<uint64_t>(part_width, 1024);
-        for (uint32_t q = 0; q < nb_slots_total; q++) {
-            const uint32_t s = slot_samples[q];
-            if (s == 0xffffffffu) continue;
-            HIPCHK(hipMemsetAsync(ctx->d_hist + (uint64_t)s * SIMKA_HIST_MAX, 0, (size_t)SIMKA_HIST_MAX * 8, ctx->stream));
-            SIMKA_LAUNCH(k_import_hist, dim3(gx, 1), dim3(256), 0, ctx->stream, (const uint32_t *)ctx->d_solid_counts, (const ull *)ctx->d_sample_base,
-                               (const uint32_t *)ctx->d_foff, (const uint32_t *)ctx->d_fcnt, (uint32_t)P, (uint32_t)part_lo, (uint32_t)part_width, s, (ull *)ctx->d_hist,
+        std::vector<uint32_t> ss;
+        for (uint32_t q = 0; q < nb_slots_total; q++) if (slot_samples[q] != 0xffffffffu) ss.push_back(slot_samples[q]);
+        std::sort(ss.begin(), ss.end());
+        for (size_t a = 0; a < ss.size(); ) {
+            size_t b = a + 1;
+            while (b < ss.size() && ss[b] == ss[b - 1] + 1u && b - a < 65535u) b++;
+            const uint32_t s0 = ss[a], ns = (uint32_t)(b - a);
+            HIPCHK(hipMemsetAsync(ctx->d_hist + (uint64_t)s0 * SIMKA_HIST_MAX, 0, (size_t)ns * SIMKA_HIST_MAX * 8, ctx->stream));
+            SIMKA_LAUNCH(k_import_hist, dim3(gx, ns), dim3(256), 0, ctx->stream, (const uint32_t *)ctx->d_solid_counts, (const ull *)ctx->d_sample_base,
+                               (const uint32_t *)ctx->d_foff, (const uint32_t *)ctx->d_fcnt, (uint32_t)P, (uint32_t)part_lo, (uint32_t)part_width, s0, (ull *)ctx->d_hist,
                                ctx->d_ovf_list, (ull *)ctx->d_ovf_cursor, (ull)ctx->ovf_cap);
+            a = b;
         }
         HIPCHK(hipGetLastError());
     }

@@ -958,6 +958,46 @@ def test_cli_multi_gpu_sample_shards_on_one_device(gpu_required, golden_dir, tmp
     assert run(str(tmp_path / "o2"), 5 - gpus).count("k-mer spectrum reused") == 5        # other GPU count, same spectra
 
 
+@pytest.mark.parametrize("gpus,k,amin,extra", [(2, 31, 2, []), (3, 21, 0, []), (5, 31, 0, ["-host-parse"]), (8, 21, 2, []), (2, 31, 2, ["-max-reads", "300"])])
+def test_cli_partition_shards_on_one_device(gpu_required, golden_dir, tmp_path, gpus, k, amin, extra):
+    """`simka -nb-gpus G -gpu-shards partition`: BASELINE.json north_star's decomposition in the C++ driver -- G contexts with shard (g, G), each
+    scanning every sample and keeping the minimizer partitions p % G == g, the per-sample totals made global before the -complex-dist merges,
+    ONE sum of the N x N accumulators at the end (here on the host: -gpu-shared puts the G contexts on one device; on G distinct devices
+    the same code takes the RCCL all-reduce).  The goldens byte for byte, all 20 matrices; a read policy against the one-GPU run."""
+    import subprocess
+    from simka_amd import build as b
+    out = str(tmp_path / "o")
+    base = [b.CLI_PATH, "-in", os.path.join(golden_dir, "example", "simka_input.txt"), "-out-tmp", str(tmp_path / "tmp"), "-simple-dist", "-complex-dist",
+            "-kmer-size", str(k), "-abundance-min", str(amin), "-verbose", "2"] + extra
+    r = subprocess.run(base + ["-out", out, "-gpu-shared", "-nb-gpus", str(gpus), "-gpu-shards", "partition"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    assert r.returncode == 0, r.stdout
+    assert "%d partition shards, one all-reduce on the host" % gpus in r.stdout, r.stdout
+    if "-max-reads" in extra:
+        ref = str(tmp_path / "ref")
+        r1 = subprocess.run(base + ["-out", ref], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+        assert r1.returncode == 0, r1.stdout
+        names = sorted(os.path.basename(f) for f in glob.glob(os.path.join(ref, "*.csv.gz")))
+        assert len(names) == 21           # (the reference's tests/truth holds 20 of the 21 matrices)
+        for nme in names:
+            with gzip.open(os.path.join(out, nme), "rb") as f, gzip.open(os.path.join(ref, nme), "rb") as h:
+                assert f.read() == h.read(), nme
+    else:
+        truth = os.path.join(golden_dir, "truth", "results_k%d_t%d" % (k, amin))
+        n = 0
+        for gzf in glob.glob(os.path.join(out, "*.csv.gz")):
+            ref = os.path.join(truth, os.path.basename(gzf)[:-3])
+            if os.path.exists(ref):
+                with gzip.open(gzf, "rb") as f, open(ref, "rb") as h:
+                    assert f.read() == h.read(), os.path.basename(gzf)
+                n += 1
+        assert n == 20
+    # the per-sample lines of the driver's report are the whole samples' totals, not a shard's
+    r1 = subprocess.run(base + ["-out", str(tmp_path / "one")], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    assert r1.returncode == 0, r1.stdout
+    pick = lambda txt: [ln for ln in txt.splitlines() if ln.startswith("\t") and " / " in ln]
+    assert pick(r.stdout) == pick(r1.stdout) and len(pick(r.stdout)) == 5
+
+
 @pytest.mark.parametrize("gpus,extra", [(2, []), (3, []), (5, []), (2, ["-host-spectra"]), (3, ["-host-parse"]), (2, ["-max-reads", "300"])])
 def test_cli_multi_gpu_spectra_stay_on_the_devices(gpu_required, golden_dir, tmp_path, gpus, extra):
     """`simka -nb-gpus G` without -keep-tmp: GPU g counts the samples i = g, g + G, ... in one context (text parsed on the GPU), the
