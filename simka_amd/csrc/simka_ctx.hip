@@ -49,6 +49,7 @@ struct simka_ctx {
     struct Lane {
         hipStream_t stream = nullptr;
         ull *d_b1_count = nullptr, *d_b1_start = nullptr, *d_b1_end = nullptr, *d_b1_cursor = nullptr;   // level-1 buckets
+        ull *d_b1_sub = nullptr;                                   // records per fill cursor of a bucket ([B1 << SKM_MAXSUB], k_skm_layout)
         uint32_t *d_tile_r0 = nullptr; uint64_t tile_r0_cap = 0;  // variable-length reads: first read of every scan tile
         uint32_t *d_redo_list = nullptr; ull *d_redo_count = nullptr;   // partitions k_skm_count_fast hands to k_skm_count
         // super-k-mer pipeline: two record buffers (level 1 / level 3 share one), level-2 counters, partition table
@@ -344,7 +345,7 @@ static uint64_t g_vmm_retired_bytes = 0;
 SIMKA_EXPORT const char *simka_last_error(const simka_ctx *ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
 
 // k_skm_scan<W, FIXED, HIST>
-using SkmScanFn = void (*)(SimkaScanArgs, SimkaSkmCfg, ull *, ull *, uint4 *, const ull *, uint32_t *, uint32_t, uint32_t, uint32_t, uint32_t *);
+using SkmScanFn = void (*)(SimkaScanArgs, SimkaSkmCfg, ull *, ull *, uint4 *, const ull *, uint32_t *, uint32_t, uint32_t, uint32_t, uint32_t *, uint32_t, ull);
 static int skm_w_index(uint32_t W) { switch (W) { case 1: return 0; case 4: return 1; case 8: return 2; case 12: return 3; case 16: return 4; default: return 5; } }
 static SkmScanFn skm_scan_kernel(int wi, bool fixed, bool hist) {
 #define SKM_ROW(W) { k_skm_scan<W, false, false>, k_skm_scan<W, false, true>, k_skm_scan<W, true, false>, k_skm_scan<W, true, true> }
@@ -427,8 +428,9 @@ static int setup_geometry(simka_ctx *ctx, uint64_t max_kmers) {
         if (!L.stream) HIPCHK(hipStreamCreateWithFlags(&L.stream, hipStreamNonBlocking));
         HIPCHK(dev_alloc(&L.d_b1_count, ctx->B1 + 1));
         HIPCHK(dev_alloc(&L.d_b1_start, ctx->B1 + 1));
-        HIPCHK(dev_alloc(&L.d_b1_end, ctx->B1 + 1));
-        HIPCHK(dev_alloc(&L.d_b1_cursor, (uint64_t)(ctx->B1 + 1) * SKM_CSTRIDE));
+        HIPCHK(dev_alloc(&L.d_b1_end, ((uint64_t)ctx->B1 << SKM_MAXSUB) + 1));
+        HIPCHK(dev_alloc(&L.d_b1_sub, ((uint64_t)ctx->B1 << SKM_MAXSUB) + 1));
+        HIPCHK(dev_alloc(&L.d_b1_cursor, (((uint64_t)ctx->B1 << SKM_MAXSUB) + 1) * SKM_CSTRIDE));
         HIPCHK(dev_alloc(&L.d_redo_list, ctx->nparts + 1));
         HIPCHK(dev_alloc(&L.d_redo_count, 2));
         HIPCHK(dev_alloc(&L.d_pstart, ctx->nparts + 1)); HIPCHK(dev_alloc(&L.d_pcnt, ctx->nparts + 1));
@@ -616,7 +618,7 @@ SIMKA_EXPORT void simka_destroy(simka_ctx *ctx) {
     if (ctx->wide) { simka_wide_destroy(ctx->wide); ctx->wide = nullptr; }
     for (auto &L : ctx->lanes) {
         if (L.stream) (void)hipStreamSynchronize(L.stream);
-        void *lp[] = { L.d_b1_count, L.d_b1_start, L.d_b1_end, L.d_b1_cursor, L.d_tile_r0, L.d_redo_list, L.d_redo_count,
+        void *lp[] = { L.d_b1_count, L.d_b1_start, L.d_b1_end, L.d_b1_cursor, L.d_b1_sub, L.d_tile_r0, L.d_redo_list, L.d_redo_count,
                        L.d_skm_a, L.d_skm_b, L.d_skm_p, L.d_pstart, L.d_pcnt, L.d_cbase, L.d_ctab };
         for (void *q : lp) if (q) (void)hipFree(q);
         if (L.stream && L.stream != ctx->stream) (void)hipStreamDestroy(L.stream);
@@ -808,17 +810,25 @@ static int skm_scan_split(simka_ctx *ctx, simka_ctx::Lane &L, uint32_t sample, c
     };
     static const bool no_gather = simka_test_knob("SIMKA_SKM_SPLIT") != nullptr;      // tests: the exact split instead of chunk sort + gather
     bool use_gather = *gather && !no_gather && L.d_cbase;
+    // Fill cursors per level-1 bucket (k_skm_scan): every tile of the launch bumps every bucket's cursor with a returning atomic, and one
+    // word serves one such atomic per ~11 ns -- a launch of T tiles cannot end before T x 11 ns, which is what a C3 sample's 184 000
+    // tiles ran at.  A launch that long gives every bucket 2^lsub cursors (the tile's number picks one); they share the bucket's region
+    // chunk by chunk.  Only where the chunk sort + gather take the records (the exact split wants a bucket contiguous) and the buckets
+    // are capacity-sized (the exact redo of an overflowed sample is the rare path); SIMKA_SCAN_SUB=n forces 2^n (tests: small inputs).
+    static const char *sub_env = simka_test_knob("SIMKA_SCAN_SUB");
+    uint32_t lsub = 0;
     auto layout = [&](uint32_t mode, ull capb) {
         launch_timed(ctx, KID_LAYOUT, [&] {
             SIMKA_LAUNCH(k_skm_layout, dim3(1), dim3(SKM_MAXB1), 0, st, L.d_b1_count, L.d_b1_start, L.d_b1_end, L.d_b1_cursor, B1, mode, capb,
                                ctx->d_arena_cursor, ctx->d_sample_base + sample, pass == 0 ? 1u : 0u, (const uint32_t *)flag, L.d_redo_count,
-                               use_gather ? L.d_cbase : (uint32_t *)nullptr, (uint32_t)SKM_CS_CHUNK);
+                               use_gather ? L.d_cbase : (uint32_t *)nullptr, (uint32_t)SKM_CS_CHUNK, lsub, L.d_b1_sub);
         }, st);
     };
+    ull scan_capb = 0;
     auto scan = [&](bool hist, const ull *limit) {
         launch_timed(ctx, hist ? KID_SCAN_HIST : KID_SKM_SCAN, [&] {
             SIMKA_LAUNCH(skm_scan_kernel(wi, fixed, hist), dim3(ntiles), dim3(SKM_BLOCK), scan_lds(hist), st, a, sk, L.d_b1_count, L.d_b1_cursor, L.d_skm_a, limit,
-                               hist ? (uint32_t *)nullptr : flag, caprec, rbytes, scan_lcap(hist), use_gather ? (uint32_t *)nullptr : L.d_skm_p);
+                               hist ? (uint32_t *)nullptr : flag, caprec, rbytes, scan_lcap(hist), use_gather ? (uint32_t *)nullptr : L.d_skm_p, hist ? 0u : lsub, scan_capb);
         }, st);
     };
     const uint32_t cstride = ((1u << sk.l2) + 2u + 1u) & ~1u;      // u16 entries per row of the chunk table (even: rows are 4-byte aligned)
@@ -827,9 +837,15 @@ static int skm_scan_split(simka_ctx *ctx, simka_ctx::Lane &L, uint32_t sample, c
         // expected records: one per (W + 1) / 2 k-mers (or per nmax, if a record takes fewer); a bucket gets its share + 12 % + slack.
         // An overflow flags the sample.
         const uint64_t est = (uint64_t)((double)kocc_up / std::max(1.0, std::min<double>((sk.W + 1) / 2.0, sk.nmax)) * 1.30 / sk.shard_count);
-        const uint64_t capb = est / B1 + est / B1 / 8 + 4096;
-        rec_cap = capb * B1;
+        uint64_t capb = est / B1 + est / B1 / 8 + 4096;
         if ((capb + SKM_CS_CHUNK - 1) / SKM_CS_CHUNK > SKM_G_MAXCH) use_gather = false;
+        if (use_gather && L.d_b1_sub) {
+            lsub = sub_env ? (uint32_t)std::min(std::max(atoi(sub_env), 0), SKM_MAXSUB) : (ntiles >= 2048u ? (uint32_t)SKM_MAXSUB : 0u);
+            while (lsub && ((capb + (((uint64_t)SKM_CS_CHUNK << lsub) - 1)) / ((uint64_t)SKM_CS_CHUNK << lsub) << lsub) > SKM_G_MAXCH) lsub--;      // (the rounded region must stay within the gather's chunk tables)
+            if (lsub) capb = (capb + (((uint64_t)SKM_CS_CHUNK << lsub) - 1)) / ((uint64_t)SKM_CS_CHUNK << lsub) * ((uint64_t)SKM_CS_CHUNK << lsub);
+        }
+        scan_capb = capb;
+        rec_cap = capb * B1;
         rc = ensure_cap(ctx, &L.d_skm_a, &L.skm_a_cap, rec_cap); if (rc) return rc;
         if (!use_gather) {
             rc = ensure_cap(ctx, &L.d_skm_b, &L.skm_b_cap, rec_cap); if (rc) return rc;
@@ -871,7 +887,7 @@ static int skm_scan_split(simka_ctx *ctx, simka_ctx::Lane &L, uint32_t sample, c
         launch_timed(ctx, KID_SKM_SPLIT, [&] {
             const size_t lds_cs = (((size_t)cstride * 2 + 15) & ~(size_t)15) + 64 + (size_t)SKM_CS_CHUNK * 16;
             SIMKA_LAUNCH(k_skm_chunksort, dim3((uint32_t)nch_max), dim3(SKM_CS_BLOCK), lds_cs, st, L.d_skm_a, (const ull *)L.d_b1_start, (const ull *)L.d_b1_count,
-                               (const uint32_t *)L.d_cbase, sk, L.d_ctab, cstride, (const uint32_t *)flag);
+                               (const uint32_t *)L.d_cbase, sk, L.d_ctab, cstride, (const uint32_t *)flag, lsub, (const ull *)L.d_b1_sub);
         }, st);
         HIPCHK(hipGetLastError());
         return SIMKA_OK;

@@ -56,6 +56,8 @@ typedef unsigned long long ull;
 #define SKM_MAXW 20
 #define SKM_RTAB 2048            // variable-length reads: read starts of one tile staged in LDS
 #define SKM_CHUNK 2048           // records per chunk of the level-2 kernels
+#define SKM_CS_CHUNK 8192         // records per chunk of k_skm_chunksort (and the unit in which the cursors of a bucket share its region)
+#define SKM_MAXSUB 3              // log2 of the fill cursors a level-1 bucket has at most
 #define SKM_L2_BLOCK 512
 #define SKM_CNT_BLOCK 512
 #define SKM_CNT_TS 4096          // slots of the count kernel's LDS table
@@ -141,7 +143,7 @@ __device__ __forceinline__ uint64_t skm_revcomp_k(uint64_t x, uint32_t sh) {
 template <int W, bool FIXED, bool HIST>
 __global__ void __launch_bounds__(SKM_BLOCK)
 k_skm_scan(SimkaScanArgs a, SimkaSkmCfg cfg, ull *b1_count, ull *b1_cursor, uint4 *l1_recs, const ull *b1_limit, uint32_t *ovf_flag, uint32_t caprec,
-           uint32_t rbytes, uint32_t lcap, uint32_t *l1_pid) {
+           uint32_t rbytes, uint32_t lcap, uint32_t *l1_pid, uint32_t lsub, ull capb) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     uint32_t &s_nrec = *(uint32_t *)(smem + 0);        // extra records of long runs (beyond the first of a start)
     uint32_t &s_nstart = *(uint32_t *)(smem + 4);
@@ -430,7 +432,11 @@ k_skm_scan(SimkaScanArgs a, SimkaSkmCfg cfg, ull *b1_count, ull *b1_cursor, uint
             if ((tid & 63u) == 63u) stmp[tid >> 6] = inc;
             excl = inc - h;
             h_res = h;
-            if (h) g_res = atomicAdd(&b1_cursor[tid * SKM_CSTRIDE], (ull)h);
+            // lsub > 0 (round 6): a bucket has 2^lsub fill cursors and the tile takes the one its number selects.  A returning atomic on ONE
+            // word is served every ~11 ns, whoever asks (MI355X_MICROARCH.md: "one word saturates at ~88 dequeues/us"), and every tile of the
+            // launch bumps every bucket's cursor: 184 000 tiles of a C3 sample kept each of the 256 words busy for 2.1 of the kernel's
+            // 2.5 ms -- the scan ran at the pace of its cursors.  The cursors of a bucket fill disjoint sets of its chunks (sub_pos below).
+            if (h) g_res = atomicAdd(&b1_cursor[(size_t)((tid << lsub) | (blockIdx.x & ((1u << lsub) - 1u))) * SKM_CSTRIDE], (ull)h);
         }
         __syncthreads();
         if (tid < SKM_MAXB1) {
@@ -454,6 +460,16 @@ k_skm_scan(SimkaScanArgs a, SimkaSkmCfg cfg, ull *b1_count, ull *b1_cursor, uint
     // ---- phase 4b: the records, straight to their place in the bucket order.  direct: more records than the staging area takes,
     // or no list (the staging area holds the partition ids): every record goes to its reserved global slot instead (phase 4d)
     const bool direct = !listed || s_nrec > caprec;
+    // where record u of the tile's reservation g in bucket b1 goes.  One cursor per bucket (lsub = 0): g is the absolute record index.
+    // 2^lsub cursors: g counts the records of cursor `sub` of the bucket, whose chunk j is chunk (j << lsub) | sub of the bucket's region
+    // [b1 * capb, (b1 + 1) * capb) -- the cursors fill the region's chunks side by side, so the chunks in use stay at its front and the
+    // chunk sort / the gather of the count kernels see one bucket as before (k_skm_layout, k_skm_chunksort).
+    const uint32_t sub = blockIdx.x & ((1u << lsub) - 1u);
+    auto rec_pos = [&](uint32_t b1, uint32_t g, uint32_t u_) -> ull {
+        if (lsub == 0u) return (ull)g + u_;
+        const uint32_t u = g + u_;
+        return (ull)b1 * capb + (((ull)(u / (uint32_t)SKM_CS_CHUNK) << lsub | sub) * (ull)SKM_CS_CHUNK) + (u % (uint32_t)SKM_CS_CHUNK);
+    };
     if (!direct) {
         for_runs([&](uint32_t e, uint32_t len, uint32_t pid) {
             const uint32_t b1 = cfg.pb ? pid >> (cfg.pb - cfg.l1) : 0u;
@@ -466,7 +482,7 @@ k_skm_scan(SimkaScanArgs a, SimkaSkmCfg cfg, ull *b1_count, ull *b1_cursor, uint
     }
     SKM_STOP_AT(5)
     if (tid < SKM_MAXB1) {
-        if (h_res && b1_limit && g_res + h_res > b1_limit[tid]) { *ovf_flag = 1u; g_res = ~0ull; }
+        if (h_res && b1_limit && g_res + h_res > b1_limit[(tid << lsub) | (blockIdx.x & ((1u << lsub) - 1u))]) { *ovf_flag = 1u; g_res = ~0ull; }
         gbase[tid] = g_res == ~0ull ? 0xffffffffu : (uint32_t)g_res;
     }
     __syncthreads();
@@ -478,18 +494,17 @@ k_skm_scan(SimkaScanArgs a, SimkaSkmCfg cfg, ull *b1_count, ull *b1_cursor, uint
             const uint4 rec = stage[i];
             const uint32_t b1 = cfg.pb ? skm_rec_pid(rec) >> (cfg.pb - cfg.l1) : 0u;
             const uint32_t g = gbase[b1];
-            if (g != 0xffffffffu) { l1_recs[(ull)g + (i - hist[b1])] = rec; if (l1_pid) l1_pid[(ull)g + (i - hist[b1])] = skm_rec_pid(rec); }       // (the exact split's first pass reads 4 bytes per record; the chunk sort needs no ids)
+            if (g != 0xffffffffu) { const ull at = rec_pos(b1, g, i - hist[b1]); l1_recs[at] = rec; if (l1_pid) l1_pid[at] = skm_rec_pid(rec); }       // (the exact split's first pass reads 4 bytes per record; the chunk sort needs no ids)
         }
     } else {
         // ---- phase 4d
         for_runs([&](uint32_t e, uint32_t len, uint32_t pid) {
             const uint32_t b1 = cfg.pb ? pid >> (cfg.pb - cfg.l1) : 0u;
             const uint32_t g32 = gbase[b1];
-            const ull g = g32;
             while (len) {
                 const uint32_t n = len < cfg.nmax ? len : cfg.nmax;
                 const uint32_t pos = atomicAdd(&lcur[b1], 1u);
-                if (g32 != 0xffffffffu) { l1_recs[g + (pos - hist[b1])] = cut(e, n, pid); if (l1_pid) l1_pid[g + (pos - hist[b1])] = pid; }
+                if (g32 != 0xffffffffu) { const ull at = rec_pos(b1, g32, pos - hist[b1]); l1_recs[at] = cut(e, n, pid); if (l1_pid) l1_pid[at] = pid; }
                 e += n; len -= n;
             }
         });
@@ -504,21 +519,38 @@ k_skm_scan(SimkaScanArgs a, SimkaSkmCfg cfg, ull *b1_count, ull *b1_cursor, uint
 // --------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(SKM_MAXB1)
 k_skm_layout(ull *b1_count, ull *b1_start, ull *b1_limit, ull *b1_cursor, uint32_t B1, uint32_t mode, ull cap,
-             ull *arena_cursor, ull *sample_base, uint32_t first_pass, const uint32_t *skip_flag, ull *redo_count, uint32_t *cbase, uint32_t cs_chunk) {
+             ull *arena_cursor, ull *sample_base, uint32_t first_pass, const uint32_t *skip_flag, ull *redo_count, uint32_t *cbase, uint32_t cs_chunk,
+             uint32_t lsub, ull *sub_count) {
     __shared__ ull s_cnt[SKM_MAXB1];
     const uint32_t tid = threadIdx.x;
     if (mode != 2u && tid == 0) { redo_count[0] = 0ull; redo_count[1] = 0ull; }      // [1]: the work counter of k_skm_count_fast
     if (mode == 1u) {
-        if (tid < B1) { b1_start[tid] = (ull)tid * cap; b1_cursor[tid * SKM_CSTRIDE] = (ull)tid * cap; b1_limit[tid] = (ull)(tid + 1) * cap; }
+        if (tid < B1) {
+            b1_start[tid] = (ull)tid * cap;
+            if (lsub == 0u) { b1_cursor[tid * SKM_CSTRIDE] = (ull)tid * cap; b1_limit[tid] = (ull)(tid + 1) * cap; }
+            else      // 2^lsub cursors: each counts its own records from 0 and owns cap >> lsub of the bucket's slots (cap: a multiple of cs_chunk << lsub)
+                for (uint32_t s_ = 0; s_ < (1u << lsub); s_++) { b1_cursor[(size_t)((tid << lsub) | s_) * SKM_CSTRIDE] = 0ull; b1_limit[(tid << lsub) | s_] = cap >> lsub; }
+        }
         if (tid == 0 && first_pass) *sample_base = *arena_cursor;
         return;
     }
     if (mode == 2u) {
         if (skip_flag && *skip_flag) return;
-        if (tid < B1) { const ull c = b1_cursor[tid * SKM_CSTRIDE] - b1_start[tid]; b1_count[tid] = c; s_cnt[tid] = c; }
+        if (tid < B1) {
+            if (lsub == 0u) { const ull c = b1_cursor[tid * SKM_CSTRIDE] - b1_start[tid]; b1_count[tid] = c; s_cnt[tid] = (c + cs_chunk - 1) / cs_chunk; }
+            else {      // chunk j of cursor s is chunk (j << lsub) | s of the bucket: the bucket's chunks in use end behind the last one any cursor reached
+                ull tot = 0, nch = 0;
+                for (uint32_t s_ = 0; s_ < (1u << lsub); s_++) {
+                    const ull c = b1_cursor[(size_t)((tid << lsub) | s_) * SKM_CSTRIDE];
+                    sub_count[(tid << lsub) | s_] = c; tot += c;
+                    if (c) { const ull last = ((((c - 1) / cs_chunk) << lsub) | s_) + 1; nch = last > nch ? last : nch; }
+                }
+                b1_count[tid] = tot; s_cnt[tid] = nch;
+            }
+        }
         if (cbase) {       // chunk numbering of k_skm_chunksort: bucket b owns the chunks [cbase[b], cbase[b + 1])
             __syncthreads();
-            if (tid == 0) { uint32_t run = 0; for (uint32_t b = 0; b < B1; b++) { cbase[b] = run; run += (uint32_t)((s_cnt[b] + cs_chunk - 1) / cs_chunk); } cbase[B1] = run; }
+            if (tid == 0) { uint32_t run = 0; for (uint32_t b = 0; b < B1; b++) { cbase[b] = run; run += (uint32_t)s_cnt[b]; } cbase[B1] = run; }
         }
         return;
     }
@@ -662,11 +694,11 @@ k_skm_split(const uint4 *l1_recs, const uint32_t *l1_pid, const ull *b1_start, c
 // needs no second record buffer and no id array -- the price is the gather in the count kernels (two 2-byte table entries per piece).
 //   cbase[b] = first chunk of bucket b in the chunk numbering of the sample (k_skm_layout), cbase[B1] = chunks of the sample.
 // --------------------------------------------------------------------------------------------
-#define SKM_CS_CHUNK 8192
 #define SKM_CS_BLOCK 1024
 #define SKM_CS_UNROLL (SKM_CS_CHUNK / SKM_CS_BLOCK)
 __global__ void __launch_bounds__(SKM_CS_BLOCK)
-k_skm_chunksort(uint4 *recs, const ull *b1_start, const ull *b1_count, const uint32_t *cbase, SimkaSkmCfg cfg, uint16_t *ctab, uint32_t cstride, const uint32_t *flag) {
+k_skm_chunksort(uint4 *recs, const ull *b1_start, const ull *b1_count, const uint32_t *cbase, SimkaSkmCfg cfg, uint16_t *ctab, uint32_t cstride, const uint32_t *flag,
+                uint32_t lsub, const ull *sub_count) {
     if (*flag) return;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const uint32_t l2 = cfg.pb - cfg.l1, F2 = 1u << l2, m2 = F2 - 1u, B1 = 1u << cfg.l1;
@@ -681,9 +713,14 @@ k_skm_chunksort(uint4 *recs, const ull *b1_start, const ull *b1_count, const uin
     uint32_t lo = 0, hi = B1;
     while (hi - lo > 1u) { const uint32_t mid = (lo + hi) >> 1; if (cbase[mid] <= gc) lo = mid; else hi = mid; }
     const uint32_t b1 = lo;
-    const ull i0 = (ull)(gc - cbase[b1]) * SKM_CS_CHUNK, n = b1_count[b1];
-    const ull st = b1_start[b1] + i0;
-    const uint32_t nc = (uint32_t)(n - i0 < (ull)SKM_CS_CHUNK ? n - i0 : (ull)SKM_CS_CHUNK);
+    const uint32_t cl = gc - cbase[b1];               // chunk of the bucket
+    const ull st = b1_start[b1] + (ull)cl * SKM_CS_CHUNK;
+    uint32_t nc;
+    if (lsub == 0u) { const ull i0 = (ull)cl * SKM_CS_CHUNK, n = b1_count[b1]; nc = (uint32_t)(n - i0 < (ull)SKM_CS_CHUNK ? n - i0 : (ull)SKM_CS_CHUNK); }
+    else {      // chunk (j << lsub) | s of the bucket is chunk j of its cursor s (k_skm_scan): full, the cursor's last, or beyond it (empty: an all-zero table row)
+        const ull c = sub_count[(b1 << lsub) | (cl & ((1u << lsub) - 1u))], i0 = (ull)(cl >> lsub) * SKM_CS_CHUNK;
+        nc = c > i0 ? (uint32_t)(c - i0 < (ull)SKM_CS_CHUNK ? c - i0 : (ull)SKM_CS_CHUNK) : 0u;
+    }
     for (uint32_t i = tid; i < (F2 + 2u) / 2u; i += SKM_CS_BLOCK) ((uint32_t *)ch)[i] = 0;
     uint4 rec[SKM_CS_UNROLL]; uint32_t lr[SKM_CS_UNROLL];
 #pragma unroll

@@ -1181,6 +1181,45 @@ def test_deep_samples_counted_in_passes(gpu_required):
         assert digest(p) == one, p
 
 
+@pytest.mark.parametrize("passes", [0, 3])
+def test_fill_cursors_per_bucket_are_result_neutral(gpu_required, golden_dir, tmp_path, passes):
+    """Round 6: a long launch of k_skm_scan gives every level-1 bucket 2^n fill cursors (a returning atomic on one word is served every
+    ~11 ns, and every tile bumps every bucket's cursor); the cursors share the bucket's region chunk by chunk, the chunk sort and the
+    count kernels' gather see the bucket as before.  SIMKA_SCAN_SUB forces n on small inputs: the statistics of tests/flat_digest.py
+    (synthetic samples, one with a poly-A third that overflows a bucket -> exact redo with one cursor) are identical for n = 0..3, alone and
+    under SIMKA_FORCE_PASSES; and the driver reproduces the goldens with eight cursors per bucket."""
+    import subprocess, sys
+
+    def digest(n):
+        env = dict(os.environ, SIMKA_SCAN_SUB=str(n))
+        if passes:
+            env["SIMKA_FORCE_PASSES"] = str(passes)
+        r = subprocess.run([sys.executable, os.path.join(ROOT_DIR, "tests", "flat_digest.py")], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=300)
+        lines = [l for l in r.stdout.splitlines() if l.startswith("DIGEST")]
+        assert r.returncode == 0 and lines, r.stdout[-2000:]
+        return lines[0]
+
+    one = digest(0)
+    for n in (1, 2, 3):
+        assert digest(n) == one, n
+    if passes:
+        return
+    from simka_amd import build as b
+    out = str(tmp_path / "o")
+    r = subprocess.run([b.CLI_PATH, "-in", os.path.join(golden_dir, "example", "simka_input.txt"), "-out", out, "-out-tmp", str(tmp_path / "tmp"), "-simple-dist", "-complex-dist",
+                        "-kmer-size", "31", "-abundance-min", "2"], env=dict(os.environ, SIMKA_SCAN_SUB="3"), stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    assert r.returncode == 0, r.stdout
+    truth = os.path.join(golden_dir, "truth", "results_k31_t2")
+    n = 0
+    for gzf in glob.glob(os.path.join(out, "*.csv.gz")):
+        ref = os.path.join(truth, os.path.basename(gzf)[:-3])
+        if os.path.exists(ref):
+            with gzip.open(gzf, "rb") as f, open(ref, "rb") as h:
+                assert f.read() == h.read(), os.path.basename(gzf)
+            n += 1
+    assert n == 20
+
+
 def test_cli_spectra_larger_than_the_arena_merge_by_partition_ranges(gpu_required, golden_dir, tmp_path):
     """When the solid spectra of all samples do not fit the HBM arena (here: -solid-capacity far too small) the driver notices the
     NOMEM, recounts with one-sample contexts, keeps the spectra in host memory and merges the partition space range by range;
