@@ -637,7 +637,10 @@ def main():
                     issue = {"valu_busy": sq["valu_busy"], "active": sq["active"], "wait": sq["wait"], "issue_stall": sq["issue_stall"], "lds_busy": sq["lds_busy"],
                              # lane-instructions per k-mer occurrence (wave instructions x 64 lanes / k-mer occurrences of a launch)
                              "inst_per_kmer": {c: per_launch("wave_inst_" + c) * 64.0 / kocc_per_launch for c in ("valu", "salu", "lds", "vmem")},
-                             "cycles_per_inst": sq["cycles_per_inst"], "waves_per_simd": WAVES_PER_SIMD.get(dom.split("<")[0]),
+                             # cycles of a wave's lifetime per instruction it executes (waits included), and the part of them in which the wave had an
+                             # instruction in flight: at waves_per_simd resident waves a SIMD issues once per active_cycles_per_inst / waves cycles
+                             "wave_cycles_per_inst": sq["cycles_per_inst"], "active_cycles_per_inst": sq["cycles_per_inst"] * sq["active"] if sq["cycles_per_inst"] else None,
+                             "waves_per_simd": WAVES_PER_SIMD.get(dom.split("<")[0]),
                              "source": os.path.relpath(sf, ROOT)}
                     issue["inst_per_kmer"]["all"] = sum(issue["inst_per_kmer"].values())
         except Exception:

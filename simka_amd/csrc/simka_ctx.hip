@@ -842,8 +842,9 @@ static int skm_scan_split(simka_ctx *ctx, simka_ctx::Lane &L, uint32_t sample, c
         if (use_gather && L.d_b1_sub) {
             // Measured (12 C3 samples, ms): 1 / 2 / 4 / 8 cursors: 30.7 / 25.9 / 25.7 / 26.8 -- the cursors ran just past their limit, two
             // lift it, and every further one costs a partial chunk per bucket (C2, 0.8 chunks per bucket: 8 cursors = the chunk sort +45 %).
-            // Two cursors where a bucket fills >= 16 chunks (C3: 67), one otherwise.
-            lsub = sub_env ? (uint32_t)std::min(std::max(atoi(sub_env), 0), SKM_MAXSUB) : (est / B1 >= 16ull * SKM_CS_CHUNK ? 1u : 0u);
+            // c3_10 (100 x 1M x 150 bp, 7 chunks per bucket): two cursors 27.7 -> 22.7 ms per 100 samples, the chunk sort + 0.2; C2 (k = 21): neutral.
+            // Two cursors where a bucket is sized for >= 4 chunks, one otherwise (small inputs: a second partial chunk per bucket for nothing).
+            lsub = sub_env ? (uint32_t)std::min(std::max(atoi(sub_env), 0), SKM_MAXSUB) : (est / B1 >= 4ull * SKM_CS_CHUNK ? 1u : 0u);
             while (lsub && ((capb + (((uint64_t)SKM_CS_CHUNK << lsub) - 1)) / ((uint64_t)SKM_CS_CHUNK << lsub) << lsub) > SKM_G_MAXCH) lsub--;      // (the rounded region must stay within the gather's chunk tables)
             if (lsub) capb = (capb + (((uint64_t)SKM_CS_CHUNK << lsub) - 1)) / ((uint64_t)SKM_CS_CHUNK << lsub) * ((uint64_t)SKM_CS_CHUNK << lsub);
         }
