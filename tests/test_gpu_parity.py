@@ -1386,13 +1386,15 @@ def test_example_goldens_through_the_sort_path(gpu_required, golden_dir, tmp_pat
     assert n == 20
 
 
-def test_randomised_inputs_against_the_oracle(gpu_required, oracle_mod):
-    """scripts/fuzz_vs_oracle.py for 20 s: random k (1..63), abundance windows, sample counts, read lengths (0..180, shorter than k
-    included), N / IUPAC / lowercase letters, empty samples, partition geometries, distance families -- totals and every
-    accumulator bit-exact, matrices within 1e-6 (NaN where the reference's arithmetic gives NaN: an empty sample with -complex-dist)."""
+@pytest.mark.parametrize("seconds,seed,env", [(20, 12345, {}), (40, 60606, {"SIMKA_SCAN_SUB": "1"}), (30, 777, {"SIMKA_LANES": "1", "SIMKA_SCAN_SUB": "3"})])
+def test_randomised_inputs_against_the_oracle(gpu_required, oracle_mod, seconds, seed, env):
+    """scripts/fuzz_vs_oracle.py for 20 + 40 + 30 s (three seeds; ~1500 random cases): random k (1..127), abundance windows, sample counts, read
+    lengths (0..180, shorter than k included), N / IUPAC / lowercase letters, empty samples, partition geometries, distance families --
+    totals and every accumulator bit-exact, matrices within 1e-6 (NaN where the reference's arithmetic gives NaN: an empty sample with
+    -complex-dist).  The second and third run force two / eight fill cursors per level-1 bucket (round 6) on these small inputs."""
     import subprocess, sys
-    r = subprocess.run([sys.executable, os.path.join(ROOT_DIR, "scripts", "fuzz_vs_oracle.py"), "20", "12345"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
-                       text=True, timeout=600)
+    r = subprocess.run([sys.executable, os.path.join(ROOT_DIR, "scripts", "fuzz_vs_oracle.py"), str(seconds), str(seed)], stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
+                       text=True, timeout=600, env=dict(os.environ, **env))
     assert r.returncode == 0 and "fuzz ok" in r.stdout, r.stdout[-3000:]
     # the script opens with the KL edge block (identical and near-identical samples, k = 21 and 31: the both-present sum cancels to exactly 0
     # and the Jensen-Shannon cell is 1 as in the reference, a near-identical pair never goes negative) -- part of this test, not a side script
