@@ -65,6 +65,9 @@ typedef unsigned long long ull;
 #define SKM_FAST_BLOCK 256       // k_skm_count_fast: 4 waves, 2048 slots, four blocks per CU
 #define SKM_FAST_TS 2048
 #define SKM_FAST_WCHUNK 8         // partitions a block takes per grab of the work counter
+#ifndef SKM_FAST_TAIL
+#define SKM_FAST_TAIL 12           // queue entries (at most) that are finished one CAS at a time instead of by another pass of the look-ahead drain; 0: off
+#endif
 #ifndef SKM_FAST_U
 #define SKM_FAST_U 1             // k-mers per lane in flight in the insert loop (2: 1..5 % slower once the partitions are handed out dynamically; 4: three blocks per CU)
 #endif
@@ -1703,7 +1706,31 @@ k_skm_count_fast(SimkaSkmSrc src, SimkaSkmCfg cfg, SimkaKeyCfg kcfg, uint32_t am
             PH(2)
         }
         DBG_ADD(8, my_k) DBG_ADD(12, 1) DBG_ADD(14, qn)
+#if SKM_FAST_TAIL
+        // the last few entries of the queue (what a pass re-queues: 1.2 passes of ~5 lanes per wave and partition on C3) are not worth a pass of
+        // the look-ahead drain (~60 VALU for 64 lanes): each of them walks on with one CAS per slot until it is placed (round 6: -0.8 %)
+        while (qn > SKM_FAST_TAIL) { drain(); DBG_ADD(13, 1) }
+        if (qn) {
+            const bool a = lane < qn;
+            ull key = 0; uint32_t slot = 0, passes = 0;
+            if (a) { key = qk[lane]; const uint32_t meta = qm[lane]; slot = meta & (TS - 1u); passes = meta >> 11; }
+            bool pend_ = a;
+            while (__ballot(pend_)) {
+                if (pend_) {
+                    const ull prev = atomicCAS(&tkeys[slot], SIMKA_EMPTY_KEY, key);
+                    if (prev == SIMKA_EMPTY_KEY || prev == key) { atomicAdd(&tcnt[slot], 1u); pend_ = false; }
+                    else {
+                        slot = (slot & ~bmask) | ((slot + 1u) & bmask);
+                        if (++passes >= 128u) { s_fail = 1u; pend_ = false; }      // (a sort block has 128 slots: full)
+                    }
+                }
+            }
+            qn = 0;
+            DBG_ADD(13, 1)
+        }
+#else
         while (qn) { drain(); DBG_ADD(13, 1) }
+#endif
         if (GATHER) tabulate(desc_n);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __syncthreads();
@@ -1715,7 +1742,7 @@ k_skm_count_fast(SimkaSkmSrc src, SimkaSkmCfg cfg, SimkaKeyCfg kcfg, uint32_t am
         // ---- summary in slot order (SimkaCompressedProcessor::process, ref: src/minikc/MiniKC.hpp:54-79)
         uint32_t cs[SPT]; ull ks[SPT];
         uint32_t nsol = 0, ndall = 0;
-        ull D = 0, N = 0, Q = 0;
+        ull N = 0, Q = 0;
         {   // the thread's 8 slots: vector loads, then the slots are reset unconditionally (vector stores, no branches).
             // The 16 threads of a group own one sort block of 128 slots (only the order of the BLOCKS matters downstream): thread l of the
             // group takes the slot pairs 2 l + 32 m, m = 0..3 -- the 16-byte key vectors l + 16 m, consecutive over the lanes of every
@@ -1723,25 +1750,30 @@ k_skm_count_fast(SimkaSkmSrc src, SimkaSkmCfg cfg, SimkaKeyCfg kcfg, uint32_t am
             // count vectors (l >> 1) + 8 m that hold them (neighbouring lanes read the same vector).
             static_assert(SPT == 8 && TS == 16u * 128u && SKM_FAST_BLOCK == 256, "16 groups of 16 threads, a sort block each");
             const uint32_t grp = tid >> 4, l = tid & 15u;
-            uint4 *c4 = (uint4 *)(tcnt + grp * 128u) + (l >> 1); ulonglong2 *k2 = (ulonglong2 *)(tkeys + grp * 128u) + l;
-            const uint4 ca = c4[0], cb = c4[8], cc = c4[16], cd = c4[24];
+            // (round 6: a lane reads its own two counts per row as one 8-byte word -- consecutive over the lanes like the key vectors -- instead of
+            //  the 16-byte vector it shared with its neighbour and a select per count)
+            uint2 *c2 = (uint2 *)(tcnt + grp * 128u) + l; ulonglong2 *k2 = (ulonglong2 *)(tkeys + grp * 128u) + l;
+            const uint2 ca = c2[0], cb = c2[16], cc = c2[32], cd = c2[48];
             const ulonglong2 ka = k2[0], kb = k2[16], kc = k2[32], kd = k2[48];
-            const uint4 z = make_uint4(0, 0, 0, 0); const ulonglong2 ek = make_ulonglong2(SIMKA_EMPTY_KEY, SIMKA_EMPTY_KEY);
-            c4[0] = z; c4[8] = z; c4[16] = z; c4[24] = z; k2[0] = ek; k2[16] = ek; k2[32] = ek; k2[48] = ek;      // (both lanes of a pair zero the same count vector)
-            const bool hi_ = (l & 1u) != 0u;
-            cs[0] = hi_ ? ca.z : ca.x; cs[1] = hi_ ? ca.w : ca.y; cs[2] = hi_ ? cb.z : cb.x; cs[3] = hi_ ? cb.w : cb.y;
-            cs[4] = hi_ ? cc.z : cc.x; cs[5] = hi_ ? cc.w : cc.y; cs[6] = hi_ ? cd.z : cd.x; cs[7] = hi_ ? cd.w : cd.y;
+            const uint2 z = make_uint2(0, 0); const ulonglong2 ek = make_ulonglong2(SIMKA_EMPTY_KEY, SIMKA_EMPTY_KEY);
+            c2[0] = z; c2[16] = z; c2[32] = z; c2[48] = z; k2[0] = ek; k2[16] = ek; k2[32] = ek; k2[48] = ek;
+            cs[0] = ca.x; cs[1] = ca.y; cs[2] = cb.x; cs[3] = cb.y; cs[4] = cc.x; cs[5] = cc.y; cs[6] = cd.x; cs[7] = cd.y;
             ks[0] = ka.x; ks[1] = ka.y; ks[2] = kb.x; ks[3] = kb.y; ks[4] = kc.x; ks[5] = kc.y; ks[6] = kd.x; ks[7] = kd.y;
         }
+        uint32_t w_ndall = 0;                   // distinct k-mers of the wave's slots: counted on the scalar unit from the compare masks
 #pragma unroll
         for (uint32_t q = 0; q < SPT; q++) {
             const uint32_t c = cs[q];
             const bool any = c != 0u, sol = any && !(c < amin || c > amax);
-            ndall += any ? 1u : 0u;
+            w_ndall += (uint32_t)__popcll(__ballot(any));
             nsol += sol ? 1u : 0u;
-            D += sol ? 1ull : 0ull; N += sol ? (ull)c : 0ull; Q += sol ? (ull)c * (ull)c : 0ull;
             cs[q] = sol ? c : 0u;
+            // (the filtered count: no select per accumulator, D is nsol, one multiply-add per sum -- round 6: -3 % of the kernel)
+            asm("v_mad_u64_u32 %0, vcc, %1, 1, %0" : "+v"(N) : "v"(cs[q]) : "vcc");      // N += cs[q] (64-bit) in ONE vector instruction
+            Q += (ull)cs[q] * (ull)cs[q];
         }
+        ndall = lane == 0u ? w_ndall : 0u;
+        const ull D = nsol;
         const bool failed = s_fail != 0u;
         // the wave's solid records, in slot order, go to its (now empty) retry queue: keys [0, cap), counts behind them
         constexpr uint32_t wcap = (SKM_FAST_QCAP * 10u) / 12u;                    // records the region takes
