@@ -798,7 +798,7 @@ static int skm_scan_split(simka_ctx *ctx, simka_ctx::Lane &L, uint32_t sample, c
     // LDS region R of the scan kernel: the m-mer hashes first, then staged records + the list of run starts (6 bytes each, as many
     // as records fit)
     const uint32_t rbytes = (uint32_t)std::max<size_t>((size_t)16 * SKM_NT * 4, (size_t)caprec * 22 + 16);
-    auto scan_lcap = [&](bool hist) { return (uint32_t)((rbytes - (hist ? 0 : (size_t)caprec * 16) - 16) / 6); };
+    auto scan_lcap = [&](bool hist) { return (uint32_t)((rbytes - (hist ? 0 : (size_t)caprec * 16) - 16) / 8); };      // (8 bytes per run start)
     auto scan_lds = [&](bool) {
         // 40 304 bytes at W = 16, fixed-length reads: 32 LDS granules of 1280 bytes, FOUR blocks per CU -- which pays for a launch of a
         // few waves of tiles (c5_50, 1845 tiles: 21.1 -> 18.8 ms per 500 samples) and costs a long one 5 % (C3, 184 000 tiles: 28.5 ->

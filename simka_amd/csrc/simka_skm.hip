@@ -158,8 +158,8 @@ k_skm_scan(SimkaScanArgs a, SimkaSkmCfg cfg, ull *b1_count, ull *b1_cursor, uint
     //   a tile with more starts than the list takes (rare): partition ids of all entries, in the layout of the hashes.
     uint32_t *hm = (uint32_t *)(smem + SKM_SCAN_HEAD);              // [4][SKM_NT][4]
     uint4 *stage = (uint4 *)hm;                                     // [caprec] (!HIST)
-    uint16_t *slist = (uint16_t *)(stage + (HIST ? 0u : caprec));   // [lcap] entry indices of the run starts
-    uint32_t *spid = (uint32_t *)(slist + ((lcap + 1u) & ~1u));     // [lcap] their minimizer values
+    uint2 *slist = (uint2 *)(stage + (HIST ? 0u : caprec));         // [lcap] run starts: (entry index, minimizer value) -- one 8-byte LDS access per start (round 6; it
+                                                                    // was a 2-byte and a 4-byte array: two stores with their addresses in each of the 16 unrolled tests)
     uint32_t *tb = (uint32_t *)(smem + SKM_SCAN_HEAD + rbytes);     // [TILE/16 + 8] the tile's bases, 16 per word
     uint32_t *smask = tb + SKM_TILE / 16 + 8;                       // [BLOCK] start | brk << 16
     uint32_t *hist = smask + SKM_BLOCK + 4;                         // [B1]   (smask has 4 pad words: all-break)
@@ -371,7 +371,7 @@ k_skm_scan(SimkaScanArgs a, SimkaSkmCfg cfg, ull *b1_count, ull *b1_cursor, uint
         if (ns && p + ns <= lcap) {
 #pragma unroll
             for (int j = 1; j <= SKM_SEG; j++)
-                if ((start >> (j - 1)) & 1u) { slist[p] = (uint16_t)(SKM_SEG * tid + (uint32_t)(j - 1)); spid[p] = mh[j]; p++; }      // (the minimizer value: its partition id is one multiply per START, not per entry)
+                if ((start >> (j - 1)) & 1u) { slist[p] = make_uint2(SKM_SEG * tid + (uint32_t)(j - 1), mh[j]); p++; }      // (the minimizer value: its partition id is one multiply per START, not per entry)
         }
     }
     __syncthreads();
@@ -397,13 +397,26 @@ k_skm_scan(SimkaScanArgs a, SimkaSkmCfg cfg, ull *b1_count, ull *b1_cursor, uint
         const ull look = ((ull)(own_ >> (jb + 1u))) | (n1 << (15u - jb)) | (n2 << (31u - jb)) | (n3 << (47u - jb));
         return (uint32_t)__ffsll((long long)look);       // look != 0: a break within 48 positions is guaranteed
     };
-    // f(entry, run length, partition id) for every run of the tile that this shard owns
+    // f(entry, run length, partition id) for every run of the tile that this shard owns.  The FIRST walk over the list (phase 3c) leaves
+    // what it worked out -- run length from the break masks (five LDS reads), partition id, ownership -- in the list entry itself:
+    // (entry | length << 16, partition id), length 0 = not this shard's; the later walks read it back with one 8-byte access.
+    // (round 5 measured the same idea with a side array slower: the scan ran at the pace of its cursors then, see k_skm_scan's reservation)
+    bool first_walk = true;
     auto for_runs = [&](auto &&f) {
         if (listed) {
             for (uint32_t si = tid; si < nstart; si += SKM_BLOCK) {
-                const uint32_t e = slist[si], pid = skm_pid(spid[si], cfg.pb);
-                if (skm_owns(pid, cfg)) f(e, len_of(e), pid);
+                const uint2 sl = slist[si];
+                if (first_walk) {
+                    const uint32_t e = sl.x, pid = skm_pid(sl.y, cfg.pb);
+                    const uint32_t len = skm_owns(pid, cfg) ? len_of(e) : 0u;
+                    slist[si] = make_uint2(e | (len << 16), pid);
+                    if (len) f(e, len, pid);
+                } else {
+                    const uint32_t len = sl.x >> 16;
+                    if (len) f(sl.x & 0xffffu, len, sl.y);
+                }
             }
+            first_walk = false;
         } else if (owner) {
             uint32_t todo = start;
             while (todo) {
