@@ -26,6 +26,7 @@
 //                            bits [102,107) n - 1        bits [107,128) partition id (<= 21 bits)
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <type_traits>
 #include "simka_device.h"
 #include "simka_kernels.h"
 
@@ -127,8 +128,9 @@ __device__ __forceinline__ uint64_t skm_revcomp64(uint64_t x) {
 // reverse complement of the k-mer in the low 2k bits of x: skm_revcomp64(x) >> (64 - 2k), with 32-bit funnel shifts (sh = 64 - 2k, wave-uniform)
 __device__ __forceinline__ uint64_t skm_revcomp_k(uint64_t x, uint32_t sh) {
     const uint32_t rl = skm_swapcomp32(__brev((uint32_t)(x >> 32))), rh = skm_swapcomp32(__brev((uint32_t)x));
-    if (sh < 32u) return ((uint64_t)(rh >> sh) << 32) | __builtin_amdgcn_alignbit(rh, rl, sh);
-    return (uint64_t)(rh >> (sh - 32u));
+    // (ONE 64-bit shift: it costs what one 32-bit funnel shift costs -- profiles/r05_valu_rate.txt -- where the two-case form with 32-bit
+    //  shifts was compiled to two shifts, a funnel shift and two selects on the wave-uniform case: round 6)
+    return (((uint64_t)rh << 32) | rl) >> sh;
 }
 
 // --------------------------------------------------------------------------------------------
@@ -806,8 +808,9 @@ struct SimkaSkmSrc {
 // --------------------------------------------------------------------------------------------
 __device__ __forceinline__ uint64_t skm_kmer_at(const uint4 &r, uint32_t j, const SimkaSkmCfg &cfg) {
     const uint32_t s = 2u * j, wd = s >> 5, sh = s & 31u;
-    const uint32_t d3 = r.w & 63u;
-    const uint32_t a0 = wd ? r.y : r.x, a1 = wd ? r.z : r.y, a2 = wd ? d3 : r.z;
+    // (the record's last word goes in unmasked: what rides above its six base bits lands beyond bit 2 (j + k) of the window, and a k-mer
+    //  of the record never reaches beyond its 102 bits -- the mask of the k-mer removes it)
+    const uint32_t a0 = wd ? r.y : r.x, a1 = wd ? r.z : r.y, a2 = wd ? r.w : r.z;
     const uint32_t lo = __builtin_amdgcn_alignbit(a1, a0, sh), hi = __builtin_amdgcn_alignbit(a2, a1, sh);
     return (((uint64_t)hi << 32) | lo) & cfg.kmask;
 }
@@ -1673,31 +1676,34 @@ k_skm_count_fast(SimkaSkmSrc src, SimkaSkmCfg cfg, SimkaKeyCfg kcfg, uint32_t am
                     const uint32_t c = (f0_ >> 6) + u;                  // (wave-uniform; c < SKM_FAST_BMW while f0_ < kt)
                     act[u] = f0_ + 64u * u + lane < kt;
                     const uint32_t mlo = __builtin_amdgcn_readlane(bmlo, c & (SKM_FAST_BMW - 1u)), mhi = __builtin_amdgcn_readlane(bmhi, c & (SKM_FAST_BMW - 1u));
-                    const uint32_t below = __builtin_amdgcn_mbcnt_hi(mhi, __builtin_amdgcn_mbcnt_lo(mlo, 0u));
-                    const uint32_t own = ((lane < 32u ? mlo : mhi) >> (lane & 31u)) & 1u;
-                    const uint32_t r = (rbefore + below + own - 1u) & 63u;      // (a lane beyond the last k-mer: any record)
+                    // records that start at or below the lane's k-mer = the set bits of the chunk's mask up to and INCLUDING the lane: bit 0 plus the
+                    // bits below the lane of the mask shifted down by one (scalar unit) -- two mbcnt, no per-lane extraction of the own bit (round 6)
+                    const ull m1 = (((ull)mhi << 32) | mlo) >> 1;
+                    const uint32_t r = __builtin_amdgcn_mbcnt_hi((uint32_t)(m1 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m1, rbefore + (mlo & 1u) - 1u)) & 63u;      // (a lane beyond the last k-mer: any record)
                     rbefore += (uint32_t)__popc(mlo) + (uint32_t)__popc(mhi);
                     rx[u] = wrec[r];
                 }
             };
             fetch(0);
-            for (uint32_t f0 = 0; f0 < kt; f0 += 64u * U) {
+            // one iteration: 64 U k-mers of the wave.  TAIL: the wave's last, partly filled iteration -- only there a lane can lie beyond the
+            // last k-mer (it swaps EMPTY for EMPTY and adds 0: straight-line code); the full iterations before it carry no activity mask,
+            // no select of the key and no masked counter value (round 6: four vector instructions less per 64 k-mers)
+            auto step = [&](uint32_t f0, auto tail_c) {
+                constexpr bool TAIL = decltype(tail_c)::value;
                 ull cu[U]; uint32_t su[U]; bool actc[U];
                 // cut, reverse complement, canonical, slot
 #pragma unroll
                 for (uint32_t u = 0; u < U; u++) {
-                    actc[u] = act[u];
+                    actc[u] = TAIL ? act[u] : true;
                     const uint64_t fw = skm_kmer_at(rx[u], (f0 + 64u * u + lane - (rx[u].w >> 6)) & 31u, cfg);
                     const uint64_t rv = skm_revcomp_k(fw, 64u - 2u * cfg.k);
                     cu[u] = fw < rv ? fw : rv;
                     su[u] = simka_key_hash32(cu[u]) >> (32u - TSL);
                 }
-                // all U inserts in flight together, the next iteration's records behind them.  No lane is masked off: a lane
-                // beyond the wave's last k-mer swaps EMPTY for EMPTY and adds 0, so the whole step is straight-line code and every wait
-                // counts exactly the LDS operations it needs
+                // all U inserts in flight together, the next iteration's records behind them
                 ull pu[U];
 #pragma unroll
-                for (uint32_t u = 0; u < U; u++) { if (!actc[u]) cu[u] = SIMKA_EMPTY_KEY; pu[u] = atomicCAS(&tkeys[su[u]], SIMKA_EMPTY_KEY, cu[u]); }
+                for (uint32_t u = 0; u < U; u++) { if (TAIL && !actc[u]) cu[u] = SIMKA_EMPTY_KEY; pu[u] = atomicCAS(&tkeys[su[u]], SIMKA_EMPTY_KEY, cu[u]); }
                 fetch(f0 + 64u * U);                 // (beyond the last k-mer: no lane is active, every lane reads some record)
 #pragma unroll
                 for (uint32_t u = 0; u < U; u++) {
@@ -1714,7 +1720,10 @@ k_skm_count_fast(SimkaSkmSrc src, SimkaSkmCfg cfg, SimkaKeyCfg kcfg, uint32_t am
                     }
                 }
                 while (qn >= 64u) drain();
-            }
+            };
+            const uint32_t kfull = kt - kt % (64u * U);
+            for (uint32_t f0 = 0; f0 < kfull; f0 += 64u * U) step(f0, std::false_type());
+            if (kfull < kt) step(kfull, std::true_type());
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // the wave's bitmap / records are rewritten by the next batch
             PH(2)
         }
