@@ -342,9 +342,12 @@ k_skm_scan(SimkaScanArgs a, SimkaSkmCfg cfg, ull *b1_count, ull *b1_cursor, uint
     uint32_t start = 0, brk = 0xffffu;
     if (owner) {
         // bit j - 1: the minimizer changes between e_{j-1} and e_j; then start = valid & (previous invalid | change), as masks
+        // (from the top down, neq = 2 neq + (mh[j] != mh[j - 1]): a compare and an add-with-carry per position -- written with shifts and ORs
+        //  the compiler spends a select on every bit: round 6)
         uint32_t neq = 0;
 #pragma unroll
-        for (int j = 1; j <= SKM_SEG; j++) neq |= (mh[j] != mh[j - 1] ? 1u : 0u) << (j - 1);
+        for (int j = SKM_SEG; j >= 1; j--)
+            asm("v_cmp_ne_u32 vcc, %1, %2\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(neq) : "v"(mh[j]), "v"(mh[j - 1]) : "vcc");
         if (tid == SKM_OWN_LO / SKM_SEG) neq |= 1u;                                  // a tile never continues a run
         const uint32_t V = (valid >> 1) & 0xffffu, PV = valid & 0xffffu;
         start = V & (~PV | neq);
