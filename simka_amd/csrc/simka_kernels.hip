@@ -1014,79 +1014,87 @@ k_pairs(const SimkaSpan *spans, const ull *cursors, const ull *entries, const ui
             uint32_t ix = TILED ? (uint32_t)idxA[a0 + x] : a0 + x;
             ull ex = ent[ix];
             PP(5)
-            for (; p < pend; p++) {
-                const uint32_t iy = rect ? (uint32_t)idxB[b0 + y] : (TILED ? (uint32_t)idxA[a0 + y] : a0 + y);
-                const ull ey = ent[iy];
-                uint32_t si = (uint32_t)(ex >> 32), sj = (uint32_t)(ey >> 32);
-                uint32_t ci = (uint32_t)ex, cj = (uint32_t)ey;
-                uint32_t li, lj, cell;
-                if (!TILED) {      // branch-free: order the pair with selects, the cell from the smaller sample's row start
-                    const uint32_t rx_ = si >> 16, ry_ = sj >> 16;
-                    si &= 0xffffu; sj &= 0xffffu;
-                    const bool lo = si < sj;
-                    const uint32_t a_ = lo ? ci : cj, b_ = lo ? cj : ci, smin = lo ? si : sj, smax = lo ? sj : si;
-                    cell = (lo ? rx_ : ry_) + smax - 1u;
-                    ci = a_; cj = b_; si = smin; sj = smax; li = si; lj = sj;
-                } else {
-                // off-diagonal tiles: every member of A precedes every member of B.  Elsewhere order the pair.
-                if (!rect && si > sj) { uint32_t t_ = si; si = sj; sj = t_; t_ = ci; ci = cj; cj = t_; }
-                li = si - baseI; lj = sj - baseJ;
-                cell = rect ? li * T + lj : li * TD - ((li * (li + 1u)) >> 1) + (lj - li - 1u);   // TD <= 65535: fits 32 bits
-                }
-#ifdef SIMKA_EXP_PAIRS_NO_BILINEAR     // experiment (garbage S / a / chord): what the pair loop costs when the bilinear accumulators are taken off it (upper bound of an MFMA offload)
-                if (pc.simple && smallc) { atomicAdd(&pk[1 * CP + cell], (ull)(ci < cj ? ci : cj) | ((ull)pair_isqrt32(ci * cj) << 32)); }
-                else
-#endif
-                {
-                atomicAdd(&pk[0 * CP + cell], (ull)ci | ((ull)cj << 32));                       // S_ij | S_ji
-                atomicAdd(&pk[1 * CP + cell], 1ull | ((ull)(ci < cj ? ci : cj) << 32));         // a | bc
-                }
-#ifdef SIMKA_EXP_PAIRS_NO_BILINEAR
-                if (pc.simple && !smallc) {
-#else
-                if (pc.simple) {
-#endif
-                    if (smallc) {       // (uniform per span) counts below 2^15: the product is a 32-bit value below 2^30
-                        const uint32_t prod32 = ci * cj;
-                        atomicAdd(&pk[2 * CP + cell], (ull)prod32 | ((ull)pair_isqrt32(prod32) << 32));  // chord | hell
+            // The pair loop in two instances (round 6): FAST = what C3 runs -- -simple-dist, every product of the span a 32-bit value, no
+            // -complex-dist -- with the three wave-uniform flags compile-time constants (the generic instance tests them for every pair: five
+            // scalar tests and branches in a ~35-instruction iteration).
+            auto pair_loop = [&](auto fast_c) {
+                constexpr bool FAST = decltype(fast_c)::value;
+                const bool simple_ = FAST ? true : (pc.simple != 0u), smallc_ = FAST ? true : smallc, cplx_ = FAST ? false : cplx;
+                for (; p < pend; p++) {
+                    const uint32_t iy = rect ? (uint32_t)idxB[b0 + y] : (TILED ? (uint32_t)idxA[a0 + y] : a0 + y);
+                    const ull ey = ent[iy];
+                    uint32_t si = (uint32_t)(ex >> 32), sj = (uint32_t)(ey >> 32);
+                    uint32_t ci = (uint32_t)ex, cj = (uint32_t)ey;
+                    uint32_t li, lj, cell;
+                    if (!TILED) {      // branch-free: order the pair with selects, the cell from the smaller sample's row start
+                        const uint32_t rx_ = si >> 16, ry_ = sj >> 16;
+                        si &= 0xffffu; sj &= 0xffffu;
+                        const bool lo = si < sj;
+                        const uint32_t a_ = lo ? ci : cj, b_ = lo ? cj : ci, smin = lo ? si : sj, smax = lo ? sj : si;
+                        cell = (lo ? rx_ : ry_) + smax - 1u;
+                        ci = a_; cj = b_; si = smin; sj = smax; li = si; lj = sj;
                     } else {
-                        const ull prod = (ull)ci * (ull)cj;
-                        const ull hell = (ull)pair_isqrt(prod) << 32;
-                        if (chord_fast) atomicAdd(&pk[2 * CP + cell], (ull)(uint32_t)prod | hell);  // chord | hell
-                        else {   // huge counts: the product goes straight to the global u64 cell
-                            atomicAdd(&pk[2 * CP + cell], hell);
-                            atomicAdd(&acc[SIMKA_ACC_CHORD * pc.nb_pairs + simka_pair_index(si, sj, N)], prod);
+                    // off-diagonal tiles: every member of A precedes every member of B.  Elsewhere order the pair.
+                    if (!rect && si > sj) { uint32_t t_ = si; si = sj; sj = t_; t_ = ci; ci = cj; cj = t_; }
+                    li = si - baseI; lj = sj - baseJ;
+                    cell = rect ? li * T + lj : li * TD - ((li * (li + 1u)) >> 1) + (lj - li - 1u);   // TD <= 65535: fits 32 bits
+                    }
+    #ifdef SIMKA_EXP_PAIRS_NO_BILINEAR     // experiment (garbage S / a / chord): what the pair loop costs when the bilinear accumulators are taken off it (upper bound of an MFMA offload)
+                    if (simple_ && smallc_) { atomicAdd(&pk[1 * CP + cell], (ull)(ci < cj ? ci : cj) | ((ull)pair_isqrt32(ci * cj) << 32)); }
+                    else
+    #endif
+                    {
+                    atomicAdd(&pk[0 * CP + cell], (ull)ci | ((ull)cj << 32));                       // S_ij | S_ji
+                    atomicAdd(&pk[1 * CP + cell], 1ull | ((ull)(ci < cj ? ci : cj) << 32));         // a | bc
+                    }
+    #ifdef SIMKA_EXP_PAIRS_NO_BILINEAR
+                    if (simple_ && !smallc_) {
+    #else
+                    if (simple_) {
+    #endif
+                        if (smallc_) {       // (uniform per span) counts below 2^15: the product is a 32-bit value below 2^30
+                            const uint32_t prod32 = ci * cj;
+                            atomicAdd(&pk[2 * CP + cell], (ull)prod32 | ((ull)pair_isqrt32(prod32) << 32));  // chord | hell
+                        } else {
+                            const ull prod = (ull)ci * (ull)cj;
+                            const ull hell = (ull)pair_isqrt(prod) << 32;
+                            if (chord_fast) atomicAdd(&pk[2 * CP + cell], (ull)(uint32_t)prod | hell);  // chord | hell
+                            else {   // huge counts: the product goes straight to the global u64 cell
+                                atomicAdd(&pk[2 * CP + cell], hell);
+                                atomicAdd(&acc[SIMKA_ACC_CHORD * pc.nb_pairs + simka_pair_index(si, sj, N)], prod);
+                            }
                         }
                     }
-                }
-                if (cplx) {
-                    // updateDistanceComplex restricted to both-present pairs (ref: src/core/SimkaAlgorithm.hpp:437-446,477-481);
-                    // the one-sided terms are closed forms of S / totals / count histograms, added on the host.
-                    // KL: with p = ci/Ni, q = cj/Nj the reference's  p ln(2p/(p+q)) + q ln(2q/(p+q))  equals
-                    // p ln p + q ln q - (p+q) ln((p+q)/2): one logarithm per pair, the p ln p terms are per entry.
-                    const double2 px = epp[ix], py = epp[iy];
-                    const double h = px.x + py.x;
-                    double dd = simka_add_rn(px.y, py.y) - simka_mul_rn(h, simka_fast_ln(h * 0.5, lntab));      // (products rounded on their own, never fused into the subtraction: identical samples give 2 a - 2 a = 0 exactly)
-                    dd = dd < 0.0 ? 0.0 : dd;            // >= 0 mathematically (Jensen); rounding noise must not drive a sum of near-identical samples negative
-                    atomicAdd(&c64[1 * CP + cell], (ull)(long long)llrint(dd * SIMKA_KL_SCALE));
-                    const uint32_t jn = (rect ? T : 0u) + lj;
-                    atomicAdd(&c64[0 * CP + cell], simka_whit_term(ci, cj, tnu[li], tnu[jn], tn[li], tn[jn]));
-                }
-                // next pair of the span
-                y++;
-                if (rect ? (y == nB) : (y == nA)) {
-                    x++; y = rect ? 0u : x + 1u;
-                    if (rect ? (x == nA) : (y >= nA)) {   // group exhausted
-                        g++;
-                        while (g < cur.ngrp && gpref[g + 1] == gpref[g]) g++;   // groups without pairs for this tile pair
-                        if (g >= cur.ngrp) break;
-                        d = gdesc[g]; a0 = d >> 16; nA = d & 0xffffu; x = 0; y = rect ? 0u : 1u;
-                        if (rect) { const uint32_t dB = gdescB[g]; b0 = dB >> 16; nB = dB & 0xffffu; }
+                    if (cplx_) {
+                        // updateDistanceComplex restricted to both-present pairs (ref: src/core/SimkaAlgorithm.hpp:437-446,477-481);
+                        // the one-sided terms are closed forms of S / totals / count histograms, added on the host.
+                        // KL: with p = ci/Ni, q = cj/Nj the reference's  p ln(2p/(p+q)) + q ln(2q/(p+q))  equals
+                        // p ln p + q ln q - (p+q) ln((p+q)/2): one logarithm per pair, the p ln p terms are per entry.
+                        const double2 px = epp[ix], py = epp[iy];
+                        const double h = px.x + py.x;
+                        double dd = simka_add_rn(px.y, py.y) - simka_mul_rn(h, simka_fast_ln(h * 0.5, lntab));      // (products rounded on their own, never fused into the subtraction: identical samples give 2 a - 2 a = 0 exactly)
+                        dd = dd < 0.0 ? 0.0 : dd;            // >= 0 mathematically (Jensen); rounding noise must not drive a sum of near-identical samples negative
+                        atomicAdd(&c64[1 * CP + cell], (ull)(long long)llrint(dd * SIMKA_KL_SCALE));
+                        const uint32_t jn = (rect ? T : 0u) + lj;
+                        atomicAdd(&c64[0 * CP + cell], simka_whit_term(ci, cj, tnu[li], tnu[jn], tn[li], tn[jn]));
                     }
-                    ix = TILED ? (uint32_t)idxA[a0 + x] : a0 + x;
-                    ex = ent[ix];
+                    // next pair of the span
+                    y++;
+                    if (rect ? (y == nB) : (y == nA)) {
+                        x++; y = rect ? 0u : x + 1u;
+                        if (rect ? (x == nA) : (y >= nA)) {   // group exhausted
+                            g++;
+                            while (g < cur.ngrp && gpref[g + 1] == gpref[g]) g++;   // groups without pairs for this tile pair
+                            if (g >= cur.ngrp) break;
+                            d = gdesc[g]; a0 = d >> 16; nA = d & 0xffffu; x = 0; y = rect ? 0u : 1u;
+                            if (rect) { const uint32_t dB = gdescB[g]; b0 = dB >> 16; nB = dB & 0xffffu; }
+                        }
+                        ix = TILED ? (uint32_t)idxA[a0 + x] : a0 + x;
+                        ex = ent[ix];
+                    }
                 }
-            }
+            };
+            if (pc.simple && smallc && !cplx) pair_loop(std::true_type()); else pair_loop(std::false_type());
         }
     }
     PP(6)
