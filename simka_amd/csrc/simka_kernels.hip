@@ -1453,54 +1453,62 @@ k_pairs_tm(const SimkaSpan *spans, const ull *cursors, const ull *tm_ent, const 
             uint32_t ix = a0 + x;
             ull ex = ent[ix];
             PP(5)
-            for (; p < pend; p++) {
-                const uint32_t iy = rect ? b0 + y : a0 + y;
-                const ull ey = ent[iy];
-                uint32_t si = (uint32_t)(ex >> 32) & 0xffffu, sj = (uint32_t)(ey >> 32) & 0xffffu;
-                uint32_t ci = (uint32_t)ex, cj = (uint32_t)ey;
-                if (!rect && si > sj) { uint32_t t_ = si; si = sj; sj = t_; t_ = ci; ci = cj; cj = t_; }
-                const uint32_t li = si - baseI, lj = sj - baseJ;
-                const uint32_t cell = rect ? li * T + lj : li * T - ((li * (li + 1u)) >> 1) + (lj - li - 1u);
-                atomicAdd(&pk[0 * CP + cell], (ull)ci | ((ull)cj << 32));                       // S_ij | S_ji
-                atomicAdd(&pk[1 * CP + cell], 1ull | ((ull)(ci < cj ? ci : cj) << 32));         // a | bc
-                if (pc.simple) {
-                    if (smallc) {       // (uniform per span) counts below 2^15: the product is a 32-bit value below 2^30
-                        const uint32_t prod32 = ci * cj;
-                        atomicAdd(&pk[2 * CP + cell], (ull)prod32 | ((ull)pair_isqrt32(prod32) << 32));  // chord | hell
-                    } else {
-                        const ull prod = (ull)ci * (ull)cj;
-                        const ull hell = (ull)pair_isqrt(prod) << 32;
-                        if (chord_fast) atomicAdd(&pk[2 * CP + cell], (ull)(uint32_t)prod | hell);  // chord | hell
-                        else {   // huge counts: the product goes straight to the global u64 cell
-                            atomicAdd(&pk[2 * CP + cell], hell);
-                            atomicAdd(&acc[SIMKA_ACC_CHORD * pc.nb_pairs + simka_pair_index(si, sj, N)], prod);
+            // two instances of the pair loop (as in k_pairs, round 6): FAST = -simple-dist with every product of the span a 32-bit value, the two
+            // wave-uniform flags compile-time constants; the -complex-dist test stays a run-time one (a compile-time `cplx` reschedules the loop
+            // for the worse: round 5)
+            auto pair_loop = [&](auto fast_c) {
+                constexpr bool FAST = decltype(fast_c)::value;
+                const bool simple_ = FAST ? true : (pc.simple != 0u), smallc_ = FAST ? true : smallc;
+                for (; p < pend; p++) {
+                    const uint32_t iy = rect ? b0 + y : a0 + y;
+                    const ull ey = ent[iy];
+                    uint32_t si = (uint32_t)(ex >> 32) & 0xffffu, sj = (uint32_t)(ey >> 32) & 0xffffu;
+                    uint32_t ci = (uint32_t)ex, cj = (uint32_t)ey;
+                    if (!rect && si > sj) { uint32_t t_ = si; si = sj; sj = t_; t_ = ci; ci = cj; cj = t_; }
+                    const uint32_t li = si - baseI, lj = sj - baseJ;
+                    const uint32_t cell = rect ? li * T + lj : li * T - ((li * (li + 1u)) >> 1) + (lj - li - 1u);
+                    atomicAdd(&pk[0 * CP + cell], (ull)ci | ((ull)cj << 32));                       // S_ij | S_ji
+                    atomicAdd(&pk[1 * CP + cell], 1ull | ((ull)(ci < cj ? ci : cj) << 32));         // a | bc
+                    if (simple_) {
+                        if (smallc_) {       // (uniform per span) counts below 2^15: the product is a 32-bit value below 2^30
+                            const uint32_t prod32 = ci * cj;
+                            atomicAdd(&pk[2 * CP + cell], (ull)prod32 | ((ull)pair_isqrt32(prod32) << 32));  // chord | hell
+                        } else {
+                            const ull prod = (ull)ci * (ull)cj;
+                            const ull hell = (ull)pair_isqrt(prod) << 32;
+                            if (chord_fast) atomicAdd(&pk[2 * CP + cell], (ull)(uint32_t)prod | hell);  // chord | hell
+                            else {   // huge counts: the product goes straight to the global u64 cell
+                                atomicAdd(&pk[2 * CP + cell], hell);
+                                atomicAdd(&acc[SIMKA_ACC_CHORD * pc.nb_pairs + simka_pair_index(si, sj, N)], prod);
+                            }
                         }
                     }
-                }
-                if (cplx) {
-                    // same arithmetic as k_pairs (ref: src/core/SimkaAlgorithm.hpp:437-446,477-481)
-                    const double2 px = epp[ix], py = epp[iy];
-                    const double h = px.x + py.x;
-                    double dd = simka_add_rn(px.y, py.y) - simka_mul_rn(h, simka_fast_ln(h * 0.5, lntab));      // (products rounded on their own, never fused into the subtraction: identical samples give 2 a - 2 a = 0 exactly)
-                    dd = dd < 0.0 ? 0.0 : dd;
-                    atomicAdd(&c64[1 * CP + cell], (ull)(long long)llrint(dd * SIMKA_KL_SCALE));
-                    const uint32_t jn = (rect ? T : 0u) + lj;
-                    atomicAdd(&c64[0 * CP + cell], simka_whit_term(ci, cj, tnu[li], tnu[jn], tn[li], tn[jn]));
-                }
-                y++;
-                if (rect ? (y == nB) : (y == nA)) {
-                    x++; y = rect ? 0u : x + 1u;
-                    if (rect ? (x == nA) : (y >= nA)) {   // group exhausted
-                        g++;
-                        while (g < cur.ng && gpref[g + 1] == gpref[g]) g++;
-                        if (g >= cur.ng) break;
-                        d = gdesc[g]; a0 = d >> 16; nA = d & 0xffffu; x = 0; y = rect ? 0u : 1u;
-                        if (rect) { const uint32_t dB = gdescB[g]; b0 = dB >> 16; nB = dB & 0xffffu; }
+                    if (cplx) {
+                        // same arithmetic as k_pairs (ref: src/core/SimkaAlgorithm.hpp:437-446,477-481)
+                        const double2 px = epp[ix], py = epp[iy];
+                        const double h = px.x + py.x;
+                        double dd = simka_add_rn(px.y, py.y) - simka_mul_rn(h, simka_fast_ln(h * 0.5, lntab));      // (products rounded on their own, never fused into the subtraction: identical samples give 2 a - 2 a = 0 exactly)
+                        dd = dd < 0.0 ? 0.0 : dd;
+                        atomicAdd(&c64[1 * CP + cell], (ull)(long long)llrint(dd * SIMKA_KL_SCALE));
+                        const uint32_t jn = (rect ? T : 0u) + lj;
+                        atomicAdd(&c64[0 * CP + cell], simka_whit_term(ci, cj, tnu[li], tnu[jn], tn[li], tn[jn]));
                     }
-                    ix = a0 + x;
-                    ex = ent[ix];
+                    y++;
+                    if (rect ? (y == nB) : (y == nA)) {
+                        x++; y = rect ? 0u : x + 1u;
+                        if (rect ? (x == nA) : (y >= nA)) {   // group exhausted
+                            g++;
+                            while (g < cur.ng && gpref[g + 1] == gpref[g]) g++;
+                            if (g >= cur.ng) break;
+                            d = gdesc[g]; a0 = d >> 16; nA = d & 0xffffu; x = 0; y = rect ? 0u : 1u;
+                            if (rect) { const uint32_t dB = gdescB[g]; b0 = dB >> 16; nB = dB & 0xffffu; }
+                        }
+                        ix = a0 + x;
+                        ex = ent[ix];
+                    }
                 }
-            }
+            };
+            if (pc.simple && smallc) pair_loop(std::true_type()); else pair_loop(std::false_type());
         }
     }
 #undef KTM_FETCH
