@@ -20,6 +20,9 @@
 #include <type_traits>
 #include "simka_device.h"
 #include "simka_kernels.h"
+#ifndef KG_PIVOTS
+#define KG_PIVOTS 1              // k_group: coarse pivots of the sample prefix table in registers (round 6)
+#endif
 
 typedef unsigned long long ull;
 
@@ -345,6 +348,16 @@ k_group(SimkaMergeIn in, const ull *seg_abs, const uint16_t *rows, uint32_t np,
             __syncthreads();
             }
             const uint32_t ns = N - s0 < (uint32_t)GB ? N - s0 : (uint32_t)GB;
+#if KG_PIVOTS
+            // (round 6) up to 128 samples in the tile: the prefixes of samples 16, 32, .. 112 in registers -- a record's group of 16 samples is a
+            // count of seven independent compares, the search over the prefix table in LDS four dependent reads instead of seven
+            uint32_t pv[7];
+            const bool piv = ns <= 128u;
+            if (piv) {
+#pragma unroll
+                for (int q = 0; q < 7; q++) pv[q] = (uint32_t)(q + 1) * 16u < ns ? spre[(q + 1) * 16] : 0xffffffffu;
+            }
+#endif
             for (uint32_t i0 = tid; i0 < tot; i0 += GB * K3_UNROLL) {
                 ull kk[K3_UNROLL], vv[K3_UNROLL];
 #pragma unroll
@@ -353,6 +366,14 @@ k_group(SimkaMergeIn in, const ull *seg_abs, const uint16_t *rows, uint32_t np,
                     kk[u] = SIMKA_EMPTY_KEY; vv[u] = 0;
                     if (i < tot) {
                         uint32_t lo = 0, hi = ns;          // largest x with spre[x] <= i
+#if KG_PIVOTS
+                        if (piv) {
+                            uint32_t grp = 0;
+#pragma unroll
+                            for (int q = 0; q < 7; q++) grp += pv[q] <= i ? 1u : 0u;
+                            lo = grp * 16u; hi = lo + 16u < ns ? lo + 16u : ns;
+                        }
+#endif
                         while (hi - lo > 1u) { const uint32_t mid = (lo + hi) >> 1; if (spre[mid] <= i) lo = mid; else hi = mid; }
                         const ull at = sbeg[lo] + (i - spre[lo]);
                         kk[u] = in.solid_keys[at]; vv[u] = ((ull)(s0 + lo) << 32) | (ull)in.solid_counts[at];
