@@ -630,19 +630,26 @@ def main():
         try:
             sf = next((f for f in (os.path.join(ROOT, "profiles", "r%02d_%s_sq_counters.json" % (rd, args.workload)) for rd in (6, 5)) if os.path.exists(f)), "")
             if world == 1 and not args.reads and not args.samples and not args.kmer_size and sf:
-                sq = json.load(open(sf))["kernels"].get(dom.split("<")[0])
-                if sq and sq["launches"]:
-                    kocc_per_launch = K_occ / max(dom_launches / max(args.steps, 1), 1)
+                sqk = json.load(open(sf))["kernels"]
+
+                def issue_of(kname, launches_per_step):
+                    sq = sqk.get(kname.split("<")[0])
+                    if not sq or not sq["launches"] or not launches_per_step:
+                        return None
+                    kocc_per_launch = K_occ / launches_per_step
                     per_launch = lambda key: sq[key] / sq["launches"]
-                    issue = {"valu_busy": sq["valu_busy"], "active": sq["active"], "wait": sq["wait"], "issue_stall": sq["issue_stall"], "lds_busy": sq["lds_busy"],
-                             # lane-instructions per k-mer occurrence (wave instructions x 64 lanes / k-mer occurrences of a launch)
-                             "inst_per_kmer": {c: per_launch("wave_inst_" + c) * 64.0 / kocc_per_launch for c in ("valu", "salu", "lds", "vmem")},
-                             # cycles of a wave's lifetime per instruction it executes (waits included), and the part of them in which the wave had an
-                             # instruction in flight: at waves_per_simd resident waves a SIMD issues once per active_cycles_per_inst / waves cycles
-                             "wave_cycles_per_inst": sq["cycles_per_inst"], "active_cycles_per_inst": sq["cycles_per_inst"] * sq["active"] if sq["cycles_per_inst"] else None,
-                             "waves_per_simd": WAVES_PER_SIMD.get(dom.split("<")[0]),
-                             "source": os.path.relpath(sf, ROOT)}
-                    issue["inst_per_kmer"]["all"] = sum(issue["inst_per_kmer"].values())
+                    out_ = {"valu_busy": sq["valu_busy"], "active": sq["active"], "wait": sq["wait"], "issue_stall": sq["issue_stall"], "lds_busy": sq["lds_busy"],
+                            # lane-instructions per k-mer occurrence of the step's share of a launch (wave instructions x 64 lanes / k-mer occurrences)
+                            "inst_per_kmer": {c: per_launch("wave_inst_" + c) * 64.0 / kocc_per_launch for c in ("valu", "salu", "lds", "vmem")},
+                            # cycles of a wave's lifetime per instruction it executes (waits included), and the part of them in which the wave had an
+                            # instruction in flight: at waves_per_simd resident waves a SIMD issues once per active_cycles_per_inst / waves cycles
+                            "wave_cycles_per_inst": sq["cycles_per_inst"], "active_cycles_per_inst": sq["cycles_per_inst"] * sq["active"] if sq["cycles_per_inst"] else None,
+                            "waves_per_simd": WAVES_PER_SIMD.get(kname.split("<")[0]), "source": os.path.relpath(sf, ROOT)}
+                    out_["inst_per_kmer"]["all"] = sum(out_["inst_per_kmer"].values())
+                    return out_
+                issue = issue_of(dom, max(dom_launches / max(args.steps, 1), 1))
+                for kname, pk_ in per_kernel.items():      # the same reading for every kernel of the step (what bounds each: VALU busy next to its HBM fraction)
+                    pk_["issue"] = issue_of(kname, pk_["launches_per_step"])
         except Exception:
             issue = None
         roofline = {"bound": "hbm", "kernel": dom, "achieved": achieved, "issue": issue, "peak": HBM_PEAK_GBS, "unit": "GB/s",
